@@ -1,0 +1,146 @@
+"""Pins the CPU oracle (oracle/soundml_oracle.py) against every golden vector the
+reference's own tests hold for the hot path, at the reference's own tolerances
+(soundml/test/stft/stft_goldens.ml, soundml/test/mel/mel_goldens.ml,
+soundml/test/window/test_window.ml)."""
+import numpy as np
+import pytest
+
+from conftest import (F32_ATOL, F32_RTOL, F64_ATOL, F64_RTOL, check_close,
+                      golden_cases, load_golden)
+from oracle import soundml_oracle as O
+
+STFT_FILES = ["fft16_hop4", "fft32_hop7", "fft64_hop16", "fft32_hop8_win20"]
+
+
+def _stft_config(p):
+    return O.stft_config(p["fft_size"], win_length=p["win_length"], hop=p["hop"],
+                         alignment=p["alignment"])
+
+
+@pytest.mark.parametrize("fname", STFT_FILES)
+def test_stft_spectra(fname):
+    for case in load_golden("stft", fname)["cases"]:
+        p = case["params"]
+        c = _stft_config(p)
+        sig = O.lcg_signal(p["length"])
+        power = {"magnitude": 1.0, "power": 2.0}[p["kind"]]
+        if p["dtype"] == "float64":
+            got = O.power_spectrum(c, sig, power)
+            check_close(got, case["values"], case["shape"], F64_RTOL, F64_ATOL, case["name"])
+        else:
+            x = sig.astype(np.float32)
+            got = O.power_spectrum(c, x, power)
+            assert got.dtype == np.float32
+            check_close(got, case["values"], case["shape"], F32_RTOL, F32_ATOL, case["name"])
+            if power == 1.0:   # the complex64-witness leg of stft_goldens.ml:88-95
+                z = O.transform(c, x, np.complex64)
+                check_close(np.abs(z).astype(np.float32), case["values"], case["shape"],
+                            F32_RTOL, F32_ATOL, case["name"] + "/complex64-witness")
+
+
+def test_stft_sign_convention():
+    for case in load_golden("stft", "complex_fft16_hop4")["cases"]:
+        p = case["params"]
+        z = O.transform(_stft_config(p), O.lcg_signal(p["length"]), np.complex128)
+        part = z.real if p["kind"] == "real" else z.imag
+        check_close(part, case["values"], case["shape"], F64_RTOL, F64_ATOL, case["name"])
+
+
+def test_coordinates():
+    for case in load_golden("stft", "coordinates")["cases"]:
+        p = case["params"]
+        if p["kind"] == "frequencies":
+            c = O.stft_config(p["fft_size"], hop=p["hop"])
+            got = O.frequencies(c, p["sample_rate"])
+        else:
+            c = O.stft_config(p["fft_size"], hop=p["hop"], alignment=p["alignment"])
+            got = O.times(c, p["sample_rate"], p["length"])
+            assert got.shape[0] == O.frames(c, p["length"])
+        check_close(got, case["values"], case["shape"], msg=case["name"])
+        check_close(got.astype(np.float32), case["values"], case["shape"], F32_RTOL, F32_ATOL,
+                    case["name"] + "/float32")
+
+
+@pytest.mark.parametrize("family", ["hann", "hamming", "blackman", "rectangular"])
+def test_windows(family):
+    for case in load_golden("window", family)["cases"]:
+        p = case["params"]
+        got = O.window(p["window"], p["n"], periodic=p["periodic"])
+        check_close(got, case["values"], case["shape"], msg=case["name"])
+
+
+def _mel_config(p):
+    return O.mel_config(p["n_mels"], p["sample_rate"], p["fft_size"], f_min=p["f_min"],
+                        f_max=p["f_max"], scale=p["scale"], norm=p["norm"])
+
+
+def test_mel_filterbank():
+    for case in load_golden("mel", "filterbank")["cases"]:
+        w = _mel_config(case["params"]).weights
+        check_close(w, case["values"], case["shape"], F64_RTOL, F64_ATOL, case["name"])
+        check_close(w.astype(np.float32), case["values"], case["shape"], F32_RTOL, F32_ATOL,
+                    case["name"] + "/float32")
+
+
+def test_mel_spectrogram():
+    for case in load_golden("mel", "mel_spectrogram")["cases"]:
+        p = case["params"]
+        sc = O.stft_config(p["fft_size"], hop=p["hop"], alignment=p["alignment"])
+        mc = _mel_config(p)
+        sig = O.lcg_signal(p["length"], seed=20260803, envelope=p["envelope"])
+        if p["dtype"] == "float64":
+            got = O.mel_spectrogram(sc, mc, sig, p["power"])
+            check_close(got, case["values"], case["shape"], F64_RTOL, F64_ATOL, case["name"])
+        else:
+            got = O.mel_spectrogram(sc, mc, sig.astype(np.float32), p["power"])
+            assert got.dtype == np.float32
+            check_close(got, case["values"], case["shape"], F32_RTOL, F32_ATOL, case["name"])
+
+
+# --- structural laws of the reference restated on the oracle -------------------------------
+
+@pytest.mark.parametrize("alignment", ["centered", "left", "right"])
+@pytest.mark.parametrize("pad", ["reflect", "edge", "constant"])
+@pytest.mark.parametrize("fft,hop", [(16, 4), (32, 7), (16, 20)])
+def test_partition_law(alignment, pad, fft, hop):
+    """stft_law.ml:79-164: every chunking of the stream == the offline transform, exactly."""
+    rng = np.random.default_rng(fft * 131 + hop)
+    c = O.stft_config(fft, hop=hop, alignment=alignment, pad=pad, pad_value=0.25)
+    for n in (1, 5, fft // 2, fft // 2 + 1, fft, 97, 200):
+        x = rng.standard_normal((2, n))
+        want = O.transform(c, x, np.complex128)
+        for trial in range(3):
+            k = O.StreamKernel(c, np.complex128)
+            parts, pos = [], 0
+            while pos < n:
+                m = int(rng.integers(0, 9)) if trial else 1
+                m = min(m, n - pos)
+                out = k.step(x[:, pos:pos + m])
+                pos += m
+                if out is not None:
+                    parts.append(out)
+            out = k.flush()
+            if out is not None:
+                parts.append(out)
+            got = np.concatenate(parts, axis=-1) if parts else np.zeros((2, c.bins, 0), complex)
+            assert got.shape == want.shape, (n, got.shape, want.shape)
+            assert np.array_equal(got, want)
+
+
+def test_transform_range_tiles():
+    """stft_grid.ml:32-73: adjacent frame ranges reassemble the full transform exactly."""
+    c = O.stft_config(64, hop=16)
+    x = O.lcg_signal(2000)
+    full = O.transform(c, x)
+    total = O.frames(c, 2000)
+    cuts = [0, 1, 7, 8, 60, total]
+    parts = [O.transform_range(c, x, a, b) for a, b in zip(cuts[:-1], cuts[1:])]
+    assert np.array_equal(np.concatenate(parts, axis=-1), full)
+
+
+def test_fir_fft_form_matches_direct():
+    rng = np.random.default_rng(7)
+    h = O.design_lowpass(63, 0.25, O.kaiser_beta(80.0))
+    assert abs(h.sum() - 1.0) < 1e-12 and np.allclose(h, h[::-1], rtol=0, atol=1e-18)
+    x = rng.standard_normal((3, 500))
+    np.testing.assert_allclose(O.fir_filter(h, x), O.fir_filter_direct(h, x), rtol=0, atol=1e-12)
