@@ -1,0 +1,208 @@
+/*
+ * soundml_amd.h -- C ABI of the MI355X-native spectral path for SoundML.
+ *
+ * This is the drop-in boundary: plain C, raw pointers + int64 extents, an int
+ * status and a thread-local error string.  Each entry point names the reference
+ * interface it replaces (paths relative to /root/reference/soundml/lib).  The
+ * OCaml side binds these with `external` + CAMLprim stubs exactly like the
+ * reference binds resample_stubs.c (resample.ml:1162-1196); see INTEGRATION.md
+ * and ocaml/soundml_amd_stubs.c.
+ *
+ * Conventions (reference: soundml.mli:3-24, stft.mli:211-250)
+ *   - time axis last; audio is [lead; n], spectra are [lead; bins; frames]
+ *     (frames fastest); `lead` is the product of all leading axes;
+ *   - inputs are borrowed for the call, outputs are caller-allocated and fully
+ *     overwritten, nothing is retained (stft.mli:454-458);
+ *   - complex outputs are interleaved (re, im) pairs of the component type;
+ *   - user-facing precondition failures return SMX_INVALID_ARGUMENT with the
+ *     reference's own message (OCaml: raise Invalid_argument); geometry /
+ *     runtime (HIP) failures return SMX_FAILURE (OCaml: Failure);
+ *   - `*_dev` entry points take DEVICE pointers on the current HIP device and a
+ *     hipStream_t (as void*); they enqueue work and return without
+ *     synchronising.  The host-pointer entry points upload, run and download
+ *     (this is what an nx-tensor caller uses).
+ *   - every extent is validated before any pointer is formed or any device
+ *     work is enqueued (discipline of resample_stubs.c:228-276).
+ *   - the library never falls back to a CPU implementation: without a HIP
+ *     device every compute entry point returns SMX_FAILURE.
+ */
+#ifndef SOUNDML_AMD_H
+#define SOUNDML_AMD_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SMX_OK 0
+#define SMX_INVALID_ARGUMENT 1
+#define SMX_FAILURE 2
+
+/* "argument not given" for optional integer arguments (OCaml ?win_length / ?hop) */
+#define SMX_DEFAULT INT64_MIN
+
+/* Stft.Config.alignment (stft.ml:53) */
+#define SMX_ALIGN_CENTERED 0
+#define SMX_ALIGN_LEFT 1
+#define SMX_ALIGN_RIGHT 2
+/* Stft.Config.pad (stft.ml:54) */
+#define SMX_PAD_REFLECT 0
+#define SMX_PAD_CONSTANT 1
+#define SMX_PAD_EDGE 2
+/* Stft.Config.scale (stft.ml:55) */
+#define SMX_SCALE_NONE 0
+#define SMX_SCALE_MAGNITUDE 1
+#define SMX_SCALE_PSD 2
+/* Window.t families built by the library (window.ml:362-375); any other family
+ * is built by the host in float64 and passed as a table (SMX_WINDOW_CUSTOM). */
+#define SMX_WINDOW_HANN 0
+#define SMX_WINDOW_RECTANGULAR 1
+#define SMX_WINDOW_HAMMING 2
+#define SMX_WINDOW_BLACKMAN 3
+#define SMX_WINDOW_BLACKMAN_HARRIS 4
+#define SMX_WINDOW_NUTTALL 5
+#define SMX_WINDOW_FLAT_TOP 6
+#define SMX_WINDOW_CUSTOM 100
+/* Mel.Config.scale / norm (mel.ml:26-27) */
+#define SMX_MEL_SLANEY 0
+#define SMX_MEL_HTK 1
+#define SMX_NORM_SLANEY 0
+#define SMX_NORM_NONE 1
+/* Interior arithmetic for float32 audio.  The reference computes in float64
+ * whatever the I/O dtype (stft.ml:28-35); SMX_INTERIOR_F32 is the documented
+ * fast deviation (north_star: 1e-5 relative), SMX_INTERIOR_F64 reproduces the
+ * reference's interior (widen, f64 window multiply, f64 FFT, one rounding).
+ * float64 audio always uses the float64 interior. */
+#define SMX_INTERIOR_F32 0
+#define SMX_INTERIOR_F64 1
+
+typedef struct smx_stft_config smx_stft_config;
+typedef struct smx_mel_config smx_mel_config;
+typedef struct smx_stft_kernel smx_stft_kernel;
+typedef struct smx_fir_plan smx_fir_plan;
+
+/* ---- library ------------------------------------------------------------ */
+const char *smx_last_error(void);      /* message of the last failing call on this thread */
+int smx_version(void);
+int smx_device_count(int *count);
+int smx_set_device(int device);        /* device used by this thread's subsequent calls */
+int smx_set_interior(int interior);    /* SMX_INTERIOR_*, process-wide default for f32 audio */
+int smx_get_interior(void);
+int smx_synchronize(void *stream);
+
+/* ---- Window.make (window.ml:374-405), float64, Hann & friends ------------ */
+int smx_window_make(int kind, int periodic, int64_t n, double *out);
+
+/* ---- Stft.Config (stft.ml:48-129) --------------------------------------- */
+int smx_stft_config_create(int64_t fft_size, int64_t win_length /* SMX_DEFAULT = fft_size */,
+                           int64_t hop /* SMX_DEFAULT = max 1 (fft_size/4) */, int alignment,
+                           int pad, double pad_value, int scale, int window_kind,
+                           const double *custom_window /* win_length doubles iff SMX_WINDOW_CUSTOM */,
+                           smx_stft_config **out);
+void smx_stft_config_destroy(smx_stft_config *c);
+int64_t smx_stft_config_fft_size(const smx_stft_config *c);
+int64_t smx_stft_config_hop(const smx_stft_config *c);
+int64_t smx_stft_config_win_length(const smx_stft_config *c);
+int64_t smx_stft_config_bins(const smx_stft_config *c);          /* stft.ml:127 */
+int64_t smx_stft_config_left_width(const smx_stft_config *c);    /* stft.ml:132-140 */
+int64_t smx_stft_config_right_width(const smx_stft_config *c);   /* stft.ml:141-142 */
+int64_t smx_stft_config_latency(const smx_stft_config *c);       /* stft.ml:144-145 */
+int smx_stft_config_analysis_window(const smx_stft_config *c, double *out /* fft_size */);
+
+/* ---- frame grid (stft.ml:217-261) ---------------------------------------- */
+int smx_stft_frames(const smx_stft_config *c, int64_t n, int64_t *out);
+int smx_stft_first_complete(const smx_stft_config *c, int64_t *out);
+int smx_stft_last_complete(const smx_stft_config *c, int64_t n, int64_t *out);
+int smx_stft_times(const smx_stft_config *c, int64_t sample_rate, int64_t n, double *out /* frames */);
+int smx_stft_frequencies(const smx_stft_config *c, int64_t sample_rate, double *out /* bins */);
+
+/* ---- Stft.transform / transform_range / power_spectrum (stft.ml:632-691) ---
+ * x: [lead; n] contiguous (x_stride = elements between consecutive signals, >= n).
+ * out: transform -> complex [lead; bins; frames]; range -> [lead; bins; p1-p0];
+ *      power_spectrum -> real [lead; bins; frames].                           */
+int smx_stft_transform_f32(const smx_stft_config *c, const float *x, int64_t lead, int64_t n,
+                           float *out_c64);
+int smx_stft_transform_f64(const smx_stft_config *c, const double *x, int64_t lead, int64_t n,
+                           double *out_c128);
+int smx_stft_transform_range_f32(const smx_stft_config *c, const float *x, int64_t lead, int64_t n,
+                                 int64_t p0, int64_t p1, float *out_c64);
+int smx_stft_transform_range_f64(const smx_stft_config *c, const double *x, int64_t lead, int64_t n,
+                                 int64_t p0, int64_t p1, double *out_c128);
+int smx_stft_power_spectrum_f32(const smx_stft_config *c, const float *x, int64_t lead, int64_t n,
+                                double power, float *out);
+int smx_stft_power_spectrum_f64(const smx_stft_config *c, const double *x, int64_t lead, int64_t n,
+                                double power, double *out);
+/* device-resident forms (the batch API the benchmark and the sharded driver use) */
+int smx_stft_transform_range_f32_dev(const smx_stft_config *c, const float *d_x, int64_t lead,
+                                     int64_t n, int64_t x_stride, int64_t p0, int64_t p1,
+                                     float *d_out_c64, void *stream);
+int smx_stft_transform_range_f64_dev(const smx_stft_config *c, const double *d_x, int64_t lead,
+                                     int64_t n, int64_t x_stride, int64_t p0, int64_t p1,
+                                     double *d_out_c128, void *stream);
+int smx_stft_power_range_f32_dev(const smx_stft_config *c, const float *d_x, int64_t lead,
+                                 int64_t n, int64_t x_stride, int64_t p0, int64_t p1, double power,
+                                 float *d_out, void *stream);
+int smx_stft_power_range_f64_dev(const smx_stft_config *c, const double *d_x, int64_t lead,
+                                 int64_t n, int64_t x_stride, int64_t p0, int64_t p1, double power,
+                                 double *d_out, void *stream);
+
+/* ---- Stft.Kernel (stft.ml:597-622): streaming analysis, device-resident carry
+ * dtype_bytes: 4 (float32 audio, complex64 spectra) or 8.
+ * step/flush write at most `capacity` frames into out [channels; bins; capacity]
+ * laid out with `capacity` as the frame stride, and report how many they emitted
+ * (0 = the reference's None).  frame_bound = stft.ml:1316-1317.               */
+int smx_stft_kernel_prepare(const smx_stft_config *c, int dtype_bytes, int64_t channels,
+                            int64_t max_block, smx_stft_kernel **out);
+void smx_stft_kernel_destroy(smx_stft_kernel *k);
+int smx_stft_kernel_frame_bound(const smx_stft_kernel *k, int64_t *out);
+int smx_stft_kernel_step(smx_stft_kernel *k, const void *chunk /* host [channels; m] */, int64_t m,
+                         void *out_complex, int64_t capacity, int64_t *emitted);
+int smx_stft_kernel_flush(smx_stft_kernel *k, void *out_complex, int64_t capacity, int64_t *emitted);
+int smx_stft_kernel_reset(smx_stft_kernel *k);
+
+/* ---- Mel.Config / Mel.apply (mel.ml:22-233) ------------------------------- */
+int smx_mel_config_create(int64_t n_mels, int64_t sample_rate, int64_t fft_size, double f_min,
+                          int has_f_max, double f_max, int scale, int norm, smx_mel_config **out);
+void smx_mel_config_destroy(smx_mel_config *c);
+int64_t smx_mel_config_n_mels(const smx_mel_config *c);
+int64_t smx_mel_config_bins(const smx_mel_config *c);
+int64_t smx_mel_config_fft_size(const smx_mel_config *c);
+double smx_mel_config_f_max(const smx_mel_config *c);
+int smx_mel_filterbank(const smx_mel_config *c, double *out /* [n_mels; bins] */); /* mel.ml:200 */
+/* s: [lead; bins; frames] -> out [lead; n_mels; frames]; `bins` is the caller's
+ * declared axis size and is checked against the config (mel.ml:210-218).     */
+int smx_mel_apply_f32(const smx_mel_config *c, const float *s, int64_t lead, int64_t bins,
+                      int64_t frames, float *out);
+int smx_mel_apply_f64(const smx_mel_config *c, const double *s, int64_t lead, int64_t bins,
+                      int64_t frames, double *out);
+int smx_mel_apply_f32_dev(const smx_mel_config *c, const float *d_s, int64_t lead, int64_t bins,
+                          int64_t frames, float *d_out, void *stream);
+int smx_mel_apply_f64_dev(const smx_mel_config *c, const double *d_s, int64_t lead, int64_t bins,
+                          int64_t frames, double *d_out, void *stream);
+
+/* ---- Soundml.mel_spectrogram (soundml.ml:12-24): fused audio -> mel -------- */
+int smx_mel_spectrogram_f32(const smx_stft_config *sc, const smx_mel_config *mc, const float *x,
+                            int64_t lead, int64_t n, double power, float *out);
+int smx_mel_spectrogram_f64(const smx_stft_config *sc, const smx_mel_config *mc, const double *x,
+                            int64_t lead, int64_t n, double power, double *out);
+int smx_mel_spectrogram_f32_dev(const smx_stft_config *sc, const smx_mel_config *mc,
+                                const float *d_x, int64_t lead, int64_t n, int64_t x_stride,
+                                double power, float *d_out, void *stream);
+
+/* ---- FIR block convolution (BASELINE config 4; model resample.ml:383-415) --
+ * y[c][i] = sum_k h[k] x[c][i-k], zeros before the stream start, i in [0, n).
+ * Overlap-save on the library's own FFT core, spectrum of h precomputed.     */
+int smx_fir_kaiser_beta(double attenuation_db, double *out);            /* resample.ml:105-109 */
+int smx_fir_design_lowpass(int64_t taps, double cutoff, double beta, double *h); /* :145-163 */
+int smx_fir_plan_create(const double *h, int64_t taps, smx_fir_plan **out);
+void smx_fir_plan_destroy(smx_fir_plan *p);
+int64_t smx_fir_plan_block(const smx_fir_plan *p);                      /* FFT length N */
+int smx_fir_apply_f32(const smx_fir_plan *p, const float *x, int64_t channels, int64_t n, float *y);
+int smx_fir_apply_f32_dev(const smx_fir_plan *p, const float *d_x, int64_t channels, int64_t n,
+                          int64_t x_stride, float *d_y, int64_t y_stride, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SOUNDML_AMD_H */

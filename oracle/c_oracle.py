@@ -1,0 +1,67 @@
+"""ctypes access to the C restatement of the oracle (oracle/oracle_stft.c).
+Test infrastructure only: used by tests/ and by bench.py's cpu_baseline leg."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+from . import soundml_oracle as O
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_SO = os.path.join(_HERE, "_build", "liboracle.so")
+_PAD = {"reflect": 0, "constant": 1, "edge": 2}
+
+
+def build() -> str:
+    subprocess.check_call(["make", "-s", "-C", _HERE])
+    return _SO
+
+
+def load():
+    if not os.path.exists(_SO):
+        build()
+    lib = C.CDLL(_SO)
+    i64, vp, ci, d = C.c_int64, C.c_void_p, C.c_int, C.c_double
+    for name in ("oracle_stft_f32", "oracle_stft_f64"):
+        fn = getattr(lib, name)
+        fn.restype = ci
+        fn.argtypes = [vp, i64, i64, ci, ci, vp, i64, ci, d, i64, ci, d, vp, ci]
+    lib.oracle_mel_apply_f32.restype = ci
+    lib.oracle_mel_apply_f32.argtypes = [vp, ci, ci, vp, i64, i64, vp]
+    return lib
+
+
+def stft(c: O.StftConfig, x: np.ndarray, power=2.0, complex_out=False, threads=1) -> np.ndarray:
+    """power_spectrum / transform of the C oracle for power-of-two fft sizes."""
+    lib = load()
+    x = np.ascontiguousarray(x)
+    assert x.dtype in (np.float32, np.float64)
+    lead_shape, n = x.shape[:-1], x.shape[-1]
+    lead = int(np.prod(lead_shape)) if lead_shape else 1
+    count = O.frames(c, n)
+    f32 = x.dtype == np.float32
+    if complex_out:
+        out = np.zeros(lead_shape + (c.bins, count), dtype=np.complex64 if f32 else np.complex128)
+    else:
+        out = np.zeros(lead_shape + (c.bins, count), dtype=x.dtype)
+    w = np.ascontiguousarray(c.analysis_window, dtype=np.float64)
+    fn = lib.oracle_stft_f32 if f32 else lib.oracle_stft_f64
+    rc = fn(x.ctypes.data, lead, n, c.fft_size, c.hop, w.ctypes.data, O.left_width(c), _PAD[c.pad],
+            float(c.pad_value), count, 1 if complex_out else 0, float(power), out.ctypes.data, int(threads))
+    if rc != 0:
+        raise ValueError("C oracle: unsupported fft size %d" % c.fft_size)
+    return out
+
+
+def mel_apply(mc: O.MelConfig, s: np.ndarray) -> np.ndarray:
+    lib = load()
+    s = np.ascontiguousarray(s, dtype=np.float32)
+    lead_shape, frames = s.shape[:-2], s.shape[-1]
+    lead = int(np.prod(lead_shape)) if lead_shape else 1
+    out = np.zeros(lead_shape + (mc.n_mels, frames), dtype=np.float32)
+    w = np.ascontiguousarray(mc.weights, dtype=np.float64)
+    lib.oracle_mel_apply_f32(w.ctypes.data, mc.n_mels, mc.bins, s.ctypes.data, lead, frames, out.ctypes.data)
+    return out

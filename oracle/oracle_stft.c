@@ -1,0 +1,214 @@
+/* CPU oracle, C restatement -- TEST INFRASTRUCTURE ONLY (see oracle/soundml_oracle.py).
+ *
+ * Restates the reference's STFT power path in plain C with the reference's
+ * float64 interior so it can be timed on all host cores as the `cpu_baseline`
+ * of bench.py (kind "port") and used as a second checker:
+ *
+ *   to_double samples                      stft.ml:345-346
+ *   frame p = padded[p*hop, p*hop + fft)   stft.ml:356-364 (Nx.stft, third-party:
+ *   x float64 window -> float64 rfft         pinned nx fork, dune-project:22-26; restated
+ *   -> one rounding to the storage dtype     by its published semantics)
+ *   boundary extension reflect/edge/const  stft.ml:300-338
+ *   |z| (storage dtype) then ^power        stft.ml:670-674
+ *   mel: W_f64 x S_f64, one rounding        mel.ml:231
+ *
+ * Pinned against the reference's golden vectors in tests/test_oracle_goldens.py
+ * (through ctypes).  Only tests/, __graft_entry__.smoke() and bench.py's
+ * cpu_baseline leg may load this library.
+ *
+ * Build: make -C oracle   (gcc -O3 -pthread, no external libraries).
+ */
+#include <math.h>
+#include <pthread.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+#ifndef M_PI
+#define M_PI 3.14159265358979323846
+#endif
+
+typedef struct {
+  int n;            /* real FFT length (power of two, >= 2) */
+  int m;            /* n / 2 */
+  int logm;
+  double *tw_re, *tw_im;     /* exp(-2 pi i j / m), j < m/2 */
+  double *pw_re, *pw_im;     /* exp(-2 pi i k / n), k <= m  */
+  int *rev;                  /* bit reversal of m points */
+} rfft_plan;
+
+static rfft_plan *plan_create(int n) {
+  rfft_plan *p = (rfft_plan *)calloc(1, sizeof(rfft_plan));
+  p->n = n;
+  p->m = n / 2;
+  p->logm = 0;
+  while ((1 << p->logm) < p->m) p->logm++;
+  int half = p->m / 2 > 0 ? p->m / 2 : 1;
+  p->tw_re = (double *)malloc(sizeof(double) * half);
+  p->tw_im = (double *)malloc(sizeof(double) * half);
+  for (int j = 0; j < half; ++j) {
+    double a = -2.0 * M_PI * (double)j / (double)p->m;
+    p->tw_re[j] = cos(a);
+    p->tw_im[j] = sin(a);
+  }
+  p->pw_re = (double *)malloc(sizeof(double) * (p->m + 1));
+  p->pw_im = (double *)malloc(sizeof(double) * (p->m + 1));
+  for (int k = 0; k <= p->m; ++k) {
+    double a = -2.0 * M_PI * (double)k / (double)n;
+    p->pw_re[k] = cos(a);
+    p->pw_im[k] = sin(a);
+  }
+  p->rev = (int *)malloc(sizeof(int) * p->m);
+  for (int i = 0; i < p->m; ++i) {
+    int r = 0;
+    for (int b = 0; b < p->logm; ++b) r |= ((i >> b) & 1) << (p->logm - 1 - b);
+    p->rev[i] = r;
+  }
+  return p;
+}
+
+static void plan_destroy(rfft_plan *p) {
+  if (!p) return;
+  free(p->tw_re); free(p->tw_im); free(p->pw_re); free(p->pw_im); free(p->rev); free(p);
+}
+
+/* real forward DFT of xw[n] -> re/im[0..m], kernel exp(-2 pi i k t / n); float64.
+ * Even/odd packing into one m-point complex FFT (radix-2, decimation in time). */
+static void rfft_forward(const rfft_plan *p, const double *xw, double *zr, double *zi, double *re, double *im) {
+  const int m = p->m;
+  for (int i = 0; i < m; ++i) {
+    zr[p->rev[i]] = xw[2 * i];
+    zi[p->rev[i]] = xw[2 * i + 1];
+  }
+  for (int half = 1; half < m; half <<= 1) {
+    const int step = (m / 2) / half;
+    for (int base = 0; base < m; base += 2 * half) {
+      for (int j = 0; j < half; ++j) {
+        const double wr = p->tw_re[j * step], wi = p->tw_im[j * step];
+        const int i0 = base + j, i1 = i0 + half;
+        const double tr = wr * zr[i1] - wi * zi[i1];
+        const double ti = wr * zi[i1] + wi * zr[i1];
+        zr[i1] = zr[i0] - tr; zi[i1] = zi[i0] - ti;
+        zr[i0] = zr[i0] + tr; zi[i0] = zi[i0] + ti;
+      }
+    }
+  }
+  for (int k = 0; k <= m; ++k) {
+    const int k0 = k % m, k1 = (m - k) % m;
+    const double ar = zr[k0], ai = zi[k0], br = zr[k1], bi = -zi[k1];      /* B = conj Z[m-k] */
+    const double er = ar + br, ei = ai + bi, dr = ar - br, di = ai - bi;
+    const double wr = p->pw_re[k], wi = p->pw_im[k];
+    /* X = (E - i w D) / 2 */
+    re[k] = 0.5 * (er + wr * di + wi * dr);
+    im[k] = 0.5 * (ei - wr * dr + wi * di);
+  }
+}
+
+static double fetch(const float *x32, const double *x64, int64_t n, int64_t s, int pad, double pad_value) {
+  if (s < 0 || s >= n) {
+    if (pad == 0) {                       /* reflect, stft.ml:300-305 */
+      if (n == 1) s = 0;
+      else {
+        const int64_t period = 2 * (n - 1);
+        int64_t mm = s % period;
+        if (mm < 0) mm += period;
+        s = mm < n ? mm : period - mm;
+      }
+    } else if (pad == 2) {                /* edge */
+      s = s < 0 ? 0 : n - 1;
+    } else {
+      return pad_value;
+    }
+  }
+  return x32 ? (double)x32[s] : x64[s];
+}
+
+typedef struct {
+  const float *x32; const double *x64;
+  int64_t lead, n; int fft, hop; const double *window; int64_t left; int pad; double pad_value;
+  double power; int64_t frames;
+  float *out32; double *out64; int complex_out;
+  int thread, threads;
+} job_t;
+
+static void *worker(void *arg) {
+  job_t *j = (job_t *)arg;
+  const int n = j->fft, m = n / 2, bins = m + 1;
+  rfft_plan *p = plan_create(n);
+  double *xw = (double *)malloc(sizeof(double) * n);
+  double *zr = (double *)malloc(sizeof(double) * (m > 0 ? m : 1)), *zi = (double *)malloc(sizeof(double) * (m > 0 ? m : 1));
+  double *re = (double *)malloc(sizeof(double) * bins), *im = (double *)malloc(sizeof(double) * bins);
+  for (int64_t clip = j->thread; clip < j->lead; clip += j->threads) {
+    const float *x32 = j->x32 ? j->x32 + clip * j->n : NULL;
+    const double *x64 = j->x64 ? j->x64 + clip * j->n : NULL;
+    for (int64_t f = 0; f < j->frames; ++f) {
+      const int64_t s0 = f * j->hop - j->left;
+      for (int i = 0; i < n; ++i) xw[i] = fetch(x32, x64, j->n, s0 + i, j->pad, j->pad_value) * j->window[i];
+      rfft_forward(p, xw, zr, zi, re, im);
+      for (int k = 0; k < bins; ++k) {
+        const int64_t o = (clip * bins + k) * j->frames + f;
+        if (j->out32) {
+          const float r32 = (float)re[k], i32 = (float)im[k];   /* one rounding to complex64 */
+          if (j->complex_out) { j->out32[2 * o] = r32; j->out32[2 * o + 1] = i32; continue; }
+          const float mag = (float)sqrt((double)r32 * (double)r32 + (double)i32 * (double)i32);
+          j->out32[o] = j->power == 2.0 ? mag * mag : (j->power == 1.0 ? mag : (float)pow((double)mag, j->power));
+        } else {
+          if (j->complex_out) { j->out64[2 * o] = re[k]; j->out64[2 * o + 1] = im[k]; continue; }
+          const double mag = hypot(re[k], im[k]);
+          j->out64[o] = j->power == 2.0 ? mag * mag : (j->power == 1.0 ? mag : pow(mag, j->power));
+        }
+      }
+    }
+  }
+  free(xw); free(zr); free(zi); free(re); free(im);
+  plan_destroy(p);
+  return NULL;
+}
+
+/* Returns 0 on success, -1 for an unsupported fft (power of two >= 2 only). */
+static int run(job_t base, int threads) {
+  if (base.fft < 2 || (base.fft & (base.fft - 1))) return -1;
+  if (threads < 1) threads = 1;
+  if (threads > 256) threads = 256;
+  pthread_t tid[256];
+  job_t jobs[256];
+  for (int t = 0; t < threads; ++t) {
+    jobs[t] = base;
+    jobs[t].thread = t;
+    jobs[t].threads = threads;
+    pthread_create(&tid[t], NULL, worker, &jobs[t]);
+  }
+  for (int t = 0; t < threads; ++t) pthread_join(tid[t], NULL);
+  return 0;
+}
+
+int oracle_stft_f32(const float *x, int64_t lead, int64_t n, int fft, int hop, const double *window,
+                    int64_t left, int pad, double pad_value, int64_t frames, int complex_out, double power,
+                    float *out, int threads) {
+  job_t j; memset(&j, 0, sizeof(j));
+  j.x32 = x; j.lead = lead; j.n = n; j.fft = fft; j.hop = hop; j.window = window; j.left = left; j.pad = pad;
+  j.pad_value = pad_value; j.power = power; j.frames = frames; j.out32 = out; j.complex_out = complex_out;
+  return run(j, threads);
+}
+
+int oracle_stft_f64(const double *x, int64_t lead, int64_t n, int fft, int hop, const double *window,
+                    int64_t left, int pad, double pad_value, int64_t frames, int complex_out, double power,
+                    double *out, int threads) {
+  job_t j; memset(&j, 0, sizeof(j));
+  j.x64 = x; j.lead = lead; j.n = n; j.fft = fft; j.hop = hop; j.window = window; j.left = left; j.pad = pad;
+  j.pad_value = pad_value; j.power = power; j.frames = frames; j.out64 = out; j.complex_out = complex_out;
+  return run(j, threads);
+}
+
+/* mel.ml:231: out[l][m][t] = (float) sum_b W[m][b] * (double) S[l][b][t] */
+int oracle_mel_apply_f32(const double *w, int n_mels, int bins, const float *s, int64_t lead, int64_t frames,
+                         float *out) {
+  for (int64_t l = 0; l < lead; ++l)
+    for (int m = 0; m < n_mels; ++m)
+      for (int64_t t = 0; t < frames; ++t) {
+        double acc = 0.0;
+        for (int b = 0; b < bins; ++b) acc += w[(int64_t)m * bins + b] * (double)s[(l * bins + b) * frames + t];
+        out[(l * n_mels + m) * frames + t] = (float)acc;
+      }
+  return 0;
+}

@@ -1,0 +1,35 @@
+"""soundml_amd -- MI355X-native spectral path for SoundML (STFT / power
+spectrogram, mel filterbank, FIR block convolution) behind the reference's own
+module names:
+
+    from soundml_amd import Stft, Mel, Window, Fir, mel_spectrogram
+
+Everything computes in hand-written HIP kernels (gfx950) behind the C ABI of
+``include/soundml_amd.h``; this package is the thin host mirror of
+``Soundml.Stft`` / ``Soundml.Mel`` / ``Soundml.mel_spectrogram`` and fails loudly
+if the HIP library is missing (no CPU fallback).
+"""
+from . import _lib
+from ._lib import Failure, InvalidArgument, LIB_PATH
+from . import stft as Stft
+from . import mel as Mel
+from . import window as Window
+from . import fir as Fir
+from .features import mel_spectrogram
+from . import shard
+
+
+def set_interior(name: str) -> None:
+    """"float32" (default, fast) or "float64" (the reference's interior, stft.ml:28-35)."""
+    _lib.check(_lib.lib.smx_set_interior(_lib.INTERIOR[name]))
+
+
+def device_count() -> int:
+    import ctypes
+    n = ctypes.c_int()
+    _lib.check(_lib.lib.smx_device_count(ctypes.byref(n)))
+    return n.value
+
+
+__all__ = ["Stft", "Mel", "Window", "Fir", "mel_spectrogram", "shard", "set_interior", "device_count",
+           "InvalidArgument", "Failure", "LIB_PATH"]

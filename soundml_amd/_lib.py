@@ -1,0 +1,125 @@
+"""ctypes binding of libsoundml_amd.so (the C ABI declared in include/soundml_amd.h).
+
+The product path never computes on the CPU: if the HIP library is missing this
+module raises at import time with build instructions, and every compute entry
+point fails with ``Failure`` when no HIP device is visible.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libsoundml_amd.so")
+
+
+class InvalidArgument(ValueError):
+    """The reference's ``Invalid_argument``: a user-facing precondition failed.
+    ``str(e)`` is the reference's message, verbatim."""
+
+
+class Failure(RuntimeError):
+    """The reference's ``Failure``: bookkeeping / runtime (HIP) error."""
+
+
+SMX_OK, SMX_INVALID_ARGUMENT, SMX_FAILURE = 0, 1, 2
+SMX_DEFAULT = -(2 ** 63)
+
+ALIGNMENT = {"centered": 0, "left": 1, "right": 2}
+PAD = {"reflect": 0, "constant": 1, "edge": 2}
+SCALE = {"none": 0, "magnitude": 1, "psd": 2}
+WINDOW = {"hann": 0, "rectangular": 1, "hamming": 2, "blackman": 3, "blackman_harris": 4,
+          "nuttall": 5, "flat_top": 6, "custom": 100}
+MEL_SCALE = {"slaney": 0, "htk": 1}
+MEL_NORM = {"slaney": 0, "none": 1}
+INTERIOR = {"float32": 0, "float64": 1}
+
+if not os.path.exists(LIB_PATH):
+    raise ImportError(
+        "soundml_amd: %s is missing. Build it with `python -c \"import __graft_entry__ as g; "
+        "g.build()\"` or `make -C soundml_amd/csrc` (hipcc, gfx950). There is no CPU fallback."
+        % LIB_PATH)
+
+lib = C.CDLL(LIB_PATH)
+
+i64, f64, cint, vp = C.c_int64, C.c_double, C.c_int, C.c_void_p
+pf32, pf64, pi64 = C.POINTER(C.c_float), C.POINTER(C.c_double), C.POINTER(C.c_int64)
+
+# name -> (restype, argtypes); mirrors include/soundml_amd.h one to one
+SIGNATURES = {
+    "smx_last_error": (C.c_char_p, []),
+    "smx_version": (cint, []),
+    "smx_device_count": (cint, [C.POINTER(cint)]),
+    "smx_set_device": (cint, [cint]),
+    "smx_set_interior": (cint, [cint]),
+    "smx_get_interior": (cint, []),
+    "smx_synchronize": (cint, [vp]),
+    "smx_window_make": (cint, [cint, cint, i64, vp]),
+    "smx_stft_config_create": (cint, [i64, i64, i64, cint, cint, f64, cint, cint, vp, C.POINTER(vp)]),
+    "smx_stft_config_destroy": (None, [vp]),
+    "smx_stft_config_fft_size": (i64, [vp]),
+    "smx_stft_config_hop": (i64, [vp]),
+    "smx_stft_config_win_length": (i64, [vp]),
+    "smx_stft_config_bins": (i64, [vp]),
+    "smx_stft_config_left_width": (i64, [vp]),
+    "smx_stft_config_right_width": (i64, [vp]),
+    "smx_stft_config_latency": (i64, [vp]),
+    "smx_stft_config_analysis_window": (cint, [vp, vp]),
+    "smx_stft_frames": (cint, [vp, i64, pi64]),
+    "smx_stft_first_complete": (cint, [vp, pi64]),
+    "smx_stft_last_complete": (cint, [vp, i64, pi64]),
+    "smx_stft_times": (cint, [vp, i64, i64, vp]),
+    "smx_stft_frequencies": (cint, [vp, i64, vp]),
+    "smx_stft_transform_f32": (cint, [vp, vp, i64, i64, vp]),
+    "smx_stft_transform_f64": (cint, [vp, vp, i64, i64, vp]),
+    "smx_stft_transform_range_f32": (cint, [vp, vp, i64, i64, i64, i64, vp]),
+    "smx_stft_transform_range_f64": (cint, [vp, vp, i64, i64, i64, i64, vp]),
+    "smx_stft_power_spectrum_f32": (cint, [vp, vp, i64, i64, f64, vp]),
+    "smx_stft_power_spectrum_f64": (cint, [vp, vp, i64, i64, f64, vp]),
+    "smx_stft_transform_range_f32_dev": (cint, [vp, vp, i64, i64, i64, i64, i64, vp, vp]),
+    "smx_stft_transform_range_f64_dev": (cint, [vp, vp, i64, i64, i64, i64, i64, vp, vp]),
+    "smx_stft_power_range_f32_dev": (cint, [vp, vp, i64, i64, i64, i64, i64, f64, vp, vp]),
+    "smx_stft_power_range_f64_dev": (cint, [vp, vp, i64, i64, i64, i64, i64, f64, vp, vp]),
+    "smx_stft_kernel_prepare": (cint, [vp, cint, i64, i64, C.POINTER(vp)]),
+    "smx_stft_kernel_destroy": (None, [vp]),
+    "smx_stft_kernel_frame_bound": (cint, [vp, pi64]),
+    "smx_stft_kernel_step": (cint, [vp, vp, i64, vp, i64, pi64]),
+    "smx_stft_kernel_flush": (cint, [vp, vp, i64, pi64]),
+    "smx_stft_kernel_reset": (cint, [vp]),
+    "smx_mel_config_create": (cint, [i64, i64, i64, f64, cint, f64, cint, cint, C.POINTER(vp)]),
+    "smx_mel_config_destroy": (None, [vp]),
+    "smx_mel_config_n_mels": (i64, [vp]),
+    "smx_mel_config_bins": (i64, [vp]),
+    "smx_mel_config_fft_size": (i64, [vp]),
+    "smx_mel_config_f_max": (f64, [vp]),
+    "smx_mel_filterbank": (cint, [vp, vp]),
+    "smx_mel_apply_f32": (cint, [vp, vp, i64, i64, i64, vp]),
+    "smx_mel_apply_f64": (cint, [vp, vp, i64, i64, i64, vp]),
+    "smx_mel_apply_f32_dev": (cint, [vp, vp, i64, i64, i64, vp, vp]),
+    "smx_mel_apply_f64_dev": (cint, [vp, vp, i64, i64, i64, vp, vp]),
+    "smx_mel_spectrogram_f32": (cint, [vp, vp, vp, i64, i64, f64, vp]),
+    "smx_mel_spectrogram_f64": (cint, [vp, vp, vp, i64, i64, f64, vp]),
+    "smx_mel_spectrogram_f32_dev": (cint, [vp, vp, vp, i64, i64, i64, f64, vp, vp]),
+    "smx_fir_kaiser_beta": (cint, [f64, pf64]),
+    "smx_fir_design_lowpass": (cint, [i64, f64, f64, vp]),
+    "smx_fir_plan_create": (cint, [vp, i64, C.POINTER(vp)]),
+    "smx_fir_plan_destroy": (None, [vp]),
+    "smx_fir_plan_block": (i64, [vp]),
+    "smx_fir_apply_f32": (cint, [vp, vp, i64, i64, vp]),
+    "smx_fir_apply_f32_dev": (cint, [vp, vp, i64, i64, i64, vp, i64, vp]),
+}
+
+for _name, (_res, _args) in SIGNATURES.items():
+    _fn = getattr(lib, _name)          # AttributeError here = the library lacks a declared symbol
+    _fn.restype = _res
+    _fn.argtypes = _args
+
+
+def check(status: int) -> None:
+    """Turn a status code into the reference's exception."""
+    if status == SMX_OK:
+        return
+    message = (lib.smx_last_error() or b"").decode("utf-8", "replace")
+    if status == SMX_INVALID_ARGUMENT:
+        raise InvalidArgument(message)
+    raise Failure(message)

@@ -1,0 +1,871 @@
+// extern "C" entry points of include/soundml_amd.h.  Every function validates
+// its arguments (raising the reference's Invalid_argument messages as
+// SMX_INVALID_ARGUMENT) before any pointer is formed or device work enqueued,
+// mirroring the discipline of the reference's stub layer
+// (resample_stubs.c:228-276).  There is no CPU compute path here: the host
+// entry points upload, launch the HIP kernels and download.
+#include <cmath>
+#include <cstdlib>
+#include <cstring>
+#include <atomic>
+#include <memory>
+
+#include "smx_internal.hpp"
+
+namespace smx {
+
+static thread_local std::string g_last_error;
+static std::atomic<int> g_interior{SMX_INTERIOR_F32};
+
+void set_last_error(const std::string &message) { g_last_error = message; }
+
+bool fast_path_disabled() {
+  const char *e = std::getenv("SMX_DISABLE_FAST");
+  return e && e[0] == '1';
+}
+
+void launch_stft(const StftJob &job) {
+  if (job.count <= 0 || job.lead <= 0) return;
+  if (launch_stft_fast(job)) return;
+  launch_stft_generic(job);
+}
+
+namespace {
+
+template <typename F>
+int guarded(F &&body) {
+  try {
+    body();
+    return SMX_OK;
+  } catch (const InvalidArgument &e) {
+    set_last_error(e.what());
+    return SMX_INVALID_ARGUMENT;
+  } catch (const std::exception &e) {
+    set_last_error(e.what());
+    return SMX_FAILURE;
+  }
+}
+
+void require_device() {
+  int count = 0;
+  hipError_t err = hipGetDeviceCount(&count);
+  if (err != hipSuccess || count < 1)
+    throw Failure("soundml_amd: no HIP device is available (this library has no CPU fallback)");
+}
+
+struct DeviceScratch {  // RAII device allocation for the host-pointer entry points
+  void *ptr = nullptr;
+  explicit DeviceScratch(size_t bytes) {
+    if (bytes == 0) bytes = 16;
+    SMX_HIP_CHECK(hipMalloc(&ptr, bytes));
+  }
+  ~DeviceScratch() { (void)hipFree(ptr); }
+  DeviceScratch(const DeviceScratch &) = delete;
+  DeviceScratch &operator=(const DeviceScratch &) = delete;
+};
+
+void check_config(const void *c, const char *fn) {
+  if (!c) throw Failure(format("%s: configuration handle is null", fn));
+}
+
+void check_rank_extents(const char *fn, int64_t lead, int64_t n) {
+  if (lead < 0 || n < 0)
+    throw Failure(format("%s: negative extent (lead %lld, n %lld)", fn, (long long)lead, (long long)n));
+}
+
+void check_range(const smx_stft_config &c, int64_t n, int64_t p0, int64_t p1) {
+  const int64_t total = c.frames(n);
+  if (p0 < 0 || p0 > p1 || p1 > total)  // stft.ml:655-661
+    throw InvalidArgument(format(
+        "transform_range: cannot take frames [%lld, %lld) of a %lld-frame transform (the range must "
+        "satisfy 0 <= p0 <= p1 <= frames)",
+        (long long)p0, (long long)p1, (long long)total));
+}
+
+// device-resident analysis of frames [p0, p1)
+void stft_range_dev(const smx_stft_config &c, const void *d_x, int in_bytes, int64_t lead, int64_t n,
+                    int64_t x_stride, int64_t p0, int64_t p1, OutMode mode, double power, void *d_out,
+                    hipStream_t stream) {
+  check_rank_extents("transform_range", lead, n);
+  if (x_stride < n) throw Failure("transform_range: x_stride is smaller than the signal length");
+  check_range(c, n, p0, p1);
+  if (p0 == p1 || lead == 0) return;  // frameless_spectrum: nothing to write (stft.ml:629-630)
+  if (!d_x || !d_out) throw Failure("transform_range: null device pointer");
+  StftJob job;
+  job.cfg = &c;
+  job.x = d_x;
+  job.in_bytes = in_bytes;
+  job.interior = in_bytes == 8 ? SMX_INTERIOR_F64 : g_interior.load();
+  job.lead = lead;
+  job.n = n;
+  job.x_stride = x_stride;
+  job.left = c.left_width();
+  job.pad = c.pad;
+  job.pad_value = c.pad_value;
+  job.p0 = p0;
+  job.count = p1 - p0;
+  job.mode = mode;
+  job.power = power;
+  job.out = d_out;
+  job.out_stride = p1 - p0;
+  job.out_offset = 0;
+  job.stream = stream;
+  launch_stft(job);
+}
+
+// host-pointer analysis: upload, run, download
+void stft_range_host(const smx_stft_config &c, const void *x, int in_bytes, int64_t lead, int64_t n,
+                     int64_t p0, int64_t p1, OutMode mode, double power, void *out) {
+  check_rank_extents("transform", lead, n);
+  check_range(c, n, p0, p1);
+  const int64_t count = p1 - p0;
+  const size_t out_elems = (size_t)lead * (size_t)c.bins() * (size_t)count * (mode == OUT_COMPLEX ? 2 : 1);
+  if (count == 0 || lead == 0) return;
+  if (!x || !out) throw Failure("transform: null pointer");
+  require_device();
+  DeviceScratch dx((size_t)lead * (size_t)n * (size_t)in_bytes);
+  DeviceScratch dout(out_elems * (size_t)in_bytes);
+  SMX_HIP_CHECK(hipMemcpy(dx.ptr, x, (size_t)lead * (size_t)n * (size_t)in_bytes, hipMemcpyHostToDevice));
+  stft_range_dev(c, dx.ptr, in_bytes, lead, n, n, p0, p1, mode, power, dout.ptr, nullptr);
+  SMX_HIP_CHECK(hipStreamSynchronize(nullptr));
+  SMX_HIP_CHECK(hipMemcpy(out, dout.ptr, out_elems * (size_t)in_bytes, hipMemcpyDeviceToHost));
+}
+
+}  // namespace
+}  // namespace smx
+
+using namespace smx;
+
+// =============================== library =====================================
+extern "C" {
+
+const char *smx_last_error(void) { return g_last_error.c_str(); }
+int smx_version(void) { return 100; }
+
+int smx_device_count(int *count) {
+  return guarded([&] {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) n = 0;
+    if (count) *count = n;
+  });
+}
+
+int smx_set_device(int device) {
+  return guarded([&] { SMX_HIP_CHECK(hipSetDevice(device)); });
+}
+
+int smx_set_interior(int interior) {
+  return guarded([&] {
+    if (interior != SMX_INTERIOR_F32 && interior != SMX_INTERIOR_F64)
+      throw InvalidArgument(format("set_interior: unknown interior %d", interior));
+    g_interior.store(interior);
+  });
+}
+int smx_get_interior(void) { return g_interior.load(); }
+
+int smx_synchronize(void *stream) {
+  return guarded([&] { SMX_HIP_CHECK(hipStreamSynchronize((hipStream_t)stream)); });
+}
+
+// =============================== Window ======================================
+int smx_window_make(int kind, int periodic, int64_t n, double *out) {
+  return guarded([&] {
+    if (n >= 1 && !out) throw Failure("make: null output");
+    window_make(kind, periodic != 0, n, out);
+  });
+}
+
+// =============================== Stft.Config =================================
+int smx_stft_config_create(int64_t fft_size, int64_t win_length, int64_t hop, int alignment, int pad,
+                           double pad_value, int scale, int window_kind, const double *custom_window,
+                           smx_stft_config **out) {
+  return guarded([&] {
+    if (!out) throw Failure("create: null output handle");
+    *out = stft_config_create(fft_size, win_length, hop, alignment, pad, pad_value, scale, window_kind,
+                              custom_window);
+  });
+}
+void smx_stft_config_destroy(smx_stft_config *c) { delete c; }
+int64_t smx_stft_config_fft_size(const smx_stft_config *c) { return c ? c->fft_size : -1; }
+int64_t smx_stft_config_hop(const smx_stft_config *c) { return c ? c->hop : -1; }
+int64_t smx_stft_config_win_length(const smx_stft_config *c) { return c ? c->win_length : -1; }
+int64_t smx_stft_config_bins(const smx_stft_config *c) { return c ? c->bins() : -1; }
+int64_t smx_stft_config_left_width(const smx_stft_config *c) { return c ? c->left_width() : -1; }
+int64_t smx_stft_config_right_width(const smx_stft_config *c) { return c ? c->right_width() : -1; }
+int64_t smx_stft_config_latency(const smx_stft_config *c) {
+  return c ? (c->alignment == SMX_ALIGN_CENTERED ? c->fft_size / 2 : 0) : -1;
+}
+int smx_stft_config_analysis_window(const smx_stft_config *c, double *out) {
+  return guarded([&] {
+    check_config(c, "analysis_window");
+    std::memcpy(out, c->analysis_window.data(), c->analysis_window.size() * sizeof(double));
+  });
+}
+
+// =============================== frame grid ==================================
+int smx_stft_frames(const smx_stft_config *c, int64_t n, int64_t *out) {
+  return guarded([&] {
+    check_config(c, "frames");
+    *out = c->frames(n);
+  });
+}
+int smx_stft_first_complete(const smx_stft_config *c, int64_t *out) {
+  return guarded([&] {
+    check_config(c, "first_complete");
+    *out = stft_first_complete(*c);
+  });
+}
+int smx_stft_last_complete(const smx_stft_config *c, int64_t n, int64_t *out) {
+  return guarded([&] {
+    check_config(c, "last_complete");
+    *out = stft_last_complete(*c, n);
+  });
+}
+static void check_sample_rate(const char *op, int64_t sample_rate) {  // stft.ml:237-243
+  if (sample_rate < 1)
+    throw InvalidArgument(format(
+        "%s: cannot use a sample rate of %lld Hz (sample_rate must be at least 1)", op,
+        (long long)sample_rate));
+}
+int smx_stft_times(const smx_stft_config *c, int64_t sample_rate, int64_t n, double *out) {
+  return guarded([&] {
+    check_config(c, "times");
+    check_sample_rate("times", sample_rate);
+    if (n < 0)
+      throw InvalidArgument(format(
+          "times: cannot analyse a signal of length %lld (length must be non-negative)", (long long)n));
+    const int64_t count = c->frames(n);
+    for (int64_t p = 0; p < count; ++p)  // stft.ml:245-254: p*hop exact, one rounding
+      out[p] = ((double)p * (double)c->hop) / (double)sample_rate;
+  });
+}
+int smx_stft_frequencies(const smx_stft_config *c, int64_t sample_rate, double *out) {
+  return guarded([&] {
+    check_config(c, "frequencies");
+    check_sample_rate("frequencies", sample_rate);
+    const double step = (double)sample_rate / (double)c->fft_size;  // stft.ml:256-261
+    for (int64_t k = 0; k < c->bins(); ++k) out[k] = (double)k * step;
+  });
+}
+
+// =============================== transforms ==================================
+int smx_stft_transform_f32(const smx_stft_config *c, const float *x, int64_t lead, int64_t n,
+                           float *out) {
+  return guarded([&] {
+    check_config(c, "transform");
+    check_rank_extents("transform", lead, n);
+    stft_range_host(*c, x, 4, lead, n, 0, c->frames(n), OUT_COMPLEX, 0.0, out);
+  });
+}
+int smx_stft_transform_f64(const smx_stft_config *c, const double *x, int64_t lead, int64_t n,
+                           double *out) {
+  return guarded([&] {
+    check_config(c, "transform");
+    check_rank_extents("transform", lead, n);
+    stft_range_host(*c, x, 8, lead, n, 0, c->frames(n), OUT_COMPLEX, 0.0, out);
+  });
+}
+int smx_stft_transform_range_f32(const smx_stft_config *c, const float *x, int64_t lead, int64_t n,
+                                 int64_t p0, int64_t p1, float *out) {
+  return guarded([&] {
+    check_config(c, "transform_range");
+    stft_range_host(*c, x, 4, lead, n, p0, p1, OUT_COMPLEX, 0.0, out);
+  });
+}
+int smx_stft_transform_range_f64(const smx_stft_config *c, const double *x, int64_t lead, int64_t n,
+                                 int64_t p0, int64_t p1, double *out) {
+  return guarded([&] {
+    check_config(c, "transform_range");
+    stft_range_host(*c, x, 8, lead, n, p0, p1, OUT_COMPLEX, 0.0, out);
+  });
+}
+int smx_stft_power_spectrum_f32(const smx_stft_config *c, const float *x, int64_t lead, int64_t n,
+                                double power, float *out) {
+  return guarded([&] {
+    check_config(c, "power_spectrum");
+    check_rank_extents("power_spectrum", lead, n);
+    stft_range_host(*c, x, 4, lead, n, 0, c->frames(n), OUT_POWER, power, out);
+  });
+}
+int smx_stft_power_spectrum_f64(const smx_stft_config *c, const double *x, int64_t lead, int64_t n,
+                                double power, double *out) {
+  return guarded([&] {
+    check_config(c, "power_spectrum");
+    check_rank_extents("power_spectrum", lead, n);
+    stft_range_host(*c, x, 8, lead, n, 0, c->frames(n), OUT_POWER, power, out);
+  });
+}
+
+int smx_stft_transform_range_f32_dev(const smx_stft_config *c, const float *d_x, int64_t lead,
+                                     int64_t n, int64_t x_stride, int64_t p0, int64_t p1,
+                                     float *d_out, void *stream) {
+  return guarded([&] {
+    check_config(c, "transform_range");
+    stft_range_dev(*c, d_x, 4, lead, n, x_stride, p0, p1, OUT_COMPLEX, 0.0, d_out, (hipStream_t)stream);
+  });
+}
+int smx_stft_transform_range_f64_dev(const smx_stft_config *c, const double *d_x, int64_t lead,
+                                     int64_t n, int64_t x_stride, int64_t p0, int64_t p1,
+                                     double *d_out, void *stream) {
+  return guarded([&] {
+    check_config(c, "transform_range");
+    stft_range_dev(*c, d_x, 8, lead, n, x_stride, p0, p1, OUT_COMPLEX, 0.0, d_out, (hipStream_t)stream);
+  });
+}
+int smx_stft_power_range_f32_dev(const smx_stft_config *c, const float *d_x, int64_t lead, int64_t n,
+                                 int64_t x_stride, int64_t p0, int64_t p1, double power, float *d_out,
+                                 void *stream) {
+  return guarded([&] {
+    check_config(c, "power_spectrum");
+    stft_range_dev(*c, d_x, 4, lead, n, x_stride, p0, p1, OUT_POWER, power, d_out, (hipStream_t)stream);
+  });
+}
+int smx_stft_power_range_f64_dev(const smx_stft_config *c, const double *d_x, int64_t lead, int64_t n,
+                                 int64_t x_stride, int64_t p0, int64_t p1, double power,
+                                 double *d_out, void *stream) {
+  return guarded([&] {
+    check_config(c, "power_spectrum");
+    stft_range_dev(*c, d_x, 8, lead, n, x_stride, p0, p1, OUT_POWER, power, d_out, (hipStream_t)stream);
+  });
+}
+
+}  // extern "C"
+
+// =============================== Stft.Kernel ==================================
+// Streaming analysis (stft.ml:366-622).  The state machine is the reference's:
+// a prelude until the left extension is computable, the pending padded suffix,
+// the last right+1 raw samples, and `skip` when hop > fft.  The carry (pending
+// suffix, tail) lives in DEVICE memory; each step uploads only the new chunk and
+// runs the same analysis kernels over [pending ++ extension ++ chunk].
+struct smx_stft_kernel {
+  const smx_stft_config *cfg = nullptr;
+  int dtype_bytes = 4;
+  int64_t channels = 0, max_block = 0;
+  int64_t left = 0, right = 0;
+  bool started = false, drained = false;
+  int64_t received = 0;
+  int64_t skip = 0;
+  // host-side mirrors of the small carried pieces (prelude and tail are at most
+  // left+1 / right+1 samples per channel); the pending padded suffix is on device
+  std::vector<unsigned char> prelude;   // [channels][prelude_len]
+  int64_t prelude_len = 0;
+  std::vector<unsigned char> tail;      // [channels][tail_len]
+  int64_t tail_len = 0;
+  void *d_stream = nullptr;             // device [channels][cap]: pending ++ new padded samples
+  int64_t cap = 0;
+  int64_t pending_len = 0;
+  void *d_out = nullptr;
+  int64_t out_cap = 0;                  // frames
+  ~smx_stft_kernel() {
+    (void)hipFree(d_stream);
+    (void)hipFree(d_out);
+  }
+};
+
+namespace smx {
+namespace {
+
+int64_t frame_bound(const smx_stft_config &c, int64_t max_block) {  // stft.ml:1316-1317 + :1307-1308
+  int64_t lat = c.alignment == SMX_ALIGN_CENTERED ? c.fft_size / 2 : 0;
+  if (c.pad == SMX_PAD_REFLECT && c.left_width() > lat) lat = c.left_width();
+  return (max_block + lat + c.hop - 1) / c.hop + 1;
+}
+
+void ensure_stream(smx_stft_kernel &k, int64_t need) {
+  if (need <= k.cap) return;
+  int64_t cap = k.cap ? k.cap : 1024;
+  while (cap < need) cap *= 2;
+  void *fresh = nullptr;
+  const size_t es = (size_t)k.dtype_bytes;
+  SMX_HIP_CHECK(hipMalloc(&fresh, (size_t)k.channels * (size_t)cap * es));
+  if (k.d_stream && k.pending_len > 0)
+    SMX_HIP_CHECK(hipMemcpy2D(fresh, (size_t)cap * es, k.d_stream, (size_t)k.cap * es,
+                              (size_t)k.pending_len * es, (size_t)k.channels, hipMemcpyDeviceToDevice));
+  (void)hipFree(k.d_stream);
+  k.d_stream = fresh;
+  k.cap = cap;
+}
+
+// stft.ml:415-442 `process`: append `extra` ([channels][extra_len] host, stream
+// order) to the pending padded stream and emit every frame that became complete.
+int64_t process(smx_stft_kernel &k, const unsigned char *extra, int64_t extra_len, void *out,
+                int64_t capacity) {
+  const smx_stft_config &c = *k.cfg;
+  const int64_t fft = c.fft_size, hop = c.hop;
+  const size_t es = (size_t)k.dtype_bytes;
+  const int64_t total = k.pending_len + extra_len;
+  ensure_stream(k, total);
+  if (extra_len > 0)
+    SMX_HIP_CHECK(hipMemcpy2D((unsigned char *)k.d_stream + (size_t)k.pending_len * es, (size_t)k.cap * es,
+                              extra, (size_t)extra_len * es, (size_t)extra_len * es, (size_t)k.channels,
+                              hipMemcpyHostToDevice));
+  const int64_t count = total < fft ? 0 : 1 + (total - fft) / hop;
+  if (count == 0) {
+    k.pending_len = total;
+    return 0;
+  }
+  if (count > capacity)
+    throw Failure(format("step: %lld frames do not fit the caller's %lld-frame output window",
+                         (long long)count, (long long)capacity));
+  const int64_t bins = c.bins();
+  if (count > k.out_cap) {
+    (void)hipFree(k.d_out);
+    k.d_out = nullptr;
+    int64_t cap = k.out_cap ? k.out_cap : 16;
+    while (cap < count) cap *= 2;
+    SMX_HIP_CHECK(hipMalloc(&k.d_out, (size_t)k.channels * (size_t)bins * (size_t)cap * 2 * es));
+    k.out_cap = cap;
+  }
+  StftJob job;
+  job.cfg = &c;
+  job.x = k.d_stream;
+  job.in_bytes = k.dtype_bytes;
+  job.interior = k.dtype_bytes == 8 ? SMX_INTERIOR_F64 : smx_get_interior();
+  job.lead = k.channels;
+  job.n = total;
+  job.x_stride = k.cap;
+  job.left = 0;                 // the stream is already padded
+  job.pad = SMX_PAD_CONSTANT;
+  job.pad_value = 0.0;
+  job.p0 = 0;
+  job.count = count;
+  job.mode = OUT_COMPLEX;
+  job.out = k.d_out;
+  job.out_stride = count;
+  job.out_offset = 0;
+  launch_stft(job);
+  // [channels; bins; count] (dense) -> caller's [channels; bins; capacity] window
+  SMX_HIP_CHECK(hipMemcpy2D(out, (size_t)capacity * 2 * es, k.d_out, (size_t)count * 2 * es,
+                            (size_t)count * 2 * es, (size_t)(k.channels * bins), hipMemcpyDeviceToHost));
+  const int64_t next_start = count * hop;
+  if (next_start >= total) {
+    k.skip += next_start - total;
+    k.pending_len = 0;
+  } else {
+    const int64_t keep = total - next_start;
+    // move the suffix to the front (rows are independent; overlapping ranges -> staged copy)
+    DeviceScratch tmp((size_t)k.channels * (size_t)keep * es);
+    SMX_HIP_CHECK(hipMemcpy2D(tmp.ptr, (size_t)keep * es,
+                              (unsigned char *)k.d_stream + (size_t)next_start * es, (size_t)k.cap * es,
+                              (size_t)keep * es, (size_t)k.channels, hipMemcpyDeviceToDevice));
+    SMX_HIP_CHECK(hipMemcpy2D(k.d_stream, (size_t)k.cap * es, tmp.ptr, (size_t)keep * es,
+                              (size_t)keep * es, (size_t)k.channels, hipMemcpyDeviceToDevice));
+    k.pending_len = keep;
+  }
+  return count;
+}
+
+template <typename T>
+void gather_rows(std::vector<unsigned char> &dst, const unsigned char *src, int64_t channels,
+                 int64_t src_len, const std::vector<int64_t> &idx, double constant, bool use_constant) {
+  dst.resize((size_t)channels * idx.size() * sizeof(T));
+  T *d = reinterpret_cast<T *>(dst.data());
+  const T *s = reinterpret_cast<const T *>(src);
+  for (int64_t ch = 0; ch < channels; ++ch)
+    for (size_t j = 0; j < idx.size(); ++j)
+      d[(size_t)ch * idx.size() + j] =
+          (use_constant || idx[j] < 0) ? (T)constant : s[(size_t)ch * (size_t)src_len + (size_t)idx[j]];
+}
+
+void gather(smx_stft_kernel &k, std::vector<unsigned char> &dst, const unsigned char *src, int64_t src_len,
+            const std::vector<int64_t> &idx) {
+  const bool constant = k.cfg->pad == SMX_PAD_CONSTANT;
+  if (k.dtype_bytes == 4)
+    gather_rows<float>(dst, src, k.channels, src_len, idx, k.cfg->pad_value, constant);
+  else
+    gather_rows<double>(dst, src, k.channels, src_len, idx, k.cfg->pad_value, constant);
+}
+
+// rows [channels][a_len] ++ [channels][b_len] -> [channels][a_len + b_len]
+std::vector<unsigned char> concat_rows(const unsigned char *a, int64_t a_len, const unsigned char *b,
+                                       int64_t b_len, int64_t channels, size_t es) {
+  std::vector<unsigned char> out((size_t)channels * (size_t)(a_len + b_len) * es);
+  for (int64_t ch = 0; ch < channels; ++ch) {
+    unsigned char *row = out.data() + (size_t)ch * (size_t)(a_len + b_len) * es;
+    if (a_len) std::memcpy(row, a + (size_t)ch * (size_t)a_len * es, (size_t)a_len * es);
+    if (b_len) std::memcpy(row + (size_t)a_len * es, b + (size_t)ch * (size_t)b_len * es, (size_t)b_len * es);
+  }
+  return out;
+}
+
+std::vector<unsigned char> slice_rows(const unsigned char *a, int64_t a_len, int64_t start, int64_t stop,
+                                      int64_t channels, size_t es) {
+  const int64_t len = stop - start;
+  std::vector<unsigned char> out((size_t)channels * (size_t)len * es);
+  for (int64_t ch = 0; ch < channels; ++ch)
+    std::memcpy(out.data() + (size_t)ch * (size_t)len * es,
+                a + ((size_t)ch * (size_t)a_len + (size_t)start) * es, (size_t)len * es);
+  return out;
+}
+
+int64_t install_threshold(const smx_stft_config &c) {  // stft.ml:447-452
+  return c.pad == SMX_PAD_REFLECT ? c.left_width() + 1 : 1;
+}
+
+void update_tail(smx_stft_kernel &k, const unsigned char *chunk, int64_t m) {  // stft.ml:492-502
+  const size_t es = (size_t)k.dtype_bytes;
+  const int64_t keep = k.right + 1;
+  if (m >= keep) {
+    k.tail = slice_rows(chunk, m, m - keep, m, k.channels, es);
+    k.tail_len = keep;
+  } else {
+    std::vector<unsigned char> combined = concat_rows(k.tail.data(), k.tail_len, chunk, m, k.channels, es);
+    const int64_t cm = k.tail_len + m;
+    const int64_t start = cm - keep > 0 ? cm - keep : 0;
+    k.tail = slice_rows(combined.data(), cm, start, cm, k.channels, es);
+    k.tail_len = cm - start;
+  }
+}
+
+int64_t install(smx_stft_kernel &k, const unsigned char *x, int64_t n, void *out, int64_t capacity) {
+  // stft.ml:476-488
+  const size_t es = (size_t)k.dtype_bytes;
+  if (k.right > 0) {
+    const int64_t keep = k.right + 1 < n ? k.right + 1 : n;
+    k.tail = slice_rows(x, n, n - keep, n, k.channels, es);
+    k.tail_len = keep;
+  }
+  k.started = true;
+  k.prelude.clear();
+  k.prelude_len = 0;
+  if (k.left == 0) return process(k, x, n, out, capacity);
+  std::vector<int64_t> idx((size_t)k.left);  // stft.ml:457-471 left_pad
+  for (int64_t j = 0; j < k.left; ++j)
+    idx[(size_t)j] = k.cfg->pad == SMX_PAD_REFLECT ? k.left - j : 0;
+  std::vector<unsigned char> lp;
+  gather(k, lp, x, n, idx);
+  std::vector<unsigned char> both = concat_rows(lp.data(), k.left, x, n, k.channels, es);
+  return process(k, both.data(), k.left + n, out, capacity);
+}
+
+}  // namespace
+}  // namespace smx
+
+extern "C" {
+
+int smx_stft_kernel_prepare(const smx_stft_config *c, int dtype_bytes, int64_t channels,
+                            int64_t max_block, smx_stft_kernel **out) {
+  return guarded([&] {
+    check_config(c, "prepare");
+    if (channels < 1)  // stft.ml:604-608
+      throw InvalidArgument(format(
+          "prepare: cannot analyse %lld channels (channels must be at least 1)", (long long)channels));
+    if (max_block < 1)  // stft.ml:609-614
+      throw InvalidArgument(format(
+          "prepare: cannot accept blocks of %lld samples (max_block must be at least 1)",
+          (long long)max_block));
+    if (dtype_bytes != 4 && dtype_bytes != 8) throw Failure("prepare: dtype_bytes must be 4 or 8");
+    if (!out) throw Failure("prepare: null output handle");
+    require_device();
+    auto k = std::make_unique<smx_stft_kernel>();
+    k->cfg = c;
+    k->dtype_bytes = dtype_bytes;
+    k->channels = channels;
+    k->max_block = max_block;
+    k->left = c->left_width();
+    k->right = c->right_width();
+    *out = k.release();
+  });
+}
+
+void smx_stft_kernel_destroy(smx_stft_kernel *k) { delete k; }
+
+int smx_stft_kernel_frame_bound(const smx_stft_kernel *k, int64_t *out) {
+  return guarded([&] {
+    if (!k) throw Failure("frame_bound: null kernel");
+    *out = frame_bound(*k->cfg, k->max_block);
+  });
+}
+
+int smx_stft_kernel_reset(smx_stft_kernel *k) {  // stft.ml:401-409
+  return guarded([&] {
+    if (!k) throw Failure("reset: null kernel");
+    k->started = k->drained = false;
+    k->received = k->skip = 0;
+    k->prelude.clear();
+    k->prelude_len = 0;
+    k->tail.clear();
+    k->tail_len = 0;
+    k->pending_len = 0;
+  });
+}
+
+int smx_stft_kernel_step(smx_stft_kernel *k, const void *chunk, int64_t m, void *out, int64_t capacity,
+                         int64_t *emitted) {
+  return guarded([&] {  // stft.ml:521-559
+    if (!k || !emitted) throw Failure("step: null argument");
+    *emitted = 0;
+    if (k->drained)
+      throw InvalidArgument(
+          "step: cannot feed a drained kernel (flush consumed the tail; reset before reusing)");
+    if (m < 0) throw Failure("step: negative chunk length");
+    if (m == 0) return;
+    if (!chunk) throw Failure("step: null chunk");
+    const size_t es = (size_t)k->dtype_bytes;
+    const unsigned char *bytes = reinterpret_cast<const unsigned char *>(chunk);
+    k->received += m;
+    if (!k->started) {
+      if (k->received >= install_threshold(*k->cfg)) {
+        std::vector<unsigned char> x = concat_rows(k->prelude.data(), k->prelude_len, bytes, m, k->channels, es);
+        *emitted = install(*k, x.data(), k->prelude_len + m, out, capacity);
+      } else {
+        k->prelude = concat_rows(k->prelude.data(), k->prelude_len, bytes, m, k->channels, es);
+        k->prelude_len += m;
+      }
+      return;
+    }
+    if (k->right > 0) update_tail(*k, bytes, m);
+    if (k->skip >= m) {
+      k->skip -= m;
+      return;
+    }
+    const int64_t dropped = k->skip;
+    k->skip = 0;
+    if (dropped == 0) {
+      *emitted = process(*k, bytes, m, out, capacity);
+    } else {
+      std::vector<unsigned char> rest = slice_rows(bytes, m, dropped, m, k->channels, es);
+      *emitted = process(*k, rest.data(), m - dropped, out, capacity);
+    }
+  });
+}
+
+int smx_stft_kernel_flush(smx_stft_kernel *k, void *out, int64_t capacity, int64_t *emitted) {
+  return guarded([&] {  // stft.ml:561-595
+    if (!k || !emitted) throw Failure("flush: null argument");
+    *emitted = 0;
+    if (k->drained) return;
+    k->drained = true;
+    const smx_stft_config &c = *k->cfg;
+    if (!k->started) {
+      if (k->received != 0) {
+        const int64_t n = k->prelude_len;
+        std::vector<int64_t> idx((size_t)(k->left + n + k->right));  // pad_signal, stft.ml:318-338
+        for (int64_t q = 0; q < k->left + n + k->right; ++q)
+          idx[(size_t)q] = source_index(c, n, q - k->left);
+        std::vector<unsigned char> padded;
+        // constant padding only replaces the borders: gather with per-index constants
+        if (k->dtype_bytes == 4)
+          gather_rows<float>(padded, k->prelude.data(), k->channels, n, idx, c.pad_value, false);
+        else
+          gather_rows<double>(padded, k->prelude.data(), k->channels, n, idx, c.pad_value, false);
+        k->started = true;
+        k->prelude.clear();
+        k->prelude_len = 0;
+        *emitted = process(*k, padded.data(), (int64_t)idx.size(), out, capacity);
+      }
+    } else if (k->right > 0) {
+      const int64_t tl = k->tail_len, r = k->right;
+      std::vector<int64_t> idx((size_t)r);  // stft.ml:506-519 right_pad
+      for (int64_t i = 0; i < r; ++i) idx[(size_t)i] = c.pad == SMX_PAD_REFLECT ? tl - 2 - i : tl - 1;
+      std::vector<unsigned char> rp;
+      gather(*k, rp, k->tail.data(), tl, idx);
+      if (k->skip >= r) {
+        k->skip -= r;
+      } else {
+        const int64_t dropped = k->skip;
+        k->skip = 0;
+        if (dropped == 0) {
+          *emitted = process(*k, rp.data(), r, out, capacity);
+        } else {
+          std::vector<unsigned char> rest = slice_rows(rp.data(), r, dropped, r, k->channels, (size_t)k->dtype_bytes);
+          *emitted = process(*k, rest.data(), r - dropped, out, capacity);
+        }
+      }
+    }
+    k->pending_len = 0;
+  });
+}
+
+}  // extern "C"
+
+// =============================== Mel ==========================================
+namespace smx {
+namespace {
+
+void check_mel_shape(const smx_mel_config &c, int64_t lead, int64_t bins, int64_t frames) {
+  if (lead < 0 || frames < 0 || bins < 0) throw Failure("apply: negative extent");
+  if (bins != c.bins())  // mel.ml:210-218
+    throw InvalidArgument(format(
+        "apply: cannot project %lld frequency bins through a filterbank built for an FFT of size %lld "
+        "(%lld bins)",
+        (long long)bins, (long long)c.fft_size, (long long)c.bins()));
+}
+
+void mel_apply_dev(const smx_mel_config &c, const void *d_s, int elem_bytes, int64_t lead, int64_t bins,
+                   int64_t frames, void *d_out, hipStream_t stream) {
+  check_mel_shape(c, lead, bins, frames);
+  if (lead == 0 || frames == 0) return;  // mel.ml:220-226: nothing to reduce over
+  if (!d_s || !d_out) throw Failure("apply: null device pointer");
+  MelJob job;
+  job.cfg = &c;
+  job.s = d_s;
+  job.elem_bytes = elem_bytes;
+  job.lead = lead;
+  job.frames = frames;
+  job.out = d_out;
+  job.stream = stream;
+  launch_mel_apply(job);
+}
+
+void mel_apply_host(const smx_mel_config &c, const void *s, int elem_bytes, int64_t lead, int64_t bins,
+                    int64_t frames, void *out) {
+  check_mel_shape(c, lead, bins, frames);
+  if (lead == 0 || frames == 0) return;
+  if (!s || !out) throw Failure("apply: null pointer");
+  require_device();
+  const size_t in_bytes = (size_t)lead * (size_t)bins * (size_t)frames * (size_t)elem_bytes;
+  const size_t out_bytes = (size_t)lead * (size_t)c.n_mels * (size_t)frames * (size_t)elem_bytes;
+  DeviceScratch ds(in_bytes), dout(out_bytes);
+  SMX_HIP_CHECK(hipMemcpy(ds.ptr, s, in_bytes, hipMemcpyHostToDevice));
+  mel_apply_dev(c, ds.ptr, elem_bytes, lead, bins, frames, dout.ptr, nullptr);
+  SMX_HIP_CHECK(hipStreamSynchronize(nullptr));
+  SMX_HIP_CHECK(hipMemcpy(out, dout.ptr, out_bytes, hipMemcpyDeviceToHost));
+}
+
+void check_fft_sizes(const smx_stft_config &sc, const smx_mel_config &mc) {  // soundml.ml:12-20
+  if (sc.fft_size != mc.fft_size)
+    throw InvalidArgument(format(
+        "mel_spectrogram: cannot project a %lld-point STFT through a filterbank built for an FFT of "
+        "size %lld (the two configurations must agree on fft_size)",
+        (long long)sc.fft_size, (long long)mc.fft_size));
+}
+
+// Soundml.mel_spectrogram on device-resident audio.  The fused kernel keeps the
+// power tile on chip; other geometries run power_spectrum into a scratch
+// spectrogram followed by Mel.apply (the reference's own composition).
+void mel_spectrogram_dev(const smx_stft_config &sc, const smx_mel_config &mc, const void *d_x,
+                         int in_bytes, int64_t lead, int64_t n, int64_t x_stride, double power,
+                         void *d_out, hipStream_t stream) {
+  check_fft_sizes(sc, mc);
+  check_rank_extents("mel_spectrogram", lead, n);
+  if (x_stride < n) throw Failure("mel_spectrogram: x_stride is smaller than the signal length");
+  const int64_t count = sc.frames(n);
+  if (lead == 0 || count == 0) return;
+  if (!d_x || !d_out) throw Failure("mel_spectrogram: null device pointer");
+  MelSpecJob job;
+  job.stft.cfg = &sc;
+  job.stft.x = d_x;
+  job.stft.in_bytes = in_bytes;
+  job.stft.interior = in_bytes == 8 ? SMX_INTERIOR_F64 : g_interior.load();
+  job.stft.lead = lead;
+  job.stft.n = n;
+  job.stft.x_stride = x_stride;
+  job.stft.left = sc.left_width();
+  job.stft.pad = sc.pad;
+  job.stft.pad_value = sc.pad_value;
+  job.stft.p0 = 0;
+  job.stft.count = count;
+  job.stft.mode = OUT_POWER;
+  job.stft.power = power;
+  job.stft.stream = stream;
+  job.mel = &mc;
+  job.out = d_out;
+  if (launch_mel_spectrogram_fused(job)) return;
+  // two-step form; scratch is stream-ordered
+  void *scratch = nullptr;
+  const size_t bytes = (size_t)lead * (size_t)sc.bins() * (size_t)count * (size_t)in_bytes;
+  SMX_HIP_CHECK(hipMallocAsync(&scratch, bytes, stream));
+  job.stft.out = scratch;
+  job.stft.out_stride = count;
+  job.stft.out_offset = 0;
+  launch_stft(job.stft);
+  mel_apply_dev(mc, scratch, in_bytes, lead, sc.bins(), count, d_out, stream);
+  SMX_HIP_CHECK(hipFreeAsync(scratch, stream));
+}
+
+void mel_spectrogram_host(const smx_stft_config &sc, const smx_mel_config &mc, const void *x, int in_bytes,
+                          int64_t lead, int64_t n, double power, void *out) {
+  check_fft_sizes(sc, mc);
+  check_rank_extents("mel_spectrogram", lead, n);
+  const int64_t count = sc.frames(n);
+  if (lead == 0 || count == 0) return;
+  if (!x || !out) throw Failure("mel_spectrogram: null pointer");
+  require_device();
+  const size_t in_total = (size_t)lead * (size_t)n * (size_t)in_bytes;
+  const size_t out_total = (size_t)lead * (size_t)mc.n_mels * (size_t)count * (size_t)in_bytes;
+  DeviceScratch dx(in_total), dout(out_total);
+  SMX_HIP_CHECK(hipMemcpy(dx.ptr, x, in_total, hipMemcpyHostToDevice));
+  mel_spectrogram_dev(sc, mc, dx.ptr, in_bytes, lead, n, n, power, dout.ptr, nullptr);
+  SMX_HIP_CHECK(hipStreamSynchronize(nullptr));
+  SMX_HIP_CHECK(hipMemcpy(out, dout.ptr, out_total, hipMemcpyDeviceToHost));
+}
+
+}  // namespace
+}  // namespace smx
+
+extern "C" {
+
+int smx_mel_config_create(int64_t n_mels, int64_t sample_rate, int64_t fft_size, double f_min,
+                          int has_f_max, double f_max, int scale, int norm, smx_mel_config **out) {
+  return guarded([&] {
+    if (!out) throw Failure("create: null output handle");
+    *out = mel_config_create(n_mels, sample_rate, fft_size, f_min, has_f_max != 0, f_max, scale, norm);
+  });
+}
+void smx_mel_config_destroy(smx_mel_config *c) { delete c; }
+int64_t smx_mel_config_n_mels(const smx_mel_config *c) { return c ? c->n_mels : -1; }
+int64_t smx_mel_config_bins(const smx_mel_config *c) { return c ? c->bins() : -1; }
+int64_t smx_mel_config_fft_size(const smx_mel_config *c) { return c ? c->fft_size : -1; }
+double smx_mel_config_f_max(const smx_mel_config *c) { return c ? c->f_max : -1.0; }
+int smx_mel_filterbank(const smx_mel_config *c, double *out) {
+  return guarded([&] {
+    check_config(c, "filterbank");
+    std::memcpy(out, c->weights.data(), c->weights.size() * sizeof(double));
+  });
+}
+int smx_mel_apply_f32(const smx_mel_config *c, const float *s, int64_t lead, int64_t bins,
+                      int64_t frames, float *out) {
+  return guarded([&] {
+    check_config(c, "apply");
+    mel_apply_host(*c, s, 4, lead, bins, frames, out);
+  });
+}
+int smx_mel_apply_f64(const smx_mel_config *c, const double *s, int64_t lead, int64_t bins,
+                      int64_t frames, double *out) {
+  return guarded([&] {
+    check_config(c, "apply");
+    mel_apply_host(*c, s, 8, lead, bins, frames, out);
+  });
+}
+int smx_mel_apply_f32_dev(const smx_mel_config *c, const float *d_s, int64_t lead, int64_t bins,
+                          int64_t frames, float *d_out, void *stream) {
+  return guarded([&] {
+    check_config(c, "apply");
+    mel_apply_dev(*c, d_s, 4, lead, bins, frames, d_out, (hipStream_t)stream);
+  });
+}
+int smx_mel_apply_f64_dev(const smx_mel_config *c, const double *d_s, int64_t lead, int64_t bins,
+                          int64_t frames, double *d_out, void *stream) {
+  return guarded([&] {
+    check_config(c, "apply");
+    mel_apply_dev(*c, d_s, 8, lead, bins, frames, d_out, (hipStream_t)stream);
+  });
+}
+int smx_mel_spectrogram_f32(const smx_stft_config *sc, const smx_mel_config *mc, const float *x,
+                            int64_t lead, int64_t n, double power, float *out) {
+  return guarded([&] {
+    check_config(sc, "mel_spectrogram");
+    check_config(mc, "mel_spectrogram");
+    mel_spectrogram_host(*sc, *mc, x, 4, lead, n, power, out);
+  });
+}
+int smx_mel_spectrogram_f64(const smx_stft_config *sc, const smx_mel_config *mc, const double *x,
+                            int64_t lead, int64_t n, double power, double *out) {
+  return guarded([&] {
+    check_config(sc, "mel_spectrogram");
+    check_config(mc, "mel_spectrogram");
+    mel_spectrogram_host(*sc, *mc, x, 8, lead, n, power, out);
+  });
+}
+int smx_mel_spectrogram_f32_dev(const smx_stft_config *sc, const smx_mel_config *mc, const float *d_x,
+                                int64_t lead, int64_t n, int64_t x_stride, double power, float *d_out,
+                                void *stream) {
+  return guarded([&] {
+    check_config(sc, "mel_spectrogram");
+    check_config(mc, "mel_spectrogram");
+    mel_spectrogram_dev(*sc, *mc, d_x, 4, lead, n, x_stride, power, d_out, (hipStream_t)stream);
+  });
+}
+
+}  // extern "C"

@@ -1,0 +1,169 @@
+// Internal declarations shared by the host layer, the HIP kernels and the C ABI.
+// Nothing here is part of the public boundary (include/soundml_amd.h).
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <map>
+#include <mutex>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "../../include/soundml_amd.h"
+
+namespace smx {
+
+// ---- errors -------------------------------------------------------------
+// Invalid_argument of the reference (user-facing precondition, message verbatim)
+struct InvalidArgument : std::runtime_error {
+  using std::runtime_error::runtime_error;
+};
+// Failure of the reference (bookkeeping / runtime error)
+struct Failure : std::runtime_error {
+  using std::runtime_error::runtime_error;
+};
+
+std::string format(const char *fmt, ...) __attribute__((format(printf, 1, 2)));
+// OCaml's "%g" differs from C's only in corner cases we never print; keep C's.
+
+void set_last_error(const std::string &message);
+
+#define SMX_HIP_CHECK(expr)                                                              \
+  do {                                                                                   \
+    hipError_t err__ = (expr);                                                           \
+    if (err__ != hipSuccess)                                                             \
+      throw ::smx::Failure(::smx::format("%s: HIP error %d (%s) at %s:%d", #expr,        \
+                                         (int)err__, hipGetErrorString(err__), __FILE__, \
+                                         __LINE__));                                     \
+  } while (0)
+
+// ---- device-resident tables owned by a config, one set per HIP device ------
+struct DeviceBuffer {
+  void *ptr = nullptr;
+  size_t bytes = 0;
+};
+
+struct StftTables {
+  // analysis window, fft_size entries
+  double *window_f64 = nullptr;
+  float *window_f32 = nullptr;
+  // generic pow2 kernel: exp(-2 pi i j / N), j < N/2 ; direct DFT kernel: j < N
+  double2 *twiddle_f64 = nullptr;
+  float2 *twiddle_f32 = nullptr;
+  int64_t twiddle_len = 0;
+  // fast kernels (N = 2048 family): half-scaled window + split twiddle tables
+  float *fast_window = nullptr;    // 0.5 * window, f32
+  float2 *fast_w_m = nullptr;      // exp(-2 pi i j / M), j < M   (M = N/2)
+  float2 *fast_w_n = nullptr;      // exp(-2 pi i k / N), k <= M
+};
+
+}  // namespace smx
+
+// ---- opaque handle bodies (C ABI names) ----------------------------------------
+struct smx_stft_config {
+  int64_t fft_size = 0, win_length = 0, hop = 0;
+  int alignment = SMX_ALIGN_CENTERED, pad = SMX_PAD_REFLECT, scale = SMX_SCALE_NONE;
+  double pad_value = 0.0;
+  int window_kind = SMX_WINDOW_HANN;
+  std::vector<double> analysis_window;  // fft_size doubles (stft.ml:57-59)
+
+  int64_t bins() const { return fft_size / 2 + 1; }
+  int64_t left_width() const;   // stft.ml:132-140
+  int64_t right_width() const;  // stft.ml:141-142
+  int64_t frames(int64_t n) const;
+
+  // lazily built device tables, keyed by HIP device ordinal; internally locked
+  // (SURVEY 8b "Threading": a plan cache must be per-handle or locked).
+  const smx::StftTables &tables() const;
+  ~smx_stft_config();
+
+ private:
+  mutable std::mutex mutex_;
+  mutable std::map<int, smx::StftTables> tables_;
+};
+
+struct smx_mel_config {
+  double f_min = 0, f_max = 0;
+  int scale = SMX_MEL_SLANEY, norm = SMX_NORM_SLANEY;
+  int64_t n_mels = 0, sample_rate = 0, fft_size = 0;
+  std::vector<double> weights;  // [n_mels; bins] float64 (mel.ml:31-33)
+  int64_t bins() const { return fft_size / 2 + 1; }
+
+  struct Tables {
+    double *w_f64 = nullptr;   // [n_mels; bins]
+    float *w_f32 = nullptr;    // [n_mels_pad; k_pad] zero padded for the MFMA kernel
+    int64_t n_mels_pad = 0, k_pad = 0;
+    // banded form: first/last non-zero bin per mel row
+    int *band_lo = nullptr, *band_hi = nullptr;
+  };
+  const Tables &tables() const;
+  ~smx_mel_config();
+
+ private:
+  mutable std::mutex mutex_;
+  mutable std::map<int, Tables> tables_;
+};
+
+namespace smx {
+
+// ---- host logic (host_config.cpp) ----------------------------------------------
+void window_make(int kind, bool periodic, int64_t n, double *out);             // window.ml:374-405
+smx_stft_config *stft_config_create(int64_t fft_size, int64_t win_length, int64_t hop,
+                                    int alignment, int pad, double pad_value, int scale,
+                                    int window_kind, const double *custom_window);
+int64_t stft_first_complete(const smx_stft_config &c);                           // stft.ml:225-227
+int64_t stft_last_complete(const smx_stft_config &c, int64_t n);                 // stft.ml:229-235
+// source sample for signal-relative position q (may be <0 or >=n); -1 = constant pad
+int64_t source_index(const smx_stft_config &c, int64_t n, int64_t q);            // stft.ml:300-338
+smx_mel_config *mel_config_create(int64_t n_mels, int64_t sample_rate, int64_t fft_size,
+                                  double f_min, bool has_f_max, double f_max, int scale, int norm);
+double kaiser_beta(double att);                                                  // resample.ml:105-109
+double bessel_i0(double x);                                                      // resample.ml:128-139
+void design_lowpass(int64_t taps, double fc, double beta, double *h);
+
+// ---- kernel launchers ----------------------------------------------------------
+enum OutMode { OUT_COMPLEX = 0, OUT_POWER = 1 };
+
+struct StftJob {
+  const smx_stft_config *cfg = nullptr;
+  const void *x = nullptr;       // device, [lead; n] with x_stride
+  int in_bytes = 4;              // 4 = float32 audio, 8 = float64
+  int interior = SMX_INTERIOR_F32;
+  int64_t lead = 0, n = 0, x_stride = 0;
+  // frame p covers padded positions [p*hop, p*hop + fft), padded q <-> source q - left
+  int64_t left = 0;
+  int pad = SMX_PAD_REFLECT;     // applied to positions outside [0, n)
+  double pad_value = 0.0;
+  int64_t p0 = 0, count = 0;     // frames [p0, p0 + count)
+  OutMode mode = OUT_POWER;
+  double power = 2.0;
+  void *out = nullptr;           // device, [lead; bins; out_stride] (+ out_offset frames)
+  int64_t out_stride = 0, out_offset = 0;
+  hipStream_t stream = nullptr;
+};
+
+void launch_stft(const StftJob &job);             // dispatch: fast path or generic
+void launch_stft_generic(const StftJob &job);     // stft_generic.hip
+bool launch_stft_fast(const StftJob &job);        // stft_fast.hip; false = not eligible
+bool fast_path_disabled();                        // env SMX_DISABLE_FAST=1 (tests)
+
+struct MelJob {
+  const smx_mel_config *cfg = nullptr;
+  const void *s = nullptr;       // device [lead; bins; frames]
+  int elem_bytes = 4;
+  int64_t lead = 0, frames = 0;
+  void *out = nullptr;           // device [lead; n_mels; frames]
+  hipStream_t stream = nullptr;
+};
+void launch_mel_apply(const MelJob &job);         // mel.hip
+
+struct MelSpecJob {
+  StftJob stft;                  // out/out_stride unused; mode/power used
+  const smx_mel_config *mel = nullptr;
+  void *out = nullptr;           // device [lead; n_mels; count]
+};
+bool launch_mel_spectrogram_fused(const MelSpecJob &job);   // mel.hip; false = not eligible
+
+}  // namespace smx

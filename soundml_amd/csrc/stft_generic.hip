@@ -1,0 +1,258 @@
+// Generic STFT kernels: any fft_size, hop, alignment and pad mode, float32 or
+// float64 audio, float32 or float64 interior.  These are the completeness path
+// (reference semantics for every Stft.Config, stft.ml:356-364 + :670-674); the
+// tuned power-of-two kernels live in stft_fast.hip and the dispatcher prefers
+// them when the geometry is eligible.
+//
+// One workgroup computes FT consecutive frames of one signal:
+//   - power-of-two N: windowed samples are written bit-reversed into an LDS
+//     buffer and transformed in place by log2(N) radix-2 passes (twiddles from a
+//     float64-built table);
+//   - any other N (or N too large for LDS): direct DFT from an LDS copy of the
+//     windowed frame against an N-entry twiddle table, O(N^2) per frame.
+// Results for the FT frames are staged in LDS and written frames-fastest so
+// the [bins; frames] layout is stored in runs of FT elements.
+#include "smx_internal.hpp"
+
+namespace smx {
+namespace {
+
+template <typename T> struct Vec2;
+template <> struct Vec2<float> { using type = float2; };
+template <> struct Vec2<double> { using type = double2; };
+
+struct GenericArgs {
+  const void *x;
+  int64_t n, x_stride, lead;
+  int64_t fft, hop, left;
+  int pad;
+  double pad_value;
+  int64_t p0, count;
+  int mode;
+  double power;
+  void *out;
+  int64_t out_stride, out_offset, bins;
+  const void *window;
+  const void *twiddle;
+  int log2n;   // >= 0 for the power-of-two kernel
+  int ft;      // frames per workgroup
+};
+
+template <typename Tin>
+__device__ inline double fetch_sample(const Tin *x, int64_t n, int64_t s, int pad, double pad_value) {
+  if (s >= 0 && s < n) return (double)x[s];
+  if (pad == SMX_PAD_REFLECT) {  // stft.ml:300-305
+    if (n == 1) return (double)x[0];
+    const int64_t period = 2 * (n - 1);
+    int64_t m = s % period;
+    if (m < 0) m += period;
+    return (double)x[m < n ? m : period - m];
+  }
+  if (pad == SMX_PAD_EDGE) return (double)x[s < 0 ? 0 : n - 1];
+  return pad_value;
+}
+
+// |z|^p with the reference's rounding order (stft.ml:670-674): the spectrum is
+// rounded to the storage component type first, the magnitude is taken in the
+// real dtype, then squared / kept / raised.
+template <typename Tacc, typename Tout>
+__device__ inline Tout magnitude_pow(Tacc re, Tacc im, double power) {
+  if constexpr (sizeof(Tacc) == 4) {
+    const float p2 = re * re + im * im;
+    if (power == 2.0) return (Tout)p2;
+    if (power == 1.0) return (Tout)sqrtf(p2);
+    return (Tout)powf(p2, (float)(0.5 * power));
+  } else {
+    const Tout r = (Tout)re, i = (Tout)im;
+    const Tout m = (Tout)sqrt((double)r * (double)r + (double)i * (double)i);
+    if (power == 2.0) return m * m;
+    if (power == 1.0) return m;
+    return (Tout)pow((double)m, power);
+  }
+}
+
+template <typename Tacc>
+__device__ inline unsigned bitrev(unsigned v, int bits) {
+  return bits == 0 ? 0u : (__brev(v) >> (32 - bits));
+}
+
+// LDS layout: work[N] complex<Tacc> | stage[bins][FT+1] of Tout or complex<Tout>
+template <typename Tin, typename Tacc, typename Tout, bool POW2>
+__global__ void __launch_bounds__(256) stft_generic_kernel(GenericArgs a) {
+  using C = typename Vec2<Tacc>::type;
+  using CO = typename Vec2<Tout>::type;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  C *work = reinterpret_cast<C *>(smem);
+  const int64_t N = a.fft;
+  const int ft = a.ft;
+  const int64_t tiles = (a.count + ft - 1) / ft;
+  const int64_t clip = blockIdx.x / tiles;
+  const int64_t tile = blockIdx.x % tiles;
+  const Tin *x = reinterpret_cast<const Tin *>(a.x) + clip * a.x_stride;
+  const Tacc *window = reinterpret_cast<const Tacc *>(a.window);
+  const C *tw = reinterpret_cast<const C *>(a.twiddle);
+  const int64_t bins = a.bins;
+  const int tid = threadIdx.x;
+  // staging region after the work buffer
+  const size_t work_bytes = POW2 ? (size_t)N * sizeof(C) : (((size_t)N * sizeof(Tacc) + 15) / 16 * 16);
+  unsigned char *stage = smem + work_bytes;
+  const int sstride = ft + 1;
+
+  const int64_t f0 = tile * ft;
+  const int nf = (int)((a.count - f0) < ft ? (a.count - f0) : ft);
+  for (int f = 0; f < nf; ++f) {
+    const int64_t p = a.p0 + f0 + f;
+    const int64_t s0 = p * a.hop - a.left;
+    if constexpr (POW2) {
+      for (int64_t i = tid; i < N; i += blockDim.x) {
+        const Tacc v = (Tacc)(fetch_sample<Tin>(x, a.n, s0 + i, a.pad, a.pad_value)) * window[i];
+        C z;
+        z.x = v;
+        z.y = (Tacc)0;
+        work[bitrev<Tacc>((unsigned)i, a.log2n)] = z;
+      }
+      for (int64_t half = 1; half < N; half <<= 1) {
+        __syncthreads();
+        const int64_t tstep = (N >> 1) / half;
+        for (int64_t b = tid; b < (N >> 1); b += blockDim.x) {
+          const int64_t j = b & (half - 1);
+          const int64_t i0 = ((b - j) << 1) + j;
+          const int64_t i1 = i0 + half;
+          const C w = tw[j * tstep];
+          const C u = work[i0], v = work[i1];
+          C t;
+          t.x = w.x * v.x - w.y * v.y;
+          t.y = w.x * v.y + w.y * v.x;
+          C lo, hi;
+          lo.x = u.x + t.x; lo.y = u.y + t.y;
+          hi.x = u.x - t.x; hi.y = u.y - t.y;
+          work[i0] = lo;
+          work[i1] = hi;
+        }
+      }
+      __syncthreads();
+      for (int64_t k = tid; k < bins; k += blockDim.x) {
+        const C z = work[k];
+        if (a.mode == OUT_COMPLEX) {
+          CO o;
+          o.x = (Tout)z.x;
+          o.y = (Tout)z.y;
+          reinterpret_cast<CO *>(stage)[k * sstride + f] = o;
+        } else {
+          reinterpret_cast<Tout *>(stage)[k * sstride + f] = magnitude_pow<Tacc, Tout>(z.x, z.y, a.power);
+        }
+      }
+      __syncthreads();
+    } else {
+      Tacc *xw = reinterpret_cast<Tacc *>(smem);
+      for (int64_t i = tid; i < N; i += blockDim.x)
+        xw[i] = (Tacc)(fetch_sample<Tin>(x, a.n, s0 + i, a.pad, a.pad_value)) * window[i];
+      __syncthreads();
+      for (int64_t k = tid; k < bins; k += blockDim.x) {
+        Tacc re = 0, im = 0;
+        int64_t idx = 0;
+        for (int64_t i = 0; i < N; ++i) {
+          const C w = tw[idx];
+          re += xw[i] * w.x;
+          im += xw[i] * w.y;
+          idx += k;
+          if (idx >= N) idx -= N;
+        }
+        if (a.mode == OUT_COMPLEX) {
+          CO o;
+          o.x = (Tout)re;
+          o.y = (Tout)im;
+          reinterpret_cast<CO *>(stage)[k * sstride + f] = o;
+        } else {
+          reinterpret_cast<Tout *>(stage)[k * sstride + f] = magnitude_pow<Tacc, Tout>(re, im, a.power);
+        }
+      }
+      __syncthreads();
+    }
+  }
+  // flush: frames fastest
+  const int64_t total = bins * nf;
+  const int64_t obase = clip * bins * a.out_stride + a.out_offset + f0;
+  for (int64_t e = tid; e < total; e += blockDim.x) {
+    const int64_t k = e / nf;
+    const int f = (int)(e % nf);
+    if (a.mode == OUT_COMPLEX)
+      reinterpret_cast<CO *>(a.out)[obase + k * a.out_stride + f] =
+          reinterpret_cast<const CO *>(stage)[k * sstride + f];
+    else
+      reinterpret_cast<Tout *>(a.out)[obase + k * a.out_stride + f] =
+          reinterpret_cast<const Tout *>(stage)[k * sstride + f];
+  }
+}
+
+constexpr size_t kLdsLimit = 160 * 1024;
+
+template <typename Tin, typename Tacc, typename Tout>
+void launch_typed(const StftJob &job, GenericArgs a) {
+  const int64_t N = a.fft;
+  const bool pow2 = (N & (N - 1)) == 0;
+  const size_t elem_out = (job.mode == OUT_COMPLEX ? 2 : 1) * sizeof(Tout);
+  auto stage_bytes = [&](int ft) { return (size_t)a.bins * (size_t)(ft + 1) * elem_out + 16; };
+  size_t work_pow2 = (size_t)N * 2 * sizeof(Tacc);
+  size_t work_dft = ((size_t)N * sizeof(Tacc) + 15) / 16 * 16;
+  bool use_pow2 = pow2 && work_pow2 + stage_bytes(1) <= kLdsLimit;
+  size_t work = use_pow2 ? work_pow2 : work_dft;
+  if (work + stage_bytes(1) > kLdsLimit)
+    throw Failure(format("stft: an FFT of size %lld does not fit the on-chip buffers of this device path",
+                         (long long)N));
+  int ft = 16;
+  while (ft > 1 && work + stage_bytes(ft) > kLdsLimit / 2) ft >>= 1;   // keep 2 workgroups per CU
+  while (ft > 1 && work + stage_bytes(ft) > kLdsLimit) ft >>= 1;
+  a.ft = ft;
+  a.log2n = -1;
+  if (use_pow2) {
+    a.log2n = 0;
+    while ((int64_t(1) << a.log2n) < N) ++a.log2n;
+  }
+  const size_t lds = work + stage_bytes(ft);
+  const int64_t tiles = (a.count + ft - 1) / ft;
+  const int64_t blocks = a.lead * tiles;
+  if (blocks > 2147483647LL) throw Failure("stft: too many frame tiles for one launch");
+  auto kernel = use_pow2 ? stft_generic_kernel<Tin, Tacc, Tout, true> : stft_generic_kernel<Tin, Tacc, Tout, false>;
+  SMX_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kernel),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  hipLaunchKernelGGL(kernel, dim3((unsigned)blocks), dim3(256), lds, job.stream, a);
+  SMX_HIP_CHECK(hipGetLastError());
+}
+
+}  // namespace
+
+void launch_stft_generic(const StftJob &job) {
+  if (job.count <= 0 || job.lead <= 0) return;
+  const smx_stft_config &c = *job.cfg;
+  const StftTables &t = c.tables();
+  GenericArgs a{};
+  a.x = job.x;
+  a.n = job.n;
+  a.x_stride = job.x_stride;
+  a.lead = job.lead;
+  a.fft = c.fft_size;
+  a.hop = c.hop;
+  a.left = job.left;
+  a.pad = job.pad;
+  a.pad_value = job.pad_value;
+  a.p0 = job.p0;
+  a.count = job.count;
+  a.mode = (int)job.mode;
+  a.power = job.power;
+  a.out = job.out;
+  a.out_stride = job.out_stride;
+  a.out_offset = job.out_offset;
+  a.bins = c.bins();
+  const bool f64_interior = job.in_bytes == 8 || job.interior == SMX_INTERIOR_F64;
+  a.window = f64_interior ? (const void *)t.window_f64 : (const void *)t.window_f32;
+  a.twiddle = f64_interior ? (const void *)t.twiddle_f64 : (const void *)t.twiddle_f32;
+  if (job.in_bytes == 8)
+    launch_typed<double, double, double>(job, a);
+  else if (f64_interior)
+    launch_typed<float, double, float>(job, a);
+  else
+    launch_typed<float, float, float>(job, a);
+}
+
+}  // namespace smx

@@ -1,0 +1,130 @@
+// Device-resident tables owned by the configuration handles: the analysis
+// window, FFT twiddles and mel weights are built on the host in float64 (the
+// reference's own precision for these tables, stft.ml:57-59 / mel.ml:31-33),
+// rounded once where a kernel consumes float32, and uploaded lazily per HIP
+// device.  Access is serialised by the handle's mutex.
+#include <cmath>
+
+#include "smx_internal.hpp"
+
+namespace smx {
+namespace {
+
+template <typename T>
+T *upload(const std::vector<T> &host) {
+  T *dev = nullptr;
+  SMX_HIP_CHECK(hipMalloc((void **)&dev, host.size() * sizeof(T) + 16));
+  SMX_HIP_CHECK(hipMemcpy(dev, host.data(), host.size() * sizeof(T), hipMemcpyHostToDevice));
+  return dev;
+}
+
+bool is_pow2(int64_t n) { return n >= 1 && (n & (n - 1)) == 0; }
+
+}  // namespace
+}  // namespace smx
+
+const smx::StftTables &smx_stft_config::tables() const {
+  int device = 0;
+  SMX_HIP_CHECK(hipGetDevice(&device));
+  std::lock_guard<std::mutex> lock(mutex_);
+  auto it = tables_.find(device);
+  if (it != tables_.end()) return it->second;
+
+  smx::StftTables t;
+  const int64_t n = fft_size;
+  std::vector<float> w32((size_t)n);
+  for (int64_t i = 0; i < n; ++i) w32[(size_t)i] = (float)analysis_window[(size_t)i];
+  t.window_f64 = smx::upload(analysis_window);
+  t.window_f32 = smx::upload(w32);
+
+  // generic kernels: N twiddles exp(-2 pi i j / N) (the radix-2 passes read j < N/2,
+  // the direct DFT all N)
+  const int64_t tw = n;
+  std::vector<double2> t64((size_t)tw);
+  std::vector<float2> t32((size_t)tw);
+  for (int64_t j = 0; j < tw; ++j) {
+    const double a = -2.0 * M_PI * (double)j / (double)n;
+    t64[(size_t)j] = make_double2(std::cos(a), std::sin(a));
+    t32[(size_t)j] = make_float2((float)std::cos(a), (float)std::sin(a));
+  }
+  t.twiddle_f64 = smx::upload(t64);
+  t.twiddle_f32 = smx::upload(t32);
+  t.twiddle_len = tw;
+
+  // fast kernels (power-of-two N >= 64): half-scaled window and split tables
+  if (smx::is_pow2(n) && n >= 64) {
+    const int64_t m = n / 2;
+    std::vector<float> hw((size_t)n);
+    for (int64_t i = 0; i < n; ++i) hw[(size_t)i] = (float)(0.5 * analysis_window[(size_t)i]);
+    std::vector<float2> wm((size_t)m), wn((size_t)m + 1);
+    for (int64_t j = 0; j < m; ++j) {
+      const double a = -2.0 * M_PI * (double)j / (double)m;
+      wm[(size_t)j] = make_float2((float)std::cos(a), (float)std::sin(a));
+    }
+    for (int64_t k = 0; k <= m; ++k) {
+      const double a = -2.0 * M_PI * (double)k / (double)n;
+      wn[(size_t)k] = make_float2((float)std::cos(a), (float)std::sin(a));
+    }
+    t.fast_window = smx::upload(hw);
+    t.fast_w_m = smx::upload(wm);
+    t.fast_w_n = smx::upload(wn);
+  }
+  return tables_.emplace(device, t).first->second;
+}
+
+smx_stft_config::~smx_stft_config() {
+  for (auto &kv : tables_) {
+    smx::StftTables &t = kv.second;
+    (void)hipFree(t.window_f64);
+    (void)hipFree(t.window_f32);
+    (void)hipFree(t.twiddle_f64);
+    (void)hipFree(t.twiddle_f32);
+    (void)hipFree(t.fast_window);
+    (void)hipFree(t.fast_w_m);
+    (void)hipFree(t.fast_w_n);
+  }
+}
+
+const smx_mel_config::Tables &smx_mel_config::tables() const {
+  int device = 0;
+  SMX_HIP_CHECK(hipGetDevice(&device));
+  std::lock_guard<std::mutex> lock(mutex_);
+  auto it = tables_.find(device);
+  if (it != tables_.end()) return it->second;
+
+  Tables t;
+  const int64_t nb = bins();
+  t.w_f64 = smx::upload(weights);
+  // MFMA operand image: rows padded to a multiple of 32 mel bands, K (bins)
+  // padded to a multiple of 32, zero filled, float32.
+  t.n_mels_pad = (n_mels + 31) / 32 * 32;
+  t.k_pad = (nb + 31) / 32 * 32;
+  std::vector<float> w32((size_t)(t.n_mels_pad * t.k_pad), 0.0f);
+  std::vector<int> lo((size_t)t.n_mels_pad, 0), hi((size_t)t.n_mels_pad, 0);
+  for (int64_t m = 0; m < n_mels; ++m) {
+    int first = -1, last = -1;
+    for (int64_t b = 0; b < nb; ++b) {
+      const double w = weights[(size_t)(m * nb + b)];
+      w32[(size_t)(m * t.k_pad + b)] = (float)w;
+      if (w != 0.0) {
+        if (first < 0) first = (int)b;
+        last = (int)b;
+      }
+    }
+    lo[(size_t)m] = first < 0 ? 0 : first;
+    hi[(size_t)m] = last < 0 ? 0 : last + 1;
+  }
+  t.w_f32 = smx::upload(w32);
+  t.band_lo = smx::upload(lo);
+  t.band_hi = smx::upload(hi);
+  return tables_.emplace(device, t).first->second;
+}
+
+smx_mel_config::~smx_mel_config() {
+  for (auto &kv : tables_) {
+    (void)hipFree(kv.second.w_f64);
+    (void)hipFree(kv.second.w_f32);
+    (void)hipFree(kv.second.band_lo);
+    (void)hipFree(kv.second.band_hi);
+  }
+}

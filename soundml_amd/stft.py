@@ -1,0 +1,241 @@
+"""``Soundml.Stft`` (analysis half) on MI355X -- host-side mirror of the reference's
+module interface over the C ABI (reference: soundml/lib/stft.mli:211-250,
+435-471; stft.ml:48-691).  Same names, argument meaning and error behaviour:
+
+    c = Stft.Config.create(fft_size=2048, hop=512)
+    s = Stft.power_spectrum(c, x)            # [...; bins; frames], x's dtype
+    z = Stft.transform(c, x)                 # complex64 / complex128
+    z = Stft.transform_range(c, x, p0=, p1=) # frames [p0, p1)
+    k = Stft.Kernel.prepare(c, dtype, channels=, max_block=); k.step(chunk); k.flush()
+
+All arithmetic runs in the HIP kernels behind the C ABI; this file only maps
+tensors to pointers and return codes to exceptions.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional
+
+import numpy as np
+
+from . import _lib
+from ._lib import check, lib
+from ._tensor import Batch, out_ptr, prod
+
+
+class Config:
+    """``Stft.Config.t`` (stft.ml:48-129).  Immutable; owns the float64 analysis
+    window and (lazily, per device) its device tables."""
+
+    def __init__(self, handle, window_name):
+        self._h = handle
+        self._window_name = window_name
+
+    @staticmethod
+    def create(fft_size: int, window="hann", win_length: Optional[int] = None,
+               hop: Optional[int] = None, alignment: str = "centered", pad="reflect",
+               scale: str = "none") -> "Config":
+        """``Stft.Config.create ?window ?win_length ?hop ?alignment ?pad ?scale ~fft_size ()``
+        (stft.ml:61-111).  ``pad`` is "reflect", "edge" or ("constant", v);
+        ``window`` is a family name or a float64 table of ``win_length`` points."""
+        pad_value = 0.0
+        if isinstance(pad, tuple):
+            pad, pad_value = pad[0], float(pad[1])
+        custom = None
+        if isinstance(window, str):
+            if window not in _lib.WINDOW:
+                raise _lib.InvalidArgument("create: unknown window family %r" % window)
+            kind, name = _lib.WINDOW[window], window
+        else:
+            table = np.ascontiguousarray(np.asarray(window, dtype=np.float64))
+            if win_length is None:
+                win_length = int(table.shape[0])
+            if table.shape[0] != win_length:
+                raise _lib.InvalidArgument("create: custom window table must have win_length points")
+            custom, kind, name = table, _lib.WINDOW["custom"], "custom"
+        for value, table_, what in ((alignment, _lib.ALIGNMENT, "alignment"), (pad, _lib.PAD, "pad"),
+                                    (scale, _lib.SCALE, "scale")):
+            if value not in table_:
+                raise _lib.InvalidArgument("create: unknown %s %r" % (what, value))
+        handle = C.c_void_p()
+        check(lib.smx_stft_config_create(
+            int(fft_size), _lib.SMX_DEFAULT if win_length is None else int(win_length),
+            _lib.SMX_DEFAULT if hop is None else int(hop), _lib.ALIGNMENT[alignment], _lib.PAD[pad],
+            pad_value, _lib.SCALE[scale], kind,
+            None if custom is None else C.c_void_p(custom.ctypes.data), C.byref(handle)))
+        return Config(handle, name)
+
+    def __del__(self):
+        h, self._h = getattr(self, "_h", None), None
+        if h and lib is not None:
+            try:
+                lib.smx_stft_config_destroy(h)
+            except Exception:
+                pass
+
+    # accessors (stft.ml:113-127)
+    fft_size = property(lambda self: lib.smx_stft_config_fft_size(self._h))
+    hop = property(lambda self: lib.smx_stft_config_hop(self._h))
+    win_length = property(lambda self: lib.smx_stft_config_win_length(self._h))
+    bins = property(lambda self: lib.smx_stft_config_bins(self._h))
+    latency = property(lambda self: lib.smx_stft_config_latency(self._h))
+
+    @property
+    def analysis_window(self) -> np.ndarray:
+        out = np.empty(self.fft_size, dtype=np.float64)
+        check(lib.smx_stft_config_analysis_window(self._h, C.c_void_p(out.ctypes.data)))
+        return out
+
+
+def left_width(c: Config) -> int:
+    return lib.smx_stft_config_left_width(c._h)
+
+
+def right_width(c: Config) -> int:
+    return lib.smx_stft_config_right_width(c._h)
+
+
+def frames(c: Config, n: int) -> int:
+    """stft.ml:217-223."""
+    out = C.c_int64()
+    check(lib.smx_stft_frames(c._h, int(n), C.byref(out)))
+    return out.value
+
+
+def first_complete(c: Config) -> int:
+    out = C.c_int64()
+    check(lib.smx_stft_first_complete(c._h, C.byref(out)))
+    return out.value
+
+
+def last_complete(c: Config, n: int) -> int:
+    out = C.c_int64()
+    check(lib.smx_stft_last_complete(c._h, int(n), C.byref(out)))
+    return out.value
+
+
+def times(dtype, c: Config, sample_rate: int, n: int) -> np.ndarray:
+    """stft.ml:245-254."""
+    count = frames(c, n) if (sample_rate >= 1 and n >= 0) else 0
+    out = np.empty(max(count, 1), dtype=np.float64)
+    check(lib.smx_stft_times(c._h, int(sample_rate), int(n), C.c_void_p(out.ctypes.data)))
+    return out[:count].astype(dtype)
+
+
+def frequencies(dtype, c: Config, sample_rate: int) -> np.ndarray:
+    """stft.ml:256-261."""
+    out = np.empty(c.bins, dtype=np.float64)
+    check(lib.smx_stft_frequencies(c._h, int(sample_rate), C.c_void_p(out.ctypes.data)))
+    return out.astype(dtype)
+
+
+def _range(c: Config, x, p0, p1, power, op):
+    b = Batch(x, op)
+    n = b.shape[-1]
+    lead_shape = b.shape[:-1]
+    lead = prod(lead_shape)
+    total = frames(c, n)
+    if p0 is None:
+        p0, p1 = 0, total
+    complex_ = power is None
+    count = max(0, p1 - p0)
+    out = b.empty(lead_shape + (c.bins, count), complex_=complex_)
+    sfx = "f32" if b.bytes == 4 else "f64"
+    if b.device:
+        with b.device_guard():
+            if complex_:
+                fn = getattr(lib, "smx_stft_transform_range_%s_dev" % sfx)
+                check(fn(c._h, b.ptr(), lead, n, n, p0, p1, out_ptr(out), b.stream()))
+            else:
+                fn = getattr(lib, "smx_stft_power_range_%s_dev" % sfx)
+                check(fn(c._h, b.ptr(), lead, n, n, p0, p1, float(power), out_ptr(out), b.stream()))
+        return out
+    if complex_:
+        fn = getattr(lib, "smx_stft_transform_range_%s" % sfx)
+        check(fn(c._h, b.ptr(), lead, n, p0, p1, out_ptr(out)))
+    else:
+        if (p0, p1) != (0, total):
+            raise _lib.Failure("power_spectrum: frame ranges are a device-path feature")
+        fn = getattr(lib, "smx_stft_power_spectrum_%s" % sfx)
+        check(fn(c._h, b.ptr(), lead, n, float(power), out_ptr(out)))
+    return b.wrap(out)
+
+
+def transform(c: Config, x):
+    """``Stft.transform cdtype c x`` (stft.ml:632-650): [...; n] -> complex [...; bins; frames].
+    The complex storage follows the input's component width (``spectrum_witness``)."""
+    return _range(c, x, None, None, None, "transform")
+
+
+def transform_range(c: Config, x, p0: int, p1: int):
+    """``Stft.transform_range cdtype c ~p0 ~p1 x`` (stft.ml:652-666)."""
+    Batch(x, "transform_range")  # rank check first, as the reference does
+    return _range(c, x, int(p0), int(p1), None, "transform_range")
+
+
+def power_spectrum(c: Config, x, power: float = 2.0):
+    """``Stft.power_spectrum ?power c x`` (stft.ml:687-691): |STFT|^power in x's dtype."""
+    return _range(c, x, None, None, float(power), "power_spectrum")
+
+
+def power_range(c: Config, x, p0: int, p1: int, power: float = 2.0):
+    """Frames [p0, p1) of ``power_spectrum`` for device-resident audio: the seam
+    clip/frame-range sharding uses."""
+    return _range(c, x, int(p0), int(p1), float(power), "power_spectrum")
+
+
+class Kernel:
+    """``Stft.Kernel`` (stft.ml:597-622): streaming analysis with the carry held
+    in device memory.  Chunks are host arrays [channels; m]; ``step`` / ``flush``
+    return complex [channels; bins; k] or ``None``.  Mutable, single-owner."""
+
+    def __init__(self, handle, cfg, dtype, channels):
+        self._h, self._cfg, self._dtype, self._channels = handle, cfg, np.dtype(dtype), channels
+        bound = C.c_int64()
+        check(lib.smx_stft_kernel_frame_bound(self._h, C.byref(bound)))
+        self.frame_bound = bound.value
+
+    @staticmethod
+    def prepare(c: Config, dtype, channels: int, max_block: int) -> "Kernel":
+        handle = C.c_void_p()
+        dt = np.dtype(dtype)
+        check(lib.smx_stft_kernel_prepare(c._h, 8 if dt == np.float64 else 4, int(channels),
+                                          int(max_block), C.byref(handle)))
+        return Kernel(handle, c, np.float64 if dt == np.float64 else np.float32, int(channels))
+
+    def __del__(self):
+        h, self._h = getattr(self, "_h", None), None
+        if h and lib is not None:
+            try:
+                lib.smx_stft_kernel_destroy(h)
+            except Exception:
+                pass
+
+    def _emit(self, call, capacity):
+        cdt = np.complex128 if self._dtype == np.float64 else np.complex64
+        out = np.zeros((self._channels, self._cfg.bins, capacity), dtype=cdt)
+        emitted = C.c_int64()
+        check(call(C.c_void_p(out.ctypes.data), capacity, C.byref(emitted)))
+        if emitted.value == 0:
+            return None
+        return np.ascontiguousarray(out[:, :, :emitted.value])
+
+    def step(self, chunk):
+        a = np.asarray(chunk)
+        if a.ndim >= 1 and 0 in a.shape[:-1]:
+            raise _lib.InvalidArgument(
+                "step: cannot analyse a chunk with a zero-size leading axis (channels must be at least 1)")
+        a = np.ascontiguousarray(a.astype(self._dtype, copy=False)).reshape(self._channels, -1)
+        m = a.shape[-1]
+        cfg = self._cfg
+        capacity = (m + cfg.fft_size + left_width(cfg) + right_width(cfg)) // cfg.hop + 2
+        return self._emit(lambda o, cap, e: lib.smx_stft_kernel_step(
+            self._h, C.c_void_p(a.ctypes.data), m, o, cap, e), capacity)
+
+    def flush(self):
+        cfg = self._cfg
+        capacity = (2 * cfg.fft_size + left_width(cfg) + right_width(cfg)) // cfg.hop + 2
+        return self._emit(lambda o, cap, e: lib.smx_stft_kernel_flush(self._h, o, cap, e), capacity)
+
+    def reset(self):
+        check(lib.smx_stft_kernel_reset(self._h))

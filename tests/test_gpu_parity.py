@@ -1,0 +1,377 @@
+"""GPU parity tests proper (`-m gpu`): the HIP path, called through the C ABI,
+against (i) the reference's committed golden vectors, (ii) the CPU oracle on
+seeded inputs, (iii) the reference's structural laws (range tiling, leading-axis
+broadcast, streaming partition law) and (iv) size-independent properties at the
+BASELINE sizes.  Nothing here reads /root/reference.
+
+Tolerances
+  * float64 audio / float64 interior: the reference's own (rtol 1e-9, atol 1e-12;
+    float32 goldens rtol 1e-6, atol 1e-7 -- stft_goldens.ml:13-17, tutils.ml:80-86).
+  * float32 interior (the fast path): north_star's 1e-5 relative, evaluated as
+    |a - e| <= 1e-5 * max|e| + 1e-5 * |e| per signal (BASELINE.md "Parity gate").
+"""
+import numpy as np
+import pytest
+
+from conftest import (F32_ATOL, F32_RTOL, F64_ATOL, F64_RTOL, check_close, load_golden)
+from oracle import soundml_oracle as O
+
+import soundml_amd as S
+from soundml_amd import Fir, Mel, Stft
+
+pytestmark = pytest.mark.gpu
+
+FAST_RTOL = 1e-5
+
+
+def check_fast(actual, expected, msg=""):
+    """north_star tolerance: rtol 1e-5 plus atol 1e-5 * peak of the expected signal."""
+    a = np.asarray(actual, dtype=np.float64)
+    e = np.asarray(expected, dtype=np.float64)
+    assert a.shape == e.shape, (msg, a.shape, e.shape)
+    peak = np.max(np.abs(e)) if e.size else 0.0
+    tol = FAST_RTOL * peak + FAST_RTOL * np.abs(e)
+    bad = np.abs(a - e) > tol
+    assert not bad.any(), "%s: %d/%d outside 1e-5 (max err %.3g, peak %.3g)" % (
+        msg, int(bad.sum()), a.size, float(np.max(np.abs(a - e))), peak)
+
+
+@pytest.fixture(autouse=True)
+def _default_interior():
+    S.set_interior("float32")
+    yield
+    S.set_interior("float32")
+
+
+def _cfg(p, **kw):
+    return Stft.Config.create(fft_size=p["fft_size"], win_length=p.get("win_length"), hop=p["hop"],
+                              alignment=p["alignment"], **kw)
+
+
+STFT_FILES = ["fft16_hop4", "fft32_hop7", "fft64_hop16", "fft32_hop8_win20"]
+
+
+@pytest.mark.parametrize("fname", STFT_FILES)
+def test_stft_goldens_float64(fname):
+    """float64 audio: the reference's float64 interior, at the reference's tolerance."""
+    for case in load_golden("stft", fname)["cases"]:
+        p = case["params"]
+        if p["dtype"] != "float64":
+            continue
+        power = {"magnitude": 1.0, "power": 2.0}[p["kind"]]
+        got = Stft.power_spectrum(_cfg(p), O.lcg_signal(p["length"]), power)
+        assert got.dtype == np.float64
+        check_close(got, case["values"], case["shape"], F64_RTOL, F64_ATOL, case["name"])
+
+
+@pytest.mark.parametrize("fname", STFT_FILES)
+def test_stft_goldens_float32_strict_interior(fname):
+    """float32 audio with the float64 interior: the reference's float32 tolerance."""
+    S.set_interior("float64")
+    for case in load_golden("stft", fname)["cases"]:
+        p = case["params"]
+        if p["dtype"] != "float32":
+            continue
+        power = {"magnitude": 1.0, "power": 2.0}[p["kind"]]
+        x = O.lcg_signal(p["length"]).astype(np.float32)
+        got = Stft.power_spectrum(_cfg(p), x, power)
+        assert got.dtype == np.float32
+        check_close(got, case["values"], case["shape"], F32_RTOL, F32_ATOL, case["name"])
+        if power == 1.0:   # complex64 witness leg (stft_goldens.ml:88-95)
+            z = Stft.transform(_cfg(p), x)
+            assert z.dtype == np.complex64
+            check_close(np.abs(z).astype(np.float32), case["values"], case["shape"], F32_RTOL, F32_ATOL,
+                        case["name"] + "/complex64-witness")
+
+
+@pytest.mark.parametrize("fname", STFT_FILES)
+def test_stft_goldens_float32_fast_interior(fname):
+    """float32 audio, float32 interior (documented deviation): north_star's 1e-5."""
+    for case in load_golden("stft", fname)["cases"]:
+        p = case["params"]
+        if p["dtype"] != "float32":
+            continue
+        power = {"magnitude": 1.0, "power": 2.0}[p["kind"]]
+        got = Stft.power_spectrum(_cfg(p), O.lcg_signal(p["length"]).astype(np.float32), power)
+        check_fast(got, np.asarray(case["values"]).reshape(case["shape"]), case["name"])
+
+
+def test_sign_convention():
+    for case in load_golden("stft", "complex_fft16_hop4")["cases"]:
+        p = case["params"]
+        z = Stft.transform(_cfg(p), O.lcg_signal(p["length"]))
+        assert z.dtype == np.complex128
+        part = z.real if p["kind"] == "real" else z.imag
+        check_close(part, case["values"], case["shape"], F64_RTOL, F64_ATOL, case["name"])
+
+
+def _mel_cfg(p):
+    return Mel.Config.create(n_mels=p["n_mels"], sample_rate=p["sample_rate"], fft_size=p["fft_size"],
+                             f_min=p["f_min"], f_max=p["f_max"], scale=p["scale"], norm=p["norm"])
+
+
+def test_mel_spectrogram_goldens():
+    for case in load_golden("mel", "mel_spectrogram")["cases"]:
+        p = case["params"]
+        sc = Stft.Config.create(fft_size=p["fft_size"], hop=p["hop"], alignment=p["alignment"])
+        mc = _mel_cfg(p)
+        sig = O.lcg_signal(p["length"], seed=20260803, envelope=p["envelope"])
+        want = np.asarray(case["values"]).reshape(case["shape"])
+        if p["dtype"] == "float64":
+            got = S.mel_spectrogram(sc, mc, sig, p["power"])
+            check_close(got, want, case["shape"], F64_RTOL, F64_ATOL, case["name"])
+        else:
+            x = sig.astype(np.float32)
+            check_fast(S.mel_spectrogram(sc, mc, x, p["power"]), want, case["name"] + "/fast")
+            S.set_interior("float64")
+            check_close(S.mel_spectrogram(sc, mc, x, p["power"]), want, case["shape"], F32_RTOL, F32_ATOL,
+                        case["name"] + "/strict")
+            S.set_interior("float32")
+
+
+# ---- against the oracle at the benchmark geometries -------------------------------------------
+
+@pytest.mark.parametrize("fft,hop,n,lead", [
+    (2048, 512, 480000, 3),     # C2 geometry, 3 clips
+    (2048, 512, 5000, 5),       # short clips: every frame touches a border
+    (2048, 512, 16 * 512 * 3 + 17, 2),
+    (1024, 256, 44100, 2),      # C1 geometry (1 s)
+    (2048, 500, 30000, 2),      # hop not a multiple of 4 (8-byte aligned loads still hold)
+    (2048, 511, 30000, 2),      # odd hop: unaligned load variant
+    (512, 128, 20000, 2),
+    (4096, 1024, 50000, 1),
+])
+@pytest.mark.parametrize("power", [2.0, 1.0])
+def test_power_spectrum_vs_oracle(fft, hop, n, lead, power):
+    rng = np.random.default_rng(fft + hop + n)
+    x = rng.uniform(-1, 1, size=(lead, n)).astype(np.float32)
+    c = Stft.Config.create(fft_size=fft, hop=hop)
+    got = Stft.power_spectrum(c, x, power)
+    want = O.power_spectrum(O.stft_config(fft, hop=hop), x, power)
+    assert got.shape == want.shape and got.dtype == np.float32
+    for i in range(lead):
+        check_fast(got[i], want[i], "clip %d" % i)
+
+
+@pytest.mark.parametrize("alignment", ["centered", "left", "right"])
+@pytest.mark.parametrize("pad", ["reflect", "edge", ("constant", 0.25)])
+@pytest.mark.parametrize("fft,hop", [(2048, 512), (64, 16), (16, 20), (31, 5)])
+def test_alignment_and_pad_modes(alignment, pad, fft, hop):
+    rng = np.random.default_rng(11)
+    n = 3 * fft + 77
+    x64 = rng.standard_normal((2, n))
+    c = Stft.Config.create(fft_size=fft, hop=hop, alignment=alignment, pad=pad)
+    if isinstance(pad, tuple):
+        o = O.stft_config(fft, hop=hop, alignment=alignment, pad=pad[0], pad_value=pad[1])
+    else:
+        o = O.stft_config(fft, hop=hop, alignment=alignment, pad=pad)
+    z = Stft.transform(c, x64)
+    want = O.transform(o, x64)
+    assert z.shape == want.shape
+    np.testing.assert_allclose(z, want, rtol=1e-9, atol=1e-10)
+    x32 = x64.astype(np.float32)
+    got = Stft.power_spectrum(c, x32)
+    for i in range(2):
+        check_fast(got[i], O.power_spectrum(o, x32)[i], "f32 clip %d" % i)
+
+
+@pytest.mark.parametrize("n", [1, 2, 7, 1023, 1024, 1025, 2047, 2048, 2049])
+def test_short_signals(n):
+    """Multi-reflection borders are valid for any n >= 1 (stft.ml:300-305)."""
+    rng = np.random.default_rng(n)
+    x = rng.standard_normal(n)
+    for fft, hop in ((2048, 512), (16, 4)):
+        c = Stft.Config.create(fft_size=fft, hop=hop)
+        o = O.stft_config(fft, hop=hop)
+        assert Stft.frames(c, n) == O.frames(o, n)
+        np.testing.assert_allclose(Stft.transform(c, x), O.transform(o, x), rtol=1e-9, atol=1e-10)
+        check_fast(Stft.power_spectrum(c, x.astype(np.float32)), O.power_spectrum(o, x.astype(np.float32)),
+                   "n=%d fft=%d" % (n, fft))
+
+
+def test_scale_and_win_length():
+    rng = np.random.default_rng(5)
+    x = rng.standard_normal((2, 9000)).astype(np.float32)
+    for scale in ("magnitude", "psd"):
+        c = Stft.Config.create(fft_size=2048, hop=512, win_length=1200, scale=scale)
+        o = O.stft_config(2048, hop=512, win_length=1200, scale=scale)
+        got, want = Stft.power_spectrum(c, x), O.power_spectrum(o, x)
+        for i in range(2):
+            check_fast(got[i], want[i], scale)
+
+
+# ---- structural laws of the reference, now on the HIP path ---------------------------------------
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+@pytest.mark.parametrize("fft,hop,n", [(64, 16, 2000), (2048, 512, 20000)])
+def test_transform_range_tiles_exactly(dtype, fft, hop, n):
+    """stft_grid.ml:32-73: adjacent ranges reassemble the full transform bit for bit."""
+    x = O.lcg_signal(n).astype(dtype)
+    c = Stft.Config.create(fft_size=fft, hop=hop)
+    full = Stft.transform(c, x)
+    total = Stft.frames(c, n)
+    cuts = [0, 1, 7, 8, total // 2, total - 1, total]
+    parts = [Stft.transform_range(c, x, a, b) for a, b in zip(cuts[:-1], cuts[1:])]
+    assert np.array_equal(np.concatenate(parts, axis=-1), full)
+
+
+@pytest.mark.parametrize("fft,hop", [(64, 16), (2048, 512)])
+def test_leading_axes_broadcast_is_per_slice(fft, hop):
+    """stft_grid.ml:180-205: a batch is exactly the stack of its slices."""
+    rng = np.random.default_rng(3)
+    x = rng.uniform(-1, 1, size=(2, 3, 4 * fft + 5)).astype(np.float32)
+    c = Stft.Config.create(fft_size=fft, hop=hop)
+    full = Stft.power_spectrum(c, x)
+    assert full.shape[:2] == (2, 3)
+    for i in range(2):
+        for j in range(3):
+            assert np.array_equal(full[i, j], Stft.power_spectrum(c, x[i, j]))
+
+
+def test_power_range_device_tiles_exactly():
+    """The sharding seam: frame ranges of device-resident audio reassemble exactly."""
+    import torch
+    x = torch.rand(3, 100000, device="cuda") * 2 - 1
+    c = Stft.Config.create(fft_size=2048, hop=512)
+    full = Stft.power_spectrum(c, x)
+    total = Stft.frames(c, x.shape[-1])
+    cuts = [0, 16, 33, 100, total]
+    parts = [Stft.power_range(c, x, a, b) for a, b in zip(cuts[:-1], cuts[1:])]
+    assert torch.equal(torch.cat(parts, dim=-1), full)
+    # device path == host path, bit for bit
+    assert np.array_equal(full.cpu().numpy(), Stft.power_spectrum(c, x.cpu().numpy()))
+
+
+@pytest.mark.parametrize("alignment", ["centered", "left", "right"])
+@pytest.mark.parametrize("pad", ["reflect", "edge", ("constant", 0.5)])
+@pytest.mark.parametrize("fft,hop", [(16, 4), (32, 7), (16, 20)])
+def test_streaming_partition_law(alignment, pad, fft, hop):
+    """stft_law.ml:79-164: every chunking of the stream equals the offline transform, exactly."""
+    rng = np.random.default_rng(fft * 7 + hop)
+    c = Stft.Config.create(fft_size=fft, hop=hop, alignment=alignment, pad=pad)
+    for n in (1, 5, fft // 2, fft // 2 + 1, 97, 200):
+        x = rng.standard_normal((2, n))
+        want = Stft.transform(c, x)
+        for trial in range(3):
+            k = Stft.Kernel.prepare(c, np.float64, channels=2, max_block=max(1, n))
+            parts, pos = [], 0
+            while pos < n:
+                m = min(int(rng.integers(0, 9)) if trial else 1, n - pos)
+                out = k.step(x[:, pos:pos + m])
+                pos += m
+                if out is not None:
+                    parts.append(out)
+            out = k.flush()
+            if out is not None:
+                parts.append(out)
+            got = np.concatenate(parts, axis=-1) if parts else np.zeros((2, c.bins, 0), np.complex128)
+            assert got.shape == want.shape, (n, trial, got.shape, want.shape)
+            assert np.array_equal(got, want), (n, trial)
+            with pytest.raises(S.InvalidArgument, match="step: cannot feed a drained kernel"):
+                k.step(x[:, :1])
+            k.reset()
+
+
+def test_streaming_2048_float32():
+    rng = np.random.default_rng(9)
+    x = rng.uniform(-1, 1, size=(2, 30000)).astype(np.float32)
+    c = Stft.Config.create(fft_size=2048, hop=512)
+    want = Stft.transform(c, x)
+    k = Stft.Kernel.prepare(c, np.float32, channels=2, max_block=4096)
+    parts = [k.step(x[:, i:i + 4096]) for i in range(0, 30000, 4096)] + [k.flush()]
+    got = np.concatenate([p for p in parts if p is not None], axis=-1)
+    assert np.array_equal(got, want)
+
+
+# ---- Mel -------------------------------------------------------------------------------------------
+
+@pytest.mark.parametrize("n_mels,sr,fft,frames,lead", [(128, 48000, 2048, 938, 2), (40, 22050, 512, 77, 3),
+                                                        (13, 16000, 128, 5, 1), (128, 48000, 2048, 1, 1)])
+def test_mel_apply_vs_oracle(n_mels, sr, fft, frames, lead):
+    rng = np.random.default_rng(n_mels + frames)
+    mc = Mel.Config.create(n_mels=n_mels, sample_rate=sr, fft_size=fft)
+    oc = O.mel_config(n_mels, sr, fft)
+    s64 = rng.uniform(0, 4, size=(lead, fft // 2 + 1, frames))
+    np.testing.assert_allclose(Mel.apply(mc, s64), O.mel_apply(oc, s64), rtol=1e-12, atol=1e-14)
+    s32 = s64.astype(np.float32)
+    got, want = Mel.apply(mc, s32), O.mel_apply(oc, s32)
+    assert got.dtype == np.float32 and got.shape == (lead, n_mels, frames)
+    for i in range(lead):
+        check_fast(got[i], want[i], "mel clip %d" % i)
+    # broadcast == per slice, exactly (mel_props.ml:136-155)
+    assert np.array_equal(got[0], Mel.apply(mc, s32[0]))
+
+
+def test_mel_spectrogram_is_the_composition():
+    """mel_props.ml:183-194: mel_spectrogram = apply . power_spectrum."""
+    rng = np.random.default_rng(21)
+    x = rng.uniform(-1, 1, size=(2, 48000)).astype(np.float32)
+    sc = Stft.Config.create(fft_size=2048, hop=512)
+    mc = Mel.Config.create(n_mels=128, sample_rate=48000, fft_size=2048)
+    got = S.mel_spectrogram(sc, mc, x)
+    comp = Mel.apply(mc, Stft.power_spectrum(sc, x))
+    want = O.mel_spectrogram(O.stft_config(2048, hop=512), O.mel_config(128, 48000, 2048), x)
+    for i in range(2):
+        check_fast(got[i], want[i], "mel_spectrogram")
+        check_fast(comp[i], want[i], "composition")
+
+
+# ---- FIR ---------------------------------------------------------------------------------------------
+
+@pytest.mark.parametrize("taps,n,ch", [(63, 5000, 2), (1, 100, 1), (8192, 60000, 2), (1000, 1, 1), (257, 16384 * 3, 3)])
+def test_fir_vs_oracle(taps, n, ch):
+    rng = np.random.default_rng(taps + n)
+    h = Fir.design_lowpass(taps, 0.25, 80.0)
+    x = rng.uniform(-1, 1, size=(ch, n)).astype(np.float32)
+    got = Fir.apply(Fir.Plan.create(h), x)
+    want = O.fir_filter(h, x)
+    assert got.shape == want.shape and got.dtype == np.float32
+    for i in range(ch):
+        check_fast(got[i], want[i], "fir")
+
+
+def test_fir_known_answers():
+    h = Fir.design_lowpass(255, 0.3, 70.0)
+    p = Fir.Plan.create(h)
+    n = 40000
+    imp = np.zeros((1, n), np.float32)
+    imp[0, 0] = 1.0
+    y = Fir.apply(p, imp)
+    np.testing.assert_allclose(y[0, :255], h, rtol=0, atol=2e-7)        # impulse -> taps
+    np.testing.assert_allclose(y[0, 255:], 0, rtol=0, atol=2e-7)
+    step = np.ones((1, n), np.float32)
+    ys = Fir.apply(p, step)
+    np.testing.assert_allclose(ys[0, 254:], 1.0, rtol=0, atol=2e-6)     # unit DC gain after the transient
+    np.testing.assert_allclose(ys[0, :255], np.cumsum(h), rtol=0, atol=2e-6)
+
+
+# ---- BASELINE sizes: size-independent properties -------------------------------------------------------
+
+def test_c2_full_size_properties():
+    """C2: 256 x 10 s x 48 kHz.  Checked without a full-size oracle: (a) Parseval per frame
+    for interior frames of a rectangular window, (b) linearity of the complex transform,
+    (c) oracle parity on the first/last two frames and an interior tile of 3 clips."""
+    import torch
+    torch.manual_seed(42)
+    lead, n = 256, 480000
+    x = torch.rand(lead, n, device="cuda") * 2 - 1
+    c = Stft.Config.create(fft_size=2048, hop=512)
+    p = Stft.power_spectrum(c, x)
+    total = Stft.frames(c, n)
+    assert tuple(p.shape) == (lead, 1025, total) and total == 938
+    assert torch.isfinite(p).all()
+    o = O.stft_config(2048, hop=512)
+    for clip in (0, 100, 255):
+        xc = x[clip].cpu().numpy()
+        for a, b in ((0, 2), (total - 2, total), (400, 416)):
+            want = np.abs(O.transform_range(o, xc, a, b, np.complex128)) ** 2
+            check_fast(p[clip, :, a:b].cpu().numpy(), want, "C2 clip %d frames %d:%d" % (clip, a, b))
+    # Parseval with a rectangular window: sum_k c_k |X_k|^2 = N * sum x^2 for interior frames
+    cr = Stft.Config.create(fft_size=2048, hop=512, window="rectangular")
+    pr = Stft.power_range(cr, x[:8], 2, 34)
+    wts = torch.full((1025,), 2.0, device="cuda")
+    wts[0] = wts[1024] = 1.0
+    lhs = (pr * wts[None, :, None]).sum(dim=1)
+    fr = x[:8].unfold(-1, 2048, 512)[:, 0:32, :]
+    rhs = 2048.0 * (fr.double() ** 2).sum(dim=-1)
+    assert torch.allclose(lhs.double(), rhs, rtol=2e-5)

@@ -1,0 +1,232 @@
+"""CPU-side tests of the product's host layer (no GPU needed): the C-ABI library
+loads and exports every symbol include/soundml_amd.h declares, and the host
+logic behind it (Config validation with the reference's messages, window tables,
+frame grid, coordinates, mel filterbank, FIR design) matches the reference's
+golden vectors and the oracle.  No compute entry point is called here."""
+import os
+import re
+
+import numpy as np
+import pytest
+
+from conftest import (F32_ATOL, F32_RTOL, F64_ATOL, F64_RTOL, ROOT, check_close, load_golden)
+from oracle import soundml_oracle as O
+
+import soundml_amd as S
+from soundml_amd import Fir, Mel, Stft, Window
+
+
+def test_library_exports_every_declared_symbol():
+    header = open(os.path.join(ROOT, "include", "soundml_amd.h")).read()
+    header = re.sub(r"/\*.*?\*/", "", header, flags=re.S)
+    declared = set(re.findall(r"\b(smx_[a-z0-9_]+)\s*\(", header))
+    assert len(declared) > 50
+    import ctypes
+    lib = ctypes.CDLL(S.LIB_PATH)
+    missing = [name for name in sorted(declared) if not hasattr(lib, name)]
+    assert not missing, missing
+    # the ctypes binding covers the same set
+    from soundml_amd import _lib
+    assert set(_lib.SIGNATURES) == declared
+
+
+def test_no_cpu_fallback_without_device():
+    if S.device_count() > 0:
+        pytest.skip("a HIP device is visible")
+    c = Stft.Config.create(fft_size=64)
+    with pytest.raises(S.Failure, match="no HIP device"):
+        Stft.power_spectrum(c, np.zeros(256, np.float32))
+    with pytest.raises(S.Failure, match="no HIP device"):
+        Mel.apply(Mel.Config.create(n_mels=8, sample_rate=16000, fft_size=64), np.zeros((33, 4), np.float32))
+
+
+def test_product_does_not_reference_the_oracle():
+    pkg = os.path.join(ROOT, "soundml_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".cpp", ".hip", ".hpp", ".h")):
+                text = open(os.path.join(dirpath, f)).read().lower()
+                assert "oracle" not in text, (dirpath, f)
+
+
+# ---- Config validation: messages verbatim (stft.ml:61-84, stft_law.ml:187-201) ---------------
+@pytest.mark.parametrize("kwargs,message", [
+    (dict(fft_size=0), "create: cannot use an FFT of size 0 (fft_size must be at least 1)"),
+    (dict(fft_size=16, win_length=17),
+     "create: cannot use a 17-point window with an FFT of size 16 (win_length must lie in [1, fft_size])"),
+    (dict(fft_size=16, win_length=0),
+     "create: cannot use a 0-point window with an FFT of size 16 (win_length must lie in [1, fft_size])"),
+    (dict(fft_size=16, hop=0), "create: cannot advance frames by 0 samples (hop must be at least 1)"),
+])
+def test_stft_config_messages(kwargs, message):
+    with pytest.raises(S.InvalidArgument) as e:
+        Stft.Config.create(**kwargs)
+    assert str(e.value) == message
+    with pytest.raises(ValueError) as e2:          # the oracle raises the same text
+        O.stft_config(**kwargs)
+    assert str(e2.value) == message
+
+
+def test_stft_config_defaults():
+    c = Stft.Config.create(fft_size=2048)
+    assert (c.fft_size, c.win_length, c.hop, c.bins) == (2048, 2048, 512, 1025)
+    assert Stft.Config.create(fft_size=3).hop == 1
+
+
+@pytest.mark.parametrize("alignment", ["centered", "left", "right"])
+@pytest.mark.parametrize("fft,hop", [(16, 4), (32, 7), (64, 16), (2048, 512), (1024, 256), (16, 20), (31, 5)])
+def test_grid_matches_oracle(alignment, fft, hop):
+    c = Stft.Config.create(fft_size=fft, hop=hop, alignment=alignment)
+    o = O.stft_config(fft, hop=hop, alignment=alignment)
+    assert Stft.left_width(c) == O.left_width(o) and Stft.right_width(c) == O.right_width(o)
+    assert Stft.first_complete(c) == O.first_complete(o)
+    for n in [0, 1, 2, fft // 2, fft - 1, fft, fft + 1, 127, 128, 1000, 441000, 480000, 1440000]:
+        assert Stft.frames(c, n) == O.frames(o, n), n
+        assert Stft.last_complete(c, n) == O.last_complete(o, n), n
+    with pytest.raises(S.InvalidArgument, match="frames: cannot analyse a signal of length -1"):
+        Stft.frames(c, -1)
+
+
+def test_baseline_frame_counts():
+    """C1 1723 frames, C2 938, C5 2813."""
+    assert Stft.frames(Stft.Config.create(fft_size=1024, hop=256), 441000) == 1723
+    c = Stft.Config.create(fft_size=2048, hop=512)
+    assert Stft.frames(c, 480000) == 938 and Stft.frames(c, 1440000) == 2813
+
+
+def test_coordinates_goldens():
+    for case in load_golden("stft", "coordinates")["cases"]:
+        p = case["params"]
+        if p["kind"] == "frequencies":
+            c = Stft.Config.create(fft_size=p["fft_size"], hop=p["hop"])
+            got = Stft.frequencies(np.float64, c, p["sample_rate"])
+            got32 = Stft.frequencies(np.float32, c, p["sample_rate"])
+        else:
+            c = Stft.Config.create(fft_size=p["fft_size"], hop=p["hop"], alignment=p["alignment"])
+            got = Stft.times(np.float64, c, p["sample_rate"], p["length"])
+            got32 = Stft.times(np.float32, c, p["sample_rate"], p["length"])
+        check_close(got, case["values"], case["shape"], msg=case["name"])
+        check_close(got32, case["values"], case["shape"], F32_RTOL, F32_ATOL, case["name"] + "/float32")
+    c = Stft.Config.create(fft_size=16)
+    with pytest.raises(S.InvalidArgument, match="times: cannot use a sample rate of 0 Hz"):
+        Stft.times(np.float64, c, 0, 10)
+
+
+@pytest.mark.parametrize("family", ["hann", "hamming", "blackman", "rectangular"])
+def test_window_goldens(family):
+    for case in load_golden("window", family)["cases"]:
+        p = case["params"]
+        got = Window.make(np.float64, p["window"], p["n"], periodic=p["periodic"])
+        check_close(got, case["values"], case["shape"], msg=case["name"])
+        assert np.array_equal(got, O.window(p["window"], p["n"], p["periodic"]))   # bit-identical to the oracle
+        check_close(Window.make(np.float32, p["window"], p["n"], periodic=p["periodic"]), case["values"],
+                    case["shape"], F32_RTOL, F32_ATOL, case["name"] + "/float32")
+    with pytest.raises(S.InvalidArgument, match="make: cannot make a 0-point window"):
+        Window.make(np.float64, family, 0)
+
+
+@pytest.mark.parametrize("scale", ["none", "magnitude", "psd"])
+@pytest.mark.parametrize("fft,win", [(2048, 2048), (32, 20), (64, 1), (33, 32)])
+def test_analysis_window_matches_oracle(scale, fft, win):
+    c = Stft.Config.create(fft_size=fft, win_length=win, scale=scale)
+    o = O.stft_config(fft, win_length=win, scale=scale)
+    np.testing.assert_allclose(c.analysis_window, o.analysis_window, rtol=1e-14, atol=1e-300)
+
+
+def _mel_kwargs(p):
+    return dict(n_mels=p["n_mels"], sample_rate=p["sample_rate"], fft_size=p["fft_size"],
+                f_min=p["f_min"], f_max=p["f_max"], scale=p["scale"], norm=p["norm"])
+
+
+def test_mel_filterbank_goldens():
+    for case in load_golden("mel", "filterbank")["cases"]:
+        m = Mel.Config.create(**_mel_kwargs(case["params"]))
+        w = Mel.filterbank(np.float64, m)
+        check_close(w, case["values"], case["shape"], F64_RTOL, F64_ATOL, case["name"])
+        check_close(Mel.filterbank(np.float32, m), case["values"], case["shape"], F32_RTOL, F32_ATOL,
+                    case["name"] + "/float32")
+        np.testing.assert_allclose(w, O.mel_config(**_mel_kwargs(case["params"])).weights, rtol=1e-13, atol=0)
+
+
+@pytest.mark.parametrize("kwargs,message", [
+    (dict(n_mels=0, sample_rate=22050, fft_size=512), "create: cannot build 0 mel bands (n_mels must be at least 1)"),
+    (dict(n_mels=8, sample_rate=0, fft_size=512),
+     "create: cannot use a sample rate of 0 Hz (sample_rate must be at least 1)"),
+    (dict(n_mels=8, sample_rate=22050, fft_size=0), "create: cannot use an FFT of size 0 (fft_size must be at least 1)"),
+    (dict(n_mels=8, sample_rate=22050, fft_size=512, f_min=-1.0),
+     "create: cannot start the filterbank at -1 Hz (f_min must be finite and non-negative)"),
+    (dict(n_mels=8, sample_rate=22050, fft_size=512, f_min=100.0, f_max=50.0),
+     "create: cannot span [100, 50] Hz (f_max must be finite and greater than f_min)"),
+    (dict(n_mels=8, sample_rate=16000, fft_size=512, f_max=8000.5),
+     "create: cannot extend the filterbank to 8000.5 Hz at a sample rate of 16000 Hz (f_max must not exceed "
+     "the Nyquist frequency 8000)"),
+    (dict(n_mels=128, sample_rate=22050, fft_size=64),
+     "create: cannot support 128 mel bands with an FFT of size 64 (at least one filter spans no FFT bin; "
+     "raise fft_size or lower n_mels)"),
+])
+def test_mel_config_messages(kwargs, message):
+    with pytest.raises(S.InvalidArgument) as e:
+        Mel.Config.create(**kwargs)
+    assert str(e.value) == message
+    with pytest.raises(ValueError) as e2:
+        O.mel_config(**kwargs)
+    assert str(e2.value) == message
+
+
+def test_mel_apply_shape_errors():
+    m = Mel.Config.create(n_mels=8, sample_rate=16000, fft_size=64)
+    with pytest.raises(S.InvalidArgument) as e:
+        Mel.apply(m, np.zeros(5, np.float32))
+    assert str(e.value) == "apply: cannot project a rank-1 tensor (the mel projection needs [...; bins; frames])"
+    with pytest.raises(S.InvalidArgument) as e:
+        Mel.apply(m, np.zeros((32, 4), np.float32))
+    assert str(e.value) == ("apply: cannot project 32 frequency bins through a filterbank built for an FFT "
+                            "of size 64 (33 bins)")
+    out = Mel.apply(m, np.zeros((3, 33, 0), np.float32))      # empty: zeros, no device needed (mel.ml:220-226)
+    assert out.shape == (3, 8, 0) and out.dtype == np.float32
+
+
+def test_mel_spectrogram_fft_size_check():
+    sc = Stft.Config.create(fft_size=512)
+    mc = Mel.Config.create(n_mels=8, sample_rate=16000, fft_size=256)
+    with pytest.raises(S.InvalidArgument) as e:
+        S.mel_spectrogram(sc, mc, np.zeros(1000, np.float32))
+    assert str(e.value) == ("mel_spectrogram: cannot project a 512-point STFT through a filterbank built for "
+                            "an FFT of size 256 (the two configurations must agree on fft_size)")
+
+
+def test_rank_and_range_errors_need_no_device():
+    c = Stft.Config.create(fft_size=16, hop=4)
+    with pytest.raises(S.InvalidArgument) as e:
+        Stft.power_spectrum(c, np.float32(1.0))
+    assert str(e.value) == "power_spectrum: cannot analyse a rank-zero tensor (the time axis must exist)"
+    with pytest.raises(S.InvalidArgument) as e:
+        Stft.transform_range(c, np.zeros(100, np.float32), 3, 1000)
+    assert str(e.value) == ("transform_range: cannot take frames [3, 1000) of a 26-frame transform "
+                            "(the range must satisfy 0 <= p0 <= p1 <= frames)")
+    # zero-size leading axis and empty ranges evaluate no frame: zeros, no device work (stft.ml:629-635)
+    z = Stft.transform(c, np.zeros((0, 100), np.float32))
+    assert z.shape == (0, 9, 26) and z.dtype == np.complex64
+    z = Stft.transform_range(c, np.zeros((2, 100), np.float64), 5, 5)
+    assert z.shape == (2, 9, 0) and z.dtype == np.complex128
+    assert Stft.power_spectrum(c, np.zeros((3, 0), np.float32)).shape == (3, 9, 0)
+
+
+def test_kernel_prepare_messages():
+    c = Stft.Config.create(fft_size=16, hop=4)
+    for kw, msg in ((dict(channels=0, max_block=4), "prepare: cannot analyse 0 channels (channels must be at least 1)"),
+                    (dict(channels=1, max_block=0),
+                     "prepare: cannot accept blocks of 0 samples (max_block must be at least 1)")):
+        with pytest.raises(S.InvalidArgument) as e:
+            Stft.Kernel.prepare(c, np.float32, **kw)
+        assert str(e.value) == msg
+
+
+def test_fir_design_matches_oracle():
+    for taps, fc, att in [(63, 0.25, 80.0), (8192, 0.25, 100.0), (64, 0.5, 40.0), (1, 0.3, 60.0)]:
+        assert Fir.kaiser_beta(att) == O.kaiser_beta(att)
+        h = Fir.design_lowpass(taps, fc, att)
+        np.testing.assert_allclose(h, O.design_lowpass(taps, fc, O.kaiser_beta(att)), rtol=1e-12, atol=1e-18)
+    with pytest.raises(S.InvalidArgument):
+        Fir.Plan.create(np.ones(9000))
+    assert Fir.Plan.create(np.ones(8192) / 8192).block == 16384

@@ -144,3 +144,39 @@ def test_fir_fft_form_matches_direct():
     assert abs(h.sum() - 1.0) < 1e-12 and np.allclose(h, h[::-1], rtol=0, atol=1e-18)
     x = rng.standard_normal((3, 500))
     np.testing.assert_allclose(O.fir_filter(h, x), O.fir_filter_direct(h, x), rtol=0, atol=1e-12)
+
+
+# --- the C restatement (oracle/oracle_stft.c) is pinned by the same goldens ---------------
+
+@pytest.mark.parametrize("fname", STFT_FILES)
+def test_c_oracle_stft_spectra(fname):
+    from oracle import c_oracle
+    for case in load_golden("stft", fname)["cases"]:
+        p = case["params"]
+        c = _stft_config(p)
+        sig = O.lcg_signal(p["length"])
+        power = {"magnitude": 1.0, "power": 2.0}[p["kind"]]
+        if p["dtype"] == "float64":
+            check_close(c_oracle.stft(c, sig, power), case["values"], case["shape"], F64_RTOL, F64_ATOL,
+                        case["name"])
+        else:
+            check_close(c_oracle.stft(c, sig.astype(np.float32), power), case["values"], case["shape"],
+                        F32_RTOL, F32_ATOL, case["name"])
+
+
+def test_c_oracle_sign_and_numpy_agreement():
+    from oracle import c_oracle
+    for case in load_golden("stft", "complex_fft16_hop4")["cases"]:
+        p = case["params"]
+        z = c_oracle.stft(_stft_config(p), O.lcg_signal(p["length"]), complex_out=True)
+        check_close(z.real if p["kind"] == "real" else z.imag, case["values"], case["shape"], F64_RTOL,
+                    F64_ATOL, case["name"])
+    rng = np.random.default_rng(0)
+    x = rng.uniform(-1, 1, size=(3, 20000)).astype(np.float32)
+    for pad in ("reflect", "edge", "constant"):
+        c = O.stft_config(2048, hop=512, pad=pad, pad_value=0.5)
+        a, b = c_oracle.stft(c, x, 2.0, threads=3), O.power_spectrum(c, x, 2.0)
+        np.testing.assert_allclose(a, b, rtol=2e-6, atol=1e-6 * np.max(b))
+    mc = O.mel_config(128, 48000, 2048)
+    s = rng.uniform(0, 2, size=(2, 1025, 7)).astype(np.float32)
+    np.testing.assert_allclose(c_oracle.mel_apply(mc, s), O.mel_apply(mc, s), rtol=1e-6, atol=1e-7)
