@@ -39,7 +39,7 @@ def cpu_baseline(fft, hop, n, target_seconds=12.0):
     t0 = time.perf_counter()
     c_oracle.stft(c, probe, 2.0, threads=cores)
     dt = time.perf_counter() - t0
-    rounds = max(1, min(8, int(target_seconds / max(dt, 1e-3))))
+    rounds = max(1, min(64, int(target_seconds / max(dt, 1e-3))))
     clips = cores * rounds
     x = rng.uniform(-1, 1, size=(clips, n)).astype(np.float32)
     t0 = time.perf_counter()

@@ -138,28 +138,45 @@ static void *worker(void *arg) {
   double *xw = (double *)malloc(sizeof(double) * n);
   double *zr = (double *)malloc(sizeof(double) * (m > 0 ? m : 1)), *zi = (double *)malloc(sizeof(double) * (m > 0 ? m : 1));
   double *re = (double *)malloc(sizeof(double) * bins), *im = (double *)malloc(sizeof(double) * bins);
+  /* frames are produced FB at a time into a [bins][FB] block so the [bins; frames]
+   * output is written in runs of FB values (plain cache blocking, same arithmetic) */
+  enum { FB = 16 };
+  double *bre = (double *)malloc(sizeof(double) * bins * FB), *bim = (double *)malloc(sizeof(double) * bins * FB);
   for (int64_t clip = j->thread; clip < j->lead; clip += j->threads) {
     const float *x32 = j->x32 ? j->x32 + clip * j->n : NULL;
     const double *x64 = j->x64 ? j->x64 + clip * j->n : NULL;
-    for (int64_t f = 0; f < j->frames; ++f) {
-      const int64_t s0 = f * j->hop - j->left;
-      for (int i = 0; i < n; ++i) xw[i] = fetch(x32, x64, j->n, s0 + i, j->pad, j->pad_value) * j->window[i];
-      rfft_forward(p, xw, zr, zi, re, im);
-      for (int k = 0; k < bins; ++k) {
-        const int64_t o = (clip * bins + k) * j->frames + f;
-        if (j->out32) {
-          const float r32 = (float)re[k], i32 = (float)im[k];   /* one rounding to complex64 */
-          if (j->complex_out) { j->out32[2 * o] = r32; j->out32[2 * o + 1] = i32; continue; }
-          const float mag = (float)sqrt((double)r32 * (double)r32 + (double)i32 * (double)i32);
-          j->out32[o] = j->power == 2.0 ? mag * mag : (j->power == 1.0 ? mag : (float)pow((double)mag, j->power));
+    for (int64_t f0 = 0; f0 < j->frames; f0 += FB) {
+      const int nf = (int)(j->frames - f0 < FB ? j->frames - f0 : FB);
+      for (int ff = 0; ff < nf; ++ff) {
+        const int64_t s0 = (f0 + ff) * j->hop - j->left;
+        if (s0 >= 0 && s0 + n <= j->n) {          /* interior frame: same arithmetic, no index mapping */
+          if (x32) for (int i = 0; i < n; ++i) xw[i] = (double)x32[s0 + i] * j->window[i];
+          else for (int i = 0; i < n; ++i) xw[i] = x64[s0 + i] * j->window[i];
         } else {
-          if (j->complex_out) { j->out64[2 * o] = re[k]; j->out64[2 * o + 1] = im[k]; continue; }
-          const double mag = hypot(re[k], im[k]);
-          j->out64[o] = j->power == 2.0 ? mag * mag : (j->power == 1.0 ? mag : pow(mag, j->power));
+          for (int i = 0; i < n; ++i) xw[i] = fetch(x32, x64, j->n, s0 + i, j->pad, j->pad_value) * j->window[i];
+        }
+        rfft_forward(p, xw, zr, zi, re, im);
+        for (int k = 0; k < bins; ++k) { bre[k * FB + ff] = re[k]; bim[k * FB + ff] = im[k]; }
+      }
+      for (int k = 0; k < bins; ++k) {
+        for (int ff = 0; ff < nf; ++ff) {
+          const int64_t o = (clip * bins + k) * j->frames + f0 + ff;
+          const double rk = bre[k * FB + ff], ik = bim[k * FB + ff];
+          if (j->out32) {
+            const float r32 = (float)rk, i32 = (float)ik;   /* one rounding to complex64 */
+            if (j->complex_out) { j->out32[2 * o] = r32; j->out32[2 * o + 1] = i32; continue; }
+            const float mag = (float)sqrt((double)r32 * (double)r32 + (double)i32 * (double)i32);
+            j->out32[o] = j->power == 2.0 ? mag * mag : (j->power == 1.0 ? mag : (float)pow((double)mag, j->power));
+          } else {
+            if (j->complex_out) { j->out64[2 * o] = rk; j->out64[2 * o + 1] = ik; continue; }
+            const double mag = hypot(rk, ik);
+            j->out64[o] = j->power == 2.0 ? mag * mag : (j->power == 1.0 ? mag : pow(mag, j->power));
+          }
         }
       }
     }
   }
+  free(bre); free(bim);
   free(xw); free(zr); free(zi); free(re); free(im);
   plan_destroy(p);
   return NULL;

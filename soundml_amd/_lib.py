@@ -9,6 +9,15 @@ from __future__ import annotations
 import ctypes as C
 import os
 
+# ONE HIP runtime per process: torch bundles its own libamdhip64 (same soname as
+# /opt/rocm's).  If torch is going to be used it must be loaded BEFORE this
+# library is dlopen'ed, so that our DT_NEEDED libamdhip64.so.7 resolves to the
+# copy torch already mapped; two runtimes in one process cannot both see the GPU.
+try:  # torch is optional plumbing (device tensors, streams); host-array callers work without it
+    import torch  # noqa: F401
+except Exception:  # pragma: no cover
+    torch = None
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libsoundml_amd.so")
 
