@@ -11,7 +11,7 @@
 //   one 64-lane wavefront owns one frame; lane l holds 16 complex points.
 //   A. n = l + 64 j      : radix-16 over j in registers        -> y_l[k1]
 //      twiddle W_M^(l k1)
-//   X. one LDS transpose (8.5 KB per wave, padded rows, conflict-free b64)
+//   X. one LDS transpose (4.3 KB per wave: re then im, padded rows, conflict-free)
 //      lane l' = 4 k1 + a receives y_(4i+a)[k1], i = 0..15
 //   B. radix-16 over i in registers, twiddle W_64^(a q)
 //   C. radix-4 over a across the 4 lanes of a quad with DPP quad_perm
@@ -22,8 +22,12 @@
 //   T. |X|^2 is written into a workgroup tile [1025 bins][16 frames] in LDS
 //      (bank-conflict-free row permutation), and the 8 waves flush the tile to
 //      HBM frames-fastest.
-// A workgroup is 8 waves = 16 frames (2 per wave); LDS = 69.6 KB exchange +
-// 69.7 KB tile; 1 workgroup per CU, 2 waves per SIMD, <= 256 VGPRs.
+// A workgroup is 16 waves = 16 frames (one per wave): 4 waves per SIMD hide LDS
+// and memory latency, so the kernel stays within 128 VGPRs (twiddles in LDS,
+// window streamed from L1) and the exchange goes through LDS in two halves
+// (real parts, then imaginary parts: 4.3 KB per wave).  LDS = 69.6 KB exchange
+// + 69.7 KB tile + 16.5 KB twiddle tables; 1 workgroup per CU.  The next
+// tile's samples are prefetched into registers before the flush barrier.
 //
 // Algorithmic HBM bytes per frame: hop*4 read + 1025*4 written = 6148 B at
 // hop 512.  Flops per frame ~= 50k VALU lane-ops.
@@ -89,6 +93,8 @@ __device__ __forceinline__ float bperm(int byte_addr, float v) {
   return __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(byte_addr, __builtin_bit_cast(int, v)));
 }
 
+constexpr int kN = 2048, kM = 1024, kBins = 1025;
+
 struct FastArgs {
   const float *x;
   int64_t n, x_stride;
@@ -107,41 +113,64 @@ struct FastArgs {
   float half_power;
 };
 
-constexpr int kN = 2048, kM = 1024, kBins = 1025;
-constexpr int kWaves = 8, kFT = 16;
-constexpr int kXRow = 68;                       // float2 per exchange row (64 + 4 pad)
-constexpr int kXWave = 16 * kXRow;              // float2 per wave
+constexpr int kWaves = 16, kFT = 16;            // one frame per wave per tile
+constexpr int kXRow = 68;                       // floats per exchange row (64 + 4 pad)
+constexpr int kXWave = 16 * kXRow;              // floats per wave (re and im go through in turn)
 constexpr int kTileStride = kFT + 1;            // floats per tile row
-constexpr size_t kExchBytes = (size_t)kWaves * kXWave * sizeof(float2);
+constexpr size_t kExchBytes = (size_t)kWaves * kXWave * sizeof(float);
 constexpr size_t kTileBytes = ((size_t)kBins * kTileStride * sizeof(float) + 15) / 16 * 16;
-constexpr size_t kTabPBytes = 16 * 64 * sizeof(float2);   // post-pass twiddles [q][lane]
-constexpr size_t kTabBBytes = 16 * 4 * sizeof(float2);    // W_64^(a q)       [q][a]
-constexpr size_t kFastLds = kExchBytes + kTileBytes + kTabPBytes + kTabBBytes;
+constexpr size_t kTabABytes = 16 * 64 * sizeof(float2);   // W_M^(l k1)          [k1][lane]
+constexpr size_t kTabPBytes = 16 * 64 * sizeof(float2);   // post-pass twiddles  [q][lane]
+constexpr size_t kTabBBytes = 16 * 4 * sizeof(float2);    // W_64^(a q)          [q][a]
+constexpr size_t kFastLds = kExchBytes + kTileBytes + kTabABytes + kTabPBytes + kTabBBytes;
+static_assert(kFastLds <= 160 * 1024, "LDS budget");
 
-__device__ __forceinline__ float fetch_padded(const float *x, int64_t n, int64_t s, int pad,
-                                              float pad_value) {
-  if (s >= 0 && s < n) return x[s];
-  if (pad == SMX_PAD_REFLECT) {  // stft.ml:300-305
-    if (n == 1) return x[0];
-    const int64_t period = 2 * (n - 1);
-    int64_t m = s % period;
-    if (m < 0) m += period;
-    return x[m < n ? m : period - m];
-  }
-  if (pad == SMX_PAD_EDGE) return x[s < 0 ? 0 : n - 1];
-  return pad_value;
+using i32x2 = __attribute__((ext_vector_type(2))) int;
+
+// 8-byte load through a buffer descriptor: SGPR base, 32-bit lane offset, immediate + SGPR offset.
+// (Plain pointer arithmetic makes hipcc materialise one 64-bit VGPR address per unrolled load.)
+__device__ __forceinline__ float2 buf_load2(__amdgpu_buffer_rsrc_t rsrc, int voff, int soff) {
+  const i32x2 r = __builtin_amdgcn_raw_buffer_load_b64(rsrc, voff, soff, 0);
+  return make_float2(__builtin_bit_cast(float, r.x), __builtin_bit_cast(float, r.y));
+}
+__device__ __forceinline__ float buf_load1(__amdgpu_buffer_rsrc_t rsrc, int voff, int soff) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, voff, soff, 0));
 }
 
+// raw (unwindowed) samples of frame p: lane l takes z[n] = (x[2n], x[2n+1]), n = l + 64 j.
+// Every frame given to this kernel lies inside the signal (border frames arrive
+// through gathered, already padded strips -- see launch_stft_fast).  p is
+// wave-uniform, so the frame's 8 KB window is one SGPR buffer descriptor.
 template <bool ALIGNED>
-__global__ void __launch_bounds__(512, 2) stft2048_power_kernel(FastArgs a) {
+__device__ __forceinline__ void load_frame(const FastArgs &a, const float *x, int64_t p, int lane,
+                                           float2 (&raw)[16]) {
+  const int64_t s0 = p * a.hop - a.left;
+  const __amdgpu_buffer_rsrc_t rsrc =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(x + s0), 0, kN * 4, 0x00020000);
+  const int voff = lane * 8;
+  if constexpr (ALIGNED) {
+#pragma unroll
+    for (int j = 0; j < 16; ++j) raw[j] = buf_load2(rsrc, voff + 512 * (j & 7), j < 8 ? 0 : 4096);
+  } else {
+#pragma unroll
+    for (int j = 0; j < 16; ++j)
+      raw[j] = make_float2(buf_load1(rsrc, voff + 512 * (j & 7), j < 8 ? 0 : 4096),
+                           buf_load1(rsrc, voff + 512 * (j & 7) + 4, j < 8 ? 0 : 4096));
+  }
+}
+
+// SQUARE = power 2 (no per-bin branch); otherwise |X|^p through pmode / half_power
+template <bool ALIGNED, bool SQUARE>
+__global__ void __launch_bounds__(1024) stft2048_power_kernel(FastArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x;
   const int lane = tid & 63;
-  const int wave = tid >> 6;
-  float2 *exch = reinterpret_cast<float2 *>(smem) + wave * kXWave;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // provably wave-uniform (scalar)
+  float *exch = reinterpret_cast<float *>(smem) + wave * kXWave;
   float *tile = reinterpret_cast<float *>(smem + kExchBytes);
-  float2 *tabP = reinterpret_cast<float2 *>(smem + kExchBytes + kTileBytes);
-  float2 *tabB = reinterpret_cast<float2 *>(smem + kExchBytes + kTileBytes + kTabPBytes);
+  float2 *tabA = reinterpret_cast<float2 *>(smem + kExchBytes + kTileBytes);
+  float2 *tabP = reinterpret_cast<float2 *>(smem + kExchBytes + kTileBytes + kTabABytes);
+  float2 *tabB = reinterpret_cast<float2 *>(smem + kExchBytes + kTileBytes + kTabABytes + kTabPBytes);
 
   // XCD-aware block -> (clip, tile group): blocks that share an XCD (b % 8) get a
   // contiguous range of virtual ids, i.e. whole clips, so halo re-reads and the
@@ -158,24 +187,16 @@ __global__ void __launch_bounds__(512, 2) stft2048_power_kernel(FastArgs a) {
   // ---- per-lane constants ----------------------------------------------------
   const int k1 = lane >> 2, qa = lane & 3;
   const int r = ((qa & 1) << 1) | (qa >> 1);
-  float2 win[16];
-  c32 twA[16];
-#pragma unroll
-  for (int j = 0; j < 16; ++j) {
-    win[j] = *reinterpret_cast<const float2 *>(a.hwin + 2 * lane + 128 * j);
-    const float2 wa = a.w_m[lane * j];            // W_M^(l k1), k1 = j
-    twA[j] = {wa.x, wa.y};
-  }
-  // workgroup-shared twiddle tables in LDS (each wave fills 2 of the 16 rows)
-#pragma unroll
-  for (int jj = 0; jj < 2; ++jj) {
-    const int j = 2 * wave + jj;
-    tabP[j * 64 + lane] = a.w_n[k1 + 256 * r + 16 * j];   // exp(-2 pi i k / N), k = k1 + 16 j + 256 r
-    if (lane < 4) tabB[j * 4 + lane] = a.w_m[16 * lane * j]; // W_64^(a j)
-  }
-  __syncthreads();
+  // workgroup-shared twiddle tables in LDS: wave w fills row w of each
+  tabA[wave * 64 + lane] = a.w_m[lane * wave];                 // W_M^(l k1), k1 = wave
+  tabP[wave * 64 + lane] = a.w_n[k1 + 256 * r + 16 * wave];    // exp(-2 pi i k / N), k = k1 + 16 q + 256 r
+  if (lane < 4) tabB[wave * 4 + lane] = a.w_m[16 * lane * wave];  // W_64^(a q)
+  const float2 *tabA_l = tabA + lane;
   const float2 *tabP_l = tabP + lane;
   const float2 *tabB_l = tabB + qa;
+  const __amdgpu_buffer_rsrc_t win_rsrc =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(a.hwin), 0, kN * 4, 0x00020000);
+
   const float s1 = qa < 2 ? 1.0f : -1.0f;
   const float s2 = (qa & 1) ? -1.0f : 1.0f;
   const bool rot = qa == 3;
@@ -189,7 +210,6 @@ __global__ void __launch_bounds__(512, 2) stft2048_power_kernel(FastArgs a) {
     addr_0 = ((((r0 & 1) << 1) | (r0 >> 1))) * 4;        // its lane = bitrev2(r0)
   }
   const bool low4 = lane < 4;
-  const int exch_wr = lane;                               // + k1 * kXRow
   const int exch_rd = k1 * kXRow + qa;                    // + 4 i
   const int tile_row0 = 4 * k1 + r;                       // + 64 q   (row' = 4 (k1 + 16 q) + r)
 
@@ -197,57 +217,56 @@ __global__ void __launch_bounds__(512, 2) stft2048_power_kernel(FastArgs a) {
   int t_end = t_begin + a.tiles_per_group;
   if (t_end > a.tiles_per_clip) t_end = a.tiles_per_clip;
 
+  // prefetch the first frame of this wave
+  float2 raw[16];
+  bool have = (int64_t)t_begin * kFT + wave < a.count;
+  if (have) load_frame<ALIGNED>(a, x, a.p0 + (int64_t)t_begin * kFT + wave, lane, raw);
+  __syncthreads();   // tables visible
+
   for (int t = t_begin; t < t_end; ++t) {
     const int64_t f0 = (int64_t)t * kFT;
-#pragma unroll 1
-    for (int ff = 0; ff < 2; ++ff) {
-      const int f = 2 * wave + ff;
-      if (f0 + f >= a.count) break;  // wave-uniform
-      const int64_t p = a.p0 + f0 + f;
-      const int64_t s0 = p * a.hop - a.left;
+    if (have) {   // wave-uniform
       c32 v[16];
-      if (s0 >= 0 && s0 + kN <= a.n) {
-        if constexpr (ALIGNED) {
-          const float2 *src = reinterpret_cast<const float2 *>(x + s0) + lane;
 #pragma unroll
-          for (int j = 0; j < 16; ++j) {
-            const float2 d = src[64 * j];
-            v[j] = {d.x * win[j].x, d.y * win[j].y};
-          }
-        } else {
-          const float *src = x + s0 + 2 * lane;
-#pragma unroll
-          for (int j = 0; j < 16; ++j) v[j] = {src[128 * j] * win[j].x, src[128 * j + 1] * win[j].y};
-        }
-      } else {
-#pragma unroll
-        for (int j = 0; j < 16; ++j) {
-          const int64_t s = s0 + 2 * lane + 128 * j;
-          v[j] = {fetch_padded(x, a.n, s, a.pad, a.pad_value) * win[j].x,
-                  fetch_padded(x, a.n, s + 1, a.pad, a.pad_value) * win[j].y};
-        }
+      for (int j = 0; j < 16; ++j) {
+        const float2 w = buf_load2(win_rsrc, lane * 8 + 512 * (j & 7), j < 8 ? 0 : 4096);
+        v[j] = {raw[j].x * w.x, raw[j].y * w.y};
       }
-      // A: radix-16 over j, twiddle
+      __builtin_amdgcn_sched_barrier(0);
+      // A: radix-16 over j, twiddle W_M^(l k1)
       fft16(v);
+      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-      for (int k = 1; k < 16; ++k) v[k] = cmul(v[k], twA[k]);
-      // X: transpose through LDS (wave-private region; LDS ops of one wave are in order)
-#pragma unroll
-      for (int k = 0; k < 16; ++k) exch[k * kXRow + exch_wr] = make_float2(v[k].x, v[k].y);
-      __builtin_amdgcn_wave_barrier();
-#pragma unroll
-      for (int i = 0; i < 16; ++i) {
-        const float2 d = exch[exch_rd + 4 * i];
-        v[i] = {d.x, d.y};
+      for (int k = 1; k < 16; ++k) {
+        const float2 w = tabA_l[64 * k];
+        v[k] = cmul(v[k], c32{w.x, w.y});
       }
+      // X: transpose through LDS, real parts then imaginary parts (wave-private
+      // region; the LDS operations of one wave execute in order)
+      __builtin_amdgcn_sched_barrier(0);
+      float tre[16];
+#pragma unroll
+      for (int k = 0; k < 16; ++k) exch[k * kXRow + lane] = v[k].x;
       __builtin_amdgcn_wave_barrier();
+#pragma unroll
+      for (int i = 0; i < 16; ++i) tre[i] = exch[exch_rd + 4 * i];
+      __builtin_amdgcn_wave_barrier();
+#pragma unroll
+      for (int k = 0; k < 16; ++k) exch[k * kXRow + lane] = v[k].y;
+      __builtin_amdgcn_wave_barrier();
+#pragma unroll
+      for (int i = 0; i < 16; ++i) v[i] = {tre[i], exch[exch_rd + 4 * i]};
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_sched_barrier(0);
       // B: radix-16 over i, twiddle W_64^(a q)
       fft16(v);
+      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int q = 1; q < 16; ++q) {
         const float2 wb = tabB_l[4 * q];
         v[q] = cmul(v[q], c32{wb.x, wb.y});
       }
+      __builtin_amdgcn_sched_barrier(0);
       // C: radix-4 across the quad (DPP).  lane a ends with r = bitrev2(a).
 #pragma unroll
       for (int q = 0; q < 16; ++q) {
@@ -258,37 +277,37 @@ __global__ void __launch_bounds__(512, 2) stft2048_power_kernel(FastArgs a) {
         v[q].x = fmaf(w.x, s2, dpp_quad<0xB1>(w.x));
         v[q].y = fmaf(w.y, s2, dpp_quad<0xB1>(w.y));
       }
+      __builtin_amdgcn_sched_barrier(0);
       // P: real-FFT post-pass.  provider rotation for the k1 = 0 lanes.
-      c32 prov[16];
-#pragma unroll
-      for (int m = 0; m < 16; ++m) {
-        prov[m].x = low4 ? v[(m + 1) & 15].x : v[m].x;
-        prov[m].y = low4 ? v[(m + 1) & 15].y : v[m].y;
-      }
-      float *col = tile + f;
+      float *col = tile + wave;
       const float nyq = 2.0f * (v[0].x - v[0].y);   // X[M] = Re Z0 - Im Z0 (true scale), lane 0
 #pragma unroll
       for (int q = 0; q < 16; ++q) {
         const int addr = q == 0 ? addr_0 : addr_g;
-        const float px = bperm(addr, prov[15 - q].x);
-        const float py = bperm(addr, prov[15 - q].y);
+        const int m = 15 - q;
+        const float sx = low4 ? v[(m + 1) & 15].x : v[m].x;
+        const float sy = low4 ? v[(m + 1) & 15].y : v[m].y;
+        const float px = bperm(addr, sx);
+        const float py = bperm(addr, sy);
         const c32 e = {v[q].x + px, v[q].y - py};
         const c32 d = {v[q].x - px, v[q].y + py};
         const float2 w = tabP_l[64 * q];
         const float tr = e.x + w.x * d.y + w.y * d.x;
         const float ti = e.y - w.x * d.x + w.y * d.y;
         float pw = tr * tr + ti * ti;
-        if (a.pmode == 1) pw = sqrtf(pw);
-        else if (a.pmode == 0) pw = __powf(pw, a.half_power);
+        if constexpr (!SQUARE) pw = a.pmode == 1 ? sqrtf(pw) : __powf(pw, a.half_power);
         col[(tile_row0 + 64 * q) * kTileStride] = pw;
+        if ((q & 3) == 3) __builtin_amdgcn_sched_barrier(0);
       }
       if (lane == 0) {
         float pw = nyq * nyq;
-        if (a.pmode == 1) pw = fabsf(nyq);
-        else if (a.pmode == 0) pw = __powf(pw, a.half_power);
+        if constexpr (!SQUARE) pw = a.pmode == 1 ? fabsf(nyq) : __powf(pw, a.half_power);
         col[kM * kTileStride] = pw;
       }
     }
+    // prefetch this wave's frame of the next tile; the loads fly during the flush
+    have = (t + 1 < t_end) && (f0 + kFT + wave < a.count);
+    if (have) load_frame<ALIGNED>(a, x, a.p0 + f0 + kFT + wave, lane, raw);
     __syncthreads();
     // ---- flush tile -> out[clip][bin][frame], frames fastest -------------------
     {
@@ -297,8 +316,8 @@ __global__ void __launch_bounds__(512, 2) stft2048_power_kernel(FastArgs a) {
       float *obase = a.out + (clip * kBins) * a.out_stride + a.out_offset + f0 + 4 * g;
       const int64_t fleft = a.count - f0 - 4 * g;    // frames remaining from this column group
 #pragma unroll
-      for (int it = 0; it < 8; ++it) {
-        const int row = 32 * (wave + 8 * (it >> 1)) + 8 * (it & 1) + rloc;
+      for (int it = 0; it < 4; ++it) {
+        const int row = 32 * (wave + 16 * (it >> 1)) + 8 * (it & 1) + rloc;
         const int bin = (row & 3) * 256 + (row >> 2);
         const float *src = tile + row * kTileStride + 4 * g;
         const float v0 = src[0], v1 = src[1], v2 = src[2], v3 = src[3];
@@ -325,49 +344,129 @@ __global__ void __launch_bounds__(512, 2) stft2048_power_kernel(FastArgs a) {
 
 }  // namespace
 
+namespace {
+
+// Border strips: out[clip][j] = padded sample at signal position pos0 + j
+// (reflect / edge / constant extension of stft.ml:300-338), so that border
+// frames run through the SAME kernel and arithmetic as interior frames.
+__global__ void __launch_bounds__(256) gather_padded_kernel(const float *x, int64_t n, int64_t x_stride,
+                                                            int64_t pos0, int64_t len, int pad,
+                                                            float pad_value, float *out, int64_t out_stride) {
+  const int64_t clip = blockIdx.y;
+  const float *src = x + clip * x_stride;
+  float *dst = out + clip * out_stride;
+  for (int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x; j < len; j += (int64_t)gridDim.x * 256) {
+    int64_t s = pos0 + j;
+    float v;
+    if (s >= 0 && s < n) {
+      v = src[s];
+    } else if (pad == SMX_PAD_REFLECT) {
+      if (n == 1) {
+        s = 0;
+      } else {
+        const int64_t period = 2 * (n - 1);
+        int64_t m = s % period;
+        if (m < 0) m += period;
+        s = m < n ? m : period - m;
+      }
+      v = src[s];
+    } else if (pad == SMX_PAD_EDGE) {
+      v = src[s < 0 ? 0 : n - 1];
+    } else {
+      v = pad_value;
+    }
+    dst[j] = v;
+  }
+}
+
+// one launch of the fused kernel over frames that all lie inside [0, n)
+void launch_interior(const StftJob &job, const float *x, int64_t n, int64_t x_stride, int64_t left,
+                     int64_t p0, int64_t count, int64_t out_offset) {
+  if (count <= 0) return;
+  const smx_stft_config &c = *job.cfg;
+  const StftTables &t = c.tables();
+  FastArgs a{};
+  a.x = x;
+  a.n = n;
+  a.x_stride = x_stride;
+  a.hop = c.hop;
+  a.left = left;
+  a.pad = 0;
+  a.pad_value = 0.0f;
+  a.p0 = p0;
+  a.count = count;
+  a.out = reinterpret_cast<float *>(job.out);
+  a.out_stride = job.out_stride;
+  a.out_offset = out_offset;
+  a.hwin = t.fast_window;
+  a.w_m = t.fast_w_m;
+  a.w_n = t.fast_w_n;
+  const int64_t tiles = (count + kFT - 1) / kFT;
+  if (tiles > 0x7fffffff) throw Failure("stft: too many frame tiles for one launch");
+  a.tiles_per_clip = (int)tiles;
+  // enough workgroups to fill 256 CUs several times over, while amortising the
+  // per-workgroup twiddle-table fill over a few tiles
+  int tpg = 8;
+  while (tpg > 1 && job.lead * ((tiles + tpg - 1) / tpg) < 2048) tpg >>= 1;
+  a.tiles_per_group = tpg;
+  a.groups_per_clip = (int)((tiles + tpg - 1) / tpg);
+  a.blocks = job.lead * a.groups_per_clip;
+  if (a.blocks > 0x7fffffff) throw Failure("stft: too many workgroups for one launch");
+  a.pmode = job.power == 2.0 ? 2 : (job.power == 1.0 ? 1 : 0);
+  a.half_power = (float)(0.5 * job.power);
+  const bool aligned = (c.hop % 2 == 0) && (left % 2 == 0) && (x_stride % 2 == 0) &&
+                       (reinterpret_cast<uintptr_t>(x) % 8 == 0);
+  const bool square = a.pmode == 2;
+  auto kernel = aligned ? (square ? stft2048_power_kernel<true, true> : stft2048_power_kernel<true, false>)
+                        : (square ? stft2048_power_kernel<false, true> : stft2048_power_kernel<false, false>);
+  SMX_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kernel),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)kFastLds));
+  hipLaunchKernelGGL(kernel, dim3((unsigned)a.blocks), dim3(1024), kFastLds, job.stream, a);
+  SMX_HIP_CHECK(hipGetLastError());
+}
+
+// frames [pa, pb) that touch a border: gather their padded span, then run the fused kernel on it
+void launch_border(const StftJob &job, int64_t pa, int64_t pb) {
+  if (pb <= pa) return;
+  const smx_stft_config &c = *job.cfg;
+  const int64_t pos0 = pa * c.hop - job.left;               // signal position of the strip's first sample
+  const int64_t len = (pb - pa - 1) * c.hop + kN;
+  const int64_t stride = (len + 1) & ~int64_t(1);            // even: keeps 8-byte aligned rows
+  float *strip = nullptr;
+  SMX_HIP_CHECK(hipMallocAsync((void **)&strip, (size_t)job.lead * (size_t)stride * sizeof(float), job.stream));
+  if (job.lead > 65535) throw Failure("stft: too many leading slices for one border launch");
+  dim3 grid((unsigned)((len + 255) / 256 < 64 ? (len + 255) / 256 : 64), (unsigned)job.lead);
+  hipLaunchKernelGGL(gather_padded_kernel, grid, dim3(256), 0, job.stream,
+                     reinterpret_cast<const float *>(job.x), job.n, job.x_stride, pos0, len, job.pad,
+                     (float)job.pad_value, strip, stride);
+  SMX_HIP_CHECK(hipGetLastError());
+  launch_interior(job, strip, len, stride, 0, 0, pb - pa, job.out_offset + (pa - job.p0));
+  SMX_HIP_CHECK(hipFreeAsync(strip, job.stream));
+}
+
+}  // namespace
+
 bool launch_stft_fast(const StftJob &job) {
   const smx_stft_config &c = *job.cfg;
   if (fast_path_disabled()) return false;
   if (c.fft_size != kN || job.in_bytes != 4 || job.interior != SMX_INTERIOR_F32) return false;
   if (job.mode != OUT_POWER) return false;
   if (job.count <= 0 || job.lead <= 0) return true;
-  const StftTables &t = c.tables();
-  FastArgs a{};
-  a.x = reinterpret_cast<const float *>(job.x);
-  a.n = job.n;
-  a.x_stride = job.x_stride;
-  a.hop = c.hop;
-  a.left = job.left;
-  a.pad = job.pad;
-  a.pad_value = (float)job.pad_value;
-  a.p0 = job.p0;
-  a.count = job.count;
-  a.out = reinterpret_cast<float *>(job.out);
-  a.out_stride = job.out_stride;
-  a.out_offset = job.out_offset;
-  a.hwin = t.fast_window;
-  a.w_m = t.fast_w_m;
-  a.w_n = t.fast_w_n;
-  const int64_t tiles = (job.count + kFT - 1) / kFT;
-  if (tiles > 0x7fffffff) return false;
-  a.tiles_per_clip = (int)tiles;
-  // enough workgroups to fill 256 CUs several times over, while amortising the
-  // per-lane twiddle loads over a few tiles
-  int tpg = 8;
-  while (tpg > 1 && job.lead * ((tiles + tpg - 1) / tpg) < 2048) tpg >>= 1;
-  a.tiles_per_group = tpg;
-  a.groups_per_clip = (int)((tiles + tpg - 1) / tpg);
-  a.blocks = job.lead * a.groups_per_clip;
-  if (a.blocks > 0x7fffffff) return false;
-  a.pmode = job.power == 2.0 ? 2 : (job.power == 1.0 ? 1 : 0);
-  a.half_power = (float)(0.5 * job.power);
-  const bool aligned = (c.hop % 2 == 0) && (job.left % 2 == 0) && (job.x_stride % 2 == 0) &&
-                       (reinterpret_cast<uintptr_t>(job.x) % 8 == 0);
-  auto kernel = aligned ? stft2048_power_kernel<true> : stft2048_power_kernel<false>;
-  SMX_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kernel),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)kFastLds));
-  hipLaunchKernelGGL(kernel, dim3((unsigned)a.blocks), dim3(512), kFastLds, job.stream, a);
-  SMX_HIP_CHECK(hipGetLastError());
+  if (job.lead > 65535) return false;
+  // frame p lies inside the signal iff 0 <= p*hop - left and p*hop - left + N <= n
+  const int64_t p0 = job.p0, p1 = job.p0 + job.count;
+  int64_t i0 = job.left > 0 ? (job.left + c.hop - 1) / c.hop : 0;
+  int64_t i1 = job.n + job.left - kN >= 0 ? (job.n + job.left - kN) / c.hop + 1 : 0;
+  if (i0 < p0) i0 = p0;
+  if (i1 > p1) i1 = p1;
+  if (i1 <= i0) {          // no interior frame in range: one strip for everything
+    launch_border(job, p0, p1);
+    return true;
+  }
+  launch_border(job, p0, i0);
+  launch_interior(job, reinterpret_cast<const float *>(job.x), job.n, job.x_stride, job.left, i0, i1 - i0,
+                  job.out_offset + (i0 - p0));
+  launch_border(job, i1, p1);
   return true;
 }
 

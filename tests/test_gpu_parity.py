@@ -326,8 +326,10 @@ def test_fir_vs_oracle(taps, n, ch):
     got = Fir.apply(Fir.Plan.create(h), x)
     want = O.fir_filter(h, x)
     assert got.shape == want.shape and got.dtype == np.float32
-    for i in range(ch):
-        check_fast(got[i], want[i], "fir")
+    # FFT convolution error scales with the filter's L1 gain times the input peak, not with the
+    # local output value: |err| <= 1e-5 * sum|h| * max|x|  (FIR path is "parity unpinned")
+    bound = 1e-5 * np.sum(np.abs(h)) * np.max(np.abs(x))
+    assert np.max(np.abs(got.astype(np.float64) - want)) <= bound
 
 
 def test_fir_known_answers():
