@@ -125,37 +125,42 @@ constexpr size_t kTabBBytes = 16 * 4 * sizeof(float2);    // W_64^(a q)         
 constexpr size_t kFastLds = kExchBytes + kTileBytes + kTabABytes + kTabPBytes + kTabBBytes;
 static_assert(kFastLds <= 160 * 1024, "LDS budget");
 
-using i32x2 = __attribute__((ext_vector_type(2))) int;
-
-// 8-byte load through a buffer descriptor: SGPR base, 32-bit lane offset, immediate + SGPR offset.
-// (Plain pointer arithmetic makes hipcc materialise one 64-bit VGPR address per unrolled load.)
-__device__ __forceinline__ float2 buf_load2(__amdgpu_buffer_rsrc_t rsrc, int voff, int soff) {
-  const i32x2 r = __builtin_amdgcn_raw_buffer_load_b64(rsrc, voff, soff, 0);
-  return make_float2(__builtin_bit_cast(float, r.x), __builtin_bit_cast(float, r.y));
-}
-__device__ __forceinline__ float buf_load1(__amdgpu_buffer_rsrc_t rsrc, int voff, int soff) {
-  return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, voff, soff, 0));
+// 16 coalesced 8-byte loads of one 8 KB window: lane l takes elements l + 64 j.
+// `base` is wave-uniform, so the loads use two SGPR bases (base, base + 4 KB) plus
+// ONE shared 32-bit lane offset with 12-bit immediates.  The +4 KB step is made
+// opaque to the optimiser: otherwise hipcc materialises a separate 64-bit VGPR
+// address per unrolled load beyond the immediate range (and spills them).
+// (__builtin_amdgcn_raw_buffer_load_b64/_b128 are not usable on this toolchain:
+// ROCm 7.2 hipcc emits a single-dword load for them.)
+__device__ __forceinline__ void load16_f2(const float2 *base, int lane, float2 (&dst)[16]) {
+  long hi_off = 512;
+  asm volatile("" : "+s"(hi_off));
+  const float2 *hi = base + hi_off;
+#pragma unroll
+  for (int j = 0; j < 16; ++j)
+    dst[j] = j < 8 ? base[(unsigned)lane + 64u * j] : hi[(unsigned)lane + 64u * (j - 8)];
 }
 
 // raw (unwindowed) samples of frame p: lane l takes z[n] = (x[2n], x[2n+1]), n = l + 64 j.
 // Every frame given to this kernel lies inside the signal (border frames arrive
-// through gathered, already padded strips -- see launch_stft_fast).  p is
-// wave-uniform, so the frame's 8 KB window is one SGPR buffer descriptor.
+// through gathered, already padded strips -- see launch_stft_fast).  p is wave-uniform.
 template <bool ALIGNED>
 __device__ __forceinline__ void load_frame(const FastArgs &a, const float *x, int64_t p, int lane,
                                            float2 (&raw)[16]) {
   const int64_t s0 = p * a.hop - a.left;
-  const __amdgpu_buffer_rsrc_t rsrc =
-      __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(x + s0), 0, kN * 4, 0x00020000);
-  const int voff = lane * 8;
   if constexpr (ALIGNED) {
-#pragma unroll
-    for (int j = 0; j < 16; ++j) raw[j] = buf_load2(rsrc, voff + 512 * (j & 7), j < 8 ? 0 : 4096);
+    load16_f2(reinterpret_cast<const float2 *>(x + s0), lane, raw);
   } else {
+    const float *src = x + s0;
+    long hi_off = 1024;
+    asm volatile("" : "+s"(hi_off));
+    const float *hi = src + hi_off;
 #pragma unroll
-    for (int j = 0; j < 16; ++j)
-      raw[j] = make_float2(buf_load1(rsrc, voff + 512 * (j & 7), j < 8 ? 0 : 4096),
-                           buf_load1(rsrc, voff + 512 * (j & 7) + 4, j < 8 ? 0 : 4096));
+    for (int j = 0; j < 16; ++j) {
+      const float *b = j < 8 ? src : hi;
+      const unsigned e = 2u * lane + 128u * (j & 7);
+      raw[j] = make_float2(b[e], b[e + 1u]);
+    }
   }
 }
 
@@ -194,8 +199,6 @@ __global__ void __launch_bounds__(1024) stft2048_power_kernel(FastArgs a) {
   const float2 *tabA_l = tabA + lane;
   const float2 *tabP_l = tabP + lane;
   const float2 *tabB_l = tabB + qa;
-  const __amdgpu_buffer_rsrc_t win_rsrc =
-      __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(a.hwin), 0, kN * 4, 0x00020000);
 
   const float s1 = qa < 2 ? 1.0f : -1.0f;
   const float s2 = (qa & 1) ? -1.0f : 1.0f;
@@ -227,10 +230,11 @@ __global__ void __launch_bounds__(1024) stft2048_power_kernel(FastArgs a) {
     const int64_t f0 = (int64_t)t * kFT;
     if (have) {   // wave-uniform
       c32 v[16];
+      {
+        float2 w[16];   // half-scaled analysis window, streamed from L1/L2 (8 KB, shared by every wave)
+        load16_f2(reinterpret_cast<const float2 *>(a.hwin), lane, w);
 #pragma unroll
-      for (int j = 0; j < 16; ++j) {
-        const float2 w = buf_load2(win_rsrc, lane * 8 + 512 * (j & 7), j < 8 ? 0 : 4096);
-        v[j] = {raw[j].x * w.x, raw[j].y * w.y};
+        for (int j = 0; j < 16; ++j) v[j] = {raw[j].x * w[j].x, raw[j].y * w[j].y};
       }
       __builtin_amdgcn_sched_barrier(0);
       // A: radix-16 over j, twiddle W_M^(l k1)
