@@ -11,7 +11,7 @@
 //   one 64-lane wavefront owns one frame; lane l holds 16 complex points.
 //   A. n = l + 64 j      : radix-16 over j in registers        -> y_l[k1]
 //      twiddle W_M^(l k1)
-//   X. one LDS transpose (4.3 KB per wave: re then im, padded rows, conflict-free)
+//   X. in-wave 16x16 transpose (permlane32/16_swap + DPP row ops, no LDS):
 //      lane l' = 4 k1 + a receives y_(4i+a)[k1], i = 0..15
 //   B. radix-16 over i in registers, twiddle W_64^(a q)
 //   C. radix-4 over a across the 4 lanes of a quad with DPP quad_perm
@@ -22,12 +22,13 @@
 //   T. |X|^2 is written into a workgroup tile [1025 bins][16 frames] in LDS
 //      (bank-conflict-free row permutation), and the 8 waves flush the tile to
 //      HBM frames-fastest.
-// A workgroup is 16 waves = 16 frames (one per wave): 4 waves per SIMD hide LDS
-// and memory latency, so the kernel stays within 128 VGPRs (twiddles in LDS,
-// window streamed from L1) and the exchange goes through LDS in two halves
-// (real parts, then imaginary parts: 4.3 KB per wave).  LDS = 69.6 KB exchange
-// + 69.7 KB tile + 16.5 KB twiddle tables; 1 workgroup per CU.  The next
-// tile's samples are prefetched into registers before the flush barrier.
+// A workgroup is 16 waves = 16 frames (one per wave), <= 128 VGPRs (twiddles in
+// LDS, window streamed from L1/L2).  The output tile is DOUBLE-BUFFERED: there
+// is one barrier per tile, after which every wave stores its share of the
+// finished tile and goes straight on to the next frame, so the HBM write drain
+// overlaps the next tile's arithmetic.  LDS = 2 x 69.7 KB tiles + 16.5 KB
+// twiddle tables; 1 workgroup per CU.  The next frame's samples and window are
+// prefetched into registers before the stores are issued.
 //
 // Algorithmic HBM bytes per frame: hop*4 read + 1025*4 written = 6148 B at
 // hop 512.  Flops per frame ~= 50k VALU lane-ops.
@@ -83,10 +84,82 @@ __device__ __forceinline__ void fft16(c32 (&v)[16]) {
   for (int i = 0; i < 16; ++i) v[i] = t[i];
 }
 
+#ifdef SMX_STAMPS
+// Diagnostic build only (make STAMPS=1): per-phase cycle sums of every wave, read back with
+// smx_debug_read_stamps().  Never compiled into the shipped library; no output depends on it.
+constexpr int kStampSlots = 12;
+__device__ unsigned long long g_stamp_sums[4096 * 16 * kStampSlots];
+#define SMX_STAMP(i)                                                                      \
+  do {                                                                                    \
+    unsigned long long t__;                                                               \
+    __builtin_amdgcn_sched_barrier(0);                                                    \
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t__)::"memory");           \
+    __builtin_amdgcn_sched_barrier(0);                                                    \
+    stamp_sum[i] += t__ - stamp_prev;                                                     \
+    stamp_prev = t__;                                                                     \
+  } while (0)
+#else
+#define SMX_STAMP(i) do { } while (0)
+#endif
+
 template <int CTRL>
 __device__ __forceinline__ float dpp_quad(float v) {
   return __builtin_bit_cast(
       float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, false));
+}
+
+template <int CTRL, int BANK_MASK>
+__device__ __forceinline__ float dpp_mov(float old, float src) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, old),
+                                                               __builtin_bit_cast(int, src), CTRL, 0xF,
+                                                               BANK_MASK, false));
+}
+// lanes 32-63 of a <-> lanes 0-31 of b / odd rows of a <-> even rows of b.  Inline asm: this
+// hipcc drops the second result of __builtin_amdgcn_permlane{32,16}_swap.  "s_nop 1" covers the
+// VALU-write -> v_permlane-read hazard (2 wait states) inside the statement.
+__device__ __forceinline__ void swap32(float &a, float &b) {
+  asm("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+}
+__device__ __forceinline__ void swap16(float &a, float &b) {
+  asm("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+}
+
+// In-wave 16x16 transpose between (lane >> 2) and the register index, for each lane & 3:
+// lane (i, a) register k  ->  lane (k, a) register i.  Four butterfly exchanges at lane
+// distances 32, 16 (permlane swaps) and 8, 4 (DPP row rotate / shift with bank masks);
+// no LDS.  Verified on hardware by tools/probes/transpose_probe.hip.
+__device__ __forceinline__ void transpose16(float (&v)[16]) {
+#pragma unroll
+  for (int k = 0; k < 16; ++k)
+    if (!(k & 8)) swap32(v[k], v[k | 8]);
+#pragma unroll
+  for (int k = 0; k < 16; ++k)
+    if (!(k & 4)) swap16(v[k], v[k | 4]);
+#pragma unroll
+  for (int k = 0; k < 16; ++k)
+    if (!(k & 2)) {
+      const float A = v[k], B = v[k | 2];
+      v[k | 2] = dpp_mov<0x128, 0x3>(B, A);   // row_ror:8 into lanes 0-7 of each row
+      v[k] = dpp_mov<0x128, 0xC>(A, B);       // row_ror:8 into lanes 8-15
+    }
+#pragma unroll
+  for (int k = 0; k < 16; ++k)
+    if (!(k & 1)) {
+      const float A = v[k], B = v[k | 1];
+      v[k | 1] = dpp_mov<0x104, 0x5>(B, A);   // row_shl:4 into banks 0, 2
+      v[k] = dpp_mov<0x114, 0xA>(A, B);       // row_shr:4 into banks 1, 3
+    }
+}
+
+// one 16-byte store to a 4-byte-aligned address (rows of [bins; frames] start anywhere).
+// hipcc splits an under-aligned 16-byte store into dwordx3 + dword; the hardware takes
+// dwordx4 at dword alignment, so emit it directly.  The trailing s_nop keeps the data
+// registers intact until the store has read them (asm stores are invisible to hipcc's
+// hazard and waitcnt bookkeeping; an uncounted younger store only makes its waits stricter).
+using f32x4 = __attribute__((ext_vector_type(4))) float;
+__device__ __forceinline__ void store4_unaligned(float *dst, float a, float b, float c, float d) {
+  const f32x4 v = {a, b, c, d};
+  asm volatile("global_store_dwordx4 %0, %1, off\n\ts_nop 1" : : "v"(dst), "v"(v) : "memory");
 }
 
 __device__ __forceinline__ float bperm(int byte_addr, float v) {
@@ -114,15 +187,12 @@ struct FastArgs {
 };
 
 constexpr int kWaves = 16, kFT = 16;            // one frame per wave per tile
-constexpr int kXRow = 68;                       // floats per exchange row (64 + 4 pad)
-constexpr int kXWave = 16 * kXRow;              // floats per wave (re and im go through in turn)
 constexpr int kTileStride = kFT + 1;            // floats per tile row
-constexpr size_t kExchBytes = (size_t)kWaves * kXWave * sizeof(float);
 constexpr size_t kTileBytes = ((size_t)kBins * kTileStride * sizeof(float) + 15) / 16 * 16;
 constexpr size_t kTabABytes = 16 * 64 * sizeof(float2);   // W_M^(l k1)          [k1][lane]
 constexpr size_t kTabPBytes = 16 * 64 * sizeof(float2);   // post-pass twiddles  [q][lane]
 constexpr size_t kTabBBytes = 16 * 4 * sizeof(float2);    // W_64^(a q)          [q][a]
-constexpr size_t kFastLds = kExchBytes + kTileBytes + kTabABytes + kTabPBytes + kTabBBytes;
+constexpr size_t kFastLds = 2 * kTileBytes + kTabABytes + kTabPBytes + kTabBBytes;   // two tiles
 static_assert(kFastLds <= 160 * 1024, "LDS budget");
 
 // 16 coalesced 8-byte loads of one 8 KB window: lane l takes elements l + 64 j.
@@ -171,11 +241,10 @@ __global__ void __launch_bounds__(1024) stft2048_power_kernel(FastArgs a) {
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // provably wave-uniform (scalar)
-  float *exch = reinterpret_cast<float *>(smem) + wave * kXWave;
-  float *tile = reinterpret_cast<float *>(smem + kExchBytes);
-  float2 *tabA = reinterpret_cast<float2 *>(smem + kExchBytes + kTileBytes);
-  float2 *tabP = reinterpret_cast<float2 *>(smem + kExchBytes + kTileBytes + kTabABytes);
-  float2 *tabB = reinterpret_cast<float2 *>(smem + kExchBytes + kTileBytes + kTabABytes + kTabPBytes);
+  float *tiles = reinterpret_cast<float *>(smem);   // two [1025][17] tiles, used alternately
+  float2 *tabA = reinterpret_cast<float2 *>(smem + 2 * kTileBytes);
+  float2 *tabP = reinterpret_cast<float2 *>(smem + 2 * kTileBytes + kTabABytes);
+  float2 *tabB = reinterpret_cast<float2 *>(smem + 2 * kTileBytes + kTabABytes + kTabPBytes);
 
   // XCD-aware block -> (clip, tile group): blocks that share an XCD (b % 8) get a
   // contiguous range of virtual ids, i.e. whole clips, so halo re-reads and the
@@ -213,29 +282,32 @@ __global__ void __launch_bounds__(1024) stft2048_power_kernel(FastArgs a) {
     addr_0 = ((((r0 & 1) << 1) | (r0 >> 1))) * 4;        // its lane = bitrev2(r0)
   }
   const bool low4 = lane < 4;
-  const int exch_rd = k1 * kXRow + qa;                    // + 4 i
   const int tile_row0 = 4 * k1 + r;                       // + 64 q   (row' = 4 (k1 + 16 q) + r)
 
   const int t_begin = group * a.tiles_per_group;
   int t_end = t_begin + a.tiles_per_group;
   if (t_end > a.tiles_per_clip) t_end = a.tiles_per_clip;
 
-  // prefetch the first frame of this wave
-  float2 raw[16];
+  // prefetch the first frame of this wave and the (half-scaled) analysis window
+  float2 raw[16], win[16];
   bool have = (int64_t)t_begin * kFT + wave < a.count;
-  if (have) load_frame<ALIGNED>(a, x, a.p0 + (int64_t)t_begin * kFT + wave, lane, raw);
+  load_frame<ALIGNED>(a, x, a.p0 + (int64_t)t_begin * kFT + (have ? wave : 0), lane, raw);
+  load16_f2(reinterpret_cast<const float2 *>(a.hwin), lane, win);
   __syncthreads();   // tables visible
+  int cur = 0;
 
+#ifdef SMX_STAMPS
+  unsigned long long stamp_sum[kStampSlots] = {0}, stamp_prev;
+  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(stamp_prev)::"memory");
+#endif
   for (int t = t_begin; t < t_end; ++t) {
     const int64_t f0 = (int64_t)t * kFT;
+    SMX_STAMP(0);
     if (have) {   // wave-uniform
       c32 v[16];
-      {
-        float2 w[16];   // half-scaled analysis window, streamed from L1/L2 (8 KB, shared by every wave)
-        load16_f2(reinterpret_cast<const float2 *>(a.hwin), lane, w);
 #pragma unroll
-        for (int j = 0; j < 16; ++j) v[j] = {raw[j].x * w[j].x, raw[j].y * w[j].y};
-      }
+      for (int j = 0; j < 16; ++j) v[j] = {raw[j].x * win[j].x, raw[j].y * win[j].y};
+      SMX_STAMP(1);
       __builtin_amdgcn_sched_barrier(0);
       // A: radix-16 over j, twiddle W_M^(l k1)
       fft16(v);
@@ -245,22 +317,17 @@ __global__ void __launch_bounds__(1024) stft2048_power_kernel(FastArgs a) {
         const float2 w = tabA_l[64 * k];
         v[k] = cmul(v[k], c32{w.x, w.y});
       }
-      // X: transpose through LDS, real parts then imaginary parts (wave-private
-      // region; the LDS operations of one wave execute in order)
-      __builtin_amdgcn_sched_barrier(0);
-      float tre[16];
+      // X: in-wave transpose: lane (i, a) register k1 -> lane (k1, a) register i  (no LDS)
+      {
+        float re[16], im[16];
 #pragma unroll
-      for (int k = 0; k < 16; ++k) exch[k * kXRow + lane] = v[k].x;
-      __builtin_amdgcn_wave_barrier();
+        for (int k = 0; k < 16; ++k) { re[k] = v[k].x; im[k] = v[k].y; }
+        transpose16(re);
+        transpose16(im);
 #pragma unroll
-      for (int i = 0; i < 16; ++i) tre[i] = exch[exch_rd + 4 * i];
-      __builtin_amdgcn_wave_barrier();
-#pragma unroll
-      for (int k = 0; k < 16; ++k) exch[k * kXRow + lane] = v[k].y;
-      __builtin_amdgcn_wave_barrier();
-#pragma unroll
-      for (int i = 0; i < 16; ++i) v[i] = {tre[i], exch[exch_rd + 4 * i]};
-      __builtin_amdgcn_wave_barrier();
+        for (int k = 0; k < 16; ++k) v[k] = {re[k], im[k]};
+      }
+      SMX_STAMP(3);
       __builtin_amdgcn_sched_barrier(0);
       // B: radix-16 over i, twiddle W_64^(a q)
       fft16(v);
@@ -270,6 +337,7 @@ __global__ void __launch_bounds__(1024) stft2048_power_kernel(FastArgs a) {
         const float2 wb = tabB_l[4 * q];
         v[q] = cmul(v[q], c32{wb.x, wb.y});
       }
+      SMX_STAMP(4);
       __builtin_amdgcn_sched_barrier(0);
       // C: radix-4 across the quad (DPP).  lane a ends with r = bitrev2(a).
 #pragma unroll
@@ -281,8 +349,10 @@ __global__ void __launch_bounds__(1024) stft2048_power_kernel(FastArgs a) {
         v[q].x = fmaf(w.x, s2, dpp_quad<0xB1>(w.x));
         v[q].y = fmaf(w.y, s2, dpp_quad<0xB1>(w.y));
       }
+      SMX_STAMP(5);
       __builtin_amdgcn_sched_barrier(0);
       // P: real-FFT post-pass.  provider rotation for the k1 = 0 lanes.
+      float *tile = tiles + cur * (kTileBytes / sizeof(float));
       float *col = tile + wave;
       const float nyq = 2.0f * (v[0].x - v[0].y);   // X[M] = Re Z0 - Im Z0 (true scale), lane 0
 #pragma unroll
@@ -309,12 +379,22 @@ __global__ void __launch_bounds__(1024) stft2048_power_kernel(FastArgs a) {
         col[kM * kTileStride] = pw;
       }
     }
-    // prefetch this wave's frame of the next tile; the loads fly during the flush
-    have = (t + 1 < t_end) && (f0 + kFT + wave < a.count);
-    if (have) load_frame<ALIGNED>(a, x, a.p0 + f0 + kFT + wave, lane, raw);
-    __syncthreads();
-    // ---- flush tile -> out[clip][bin][frame], frames fastest -------------------
+    SMX_STAMP(6);
+    // prefetch this wave's frame of the next tile (in flight across the barrier and the flush)
+    // (unconditional: without a next frame the tile's first frame is re-read and ignored, so
+    //  raw/win never carry old values around the loop and stay out of the compute's registers)
+    const bool have_next = (t + 1 < t_end) && (f0 + kFT + wave < a.count);
+    load_frame<ALIGNED>(a, x, a.p0 + f0 + (have_next ? kFT + wave : 0), lane, raw);
+    SMX_STAMP(7);
+    __syncthreads();   // the ONLY barrier per tile: tile[cur] complete; tile[cur^1] free again
+    SMX_STAMP(8);
+    // window for the next frame: issued BEFORE the flush stores so that waiting for it
+    // (in-order vmcnt) never waits for the stores
+    load16_f2(reinterpret_cast<const float2 *>(a.hwin), lane, win);
+    // ---- flush tile[cur] -> out[clip][bin][frame], frames fastest; the stores drain
+    // while the next tile is computed into the other buffer ----------------------------
     {
+      const float *tile = tiles + cur * (kTileBytes / sizeof(float));
       const int hsel = lane >> 5, jj = (lane & 31) >> 2, g = lane & 3;
       const int rloc = (jj & 3) + 16 * (jj >> 2) + 4 * hsel;
       float *obase = a.out + (clip * kBins) * a.out_stride + a.out_offset + f0 + 4 * g;
@@ -327,8 +407,7 @@ __global__ void __launch_bounds__(1024) stft2048_power_kernel(FastArgs a) {
         const float v0 = src[0], v1 = src[1], v2 = src[2], v3 = src[3];
         float *dst = obase + (int64_t)bin * a.out_stride;
         if (fleft >= 4) {
-          struct __attribute__((packed, aligned(4))) f4 { float a, b, c, d; };
-          *reinterpret_cast<f4 *>(dst) = f4{v0, v1, v2, v3};
+          store4_unaligned(dst, v0, v1, v2, v3);
         } else {
           if (fleft > 0) dst[0] = v0;
           if (fleft > 1) dst[1] = v1;
@@ -342,8 +421,14 @@ __global__ void __launch_bounds__(1024) stft2048_power_kernel(FastArgs a) {
               tile[kM * kTileStride + lane];
       }
     }
-    __syncthreads();
+    SMX_STAMP(9);
+    have = have_next;
+    cur ^= 1;
   }
+#ifdef SMX_STAMPS
+  if (lane == 0 && blockIdx.x < 4096)
+    for (int i = 0; i < kStampSlots; ++i) g_stamp_sums[(blockIdx.x * 16 + wave) * kStampSlots + i] = stamp_sum[i];
+#endif
 }
 
 }  // namespace
@@ -449,6 +534,12 @@ void launch_border(const StftJob &job, int64_t pa, int64_t pb) {
 }
 
 }  // namespace
+
+#ifdef SMX_STAMPS
+extern "C" int smx_debug_read_stamps(unsigned long long *out, int count) {
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_stamp_sums), sizeof(unsigned long long) * (size_t)count);
+}
+#endif
 
 bool launch_stft_fast(const StftJob &job) {
   const smx_stft_config &c = *job.cfg;

@@ -1,0 +1,31 @@
+"""Diagnostic: per-phase cycle shares of the fused STFT kernel (stamps build, make STAMPS=1)."""
+import ctypes, os, sys
+import numpy as np
+import torch
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+lib = ctypes.CDLL(os.path.join(ROOT, "soundml_amd", "lib_stamps", "libsoundml_amd.so"))
+i64, vp = ctypes.c_int64, ctypes.c_void_p
+h = vp()
+lib.smx_stft_config_create.argtypes = [i64, i64, i64, ctypes.c_int, ctypes.c_int, ctypes.c_double, ctypes.c_int, ctypes.c_int, vp, ctypes.POINTER(vp)]
+assert lib.smx_stft_config_create(2048, -(2**63), 512, 0, 0, 0.0, 0, 0, None, ctypes.byref(h)) == 0
+clips, n = 256, 480000
+x = torch.rand(clips, n, device="cuda") * 2 - 1
+out = torch.empty(clips, 1025, 938, device="cuda")
+lib.smx_stft_power_range_f32_dev.argtypes = [vp, vp, i64, i64, i64, i64, i64, ctypes.c_double, vp, vp]
+for _ in range(2):
+    # interior frames only (2..936): one launch of the fused kernel
+    rc = lib.smx_stft_power_range_f32_dev(h, vp(x.data_ptr()), clips, n, n, 2, 936, 2.0, vp(out.data_ptr()), None)
+    assert rc == 0
+torch.cuda.synchronize()
+S = 12
+buf = np.zeros(2048 * 16 * S, dtype=np.uint64)
+assert lib.smx_debug_read_stamps(buf.ctypes.data_as(ctypes.POINTER(ctypes.c_ulonglong)), buf.size) == 0
+st = buf.reshape(2048, 16, S).astype(np.float64)
+tot = st.sum(axis=2)
+names = ["loop top", "win load+mul", "fft A+tw", "exchange", "fft B+tw", "dpp radix4", "post+tile wr", "prefetch issue",
+         "barrier1", "flush", "barrier2", "-"]
+mean = st.mean(axis=(0, 1))
+print("cycles per workgroup-wave (8 tiles): total %.0f" % tot.mean())
+for i, nm in enumerate(names[:11]):
+    print("  %-16s %9.0f  %5.1f%%   (per tile %.0f)" % (nm, mean[i], 100 * mean[i] / mean.sum(), mean[i] / 8))
+print("per-wave totals (mean over WGs):", np.round(tot.mean(axis=0) / 8))
