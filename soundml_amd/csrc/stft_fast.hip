@@ -32,6 +32,8 @@
 //
 // Algorithmic HBM bytes per frame: hop*4 read + 1025*4 written = 6148 B at
 // hop 512.  Flops per frame ~= 50k VALU lane-ops.
+#include <cstdlib>
+
 #include "smx_internal.hpp"
 
 namespace smx {
@@ -56,8 +58,9 @@ __device__ __forceinline__ void fft4(c32 &a, c32 &b, c32 &c, c32 &d) {
   d = t1 - t3;
 }
 
-// 16-point forward DFT, natural order in and out, fully in registers (4 x 4).
-__device__ __forceinline__ void fft16(c32 (&v)[16]) {
+// 16-point forward DFT, natural order in and out, fully in registers (4 x 4), in two passes
+// (pass 1: four 4-point DFTs + inner twiddles; pass 2: four 4-point DFTs + index transpose).
+__device__ __forceinline__ void fft16_pass1(c32 (&v)[16]) {
   constexpr float c1 = 0.92387953251128674f, s1 = 0.38268343236508977f;
   constexpr float h = 0.70710678118654752f;
 #pragma unroll
@@ -72,6 +75,8 @@ __device__ __forceinline__ void fft16(c32 (&v)[16]) {
   v[4 * 3 + 1] = cmul(v[4 * 3 + 1], c32{s1, -c1});   // W^3
   v[4 * 3 + 2] = cmul(v[4 * 3 + 2], c32{-h, -h});    // W^6
   v[4 * 3 + 3] = cmul(v[4 * 3 + 3], c32{-c1, s1});   // W^9
+}
+__device__ __forceinline__ void fft16_pass2(c32 (&v)[16]) {
 #pragma unroll
   for (int k0 = 0; k0 < 4; ++k0) fft4(v[4 * k0], v[4 * k0 + 1], v[4 * k0 + 2], v[4 * k0 + 3]);
   // X[k0 + 4 k1] sits at v[4 k0 + k1]: transpose the 4x4 index
@@ -82,6 +87,10 @@ __device__ __forceinline__ void fft16(c32 (&v)[16]) {
     for (int k1 = 0; k1 < 4; ++k1) t[k0 + 4 * k1] = v[4 * k0 + k1];
 #pragma unroll
   for (int i = 0; i < 16; ++i) v[i] = t[i];
+}
+__device__ __forceinline__ void fft16(c32 (&v)[16]) {
+  fft16_pass1(v);
+  fft16_pass2(v);
 }
 
 #ifdef SMX_STAMPS
@@ -157,9 +166,10 @@ __device__ __forceinline__ void transpose16(float (&v)[16]) {
 // registers intact until the store has read them (asm stores are invisible to hipcc's
 // hazard and waitcnt bookkeeping; an uncounted younger store only makes its waits stricter).
 using f32x4 = __attribute__((ext_vector_type(4))) float;
-__device__ __forceinline__ void store4_unaligned(float *dst, float a, float b, float c, float d) {
+__device__ __forceinline__ void store4_unaligned(float *base /* wave-uniform */, unsigned byte_off, float a,
+                                                 float b, float c, float d) {
   const f32x4 v = {a, b, c, d};
-  asm volatile("global_store_dwordx4 %0, %1, off\n\ts_nop 1" : : "v"(dst), "v"(v) : "memory");
+  asm volatile("global_store_dwordx4 %0, %1, %2\n\ts_nop 1" : : "v"(byte_off), "v"(v), "s"(base) : "memory");
 }
 
 __device__ __forceinline__ float bperm(int byte_addr, float v) {
@@ -183,16 +193,21 @@ struct FastArgs {
   int tiles_per_clip, groups_per_clip, tiles_per_group;
   int64_t blocks;
   int pmode;            // 2: power 2, 1: power 1, 0: general
+  int abl_nostore;      // diagnostic builds only
   float half_power;
 };
 
 constexpr int kWaves = 16, kFT = 16;            // one frame per wave per tile
-constexpr int kTileStride = kFT + 1;            // floats per tile row
-constexpr size_t kTileBytes = ((size_t)kBins * kTileStride * sizeof(float) + 15) / 16 * 16;
-constexpr size_t kTabABytes = 16 * 64 * sizeof(float2);   // W_M^(l k1)          [k1][lane]
-constexpr size_t kTabPBytes = 16 * 64 * sizeof(float2);   // post-pass twiddles  [q][lane]
-constexpr size_t kTabBBytes = 16 * 4 * sizeof(float2);    // W_64^(a q)          [q][a]
-constexpr size_t kFastLds = 2 * kTileBytes + kTabABytes + kTabPBytes + kTabBBytes;   // two tiles
+constexpr int kTileStride = kFT + 1;            // floats per tile row (pad column 16)
+// A tile holds bins 0..1023 as rows; bin 1024 (Nyquist) of frame f lives in the otherwise
+// unused pad slot of row f.  This, and dropping the trivial k1 = 0 twiddle row, is what makes
+// two tiles + all tables + the window fit the 160 KB of LDS exactly.
+constexpr size_t kTileBytes = (size_t)kM * kTileStride * sizeof(float);                  // 69,632
+constexpr size_t kTabABytes = 15 * 64 * sizeof(float2);   // W_M^(l k1), k1 = 1..15     [k1-1][lane]
+constexpr size_t kTabPBytes = 16 * 64 * sizeof(float2);   // post-pass twiddles         [q][lane]
+constexpr size_t kTabBBytes = 16 * 4 * sizeof(float2);    // W_64^(a q)                 [q][a]
+constexpr size_t kWinBytes = (size_t)kM * sizeof(float2); // 0.5 * window as (even, odd) pairs
+constexpr size_t kFastLds = 2 * kTileBytes + kTabABytes + kTabPBytes + kTabBBytes + kWinBytes;
 static_assert(kFastLds <= 160 * 1024, "LDS budget");
 
 // 16 coalesced 8-byte loads of one 8 KB window: lane l takes elements l + 64 j.
@@ -234,8 +249,56 @@ __device__ __forceinline__ void load_frame(const FastArgs &a, const float *x, in
   }
 }
 
+// One quarter of a wave's share of a finished tile: 16 tile rows (bins) x 4 frames per lane ->
+// out[clip][bin][f0 + 4g .. +3].  LDS reads are bank-conflict free (row set {0-3,16-19}+4h per
+// half-wave); each 4-lane group stores one 64-byte run.  Called between the FFT stages of the
+// NEXT frame so the store traffic is spread over the arithmetic instead of bursting.
+// Addresses: `obase` (clip / tile origin) is wave-uniform and stays in SGPRs; lanes carry one
+// 32-bit byte offset (goff0) and one LDS offset (row0), the four parts differ by constants.
+struct FlushLane {
+  int row0;          // tile row of part 0: 32 * wave + rloc
+  unsigned goff0;    // byte offset of out[bin0][4 g] from the tile origin
+  int g;
+};
+__device__ __forceinline__ void flush_part(const FastArgs &a, const float *tile, int it, const FlushLane &fl,
+                                           float *obase, int64_t frames_left, int wave, int lane) {
+  const int row = fl.row0 + 512 * (it >> 1) + 8 * (it & 1);
+  const float *src = tile + row * kTileStride + 4 * fl.g;
+  const float v0 = src[0], v1 = src[1], v2 = src[2], v3 = src[3];
+  // bin(row + 8) = bin + 2, bin(row + 512) = bin + 128
+  const unsigned goff = fl.goff0 + (unsigned)(2 * (it & 1) + 128 * (it >> 1)) * (unsigned)a.out_stride * 4u;
+  const int64_t fleft = frames_left - 4 * fl.g;    // frames remaining from this column group
+#ifdef SMX_DIAG
+  if (a.abl_nostore) {   // timing-only ablation: keep the LDS reads alive, drop the HBM stores
+    asm volatile("" ::"v"(v0), "v"(v1), "v"(v2), "v"(v3));
+    return;
+  }
+#endif
+  if (fleft >= 4) {
+    store4_unaligned(obase, goff, v0, v1, v2, v3);
+  } else {
+    float *dst = reinterpret_cast<float *>(reinterpret_cast<char *>(obase) + goff);
+    if (fleft > 0) dst[0] = v0;
+    if (fleft > 1) dst[1] = v1;
+    if (fleft > 2) dst[2] = v2;
+  }
+  if (it == 3 && wave == 0 && lane < 16) {   // bin 1024 (row 1024): 16 frames by 16 lanes
+    if (lane < frames_left) obase[(int64_t)kM * a.out_stride + lane] = tile[lane * kTileStride + kFT];
+  }
+}
+
 // SQUARE = power 2 (no per-bin branch); otherwise |X|^p through pmode / half_power
-template <bool ALIGNED, bool SQUARE>
+#if defined(SMX_STAMPS) && !defined(SMX_DIAG)
+#define SMX_DIAG 1
+#endif
+#ifdef SMX_DIAG
+#define SMX_ABL_PARAM , int ABL
+#define SMX_ABL(n) (ABL == (n))
+#else
+#define SMX_ABL_PARAM
+#define SMX_ABL(n) false
+#endif
+template <bool ALIGNED, bool SQUARE SMX_ABL_PARAM>
 __global__ void __launch_bounds__(1024) stft2048_power_kernel(FastArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x;
@@ -245,6 +308,7 @@ __global__ void __launch_bounds__(1024) stft2048_power_kernel(FastArgs a) {
   float2 *tabA = reinterpret_cast<float2 *>(smem + 2 * kTileBytes);
   float2 *tabP = reinterpret_cast<float2 *>(smem + 2 * kTileBytes + kTabABytes);
   float2 *tabB = reinterpret_cast<float2 *>(smem + 2 * kTileBytes + kTabABytes + kTabPBytes);
+  float2 *winL = reinterpret_cast<float2 *>(smem + 2 * kTileBytes + kTabABytes + kTabPBytes + kTabBBytes);
 
   // XCD-aware block -> (clip, tile group): blocks that share an XCD (b % 8) get a
   // contiguous range of virtual ids, i.e. whole clips, so halo re-reads and the
@@ -262,10 +326,12 @@ __global__ void __launch_bounds__(1024) stft2048_power_kernel(FastArgs a) {
   const int k1 = lane >> 2, qa = lane & 3;
   const int r = ((qa & 1) << 1) | (qa >> 1);
   // workgroup-shared twiddle tables in LDS: wave w fills row w of each
-  tabA[wave * 64 + lane] = a.w_m[lane * wave];                 // W_M^(l k1), k1 = wave
+  if (wave > 0) tabA[(wave - 1) * 64 + lane] = a.w_m[lane * wave];   // W_M^(l k1), k1 = wave
+  winL[tid] = reinterpret_cast<const float2 *>(a.hwin)[tid];         // the whole window, once per workgroup
   tabP[wave * 64 + lane] = a.w_n[k1 + 256 * r + 16 * wave];    // exp(-2 pi i k / N), k = k1 + 16 q + 256 r
   if (lane < 4) tabB[wave * 4 + lane] = a.w_m[16 * lane * wave];  // W_64^(a q)
-  const float2 *tabA_l = tabA + lane;
+  const float2 *tabA_l = tabA + lane - 64;   // row k1 - 1
+  const float2 *winL_l = winL + lane;
   const float2 *tabP_l = tabP + lane;
   const float2 *tabB_l = tabB + qa;
 
@@ -288,13 +354,28 @@ __global__ void __launch_bounds__(1024) stft2048_power_kernel(FastArgs a) {
   int t_end = t_begin + a.tiles_per_group;
   if (t_end > a.tiles_per_clip) t_end = a.tiles_per_clip;
 
-  // prefetch the first frame of this wave and the (half-scaled) analysis window
-  float2 raw[16], win[16];
+  // prefetch the first frame of this wave
+  float2 raw[16];
   bool have = (int64_t)t_begin * kFT + wave < a.count;
-  load_frame<ALIGNED>(a, x, a.p0 + (int64_t)t_begin * kFT + (have ? wave : 0), lane, raw);
-  load16_f2(reinterpret_cast<const float2 *>(a.hwin), lane, win);
+  if constexpr (SMX_ABL(2) || SMX_ABL(3)) {
+#pragma unroll
+    for (int j = 0; j < 16; ++j) raw[j] = make_float2((float)(lane + j), (float)(lane - j));
+  } else {
+    load_frame<ALIGNED>(a, x, a.p0 + (int64_t)t_begin * kFT + (have ? wave : 0), lane, raw);
+  }
   __syncthreads();   // tables visible
   int cur = 0;
+  bool pending = false;      // tile[cur ^ 1] holds the finished previous tile, not yet stored
+  int64_t pend_f0 = 0;
+  FlushLane fl;
+  {
+    const int hsel = lane >> 5, jj = (lane & 31) >> 2;
+    fl.g = lane & 3;
+    fl.row0 = 32 * wave + (jj & 3) + 16 * (jj >> 2) + 4 * hsel;
+    const int bin0 = (fl.row0 & 3) * 256 + (fl.row0 >> 2);
+    fl.goff0 = ((unsigned)bin0 * (unsigned)a.out_stride + 4u * fl.g) * 4u;
+  }
+  float *const clip_out = a.out + (clip * kBins) * a.out_stride + a.out_offset;   // wave-uniform
 
 #ifdef SMX_STAMPS
   unsigned long long stamp_sum[kStampSlots] = {0}, stamp_prev;
@@ -306,37 +387,62 @@ __global__ void __launch_bounds__(1024) stft2048_power_kernel(FastArgs a) {
     if (have) {   // wave-uniform
       c32 v[16];
 #pragma unroll
-      for (int j = 0; j < 16; ++j) v[j] = {raw[j].x * win[j].x, raw[j].y * win[j].y};
+      for (int j = 0; j < 16; ++j) {
+        const float2 w = winL_l[64 * j];
+        v[j] = {raw[j].x * w.x, raw[j].y * w.y};
+      }
+      // The previous tile's stores are spread over 16 points of this frame's arithmetic and
+      // staggered across waves (point p serves the 4 waves with (wave & 3) == (p & 3), part p >> 2),
+      // so at most 4 KB of stores enter the memory pipeline at a time.
+      const float *ptile = tiles + (cur ^ 1) * (kTileBytes / sizeof(float));
+      float *const pout = clip_out + pend_f0;
+      const int64_t pleft = a.count - pend_f0;
+      const int wslot = pending ? (wave & 3) : -1;      // scalar
+#define SMX_FLUSH_POINT(p) \
+  if (wslot == ((p) & 3)) flush_part(a, ptile, (p) >> 2, fl, pout, pleft, wave, lane)
+      SMX_FLUSH_POINT(0);
       SMX_STAMP(1);
       __builtin_amdgcn_sched_barrier(0);
       // A: radix-16 over j, twiddle W_M^(l k1)
-      fft16(v);
+      fft16_pass1(v);
+      SMX_FLUSH_POINT(1);
+      fft16_pass2(v);
+      SMX_FLUSH_POINT(2);
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int k = 1; k < 16; ++k) {
         const float2 w = tabA_l[64 * k];
         v[k] = cmul(v[k], c32{w.x, w.y});
       }
+      SMX_FLUSH_POINT(3);
+      SMX_STAMP(2);
+      __builtin_amdgcn_sched_barrier(0);
       // X: in-wave transpose: lane (i, a) register k1 -> lane (k1, a) register i  (no LDS)
       {
         float re[16], im[16];
 #pragma unroll
         for (int k = 0; k < 16; ++k) { re[k] = v[k].x; im[k] = v[k].y; }
-        transpose16(re);
-        transpose16(im);
+        if constexpr (!SMX_ABL(5)) transpose16(re);
+        SMX_FLUSH_POINT(4);
+        if constexpr (!SMX_ABL(5)) transpose16(im);
 #pragma unroll
         for (int k = 0; k < 16; ++k) v[k] = {re[k], im[k]};
       }
+      SMX_FLUSH_POINT(5);
       SMX_STAMP(3);
       __builtin_amdgcn_sched_barrier(0);
       // B: radix-16 over i, twiddle W_64^(a q)
-      fft16(v);
+      fft16_pass1(v);
+      SMX_FLUSH_POINT(6);
+      fft16_pass2(v);
+      SMX_FLUSH_POINT(7);
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int q = 1; q < 16; ++q) {
         const float2 wb = tabB_l[4 * q];
         v[q] = cmul(v[q], c32{wb.x, wb.y});
       }
+      SMX_FLUSH_POINT(8);
       SMX_STAMP(4);
       __builtin_amdgcn_sched_barrier(0);
       // C: radix-4 across the quad (DPP).  lane a ends with r = bitrev2(a).
@@ -348,7 +454,9 @@ __global__ void __launch_bounds__(1024) stft2048_power_kernel(FastArgs a) {
         const c32 w = rot ? c32{u.y, -u.x} : u;
         v[q].x = fmaf(w.x, s2, dpp_quad<0xB1>(w.x));
         v[q].y = fmaf(w.y, s2, dpp_quad<0xB1>(w.y));
+        if (q == 7) { SMX_FLUSH_POINT(9); }
       }
+      SMX_FLUSH_POINT(10);
       SMX_STAMP(5);
       __builtin_amdgcn_sched_barrier(0);
       // P: real-FFT post-pass.  provider rotation for the k1 = 0 lanes.
@@ -361,8 +469,8 @@ __global__ void __launch_bounds__(1024) stft2048_power_kernel(FastArgs a) {
         const int m = 15 - q;
         const float sx = low4 ? v[(m + 1) & 15].x : v[m].x;
         const float sy = low4 ? v[(m + 1) & 15].y : v[m].y;
-        const float px = bperm(addr, sx);
-        const float py = bperm(addr, sy);
+        const float px = SMX_ABL(4) ? sx : bperm(addr, sx);
+        const float py = SMX_ABL(4) ? sy : bperm(addr, sy);
         const c32 e = {v[q].x + px, v[q].y - py};
         const c32 d = {v[q].x - px, v[q].y + py};
         const float2 w = tabP_l[64 * q];
@@ -371,59 +479,51 @@ __global__ void __launch_bounds__(1024) stft2048_power_kernel(FastArgs a) {
         float pw = tr * tr + ti * ti;
         if constexpr (!SQUARE) pw = a.pmode == 1 ? sqrtf(pw) : __powf(pw, a.half_power);
         col[(tile_row0 + 64 * q) * kTileStride] = pw;
-        if ((q & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+        if ((q & 3) == 3) {
+          __builtin_amdgcn_sched_barrier(0);
+          if (q == 3) { SMX_FLUSH_POINT(11); }
+          if (q == 7) { SMX_FLUSH_POINT(12); }
+          if (q == 11) { SMX_FLUSH_POINT(13); }
+          if (q == 15) { SMX_FLUSH_POINT(14); SMX_FLUSH_POINT(15); }
+        }
       }
+#undef SMX_FLUSH_POINT
       if (lane == 0) {
         float pw = nyq * nyq;
         if constexpr (!SQUARE) pw = a.pmode == 1 ? fabsf(nyq) : __powf(pw, a.half_power);
-        col[kM * kTileStride] = pw;
+        tile[wave * kTileStride + kFT] = pw;   // Nyquist bin of frame `wave`: pad slot of row `wave`
       }
+    }
+    else if (pending) {   // no frame for this wave in this tile: still store its share of the previous one
+      const float *ptile = tiles + (cur ^ 1) * (kTileBytes / sizeof(float));
+#pragma unroll
+      for (int it = 0; it < 4; ++it) flush_part(a, ptile, it, fl, clip_out + pend_f0, a.count - pend_f0, wave, lane);
     }
     SMX_STAMP(6);
     // prefetch this wave's frame of the next tile (in flight across the barrier and the flush)
     // (unconditional: without a next frame the tile's first frame is re-read and ignored, so
     //  raw/win never carry old values around the loop and stay out of the compute's registers)
     const bool have_next = (t + 1 < t_end) && (f0 + kFT + wave < a.count);
-    load_frame<ALIGNED>(a, x, a.p0 + f0 + (have_next ? kFT + wave : 0), lane, raw);
+    if constexpr (SMX_ABL(2) || SMX_ABL(3)) {
+#pragma unroll
+      for (int j = 0; j < 16; ++j) raw[j] = make_float2(raw[j].x + 1.0f, raw[j].y - 1.0f);
+    } else {
+      load_frame<ALIGNED>(a, x, a.p0 + f0 + (have_next ? kFT + wave : 0), lane, raw);
+    }
     SMX_STAMP(7);
     __syncthreads();   // the ONLY barrier per tile: tile[cur] complete; tile[cur^1] free again
     SMX_STAMP(8);
-    // window for the next frame: issued BEFORE the flush stores so that waiting for it
-    // (in-order vmcnt) never waits for the stores
-    load16_f2(reinterpret_cast<const float2 *>(a.hwin), lane, win);
-    // ---- flush tile[cur] -> out[clip][bin][frame], frames fastest; the stores drain
-    // while the next tile is computed into the other buffer ----------------------------
-    {
-      const float *tile = tiles + cur * (kTileBytes / sizeof(float));
-      const int hsel = lane >> 5, jj = (lane & 31) >> 2, g = lane & 3;
-      const int rloc = (jj & 3) + 16 * (jj >> 2) + 4 * hsel;
-      float *obase = a.out + (clip * kBins) * a.out_stride + a.out_offset + f0 + 4 * g;
-      const int64_t fleft = a.count - f0 - 4 * g;    // frames remaining from this column group
-#pragma unroll
-      for (int it = 0; it < 4; ++it) {
-        const int row = 32 * (wave + 16 * (it >> 1)) + 8 * (it & 1) + rloc;
-        const int bin = (row & 3) * 256 + (row >> 2);
-        const float *src = tile + row * kTileStride + 4 * g;
-        const float v0 = src[0], v1 = src[1], v2 = src[2], v3 = src[3];
-        float *dst = obase + (int64_t)bin * a.out_stride;
-        if (fleft >= 4) {
-          store4_unaligned(dst, v0, v1, v2, v3);
-        } else {
-          if (fleft > 0) dst[0] = v0;
-          if (fleft > 1) dst[1] = v1;
-          if (fleft > 2) dst[2] = v2;
-        }
-      }
-      if (wave == 0 && lane < 16) {   // bin 1024 (row 1024): 16 frames by 16 lanes
-        const int64_t fl = a.count - f0;
-        if (lane < fl)
-          a.out[(clip * kBins + kM) * a.out_stride + a.out_offset + f0 + lane] =
-              tile[kM * kTileStride + lane];
-      }
-    }
-    SMX_STAMP(9);
+    // tile[cur] is complete; its stores are interleaved with the next frame's stages
+    pending = true;
+    pend_f0 = f0;
     have = have_next;
     cur ^= 1;
+    SMX_STAMP(9);
+  }
+  if (pending) {   // the last tile of this group
+    const float *ptile = tiles + (cur ^ 1) * (kTileBytes / sizeof(float));
+#pragma unroll
+    for (int it = 0; it < 4; ++it) flush_part(a, ptile, it, fl, clip_out + pend_f0, a.count - pend_f0, wave, lane);
   }
 #ifdef SMX_STAMPS
   if (lane == 0 && blockIdx.x < 4096)
@@ -506,8 +606,20 @@ void launch_interior(const StftJob &job, const float *x, int64_t n, int64_t x_st
   const bool aligned = (c.hop % 2 == 0) && (left % 2 == 0) && (x_stride % 2 == 0) &&
                        (reinterpret_cast<uintptr_t>(x) % 8 == 0);
   const bool square = a.pmode == 2;
+#ifdef SMX_DIAG
+  const char *abl_env = std::getenv("SMX_ABLATE");
+  const int abl = abl_env ? std::atoi(abl_env) : 0;
+  a.abl_nostore = (abl == 1 || abl == 3) ? 1 : 0;
+  auto kernel = abl == 2 ? stft2048_power_kernel<true, true, 2>
+              : abl == 3 ? stft2048_power_kernel<true, true, 3>
+              : abl == 4 ? stft2048_power_kernel<true, true, 4>
+              : abl == 5 ? stft2048_power_kernel<true, true, 5>
+                         : stft2048_power_kernel<true, true, 0>;
+  (void)aligned; (void)square;
+#else
   auto kernel = aligned ? (square ? stft2048_power_kernel<true, true> : stft2048_power_kernel<true, false>)
                         : (square ? stft2048_power_kernel<false, true> : stft2048_power_kernel<false, false>);
+#endif
   SMX_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kernel),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)kFastLds));
   hipLaunchKernelGGL(kernel, dim3((unsigned)a.blocks), dim3(1024), kFastLds, job.stream, a);
@@ -548,6 +660,7 @@ bool launch_stft_fast(const StftJob &job) {
   if (job.mode != OUT_POWER) return false;
   if (job.count <= 0 || job.lead <= 0) return true;
   if (job.lead > 65535) return false;
+  if ((int64_t)kBins * job.out_stride * 4 >= (int64_t(1) << 32)) return false;   // 32-bit row offsets
   // frame p lies inside the signal iff 0 <= p*hop - left and p*hop - left + N <= n
   const int64_t p0 = job.p0, p1 = job.p0 + job.count;
   int64_t i0 = job.left > 0 ? (job.left + c.hop - 1) / c.hop : 0;
