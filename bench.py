@@ -110,10 +110,7 @@ def main():
         dist.barrier()
     torch.cuda.synchronize(dev)
     elapsed = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    elapsed = S.shard.timed_region_max(elapsed, device=dev)
     kernel_ms = sorted(a.elapsed_time(b) for a, b in ev)
     avg_kernel_ms = sum(kernel_ms) / len(kernel_ms)
 

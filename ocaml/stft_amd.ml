@@ -1,0 +1,78 @@
+(* stft_amd.ml -- the OCaml side of the drop-in: the three bodies of stft.ml / mel.ml that the
+   hot path funnels through, re-expressed over the C ABI.  Everything else in Soundml.Stft
+   (Config, frame grid, Kernel state machine, Pipeline stages, synthesis) stays as it is.
+
+   NOT compiled in this repository (no OCaml toolchain in the build image); see INTEGRATION.md
+   for where each definition replaces the reference's. *)
+
+type stft_handle
+type mel_handle
+
+external stft_config_c :
+  int -> int -> int -> int -> int -> float -> int ->
+  (float, Bigarray.float64_elt, Bigarray.c_layout) Bigarray.Array1.t -> stft_handle
+  = "soundml_amd_stft_config_bc" "soundml_amd_stft_config"
+
+(* x, out: flat Bigarray views of contiguous nx storage; lead, n, p0, p1, mode (0 complex, 1 power), power *)
+external stft_range_c :
+  stft_handle -> ('a, 'b, Bigarray.c_layout) Bigarray.Array1.t ->
+  ('c, 'd, Bigarray.c_layout) Bigarray.Array1.t -> int -> int -> int -> int -> int -> float -> unit
+  = "soundml_amd_stft_range_bc" "soundml_amd_stft_range"
+
+external mel_config_c : int -> int -> int -> float -> float -> int -> int -> mel_handle
+  = "soundml_amd_mel_config_bc" "soundml_amd_mel_config"
+
+external mel_apply_c :
+  mel_handle -> ('a, 'b, Bigarray.c_layout) Bigarray.Array1.t ->
+  ('a, 'b, Bigarray.c_layout) Bigarray.Array1.t -> int -> int -> int -> unit
+  = "soundml_amd_mel_apply_bc" "soundml_amd_mel_apply"
+
+external mel_spectrogram_c :
+  stft_handle -> mel_handle -> ('a, 'b, Bigarray.c_layout) Bigarray.Array1.t ->
+  ('a, 'b, Bigarray.c_layout) Bigarray.Array1.t -> int -> int -> float -> unit
+  = "soundml_amd_mel_spectrogram_bc" "soundml_amd_mel_spectrogram"
+
+let flat t = Nx_buffer.to_bigarray1 (Nx.to_buffer (Nx.contiguous t))
+
+let alignment_code = function `Centered -> 0 | `Left -> 1 | `Right -> 2
+let pad_code = function `Reflect -> (0, 0.) | `Constant v -> (1, v) | `Edge -> (2, 0.)
+let scale_code = function `None -> 0 | `Magnitude -> 1 | `Psd -> 2
+
+(* One handle per Stft.Config.t, built lazily from the config's own fields; the window table is
+   the config's float64 window (Window.make), so all eleven window families work unchanged. *)
+let handle_of_config (c : Stft.Config.t) =
+  let pad, pad_value = pad_code (Stft.Config.pad c) in
+  let window =
+    Nx_buffer.to_bigarray1
+      (Nx.to_buffer (Window.make Nx.float64 ~periodic:true (Stft.Config.window c) (Stft.Config.win_length c)))
+  in
+  stft_config_c (Stft.Config.fft_size c) (Stft.Config.win_length c) (Stft.Config.hop c)
+    (alignment_code (Stft.Config.alignment c)) pad pad_value (scale_code (Stft.Config.scale c)) window
+
+(* Replaces stft.ml:632-650 [transform] for the offline face: frames [0, frames) of the whole
+   signal in one device pass (borders included), instead of Kernel.step + Kernel.flush + concat. *)
+let transform cdtype (c : Stft.Config.t) x =
+  let shape = Nx.shape x in
+  let nd = Array.length shape in
+  let n = shape.(nd - 1) in
+  let lead = Array.fold_left ( * ) 1 (Array.sub shape 0 (nd - 1)) in
+  let count = Stft.frames c ~n in
+  let out = Nx.empty cdtype (Array.append (Array.sub shape 0 (nd - 1)) [|Stft.Config.bins c; count|]) in
+  if lead > 0 && count > 0 then
+    stft_range_c (handle_of_config c) (flat x) (Nx_buffer.to_bigarray1 (Nx.to_buffer out)) lead n 0 count 0 0. ;
+  out
+
+(* Replaces stft.ml:687-691 [power_spectrum]: |STFT|^power without materialising the complex
+   spectrum (the fused kernel for fft_size 2048, the generic kernels otherwise). *)
+let power_spectrum ?(power = 2.) (c : Stft.Config.t) x =
+  let shape = Nx.shape x in
+  let nd = Array.length shape in
+  let n = shape.(nd - 1) in
+  let lead = Array.fold_left ( * ) 1 (Array.sub shape 0 (nd - 1)) in
+  let count = Stft.frames c ~n in
+  let out =
+    Nx.empty (Nx.dtype x) (Array.append (Array.sub shape 0 (nd - 1)) [|Stft.Config.bins c; count|])
+  in
+  if lead > 0 && count > 0 then
+    stft_range_c (handle_of_config c) (flat x) (Nx_buffer.to_bigarray1 (Nx.to_buffer out)) lead n 0 count 1 power ;
+  out

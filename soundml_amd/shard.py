@@ -41,3 +41,23 @@ def gather_host(local, group=None):
     parts = [None] * world
     dist.all_gather_object(parts, local.cpu() if hasattr(local, "cpu") else local, group=group)
     return torch.cat([torch.as_tensor(p) for p in parts], dim=0)
+
+
+def timed_region_max(elapsed_seconds: float, device=None, group=None) -> float:
+    """The benchmark's clock: every rank times the same K steps between two barriers; the job's
+    time is the MAX over ranks (one all-reduce of a scalar, outside the data path)."""
+    import torch
+    import torch.distributed as dist
+
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return float(elapsed_seconds)
+    t = torch.tensor([elapsed_seconds], dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
+    return float(t.item())
+
+
+def barrier(group=None) -> None:
+    import torch.distributed as dist
+
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+        dist.barrier(group=group)

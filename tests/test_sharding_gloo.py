@@ -1,0 +1,65 @@
+"""The N>1 path on CPU: two processes over gloo (the production backend is RCCL = "nccl").
+Clips shard embarrassingly, so what must hold is (a) the partition covers every
+clip exactly once, (b) a rank's shard result equals the same slice of the full batch exactly
+(the reference's per-slice law, stft_grid.ml:180-205; checked here on the oracle because the
+HIP path needs a GPU), (c) the timing reduction is the MAX over ranks, (d) the optional host
+gather reassembles the batch in clip order."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from soundml_amd import shard
+
+
+def test_clip_range_partitions():
+    for total in (0, 1, 2, 7, 256, 4096, 4097):
+        for world in (1, 2, 3, 4, 8):
+            seen = []
+            for r in range(world):
+                lo, hi = shard.clip_range(total, world, r)
+                assert 0 <= lo <= hi <= total
+                seen.extend(range(lo, hi))
+                assert hi - lo in (total // world, total // world + 1)
+            assert seen == list(range(total))
+    assert shard.clip_range(4096, 8, 3) == (1536, 2048)      # BASELINE C5: 512 clips per GPU
+    with pytest.raises(ValueError):
+        shard.clip_range(4, 2, 2)
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank, world, port, tmp):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from oracle import soundml_oracle as O
+        rng = np.random.default_rng(123)                  # every rank can regenerate the whole batch
+        x = rng.uniform(-1, 1, size=(5, 3000)).astype(np.float32)
+        c = O.stft_config(256, hop=64)
+        lo, hi = shard.clip_range(x.shape[0], world, rank)
+        local = O.power_spectrum(c, x[lo:hi])             # this rank's shard, no communication
+        full = O.power_spectrum(c, x)
+        assert np.array_equal(local, full[lo:hi])         # shard == slice of the batch, exactly
+        shard.barrier()
+        t = shard.timed_region_max(0.25 + rank)           # MAX over ranks
+        assert t == 0.25 + (world - 1)
+        gathered = shard.gather_host(torch.from_numpy(local))
+        assert np.array_equal(gathered.numpy(), full)
+        open(os.path.join(tmp, "ok%d" % rank), "w").write("ok")
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_ranks_gloo(tmp_path):
+    world = 2
+    mp.spawn(_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    assert all((tmp_path / ("ok%d" % r)).exists() for r in range(world))
