@@ -1,0 +1,34 @@
+"""In-process A/B timing of two builds of libsoundml_amd.so (interleaved rounds, same device, same data):
+  python tools/ab.py soundml_amd/lib_a/libsoundml_amd.so soundml_amd/lib/libsoundml_amd.so
+(methodology: per-variant median and min over interleaved rounds; never compare separate runs/boxes)."""
+import ctypes, os, sys
+import torch
+i64, vp = ctypes.c_int64, ctypes.c_void_p
+paths = sys.argv[1:]
+libs = []
+clips, n = 256, 480000
+x = torch.rand(clips, n, device="cuda") * 2 - 1
+out = torch.empty(clips, 1025, 938, device="cuda")
+for p in paths:
+    lib = ctypes.CDLL(os.path.abspath(p))
+    h = vp()
+    lib.smx_stft_config_create.argtypes = [i64, i64, i64, ctypes.c_int, ctypes.c_int, ctypes.c_double, ctypes.c_int, ctypes.c_int, vp, ctypes.POINTER(vp)]
+    assert lib.smx_stft_config_create(2048, -(2**63), 512, 0, 0, 0.0, 0, 0, None, ctypes.byref(h)) == 0
+    lib.smx_stft_power_range_f32_dev.argtypes = [vp, vp, i64, i64, i64, i64, i64, ctypes.c_double, vp, vp]
+    libs.append((p, lib, h))
+def run(lib, h):
+    assert lib.smx_stft_power_range_f32_dev(h, vp(x.data_ptr()), clips, n, n, 0, 938, 2.0, vp(out.data_ptr()), None) == 0
+for _, lib, h in libs:
+    for _ in range(3): run(lib, h)
+torch.cuda.synchronize()
+ts = {p: [] for p in paths}
+for rnd in range(15):
+    for p, lib, h in libs:
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        for _ in range(4): run(lib, h)
+        b.record(); torch.cuda.synchronize()
+        ts[p].append(a.elapsed_time(b) / 4)
+for p in paths:
+    v = sorted(ts[p])
+    print("%-45s median %.4f ms  min %.4f ms  (%.1f Mframes/s)" % (p, v[len(v) // 2], v[0], clips * 938 / v[len(v) // 2] / 1e3))

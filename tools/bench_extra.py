@@ -1,0 +1,69 @@
+#!/usr/bin/env python3
+"""Secondary measurements (not the bench.py contract): BASELINE configs C1 (plumbing), C3 (mel), C4 (FIR).
+Prints one JSON line per config; parity of each against the oracle is checked on a subset in the same run."""
+import json, os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np
+import torch
+import soundml_amd as S
+from soundml_amd import Stft, Mel, Fir
+from oracle import soundml_oracle as O
+
+
+def timeit(fn, reps=20, warm=3):
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    ts = []
+    for _ in range(reps):
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record(); fn(); b.record(); torch.cuda.synchronize()
+        ts.append(a.elapsed_time(b))
+    ts.sort()
+    return ts[len(ts) // 2], ts[0]
+
+
+def rel_err(got, want):
+    want = np.asarray(want, np.float64)
+    return float(np.max(np.abs(np.asarray(got, np.float64) - want)) / np.max(np.abs(want)))
+
+
+# C1: one 10 s mono 44.1 kHz 440 Hz sine, fft 1024 hop 256 (the reference's example / plumbing config)
+n = 441000
+x1 = np.sin(2 * np.pi * 440.0 * np.arange(n) / 44100.0).astype(np.float32)
+c1 = Stft.Config.create(fft_size=1024, hop=256)
+t0 = time.perf_counter(); p1 = Stft.power_spectrum(c1, x1); host_ms = (time.perf_counter() - t0) * 1e3
+want = O.power_spectrum(O.stft_config(1024, hop=256), x1)
+x1d = torch.from_numpy(x1).cuda()
+med, mn = timeit(lambda: Stft.power_spectrum(c1, x1d))
+print(json.dumps({"config": "C1", "shape": list(p1.shape), "host_call_ms": round(host_ms, 3), "device_ms": round(med, 4),
+                  "peak_bin": int(np.argmax(p1[:, 800])), "max_rel_err_vs_oracle": rel_err(p1, want)}))
+
+# C3: mel spectrogram (128 mels) on the C2 batch
+torch.manual_seed(42)
+x = torch.rand(256, 480000, device="cuda") * 2 - 1
+sc = Stft.Config.create(fft_size=2048, hop=512)
+mc = Mel.Config.create(n_mels=128, sample_rate=48000, fft_size=2048)
+frames = Stft.frames(sc, 480000)
+med, mn = timeit(lambda: S.mel_spectrogram(sc, mc, x), reps=10)
+p = Stft.power_spectrum(sc, x)
+med_apply, _ = timeit(lambda: Mel.apply(mc, p), reps=10)
+m = S.mel_spectrogram(sc, mc, x[:2])
+wm = O.mel_spectrogram(O.stft_config(2048, hop=512), O.mel_config(128, 48000, 2048), x[:2].cpu().numpy())
+flop = 2.0 * 128 * 1025 * 256 * frames
+print(json.dumps({"config": "C3", "mel_spectrogram_ms": round(med, 4), "mel_apply_only_ms": round(med_apply, 4),
+                  "Mframes_per_s": round(256 * frames / med / 1e3, 1), "dense_equiv_TFLOPs_apply": round(flop / med_apply / 1e9, 2),
+                  "apply_GBs": round((256 * frames * (4100 + 512)) / med_apply / 1e6, 1), "max_rel_err_vs_oracle": rel_err(m.cpu().numpy(), wm)}))
+del p
+
+# C4: 8192-tap lowpass on 8 ch x 60 s 48 kHz
+h = Fir.design_lowpass(8192, 0.25, 100.0)
+plan = Fir.Plan.create(h)
+xs = torch.rand(8, 2880000, device="cuda") * 2 - 1
+med, mn = timeit(lambda: Fir.apply(plan, xs), reps=10)
+y = Fir.apply(plan, xs[:1, :100000]).cpu().numpy()
+wy = O.fir_filter(h, xs[:1, :100000].cpu().numpy())
+print(json.dumps({"config": "C4", "fir_ms": round(med, 4), "Msamples_per_s": round(8 * 2880000 / med / 1e3, 1),
+                  "GBs_algorithmic": round(8 * 2880000 * 8 / med / 1e6, 1), "block": plan.block,
+                  "max_abs_err_vs_oracle": float(np.max(np.abs(y.astype(np.float64) - wy)))}))

@@ -119,3 +119,46 @@ for half in range(2):
         banks = (rloc * 17 + 4 * g + c) % 32
         assert len(set(banks)) == 32
 print("index math + bank-conflict model OK")
+
+# ---- pair-sharing post-pass: lane holding Z[k] (q < 8) also produces X[M-k] ------------------
+tile2 = np.full(1024, np.nan); nyq2 = None
+srow0 = np.where(lane >= 4, 67 - (4 * k1 + r), 3 - (4 * k1 + r) + 64)
+writes = collections = 0
+import collections as _c
+cnt = _c.Counter()
+for q in range(8):
+    addr = addr_0 if q == 0 else addr_g
+    p = prov[addr, 15 - q]
+    A = v[:, q]
+    E = A + np.conj(p); D = A - np.conj(p)
+    w = w_n[k1 + 256 * r + 16 * q]
+    P = w * D
+    Xk = (E.real + P.imag) + 1j * (E.imag - P.real)
+    Xm = (E.real - P.imag) + 1j * (-E.imag - P.real)
+    rows_p = 4 * k1 + r + 64 * q
+    for l in range(64):
+        tile2[rows_p[l]] = abs(Xk[l]) ** 2; cnt[rows_p[l]] += 1
+        if not (l < 4 and q == 0):
+            rs = srow0[l] + 64 * (15 - q)
+            tile2[rs] = abs(Xm[l]) ** 2; cnt[rs] += 1
+# lanes 0..3, q = 8: primary only, partner register 8 of lane 3 - rr
+p8 = v[addr_g, 8]
+A = v[:, 8]; E = A + np.conj(p8); D = A - np.conj(p8); w = w_n[k1 + 256 * r + 16 * 8]; P = w * D
+Xk = (E.real + P.imag) + 1j * (E.imag - P.real)
+for l in range(4):
+    row = 4 * k1[l] + r[l] + 64 * 8
+    tile2[row] = abs(Xk[l]) ** 2; cnt[row] += 1
+assert set(cnt) == set(range(1024)) and max(cnt.values()) == 1, (len(cnt), max(cnt.values()))
+out2 = np.empty(1025)
+for row in range(1024):
+    out2[(row & 3) * 256 + (row >> 2)] = tile2[row]
+out2[1024] = (2 * (v[0, 0].real - v[0, 0].imag)) ** 2
+err2 = np.max(np.abs(out2 - np.abs(ref) ** 2)) / np.max(np.abs(ref) ** 2)
+print("pair-sharing post-pass max rel err:", err2)
+assert err2 < 1e-12
+for half in range(2):   # bank check of the secondary writes
+    ln = lane[32 * half:32 * half + 32]
+    for q in range(8):
+        banks = ((srow0[ln] + 64 * (15 - q)) * 17) % 32
+        assert len(set(banks)) == 32
+print("pair-sharing: every row written exactly once, secondary writes conflict-free")
