@@ -124,6 +124,4 @@ void launch_mel_apply(const MelJob &job) {
   SMX_HIP_CHECK(hipGetLastError());
 }
 
-bool launch_mel_spectrogram_fused(const MelSpecJob &) { return false; }
-
 }  // namespace smx

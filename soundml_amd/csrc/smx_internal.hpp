@@ -84,6 +84,14 @@ struct smx_stft_config {
   mutable std::map<int, smx::StftTables> tables_;
 };
 
+namespace smx {
+struct MelFusedPlan {      // per device; built lazily by stft_fast.hip
+  void *items = nullptr;   // MelItem[16]
+  float *w_mfma = nullptr; // MFMA A operands in lane order
+  int state = 0;           // 0 not built, 1 usable, -1 this configuration is not eligible
+};
+}  // namespace smx
+
 struct smx_mel_config {
   double f_min = 0, f_max = 0;
   int scale = SMX_MEL_SLANEY, norm = SMX_NORM_SLANEY;
@@ -99,11 +107,13 @@ struct smx_mel_config {
     int *band_lo = nullptr, *band_hi = nullptr;
   };
   const Tables &tables() const;
+  const smx::MelFusedPlan &fused_plan() const;   // stft_fast.hip
   ~smx_mel_config();
 
  private:
   mutable std::mutex mutex_;
   mutable std::map<int, Tables> tables_;
+  mutable std::map<int, smx::MelFusedPlan> fused_;
 };
 
 namespace smx {

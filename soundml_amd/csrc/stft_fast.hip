@@ -293,62 +293,221 @@ __device__ __forceinline__ void flush_part(const FastArgs &a, const float *tile,
 #endif
 #ifdef SMX_DIAG
 #define SMX_ABL_PARAM , int ABL
+#define SMX_ABL_ARG , ABL
+#define SMX_ABL_ZERO , 0
 #define SMX_ABL(n) (ABL == (n))
 #else
 #define SMX_ABL_PARAM
+#define SMX_ABL_ARG
+#define SMX_ABL_ZERO
 #define SMX_ABL(n) false
 #endif
+
+// Per-lane constants of the frame pipeline (see the header comment for the digit layout).
+struct LaneConst {
+  int k1, qa, r;
+  float s1, s2;
+  bool rot, low4;
+  int addr_g, addr_0;       // ds_bpermute byte addresses of the post-pass partner lane
+  int tile_row0;            // tile row of register q is tile_row0 + 64 q
+  const float2 *tabA_l, *winL_l, *tabP_l, *tabB_l;
+};
+
+struct Lds {
+  float *tiles;
+  float2 *tabA, *tabP, *tabB, *winL;
+};
+
+__device__ __forceinline__ Lds carve_lds(unsigned char *smem) {
+  Lds l;
+  l.tiles = reinterpret_cast<float *>(smem);   // two [1024][17] tiles, used alternately
+  l.tabA = reinterpret_cast<float2 *>(smem + 2 * kTileBytes);
+  l.tabP = reinterpret_cast<float2 *>(smem + 2 * kTileBytes + kTabABytes);
+  l.tabB = reinterpret_cast<float2 *>(smem + 2 * kTileBytes + kTabABytes + kTabPBytes);
+  l.winL = reinterpret_cast<float2 *>(smem + 2 * kTileBytes + kTabABytes + kTabPBytes + kTabBBytes);
+  return l;
+}
+
+// Fills the workgroup-shared LDS tables (wave w writes row w of each) and returns this lane's constants.
+// The caller must __syncthreads() before the tables are read.
+__device__ __forceinline__ LaneConst setup_lane(const FastArgs &a, const Lds &lds, int tid, int lane, int wave) {
+  LaneConst L;
+  L.k1 = lane >> 2;
+  L.qa = lane & 3;
+  L.r = ((L.qa & 1) << 1) | (L.qa >> 1);
+  if (wave > 0) lds.tabA[(wave - 1) * 64 + lane] = a.w_m[lane * wave];          // W_M^(l k1), k1 = wave
+  lds.winL[tid] = reinterpret_cast<const float2 *>(a.hwin)[tid];                // the whole window, once per workgroup
+  lds.tabP[wave * 64 + lane] = a.w_n[L.k1 + 256 * L.r + 16 * wave];             // exp(-2 pi i k / N), k = k1 + 16 q + 256 r
+  if (lane < 4) lds.tabB[wave * 4 + lane] = a.w_m[16 * lane * wave];            // W_64^(a q)
+  L.tabA_l = lds.tabA + lane - 64;   // row k1 - 1
+  L.winL_l = lds.winL + lane;
+  L.tabP_l = lds.tabP + lane;
+  L.tabB_l = lds.tabB + L.qa;
+  L.s1 = L.qa < 2 ? 1.0f : -1.0f;
+  L.s2 = (L.qa & 1) ? -1.0f : 1.0f;
+  L.rot = L.qa == 3;
+  if (lane >= 4) {
+    L.addr_g = L.addr_0 = (67 - lane) * 4;
+  } else {
+    L.addr_g = (3 - lane) * 4;
+    const int r0 = (4 - L.r) & 3;                            // partner r for q = 0
+    L.addr_0 = ((((r0 & 1) << 1) | (r0 >> 1))) * 4;          // its lane = bitrev2(r0)
+  }
+  L.low4 = lane < 4;
+  L.tile_row0 = 4 * L.k1 + L.r;                              // row' = 4 (k1 + 16 q) + r
+  return L;
+}
+
+// XCD-aware block -> (clip, tile group): blocks that share an XCD (b % 8) get a contiguous range
+// of virtual ids, i.e. whole clips, so halo re-reads and neighbouring partial lines meet in one L2.
+__device__ __forceinline__ void block_to_work(const FastArgs &a, int64_t &clip, int &group) {
+  int64_t vb = blockIdx.x;
+  const int64_t nb = a.blocks, q = nb / 8, r = nb % 8, xcd = vb % 8, idx = vb / 8;
+  vb = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+  clip = vb / a.groups_per_clip;
+  group = (int)(vb % a.groups_per_clip);
+}
+
+// One frame: raw samples (registers) -> window -> FFT(1024 complex) -> real post-pass -> |X|^p
+// written as column `wave` of `tile`.  `hook.at<P>()` is called at 16 points between the stages;
+// the power kernel uses them to trickle out the previous tile's stores.
+template <bool SQUARE SMX_ABL_PARAM, class Hook>
+__device__ __forceinline__ void frame_to_tile(const FastArgs &a, const LaneConst &L, const float2 (&raw)[16],
+                                              float *tile, int wave, int lane, const Hook &hook) {
+  c32 v[16];
+#pragma unroll
+  for (int j = 0; j < 16; ++j) {
+    const float2 w = L.winL_l[64 * j];
+    v[j] = {raw[j].x * w.x, raw[j].y * w.y};
+  }
+  hook.template at<0>();
+  __builtin_amdgcn_sched_barrier(0);
+  // A: radix-16 over j, twiddle W_M^(l k1)
+  fft16_pass1(v);
+  hook.template at<1>();
+  fft16_pass2(v);
+  hook.template at<2>();
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+  for (int k = 1; k < 16; ++k) {
+    const float2 w = L.tabA_l[64 * k];
+    v[k] = cmul(v[k], c32{w.x, w.y});
+  }
+  hook.template at<3>();
+  __builtin_amdgcn_sched_barrier(0);
+  // X: in-wave transpose: lane (i, a) register k1 -> lane (k1, a) register i  (no LDS)
+  {
+    float re[16], im[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) { re[k] = v[k].x; im[k] = v[k].y; }
+    if constexpr (!SMX_ABL(5)) transpose16(re);
+    hook.template at<4>();
+    if constexpr (!SMX_ABL(5)) transpose16(im);
+#pragma unroll
+    for (int k = 0; k < 16; ++k) v[k] = {re[k], im[k]};
+  }
+  hook.template at<5>();
+  __builtin_amdgcn_sched_barrier(0);
+  // B: radix-16 over i, twiddle W_64^(a q)
+  fft16_pass1(v);
+  hook.template at<6>();
+  fft16_pass2(v);
+  hook.template at<7>();
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+  for (int q = 1; q < 16; ++q) {
+    const float2 wb = L.tabB_l[4 * q];
+    v[q] = cmul(v[q], c32{wb.x, wb.y});
+  }
+  hook.template at<8>();
+  __builtin_amdgcn_sched_barrier(0);
+  // C: radix-4 across the quad (DPP).  lane a ends with r = bitrev2(a).
+#pragma unroll
+  for (int q = 0; q < 16; ++q) {
+    c32 u;
+    u.x = fmaf(v[q].x, L.s1, dpp_quad<0x4E>(v[q].x));
+    u.y = fmaf(v[q].y, L.s1, dpp_quad<0x4E>(v[q].y));
+    const c32 w = L.rot ? c32{u.y, -u.x} : u;
+    v[q].x = fmaf(w.x, L.s2, dpp_quad<0xB1>(w.x));
+    v[q].y = fmaf(w.y, L.s2, dpp_quad<0xB1>(w.y));
+    if (q == 7) hook.template at<9>();
+  }
+  hook.template at<10>();
+  __builtin_amdgcn_sched_barrier(0);
+  // P: real-FFT post-pass.  provider rotation for the k1 = 0 lanes.
+  float *col = tile + wave;
+  const float nyq = 2.0f * (v[0].x - v[0].y);   // X[M] = Re Z0 - Im Z0 (true scale), lane 0
+#pragma unroll
+  for (int q = 0; q < 16; ++q) {
+    const int addr = q == 0 ? L.addr_0 : L.addr_g;
+    const int m = 15 - q;
+    const float sx = L.low4 ? v[(m + 1) & 15].x : v[m].x;
+    const float sy = L.low4 ? v[(m + 1) & 15].y : v[m].y;
+    const float px = SMX_ABL(4) ? sx : bperm(addr, sx);
+    const float py = SMX_ABL(4) ? sy : bperm(addr, sy);
+    const c32 e = {v[q].x + px, v[q].y - py};
+    const c32 d = {v[q].x - px, v[q].y + py};
+    const float2 w = L.tabP_l[64 * q];
+    const float tr = e.x + w.x * d.y + w.y * d.x;
+    const float ti = e.y - w.x * d.x + w.y * d.y;
+    float pw = tr * tr + ti * ti;
+    if constexpr (!SQUARE) pw = a.pmode == 1 ? sqrtf(pw) : __powf(pw, a.half_power);
+    col[(L.tile_row0 + 64 * q) * kTileStride] = pw;
+    if ((q & 3) == 3) {
+      __builtin_amdgcn_sched_barrier(0);
+      if (q == 3) hook.template at<11>();
+      if (q == 7) hook.template at<12>();
+      if (q == 11) hook.template at<13>();
+      if (q == 15) { hook.template at<14>(); hook.template at<15>(); }
+    }
+  }
+  if (lane == 0) {
+    float pw = nyq * nyq;
+    if constexpr (!SQUARE) pw = a.pmode == 1 ? fabsf(nyq) : __powf(pw, a.half_power);
+    tile[wave * kTileStride + kFT] = pw;   // Nyquist bin of frame `wave`: pad slot of row `wave`
+  }
+}
+
+template <bool ALIGNED SMX_ABL_PARAM>
+__device__ __forceinline__ void prefetch_frame(const FastArgs &a, const float *x, int64_t p, int lane, float2 (&raw)[16]) {
+  if constexpr (SMX_ABL(2) || SMX_ABL(3)) {
+#pragma unroll
+    for (int j = 0; j < 16; ++j) raw[j] = make_float2((float)(lane + j) + raw[j].x * 0.0f, (float)(lane - j));
+  } else {
+    load_frame<ALIGNED>(a, x, p, lane, raw);
+  }
+}
+
+// ---- power spectrogram kernel -------------------------------------------------------------------
+// The previous tile's stores are spread over 16 points of the next frame's arithmetic and staggered
+// across waves (point p serves the 4 waves with (wave & 3) == (p & 3), part p >> 2), so at most
+// 4 KB of stores enter the memory pipeline at a time.
+struct FlushHook {
+  const FastArgs &a;
+  const float *ptile;
+  const FlushLane &fl;
+  float *pout;
+  int64_t pleft;
+  int wslot, wave, lane;
+  template <int P>
+  __device__ __forceinline__ void at() const {
+    if (wslot == (P & 3)) flush_part(a, ptile, P >> 2, fl, pout, pleft, wave, lane);
+  }
+};
+
+// SQUARE = power 2 (no per-bin branch); otherwise |X|^p through pmode / half_power
 template <bool ALIGNED, bool SQUARE SMX_ABL_PARAM>
 __global__ void __launch_bounds__(1024) stft2048_power_kernel(FastArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // provably wave-uniform (scalar)
-  float *tiles = reinterpret_cast<float *>(smem);   // two [1025][17] tiles, used alternately
-  float2 *tabA = reinterpret_cast<float2 *>(smem + 2 * kTileBytes);
-  float2 *tabP = reinterpret_cast<float2 *>(smem + 2 * kTileBytes + kTabABytes);
-  float2 *tabB = reinterpret_cast<float2 *>(smem + 2 * kTileBytes + kTabABytes + kTabPBytes);
-  float2 *winL = reinterpret_cast<float2 *>(smem + 2 * kTileBytes + kTabABytes + kTabPBytes + kTabBBytes);
-
-  // XCD-aware block -> (clip, tile group): blocks that share an XCD (b % 8) get a
-  // contiguous range of virtual ids, i.e. whole clips, so halo re-reads and the
-  // partial output lines of neighbouring tiles meet in one L2.
-  int64_t vb = blockIdx.x;
-  {
-    const int64_t nb = a.blocks, q = nb / 8, r = nb % 8, xcd = vb % 8, idx = vb / 8;
-    vb = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
-  }
-  const int64_t clip = vb / a.groups_per_clip;
-  const int group = (int)(vb % a.groups_per_clip);
+  const Lds lds = carve_lds(smem);
+  int64_t clip;
+  int group;
+  block_to_work(a, clip, group);
   const float *x = a.x + clip * a.x_stride;
-
-  // ---- per-lane constants ----------------------------------------------------
-  const int k1 = lane >> 2, qa = lane & 3;
-  const int r = ((qa & 1) << 1) | (qa >> 1);
-  // workgroup-shared twiddle tables in LDS: wave w fills row w of each
-  if (wave > 0) tabA[(wave - 1) * 64 + lane] = a.w_m[lane * wave];   // W_M^(l k1), k1 = wave
-  winL[tid] = reinterpret_cast<const float2 *>(a.hwin)[tid];         // the whole window, once per workgroup
-  tabP[wave * 64 + lane] = a.w_n[k1 + 256 * r + 16 * wave];    // exp(-2 pi i k / N), k = k1 + 16 q + 256 r
-  if (lane < 4) tabB[wave * 4 + lane] = a.w_m[16 * lane * wave];  // W_64^(a q)
-  const float2 *tabA_l = tabA + lane - 64;   // row k1 - 1
-  const float2 *winL_l = winL + lane;
-  const float2 *tabP_l = tabP + lane;
-  const float2 *tabB_l = tabB + qa;
-
-  const float s1 = qa < 2 ? 1.0f : -1.0f;
-  const float s2 = (qa & 1) ? -1.0f : 1.0f;
-  const bool rot = qa == 3;
-  // partner lanes for the real-FFT post-pass (byte addresses for ds_bpermute)
-  int addr_g, addr_0;
-  if (lane >= 4) {
-    addr_g = addr_0 = (67 - lane) * 4;
-  } else {
-    addr_g = (3 - lane) * 4;
-    const int r0 = (4 - r) & 3;                          // partner r for q = 0
-    addr_0 = ((((r0 & 1) << 1) | (r0 >> 1))) * 4;        // its lane = bitrev2(r0)
-  }
-  const bool low4 = lane < 4;
-  const int tile_row0 = 4 * k1 + r;                       // + 64 q   (row' = 4 (k1 + 16 q) + r)
+  const LaneConst L = setup_lane(a, lds, tid, lane, wave);
 
   const int t_begin = group * a.tiles_per_group;
   int t_end = t_begin + a.tiles_per_group;
@@ -357,12 +516,9 @@ __global__ void __launch_bounds__(1024) stft2048_power_kernel(FastArgs a) {
   // prefetch the first frame of this wave
   float2 raw[16];
   bool have = (int64_t)t_begin * kFT + wave < a.count;
-  if constexpr (SMX_ABL(2) || SMX_ABL(3)) {
 #pragma unroll
-    for (int j = 0; j < 16; ++j) raw[j] = make_float2((float)(lane + j), (float)(lane - j));
-  } else {
-    load_frame<ALIGNED>(a, x, a.p0 + (int64_t)t_begin * kFT + (have ? wave : 0), lane, raw);
-  }
+  for (int j = 0; j < 16; ++j) raw[j] = make_float2(0.f, 0.f);
+  prefetch_frame<ALIGNED SMX_ABL_ARG>(a, x, a.p0 + (int64_t)t_begin * kFT + (have ? wave : 0), lane, raw);
   __syncthreads();   // tables visible
   int cur = 0;
   bool pending = false;      // tile[cur ^ 1] holds the finished previous tile, not yet stored
@@ -384,132 +540,20 @@ __global__ void __launch_bounds__(1024) stft2048_power_kernel(FastArgs a) {
   for (int t = t_begin; t < t_end; ++t) {
     const int64_t f0 = (int64_t)t * kFT;
     SMX_STAMP(0);
+    const float *ptile = lds.tiles + (cur ^ 1) * (kTileBytes / sizeof(float));
     if (have) {   // wave-uniform
-      c32 v[16];
-#pragma unroll
-      for (int j = 0; j < 16; ++j) {
-        const float2 w = winL_l[64 * j];
-        v[j] = {raw[j].x * w.x, raw[j].y * w.y};
-      }
-      // The previous tile's stores are spread over 16 points of this frame's arithmetic and
-      // staggered across waves (point p serves the 4 waves with (wave & 3) == (p & 3), part p >> 2),
-      // so at most 4 KB of stores enter the memory pipeline at a time.
-      const float *ptile = tiles + (cur ^ 1) * (kTileBytes / sizeof(float));
-      float *const pout = clip_out + pend_f0;
-      const int64_t pleft = a.count - pend_f0;
-      const int wslot = pending ? (wave & 3) : -1;      // scalar
-#define SMX_FLUSH_POINT(p) \
-  if (wslot == ((p) & 3)) flush_part(a, ptile, (p) >> 2, fl, pout, pleft, wave, lane)
-      SMX_FLUSH_POINT(0);
-      SMX_STAMP(1);
-      __builtin_amdgcn_sched_barrier(0);
-      // A: radix-16 over j, twiddle W_M^(l k1)
-      fft16_pass1(v);
-      SMX_FLUSH_POINT(1);
-      fft16_pass2(v);
-      SMX_FLUSH_POINT(2);
-      __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-      for (int k = 1; k < 16; ++k) {
-        const float2 w = tabA_l[64 * k];
-        v[k] = cmul(v[k], c32{w.x, w.y});
-      }
-      SMX_FLUSH_POINT(3);
-      SMX_STAMP(2);
-      __builtin_amdgcn_sched_barrier(0);
-      // X: in-wave transpose: lane (i, a) register k1 -> lane (k1, a) register i  (no LDS)
-      {
-        float re[16], im[16];
-#pragma unroll
-        for (int k = 0; k < 16; ++k) { re[k] = v[k].x; im[k] = v[k].y; }
-        if constexpr (!SMX_ABL(5)) transpose16(re);
-        SMX_FLUSH_POINT(4);
-        if constexpr (!SMX_ABL(5)) transpose16(im);
-#pragma unroll
-        for (int k = 0; k < 16; ++k) v[k] = {re[k], im[k]};
-      }
-      SMX_FLUSH_POINT(5);
-      SMX_STAMP(3);
-      __builtin_amdgcn_sched_barrier(0);
-      // B: radix-16 over i, twiddle W_64^(a q)
-      fft16_pass1(v);
-      SMX_FLUSH_POINT(6);
-      fft16_pass2(v);
-      SMX_FLUSH_POINT(7);
-      __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-      for (int q = 1; q < 16; ++q) {
-        const float2 wb = tabB_l[4 * q];
-        v[q] = cmul(v[q], c32{wb.x, wb.y});
-      }
-      SMX_FLUSH_POINT(8);
-      SMX_STAMP(4);
-      __builtin_amdgcn_sched_barrier(0);
-      // C: radix-4 across the quad (DPP).  lane a ends with r = bitrev2(a).
-#pragma unroll
-      for (int q = 0; q < 16; ++q) {
-        c32 u;
-        u.x = fmaf(v[q].x, s1, dpp_quad<0x4E>(v[q].x));
-        u.y = fmaf(v[q].y, s1, dpp_quad<0x4E>(v[q].y));
-        const c32 w = rot ? c32{u.y, -u.x} : u;
-        v[q].x = fmaf(w.x, s2, dpp_quad<0xB1>(w.x));
-        v[q].y = fmaf(w.y, s2, dpp_quad<0xB1>(w.y));
-        if (q == 7) { SMX_FLUSH_POINT(9); }
-      }
-      SMX_FLUSH_POINT(10);
-      SMX_STAMP(5);
-      __builtin_amdgcn_sched_barrier(0);
-      // P: real-FFT post-pass.  provider rotation for the k1 = 0 lanes.
-      float *tile = tiles + cur * (kTileBytes / sizeof(float));
-      float *col = tile + wave;
-      const float nyq = 2.0f * (v[0].x - v[0].y);   // X[M] = Re Z0 - Im Z0 (true scale), lane 0
-#pragma unroll
-      for (int q = 0; q < 16; ++q) {
-        const int addr = q == 0 ? addr_0 : addr_g;
-        const int m = 15 - q;
-        const float sx = low4 ? v[(m + 1) & 15].x : v[m].x;
-        const float sy = low4 ? v[(m + 1) & 15].y : v[m].y;
-        const float px = SMX_ABL(4) ? sx : bperm(addr, sx);
-        const float py = SMX_ABL(4) ? sy : bperm(addr, sy);
-        const c32 e = {v[q].x + px, v[q].y - py};
-        const c32 d = {v[q].x - px, v[q].y + py};
-        const float2 w = tabP_l[64 * q];
-        const float tr = e.x + w.x * d.y + w.y * d.x;
-        const float ti = e.y - w.x * d.x + w.y * d.y;
-        float pw = tr * tr + ti * ti;
-        if constexpr (!SQUARE) pw = a.pmode == 1 ? sqrtf(pw) : __powf(pw, a.half_power);
-        col[(tile_row0 + 64 * q) * kTileStride] = pw;
-        if ((q & 3) == 3) {
-          __builtin_amdgcn_sched_barrier(0);
-          if (q == 3) { SMX_FLUSH_POINT(11); }
-          if (q == 7) { SMX_FLUSH_POINT(12); }
-          if (q == 11) { SMX_FLUSH_POINT(13); }
-          if (q == 15) { SMX_FLUSH_POINT(14); SMX_FLUSH_POINT(15); }
-        }
-      }
-#undef SMX_FLUSH_POINT
-      if (lane == 0) {
-        float pw = nyq * nyq;
-        if constexpr (!SQUARE) pw = a.pmode == 1 ? fabsf(nyq) : __powf(pw, a.half_power);
-        tile[wave * kTileStride + kFT] = pw;   // Nyquist bin of frame `wave`: pad slot of row `wave`
-      }
-    }
-    else if (pending) {   // no frame for this wave in this tile: still store its share of the previous one
-      const float *ptile = tiles + (cur ^ 1) * (kTileBytes / sizeof(float));
+      const FlushHook hook{a, ptile, fl, clip_out + pend_f0, a.count - pend_f0, pending ? (wave & 3) : -1, wave, lane};
+      frame_to_tile<SQUARE SMX_ABL_ARG>(a, L, raw, lds.tiles + cur * (kTileBytes / sizeof(float)), wave, lane, hook);
+    } else if (pending) {   // no frame for this wave in this tile: still store its share of the previous one
 #pragma unroll
       for (int it = 0; it < 4; ++it) flush_part(a, ptile, it, fl, clip_out + pend_f0, a.count - pend_f0, wave, lane);
     }
     SMX_STAMP(6);
-    // prefetch this wave's frame of the next tile (in flight across the barrier and the flush)
+    // prefetch this wave's frame of the next tile (in flight across the barrier)
     // (unconditional: without a next frame the tile's first frame is re-read and ignored, so
-    //  raw/win never carry old values around the loop and stay out of the compute's registers)
+    //  raw never carries old values around the loop and stays out of the compute's registers)
     const bool have_next = (t + 1 < t_end) && (f0 + kFT + wave < a.count);
-    if constexpr (SMX_ABL(2) || SMX_ABL(3)) {
-#pragma unroll
-      for (int j = 0; j < 16; ++j) raw[j] = make_float2(raw[j].x + 1.0f, raw[j].y - 1.0f);
-    } else {
-      load_frame<ALIGNED>(a, x, a.p0 + f0 + (have_next ? kFT + wave : 0), lane, raw);
-    }
+    prefetch_frame<ALIGNED SMX_ABL_ARG>(a, x, a.p0 + f0 + (have_next ? kFT + wave : 0), lane, raw);
     SMX_STAMP(7);
     __syncthreads();   // the ONLY barrier per tile: tile[cur] complete; tile[cur^1] free again
     SMX_STAMP(8);
@@ -518,10 +562,9 @@ __global__ void __launch_bounds__(1024) stft2048_power_kernel(FastArgs a) {
     pend_f0 = f0;
     have = have_next;
     cur ^= 1;
-    SMX_STAMP(9);
   }
   if (pending) {   // the last tile of this group
-    const float *ptile = tiles + (cur ^ 1) * (kTileBytes / sizeof(float));
+    const float *ptile = lds.tiles + (cur ^ 1) * (kTileBytes / sizeof(float));
 #pragma unroll
     for (int it = 0; it < 4; ++it) flush_part(a, ptile, it, fl, clip_out + pend_f0, a.count - pend_f0, wave, lane);
   }
@@ -529,6 +572,137 @@ __global__ void __launch_bounds__(1024) stft2048_power_kernel(FastArgs a) {
   if (lane == 0 && blockIdx.x < 4096)
     for (int i = 0; i < kStampSlots; ++i) g_stamp_sums[(blockIdx.x * 16 + wave) * kStampSlots + i] = stamp_sum[i];
 #endif
+}
+
+// ---- fused audio -> mel kernel -------------------------------------------------------------------
+// Soundml.mel_spectrogram (soundml.ml:12-24) = Mel.apply (Stft.power_spectrum x) with the power
+// tile kept in LDS: the finished tile [1024 bins][16 frames] is the B operand of
+// v_mfma_f32_16x16x4_f32 (k = bins, n = frames), the banded filterbank the A operand, and only
+// [n_mels][16] floats per tile reach HBM (8 KB instead of 65.6 KB).  The filters are banded, so
+// each 16-mel block walks only the union of its rows' supports (274 MFMAs per tile for 128 mels
+// at 2048 / 48 kHz instead of 2056).  A host-built plan gives every wave one item
+// (mel block, K range): heavy blocks are split in K between an owner wave and up to three helper
+// waves whose partial 16x16 accumulators travel through the spare pad column of the tile buffer
+// and are added by the owner in a fixed order (deterministic, no atomics).
+// Pipeline per tile t (one barrier): owner finishes tile t-2 | every wave runs its MFMA item on
+// tile t-1 | every wave computes its frame of tile t.
+using f32x4v = __attribute__((ext_vector_type(4))) float;
+
+struct MelItem {          // one per wave; wave-uniform, read through scalar loads
+  int block;              // 16-mel block index
+  int k4_begin, k4_count; // MFMA steps: bins [4 k4_begin, 4 (k4_begin + k4_count))
+  int a_offset;           // offset (in 64-float rows) of this item's A operands in w_mfma
+  int slot;               // helper: partial slot 0..2; owner / idle: -1
+  int owner;              // 1: this wave stores the block's result
+  int nslots;             // owner: number of helper partials to add
+  int slots[3];
+};
+
+struct MelFusedArgs {
+  const MelItem *items;   // [16]
+  const float *w_mfma;    // [rows][64]: A operand of MFMA step i of an item, in lane order
+  float *out;             // [lead; n_mels; out_stride]
+  int64_t out_stride, out_offset;
+  int n_mels;
+};
+
+struct NoHook {
+  template <int P>
+  __device__ __forceinline__ void at() const {}
+};
+
+template <bool ALIGNED, bool SQUARE>
+__global__ void __launch_bounds__(1024) stft2048_mel_kernel(FastArgs a, MelFusedArgs m) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const Lds lds = carve_lds(smem);
+  int64_t clip;
+  int group;
+  block_to_work(a, clip, group);
+  const float *x = a.x + clip * a.x_stride;
+  const LaneConst L = setup_lane(a, lds, tid, lane, wave);
+  const MelItem item = m.items[wave];          // scalar loads (wave-uniform address)
+
+  const int t_begin = group * a.tiles_per_group;
+  int t_end = t_begin + a.tiles_per_group;
+  if (t_end > a.tiles_per_clip) t_end = a.tiles_per_clip;
+
+  float2 raw[16];
+  bool have = (int64_t)t_begin * kFT + wave < a.count;
+  load_frame<ALIGNED>(a, x, a.p0 + (int64_t)t_begin * kFT + (have ? wave : 0), lane, raw);
+  __syncthreads();   // tables visible
+
+  float *const clip_out = m.out + (clip * m.n_mels) * m.out_stride + m.out_offset;   // wave-uniform
+  const int pad_lane = (16 + lane) * kTileStride + kFT;     // pad-column slot of this lane (rows >= 16)
+  constexpr int kTileFloats = kTileBytes / sizeof(float);
+  int cur = 0;
+  int stage = 0;              // tiles computed so far in this group
+  int64_t f0_m1 = 0, f0_m2 = 0;   // first frame of tile t-1 / t-2
+  f32x4v acc_prev = {0.f, 0.f, 0.f, 0.f};
+
+  // (A) owner: finish the tile whose MFMA partials were produced one iteration ago
+  auto finish = [&](const float *buf, int64_t f0) {
+    if (!item.owner) return;
+    f32x4v total = acc_prev;
+    for (int s = 0; s < item.nslots; ++s) {
+      const float *pp = buf + pad_lane + (256 * item.slots[s]) * kTileStride;
+#pragma unroll
+      for (int reg = 0; reg < 4; ++reg) total[reg] += pp[(64 * reg) * kTileStride];
+    }
+    const int f = lane & 15;
+    if (f0 + f < a.count) {
+#pragma unroll
+      for (int reg = 0; reg < 4; ++reg) {
+        const int mel = 16 * item.block + 4 * (lane >> 4) + reg;
+        if (mel < m.n_mels) clip_out[(int64_t)mel * m.out_stride + f0 + f] = total[reg];
+      }
+    }
+  };
+  // (B) every wave: its MFMA item over the finished tile in `buf`
+  auto mfma_item = [&](float *buf) {
+    if (item.k4_count <= 0) return;
+    f32x4v acc = {0.f, 0.f, 0.f, 0.f};
+    const float *arow = m.w_mfma + ((int64_t)item.a_offset * 64 + lane);
+    const int kk = lane >> 4, f = lane & 15;
+    for (int i = 0; i < item.k4_count; ++i) {
+      const int kabs = 4 * (item.k4_begin + i) + kk;
+      const int row = 4 * (kabs & 255) + (kabs >> 8);
+      const float b = kabs < kM ? buf[row * kTileStride + f] : 0.0f;
+      const float av = arow[(int64_t)i * 64];
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av, b, acc, 0, 0, 0);
+    }
+    if (item.owner) {
+      acc_prev = acc;
+    } else {
+      float *pp = buf + pad_lane + (256 * item.slot) * kTileStride;
+#pragma unroll
+      for (int reg = 0; reg < 4; ++reg) pp[(64 * reg) * kTileStride] = acc[reg];
+    }
+  };
+
+  for (int t = t_begin; t < t_end; ++t) {
+    const int64_t f0 = (int64_t)t * kFT;
+    float *tcur = lds.tiles + cur * kTileFloats;
+    float *tprev = lds.tiles + (cur ^ 1) * kTileFloats;
+    if (stage >= 2) finish(tcur, f0_m2);          // partials of tile t-2 sit in this buffer's pad column
+    if (stage >= 1) mfma_item(tprev);             // tile t-1
+    if (have) frame_to_tile<SQUARE SMX_ABL_ZERO>(a, L, raw, tcur, wave, lane, NoHook{});
+    const bool have_next = (t + 1 < t_end) && (f0 + kFT + wave < a.count);
+    load_frame<ALIGNED>(a, x, a.p0 + f0 + (have_next ? kFT + wave : 0), lane, raw);
+    __syncthreads();
+    f0_m2 = f0_m1;
+    f0_m1 = f0;
+    have = have_next;
+    cur ^= 1;
+    ++stage;
+  }
+  // drain: tile T-2 (partials in buffer `cur`), MFMA on tile T-1 (buffer cur^1), then its finish
+  if (stage >= 2) finish(lds.tiles + cur * kTileFloats, f0_m2);
+  if (stage >= 1) mfma_item(lds.tiles + (cur ^ 1) * kTileFloats);
+  __syncthreads();
+  if (stage >= 1) finish(lds.tiles + (cur ^ 1) * kTileFloats, f0_m1);
 }
 
 }  // namespace
@@ -568,9 +742,17 @@ __global__ void __launch_bounds__(256) gather_padded_kernel(const float *x, int6
   }
 }
 
+// What a launch produces: the power spectrogram (mel == nullptr) or the fused mel spectrogram.
+struct FastTarget {
+  void *out = nullptr;
+  int64_t out_stride = 0;       // frames dimension of the output
+  int64_t out_offset = 0;       // frame offset of this job's first frame
+  const MelFusedArgs *mel = nullptr;
+};
+
 // one launch of the fused kernel over frames that all lie inside [0, n)
-void launch_interior(const StftJob &job, const float *x, int64_t n, int64_t x_stride, int64_t left,
-                     int64_t p0, int64_t count, int64_t out_offset) {
+void launch_interior(const StftJob &job, const FastTarget &tg, const float *x, int64_t n, int64_t x_stride,
+                     int64_t left, int64_t p0, int64_t count, int64_t out_offset) {
   if (count <= 0) return;
   const smx_stft_config &c = *job.cfg;
   const StftTables &t = c.tables();
@@ -584,8 +766,8 @@ void launch_interior(const StftJob &job, const float *x, int64_t n, int64_t x_st
   a.pad_value = 0.0f;
   a.p0 = p0;
   a.count = count;
-  a.out = reinterpret_cast<float *>(job.out);
-  a.out_stride = job.out_stride;
+  a.out = reinterpret_cast<float *>(tg.out);
+  a.out_stride = tg.out_stride;
   a.out_offset = out_offset;
   a.hwin = t.fast_window;
   a.w_m = t.fast_w_m;
@@ -606,6 +788,17 @@ void launch_interior(const StftJob &job, const float *x, int64_t n, int64_t x_st
   const bool aligned = (c.hop % 2 == 0) && (left % 2 == 0) && (x_stride % 2 == 0) &&
                        (reinterpret_cast<uintptr_t>(x) % 8 == 0);
   const bool square = a.pmode == 2;
+  if (tg.mel) {
+    MelFusedArgs m = *tg.mel;
+    m.out_offset = out_offset;
+    auto kernel = aligned ? (square ? stft2048_mel_kernel<true, true> : stft2048_mel_kernel<true, false>)
+                          : (square ? stft2048_mel_kernel<false, true> : stft2048_mel_kernel<false, false>);
+    SMX_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kernel),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)kFastLds));
+    hipLaunchKernelGGL(kernel, dim3((unsigned)a.blocks), dim3(1024), kFastLds, job.stream, a, m);
+    SMX_HIP_CHECK(hipGetLastError());
+    return;
+  }
 #ifdef SMX_DIAG
   const char *abl_env = std::getenv("SMX_ABLATE");
   const int abl = abl_env ? std::atoi(abl_env) : 0;
@@ -627,7 +820,7 @@ void launch_interior(const StftJob &job, const float *x, int64_t n, int64_t x_st
 }
 
 // frames [pa, pb) that touch a border: gather their padded span, then run the fused kernel on it
-void launch_border(const StftJob &job, int64_t pa, int64_t pb) {
+void launch_border(const StftJob &job, const FastTarget &tg, int64_t pa, int64_t pb) {
   if (pb <= pa) return;
   const smx_stft_config &c = *job.cfg;
   const int64_t pos0 = pa * c.hop - job.left;               // signal position of the strip's first sample
@@ -635,14 +828,41 @@ void launch_border(const StftJob &job, int64_t pa, int64_t pb) {
   const int64_t stride = (len + 1) & ~int64_t(1);            // even: keeps 8-byte aligned rows
   float *strip = nullptr;
   SMX_HIP_CHECK(hipMallocAsync((void **)&strip, (size_t)job.lead * (size_t)stride * sizeof(float), job.stream));
-  if (job.lead > 65535) throw Failure("stft: too many leading slices for one border launch");
   dim3 grid((unsigned)((len + 255) / 256 < 64 ? (len + 255) / 256 : 64), (unsigned)job.lead);
   hipLaunchKernelGGL(gather_padded_kernel, grid, dim3(256), 0, job.stream,
                      reinterpret_cast<const float *>(job.x), job.n, job.x_stride, pos0, len, job.pad,
                      (float)job.pad_value, strip, stride);
   SMX_HIP_CHECK(hipGetLastError());
-  launch_interior(job, strip, len, stride, 0, 0, pb - pa, job.out_offset + (pa - job.p0));
+  launch_interior(job, tg, strip, len, stride, 0, 0, pb - pa, tg.out_offset + (pa - job.p0));
   SMX_HIP_CHECK(hipFreeAsync(strip, job.stream));
+}
+
+bool fast_eligible(const StftJob &job) {
+  const smx_stft_config &c = *job.cfg;
+  if (fast_path_disabled()) return false;
+  if (c.fft_size != kN || job.in_bytes != 4 || job.interior != SMX_INTERIOR_F32) return false;
+  if (job.mode != OUT_POWER) return false;
+  if (job.lead > 65535) return false;
+  return true;
+}
+
+// splits frames [p0, p0 + count) into left border / interior / right border launches
+void launch_ranges(const StftJob &job, const FastTarget &tg) {
+  const smx_stft_config &c = *job.cfg;
+  // frame p lies inside the signal iff 0 <= p*hop - left and p*hop - left + N <= n
+  const int64_t p0 = job.p0, p1 = job.p0 + job.count;
+  int64_t i0 = job.left > 0 ? (job.left + c.hop - 1) / c.hop : 0;
+  int64_t i1 = job.n + job.left - kN >= 0 ? (job.n + job.left - kN) / c.hop + 1 : 0;
+  if (i0 < p0) i0 = p0;
+  if (i1 > p1) i1 = p1;
+  if (i1 <= i0) {          // no interior frame in range: one strip for everything
+    launch_border(job, tg, p0, p1);
+    return;
+  }
+  launch_border(job, tg, p0, i0);
+  launch_interior(job, tg, reinterpret_cast<const float *>(job.x), job.n, job.x_stride, job.left, i0, i1 - i0,
+                  tg.out_offset + (i0 - p0));
+  launch_border(job, tg, i1, p1);
 }
 
 }  // namespace
@@ -654,28 +874,124 @@ extern "C" int smx_debug_read_stamps(unsigned long long *out, int count) {
 #endif
 
 bool launch_stft_fast(const StftJob &job) {
-  const smx_stft_config &c = *job.cfg;
-  if (fast_path_disabled()) return false;
-  if (c.fft_size != kN || job.in_bytes != 4 || job.interior != SMX_INTERIOR_F32) return false;
-  if (job.mode != OUT_POWER) return false;
+  if (!fast_eligible(job)) return false;
   if (job.count <= 0 || job.lead <= 0) return true;
-  if (job.lead > 65535) return false;
   if ((int64_t)kBins * job.out_stride * 4 >= (int64_t(1) << 32)) return false;   // 32-bit row offsets
-  // frame p lies inside the signal iff 0 <= p*hop - left and p*hop - left + N <= n
-  const int64_t p0 = job.p0, p1 = job.p0 + job.count;
-  int64_t i0 = job.left > 0 ? (job.left + c.hop - 1) / c.hop : 0;
-  int64_t i1 = job.n + job.left - kN >= 0 ? (job.n + job.left - kN) / c.hop + 1 : 0;
-  if (i0 < p0) i0 = p0;
-  if (i1 > p1) i1 = p1;
-  if (i1 <= i0) {          // no interior frame in range: one strip for everything
-    launch_border(job, p0, p1);
-    return true;
-  }
-  launch_border(job, p0, i0);
-  launch_interior(job, reinterpret_cast<const float *>(job.x), job.n, job.x_stride, job.left, i0, i1 - i0,
-                  job.out_offset + (i0 - p0));
-  launch_border(job, i1, p1);
+  FastTarget tg;
+  tg.out = job.out;
+  tg.out_stride = job.out_stride;
+  tg.out_offset = job.out_offset;
+  launch_ranges(job, tg);
+  return true;
+}
+
+bool launch_mel_spectrogram_fused(const MelSpecJob &job) {
+  if (!fast_eligible(job.stft)) return false;
+  if (job.stft.count <= 0 || job.stft.lead <= 0) return true;
+  const MelFusedPlan &plan = job.mel->fused_plan();
+  if (plan.state != 1) return false;
+  MelFusedArgs m{};
+  m.items = reinterpret_cast<const MelItem *>(plan.items);
+  m.w_mfma = plan.w_mfma;
+  m.out = reinterpret_cast<float *>(job.out);
+  m.out_stride = job.stft.count;
+  m.out_offset = 0;
+  m.n_mels = (int)job.mel->n_mels;
+  FastTarget tg;
+  tg.out = job.out;
+  tg.out_stride = job.stft.count;
+  tg.out_offset = 0;
+  tg.mel = &m;
+  launch_ranges(job.stft, tg);
   return true;
 }
 
 }  // namespace smx
+
+// ---- MFMA work plan of the fused mel kernel (per mel configuration and device) ---------------------
+const smx::MelFusedPlan &smx_mel_config::fused_plan() const {
+  using namespace smx;
+  int device = 0;
+  SMX_HIP_CHECK(hipGetDevice(&device));
+  std::lock_guard<std::mutex> lock(mutex_);
+  MelFusedPlan &plan = fused_[device];
+  if (plan.state != 0) return plan;
+  plan.state = -1;
+  const int64_t nb = bins();
+  if (fft_size != kN || n_mels < 1 || n_mels > 256) return plan;
+  // the Nyquist bin is kept outside the tile rows: it must not contribute (true whenever f_max <= Nyquist)
+  for (int64_t mm = 0; mm < n_mels; ++mm)
+    if (weights[(size_t)(mm * nb + (nb - 1))] != 0.0) return plan;
+  const int blocks = (int)((n_mels + 15) / 16);
+  if (blocks > 16) return plan;
+  std::vector<int> k4lo((size_t)blocks, 0), k4n((size_t)blocks, 0), pieces((size_t)blocks, 1);
+  for (int b = 0; b < blocks; ++b) {
+    int lo = (int)nb, hi = 0;
+    for (int64_t mm = 16 * b; mm < 16 * (b + 1) && mm < n_mels; ++mm)
+      for (int64_t k = 0; k < nb - 1; ++k)
+        if (weights[(size_t)(mm * nb + k)] != 0.0) {
+          if (k < lo) lo = (int)k;
+          if (k + 1 > hi) hi = (int)k + 1;
+        }
+    if (hi > lo) {
+      k4lo[(size_t)b] = lo / 4;
+      k4n[(size_t)b] = (hi + 3) / 4 - lo / 4;
+    }
+  }
+  // split the heaviest blocks in K: at most 3 helper pieces (their partials live in the tile's pad column)
+  int total_pieces = blocks, helpers = 0;
+  while (helpers < 3 && total_pieces < 16) {
+    int best = -1;
+    double load = 12.0;   // not worth splitting below ~12 MFMAs per piece
+    for (int b = 0; b < blocks; ++b) {
+      const double l = (double)k4n[(size_t)b] / pieces[(size_t)b];
+      if (l > load) { load = l; best = b; }
+    }
+    if (best < 0) break;
+    ++pieces[(size_t)best];
+    ++helpers;
+    ++total_pieces;
+  }
+  std::vector<MelItem> items(16);
+  for (auto &it : items) { it = MelItem{}; it.slot = -1; }
+  std::vector<float> wm;
+  int next_wave = blocks, next_slot = 0;
+  auto emit_operands = [&](MelItem &it) {
+    it.a_offset = (int)(wm.size() / 64);
+    for (int i = 0; i < it.k4_count; ++i)
+      for (int lane = 0; lane < 64; ++lane) {
+        const int64_t mm = 16 * (int64_t)it.block + (lane & 15);
+        const int64_t k = 4 * (int64_t)(it.k4_begin + i) + (lane >> 4);
+        wm.push_back((mm < n_mels && k < nb - 1) ? (float)weights[(size_t)(mm * nb + k)] : 0.0f);
+      }
+  };
+  for (int b = 0; b < blocks; ++b) {
+    const int np = pieces[(size_t)b], n = k4n[(size_t)b];
+    int begin = k4lo[(size_t)b];
+    for (int pc = 0; pc < np; ++pc) {
+      const int cnt = n / np + (pc < n % np ? 1 : 0);
+      MelItem &it = pc == 0 ? items[(size_t)b] : items[(size_t)next_wave];
+      it.block = b;
+      it.k4_begin = begin;
+      it.k4_count = cnt;
+      if (pc == 0) {
+        it.owner = 1;
+      } else {
+        it.slot = next_slot;
+        MelItem &own = items[(size_t)b];
+        own.slots[own.nslots++] = next_slot;
+        ++next_slot;
+        ++next_wave;
+      }
+      emit_operands(it);
+      begin += cnt;
+    }
+  }
+  if (wm.empty()) wm.assign(64, 0.0f);
+  SMX_HIP_CHECK(hipMalloc(&plan.items, items.size() * sizeof(MelItem)));
+  SMX_HIP_CHECK(hipMemcpy(plan.items, items.data(), items.size() * sizeof(MelItem), hipMemcpyHostToDevice));
+  SMX_HIP_CHECK(hipMalloc((void **)&plan.w_mfma, wm.size() * sizeof(float)));
+  SMX_HIP_CHECK(hipMemcpy(plan.w_mfma, wm.data(), wm.size() * sizeof(float), hipMemcpyHostToDevice));
+  plan.state = 1;
+  return plan;
+}

@@ -127,4 +127,8 @@ smx_mel_config::~smx_mel_config() {
     (void)hipFree(kv.second.band_lo);
     (void)hipFree(kv.second.band_hi);
   }
+  for (auto &kv : fused_) {
+    (void)hipFree(kv.second.items);
+    (void)hipFree(kv.second.w_mfma);
+  }
 }

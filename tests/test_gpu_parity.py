@@ -316,6 +316,33 @@ def test_mel_spectrogram_is_the_composition():
         check_fast(comp[i], want[i], "composition")
 
 
+@pytest.mark.parametrize("n_mels,sr,n,lead,power", [
+    (128, 48000, 48000, 2, 2.0),     # C3 geometry
+    (128, 48000, 16 * 512 * 5 + 1234, 3, 2.0),   # several tiles + tail tile
+    (128, 48000, 3000, 4, 2.0),      # every frame is a border frame
+    (80, 16000, 20000, 2, 2.0),      # 5 mel blocks
+    (40, 22050, 30000, 1, 1.0),      # magnitude mel, 3 mel blocks (one partly empty)
+    (13, 48000, 9000, 2, 2.0),       # single partial block
+    (200, 48000, 20000, 1, 2.0),     # 13 mel blocks
+])
+def test_fused_mel_spectrogram_vs_oracle(n_mels, sr, n, lead, power):
+    """The fused audio -> mel kernel (fft 2048): MFMA over the LDS-resident power tile."""
+    rng = np.random.default_rng(n_mels + n)
+    x = rng.uniform(-1, 1, size=(lead, n)).astype(np.float32)
+    sc = Stft.Config.create(fft_size=2048, hop=512)
+    mc = Mel.Config.create(n_mels=n_mels, sample_rate=sr, fft_size=2048)
+    got = S.mel_spectrogram(sc, mc, x, power)
+    want = O.mel_spectrogram(O.stft_config(2048, hop=512), O.mel_config(n_mels, sr, 2048), x, power)
+    assert got.shape == want.shape and got.dtype == np.float32
+    for i in range(lead):
+        check_fast(got[i], want[i], "fused mel clip %d" % i)
+    # a batch is exactly the stack of its slices (deterministic reduction order)
+    assert np.array_equal(got[0], S.mel_spectrogram(sc, mc, x[0], power))
+    # device-resident path == host path, bit for bit
+    import torch
+    assert np.array_equal(S.mel_spectrogram(sc, mc, torch.from_numpy(x).cuda(), power).cpu().numpy(), got)
+
+
 # ---- FIR ---------------------------------------------------------------------------------------------
 
 @pytest.mark.parametrize("taps,n,ch", [(63, 5000, 2), (1, 100, 1), (8192, 60000, 2), (1000, 1, 1), (257, 16384 * 3, 3)])
