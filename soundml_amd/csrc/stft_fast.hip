@@ -606,9 +606,39 @@ struct MelFusedArgs {
   int n_mels;
 };
 
-struct NoHook {
+// MFMA steps of the previous tile, spread over the 16 points of the current frame's arithmetic:
+// point P runs steps 3P..3P+2 of this wave's item (A operands were loaded at point P-1, the B
+// operand comes from the finished tile in LDS) and issues the A loads of point P+1.  The MFMAs
+// execute on the matrix pipe under the FFT's VALU work.
+struct MelHook {
+  f32x4v &acc;
+  float (&av)[3];
+  const float *abase;    // wave-uniform: the item's A operands, [step][64 lanes]
+  unsigned lane_u;
+  const float *buf;      // finished tile (previous buffer)
+  int count, k4_begin, kk, f;
+  __device__ __forceinline__ void load(int point) const {
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      const int step = 3 * point + j;
+      if (step < count) av[j] = (abase + 192 * point)[lane_u + 64u * j];   // SGPR base + lane offset + immediate
+    }
+  }
   template <int P>
-  __device__ __forceinline__ void at() const {}
+  __device__ __forceinline__ void at() const {
+    if (3 * P >= count) return;    // wave-uniform
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      const int step = 3 * P + j;
+      if (step < count) {
+        const int kabs = 4 * (k4_begin + step) + kk;
+        const int row = 4 * (kabs & 255) + (kabs >> 8);
+        const float b = kabs < kM ? buf[row * kTileStride + f] : (kabs == kM ? buf[f * kTileStride + kFT] : 0.0f);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[j], b, acc, 0, 0, 0);
+      }
+    }
+    if (P < 15) load(P + 1);
+  }
 };
 
 template <bool ALIGNED, bool SQUARE>
@@ -623,7 +653,16 @@ __global__ void __launch_bounds__(1024) stft2048_mel_kernel(FastArgs a, MelFused
   block_to_work(a, clip, group);
   const float *x = a.x + clip * a.x_stride;
   const LaneConst L = setup_lane(a, lds, tid, lane, wave);
-  const MelItem item = m.items[wave];          // scalar loads (wave-uniform address)
+  MelItem item = m.items[wave];                // wave-uniform: force every field into SGPRs
+  item.block = __builtin_amdgcn_readfirstlane(item.block);
+  item.k4_begin = __builtin_amdgcn_readfirstlane(item.k4_begin);
+  item.k4_count = __builtin_amdgcn_readfirstlane(item.k4_count);
+  item.a_offset = __builtin_amdgcn_readfirstlane(item.a_offset);
+  item.slot = __builtin_amdgcn_readfirstlane(item.slot);
+  item.owner = __builtin_amdgcn_readfirstlane(item.owner);
+  item.nslots = __builtin_amdgcn_readfirstlane(item.nslots);
+#pragma unroll
+  for (int i = 0; i < 3; ++i) item.slots[i] = __builtin_amdgcn_readfirstlane(item.slots[i]);
 
   const int t_begin = group * a.tiles_per_group;
   int t_end = t_begin + a.tiles_per_group;
@@ -669,7 +708,8 @@ __global__ void __launch_bounds__(1024) stft2048_mel_kernel(FastArgs a, MelFused
     for (int i = 0; i < item.k4_count; ++i) {
       const int kabs = 4 * (item.k4_begin + i) + kk;
       const int row = 4 * (kabs & 255) + (kabs >> 8);
-      const float b = kabs < kM ? buf[row * kTileStride + f] : 0.0f;
+      // bins 0..1023 are tile rows; the Nyquist bin of frame f sits in the pad slot of row f
+      const float b = kabs < kM ? buf[row * kTileStride + f] : (kabs == kM ? buf[f * kTileStride + kFT] : 0.0f);
       const float av = arow[(int64_t)i * 64];
       acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av, b, acc, 0, 0, 0);
     }
@@ -687,8 +727,27 @@ __global__ void __launch_bounds__(1024) stft2048_mel_kernel(FastArgs a, MelFused
     float *tcur = lds.tiles + cur * kTileFloats;
     float *tprev = lds.tiles + (cur ^ 1) * kTileFloats;
     if (stage >= 2) finish(tcur, f0_m2);          // partials of tile t-2 sit in this buffer's pad column
-    if (stage >= 1) mfma_item(tprev);             // tile t-1
-    if (have) frame_to_tile<SQUARE SMX_ABL_ZERO>(a, L, raw, tcur, wave, lane, NoHook{});
+    if (have) {
+      // tile t-1's MFMA steps ride along the FFT of tile t (none at the first tile of the group)
+      f32x4v acc = {0.f, 0.f, 0.f, 0.f};
+      float av[3] = {0.f, 0.f, 0.f};
+      const int steps = stage >= 1 ? item.k4_count : 0;
+      const MelHook hook{acc, av, m.w_mfma + (int64_t)item.a_offset * 64, (unsigned)lane, tprev, steps,
+                         item.k4_begin, lane >> 4, lane & 15};
+      hook.load(0);
+      frame_to_tile<SQUARE SMX_ABL_ZERO>(a, L, raw, tcur, wave, lane, hook);
+      if (steps > 0) {
+        if (item.owner) {
+          acc_prev = acc;
+        } else {
+          float *pp = tprev + pad_lane + (256 * item.slot) * kTileStride;
+#pragma unroll
+          for (int reg = 0; reg < 4; ++reg) pp[(64 * reg) * kTileStride] = acc[reg];
+        }
+      }
+    } else if (stage >= 1) {
+      mfma_item(tprev);                           // a wave without a frame in this (tail) tile
+    }
     const bool have_next = (t + 1 < t_end) && (f0 + kFT + wave < a.count);
     load_frame<ALIGNED>(a, x, a.p0 + f0 + (have_next ? kFT + wave : 0), lane, raw);
     __syncthreads();
@@ -919,16 +978,13 @@ const smx::MelFusedPlan &smx_mel_config::fused_plan() const {
   plan.state = -1;
   const int64_t nb = bins();
   if (fft_size != kN || n_mels < 1 || n_mels > 256) return plan;
-  // the Nyquist bin is kept outside the tile rows: it must not contribute (true whenever f_max <= Nyquist)
-  for (int64_t mm = 0; mm < n_mels; ++mm)
-    if (weights[(size_t)(mm * nb + (nb - 1))] != 0.0) return plan;
   const int blocks = (int)((n_mels + 15) / 16);
   if (blocks > 16) return plan;
   std::vector<int> k4lo((size_t)blocks, 0), k4n((size_t)blocks, 0), pieces((size_t)blocks, 1);
   for (int b = 0; b < blocks; ++b) {
     int lo = (int)nb, hi = 0;
     for (int64_t mm = 16 * b; mm < 16 * (b + 1) && mm < n_mels; ++mm)
-      for (int64_t k = 0; k < nb - 1; ++k)
+      for (int64_t k = 0; k < nb; ++k)
         if (weights[(size_t)(mm * nb + k)] != 0.0) {
           if (k < lo) lo = (int)k;
           if (k + 1 > hi) hi = (int)k + 1;
@@ -962,7 +1018,7 @@ const smx::MelFusedPlan &smx_mel_config::fused_plan() const {
       for (int lane = 0; lane < 64; ++lane) {
         const int64_t mm = 16 * (int64_t)it.block + (lane & 15);
         const int64_t k = 4 * (int64_t)(it.k4_begin + i) + (lane >> 4);
-        wm.push_back((mm < n_mels && k < nb - 1) ? (float)weights[(size_t)(mm * nb + k)] : 0.0f);
+        wm.push_back((mm < n_mels && k < nb) ? (float)weights[(size_t)(mm * nb + k)] : 0.0f);
       }
   };
   for (int b = 0; b < blocks; ++b) {
@@ -987,6 +1043,8 @@ const smx::MelFusedPlan &smx_mel_config::fused_plan() const {
       begin += cnt;
     }
   }
+  if (std::getenv("SMX_MEL_NOMFMA"))   // diagnostic: plan without MFMA work (results are zeros)
+    for (auto &it : items) it.k4_count = 0;
   if (wm.empty()) wm.assign(64, 0.0f);
   SMX_HIP_CHECK(hipMalloc(&plan.items, items.size() * sizeof(MelItem)));
   SMX_HIP_CHECK(hipMemcpy(plan.items, items.data(), items.size() * sizeof(MelItem), hipMemcpyHostToDevice));
