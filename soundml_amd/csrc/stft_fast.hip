@@ -606,39 +606,9 @@ struct MelFusedArgs {
   int n_mels;
 };
 
-// MFMA steps of the previous tile, spread over the 16 points of the current frame's arithmetic:
-// point P runs steps 3P..3P+2 of this wave's item (A operands were loaded at point P-1, the B
-// operand comes from the finished tile in LDS) and issues the A loads of point P+1.  The MFMAs
-// execute on the matrix pipe under the FFT's VALU work.
-struct MelHook {
-  f32x4v &acc;
-  float (&av)[3];
-  const float *abase;    // wave-uniform: the item's A operands, [step][64 lanes]
-  unsigned lane_u;
-  const float *buf;      // finished tile (previous buffer)
-  int count, k4_begin, kk, f;
-  __device__ __forceinline__ void load(int point) const {
-#pragma unroll
-    for (int j = 0; j < 3; ++j) {
-      const int step = 3 * point + j;
-      if (step < count) av[j] = (abase + 192 * point)[lane_u + 64u * j];   // SGPR base + lane offset + immediate
-    }
-  }
+struct NoHook {
   template <int P>
-  __device__ __forceinline__ void at() const {
-    if (3 * P >= count) return;    // wave-uniform
-#pragma unroll
-    for (int j = 0; j < 3; ++j) {
-      const int step = 3 * P + j;
-      if (step < count) {
-        const int kabs = 4 * (k4_begin + step) + kk;
-        const int row = 4 * (kabs & 255) + (kabs >> 8);
-        const float b = kabs < kM ? buf[row * kTileStride + f] : (kabs == kM ? buf[f * kTileStride + kFT] : 0.0f);
-        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[j], b, acc, 0, 0, 0);
-      }
-    }
-    if (P < 15) load(P + 1);
-  }
+  __device__ __forceinline__ void at() const {}
 };
 
 template <bool ALIGNED, bool SQUARE>
@@ -699,19 +669,54 @@ __global__ void __launch_bounds__(1024) stft2048_mel_kernel(FastArgs a, MelFused
       }
     }
   };
-  // (B) every wave: its MFMA item over the finished tile in `buf`
+  // (B) every wave: its MFMA item over the finished tile in `buf`, BEFORE its own FFT so that the
+  // MFMA operands and the FFT state are never live together (the kernel sits at the 128-VGPR cap).
+  // A operands arrive 16 steps at a time (SGPR base + lane offset), the next chunk is in flight
+  // while the current one is multiplied; B comes from the tile in LDS.
   auto mfma_item = [&](float *buf) {
     if (item.k4_count <= 0) return;
     f32x4v acc = {0.f, 0.f, 0.f, 0.f};
-    const float *arow = m.w_mfma + ((int64_t)item.a_offset * 64 + lane);
+    const float *abase = m.w_mfma + (int64_t)item.a_offset * 64;    // wave-uniform
+    const unsigned lane_u = (unsigned)lane;
     const int kk = lane >> 4, f = lane & 15;
-    for (int i = 0; i < item.k4_count; ++i) {
-      const int kabs = 4 * (item.k4_begin + i) + kk;
-      const int row = 4 * (kabs & 255) + (kabs >> 8);
-      // bins 0..1023 are tile rows; the Nyquist bin of frame f sits in the pad slot of row f
-      const float b = kabs < kM ? buf[row * kTileStride + f] : (kabs == kM ? buf[f * kTileStride + kFT] : 0.0f);
-      const float av = arow[(int64_t)i * 64];
-      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av, b, acc, 0, 0, 0);
+    float av[16], an[16];
+    auto load_chunk = [&](int c, float (&dst)[16]) {
+      const float *cb = abase + (int64_t)c * 16 * 64;
+#pragma unroll
+      for (int j = 0; j < 16; ++j)
+        if (16 * c + j < item.k4_count) dst[j] = cb[lane_u + 64u * j];
+    };
+#pragma unroll
+    for (int j = 0; j < 16; ++j) av[j] = an[j] = 0.0f;
+    const int chunks = (item.k4_count + 15) >> 4;
+    load_chunk(0, av);
+    for (int c = 0; c < chunks; ++c) {
+      if (c + 1 < chunks) load_chunk(c + 1, an);
+      const int k4c = item.k4_begin + 16 * c;                 // first MFMA step of this chunk (scalar)
+      if (((4 * k4c) & 255) <= 192) {
+        // fast path: the chunk's 64 bins stay inside one 256-bin block (and below the Nyquist bin),
+        // so tile rows advance by 16 per step: one base address, immediate offsets
+        const int kabs0 = 4 * k4c + kk;
+        const float *bp = buf + (4 * (kabs0 & 255) + (kabs0 >> 8)) * kTileStride + f;
+#pragma unroll
+        for (int j = 0; j < 16; ++j)
+          if (16 * c + j < item.k4_count)
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[j], bp[16 * kTileStride * j], acc, 0, 0, 0);
+      } else {
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+          const int step = 16 * c + j;
+          if (step < item.k4_count) {
+            const int kabs = 4 * (item.k4_begin + step) + kk;
+            const int row = 4 * (kabs & 255) + (kabs >> 8);
+            // bins 0..1023 are tile rows; the Nyquist bin of frame f sits in the pad slot of row f
+            const float b = kabs < kM ? buf[row * kTileStride + f] : (kabs == kM ? buf[f * kTileStride + kFT] : 0.0f);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[j], b, acc, 0, 0, 0);
+          }
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < 16; ++j) av[j] = an[j];
     }
     if (item.owner) {
       acc_prev = acc;
@@ -727,27 +732,8 @@ __global__ void __launch_bounds__(1024) stft2048_mel_kernel(FastArgs a, MelFused
     float *tcur = lds.tiles + cur * kTileFloats;
     float *tprev = lds.tiles + (cur ^ 1) * kTileFloats;
     if (stage >= 2) finish(tcur, f0_m2);          // partials of tile t-2 sit in this buffer's pad column
-    if (have) {
-      // tile t-1's MFMA steps ride along the FFT of tile t (none at the first tile of the group)
-      f32x4v acc = {0.f, 0.f, 0.f, 0.f};
-      float av[3] = {0.f, 0.f, 0.f};
-      const int steps = stage >= 1 ? item.k4_count : 0;
-      const MelHook hook{acc, av, m.w_mfma + (int64_t)item.a_offset * 64, (unsigned)lane, tprev, steps,
-                         item.k4_begin, lane >> 4, lane & 15};
-      hook.load(0);
-      frame_to_tile<SQUARE SMX_ABL_ZERO>(a, L, raw, tcur, wave, lane, hook);
-      if (steps > 0) {
-        if (item.owner) {
-          acc_prev = acc;
-        } else {
-          float *pp = tprev + pad_lane + (256 * item.slot) * kTileStride;
-#pragma unroll
-          for (int reg = 0; reg < 4; ++reg) pp[(64 * reg) * kTileStride] = acc[reg];
-        }
-      }
-    } else if (stage >= 1) {
-      mfma_item(tprev);                           // a wave without a frame in this (tail) tile
-    }
+    if (stage >= 1) mfma_item(tprev);             // tile t-1
+    if (have) frame_to_tile<SQUARE SMX_ABL_ZERO>(a, L, raw, tcur, wave, lane, NoHook{});
     const bool have_next = (t + 1 < t_end) && (f0 + kFT + wave < a.count);
     load_frame<ALIGNED>(a, x, a.p0 + f0 + (have_next ? kFT + wave : 0), lane, raw);
     __syncthreads();
