@@ -190,8 +190,9 @@ struct FastArgs {
   const float *hwin;    // 0.5 * window, 2048
   const float2 *w_m;    // exp(-2 pi i j / 1024)
   const float2 *w_n;    // exp(-2 pi i k / 2048), k <= 1024
-  int tiles_per_clip, groups_per_clip, tiles_per_group;
-  int64_t blocks;
+  int tiles_per_clip;
+  int64_t total_tiles;     // lead * tiles_per_clip: a flat (clip, tile) sequence
+  int64_t blocks;          // persistent workgroups; each owns a contiguous range of the sequence
   int pmode;            // 2: power 2, 1: power 1, 0: general
   int abl_nostore;      // diagnostic builds only
   float half_power;
@@ -358,14 +359,16 @@ __device__ __forceinline__ LaneConst setup_lane(const FastArgs &a, const Lds &ld
   return L;
 }
 
-// XCD-aware block -> (clip, tile group): blocks that share an XCD (b % 8) get a contiguous range
-// of virtual ids, i.e. whole clips, so halo re-reads and neighbouring partial lines meet in one L2.
-__device__ __forceinline__ void block_to_work(const FastArgs &a, int64_t &clip, int &group) {
+// Persistent workgroups: block b owns a contiguous range of the flat (clip, tile) sequence.
+// XCD-aware: blocks that share an XCD (b % 8) get neighbouring ranges, i.e. whole runs of clips,
+// so halo re-reads and the partial output lines of neighbouring tiles meet in one L2.
+__device__ __forceinline__ void block_to_range(const FastArgs &a, int64_t &tau_begin, int64_t &tau_end) {
   int64_t vb = blockIdx.x;
   const int64_t nb = a.blocks, q = nb / 8, r = nb % 8, xcd = vb % 8, idx = vb / 8;
   vb = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
-  clip = vb / a.groups_per_clip;
-  group = (int)(vb % a.groups_per_clip);
+  const int64_t base = a.total_tiles / nb, extra = a.total_tiles % nb;
+  tau_begin = vb * base + (vb < extra ? vb : extra);
+  tau_end = tau_begin + base + (vb < extra ? 1 : 0);
 }
 
 // One frame: raw samples (registers) -> window -> FFT(1024 complex) -> real post-pass -> |X|^p
@@ -503,26 +506,36 @@ __global__ void __launch_bounds__(1024) stft2048_power_kernel(FastArgs a) {
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // provably wave-uniform (scalar)
   const Lds lds = carve_lds(smem);
-  int64_t clip;
-  int group;
-  block_to_work(a, clip, group);
-  const float *x = a.x + clip * a.x_stride;
   const LaneConst L = setup_lane(a, lds, tid, lane, wave);
+  int64_t tau_begin, tau_end;
+  block_to_range(a, tau_begin, tau_end);
+  if (tau_begin >= tau_end) return;   // uniform for the workgroup
 
-  const int t_begin = group * a.tiles_per_group;
-  int t_end = t_begin + a.tiles_per_group;
-  if (t_end > a.tiles_per_clip) t_end = a.tiles_per_clip;
+  // tile tau -> (clip, first frame, does this wave have a frame)
+  auto frame_of = [&](int64_t tau, const float *&xs, int64_t &p, bool &hv) {
+    const int64_t clip = tau / a.tiles_per_clip;
+    const int64_t f0 = (tau % a.tiles_per_clip) * kFT;
+    hv = f0 + wave < a.count;
+    xs = a.x + clip * a.x_stride;
+    p = a.p0 + f0 + (hv ? wave : 0);
+  };
 
   // prefetch the first frame of this wave
   float2 raw[16];
-  bool have = (int64_t)t_begin * kFT + wave < a.count;
 #pragma unroll
   for (int j = 0; j < 16; ++j) raw[j] = make_float2(0.f, 0.f);
-  prefetch_frame<ALIGNED SMX_ABL_ARG>(a, x, a.p0 + (int64_t)t_begin * kFT + (have ? wave : 0), lane, raw);
+  bool have;
+  {
+    const float *xs;
+    int64_t p;
+    frame_of(tau_begin, xs, p, have);
+    prefetch_frame<ALIGNED SMX_ABL_ARG>(a, xs, p, lane, raw);
+  }
   __syncthreads();   // tables visible
   int cur = 0;
   bool pending = false;      // tile[cur ^ 1] holds the finished previous tile, not yet stored
-  int64_t pend_f0 = 0;
+  float *pend_out = nullptr; // its output origin (clip, first frame) and frames left in that clip
+  int64_t pend_left = 0;
   FlushLane fl;
   {
     const int hsel = lane >> 5, jj = (lane & 31) >> 2;
@@ -531,42 +544,53 @@ __global__ void __launch_bounds__(1024) stft2048_power_kernel(FastArgs a) {
     const int bin0 = (fl.row0 & 3) * 256 + (fl.row0 >> 2);
     fl.goff0 = ((unsigned)bin0 * (unsigned)a.out_stride + 4u * fl.g) * 4u;
   }
-  float *const clip_out = a.out + (clip * kBins) * a.out_stride + a.out_offset;   // wave-uniform
 
 #ifdef SMX_STAMPS
   unsigned long long stamp_sum[kStampSlots] = {0}, stamp_prev;
   asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(stamp_prev)::"memory");
 #endif
-  for (int t = t_begin; t < t_end; ++t) {
-    const int64_t f0 = (int64_t)t * kFT;
+  for (int64_t tau = tau_begin; tau < tau_end; ++tau) {
+    const int64_t clip = tau / a.tiles_per_clip;
+    const int64_t f0 = (tau % a.tiles_per_clip) * kFT;
     SMX_STAMP(0);
     const float *ptile = lds.tiles + (cur ^ 1) * (kTileBytes / sizeof(float));
     if (have) {   // wave-uniform
-      const FlushHook hook{a, ptile, fl, clip_out + pend_f0, a.count - pend_f0, pending ? (wave & 3) : -1, wave, lane};
+      const FlushHook hook{a, ptile, fl, pend_out, pend_left, pending ? (wave & 3) : -1, wave, lane};
       frame_to_tile<SQUARE SMX_ABL_ARG>(a, L, raw, lds.tiles + cur * (kTileBytes / sizeof(float)), wave, lane, hook);
     } else if (pending) {   // no frame for this wave in this tile: still store its share of the previous one
 #pragma unroll
-      for (int it = 0; it < 4; ++it) flush_part(a, ptile, it, fl, clip_out + pend_f0, a.count - pend_f0, wave, lane);
+      for (int it = 0; it < 4; ++it) flush_part(a, ptile, it, fl, pend_out, pend_left, wave, lane);
     }
     SMX_STAMP(6);
-    // prefetch this wave's frame of the next tile (in flight across the barrier)
-    // (unconditional: without a next frame the tile's first frame is re-read and ignored, so
-    //  raw never carries old values around the loop and stays out of the compute's registers)
-    const bool have_next = (t + 1 < t_end) && (f0 + kFT + wave < a.count);
-    prefetch_frame<ALIGNED SMX_ABL_ARG>(a, x, a.p0 + f0 + (have_next ? kFT + wave : 0), lane, raw);
+    // prefetch this wave's frame of the next tile (possibly of the next clip), in flight across the
+    // barrier.  Unconditional: past the end the current tile's first frame is re-read and ignored, so
+    // raw never carries old values around the loop and stays out of the compute's registers.
+    bool have_next = false;
+    {
+      const float *xs;
+      int64_t p;
+      if (tau + 1 < tau_end) {
+        frame_of(tau + 1, xs, p, have_next);
+      } else {
+        xs = a.x + clip * a.x_stride;
+        p = a.p0 + f0;
+      }
+      prefetch_frame<ALIGNED SMX_ABL_ARG>(a, xs, p, lane, raw);
+    }
     SMX_STAMP(7);
     __syncthreads();   // the ONLY barrier per tile: tile[cur] complete; tile[cur^1] free again
     SMX_STAMP(8);
     // tile[cur] is complete; its stores are interleaved with the next frame's stages
     pending = true;
-    pend_f0 = f0;
+    pend_out = a.out + (clip * kBins) * a.out_stride + a.out_offset + f0;   // wave-uniform
+    pend_left = a.count - f0;
     have = have_next;
     cur ^= 1;
   }
-  if (pending) {   // the last tile of this group
+  if (pending) {   // the last tile of this workgroup
     const float *ptile = lds.tiles + (cur ^ 1) * (kTileBytes / sizeof(float));
 #pragma unroll
-    for (int it = 0; it < 4; ++it) flush_part(a, ptile, it, fl, clip_out + pend_f0, a.count - pend_f0, wave, lane);
+    for (int it = 0; it < 4; ++it) flush_part(a, ptile, it, fl, pend_out, pend_left, wave, lane);
   }
 #ifdef SMX_STAMPS
   if (lane == 0 && blockIdx.x < 4096)
@@ -618,11 +642,10 @@ __global__ void __launch_bounds__(1024) stft2048_mel_kernel(FastArgs a, MelFused
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const Lds lds = carve_lds(smem);
-  int64_t clip;
-  int group;
-  block_to_work(a, clip, group);
-  const float *x = a.x + clip * a.x_stride;
   const LaneConst L = setup_lane(a, lds, tid, lane, wave);
+  int64_t tau_begin, tau_end;
+  block_to_range(a, tau_begin, tau_end);
+  if (tau_begin >= tau_end) return;            // uniform for the workgroup
   MelItem item = m.items[wave];                // wave-uniform: force every field into SGPRs
   item.block = __builtin_amdgcn_readfirstlane(item.block);
   item.k4_begin = __builtin_amdgcn_readfirstlane(item.k4_begin);
@@ -634,25 +657,34 @@ __global__ void __launch_bounds__(1024) stft2048_mel_kernel(FastArgs a, MelFused
 #pragma unroll
   for (int i = 0; i < 3; ++i) item.slots[i] = __builtin_amdgcn_readfirstlane(item.slots[i]);
 
-  const int t_begin = group * a.tiles_per_group;
-  int t_end = t_begin + a.tiles_per_group;
-  if (t_end > a.tiles_per_clip) t_end = a.tiles_per_clip;
-
+  // tile tau -> (clip, first frame, does this wave have a frame)
+  auto frame_of = [&](int64_t tau, const float *&xs, int64_t &p, bool &hv) {
+    const int64_t clip = tau / a.tiles_per_clip;
+    const int64_t f0 = (tau % a.tiles_per_clip) * kFT;
+    hv = f0 + wave < a.count;
+    xs = a.x + clip * a.x_stride;
+    p = a.p0 + f0 + (hv ? wave : 0);
+  };
   float2 raw[16];
-  bool have = (int64_t)t_begin * kFT + wave < a.count;
-  load_frame<ALIGNED>(a, x, a.p0 + (int64_t)t_begin * kFT + (have ? wave : 0), lane, raw);
+  bool have;
+  {
+    const float *xs;
+    int64_t p;
+    frame_of(tau_begin, xs, p, have);
+    load_frame<ALIGNED>(a, xs, p, lane, raw);
+  }
   __syncthreads();   // tables visible
-
-  float *const clip_out = m.out + (clip * m.n_mels) * m.out_stride + m.out_offset;   // wave-uniform
   const int pad_lane = (16 + lane) * kTileStride + kFT;     // pad-column slot of this lane (rows >= 16)
   constexpr int kTileFloats = kTileBytes / sizeof(float);
   int cur = 0;
   int stage = 0;              // tiles computed so far in this group
-  int64_t f0_m1 = 0, f0_m2 = 0;   // first frame of tile t-1 / t-2
+  // output origin (clip, first frame) and frames left in the clip, of tile t-1 / t-2
+  float *out_m1 = nullptr, *out_m2 = nullptr;
+  int64_t left_m1 = 0, left_m2 = 0;
   f32x4v acc_prev = {0.f, 0.f, 0.f, 0.f};
 
   // (A) owner: finish the tile whose MFMA partials were produced one iteration ago
-  auto finish = [&](const float *buf, int64_t f0) {
+  auto finish = [&](const float *buf, float *obase, int64_t frames_left) {
     if (!item.owner) return;
     f32x4v total = acc_prev;
     for (int s = 0; s < item.nslots; ++s) {
@@ -661,11 +693,11 @@ __global__ void __launch_bounds__(1024) stft2048_mel_kernel(FastArgs a, MelFused
       for (int reg = 0; reg < 4; ++reg) total[reg] += pp[(64 * reg) * kTileStride];
     }
     const int f = lane & 15;
-    if (f0 + f < a.count) {
+    if (f < frames_left) {
 #pragma unroll
       for (int reg = 0; reg < 4; ++reg) {
         const int mel = 16 * item.block + 4 * (lane >> 4) + reg;
-        if (mel < m.n_mels) clip_out[(int64_t)mel * m.out_stride + f0 + f] = total[reg];
+        if (mel < m.n_mels) obase[(int64_t)mel * m.out_stride + f] = total[reg];
       }
     }
   };
@@ -727,27 +759,40 @@ __global__ void __launch_bounds__(1024) stft2048_mel_kernel(FastArgs a, MelFused
     }
   };
 
-  for (int t = t_begin; t < t_end; ++t) {
-    const int64_t f0 = (int64_t)t * kFT;
+  for (int64_t tau = tau_begin; tau < tau_end; ++tau) {
+    const int64_t clip = tau / a.tiles_per_clip;
+    const int64_t f0 = (tau % a.tiles_per_clip) * kFT;
     float *tcur = lds.tiles + cur * kTileFloats;
     float *tprev = lds.tiles + (cur ^ 1) * kTileFloats;
-    if (stage >= 2) finish(tcur, f0_m2);          // partials of tile t-2 sit in this buffer's pad column
-    if (stage >= 1) mfma_item(tprev);             // tile t-1
+    if (stage >= 2) finish(tcur, out_m2, left_m2);   // partials of tile t-2 sit in this buffer's pad column
+    if (stage >= 1) mfma_item(tprev);                // tile t-1
     if (have) frame_to_tile<SQUARE SMX_ABL_ZERO>(a, L, raw, tcur, wave, lane, NoHook{});
-    const bool have_next = (t + 1 < t_end) && (f0 + kFT + wave < a.count);
-    load_frame<ALIGNED>(a, x, a.p0 + f0 + (have_next ? kFT + wave : 0), lane, raw);
+    bool have_next = false;
+    {
+      const float *xs;
+      int64_t p;
+      if (tau + 1 < tau_end) {
+        frame_of(tau + 1, xs, p, have_next);
+      } else {
+        xs = a.x + clip * a.x_stride;
+        p = a.p0 + f0;
+      }
+      load_frame<ALIGNED>(a, xs, p, lane, raw);
+    }
     __syncthreads();
-    f0_m2 = f0_m1;
-    f0_m1 = f0;
+    out_m2 = out_m1;
+    left_m2 = left_m1;
+    out_m1 = m.out + (clip * m.n_mels) * m.out_stride + m.out_offset + f0;   // wave-uniform
+    left_m1 = a.count - f0;
     have = have_next;
     cur ^= 1;
-    ++stage;
+    if (stage < 2) ++stage;
   }
   // drain: tile T-2 (partials in buffer `cur`), MFMA on tile T-1 (buffer cur^1), then its finish
-  if (stage >= 2) finish(lds.tiles + cur * kTileFloats, f0_m2);
+  if (stage >= 2) finish(lds.tiles + cur * kTileFloats, out_m2, left_m2);
   if (stage >= 1) mfma_item(lds.tiles + (cur ^ 1) * kTileFloats);
   __syncthreads();
-  if (stage >= 1) finish(lds.tiles + (cur ^ 1) * kTileFloats, f0_m1);
+  if (stage >= 1) finish(lds.tiles + (cur ^ 1) * kTileFloats, out_m1, left_m1);
 }
 
 }  // namespace
@@ -820,14 +865,18 @@ void launch_interior(const StftJob &job, const FastTarget &tg, const float *x, i
   const int64_t tiles = (count + kFT - 1) / kFT;
   if (tiles > 0x7fffffff) throw Failure("stft: too many frame tiles for one launch");
   a.tiles_per_clip = (int)tiles;
-  // enough workgroups to fill 256 CUs several times over, while amortising the
-  // per-workgroup twiddle-table fill over a few tiles
-  int tpg = 8;
-  while (tpg > 1 && job.lead * ((tiles + tpg - 1) / tpg) < 2048) tpg >>= 1;
-  a.tiles_per_group = tpg;
-  a.groups_per_clip = (int)((tiles + tpg - 1) / tpg);
-  a.blocks = job.lead * a.groups_per_clip;
-  if (a.blocks > 0x7fffffff) throw Failure("stft: too many workgroups for one launch");
+  // persistent workgroups: one per CU (160 KB of LDS each), every one walks a contiguous range of the
+  // flat (clip, tile) sequence, so the table fill / first-load latency / final flush are paid once
+  a.total_tiles = job.lead * tiles;
+  static int cu_count = 0;
+  if (cu_count == 0) {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    SMX_HIP_CHECK(hipGetDevice(&dev));
+    SMX_HIP_CHECK(hipGetDeviceProperties(&prop, dev));
+    cu_count = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+  }
+  a.blocks = a.total_tiles < cu_count ? a.total_tiles : cu_count;
   a.pmode = job.power == 2.0 ? 2 : (job.power == 1.0 ? 1 : 0);
   a.half_power = (float)(0.5 * job.power);
   const bool aligned = (c.hop % 2 == 0) && (left % 2 == 0) && (x_stride % 2 == 0) &&
