@@ -8,16 +8,24 @@
 // Two consecutive real blocks of one channel are packed as ONE complex signal
 // z = a + i b: filtering with a real h commutes with the packing, so a single
 // complex FFT(N) -> pointwise multiply with H -> inverse FFT(N) yields both
-// blocks (real part / imaginary part) with no real-FFT post-pass.  The forward
-// transform is decimation-in-frequency (natural in, bit-reversed out) and the
-// inverse decimation-in-time (bit-reversed in, natural out); H is stored in
-// bit-reversed order with the 1/N folded in, so no reordering pass exists.
-// One 1024-thread workgroup owns a block pair; the N complex points live in
-// LDS (N = 16384 -> 128 KB); radix-2 passes, twiddles from a float64-built table.
+// blocks (real part / imaginary part) with no real-FFT post-pass.
+//
+// FFT: in-place Stockham (autosort) passes of radix 16 / 4 / 2 -- N = 16384 is
+// 16.16.16.4.  One workgroup of N/16 threads owns a block pair; every thread keeps 16
+// complex points in registers, so a pass is: read 16 (lane-contiguous, conflict free),
+// barrier, twiddle + register DFT, write 16 to the autosort positions, barrier.  LDS
+// addresses are XOR-swizzled (a ^ ((a >> 5) & 31)) which makes every pass's reads
+// conflict free and its writes at most 2-way (tools/sim_fir_fft.py).  The first
+// pass reads HBM straight into registers, the last inverse pass stores to HBM from
+// registers, the H multiply happens in registers between the two transforms and the
+// inverse is conj(FFT(conj(.))) with 1/N folded into H: 7 LDS round trips for
+// N = 16384.  Twiddles: one table read per pass and radix group, powers by binary
+// multiplication (depth <= 4).
 //
 // Algorithmic HBM bytes: 8 B per sample (4 in + 4 out) plus the (taps-1)/L halo.
 #include <cmath>
 
+#include "fft_device.hpp"
 #include "smx_internal.hpp"
 
 struct smx_fir_plan {
@@ -27,7 +35,7 @@ struct smx_fir_plan {
   int log2n = 0;
   std::vector<double> h;
   struct Tables {
-    float2 *h_br = nullptr;   // H[brev(pos)] / N
+    float2 *h_nat = nullptr;  // H[k] / N, natural order
     float2 *tw = nullptr;     // exp(-2 pi i j / N), j < N/2
   };
   const Tables &tables() const;
@@ -54,11 +62,122 @@ struct FirArgs {
   int64_t taps, nfft, valid;
   int log2n;
   int64_t pairs_per_channel;
-  const float2 *h_br;
-  const float2 *tw;
+  const float2 *h_nat;
+  const float2 *tw;     // exp(-2 pi i j / N), j < N/2
 };
 
-__global__ void __launch_bounds__(1024) fir_ols_kernel(FirArgs a) {
+using namespace fftdev;
+
+__device__ __forceinline__ int swz(int a) { return a ^ ((a >> 5) & 31); }
+
+// powers w^1 .. w^(R-1) of a unit twiddle by binary multiplication (depth <= 4)
+template <int R>
+__device__ __forceinline__ void twiddle_powers(c32 w1, c32 (&w)[16]) {
+  w[1] = w1;
+  if constexpr (R >= 4) {
+    w[2] = cmul(w1, w1);
+    w[3] = cmul(w[2], w1);
+  }
+  if constexpr (R >= 16) {
+    w[4] = cmul(w[2], w[2]);
+    w[5] = cmul(w[4], w1);
+    w[6] = cmul(w[4], w[2]);
+    w[7] = cmul(w[4], w[3]);
+    w[8] = cmul(w[4], w[4]);
+#pragma unroll
+    for (int j = 9; j < 16; ++j) w[j] = cmul(w[8], w[j - 8]);
+  }
+}
+
+// One Stockham pass of radix R with sub-transform size NS (see tools/sim_fir_fft.py).
+// r[i*R + j] is element j of radix group i (G = 16/R groups per thread, t_i = tid + T*i).
+// READ: registers come from LDS (false for the very first pass: they hold the loaded samples);
+// WRITE: results go back to LDS at the autosort positions (false for the last pass of a transform,
+// whose outputs stay in registers with natural index out_index<R,NS>(tid, i, j)).
+template <int N, int R, int NS, bool READ, bool WRITE>
+__device__ __forceinline__ void stockham_pass(c32 (&r)[16], float2 *z, int tid, const float2 *tw) {
+  constexpr int T = N / 16, G = 16 / R;
+  if constexpr (READ) {
+    __syncthreads();   // the previous pass's writes are visible
+#pragma unroll
+    for (int i = 0; i < G; ++i)
+#pragma unroll
+      for (int j = 0; j < R; ++j) {
+        const float2 v = z[swz(tid + T * (i + G * j))];
+        r[i * R + j] = {v.x, v.y};
+      }
+    __syncthreads();   // everyone holds its points: the buffer may be overwritten
+  }
+#pragma unroll
+  for (int i = 0; i < G; ++i) {
+    if constexpr (NS > 1) {
+      const int k = (tid + T * i) % NS;
+      const float2 w1 = tw[k * (N / (NS * R))];
+      c32 w[16];
+      twiddle_powers<R>(c32{w1.x, w1.y}, w);
+#pragma unroll
+      for (int j = 1; j < R; ++j) r[i * R + j] = cmul(r[i * R + j], w[j]);
+    }
+    if constexpr (R == 16) {
+      fft16(r);
+    } else if constexpr (R == 4) {
+      fft4(r[4 * i], r[4 * i + 1], r[4 * i + 2], r[4 * i + 3]);
+    } else {
+      const c32 u = r[2 * i], v = r[2 * i + 1];
+      r[2 * i] = u + v;
+      r[2 * i + 1] = u - v;
+    }
+  }
+  if constexpr (WRITE) {
+#pragma unroll
+    for (int i = 0; i < G; ++i) {
+      const int t = tid + T * i, k = t % NS;
+      const int j0 = (t / NS) * NS * R + k;
+#pragma unroll
+      for (int j = 0; j < R; ++j) z[swz(j0 + j * NS)] = make_float2(r[i * R + j].x, r[i * R + j].y);
+    }
+  }
+}
+
+template <int R, int NS, int T>
+__device__ __forceinline__ int out_index(int tid, int i, int j) {
+  const int t = tid + T * i, k = t % NS;
+  return (t / NS) * NS * R + k + j * NS;
+}
+
+// forward FFT of the 16 points per thread; FIRST: registers already hold element tid + T*m in r[m].
+// On return r[i*R + j] (last radix R, its NS) holds natural-order element out_index<R, NS, T>(tid, i, j).
+template <int LOG2N, bool FIRST>
+__device__ __forceinline__ void fft_passes(c32 (&r)[16], float2 *z, int tid, const float2 *tw) {
+  constexpr int N = 1 << LOG2N;
+  stockham_pass<N, 16, 1, !FIRST, true>(r, z, tid, tw);
+  stockham_pass<N, 16, 16, true, true>(r, z, tid, tw);
+  if constexpr (LOG2N == 10) {
+    stockham_pass<N, 4, 256, true, false>(r, z, tid, tw);
+  } else if constexpr (LOG2N == 11) {
+    stockham_pass<N, 4, 256, true, true>(r, z, tid, tw);
+    stockham_pass<N, 2, 1024, true, false>(r, z, tid, tw);
+  } else if constexpr (LOG2N == 12) {
+    stockham_pass<N, 16, 256, true, false>(r, z, tid, tw);
+  } else if constexpr (LOG2N == 13) {
+    stockham_pass<N, 16, 256, true, true>(r, z, tid, tw);
+    stockham_pass<N, 2, 4096, true, false>(r, z, tid, tw);
+  } else {
+    stockham_pass<N, 16, 256, true, true>(r, z, tid, tw);
+    stockham_pass<N, 4, 4096, true, false>(r, z, tid, tw);
+  }
+}
+
+template <int LOG2N>
+struct LastPass {   // radix / sub-size of the final pass of fft_passes<LOG2N>
+  static constexpr int R = (LOG2N == 10 || LOG2N == 14) ? 4 : (LOG2N == 12 ? 16 : 2);
+  static constexpr int NS = (1 << LOG2N) / R;
+};
+
+template <int LOG2N>
+__global__ void __launch_bounds__((1 << LOG2N) / 16) fir_ols_kernel(FirArgs a) {
+  constexpr int N = 1 << LOG2N, T = N / 16;
+  constexpr int RL = LastPass<LOG2N>::R, NSL = LastPass<LOG2N>::NS, GL = 16 / RL;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   float2 *z = reinterpret_cast<float2 *>(smem);
   const int tid = threadIdx.x;
@@ -66,56 +185,39 @@ __global__ void __launch_bounds__(1024) fir_ols_kernel(FirArgs a) {
   const int64_t pair = blockIdx.x % a.pairs_per_channel;
   const float *x = a.x + channel * a.x_stride;
   float *y = a.y + channel * a.y_stride;
-  const int64_t N = a.nfft;
   const int64_t base_a = (2 * pair) * a.valid - (a.taps - 1);      // first input of block a
   const int64_t base_b = base_a + a.valid;
-  for (int64_t i = tid; i < N; i += 1024) {
-    const int64_t sa = base_a + i, sb = base_b + i;
-    float2 v;
-    v.x = (sa >= 0 && sa < a.n) ? x[sa] : 0.0f;
-    v.y = (sb >= 0 && sb < a.n) ? x[sb] : 0.0f;
-    z[i] = v;
+  c32 r[16];
+#pragma unroll
+  for (int m = 0; m < 16; ++m) {   // element tid + T*m: lane-contiguous HBM reads, zeros outside the stream
+    const int64_t sa = base_a + tid + T * m, sb = base_b + tid + T * m;
+    r[m].x = (sa >= 0 && sa < a.n) ? x[sa] : 0.0f;
+    r[m].y = (sb >= 0 && sb < a.n) ? x[sb] : 0.0f;
   }
-  // forward DIF: natural -> bit-reversed
-  for (int64_t half = N >> 1; half >= 1; half >>= 1) {
-    __syncthreads();
-    const int64_t tstep = (N >> 1) / half;
-    for (int64_t b = tid; b < (N >> 1); b += 1024) {
-      const int64_t j = b & (half - 1);
-      const int64_t i0 = ((b - j) << 1) + j, i1 = i0 + half;
-      const float2 w = a.tw[j * tstep];
-      const float2 u = z[i0], v = z[i1];
-      const float2 d = make_float2(u.x - v.x, u.y - v.y);
-      z[i0] = make_float2(u.x + v.x, u.y + v.y);
-      z[i1] = make_float2(d.x * w.x - d.y * w.y, d.x * w.y + d.y * w.x);
+  fft_passes<LOG2N, true>(r, z, tid, a.tw);
+  // Y = Z * H (1/N folded in); inverse = conj(FFT(conj(Y))): store conj(Y) for the second transform
+#pragma unroll
+  for (int i = 0; i < GL; ++i)
+#pragma unroll
+    for (int j = 0; j < RL; ++j) {
+      const int idx = out_index<RL, NSL, T>(tid, i, j);
+      const float2 hv = a.h_nat[idx];
+      const c32 yv = cmul(r[i * RL + j], c32{hv.x, hv.y});
+      z[swz(idx)] = make_float2(yv.x, -yv.y);
     }
-  }
-  __syncthreads();
-  for (int64_t i = tid; i < N; i += 1024) {
-    const float2 hv = a.h_br[i], v = z[i];
-    z[i] = make_float2(v.x * hv.x - v.y * hv.y, v.x * hv.y + v.y * hv.x);
-  }
-  // inverse DIT: bit-reversed -> natural (conjugate twiddles)
-  for (int64_t half = 1; half < N; half <<= 1) {
-    __syncthreads();
-    const int64_t tstep = (N >> 1) / half;
-    for (int64_t b = tid; b < (N >> 1); b += 1024) {
-      const int64_t j = b & (half - 1);
-      const int64_t i0 = ((b - j) << 1) + j, i1 = i0 + half;
-      const float2 w = a.tw[j * tstep];
-      const float2 u = z[i0], v = z[i1];
-      const float2 t = make_float2(v.x * w.x + v.y * w.y, v.y * w.x - v.x * w.y);   // v * conj(w)
-      z[i0] = make_float2(u.x + t.x, u.y + t.y);
-      z[i1] = make_float2(u.x - t.x, u.y - t.y);
-    }
-  }
-  __syncthreads();
+  fft_passes<LOG2N, false>(r, z, tid, a.tw);
   const int64_t out_a = (2 * pair) * a.valid, out_b = out_a + a.valid;
-  for (int64_t i = tid; i < a.valid; i += 1024) {
-    const float2 v = z[i + a.taps - 1];
-    if (out_a + i < a.n) y[out_a + i] = v.x;
-    if (out_b + i < a.n) y[out_b + i] = v.y;
-  }
+  const int skip = (int)a.taps - 1;
+#pragma unroll
+  for (int i = 0; i < GL; ++i)
+#pragma unroll
+    for (int j = 0; j < RL; ++j) {
+      const int idx = out_index<RL, NSL, T>(tid, i, j) - skip;   // position inside the valid span
+      if (idx >= 0) {
+        if (out_a + idx < a.n) y[out_a + idx] = r[i * RL + j].x;      // Re(conj(.)) =  Re
+        if (out_b + idx < a.n) y[out_b + idx] = -r[i * RL + j].y;     // Im(conj(.)) = -Im
+      }
+    }
 }
 
 }  // namespace
@@ -127,11 +229,10 @@ const smx_fir_plan::Tables &smx_fir_plan::tables() const {
   std::lock_guard<std::mutex> lock(mutex_);
   auto it = tables_.find(device);
   if (it != tables_.end()) return it->second;
-  // H = DFT_N(h) in float64 (direct recurrence-free evaluation through a radix-2 FFT in double)
+  // H = DFT_N(h) in float64: iterative DIF (bit-reversed out), then unscrambled to natural order
   const int64_t N = nfft;
   std::vector<double> re((size_t)N, 0.0), im((size_t)N, 0.0);
   for (int64_t i = 0; i < taps; ++i) re[(size_t)i] = h[(size_t)i];
-  // iterative DIF in double, output bit-reversed: exactly the order the kernel multiplies in
   for (int64_t half = N >> 1; half >= 1; half >>= 1) {
     const int64_t tstep = (N >> 1) / half;
     for (int64_t b = 0; b < (N >> 1); ++b) {
@@ -147,15 +248,17 @@ const smx_fir_plan::Tables &smx_fir_plan::tables() const {
     }
   }
   std::vector<float2> hb((size_t)N), tw((size_t)(N / 2 > 0 ? N / 2 : 1));
-  for (int64_t i = 0; i < N; ++i)
-    hb[(size_t)i] = make_float2((float)(re[(size_t)i] / (double)N), (float)(im[(size_t)i] / (double)N));
+  for (int64_t i = 0; i < N; ++i) {
+    const unsigned k = smx::brev_host((unsigned)i, log2n);   // position i holds H[brev(i)]
+    hb[k] = make_float2((float)(re[(size_t)i] / (double)N), (float)(im[(size_t)i] / (double)N));
+  }
   for (int64_t j = 0; j < N / 2; ++j) {
     const double ang = -2.0 * M_PI * (double)j / (double)N;
     tw[(size_t)j] = make_float2((float)std::cos(ang), (float)std::sin(ang));
   }
   Tables t;
-  SMX_HIP_CHECK(hipMalloc((void **)&t.h_br, hb.size() * sizeof(float2)));
-  SMX_HIP_CHECK(hipMemcpy(t.h_br, hb.data(), hb.size() * sizeof(float2), hipMemcpyHostToDevice));
+  SMX_HIP_CHECK(hipMalloc((void **)&t.h_nat, hb.size() * sizeof(float2)));
+  SMX_HIP_CHECK(hipMemcpy(t.h_nat, hb.data(), hb.size() * sizeof(float2), hipMemcpyHostToDevice));
   SMX_HIP_CHECK(hipMalloc((void **)&t.tw, tw.size() * sizeof(float2)));
   SMX_HIP_CHECK(hipMemcpy(t.tw, tw.data(), tw.size() * sizeof(float2), hipMemcpyHostToDevice));
   return tables_.emplace(device, t).first->second;
@@ -163,7 +266,7 @@ const smx_fir_plan::Tables &smx_fir_plan::tables() const {
 
 smx_fir_plan::~smx_fir_plan() {
   for (auto &kv : tables_) {
-    (void)hipFree(kv.second.h_br);
+    (void)hipFree(kv.second.h_nat);
     (void)hipFree(kv.second.tw);
   }
 }
@@ -204,14 +307,24 @@ void fir_apply_dev(const smx_fir_plan &p, const float *d_x, int64_t channels, in
   a.log2n = p.log2n;
   const int64_t blocks = (n + p.valid - 1) / p.valid;
   a.pairs_per_channel = (blocks + 1) / 2;
-  a.h_br = t.h_br;
+  a.h_nat = t.h_nat;
   a.tw = t.tw;
   const int64_t grid = channels * a.pairs_per_channel;
   if (grid > 0x7fffffff) throw Failure("fir_apply: too many blocks for one launch");
   const size_t lds = (size_t)p.nfft * sizeof(float2);
-  SMX_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(fir_ols_kernel),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  hipLaunchKernelGGL(fir_ols_kernel, dim3((unsigned)grid), dim3(1024), lds, stream, a);
+  auto launch = [&](auto kernel, int threads) {
+    SMX_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kernel),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(kernel, dim3((unsigned)grid), dim3(threads), lds, stream, a);
+  };
+  switch (p.log2n) {
+    case 10: launch(fir_ols_kernel<10>, 64); break;
+    case 11: launch(fir_ols_kernel<11>, 128); break;
+    case 12: launch(fir_ols_kernel<12>, 256); break;
+    case 13: launch(fir_ols_kernel<13>, 512); break;
+    case 14: launch(fir_ols_kernel<14>, 1024); break;
+    default: throw Failure("fir_apply: unsupported block size");
+  }
   SMX_HIP_CHECK(hipGetLastError());
 }
 }  // namespace
