@@ -33,6 +33,7 @@
 // Algorithmic HBM bytes per frame: hop*4 read + 1025*4 written = 6148 B at
 // hop 512.  Flops per frame ~= 50k VALU lane-ops.
 #include <cstdlib>
+#include <type_traits>
 
 #include "fft_device.hpp"
 #include "smx_internal.hpp"
@@ -429,8 +430,10 @@ struct FlushHook {
   }
 };
 
-// SQUARE = power 2 (no per-bin branch); otherwise |X|^p through pmode / half_power
-template <bool ALIGNED, bool SQUARE SMX_ABL_PARAM>
+// SQUARE = power 2 (no per-bin branch); otherwise |X|^p through pmode / half_power.
+// STRIP only names the instantiation used for the small gathered border strips, so that kernel-trace
+// statistics separate them from the interior launch (the code is identical).
+template <bool ALIGNED, bool SQUARE, bool STRIP SMX_ABL_PARAM>
 __global__ void __launch_bounds__(1024) stft2048_power_kernel(FastArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x;
@@ -566,7 +569,7 @@ struct NoHook {
   __device__ __forceinline__ void at() const {}
 };
 
-template <bool ALIGNED, bool SQUARE>
+template <bool ALIGNED, bool SQUARE, bool STRIP>
 __global__ void __launch_bounds__(1024) stft2048_mel_kernel(FastArgs a, MelFusedArgs m) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x;
@@ -773,7 +776,7 @@ struct FastTarget {
 
 // one launch of the fused kernel over frames that all lie inside [0, n)
 void launch_interior(const StftJob &job, const FastTarget &tg, const float *x, int64_t n, int64_t x_stride,
-                     int64_t left, int64_t p0, int64_t count, int64_t out_offset) {
+                     int64_t left, int64_t p0, int64_t count, int64_t out_offset, bool strip = false) {
   if (count <= 0) return;
   const smx_stft_config &c = *job.cfg;
   const StftTables &t = c.tables();
@@ -816,8 +819,12 @@ void launch_interior(const StftJob &job, const FastTarget &tg, const float *x, i
   if (tg.mel) {
     MelFusedArgs m = *tg.mel;
     m.out_offset = out_offset;
-    auto kernel = aligned ? (square ? stft2048_mel_kernel<true, true> : stft2048_mel_kernel<true, false>)
-                          : (square ? stft2048_mel_kernel<false, true> : stft2048_mel_kernel<false, false>);
+    auto pick = [&](auto strip_tag) {
+      constexpr bool S = decltype(strip_tag)::value;
+      return aligned ? (square ? stft2048_mel_kernel<true, true, S> : stft2048_mel_kernel<true, false, S>)
+                     : (square ? stft2048_mel_kernel<false, true, S> : stft2048_mel_kernel<false, false, S>);
+    };
+    auto kernel = strip ? pick(std::true_type{}) : pick(std::false_type{});
     SMX_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kernel),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)kFastLds));
     hipLaunchKernelGGL(kernel, dim3((unsigned)a.blocks), dim3(1024), kFastLds, job.stream, a, m);
@@ -828,15 +835,19 @@ void launch_interior(const StftJob &job, const FastTarget &tg, const float *x, i
   const char *abl_env = std::getenv("SMX_ABLATE");
   const int abl = abl_env ? std::atoi(abl_env) : 0;
   a.abl_nostore = (abl == 1 || abl == 3) ? 1 : 0;
-  auto kernel = abl == 2 ? stft2048_power_kernel<true, true, 2>
-              : abl == 3 ? stft2048_power_kernel<true, true, 3>
-              : abl == 4 ? stft2048_power_kernel<true, true, 4>
-              : abl == 5 ? stft2048_power_kernel<true, true, 5>
-                         : stft2048_power_kernel<true, true, 0>;
-  (void)aligned; (void)square;
+  auto kernel = abl == 2 ? stft2048_power_kernel<true, true, false, 2>
+              : abl == 3 ? stft2048_power_kernel<true, true, false, 3>
+              : abl == 4 ? stft2048_power_kernel<true, true, false, 4>
+              : abl == 5 ? stft2048_power_kernel<true, true, false, 5>
+                         : stft2048_power_kernel<true, true, false, 0>;
+  (void)aligned; (void)square; (void)strip;
 #else
-  auto kernel = aligned ? (square ? stft2048_power_kernel<true, true> : stft2048_power_kernel<true, false>)
-                        : (square ? stft2048_power_kernel<false, true> : stft2048_power_kernel<false, false>);
+  auto pick = [&](auto strip_tag) {
+    constexpr bool S = decltype(strip_tag)::value;
+    return aligned ? (square ? stft2048_power_kernel<true, true, S> : stft2048_power_kernel<true, false, S>)
+                   : (square ? stft2048_power_kernel<false, true, S> : stft2048_power_kernel<false, false, S>);
+  };
+  auto kernel = strip ? pick(std::true_type{}) : pick(std::false_type{});
 #endif
   SMX_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kernel),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)kFastLds));
@@ -858,7 +869,7 @@ void launch_border(const StftJob &job, const FastTarget &tg, int64_t pa, int64_t
                      reinterpret_cast<const float *>(job.x), job.n, job.x_stride, pos0, len, job.pad,
                      (float)job.pad_value, strip, stride);
   SMX_HIP_CHECK(hipGetLastError());
-  launch_interior(job, tg, strip, len, stride, 0, 0, pb - pa, tg.out_offset + (pa - job.p0));
+  launch_interior(job, tg, strip, len, stride, 0, 0, pb - pa, tg.out_offset + (pa - job.p0), /*strip=*/true);
   SMX_HIP_CHECK(hipFreeAsync(strip, job.stream));
 }
 
