@@ -63,7 +63,7 @@ __device__ __forceinline__ void fft16(c32 (&v)[16]) {
 #ifdef SMX_STAMPS
 // Diagnostic build only (make STAMPS=1): per-phase cycle sums of every wave, read back with
 // smx_debug_read_stamps().  Never compiled into the shipped library; no output depends on it.
-constexpr int kStampSlots = 12;
+constexpr int kStampSlots = 24;
 __device__ unsigned long long g_stamp_sums[4096 * 16 * kStampSlots];
 #define SMX_STAMP(i)                                                                      \
   do {                                                                                    \

@@ -125,11 +125,16 @@ struct FastArgs {
   int tiles_per_clip;
   int64_t total_tiles;     // lead * tiles_per_clip: a flat (clip, tile) sequence
   int64_t blocks;          // persistent workgroups; each owns a contiguous range of the sequence
+  int interleave;       // power kernel: workgroups of an XCD share a chunk of the sequence tile by tile
   int pmode;            // 2: power 2, 1: power 1, 0: general
   int abl_nostore;      // diagnostic builds only
   float half_power;
 };
 
+#ifndef SMX_LDSX
+#define SMX_LDSX 0
+#endif
+constexpr bool kLdsX = SMX_LDSX != 0;   // power kernel: transpose through the tile column (see frame_to_tile)
 constexpr int kWaves = 16, kFT = 16;            // one frame per wave per tile
 constexpr int kTileStride = kFT + 1;            // floats per tile row (pad column 16)
 // A tile holds bins 0..1023 as rows; bin 1024 (Nyquist) of frame f lives in the otherwise
@@ -163,13 +168,11 @@ __device__ __forceinline__ void load16_f2(const float2 *base, int lane, float2 (
 // Every frame given to this kernel lies inside the signal (border frames arrive
 // through gathered, already padded strips -- see launch_stft_fast).  p is wave-uniform.
 template <bool ALIGNED>
-__device__ __forceinline__ void load_frame(const FastArgs &a, const float *x, int64_t p, int lane,
+__device__ __forceinline__ void load_frame(const float *src /* first sample of the frame */, int lane,
                                            float2 (&raw)[16]) {
-  const int64_t s0 = p * a.hop - a.left;
   if constexpr (ALIGNED) {
-    load16_f2(reinterpret_cast<const float2 *>(x + s0), lane, raw);
+    load16_f2(reinterpret_cast<const float2 *>(src), lane, raw);
   } else {
-    const float *src = x + s0;
     long hi_off = 1024;
     asm volatile("" : "+s"(hi_off));
     const float *hi = src + hi_off;
@@ -188,19 +191,27 @@ __device__ __forceinline__ void load_frame(const FastArgs &a, const float *x, in
 // NEXT frame so the store traffic is spread over the arithmetic instead of bursting.
 // Addresses: `obase` (clip / tile origin) is wave-uniform and stays in SGPRs; lanes carry one
 // 32-bit byte offset (goff0) and one LDS offset (row0), the four parts differ by constants.
+// Pad-column row that holds the Nyquist bin of frame f.  With the LDS transpose (LDSX) pad rows
+// [64 w, 64 w + 60) are wave w's scratch, so the Nyquist slots move to the free rows 64 f + 60.
+template <bool LDSX>
+__device__ __forceinline__ constexpr int nyquist_row(int f) {
+  return LDSX ? 64 * f + 60 : f;
+}
+
 struct FlushLane {
   int row0;          // tile row of part 0: 32 * wave + rloc
   unsigned goff0;    // byte offset of out[bin0][4 g] from the tile origin
   int g;
 };
+template <bool LDSX>
 __device__ __forceinline__ void flush_part(const FastArgs &a, const float *tile, int it, const FlushLane &fl,
-                                           float *obase, int64_t frames_left, int wave, int lane) {
+                                           float *obase, int frames_left, int wave, int lane) {
   const int row = fl.row0 + 512 * (it >> 1) + 8 * (it & 1);
   const float *src = tile + row * kTileStride + 4 * fl.g;
   const float v0 = src[0], v1 = src[1], v2 = src[2], v3 = src[3];
   // bin(row + 8) = bin + 2, bin(row + 512) = bin + 128
   const unsigned goff = fl.goff0 + (unsigned)(2 * (it & 1) + 128 * (it >> 1)) * (unsigned)a.out_stride * 4u;
-  const int64_t fleft = frames_left - 4 * fl.g;    // frames remaining from this column group
+  const int fleft = frames_left - 4 * fl.g;    // frames remaining from this column group
 #ifdef SMX_DIAG
   if (a.abl_nostore) {   // timing-only ablation: keep the LDS reads alive, drop the HBM stores
     asm volatile("" ::"v"(v0), "v"(v1), "v"(v2), "v"(v3));
@@ -216,7 +227,7 @@ __device__ __forceinline__ void flush_part(const FastArgs &a, const float *tile,
     if (fleft > 2) dst[2] = v2;
   }
   if (it == 3 && wave == 0 && lane < 16) {   // bin 1024 (row 1024): 16 frames by 16 lanes
-    if (lane < frames_left) obase[(int64_t)kM * a.out_stride + lane] = tile[lane * kTileStride + kFT];
+    if (lane < frames_left) obase[(int64_t)kM * a.out_stride + lane] = tile[nyquist_row<LDSX>(lane) * kTileStride + kFT];
   }
 }
 
@@ -271,7 +282,11 @@ __device__ __forceinline__ LaneConst setup_lane(const FastArgs &a, const Lds &ld
   if (wave > 0) lds.tabA[(wave - 1) * 64 + lane] = a.w_m[lane * wave];          // W_M^(l k1), k1 = wave
   lds.winL[tid] = reinterpret_cast<const float2 *>(a.hwin)[tid];                // the whole window, once per workgroup
   lds.tabP[wave * 64 + lane] = a.w_n[L.k1 + 256 * L.r + 16 * wave];             // exp(-2 pi i k / N), k = k1 + 16 q + 256 r
-  if (lane < 4) lds.tabB[wave * 4 + lane] = a.w_m[16 * lane * wave];            // W_64^(a q)
+  if (lane < 4) {
+    // row q = 0 (all ones) is never read: it holds the power kernel's synchronisation counters
+    if (wave > 0) lds.tabB[wave * 4 + lane] = a.w_m[16 * lane * wave];          // W_64^(a q)
+    else reinterpret_cast<unsigned *>(lds.tabB)[lane] = 0u;
+  }
   L.tabA_l = lds.tabA + lane - 64;   // row k1 - 1
   L.winL_l = lds.winL + lane;
   L.tabP_l = lds.tabP + lane;
@@ -306,7 +321,7 @@ __device__ __forceinline__ void block_to_range(const FastArgs &a, int64_t &tau_b
 // One frame: raw samples (registers) -> window -> FFT(1024 complex) -> real post-pass -> |X|^p
 // written as column `wave` of `tile`.  `hook.at<P>()` is called at 16 points between the stages;
 // the power kernel uses them to trickle out the previous tile's stores.
-template <bool SQUARE SMX_ABL_PARAM, class Hook>
+template <bool SQUARE, bool LDSX SMX_ABL_PARAM, class Hook>
 __device__ __forceinline__ void frame_to_tile(const FastArgs &a, const LaneConst &L, const float2 (&raw)[16],
                                               float *tile, int wave, int lane, const Hook &hook) {
   c32 v[16];
@@ -330,8 +345,35 @@ __device__ __forceinline__ void frame_to_tile(const FastArgs &a, const LaneConst
   }
   hook.template at<3>();
   __builtin_amdgcn_sched_barrier(0);
-  // X: in-wave transpose: lane (i, a) register k1 -> lane (k1, a) register i  (no LDS)
-  {
+  // X: transpose lane (i, a) register k1 -> lane (k1, a) register i.
+  if constexpr (LDSX) {
+    hook.ready();
+    // Through LDS, in place: until this wave writes its powers, column `wave` of the tile being
+    // filled (1024 slots) and pad rows [64 wave, 64 wave + 60) belong to this wave alone, so no
+    // barrier is involved (DS operations of one wave execute in order).  Element (i, a, k1) sits in
+    // slot s = 68 i + 4 k1 + a: both the writes (k1 fixed) and the reads (i fixed) spread a
+    // half-wave over 32 different banks, and every address is one lane base + an immediate.
+    // Slots >= 1024 (only i = 15, k1 >= 1) continue in the pad rows.
+    const int hi = lane >> 2, lo = lane & 3;
+    float *colw = tile + wave;
+    const int w0 = (68 * hi + lo) * kTileStride;                                        // k1 = 0
+    const int w1 = hi < 15 ? w0 + 4 * kTileStride : (64 * wave + lo) * kTileStride + kFT - wave;   // k1 = 1
+    const int r0 = lane * kTileStride;                                                  // i = 0 (slot 4 k1 + a = lane)
+    const int r15 = hi == 0 ? (1020 + lo) * kTileStride : (64 * wave + lane - 4) * kTileStride + kFT - wave;
+    auto exchange = [&](auto get, auto put) {
+#pragma unroll
+      for (int k = 0; k < 16; ++k) colw[k == 0 ? w0 : w1 + 4 * kTileStride * (k - 1)] = get(k);
+#pragma unroll
+      for (int i = 0; i < 16; ++i) put(i, colw[i == 15 ? r15 : r0 + 68 * kTileStride * i]);
+    };
+    float re[16], im[16];
+    exchange([&](int k) { return v[k].x; }, [&](int i, float x) { re[i] = x; });
+    hook.template at<4>();
+    exchange([&](int k) { return v[k].y; }, [&](int i, float x) { im[i] = x; });
+#pragma unroll
+    for (int k = 0; k < 16; ++k) v[k] = {re[k], im[k]};
+  } else {
+    // in registers (permlane swaps + DPP), used where the tile's pad column is busy (mel kernel)
     float re[16], im[16];
 #pragma unroll
     for (int k = 0; k < 16; ++k) { re[k] = v[k].x; im[k] = v[k].y; }
@@ -370,6 +412,7 @@ __device__ __forceinline__ void frame_to_tile(const FastArgs &a, const LaneConst
   hook.template at<10>();
   __builtin_amdgcn_sched_barrier(0);
   // P: real-FFT post-pass.  provider rotation for the k1 = 0 lanes.
+  if constexpr (!LDSX) hook.ready();
   float *col = tile + wave;
   const float nyq = 2.0f * (v[0].x - v[0].y);   // X[M] = Re Z0 - Im Z0 (true scale), lane 0
 #pragma unroll
@@ -399,41 +442,65 @@ __device__ __forceinline__ void frame_to_tile(const FastArgs &a, const LaneConst
   if (lane == 0) {
     float pw = nyq * nyq;
     if constexpr (!SQUARE) pw = a.pmode == 1 ? fabsf(nyq) : __powf(pw, a.half_power);
-    tile[wave * kTileStride + kFT] = pw;   // Nyquist bin of frame `wave`: pad slot of row `wave`
+    tile[nyquist_row<LDSX>(wave) * kTileStride + kFT] = pw;   // Nyquist bin of frame `wave`: a pad slot
   }
 }
 
 template <bool ALIGNED SMX_ABL_PARAM>
-__device__ __forceinline__ void prefetch_frame(const FastArgs &a, const float *x, int64_t p, int lane, float2 (&raw)[16]) {
+__device__ __forceinline__ void prefetch_frame(const FastArgs &a, const float *src, int lane, float2 (&raw)[16]) {
   if constexpr (SMX_ABL(2) || SMX_ABL(3)) {
 #pragma unroll
     for (int j = 0; j < 16; ++j) raw[j] = make_float2((float)(lane + j) + raw[j].x * 0.0f, (float)(lane - j));
   } else {
-    load_frame<ALIGNED>(a, x, p, lane, raw);
+    load_frame<ALIGNED>(src, lane, raw);
   }
 }
 
 // ---- power spectrogram kernel -------------------------------------------------------------------
-// The previous tile's stores are spread over 16 points of the next frame's arithmetic and staggered
-// across waves (point p serves the 4 waves with (wave & 3) == (p & 3), part p >> 2), so at most
-// 4 KB of stores enter the memory pipeline at a time.
-struct FlushHook {
-  const FastArgs &a;
-  const float *ptile;
-  const FlushLane &fl;
-  float *pout;
-  int64_t pleft;
-  int wslot, wave, lane;
+// Wave-level synchronisation through two pairs of monotonic LDS counters instead of a workgroup
+// barrier per tile.  All 16 waves of a barrier-synchronised workgroup sit in the same phase of the
+// frame at the same time (all reading twiddles, all in the butterflies, ...), so the LDS pipe and the
+// VALUs are busy alternately, never together -- measured: tile time = VALU time + LDS time.  With
+// counters a wave only waits for what it really depends on, one frame of slack each way:
+//   filled[b]  += 1 by every wave once its column of the tile in buffer b is written (or skipped);
+//                 a wave stores its share of that tile only when filled[b] reaches 16 per tile;
+//   drained[b] += 1 by every wave once it has read its share of the tile out of buffer b;
+//                 a wave writes into buffer b again only when drained[b] reaches 16 per tile.
+// The waves drift apart by up to a frame and overlap each other's LDS and VALU phases.
+struct Counters {
+  unsigned *filled, *drained;   // [2] each, in the unused q = 0 row of the W_64 table
+};
+__device__ __forceinline__ void lds_signal(unsigned *c, int lane) {
+  if (lane == 0) __hip_atomic_fetch_add(c, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+__device__ __forceinline__ void lds_wait(unsigned *c, unsigned target) {
+  while ((unsigned)__builtin_amdgcn_readfirstlane(
+             (int)__hip_atomic_load(c, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP)) < target)
+    __builtin_amdgcn_s_sleep(2);
+}
+
+struct SyncHook {
+  unsigned *drained;
+  unsigned target;
+#ifdef SMX_STAMPS
+  unsigned long long *stamp_sum, *stamp_prev_p;
+#endif
+  // the tile buffer about to be written (or used as transpose scratch) has been read out by every wave
+  __device__ __forceinline__ void ready() const { lds_wait(drained, target); }
   template <int P>
   __device__ __forceinline__ void at() const {
-    if (wslot == (P & 3)) flush_part(a, ptile, P >> 2, fl, pout, pleft, wave, lane);
+#ifdef SMX_STAMPS
+    unsigned long long &stamp_prev = *stamp_prev_p;
+    SMX_STAMP(1 + P);
+#endif
   }
 };
 
 // SQUARE = power 2 (no per-bin branch); otherwise |X|^p through pmode / half_power.
+// LDSX: 16x16 transpose through the wave's own tile column (true) or in registers (false).
 // STRIP only names the instantiation used for the small gathered border strips, so that kernel-trace
 // statistics separate them from the interior launch (the code is identical).
-template <bool ALIGNED, bool SQUARE, bool STRIP SMX_ABL_PARAM>
+template <bool ALIGNED, bool SQUARE, bool STRIP, bool LDSX SMX_ABL_PARAM>
 __global__ void __launch_bounds__(1024) stft2048_power_kernel(FastArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x;
@@ -441,35 +508,58 @@ __global__ void __launch_bounds__(1024) stft2048_power_kernel(FastArgs a) {
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // provably wave-uniform (scalar)
   const Lds lds = carve_lds(smem);
   const LaneConst L = setup_lane(a, lds, tid, lane, wave);
-  int64_t tau_begin, tau_end;
-  block_to_range(a, tau_begin, tau_end);
-  if (tau_begin >= tau_end) return;   // uniform for the workgroup
-
-  // tile tau -> (clip, first frame, does this wave have a frame)
-  auto frame_of = [&](int64_t tau, const float *&xs, int64_t &p, bool &hv) {
-    const int64_t clip = tau / a.tiles_per_clip;
-    const int64_t f0 = (tau % a.tiles_per_clip) * kFT;
+  const Counters cnt{reinterpret_cast<unsigned *>(lds.tabB), reinterpret_cast<unsigned *>(lds.tabB) + 2};
+  // This workgroup's tiles: tau0, tau0 + step, ... (ntiles of them) of the flat (clip, tile) sequence.
+  int64_t tau0;
+  int step, ntiles;
+  if (a.interleave) {
+    // The workgroups of one XCD walk a contiguous chunk of the sequence side by side: at any time the
+    // XCD is writing ~32 neighbouring tiles of the same clip, i.e. for every bin one contiguous run of
+    // ~2 KB, which its L2 can assemble into whole lines before they go to HBM.
+    const int64_t nb = a.blocks, xcd = blockIdx.x % 8, idx = blockIdx.x / 8;
+    const int64_t nx = (nb - xcd + 7) / 8;                            // workgroups on this XCD
+    const int64_t nxcd = nb < 8 ? nb : 8;                             // XCDs that received a workgroup
+    const int64_t x0 = a.total_tiles * xcd / nxcd, x1 = a.total_tiles * (xcd + 1) / nxcd;
+    if (a.interleave == 2) {   // all workgroups side by side; an XCD holds 32 neighbouring tiles of every 256
+      const int64_t q = nb / 8, r = nb % 8;
+      tau0 = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+      step = (int)nb;
+      ntiles = tau0 < a.total_tiles ? (int)((a.total_tiles - tau0 + nb - 1) / nb) : 0;
+    } else {
+      tau0 = x0 + idx;
+      step = (int)nx;
+      ntiles = tau0 < x1 ? (int)((x1 - tau0 + nx - 1) / nx) : 0;
+    }
+  } else {
+    int64_t tau_end;
+    block_to_range(a, tau0, tau_end);
+    step = 1;
+    ntiles = (int)(tau_end - tau0);
+  }
+  if (ntiles <= 0) return;   // uniform for the workgroup
+  // Position in the sequence, advanced incrementally: the only divisions of the kernel are these
+  // (a scalar 64-bit division costs a few hundred dependent SALU instructions).
+  int ft = (int)(tau0 % a.tiles_per_clip);                              // tile index inside the clip
+  const float *xclip = a.x + (tau0 / a.tiles_per_clip) * a.x_stride;
+  float *oclip = a.out + (tau0 / a.tiles_per_clip) * kBins * a.out_stride + a.out_offset;
+  const int64_t x_step = a.x_stride, o_step = kBins * a.out_stride;
+  const int step_clips = step / a.tiles_per_clip, step_tiles = step % a.tiles_per_clip;   // one step = this many clips + tiles
+  // first sample of this wave's frame in tile t of the clip at xc (a wave without a frame re-reads the
+  // tile's first frame and ignores it)
+  auto frame_ptr = [&](const float *xc, int t, bool &hv) {
+    const int64_t f0 = (int64_t)t * kFT;
     hv = f0 + wave < a.count;
-    xs = a.x + clip * a.x_stride;
-    p = a.p0 + f0 + (hv ? wave : 0);
+    return xc + ((a.p0 + f0 + (hv ? wave : 0)) * a.hop - a.left);
   };
 
-  // prefetch the first frame of this wave
   float2 raw[16];
 #pragma unroll
   for (int j = 0; j < 16; ++j) raw[j] = make_float2(0.f, 0.f);
   bool have;
-  {
-    const float *xs;
-    int64_t p;
-    frame_of(tau_begin, xs, p, have);
-    prefetch_frame<ALIGNED SMX_ABL_ARG>(a, xs, p, lane, raw);
-  }
-  __syncthreads();   // tables visible
-  int cur = 0;
-  bool pending = false;      // tile[cur ^ 1] holds the finished previous tile, not yet stored
-  float *pend_out = nullptr; // its output origin (clip, first frame) and frames left in that clip
-  int64_t pend_left = 0;
+  prefetch_frame<ALIGNED SMX_ABL_ARG>(a, frame_ptr(xclip, ft, have), lane, raw);
+  __syncthreads();   // tables and zeroed counters visible: the only workgroup barrier of the kernel
+  float *pend_out = nullptr; // output origin (clip, first frame) of the previous tile and frames left in that clip
+  int pend_left = 0;
   FlushLane fl;
   {
     const int hsel = lane >> 5, jj = (lane & 31) >> 2;
@@ -478,54 +568,60 @@ __global__ void __launch_bounds__(1024) stft2048_power_kernel(FastArgs a) {
     const int bin0 = (fl.row0 & 3) * 256 + (fl.row0 >> 2);
     fl.goff0 = ((unsigned)bin0 * (unsigned)a.out_stride + 4u * fl.g) * 4u;
   }
+  constexpr int kTileFloats = kTileBytes / sizeof(float);
+  // this wave's share of the tile in buffer b (the `fills`-th tile written there), once every column is in
+  auto flush_tile = [&](int b, unsigned fills) {
+    lds_wait(cnt.filled + b, 16u * fills);
+    const float *ptile = lds.tiles + b * kTileFloats;
+#pragma unroll
+    for (int part = 0; part < 4; ++part) flush_part<LDSX>(a, ptile, part, fl, pend_out, pend_left, wave, lane);
+    lds_signal(cnt.drained + b, lane);
+  };
 
 #ifdef SMX_STAMPS
   unsigned long long stamp_sum[kStampSlots] = {0}, stamp_prev;
   asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(stamp_prev)::"memory");
 #endif
-  for (int64_t tau = tau_begin; tau < tau_end; ++tau) {
-    const int64_t clip = tau / a.tiles_per_clip;
-    const int64_t f0 = (tau % a.tiles_per_clip) * kFT;
+  for (int it = 0; it < ntiles; ++it) {   // tile `it` of this workgroup lives in buffer it & 1
+    const int b = it & 1;
     SMX_STAMP(0);
-    const float *ptile = lds.tiles + (cur ^ 1) * (kTileBytes / sizeof(float));
     if (have) {   // wave-uniform
-      const FlushHook hook{a, ptile, fl, pend_out, pend_left, pending ? (wave & 3) : -1, wave, lane};
-      frame_to_tile<SQUARE SMX_ABL_ARG>(a, L, raw, lds.tiles + cur * (kTileBytes / sizeof(float)), wave, lane, hook);
-    } else if (pending) {   // no frame for this wave in this tile: still store its share of the previous one
-#pragma unroll
-      for (int it = 0; it < 4; ++it) flush_part(a, ptile, it, fl, pend_out, pend_left, wave, lane);
+      // buffer b last held tile it - 2, the (it >> 1)-th tile written there
+#ifdef SMX_STAMPS
+      const SyncHook hook{cnt.drained + b, 16u * ((unsigned)it >> 1), stamp_sum, &stamp_prev};
+#else
+      const SyncHook hook{cnt.drained + b, 16u * ((unsigned)it >> 1)};
+#endif
+      frame_to_tile<SQUARE, LDSX SMX_ABL_ARG>(a, L, raw, lds.tiles + b * kTileFloats, wave, lane, hook);
     }
-    SMX_STAMP(6);
-    // prefetch this wave's frame of the next tile (possibly of the next clip), in flight across the
-    // barrier.  Unconditional: past the end the current tile's first frame is re-read and ignored, so
-    // raw never carries old values around the loop and stays out of the compute's registers.
-    bool have_next = false;
-    {
-      const float *xs;
-      int64_t p;
-      if (tau + 1 < tau_end) {
-        frame_of(tau + 1, xs, p, have_next);
-      } else {
-        xs = a.x + clip * a.x_stride;
-        p = a.p0 + f0;
-      }
-      prefetch_frame<ALIGNED SMX_ABL_ARG>(a, xs, p, lane, raw);
+    lds_signal(cnt.filled + b, lane);
+    SMX_STAMP(17);
+    // prefetch this wave's frame of the next tile (possibly of the next clip); the loads are in flight
+    // while the previous tile is stored.  Unconditional: past the end the current tile's first frame is
+    // re-read and ignored, so raw never carries old values around the loop.
+    int ftnext = ft + step_tiles, dclip = step_clips;
+    if (ftnext >= a.tiles_per_clip) {
+      ftnext -= a.tiles_per_clip;
+      ++dclip;
     }
-    SMX_STAMP(7);
-    __syncthreads();   // the ONLY barrier per tile: tile[cur] complete; tile[cur^1] free again
-    SMX_STAMP(8);
-    // tile[cur] is complete; its stores are interleaved with the next frame's stages
-    pending = true;
-    pend_out = a.out + (clip * kBins) * a.out_stride + a.out_offset + f0;   // wave-uniform
-    pend_left = a.count - f0;
+    const float *xnext = xclip + dclip * x_step;
+    float *onext = oclip + dclip * o_step;
+    bool have_next;
+    const float *src = frame_ptr(it + 1 < ntiles ? xnext : xclip, it + 1 < ntiles ? ftnext : ft, have_next);
+    have_next = have_next && it + 1 < ntiles;
+    prefetch_frame<ALIGNED SMX_ABL_ARG>(a, src, lane, raw);
+    SMX_STAMP(18);
+    if (it > 0) flush_tile(b ^ 1, ((unsigned)(it - 1) >> 1) + 1);   // tile it - 1
+    SMX_STAMP(19);
+    pend_out = oclip + ft * kFT;   // wave-uniform
+    const int64_t left = a.count - (int64_t)ft * kFT;
+    pend_left = left < kFT ? (int)left : kFT;
     have = have_next;
-    cur ^= 1;
+    xclip = xnext;
+    oclip = onext;
+    ft = ftnext;
   }
-  if (pending) {   // the last tile of this workgroup
-    const float *ptile = lds.tiles + (cur ^ 1) * (kTileBytes / sizeof(float));
-#pragma unroll
-    for (int it = 0; it < 4; ++it) flush_part(a, ptile, it, fl, pend_out, pend_left, wave, lane);
-  }
+  flush_tile((ntiles - 1) & 1, ((unsigned)(ntiles - 1) >> 1) + 1);   // the last tile of this workgroup
 #ifdef SMX_STAMPS
   if (lane == 0 && blockIdx.x < 4096)
     for (int i = 0; i < kStampSlots; ++i) g_stamp_sums[(blockIdx.x * 16 + wave) * kStampSlots + i] = stamp_sum[i];
@@ -567,6 +663,7 @@ struct MelFusedArgs {
 struct NoHook {
   template <int P>
   __device__ __forceinline__ void at() const {}
+  __device__ __forceinline__ void ready() const {}
 };
 
 template <bool ALIGNED, bool SQUARE, bool STRIP>
@@ -605,7 +702,7 @@ __global__ void __launch_bounds__(1024) stft2048_mel_kernel(FastArgs a, MelFused
     const float *xs;
     int64_t p;
     frame_of(tau_begin, xs, p, have);
-    load_frame<ALIGNED>(a, xs, p, lane, raw);
+    load_frame<ALIGNED>(xs + (p * a.hop - a.left), lane, raw);
   }
   __syncthreads();   // tables visible
   const int pad_lane = (16 + lane) * kTileStride + kFT;     // pad-column slot of this lane (rows >= 16)
@@ -700,7 +797,7 @@ __global__ void __launch_bounds__(1024) stft2048_mel_kernel(FastArgs a, MelFused
     float *tprev = lds.tiles + (cur ^ 1) * kTileFloats;
     if (stage >= 2) finish(tcur, out_m2, left_m2);   // partials of tile t-2 sit in this buffer's pad column
     if (stage >= 1) mfma_item(tprev);                // tile t-1
-    if (have) frame_to_tile<SQUARE SMX_ABL_ZERO>(a, L, raw, tcur, wave, lane, NoHook{});
+    if (have) frame_to_tile<SQUARE, false SMX_ABL_ZERO>(a, L, raw, tcur, wave, lane, NoHook{});
     bool have_next = false;
     {
       const float *xs;
@@ -711,7 +808,7 @@ __global__ void __launch_bounds__(1024) stft2048_mel_kernel(FastArgs a, MelFused
         xs = a.x + clip * a.x_stride;
         p = a.p0 + f0;
       }
-      load_frame<ALIGNED>(a, xs, p, lane, raw);
+      load_frame<ALIGNED>(xs + (p * a.hop - a.left), lane, raw);
     }
     __syncthreads();
     out_m2 = out_m1;
@@ -811,6 +908,10 @@ void launch_interior(const StftJob &job, const FastTarget &tg, const float *x, i
     cu_count = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
   }
   a.blocks = a.total_tiles < cu_count ? a.total_tiles : cu_count;
+  {
+    const char *e = std::getenv("SMX_INTERLEAVE");
+    a.interleave = e ? std::atoi(e) : 2;
+  }
   a.pmode = job.power == 2.0 ? 2 : (job.power == 1.0 ? 1 : 0);
   a.half_power = (float)(0.5 * job.power);
   const bool aligned = (c.hop % 2 == 0) && (left % 2 == 0) && (x_stride % 2 == 0) &&
@@ -835,19 +936,21 @@ void launch_interior(const StftJob &job, const FastTarget &tg, const float *x, i
   const char *abl_env = std::getenv("SMX_ABLATE");
   const int abl = abl_env ? std::atoi(abl_env) : 0;
   a.abl_nostore = (abl == 1 || abl == 3) ? 1 : 0;
-  auto kernel = abl == 2 ? stft2048_power_kernel<true, true, false, 2>
-              : abl == 3 ? stft2048_power_kernel<true, true, false, 3>
-              : abl == 4 ? stft2048_power_kernel<true, true, false, 4>
-              : abl == 5 ? stft2048_power_kernel<true, true, false, 5>
-                         : stft2048_power_kernel<true, true, false, 0>;
+  auto kernel = abl == 2 ? stft2048_power_kernel<true, true, false, kLdsX, 2>
+              : abl == 3 ? stft2048_power_kernel<true, true, false, kLdsX, 3>
+              : abl == 4 ? stft2048_power_kernel<true, true, false, kLdsX, 4>
+              : abl == 5 ? stft2048_power_kernel<true, true, false, kLdsX, 5>
+                         : stft2048_power_kernel<true, true, false, kLdsX, 0>;
   (void)aligned; (void)square; (void)strip;
 #else
-  auto pick = [&](auto strip_tag) {
-    constexpr bool S = decltype(strip_tag)::value;
-    return aligned ? (square ? stft2048_power_kernel<true, true, S> : stft2048_power_kernel<true, false, S>)
-                   : (square ? stft2048_power_kernel<false, true, S> : stft2048_power_kernel<false, false, S>);
+  auto pick = [&](auto strip_tag, auto ldsx_tag) {
+    constexpr bool S = decltype(strip_tag)::value, X = decltype(ldsx_tag)::value;
+    return aligned ? (square ? stft2048_power_kernel<true, true, S, X> : stft2048_power_kernel<true, false, S, X>)
+                   : (square ? stft2048_power_kernel<false, true, S, X> : stft2048_power_kernel<false, false, S, X>);
   };
-  auto kernel = strip ? pick(std::true_type{}) : pick(std::false_type{});
+  static const bool ldsx = [] { const char *e = std::getenv("SMX_LDSX"); return e ? std::atoi(e) != 0 : kLdsX; }();
+  auto kernel = strip ? (ldsx ? pick(std::true_type{}, std::true_type{}) : pick(std::true_type{}, std::false_type{}))
+                      : (ldsx ? pick(std::false_type{}, std::true_type{}) : pick(std::false_type{}, std::false_type{}));
 #endif
   SMX_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kernel),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)kFastLds));

@@ -5,30 +5,44 @@ import ctypes, os, sys
 import torch
 i64, vp = ctypes.c_int64, ctypes.c_void_p
 paths = sys.argv[1:]
+N_ENV = int(os.environ.get("AB_N", "480000"))   # AB_N=482816 gives 944 frames: 64-byte aligned output rows
 libs = []
-clips, n = 256, 480000
+clips, n = 256, N_ENV
+frames = 1 + n // 512
 x = torch.rand(clips, n, device="cuda") * 2 - 1
-out = torch.empty(clips, 1025, 938, device="cuda")
+out = torch.empty(clips, 1025, frames, device="cuda")
+# "path@VAR=val" sets an environment variable around that variant's launches (for options read per launch)
 for p in paths:
-    lib = ctypes.CDLL(os.path.abspath(p))
+    lib = ctypes.CDLL(os.path.abspath(p.split("@")[0]))
     h = vp()
     lib.smx_stft_config_create.argtypes = [i64, i64, i64, ctypes.c_int, ctypes.c_int, ctypes.c_double, ctypes.c_int, ctypes.c_int, vp, ctypes.POINTER(vp)]
     assert lib.smx_stft_config_create(2048, -(2**63), 512, 0, 0, 0.0, 0, 0, None, ctypes.byref(h)) == 0
     lib.smx_stft_power_range_f32_dev.argtypes = [vp, vp, i64, i64, i64, i64, i64, ctypes.c_double, vp, vp]
     libs.append((p, lib, h))
+def setenv(p):
+    for kv in p.split("@")[1:]:
+        k, v = kv.split("=")
+        os.environ[k] = v
+def clearenv(p):
+    for kv in p.split("@")[1:]:
+        os.environ.pop(kv.split("=")[0], None)
 def run(lib, h):
-    assert lib.smx_stft_power_range_f32_dev(h, vp(x.data_ptr()), clips, n, n, 0, 938, 2.0, vp(out.data_ptr()), None) == 0
-for _, lib, h in libs:
+    assert lib.smx_stft_power_range_f32_dev(h, vp(x.data_ptr()), clips, n, n, 0, frames, 2.0, vp(out.data_ptr()), None) == 0
+for p, lib, h in libs:
+    setenv(p)
     for _ in range(3): run(lib, h)
+    clearenv(p)
 torch.cuda.synchronize()
 ts = {p: [] for p in paths}
 for rnd in range(15):
     for p, lib, h in libs:
         a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        setenv(p)
         a.record()
         for _ in range(4): run(lib, h)
         b.record(); torch.cuda.synchronize()
+        clearenv(p)
         ts[p].append(a.elapsed_time(b) / 4)
 for p in paths:
     v = sorted(ts[p])
-    print("%-45s median %.4f ms  min %.4f ms  (%.1f Mframes/s)" % (p, v[len(v) // 2], v[0], clips * 938 / v[len(v) // 2] / 1e3))
+    print("%-45s median %.4f ms  min %.4f ms  (%.1f Mframes/s)" % (p, v[len(v) // 2], v[0], clips * frames / v[len(v) // 2] / 1e3))

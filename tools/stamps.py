@@ -17,15 +17,18 @@ for _ in range(2):
     rc = lib.smx_stft_power_range_f32_dev(h, vp(x.data_ptr()), clips, n, n, 2, 936, 2.0, vp(out.data_ptr()), None)
     assert rc == 0
 torch.cuda.synchronize()
-S = 12
-buf = np.zeros(2048 * 16 * S, dtype=np.uint64)
+S = 24
+nwg = 256
+buf = np.zeros(nwg * 16 * S, dtype=np.uint64)
 assert lib.smx_debug_read_stamps(buf.ctypes.data_as(ctypes.POINTER(ctypes.c_ulonglong)), buf.size) == 0
-st = buf.reshape(2048, 16, S).astype(np.float64)
+st = buf.reshape(nwg, 16, S).astype(np.float64)
 tot = st.sum(axis=2)
-names = ["loop top", "win load+mul", "fft A+tw", "exchange", "fft B+tw", "dpp radix4", "post+tile wr", "prefetch issue",
-         "barrier1", "flush", "barrier2", "-"]
+names = ["loop top", "window", "A pass1", "A pass2", "A twiddle", "X re (+ready)", "X im", "B pass1", "B pass2", "B twiddle",
+         "C q<8", "C q>=8", "P q0-3 (+ready)", "P q4-7", "P q8-11", "P q12-15", "(hook15)", "nyquist+signal", "prefetch issue", "wait filled+flush"]
 mean = st.mean(axis=(0, 1))
-print("cycles per workgroup-wave (8 tiles): total %.0f" % tot.mean())
-for i, nm in enumerate(names[:11]):
-    print("  %-16s %9.0f  %5.1f%%   (per tile %.0f)" % (nm, mean[i], 100 * mean[i] / mean.sum(), mean[i] / 8))
-print("per-wave totals (mean over WGs):", np.round(tot.mean(axis=0) / 8))
+tiles = 256 * 934 / 16 / nwg
+print("s_memtime ticks per wave: total %.0f over %.1f tiles (%.0f per tile)" % (tot.mean(), tiles, tot.mean() / tiles))
+for i, nm in enumerate(names):
+    print("  %-16s %9.0f  %5.1f%%   (per tile %.0f)" % (nm, mean[i], 100 * mean[i] / mean.sum(), mean[i] / tiles))
+print("per-wave totals (mean over WGs):", np.round(tot.mean(axis=0) / tiles))
+print("per-wave flush phase:", np.round(st[:, :, 19].mean(axis=0) / tiles))
