@@ -55,6 +55,20 @@ __device__ __forceinline__ float dpp_mov(float old, float src) {
                                                                __builtin_bit_cast(int, src), CTRL, 0xF,
                                                                BANK_MASK, false));
 }
+// x[i] += k * x[i] of the quad partner (quad_perm QP), 8 complex values per statement:
+// v_fmac_f32 with a DPP source does the cross-lane read and the butterfly in one instruction.
+// hipcc does not form it from the builtins, and its hazard recogniser does not look inside asm, so
+// the statement starts with the 2 wait states a DPP read needs after a VALU write.
+#define SMX_FD(n, QP) "v_fmac_f32_dpp %" #n ", %" #n ", %16 quad_perm:" QP " row_mask:0xf bank_mask:0xf\n\t"
+#define SMX_FMAC_DPP8(QP, V, K)                                                                              \
+  asm("s_nop 1\n\t" SMX_FD(0, QP) SMX_FD(1, QP) SMX_FD(2, QP) SMX_FD(3, QP) SMX_FD(4, QP) SMX_FD(5, QP)     \
+      SMX_FD(6, QP) SMX_FD(7, QP) SMX_FD(8, QP) SMX_FD(9, QP) SMX_FD(10, QP) SMX_FD(11, QP) SMX_FD(12, QP)   \
+      SMX_FD(13, QP) SMX_FD(14, QP) SMX_FD(15, QP)                                                           \
+      : "+v"((V)[0].x), "+v"((V)[0].y), "+v"((V)[1].x), "+v"((V)[1].y), "+v"((V)[2].x), "+v"((V)[2].y),       \
+        "+v"((V)[3].x), "+v"((V)[3].y), "+v"((V)[4].x), "+v"((V)[4].y), "+v"((V)[5].x), "+v"((V)[5].y),       \
+        "+v"((V)[6].x), "+v"((V)[6].y), "+v"((V)[7].x), "+v"((V)[7].y)                                        \
+      : "v"(K))
+
 // lanes 32-63 of a <-> lanes 0-31 of b / odd rows of a <-> even rows of b.  Inline asm: this
 // hipcc drops the second result of __builtin_amdgcn_permlane{32,16}_swap.  "s_nop 1" covers the
 // VALU-write -> v_permlane-read hazard (2 wait states) inside the statement.
@@ -134,6 +148,19 @@ struct FastArgs {
 #ifndef SMX_LDSX
 #define SMX_LDSX 0
 #endif
+#ifdef SMX_NOFENCE
+#define SMX_FENCE() do { } while (0)
+#else
+#define SMX_FENCE() __builtin_amdgcn_sched_barrier(0)
+#endif
+#ifndef SMX_EARLY_PREFETCH
+#define SMX_EARLY_PREFETCH 0
+#endif
+constexpr bool kEarlyPrefetch = SMX_EARLY_PREFETCH != 0;
+#ifndef SMX_PRE
+#define SMX_PRE 1
+#endif
+constexpr bool kPre = SMX_PRE != 0;   // power kernel: twiddle tables read one stage ahead
 constexpr bool kLdsX = SMX_LDSX != 0;   // power kernel: transpose through the tile column (see frame_to_tile)
 constexpr int kWaves = 16, kFT = 16;            // one frame per wave per tile
 constexpr int kTileStride = kFT + 1;            // floats per tile row (pad column 16)
@@ -205,7 +232,7 @@ struct FlushLane {
 };
 template <bool LDSX>
 __device__ __forceinline__ void flush_part(const FastArgs &a, const float *tile, int it, const FlushLane &fl,
-                                           float *obase, int frames_left, int wave, int lane) {
+                                           float *obase, int frames_left, int wave, int lane, int ft = 0) {
   const int row = fl.row0 + 512 * (it >> 1) + 8 * (it & 1);
   const float *src = tile + row * kTileStride + 4 * fl.g;
   const float v0 = src[0], v1 = src[1], v2 = src[2], v3 = src[3];
@@ -213,8 +240,21 @@ __device__ __forceinline__ void flush_part(const FastArgs &a, const float *tile,
   const unsigned goff = fl.goff0 + (unsigned)(2 * (it & 1) + 128 * (it >> 1)) * (unsigned)a.out_stride * 4u;
   const int fleft = frames_left - 4 * fl.g;    // frames remaining from this column group
 #ifdef SMX_DIAG
-  if (a.abl_nostore) {   // timing-only ablation: keep the LDS reads alive, drop the HBM stores
+  if (a.abl_nostore == 1) {   // timing-only ablation: keep the LDS reads alive, drop the HBM stores
     asm volatile("" ::"v"(v0), "v"(v1), "v"(v2), "v"(v3));
+    return;
+  }
+  if (a.abl_nostore == 5) {   // timing-only: every 64-byte run moved down to a 64-byte boundary (no partial sectors)
+    const uintptr_t addr = (reinterpret_cast<uintptr_t>(obase) + goff) & ~uintptr_t(63);
+    *reinterpret_cast<f32x4 *>(addr + 16 * fl.g) = f32x4{v0, v1, v2, v3};
+    return;
+  }
+  if (a.abl_nostore >= 2) {   // timing-only: the same bytes as runs of 64 << k bytes (k = abl_nostore - 1)
+    const int k = a.abl_nostore - 1, lr = 4 << k, rpi = 64 / lr, msk = (1 << k) - 1;
+    const int r = (4 * wave + it) * rpi + lane / lr;
+    const int bin = (r << k) + (ft & msk);
+    const unsigned off = ((unsigned)bin * (unsigned)a.out_stride + 4u * (lane % lr)) * 4u;
+    store4_unaligned(obase - 16 * (ft & msk), off, v0, v1, v2, v3);
     return;
   }
 #endif
@@ -250,7 +290,7 @@ __device__ __forceinline__ void flush_part(const FastArgs &a, const float *tile,
 // Per-lane constants of the frame pipeline (see the header comment for the digit layout).
 struct LaneConst {
   int k1, qa, r;
-  float s1, s2;
+  float s12, kap1, kap2;    // quad radix-4: sign folded into the data, butterfly multipliers
   bool rot, low4;
   int addr_g, addr_0;       // ds_bpermute byte addresses of the post-pass partner lane
   int tile_row0;            // tile row of register q is tile_row0 + 64 q
@@ -284,15 +324,21 @@ __device__ __forceinline__ LaneConst setup_lane(const FastArgs &a, const Lds &ld
   lds.tabP[wave * 64 + lane] = a.w_n[L.k1 + 256 * L.r + 16 * wave];             // exp(-2 pi i k / N), k = k1 + 16 q + 256 r
   if (lane < 4) {
     // row q = 0 (all ones) is never read: it holds the power kernel's synchronisation counters
-    if (wave > 0) lds.tabB[wave * 4 + lane] = a.w_m[16 * lane * wave];          // W_64^(a q)
+    if (wave > 0) {                                                             // s1 s2 W_64^(a q), a = lane
+      const float sg = ((lane < 2) != ((lane & 1) == 0)) ? -1.0f : 1.0f;
+      const float2 w = a.w_m[16 * lane * wave];
+      lds.tabB[wave * 4 + lane] = make_float2(sg * w.x, sg * w.y);
+    }
     else reinterpret_cast<unsigned *>(lds.tabB)[lane] = 0u;
   }
   L.tabA_l = lds.tabA + lane - 64;   // row k1 - 1
   L.winL_l = lds.winL + lane;
   L.tabP_l = lds.tabP + lane;
   L.tabB_l = lds.tabB + L.qa;
-  L.s1 = L.qa < 2 ? 1.0f : -1.0f;
-  L.s2 = (L.qa & 1) ? -1.0f : 1.0f;
+  const float s1 = L.qa < 2 ? 1.0f : -1.0f, s2 = (L.qa & 1) ? -1.0f : 1.0f;
+  L.s12 = s1 * s2;
+  L.kap1 = -s1;
+  L.kap2 = -s2;
   L.rot = L.qa == 3;
   if (lane >= 4) {
     L.addr_g = L.addr_0 = (67 - lane) * 4;
@@ -321,30 +367,47 @@ __device__ __forceinline__ void block_to_range(const FastArgs &a, int64_t &tau_b
 // One frame: raw samples (registers) -> window -> FFT(1024 complex) -> real post-pass -> |X|^p
 // written as column `wave` of `tile`.  `hook.at<P>()` is called at 16 points between the stages;
 // the power kernel uses them to trickle out the previous tile's stores.
-template <bool SQUARE, bool LDSX SMX_ABL_PARAM, class Hook>
-__device__ __forceinline__ void frame_to_tile(const FastArgs &a, const LaneConst &L, const float2 (&raw)[16],
+// PRE: each twiddle table is read from LDS one stage before it is used (30 more live registers),
+// so its latency -- long when 16 waves queue on the LDS pipe -- hides behind the stage in between.
+template <bool SQUARE, bool LDSX, bool PRE SMX_ABL_PARAM, class Hook>
+__device__ __forceinline__ void frame_to_tile(const FastArgs &a, const LaneConst &L, float2 (&raw)[16],
                                               float *tile, int wave, int lane, const Hook &hook) {
   c32 v[16];
+  float2 win[16], tw[16];
 #pragma unroll
-  for (int j = 0; j < 16; ++j) {
-    const float2 w = L.winL_l[64 * j];
-    v[j] = {raw[j].x * w.x, raw[j].y * w.y};
+  for (int j = 0; j < 16; ++j) win[j] = L.winL_l[64 * j];
+  if constexpr (PRE) {
+#pragma unroll
+    for (int k = 1; k < 16; ++k) tw[k] = L.tabA_l[64 * k];
   }
+#pragma unroll
+  for (int j = 0; j < 16; ++j) v[j] = {raw[j].x * win[j].x, raw[j].y * win[j].y};
+  if constexpr (SMX_ABL(6)) {   // timing-only: memory traffic and synchronisation without the FFT
+    hook.ready();
+#pragma unroll
+    for (int q = 0; q < 16; ++q) (tile + wave)[(L.tile_row0 + 64 * q) * kTileStride] = v[q].x + v[q].y;
+    return;
+  }
+  hook.after_window(raw);   // raw is free again: the power kernel reloads it with the next frame here
   hook.template at<0>();
-  __builtin_amdgcn_sched_barrier(0);
+  SMX_FENCE();
   // A: radix-16 over j, twiddle W_M^(l k1)
   fft16_pass1(v);
   hook.template at<1>();
   fft16_pass2(v);
   hook.template at<2>();
-  __builtin_amdgcn_sched_barrier(0);
+  SMX_FENCE();
 #pragma unroll
   for (int k = 1; k < 16; ++k) {
-    const float2 w = L.tabA_l[64 * k];
+    const float2 w = PRE ? tw[k] : L.tabA_l[64 * k];
     v[k] = cmul(v[k], c32{w.x, w.y});
   }
+  if constexpr (PRE) {
+#pragma unroll
+    for (int q = 1; q < 16; ++q) tw[q] = L.tabB_l[4 * q];
+  }
   hook.template at<3>();
-  __builtin_amdgcn_sched_barrier(0);
+  SMX_FENCE();
   // X: transpose lane (i, a) register k1 -> lane (k1, a) register i.
   if constexpr (LDSX) {
     hook.ready();
@@ -384,59 +447,92 @@ __device__ __forceinline__ void frame_to_tile(const FastArgs &a, const LaneConst
     for (int k = 0; k < 16; ++k) v[k] = {re[k], im[k]};
   }
   hook.template at<5>();
-  __builtin_amdgcn_sched_barrier(0);
+  SMX_FENCE();
   // B: radix-16 over i, twiddle W_64^(a q)
   fft16_pass1(v);
   hook.template at<6>();
   fft16_pass2(v);
   hook.template at<7>();
-  __builtin_amdgcn_sched_barrier(0);
+  SMX_FENCE();
 #pragma unroll
   for (int q = 1; q < 16; ++q) {
-    const float2 wb = L.tabB_l[4 * q];
+    const float2 wb = PRE ? tw[q] : L.tabB_l[4 * q];
     v[q] = cmul(v[q], c32{wb.x, wb.y});
   }
+  if constexpr (PRE) {
+#pragma unroll
+    for (int q = 0; q < 16; ++q) tw[q] = L.tabP_l[64 * q];
+  }
   hook.template at<8>();
-  __builtin_amdgcn_sched_barrier(0);
-  // C: radix-4 across the quad (DPP).  lane a ends with r = bitrev2(a).
+  SMX_FENCE();
+  // C: radix-4 across the quad.  lane a ends with r = bitrev2(a).
+  // Butterfly 1 pairs lane a with a ^ 2 (u = +-v + partner), then lane 3 multiplies by -i, butterfly 2
+  // pairs a with a ^ 1.  The lane signs s1 (a < 2 ? + : -) and s2 (a even ? + : -) are folded into the
+  // W_64 table (and into v[0]), which turns each butterfly into x += kappa * partner(x) with
+  // kappa1 = -s1, kappa2 = -s2: one v_fmac_f32_dpp per component.  Sign flips are exact, so the values
+  // are those of the plain formulation bit for bit.
+  v[0].x *= L.s12;
+  v[0].y *= L.s12;
+  SMX_FMAC_DPP8("[2,3,0,1]", v, L.kap1);
+  SMX_FMAC_DPP8("[2,3,0,1]", v + 8, L.kap1);
+  hook.template at<9>();
 #pragma unroll
   for (int q = 0; q < 16; ++q) {
-    c32 u;
-    u.x = fmaf(v[q].x, L.s1, dpp_quad<0x4E>(v[q].x));
-    u.y = fmaf(v[q].y, L.s1, dpp_quad<0x4E>(v[q].y));
-    const c32 w = L.rot ? c32{u.y, -u.x} : u;
-    v[q].x = fmaf(w.x, L.s2, dpp_quad<0xB1>(w.x));
-    v[q].y = fmaf(w.y, L.s2, dpp_quad<0xB1>(w.y));
-    if (q == 7) hook.template at<9>();
+    const c32 u = v[q];
+    v[q] = L.rot ? c32{u.y, -u.x} : u;
   }
+  SMX_FMAC_DPP8("[1,0,3,2]", v, L.kap2);
+  SMX_FMAC_DPP8("[1,0,3,2]", v + 8, L.kap2);
   hook.template at<10>();
-  __builtin_amdgcn_sched_barrier(0);
+  SMX_FENCE();
   // P: real-FFT post-pass.  provider rotation for the k1 = 0 lanes.
   if constexpr (!LDSX) hook.ready();
   float *col = tile + wave;
   const float nyq = 2.0f * (v[0].x - v[0].y);   // X[M] = Re Z0 - Im Z0 (true scale), lane 0
-#pragma unroll
-  for (int q = 0; q < 16; ++q) {
+  auto partner = [&](int q, float &px, float &py) {   // Z[M - k] of register q's bin k
     const int addr = q == 0 ? L.addr_0 : L.addr_g;
     const int m = 15 - q;
     const float sx = L.low4 ? v[(m + 1) & 15].x : v[m].x;
     const float sy = L.low4 ? v[(m + 1) & 15].y : v[m].y;
-    const float px = SMX_ABL(4) ? sx : bperm(addr, sx);
-    const float py = SMX_ABL(4) ? sy : bperm(addr, sy);
+    px = SMX_ABL(4) ? sx : bperm(addr, sx);
+    py = SMX_ABL(4) ? sy : bperm(addr, sy);
+  };
+  auto finish_bin = [&](int q, float px, float py, float2 w) {
     const c32 e = {v[q].x + px, v[q].y - py};
     const c32 d = {v[q].x - px, v[q].y + py};
-    const float2 w = L.tabP_l[64 * q];
     const float tr = e.x + w.x * d.y + w.y * d.x;
     const float ti = e.y - w.x * d.x + w.y * d.y;
     float pw = tr * tr + ti * ti;
     if constexpr (!SQUARE) pw = a.pmode == 1 ? sqrtf(pw) : __powf(pw, a.half_power);
     col[(L.tile_row0 + 64 * q) * kTileStride] = pw;
-    if ((q & 3) == 3) {
-      __builtin_amdgcn_sched_barrier(0);
+  };
+  if constexpr (PRE) {
+    // all 32 lane exchanges in flight before the first result is needed
+    float px[16], py[16];
+#pragma unroll
+    for (int q = 0; q < 16; ++q) partner(q, px[q], py[q]);
+    SMX_FENCE();
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+      finish_bin(q, px[q], py[q], tw[q]);
       if (q == 3) hook.template at<11>();
       if (q == 7) hook.template at<12>();
       if (q == 11) hook.template at<13>();
       if (q == 15) { hook.template at<14>(); hook.template at<15>(); }
+    }
+  } else {
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+      float px, py;
+      partner(q, px, py);
+      finish_bin(q, px, py, L.tabP_l[64 * q]);
+      if ((q & 3) == 3) {
+        SMX_FENCE();
+        if (q == 3) hook.template at<11>();
+        if (q == 7) hook.template at<12>();
+        if (q == 11) hook.template at<13>();
+        if (q == 15) { hook.template at<14>(); hook.template at<15>(); }
+      }
     }
   }
   if (lane == 0) {
@@ -479,9 +575,18 @@ __device__ __forceinline__ void lds_wait(unsigned *c, unsigned target) {
     __builtin_amdgcn_s_sleep(2);
 }
 
+template <bool ALIGNED SMX_ABL_PARAM>
 struct SyncHook {
+  const FastArgs &a;
   unsigned *drained;
   unsigned target;
+  const float *next_src;   // first sample of this wave's next frame
+  int lane;
+  // The next frame's samples are requested as soon as the current ones have been windowed, a whole
+  // frame ahead of their use: the 16 loads of the 16 waves no longer queue up behind each other.
+  __device__ __forceinline__ void after_window(float2 (&raw)[16]) const {
+    if constexpr (kEarlyPrefetch) prefetch_frame<ALIGNED SMX_ABL_ARG>(a, next_src, lane, raw);
+  }
 #ifdef SMX_STAMPS
   unsigned long long *stamp_sum, *stamp_prev_p;
 #endif
@@ -559,7 +664,7 @@ __global__ void __launch_bounds__(1024) stft2048_power_kernel(FastArgs a) {
   prefetch_frame<ALIGNED SMX_ABL_ARG>(a, frame_ptr(xclip, ft, have), lane, raw);
   __syncthreads();   // tables and zeroed counters visible: the only workgroup barrier of the kernel
   float *pend_out = nullptr; // output origin (clip, first frame) of the previous tile and frames left in that clip
-  int pend_left = 0;
+  int pend_left = 0, pend_ft = 0;
   FlushLane fl;
   {
     const int hsel = lane >> 5, jj = (lane & 31) >> 2;
@@ -574,7 +679,7 @@ __global__ void __launch_bounds__(1024) stft2048_power_kernel(FastArgs a) {
     lds_wait(cnt.filled + b, 16u * fills);
     const float *ptile = lds.tiles + b * kTileFloats;
 #pragma unroll
-    for (int part = 0; part < 4; ++part) flush_part<LDSX>(a, ptile, part, fl, pend_out, pend_left, wave, lane);
+    for (int part = 0; part < 4; ++part) flush_part<LDSX>(a, ptile, part, fl, pend_out, pend_left, wave, lane, pend_ft);
     lds_signal(cnt.drained + b, lane);
   };
 
@@ -585,20 +690,8 @@ __global__ void __launch_bounds__(1024) stft2048_power_kernel(FastArgs a) {
   for (int it = 0; it < ntiles; ++it) {   // tile `it` of this workgroup lives in buffer it & 1
     const int b = it & 1;
     SMX_STAMP(0);
-    if (have) {   // wave-uniform
-      // buffer b last held tile it - 2, the (it >> 1)-th tile written there
-#ifdef SMX_STAMPS
-      const SyncHook hook{cnt.drained + b, 16u * ((unsigned)it >> 1), stamp_sum, &stamp_prev};
-#else
-      const SyncHook hook{cnt.drained + b, 16u * ((unsigned)it >> 1)};
-#endif
-      frame_to_tile<SQUARE, LDSX SMX_ABL_ARG>(a, L, raw, lds.tiles + b * kTileFloats, wave, lane, hook);
-    }
-    lds_signal(cnt.filled + b, lane);
-    SMX_STAMP(17);
-    // prefetch this wave's frame of the next tile (possibly of the next clip); the loads are in flight
-    // while the previous tile is stored.  Unconditional: past the end the current tile's first frame is
-    // re-read and ignored, so raw never carries old values around the loop.
+    // next tile of this workgroup (possibly of another clip).  Past the end the current tile's first
+    // frame is re-read and ignored, so raw never carries old values around the loop.
     int ftnext = ft + step_tiles, dclip = step_clips;
     if (ftnext >= a.tiles_per_clip) {
       ftnext -= a.tiles_per_clip;
@@ -609,11 +702,25 @@ __global__ void __launch_bounds__(1024) stft2048_power_kernel(FastArgs a) {
     bool have_next;
     const float *src = frame_ptr(it + 1 < ntiles ? xnext : xclip, it + 1 < ntiles ? ftnext : ft, have_next);
     have_next = have_next && it + 1 < ntiles;
-    prefetch_frame<ALIGNED SMX_ABL_ARG>(a, src, lane, raw);
+    if (have) {   // wave-uniform
+      // buffer b last held tile it - 2, the (it >> 1)-th tile written there
+#ifdef SMX_STAMPS
+      const SyncHook<ALIGNED SMX_ABL_ARG> hook{a, cnt.drained + b, 16u * ((unsigned)it >> 1), src, lane, stamp_sum, &stamp_prev};
+#else
+      const SyncHook<ALIGNED SMX_ABL_ARG> hook{a, cnt.drained + b, 16u * ((unsigned)it >> 1), src, lane};
+#endif
+      frame_to_tile<SQUARE, LDSX, kPre SMX_ABL_ARG>(a, L, raw, lds.tiles + b * kTileFloats, wave, lane, hook);
+    } else if constexpr (kEarlyPrefetch) {
+      prefetch_frame<ALIGNED SMX_ABL_ARG>(a, src, lane, raw);
+    }
+    lds_signal(cnt.filled + b, lane);
+    SMX_STAMP(17);
+    if constexpr (!kEarlyPrefetch) prefetch_frame<ALIGNED SMX_ABL_ARG>(a, src, lane, raw);
     SMX_STAMP(18);
     if (it > 0) flush_tile(b ^ 1, ((unsigned)(it - 1) >> 1) + 1);   // tile it - 1
     SMX_STAMP(19);
     pend_out = oclip + ft * kFT;   // wave-uniform
+    pend_ft = ft;
     const int64_t left = a.count - (int64_t)ft * kFT;
     pend_left = left < kFT ? (int)left : kFT;
     have = have_next;
@@ -664,6 +771,7 @@ struct NoHook {
   template <int P>
   __device__ __forceinline__ void at() const {}
   __device__ __forceinline__ void ready() const {}
+  __device__ __forceinline__ void after_window(float2 (&)[16]) const {}
 };
 
 template <bool ALIGNED, bool SQUARE, bool STRIP>
@@ -797,7 +905,7 @@ __global__ void __launch_bounds__(1024) stft2048_mel_kernel(FastArgs a, MelFused
     float *tprev = lds.tiles + (cur ^ 1) * kTileFloats;
     if (stage >= 2) finish(tcur, out_m2, left_m2);   // partials of tile t-2 sit in this buffer's pad column
     if (stage >= 1) mfma_item(tprev);                // tile t-1
-    if (have) frame_to_tile<SQUARE, false SMX_ABL_ZERO>(a, L, raw, tcur, wave, lane, NoHook{});
+    if (have) frame_to_tile<SQUARE, false, false SMX_ABL_ZERO>(a, L, raw, tcur, wave, lane, NoHook{});
     bool have_next = false;
     {
       const float *xs;
@@ -935,11 +1043,13 @@ void launch_interior(const StftJob &job, const FastTarget &tg, const float *x, i
 #ifdef SMX_DIAG
   const char *abl_env = std::getenv("SMX_ABLATE");
   const int abl = abl_env ? std::atoi(abl_env) : 0;
-  a.abl_nostore = (abl == 1 || abl == 3) ? 1 : 0;
+  a.abl_nostore = (abl == 1 || abl == 3 || abl == 7) ? 1 : (abl == 8 || abl == 9) ? 2 : 0;
+  if (const char *w = std::getenv("SMX_ABL_RUN")) a.abl_nostore = std::atoi(w);   // 2: 128 B, 3: 256 B, 4: 512 B runs
   auto kernel = abl == 2 ? stft2048_power_kernel<true, true, false, kLdsX, 2>
               : abl == 3 ? stft2048_power_kernel<true, true, false, kLdsX, 3>
               : abl == 4 ? stft2048_power_kernel<true, true, false, kLdsX, 4>
               : abl == 5 ? stft2048_power_kernel<true, true, false, kLdsX, 5>
+              : (abl == 6 || abl == 7 || abl == 8) ? stft2048_power_kernel<true, true, false, kLdsX, 6>
                          : stft2048_power_kernel<true, true, false, kLdsX, 0>;
   (void)aligned; (void)square; (void)strip;
 #else

@@ -34,7 +34,7 @@ for p, lib, h in libs:
     clearenv(p)
 torch.cuda.synchronize()
 ts = {p: [] for p in paths}
-for rnd in range(15):
+for rnd in range(int(os.environ.get("AB_ROUNDS", "40"))):
     for p, lib, h in libs:
         a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         setenv(p)
@@ -45,4 +45,5 @@ for rnd in range(15):
         ts[p].append(a.elapsed_time(b) / 4)
 for p in paths:
     v = sorted(ts[p])
-    print("%-45s median %.4f ms  min %.4f ms  (%.1f Mframes/s)" % (p, v[len(v) // 2], v[0], clips * frames / v[len(v) // 2] / 1e3))
+    print("%-52s min %.4f  q1 %.4f  median %.4f  q3 %.4f ms  (%.1f Mframes/s at median)"
+          % (p[-52:], v[0], v[len(v) // 4], v[len(v) // 2], v[3 * len(v) // 4], clips * frames / v[len(v) // 2] / 1e3))

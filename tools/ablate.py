@@ -1,5 +1,6 @@
 """Diagnostic: time the fused STFT kernel (stamps build) under timing-only ablations.
-SMX_ABLATE: 0 none, 1 no HBM stores, 2 no sample loads, 3 neither, 4 no post-pass permutes, 5 no transposes."""
+SMX_ABLATE: 0 none, 1 no HBM stores, 2 no sample loads, 3 neither, 4 no post-pass permutes, 5 no transposes, 6 no FFT (memory + sync only), 7 no FFT and no stores,
+8 no FFT + stores as 128-byte runs, 9 full compute + stores as 128-byte runs."""
 import ctypes, os, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if len(sys.argv) > 1:
@@ -23,6 +24,6 @@ if len(sys.argv) > 1:
         a.record(); run(); b.record(); torch.cuda.synchronize(); ts.append(a.elapsed_time(b))
     print("ablate=%s  median %.3f ms  min %.3f ms" % (os.environ.get("SMX_ABLATE", "0"), sorted(ts)[5], min(ts)))
 else:
-    for abl in "012345":
+    for abl in os.environ.get("ABLS", "016789"):
         env = dict(os.environ, SMX_ABLATE=abl)
         subprocess.call([sys.executable, __file__, "run"], env=env)

@@ -14,7 +14,7 @@ for m in re.finditer(r"^(_Z\S+):.*?\n(.*?)^\.Lfunc_end\d+:", text, re.S | re.M):
         continue
     c = collections.Counter()
     for line in body.split("\n"):
-        if line.startswith("\t") and not line.startswith("\t."):
+        if line.startswith("\t") and not line.startswith("\t.") and line.strip():
             t = line.strip().split()[0]
             if re.match(r"(v_|s_|ds_|global_|buffer_|scratch_)", t):
                 c[t] += 1
