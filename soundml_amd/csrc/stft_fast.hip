@@ -364,6 +364,64 @@ __device__ __forceinline__ void block_to_range(const FastArgs &a, int64_t &tau_b
   tau_end = tau_begin + base + (vb < extra ? 1 : 0);
 }
 
+// The tiles of one workgroup: tau0, tau0 + step, ... (ntiles of them) of the flat (clip, tile)
+// sequence, walked without divisions (a scalar 64-bit division costs a few hundred dependent SALU
+// instructions; the only ones are in init()).
+struct TileWalk {
+  int ntiles, ft, step_clips, step_tiles;   // ft: tile index inside the clip
+  const float *xclip;                       // first sample of the current clip
+  float *oclip;                             // output origin of the current clip
+  int64_t x_step, o_step;                   // per-clip strides of input and output
+
+  __device__ __forceinline__ void init(const FastArgs &a, float *out, int64_t out_clip_floats) {
+    int64_t tau0;
+    int step;
+    if (a.interleave) {
+      // The workgroups of one XCD walk a contiguous chunk of the sequence side by side: at any time the
+      // XCD is writing ~32 neighbouring tiles of the same clip, i.e. for every bin one contiguous run of
+      // ~2 KB, which its L2 can assemble into whole lines before they go to HBM.
+      const int64_t nb = a.blocks, xcd = blockIdx.x % 8, idx = blockIdx.x / 8;
+      if (a.interleave == 2) {   // all workgroups side by side; an XCD holds 32 neighbouring tiles of every 256
+        const int64_t q = nb / 8, r = nb % 8;
+        tau0 = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+        step = (int)nb;
+        ntiles = tau0 < a.total_tiles ? (int)((a.total_tiles - tau0 + nb - 1) / nb) : 0;
+      } else {
+        const int64_t nx = (nb - xcd + 7) / 8;                            // workgroups on this XCD
+        const int64_t nxcd = nb < 8 ? nb : 8;                             // XCDs that received a workgroup
+        const int64_t x0 = a.total_tiles * xcd / nxcd, x1 = a.total_tiles * (xcd + 1) / nxcd;
+        tau0 = x0 + idx;
+        step = (int)nx;
+        ntiles = tau0 < x1 ? (int)((x1 - tau0 + nx - 1) / nx) : 0;
+      }
+    } else {
+      int64_t tau_end;
+      block_to_range(a, tau0, tau_end);
+      step = 1;
+      ntiles = (int)(tau_end - tau0);
+    }
+    if (ntiles <= 0) return;
+    ft = (int)(tau0 % a.tiles_per_clip);
+    x_step = a.x_stride;
+    o_step = out_clip_floats;
+    xclip = a.x + (tau0 / a.tiles_per_clip) * x_step;
+    oclip = out + (tau0 / a.tiles_per_clip) * o_step;
+    step_clips = step / a.tiles_per_clip;
+    step_tiles = step % a.tiles_per_clip;
+  }
+  // the tile after the current one
+  __device__ __forceinline__ void peek(const FastArgs &a, int &ftn, const float *&xn, float *&on) const {
+    ftn = ft + step_tiles;
+    int dclip = step_clips;
+    if (ftn >= a.tiles_per_clip) {
+      ftn -= a.tiles_per_clip;
+      ++dclip;
+    }
+    xn = xclip + dclip * x_step;
+    on = oclip + dclip * o_step;
+  }
+};
+
 // One frame: raw samples (registers) -> window -> FFT(1024 complex) -> real post-pass -> |X|^p
 // written as column `wave` of `tile`.  `hook.at<P>()` is called at 16 points between the stages;
 // the power kernel uses them to trickle out the previous tile's stores.
@@ -614,41 +672,10 @@ __global__ void __launch_bounds__(1024) stft2048_power_kernel(FastArgs a) {
   const Lds lds = carve_lds(smem);
   const LaneConst L = setup_lane(a, lds, tid, lane, wave);
   const Counters cnt{reinterpret_cast<unsigned *>(lds.tabB), reinterpret_cast<unsigned *>(lds.tabB) + 2};
-  // This workgroup's tiles: tau0, tau0 + step, ... (ntiles of them) of the flat (clip, tile) sequence.
-  int64_t tau0;
-  int step, ntiles;
-  if (a.interleave) {
-    // The workgroups of one XCD walk a contiguous chunk of the sequence side by side: at any time the
-    // XCD is writing ~32 neighbouring tiles of the same clip, i.e. for every bin one contiguous run of
-    // ~2 KB, which its L2 can assemble into whole lines before they go to HBM.
-    const int64_t nb = a.blocks, xcd = blockIdx.x % 8, idx = blockIdx.x / 8;
-    const int64_t nx = (nb - xcd + 7) / 8;                            // workgroups on this XCD
-    const int64_t nxcd = nb < 8 ? nb : 8;                             // XCDs that received a workgroup
-    const int64_t x0 = a.total_tiles * xcd / nxcd, x1 = a.total_tiles * (xcd + 1) / nxcd;
-    if (a.interleave == 2) {   // all workgroups side by side; an XCD holds 32 neighbouring tiles of every 256
-      const int64_t q = nb / 8, r = nb % 8;
-      tau0 = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
-      step = (int)nb;
-      ntiles = tau0 < a.total_tiles ? (int)((a.total_tiles - tau0 + nb - 1) / nb) : 0;
-    } else {
-      tau0 = x0 + idx;
-      step = (int)nx;
-      ntiles = tau0 < x1 ? (int)((x1 - tau0 + nx - 1) / nx) : 0;
-    }
-  } else {
-    int64_t tau_end;
-    block_to_range(a, tau0, tau_end);
-    step = 1;
-    ntiles = (int)(tau_end - tau0);
-  }
-  if (ntiles <= 0) return;   // uniform for the workgroup
-  // Position in the sequence, advanced incrementally: the only divisions of the kernel are these
-  // (a scalar 64-bit division costs a few hundred dependent SALU instructions).
-  int ft = (int)(tau0 % a.tiles_per_clip);                              // tile index inside the clip
-  const float *xclip = a.x + (tau0 / a.tiles_per_clip) * a.x_stride;
-  float *oclip = a.out + (tau0 / a.tiles_per_clip) * kBins * a.out_stride + a.out_offset;
-  const int64_t x_step = a.x_stride, o_step = kBins * a.out_stride;
-  const int step_clips = step / a.tiles_per_clip, step_tiles = step % a.tiles_per_clip;   // one step = this many clips + tiles
+  TileWalk tw;
+  tw.init(a, a.out + a.out_offset, kBins * a.out_stride);
+  if (tw.ntiles <= 0) return;   // uniform for the workgroup
+  const int ntiles = tw.ntiles;
   // first sample of this wave's frame in tile t of the clip at xc (a wave without a frame re-reads the
   // tile's first frame and ignores it)
   auto frame_ptr = [&](const float *xc, int t, bool &hv) {
@@ -661,7 +688,7 @@ __global__ void __launch_bounds__(1024) stft2048_power_kernel(FastArgs a) {
 #pragma unroll
   for (int j = 0; j < 16; ++j) raw[j] = make_float2(0.f, 0.f);
   bool have;
-  prefetch_frame<ALIGNED SMX_ABL_ARG>(a, frame_ptr(xclip, ft, have), lane, raw);
+  prefetch_frame<ALIGNED SMX_ABL_ARG>(a, frame_ptr(tw.xclip, tw.ft, have), lane, raw);
   __syncthreads();   // tables and zeroed counters visible: the only workgroup barrier of the kernel
   float *pend_out = nullptr; // output origin (clip, first frame) of the previous tile and frames left in that clip
   int pend_left = 0, pend_ft = 0;
@@ -692,15 +719,12 @@ __global__ void __launch_bounds__(1024) stft2048_power_kernel(FastArgs a) {
     SMX_STAMP(0);
     // next tile of this workgroup (possibly of another clip).  Past the end the current tile's first
     // frame is re-read and ignored, so raw never carries old values around the loop.
-    int ftnext = ft + step_tiles, dclip = step_clips;
-    if (ftnext >= a.tiles_per_clip) {
-      ftnext -= a.tiles_per_clip;
-      ++dclip;
-    }
-    const float *xnext = xclip + dclip * x_step;
-    float *onext = oclip + dclip * o_step;
+    int ftnext;
+    const float *xnext;
+    float *onext;
+    tw.peek(a, ftnext, xnext, onext);
     bool have_next;
-    const float *src = frame_ptr(it + 1 < ntiles ? xnext : xclip, it + 1 < ntiles ? ftnext : ft, have_next);
+    const float *src = frame_ptr(it + 1 < ntiles ? xnext : tw.xclip, it + 1 < ntiles ? ftnext : tw.ft, have_next);
     have_next = have_next && it + 1 < ntiles;
     if (have) {   // wave-uniform
       // buffer b last held tile it - 2, the (it >> 1)-th tile written there
@@ -719,14 +743,14 @@ __global__ void __launch_bounds__(1024) stft2048_power_kernel(FastArgs a) {
     SMX_STAMP(18);
     if (it > 0) flush_tile(b ^ 1, ((unsigned)(it - 1) >> 1) + 1);   // tile it - 1
     SMX_STAMP(19);
-    pend_out = oclip + ft * kFT;   // wave-uniform
-    pend_ft = ft;
-    const int64_t left = a.count - (int64_t)ft * kFT;
+    pend_out = tw.oclip + tw.ft * kFT;   // wave-uniform
+    pend_ft = tw.ft;
+    const int64_t left = a.count - (int64_t)tw.ft * kFT;
     pend_left = left < kFT ? (int)left : kFT;
     have = have_next;
-    xclip = xnext;
-    oclip = onext;
-    ft = ftnext;
+    tw.xclip = xnext;
+    tw.oclip = onext;
+    tw.ft = ftnext;
   }
   flush_tile((ntiles - 1) & 1, ((unsigned)(ntiles - 1) >> 1) + 1);   // the last tile of this workgroup
 #ifdef SMX_STAMPS
@@ -774,6 +798,15 @@ struct NoHook {
   __device__ __forceinline__ void after_window(float2 (&)[16]) const {}
 };
 
+struct ReadyHook {   // frame_to_tile calls ready() just before the powers overwrite the tile buffer
+  unsigned *c;
+  unsigned target;
+  template <int P>
+  __device__ __forceinline__ void at() const {}
+  __device__ __forceinline__ void ready() const { lds_wait(c, target); }
+  __device__ __forceinline__ void after_window(float2 (&)[16]) const {}
+};
+
 template <bool ALIGNED, bool SQUARE, bool STRIP>
 __global__ void __launch_bounds__(1024) stft2048_mel_kernel(FastArgs a, MelFusedArgs m) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -782,9 +815,10 @@ __global__ void __launch_bounds__(1024) stft2048_mel_kernel(FastArgs a, MelFused
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const Lds lds = carve_lds(smem);
   const LaneConst L = setup_lane(a, lds, tid, lane, wave);
-  int64_t tau_begin, tau_end;
-  block_to_range(a, tau_begin, tau_end);
-  if (tau_begin >= tau_end) return;            // uniform for the workgroup
+  TileWalk tw;
+  tw.init(a, m.out + m.out_offset, (int64_t)m.n_mels * m.out_stride);
+  if (tw.ntiles <= 0) return;                  // uniform for the workgroup
+  const int ntiles = tw.ntiles;
   MelItem item = m.items[wave];                // wave-uniform: force every field into SGPRs
   item.block = __builtin_amdgcn_readfirstlane(item.block);
   item.k4_begin = __builtin_amdgcn_readfirstlane(item.k4_begin);
@@ -796,31 +830,27 @@ __global__ void __launch_bounds__(1024) stft2048_mel_kernel(FastArgs a, MelFused
 #pragma unroll
   for (int i = 0; i < 3; ++i) item.slots[i] = __builtin_amdgcn_readfirstlane(item.slots[i]);
 
-  // tile tau -> (clip, first frame, does this wave have a frame)
-  auto frame_of = [&](int64_t tau, const float *&xs, int64_t &p, bool &hv) {
-    const int64_t clip = tau / a.tiles_per_clip;
-    const int64_t f0 = (tau % a.tiles_per_clip) * kFT;
+  auto frame_ptr = [&](const float *xc, int t, bool &hv) {
+    const int64_t f0 = (int64_t)t * kFT;
     hv = f0 + wave < a.count;
-    xs = a.x + clip * a.x_stride;
-    p = a.p0 + f0 + (hv ? wave : 0);
+    return xc + ((a.p0 + f0 + (hv ? wave : 0)) * a.hop - a.left);
   };
   float2 raw[16];
   bool have;
-  {
-    const float *xs;
-    int64_t p;
-    frame_of(tau_begin, xs, p, have);
-    load_frame<ALIGNED>(xs + (p * a.hop - a.left), lane, raw);
-  }
-  __syncthreads();   // tables visible
+  load_frame<ALIGNED>(frame_ptr(tw.xclip, tw.ft, have), lane, raw);
+  __syncthreads();   // tables and zeroed counters visible: the only workgroup barrier of the kernel
   const int pad_lane = (16 + lane) * kTileStride + kFT;     // pad-column slot of this lane (rows >= 16)
   constexpr int kTileFloats = kTileBytes / sizeof(float);
-  int cur = 0;
-  int stage = 0;              // tiles computed so far in this group
   // output origin (clip, first frame) and frames left in the clip, of tile t-1 / t-2
-  float *out_m1 = nullptr, *out_m2 = nullptr;
-  int64_t left_m1 = 0, left_m2 = 0;
+  float *out_cur = nullptr, *out_m1 = nullptr, *out_m2 = nullptr;
+  int64_t left_cur = 0, left_m1 = 0, left_m2 = 0;
   f32x4v acc_prev = {0.f, 0.f, 0.f, 0.f};
+  // Wave-level synchronisation through monotonic LDS counters (see the power kernel), per buffer:
+  //   filled: the wave's column of the tile is written;  mdone: its MFMA item over the tile (and its
+  //   partial sums, if it is a helper) is done;  fin: the owner has read the partials of the tile.
+  unsigned *const c_filled = reinterpret_cast<unsigned *>(lds.tabB);
+  unsigned *const c_mdone = c_filled + 2, *const c_fin = c_filled + 4;
+  auto nth = [](int tile) { return 16u * (((unsigned)tile >> 1) + 1u); };   // counter value once tile `tile` is through
 
   // (A) owner: finish the tile whose MFMA partials were produced one iteration ago
   auto finish = [&](const float *buf, float *obase, int64_t frames_left) {
@@ -898,40 +928,49 @@ __global__ void __launch_bounds__(1024) stft2048_mel_kernel(FastArgs a, MelFused
     }
   };
 
-  for (int64_t tau = tau_begin; tau < tau_end; ++tau) {
-    const int64_t clip = tau / a.tiles_per_clip;
-    const int64_t f0 = (tau % a.tiles_per_clip) * kFT;
-    float *tcur = lds.tiles + cur * kTileFloats;
-    float *tprev = lds.tiles + (cur ^ 1) * kTileFloats;
-    if (stage >= 2) finish(tcur, out_m2, left_m2);   // partials of tile t-2 sit in this buffer's pad column
-    if (stage >= 1) mfma_item(tprev);                // tile t-1
-    if (have) frame_to_tile<SQUARE, false, false SMX_ABL_ZERO>(a, L, raw, tcur, wave, lane, NoHook{});
-    bool have_next = false;
-    {
-      const float *xs;
-      int64_t p;
-      if (tau + 1 < tau_end) {
-        frame_of(tau + 1, xs, p, have_next);
-      } else {
-        xs = a.x + clip * a.x_stride;
-        p = a.p0 + f0;
-      }
-      load_frame<ALIGNED>(xs + (p * a.hop - a.left), lane, raw);
+  // Iteration t: frame of tile t -> buffer t & 1 | owner finishes tile t-2 | MFMA item over tile t-1.
+  // Each step waits only for what it consumes, a whole frame behind the producers, so the waves
+  // drift apart and overlap each other's LDS, MFMA and VALU phases; two extra iterations drain.
+  for (int t = 0; t < ntiles + 2; ++t) {
+    const int b = t & 1;
+    float *tcur = lds.tiles + b * kTileFloats;
+    float *tprev = lds.tiles + (b ^ 1) * kTileFloats;
+    if (t < ntiles) {
+      // every MFMA read of tile t-2 (same buffer) must be over before the powers of tile t land
+      if (have) frame_to_tile<SQUARE, false, false SMX_ABL_ZERO>(a, L, raw, tcur, wave, lane,
+                                                               ReadyHook{c_mdone + b, t >= 2 ? nth(t - 2) : 0u});
+      lds_signal(c_filled + b, lane);
+      int ftnext;
+      const float *xnext;
+      float *onext;
+      tw.peek(a, ftnext, xnext, onext);
+      bool have_next;
+      const float *src = frame_ptr(t + 1 < ntiles ? xnext : tw.xclip, t + 1 < ntiles ? ftnext : tw.ft, have_next);
+      have_next = have_next && t + 1 < ntiles;
+      load_frame<ALIGNED>(src, lane, raw);
+      out_cur = tw.oclip + tw.ft * kFT;   // wave-uniform
+      left_cur = a.count - (int64_t)tw.ft * kFT;
+      have = have_next;
+      tw.xclip = xnext;
+      tw.oclip = onext;
+      tw.ft = ftnext;
     }
-    __syncthreads();
+    if (t >= 2) {   // tile t-2: its partials sit in this buffer's pad column once every helper is through
+      lds_wait(c_mdone + b, nth(t - 2));
+      finish(tcur, out_m2, left_m2);
+      lds_signal(c_fin + b, lane);
+    }
+    if (t >= 1 && t - 1 < ntiles) {   // tile t-1
+      lds_wait(c_filled + (b ^ 1), nth(t - 1));
+      if (t >= 3) lds_wait(c_fin + (b ^ 1), nth(t - 3));   // the partial slots of tile t-3 have been read
+      mfma_item(tprev);
+      lds_signal(c_mdone + (b ^ 1), lane);
+    }
     out_m2 = out_m1;
     left_m2 = left_m1;
-    out_m1 = m.out + (clip * m.n_mels) * m.out_stride + m.out_offset + f0;   // wave-uniform
-    left_m1 = a.count - f0;
-    have = have_next;
-    cur ^= 1;
-    if (stage < 2) ++stage;
+    out_m1 = out_cur;
+    left_m1 = left_cur;
   }
-  // drain: tile T-2 (partials in buffer `cur`), MFMA on tile T-1 (buffer cur^1), then its finish
-  if (stage >= 2) finish(lds.tiles + cur * kTileFloats, out_m2, left_m2);
-  if (stage >= 1) mfma_item(lds.tiles + (cur ^ 1) * kTileFloats);
-  __syncthreads();
-  if (stage >= 1) finish(lds.tiles + (cur ^ 1) * kTileFloats, out_m1, left_m1);
 }
 
 }  // namespace
