@@ -369,6 +369,7 @@ __device__ __forceinline__ void block_to_range(const FastArgs &a, int64_t &tau_b
 // instructions; the only ones are in init()).
 struct TileWalk {
   int ntiles, ft, step_clips, step_tiles;   // ft: tile index inside the clip
+  int group;                                // tiles taken back to back (1 normally); a power of two
   const float *xclip;                       // first sample of the current clip
   float *oclip;                             // output origin of the current clip
   int64_t x_step, o_step;                   // per-clip strides of input and output
@@ -381,7 +382,24 @@ struct TileWalk {
       // XCD is writing ~32 neighbouring tiles of the same clip, i.e. for every bin one contiguous run of
       // ~2 KB, which its L2 can assemble into whole lines before they go to HBM.
       const int64_t nb = a.blocks, xcd = blockIdx.x % 8, idx = blockIdx.x / 8;
-      if (a.interleave == 2) {   // all workgroups side by side; an XCD holds 32 neighbouring tiles of every 256
+      group = 1;
+      if (a.interleave == 3 || a.interleave == 4) {   // as 2, but each workgroup takes `group` neighbouring tiles back to back
+        group = a.interleave == 3 ? 2 : 4;   // (measured: worse than 2 -- what counts is that the tiles written at the same time are neighbours)
+        const int64_t q = nb / 8, r = nb % 8, g = group;
+        const int64_t vb = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+        tau0 = g * vb;
+        step = (int)(g * nb - (g - 1));                                  // after the last tile of a group
+        ntiles = 0;
+        if (tau0 < a.total_tiles) {
+          const int64_t rounds = (a.total_tiles - tau0 + g * nb - 1) / (g * nb);
+          const int64_t last = a.total_tiles - (tau0 + g * nb * (rounds - 1));
+          ntiles = (int)((rounds - 1) * g + (last < g ? last : g));
+        }
+      } else if (a.interleave == 5) {   // experiment: neighbouring tiles on different XCDs
+        tau0 = blockIdx.x;
+        step = (int)nb;
+        ntiles = tau0 < a.total_tiles ? (int)((a.total_tiles - tau0 + nb - 1) / nb) : 0;
+      } else if (a.interleave == 2) {   // all workgroups side by side; an XCD holds 32 neighbouring tiles of every 256
         const int64_t q = nb / 8, r = nb % 8;
         tau0 = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
         step = (int)nb;
@@ -398,6 +416,7 @@ struct TileWalk {
       int64_t tau_end;
       block_to_range(a, tau0, tau_end);
       step = 1;
+      group = 1;
       ntiles = (int)(tau_end - tau0);
     }
     if (ntiles <= 0) return;
@@ -409,10 +428,11 @@ struct TileWalk {
     step_clips = step / a.tiles_per_clip;
     step_tiles = step % a.tiles_per_clip;
   }
-  // the tile after the current one
-  __device__ __forceinline__ void peek(const FastArgs &a, int &ftn, const float *&xn, float *&on) const {
-    ftn = ft + step_tiles;
-    int dclip = step_clips;
+  // the tile after the current one (`it` = tiles already taken by this workgroup before the current one)
+  __device__ __forceinline__ void peek(const FastArgs &a, int it, int &ftn, const float *&xn, float *&on) const {
+    const bool big = ((it + 1) & (group - 1)) == 0;   // group = 1: always
+    ftn = ft + (big ? step_tiles : 1);
+    int dclip = big ? step_clips : 0;
     if (ftn >= a.tiles_per_clip) {
       ftn -= a.tiles_per_clip;
       ++dclip;
@@ -427,7 +447,8 @@ struct TileWalk {
 // the power kernel uses them to trickle out the previous tile's stores.
 // PRE: each twiddle table is read from LDS one stage before it is used (30 more live registers),
 // so its latency -- long when 16 waves queue on the LDS pipe -- hides behind the stage in between.
-template <bool SQUARE, bool LDSX, bool PRE SMX_ABL_PARAM, class Hook>
+// CPLX: the spectrum itself goes to the tile (real parts in `tile`, imaginary parts in the plane after it).
+template <bool SQUARE, bool LDSX, bool PRE, bool CPLX SMX_ABL_PARAM, class Hook>
 __device__ __forceinline__ void frame_to_tile(const FastArgs &a, const LaneConst &L, float2 (&raw)[16],
                                               float *tile, int wave, int lane, const Hook &hook) {
   c32 v[16];
@@ -560,9 +581,14 @@ __device__ __forceinline__ void frame_to_tile(const FastArgs &a, const LaneConst
     const c32 d = {v[q].x - px, v[q].y + py};
     const float tr = e.x + w.x * d.y + w.y * d.x;
     const float ti = e.y - w.x * d.x + w.y * d.y;
-    float pw = tr * tr + ti * ti;
-    if constexpr (!SQUARE) pw = a.pmode == 1 ? sqrtf(pw) : __powf(pw, a.half_power);
-    col[(L.tile_row0 + 64 * q) * kTileStride] = pw;
+    if constexpr (CPLX) {
+      col[(L.tile_row0 + 64 * q) * kTileStride] = tr;
+      col[(L.tile_row0 + 64 * q) * kTileStride + kTileBytes / sizeof(float)] = ti;
+    } else {
+      float pw = tr * tr + ti * ti;
+      if constexpr (!SQUARE) pw = a.pmode == 1 ? sqrtf(pw) : __powf(pw, a.half_power);
+      col[(L.tile_row0 + 64 * q) * kTileStride] = pw;
+    }
   };
   if constexpr (PRE) {
     // all 32 lane exchanges in flight before the first result is needed
@@ -594,8 +620,11 @@ __device__ __forceinline__ void frame_to_tile(const FastArgs &a, const LaneConst
     }
   }
   if (lane == 0) {
-    float pw = nyq * nyq;
-    if constexpr (!SQUARE) pw = a.pmode == 1 ? fabsf(nyq) : __powf(pw, a.half_power);
+    float pw = nyq;                       // CPLX: X[M] is real
+    if constexpr (!CPLX) {
+      pw = nyq * nyq;
+      if constexpr (!SQUARE) pw = a.pmode == 1 ? fabsf(nyq) : __powf(pw, a.half_power);
+    }
     tile[nyquist_row<LDSX>(wave) * kTileStride + kFT] = pw;   // Nyquist bin of frame `wave`: a pad slot
   }
 }
@@ -722,7 +751,7 @@ __global__ void __launch_bounds__(1024) stft2048_power_kernel(FastArgs a) {
     int ftnext;
     const float *xnext;
     float *onext;
-    tw.peek(a, ftnext, xnext, onext);
+    tw.peek(a, it, ftnext, xnext, onext);
     bool have_next;
     const float *src = frame_ptr(it + 1 < ntiles ? xnext : tw.xclip, it + 1 < ntiles ? ftnext : tw.ft, have_next);
     have_next = have_next && it + 1 < ntiles;
@@ -733,7 +762,7 @@ __global__ void __launch_bounds__(1024) stft2048_power_kernel(FastArgs a) {
 #else
       const SyncHook<ALIGNED SMX_ABL_ARG> hook{a, cnt.drained + b, 16u * ((unsigned)it >> 1), src, lane};
 #endif
-      frame_to_tile<SQUARE, LDSX, kPre SMX_ABL_ARG>(a, L, raw, lds.tiles + b * kTileFloats, wave, lane, hook);
+      frame_to_tile<SQUARE, LDSX, kPre, false SMX_ABL_ARG>(a, L, raw, lds.tiles + b * kTileFloats, wave, lane, hook);
     } else if constexpr (kEarlyPrefetch) {
       prefetch_frame<ALIGNED SMX_ABL_ARG>(a, src, lane, raw);
     }
@@ -757,6 +786,128 @@ __global__ void __launch_bounds__(1024) stft2048_power_kernel(FastArgs a) {
   if (lane == 0 && blockIdx.x < 4096)
     for (int i = 0; i < kStampSlots; ++i) g_stamp_sums[(blockIdx.x * 16 + wave) * kStampSlots + i] = stamp_sum[i];
 #endif
+}
+
+// ---- complex spectrum kernel (Stft.transform / transform_range, stft.ml:632-666) ------------------
+// Same frame pipeline; the tile holds the spectrum of 16 frames as two planes (re, im) in the space
+// of the power kernel's two buffers, so there is ONE tile: a wave stores its share of the previous
+// tile in the middle of its next FFT (after the transposes) and writes its new column at the end, which
+// leaves about half a frame of slack on either side of both counters.  A tile row leaves as 16 frames x
+// 8 bytes = one 128-byte run of out[clip][bin][frame] (interleaved re, im).
+struct CplxFlushLane {
+  int row0;          // tile row of instruction 0
+  unsigned goff0;    // byte offset of out[bin(row0)][2 g] from the tile origin
+  int g;             // frames 2 g, 2 g + 1
+};
+__device__ __forceinline__ void cplx_flush(const FastArgs &a, const float *re, int wave, int lane,
+                                           const CplxFlushLane &fl, float *obase, int frames_left) {
+  const float *im = re + kTileBytes / sizeof(float);
+  const int fleft = frames_left - 2 * fl.g;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    // rows advance by 4 per instruction inside a 32-row block: bin(row + 4) = bin + 1, bin(row + 32) = bin + 8
+    const int row = fl.row0 + 32 * (i >> 2) + 4 * (i & 3);
+    const float *pr = re + row * kTileStride + 2 * fl.g, *pi = im + row * kTileStride + 2 * fl.g;
+    const float r0 = pr[0], r1 = pr[1], i0 = pi[0], i1 = pi[1];
+    const unsigned goff = fl.goff0 + (unsigned)((i & 3) + 8 * (i >> 2)) * (unsigned)a.out_stride * 8u;
+    if (fleft >= 2) {
+      store4_unaligned(obase, goff, r0, i0, r1, i1);
+    } else if (fleft == 1) {
+      float *dst = reinterpret_cast<float *>(reinterpret_cast<char *>(obase) + goff);
+      dst[0] = r0;
+      dst[1] = i0;
+    }
+  }
+  if (wave == 0 && lane < 16 && lane < frames_left) {   // bin 1024: real
+    float *dst = obase + ((int64_t)kM * a.out_stride + lane) * 2;
+    dst[0] = re[nyquist_row<false>(lane) * kTileStride + kFT];
+    dst[1] = 0.0f;
+  }
+}
+
+template <bool ALIGNED>
+struct CplxHook {
+  const FastArgs &a;
+  unsigned *filled, *drained;
+  unsigned tiles_before;     // tiles this workgroup has completed before the current one
+  const float *tile;
+  const CplxFlushLane &fl;
+  float *pout;
+  int pleft, wave, lane;
+  __device__ __forceinline__ void flush_previous() const {
+    if (tiles_before == 0) return;
+    lds_wait(filled, 16u * tiles_before);
+    cplx_flush(a, tile, wave, lane, fl, pout, pleft);
+    lds_signal(drained, lane);
+  }
+  template <int P>
+  __device__ __forceinline__ void at() const {
+    if constexpr (P == 5) flush_previous();
+  }
+  __device__ __forceinline__ void ready() const { lds_wait(drained, 16u * tiles_before); }
+  __device__ __forceinline__ void after_window(float2 (&)[16]) const {}
+};
+
+template <bool ALIGNED, bool STRIP>
+__global__ void __launch_bounds__(1024) stft2048_complex_kernel(FastArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const Lds lds = carve_lds(smem);
+  const LaneConst L = setup_lane(a, lds, tid, lane, wave);
+  unsigned *const c_filled = reinterpret_cast<unsigned *>(lds.tabB), *const c_drained = c_filled + 1;
+  TileWalk tw;
+  tw.init(a, a.out + 2 * a.out_offset, 2 * kBins * a.out_stride);
+  if (tw.ntiles <= 0) return;   // uniform for the workgroup
+  const int ntiles = tw.ntiles;
+  auto frame_ptr = [&](const float *xc, int t, bool &hv) {
+    const int64_t f0 = (int64_t)t * kFT;
+    hv = f0 + wave < a.count;
+    return xc + ((a.p0 + f0 + (hv ? wave : 0)) * a.hop - a.left);
+  };
+  float2 raw[16];
+  bool have;
+  load_frame<ALIGNED>(frame_ptr(tw.xclip, tw.ft, have), lane, raw);
+  __syncthreads();   // tables and zeroed counters visible
+  CplxFlushLane fl;
+  {
+    // one store = 8 rows x 128 bytes; rows {0, 1, 16, 17} (+2 for the upper half-wave) keep the four
+    // LDS reads of a lane conflict free at row stride 17
+    const int half = lane >> 5, ridx = (lane & 31) >> 3;
+    fl.g = lane & 7;
+    fl.row0 = 64 * wave + (ridx & 1) + 16 * (ridx >> 1) + 2 * half;
+    const int bin0 = (fl.row0 & 3) * 256 + (fl.row0 >> 2);
+    fl.goff0 = ((unsigned)bin0 * (unsigned)a.out_stride + 2u * fl.g) * 8u;
+  }
+  float *pend_out = nullptr;
+  int pend_left = 0;
+  for (int it = 0; it < ntiles; ++it) {
+    const CplxHook<ALIGNED> hook{a, c_filled, c_drained, (unsigned)it, lds.tiles, fl, pend_out, pend_left, wave, lane};
+    if (have) {
+      frame_to_tile<true, false, false, true SMX_ABL_ZERO>(a, L, raw, lds.tiles, wave, lane, hook);
+    } else {
+      hook.flush_previous();
+    }
+    lds_signal(c_filled, lane);
+    int ftnext;
+    const float *xnext;
+    float *onext;
+    tw.peek(a, it, ftnext, xnext, onext);
+    bool have_next;
+    const float *src = frame_ptr(it + 1 < ntiles ? xnext : tw.xclip, it + 1 < ntiles ? ftnext : tw.ft, have_next);
+    have_next = have_next && it + 1 < ntiles;
+    load_frame<ALIGNED>(src, lane, raw);
+    pend_out = tw.oclip + 2 * tw.ft * kFT;   // wave-uniform
+    const int64_t left = a.count - (int64_t)tw.ft * kFT;
+    pend_left = left < kFT ? (int)left : kFT;
+    have = have_next;
+    tw.xclip = xnext;
+    tw.oclip = onext;
+    tw.ft = ftnext;
+  }
+  lds_wait(c_filled, 16u * (unsigned)ntiles);
+  cplx_flush(a, lds.tiles, wave, lane, fl, pend_out, pend_left);
 }
 
 // ---- fused audio -> mel kernel -------------------------------------------------------------------
@@ -937,13 +1088,13 @@ __global__ void __launch_bounds__(1024) stft2048_mel_kernel(FastArgs a, MelFused
     float *tprev = lds.tiles + (b ^ 1) * kTileFloats;
     if (t < ntiles) {
       // every MFMA read of tile t-2 (same buffer) must be over before the powers of tile t land
-      if (have) frame_to_tile<SQUARE, false, false SMX_ABL_ZERO>(a, L, raw, tcur, wave, lane,
+      if (have) frame_to_tile<SQUARE, false, false, false SMX_ABL_ZERO>(a, L, raw, tcur, wave, lane,
                                                                ReadyHook{c_mdone + b, t >= 2 ? nth(t - 2) : 0u});
       lds_signal(c_filled + b, lane);
       int ftnext;
       const float *xnext;
       float *onext;
-      tw.peek(a, ftnext, xnext, onext);
+      tw.peek(a, t, ftnext, xnext, onext);
       bool have_next;
       const float *src = frame_ptr(t + 1 < ntiles ? xnext : tw.xclip, t + 1 < ntiles ? ftnext : tw.ft, have_next);
       have_next = have_next && t + 1 < ntiles;
@@ -1016,6 +1167,7 @@ struct FastTarget {
   int64_t out_stride = 0;       // frames dimension of the output
   int64_t out_offset = 0;       // frame offset of this job's first frame
   const MelFusedArgs *mel = nullptr;
+  bool complex_out = false;     // Stft.transform: interleaved (re, im)
 };
 
 // one launch of the fused kernel over frames that all lie inside [0, n)
@@ -1079,6 +1231,15 @@ void launch_interior(const StftJob &job, const FastTarget &tg, const float *x, i
     SMX_HIP_CHECK(hipGetLastError());
     return;
   }
+  if (tg.complex_out) {
+    auto kernel = strip ? (aligned ? stft2048_complex_kernel<true, true> : stft2048_complex_kernel<false, true>)
+                        : (aligned ? stft2048_complex_kernel<true, false> : stft2048_complex_kernel<false, false>);
+    SMX_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kernel),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)kFastLds));
+    hipLaunchKernelGGL(kernel, dim3((unsigned)a.blocks), dim3(1024), kFastLds, job.stream, a);
+    SMX_HIP_CHECK(hipGetLastError());
+    return;
+  }
 #ifdef SMX_DIAG
   const char *abl_env = std::getenv("SMX_ABLATE");
   const int abl = abl_env ? std::atoi(abl_env) : 0;
@@ -1129,7 +1290,6 @@ bool fast_eligible(const StftJob &job) {
   const smx_stft_config &c = *job.cfg;
   if (fast_path_disabled()) return false;
   if (c.fft_size != kN || job.in_bytes != 4 || job.interior != SMX_INTERIOR_F32) return false;
-  if (job.mode != OUT_POWER) return false;
   if (job.lead > 65535) return false;
   return true;
 }
@@ -1164,8 +1324,10 @@ extern "C" int smx_debug_read_stamps(unsigned long long *out, int count) {
 bool launch_stft_fast(const StftJob &job) {
   if (!fast_eligible(job)) return false;
   if (job.count <= 0 || job.lead <= 0) return true;
-  if ((int64_t)kBins * job.out_stride * 4 >= (int64_t(1) << 32)) return false;   // 32-bit row offsets
+  const int64_t elem = job.mode == OUT_COMPLEX ? 8 : 4;
+  if ((int64_t)kBins * job.out_stride * elem >= (int64_t(1) << 32)) return false;   // 32-bit row offsets
   FastTarget tg;
+  tg.complex_out = job.mode == OUT_COMPLEX;
   tg.out = job.out;
   tg.out_stride = job.out_stride;
   tg.out_offset = job.out_offset;

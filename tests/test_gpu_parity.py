@@ -153,6 +153,25 @@ def test_power_spectrum_vs_oracle(fft, hop, n, lead, power):
         check_fast(got[i], want[i], "clip %d" % i)
 
 
+@pytest.mark.parametrize("hop,n,lead", [(512, 480000, 2), (512, 5000, 3), (512, 16 * 512 * 3 + 17, 2), (500, 30000, 2),
+                                        (511, 30000, 2)])
+def test_transform_float32_vs_oracle(hop, n, lead):
+    """Stft.transform on float32 audio at fft 2048 (the fused complex-spectrum kernel): real and imaginary
+    parts against the float64 oracle, every frame including the reflected borders and the ragged last tile."""
+    rng = np.random.default_rng(hop + n)
+    x = rng.uniform(-1, 1, size=(lead, n)).astype(np.float32)
+    c = Stft.Config.create(fft_size=2048, hop=hop)
+    got = Stft.transform(c, x)
+    want = O.transform(O.stft_config(2048, hop=hop), x)
+    assert got.shape == want.shape and got.dtype == np.complex64
+    for i in range(lead):
+        check_fast(got[i].real, want[i].real, "re clip %d" % i)
+        check_fast(got[i].imag, want[i].imag, "im clip %d" % i)
+    # and it is the spectrum whose squared magnitude power_spectrum returns
+    pw = Stft.power_spectrum(c, x)
+    check_fast(pw, np.abs(got.astype(np.complex128)) ** 2, "power vs |transform|^2")
+
+
 @pytest.mark.parametrize("alignment", ["centered", "left", "right"])
 @pytest.mark.parametrize("pad", ["reflect", "edge", ("constant", 0.25)])
 @pytest.mark.parametrize("fft,hop", [(2048, 512), (64, 16), (16, 20), (31, 5)])
