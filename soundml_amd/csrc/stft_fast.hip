@@ -295,6 +295,7 @@ struct LaneConst {
   int addr_g, addr_0;       // ds_bpermute byte addresses of the post-pass partner lane
   int tile_row0;            // tile row of register q is tile_row0 + 64 q
   const float2 *tabA_l, *winL_l, *tabP_l, *tabB_l;
+  const float2 *tabP_g;     // the same twiddles in global memory: exp(-2 pi i k / N), k = k1 + 256 r + 16 q
 };
 
 struct Lds {
@@ -314,6 +315,7 @@ __device__ __forceinline__ Lds carve_lds(unsigned char *smem) {
 
 // Fills the workgroup-shared LDS tables (wave w writes row w of each) and returns this lane's constants.
 // The caller must __syncthreads() before the tables are read.
+template <bool FILL_TABP = true>
 __device__ __forceinline__ LaneConst setup_lane(const FastArgs &a, const Lds &lds, int tid, int lane, int wave) {
   LaneConst L;
   L.k1 = lane >> 2;
@@ -321,7 +323,8 @@ __device__ __forceinline__ LaneConst setup_lane(const FastArgs &a, const Lds &ld
   L.r = ((L.qa & 1) << 1) | (L.qa >> 1);
   if (wave > 0) lds.tabA[(wave - 1) * 64 + lane] = a.w_m[lane * wave];          // W_M^(l k1), k1 = wave
   lds.winL[tid] = reinterpret_cast<const float2 *>(a.hwin)[tid];                // the whole window, once per workgroup
-  lds.tabP[wave * 64 + lane] = a.w_n[L.k1 + 256 * L.r + 16 * wave];             // exp(-2 pi i k / N), k = k1 + 16 q + 256 r
+  if constexpr (FILL_TABP) lds.tabP[wave * 64 + lane] = a.w_n[L.k1 + 256 * L.r + 16 * wave];   // exp(-2 pi i k / N), k = k1 + 16 q + 256 r
+  L.tabP_g = a.w_n + L.k1 + 256 * L.r;
   if (lane < 4) {
     // row q = 0 (all ones) is never read: it holds the power kernel's synchronisation counters
     if (wave > 0) {                                                             // s1 s2 W_64^(a q), a = lane
@@ -448,7 +451,9 @@ struct TileWalk {
 // PRE: each twiddle table is read from LDS one stage before it is used (30 more live registers),
 // so its latency -- long when 16 waves queue on the LDS pipe -- hides behind the stage in between.
 // CPLX: the spectrum itself goes to the tile (real parts in `tile`, imaginary parts in the plane after it).
-template <bool SQUARE, bool LDSX, bool PRE, bool CPLX SMX_ABL_PARAM, class Hook>
+// TABPG: the post-pass twiddles come from global memory (a.w_n, L2 resident), requested before stage C,
+//        for the kernel that uses the LDS space of that table for something else (mel).
+template <bool SQUARE, bool LDSX, bool PRE, bool CPLX, bool TABPG SMX_ABL_PARAM, class Hook>
 __device__ __forceinline__ void frame_to_tile(const FastArgs &a, const LaneConst &L, float2 (&raw)[16],
                                               float *tile, int wave, int lane, const Hook &hook) {
   c32 v[16];
@@ -538,7 +543,10 @@ __device__ __forceinline__ void frame_to_tile(const FastArgs &a, const LaneConst
     const float2 wb = PRE ? tw[q] : L.tabB_l[4 * q];
     v[q] = cmul(v[q], c32{wb.x, wb.y});
   }
-  if constexpr (PRE) {
+  if constexpr (TABPG) {
+#pragma unroll
+    for (int q = 0; q < 16; ++q) tw[q] = L.tabP_g[16 * q];
+  } else if constexpr (PRE) {
 #pragma unroll
     for (int q = 0; q < 16; ++q) tw[q] = L.tabP_l[64 * q];
   }
@@ -609,7 +617,7 @@ __device__ __forceinline__ void frame_to_tile(const FastArgs &a, const LaneConst
     for (int q = 0; q < 16; ++q) {
       float px, py;
       partner(q, px, py);
-      finish_bin(q, px, py, L.tabP_l[64 * q]);
+      finish_bin(q, px, py, TABPG ? tw[q] : L.tabP_l[64 * q]);
       if ((q & 3) == 3) {
         SMX_FENCE();
         if (q == 3) hook.template at<11>();
@@ -762,7 +770,7 @@ __global__ void __launch_bounds__(1024) stft2048_power_kernel(FastArgs a) {
 #else
       const SyncHook<ALIGNED SMX_ABL_ARG> hook{a, cnt.drained + b, 16u * ((unsigned)it >> 1), src, lane};
 #endif
-      frame_to_tile<SQUARE, LDSX, kPre, false SMX_ABL_ARG>(a, L, raw, lds.tiles + b * kTileFloats, wave, lane, hook);
+      frame_to_tile<SQUARE, LDSX, kPre, false, false SMX_ABL_ARG>(a, L, raw, lds.tiles + b * kTileFloats, wave, lane, hook);
     } else if constexpr (kEarlyPrefetch) {
       prefetch_frame<ALIGNED SMX_ABL_ARG>(a, src, lane, raw);
     }
@@ -885,7 +893,7 @@ __global__ void __launch_bounds__(1024) stft2048_complex_kernel(FastArgs a) {
   for (int it = 0; it < ntiles; ++it) {
     const CplxHook<ALIGNED> hook{a, c_filled, c_drained, (unsigned)it, lds.tiles, fl, pend_out, pend_left, wave, lane};
     if (have) {
-      frame_to_tile<true, false, false, true SMX_ABL_ZERO>(a, L, raw, lds.tiles, wave, lane, hook);
+      frame_to_tile<true, false, false, true, false SMX_ABL_ZERO>(a, L, raw, lds.tiles, wave, lane, hook);
     } else {
       hook.flush_previous();
     }
@@ -924,19 +932,24 @@ __global__ void __launch_bounds__(1024) stft2048_complex_kernel(FastArgs a) {
 // tile t-1 | every wave computes its frame of tile t.
 using f32x4v = __attribute__((ext_vector_type(4))) float;
 
+// Partial 16x16 sums travel from helper to owner through LDS: slots 0-2 in the pad column of the tile's
+// own buffer, slots 3-6 in the space of the post-pass twiddle table (which this kernel reads from global
+// memory instead), one set per buffer parity.
+constexpr int kMelHelpers = 7, kMelPadSlots = 3, kMelMaxSteps = 24;
 struct MelItem {          // one per wave; wave-uniform, read through scalar loads
   int block;              // 16-mel block index
   int k4_begin, k4_count; // MFMA steps: bins [4 k4_begin, 4 (k4_begin + k4_count))
   int a_offset;           // offset (in 64-float rows) of this item's A operands in w_mfma
-  int slot;               // helper: partial slot 0..2; owner / idle: -1
+  int slot;               // helper: partial slot 0..7; owner / idle: -1
   int owner;              // 1: this wave stores the block's result
   int nslots;             // owner: number of helper partials to add
-  int slots[3];
+  int slots[kMelHelpers];
 };
 
 struct MelFusedArgs {
   const MelItem *items;   // [16]
   const float *w_mfma;    // [rows][64]: A operand of MFMA step i of an item, in lane order
+  float *scratch;         // per workgroup: partial-sum records of helper slots >= kMelPadSlots
   float *out;             // [lead; n_mels; out_stride]
   int64_t out_stride, out_offset;
   int n_mels;
@@ -970,16 +983,35 @@ __global__ void __launch_bounds__(1024) stft2048_mel_kernel(FastArgs a, MelFused
   tw.init(a, m.out + m.out_offset, (int64_t)m.n_mels * m.out_stride);
   if (tw.ntiles <= 0) return;                  // uniform for the workgroup
   const int ntiles = tw.ntiles;
-  MelItem item = m.items[wave];                // wave-uniform: force every field into SGPRs
-  item.block = __builtin_amdgcn_readfirstlane(item.block);
-  item.k4_begin = __builtin_amdgcn_readfirstlane(item.k4_begin);
-  item.k4_count = __builtin_amdgcn_readfirstlane(item.k4_count);
-  item.a_offset = __builtin_amdgcn_readfirstlane(item.a_offset);
-  item.slot = __builtin_amdgcn_readfirstlane(item.slot);
-  item.owner = __builtin_amdgcn_readfirstlane(item.owner);
-  item.nslots = __builtin_amdgcn_readfirstlane(item.nslots);
+  // This wave's item, every field in an SGPR.  (Only static indices below: a dynamically indexed copy of the
+  // struct would live in scratch memory and come back as vector values.)
+  struct {
+    int block, k4_begin, k4_count, a_offset, slot, owner, nslots, slots[kMelHelpers];
+  } item;
+  {
+    const MelItem *src = m.items + wave;
+    item.block = __builtin_amdgcn_readfirstlane(src->block);
+    item.k4_begin = __builtin_amdgcn_readfirstlane(src->k4_begin);
+    item.k4_count = __builtin_amdgcn_readfirstlane(src->k4_count);
+    item.a_offset = __builtin_amdgcn_readfirstlane(src->a_offset);
+    item.slot = __builtin_amdgcn_readfirstlane(src->slot);
+    item.owner = __builtin_amdgcn_readfirstlane(src->owner);
+    item.nslots = __builtin_amdgcn_readfirstlane(src->nslots);
 #pragma unroll
-  for (int i = 0; i < 3; ++i) item.slots[i] = __builtin_amdgcn_readfirstlane(item.slots[i]);
+    for (int i = 0; i < kMelHelpers; ++i) item.slots[i] = __builtin_amdgcn_readfirstlane(src->slots[i]);
+  }
+  // This wave's A operands (filterbank weights of its item in MFMA lane order) stay in registers for the
+  // whole kernel: they are the same for every tile.  Rows past the item belong to the next items or to
+  // the table's zero padding and are never multiplied.
+  float aw[kMelMaxSteps];
+  {
+    const float *abase = m.w_mfma + (int64_t)item.a_offset * 64;    // wave-uniform
+#pragma unroll
+    for (int j = 0; j < kMelMaxSteps; ++j) {
+      const float w = abase[(unsigned)lane + 64u * (unsigned)j];
+      aw[j] = j < item.k4_count ? w : 0.0f;   // steps past the item multiply by zero
+    }
+  }
 
   auto frame_ptr = [&](const float *xc, int t, bool &hv) {
     const int64_t f0 = (int64_t)t * kFT;
@@ -1003,14 +1035,47 @@ __global__ void __launch_bounds__(1024) stft2048_mel_kernel(FastArgs a, MelFused
   unsigned *const c_mdone = c_filled + 2, *const c_fin = c_filled + 4;
   auto nth = [](int tile) { return 16u * (((unsigned)tile >> 1) + 1u); };   // counter value once tile `tile` is through
 
+  // Partial slot sl of the tile in buffer `buf` (parity `par`).  Slots 0-2 are in LDS (pad column of the
+  // tile's buffer); further slots are 1 KB records of this workgroup in global memory (L2): one 16-byte
+  // store per helper lane, read back by the owner (same CU, same L1: workgroup scope) an iteration later.
+  float *const gslots = m.scratch + (int64_t)blockIdx.x * (2 * (kMelHelpers - kMelPadSlots) * 256);
+  auto put_partial = [&](float *buf, int par, int sl, f32x4v acc) {
+    if (sl < kMelPadSlots) {
+      float *pp = buf + pad_lane + (256 * sl) * kTileStride;
+#pragma unroll
+      for (int reg = 0; reg < 4; ++reg) pp[(64 * reg) * kTileStride] = acc[reg];
+    } else {
+      float *g = gslots + (((kMelHelpers - kMelPadSlots) * par + (sl - kMelPadSlots)) * 64 + lane) * 4;
+#pragma unroll
+      for (int reg = 0; reg < 4; ++reg)
+        __hip_atomic_store(g + reg, acc[reg], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");   // complete before this wave signals mdone
+    }
+  };
+  auto get_partial = [&](const float *buf, int par, int sl) -> f32x4v {
+    f32x4v v;
+    if (sl < kMelPadSlots) {
+      const float *pp = buf + pad_lane + (256 * sl) * kTileStride;
+#pragma unroll
+      for (int reg = 0; reg < 4; ++reg) v[reg] = pp[(64 * reg) * kTileStride];
+    } else {
+      const float *g = gslots + (((kMelHelpers - kMelPadSlots) * par + (sl - kMelPadSlots)) * 64 + lane) * 4;
+#pragma unroll
+      for (int reg = 0; reg < 4; ++reg) v[reg] = __hip_atomic_load(g + reg, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
+    return v;
+  };
   // (A) owner: finish the tile whose MFMA partials were produced one iteration ago
-  auto finish = [&](const float *buf, float *obase, int64_t frames_left) {
+  auto finish = [&](float *buf, int par, float *obase, int64_t frames_left) {
     if (!item.owner) return;
     f32x4v total = acc_prev;
-    for (int s = 0; s < item.nslots; ++s) {
-      const float *pp = buf + pad_lane + (256 * item.slots[s]) * kTileStride;
 #pragma unroll
-      for (int reg = 0; reg < 4; ++reg) total[reg] += pp[(64 * reg) * kTileStride];
+    for (int s = 0; s < kMelHelpers; ++s) {   // fixed order: the sum does not depend on timing
+      if (s < item.nslots) {
+        const f32x4v part = get_partial(buf, par, item.slots[s]);
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) total[reg] += part[reg];
+      }
     }
     const int f = lane & 15;
     if (f < frames_left) {
@@ -1021,61 +1086,49 @@ __global__ void __launch_bounds__(1024) stft2048_mel_kernel(FastArgs a, MelFused
       }
     }
   };
-  // (B) every wave: its MFMA item over the finished tile in `buf`, BEFORE its own FFT so that the
-  // MFMA operands and the FFT state are never live together (the kernel sits at the 128-VGPR cap).
-  // A operands arrive 16 steps at a time (SGPR base + lane offset), the next chunk is in flight
-  // while the current one is multiplied; B comes from the tile in LDS.
-  auto mfma_item = [&](float *buf) {
+  // (B) every wave: its MFMA item over the finished tile in `buf`: A from registers, B from the tile.
+  // Tile rows advance by 16 per step (4 bins); an item spans at most 128 bins, so it crosses a 256-bin
+  // block boundary (where the row index wraps) at most once: two lane bases, chosen per step by a scalar.
+  const int kk = lane >> 4, fcol = lane & 15;
+  const int kabs0 = 4 * item.k4_begin + kk;
+  const int cross = (256 - ((4 * item.k4_begin) & 255)) >> 2;                 // first step of the next block (scalar)
+  const int boff0 = (4 * (kabs0 & 255) + (kabs0 >> 8)) * kTileStride + fcol;
+  constexpr int kWrap = (4 * 256 - 1) * kTileStride;                          // after the wrap: row - 1023
+  const bool touches_end = 4 * (item.k4_begin + item.k4_count) > kM;          // the item of bins >= 1024 (scalar)
+  auto mfma_item = [&](float *buf, int par) {
     if (item.k4_count <= 0) return;
     f32x4v acc = {0.f, 0.f, 0.f, 0.f};
-    const float *abase = m.w_mfma + (int64_t)item.a_offset * 64;    // wave-uniform
-    const unsigned lane_u = (unsigned)lane;
-    const int kk = lane >> 4, f = lane & 15;
-    float av[16], an[16];
-    auto load_chunk = [&](int c, float (&dst)[16]) {
-      const float *cb = abase + (int64_t)c * 16 * 64;
+    // Steps in groups of 4; inside the last group, steps past the item have zero weights and re-read the
+    // item's last rows.  One lane base that changes with the buffer (so the per-step addresses are formed
+    // here, one add each, instead of living in registers across the FFT) plus a scalar offset per step.
+    // Two accumulators halve the dependent MFMA chain; they are added in a fixed order.
+    const float *bp = buf + boff0;
+    const float nyq = buf[fcol * kTileStride + kFT];
+    f32x4v acc1 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-      for (int j = 0; j < 16; ++j)
-        if (16 * c + j < item.k4_count) dst[j] = cb[lane_u + 64u * j];
-    };
+    for (int g = 0; g < kMelMaxSteps; g += 4) {   // groups of 4 steps; whole groups past the item are skipped (scalar branch)
+      if (g < item.k4_count) {
+        float bv[4];
 #pragma unroll
-    for (int j = 0; j < 16; ++j) av[j] = an[j] = 0.0f;
-    const int chunks = (item.k4_count + 15) >> 4;
-    load_chunk(0, av);
-    for (int c = 0; c < chunks; ++c) {
-      if (c + 1 < chunks) load_chunk(c + 1, an);
-      const int k4c = item.k4_begin + 16 * c;                 // first MFMA step of this chunk (scalar)
-      if (((4 * k4c) & 255) <= 192) {
-        // fast path: the chunk's 64 bins stay inside one 256-bin block (and below the Nyquist bin),
-        // so tile rows advance by 16 per step: one base address, immediate offsets
-        const int kabs0 = 4 * k4c + kk;
-        const float *bp = buf + (4 * (kabs0 & 255) + (kabs0 >> 8)) * kTileStride + f;
-#pragma unroll
-        for (int j = 0; j < 16; ++j)
-          if (16 * c + j < item.k4_count)
-            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[j], bp[16 * kTileStride * j], acc, 0, 0, 0);
-      } else {
-#pragma unroll
-        for (int j = 0; j < 16; ++j) {
-          const int step = 16 * c + j;
-          if (step < item.k4_count) {
-            const int kabs = 4 * (item.k4_begin + step) + kk;
-            const int row = 4 * (kabs & 255) + (kabs >> 8);
-            // bins 0..1023 are tile rows; the Nyquist bin of frame f sits in the pad slot of row f
-            const float b = kabs < kM ? buf[row * kTileStride + f] : (kabs == kM ? buf[f * kTileStride + kFT] : 0.0f);
-            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[j], b, acc, 0, 0, 0);
-          }
+        for (int i = 0; i < 4; ++i) {
+          const int j = g + i;
+          const int jj = j < item.k4_count ? j : item.k4_count - 1;   // scalar
+          const int sofs = __builtin_amdgcn_readfirstlane(jj < cross ? 16 * kTileStride * jj : 16 * kTileStride * jj - kWrap);
+          bv[i] = bp[sofs];
+          // bins 1024..1027: the Nyquist bin of frame f sits in the pad slot of row f, the rest do not exist
+          if (touches_end && jj == item.k4_count - 1) bv[i] = kk == 0 ? nyq : 0.0f;
         }
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(aw[g], bv[0], acc, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(aw[g + 1], bv[1], acc1, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(aw[g + 2], bv[2], acc, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(aw[g + 3], bv[3], acc1, 0, 0, 0);
       }
-#pragma unroll
-      for (int j = 0; j < 16; ++j) av[j] = an[j];
     }
+    acc += acc1;
     if (item.owner) {
       acc_prev = acc;
     } else {
-      float *pp = buf + pad_lane + (256 * item.slot) * kTileStride;
-#pragma unroll
-      for (int reg = 0; reg < 4; ++reg) pp[(64 * reg) * kTileStride] = acc[reg];
+      put_partial(buf, par, item.slot, acc);
     }
   };
 
@@ -1088,8 +1141,10 @@ __global__ void __launch_bounds__(1024) stft2048_mel_kernel(FastArgs a, MelFused
     float *tprev = lds.tiles + (b ^ 1) * kTileFloats;
     if (t < ntiles) {
       // every MFMA read of tile t-2 (same buffer) must be over before the powers of tile t land
-      if (have) frame_to_tile<SQUARE, false, false, false SMX_ABL_ZERO>(a, L, raw, tcur, wave, lane,
-                                                               ReadyHook{c_mdone + b, t >= 2 ? nth(t - 2) : 0u});
+      if (have) {
+        frame_to_tile<SQUARE, false, false, false, false SMX_ABL_ZERO>(a, L, raw, tcur, wave, lane,
+                                                                        ReadyHook{c_mdone + b, t >= 2 ? nth(t - 2) : 0u});
+      }
       lds_signal(c_filled + b, lane);
       int ftnext;
       const float *xnext;
@@ -1108,13 +1163,13 @@ __global__ void __launch_bounds__(1024) stft2048_mel_kernel(FastArgs a, MelFused
     }
     if (t >= 2) {   // tile t-2: its partials sit in this buffer's pad column once every helper is through
       lds_wait(c_mdone + b, nth(t - 2));
-      finish(tcur, out_m2, left_m2);
+      finish(tcur, b, out_m2, left_m2);
       lds_signal(c_fin + b, lane);
     }
     if (t >= 1 && t - 1 < ntiles) {   // tile t-1
       lds_wait(c_filled + (b ^ 1), nth(t - 1));
       if (t >= 3) lds_wait(c_fin + (b ^ 1), nth(t - 3));   // the partial slots of tile t-3 have been read
-      mfma_item(tprev);
+      mfma_item(tprev, b ^ 1);
       lds_signal(c_mdone + (b ^ 1), lane);
     }
     out_m2 = out_m1;
@@ -1343,6 +1398,18 @@ bool launch_mel_spectrogram_fused(const MelSpecJob &job) {
   MelFusedArgs m{};
   m.items = reinterpret_cast<const MelItem *>(plan.items);
   m.w_mfma = plan.w_mfma;
+  // partial-sum records of the global helper slots: one set per persistent workgroup (at most one per CU),
+  // stream-ordered so that concurrent calls on other streams never share them
+  {
+    static const int cus = [] {
+      int dev = 0;
+      hipDeviceProp_t prop;
+      if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return 256;
+      return prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    }();
+    SMX_HIP_CHECK(hipMallocAsync((void **)&m.scratch, (size_t)cus * 2 * (kMelHelpers - kMelPadSlots) * 256 * sizeof(float),
+                                 job.stft.stream));
+  }
   m.out = reinterpret_cast<float *>(job.out);
   m.out_stride = job.stft.count;
   m.out_offset = 0;
@@ -1353,6 +1420,7 @@ bool launch_mel_spectrogram_fused(const MelSpecJob &job) {
   tg.out_offset = 0;
   tg.mel = &m;
   launch_ranges(job.stft, tg);
+  SMX_HIP_CHECK(hipFreeAsync(m.scratch, job.stft.stream));
   return true;
 }
 
@@ -1385,11 +1453,11 @@ const smx::MelFusedPlan &smx_mel_config::fused_plan() const {
       k4n[(size_t)b] = (hi + 3) / 4 - lo / 4;
     }
   }
-  // split the heaviest blocks in K: at most 3 helper pieces (their partials live in the tile's pad column)
+  // split the heaviest blocks in K among the waves that own no block: at most kMelHelpers helper pieces
   int total_pieces = blocks, helpers = 0;
-  while (helpers < 3 && total_pieces < 16) {
+  while (helpers < kMelHelpers && total_pieces < 16) {
     int best = -1;
-    double load = 12.0;   // not worth splitting below ~12 MFMAs per piece
+    double load = 8.0;    // not worth splitting below ~8 MFMAs per piece
     for (int b = 0; b < blocks; ++b) {
       const double l = (double)k4n[(size_t)b] / pieces[(size_t)b];
       if (l > load) { load = l; best = b; }
@@ -1434,9 +1502,11 @@ const smx::MelFusedPlan &smx_mel_config::fused_plan() const {
       begin += cnt;
     }
   }
+  for (const auto &it : items)
+    if (it.k4_count > kMelMaxSteps) return plan;   // the A operands of an item must fit its wave's registers
   if (std::getenv("SMX_MEL_NOMFMA"))   // diagnostic: plan without MFMA work (results are zeros)
     for (auto &it : items) it.k4_count = 0;
-  if (wm.empty()) wm.assign(64, 0.0f);
+  wm.resize(wm.size() + 64 * (size_t)kMelMaxSteps, 0.0f);   // every item can be read kMelMaxSteps rows deep
   SMX_HIP_CHECK(hipMalloc(&plan.items, items.size() * sizeof(MelItem)));
   SMX_HIP_CHECK(hipMemcpy(plan.items, items.data(), items.size() * sizeof(MelItem), hipMemcpyHostToDevice));
   SMX_HIP_CHECK(hipMalloc((void **)&plan.w_mfma, wm.size() * sizeof(float)));
