@@ -466,7 +466,7 @@ __device__ __forceinline__ void frame_to_tile(const FastArgs &a, const LaneConst
   }
 #pragma unroll
   for (int j = 0; j < 16; ++j) v[j] = {raw[j].x * win[j].x, raw[j].y * win[j].y};
-  if constexpr (SMX_ABL(6)) {   // timing-only: memory traffic and synchronisation without the FFT
+  if constexpr (SMX_ABL(6) || SMX_ABL(9)) {   // timing-only: memory traffic and synchronisation without the FFT (9: no loads either)
     hook.ready();
 #pragma unroll
     for (int q = 0; q < 16; ++q) (tile + wave)[(L.tile_row0 + 64 * q) * kTileStride] = v[q].x + v[q].y;
@@ -639,7 +639,7 @@ __device__ __forceinline__ void frame_to_tile(const FastArgs &a, const LaneConst
 
 template <bool ALIGNED SMX_ABL_PARAM>
 __device__ __forceinline__ void prefetch_frame(const FastArgs &a, const float *src, int lane, float2 (&raw)[16]) {
-  if constexpr (SMX_ABL(2) || SMX_ABL(3)) {
+  if constexpr (SMX_ABL(2) || SMX_ABL(3) || SMX_ABL(9)) {
 #pragma unroll
     for (int j = 0; j < 16; ++j) raw[j] = make_float2((float)(lane + j) + raw[j].x * 0.0f, (float)(lane - j));
   } else {
@@ -1298,13 +1298,14 @@ void launch_interior(const StftJob &job, const FastTarget &tg, const float *x, i
 #ifdef SMX_DIAG
   const char *abl_env = std::getenv("SMX_ABLATE");
   const int abl = abl_env ? std::atoi(abl_env) : 0;
-  a.abl_nostore = (abl == 1 || abl == 3 || abl == 7) ? 1 : (abl == 8 || abl == 9) ? 2 : 0;
+  a.abl_nostore = (abl == 1 || abl == 3 || abl == 7) ? 1 : abl == 8 ? 2 : 0;
   if (const char *w = std::getenv("SMX_ABL_RUN")) a.abl_nostore = std::atoi(w);   // 2: 128 B, 3: 256 B, 4: 512 B runs
   auto kernel = abl == 2 ? stft2048_power_kernel<true, true, false, kLdsX, 2>
               : abl == 3 ? stft2048_power_kernel<true, true, false, kLdsX, 3>
               : abl == 4 ? stft2048_power_kernel<true, true, false, kLdsX, 4>
               : abl == 5 ? stft2048_power_kernel<true, true, false, kLdsX, 5>
               : (abl == 6 || abl == 7 || abl == 8) ? stft2048_power_kernel<true, true, false, kLdsX, 6>
+              : abl == 9 ? stft2048_power_kernel<true, true, false, kLdsX, 9>
                          : stft2048_power_kernel<true, true, false, kLdsX, 0>;
   (void)aligned; (void)square; (void)strip;
 #else
