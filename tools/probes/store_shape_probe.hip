@@ -1,7 +1,8 @@
 // Probe: cost of the spectrogram's scattered row-run stores by themselves (diagnostic, not part of the library).
 // out[clip][1025][pitch] floats; a "tile" = RUN frames (RUN*4 bytes per row) x 1024 rows, written by one workgroup
 // of 16 waves with global_store_dwordx4 (RUN/4 lanes per row).  Tiles are dealt to workgroups either round robin
-// (mode 0: neighbours on different XCDs) or XCD-contiguous (mode 2: 32 neighbouring tiles per XCD at a time).
+// (mode 0: neighbours on different XCDs), XCD-contiguous (mode 2: 32 neighbouring tiles per XCD at a time) or as
+// one contiguous range per workgroup (mode 1).
 //   ./store_shape_probe <run frames: 16|32|64|128> <pitch floats> <mode 0|2> [shift floats]
 // Build: hipcc -O3 --offload-arch=gfx950 -o store_shape_probe store_shape_probe.hip
 #include <hip/hip_runtime.h>
@@ -19,7 +20,11 @@ __global__ void __launch_bounds__(1024) k(float *out, long pitch_f, long total_t
   const long tpc = pitch_f / RUN;
   constexpr int LPR = RUN / 4;             // lanes per row (16 bytes each)
   constexpr int RPI = 64 / LPR;            // rows per instruction
-  for (long g = vb; g < total_tiles; g += nb) {
+  // mode 1: every workgroup walks its own contiguous range of tiles (its own clips), one after the other
+  const long per = (total_tiles + nb - 1) / nb;
+  const long g0 = mode == 1 ? vb * per : vb, g1 = mode == 1 ? (g0 + per < total_tiles ? g0 + per : total_tiles) : total_tiles;
+  const long gs = mode == 1 ? 1 : nb;
+  for (long g = g0; g < g1; g += gs) {
     float *base = out + (g / tpc) * 1025 * pitch_f + RUN * (g % tpc) + shift;
     for (int i = 0; i < 64 / RPI; ++i) {   // 64 rows per wave
       const int row = 64 * wave + RPI * i + lane / LPR;
