@@ -190,6 +190,24 @@ int smx_mel_spectrogram_f32_dev(const smx_stft_config *sc, const smx_mel_config 
                                 const float *d_x, int64_t lead, int64_t n, int64_t x_stride,
                                 double power, float *d_out, void *stream);
 
+/* ---- Least-squares synthesis: Stft.invert (stft.ml:902-939, stft.mli "invert") --------------------
+ * x[m] = (sum_p w[m - p hop] irfft(Z[:, p])[m - p hop]) / (sum_p w^2[m - p hop]) in padded coordinates,
+ * boundary extension trimmed, cut or zero-extended to `length`.  z is [lead; bins; frames] complex
+ * (interleaved re, im; frames fastest), out is [lead; out_len] with out_len = length when has_length,
+ * else smx_stft_output_length(frames).  The imaginary parts of the DC and Nyquist bins are ignored.
+ * Invalid_argument (messages of stft.ml:745-786): wrong bin count, negative length, a window / hop pair
+ * whose overlap-added squared window does not stay above 1e-10 of its maximum (smx_stft_nola).        */
+int smx_stft_nola(const smx_stft_config *c, int *invertible);                         /* stft.ml:731-743 */
+int smx_stft_output_length(const smx_stft_config *c, int64_t frames, int64_t *length); /* stft.ml:792-796 */
+int smx_stft_invert_f32(const smx_stft_config *c, const float *z_c64, int64_t lead, int64_t bins,
+                        int64_t frames, int has_length, int64_t length, float *out);
+int smx_stft_invert_f64(const smx_stft_config *c, const double *z_c128, int64_t lead, int64_t bins,
+                        int64_t frames, int has_length, int64_t length, double *out);
+int smx_stft_invert_f32_dev(const smx_stft_config *c, const float *d_z_c64, int64_t lead, int64_t bins,
+                            int64_t frames, int has_length, int64_t length, float *d_out, void *stream);
+int smx_stft_invert_f64_dev(const smx_stft_config *c, const double *d_z_c128, int64_t lead, int64_t bins,
+                            int64_t frames, int has_length, int64_t length, double *d_out, void *stream);
+
 /* ---- FIR block convolution (BASELINE config 4; model resample.ml:383-415) --
  * y[c][i] = sum_k h[k] x[c][i-k], zeros before the stream start, i in [0, n).
  * Overlap-save on the library's own FFT core, spectrum of h precomputed.     */

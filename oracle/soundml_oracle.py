@@ -455,6 +455,131 @@ class StreamKernel:
         return out
 
 
+# ---------------------------------------------------------------------------
+# Least-squares synthesis (Stft.invert, stft.ml:693-939)
+# ---------------------------------------------------------------------------
+
+def _ceil_div(a: int, b: int) -> int:
+    return -((-a) // b)
+
+
+def folded_square_window(c: StftConfig) -> np.ndarray:
+    """stft.ml:712-720: overlap-added squared window per residue class modulo the hop (j ascending)."""
+    folded = [0.0] * c.hop
+    w = c.analysis_window
+    for j in range(c.fft_size):
+        folded[j % c.hop] += float(w[j]) * float(w[j])
+    return np.array(folded, dtype=np.float64)
+
+
+def nola(c: StftConfig) -> bool:
+    """stft.ml:731-743: hop <= fft and the fold stays above 1e-10 of its maximum."""
+    if c.hop > c.fft_size:
+        return False
+    folded = folded_square_window(c)
+    return float(folded.min()) > 1e-10 * float(folded.max())
+
+
+def _check_synthesis(op: str, c: StftConfig, z: np.ndarray, length: Optional[int]) -> None:
+    """stft.ml:745-786: messages verbatim, in the reference's order (frames, length, invertibility)."""
+    if z.ndim < 2:
+        raise ValueError("%s: cannot invert a rank-%d tensor (the bin and frame axes must exist)" % (op, z.ndim))
+    bins = z.shape[-2]
+    if bins != c.bins:
+        raise ValueError(
+            "%s: cannot invert %d frequency bins of a %d-point transform (the bin axis must hold "
+            "fft_size / 2 + 1 = %d values)" % (op, bins, c.fft_size, c.bins))
+    if length is not None and length < 0:
+        raise ValueError("%s: cannot synthesise a signal of length %d (length must be non-negative)" % (op, length))
+    if not nola(c):
+        raise ValueError(
+            "%s: cannot invert a %d-point window advanced by %d samples inside a %d-point frame (the "
+            "overlap-added squared window must stay above 1e-10 of its largest value at every position)"
+            % (op, c.win_length, c.hop, c.fft_size))
+
+
+def output_length(c: StftConfig, frames_: int) -> int:
+    """stft.ml:792-796: the frame-count fixed point of the geometry."""
+    if frames_ == 0:
+        return 0
+    return (frames_ - 1) * c.hop + c.fft_size - left_width(c) - right_width(c)
+
+
+def _guard(v: float) -> float:
+    return 1.0 if v == 0.0 else v       # stft.ml:836
+
+
+def partial_envelope(c: StftConfig, last: int, q: int) -> float:
+    """stft.ml:844-853: tap-by-tap sum, p ascending, capped at frame ``last``."""
+    first = max(0, _ceil_div(q - c.fft_size + 1, c.hop))
+    last = min(last, q // c.hop)
+    total = 0.0
+    w = c.analysis_window
+    for p in range(first, last + 1):
+        j = q - p * c.hop
+        total += float(w[j]) * float(w[j])
+    return _guard(total)
+
+
+def envelope(c: StftConfig, frames_: int) -> np.ndarray:
+    """stft.ml:863-889: partial sums on the borders, one period of the fold tiled over the interior."""
+    fft, hop = c.fft_size, c.hop
+    complete = folded_square_window(c)
+    span = (frames_ - 1) * hop + fft
+    head = min(span, fft - hop)
+    stop = max(head, min(span, frames_ * hop))
+    out = np.empty(span, dtype=np.float64)
+    for q in range(head):
+        out[q] = partial_envelope(c, frames_ - 1, q)
+    for q in range(head, stop):
+        out[q] = _guard(float(complete[q % hop]))
+    for q in range(stop, span):
+        out[q] = partial_envelope(c, frames_ - 1, q)
+    return out
+
+
+def overlap_add(c: StftConfig, windowed: np.ndarray) -> np.ndarray:
+    """stft.ml:806-831: [..; frames; fft] -> [..; (frames-1) hop + fft].  The reference adds the block planes
+    k = 0, 1, ... in turn; position (p + k) hop + j receives tap [p; k; j], i.e. per position the frames arrive
+    in DESCENDING p.  The same order here."""
+    fft, hop = c.fft_size, c.hop
+    count = windowed.shape[-2]
+    blocks = _ceil_div(fft, hop)
+    lead = windowed.shape[:-2]
+    widened = np.zeros(lead + (count, blocks * hop), dtype=np.float64)
+    widened[..., :fft] = windowed
+    grid = widened.reshape(lead + (count, blocks, hop))
+    total = np.zeros(lead + (count + blocks - 1, hop), dtype=np.float64)
+    for k in range(blocks):
+        total[..., k:k + count, :] = total[..., k:k + count, :] + grid[..., :, k, :]
+    return total.reshape(lead + ((count + blocks - 1) * hop,))[..., :(count - 1) * hop + fft]
+
+
+def invert(c: StftConfig, z: np.ndarray, length: Optional[int] = None, dtype=None) -> np.ndarray:
+    """``Stft.invert dtype c ?length z`` (stft.ml:902-939): float64 interior whatever the dtypes."""
+    z = np.asarray(z)
+    _check_synthesis("invert", c, z, length)
+    if dtype is None:
+        dtype = np.float32 if z.dtype == np.complex64 else np.float64
+    fft, hop, left = c.fft_size, c.hop, left_width(c)
+    total_frames = z.shape[-1]
+    lead = z.shape[:-2]
+    out_len = length if length is not None else output_length(c, total_frames)
+    count = total_frames if length is None else min(total_frames, _ceil_div(length + left, hop))
+    if count == 0 or out_len == 0 or any(d == 0 for d in lead):
+        return np.zeros(lead + (out_len,), dtype=dtype)
+    z = z[..., :count].astype(np.complex128)
+    span = (count - 1) * hop + fft
+    y = np.fft.irfft(np.swapaxes(z, -1, -2), n=fft, axis=-1)         # [..; count; fft]
+    y = y * c.analysis_window
+    y = overlap_add(c, y) / envelope(c, count)
+    stop = min(span, left + out_len)
+    y = y[..., left:stop]
+    if stop - left != out_len:
+        y = np.concatenate([y, np.zeros(lead + (out_len - (stop - left),), dtype=np.float64)], axis=-1)
+    return y.astype(dtype)
+
+
 # ----------------------------------------------------------------------------
 # Mel (mel.ml, convert.ml:70-102)
 # ----------------------------------------------------------------------------

@@ -10,6 +10,8 @@
 #include <atomic>
 #include <memory>
 
+#include <algorithm>
+
 #include "smx_internal.hpp"
 
 namespace smx {
@@ -129,6 +131,65 @@ void stft_range_host(const smx_stft_config &c, const void *x, int in_bytes, int6
   stft_range_dev(c, dx.ptr, in_bytes, lead, n, n, p0, p1, mode, power, dout.ptr, nullptr);
   SMX_HIP_CHECK(hipStreamSynchronize(nullptr));
   SMX_HIP_CHECK(hipMemcpy(out, dout.ptr, out_elems * (size_t)in_bytes, hipMemcpyDeviceToHost));
+}
+
+
+// Stft.invert's checks (stft.ml:745-786), in the reference's order and wording
+void check_synthesis(const smx_stft_config &c, int64_t bins, int64_t length, bool has_length) {
+  if (bins != c.bins())
+    throw InvalidArgument(format(
+        "invert: cannot invert %lld frequency bins of a %lld-point transform (the bin axis must hold "
+        "fft_size / 2 + 1 = %lld values)",
+        (long long)bins, (long long)c.fft_size, (long long)c.bins()));
+  if (has_length && length < 0)
+    throw InvalidArgument(format("invert: cannot synthesise a signal of length %lld (length must be non-negative)",
+                                 (long long)length));
+  if (!stft_nola(c))
+    throw InvalidArgument(format(
+        "invert: cannot invert a %lld-point window advanced by %lld samples inside a %lld-point frame (the "
+        "overlap-added squared window must stay above 1e-10 of its largest value at every position)",
+        (long long)c.win_length, (long long)c.hop, (long long)c.fft_size));
+}
+
+// length < 0 means "not given" at the ABI only after the explicit has_length flag said so
+void invert_dev(const smx_stft_config &c, const void *d_z, int z_bytes, int64_t lead, int64_t bins, int64_t frames,
+                int has_length, int64_t length, void *d_out, hipStream_t stream) {
+  if (lead < 0 || frames < 0) throw Failure("invert: negative extent");
+  check_synthesis(c, bins, length, has_length != 0);
+  const int64_t out_len = has_length ? length : stft_output_length(c, frames);
+  if (lead == 0 || out_len == 0) return;
+  if (!d_out || (frames > 0 && !d_z)) throw Failure("invert: null device pointer");
+  IstftJob job;
+  job.cfg = &c;
+  job.z = d_z;
+  job.z_bytes = z_bytes;
+  job.interior = z_bytes == 16 ? SMX_INTERIOR_F64 : g_interior.load();
+  job.lead = lead;
+  job.frames = frames;
+  // only the frames the output can reach are inverted (stft.ml:915-921)
+  const int64_t left = c.left_width();
+  job.count = has_length ? std::min<int64_t>(frames, (length + left + c.hop - 1) / c.hop) : frames;
+  job.out_len = out_len;
+  job.out = d_out;
+  job.stream = stream;
+  launch_istft(job);
+}
+
+void invert_host(const smx_stft_config &c, const void *z, int z_bytes, int64_t lead, int64_t bins, int64_t frames,
+                 int has_length, int64_t length, void *out) {
+  if (lead < 0 || frames < 0) throw Failure("invert: negative extent");
+  check_synthesis(c, bins, length, has_length != 0);
+  const int64_t out_len = has_length ? length : stft_output_length(c, frames);
+  if (lead == 0 || out_len == 0) return;
+  if (!out || (frames > 0 && !z)) throw Failure("invert: null pointer");
+  require_device();
+  const size_t zb = (size_t)lead * (size_t)bins * (size_t)frames * (size_t)z_bytes;
+  const size_t ob = (size_t)lead * (size_t)out_len * (size_t)(z_bytes / 2);
+  DeviceScratch dz(zb), dout(ob);
+  if (zb) SMX_HIP_CHECK(hipMemcpy(dz.ptr, z, zb, hipMemcpyHostToDevice));
+  invert_dev(c, dz.ptr, z_bytes, lead, bins, frames, has_length, length, dout.ptr, nullptr);
+  SMX_HIP_CHECK(hipStreamSynchronize(nullptr));
+  SMX_HIP_CHECK(hipMemcpy(out, dout.ptr, ob, hipMemcpyDeviceToHost));
 }
 
 }  // namespace
@@ -865,6 +926,50 @@ int smx_mel_spectrogram_f32_dev(const smx_stft_config *sc, const smx_mel_config 
     check_config(sc, "mel_spectrogram");
     check_config(mc, "mel_spectrogram");
     mel_spectrogram_dev(*sc, *mc, d_x, 4, lead, n, x_stride, power, d_out, (hipStream_t)stream);
+  });
+}
+
+
+// ---- least-squares synthesis: Stft.invert (stft.ml:902-939) ----------------------------------------
+int smx_stft_nola(const smx_stft_config *c, int *invertible) {
+  return guarded([&] {
+    check_config(c, "nola");
+    if (invertible) *invertible = stft_nola(*c) ? 1 : 0;
+  });
+}
+int smx_stft_output_length(const smx_stft_config *c, int64_t frames, int64_t *length) {
+  return guarded([&] {
+    check_config(c, "output_length");
+    if (frames < 0) throw Failure("output_length: negative frame count");
+    if (length) *length = stft_output_length(*c, frames);
+  });
+}
+int smx_stft_invert_f32(const smx_stft_config *c, const float *z, int64_t lead, int64_t bins, int64_t frames,
+                        int has_length, int64_t length, float *out) {
+  return guarded([&] {
+    check_config(c, "invert");
+    invert_host(*c, z, 8, lead, bins, frames, has_length, length, out);
+  });
+}
+int smx_stft_invert_f64(const smx_stft_config *c, const double *z, int64_t lead, int64_t bins, int64_t frames,
+                        int has_length, int64_t length, double *out) {
+  return guarded([&] {
+    check_config(c, "invert");
+    invert_host(*c, z, 16, lead, bins, frames, has_length, length, out);
+  });
+}
+int smx_stft_invert_f32_dev(const smx_stft_config *c, const float *d_z, int64_t lead, int64_t bins, int64_t frames,
+                            int has_length, int64_t length, float *d_out, void *stream) {
+  return guarded([&] {
+    check_config(c, "invert");
+    invert_dev(*c, d_z, 8, lead, bins, frames, has_length, length, d_out, (hipStream_t)stream);
+  });
+}
+int smx_stft_invert_f64_dev(const smx_stft_config *c, const double *d_z, int64_t lead, int64_t bins, int64_t frames,
+                            int has_length, int64_t length, double *d_out, void *stream) {
+  return guarded([&] {
+    check_config(c, "invert");
+    invert_dev(*c, d_z, 16, lead, bins, frames, has_length, length, d_out, (hipStream_t)stream);
   });
 }
 

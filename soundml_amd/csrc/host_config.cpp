@@ -9,6 +9,8 @@
 #include <cstdio>
 #include <limits>
 
+#include <algorithm>
+
 #include "smx_internal.hpp"
 
 namespace smx {
@@ -173,6 +175,62 @@ namespace smx {
 
 int64_t stft_first_complete(const smx_stft_config &c) {
   return (c.left_width() + c.hop - 1) / c.hop;
+}
+
+// ---- least-squares synthesis bookkeeping (stft.ml:708-889) --------------------------------------
+namespace {
+std::vector<double> folded_square_window(const smx_stft_config &c) {   // stft.ml:712-720, j ascending
+  std::vector<double> folded((size_t)c.hop, 0.0);
+  for (int64_t j = 0; j < c.fft_size; ++j) {
+    const double w = c.analysis_window[(size_t)j];
+    folded[(size_t)(j % c.hop)] += w * w;
+  }
+  return folded;
+}
+inline double guard(double v) { return v == 0.0 ? 1.0 : v; }   // stft.ml:836
+inline int64_t ceil_div(int64_t a, int64_t b) { return a >= 0 ? (a + b - 1) / b : -((-a) / b); }
+}  // namespace
+
+bool stft_nola(const smx_stft_config &c) {
+  if (c.hop > c.fft_size) return false;
+  const std::vector<double> folded = folded_square_window(c);
+  double lo = folded[0], hi = 0.0;
+  for (double v : folded) {
+    if (v < lo) lo = v;
+    if (v > hi) hi = v;
+  }
+  return lo > 1e-10 * hi;
+}
+
+int64_t stft_output_length(const smx_stft_config &c, int64_t frames) {
+  if (frames == 0) return 0;
+  return (frames - 1) * c.hop + c.fft_size - c.left_width() - c.right_width();
+}
+
+void stft_envelope(const smx_stft_config &c, int64_t frames, std::vector<double> &head, std::vector<double> &period,
+                   std::vector<double> &tail, int64_t &head_n, int64_t &stop) {
+  const int64_t fft = c.fft_size, hop = c.hop;
+  const int64_t span = (frames - 1) * hop + fft;
+  head_n = span < fft - hop ? span : fft - hop;
+  int64_t interior_end = span < frames * hop ? span : frames * hop;
+  stop = head_n > interior_end ? head_n : interior_end;
+  auto partial = [&](int64_t q) {   // stft.ml:844-853: p ascending, capped at the last frame
+    const int64_t first = std::max<int64_t>(0, ceil_div(q - fft + 1, hop));
+    const int64_t last = std::min<int64_t>(frames - 1, q / hop);
+    double total = 0.0;
+    for (int64_t p = first; p <= last; ++p) {
+      const double w = c.analysis_window[(size_t)(q - p * hop)];
+      total += w * w;
+    }
+    return guard(total);
+  };
+  head.resize((size_t)head_n);
+  for (int64_t q = 0; q < head_n; ++q) head[(size_t)q] = partial(q);
+  const std::vector<double> folded = folded_square_window(c);
+  period.resize((size_t)hop);
+  for (int64_t r = 0; r < hop; ++r) period[(size_t)r] = guard(folded[(size_t)r]);
+  tail.resize((size_t)(span - stop));
+  for (int64_t q = stop; q < span; ++q) tail[(size_t)(q - stop)] = partial(q);
 }
 
 int64_t stft_last_complete(const smx_stft_config &c, int64_t n) {

@@ -129,6 +129,12 @@ int64_t stft_last_complete(const smx_stft_config &c, int64_t n);                
 int64_t source_index(const smx_stft_config &c, int64_t n, int64_t q);            // stft.ml:300-338
 smx_mel_config *mel_config_create(int64_t n_mels, int64_t sample_rate, int64_t fft_size,
                                   double f_min, bool has_f_max, double f_max, int scale, int norm);
+bool stft_nola(const smx_stft_config &c);                                        // stft.ml:731-743
+int64_t stft_output_length(const smx_stft_config &c, int64_t frames);            // stft.ml:792-796
+// envelope over the span of `frames` frames as three pieces: positions [0, head) and [stop, span) summed tap by
+// tap, one period of the folded squared window for [head, stop) (stft.ml:836-889); all guarded against 0
+void stft_envelope(const smx_stft_config &c, int64_t frames, std::vector<double> &head, std::vector<double> &period,
+                   std::vector<double> &tail, int64_t &head_n, int64_t &stop);
 double kaiser_beta(double att);                                                  // resample.ml:105-109
 double bessel_i0(double x);                                                      // resample.ml:128-139
 void design_lowpass(int64_t taps, double fc, double beta, double *h);
@@ -158,6 +164,20 @@ void launch_stft(const StftJob &job);             // dispatch: fast path or gene
 void launch_stft_generic(const StftJob &job);     // stft_generic.hip
 bool launch_stft_fast(const StftJob &job);        // stft_fast.hip; false = not eligible
 bool fast_path_disabled();                        // env SMX_DISABLE_FAST=1 (tests)
+
+// Stft.invert (stft.ml:902-939) on device-resident data
+struct IstftJob {
+  const smx_stft_config *cfg = nullptr;
+  const void *z = nullptr;       // device [lead; bins; frames] complex (interleaved), frames fastest
+  int z_bytes = 8;               // 8 = complex64, 16 = complex128
+  int interior = SMX_INTERIOR_F32;
+  int64_t lead = 0, frames = 0;
+  int64_t count = 0;             // frames that reach the output
+  int64_t out_len = 0;
+  void *out = nullptr;           // device [lead; out_len], float32 for complex64 input, float64 for complex128
+  hipStream_t stream = nullptr;
+};
+void launch_istft(const IstftJob &job);           // istft.hip
 
 struct MelJob {
   const smx_mel_config *cfg = nullptr;

@@ -184,6 +184,71 @@ def power_range(c: Config, x, p0: int, p1: int, power: float = 2.0):
     return _range(c, x, int(p0), int(p1), float(power), "power_spectrum")
 
 
+def nola(c: Config) -> bool:
+    """``Stft.nola c`` (stft.ml:731-743): the overlap-added squared window clears 1e-10 of its maximum."""
+    v = C.c_int()
+    check(lib.smx_stft_nola(c._h, C.byref(v)))
+    return bool(v.value)
+
+
+def output_length(c: Config, frames: int) -> int:
+    """``Stft.output_length c ~frames`` (stft.ml:792-796)."""
+    v = C.c_int64()
+    check(lib.smx_stft_output_length(c._h, int(frames), C.byref(v)))
+    return v.value
+
+
+def invert(c: Config, z, length=None):
+    """``Stft.invert dtype c ?length z`` (stft.ml:902-939): complex [...; bins; frames] -> real [...; length],
+    the least-squares synthesis.  complex64 spectra give float32 signals, complex128 float64; a device
+    (torch) spectrum stays on the device."""
+    from ._tensor import is_device, is_torch, torch
+    shape = tuple(z.shape)
+    if len(shape) < 2:  # stft.ml:760-766, before anything else
+        raise _lib.InvalidArgument(
+            "invert: cannot invert a rank-%d tensor (the bin and frame axes must exist)" % len(shape))
+    bins, frames = int(shape[-2]), int(shape[-1])
+    lead_shape = shape[:-2]
+    lead = 1
+    for d in lead_shape:
+        lead *= int(d)
+    has_length = length is not None
+    if is_device(z):
+        if z.dtype not in (torch.complex64, torch.complex128):
+            z = z.to(torch.complex64)
+        zc = z.contiguous()
+        wide = zc.dtype == torch.complex128
+        # the checks run inside the ABI before the output length is needed: ask it for them first with no data
+        fn = lib.smx_stft_invert_f64_dev if wide else lib.smx_stft_invert_f32_dev
+        if not has_length:
+            check(fn(c._h, None, 0, bins, frames, 0, 0, None, None))
+        out_len = int(length) if has_length else output_length(c, frames)
+        if has_length and out_len < 0:
+            check(fn(c._h, None, 0, bins, frames, 1, out_len, None, None))
+        out = torch.zeros(lead_shape + (out_len,), dtype=torch.float64 if wide else torch.float32, device=zc.device)
+        with torch.cuda.device(zc.device):
+            stream = C.c_void_p(torch.cuda.current_stream(zc.device).cuda_stream)
+            zr = torch.view_as_real(zc)
+            check(fn(c._h, C.c_void_p(zr.data_ptr()), lead, bins, frames, 1 if has_length else 0,
+                     out_len if has_length else 0, C.c_void_p(out.data_ptr()), stream))
+        return out
+    was_torch = is_torch(z)
+    a = z.detach().cpu().numpy() if was_torch else np.asarray(z)
+    if a.dtype not in (np.complex64, np.complex128):
+        a = a.astype(np.complex64 if a.dtype == np.float32 else np.complex128)
+    a = np.ascontiguousarray(a)
+    wide = a.dtype == np.complex128
+    fn = lib.smx_stft_invert_f64 if wide else lib.smx_stft_invert_f32
+    if has_length and int(length) < 0 or not has_length:
+        # run the checks (and nothing else: lead 0) so that the reference's errors come first
+        check(fn(c._h, None, 0, bins, frames, 1 if has_length else 0, int(length) if has_length else 0, None))
+    out_len = int(length) if has_length else output_length(c, frames)
+    out = np.zeros(lead_shape + (out_len,), dtype=np.float64 if wide else np.float32)
+    check(fn(c._h, C.c_void_p(a.ctypes.data), lead, bins, frames, 1 if has_length else 0,
+             out_len if has_length else 0, C.c_void_p(out.ctypes.data)))
+    return torch.from_numpy(out) if was_torch else out
+
+
 class Kernel:
     """``Stft.Kernel`` (stft.ml:597-622): streaming analysis with the carry held
     in device memory.  Chunks are host arrays [channels; m]; ``step`` / ``flush``

@@ -48,3 +48,24 @@ def check_close(actual, expected, shape=None, rtol=F64_STRICT_RTOL, atol=F64_STR
         raise AssertionError(
             "%s: index %d: got %.17g, expected %.17g (delta %.3g, tolerance %.3g); %d/%d bad"
             % (msg, i, a[i], e[i], abs(a[i] - e[i]), tol[i], int(bad.sum()), a.size))
+
+
+def istft_golden_spectrum(fft_size, frames):
+    """The synthetic spectrum of the reference's synthesis goldens (istft_goldens.ml:31-49): two 31-bit LCG
+    streams, the imaginary parts of the DC and Nyquist bins zero."""
+    import numpy as np
+    from oracle import soundml_oracle as O
+    bins = fft_size // 2 + 1
+    re = O.lcg_signal(bins * frames, 20250803)
+    im = O.lcg_signal(bins * frames, 20250804)
+    z = (re + 1j * im).reshape(bins, frames)
+    z[0] = z[0].real
+    if fft_size % 2 == 0:
+        z[-1] = z[-1].real
+    return z
+
+
+def istft_golden_config(make, params):
+    """Stft.Config of a synthesis golden case (istft_goldens.ml:63-69): constant-zero padding."""
+    return make(params["fft_size"], win_length=params["win_length"], hop=params["hop"],
+                alignment=params["alignment"], pad="constant", pad_value=0.0)

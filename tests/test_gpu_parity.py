@@ -302,6 +302,74 @@ def test_streaming_2048_float32():
     assert np.array_equal(got, want)
 
 
+
+# ---- least-squares synthesis: Stft.invert --------------------------------------------------------------
+
+@pytest.mark.parametrize("vectors", ["inverse_fft2048_hop512", "inverse_fft64_hop16"])
+def test_invert_goldens(vectors):
+    """The reference's librosa-0.11 synthesis vectors (istft_goldens.ml) on the HIP path: float64 cases at the
+    reference's float64 tolerance, float32 cases at its float32 tolerance with the float64 interior and at the
+    north-star tolerance with the float32 interior."""
+    from conftest import F32_ATOL, F32_RTOL, F64_ATOL, F64_RTOL, check_close, istft_golden_config, istft_golden_spectrum, load_golden
+    for case in load_golden("istft", vectors)["cases"]:
+        p = case["params"]
+        c = istft_golden_config(lambda fft, pad, pad_value, **kw: Stft.Config.create(fft_size=fft, pad=(pad, pad_value), **kw), p)
+        z = istft_golden_spectrum(p["fft_size"], p["frames"])
+        want = np.array(case["values"])
+        if p["dtype"] == "float64":
+            got = Stft.invert(c, z, p.get("length"))
+            assert got.dtype == np.float64
+            check_close(got, want, shape=case["shape"], rtol=F64_RTOL, atol=F64_ATOL, msg=case["name"])
+        else:
+            S.set_interior("float64")
+            got = Stft.invert(c, z.astype(np.complex64), p.get("length"))
+            assert got.dtype == np.float32
+            check_close(got, want, shape=case["shape"], rtol=F32_RTOL, atol=F32_ATOL, msg=case["name"])
+            S.set_interior("float32")
+            check_fast(Stft.invert(c, z.astype(np.complex64), p.get("length")), want, case["name"])
+
+
+@pytest.mark.parametrize("fft,hop,win,alignment", [(2048, 512, None, "centered"), (2048, 512, 1200, "left"), (1024, 256, None, "right"),
+                                                   (64, 16, None, "centered"), (48, 12, None, "centered"), (31, 5, None, "left"),
+                                                   (64, 60, None, "centered"), (100, 33, 64, "right")])
+@pytest.mark.parametrize("length_mode", ["default", "short", "long"])
+def test_invert_vs_oracle(fft, hop, win, alignment, length_mode):
+    """Random (inconsistent) spectra: the least-squares solution itself, every alignment, power-of-two and other
+    sizes, default / cut / zero-extended lengths, two leading axes."""
+    rng = np.random.default_rng(fft * 7 + hop)
+    c = Stft.Config.create(fft_size=fft, hop=hop, win_length=win, alignment=alignment)
+    o = O.stft_config(fft, hop=hop, win_length=win, alignment=alignment)
+    frames = 23
+    z = rng.standard_normal((2, 3, fft // 2 + 1, frames)) + 1j * rng.standard_normal((2, 3, fft // 2 + 1, frames))
+    default = O.output_length(o, frames)
+    length = {"default": None, "short": max(1, default // 3), "long": default + 2 * fft + 5}[length_mode]
+    want = O.invert(o, z, length)
+    got = Stft.invert(c, z, length)
+    assert got.shape == want.shape and got.dtype == np.float64
+    np.testing.assert_allclose(got, want, rtol=1e-9, atol=1e-11)
+    z32 = z.astype(np.complex64)
+    got32 = Stft.invert(c, z32, length)
+    assert got32.dtype == np.float32
+    check_fast(got32, O.invert(o, z32, length), "float32")
+
+
+def test_invert_round_trip_and_device_path():
+    """invert (transform x) restores x on the interior (stft.mli, istft_law.ml); a device-resident spectrum gives
+    the host result bit for bit."""
+    import torch
+    rng = np.random.default_rng(21)
+    x = rng.uniform(-1, 1, size=(3, 40000)).astype(np.float32)
+    c = Stft.Config.create(fft_size=2048, hop=512)
+    z = Stft.transform(c, x)
+    y = Stft.invert(c, z, length=x.shape[-1])
+    assert y.shape == x.shape and y.dtype == np.float32
+    assert np.max(np.abs(y - x)) < 2e-5
+    zd = torch.from_numpy(z).cuda()
+    yd = Stft.invert(c, zd, length=x.shape[-1])
+    assert yd.is_cuda and np.array_equal(yd.cpu().numpy(), y)
+    assert np.array_equal(Stft.invert(c, zd).cpu().numpy(), Stft.invert(c, z))
+
+
 # ---- Mel -------------------------------------------------------------------------------------------
 
 @pytest.mark.parametrize("n_mels,sr,fft,frames,lead", [(128, 48000, 2048, 938, 2), (40, 22050, 512, 77, 3),

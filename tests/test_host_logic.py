@@ -230,3 +230,39 @@ def test_fir_design_matches_oracle():
     with pytest.raises(S.InvalidArgument):
         Fir.Plan.create(np.ones(9000))
     assert Fir.Plan.create(np.ones(8192) / 8192).block == 16384
+
+
+# ---- least-squares synthesis bookkeeping (host side of Stft.invert; no device needed) ----------------
+
+@pytest.mark.parametrize("fft,hop,win,alignment", [(2048, 512, None, "centered"), (64, 16, None, "left"), (64, 64, None, "centered"),
+                                                   (64, 48, 20, "centered"), (31, 5, None, "right"), (16, 20, None, "centered")])
+def test_nola_and_output_length_match_oracle(fft, hop, win, alignment):
+    c = Stft.Config.create(fft_size=fft, hop=hop, win_length=win, alignment=alignment)
+    o = O.stft_config(fft, hop=hop, win_length=win, alignment=alignment)
+    assert Stft.nola(c) == O.nola(o)
+    for frames in (0, 1, 2, 7, 938):
+        assert Stft.output_length(c, frames) == O.output_length(o, frames)
+
+
+def test_invert_checks_need_no_device():
+    """stft.ml:745-786: rank, bin count, length and invertibility are rejected with the reference's words
+    before any device work (the spectral shape is checked before any transform, istft_law.ml:673-683)."""
+    c = Stft.Config.create(fft_size=64, hop=16)
+    with pytest.raises(S.InvalidArgument) as e:
+        Stft.invert(c, np.zeros(33, np.complex128))
+    assert str(e.value) == "invert: cannot invert a rank-1 tensor (the bin and frame axes must exist)"
+    with pytest.raises(S.InvalidArgument) as e:
+        Stft.invert(c, np.zeros((30, 4), np.complex128))
+    assert str(e.value) == ("invert: cannot invert 30 frequency bins of a 64-point transform (the bin axis must hold "
+                            "fft_size / 2 + 1 = 33 values)")
+    with pytest.raises(S.InvalidArgument) as e:
+        Stft.invert(c, np.zeros((33, 4), np.complex128), length=-3)
+    assert str(e.value) == "invert: cannot synthesise a signal of length -3 (length must be non-negative)"
+    wide = Stft.Config.create(fft_size=64, hop=64)
+    with pytest.raises(S.InvalidArgument) as e:
+        Stft.invert(wide, np.zeros((33, 4), np.complex128))
+    assert str(e.value) == ("invert: cannot invert a 64-point window advanced by 64 samples inside a 64-point frame (the "
+                            "overlap-added squared window must stay above 1e-10 of its largest value at every position)")
+    # an empty request synthesises nothing (istft_law.ml:562): zero frames -> zero samples, no device touched
+    assert Stft.invert(c, np.zeros((33, 0), np.complex128)).shape == (0,)
+    assert Stft.invert(c, np.zeros((0, 33, 5), np.complex64)).shape == (0, Stft.output_length(c, 5))

@@ -99,6 +99,41 @@ def test_mel_spectrogram():
 
 # --- structural laws of the reference restated on the oracle -------------------------------
 
+@pytest.mark.parametrize("vectors", ["inverse_fft2048_hop512", "inverse_fft64_hop16"])
+def test_istft_goldens(vectors):
+    """Stft.invert restated (oracle.invert) against the reference's librosa-0.11 synthesis vectors
+    (soundml/test/istft/vectors, replayed by istft_goldens.ml with these tolerances)."""
+    from conftest import istft_golden_config, istft_golden_spectrum
+    for case in load_golden("istft", vectors)["cases"]:
+        p = case["params"]
+        cfg = istft_golden_config(lambda fft, **kw: O.stft_config(fft, **kw), p)
+        z = istft_golden_spectrum(p["fft_size"], p["frames"])
+        f32 = p["dtype"] == "float32"
+        got = O.invert(cfg, z.astype(np.complex64) if f32 else z, p.get("length"))
+        assert got.dtype == (np.float32 if f32 else np.float64)
+        check_close(got, case["values"], shape=case["shape"], rtol=F32_RTOL if f32 else F64_RTOL,
+                    atol=F32_ATOL if f32 else F64_ATOL, msg=case["name"])
+
+
+def test_istft_oracle_laws():
+    """istft_law.ml: the default length is the frame-count fixed point; a round trip restores the interior;
+    the criterion rejects a hop the squared window cannot cover."""
+    rng = np.random.default_rng(3)
+    for fft, hop, align in ((64, 16, "centered"), (64, 16, "left"), (64, 16, "right"), (48, 12, "centered"), (31, 5, "centered")):
+        cfg = O.stft_config(fft, hop=hop, alignment=align)
+        x = rng.standard_normal(700)
+        z = O.transform(cfg, x)
+        assert O.frames(cfg, O.output_length(cfg, z.shape[-1])) == z.shape[-1]
+        y = O.invert(cfg, z, length=x.size)
+        lo, hi = fft, x.size - fft
+        np.testing.assert_allclose(y[lo:hi], x[lo:hi], rtol=0, atol=1e-10)
+    assert not O.nola(O.stft_config(64, hop=64))
+    with pytest.raises(ValueError, match="cannot invert a 64-point window advanced by 64 samples"):
+        O.invert(O.stft_config(64, hop=64), np.zeros((33, 4), np.complex128))
+    with pytest.raises(ValueError, match="cannot invert 30 frequency bins"):
+        O.invert(O.stft_config(64, hop=16), np.zeros((30, 4), np.complex128))
+
+
 @pytest.mark.parametrize("alignment", ["centered", "left", "right"])
 @pytest.mark.parametrize("pad", ["reflect", "edge", "constant"])
 @pytest.mark.parametrize("fft,hop", [(16, 4), (32, 7), (16, 20)])
