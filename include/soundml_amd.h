@@ -190,6 +190,19 @@ int smx_mel_spectrogram_f32_dev(const smx_stft_config *sc, const smx_mel_config 
                                 const float *d_x, int64_t lead, int64_t n, int64_t x_stride,
                                 double power, float *d_out, void *stream);
 
+/* ---- Soundml.mfcc (soundml.ml:50-95): mel_spectrogram (power 2) -> power_to_db with the 80 dB clamp under
+ * the maximum of the WHOLE tensor (convert.ml:30-50) -> orthonormal DCT-II along the mel axis, first n_mfcc
+ * rows -> optional sinusoidal lifter.  float64 interior after the mel spectrogram, one rounding to the audio
+ * dtype.  out is [lead; n_mfcc; frames].  Invalid_argument: fft sizes differ, n_mfcc outside [1, n_mels],
+ * lifter negative or not finite (messages of soundml.ml:52-70).                                          */
+int smx_mfcc_f32(const smx_stft_config *sc, const smx_mel_config *mc, const float *x, int64_t lead, int64_t n,
+                 int64_t n_mfcc, int has_lifter, double lifter, float *out);
+int smx_mfcc_f64(const smx_stft_config *sc, const smx_mel_config *mc, const double *x, int64_t lead, int64_t n,
+                 int64_t n_mfcc, int has_lifter, double lifter, double *out);
+int smx_mfcc_f32_dev(const smx_stft_config *sc, const smx_mel_config *mc, const float *d_x, int64_t lead,
+                     int64_t n, int64_t x_stride, int64_t n_mfcc, int has_lifter, double lifter, float *d_out,
+                     void *stream);
+
 /* ---- Least-squares synthesis: Stft.invert (stft.ml:902-939, stft.mli "invert") --------------------
  * x[m] = (sum_p w[m - p hop] irfft(Z[:, p])[m - p hop]) / (sum_p w^2[m - p hop]) in padded coordinates,
  * boundary extension trimmed, cut or zero-extended to `length`.  z is [lead; bins; frames] complex

@@ -724,6 +724,59 @@ def mel_spectrogram(sc: StftConfig, mc: MelConfig, x: np.ndarray, power: float =
     return mel_apply(mc, power_spectrum(sc, x, power))
 
 
+# ---------------------------------------------------------------------------
+# Log-mel / MFCC (convert.ml:30-50, soundml.ml:26-95)
+# ---------------------------------------------------------------------------
+
+def power_to_db(s: np.ndarray, reference: float = 1.0, amin: float = 1e-10,
+                top_db: Optional[float] = None) -> np.ndarray:
+    """convert.ml:30-50 ``to_db`` with gain 10 in the input's dtype: floor at amin, scale * ln, subtract the
+    reference offset, then clamp at (maximum of the whole tensor) - top_db."""
+    s = np.asarray(s)
+    if s.size == 0:
+        return s.copy()
+    dt = s.dtype
+    scale = 10.0 / 10.0 * (10.0 / math.log(10.0))
+    floored = np.maximum(s, dt.type(amin))
+    offset = scale * math.log(max(amin, reference))
+    db = (np.log(floored) * dt.type(scale) - dt.type(offset)).astype(dt)
+    if top_db is None:
+        return db
+    return np.maximum(db, dt.type(float(db.max()) - top_db))
+
+
+def mfcc(sc: StftConfig, mc: MelConfig, x: np.ndarray, n_mfcc: int = 20, lifter: Optional[float] = None) -> np.ndarray:
+    """``Soundml.mfcc`` (soundml.ml:50-95): log-mel (80 dB clamp) -> raw DCT-II along the mel axis -> orthonormal
+    row scales -> optional sinusoidal lifter, float64 interior after the mel spectrogram, one rounding."""
+    if sc.fft_size != mc.fft_size:
+        raise ValueError(
+            "mfcc: cannot project a %d-point STFT through a filterbank built for an FFT of size %d (the two "
+            "configurations must agree on fft_size)" % (sc.fft_size, mc.fft_size))
+    if n_mfcc < 1 or n_mfcc > mc.n_mels:
+        raise ValueError("mfcc: cannot keep %d cepstral coefficients of %d mel bands (n_mfcc must lie in "
+                         "[1, n_mels])" % (n_mfcc, mc.n_mels))
+    if lifter is not None and not (math.isfinite(lifter) and lifter >= 0.0):
+        raise ValueError("mfcc: cannot lifter with a coefficient of %s (lifter must be finite and non-negative)"
+                         % _g(lifter))
+    x = np.asarray(x)
+    mel = mel_spectrogram(sc, mc, x)
+    dtype = x.dtype if x.dtype in (np.float32, np.float64) else np.float32
+    if mel.size == 0:
+        return np.zeros(mel.shape[:-2] + (n_mfcc, mel.shape[-1]), dtype=dtype)
+    db = power_to_db(mel.astype(np.float64), top_db=80.0)
+    n = mc.n_mels
+    k = np.arange(n_mfcc, dtype=np.float64)[:, None]
+    m = np.arange(n, dtype=np.float64)[None, :]
+    raw = 2.0 * np.cos(np.pi * k * (2.0 * m + 1.0) / (2.0 * n))             # type-II, unnormalised
+    cep = np.einsum("km,...mt->...kt", raw, db)
+    scales = np.where(np.arange(n_mfcc) == 0, 1.0 / math.sqrt(4.0 * n), 1.0 / math.sqrt(2.0 * n))[:, None]
+    cep = cep * scales
+    if lifter is not None and lifter > 0.0:
+        w = 1.0 + lifter / 2.0 * np.sin(np.pi * (np.arange(n_mfcc, dtype=np.float64) + 1.0) / lifter)
+        cep = cep * w[:, None]
+    return cep.astype(dtype)
+
+
 # ----------------------------------------------------------------------------
 # FIR (BASELINE config 4; model: resample.ml:105-163) -- parity unpinned
 # ----------------------------------------------------------------------------

@@ -89,6 +89,9 @@ SIGNATURES = {
     "smx_stft_transform_range_f64_dev": (cint, [vp, vp, i64, i64, i64, i64, i64, vp, vp]),
     "smx_stft_power_range_f32_dev": (cint, [vp, vp, i64, i64, i64, i64, i64, f64, vp, vp]),
     "smx_stft_power_range_f64_dev": (cint, [vp, vp, i64, i64, i64, i64, i64, f64, vp, vp]),
+    "smx_mfcc_f32": (cint, [vp, vp, vp, i64, i64, i64, cint, f64, vp]),
+    "smx_mfcc_f64": (cint, [vp, vp, vp, i64, i64, i64, cint, f64, vp]),
+    "smx_mfcc_f32_dev": (cint, [vp, vp, vp, i64, i64, i64, i64, cint, f64, vp, vp]),
     "smx_stft_nola": (cint, [vp, C.POINTER(cint)]),
     "smx_stft_output_length": (cint, [vp, i64, pi64]),
     "smx_stft_invert_f32": (cint, [vp, vp, i64, i64, i64, cint, i64, vp]),

@@ -852,6 +852,65 @@ void mel_spectrogram_host(const smx_stft_config &sc, const smx_mel_config &mc, c
   SMX_HIP_CHECK(hipMemcpy(out, dout.ptr, out_total, hipMemcpyDeviceToHost));
 }
 
+
+// Soundml.mfcc (soundml.ml:50-95): checks in the reference's order and words, then mel_spectrogram + the tail
+void check_mfcc(const smx_stft_config &sc, const smx_mel_config &mc, int64_t n_mfcc, int has_lifter, double lifter) {
+  if (sc.fft_size != mc.fft_size)
+    throw InvalidArgument(format(
+        "mfcc: cannot project a %lld-point STFT through a filterbank built for an FFT of size %lld (the two "
+        "configurations must agree on fft_size)",
+        (long long)sc.fft_size, (long long)mc.fft_size));
+  if (n_mfcc < 1 || n_mfcc > mc.n_mels)
+    throw InvalidArgument(format(
+        "mfcc: cannot keep %lld cepstral coefficients of %lld mel bands (n_mfcc must lie in [1, n_mels])",
+        (long long)n_mfcc, (long long)mc.n_mels));
+  if (has_lifter && !(std::isfinite(lifter) && lifter >= 0.0))
+    throw InvalidArgument(format("mfcc: cannot lifter with a coefficient of %g (lifter must be finite and non-negative)",
+                                 lifter));
+}
+
+void mfcc_dev(const smx_stft_config &sc, const smx_mel_config &mc, const void *d_x, int in_bytes, int64_t lead,
+              int64_t n, int64_t x_stride, int64_t n_mfcc, int has_lifter, double lifter, void *d_out,
+              hipStream_t stream) {
+  check_mfcc(sc, mc, n_mfcc, has_lifter, lifter);
+  check_rank_extents("mfcc", lead, n);
+  const int64_t count = sc.frames(n);
+  if (lead == 0 || count == 0) return;
+  if (!d_x || !d_out) throw Failure("mfcc: null device pointer");
+  void *mel = nullptr;
+  SMX_HIP_CHECK(hipMallocAsync(&mel, (size_t)lead * (size_t)mc.n_mels * (size_t)count * (size_t)in_bytes, stream));
+  mel_spectrogram_dev(sc, mc, d_x, in_bytes, lead, n, x_stride, 2.0, mel, stream);
+  MfccJob job;
+  job.mel = mel;
+  job.elem_bytes = in_bytes;
+  job.lead = lead;
+  job.frames = count;
+  job.n_mels = (int)mc.n_mels;
+  job.n_mfcc = (int)n_mfcc;
+  job.lifter = has_lifter ? lifter : 0.0;
+  job.out = d_out;
+  job.stream = stream;
+  launch_mfcc(job);
+  SMX_HIP_CHECK(hipFreeAsync(mel, stream));
+}
+
+void mfcc_host(const smx_stft_config &sc, const smx_mel_config &mc, const void *x, int in_bytes, int64_t lead,
+               int64_t n, int64_t n_mfcc, int has_lifter, double lifter, void *out) {
+  check_mfcc(sc, mc, n_mfcc, has_lifter, lifter);
+  check_rank_extents("mfcc", lead, n);
+  const int64_t count = sc.frames(n);
+  if (lead == 0 || count == 0) return;
+  if (!x || !out) throw Failure("mfcc: null pointer");
+  require_device();
+  const size_t in_total = (size_t)lead * (size_t)n * (size_t)in_bytes;
+  const size_t out_total = (size_t)lead * (size_t)n_mfcc * (size_t)count * (size_t)in_bytes;
+  DeviceScratch dx(in_total), dout(out_total);
+  SMX_HIP_CHECK(hipMemcpy(dx.ptr, x, in_total, hipMemcpyHostToDevice));
+  mfcc_dev(sc, mc, dx.ptr, in_bytes, lead, n, n, n_mfcc, has_lifter, lifter, dout.ptr, nullptr);
+  SMX_HIP_CHECK(hipStreamSynchronize(nullptr));
+  SMX_HIP_CHECK(hipMemcpy(out, dout.ptr, out_total, hipMemcpyDeviceToHost));
+}
+
 }  // namespace
 }  // namespace smx
 
@@ -929,6 +988,32 @@ int smx_mel_spectrogram_f32_dev(const smx_stft_config *sc, const smx_mel_config 
   });
 }
 
+
+// ---- Soundml.mfcc (soundml.ml:50-95) --------------------------------------------------------------
+int smx_mfcc_f32(const smx_stft_config *sc, const smx_mel_config *mc, const float *x, int64_t lead, int64_t n,
+                 int64_t n_mfcc, int has_lifter, double lifter, float *out) {
+  return guarded([&] {
+    check_config(sc, "mfcc");
+    check_config(mc, "mfcc");
+    mfcc_host(*sc, *mc, x, 4, lead, n, n_mfcc, has_lifter, lifter, out);
+  });
+}
+int smx_mfcc_f64(const smx_stft_config *sc, const smx_mel_config *mc, const double *x, int64_t lead, int64_t n,
+                 int64_t n_mfcc, int has_lifter, double lifter, double *out) {
+  return guarded([&] {
+    check_config(sc, "mfcc");
+    check_config(mc, "mfcc");
+    mfcc_host(*sc, *mc, x, 8, lead, n, n_mfcc, has_lifter, lifter, out);
+  });
+}
+int smx_mfcc_f32_dev(const smx_stft_config *sc, const smx_mel_config *mc, const float *d_x, int64_t lead, int64_t n,
+                     int64_t x_stride, int64_t n_mfcc, int has_lifter, double lifter, float *d_out, void *stream) {
+  return guarded([&] {
+    check_config(sc, "mfcc");
+    check_config(mc, "mfcc");
+    mfcc_dev(*sc, *mc, d_x, 4, lead, n, x_stride, n_mfcc, has_lifter, lifter, d_out, (hipStream_t)stream);
+  });
+}
 
 // ---- least-squares synthesis: Stft.invert (stft.ml:902-939) ----------------------------------------
 int smx_stft_nola(const smx_stft_config *c, int *invertible) {

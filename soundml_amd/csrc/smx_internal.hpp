@@ -4,6 +4,8 @@
 
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
+#include <cmath>
 #include <cstdint>
 #include <map>
 #include <mutex>
@@ -188,6 +190,18 @@ struct MelJob {
   hipStream_t stream = nullptr;
 };
 void launch_mel_apply(const MelJob &job);         // mel.hip
+
+// log-mel + DCT tail of Soundml.mfcc (soundml.ml:50-95) on a device-resident mel spectrogram
+struct MfccJob {
+  const void *mel = nullptr;     // device [lead; n_mels; frames]
+  int elem_bytes = 4;
+  int64_t lead = 0, frames = 0;
+  int n_mels = 0, n_mfcc = 0;
+  double lifter = 0.0;           // 0: none
+  void *out = nullptr;           // device [lead; n_mfcc; frames]
+  hipStream_t stream = nullptr;
+};
+void launch_mfcc(const MfccJob &job);             // mfcc.hip
 
 struct MelSpecJob {
   StftJob stft;                  // out/out_stride unused; mode/power used

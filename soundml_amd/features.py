@@ -32,3 +32,31 @@ def mel_spectrogram(stft_config, mel_config, x, power: float = 2.0):
     fn = lib.smx_mel_spectrogram_f32 if b.bytes == 4 else lib.smx_mel_spectrogram_f64
     check(fn(stft_config._h, mel_config._h, b.ptr(), lead, n, float(power), out_ptr(out)))
     return b.wrap(out)
+
+
+def mfcc(stft_config, mel_config, x, n_mfcc: int = 20, lifter=None):
+    """``Soundml.mfcc stft mel ?n_mfcc ?lifter x`` (soundml.ml:50-95): log-mel spectrogram (80 dB clamp under the
+    maximum of the whole tensor), orthonormal DCT-II along the mel axis, optional sinusoidal lifter;
+    [...; n] -> [...; n_mfcc; frames] in x's dtype."""
+    has_lifter = lifter is not None
+    lift = float(lifter) if has_lifter else 0.0
+    if stft_config.fft_size != mel_config.fft_size or not (1 <= int(n_mfcc) <= mel_config.n_mels) or \
+            (has_lifter and not (lift >= 0.0 and lift != float("inf"))):
+        # the reference's checks come before the tensor is looked at (soundml.ml:51-70): let the ABI word them
+        check(lib.smx_mfcc_f32(stft_config._h, mel_config._h, None, 0, 0, int(n_mfcc), 1 if has_lifter else 0, lift, None))
+    b = Batch(x, "power_spectrum")
+    n = int(b.shape[-1])
+    lead_shape = b.shape[:-1]
+    lead = prod(lead_shape)
+    count = Stft.frames(stft_config, n)
+    out = b.empty(lead_shape + (int(n_mfcc), count))
+    if b.device:
+        if b.bytes != 4:
+            raise _lib.Failure("mfcc: device-resident float64 audio is not supported; pass a host array")
+        with b.device_guard():
+            check(lib.smx_mfcc_f32_dev(stft_config._h, mel_config._h, b.ptr(), lead, n, n, int(n_mfcc),
+                                       1 if has_lifter else 0, lift, out_ptr(out), b.stream()))
+        return out
+    fn = lib.smx_mfcc_f32 if b.bytes == 4 else lib.smx_mfcc_f64
+    check(fn(stft_config._h, mel_config._h, b.ptr(), lead, n, int(n_mfcc), 1 if has_lifter else 0, lift, out_ptr(out)))
+    return b.wrap(out)

@@ -430,6 +430,63 @@ def test_fused_mel_spectrogram_vs_oracle(n_mels, sr, n, lead, power):
     assert np.array_equal(S.mel_spectrogram(sc, mc, torch.from_numpy(x).cuda(), power).cpu().numpy(), got)
 
 
+
+# ---- log-mel / MFCC tail -----------------------------------------------------------------------------------
+
+def test_mfcc_goldens():
+    """librosa.feature.mfcc vectors of the reference (mel_goldens.ml:131-158) on the HIP path, the reference's
+    tolerances; float32 cases with the float64 STFT interior (its contract) and with the float32 one."""
+    from conftest import check_close, load_golden
+    from test_oracle_goldens import _mfcc_case
+    for case in load_golden("mel", "mfcc")["cases"]:
+        sc, mc, x, n_mfcc, lifter = _mfcc_case(
+            case, lambda fft, **kw: Stft.Config.create(fft_size=fft, **kw),
+            lambda n_mels, sr, fft, **kw: Mel.Config.create(n_mels=n_mels, sample_rate=sr, fft_size=fft, **kw), O.lcg_signal)
+        f32 = case["params"]["dtype"] == "float32"
+        for interior in (("float64", "float32") if f32 else ("float64",)):
+            S.set_interior(interior)
+            got = S.mfcc(sc, mc, x, n_mfcc=n_mfcc, lifter=lifter)
+            assert got.dtype == (np.float32 if f32 else np.float64)
+            check_close(got, case["values"], shape=case["shape"], rtol=1e-4 if f32 else 1e-9,
+                        atol=1e-4 if f32 else 1e-9, msg=case["name"] + " " + interior)
+        S.set_interior("float32")
+
+
+@pytest.mark.parametrize("n_mfcc,lifter", [(20, None), (13, 22.0), (128, None)])
+def test_mfcc_vs_oracle_batch(n_mfcc, lifter):
+    """C3 geometry (fft 2048, 128 mels, fused mel kernel underneath), a batch with very different levels so that
+    the 80 dB clamp under the GLOBAL maximum acts on the quiet clips; device-resident input gives the host result."""
+    import torch
+    rng = np.random.default_rng(77)
+    x = rng.uniform(-1, 1, size=(3, 30000)).astype(np.float32)
+    x[1] *= 1e-3
+    x[2, 15000:] = 0.0
+    sc = Stft.Config.create(fft_size=2048, hop=512)
+    mc = Mel.Config.create(n_mels=128, sample_rate=48000, fft_size=2048)
+    want = O.mfcc(O.stft_config(2048, hop=512), O.mel_config(128, 48000, 2048), x, n_mfcc, lifter)
+    got = S.mfcc(sc, mc, x, n_mfcc=n_mfcc, lifter=lifter)
+    assert got.shape == want.shape == (3, n_mfcc, 59) and got.dtype == np.float32
+    np.testing.assert_allclose(got, want, rtol=1e-4, atol=2e-3)   # log domain: 1e-5 relative on a power is 4e-5 dB per band
+    gd = S.mfcc(sc, mc, torch.from_numpy(x).cuda(), n_mfcc=n_mfcc, lifter=lifter)
+    assert gd.is_cuda and np.array_equal(gd.cpu().numpy(), got)
+
+
+def test_mfcc_messages():
+    sc = Stft.Config.create(fft_size=512, hop=128)
+    mc = Mel.Config.create(n_mels=40, sample_rate=22050, fft_size=512)
+    x = np.zeros(1000, np.float32)
+    with pytest.raises(S.InvalidArgument) as e:
+        S.mfcc(sc, mc, x, n_mfcc=41)
+    assert str(e.value) == "mfcc: cannot keep 41 cepstral coefficients of 40 mel bands (n_mfcc must lie in [1, n_mels])"
+    with pytest.raises(S.InvalidArgument) as e:
+        S.mfcc(sc, mc, x, lifter=-1.0)
+    assert str(e.value) == "mfcc: cannot lifter with a coefficient of -1 (lifter must be finite and non-negative)"
+    with pytest.raises(S.InvalidArgument) as e:
+        S.mfcc(Stft.Config.create(fft_size=256, hop=64), mc, x)
+    assert str(e.value).startswith("mfcc: cannot project a 256-point STFT through a filterbank built for an FFT of size 512")
+    assert S.mfcc(sc, mc, np.zeros((0, 1000), np.float32)).shape == (0, 20, Stft.frames(sc, 1000))
+
+
 # ---- FIR ---------------------------------------------------------------------------------------------
 
 @pytest.mark.parametrize("taps,n,ch", [(63, 5000, 2), (1, 100, 1), (8192, 60000, 2), (1000, 1, 1), (257, 16384 * 3, 3)])

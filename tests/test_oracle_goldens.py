@@ -99,6 +99,28 @@ def test_mel_spectrogram():
 
 # --- structural laws of the reference restated on the oracle -------------------------------
 
+def _mfcc_case(case, make_stft, make_mel, lcg):
+    p = case["params"]
+    sc = make_stft(p["fft_size"], hop=p["hop"], alignment=p["alignment"])
+    mc = make_mel(p["n_mels"], p["sample_rate"], p["fft_size"], f_min=p["f_min"], f_max=p["f_max"],
+                  scale=p["scale"], norm=p["norm"])
+    x = lcg(p["length"], 20260803, envelope=p["envelope"])     # mel_goldens.ml:34-42
+    if p["dtype"] == "float32":
+        x = x.astype(np.float32)
+    return sc, mc, x, p["n_mfcc"], (None if p["lifter"] == 0.0 else p["lifter"])
+
+
+def test_mfcc_goldens():
+    """Soundml.mfcc restated (oracle.mfcc) against librosa.feature.mfcc vectors (mel_goldens.ml:131-158):
+    float64 rtol 1e-9 / atol 1e-9, float32 1e-4 / 1e-4 as the reference sets them."""
+    for case in load_golden("mel", "mfcc")["cases"]:
+        sc, mc, x, n_mfcc, lifter = _mfcc_case(case, lambda fft, **kw: O.stft_config(fft, **kw), O.mel_config, O.lcg_signal)
+        got = O.mfcc(sc, mc, x, n_mfcc, lifter)
+        f32 = case["params"]["dtype"] == "float32"
+        check_close(got, case["values"], shape=case["shape"], rtol=1e-4 if f32 else 1e-9, atol=1e-4 if f32 else 1e-9,
+                    msg=case["name"])
+
+
 @pytest.mark.parametrize("vectors", ["inverse_fft2048_hop512", "inverse_fft64_hop16"])
 def test_istft_goldens(vectors):
     """Stft.invert restated (oracle.invert) against the reference's librosa-0.11 synthesis vectors
