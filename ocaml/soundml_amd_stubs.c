@@ -192,3 +192,67 @@ CAMLprim value soundml_amd_mel_spectrogram_bc(value *argv, int argn) {
   (void)argn;
   return soundml_amd_mel_spectrogram(argv[0], argv[1], argv[2], argv[3], argv[4], argv[5], argv[6]);
 }
+
+/* Stft.invert (stft.ml:902-939): z is the complex spectrum [lead; bins; frames] as a flat Bigarray of
+   complex32 / complex64 (interleaved components), out [lead; out_len]; length < 0 = not given */
+CAMLprim value soundml_amd_stft_invert(value v_cfg, value v_z, value v_out, value v_lead, value v_bins,
+                                       value v_frames, value v_length) {
+  CAMLparam5(v_cfg, v_z, v_out, v_lead, v_bins);
+  CAMLxparam2(v_frames, v_length);
+  const smx_stft_config *c = Stft_val(v_cfg);
+  const int64_t lead = Long_val(v_lead), bins = Long_val(v_bins), frames = Long_val(v_frames);
+  const int64_t length = Long_val(v_length);
+  const int has_length = length >= 0;
+  const int zkind = ba_kind(v_z), okind = ba_kind(v_out);
+  const int wide = zkind == CAML_BA_COMPLEX64;
+  if ((zkind != CAML_BA_COMPLEX32 && zkind != CAML_BA_COMPLEX64) || okind != (wide ? CAML_BA_FLOAT64 : CAML_BA_FLOAT32))
+    caml_failwith("soundml_amd: unsupported or mixed dtypes");
+  int64_t out_len = length;
+  if (!has_length) smx_raise(smx_stft_output_length(c, frames < 0 ? 0 : frames, &out_len));
+  if (lead < 0 || bins < 0 || frames < 0 || ba_dim(v_z) < lead * bins * frames || ba_dim(v_out) < lead * out_len)
+    caml_failwith("soundml_amd: buffer extents disagree with geometry");
+  void *z = Caml_ba_data_val(v_z), *out = Caml_ba_data_val(v_out);
+  int status;
+  caml_release_runtime_system();
+  status = wide ? smx_stft_invert_f64(c, (const double *)z, lead, bins, frames, has_length, length, (double *)out)
+                : smx_stft_invert_f32(c, (const float *)z, lead, bins, frames, has_length, length, (float *)out);
+  caml_acquire_runtime_system();
+  smx_raise(status);
+  CAMLreturn(Val_unit);
+}
+CAMLprim value soundml_amd_stft_invert_bc(value *argv, int argn) {
+  (void)argn;
+  return soundml_amd_stft_invert(argv[0], argv[1], argv[2], argv[3], argv[4], argv[5], argv[6]);
+}
+
+/* Soundml.mfcc (soundml.ml:50-95): lifter < 0 = not given (the OCaml side validates the user's value first) */
+CAMLprim value soundml_amd_mfcc(value v_stft, value v_mel, value v_x, value v_out, value v_lead, value v_n,
+                                value v_n_mfcc, value v_lifter) {
+  CAMLparam5(v_stft, v_mel, v_x, v_out, v_lead);
+  CAMLxparam3(v_n, v_n_mfcc, v_lifter);
+  const smx_stft_config *sc = Stft_val(v_stft);
+  const smx_mel_config *mc = Mel_val(v_mel);
+  const int64_t lead = Long_val(v_lead), n = Long_val(v_n), n_mfcc = Long_val(v_n_mfcc);
+  const double lifter = Double_val(v_lifter);
+  const int has_lifter = lifter >= 0.0;
+  const int kind = ba_kind(v_x);
+  if ((kind != CAML_BA_FLOAT32 && kind != CAML_BA_FLOAT64) || ba_kind(v_out) != kind)
+    caml_failwith("soundml_amd: unsupported or mixed dtypes");
+  int64_t frames = 0;
+  smx_raise(smx_stft_frames(sc, n, &frames));
+  if (lead < 0 || n_mfcc < 0 || ba_dim(v_x) < lead * n || ba_dim(v_out) < lead * n_mfcc * frames)
+    caml_failwith("soundml_amd: buffer extents disagree with geometry");
+  void *x = Caml_ba_data_val(v_x), *out = Caml_ba_data_val(v_out);
+  int status;
+  caml_release_runtime_system();
+  status = kind == CAML_BA_FLOAT32
+               ? smx_mfcc_f32(sc, mc, (const float *)x, lead, n, n_mfcc, has_lifter, lifter, (float *)out)
+               : smx_mfcc_f64(sc, mc, (const double *)x, lead, n, n_mfcc, has_lifter, lifter, (double *)out);
+  caml_acquire_runtime_system();
+  smx_raise(status);
+  CAMLreturn(Val_unit);
+}
+CAMLprim value soundml_amd_mfcc_bc(value *argv, int argn) {
+  (void)argn;
+  return soundml_amd_mfcc(argv[0], argv[1], argv[2], argv[3], argv[4], argv[5], argv[6], argv[7]);
+}

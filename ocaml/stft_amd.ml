@@ -76,3 +76,23 @@ let power_spectrum ?(power = 2.) (c : Stft.Config.t) x =
   if lead > 0 && count > 0 then
     stft_range_c (handle_of_config c) (flat x) (Nx_buffer.to_bigarray1 (Nx.to_buffer out)) lead n 0 count 1 power ;
   out
+
+external stft_invert_c :
+  stft_handle -> ('a, 'b, Bigarray.c_layout) Bigarray.Array1.t ->
+  ('c, 'd, Bigarray.c_layout) Bigarray.Array1.t -> int -> int -> int -> int -> unit
+  = "soundml_amd_stft_invert_bc" "soundml_amd_stft_invert"
+
+(* Replaces the body of stft.ml:902-939 [synthesise] under [invert]: [check_synthesis] stays in OCaml (the C
+   side repeats it with the same messages), the output is allocated here. *)
+let invert dtype (c : Stft.Config.t) ?length z =
+  let shape = Nx.shape z in
+  let nd = Array.length shape in
+  let bins = shape.(nd - 2) and frames = shape.(nd - 1) in
+  let batch = Array.sub shape 0 (nd - 2) in
+  let lead = Array.fold_left ( * ) 1 batch in
+  let out_len = match length with Some n -> n | None -> Stft.output_length c ~frames in
+  let out = Nx.zeros dtype (Array.append batch [|out_len|]) in
+  if lead > 0 && out_len > 0 then
+    stft_invert_c (handle_of_config c) (flat z) (Nx_buffer.to_bigarray1 (Nx.to_buffer out)) lead bins frames
+      (match length with Some n -> n | None -> -1) ;
+  out
