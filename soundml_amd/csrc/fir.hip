@@ -68,112 +68,6 @@ struct FirArgs {
 
 using namespace fftdev;
 
-__device__ __forceinline__ int swz(int a) { return a ^ ((a >> 5) & 31); }
-
-// powers w^1 .. w^(R-1) of a unit twiddle by binary multiplication (depth <= 4)
-template <int R>
-__device__ __forceinline__ void twiddle_powers(c32 w1, c32 (&w)[16]) {
-  w[1] = w1;
-  if constexpr (R >= 4) {
-    w[2] = cmul(w1, w1);
-    w[3] = cmul(w[2], w1);
-  }
-  if constexpr (R >= 16) {
-    w[4] = cmul(w[2], w[2]);
-    w[5] = cmul(w[4], w1);
-    w[6] = cmul(w[4], w[2]);
-    w[7] = cmul(w[4], w[3]);
-    w[8] = cmul(w[4], w[4]);
-#pragma unroll
-    for (int j = 9; j < 16; ++j) w[j] = cmul(w[8], w[j - 8]);
-  }
-}
-
-// One Stockham pass of radix R with sub-transform size NS (see tools/sim_fir_fft.py).
-// r[i*R + j] is element j of radix group i (G = 16/R groups per thread, t_i = tid + T*i).
-// READ: registers come from LDS (false for the very first pass: they hold the loaded samples);
-// WRITE: results go back to LDS at the autosort positions (false for the last pass of a transform,
-// whose outputs stay in registers with natural index out_index<R,NS>(tid, i, j)).
-template <int N, int R, int NS, bool READ, bool WRITE>
-__device__ __forceinline__ void stockham_pass(c32 (&r)[16], float2 *z, int tid, const float2 *tw) {
-  constexpr int T = N / 16, G = 16 / R;
-  if constexpr (READ) {
-    __syncthreads();   // the previous pass's writes are visible
-#pragma unroll
-    for (int i = 0; i < G; ++i)
-#pragma unroll
-      for (int j = 0; j < R; ++j) {
-        const float2 v = z[swz(tid + T * (i + G * j))];
-        r[i * R + j] = {v.x, v.y};
-      }
-    __syncthreads();   // everyone holds its points: the buffer may be overwritten
-  }
-#pragma unroll
-  for (int i = 0; i < G; ++i) {
-    if constexpr (NS > 1) {
-      const int k = (tid + T * i) % NS;
-      const float2 w1 = tw[k * (N / (NS * R))];
-      c32 w[16];
-      twiddle_powers<R>(c32{w1.x, w1.y}, w);
-#pragma unroll
-      for (int j = 1; j < R; ++j) r[i * R + j] = cmul(r[i * R + j], w[j]);
-    }
-    if constexpr (R == 16) {
-      fft16(r);
-    } else if constexpr (R == 4) {
-      fft4(r[4 * i], r[4 * i + 1], r[4 * i + 2], r[4 * i + 3]);
-    } else {
-      const c32 u = r[2 * i], v = r[2 * i + 1];
-      r[2 * i] = u + v;
-      r[2 * i + 1] = u - v;
-    }
-  }
-  if constexpr (WRITE) {
-#pragma unroll
-    for (int i = 0; i < G; ++i) {
-      const int t = tid + T * i, k = t % NS;
-      const int j0 = (t / NS) * NS * R + k;
-#pragma unroll
-      for (int j = 0; j < R; ++j) z[swz(j0 + j * NS)] = make_float2(r[i * R + j].x, r[i * R + j].y);
-    }
-  }
-}
-
-template <int R, int NS, int T>
-__device__ __forceinline__ int out_index(int tid, int i, int j) {
-  const int t = tid + T * i, k = t % NS;
-  return (t / NS) * NS * R + k + j * NS;
-}
-
-// forward FFT of the 16 points per thread; FIRST: registers already hold element tid + T*m in r[m].
-// On return r[i*R + j] (last radix R, its NS) holds natural-order element out_index<R, NS, T>(tid, i, j).
-template <int LOG2N, bool FIRST>
-__device__ __forceinline__ void fft_passes(c32 (&r)[16], float2 *z, int tid, const float2 *tw) {
-  constexpr int N = 1 << LOG2N;
-  stockham_pass<N, 16, 1, !FIRST, true>(r, z, tid, tw);
-  stockham_pass<N, 16, 16, true, true>(r, z, tid, tw);
-  if constexpr (LOG2N == 10) {
-    stockham_pass<N, 4, 256, true, false>(r, z, tid, tw);
-  } else if constexpr (LOG2N == 11) {
-    stockham_pass<N, 4, 256, true, true>(r, z, tid, tw);
-    stockham_pass<N, 2, 1024, true, false>(r, z, tid, tw);
-  } else if constexpr (LOG2N == 12) {
-    stockham_pass<N, 16, 256, true, false>(r, z, tid, tw);
-  } else if constexpr (LOG2N == 13) {
-    stockham_pass<N, 16, 256, true, true>(r, z, tid, tw);
-    stockham_pass<N, 2, 4096, true, false>(r, z, tid, tw);
-  } else {
-    stockham_pass<N, 16, 256, true, true>(r, z, tid, tw);
-    stockham_pass<N, 4, 4096, true, false>(r, z, tid, tw);
-  }
-}
-
-template <int LOG2N>
-struct LastPass {   // radix / sub-size of the final pass of fft_passes<LOG2N>
-  static constexpr int R = (LOG2N == 10 || LOG2N == 14) ? 4 : (LOG2N == 12 ? 16 : 2);
-  static constexpr int NS = (1 << LOG2N) / R;
-};
-
 template <int LOG2N>
 __global__ void __launch_bounds__((1 << LOG2N) / 16) fir_ols_kernel(FirArgs a) {
   constexpr int N = 1 << LOG2N, T = N / 16;

@@ -11,6 +11,9 @@
 //                        stft.ml:806-831), divides by the envelope and trims / zero-extends.
 // No atomics: the sum is deterministic.  The envelope (partial sums on both borders, one period of the
 // folded squared window in between, stft.ml:836-889) is built on the host in float64 and uploaded.
+#include <cstdlib>
+
+#include "fft_device.hpp"
 #include "smx_internal.hpp"
 
 namespace smx {
@@ -137,6 +140,128 @@ __global__ void __launch_bounds__(256) istft_ola_kernel(OlaArgs a) {
   out[m] = (Tout)((double)acc / env);
 }
 
+
+// ---- fused synthesis for fft 2048 / hop 512, float32 interior --------------------------------------------
+// One workgroup = 16 waves = 16 consecutive frames f_lo .. f_lo + 15, of which it completes the 13 hops of output
+// that need no other frame: padded positions [512 (f_lo + 3), 512 (f_lo + 16)).  Tiles therefore advance by 13
+// frames and re-invert 3 (19 % more transforms) in exchange for no carry between workgroups, no atomics and the
+// reference's summation order (frame index descending) at every position.
+//   1. the [1025; 16] block of the spectrum goes through LDS (rows are 128 contiguous bytes in memory);
+//   2. wave f reads column f and the mirrored column, forms the half-size spectrum
+//      Z'[k] = E + i conj(w_k) D,  E = Z[k] + conj Z[M-k],  D = Z[k] - conj Z[M-k]   (the inverse of the
+//      analysis post-pass; 1/2 and 1/M are in the synthesis window), M = 1024;
+//   3. z = conj(FFT_M(conj Z')) by the Stockham passes of fft_device.hpp in a wave-private 8 KB buffer;
+//   4. x[2n] + i x[2n+1] = z[n], windowed, stays in that buffer as the wave's 2048 samples;
+//   5. every thread gathers 6-7 output positions from the <= 4 frames that reach them, divides by the
+//      envelope and stores: 26 KB of contiguous output per workgroup.
+constexpr int kSynM = 1024, kSynFrames = 16, kSynHops = 13;
+constexpr int kSynStride = kSynFrames + 1;                       // plane row stride (floats)
+constexpr size_t kSynPlane = (size_t)(kSynM + 1) * kSynStride * sizeof(float);          // 69,700
+constexpr size_t kSynRegionA = 2 * kSynPlane > (size_t)kSynFrames * kSynM * 8 ? 2 * kSynPlane : (size_t)kSynFrames * kSynM * 8;
+constexpr size_t kSynLds = ((kSynRegionA + 15) / 16) * 16 + (size_t)kSynM * sizeof(float2);
+
+struct SynArgs {
+  const float2 *z;       // [lead; 1025; frames]
+  float *out;            // [lead; out_len]
+  int64_t frames, count, out_len, left, span;
+  int tiles_per_clip;
+  const float2 *w_m, *w_n, *synth_window;
+  const double *env_head, *env_period, *env_tail;
+  int64_t head, stop;
+};
+
+__global__ void __launch_bounds__(1024) istft2048_kernel(SynArgs a) {
+  using namespace fftdev;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  float *re = reinterpret_cast<float *>(smem);
+  float *im = re + (kSynM + 1) * kSynStride;
+  float2 *swin = reinterpret_cast<float2 *>(smem + ((kSynRegionA + 15) / 16) * 16);
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int64_t clip = blockIdx.x / a.tiles_per_clip;
+  const int tile = blockIdx.x % a.tiles_per_clip;
+  const int64_t f_lo = (int64_t)kSynHops * tile - 3;
+  const float2 *z = a.z + clip * (int64_t)(kSynM + 1) * a.frames;
+  swin[tid] = a.synth_window[tid];
+  // 1. stage: element e = (row, frame) with the frame fastest: 16 lanes read one 128-byte row piece
+#pragma unroll
+  for (int i = 0; i < 17; ++i) {
+    const int e = tid + 1024 * i;
+    const int row = e >> 4, f = e & 15;
+    if (row <= kSynM) {
+      const int64_t p = f_lo + f;
+      float2 v = make_float2(0.f, 0.f);
+      if (p >= 0 && p < a.count) v = z[(int64_t)row * a.frames + p];
+      re[row * kSynStride + f] = v.x;
+      im[row * kSynStride + f] = v.y;
+    }
+  }
+  __syncthreads();
+  // 2. half-size spectrum of frame `wave`, conjugated for the conj(FFT(conj .)) inverse
+  const bool have = f_lo + wave >= 0 && f_lo + wave < a.count;   // wave-uniform
+  c32 r[16];
+#pragma unroll
+  for (int m = 0; m < 16; ++m) {
+    const int k = lane + 64 * m, km = kSynM - k;
+    float zr = re[k * kSynStride + wave], zi = im[k * kSynStride + wave];
+    float pr = re[km * kSynStride + wave], pi = im[km * kSynStride + wave];
+    if (k == 0) { zi = 0.f; pi = 0.f; }             // the imaginary parts of the DC and Nyquist bins do not take part
+    const float er = zr + pr, ei = zi - pi;           // E = Z[k] + conj Z[M-k]
+    const float dr = zr - pr, di = zi + pi;           // D = Z[k] - conj Z[M-k]
+    const float2 w = a.w_n[k];                        // exp(-2 pi i k / N); conj(w) = (w.x, -w.y)
+    // i conj(w) D = i (w.x - i w.y)(dr + i di) = i (w.x dr + w.y di) - (w.x di - w.y dr)
+    const float tr = er - (w.x * di - w.y * dr);
+    const float ti = ei + (w.x * dr + w.y * di);
+    r[m] = {tr, -ti};                                 // conj(Z')
+  }
+  __syncthreads();   // every column is in registers: the planes become the waves' private buffers
+  // 3. forward transform of conj(Z') in the wave's 8 KB buffer
+  float2 *buf = reinterpret_cast<float2 *>(smem) + wave * kSynM;
+  if (have) {
+    fft_passes<10, true, true>(r, buf, lane, a.w_m);
+    // 4. z[n] = conj(r) / M; samples 2n, 2n+1, windowed (the signs and 1/(2M) are in the table)
+    constexpr int RL = LastPass<10>::R, NSL = LastPass<10>::NS, GL = 16 / RL;
+    asm volatile("" ::: "memory");
+#pragma unroll
+    for (int i = 0; i < GL; ++i)
+#pragma unroll
+      for (int j = 0; j < RL; ++j) {
+        const int n = out_index<RL, NSL, 64>(lane, i, j);
+        const float2 w = swin[n];
+        buf[n] = make_float2(r[i * RL + j].x * w.x, r[i * RL + j].y * w.y);
+      }
+  }
+  __syncthreads();
+  // 5. overlap-add of the 13 complete hops: local position q in [1536, 8192)
+  const float *slots = reinterpret_cast<const float *>(smem);     // slot f = 2048 floats at f * 2048
+  float *out = a.out + clip * a.out_len;
+  const int64_t q0 = 512 * f_lo;
+#pragma unroll
+  for (int i = 0; i < 7; ++i) {
+    const int q = 1536 + tid + 1024 * i;
+    if (q < 512 * kSynFrames) {
+      const int64_t Q = q0 + q;                                    // padded position
+      const int64_t mo = Q - a.left;
+      if (mo >= 0 && mo < a.out_len) {
+        float v = 0.f;
+        if (Q < a.span) {
+          float acc = 0.f;
+          const int fh = q >> 9;
+#pragma unroll
+          for (int d = 0; d < 4; ++d) {                            // frame index descending (stft.ml:806-831)
+            const int f = fh - d;
+            const int64_t p = f_lo + f;
+            if (p >= 0 && p < a.count) acc += slots[f * 2048 + (q - 512 * f)];
+          }
+          const double env = Q < a.head ? a.env_head[Q] : (Q < a.stop ? a.env_period[Q & 511] : a.env_tail[Q - a.stop]);
+          v = (float)((double)acc / env);
+        }
+        out[mo] = v;
+      }
+    }
+  }
+}
+
 constexpr size_t kLdsLimit = 160 * 1024;
 
 template <typename Tz, typename Tacc>
@@ -194,6 +319,39 @@ void launch_istft(const IstftJob &job) {
   packed.push_back(1.0);
   SMX_HIP_CHECK(hipMemcpyAsync(d_env, packed.data(), packed.size() * sizeof(double), hipMemcpyHostToDevice, job.stream));
   SMX_HIP_CHECK(hipStreamSynchronize(job.stream));   // `packed` is pageable host memory that dies with this call
+  // fused path: fft 2048, hop 512, complex64 spectrum, float32 interior
+  static const bool fast_off = std::getenv("SMX_DISABLE_FAST") != nullptr;
+  if (!fast_off && !f64 && fft == 2048 && hop == 512 && job.lead <= 0x7fffffff / 4096) {
+    SynArgs sa{};
+    sa.z = reinterpret_cast<const float2 *>(job.z);
+    sa.out = reinterpret_cast<float *>(job.out);
+    sa.frames = job.frames;
+    sa.count = count;
+    sa.out_len = job.out_len;
+    sa.left = c.left_width();
+    sa.span = span;
+    // tiles cover padded positions [0, 512 * 13 * tiles): everything the output can ask for
+    const int64_t need = std::max<int64_t>(span, sa.left + job.out_len);
+    const int64_t tiles = (need + 512 * kSynHops - 1) / (512 * kSynHops);
+    sa.tiles_per_clip = (int)tiles;
+    sa.w_m = t.fast_w_m;
+    sa.w_n = t.fast_w_n;
+    sa.synth_window = t.fast_synth_window;
+    sa.env_head = d_env;
+    sa.env_period = d_env + head.size();
+    sa.env_tail = d_env + head.size() + period.size();
+    sa.head = head_n;
+    sa.stop = stop;
+    const int64_t blocks = job.lead * tiles;
+    if (blocks <= 0x7fffffff) {
+      SMX_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(istft2048_kernel),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)kSynLds));
+      hipLaunchKernelGGL(istft2048_kernel, dim3((unsigned)blocks), dim3(1024), kSynLds, job.stream, sa);
+      SMX_HIP_CHECK(hipGetLastError());
+      SMX_HIP_CHECK(hipFreeAsync(d_env, job.stream));
+      return;
+    }
+  }
   // clips in chunks so that the windowed frames y stay within ~1 GiB
   const size_t acc_bytes = f64 ? 8 : 4;
   const size_t per_clip = (size_t)count * (size_t)fft * acc_bytes;

@@ -59,6 +59,7 @@ struct StftTables {
   float *fast_window = nullptr;    // 0.5 * window, f32
   float2 *fast_w_m = nullptr;      // exp(-2 pi i j / M), j < M   (M = N/2)
   float2 *fast_w_n = nullptr;      // exp(-2 pi i k / N), k <= M
+  float2 *fast_synth_window = nullptr;   // (w[2j], -w[2j+1]) / (2M): synthesis window of the fast inverse kernel
 };
 
 }  // namespace smx

@@ -65,9 +65,15 @@ const smx::StftTables &smx_stft_config::tables() const {
       const double a = -2.0 * M_PI * (double)k / (double)n;
       wn[(size_t)k] = make_float2((float)std::cos(a), (float)std::sin(a));
     }
+    // synthesis: the window with the inverse transform's 1/(2M) and the conj(FFT(conj .)) sign folded in
+    std::vector<float2> sw((size_t)m);
+    for (int64_t j = 0; j < m; ++j)
+      sw[(size_t)j] = make_float2((float)(analysis_window[(size_t)(2 * j)] / (double)(2 * m)),
+                                  (float)(-analysis_window[(size_t)(2 * j + 1)] / (double)(2 * m)));
     t.fast_window = smx::upload(hw);
     t.fast_w_m = smx::upload(wm);
     t.fast_w_n = smx::upload(wn);
+    t.fast_synth_window = smx::upload(sw);
   }
   return tables_.emplace(device, t).first->second;
 }
@@ -82,6 +88,7 @@ smx_stft_config::~smx_stft_config() {
     (void)hipFree(t.fast_window);
     (void)hipFree(t.fast_w_m);
     (void)hipFree(t.fast_w_n);
+    (void)hipFree(t.fast_synth_window);
   }
 }
 

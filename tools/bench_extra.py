@@ -60,7 +60,13 @@ zc = torch.view_as_complex(out_c[:2]).cpu().numpy()
 wz = O.transform(O.stft_config(2048, hop=512), x[:2].cpu().numpy())
 print(json.dumps({"config": "C2 complex (Stft.transform)", "transform_ms": round(med_c, 4), "Mframes_per_s": round(256 * frames / med_c / 1e3, 1),
                   "GBs_algorithmic": round(256 * frames * 10248 / med_c / 1e6, 1), "max_rel_err_vs_oracle": rel_err(zc, wz)}))
-del out_c
+out_x = torch.empty(256, 480000, device="cuda")
+med_i, _ = timeit(lambda: check(lib.smx_stft_invert_f32_dev(sc._h, vp(out_c.data_ptr()), 256, 1025, frames, 1, 480000,
+                                                            vp(out_x.data_ptr()), None)), reps=10)
+print(json.dumps({"config": "C2 inverse (Stft.invert of the transform)", "invert_ms": round(med_i, 4),
+                  "Mframes_per_s": round(256 * frames / med_i / 1e3, 1), "GBs_algorithmic": round(256 * frames * 10248 / med_i / 1e6, 1),
+                  "max_abs_round_trip_err": float((out_x[:, 4096:-4096] - x[:, 4096:-4096]).abs().max())}))
+del out_c, out_x
 p = Stft.power_spectrum(sc, x)
 med_apply, _ = timeit(lambda: Mel.apply(mc, p), reps=10)
 m = S.mel_spectrogram(sc, mc, x[:2])
