@@ -190,6 +190,21 @@ int smx_mel_spectrogram_f32_dev(const smx_stft_config *sc, const smx_mel_config 
                                 const float *d_x, int64_t lead, int64_t n, int64_t x_stride,
                                 double power, float *d_out, void *stream);
 
+/* ---- Stft.griffin_lim (stft.ml:941-1017): phase reconstruction from magnitudes s [lead; bins; frames].
+ * c_k = analyse (synthesise (s * angles_k)),  angles_{k+1} = unit (c_k - a c_{k-1}),  a = momentum / (1 + momentum);
+ * the loop runs at the natural length, `length` applies to the final synthesis only.  init_phase (radians,
+ * same shape) or NULL for the all-ones phase.  out is [lead; out_len] as for smx_stft_invert_*.
+ * Invalid_argument: the synthesis checks, n_iter < 1, momentum < 0 (messages of stft.ml:963-976).           */
+int smx_stft_griffin_lim_f32(const smx_stft_config *c, const float *s, int64_t lead, int64_t bins, int64_t frames,
+                             int64_t n_iter, double momentum, const float *init_phase, int has_length,
+                             int64_t length, float *out);
+int smx_stft_griffin_lim_f64(const smx_stft_config *c, const double *s, int64_t lead, int64_t bins, int64_t frames,
+                             int64_t n_iter, double momentum, const double *init_phase, int has_length,
+                             int64_t length, double *out);
+int smx_stft_griffin_lim_f32_dev(const smx_stft_config *c, const float *d_s, int64_t lead, int64_t bins,
+                                 int64_t frames, int64_t n_iter, double momentum, const float *d_init_phase,
+                                 int has_length, int64_t length, float *d_out, void *stream);
+
 /* ---- Soundml.mfcc (soundml.ml:50-95): mel_spectrogram (power 2) -> power_to_db with the 80 dB clamp under
  * the maximum of the WHOLE tensor (convert.ml:30-50) -> orthonormal DCT-II along the mel axis, first n_mfcc
  * rows -> optional sinusoidal lifter.  float64 interior after the mel spectrogram, one rounding to the audio

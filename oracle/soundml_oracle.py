@@ -555,19 +555,15 @@ def overlap_add(c: StftConfig, windowed: np.ndarray) -> np.ndarray:
     return total.reshape(lead + ((count + blocks - 1) * hop,))[..., :(count - 1) * hop + fft]
 
 
-def invert(c: StftConfig, z: np.ndarray, length: Optional[int] = None, dtype=None) -> np.ndarray:
-    """``Stft.invert dtype c ?length z`` (stft.ml:902-939): float64 interior whatever the dtypes."""
-    z = np.asarray(z)
-    _check_synthesis("invert", c, z, length)
-    if dtype is None:
-        dtype = np.float32 if z.dtype == np.complex64 else np.float64
+def synthesise(c: StftConfig, z: np.ndarray, length: Optional[int] = None) -> np.ndarray:
+    """stft.ml:902-931 on a checked complex128 spectrum: float64 signal [...; out_len]."""
     fft, hop, left = c.fft_size, c.hop, left_width(c)
     total_frames = z.shape[-1]
     lead = z.shape[:-2]
     out_len = length if length is not None else output_length(c, total_frames)
     count = total_frames if length is None else min(total_frames, _ceil_div(length + left, hop))
     if count == 0 or out_len == 0 or any(d == 0 for d in lead):
-        return np.zeros(lead + (out_len,), dtype=dtype)
+        return np.zeros(lead + (out_len,), dtype=np.float64)
     z = z[..., :count].astype(np.complex128)
     span = (count - 1) * hop + fft
     y = np.fft.irfft(np.swapaxes(z, -1, -2), n=fft, axis=-1)         # [..; count; fft]
@@ -577,7 +573,51 @@ def invert(c: StftConfig, z: np.ndarray, length: Optional[int] = None, dtype=Non
     y = y[..., left:stop]
     if stop - left != out_len:
         y = np.concatenate([y, np.zeros(lead + (out_len - (stop - left),), dtype=np.float64)], axis=-1)
-    return y.astype(dtype)
+    return y
+
+
+def invert(c: StftConfig, z: np.ndarray, length: Optional[int] = None, dtype=None) -> np.ndarray:
+    """``Stft.invert dtype c ?length z`` (stft.ml:933-939): float64 interior whatever the dtypes."""
+    z = np.asarray(z)
+    _check_synthesis("invert", c, z, length)
+    if dtype is None:
+        dtype = np.float32 if z.dtype == np.complex64 else np.float64
+    return synthesise(c, z, length).astype(dtype)
+
+
+def griffin_lim(c: StftConfig, s: np.ndarray, n_iter: int = 32, momentum: float = 0.99, init=None,
+                length: Optional[int] = None) -> np.ndarray:
+    """``Stft.griffin_lim`` (stft.ml:941-1017): c_k = analyse (synthesise (S angles_k)),
+    angles_{k+1} = unit (c_k - a c_{k-1}), a = mu / (1 + mu); all-ones initial phase unless ``init`` (radians)."""
+    s = np.asarray(s)
+    _check_synthesis("griffin_lim", c, s, length)
+    if n_iter < 1:
+        raise ValueError("griffin_lim: cannot run %d iterations (n_iter must be at least 1)" % n_iter)
+    if momentum < 0.0:
+        raise ValueError("griffin_lim: cannot use a momentum of %s (momentum must be non-negative)" % _g(momentum))
+    dtype = s.dtype if s.dtype in (np.float32, np.float64) else np.float32
+    magnitudes = s.astype(np.float64).astype(np.complex128)
+    if init is None:
+        angles = np.ones(s.shape, dtype=np.complex128)
+    else:
+        p = np.asarray(init)
+        if p.shape != s.shape:
+            raise ValueError(
+                "griffin_lim: cannot start from a [%s] phase for a [%s] spectrogram (the initial phase must "
+                "have the shape of the magnitudes)" % ("; ".join(map(str, p.shape)), "; ".join(map(str, s.shape))))
+        p = p.astype(np.float64)
+        angles = np.cos(p) + 1j * np.sin(p)
+    frames_ = s.shape[-1]
+    beta = momentum / (1.0 + momentum)
+    iterate = output_length(c, frames_) > 0 and frames_ > 0 and not any(d == 0 for d in s.shape[:-2])
+    previous = None
+    tiny = float(np.finfo(np.float64).tiny)
+    for _ in range(n_iter if iterate else 0):
+        rebuilt = transform_range(c, synthesise(c, magnitudes * angles), 0, frames_, np.complex128)
+        extrapolated = rebuilt if previous is None else rebuilt - previous * beta
+        angles = extrapolated / (np.abs(extrapolated) + tiny)
+        previous = rebuilt
+    return synthesise(c, magnitudes * angles, length).astype(dtype)
 
 
 # ----------------------------------------------------------------------------

@@ -89,6 +89,9 @@ SIGNATURES = {
     "smx_stft_transform_range_f64_dev": (cint, [vp, vp, i64, i64, i64, i64, i64, vp, vp]),
     "smx_stft_power_range_f32_dev": (cint, [vp, vp, i64, i64, i64, i64, i64, f64, vp, vp]),
     "smx_stft_power_range_f64_dev": (cint, [vp, vp, i64, i64, i64, i64, i64, f64, vp, vp]),
+    "smx_stft_griffin_lim_f32": (cint, [vp, vp, i64, i64, i64, i64, f64, vp, cint, i64, vp]),
+    "smx_stft_griffin_lim_f64": (cint, [vp, vp, i64, i64, i64, i64, f64, vp, cint, i64, vp]),
+    "smx_stft_griffin_lim_f32_dev": (cint, [vp, vp, i64, i64, i64, i64, f64, vp, cint, i64, vp, vp]),
     "smx_mfcc_f32": (cint, [vp, vp, vp, i64, i64, i64, cint, f64, vp]),
     "smx_mfcc_f64": (cint, [vp, vp, vp, i64, i64, i64, cint, f64, vp]),
     "smx_mfcc_f32_dev": (cint, [vp, vp, vp, i64, i64, i64, i64, cint, f64, vp, vp]),

@@ -853,6 +853,118 @@ void mel_spectrogram_host(const smx_stft_config &sc, const smx_mel_config &mc, c
 }
 
 
+// Stft.griffin_lim (stft.ml:961-1017) on device-resident data: the reference's loop, its transforms replaced by
+// this library's synthesis and analysis launches, everything on `stream`.
+void griffin_lim_dev(const smx_stft_config &c, const void *d_s, int elem_bytes, int64_t lead, int64_t bins,
+                     int64_t frames, int64_t n_iter, double momentum, const void *d_phase, int has_length,
+                     int64_t length, void *d_out, hipStream_t stream) {
+  if (lead < 0 || frames < 0) throw Failure("griffin_lim: negative extent");
+  // check_synthesis "griffin_lim" (stft.ml:963), then the loop's own preconditions
+  if (bins != c.bins())
+    throw InvalidArgument(format(
+        "griffin_lim: cannot invert %lld frequency bins of a %lld-point transform (the bin axis must hold "
+        "fft_size / 2 + 1 = %lld values)",
+        (long long)bins, (long long)c.fft_size, (long long)c.bins()));
+  if (has_length && length < 0)
+    throw InvalidArgument(format("griffin_lim: cannot synthesise a signal of length %lld (length must be non-negative)",
+                                 (long long)length));
+  if (!stft_nola(c))
+    throw InvalidArgument(format(
+        "griffin_lim: cannot invert a %lld-point window advanced by %lld samples inside a %lld-point frame (the "
+        "overlap-added squared window must stay above 1e-10 of its largest value at every position)",
+        (long long)c.win_length, (long long)c.hop, (long long)c.fft_size));
+  if (n_iter < 1)
+    throw InvalidArgument(format("griffin_lim: cannot run %lld iterations (n_iter must be at least 1)", (long long)n_iter));
+  if (momentum < 0.0)
+    throw InvalidArgument(format("griffin_lim: cannot use a momentum of %g (momentum must be non-negative)", momentum));
+  const int64_t natural = stft_output_length(c, frames);
+  const int64_t out_len = has_length ? length : natural;
+  if (lead == 0 || out_len == 0) return;
+  if (!d_out || (frames > 0 && !d_s)) throw Failure("griffin_lim: null device pointer");
+  const int64_t total = lead * bins * frames;
+  if (elem_bytes == 4 && g_interior.load() == SMX_INTERIOR_F64) {
+    // the reference's loop is float64 throughout whatever the dtype of s (stft.ml:977, 1017): widen, run, narrow
+    double *s64 = nullptr, *p64 = nullptr, *o64 = nullptr;
+    const size_t n64 = (size_t)std::max<int64_t>(total, 1) * sizeof(double);
+    SMX_HIP_CHECK(hipMallocAsync((void **)&s64, n64, stream));
+    launch_gl_widen((const float *)d_s, s64, total, stream);
+    if (d_phase) {
+      SMX_HIP_CHECK(hipMallocAsync((void **)&p64, n64, stream));
+      launch_gl_widen((const float *)d_phase, p64, total, stream);
+    }
+    SMX_HIP_CHECK(hipMallocAsync((void **)&o64, (size_t)lead * (size_t)out_len * sizeof(double), stream));
+    griffin_lim_dev(c, s64, 8, lead, bins, frames, n_iter, momentum, p64, has_length, length, o64, stream);
+    launch_gl_narrow(o64, (float *)d_out, lead * out_len, stream);
+    for (void *ptr : {(void *)s64, (void *)p64, (void *)o64})
+      if (ptr) SMX_HIP_CHECK(hipFreeAsync(ptr, stream));
+    return;
+  }
+  const int z_bytes = 2 * elem_bytes;
+  auto synth = [&](const void *z, int has_len, int64_t len, void *out, int64_t olen) {
+    IstftJob job;
+    job.cfg = &c;
+    job.z = z;
+    job.z_bytes = z_bytes;
+    job.interior = elem_bytes == 8 ? SMX_INTERIOR_F64 : g_interior.load();
+    job.lead = lead;
+    job.frames = frames;
+    job.count = has_len ? std::min<int64_t>(frames, (len + c.left_width() + c.hop - 1) / c.hop) : frames;
+    job.out_len = olen;
+    job.out = out;
+    job.stream = stream;
+    launch_istft(job);
+  };
+  void *angles = nullptr, *zbuf = nullptr, *rebuilt = nullptr, *previous = nullptr, *signal = nullptr;
+  const size_t cbytes = (size_t)std::max<int64_t>(total, 1) * (size_t)z_bytes;
+  SMX_HIP_CHECK(hipMallocAsync(&angles, cbytes, stream));
+  SMX_HIP_CHECK(hipMallocAsync(&zbuf, cbytes, stream));
+  launch_gl_init(d_phase, angles, total, elem_bytes, stream);
+  const bool iterate = natural > 0 && frames > 0;   // stft.ml:993-996
+  if (iterate) {
+    SMX_HIP_CHECK(hipMallocAsync(&rebuilt, cbytes, stream));
+    SMX_HIP_CHECK(hipMallocAsync(&previous, cbytes, stream));
+    SMX_HIP_CHECK(hipMallocAsync(&signal, (size_t)lead * (size_t)natural * (size_t)elem_bytes, stream));
+    const double beta = momentum / (1.0 + momentum);
+    bool has_prev = false;
+    for (int64_t k = 0; k < n_iter; ++k) {
+      launch_gl_apply(d_s, angles, zbuf, total, elem_bytes, stream);
+      synth(zbuf, 0, 0, signal, natural);
+      stft_range_dev(c, signal, elem_bytes, lead, natural, natural, 0, frames, OUT_COMPLEX, 0.0, rebuilt, stream);
+      launch_gl_update(rebuilt, has_prev ? previous : nullptr, beta, angles, total, elem_bytes, stream);
+      std::swap(rebuilt, previous);   // previous <- rebuilt
+      has_prev = true;
+    }
+  }
+  launch_gl_apply(d_s, angles, zbuf, total, elem_bytes, stream);
+  synth(zbuf, has_length, length, d_out, out_len);
+  for (void *ptr : {angles, zbuf, rebuilt, previous, signal})
+    if (ptr) SMX_HIP_CHECK(hipFreeAsync(ptr, stream));
+}
+
+void griffin_lim_host(const smx_stft_config &c, const void *s, int elem_bytes, int64_t lead, int64_t bins,
+                      int64_t frames, int64_t n_iter, double momentum, const void *phase, int has_length,
+                      int64_t length, void *out) {
+  if (lead < 0 || frames < 0) throw Failure("griffin_lim: negative extent");
+  const int64_t out_len = has_length ? length : (frames >= 0 ? stft_output_length(c, frames) : 0);
+  const bool run = lead > 0 && out_len > 0 && bins == c.bins() && stft_nola(c) && n_iter >= 1 && momentum >= 0.0 &&
+                   !(has_length && length < 0);
+  if (!run) {   // the checks (and nothing else) run without a device
+    griffin_lim_dev(c, nullptr, elem_bytes, 0, bins, frames, n_iter, momentum, nullptr, has_length, length, nullptr, nullptr);
+    return;
+  }
+  if (!out || (frames > 0 && !s)) throw Failure("griffin_lim: null pointer");
+  require_device();
+  const size_t sb = (size_t)lead * (size_t)bins * (size_t)frames * (size_t)elem_bytes;
+  const size_t ob = (size_t)lead * (size_t)out_len * (size_t)elem_bytes;
+  DeviceScratch ds(sb), dp(phase ? sb : 16), dout(ob);
+  if (sb) SMX_HIP_CHECK(hipMemcpy(ds.ptr, s, sb, hipMemcpyHostToDevice));
+  if (phase && sb) SMX_HIP_CHECK(hipMemcpy(dp.ptr, phase, sb, hipMemcpyHostToDevice));
+  griffin_lim_dev(c, ds.ptr, elem_bytes, lead, bins, frames, n_iter, momentum, phase ? dp.ptr : nullptr, has_length,
+                  length, dout.ptr, nullptr);
+  SMX_HIP_CHECK(hipStreamSynchronize(nullptr));
+  SMX_HIP_CHECK(hipMemcpy(out, dout.ptr, ob, hipMemcpyDeviceToHost));
+}
+
 // Soundml.mfcc (soundml.ml:50-95): checks in the reference's order and words, then mel_spectrogram + the tail
 void check_mfcc(const smx_stft_config &sc, const smx_mel_config &mc, int64_t n_mfcc, int has_lifter, double lifter) {
   if (sc.fft_size != mc.fft_size)
@@ -988,6 +1100,33 @@ int smx_mel_spectrogram_f32_dev(const smx_stft_config *sc, const smx_mel_config 
   });
 }
 
+
+// ---- Stft.griffin_lim (stft.ml:961-1017) -----------------------------------------------------------
+int smx_stft_griffin_lim_f32(const smx_stft_config *c, const float *s, int64_t lead, int64_t bins, int64_t frames,
+                             int64_t n_iter, double momentum, const float *init_phase, int has_length,
+                             int64_t length, float *out) {
+  return guarded([&] {
+    check_config(c, "griffin_lim");
+    griffin_lim_host(*c, s, 4, lead, bins, frames, n_iter, momentum, init_phase, has_length, length, out);
+  });
+}
+int smx_stft_griffin_lim_f64(const smx_stft_config *c, const double *s, int64_t lead, int64_t bins, int64_t frames,
+                             int64_t n_iter, double momentum, const double *init_phase, int has_length,
+                             int64_t length, double *out) {
+  return guarded([&] {
+    check_config(c, "griffin_lim");
+    griffin_lim_host(*c, s, 8, lead, bins, frames, n_iter, momentum, init_phase, has_length, length, out);
+  });
+}
+int smx_stft_griffin_lim_f32_dev(const smx_stft_config *c, const float *d_s, int64_t lead, int64_t bins,
+                                 int64_t frames, int64_t n_iter, double momentum, const float *d_init_phase,
+                                 int has_length, int64_t length, float *d_out, void *stream) {
+  return guarded([&] {
+    check_config(c, "griffin_lim");
+    griffin_lim_dev(*c, d_s, 4, lead, bins, frames, n_iter, momentum, d_init_phase, has_length, length, d_out,
+                    (hipStream_t)stream);
+  });
+}
 
 // ---- Soundml.mfcc (soundml.ml:50-95) --------------------------------------------------------------
 int smx_mfcc_f32(const smx_stft_config *sc, const smx_mel_config *mc, const float *x, int64_t lead, int64_t n,

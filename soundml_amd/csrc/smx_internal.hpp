@@ -182,6 +182,14 @@ struct IstftJob {
 };
 void launch_istft(const IstftJob &job);           // istft.hip
 
+// elementwise steps of Stft.griffin_lim (griffinlim.hip); elem_bytes 4 = float32 / complex64, 8 = float64 / complex128
+void launch_gl_widen(const float *src, double *dst, int64_t total, hipStream_t stream);    // float32 -> float64
+void launch_gl_narrow(const double *src, float *dst, int64_t total, hipStream_t stream);   // float64 -> float32
+void launch_gl_init(const void *phase, void *angles, int64_t total, int elem_bytes, hipStream_t stream);
+void launch_gl_apply(const void *mag, const void *angles, void *z, int64_t total, int elem_bytes, hipStream_t stream);
+void launch_gl_update(const void *rebuilt, const void *previous, double beta, void *angles, int64_t total,
+                      int elem_bytes, hipStream_t stream);
+
 struct MelJob {
   const smx_mel_config *cfg = nullptr;
   const void *s = nullptr;       // device [lead; bins; frames]

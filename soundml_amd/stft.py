@@ -249,6 +249,59 @@ def invert(c: Config, z, length=None):
     return torch.from_numpy(out) if was_torch else out
 
 
+def griffin_lim(c: Config, s, n_iter: int = 32, momentum: float = 0.99, init=None, length=None):
+    """``Stft.griffin_lim ?n_iter ?momentum ?init ?length c s`` (stft.ml:941-1017): a signal whose spectrogram
+    magnitudes approach s [...; bins; frames].  ``init`` is an initial phase in radians (default: all-ones phase);
+    float32 magnitudes give a float32 signal.  A device (torch) spectrogram stays on the device."""
+    from ._tensor import is_device, is_torch, torch
+    shape = tuple(s.shape)
+    if len(shape) < 2:
+        raise _lib.InvalidArgument(
+            "griffin_lim: cannot invert a rank-%d tensor (the bin and frame axes must exist)" % len(shape))
+    bins, frames = int(shape[-2]), int(shape[-1])
+    lead_shape = shape[:-2]
+    lead = 1
+    for d in lead_shape:
+        lead *= int(d)
+    has_length = length is not None
+    if init is not None and tuple(init.shape) != shape:   # stft.ml:978-986, worded there
+        raise _lib.InvalidArgument(
+            "griffin_lim: cannot start from a [%s] phase for a [%s] spectrogram (the initial phase must have the "
+            "shape of the magnitudes)" % ("; ".join(map(str, init.shape)), "; ".join(map(str, shape))))
+    args_tail = (int(n_iter), float(momentum))
+    if is_device(s):
+        sd = s.contiguous().to(torch.float32)
+        pd = None if init is None else init.to(sd.device).contiguous().to(torch.float32)
+        check(lib.smx_stft_griffin_lim_f32_dev(c._h, None, 0, bins, frames, *args_tail, None, 1 if has_length else 0,
+                                               int(length) if has_length else 0, None, None))   # the checks first
+        out_len = int(length) if has_length else output_length(c, frames)
+        out = torch.zeros(lead_shape + (out_len,), dtype=torch.float32, device=sd.device)
+        with torch.cuda.device(sd.device):
+            stream = C.c_void_p(torch.cuda.current_stream(sd.device).cuda_stream)
+            check(lib.smx_stft_griffin_lim_f32_dev(c._h, C.c_void_p(sd.data_ptr()), lead, bins, frames, *args_tail,
+                                                   None if pd is None else C.c_void_p(pd.data_ptr()),
+                                                   1 if has_length else 0, out_len if has_length else 0,
+                                                   C.c_void_p(out.data_ptr()), stream))
+        return out
+    was_torch = is_torch(s)
+    a = s.detach().cpu().numpy() if was_torch else np.asarray(s)
+    if a.dtype not in (np.float32, np.float64):
+        a = a.astype(np.float32)
+    a = np.ascontiguousarray(a)
+    wide = a.dtype == np.float64
+    p = None
+    if init is not None:
+        p = np.ascontiguousarray(np.asarray(init.detach().cpu().numpy() if is_torch(init) else init, dtype=a.dtype))
+    fn = lib.smx_stft_griffin_lim_f64 if wide else lib.smx_stft_griffin_lim_f32
+    check(fn(c._h, None, 0, bins, frames, *args_tail, None, 1 if has_length else 0, int(length) if has_length else 0, None))
+    out_len = int(length) if has_length else output_length(c, frames)
+    out = np.zeros(lead_shape + (out_len,), dtype=a.dtype)
+    check(fn(c._h, C.c_void_p(a.ctypes.data), lead, bins, frames, *args_tail,
+             None if p is None else C.c_void_p(p.ctypes.data), 1 if has_length else 0,
+             out_len if has_length else 0, C.c_void_p(out.ctypes.data)))
+    return torch.from_numpy(out) if was_torch else out
+
+
 class Kernel:
     """``Stft.Kernel`` (stft.ml:597-622): streaming analysis with the carry held
     in device memory.  Chunks are host arrays [channels; m]; ``step`` / ``flush``

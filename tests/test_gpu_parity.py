@@ -16,6 +16,9 @@ import pytest
 from conftest import (F32_ATOL, F32_RTOL, F64_ATOL, F64_RTOL, check_close, load_golden)
 from oracle import soundml_oracle as O
 
+# every synthesis vector file of the reference (soundml/test/istft/vectors; Griffin-Lim files apart)
+ISTFT_FILES = ["inverse_fft2048_hop512", "inverse_fft64_hop16", "inverse_fft16_hop4", "inverse_fft2048_hop500_win1200", "inverse_fft31_hop5", "inverse_fft32_hop7", "inverse_fft32_hop8_win20", "inverse_fft64_hop17_win40", "lengths"]
+
 import soundml_amd as S
 from soundml_amd import Fir, Mel, Stft
 
@@ -305,7 +308,7 @@ def test_streaming_2048_float32():
 
 # ---- least-squares synthesis: Stft.invert --------------------------------------------------------------
 
-@pytest.mark.parametrize("vectors", ["inverse_fft2048_hop512", "inverse_fft64_hop16"])
+@pytest.mark.parametrize("vectors", ISTFT_FILES)
 def test_invert_goldens(vectors):
     """The reference's librosa-0.11 synthesis vectors (istft_goldens.ml) on the HIP path: float64 cases at the
     reference's float64 tolerance, float32 cases at its float32 tolerance with the float64 interior and at the
@@ -368,6 +371,63 @@ def test_invert_round_trip_and_device_path():
     yd = Stft.invert(c, zd, length=x.shape[-1])
     assert yd.is_cuda and np.array_equal(yd.cpu().numpy(), y)
     assert np.array_equal(Stft.invert(c, zd).cpu().numpy(), Stft.invert(c, z))
+
+
+GL_FILES = ["griffinlim_fft64_hop16", "griffinlim_fft64_hop16_win40", "griffinlim_fft512_hop128"]
+
+
+@pytest.mark.parametrize("vectors", GL_FILES)
+def test_griffin_lim_goldens(vectors):
+    """librosa.griffinlim vectors of the reference (gl_goldens.ml) on the HIP path: up to 32 synthesis / analysis
+    round trips, float64 at the reference's 1e-9 / 1e-12."""
+    from conftest import F32_ATOL, F32_RTOL, F64_ATOL, F64_RTOL, check_close, istft_golden_config, load_golden
+    from test_oracle_goldens import gl_golden_magnitudes
+    for case in load_golden("istft", vectors)["cases"]:
+        p = case["params"]
+        c = istft_golden_config(lambda fft, pad, pad_value, **kw: Stft.Config.create(fft_size=fft, pad=(pad, pad_value), **kw), p)
+        mag = gl_golden_magnitudes(p["fft_size"], p["frames"])
+        f32 = p["dtype"] == "float32"
+        if f32:
+            S.set_interior("float64")
+        got = Stft.griffin_lim(c, mag.astype(np.float32) if f32 else mag, n_iter=p["n_iter"], momentum=p["momentum"],
+                               length=p.get("length"))
+        S.set_interior("float32")
+        check_close(got, case["values"], shape=case["shape"], rtol=F32_RTOL if f32 else F64_RTOL,
+                    atol=F32_ATOL if f32 else F64_ATOL, msg=case["name"])
+
+
+def test_griffin_lim_fast_path_and_messages():
+    """fft 2048 / hop 512 float32 (fused synthesis + fused complex analysis kernels in the loop): the iteration is a
+    non-expansive map, so float32 rounding stays at the 1e-5 level of the signal's peak after 8 round trips; initial
+    phase, batch and device-resident inputs; the reference's messages."""
+    import torch
+    rng = np.random.default_rng(5)
+    x = rng.uniform(-1, 1, size=(2, 20000)).astype(np.float32)
+    c = Stft.Config.create(fft_size=2048, hop=512)
+    o = O.stft_config(2048, hop=512)
+    z = Stft.transform(c, x)
+    mag = np.abs(z).astype(np.float32)
+    phase = (np.angle(z) + 0.3 * rng.standard_normal(z.shape)).astype(np.float32)
+    want = O.griffin_lim(o, mag, 8, 0.99, phase, None)
+    got = Stft.griffin_lim(c, mag, n_iter=8, momentum=0.99, init=phase)
+    assert got.shape == want.shape and got.dtype == np.float32
+    # float32 round trips: 1e-4 of the peak on the interior; on the last fft_size samples of a clip the envelope
+    # falls to ~1e-4 of its interior value and divides the rounding of every pass (the reference's loop is
+    # float64 there -- set_interior("float64") reproduces it, see test_griffin_lim_goldens)
+    peak = np.max(np.abs(want))
+    assert np.max(np.abs(got - want)[:, 2048:-2048]) < 2e-4 * peak
+    assert np.linalg.norm(got - want) < 1e-3 * np.linalg.norm(want)
+    gd = Stft.griffin_lim(c, torch.from_numpy(mag).cuda(), n_iter=8, momentum=0.99, init=torch.from_numpy(phase).cuda())
+    assert gd.is_cuda and np.array_equal(gd.cpu().numpy(), got)
+    with pytest.raises(S.InvalidArgument) as e:
+        Stft.griffin_lim(c, mag, n_iter=0)
+    assert str(e.value) == "griffin_lim: cannot run 0 iterations (n_iter must be at least 1)"
+    with pytest.raises(S.InvalidArgument) as e:
+        Stft.griffin_lim(c, mag, momentum=-0.5)
+    assert str(e.value) == "griffin_lim: cannot use a momentum of -0.5 (momentum must be non-negative)"
+    with pytest.raises(S.InvalidArgument) as e:
+        Stft.griffin_lim(c, mag, init=phase[:1])
+    assert str(e.value).startswith("griffin_lim: cannot start from a [1; 1025; 40] phase for a [2; 1025; 40] spectrogram")
 
 
 # ---- Mel -------------------------------------------------------------------------------------------

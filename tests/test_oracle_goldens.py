@@ -9,6 +9,9 @@ from conftest import (F32_ATOL, F32_RTOL, F64_ATOL, F64_RTOL, check_close,
                       golden_cases, load_golden)
 from oracle import soundml_oracle as O
 
+# every synthesis vector file of the reference (soundml/test/istft/vectors; Griffin-Lim files apart)
+ISTFT_FILES = ["inverse_fft2048_hop512", "inverse_fft64_hop16", "inverse_fft16_hop4", "inverse_fft2048_hop500_win1200", "inverse_fft31_hop5", "inverse_fft32_hop7", "inverse_fft32_hop8_win20", "inverse_fft64_hop17_win40", "lengths"]
+
 STFT_FILES = ["fft16_hop4", "fft32_hop7", "fft64_hop16", "fft32_hop8_win20"]
 
 
@@ -121,7 +124,7 @@ def test_mfcc_goldens():
                     msg=case["name"])
 
 
-@pytest.mark.parametrize("vectors", ["inverse_fft2048_hop512", "inverse_fft64_hop16"])
+@pytest.mark.parametrize("vectors", ISTFT_FILES)
 def test_istft_goldens(vectors):
     """Stft.invert restated (oracle.invert) against the reference's librosa-0.11 synthesis vectors
     (soundml/test/istft/vectors, replayed by istft_goldens.ml with these tolerances)."""
@@ -133,6 +136,30 @@ def test_istft_goldens(vectors):
         f32 = p["dtype"] == "float32"
         got = O.invert(cfg, z.astype(np.complex64) if f32 else z, p.get("length"))
         assert got.dtype == (np.float32 if f32 else np.float64)
+        check_close(got, case["values"], shape=case["shape"], rtol=F32_RTOL if f32 else F64_RTOL,
+                    atol=F32_ATOL if f32 else F64_ATOL, msg=case["name"])
+
+
+GL_FILES = ["griffinlim_fft64_hop16", "griffinlim_fft64_hop16_win40", "griffinlim_fft512_hop128"]
+
+
+def gl_golden_magnitudes(fft_size, frames):
+    """gl_goldens.ml:36-38: one 31-bit LCG stream shifted into [0, 2)."""
+    bins = fft_size // 2 + 1
+    return (O.lcg_signal(bins * frames, 20250803) + 1.0).reshape(bins, frames)
+
+
+@pytest.mark.parametrize("vectors", GL_FILES)
+def test_griffin_lim_goldens(vectors):
+    """Stft.griffin_lim restated (oracle.griffin_lim) against librosa.griffinlim vectors at the deterministic
+    settings (all-ones initial phase, zero padding; gl_goldens.ml), the reference's float64 tolerance."""
+    from conftest import istft_golden_config
+    for case in load_golden("istft", vectors)["cases"]:
+        p = case["params"]
+        cfg = istft_golden_config(lambda fft, **kw: O.stft_config(fft, **kw), p)
+        mag = gl_golden_magnitudes(p["fft_size"], p["frames"])
+        f32 = p["dtype"] == "float32"
+        got = O.griffin_lim(cfg, mag.astype(np.float32) if f32 else mag, p["n_iter"], p["momentum"], None, p.get("length"))
         check_close(got, case["values"], shape=case["shape"], rtol=F32_RTOL if f32 else F64_RTOL,
                     atol=F32_ATOL if f32 else F64_ATOL, msg=case["name"])
 
