@@ -139,6 +139,11 @@ struct FastArgs {
   int tiles_per_clip;
   int64_t total_tiles;     // lead * tiles_per_clip: a flat (clip, tile) sequence
   int64_t blocks;          // persistent workgroups; each owns a contiguous range of the sequence
+  // power kernel: the frames that touch a border of the signal (reflect / edge / constant padding) are
+  // computed by the same launch, after the interior tiles (0 = none: they come as gathered strips)
+  int border_left, border_right;       // border frames per clip before / after the interior range
+  int64_t border_p0, border_i1;        // first frame of the request, first frame after the interior range
+  int64_t border_out_offset;           // output frame offset of frame border_p0
   int interleave;       // power kernel: workgroups of an XCD share a chunk of the sequence tile by tile
   int pmode;            // 2: power 2, 1: power 1, 0: general
   int abl_nostore;      // diagnostic builds only
@@ -365,6 +370,20 @@ __device__ __forceinline__ void block_to_range(const FastArgs &a, int64_t &tau_b
   const int64_t base = a.total_tiles / nb, extra = a.total_tiles % nb;
   tau_begin = vb * base + (vb < extra ? vb : extra);
   tau_end = tau_begin + base + (vb < extra ? 1 : 0);
+}
+
+// sample s of a signal of n samples extended by the configuration's padding (stft.ml:300-338); 32-bit positions
+__device__ __forceinline__ float fetch_padded(const float *x, int n, int s, int pad, float pad_value) {
+  if ((unsigned)s < (unsigned)n) return x[s];
+  if (pad == SMX_PAD_REFLECT) {
+    if (n == 1) return x[0];
+    const int period = 2 * (n - 1);
+    int m = s % period;
+    if (m < 0) m += period;
+    return x[m < n ? m : period - m];
+  }
+  if (pad == SMX_PAD_EDGE) return x[s < 0 ? 0 : n - 1];
+  return pad_value;
 }
 
 // The tiles of one workgroup: tau0, tau0 + step, ... (ntiles of them) of the flat (clip, tile)
@@ -670,6 +689,13 @@ __device__ __forceinline__ void lds_wait(unsigned *c, unsigned target) {
     __builtin_amdgcn_s_sleep(2);
 }
 
+struct NoHook {
+  template <int P>
+  __device__ __forceinline__ void at() const {}
+  __device__ __forceinline__ void ready() const {}
+  __device__ __forceinline__ void after_window(float2 (&)[16]) const {}
+};
+
 template <bool ALIGNED SMX_ABL_PARAM>
 struct SyncHook {
   const FastArgs &a;
@@ -790,6 +816,50 @@ __global__ void __launch_bounds__(1024) stft2048_power_kernel(FastArgs a) {
     tw.ft = ftnext;
   }
   flush_tile((ntiles - 1) & 1, ((unsigned)(ntiles - 1) >> 1) + 1);   // the last tile of this workgroup
+  // Border frames (the few per clip whose window reaches past either end of the signal): same frame code on
+  // samples fetched through the padding rule, 16 (clip, frame) pairs per tile, results scattered to their
+  // places.  A few dozen tiles in all, so plain barriers and element-wise stores do.
+  if (a.border_left + a.border_right > 0) {
+    const int per = a.border_left + a.border_right;
+    const int64_t lead = a.total_tiles / a.tiles_per_clip;
+    const int64_t total = lead * per;
+    auto locate = [&](int64_t beta, int64_t &clip, int64_t &p) {
+      clip = beta / per;
+      const int r = (int)(beta % per);
+      p = r < a.border_left ? a.border_p0 + r : a.border_i1 + (r - a.border_left);
+    };
+    float *bt_tile = lds.tiles;
+    for (int64_t bt = blockIdx.x; bt * kFT < total; bt += gridDim.x) {
+      __syncthreads();   // the buffer is free: every wave is past its last flush / the previous border tile
+      const int64_t beta = bt * kFT + wave;
+      if (beta < total) {   // wave-uniform
+        int64_t clip, p;
+        locate(beta, clip, p);
+        const float *xs = a.x + clip * a.x_stride;
+        const int s0 = (int)(p * a.hop - a.left);
+        float2 braw[16];
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+          const int s = s0 + 2 * (lane + 64 * j);
+          braw[j] = make_float2(fetch_padded(xs, (int)a.n, s, a.pad, a.pad_value),
+                                fetch_padded(xs, (int)a.n, s + 1, a.pad, a.pad_value));
+        }
+        frame_to_tile<SQUARE, false, false, false, false SMX_ABL_ZERO>(a, L, braw, bt_tile, wave, lane, NoHook{});
+      }
+      __syncthreads();
+      for (int e = tid; e < kBins * kFT; e += 1024) {
+        const int k = e / kFT, f = e % kFT;
+        const int64_t bf = bt * kFT + f;
+        if (bf < total) {
+          int64_t clip, p;
+          locate(bf, clip, p);
+          const float v = k < kM ? bt_tile[(4 * (k & 255) + (k >> 8)) * kTileStride + f]
+                                 : bt_tile[nyquist_row<false>(f) * kTileStride + kFT];
+          a.out[(clip * kBins + k) * a.out_stride + a.border_out_offset + (p - a.border_p0)] = v;
+        }
+      }
+    }
+  }
 #ifdef SMX_STAMPS
   if (lane == 0 && blockIdx.x < 4096)
     for (int i = 0; i < kStampSlots; ++i) g_stamp_sums[(blockIdx.x * 16 + wave) * kStampSlots + i] = stamp_sum[i];
@@ -955,12 +1025,6 @@ struct MelFusedArgs {
   int n_mels;
 };
 
-struct NoHook {
-  template <int P>
-  __device__ __forceinline__ void at() const {}
-  __device__ __forceinline__ void ready() const {}
-  __device__ __forceinline__ void after_window(float2 (&)[16]) const {}
-};
 
 struct ReadyHook {   // frame_to_tile calls ready() just before the powers overwrite the tile buffer
   unsigned *c;
@@ -1223,6 +1287,9 @@ struct FastTarget {
   int64_t out_offset = 0;       // frame offset of this job's first frame
   const MelFusedArgs *mel = nullptr;
   bool complex_out = false;     // Stft.transform: interleaved (re, im)
+  // power kernel only: border frames folded into the interior launch (see stft2048_power_kernel's epilogue)
+  int border_left = 0, border_right = 0;
+  int64_t border_p0 = 0, border_i1 = 0;
 };
 
 // one launch of the fused kernel over frames that all lie inside [0, n)
@@ -1237,8 +1304,8 @@ void launch_interior(const StftJob &job, const FastTarget &tg, const float *x, i
   a.x_stride = x_stride;
   a.hop = c.hop;
   a.left = left;
-  a.pad = 0;
-  a.pad_value = 0.0f;
+  a.pad = job.pad;
+  a.pad_value = (float)job.pad_value;
   a.p0 = p0;
   a.count = count;
   a.out = reinterpret_cast<float *>(tg.out);
@@ -1268,6 +1335,11 @@ void launch_interior(const StftJob &job, const FastTarget &tg, const float *x, i
   }
   a.pmode = job.power == 2.0 ? 2 : (job.power == 1.0 ? 1 : 0);
   a.half_power = (float)(0.5 * job.power);
+  a.border_left = strip ? 0 : tg.border_left;
+  a.border_right = strip ? 0 : tg.border_right;
+  a.border_p0 = tg.border_p0;
+  a.border_i1 = tg.border_i1;
+  a.border_out_offset = tg.out_offset;
   const bool aligned = (c.hop % 2 == 0) && (left % 2 == 0) && (x_stride % 2 == 0) &&
                        (reinterpret_cast<uintptr_t>(x) % 8 == 0);
   const bool square = a.pmode == 2;
@@ -1361,6 +1433,20 @@ void launch_ranges(const StftJob &job, const FastTarget &tg) {
   if (i1 > p1) i1 = p1;
   if (i1 <= i0) {          // no interior frame in range: one strip for everything
     launch_border(job, tg, p0, p1);
+    return;
+  }
+  // power spectrogram: the border frames ride in the interior launch (no gathers, no extra launches) whenever
+  // 32-bit sample positions suffice for the padding rule
+  static const bool fold_off = std::getenv("SMX_NO_BORDER_FOLD") != nullptr;
+  if (!tg.mel && !tg.complex_out && !fold_off && job.n < (int64_t(1) << 30) && (i0 - p0) + (p1 - i1) > 0 &&
+      (i0 - p0) + (p1 - i1) < 4096) {
+    FastTarget folded = tg;
+    folded.border_left = (int)(i0 - p0);
+    folded.border_right = (int)(p1 - i1);
+    folded.border_p0 = p0;
+    folded.border_i1 = i1;
+    launch_interior(job, folded, reinterpret_cast<const float *>(job.x), job.n, job.x_stride, job.left, i0, i1 - i0,
+                    tg.out_offset + (i0 - p0));
     return;
   }
   launch_border(job, tg, p0, i0);

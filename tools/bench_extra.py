@@ -66,7 +66,12 @@ med_i, _ = timeit(lambda: check(lib.smx_stft_invert_f32_dev(sc._h, vp(out_c.data
 print(json.dumps({"config": "C2 inverse (Stft.invert of the transform)", "invert_ms": round(med_i, 4),
                   "Mframes_per_s": round(256 * frames / med_i / 1e3, 1), "GBs_algorithmic": round(256 * frames * 10248 / med_i / 1e6, 1),
                   "max_abs_round_trip_err": float((out_x[:, 4096:-4096] - x[:, 4096:-4096]).abs().max())}))
-del out_c, out_x
+mag = torch.view_as_complex(out_c).abs().contiguous()
+med_g, _ = timeit(lambda: check(lib.smx_stft_griffin_lim_f32_dev(sc._h, vp(mag.data_ptr()), 256, 1025, frames, 32, 0.99, None, 1,
+                                                                 480000, vp(out_x.data_ptr()), None)), reps=3, warm=1)
+print(json.dumps({"config": "C2 Griffin-Lim (32 iterations, 256 clips)", "griffin_lim_ms": round(med_g, 2),
+                  "ms_per_clip": round(med_g / 256, 3), "analysis_synthesis_pairs_per_s": round(32 * 256 / med_g * 1e3, 1)}))
+del out_c, out_x, mag
 p = Stft.power_spectrum(sc, x)
 med_apply, _ = timeit(lambda: Mel.apply(mc, p), reps=10)
 m = S.mel_spectrogram(sc, mc, x[:2])
