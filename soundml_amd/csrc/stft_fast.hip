@@ -167,7 +167,7 @@ constexpr bool kEarlyPrefetch = SMX_EARLY_PREFETCH != 0;
 #endif
 constexpr bool kPre = SMX_PRE != 0;   // power kernel: twiddle tables read one stage ahead
 constexpr bool kLdsX = SMX_LDSX != 0;   // power kernel: transpose through the tile column (see frame_to_tile)
-constexpr int kWaves = 16, kFT = 16;            // one frame per wave per tile
+constexpr int kFT = 16;                         // frames per tile: one per wave, 16 waves per workgroup
 constexpr int kTileStride = kFT + 1;            // floats per tile row (pad column 16)
 // A tile holds bins 0..1023 as rows; bin 1024 (Nyquist) of frame f lives in the otherwise
 // unused pad slot of row f.  This, and dropping the trivial k1 = 0 twiddle row, is what makes
