@@ -608,3 +608,57 @@ def test_c2_full_size_properties():
     fr = x[:8].unfold(-1, 2048, 512)[:, 0:32, :]
     rhs = 2048.0 * (fr.double() ** 2).sum(dim=-1)
     assert torch.allclose(lhs.double(), rhs, rtol=2e-5)
+
+
+# ---- randomized cross-check of the fused kernels against the generic ones -------------------------------
+
+@pytest.mark.timeout(600)
+def test_fused_kernels_match_generic_on_random_geometries(monkeypatch):
+    """The fused fft-2048 kernels (counter-synchronised persistent workgroups, border frames folded in, XCD tile
+    order) against the library's own generic kernels (SMX_DISABLE_FAST) over random batch sizes, lengths, hops,
+    alignments and paddings; each fused result is also bit-for-bit reproducible."""
+    import subprocess, sys, json, os, tempfile
+    rng = np.random.default_rng(20261003)
+    cases = []
+    for _ in range(24):
+        cases.append(dict(lead=int(rng.choice([1, 2, 3, 5, 17, 64, 300])), n=int(rng.integers(1, 70000)),
+                          hop=int(rng.choice([512, 512, 512, 300, 77, 1024, 2048, 3000, 511])),
+                          alignment=str(rng.choice(["centered", "left", "right"])),
+                          pad=str(rng.choice(["reflect", "edge", "constant"])), power=float(rng.choice([2.0, 2.0, 1.0, 0.7]))))
+    def run(disable_fast):
+        # the switch is read once per process: run each side in its own interpreter
+        code = """
+import json, sys, numpy as np
+sys.path.insert(0, %r)
+import soundml_amd as S
+from soundml_amd import Stft
+cases = json.loads(sys.argv[1])
+out = {}
+for i, c in enumerate(cases):
+    rng = np.random.default_rng(1000 + i)
+    x = rng.uniform(-1, 1, size=(c['lead'], c['n'])).astype(np.float32)
+    pad = (c['pad'], 0.25) if c['pad'] == 'constant' else c['pad']
+    cfg = Stft.Config.create(fft_size=2048, hop=c['hop'], alignment=c['alignment'], pad=pad)
+    a = Stft.power_spectrum(cfg, x, c['power'])
+    b = Stft.power_spectrum(cfg, x, c['power'])
+    assert np.array_equal(a, b), ('not reproducible', c)
+    z = Stft.transform(cfg, x)
+    out['p%%d' %% i] = a
+    out['z%%d' %% i] = z
+np.savez(sys.argv[2], **out)
+""" % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+        env = dict(os.environ)
+        if disable_fast:
+            env["SMX_DISABLE_FAST"] = "1"
+        else:
+            env.pop("SMX_DISABLE_FAST", None)
+        path = tempfile.mktemp(suffix=".npz")
+        subprocess.run([sys.executable, "-c", code, json.dumps(cases), path], check=True, env=env, timeout=500)
+        data = dict(np.load(path))
+        os.remove(path)
+        return data
+    fused, generic = run(False), run(True)
+    for i, c in enumerate(cases):
+        check_fast(fused["p%d" % i], generic["p%d" % i], "power %s" % c)
+        check_fast(fused["z%d" % i].real, generic["z%d" % i].real, "re %s" % c)
+        check_fast(fused["z%d" % i].imag, generic["z%d" % i].imag, "im %s" % c)
