@@ -1330,8 +1330,12 @@ void launch_interior(const StftJob &job, const FastTarget &tg, const float *x, i
   }
   a.blocks = a.total_tiles < cu_count ? a.total_tiles : cu_count;
   {
+    // Tile order (TileWalk::init).  Measured on whole batches: while input + output stay within ~2 GB the
+    // chip-wide order (2) is 0-3 % ahead; beyond that the per-XCD chunks (1) win by 3-33 % (C5, 71 GB:
+    // 409 vs 308 Mframes/s) -- every XCD then stays inside one clip's pages for several tiles.
     const char *e = std::getenv("SMX_INTERLEAVE");
-    a.interleave = e ? std::atoi(e) : 2;
+    const double footprint = (double)job.lead * ((double)n + (double)kBins * (double)count) * 4.0;
+    a.interleave = e ? std::atoi(e) : (footprint <= 2.0e9 ? 2 : 1);
   }
   a.pmode = job.power == 2.0 ? 2 : (job.power == 1.0 ? 1 : 0);
   a.half_power = (float)(0.5 * job.power);
