@@ -150,9 +150,6 @@ struct FastArgs {
   float half_power;
 };
 
-#ifndef SMX_LDSX
-#define SMX_LDSX 0
-#endif
 #ifdef SMX_NOFENCE
 #define SMX_FENCE() do { } while (0)
 #else
@@ -166,7 +163,6 @@ constexpr bool kEarlyPrefetch = SMX_EARLY_PREFETCH != 0;
 #define SMX_PRE 1
 #endif
 constexpr bool kPre = SMX_PRE != 0;   // power kernel: twiddle tables read one stage ahead
-constexpr bool kLdsX = SMX_LDSX != 0;   // power kernel: transpose through the tile column (see frame_to_tile)
 constexpr int kFT = 16;                         // frames per tile: one per wave, 16 waves per workgroup
 constexpr int kTileStride = kFT + 1;            // floats per tile row (pad column 16)
 // A tile holds bins 0..1023 as rows; bin 1024 (Nyquist) of frame f lives in the otherwise
@@ -223,19 +219,14 @@ __device__ __forceinline__ void load_frame(const float *src /* first sample of t
 // NEXT frame so the store traffic is spread over the arithmetic instead of bursting.
 // Addresses: `obase` (clip / tile origin) is wave-uniform and stays in SGPRs; lanes carry one
 // 32-bit byte offset (goff0) and one LDS offset (row0), the four parts differ by constants.
-// Pad-column row that holds the Nyquist bin of frame f.  With the LDS transpose (LDSX) pad rows
-// [64 w, 64 w + 60) are wave w's scratch, so the Nyquist slots move to the free rows 64 f + 60.
-template <bool LDSX>
-__device__ __forceinline__ constexpr int nyquist_row(int f) {
-  return LDSX ? 64 * f + 60 : f;
-}
+// Pad-column row that holds the Nyquist bin of frame f: the otherwise unused pad slot of row f.
+__device__ __forceinline__ constexpr int nyquist_row(int f) { return f; }
 
 struct FlushLane {
   int row0;          // tile row of part 0: 32 * wave + rloc
   unsigned goff0;    // byte offset of out[bin0][4 g] from the tile origin
   int g;
 };
-template <bool LDSX>
 __device__ __forceinline__ void flush_part(const FastArgs &a, const float *tile, int it, const FlushLane &fl,
                                            float *obase, int frames_left, int wave, int lane, int ft = 0) {
   const int row = fl.row0 + 512 * (it >> 1) + 8 * (it & 1);
@@ -272,7 +263,7 @@ __device__ __forceinline__ void flush_part(const FastArgs &a, const float *tile,
     if (fleft > 2) dst[2] = v2;
   }
   if (it == 3 && wave == 0 && lane < 16) {   // bin 1024 (row 1024): 16 frames by 16 lanes
-    if (lane < frames_left) obase[(int64_t)kM * a.out_stride + lane] = tile[nyquist_row<LDSX>(lane) * kTileStride + kFT];
+    if (lane < frames_left) obase[(int64_t)kM * a.out_stride + lane] = tile[nyquist_row(lane) * kTileStride + kFT];
   }
 }
 
@@ -472,7 +463,7 @@ struct TileWalk {
 // CPLX: the spectrum itself goes to the tile (real parts in `tile`, imaginary parts in the plane after it).
 // TABPG: the post-pass twiddles come from global memory (a.w_n, L2 resident), requested before stage C,
 //        for the kernel that uses the LDS space of that table for something else (mel).
-template <bool SQUARE, bool LDSX, bool PRE, bool CPLX, bool TABPG SMX_ABL_PARAM, class Hook>
+template <bool SQUARE, bool PRE, bool CPLX, bool TABPG SMX_ABL_PARAM, class Hook>
 __device__ __forceinline__ void frame_to_tile(const FastArgs &a, const LaneConst &L, float2 (&raw)[16],
                                               float *tile, int wave, int lane, const Hook &hook) {
   c32 v[16];
@@ -511,35 +502,10 @@ __device__ __forceinline__ void frame_to_tile(const FastArgs &a, const LaneConst
   }
   hook.template at<3>();
   SMX_FENCE();
-  // X: transpose lane (i, a) register k1 -> lane (k1, a) register i.
-  if constexpr (LDSX) {
-    hook.ready();
-    // Through LDS, in place: until this wave writes its powers, column `wave` of the tile being
-    // filled (1024 slots) and pad rows [64 wave, 64 wave + 60) belong to this wave alone, so no
-    // barrier is involved (DS operations of one wave execute in order).  Element (i, a, k1) sits in
-    // slot s = 68 i + 4 k1 + a: both the writes (k1 fixed) and the reads (i fixed) spread a
-    // half-wave over 32 different banks, and every address is one lane base + an immediate.
-    // Slots >= 1024 (only i = 15, k1 >= 1) continue in the pad rows.
-    const int hi = lane >> 2, lo = lane & 3;
-    float *colw = tile + wave;
-    const int w0 = (68 * hi + lo) * kTileStride;                                        // k1 = 0
-    const int w1 = hi < 15 ? w0 + 4 * kTileStride : (64 * wave + lo) * kTileStride + kFT - wave;   // k1 = 1
-    const int r0 = lane * kTileStride;                                                  // i = 0 (slot 4 k1 + a = lane)
-    const int r15 = hi == 0 ? (1020 + lo) * kTileStride : (64 * wave + lane - 4) * kTileStride + kFT - wave;
-    auto exchange = [&](auto get, auto put) {
-#pragma unroll
-      for (int k = 0; k < 16; ++k) colw[k == 0 ? w0 : w1 + 4 * kTileStride * (k - 1)] = get(k);
-#pragma unroll
-      for (int i = 0; i < 16; ++i) put(i, colw[i == 15 ? r15 : r0 + 68 * kTileStride * i]);
-    };
-    float re[16], im[16];
-    exchange([&](int k) { return v[k].x; }, [&](int i, float x) { re[i] = x; });
-    hook.template at<4>();
-    exchange([&](int k) { return v[k].y; }, [&](int i, float x) { im[i] = x; });
-#pragma unroll
-    for (int k = 0; k < 16; ++k) v[k] = {re[k], im[k]};
-  } else {
-    // in registers (permlane swaps + DPP), used where the tile's pad column is busy (mel kernel)
+  // X: transpose lane (i, a) register k1 -> lane (k1, a) register i, in registers (permlane swaps + DPP); a
+  // variant through the wave's own tile column in LDS removed ~500 VALU cycles per frame but measured slower
+  // (it ties the transpose to the tile buffer's availability)
+  {
     float re[16], im[16];
 #pragma unroll
     for (int k = 0; k < 16; ++k) { re[k] = v[k].x; im[k] = v[k].y; }
@@ -592,7 +558,7 @@ __device__ __forceinline__ void frame_to_tile(const FastArgs &a, const LaneConst
   hook.template at<10>();
   SMX_FENCE();
   // P: real-FFT post-pass.  provider rotation for the k1 = 0 lanes.
-  if constexpr (!LDSX) hook.ready();
+  hook.ready();
   float *col = tile + wave;
   const float nyq = 2.0f * (v[0].x - v[0].y);   // X[M] = Re Z0 - Im Z0 (true scale), lane 0
   auto partner = [&](int q, float &px, float &py) {   // Z[M - k] of register q's bin k
@@ -652,7 +618,7 @@ __device__ __forceinline__ void frame_to_tile(const FastArgs &a, const LaneConst
       pw = nyq * nyq;
       if constexpr (!SQUARE) pw = a.pmode == 1 ? fabsf(nyq) : __powf(pw, a.half_power);
     }
-    tile[nyquist_row<LDSX>(wave) * kTileStride + kFT] = pw;   // Nyquist bin of frame `wave`: a pad slot
+    tile[nyquist_row(wave) * kTileStride + kFT] = pw;   // Nyquist bin of frame `wave`: a pad slot
   }
 }
 
@@ -723,10 +689,9 @@ struct SyncHook {
 };
 
 // SQUARE = power 2 (no per-bin branch); otherwise |X|^p through pmode / half_power.
-// LDSX: 16x16 transpose through the wave's own tile column (true) or in registers (false).
 // STRIP only names the instantiation used for the small gathered border strips, so that kernel-trace
 // statistics separate them from the interior launch (the code is identical).
-template <bool ALIGNED, bool SQUARE, bool STRIP, bool LDSX SMX_ABL_PARAM>
+template <bool ALIGNED, bool SQUARE, bool STRIP SMX_ABL_PARAM>
 __global__ void __launch_bounds__(1024) stft2048_power_kernel(FastArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x;
@@ -769,7 +734,7 @@ __global__ void __launch_bounds__(1024) stft2048_power_kernel(FastArgs a) {
     lds_wait(cnt.filled + b, 16u * fills);
     const float *ptile = lds.tiles + b * kTileFloats;
 #pragma unroll
-    for (int part = 0; part < 4; ++part) flush_part<LDSX>(a, ptile, part, fl, pend_out, pend_left, wave, lane, pend_ft);
+    for (int part = 0; part < 4; ++part) flush_part(a, ptile, part, fl, pend_out, pend_left, wave, lane, pend_ft);
     lds_signal(cnt.drained + b, lane);
   };
 
@@ -796,7 +761,7 @@ __global__ void __launch_bounds__(1024) stft2048_power_kernel(FastArgs a) {
 #else
       const SyncHook<ALIGNED SMX_ABL_ARG> hook{a, cnt.drained + b, 16u * ((unsigned)it >> 1), src, lane};
 #endif
-      frame_to_tile<SQUARE, LDSX, kPre, false, false SMX_ABL_ARG>(a, L, raw, lds.tiles + b * kTileFloats, wave, lane, hook);
+      frame_to_tile<SQUARE, kPre, false, false SMX_ABL_ARG>(a, L, raw, lds.tiles + b * kTileFloats, wave, lane, hook);
     } else if constexpr (kEarlyPrefetch) {
       prefetch_frame<ALIGNED SMX_ABL_ARG>(a, src, lane, raw);
     }
@@ -844,7 +809,7 @@ __global__ void __launch_bounds__(1024) stft2048_power_kernel(FastArgs a) {
           braw[j] = make_float2(fetch_padded(xs, (int)a.n, s, a.pad, a.pad_value),
                                 fetch_padded(xs, (int)a.n, s + 1, a.pad, a.pad_value));
         }
-        frame_to_tile<SQUARE, false, false, false, false SMX_ABL_ZERO>(a, L, braw, bt_tile, wave, lane, NoHook{});
+        frame_to_tile<SQUARE, false, false, false SMX_ABL_ZERO>(a, L, braw, bt_tile, wave, lane, NoHook{});
       }
       __syncthreads();
       for (int e = tid; e < kBins * kFT; e += 1024) {
@@ -854,7 +819,7 @@ __global__ void __launch_bounds__(1024) stft2048_power_kernel(FastArgs a) {
           int64_t clip, p;
           locate(bf, clip, p);
           const float v = k < kM ? bt_tile[(4 * (k & 255) + (k >> 8)) * kTileStride + f]
-                                 : bt_tile[nyquist_row<false>(f) * kTileStride + kFT];
+                                 : bt_tile[nyquist_row(f) * kTileStride + kFT];
           a.out[(clip * kBins + k) * a.out_stride + a.border_out_offset + (p - a.border_p0)] = v;
         }
       }
@@ -898,7 +863,7 @@ __device__ __forceinline__ void cplx_flush(const FastArgs &a, const float *re, i
   }
   if (wave == 0 && lane < 16 && lane < frames_left) {   // bin 1024: real
     float *dst = obase + ((int64_t)kM * a.out_stride + lane) * 2;
-    dst[0] = re[nyquist_row<false>(lane) * kTileStride + kFT];
+    dst[0] = re[nyquist_row(lane) * kTileStride + kFT];
     dst[1] = 0.0f;
   }
 }
@@ -963,7 +928,7 @@ __global__ void __launch_bounds__(1024) stft2048_complex_kernel(FastArgs a) {
   for (int it = 0; it < ntiles; ++it) {
     const CplxHook<ALIGNED> hook{a, c_filled, c_drained, (unsigned)it, lds.tiles, fl, pend_out, pend_left, wave, lane};
     if (have) {
-      frame_to_tile<true, false, false, true, false SMX_ABL_ZERO>(a, L, raw, lds.tiles, wave, lane, hook);
+      frame_to_tile<true, false, true, false SMX_ABL_ZERO>(a, L, raw, lds.tiles, wave, lane, hook);
     } else {
       hook.flush_previous();
     }
@@ -1206,7 +1171,7 @@ __global__ void __launch_bounds__(1024) stft2048_mel_kernel(FastArgs a, MelFused
     if (t < ntiles) {
       // every MFMA read of tile t-2 (same buffer) must be over before the powers of tile t land
       if (have) {
-        frame_to_tile<SQUARE, false, false, false, false SMX_ABL_ZERO>(a, L, raw, tcur, wave, lane,
+        frame_to_tile<SQUARE, false, false, false SMX_ABL_ZERO>(a, L, raw, tcur, wave, lane,
                                                                         ReadyHook{c_mdone + b, t >= 2 ? nth(t - 2) : 0u});
       }
       lds_signal(c_filled + b, lane);
@@ -1376,23 +1341,21 @@ void launch_interior(const StftJob &job, const FastTarget &tg, const float *x, i
   const int abl = abl_env ? std::atoi(abl_env) : 0;
   a.abl_nostore = (abl == 1 || abl == 3 || abl == 7) ? 1 : abl == 8 ? 2 : 0;
   if (const char *w = std::getenv("SMX_ABL_RUN")) a.abl_nostore = std::atoi(w);   // 2: 128 B, 3: 256 B, 4: 512 B runs
-  auto kernel = abl == 2 ? stft2048_power_kernel<true, true, false, kLdsX, 2>
-              : abl == 3 ? stft2048_power_kernel<true, true, false, kLdsX, 3>
-              : abl == 4 ? stft2048_power_kernel<true, true, false, kLdsX, 4>
-              : abl == 5 ? stft2048_power_kernel<true, true, false, kLdsX, 5>
-              : (abl == 6 || abl == 7 || abl == 8) ? stft2048_power_kernel<true, true, false, kLdsX, 6>
-              : abl == 9 ? stft2048_power_kernel<true, true, false, kLdsX, 9>
-                         : stft2048_power_kernel<true, true, false, kLdsX, 0>;
+  auto kernel = abl == 2 ? stft2048_power_kernel<true, true, false, 2>
+              : abl == 3 ? stft2048_power_kernel<true, true, false, 3>
+              : abl == 4 ? stft2048_power_kernel<true, true, false, 4>
+              : abl == 5 ? stft2048_power_kernel<true, true, false, 5>
+              : (abl == 6 || abl == 7 || abl == 8) ? stft2048_power_kernel<true, true, false, 6>
+              : abl == 9 ? stft2048_power_kernel<true, true, false, 9>
+                         : stft2048_power_kernel<true, true, false, 0>;
   (void)aligned; (void)square; (void)strip;
 #else
-  auto pick = [&](auto strip_tag, auto ldsx_tag) {
-    constexpr bool S = decltype(strip_tag)::value, X = decltype(ldsx_tag)::value;
-    return aligned ? (square ? stft2048_power_kernel<true, true, S, X> : stft2048_power_kernel<true, false, S, X>)
-                   : (square ? stft2048_power_kernel<false, true, S, X> : stft2048_power_kernel<false, false, S, X>);
+  auto pick = [&](auto strip_tag) {
+    constexpr bool S = decltype(strip_tag)::value;
+    return aligned ? (square ? stft2048_power_kernel<true, true, S> : stft2048_power_kernel<true, false, S>)
+                   : (square ? stft2048_power_kernel<false, true, S> : stft2048_power_kernel<false, false, S>);
   };
-  static const bool ldsx = [] { const char *e = std::getenv("SMX_LDSX"); return e ? std::atoi(e) != 0 : kLdsX; }();
-  auto kernel = strip ? (ldsx ? pick(std::true_type{}, std::true_type{}) : pick(std::true_type{}, std::false_type{}))
-                      : (ldsx ? pick(std::false_type{}, std::true_type{}) : pick(std::false_type{}, std::false_type{}));
+  auto kernel = strip ? pick(std::true_type{}) : pick(std::false_type{});
 #endif
   SMX_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kernel),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)kFastLds));
