@@ -1,37 +1,30 @@
-// Fused framing + window + real FFT(2048) + |.|^p for gfx950 (MI355X).
-//
-// Replaces, for float32 audio and fft_size = 2048, the reference's hot call
+// Fused framing + window + real FFT(2048) + output stage for gfx950 (MI355X): the three fft-2048 kernels
+//   stft2048_power_kernel     |X|^p               Stft.power_spectrum          stft.ml:670-691
+//   stft2048_complex_kernel   X                   Stft.transform / _range      stft.ml:632-666
+//   stft2048_mel_kernel       W |X|^p (MFMA)      Soundml.mel_spectrogram      soundml.ml:12-24
+// They replace, for float32 audio, the reference's hot call
 //   Nx.stft cdtype ~window:fft ~step:hop ~win (to_double samples)   stft.ml:356-364
-//   |> Nx.magnitude |> Nx.square                                     stft.ml:670-674
-// with one kernel that reads each audio sample from HBM once (hop-strided
-// overlapping frames are re-read through L2) and writes the [bins; frames]
-// power spectrogram once, in 64-byte runs along the frame axis.
+// Each audio sample is read from HBM once (hop-strided overlapping frames are re-read through L1 / L2) and
+// the [bins; frames] result is written once, in 64-byte (power) or 128-byte (complex) runs along the frame axis.
 //
-// Decomposition (M = N/2 = 1024 complex points, z[n] = x[2n] + i x[2n+1]):
-//   one 64-lane wavefront owns one frame; lane l holds 16 complex points.
-//   A. n = l + 64 j      : radix-16 over j in registers        -> y_l[k1]
-//      twiddle W_M^(l k1)
+// Frame pipeline (M = N/2 = 1024 complex points, z[n] = x[2n] + i x[2n+1]); one 64-lane wavefront owns one
+// frame, lane l holds 16 complex points:
+//   A. n = l + 64 j      : radix-16 over j in registers        -> y_l[k1],  twiddle W_M^(l k1)
 //   X. in-wave 16x16 transpose (permlane32/16_swap + DPP row ops, no LDS):
 //      lane l' = 4 k1 + a receives y_(4i+a)[k1], i = 0..15
 //   B. radix-16 over i in registers, twiddle W_64^(a q)
-//   C. radix-4 over a across the 4 lanes of a quad with DPP quad_perm
+//   C. radix-4 over a across the 4 lanes of a quad (v_fmac_f32_dpp)
 //      -> lane (k1, rr), register q holds Z[k1 + 16 q + 256 r], r = bitrev2(rr)
-//   P. real-FFT post-pass: partner Z[M-k] fetched with ds_bpermute
-//      (lane 67-l', register 15-q; lanes 0..3 are the k1 = 0 column and pair
-//      inside themselves), X[k] = E - i w_k D with the 1/2 folded into the window.
-//   T. |X|^2 is written into a workgroup tile [1025 bins][16 frames] in LDS
-//      (bank-conflict-free row permutation), and the 8 waves flush the tile to
-//      HBM frames-fastest.
-// A workgroup is 16 waves = 16 frames (one per wave), <= 128 VGPRs (twiddles in
-// LDS, window streamed from L1/L2).  The output tile is DOUBLE-BUFFERED: there
-// is one barrier per tile, after which every wave stores its share of the
-// finished tile and goes straight on to the next frame, so the HBM write drain
-// overlaps the next tile's arithmetic.  LDS = 2 x 69.7 KB tiles + 16.5 KB
-// twiddle tables; 1 workgroup per CU.  The next frame's samples and window are
-// prefetched into registers before the stores are issued.
+//   P. real-FFT post-pass: partner Z[M-k] fetched with ds_bpermute (lane 67-l', register 15-q; lanes 0..3 are
+//      the k1 = 0 column and pair inside themselves), X[k] = E - i w_k D with the 1/2 folded into the window.
+//   T. the result goes into a workgroup tile [1024 bins (+ Nyquist in the pad column)][16 frames] in LDS with a
+//      bank-conflict-free row permutation.
+// A workgroup is 16 waves = 16 consecutive frames of one clip, one persistent workgroup per CU (LDS is full:
+// two 69.6 KB tiles + 24.5 KB of tables incl. the window).  There is no workgroup barrier in the loops: waves
+// synchronise through monotonic LDS counters and wait only for what they consume (see the kernels).
 //
-// Algorithmic HBM bytes per frame: hop*4 read + 1025*4 written = 6148 B at
-// hop 512.  Flops per frame ~= 50k VALU lane-ops.
+// Algorithmic HBM bytes per frame at hop 512: power 2048 + 4100 = 6148 B, complex 2048 + 8200 = 10248 B,
+// mel 2048 + 4 n_mels.
 #include <cstdlib>
 #include <type_traits>
 
@@ -155,10 +148,6 @@ struct FastArgs {
 #else
 #define SMX_FENCE() __builtin_amdgcn_sched_barrier(0)
 #endif
-#ifndef SMX_EARLY_PREFETCH
-#define SMX_EARLY_PREFETCH 0
-#endif
-constexpr bool kEarlyPrefetch = SMX_EARLY_PREFETCH != 0;
 #ifndef SMX_PRE
 #define SMX_PRE 1
 #endif
@@ -382,7 +371,6 @@ __device__ __forceinline__ float fetch_padded(const float *x, int n, int s, int 
 // instructions; the only ones are in init()).
 struct TileWalk {
   int ntiles, ft, step_clips, step_tiles;   // ft: tile index inside the clip
-  int group;                                // tiles taken back to back (1 normally); a power of two
   const float *xclip;                       // first sample of the current clip
   float *oclip;                             // output origin of the current clip
   int64_t x_step, o_step;                   // per-clip strides of input and output
@@ -395,24 +383,7 @@ struct TileWalk {
       // XCD is writing ~32 neighbouring tiles of the same clip, i.e. for every bin one contiguous run of
       // ~2 KB, which its L2 can assemble into whole lines before they go to HBM.
       const int64_t nb = a.blocks, xcd = blockIdx.x % 8, idx = blockIdx.x / 8;
-      group = 1;
-      if (a.interleave == 3 || a.interleave == 4) {   // as 2, but each workgroup takes `group` neighbouring tiles back to back
-        group = a.interleave == 3 ? 2 : 4;   // (measured: worse than 2 -- what counts is that the tiles written at the same time are neighbours)
-        const int64_t q = nb / 8, r = nb % 8, g = group;
-        const int64_t vb = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
-        tau0 = g * vb;
-        step = (int)(g * nb - (g - 1));                                  // after the last tile of a group
-        ntiles = 0;
-        if (tau0 < a.total_tiles) {
-          const int64_t rounds = (a.total_tiles - tau0 + g * nb - 1) / (g * nb);
-          const int64_t last = a.total_tiles - (tau0 + g * nb * (rounds - 1));
-          ntiles = (int)((rounds - 1) * g + (last < g ? last : g));
-        }
-      } else if (a.interleave == 5) {   // experiment: neighbouring tiles on different XCDs
-        tau0 = blockIdx.x;
-        step = (int)nb;
-        ntiles = tau0 < a.total_tiles ? (int)((a.total_tiles - tau0 + nb - 1) / nb) : 0;
-      } else if (a.interleave == 2) {   // all workgroups side by side; an XCD holds 32 neighbouring tiles of every 256
+      if (a.interleave == 2) {   // all workgroups side by side; an XCD holds 32 neighbouring tiles of every 256
         const int64_t q = nb / 8, r = nb % 8;
         tau0 = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
         step = (int)nb;
@@ -429,7 +400,6 @@ struct TileWalk {
       int64_t tau_end;
       block_to_range(a, tau0, tau_end);
       step = 1;
-      group = 1;
       ntiles = (int)(tau_end - tau0);
     }
     if (ntiles <= 0) return;
@@ -441,11 +411,10 @@ struct TileWalk {
     step_clips = step / a.tiles_per_clip;
     step_tiles = step % a.tiles_per_clip;
   }
-  // the tile after the current one (`it` = tiles already taken by this workgroup before the current one)
-  __device__ __forceinline__ void peek(const FastArgs &a, int it, int &ftn, const float *&xn, float *&on) const {
-    const bool big = ((it + 1) & (group - 1)) == 0;   // group = 1: always
-    ftn = ft + (big ? step_tiles : 1);
-    int dclip = big ? step_clips : 0;
+  // the tile after the current one
+  __device__ __forceinline__ void peek(const FastArgs &a, int &ftn, const float *&xn, float *&on) const {
+    ftn = ft + step_tiles;
+    int dclip = step_clips;
     if (ftn >= a.tiles_per_clip) {
       ftn -= a.tiles_per_clip;
       ++dclip;
@@ -482,7 +451,6 @@ __device__ __forceinline__ void frame_to_tile(const FastArgs &a, const LaneConst
     for (int q = 0; q < 16; ++q) (tile + wave)[(L.tile_row0 + 64 * q) * kTileStride] = v[q].x + v[q].y;
     return;
   }
-  hook.after_window(raw);   // raw is free again: the power kernel reloads it with the next frame here
   hook.template at<0>();
   SMX_FENCE();
   // A: radix-16 over j, twiddle W_M^(l k1)
@@ -659,25 +627,15 @@ struct NoHook {
   template <int P>
   __device__ __forceinline__ void at() const {}
   __device__ __forceinline__ void ready() const {}
-  __device__ __forceinline__ void after_window(float2 (&)[16]) const {}
 };
 
-template <bool ALIGNED SMX_ABL_PARAM>
 struct SyncHook {
-  const FastArgs &a;
   unsigned *drained;
   unsigned target;
-  const float *next_src;   // first sample of this wave's next frame
-  int lane;
-  // The next frame's samples are requested as soon as the current ones have been windowed, a whole
-  // frame ahead of their use: the 16 loads of the 16 waves no longer queue up behind each other.
-  __device__ __forceinline__ void after_window(float2 (&raw)[16]) const {
-    if constexpr (kEarlyPrefetch) prefetch_frame<ALIGNED SMX_ABL_ARG>(a, next_src, lane, raw);
-  }
 #ifdef SMX_STAMPS
   unsigned long long *stamp_sum, *stamp_prev_p;
 #endif
-  // the tile buffer about to be written (or used as transpose scratch) has been read out by every wave
+  // the tile buffer about to be written has been read out by every wave
   __device__ __forceinline__ void ready() const { lds_wait(drained, target); }
   template <int P>
   __device__ __forceinline__ void at() const {
@@ -750,24 +708,22 @@ __global__ void __launch_bounds__(1024) stft2048_power_kernel(FastArgs a) {
     int ftnext;
     const float *xnext;
     float *onext;
-    tw.peek(a, it, ftnext, xnext, onext);
+    tw.peek(a, ftnext, xnext, onext);
     bool have_next;
     const float *src = frame_ptr(it + 1 < ntiles ? xnext : tw.xclip, it + 1 < ntiles ? ftnext : tw.ft, have_next);
     have_next = have_next && it + 1 < ntiles;
     if (have) {   // wave-uniform
       // buffer b last held tile it - 2, the (it >> 1)-th tile written there
 #ifdef SMX_STAMPS
-      const SyncHook<ALIGNED SMX_ABL_ARG> hook{a, cnt.drained + b, 16u * ((unsigned)it >> 1), src, lane, stamp_sum, &stamp_prev};
+      const SyncHook hook{cnt.drained + b, 16u * ((unsigned)it >> 1), stamp_sum, &stamp_prev};
 #else
-      const SyncHook<ALIGNED SMX_ABL_ARG> hook{a, cnt.drained + b, 16u * ((unsigned)it >> 1), src, lane};
+      const SyncHook hook{cnt.drained + b, 16u * ((unsigned)it >> 1)};
 #endif
       frame_to_tile<SQUARE, kPre, false, false SMX_ABL_ARG>(a, L, raw, lds.tiles + b * kTileFloats, wave, lane, hook);
-    } else if constexpr (kEarlyPrefetch) {
-      prefetch_frame<ALIGNED SMX_ABL_ARG>(a, src, lane, raw);
     }
     lds_signal(cnt.filled + b, lane);
     SMX_STAMP(17);
-    if constexpr (!kEarlyPrefetch) prefetch_frame<ALIGNED SMX_ABL_ARG>(a, src, lane, raw);
+    prefetch_frame<ALIGNED SMX_ABL_ARG>(a, src, lane, raw);
     SMX_STAMP(18);
     if (it > 0) flush_tile(b ^ 1, ((unsigned)(it - 1) >> 1) + 1);   // tile it - 1
     SMX_STAMP(19);
@@ -888,7 +844,6 @@ struct CplxHook {
     if constexpr (P == 5) flush_previous();
   }
   __device__ __forceinline__ void ready() const { lds_wait(drained, 16u * tiles_before); }
-  __device__ __forceinline__ void after_window(float2 (&)[16]) const {}
 };
 
 template <bool ALIGNED, bool STRIP>
@@ -936,7 +891,7 @@ __global__ void __launch_bounds__(1024) stft2048_complex_kernel(FastArgs a) {
     int ftnext;
     const float *xnext;
     float *onext;
-    tw.peek(a, it, ftnext, xnext, onext);
+    tw.peek(a, ftnext, xnext, onext);
     bool have_next;
     const float *src = frame_ptr(it + 1 < ntiles ? xnext : tw.xclip, it + 1 < ntiles ? ftnext : tw.ft, have_next);
     have_next = have_next && it + 1 < ntiles;
@@ -997,7 +952,6 @@ struct ReadyHook {   // frame_to_tile calls ready() just before the powers overw
   template <int P>
   __device__ __forceinline__ void at() const {}
   __device__ __forceinline__ void ready() const { lds_wait(c, target); }
-  __device__ __forceinline__ void after_window(float2 (&)[16]) const {}
 };
 
 template <bool ALIGNED, bool SQUARE, bool STRIP>
@@ -1178,7 +1132,7 @@ __global__ void __launch_bounds__(1024) stft2048_mel_kernel(FastArgs a, MelFused
       int ftnext;
       const float *xnext;
       float *onext;
-      tw.peek(a, t, ftnext, xnext, onext);
+      tw.peek(a, ftnext, xnext, onext);
       bool have_next;
       const float *src = frame_ptr(t + 1 < ntiles ? xnext : tw.xclip, t + 1 < ntiles ? ftnext : tw.ft, have_next);
       have_next = have_next && t + 1 < ntiles;
