@@ -1512,6 +1512,8 @@ const smx::MelFusedPlan &smx_mel_config::fused_plan() const {
   }
   for (const auto &it : items)
     if (it.k4_count > kMelMaxSteps) return plan;   // the A operands of an item must fit its wave's registers
+  if (std::getenv("SMX_MEL_ONESTEP"))  // diagnostic: one MFMA step per item (wrong results): the cost of the protocol alone
+    for (auto &it : items) it.k4_count = it.k4_count > 0 ? 1 : 0;
   if (std::getenv("SMX_MEL_NOMFMA"))   // diagnostic: plan without MFMA work (results are zeros)
     for (auto &it : items) it.k4_count = 0;
   wm.resize(wm.size() + 64 * (size_t)kMelMaxSteps, 0.0f);   // every item can be read kMelMaxSteps rows deep
