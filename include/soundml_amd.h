@@ -164,6 +164,10 @@ int smx_stft_kernel_reset(smx_stft_kernel *k);
 /* ---- Mel.Config / Mel.apply (mel.ml:22-233) ------------------------------- */
 int smx_mel_config_create(int64_t n_mels, int64_t sample_rate, int64_t fft_size, double f_min,
                           int has_f_max, double f_max, int scale, int norm, smx_mel_config **out);
+/* A filterbank handle over caller-supplied float64 weights [rows; fft_size/2 + 1] (copied): every projection of
+ * the reference that is `matmul W (power spectrum)` with its own W -- Chroma.apply's chroma filters
+ * (chroma.ml:307), a mel bank built elsewhere -- runs through smx_mel_apply_* / smx_mel_spectrogram_*.       */
+int smx_mel_config_from_weights(int64_t rows, int64_t fft_size, const double *weights, smx_mel_config **out);
 void smx_mel_config_destroy(smx_mel_config *c);
 int64_t smx_mel_config_n_mels(const smx_mel_config *c);
 int64_t smx_mel_config_bins(const smx_mel_config *c);

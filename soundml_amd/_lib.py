@@ -108,6 +108,7 @@ SIGNATURES = {
     "smx_stft_kernel_flush": (cint, [vp, vp, i64, pi64]),
     "smx_stft_kernel_reset": (cint, [vp]),
     "smx_mel_config_create": (cint, [i64, i64, i64, f64, cint, f64, cint, cint, C.POINTER(vp)]),
+    "smx_mel_config_from_weights": (cint, [i64, i64, vp, C.POINTER(vp)]),
     "smx_mel_config_destroy": (None, [vp]),
     "smx_mel_config_n_mels": (i64, [vp]),
     "smx_mel_config_bins": (i64, [vp]),

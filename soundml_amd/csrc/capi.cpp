@@ -1035,6 +1035,19 @@ int smx_mel_config_create(int64_t n_mels, int64_t sample_rate, int64_t fft_size,
     *out = mel_config_create(n_mels, sample_rate, fft_size, f_min, has_f_max != 0, f_max, scale, norm);
   });
 }
+int smx_mel_config_from_weights(int64_t rows, int64_t fft_size, const double *weights, smx_mel_config **out) {
+  return guarded([&] {
+    if (!out || !weights) throw Failure("from_weights: null pointer");
+    if (rows < 1) throw InvalidArgument(format("from_weights: cannot build %lld filters (rows must be at least 1)", (long long)rows));
+    if (fft_size < 1)
+      throw InvalidArgument(format("from_weights: cannot use an FFT of size %lld (fft_size must be at least 1)", (long long)fft_size));
+    smx_mel_config *c = new smx_mel_config();
+    c->n_mels = rows;
+    c->fft_size = fft_size;
+    c->weights.assign(weights, weights + (size_t)rows * (size_t)(fft_size / 2 + 1));
+    *out = c;
+  });
+}
 void smx_mel_config_destroy(smx_mel_config *c) { delete c; }
 int64_t smx_mel_config_n_mels(const smx_mel_config *c) { return c ? c->n_mels : -1; }
 int64_t smx_mel_config_bins(const smx_mel_config *c) { return c ? c->bins() : -1; }

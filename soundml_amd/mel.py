@@ -38,6 +38,18 @@ class Config:
                                         _lib.MEL_SCALE[scale], _lib.MEL_NORM[norm], C.byref(handle)))
         return Config(handle)
 
+    @staticmethod
+    def from_weights(weights, fft_size: int) -> "Config":
+        """A projection with caller-supplied weights [rows; fft_size // 2 + 1] (e.g. the reference's chroma
+        filters, chroma.ml:307): `apply` and `mel_spectrogram` then compute W @ spectrogram with it."""
+        w = np.ascontiguousarray(np.asarray(weights, dtype=np.float64))
+        if w.ndim != 2 or w.shape[1] != int(fft_size) // 2 + 1:
+            raise _lib.InvalidArgument("from_weights: cannot use weights of shape %s with an FFT of size %d (the "
+                                       "bin axis must hold fft_size / 2 + 1 values)" % (list(w.shape), int(fft_size)))
+        handle = C.c_void_p()
+        check(lib.smx_mel_config_from_weights(int(w.shape[0]), int(fft_size), C.c_void_p(w.ctypes.data), C.byref(handle)))
+        return Config(handle)
+
     def __del__(self):
         h, self._h = getattr(self, "_h", None), None
         if h and lib is not None:

@@ -491,6 +491,24 @@ def test_fused_mel_spectrogram_vs_oracle(n_mels, sr, n, lead, power):
 
 
 
+def test_filterbank_from_weights():
+    """Caller-supplied dense weights (the shape of Chroma.apply, chroma.ml:307: 12 rows over all bins) through the
+    same entry points: W @ S in float64 for float64 spectrograms, the float32 MFMA kernel for float32 ones, and the
+    spectrogram composition from audio (no banded structure, so the unfused path)."""
+    rng = np.random.default_rng(12)
+    w = np.abs(rng.standard_normal((12, 1025)))
+    bank = Mel.Config.from_weights(w, 2048)
+    assert bank.n_mels == 12 and bank.bins == 1025
+    s64 = np.abs(rng.standard_normal((3, 1025, 41)))
+    np.testing.assert_allclose(Mel.apply(bank, s64), np.einsum("mb,lbt->lmt", w, s64), rtol=1e-12, atol=1e-12)
+    s32 = s64.astype(np.float32)
+    check_fast(Mel.apply(bank, s32), np.einsum("mb,lbt->lmt", w, s32.astype(np.float64)), "float32 apply")
+    x = rng.uniform(-1, 1, size=(2, 20000)).astype(np.float32)
+    sc = Stft.Config.create(fft_size=2048, hop=512)
+    want = np.einsum("mb,lbt->lmt", w, O.power_spectrum(O.stft_config(2048, hop=512), x).astype(np.float64))
+    check_fast(S.mel_spectrogram(sc, bank, x), want, "chroma-like spectrogram")
+
+
 # ---- log-mel / MFCC tail -----------------------------------------------------------------------------------
 
 def test_mfcc_goldens():
