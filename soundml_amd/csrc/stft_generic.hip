@@ -12,6 +12,7 @@
 //     windowed frame against an N-entry twiddle table, O(N^2) per frame.
 // Results for the FT frames are staged in LDS and written frames-fastest so
 // the [bins; frames] layout is stored in runs of FT elements.
+#include "fft_device.hpp"
 #include "smx_internal.hpp"
 
 namespace smx {
@@ -36,6 +37,7 @@ struct GenericArgs {
   const void *twiddle;
   int log2n;   // >= 0 for the power-of-two kernel
   int ft;      // frames per workgroup
+  int direct;  // Stockham kernel: results go straight from registers to memory (no room for an LDS stage)
 };
 
 template <typename Tin>
@@ -187,6 +189,103 @@ __global__ void __launch_bounds__(256) stft_generic_kernel(GenericArgs a) {
 
 constexpr size_t kLdsLimit = 160 * 1024;
 
+// ---- power-of-two sizes 1024 .. 16384, float32 interior: Stockham passes of fft_device.hpp ---------------------
+// N/16 threads own one frame (16 points each in registers, 3-4 LDS round trips instead of log2 N radix-2 passes);
+// a workgroup of >= 256 threads transforms G = 256 / (N/16) frames at a time (one for N >= 4096) and FT frames in
+// all, staged in LDS and written frames-fastest like the kernels above.  The frame is transformed as a complex
+// signal with zero imaginary part; bins above N/2 are dropped.
+template <int LOG2N, typename Tin>
+__global__ void __launch_bounds__((1 << LOG2N) / 16 < 256 ? 256 : (1 << LOG2N) / 16) stft_stockham_kernel(GenericArgs a) {
+  using namespace fftdev;
+  constexpr int N = 1 << LOG2N, T = N / 16, G = T < 256 ? 256 / T : 1;
+  constexpr int RL = LastPass<LOG2N>::R, NSL = LastPass<LOG2N>::NS, GL = 16 / RL;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  float2 *work = reinterpret_cast<float2 *>(smem);                       // G buffers of N complex
+  unsigned char *stage = smem + (size_t)G * N * sizeof(float2);
+  const int ft = a.ft, sstride = ft + 1;
+  const int64_t tiles = (a.count + ft - 1) / ft;
+  const int64_t clip = blockIdx.x / tiles, tile = blockIdx.x % tiles;
+  const Tin *x = reinterpret_cast<const Tin *>(a.x) + clip * a.x_stride;
+  const float *window = reinterpret_cast<const float *>(a.window);
+  const float2 *tw = reinterpret_cast<const float2 *>(a.twiddle);         // exp(-2 pi i j / N), j < N
+  const int64_t bins = a.bins;
+  const int tid = threadIdx.x % T, grp = threadIdx.x / T;
+  const int64_t f0 = tile * ft;
+  const int nf = (int)((a.count - f0) < ft ? (a.count - f0) : ft);
+  for (int fb = 0; fb < nf; fb += G) {
+    const int f = fb + grp;
+    const bool have = f < nf;                          // uniform per group of T threads (T >= 64: per wave)
+    c32 r[16];
+    if (have) {
+      const int64_t s0 = (a.p0 + f0 + f) * a.hop - a.left;
+#pragma unroll
+      for (int m = 0; m < 16; ++m) {
+        const int i = tid + T * m;
+        r[m] = {(float)fetch_sample<Tin>(x, a.n, s0 + i, a.pad, a.pad_value) * window[i], 0.0f};
+      }
+    } else {
+#pragma unroll
+      for (int m = 0; m < 16; ++m) r[m] = {0.0f, 0.0f};
+    }
+    // every thread takes part in the barriers of the passes; groups without a frame transform zeros
+    fft_passes<LOG2N, true>(r, work + (size_t)grp * N, tid, tw);
+    if (have) {
+#pragma unroll
+      for (int i = 0; i < GL; ++i)
+#pragma unroll
+        for (int j = 0; j < RL; ++j) {
+          const int k = out_index<RL, NSL, T>(tid, i, j);
+          if (k < bins) {
+            const c32 z = r[i * RL + j];
+            if (a.direct) {
+              const int64_t o = clip * bins * a.out_stride + a.out_offset + f0 + f + (int64_t)k * a.out_stride;
+              if (a.mode == OUT_COMPLEX) reinterpret_cast<float2 *>(a.out)[o] = make_float2(z.x, z.y);
+              else reinterpret_cast<float *>(a.out)[o] = magnitude_pow<float, float>(z.x, z.y, a.power);
+            } else if (a.mode == OUT_COMPLEX) {
+              reinterpret_cast<float2 *>(stage)[k * sstride + f] = make_float2(z.x, z.y);
+            } else {
+              reinterpret_cast<float *>(stage)[k * sstride + f] = magnitude_pow<float, float>(z.x, z.y, a.power);
+            }
+          }
+        }
+    }
+    __syncthreads();   // the next round's first pass writes the work buffers again
+  }
+  if (a.direct) return;
+  const int64_t total = bins * nf;
+  const int64_t obase = clip * bins * a.out_stride + a.out_offset + f0;
+  for (int64_t e = threadIdx.x; e < total; e += blockDim.x) {
+    const int64_t k = e / nf;
+    const int f = (int)(e % nf);
+    if (a.mode == OUT_COMPLEX)
+      reinterpret_cast<float2 *>(a.out)[obase + k * a.out_stride + f] = reinterpret_cast<const float2 *>(stage)[k * sstride + f];
+    else
+      reinterpret_cast<float *>(a.out)[obase + k * a.out_stride + f] = reinterpret_cast<const float *>(stage)[k * sstride + f];
+  }
+}
+
+template <int LOG2N>
+bool launch_stockham(const StftJob &job, GenericArgs a) {
+  constexpr int N = 1 << LOG2N, T = N / 16, G = T < 256 ? 256 / T : 1, THREADS = T < 256 ? 256 : T;
+  const size_t elem_out = (job.mode == OUT_COMPLEX ? 2 : 1) * sizeof(float);
+  const size_t work = (size_t)G * N * sizeof(float2);
+  auto stage_bytes = [&](int ft) { return (size_t)a.bins * (size_t)(ft + 1) * elem_out + 16; };
+  int ft = 16;
+  while (ft > G && work + stage_bytes(ft) > kLdsLimit) ft >>= 1;
+  a.direct = work + stage_bytes(ft) > kLdsLimit ? 1 : 0;   // fft 16384: the work buffer alone is 128 KB
+  if (a.direct) ft = G;
+  if (work > kLdsLimit) return false;
+  a.ft = ft;
+  const int64_t blocks = a.lead * ((a.count + ft - 1) / ft);
+  if (blocks > 2147483647LL) throw Failure("stft: too many frame tiles for one launch");
+  const size_t lds = a.direct ? work : work + stage_bytes(ft);
+  auto kernel = stft_stockham_kernel<LOG2N, float>;
+  SMX_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  hipLaunchKernelGGL(kernel, dim3((unsigned)blocks), dim3(THREADS), lds, job.stream, a);
+  SMX_HIP_CHECK(hipGetLastError());
+  return true;
+}
+
 template <typename Tin, typename Tacc, typename Tout>
 void launch_typed(const StftJob &job, GenericArgs a) {
   const int64_t N = a.fft;
@@ -247,6 +346,18 @@ void launch_stft_generic(const StftJob &job) {
   const bool f64_interior = job.in_bytes == 8 || job.interior == SMX_INTERIOR_F64;
   a.window = f64_interior ? (const void *)t.window_f64 : (const void *)t.window_f32;
   a.twiddle = f64_interior ? (const void *)t.twiddle_f64 : (const void *)t.twiddle_f32;
+  if (job.in_bytes == 4 && !f64_interior && !fast_path_disabled()) {
+    bool done = false;
+    switch (c.fft_size) {
+      case 1024: done = launch_stockham<10>(job, a); break;
+      case 2048: done = launch_stockham<11>(job, a); break;
+      case 4096: done = launch_stockham<12>(job, a); break;
+      case 8192: done = launch_stockham<13>(job, a); break;
+      case 16384: done = launch_stockham<14>(job, a); break;
+      default: break;
+    }
+    if (done) return;
+  }
   if (job.in_bytes == 8)
     launch_typed<double, double, double>(job, a);
   else if (f64_interior)

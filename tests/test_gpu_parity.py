@@ -175,6 +175,27 @@ def test_transform_float32_vs_oracle(hop, n, lead):
     check_fast(pw, np.abs(got.astype(np.complex128)) ** 2, "power vs |transform|^2")
 
 
+@pytest.mark.parametrize("fft,hop", [(1024, 256), (4096, 1024), (8192, 2048), (16384, 4096), (1024, 300)])
+def test_power_of_two_sizes_float32(fft, hop):
+    """fft 1024 .. 16384 on float32 audio (the Stockham-pass kernel of stft_generic.hip; 16384 falls back to the
+    radix-2 kernel): spectrum and power against the oracle, reflected borders and ragged last tile included, and
+    adjacent frame ranges reassemble the whole bit for bit (stft_grid.ml:32-73)."""
+    rng = np.random.default_rng(fft + hop)
+    n = 7 * fft + 333
+    x = rng.uniform(-1, 1, size=(3, n)).astype(np.float32)
+    c = Stft.Config.create(fft_size=fft, hop=hop)
+    o = O.stft_config(fft, hop=hop)
+    z, want = Stft.transform(c, x), O.transform(o, x)
+    assert z.shape == want.shape and z.dtype == np.complex64
+    check_fast(z.real, want.real, "re")
+    check_fast(z.imag, want.imag, "im")
+    check_fast(Stft.power_spectrum(c, x), O.power_spectrum(o, x), "power")
+    total = Stft.frames(c, n)
+    cuts = [0, 1, 5, total // 2, total - 1, total]
+    parts = [Stft.transform_range(c, x, a, b) for a, b in zip(cuts[:-1], cuts[1:])]
+    assert np.array_equal(np.concatenate(parts, axis=-1), z)
+
+
 @pytest.mark.parametrize("alignment", ["centered", "left", "right"])
 @pytest.mark.parametrize("pad", ["reflect", "edge", ("constant", 0.25)])
 @pytest.mark.parametrize("fft,hop", [(2048, 512), (64, 16), (16, 20), (31, 5)])
