@@ -156,27 +156,34 @@ __device__ __forceinline__ int out_index(int tid, int i, int j) {
 template <int LOG2N, bool FIRST, bool WAVE = false>
 __device__ __forceinline__ void fft_passes(c32 (&r)[16], float2 *z, int tid, const float2 *tw) {
   constexpr int N = 1 << LOG2N;
+  static_assert(LOG2N >= 8 && LOG2N <= 14, "transform sizes 256 .. 16384");
   stockham_pass<N, 16, 1, !FIRST, true, WAVE>(r, z, tid, tw);
-  stockham_pass<N, 16, 16, true, true, WAVE>(r, z, tid, tw);
-  if constexpr (LOG2N == 10) {
-    stockham_pass<N, 4, 256, true, false, WAVE>(r, z, tid, tw);
-  } else if constexpr (LOG2N == 11) {
-    stockham_pass<N, 4, 256, true, true, WAVE>(r, z, tid, tw);
-    stockham_pass<N, 2, 1024, true, false, WAVE>(r, z, tid, tw);
-  } else if constexpr (LOG2N == 12) {
-    stockham_pass<N, 16, 256, true, false, WAVE>(r, z, tid, tw);
-  } else if constexpr (LOG2N == 13) {
-    stockham_pass<N, 16, 256, true, true, WAVE>(r, z, tid, tw);
-    stockham_pass<N, 2, 4096, true, false, WAVE>(r, z, tid, tw);
+  if constexpr (LOG2N == 8) {
+    stockham_pass<N, 16, 16, true, false, WAVE>(r, z, tid, tw);
   } else {
-    stockham_pass<N, 16, 256, true, true, WAVE>(r, z, tid, tw);
-    stockham_pass<N, 4, 4096, true, false, WAVE>(r, z, tid, tw);
+    stockham_pass<N, 16, 16, true, true, WAVE>(r, z, tid, tw);
+    if constexpr (LOG2N == 9) {
+      stockham_pass<N, 2, 256, true, false, WAVE>(r, z, tid, tw);
+    } else if constexpr (LOG2N == 10) {
+      stockham_pass<N, 4, 256, true, false, WAVE>(r, z, tid, tw);
+    } else if constexpr (LOG2N == 11) {
+      stockham_pass<N, 4, 256, true, true, WAVE>(r, z, tid, tw);
+      stockham_pass<N, 2, 1024, true, false, WAVE>(r, z, tid, tw);
+    } else if constexpr (LOG2N == 12) {
+      stockham_pass<N, 16, 256, true, false, WAVE>(r, z, tid, tw);
+    } else if constexpr (LOG2N == 13) {
+      stockham_pass<N, 16, 256, true, true, WAVE>(r, z, tid, tw);
+      stockham_pass<N, 2, 4096, true, false, WAVE>(r, z, tid, tw);
+    } else {
+      stockham_pass<N, 16, 256, true, true, WAVE>(r, z, tid, tw);
+      stockham_pass<N, 4, 4096, true, false, WAVE>(r, z, tid, tw);
+    }
   }
 }
 
 template <int LOG2N>
 struct LastPass {   // radix / sub-size of the final pass of fft_passes<LOG2N>
-  static constexpr int R = (LOG2N == 10 || LOG2N == 14) ? 4 : (LOG2N == 12 ? 16 : 2);
+  static constexpr int R = (LOG2N == 10 || LOG2N == 14) ? 4 : ((LOG2N == 12 || LOG2N == 8) ? 16 : 2);
   static constexpr int NS = (1 << LOG2N) / R;
 };
 

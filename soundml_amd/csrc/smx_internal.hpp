@@ -59,6 +59,13 @@ struct StftTables {
   float *fast_window = nullptr;    // 0.5 * window, f32
   float2 *fast_w_m = nullptr;      // exp(-2 pi i j / M), j < M   (M = N/2)
   float2 *fast_w_n = nullptr;      // exp(-2 pi i k / N), k <= M
+  // chirp-z (Bluestein) path of the generic float32 kernels for sizes that are not powers of two: an N-point DFT
+  // as one circular convolution of length blu_m = 2^blu_log2m >= 2 N - 1
+  float2 *blu_chirp = nullptr;     // exp(-i pi n^2 / N) * window[n], n < N   (window folded in)
+  float2 *blu_post = nullptr;      // exp(-i pi k^2 / N), k < N
+  float2 *blu_filter = nullptr;    // FFT_M of exp(+i pi m^2 / N) (wrapped), times 1/M, natural order
+  float2 *blu_tw = nullptr;        // exp(-2 pi i j / M), j < M/2
+  int blu_log2m = 0;
   float2 *fast_synth_window = nullptr;   // (w[2j], -w[2j+1]) / (2M): synthesis window of the fast inverse kernel
 };
 

@@ -57,13 +57,16 @@ __device__ inline double fetch_sample(const Tin *x, int64_t n, int64_t s, int pa
 // |z|^p with the reference's rounding order (stft.ml:670-674): the spectrum is
 // rounded to the storage component type first, the magnitude is taken in the
 // real dtype, then squared / kept / raised.
+// kept out of line: the general power is rare and long, and the callers below are unrolled 16 times
+__device__ __noinline__ float general_power_f32(float p2, float half_power) { return powf(p2, half_power); }
+
 template <typename Tacc, typename Tout>
 __device__ inline Tout magnitude_pow(Tacc re, Tacc im, double power) {
   if constexpr (sizeof(Tacc) == 4) {
     const float p2 = re * re + im * im;
     if (power == 2.0) return (Tout)p2;
     if (power == 1.0) return (Tout)sqrtf(p2);
-    return (Tout)powf(p2, (float)(0.5 * power));
+    return (Tout)general_power_f32(p2, (float)(0.5 * power));
   } else {
     const Tout r = (Tout)re, i = (Tout)im;
     const Tout m = (Tout)sqrt((double)r * (double)r + (double)i * (double)i);
@@ -218,10 +221,22 @@ __global__ void __launch_bounds__((1 << LOG2N) / 16 < 256 ? 256 : (1 << LOG2N) /
     c32 r[16];
     if (have) {
       const int64_t s0 = (a.p0 + f0 + f) * a.hop - a.left;
+      if (s0 >= 0 && s0 + N <= a.n) {   // the frame lies inside the signal (uniform per group): plain loads
+        const Tin *xs = x + s0;
 #pragma unroll
-      for (int m = 0; m < 16; ++m) {
-        const int i = tid + T * m;
-        r[m] = {(float)fetch_sample<Tin>(x, a.n, s0 + i, a.pad, a.pad_value) * window[i], 0.0f};
+        for (int m = 0; m < 16; ++m) {
+          const int i = tid + T * m;
+          r[m] = {(float)xs[i] * window[i], 0.0f};
+        }
+      } else {
+#pragma unroll 1
+        for (int m = 0; m < 16; ++m) {
+          const int i = tid + T * m;
+          const float v = (float)fetch_sample<Tin>(x, a.n, s0 + i, a.pad, a.pad_value) * window[i];
+#pragma unroll
+          for (int mm = 0; mm < 16; ++mm)
+            if (mm == m) r[mm] = {v, 0.0f};
+        }
       }
     } else {
 #pragma unroll
@@ -282,6 +297,121 @@ bool launch_stockham(const StftJob &job, GenericArgs a) {
   auto kernel = stft_stockham_kernel<LOG2N, float>;
   SMX_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   hipLaunchKernelGGL(kernel, dim3((unsigned)blocks), dim3(THREADS), lds, job.stream, a);
+  SMX_HIP_CHECK(hipGetLastError());
+  return true;
+}
+
+// ---- any other size up to 8192, float32 interior: chirp-z (Bluestein) on the same Stockham passes ------------
+// X[k] = c_k sum_n (x[n] w[n] c_n) conj(c)_(k-n),  c_n = exp(-i pi n^2 / N): one circular convolution of length
+// M = 2^LOG2M >= 2 N - 1, i.e. FFT_M -> multiply by the filter's spectrum -> inverse FFT_M (as conj(FFT(conj .))),
+// exactly the structure of the FIR kernel.  O(M log M) per frame instead of the direct DFT's O(N^2).
+struct BluArgs {
+  const float2 *chirp, *post, *filter, *tw;
+};
+
+template <int LOG2M, typename Tin>
+__global__ void __launch_bounds__((1 << LOG2M) / 16 < 256 ? 256 : (1 << LOG2M) / 16) stft_bluestein_kernel(GenericArgs a, BluArgs b) {
+  using namespace fftdev;
+  constexpr int M = 1 << LOG2M, T = M / 16, G = T < 256 ? 256 / T : 1;
+  constexpr int RL = LastPass<LOG2M>::R, NSL = LastPass<LOG2M>::NS, GL = 16 / RL;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  float2 *work = reinterpret_cast<float2 *>(smem);
+  unsigned char *stage = smem + (size_t)G * M * sizeof(float2);
+  const int ft = a.ft, sstride = ft + 1;
+  const int N = (int)a.fft;
+  const int64_t tiles = (a.count + ft - 1) / ft;
+  const int64_t clip = blockIdx.x / tiles, tile = blockIdx.x % tiles;
+  const Tin *x = reinterpret_cast<const Tin *>(a.x) + clip * a.x_stride;
+  const int64_t bins = a.bins;
+  const int tid = threadIdx.x % T, grp = threadIdx.x / T;
+  float2 *z = work + (size_t)grp * M;
+  const int64_t f0 = tile * ft;
+  const int nf = (int)((a.count - f0) < ft ? (a.count - f0) : ft);
+  for (int fb = 0; fb < nf; fb += G) {
+    const int f = fb + grp;
+    const bool have = f < nf;
+    c32 r[16];
+#pragma unroll
+    for (int m = 0; m < 16; ++m) r[m] = {0.0f, 0.0f};
+    if (have) {
+      const int64_t s0 = (a.p0 + f0 + f) * a.hop - a.left;
+      const bool inside = s0 >= 0 && s0 + N <= a.n;   // uniform per group: plain loads
+#pragma unroll
+      for (int m = 0; m < 16; ++m) {
+        const int i = tid + T * m;
+        if (i < N) {
+          const float v = inside ? (float)x[s0 + i] : (float)fetch_sample<Tin>(x, a.n, s0 + i, a.pad, a.pad_value);
+          const float2 c = b.chirp[i];          // window folded in
+          r[m] = {v * c.x, v * c.y};
+        }
+      }
+    }
+    fft_passes<LOG2M, true>(r, z, tid, b.tw);
+    // product with the filter's spectrum (1/M folded in), conjugated for the inverse transform
+#pragma unroll
+    for (int i = 0; i < GL; ++i)
+#pragma unroll
+      for (int j = 0; j < RL; ++j) {
+        const int idx = out_index<RL, NSL, T>(tid, i, j);
+        const float2 h = b.filter[idx];
+        const c32 y = cmul(r[i * RL + j], c32{h.x, h.y});
+        z[swz(idx)] = make_float2(y.x, -y.y);
+      }
+    fft_passes<LOG2M, false>(r, z, tid, b.tw);
+    if (have) {
+#pragma unroll
+      for (int i = 0; i < GL; ++i)
+#pragma unroll
+        for (int j = 0; j < RL; ++j) {
+          const int k = out_index<RL, NSL, T>(tid, i, j);
+          if (k < bins) {
+            const float2 c = b.post[k];
+            const c32 v = cmul(c32{r[i * RL + j].x, -r[i * RL + j].y}, c32{c.x, c.y});   // conj of the transform, times c_k
+            if (a.direct) {
+              const int64_t o = clip * bins * a.out_stride + a.out_offset + f0 + f + (int64_t)k * a.out_stride;
+              if (a.mode == OUT_COMPLEX) reinterpret_cast<float2 *>(a.out)[o] = make_float2(v.x, v.y);
+              else reinterpret_cast<float *>(a.out)[o] = magnitude_pow<float, float>(v.x, v.y, a.power);
+            } else if (a.mode == OUT_COMPLEX) {
+              reinterpret_cast<float2 *>(stage)[k * sstride + f] = make_float2(v.x, v.y);
+            } else {
+              reinterpret_cast<float *>(stage)[k * sstride + f] = magnitude_pow<float, float>(v.x, v.y, a.power);
+            }
+          }
+        }
+    }
+    __syncthreads();
+  }
+  if (a.direct) return;
+  const int64_t total = bins * nf;
+  const int64_t obase = clip * bins * a.out_stride + a.out_offset + f0;
+  for (int64_t e = threadIdx.x; e < total; e += blockDim.x) {
+    const int64_t k = e / nf;
+    const int f = (int)(e % nf);
+    if (a.mode == OUT_COMPLEX)
+      reinterpret_cast<float2 *>(a.out)[obase + k * a.out_stride + f] = reinterpret_cast<const float2 *>(stage)[k * sstride + f];
+    else
+      reinterpret_cast<float *>(a.out)[obase + k * a.out_stride + f] = reinterpret_cast<const float *>(stage)[k * sstride + f];
+  }
+}
+
+template <int LOG2M>
+bool launch_bluestein(const StftJob &job, GenericArgs a, const BluArgs &b) {
+  constexpr int M = 1 << LOG2M, T = M / 16, G = T < 256 ? 256 / T : 1, THREADS = T < 256 ? 256 : T;
+  const size_t elem_out = (job.mode == OUT_COMPLEX ? 2 : 1) * sizeof(float);
+  const size_t work = (size_t)G * M * sizeof(float2);
+  auto stage_bytes = [&](int ft) { return (size_t)a.bins * (size_t)(ft + 1) * elem_out + 16; };
+  int ft = 16;
+  while (ft > G && work + stage_bytes(ft) > kLdsLimit) ft >>= 1;
+  a.direct = work + stage_bytes(ft) > kLdsLimit ? 1 : 0;
+  if (a.direct) ft = G;
+  if (work > kLdsLimit) return false;
+  a.ft = ft;
+  const int64_t blocks = a.lead * ((a.count + ft - 1) / ft);
+  if (blocks > 2147483647LL) throw Failure("stft: too many frame tiles for one launch");
+  const size_t lds = a.direct ? work : work + stage_bytes(ft);
+  auto kernel = stft_bluestein_kernel<LOG2M, float>;
+  SMX_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  hipLaunchKernelGGL(kernel, dim3((unsigned)blocks), dim3(THREADS), lds, job.stream, a, b);
   SMX_HIP_CHECK(hipGetLastError());
   return true;
 }
@@ -349,12 +479,27 @@ void launch_stft_generic(const StftJob &job) {
   if (job.in_bytes == 4 && !f64_interior && !fast_path_disabled()) {
     bool done = false;
     switch (c.fft_size) {
+      case 256: done = launch_stockham<8>(job, a); break;
+      case 512: done = launch_stockham<9>(job, a); break;
       case 1024: done = launch_stockham<10>(job, a); break;
       case 2048: done = launch_stockham<11>(job, a); break;
       case 4096: done = launch_stockham<12>(job, a); break;
       case 8192: done = launch_stockham<13>(job, a); break;
       case 16384: done = launch_stockham<14>(job, a); break;
       default: break;
+    }
+    if (!done && t.blu_log2m >= 8) {   // not a power of two: chirp-z
+      const BluArgs b{t.blu_chirp, t.blu_post, t.blu_filter, t.blu_tw};
+      switch (t.blu_log2m) {
+        case 8: done = launch_bluestein<8>(job, a, b); break;
+        case 9: done = launch_bluestein<9>(job, a, b); break;
+        case 10: done = launch_bluestein<10>(job, a, b); break;
+        case 11: done = launch_bluestein<11>(job, a, b); break;
+        case 12: done = launch_bluestein<12>(job, a, b); break;
+        case 13: done = launch_bluestein<13>(job, a, b); break;
+        case 14: done = launch_bluestein<14>(job, a, b); break;
+        default: break;
+      }
     }
     if (done) return;
   }

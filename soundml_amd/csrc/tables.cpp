@@ -51,6 +51,66 @@ const smx::StftTables &smx_stft_config::tables() const {
   t.twiddle_f32 = smx::upload(t32);
   t.twiddle_len = tw;
 
+  // chirp-z tables for sizes that are not powers of two (M = 256 .. 16384: N <= 8192)
+  if (!smx::is_pow2(n) && n >= 2) {
+    int log2m = 8;
+    while ((int64_t(1) << log2m) < 2 * n - 1) ++log2m;
+    if (log2m <= 14) {
+      const int64_t m = int64_t(1) << log2m;
+      auto chirp_angle = [&](int64_t i) {   // pi i^2 / N with i^2 reduced modulo 2 N (the chirp has that period)
+        const int64_t r = (i * i) % (2 * n);
+        return M_PI * (double)r / (double)n;
+      };
+      std::vector<float2> chirp((size_t)n), post((size_t)n), tw((size_t)(m / 2));
+      for (int64_t i = 0; i < n; ++i) {
+        const double a = chirp_angle(i), w = analysis_window[(size_t)i];
+        chirp[(size_t)i] = make_float2((float)(w * std::cos(a)), (float)(-w * std::sin(a)));
+        post[(size_t)i] = make_float2((float)std::cos(a), (float)(-std::sin(a)));
+      }
+      // filter b[j] = exp(+i pi j^2 / N) for |j| < N, wrapped into M points; its spectrum by an in-place
+      // float64 radix-2 DIF transform, unscrambled, with the inverse transform's 1/M folded in
+      std::vector<double> re((size_t)m, 0.0), im((size_t)m, 0.0);
+      for (int64_t j = 0; j < n; ++j) {
+        const double a = chirp_angle(j);
+        re[(size_t)j] = std::cos(a);
+        im[(size_t)j] = std::sin(a);
+        if (j > 0) {
+          re[(size_t)(m - j)] = std::cos(a);
+          im[(size_t)(m - j)] = std::sin(a);
+        }
+      }
+      for (int64_t half = m >> 1; half >= 1; half >>= 1) {
+        const int64_t tstep = (m >> 1) / half;
+        for (int64_t b = 0; b < (m >> 1); ++b) {
+          const int64_t j = b & (half - 1);
+          const int64_t i0 = ((b - j) << 1) + j, i1 = i0 + half;
+          const double ang = -2.0 * M_PI * (double)(j * tstep) / (double)m;
+          const double wr = std::cos(ang), wi = std::sin(ang);
+          const double dr = re[(size_t)i0] - re[(size_t)i1], di = im[(size_t)i0] - im[(size_t)i1];
+          re[(size_t)i0] += re[(size_t)i1];
+          im[(size_t)i0] += im[(size_t)i1];
+          re[(size_t)i1] = dr * wr - di * wi;
+          im[(size_t)i1] = dr * wi + di * wr;
+        }
+      }
+      std::vector<float2> filt((size_t)m);
+      for (int64_t i = 0; i < m; ++i) {
+        unsigned k = 0;
+        for (int bit = 0; bit < log2m; ++bit) k |= ((unsigned)(i >> bit) & 1u) << (log2m - 1 - bit);   // position i holds B[brev(i)]
+        filt[k] = make_float2((float)(re[(size_t)i] / (double)m), (float)(im[(size_t)i] / (double)m));
+      }
+      for (int64_t j = 0; j < m / 2; ++j) {
+        const double a = -2.0 * M_PI * (double)j / (double)m;
+        tw[(size_t)j] = make_float2((float)std::cos(a), (float)std::sin(a));
+      }
+      t.blu_chirp = smx::upload(chirp);
+      t.blu_post = smx::upload(post);
+      t.blu_filter = smx::upload(filt);
+      t.blu_tw = smx::upload(tw);
+      t.blu_log2m = log2m;
+    }
+  }
+
   // fast kernels (power-of-two N >= 64): half-scaled window and split tables
   if (smx::is_pow2(n) && n >= 64) {
     const int64_t m = n / 2;
@@ -89,6 +149,10 @@ smx_stft_config::~smx_stft_config() {
     (void)hipFree(t.fast_w_m);
     (void)hipFree(t.fast_w_n);
     (void)hipFree(t.fast_synth_window);
+    (void)hipFree(t.blu_chirp);
+    (void)hipFree(t.blu_post);
+    (void)hipFree(t.blu_filter);
+    (void)hipFree(t.blu_tw);
   }
 }
 

@@ -175,10 +175,11 @@ def test_transform_float32_vs_oracle(hop, n, lead):
     check_fast(pw, np.abs(got.astype(np.complex128)) ** 2, "power vs |transform|^2")
 
 
-@pytest.mark.parametrize("fft,hop", [(1024, 256), (4096, 1024), (8192, 2048), (16384, 4096), (1024, 300)])
-def test_power_of_two_sizes_float32(fft, hop):
-    """fft 1024 .. 16384 on float32 audio (the Stockham-pass kernel of stft_generic.hip; 16384 falls back to the
-    radix-2 kernel): spectrum and power against the oracle, reflected borders and ragged last tile included, and
+@pytest.mark.parametrize("fft,hop", [(256, 64), (512, 128), (1024, 256), (4096, 1024), (8192, 2048), (16384, 4096), (1024, 300),
+                                     (400, 160), (441, 220), (100, 33), (1200, 300), (3000, 750), (6000, 1500), (8191, 2047)])
+def test_other_sizes_float32(fft, hop):
+    """Float32 audio at sizes other than 2048: powers of two 256 .. 16384 on the Stockham-pass kernel, everything
+    else up to 8192 by chirp-z (Bluestein) on the same passes (stft_generic.hip): spectrum and power against the oracle, reflected borders and ragged last tile included, and
     adjacent frame ranges reassemble the whole bit for bit (stft_grid.ml:32-73)."""
     rng = np.random.default_rng(fft + hop)
     n = 7 * fft + 333
