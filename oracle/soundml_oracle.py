@@ -817,6 +817,282 @@ def mfcc(sc: StftConfig, mc: MelConfig, x: np.ndarray, n_mfcc: int = 20, lifter:
     return cep.astype(dtype)
 
 
+# ---------------------------------------------------------------------------
+# Spectral-shape features (spectral.ml:122-255): one reduction along the bin axis, float64 interior
+# ---------------------------------------------------------------------------
+
+MIN_FLOAT = 2.2250738585072014e-308     # Float.min_float
+
+
+def _check_spectrogram(op: str, s: np.ndarray) -> None:
+    if s.ndim < 2:
+        raise ValueError("%s: cannot analyse a rank-%d tensor (a spectrogram is [...; bins; frames])" % (op, s.ndim))
+
+
+def _check_magnitudes(op: str, s: np.ndarray) -> None:
+    """spectral.ml:91-98: negative entries and NaN both fail ``s >= 0``."""
+    if s.size > 0 and not bool(np.all(s >= 0)):
+        raise ValueError("%s: cannot analyse a spectrogram with negative or NaN values (a magnitude spectrogram "
+                         "is non-negative)" % op)
+
+
+def spectral_grid(op: str, s: np.ndarray, sample_rate: int, freqs=None) -> np.ndarray:
+    """spectral.ml:105-136: the caller's grid cast to float64, or bin k at k * step with
+    step = 1 / (fft_size * (1 / sample_rate)), fft_size = 2 (bins - 1)."""
+    if sample_rate < 1:
+        raise ValueError("%s: cannot use a sample rate of %d Hz (sample_rate must be at least 1)" % (op, sample_rate))
+    if freqs is not None and np.asarray(freqs).ndim != 1:
+        raise ValueError("%s: cannot use a rank-%d freqs tensor (freqs is rank-one, one frequency per bin)"
+                         % (op, np.asarray(freqs).ndim))
+    bins = s.shape[-2]
+    if freqs is not None:
+        f = np.asarray(freqs)
+        if f.shape[0] != bins:
+            raise ValueError("%s: cannot pair %d bin frequencies with %d bins (freqs holds one frequency per bin)"
+                             % (op, f.shape[0], bins))
+        return f.astype(np.float64)
+    if bins < 2:
+        raise ValueError("%s: cannot derive bin frequencies for a %d-bin spectrogram (the implied FFT size is %d; "
+                         "pass freqs explicitly)" % (op, bins, 2 * (bins - 1)))
+    fft_size = 2 * (bins - 1)
+    step = 1.0 / (float(fft_size) * (1.0 / float(sample_rate)))
+    return np.arange(bins, dtype=np.float64) * step
+
+
+def _empty_feature(s: np.ndarray) -> np.ndarray:
+    return np.zeros(s.shape[:-2] + (1, s.shape[-1]), dtype=s.dtype)
+
+
+def _normalised(s64: np.ndarray) -> np.ndarray:
+    """spectral.ml:155-163: frames scaled to unit sum; sums below the smallest normal double divide by 1."""
+    length = s64.sum(axis=-2, keepdims=True)
+    return s64 / np.where(length < MIN_FLOAT, 1.0, length)
+
+
+def _centroid_core(fq: np.ndarray, s64: np.ndarray) -> np.ndarray:
+    return (fq[:, None] * _normalised(s64)).sum(axis=-2, keepdims=True)       # spectral.ml:168-169
+
+
+def spectral_centroid(s: np.ndarray, sample_rate: int, freqs=None) -> np.ndarray:
+    """``Spectral.centroid`` (spectral.ml:171-177)."""
+    op = "spectral_centroid"
+    s = np.asarray(s)
+    _check_spectrogram(op, s)
+    fq = spectral_grid(op, s, sample_rate, freqs)
+    _check_magnitudes(op, s)
+    if 0 in s.shape:
+        return _empty_feature(s)
+    return _centroid_core(fq, s.astype(np.float64)).astype(s.dtype)
+
+
+def spectral_bandwidth(s: np.ndarray, sample_rate: int, p: float = 2.0, freqs=None, centroid=None) -> np.ndarray:
+    """``Spectral.bandwidth`` (spectral.ml:179-218): (sum normalised * |centroid - f|^p)^(1/p)."""
+    op = "spectral_bandwidth"
+    s = np.asarray(s)
+    _check_spectrogram(op, s)
+    if not (math.isfinite(p) and p > 0.0):
+        raise ValueError("%s: cannot raise deviations to the power %s (p must be finite and positive)" % (op, _g(p)))
+    fq = spectral_grid(op, s, sample_rate, freqs)
+    if centroid is not None:
+        c = np.asarray(centroid)
+        if c.ndim < 2:
+            raise ValueError("%s: cannot reuse a rank-%d centroid (centroid must be [...; 1; frames])" % (op, c.ndim))
+        if c.shape[-2] != 1 or c.shape[-1] != s.shape[-1]:
+            raise ValueError("%s: cannot reuse a centroid with %d rows over %d frames for a %d-frame spectrogram "
+                             "(centroid must be [...; 1; frames], one frequency per frame)"
+                             % (op, c.shape[-2], c.shape[-1], s.shape[-1]))
+    _check_magnitudes(op, s)
+    if 0 in s.shape:
+        return _empty_feature(s)
+    s64 = s.astype(np.float64)
+    c64 = np.asarray(centroid).astype(np.float64) if centroid is not None else _centroid_core(fq, s64)
+    deviation = np.abs(c64 - fq[:, None])
+    weighted = _normalised(s64) * np.power(deviation, p)
+    return np.power(weighted.sum(axis=-2, keepdims=True), 1.0 / p).astype(s.dtype)
+
+
+def spectral_rolloff(s: np.ndarray, sample_rate: int, roll_percent: float = 0.85, freqs=None) -> np.ndarray:
+    """``Spectral.rolloff`` (spectral.ml:220-243): the smallest bin frequency whose cumulative magnitude reaches
+    roll_percent of the frame total (the total is the last cumulative value)."""
+    op = "spectral_rolloff"
+    s = np.asarray(s)
+    _check_spectrogram(op, s)
+    if not (roll_percent > 0.0 and roll_percent < 1.0):
+        raise ValueError("%s: cannot keep %s of the spectral energy (roll_percent must lie strictly between 0 and 1)"
+                         % (op, _g(roll_percent)))
+    fq = spectral_grid(op, s, sample_rate, freqs)
+    _check_magnitudes(op, s)
+    if 0 in s.shape:
+        return _empty_feature(s)
+    cumulative = np.cumsum(s.astype(np.float64), axis=-2)
+    total = cumulative[..., -1:, :]
+    reached = cumulative >= total * roll_percent
+    candidates = np.where(reached, fq[:, None], np.inf)
+    return candidates.min(axis=-2, keepdims=True).astype(s.dtype)
+
+
+def spectral_flatness(s: np.ndarray, amin: float = 1e-10, power: float = 2.0) -> np.ndarray:
+    """``Spectral.flatness`` (spectral.ml:245-255): geometric over arithmetic mean of max(s^power, amin)."""
+    op = "spectral_flatness"
+    s = np.asarray(s)
+    _check_spectrogram(op, s)
+    if not (math.isfinite(amin) and amin > 0.0):
+        raise ValueError("%s: cannot floor the spectrum at %s (amin must be finite and positive)" % (op, _g(amin)))
+    if not (math.isfinite(power) and power > 0.0):
+        raise ValueError("%s: cannot raise magnitudes to the power %s (power must be finite and positive)"
+                         % (op, _g(power)))
+    _check_magnitudes(op, s)
+    if 0 in s.shape:
+        return _empty_feature(s)
+    floored = np.maximum(np.power(s.astype(np.float64), power), amin)
+    geometric = np.exp(np.log(floored).mean(axis=-2, keepdims=True))
+    return (geometric / floored.mean(axis=-2, keepdims=True)).astype(s.dtype)
+
+
+# ---------------------------------------------------------------------------
+# Chroma over a linear-frequency spectrum (chroma.ml:22-317, soundml.ml:97-107)
+# ---------------------------------------------------------------------------
+
+def _round_half_even(x: float) -> float:
+    below = math.floor(x)
+    fraction = x - below
+    if fraction > 0.5:
+        return below + 1.0
+    if fraction < 0.5:
+        return below
+    return below if math.fmod(below, 2.0) == 0.0 else below + 1.0
+
+
+@dataclass
+class ChromaConfig:
+    n_chroma: int
+    tuning: float
+    ctroct: float
+    octwidth: Optional[float]
+    base_c: bool
+    sample_rate: int
+    fft_size: int
+    weights: np.ndarray          # float64 [n_chroma; bins]
+
+    @property
+    def bins(self) -> int:
+        return self.fft_size // 2 + 1
+
+
+def chroma_weights(n_chroma, tuning, ctroct, octwidth, base_c, sample_rate, fft_size) -> np.ndarray:
+    """chroma.ml:101-175, scalar float64 in the reference's operation order: Gaussian bumps in the wrapped chroma
+    distance, unit euclidean columns, optional octave envelope, rows rolled so row 0 is C."""
+    bins = fft_size // 2 + 1
+    a440 = 440.0 * math.pow(2.0, tuning / float(n_chroma)) / 16.0
+    step = float(sample_rate) / float(fft_size)
+
+    def position(j):
+        return float(n_chroma) * math.log2(float(j) * step / a440)
+    positions = [0.0] * fft_size
+    for j in range(fft_size):
+        positions[j] = position(1) - 1.5 * float(n_chroma) if j == 0 else position(j)
+    widths = [1.0 if j == fft_size - 1 else max(positions[j + 1] - positions[j], 1.0) for j in range(fft_size)]
+    half = _round_half_even(float(n_chroma) / 2.0)
+    chroma = float(n_chroma)
+    w = np.zeros((n_chroma, bins), dtype=np.float64)
+    for c in range(n_chroma):
+        for j in range(bins):
+            d = positions[j] - float(c)
+            v = math.fmod(d + half + 10.0 * chroma, chroma)
+            wrapped = (v + chroma if v < 0.0 else v) - half
+            spread = 2.0 * wrapped / widths[j]
+            w[c, j] = math.exp(-0.5 * spread * spread)
+    for j in range(bins):
+        total = 0.0
+        for c in range(n_chroma):
+            total += w[c, j] * w[c, j]
+        length = math.sqrt(total)
+        if length < MIN_FLOAT:
+            length = 1.0
+        for c in range(n_chroma):
+            w[c, j] = w[c, j] / length
+    if octwidth is not None:
+        for j in range(bins):
+            offset = (positions[j] / chroma - ctroct) / octwidth
+            w[:, j] *= math.exp(-0.5 * offset * offset)
+    if base_c:
+        shift = 3 * (n_chroma // 12)
+        w = w[(np.arange(n_chroma) + shift) % n_chroma, :]
+    return np.ascontiguousarray(w)
+
+
+def chroma_config(sample_rate: int, fft_size: int, n_chroma: int = 12, tuning: float = 0.0, ctroct: float = 5.0,
+                  octwidth: Optional[float] = 2.0, base_c: bool = True) -> ChromaConfig:
+    """``Chroma.Config.create`` (chroma.ml:177-222), messages verbatim."""
+    if n_chroma < 1:
+        raise ValueError("create: cannot build %d chroma bands (n_chroma must be at least 1)" % n_chroma)
+    if sample_rate < 1:
+        raise ValueError("create: cannot use a sample rate of %d Hz (sample_rate must be at least 1)" % sample_rate)
+    if fft_size < 1:
+        raise ValueError("create: cannot use an FFT of size %d (fft_size must be at least 1)" % fft_size)
+    if not math.isfinite(tuning):
+        raise ValueError("create: cannot shift the scale by %s bins (tuning must be finite)" % _g(tuning))
+    if not math.isfinite(ctroct):
+        raise ValueError("create: cannot centre the octave envelope at %s (ctroct must be finite)" % _g(ctroct))
+    if octwidth is not None and not (math.isfinite(octwidth) and octwidth > 0.0):
+        raise ValueError("create: cannot use an octave envelope of half-width %s (octwidth must be finite and "
+                         "positive)" % _g(octwidth))
+    return ChromaConfig(n_chroma, float(tuning), float(ctroct), None if octwidth is None else float(octwidth),
+                        bool(base_c), sample_rate, fft_size,
+                        chroma_weights(n_chroma, tuning, ctroct, octwidth, base_c, sample_rate, fft_size))
+
+
+def _check_norm(op: str, norm) -> None:
+    if norm in ("inf", None):
+        return
+    if not (math.isfinite(norm) and norm > 0.0):
+        raise ValueError("%s: cannot normalise in the %s-norm (the exponent must be finite and positive)"
+                         % (op, _g(norm)))
+
+
+def frame_normalise(x: np.ndarray, norm, tiny: float) -> np.ndarray:
+    """chroma.ml:58-88: divide each frame by its length in the norm ("inf", a positive exponent, or None);
+    lengths under ``tiny`` (the smallest normal of the caller's dtype) divide by one."""
+    if norm is None:
+        return x
+    mag = np.abs(x)
+    if norm == "inf":
+        lengths = mag.max(axis=-2, keepdims=True)
+    elif norm == 1.0:
+        lengths = mag.sum(axis=-2, keepdims=True)
+    elif norm == 2.0:
+        lengths = np.sqrt(np.square(mag).sum(axis=-2, keepdims=True))
+    else:
+        lengths = np.power(np.power(mag, norm).sum(axis=-2, keepdims=True), 1.0 / norm)
+    return x / np.where(lengths < tiny, 1.0, lengths)
+
+
+def chroma_apply(c: ChromaConfig, s: np.ndarray, norm="inf") -> np.ndarray:
+    """``Chroma.apply`` (chroma.ml:285-317): weights (float64) x spectrum cast to float64, per-frame normalisation,
+    one cast to the input dtype."""
+    _check_norm("apply", norm)
+    s = np.asarray(s)
+    if s.ndim < 2:
+        raise ValueError("apply: cannot project a rank-%d tensor (the projection needs [...; bins; frames])" % s.ndim)
+    if s.shape[-2] != c.bins:
+        raise ValueError("apply: cannot project %d frequency bins through a matrix built for an FFT of size %d "
+                         "(%d bins)" % (s.shape[-2], c.fft_size, c.bins))
+    if 0 in s.shape:
+        return np.zeros(s.shape[:-2] + (c.n_chroma, s.shape[-1]), dtype=s.dtype)
+    raw = np.einsum("cb,...bt->...ct", c.weights, s.astype(np.float64))
+    tiny = MIN_FLOAT if s.dtype == np.float64 else 2.0 ** -126
+    return frame_normalise(raw, norm, tiny).astype(s.dtype)
+
+
+def chroma_stft(sc: StftConfig, cc: ChromaConfig, x: np.ndarray, power: float = 2.0, norm="inf") -> np.ndarray:
+    """``Soundml.chroma_stft`` (soundml.ml:97-107)."""
+    if sc.fft_size != cc.fft_size:
+        raise ValueError(
+            "chroma_stft: cannot project a %d-point STFT through a filterbank built for an FFT of size %d (the two "
+            "configurations must agree on fft_size)" % (sc.fft_size, cc.fft_size))
+    return chroma_apply(cc, power_spectrum(sc, x, power), norm)
+
+
 # ----------------------------------------------------------------------------
 # FIR (BASELINE config 4; model: resample.ml:105-163) -- parity unpinned
 # ----------------------------------------------------------------------------
@@ -902,3 +1178,21 @@ def lcg_signal(n: int, seed: int = 20250803, envelope: bool = False) -> np.ndarr
             v = v * math.exp(-12.0 * float(i) / float(n))
         out[i] = v
     return out
+
+
+def harmonic_signal(n: int, sample_rate: int, seed: int = 20260803) -> np.ndarray:
+    """chroma_goldens.ml:56-83: three decaying harmonic notes, a transient a quarter of the way in, and an LCG
+    noise floor (accumulated note by note, harmonic by harmonic, like the reference's loops)."""
+    base = lcg_signal(n, seed)
+    y = np.zeros(n, dtype=np.float64)
+    sr = float(sample_rate)
+    t = np.arange(n, dtype=np.float64) / sr
+    for f0, fraction in ((65.406, 0.0), (130.813, 0.23), (246.942, 0.55)):
+        onset = fraction * float(n) / sr
+        env = np.where(t >= onset, np.exp(-3.0 * np.maximum(t - onset, 0.0)), 0.0)
+        for h in range(1, 25):
+            hf = float(h)
+            if f0 * hf < 0.45 * sr:
+                y = y + math.pow(0.7, hf) * env * np.sin(2.0 * math.pi * f0 * hf * (t - onset))
+    y[n // 4] += 3.0
+    return 0.2 * y + 0.002 * base

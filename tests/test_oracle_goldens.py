@@ -264,3 +264,96 @@ def test_c_oracle_sign_and_numpy_agreement():
     mc = O.mel_config(128, 48000, 2048)
     s = rng.uniform(0, 2, size=(2, 1025, 7)).astype(np.float32)
     np.testing.assert_allclose(c_oracle.mel_apply(mc, s), O.mel_apply(mc, s), rtol=1e-6, atol=1e-7)
+
+
+# ---- spectral-shape features (soundml/test/spectral/spectral_goldens.ml) ----------------------------------------
+
+SPECTRAL_FILES = ["spectral_centroid", "spectral_bandwidth", "spectral_rolloff", "spectral_flatness"]
+
+
+def spectral_golden_input(p):
+    """spectral_goldens.ml:27-40,84-132: |LCG| (optionally squared) reshaped to shape_s, or the magnitude STFT of
+    the LCG signal (seed 20261024)."""
+    f32 = p["dtype"] == "float32"
+    if p["source"] == "spectrogram":
+        shape = p["shape_s"]
+        v = np.abs(O.lcg_signal(int(np.prod(shape)), 20261024))
+        if p["squared"]:
+            v = v * v
+        s = v.reshape(shape)
+        return s.astype(np.float32) if f32 else s
+    x = O.lcg_signal(p["length"], 20261024)
+    return O.power_spectrum(O.stft_config(p["fft_size"], hop=p["hop"]), x.astype(np.float32) if f32 else x, 1.0)
+
+
+def spectral_golden_freqs(p, s):
+    if p["freqs"] == "fft":
+        return None
+    bins = s.shape[-2]                       # spectral_goldens.ml:51-53: 10 (k+1)(k+2)/2, exact integers
+    return np.array([10.0 * float((k + 1) * (k + 2)) / 2.0 for k in range(bins)], dtype=s.dtype)
+
+
+def run_spectral(mod, stem, p, s, freqs):
+    if stem == "spectral_centroid":
+        return mod.spectral_centroid(s, sample_rate=p["sample_rate"], freqs=freqs)
+    if stem == "spectral_bandwidth":
+        return mod.spectral_bandwidth(s, sample_rate=p["sample_rate"], p=p["p"], freqs=freqs)
+    if stem == "spectral_rolloff":
+        return mod.spectral_rolloff(s, sample_rate=p["sample_rate"], roll_percent=p["roll_percent"], freqs=freqs)
+    return mod.spectral_flatness(s, amin=p["amin"], power=p["power"])
+
+
+@pytest.mark.parametrize("stem", SPECTRAL_FILES)
+def test_spectral_goldens(stem):
+    """Spectral.{centroid,bandwidth,rolloff,flatness} restated against the librosa-0.11 vectors at the reference's
+    tolerances (spectral_goldens.ml:21-23: float64 1e-9 / 1e-12; float32 the shared 1e-6 / 1e-7)."""
+    for case in load_golden("spectral", stem)["cases"]:
+        p = case["params"]
+        s = spectral_golden_input(p)
+        got = run_spectral(O, stem, p, s, spectral_golden_freqs(p, s))
+        f32 = p["dtype"] == "float32"
+        assert got.dtype == (np.float32 if f32 else np.float64)
+        check_close(got, case["values"], shape=case["shape"], rtol=F32_RTOL if f32 else F64_RTOL,
+                    atol=F32_ATOL if f32 else F64_ATOL, msg=case["name"])
+
+
+# ---- chroma over the linear-frequency spectrum (soundml/test/chroma/chroma_goldens.ml) ---------------------------
+
+def chroma_golden_config(make, p):
+    return make(p["sample_rate"], p["fft_size"], n_chroma=p["n_chroma"], tuning=p["tuning"],
+                ctroct=p.get("ctroct", 5.0), octwidth=p.get("octwidth", 2.0), base_c=p.get("base_c", True))
+
+
+CHROMA_NORMS = {"inf": "inf", "l1": 1.0, "l2": 2.0, "none": None}
+
+
+def test_chroma_filterbank_goldens():
+    """Chroma.Config weights against librosa.filters.chroma (chroma_goldens.ml:111-136): closed form, 1e-12
+    relative + 1e-13 of the peak."""
+    for case in load_golden("chroma", "chroma_fb")["cases"]:
+        p = case["params"]
+        if p["kind"] != "filterbank":
+            continue                                  # constant-Q projections: out of scope (no CQT here)
+        c = chroma_golden_config(O.chroma_config, p)
+        peak = float(np.max(np.abs(case["values"])))
+        check_close(c.weights, case["values"], shape=case["shape"], rtol=1e-12, atol=1e-13 * peak, msg=case["name"])
+        check_close(c.weights.astype(np.float32), case["values"], shape=case["shape"], rtol=F32_RTOL, atol=F32_ATOL,
+                    msg=case["name"] + "/float32")
+
+
+def test_chroma_stft_goldens():
+    """Soundml.chroma_stft against librosa.feature.chroma_stft on the harmonic test signal
+    (chroma_goldens.ml:165-196: zero padding, closed-form tolerances; float32 input is the quantised signal)."""
+    for case in load_golden("chroma", "chroma_stft")["cases"]:
+        p = case["params"]
+        sc = O.stft_config(p["fft_size"], hop=p["hop"], pad="constant", pad_value=0.0)
+        cc = chroma_golden_config(O.chroma_config, p)
+        x = O.harmonic_signal(p["length"], p["sample_rate"])
+        f32 = p["dtype"] == "float32"
+        got = O.chroma_stft(sc, cc, x.astype(np.float32) if f32 else x, power=p["power"], norm=CHROMA_NORMS[p["norm"]])
+        peak = float(np.max(np.abs(case["values"])))
+        if f32:
+            assert got.dtype == np.float32
+            check_close(got, case["values"], shape=case["shape"], rtol=F32_RTOL, atol=F32_ATOL, msg=case["name"])
+        else:
+            check_close(got, case["values"], shape=case["shape"], rtol=1e-12, atol=1e-13 * peak, msg=case["name"])
