@@ -79,6 +79,7 @@ extern "C" {
 
 typedef struct smx_stft_config smx_stft_config;
 typedef struct smx_mel_config smx_mel_config;
+typedef struct smx_chroma_config smx_chroma_config;
 typedef struct smx_stft_kernel smx_stft_kernel;
 typedef struct smx_fir_plan smx_fir_plan;
 
@@ -221,6 +222,82 @@ int smx_mfcc_f64(const smx_stft_config *sc, const smx_mel_config *mc, const doub
 int smx_mfcc_f32_dev(const smx_stft_config *sc, const smx_mel_config *mc, const float *d_x, int64_t lead,
                      int64_t n, int64_t x_stride, int64_t n_mfcc, int has_lifter, double lifter, float *d_out,
                      void *stream);
+
+/* ---- Spectral-shape features (spectral.ml:171-255; Soundml.spectral_* re-exports, soundml.ml:119-133) ------
+ * One reduction along the bin axis of a magnitude spectrogram s [lead; bins; frames] (frames fastest) into
+ * [lead; 1; frames]; float64 interior in the reference's operation order, one rounding to the dtype of s.
+ *   centroid   sum_k f_k * (s_k / max(sum s, guarded))            (frames whose sum is below the smallest
+ *                                                                   normal double divide by 1)
+ *   bandwidth  (sum_k (s_k / sum s) * |centroid - f_k|^p)^(1/p)    centroid: the caller's [lead; 1; frames]
+ *                                                                   (c_rows / c_frames are its last two
+ *                                                                   extents, checked) or NULL = computed
+ *   rolloff    min { f_k : cumsum_k >= roll_percent * cumsum_last }
+ *   flatness   exp(mean log m) / mean m,  m = max(s^power, amin)
+ * freqs: HOST pointer to `n_freqs` bin frequencies (float64), or NULL = the FFT grid of the 2 (bins - 1)
+ * point transform, bin k at k * (1 / (fft_size * (1 / sample_rate))) (spectral.ml:105-136).
+ * Invalid_argument (messages of spectral.ml:27-98): sample_rate < 1, n_freqs != bins, bins < 2 without
+ * freqs, p / roll_percent / amin / power out of range, a centroid of the wrong shape, and a spectrogram
+ * holding a negative or NaN entry.  That last check reads the data, so the _dev entry points synchronise
+ * the stream before returning.  Empty extents write nothing (the result is all zero by contract).         */
+int smx_spectral_centroid_f32(const float *s, int64_t lead, int64_t bins, int64_t frames, const double *freqs,
+                              int64_t n_freqs, int64_t sample_rate, float *out);
+int smx_spectral_centroid_f64(const double *s, int64_t lead, int64_t bins, int64_t frames, const double *freqs,
+                              int64_t n_freqs, int64_t sample_rate, double *out);
+int smx_spectral_centroid_f32_dev(const float *d_s, int64_t lead, int64_t bins, int64_t frames,
+                                  const double *freqs, int64_t n_freqs, int64_t sample_rate, float *d_out,
+                                  void *stream);
+int smx_spectral_bandwidth_f32(const float *s, int64_t lead, int64_t bins, int64_t frames, double p,
+                               const double *freqs, int64_t n_freqs, const float *centroid, int64_t c_rows,
+                               int64_t c_frames, int64_t sample_rate, float *out);
+int smx_spectral_bandwidth_f64(const double *s, int64_t lead, int64_t bins, int64_t frames, double p,
+                               const double *freqs, int64_t n_freqs, const double *centroid, int64_t c_rows,
+                               int64_t c_frames, int64_t sample_rate, double *out);
+int smx_spectral_bandwidth_f32_dev(const float *d_s, int64_t lead, int64_t bins, int64_t frames, double p,
+                                   const double *freqs, int64_t n_freqs, const float *d_centroid, int64_t c_rows,
+                                   int64_t c_frames, int64_t sample_rate, float *d_out, void *stream);
+int smx_spectral_rolloff_f32(const float *s, int64_t lead, int64_t bins, int64_t frames, double roll_percent,
+                             const double *freqs, int64_t n_freqs, int64_t sample_rate, float *out);
+int smx_spectral_rolloff_f64(const double *s, int64_t lead, int64_t bins, int64_t frames, double roll_percent,
+                             const double *freqs, int64_t n_freqs, int64_t sample_rate, double *out);
+int smx_spectral_rolloff_f32_dev(const float *d_s, int64_t lead, int64_t bins, int64_t frames,
+                                 double roll_percent, const double *freqs, int64_t n_freqs, int64_t sample_rate,
+                                 float *d_out, void *stream);
+int smx_spectral_flatness_f32(const float *s, int64_t lead, int64_t bins, int64_t frames, double amin,
+                              double power, float *out);
+int smx_spectral_flatness_f64(const double *s, int64_t lead, int64_t bins, int64_t frames, double amin,
+                              double power, double *out);
+int smx_spectral_flatness_f32_dev(const float *d_s, int64_t lead, int64_t bins, int64_t frames, double amin,
+                                  double power, float *d_out, void *stream);
+
+/* ---- Chroma over a linear-frequency spectrum (chroma.ml:95-317; Soundml.chroma_stft, soundml.ml:97-107) --
+ * Config: the float64 [n_chroma; bins] projection of chroma.ml:109-175 (Gaussian bumps in the wrapped
+ * chroma distance, unit euclidean columns, optional octave envelope, rows rolled so row 0 is C).
+ * apply: out = cast(normalise(W x cast_f64(s))) with the per-frame norm of chroma.ml:58-88: lengths below
+ * the smallest normal of the dtype of s divide by 1.  s is [lead; bins; frames], out [lead; n_chroma; frames].
+ * chroma_stft = apply . Stft.power_spectrum ~power (fft sizes must agree).                                 */
+#define SMX_CHROMA_NORM_NONE 0
+#define SMX_CHROMA_NORM_INF 1
+#define SMX_CHROMA_NORM_P 2      /* norm_p: finite, positive */
+int smx_chroma_config_create(int64_t n_chroma, double tuning, double ctroct, int has_octwidth, double octwidth,
+                             int base_c, int64_t sample_rate, int64_t fft_size, smx_chroma_config **out);
+void smx_chroma_config_destroy(smx_chroma_config *c);
+int64_t smx_chroma_config_n_chroma(const smx_chroma_config *c);
+int64_t smx_chroma_config_bins(const smx_chroma_config *c);
+int64_t smx_chroma_config_fft_size(const smx_chroma_config *c);
+int smx_chroma_filterbank(const smx_chroma_config *c, double *out /* [n_chroma; bins] */); /* chroma.ml:259 */
+int smx_chroma_apply_f32(const smx_chroma_config *c, const float *s, int64_t lead, int64_t bins, int64_t frames,
+                         int norm, double norm_p, float *out);
+int smx_chroma_apply_f64(const smx_chroma_config *c, const double *s, int64_t lead, int64_t bins, int64_t frames,
+                         int norm, double norm_p, double *out);
+int smx_chroma_apply_f32_dev(const smx_chroma_config *c, const float *d_s, int64_t lead, int64_t bins,
+                             int64_t frames, int norm, double norm_p, float *d_out, void *stream);
+int smx_chroma_stft_f32(const smx_stft_config *sc, const smx_chroma_config *cc, const float *x, int64_t lead,
+                        int64_t n, double power, int norm, double norm_p, float *out);
+int smx_chroma_stft_f64(const smx_stft_config *sc, const smx_chroma_config *cc, const double *x, int64_t lead,
+                        int64_t n, double power, int norm, double norm_p, double *out);
+int smx_chroma_stft_f32_dev(const smx_stft_config *sc, const smx_chroma_config *cc, const float *d_x,
+                            int64_t lead, int64_t n, int64_t x_stride, double power, int norm, double norm_p,
+                            float *d_out, void *stream);
 
 /* ---- Least-squares synthesis: Stft.invert (stft.ml:902-939, stft.mli "invert") --------------------
  * x[m] = (sum_p w[m - p hop] irfft(Z[:, p])[m - p hop]) / (sum_p w^2[m - p hop]) in padded coordinates,

@@ -2,7 +2,7 @@
 spectrogram, mel filterbank, FIR block convolution) behind the reference's own
 module names:
 
-    from soundml_amd import Stft, Mel, Window, Fir, mel_spectrogram, mfcc
+    from soundml_amd import Stft, Mel, Chroma, Window, Fir, mel_spectrogram, mfcc, chroma_stft, spectral_centroid
 
 Everything computes in hand-written HIP kernels (gfx950) behind the C ABI of
 ``include/soundml_amd.h``; this package is the thin host mirror of
@@ -15,7 +15,9 @@ from . import stft as Stft
 from . import mel as Mel
 from . import window as Window
 from . import fir as Fir
-from .features import mel_spectrogram, mfcc
+from . import chroma as Chroma
+from .features import mel_spectrogram, mfcc, chroma_stft
+from .spectral import spectral_centroid, spectral_bandwidth, spectral_rolloff, spectral_flatness
 from . import shard
 
 
@@ -31,5 +33,6 @@ def device_count() -> int:
     return n.value
 
 
-__all__ = ["Stft", "Mel", "Window", "Fir", "mel_spectrogram", "mfcc", "shard", "set_interior", "device_count",
+__all__ = ["Stft", "Mel", "Chroma", "Window", "Fir", "mel_spectrogram", "mfcc", "chroma_stft", "spectral_centroid",
+           "spectral_bandwidth", "spectral_rolloff", "spectral_flatness", "shard", "set_interior", "device_count",
            "InvalidArgument", "Failure", "LIB_PATH"]

@@ -95,6 +95,30 @@ SIGNATURES = {
     "smx_mfcc_f32": (cint, [vp, vp, vp, i64, i64, i64, cint, f64, vp]),
     "smx_mfcc_f64": (cint, [vp, vp, vp, i64, i64, i64, cint, f64, vp]),
     "smx_mfcc_f32_dev": (cint, [vp, vp, vp, i64, i64, i64, i64, cint, f64, vp, vp]),
+    "smx_spectral_centroid_f32": (cint, [vp, i64, i64, i64, vp, i64, i64, vp]),
+    "smx_spectral_centroid_f64": (cint, [vp, i64, i64, i64, vp, i64, i64, vp]),
+    "smx_spectral_centroid_f32_dev": (cint, [vp, i64, i64, i64, vp, i64, i64, vp, vp]),
+    "smx_spectral_bandwidth_f32": (cint, [vp, i64, i64, i64, f64, vp, i64, vp, i64, i64, i64, vp]),
+    "smx_spectral_bandwidth_f64": (cint, [vp, i64, i64, i64, f64, vp, i64, vp, i64, i64, i64, vp]),
+    "smx_spectral_bandwidth_f32_dev": (cint, [vp, i64, i64, i64, f64, vp, i64, vp, i64, i64, i64, vp, vp]),
+    "smx_spectral_rolloff_f32": (cint, [vp, i64, i64, i64, f64, vp, i64, i64, vp]),
+    "smx_spectral_rolloff_f64": (cint, [vp, i64, i64, i64, f64, vp, i64, i64, vp]),
+    "smx_spectral_rolloff_f32_dev": (cint, [vp, i64, i64, i64, f64, vp, i64, i64, vp, vp]),
+    "smx_spectral_flatness_f32": (cint, [vp, i64, i64, i64, f64, f64, vp]),
+    "smx_spectral_flatness_f64": (cint, [vp, i64, i64, i64, f64, f64, vp]),
+    "smx_spectral_flatness_f32_dev": (cint, [vp, i64, i64, i64, f64, f64, vp, vp]),
+    "smx_chroma_config_create": (cint, [i64, f64, f64, cint, f64, cint, i64, i64, C.POINTER(vp)]),
+    "smx_chroma_config_destroy": (None, [vp]),
+    "smx_chroma_config_n_chroma": (i64, [vp]),
+    "smx_chroma_config_bins": (i64, [vp]),
+    "smx_chroma_config_fft_size": (i64, [vp]),
+    "smx_chroma_filterbank": (cint, [vp, vp]),
+    "smx_chroma_apply_f32": (cint, [vp, vp, i64, i64, i64, cint, f64, vp]),
+    "smx_chroma_apply_f64": (cint, [vp, vp, i64, i64, i64, cint, f64, vp]),
+    "smx_chroma_apply_f32_dev": (cint, [vp, vp, i64, i64, i64, cint, f64, vp, vp]),
+    "smx_chroma_stft_f32": (cint, [vp, vp, vp, i64, i64, f64, cint, f64, vp]),
+    "smx_chroma_stft_f64": (cint, [vp, vp, vp, i64, i64, f64, cint, f64, vp]),
+    "smx_chroma_stft_f32_dev": (cint, [vp, vp, vp, i64, i64, i64, f64, cint, f64, vp, vp]),
     "smx_stft_nola": (cint, [vp, C.POINTER(cint)]),
     "smx_stft_output_length": (cint, [vp, i64, pi64]),
     "smx_stft_invert_f32": (cint, [vp, vp, i64, i64, i64, cint, i64, vp]),

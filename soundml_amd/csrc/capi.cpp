@@ -1023,6 +1023,204 @@ void mfcc_host(const smx_stft_config &sc, const smx_mel_config &mc, const void *
   SMX_HIP_CHECK(hipMemcpy(out, dout.ptr, out_total, hipMemcpyDeviceToHost));
 }
 
+// ---- Spectral.* (spectral.ml:27-255): checks in the reference's order and words, then one launch -------------
+const char *spectral_op(int feature) {
+  switch (feature) {
+    case SPECTRAL_CENTROID: return "spectral_centroid";
+    case SPECTRAL_BANDWIDTH: return "spectral_bandwidth";
+    case SPECTRAL_ROLLOFF: return "spectral_rolloff";
+    default: return "spectral_flatness";
+  }
+}
+
+struct SpectralParams {
+  int feature = SPECTRAL_CENTROID;
+  double p = 2.0, power = 2.0;          // p: bandwidth exponent | roll_percent | amin
+  const double *freqs = nullptr;        // host
+  int64_t n_freqs = 0, sample_rate = 0;
+  bool has_centroid = false;
+  int64_t c_rows = 0, c_frames = 0;
+};
+
+// everything that does not read the data; returns the FFT-grid step (0 with a custom grid)
+double check_spectral(const SpectralParams &q, int64_t lead, int64_t bins, int64_t frames) {
+  const char *op = spectral_op(q.feature);
+  if (lead < 0 || bins < 0 || frames < 0)
+    throw Failure(format("%s: negative extent (lead %lld, bins %lld, frames %lld)", op, (long long)lead,
+                         (long long)bins, (long long)frames));
+  if (q.feature == SPECTRAL_BANDWIDTH && !(std::isfinite(q.p) && q.p > 0.0))
+    throw InvalidArgument(format("%s: cannot raise deviations to the power %g (p must be finite and positive)", op, q.p));
+  if (q.feature == SPECTRAL_ROLLOFF && !(q.p > 0.0 && q.p < 1.0))
+    throw InvalidArgument(format(
+        "%s: cannot keep %g of the spectral energy (roll_percent must lie strictly between 0 and 1)", op, q.p));
+  double step = 0.0;
+  if (q.feature == SPECTRAL_FLATNESS) {
+    if (!(std::isfinite(q.p) && q.p > 0.0))
+      throw InvalidArgument(format("%s: cannot floor the spectrum at %g (amin must be finite and positive)", op, q.p));
+    if (!(std::isfinite(q.power) && q.power > 0.0))
+      throw InvalidArgument(format(
+          "%s: cannot raise magnitudes to the power %g (power must be finite and positive)", op, q.power));
+    return step;
+  }
+  // grid (spectral.ml:105-136)
+  if (q.sample_rate < 1)
+    throw InvalidArgument(format("%s: cannot use a sample rate of %lld Hz (sample_rate must be at least 1)", op,
+                                 (long long)q.sample_rate));
+  if (q.freqs) {
+    if (q.n_freqs != bins)
+      throw InvalidArgument(format(
+          "%s: cannot pair %lld bin frequencies with %lld bins (freqs holds one frequency per bin)", op,
+          (long long)q.n_freqs, (long long)bins));
+  } else {
+    if (bins < 2)
+      throw InvalidArgument(format(
+          "%s: cannot derive bin frequencies for a %lld-bin spectrogram (the implied FFT size is %lld; pass "
+          "freqs explicitly)", op, (long long)bins, (long long)(2 * (bins - 1))));
+    const int64_t fft_size = 2 * (bins - 1);
+    step = 1.0 / ((double)fft_size * (1.0 / (double)q.sample_rate));
+  }
+  if (q.feature == SPECTRAL_BANDWIDTH && q.has_centroid && (q.c_rows != 1 || q.c_frames != frames))
+    throw InvalidArgument(format(
+        "%s: cannot reuse a centroid with %lld rows over %lld frames for a %lld-frame spectrogram (centroid must "
+        "be [...; 1; frames], one frequency per frame)", op, (long long)q.c_rows, (long long)q.c_frames,
+        (long long)frames));
+  return step;
+}
+
+void spectral_dev(const SpectralParams &q, const void *d_s, int elem_bytes, int64_t lead, int64_t bins,
+                  int64_t frames, const void *d_centroid, void *d_out, hipStream_t stream) {
+  const double step = check_spectral(q, lead, bins, frames);
+  if (lead == 0 || bins == 0 || frames == 0) return;   // empty_feature: all zero by contract, nothing to reduce
+  if (!d_s || !d_out) throw Failure(format("%s: null device pointer", spectral_op(q.feature)));
+  SpectralJob job;
+  job.feature = q.feature;
+  job.s = d_s;
+  job.elem_bytes = elem_bytes;
+  job.lead = lead;
+  job.bins = bins;
+  job.frames = frames;
+  job.freqs = q.freqs;
+  job.step = step;
+  job.p = q.p;
+  job.power = q.power;
+  job.centroid = q.has_centroid ? d_centroid : nullptr;
+  job.out = d_out;
+  job.stream = stream;
+  if (!launch_spectral(job))
+    throw InvalidArgument(format(
+        "%s: cannot analyse a spectrogram with negative or NaN values (a magnitude spectrogram is non-negative)",
+        spectral_op(q.feature)));
+}
+
+void spectral_host(const SpectralParams &q, const void *s, int elem_bytes, int64_t lead, int64_t bins,
+                   int64_t frames, const void *centroid, void *out) {
+  check_spectral(q, lead, bins, frames);
+  if (lead == 0 || bins == 0 || frames == 0) return;
+  if (!s || !out) throw Failure(format("%s: null pointer", spectral_op(q.feature)));
+  require_device();
+  const size_t in_total = (size_t)lead * (size_t)bins * (size_t)frames * (size_t)elem_bytes;
+  const size_t out_total = (size_t)lead * (size_t)frames * (size_t)elem_bytes;
+  DeviceScratch ds(in_total), dout(out_total), dc(q.has_centroid ? out_total : 0);
+  SMX_HIP_CHECK(hipMemcpy(ds.ptr, s, in_total, hipMemcpyHostToDevice));
+  if (q.has_centroid) SMX_HIP_CHECK(hipMemcpy(dc.ptr, centroid, out_total, hipMemcpyHostToDevice));
+  spectral_dev(q, ds.ptr, elem_bytes, lead, bins, frames, dc.ptr, dout.ptr, nullptr);
+  SMX_HIP_CHECK(hipStreamSynchronize(nullptr));
+  SMX_HIP_CHECK(hipMemcpy(out, dout.ptr, out_total, hipMemcpyDeviceToHost));
+}
+
+// ---- Chroma.apply / Soundml.chroma_stft (chroma.ml:285-317, soundml.ml:97-107) ------------------------------
+void check_chroma_norm(const char *op, int norm, double norm_p) {   // chroma.ml:30-40
+  if (norm == SMX_CHROMA_NORM_NONE || norm == SMX_CHROMA_NORM_INF) return;
+  if (norm != SMX_CHROMA_NORM_P) throw Failure(format("%s: unknown norm %d", op, norm));
+  if (!(std::isfinite(norm_p) && norm_p > 0.0))
+    throw InvalidArgument(format(
+        "%s: cannot normalise in the %g-norm (the exponent must be finite and positive)", op, norm_p));
+}
+
+void chroma_apply_dev(const smx_chroma_config &c, const void *d_s, int elem_bytes, int64_t lead, int64_t bins,
+                      int64_t frames, int norm, double norm_p, void *d_out, hipStream_t stream) {
+  check_chroma_norm("apply", norm, norm_p);
+  if (lead < 0 || bins < 0 || frames < 0)
+    throw Failure(format("apply: negative extent (lead %lld, bins %lld, frames %lld)", (long long)lead,
+                         (long long)bins, (long long)frames));
+  if (bins != c.bins())
+    throw InvalidArgument(format(
+        "apply: cannot project %lld frequency bins through a matrix built for an FFT of size %lld (%lld bins)",
+        (long long)bins, (long long)c.fft_size, (long long)c.bins()));
+  if (lead == 0 || frames == 0) return;
+  if (!d_s || !d_out) throw Failure("apply: null device pointer");
+  ChromaJob job;
+  job.config = &c;
+  job.s = d_s;
+  job.elem_bytes = elem_bytes;
+  job.lead = lead;
+  job.frames = frames;
+  job.norm = norm;
+  job.norm_p = norm_p;
+  job.out = d_out;
+  job.stream = stream;
+  launch_chroma(job);
+}
+
+void chroma_apply_host(const smx_chroma_config &c, const void *s, int elem_bytes, int64_t lead, int64_t bins,
+                       int64_t frames, int norm, double norm_p, void *out) {
+  check_chroma_norm("apply", norm, norm_p);
+  if (bins != c.bins() || lead <= 0 || frames <= 0) {   // the checks and the empty case, nothing to upload
+    chroma_apply_dev(c, nullptr, elem_bytes, lead, bins, frames, norm, norm_p, nullptr, nullptr);
+    return;
+  }
+  if (!s || !out) throw Failure("apply: null pointer");
+  require_device();
+  const size_t in_total = (size_t)lead * (size_t)bins * (size_t)frames * (size_t)elem_bytes;
+  const size_t out_total = (size_t)lead * (size_t)c.n_chroma * (size_t)frames * (size_t)elem_bytes;
+  DeviceScratch ds(in_total), dout(out_total);
+  SMX_HIP_CHECK(hipMemcpy(ds.ptr, s, in_total, hipMemcpyHostToDevice));
+  chroma_apply_dev(c, ds.ptr, elem_bytes, lead, bins, frames, norm, norm_p, dout.ptr, nullptr);
+  SMX_HIP_CHECK(hipStreamSynchronize(nullptr));
+  SMX_HIP_CHECK(hipMemcpy(out, dout.ptr, out_total, hipMemcpyDeviceToHost));
+}
+
+void check_chroma_stft(const smx_stft_config &sc, const smx_chroma_config &cc) {   // soundml.ml:98-106
+  if (sc.fft_size != cc.fft_size)
+    throw InvalidArgument(format(
+        "chroma_stft: cannot project a %lld-point STFT through a filterbank built for an FFT of size %lld (the two "
+        "configurations must agree on fft_size)", (long long)sc.fft_size, (long long)cc.fft_size));
+}
+
+void chroma_stft_dev(const smx_stft_config &sc, const smx_chroma_config &cc, const void *d_x, int in_bytes,
+                     int64_t lead, int64_t n, int64_t x_stride, double power, int norm, double norm_p, void *d_out,
+                     hipStream_t stream) {
+  check_chroma_stft(sc, cc);
+  check_chroma_norm("apply", norm, norm_p);
+  check_rank_extents("chroma_stft", lead, n);
+  const int64_t count = sc.frames(n);
+  if (lead == 0 || count == 0) return;
+  if (!d_x || !d_out) throw Failure("chroma_stft: null device pointer");
+  void *spec = nullptr;
+  SMX_HIP_CHECK(hipMallocAsync(&spec, (size_t)lead * (size_t)sc.bins() * (size_t)count * (size_t)in_bytes, stream));
+  stft_range_dev(sc, d_x, in_bytes, lead, n, x_stride, 0, count, OUT_POWER, power, spec, stream);
+  chroma_apply_dev(cc, spec, in_bytes, lead, sc.bins(), count, norm, norm_p, d_out, stream);
+  SMX_HIP_CHECK(hipFreeAsync(spec, stream));
+}
+
+void chroma_stft_host(const smx_stft_config &sc, const smx_chroma_config &cc, const void *x, int in_bytes,
+                      int64_t lead, int64_t n, double power, int norm, double norm_p, void *out) {
+  check_chroma_stft(sc, cc);
+  check_chroma_norm("apply", norm, norm_p);
+  check_rank_extents("chroma_stft", lead, n);
+  const int64_t count = sc.frames(n);
+  if (lead == 0 || count == 0) return;
+  if (!x || !out) throw Failure("chroma_stft: null pointer");
+  require_device();
+  const size_t in_total = (size_t)lead * (size_t)n * (size_t)in_bytes;
+  const size_t out_total = (size_t)lead * (size_t)cc.n_chroma * (size_t)count * (size_t)in_bytes;
+  DeviceScratch dx(in_total), dout(out_total);
+  SMX_HIP_CHECK(hipMemcpy(dx.ptr, x, in_total, hipMemcpyHostToDevice));
+  chroma_stft_dev(sc, cc, dx.ptr, in_bytes, lead, n, n, power, norm, norm_p, dout.ptr, nullptr);
+  SMX_HIP_CHECK(hipStreamSynchronize(nullptr));
+  SMX_HIP_CHECK(hipMemcpy(out, dout.ptr, out_total, hipMemcpyDeviceToHost));
+}
+
 }  // namespace
 }  // namespace smx
 
@@ -1138,6 +1336,206 @@ int smx_stft_griffin_lim_f32_dev(const smx_stft_config *c, const float *d_s, int
     check_config(c, "griffin_lim");
     griffin_lim_dev(*c, d_s, 4, lead, bins, frames, n_iter, momentum, d_init_phase, has_length, length, d_out,
                     (hipStream_t)stream);
+  });
+}
+
+// ---- Spectral.* (spectral.ml:171-255) ---------------------------------------------------------------
+int smx_spectral_centroid_f32(const float *s, int64_t lead, int64_t bins, int64_t frames, const double *freqs, int64_t n_freqs, int64_t sample_rate, float *out) {
+  return guarded([&] {
+    SpectralParams q;
+    q.feature = SPECTRAL_CENTROID;
+    q.freqs = freqs;
+    q.n_freqs = n_freqs;
+    q.sample_rate = sample_rate;
+    spectral_host(q, s, 4, lead, bins, frames, nullptr, out);
+  });
+}
+int smx_spectral_centroid_f64(const double *s, int64_t lead, int64_t bins, int64_t frames, const double *freqs, int64_t n_freqs, int64_t sample_rate, double *out) {
+  return guarded([&] {
+    SpectralParams q;
+    q.feature = SPECTRAL_CENTROID;
+    q.freqs = freqs;
+    q.n_freqs = n_freqs;
+    q.sample_rate = sample_rate;
+    spectral_host(q, s, 8, lead, bins, frames, nullptr, out);
+  });
+}
+int smx_spectral_centroid_f32_dev(const float *d_s, int64_t lead, int64_t bins, int64_t frames, const double *freqs, int64_t n_freqs, int64_t sample_rate, float *d_out, void *stream) {
+  return guarded([&] {
+    SpectralParams q;
+    q.feature = SPECTRAL_CENTROID;
+    q.freqs = freqs;
+    q.n_freqs = n_freqs;
+    q.sample_rate = sample_rate;
+    spectral_dev(q, d_s, 4, lead, bins, frames, nullptr, d_out, (hipStream_t)stream);
+  });
+}
+int smx_spectral_bandwidth_f32(const float *s, int64_t lead, int64_t bins, int64_t frames, double p, const double *freqs, int64_t n_freqs, const float *centroid, int64_t c_rows, int64_t c_frames, int64_t sample_rate, float *out) {
+  return guarded([&] {
+    SpectralParams q;
+    q.feature = SPECTRAL_BANDWIDTH;
+    q.p = p;
+    q.freqs = freqs;
+    q.n_freqs = n_freqs;
+    q.sample_rate = sample_rate;
+    q.has_centroid = centroid != nullptr;
+    q.c_rows = c_rows;
+    q.c_frames = c_frames;
+    spectral_host(q, s, 4, lead, bins, frames, centroid, out);
+  });
+}
+int smx_spectral_bandwidth_f64(const double *s, int64_t lead, int64_t bins, int64_t frames, double p, const double *freqs, int64_t n_freqs, const double *centroid, int64_t c_rows, int64_t c_frames, int64_t sample_rate, double *out) {
+  return guarded([&] {
+    SpectralParams q;
+    q.feature = SPECTRAL_BANDWIDTH;
+    q.p = p;
+    q.freqs = freqs;
+    q.n_freqs = n_freqs;
+    q.sample_rate = sample_rate;
+    q.has_centroid = centroid != nullptr;
+    q.c_rows = c_rows;
+    q.c_frames = c_frames;
+    spectral_host(q, s, 8, lead, bins, frames, centroid, out);
+  });
+}
+int smx_spectral_bandwidth_f32_dev(const float *d_s, int64_t lead, int64_t bins, int64_t frames, double p, const double *freqs, int64_t n_freqs, const float *d_centroid, int64_t c_rows, int64_t c_frames, int64_t sample_rate, float *d_out, void *stream) {
+  return guarded([&] {
+    SpectralParams q;
+    q.feature = SPECTRAL_BANDWIDTH;
+    q.p = p;
+    q.freqs = freqs;
+    q.n_freqs = n_freqs;
+    q.sample_rate = sample_rate;
+    q.has_centroid = d_centroid != nullptr;
+    q.c_rows = c_rows;
+    q.c_frames = c_frames;
+    spectral_dev(q, d_s, 4, lead, bins, frames, d_centroid, d_out, (hipStream_t)stream);
+  });
+}
+int smx_spectral_rolloff_f32(const float *s, int64_t lead, int64_t bins, int64_t frames, double roll_percent, const double *freqs, int64_t n_freqs, int64_t sample_rate, float *out) {
+  return guarded([&] {
+    SpectralParams q;
+    q.feature = SPECTRAL_ROLLOFF;
+    q.p = roll_percent;
+    q.freqs = freqs;
+    q.n_freqs = n_freqs;
+    q.sample_rate = sample_rate;
+    spectral_host(q, s, 4, lead, bins, frames, nullptr, out);
+  });
+}
+int smx_spectral_rolloff_f64(const double *s, int64_t lead, int64_t bins, int64_t frames, double roll_percent, const double *freqs, int64_t n_freqs, int64_t sample_rate, double *out) {
+  return guarded([&] {
+    SpectralParams q;
+    q.feature = SPECTRAL_ROLLOFF;
+    q.p = roll_percent;
+    q.freqs = freqs;
+    q.n_freqs = n_freqs;
+    q.sample_rate = sample_rate;
+    spectral_host(q, s, 8, lead, bins, frames, nullptr, out);
+  });
+}
+int smx_spectral_rolloff_f32_dev(const float *d_s, int64_t lead, int64_t bins, int64_t frames, double roll_percent, const double *freqs, int64_t n_freqs, int64_t sample_rate, float *d_out, void *stream) {
+  return guarded([&] {
+    SpectralParams q;
+    q.feature = SPECTRAL_ROLLOFF;
+    q.p = roll_percent;
+    q.freqs = freqs;
+    q.n_freqs = n_freqs;
+    q.sample_rate = sample_rate;
+    spectral_dev(q, d_s, 4, lead, bins, frames, nullptr, d_out, (hipStream_t)stream);
+  });
+}
+int smx_spectral_flatness_f32(const float *s, int64_t lead, int64_t bins, int64_t frames, double amin, double power, float *out) {
+  return guarded([&] {
+    SpectralParams q;
+    q.feature = SPECTRAL_FLATNESS;
+    q.p = amin;
+    q.power = power;
+    spectral_host(q, s, 4, lead, bins, frames, nullptr, out);
+  });
+}
+int smx_spectral_flatness_f64(const double *s, int64_t lead, int64_t bins, int64_t frames, double amin, double power, double *out) {
+  return guarded([&] {
+    SpectralParams q;
+    q.feature = SPECTRAL_FLATNESS;
+    q.p = amin;
+    q.power = power;
+    spectral_host(q, s, 8, lead, bins, frames, nullptr, out);
+  });
+}
+int smx_spectral_flatness_f32_dev(const float *d_s, int64_t lead, int64_t bins, int64_t frames, double amin, double power, float *d_out, void *stream) {
+  return guarded([&] {
+    SpectralParams q;
+    q.feature = SPECTRAL_FLATNESS;
+    q.p = amin;
+    q.power = power;
+    spectral_dev(q, d_s, 4, lead, bins, frames, nullptr, d_out, (hipStream_t)stream);
+  });
+}
+
+// ---- Chroma (chroma.ml:95-317, soundml.ml:97-107) ---------------------------------------------------
+int smx_chroma_config_create(int64_t n_chroma, double tuning, double ctroct, int has_octwidth, double octwidth,
+                             int base_c, int64_t sample_rate, int64_t fft_size, smx_chroma_config **out) {
+  return guarded([&] {
+    if (!out) throw Failure("create: null output handle");
+    *out = chroma_config_create(n_chroma, tuning, ctroct, has_octwidth != 0, octwidth, base_c != 0, sample_rate, fft_size);
+  });
+}
+void smx_chroma_config_destroy(smx_chroma_config *c) { delete c; }
+int64_t smx_chroma_config_n_chroma(const smx_chroma_config *c) { return c ? c->n_chroma : -1; }
+int64_t smx_chroma_config_bins(const smx_chroma_config *c) { return c ? c->bins() : -1; }
+int64_t smx_chroma_config_fft_size(const smx_chroma_config *c) { return c ? c->fft_size : -1; }
+int smx_chroma_filterbank(const smx_chroma_config *c, double *out) {
+  return guarded([&] {
+    check_config(c, "filterbank");
+    if (!out) throw Failure("filterbank: null pointer");
+    std::memcpy(out, c->weights.data(), c->weights.size() * sizeof(double));
+  });
+}
+int smx_chroma_apply_f32(const smx_chroma_config *c, const float *s, int64_t lead, int64_t bins, int64_t frames,
+                         int norm, double norm_p, float *out) {
+  return guarded([&] {
+    check_config(c, "apply");
+    chroma_apply_host(*c, s, 4, lead, bins, frames, norm, norm_p, out);
+  });
+}
+int smx_chroma_apply_f64(const smx_chroma_config *c, const double *s, int64_t lead, int64_t bins, int64_t frames,
+                         int norm, double norm_p, double *out) {
+  return guarded([&] {
+    check_config(c, "apply");
+    chroma_apply_host(*c, s, 8, lead, bins, frames, norm, norm_p, out);
+  });
+}
+int smx_chroma_apply_f32_dev(const smx_chroma_config *c, const float *d_s, int64_t lead, int64_t bins,
+                             int64_t frames, int norm, double norm_p, float *d_out, void *stream) {
+  return guarded([&] {
+    check_config(c, "apply");
+    chroma_apply_dev(*c, d_s, 4, lead, bins, frames, norm, norm_p, d_out, (hipStream_t)stream);
+  });
+}
+int smx_chroma_stft_f32(const smx_stft_config *sc, const smx_chroma_config *cc, const float *x, int64_t lead,
+                        int64_t n, double power, int norm, double norm_p, float *out) {
+  return guarded([&] {
+    check_config(sc, "chroma_stft");
+    check_config(cc, "chroma_stft");
+    chroma_stft_host(*sc, *cc, x, 4, lead, n, power, norm, norm_p, out);
+  });
+}
+int smx_chroma_stft_f64(const smx_stft_config *sc, const smx_chroma_config *cc, const double *x, int64_t lead,
+                        int64_t n, double power, int norm, double norm_p, double *out) {
+  return guarded([&] {
+    check_config(sc, "chroma_stft");
+    check_config(cc, "chroma_stft");
+    chroma_stft_host(*sc, *cc, x, 8, lead, n, power, norm, norm_p, out);
+  });
+}
+int smx_chroma_stft_f32_dev(const smx_stft_config *sc, const smx_chroma_config *cc, const float *d_x,
+                            int64_t lead, int64_t n, int64_t x_stride, double power, int norm, double norm_p,
+                            float *d_out, void *stream) {
+  return guarded([&] {
+    check_config(sc, "chroma_stft");
+    check_config(cc, "chroma_stft");
+    chroma_stft_dev(*sc, *cc, d_x, 4, lead, n, x_stride, power, norm, norm_p, d_out, (hipStream_t)stream);
   });
 }
 

@@ -408,4 +408,87 @@ void design_lowpass(int64_t taps, double fc, double beta, double *h) {
   for (int64_t i = 0; i < taps; ++i) h[i] = h[i] * gain;
 }
 
+// ---- Chroma.Config (chroma.ml:95-222) ------------------------------------------------------------------
+namespace {
+double round_half_even(double x) {   // chroma.ml:93-99: ties to the even neighbour
+  const double below = std::floor(x), fraction = x - below;
+  if (fraction > 0.5) return below + 1.0;
+  if (fraction < 0.5) return below;
+  return std::fmod(below, 2.0) == 0.0 ? below : below + 1.0;
+}
+}  // namespace
+
+smx_chroma_config *chroma_config_create(int64_t n_chroma, double tuning, double ctroct, bool has_octwidth,
+                                        double octwidth, bool base_c, int64_t sample_rate, int64_t fft_size) {
+  if (n_chroma < 1)
+    throw InvalidArgument(format("create: cannot build %lld chroma bands (n_chroma must be at least 1)",
+                                 (long long)n_chroma));
+  if (sample_rate < 1)
+    throw InvalidArgument(format("create: cannot use a sample rate of %lld Hz (sample_rate must be at least 1)",
+                                 (long long)sample_rate));
+  if (fft_size < 1)
+    throw InvalidArgument(format("create: cannot use an FFT of size %lld (fft_size must be at least 1)",
+                                 (long long)fft_size));
+  if (!std::isfinite(tuning))
+    throw InvalidArgument(format("create: cannot shift the scale by %g bins (tuning must be finite)", tuning));
+  if (!std::isfinite(ctroct))
+    throw InvalidArgument(format("create: cannot centre the octave envelope at %g (ctroct must be finite)", ctroct));
+  if (has_octwidth && !(std::isfinite(octwidth) && octwidth > 0.0))
+    throw InvalidArgument(format(
+        "create: cannot use an octave envelope of half-width %g (octwidth must be finite and positive)", octwidth));
+
+  // chroma.ml:109-175 weights_of, scalar float64 in the reference's order
+  const int64_t bins = fft_size / 2 + 1;
+  const double chroma = (double)n_chroma;
+  const double a440 = 440.0 * std::pow(2.0, tuning / chroma) / 16.0;
+  const double step = (double)sample_rate / (double)fft_size;
+  auto position = [&](int64_t j) { return chroma * std::log2((double)j * step / a440); };
+  std::vector<double> positions((size_t)fft_size), widths((size_t)fft_size);
+  for (int64_t j = 0; j < fft_size; ++j)
+    positions[(size_t)j] = j == 0 ? position(1) - 1.5 * chroma : position(j);   // bin 0 carries no frequency
+  for (int64_t j = 0; j < fft_size; ++j)
+    widths[(size_t)j] = j == fft_size - 1 ? 1.0 : std::max(positions[(size_t)j + 1] - positions[(size_t)j], 1.0);
+  const double half = round_half_even(chroma / 2.0);
+  std::vector<double> w((size_t)(n_chroma * bins), 0.0);
+  for (int64_t c = 0; c < n_chroma; ++c)
+    for (int64_t j = 0; j < bins; ++j) {
+      const double d = positions[(size_t)j] - (double)c;
+      const double v = std::fmod(d + half + 10.0 * chroma, chroma);
+      const double wrapped = (v < 0.0 ? v + chroma : v) - half;
+      const double spread = 2.0 * wrapped / widths[(size_t)j];
+      w[(size_t)(c * bins + j)] = std::exp(-0.5 * spread * spread);
+    }
+  for (int64_t j = 0; j < bins; ++j) {   // unit euclidean columns
+    double sum = 0.0;
+    for (int64_t c = 0; c < n_chroma; ++c) sum += w[(size_t)(c * bins + j)] * w[(size_t)(c * bins + j)];
+    double length = std::sqrt(sum);
+    if (length < 2.2250738585072014e-308) length = 1.0;
+    for (int64_t c = 0; c < n_chroma; ++c) w[(size_t)(c * bins + j)] = w[(size_t)(c * bins + j)] / length;
+  }
+  if (has_octwidth)
+    for (int64_t j = 0; j < bins; ++j) {
+      const double offset = (positions[(size_t)j] / chroma - ctroct) / octwidth;
+      const double envelope = std::exp(-0.5 * offset * offset);
+      for (int64_t c = 0; c < n_chroma; ++c) w[(size_t)(c * bins + j)] = w[(size_t)(c * bins + j)] * envelope;
+    }
+  smx_chroma_config *cfg = new smx_chroma_config();
+  cfg->n_chroma = n_chroma;
+  cfg->tuning = tuning;
+  cfg->ctroct = ctroct;
+  cfg->has_octwidth = has_octwidth;
+  cfg->octwidth = has_octwidth ? octwidth : 0.0;
+  cfg->base_c = base_c;
+  cfg->sample_rate = sample_rate;
+  cfg->fft_size = fft_size;
+  if (!base_c) {
+    cfg->weights = std::move(w);
+  } else {   // row 0 is C rather than A
+    const int64_t shift = 3 * (n_chroma / 12);
+    cfg->weights.resize(w.size());
+    for (int64_t c = 0; c < n_chroma; ++c)
+      std::copy_n(&w[(size_t)(((c + shift) % n_chroma) * bins)], (size_t)bins, &cfg->weights[(size_t)(c * bins)]);
+  }
+  return cfg;
+}
+
 }  // namespace smx

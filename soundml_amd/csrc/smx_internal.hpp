@@ -126,6 +126,21 @@ struct smx_mel_config {
   mutable std::map<int, smx::MelFusedPlan> fused_;
 };
 
+// Chroma.Config.t (chroma.ml:95-107): the [n_chroma; bins] projection matrix, float64, built once on the host
+struct smx_chroma_config {
+  int64_t n_chroma = 12, sample_rate = 0, fft_size = 0;
+  double tuning = 0.0, ctroct = 5.0, octwidth = 2.0;
+  bool has_octwidth = true, base_c = true;
+  std::vector<double> weights;   // [n_chroma; bins]
+  int64_t bins() const { return fft_size / 2 + 1; }
+  const double *device_weights() const;   // tables.cpp: transposed [bins; n_chroma] on the current device
+  ~smx_chroma_config();
+
+ private:
+  mutable std::mutex mutex_;
+  mutable std::map<int, double *> tables_;
+};
+
 namespace smx {
 
 // ---- host logic (host_config.cpp) ----------------------------------------------
@@ -139,6 +154,8 @@ int64_t stft_last_complete(const smx_stft_config &c, int64_t n);                
 int64_t source_index(const smx_stft_config &c, int64_t n, int64_t q);            // stft.ml:300-338
 smx_mel_config *mel_config_create(int64_t n_mels, int64_t sample_rate, int64_t fft_size,
                                   double f_min, bool has_f_max, double f_max, int scale, int norm);
+smx_chroma_config *chroma_config_create(int64_t n_chroma, double tuning, double ctroct, bool has_octwidth,
+                                        double octwidth, bool base_c, int64_t sample_rate, int64_t fft_size);
 bool stft_nola(const smx_stft_config &c);                                        // stft.ml:731-743
 int64_t stft_output_length(const smx_stft_config &c, int64_t frames);            // stft.ml:792-796
 // envelope over the span of `frames` frames as three pieces: positions [0, head) and [stop, span) summed tap by
@@ -218,6 +235,38 @@ struct MfccJob {
   hipStream_t stream = nullptr;
 };
 void launch_mfcc(const MfccJob &job);             // mfcc.hip
+
+// spectral-shape features over a device-resident spectrogram [lead; bins; frames] (spectral.ml:171-255)
+enum SpectralFeature { SPECTRAL_CENTROID = 0, SPECTRAL_BANDWIDTH = 1, SPECTRAL_ROLLOFF = 2, SPECTRAL_FLATNESS = 3 };
+struct SpectralJob {
+  int feature = SPECTRAL_CENTROID;
+  const void *s = nullptr;       // device [lead; bins; frames]
+  int elem_bytes = 4;
+  int64_t lead = 0, bins = 0, frames = 0;
+  const double *freqs = nullptr; // HOST [bins] custom grid, or null: bin k at k * step
+  double step = 0.0;
+  double p = 2.0;                // bandwidth exponent | roll_percent | flatness amin
+  double power = 2.0;            // flatness power
+  const void *centroid = nullptr;   // device [lead; 1; frames] (bandwidth), element type of s, or null
+  void *out = nullptr;           // device [lead; 1; frames]
+  hipStream_t stream = nullptr;
+};
+// returns false when the spectrogram holds a negative or NaN entry (nothing useful is written then);
+// synchronises the stream to read that verdict
+bool launch_spectral(const SpectralJob &job);   // spectral.hip
+
+// Chroma.apply (chroma.ml:285-317): float64 projection + per-frame normalisation, one rounding
+struct ChromaJob {
+  const smx_chroma_config *config = nullptr;
+  const void *s = nullptr;       // device [lead; bins; frames]
+  int elem_bytes = 4;
+  int64_t lead = 0, frames = 0;
+  int norm = SMX_CHROMA_NORM_INF;
+  double norm_p = 0.0;           // exponent for SMX_CHROMA_NORM_P
+  void *out = nullptr;           // device [lead; n_chroma; frames]
+  hipStream_t stream = nullptr;
+};
+void launch_chroma(const ChromaJob &job);       // spectral.hip
 
 struct MelSpecJob {
   StftJob stft;                  // out/out_stride unused; mode/power used

@@ -203,3 +203,23 @@ smx_mel_config::~smx_mel_config() {
     (void)hipFree(kv.second.w_mfma);
   }
 }
+
+const double *smx_chroma_config::device_weights() const {
+  int device = 0;
+  SMX_HIP_CHECK(hipGetDevice(&device));
+  std::lock_guard<std::mutex> lock(mutex_);
+  auto it = tables_.find(device);
+  if (it != tables_.end()) return it->second;
+  // transposed [bins; n_chroma]: the projection kernel reads one bin's column of weights with scalar loads
+  const int64_t nb = bins();
+  std::vector<double> wt((size_t)(nb * n_chroma));
+  for (int64_t c = 0; c < n_chroma; ++c)
+    for (int64_t j = 0; j < nb; ++j) wt[(size_t)(j * n_chroma + c)] = weights[(size_t)(c * nb + j)];
+  double *dev = smx::upload(wt);
+  tables_.emplace(device, dev);
+  return dev;
+}
+
+smx_chroma_config::~smx_chroma_config() {
+  for (auto &kv : tables_) (void)hipFree(kv.second);
+}

@@ -1,4 +1,4 @@
-"""Flat feature API: ``Soundml.mel_spectrogram`` (soundml.ml:12-24)."""
+"""Flat feature API: ``Soundml.mel_spectrogram`` / ``mfcc`` / ``chroma_stft`` (soundml.ml:12-107)."""
 from __future__ import annotations
 
 from . import _lib
@@ -59,4 +59,30 @@ def mfcc(stft_config, mel_config, x, n_mfcc: int = 20, lifter=None):
         return out
     fn = lib.smx_mfcc_f32 if b.bytes == 4 else lib.smx_mfcc_f64
     check(fn(stft_config._h, mel_config._h, b.ptr(), lead, n, int(n_mfcc), 1 if has_lifter else 0, lift, out_ptr(out)))
+    return b.wrap(out)
+
+
+def chroma_stft(stft_config, chroma_config, x, power: float = 2.0, norm="inf"):
+    """``Soundml.chroma_stft stft chroma ?power ?norm x`` (soundml.ml:97-107) =
+    Chroma.apply ?norm chroma (Stft.power_spectrum ~power stft x); [...; n] -> [...; n_chroma; frames]."""
+    from . import chroma as Chroma
+    kind, p = Chroma.norm_args(norm)
+    if stft_config.fft_size != chroma_config.fft_size or (kind == Chroma.NORM_P and not (p > 0.0 and p != float("inf"))):
+        # the reference's checks come before the tensor is looked at: let the ABI word them
+        check(lib.smx_chroma_stft_f32(stft_config._h, chroma_config._h, None, 0, 0, float(power), kind, p, None))
+    b = Batch(x, "power_spectrum")
+    n = int(b.shape[-1])
+    lead_shape = b.shape[:-1]
+    lead = prod(lead_shape)
+    count = Stft.frames(stft_config, n)
+    out = b.empty(lead_shape + (chroma_config.n_chroma, count))
+    if b.device:
+        if b.bytes != 4:
+            return Chroma.apply(chroma_config, Stft.power_spectrum(stft_config, x, power), norm)
+        with b.device_guard():
+            check(lib.smx_chroma_stft_f32_dev(stft_config._h, chroma_config._h, b.ptr(), lead, n, n, float(power),
+                                              kind, p, out_ptr(out), b.stream()))
+        return out
+    fn = lib.smx_chroma_stft_f32 if b.bytes == 4 else lib.smx_chroma_stft_f64
+    check(fn(stft_config._h, chroma_config._h, b.ptr(), lead, n, float(power), kind, p, out_ptr(out)))
     return b.wrap(out)

@@ -587,6 +587,194 @@ def test_mfcc_messages():
     assert S.mfcc(sc, mc, np.zeros((0, 1000), np.float32)).shape == (0, 20, Stft.frames(sc, 1000))
 
 
+# ---- spectral-shape features ------------------------------------------------------------
+
+SPECTRAL_FILES = ["spectral_centroid", "spectral_bandwidth", "spectral_rolloff", "spectral_flatness"]
+
+
+@pytest.mark.parametrize("stem", SPECTRAL_FILES)
+def test_spectral_goldens(stem):
+    """librosa-0.11 vectors of the reference (spectral_goldens.ml) on the HIP path, the reference's tolerances:
+    float64 1e-9 / 1e-12, float32 1e-6 / 1e-7.  The end-to-end "signal" cases take the magnitude spectrogram from
+    this library's own STFT (float64 interior for the float32 cases: the reference's contract)."""
+    from test_oracle_goldens import run_spectral, spectral_golden_freqs
+    for case in load_golden("spectral", stem)["cases"]:
+        p = case["params"]
+        f32 = p["dtype"] == "float32"
+        if p["source"] == "spectrogram":
+            v = np.abs(O.lcg_signal(int(np.prod(p["shape_s"])), 20261024))
+            s = (v * v if p["squared"] else v).reshape(p["shape_s"])
+            s = s.astype(np.float32) if f32 else s
+        else:
+            x = O.lcg_signal(p["length"], 20261024)
+            S.set_interior("float64")
+            s = Stft.power_spectrum(Stft.Config.create(fft_size=p["fft_size"], hop=p["hop"]),
+                                    x.astype(np.float32) if f32 else x, power=1.0)
+            S.set_interior("float32")
+        got = run_spectral(S, stem, p, s, spectral_golden_freqs(p, s))
+        assert got.dtype == (np.float32 if f32 else np.float64)
+        check_close(got, case["values"], shape=case["shape"], rtol=F32_RTOL if f32 else F64_RTOL,
+                    atol=F32_ATOL if f32 else F64_ATOL, msg=case["name"])
+
+
+@pytest.mark.parametrize("shape", [(1025, 938), (3, 513, 130), (2, 2, 40, 65), (2, 1)])
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_spectral_vs_oracle(shape, dtype):
+    """Every feature against the oracle on seeded magnitudes, at the C2 spectrogram shape among others (bins split
+    over four waves, frame tiles ragged), with silent frames, the FFT grid and a custom one, a reused centroid,
+    odd exponents; device-resident float32 input gives the host result bit for bit."""
+    import torch
+    rng = np.random.default_rng(sum(shape))
+    s = np.abs(rng.standard_normal(shape)).astype(dtype)
+    s[..., :, 0] = 0.0                                        # a silent frame: the underflow guards
+    rtol, atol = (2e-6, 1e-7) if dtype == np.float32 else (1e-11, 1e-13)
+    bins = shape[-2]
+    custom = np.cumsum(rng.uniform(1.0, 50.0, size=bins)).astype(dtype)
+    cases = [("centroid", lambda M, a: M.spectral_centroid(a, sample_rate=22050)),
+             ("centroid/custom", lambda M, a: M.spectral_centroid(a, sample_rate=8000, freqs=custom)),
+             ("bandwidth", lambda M, a: M.spectral_bandwidth(a, sample_rate=22050)),
+             ("bandwidth/p3", lambda M, a: M.spectral_bandwidth(a, sample_rate=22050, p=3.0, freqs=custom)),
+             ("bandwidth/p1", lambda M, a: M.spectral_bandwidth(a, sample_rate=44100, p=1.0)),
+             ("rolloff", lambda M, a: M.spectral_rolloff(a, sample_rate=22050)),
+             ("rolloff/10", lambda M, a: M.spectral_rolloff(a, sample_rate=22050, roll_percent=0.1, freqs=custom)),
+             ("flatness", lambda M, a: M.spectral_flatness(a)),
+             ("flatness/p1.5", lambda M, a: M.spectral_flatness(a, amin=1e-3, power=1.5))]
+    for name, fn in cases:
+        want = fn(O, s)
+        got = fn(S, s)
+        assert got.dtype == dtype and got.shape == want.shape == shape[:-2] + (1, shape[-1]), name
+        if name.startswith("rolloff"):
+            # a bin frequency: exact unless the running sum lands within rounding of the threshold
+            assert np.mean(got == want) >= 0.999, name
+        else:
+            np.testing.assert_allclose(got, want, rtol=rtol, atol=atol * float(np.max(want)), err_msg=name)
+        if dtype == np.float32:
+            gd = fn(S, torch.from_numpy(s).cuda())
+            assert gd.is_cuda and np.array_equal(gd.cpu().numpy(), got), name
+    c = S.spectral_centroid(s, sample_rate=22050)
+    got = S.spectral_bandwidth(s, sample_rate=22050, centroid=c)
+    np.testing.assert_allclose(got, O.spectral_bandwidth(s, sample_rate=22050, centroid=c), rtol=rtol,
+                               atol=atol * float(np.max(got)))
+
+
+def test_spectral_messages_and_edges():
+    s = np.abs(np.random.default_rng(1).standard_normal((9, 12))).astype(np.float32)
+    for fn, op in ((lambda a: S.spectral_centroid(a, sample_rate=22050), "spectral_centroid"),
+                   (lambda a: S.spectral_bandwidth(a, sample_rate=22050), "spectral_bandwidth"),
+                   (lambda a: S.spectral_rolloff(a, sample_rate=22050), "spectral_rolloff"),
+                   (lambda a: S.spectral_flatness(a), "spectral_flatness")):
+        for poison in (-1e-3, float("nan")):
+            t = s.copy()
+            t[4, 7] = poison
+            with pytest.raises(S.InvalidArgument) as e:
+                fn(t)
+            assert str(e.value) == ("%s: cannot analyse a spectrogram with negative or NaN values (a magnitude "
+                                    "spectrogram is non-negative)" % op)
+        with pytest.raises(S.InvalidArgument) as e:
+            fn(np.zeros(5, np.float32))
+        assert str(e.value) == "%s: cannot analyse a rank-1 tensor (a spectrogram is [...; bins; frames])" % op
+        for shape in ((0, 9, 12), (9, 0), (2, 0, 5)):           # nothing to reduce: zeros of the feature shape
+            if shape == (2, 0, 5) and op != "spectral_flatness":
+                continue                                         # zero bins cannot imply a grid (checked below)
+            out = fn(np.zeros(shape, np.float32))
+            assert out.shape == shape[:-2] + (1, shape[-1]) and not out.any()
+    with pytest.raises(S.InvalidArgument) as e:
+        S.spectral_centroid(np.zeros((1, 4), np.float32), sample_rate=22050)
+    assert str(e.value) == ("spectral_centroid: cannot derive bin frequencies for a 1-bin spectrogram (the implied FFT "
+                            "size is 0; pass freqs explicitly)")
+    assert S.spectral_centroid(np.ones((1, 4), np.float32), sample_rate=22050, freqs=np.array([7.0])).tolist() == [[7.0] * 4]
+    # an all-zero frame: centroid 0, bandwidth 0, roll-off at the first bin, flatness 1 (amin / amin)
+    z = np.zeros((5, 3), np.float64)
+    assert not S.spectral_centroid(z, sample_rate=100).any() and not S.spectral_bandwidth(z, sample_rate=100).any()
+    assert not S.spectral_rolloff(z, sample_rate=100).any()
+    np.testing.assert_allclose(S.spectral_flatness(z), np.ones((1, 3)), rtol=1e-12)
+
+
+# ---- chroma over the linear-frequency spectrum -------------------------------------------------------------
+
+def test_chroma_stft_goldens():
+    """librosa.feature.chroma_stft vectors (chroma_goldens.ml:165-196) through Soundml.chroma_stft on the HIP path:
+    closed-form tolerance for float64, the shared float32 one with the float64 STFT interior (the reference's
+    contract) and north_star's 1e-5 with the float32 interior."""
+    from test_oracle_goldens import CHROMA_NORMS, chroma_golden_config
+    for case in load_golden("chroma", "chroma_stft")["cases"]:
+        p = case["params"]
+        sc = Stft.Config.create(fft_size=p["fft_size"], hop=p["hop"], pad=("constant", 0.0))
+        cc = chroma_golden_config(lambda sr, fft, **kw: S.Chroma.Config.create(sr, fft, **kw), p)
+        x = O.harmonic_signal(p["length"], p["sample_rate"])
+        peak = float(np.max(np.abs(case["values"])))
+        if p["dtype"] == "float64":
+            got = S.chroma_stft(sc, cc, x, power=p["power"], norm=CHROMA_NORMS[p["norm"]])
+            assert got.dtype == np.float64
+            check_close(got, case["values"], shape=case["shape"], rtol=1e-9, atol=1e-12 * peak, msg=case["name"])
+        else:
+            S.set_interior("float64")
+            got = S.chroma_stft(sc, cc, x.astype(np.float32), power=p["power"], norm=CHROMA_NORMS[p["norm"]])
+            S.set_interior("float32")
+            assert got.dtype == np.float32
+            check_close(got, case["values"], shape=case["shape"], rtol=F32_RTOL, atol=F32_ATOL, msg=case["name"])
+            fast = S.chroma_stft(sc, cc, x.astype(np.float32), power=p["power"], norm=CHROMA_NORMS[p["norm"]])
+            check_fast(fast, np.asarray(case["values"]).reshape(case["shape"]), case["name"] + " float32 interior")
+
+
+@pytest.mark.parametrize("n_chroma,norm", [(12, "inf"), (12, None), (24, 2.0), (13, 1.0), (36, 3.0), (5, "inf")])
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_chroma_apply_vs_oracle(n_chroma, norm, dtype):
+    """Chroma.apply against the oracle: one, two and three row chunks, every norm, a silent frame (length below
+    the smallest normal: left alone), leading axes; device-resident input gives the host result."""
+    import torch
+    rng = np.random.default_rng(n_chroma)
+    cc = S.Chroma.Config.create(22050, 2048, n_chroma=n_chroma, tuning=0.1)
+    oc = O.chroma_config(22050, 2048, n_chroma=n_chroma, tuning=0.1)
+    s = (rng.standard_normal((2, 3, 1025, 70)) ** 2).astype(dtype)
+    s[0, 1, :, 5] = 0.0
+    s[1, 2, :, 9] = 1e-30 if dtype == np.float32 else 1e-300   # projects below the smallest normal
+    got = S.Chroma.apply(cc, s, norm=norm)
+    want = O.chroma_apply(oc, s, norm=norm)
+    assert got.dtype == dtype and got.shape == want.shape == (2, 3, n_chroma, 70)
+    rtol = 2e-6 if dtype == np.float32 else 1e-11
+    np.testing.assert_allclose(got, want, rtol=rtol, atol=rtol * float(np.max(np.abs(want))))
+    assert not got[0, 1, :, 5].any()
+    if dtype == np.float32:
+        gd = S.Chroma.apply(cc, torch.from_numpy(s).cuda(), norm=norm)
+        assert gd.is_cuda and np.array_equal(gd.cpu().numpy(), got)
+
+
+def test_chroma_stft_vs_oracle_c2_geometry():
+    """Soundml.chroma_stft at the C2 geometry (fft 2048 hop 512 reflect, fused power kernel underneath) on a small
+    batch, host and device-resident."""
+    import torch
+    rng = np.random.default_rng(5)
+    x = rng.uniform(-1, 1, size=(3, 40000)).astype(np.float32)
+    sc = Stft.Config.create(fft_size=2048, hop=512)
+    cc = S.Chroma.Config.create(48000, 2048)
+    want = O.chroma_stft(O.stft_config(2048, hop=512), O.chroma_config(48000, 2048), x)
+    got = S.chroma_stft(sc, cc, x)
+    assert got.shape == want.shape == (3, 12, 79) and got.dtype == np.float32
+    np.testing.assert_allclose(got, want, rtol=1e-5, atol=1e-5)            # normalised to a peak of 1 per frame
+    gd = S.chroma_stft(sc, cc, torch.from_numpy(x).cuda())
+    assert gd.is_cuda and np.array_equal(gd.cpu().numpy(), got)
+    assert S.chroma_stft(sc, cc, np.zeros((0, 4000), np.float32)).shape == (0, 12, Stft.frames(sc, 4000))
+
+
+def test_chroma_messages():
+    cc = S.Chroma.Config.create(22050, 512)
+    with pytest.raises(S.InvalidArgument) as e:
+        S.Chroma.apply(cc, np.zeros((100, 4), np.float32))
+    assert str(e.value) == ("apply: cannot project 100 frequency bins through a matrix built for an FFT of size 512 "
+                            "(257 bins)")
+    with pytest.raises(S.InvalidArgument) as e:
+        S.Chroma.apply(cc, np.zeros((257, 4), np.float32), norm=-2.0)
+    assert str(e.value) == "apply: cannot normalise in the -2-norm (the exponent must be finite and positive)"
+    with pytest.raises(S.InvalidArgument) as e:
+        S.Chroma.apply(cc, np.zeros(7, np.float32))
+    assert str(e.value) == "apply: cannot project a rank-1 tensor (the projection needs [...; bins; frames])"
+    with pytest.raises(S.InvalidArgument) as e:
+        S.chroma_stft(Stft.Config.create(fft_size=256, hop=64), cc, np.zeros(1000, np.float32))
+    assert str(e.value).startswith("chroma_stft: cannot project a 256-point STFT through a filterbank built for an FFT of size 512")
+    assert S.Chroma.apply(cc, np.zeros((2, 257, 0), np.float64)).shape == (2, 12, 0)
+
+
 # ---- FIR ---------------------------------------------------------------------------------------------
 
 @pytest.mark.parametrize("taps,n,ch", [(63, 5000, 2), (1, 100, 1), (8192, 60000, 2), (1000, 1, 1), (257, 16384 * 3, 3)])

@@ -266,3 +266,62 @@ def test_invert_checks_need_no_device():
     # an empty request synthesises nothing (istft_law.ml:562): zero frames -> zero samples, no device touched
     assert Stft.invert(c, np.zeros((33, 0), np.complex128)).shape == (0,)
     assert Stft.invert(c, np.zeros((0, 33, 5), np.complex64)).shape == (0, Stft.output_length(c, 5))
+
+
+# ---- Chroma.Config / spectral parameter checks: host arithmetic of the C ABI, no device ------------------------
+
+def test_chroma_filterbank_goldens_through_the_abi():
+    """Chroma.Config weights (chroma.ml:109-175) as the library builds them, against librosa.filters.chroma
+    (chroma_goldens.ml:111-136: 1e-12 relative + 1e-13 of the peak) and bit for bit against the oracle."""
+    import soundml_amd as S
+    from conftest import check_close, load_golden
+    from oracle import soundml_oracle as O
+    from test_oracle_goldens import chroma_golden_config
+    for case in load_golden("chroma", "chroma_fb")["cases"]:
+        p = case["params"]
+        if p["kind"] != "filterbank":
+            continue
+        c = chroma_golden_config(lambda sr, fft, **kw: S.Chroma.Config.create(sr, fft, **kw), p)
+        w = S.Chroma.filterbank(np.float64, c)
+        peak = float(np.max(np.abs(case["values"])))
+        check_close(w, case["values"], shape=case["shape"], rtol=1e-12, atol=1e-13 * peak, msg=case["name"])
+        assert np.array_equal(w, chroma_golden_config(O.chroma_config, p).weights), case["name"]
+        assert S.Chroma.filterbank(np.float32, c).dtype == np.float32
+        assert (c.n_chroma, c.bins, c.fft_size) == (p["n_chroma"], p["fft_size"] // 2 + 1, p["fft_size"])
+
+
+def test_chroma_config_messages():
+    import soundml_amd as S
+    create = S.Chroma.Config.create
+    for kwargs, message in [
+            (dict(sample_rate=22050, fft_size=512, n_chroma=0), "create: cannot build 0 chroma bands (n_chroma must be at least 1)"),
+            (dict(sample_rate=0, fft_size=512), "create: cannot use a sample rate of 0 Hz (sample_rate must be at least 1)"),
+            (dict(sample_rate=22050, fft_size=0), "create: cannot use an FFT of size 0 (fft_size must be at least 1)"),
+            (dict(sample_rate=22050, fft_size=512, tuning=float("nan")), "create: cannot shift the scale by nan bins (tuning must be finite)"),
+            (dict(sample_rate=22050, fft_size=512, ctroct=float("inf")), "create: cannot centre the octave envelope at inf (ctroct must be finite)"),
+            (dict(sample_rate=22050, fft_size=512, octwidth=0.0), "create: cannot use an octave envelope of half-width 0 (octwidth must be finite and positive)")]:
+        with pytest.raises(S.InvalidArgument) as e:
+            create(**kwargs)
+        assert str(e.value) == message
+    a, b = create(22050, 512), create(22050, 512)
+    assert a == b and a != create(22050, 512, octwidth=None)
+    assert repr(a) == "chroma(n_chroma=12, sample_rate=22050, fft_size=512, tuning=0, ctroct=5, octwidth=2, base_c=true)"
+
+
+def test_spectral_parameter_messages():
+    """spectral.ml:35-98: the chunk-independent checks come before any device work."""
+    import soundml_amd as S
+    s = np.ones((9, 4), np.float32)
+    for call, message in [
+            (lambda: S.spectral_centroid(s, sample_rate=0), "spectral_centroid: cannot use a sample rate of 0 Hz (sample_rate must be at least 1)"),
+            (lambda: S.spectral_centroid(s, sample_rate=8000, freqs=np.ones(5)), "spectral_centroid: cannot pair 5 bin frequencies with 9 bins (freqs holds one frequency per bin)"),
+            (lambda: S.spectral_centroid(s, sample_rate=8000, freqs=np.ones((9, 1))), "spectral_centroid: cannot use a rank-2 freqs tensor (freqs is rank-one, one frequency per bin)"),
+            (lambda: S.spectral_bandwidth(s, sample_rate=8000, p=0.0), "spectral_bandwidth: cannot raise deviations to the power 0 (p must be finite and positive)"),
+            (lambda: S.spectral_bandwidth(s, sample_rate=8000, centroid=np.ones(4)), "spectral_bandwidth: cannot reuse a rank-1 centroid (centroid must be [...; 1; frames])"),
+            (lambda: S.spectral_bandwidth(s, sample_rate=8000, centroid=np.ones((2, 4))), "spectral_bandwidth: cannot reuse a centroid with 2 rows over 4 frames for a 4-frame spectrogram (centroid must be [...; 1; frames], one frequency per frame)"),
+            (lambda: S.spectral_rolloff(s, sample_rate=8000, roll_percent=1.0), "spectral_rolloff: cannot keep 1 of the spectral energy (roll_percent must lie strictly between 0 and 1)"),
+            (lambda: S.spectral_flatness(s, amin=0.0), "spectral_flatness: cannot floor the spectrum at 0 (amin must be finite and positive)"),
+            (lambda: S.spectral_flatness(s, power=float("inf")), "spectral_flatness: cannot raise magnitudes to the power inf (power must be finite and positive)")]:
+        with pytest.raises(S.InvalidArgument) as e:
+            call()
+        assert str(e.value) == message
