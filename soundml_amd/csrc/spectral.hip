@@ -35,6 +35,21 @@ __device__ __forceinline__ double pow_fixed(double v, double p) {   // Nx.pow_s 
   return pow(v, p);
 }
 
+// walks bins [k0, k1) of one frame column in order, kDepth loads in flight at a time
+constexpr int kDepth = 8;
+template <typename T, typename F>
+__device__ __forceinline__ void for_bins(const T *col, int64_t frames, int64_t k0, int64_t k1, F &&f) {
+  int64_t k = k0;
+  for (; k + kDepth <= k1; k += kDepth) {
+    T v[kDepth];
+#pragma unroll
+    for (int j = 0; j < kDepth; ++j) v[j] = col[(k + j) * frames];
+#pragma unroll
+    for (int j = 0; j < kDepth; ++j) f(k + j, (double)v[j]);
+  }
+  for (; k < k1; ++k) f(k, (double)col[k * frames]);
+}
+
 template <typename T, int FEATURE, int Q>
 __global__ void __launch_bounds__(64 * Q) spectral_kernel(SpectralArgs a) {
   __shared__ double red[2][Q][64];
@@ -61,44 +76,37 @@ __global__ void __launch_bounds__(64 * Q) spectral_kernel(SpectralArgs a) {
 
   if constexpr (FEATURE == SPECTRAL_FLATNESS) {
     double sl = 0.0, sa = 0.0;
-#pragma unroll 4
-    for (int64_t k = k0; k < k1; ++k) {
-      const double v = (double)col[k * a.frames];
+    for_bins(col, a.frames, k0, k1, [&](int64_t, double v) {
       bad |= !(v >= 0.0);
       const double pw = pow_fixed(v, a.power);
       const double f = pw > a.p ? pw : a.p;            // a.p = amin
       sl += log(f);
       sa += f;
-    }
+    });
     sl = combine(sl, 0);
     sa = combine(sa, 1);
     result = exp(sl / (double)a.bins) / (sa / (double)a.bins);
   } else if constexpr (FEATURE == SPECTRAL_ROLLOFF) {
     double cum = 0.0;
-#pragma unroll 8
-    for (int64_t k = 0; k < a.bins; ++k) {
-      const double v = (double)col[k * a.frames];
+    for_bins(col, a.frames, 0, a.bins, [&](int64_t, double v) {
       bad |= !(v >= 0.0);
       cum += v;
-    }
+    });
     const double threshold = cum * a.p;                // a.p = roll_percent; the total is the last cumulative value
     cum = 0.0;
     double best = INFINITY;
-#pragma unroll 8
-    for (int64_t k = 0; k < a.bins; ++k) {
-      cum += (double)col[k * a.frames];
+    for_bins(col, a.frames, 0, a.bins, [&](int64_t k, double v) {
+      cum += v;
       const double f = fq(k);
       best = (cum >= threshold && f < best) ? f : best;
-    }
+    });
     result = best;
   } else {
     double len = 0.0;
-#pragma unroll 8
-    for (int64_t k = k0; k < k1; ++k) {
-      const double v = (double)col[k * a.frames];
+    for_bins(col, a.frames, k0, k1, [&](int64_t, double v) {
       bad |= !(v >= 0.0);
       len += v;
-    }
+    });
     len = combine(len, 0);
     const double safe = len < DBL_MIN ? 1.0 : len;     // spectral.ml:155-163
     double c64;
@@ -106,19 +114,17 @@ __global__ void __launch_bounds__(64 * Q) spectral_kernel(SpectralArgs a) {
       c64 = (double)reinterpret_cast<const T *>(a.centroid)[clip * a.frames + tc];
     } else {
       double c = 0.0;
-#pragma unroll 8
-      for (int64_t k = k0; k < k1; ++k) c += fq(k) * ((double)col[k * a.frames] / safe);
+      for_bins(col, a.frames, k0, k1, [&](int64_t k, double v) { c += fq(k) * (v / safe); });
       c64 = combine(c, 1);
     }
     if constexpr (FEATURE == SPECTRAL_CENTROID) {
       result = c64;
     } else {
       double w = 0.0;
-#pragma unroll 4
-      for (int64_t k = k0; k < k1; ++k) {
+      for_bins(col, a.frames, k0, k1, [&](int64_t k, double v) {
         const double deviation = fabs(c64 - fq(k));
-        w += ((double)col[k * a.frames] / safe) * pow_fixed(deviation, a.p);
-      }
+        w += (v / safe) * pow_fixed(deviation, a.p);
+      });
       w = combine(w, 0);
       result = a.p == 2.0 ? sqrt(w) : (a.p == 1.0 ? w : pow(w, a.inv_p));
     }
@@ -152,7 +158,8 @@ constexpr int kChromaChunk = 12;   // chroma rows accumulated per pass over the 
 struct ChromaArgs {
   const void *s;            // [lead; bins; frames]
   double *raw;              // [lead; n_chroma; frames] float64 scratch
-  const double *wt;         // [bins; n_chroma]
+  const double *wt;         // [bins; rows_pad], rows_pad = n_chroma rounded up to a multiple of kChromaChunk
+  int64_t rows_pad;
   void *out;                // [lead; n_chroma; frames]
   int64_t lead, bins, frames, ftiles;
   int n_chroma, norm;
@@ -166,16 +173,28 @@ __global__ void __launch_bounds__(256) chroma_project_kernel(ChromaArgs a) {
   if (t >= a.frames) return;
   const int c0 = blockIdx.y * kChromaChunk;
   const T *col = reinterpret_cast<const T *>(a.s) + clip * a.bins * a.frames + t;
+  const double *wt = a.wt + c0;                        // rows padded with zeros to a whole chunk: no guards below
   double acc[kChromaChunk];
 #pragma unroll
   for (int i = 0; i < kChromaChunk; ++i) acc[i] = 0.0;
-#pragma unroll 2
-  for (int64_t k = 0; k < a.bins; ++k) {
-    const double v = (double)col[k * a.frames];
-    const double *w = a.wt + k * a.n_chroma + c0;      // uniform: scalar loads
+  int64_t k = 0;
+  for (; k + kDepth <= a.bins; k += kDepth) {
+    T v[kDepth];
 #pragma unroll
-    for (int i = 0; i < kChromaChunk; ++i)
-      if (c0 + i < a.n_chroma) acc[i] += w[i] * v;
+    for (int j = 0; j < kDepth; ++j) v[j] = col[(k + j) * a.frames];
+#pragma unroll
+    for (int j = 0; j < kDepth; ++j) {
+      const double *w = wt + (k + j) * a.rows_pad;     // uniform: scalar loads
+      const double d = (double)v[j];
+#pragma unroll
+      for (int i = 0; i < kChromaChunk; ++i) acc[i] += w[i] * d;
+    }
+  }
+  for (; k < a.bins; ++k) {
+    const double *w = wt + k * a.rows_pad;
+    const double d = (double)col[k * a.frames];
+#pragma unroll
+    for (int i = 0; i < kChromaChunk; ++i) acc[i] += w[i] * d;
   }
   double *raw = a.raw + (clip * a.n_chroma + c0) * a.frames + t;
 #pragma unroll
@@ -256,6 +275,7 @@ void launch_chroma(const ChromaJob &job) {
   a.frames = job.frames;
   a.ftiles = (job.frames + 255) / 256;
   a.n_chroma = (int)c.n_chroma;
+  a.rows_pad = (c.n_chroma + kChromaChunk - 1) / kChromaChunk * kChromaChunk;
   a.norm = job.norm;
   a.norm_p = job.norm_p;
   a.inv_p = job.norm == SMX_CHROMA_NORM_P ? 1.0 / job.norm_p : 1.0;

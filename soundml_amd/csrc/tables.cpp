@@ -210,11 +210,12 @@ const double *smx_chroma_config::device_weights() const {
   std::lock_guard<std::mutex> lock(mutex_);
   auto it = tables_.find(device);
   if (it != tables_.end()) return it->second;
-  // transposed [bins; n_chroma]: the projection kernel reads one bin's column of weights with scalar loads
-  const int64_t nb = bins();
-  std::vector<double> wt((size_t)(nb * n_chroma));
+  // transposed [bins; rows_pad] (rows padded with zeros to a multiple of the kernel's chunk of 12): the projection
+  // kernel reads one bin's column of weights with scalar loads
+  const int64_t nb = bins(), rows_pad = (n_chroma + 11) / 12 * 12;
+  std::vector<double> wt((size_t)(nb * rows_pad), 0.0);
   for (int64_t c = 0; c < n_chroma; ++c)
-    for (int64_t j = 0; j < nb; ++j) wt[(size_t)(j * n_chroma + c)] = weights[(size_t)(c * nb + j)];
+    for (int64_t j = 0; j < nb; ++j) wt[(size_t)(j * rows_pad + c)] = weights[(size_t)(c * nb + j)];
   double *dev = smx::upload(wt);
   tables_.emplace(device, dev);
   return dev;

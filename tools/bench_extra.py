@@ -80,6 +80,30 @@ flop = 2.0 * 128 * 1025 * 256 * frames
 print(json.dumps({"config": "C3", "mel_spectrogram_ms": round(med, 4), "mel_apply_only_ms": round(med_apply, 4),
                   "Mframes_per_s": round(256 * frames / med / 1e3, 1), "GBs_algorithmic_fused": round(256 * frames * 2560 / med / 1e6, 1), "dense_equiv_TFLOPs_apply": round(flop / med_apply / 1e9, 2),
                   "apply_GBs": round((256 * frames * (4100 + 512)) / med_apply / 1e6, 1), "max_rel_err_vs_oracle": rel_err(m.cpu().numpy(), wm)}))
+# spectral-shape features and chroma on the C2 spectrogram (256 x 1025 x 938 float32, 984 MB read once per pass)
+spec_bytes = 256 * frames * 1025 * 4
+feat_out = torch.empty(256, 1, frames, device="cuda")
+rows = {}
+for name, call in (
+        ("centroid", lambda: lib.smx_spectral_centroid_f32_dev(vp(p.data_ptr()), 256, 1025, frames, None, 0, 48000, vp(feat_out.data_ptr()), None)),
+        ("bandwidth", lambda: lib.smx_spectral_bandwidth_f32_dev(vp(p.data_ptr()), 256, 1025, frames, 2.0, None, 0, None, 0, 0, 48000, vp(feat_out.data_ptr()), None)),
+        ("rolloff", lambda: lib.smx_spectral_rolloff_f32_dev(vp(p.data_ptr()), 256, 1025, frames, 0.85, None, 0, 48000, vp(feat_out.data_ptr()), None)),
+        ("flatness", lambda: lib.smx_spectral_flatness_f32_dev(vp(p.data_ptr()), 256, 1025, frames, 1e-10, 2.0, vp(feat_out.data_ptr()), None))):
+    ms, _ = timeit(lambda: check(call()), reps=10)
+    rows[name + "_ms"] = round(ms, 4)
+    rows[name + "_GBs_one_pass"] = round(spec_bytes / ms / 1e6, 1)
+got_c = S.spectral_centroid(p[:2], sample_rate=48000).cpu().numpy()
+rows["centroid_max_rel_err_vs_oracle"] = rel_err(got_c, O.spectral_centroid(p[:2].cpu().numpy(), sample_rate=48000))
+print(json.dumps({"config": "C2 spectral features (device spectrogram -> [256; 1; 938], includes the validity readback)", **rows}))
+cc = S.Chroma.Config.create(48000, 2048)
+out_ch = torch.empty(256, 12, frames, device="cuda")
+med_ca, _ = timeit(lambda: check(lib.smx_chroma_apply_f32_dev(cc._h, vp(p.data_ptr()), 256, 1025, frames, 1, 0.0, vp(out_ch.data_ptr()), None)), reps=10)
+med_cs, _ = timeit(lambda: check(lib.smx_chroma_stft_f32_dev(sc._h, cc._h, vp(x.data_ptr()), 256, 480000, 480000, 2.0, 1, 0.0,
+                                                             vp(out_ch.data_ptr()), None)), reps=10)
+wc = O.chroma_stft(O.stft_config(2048, hop=512), O.chroma_config(48000, 2048), x[:2].cpu().numpy())
+print(json.dumps({"config": "C2 chroma (12 bands, inf norm)", "chroma_apply_ms": round(med_ca, 4), "apply_GBs": round(spec_bytes / med_ca / 1e6, 1),
+                  "chroma_stft_ms": round(med_cs, 4), "Mframes_per_s": round(256 * frames / med_cs / 1e3, 1),
+                  "max_abs_err_vs_oracle": float(np.max(np.abs(out_ch[:2].cpu().numpy() - wc)))}))
 del p
 
 # C4: 8192-tap lowpass on 8 ch x 60 s 48 kHz
