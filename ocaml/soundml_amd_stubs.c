@@ -256,3 +256,119 @@ CAMLprim value soundml_amd_mfcc_bc(value *argv, int argn) {
   (void)argn;
   return soundml_amd_mfcc(argv[0], argv[1], argv[2], argv[3], argv[4], argv[5], argv[6], argv[7]);
 }
+
+/* Spectral.{centroid,bandwidth,rolloff,flatness} (spectral.ml:171-255): one stub, the feature tagged.
+ * v_feature: 0 centroid, 1 bandwidth, 2 roll-off, 3 flatness; v_a: p | roll_percent | amin; v_b: flatness power.
+ * The OCaml side keeps check_rank / check_p / ... (same messages) and allocates [...; 1; frames]; freqs is the
+ * float64 grid or an empty Bigarray (= the FFT grid); the reused centroid is passed as zero frames when absent. */
+CAMLprim value soundml_amd_spectral(value v_feature, value v_s, value v_out, value v_lead, value v_bins,
+                                    value v_frames, value v_a, value v_b, value v_freqs, value v_centroid,
+                                    value v_sample_rate) {
+  CAMLparam5(v_feature, v_s, v_out, v_lead, v_bins);
+  CAMLxparam5(v_frames, v_a, v_b, v_freqs, v_centroid);
+  CAMLxparam1(v_sample_rate);
+  const int feature = Int_val(v_feature);
+  const int64_t lead = Long_val(v_lead), bins = Long_val(v_bins), frames = Long_val(v_frames);
+  const int64_t sample_rate = Long_val(v_sample_rate);
+  const double a = Double_val(v_a), b = Double_val(v_b);
+  const int kind = ba_kind(v_s);
+  if ((kind != CAML_BA_FLOAT32 && kind != CAML_BA_FLOAT64) || ba_kind(v_out) != kind)
+    caml_failwith("soundml_amd: unsupported or mixed dtypes");
+  if (lead < 0 || bins < 0 || frames < 0 || ba_dim(v_s) < lead * bins * frames || ba_dim(v_out) < lead * frames)
+    caml_failwith("soundml_amd: buffer extents disagree with geometry");
+  const int64_t n_freqs = ba_dim(v_freqs);
+  if (n_freqs > 0 && ba_kind(v_freqs) != CAML_BA_FLOAT64) caml_failwith("soundml_amd: freqs must be float64");
+  const double *freqs = n_freqs > 0 ? (const double *)Caml_ba_data_val(v_freqs) : NULL;
+  const int has_centroid = ba_dim(v_centroid) > 0;
+  if (has_centroid && (ba_kind(v_centroid) != kind || ba_dim(v_centroid) < lead * frames))
+    caml_failwith("soundml_amd: centroid buffer disagrees with the spectrogram");
+  const void *cen = has_centroid ? Caml_ba_data_val(v_centroid) : NULL;
+  void *s = Caml_ba_data_val(v_s), *out = Caml_ba_data_val(v_out);
+  const int f32 = kind == CAML_BA_FLOAT32;
+  int status = SMX_FAILURE;
+  caml_release_runtime_system();
+  switch (feature) {
+    case 0:
+      status = f32 ? smx_spectral_centroid_f32((const float *)s, lead, bins, frames, freqs, n_freqs, sample_rate, (float *)out)
+                   : smx_spectral_centroid_f64((const double *)s, lead, bins, frames, freqs, n_freqs, sample_rate, (double *)out);
+      break;
+    case 1:
+      status = f32 ? smx_spectral_bandwidth_f32((const float *)s, lead, bins, frames, a, freqs, n_freqs, (const float *)cen,
+                                                1, frames, sample_rate, (float *)out)
+                   : smx_spectral_bandwidth_f64((const double *)s, lead, bins, frames, a, freqs, n_freqs, (const double *)cen,
+                                                1, frames, sample_rate, (double *)out);
+      break;
+    case 2:
+      status = f32 ? smx_spectral_rolloff_f32((const float *)s, lead, bins, frames, a, freqs, n_freqs, sample_rate, (float *)out)
+                   : smx_spectral_rolloff_f64((const double *)s, lead, bins, frames, a, freqs, n_freqs, sample_rate, (double *)out);
+      break;
+    case 3:
+      status = f32 ? smx_spectral_flatness_f32((const float *)s, lead, bins, frames, a, b, (float *)out)
+                   : smx_spectral_flatness_f64((const double *)s, lead, bins, frames, a, b, (double *)out);
+      break;
+    default: break;
+  }
+  caml_acquire_runtime_system();
+  smx_raise(status);
+  CAMLreturn(Val_unit);
+}
+CAMLprim value soundml_amd_spectral_bc(value *argv, int argn) {
+  (void)argn;
+  return soundml_amd_spectral(argv[0], argv[1], argv[2], argv[3], argv[4], argv[5], argv[6], argv[7], argv[8], argv[9],
+                              argv[10]);
+}
+
+/* Chroma.Config handle built from the config's own scalar fields (chroma.ml:177-222); the library rebuilds
+ * the float64 weights with the reference's arithmetic (bit-identical on the same libm).  octwidth < 0 = None. */
+#define Chroma_val(v) (*((smx_chroma_config **)Data_custom_val(v)))
+static void chroma_finalize(value v) { smx_chroma_config_destroy(Chroma_val(v)); }
+static struct custom_operations chroma_ops = {"soundml.amd.chroma_config", chroma_finalize, custom_compare_default,
+                                              custom_hash_default, custom_serialize_default,
+                                              custom_deserialize_default, custom_compare_ext_default,
+                                              custom_fixed_length_default};
+CAMLprim value soundml_amd_chroma_config(value v_n_chroma, value v_tuning, value v_ctroct, value v_octwidth,
+                                         value v_base_c, value v_sample_rate, value v_fft) {
+  CAMLparam5(v_n_chroma, v_tuning, v_ctroct, v_octwidth, v_base_c);
+  CAMLxparam2(v_sample_rate, v_fft);
+  CAMLlocal1(v_handle);
+  const double octwidth = Double_val(v_octwidth);
+  smx_chroma_config *c = NULL;
+  smx_raise(smx_chroma_config_create(Long_val(v_n_chroma), Double_val(v_tuning), Double_val(v_ctroct), octwidth >= 0.0,
+                                     octwidth, Bool_val(v_base_c), Long_val(v_sample_rate), Long_val(v_fft), &c));
+  v_handle = caml_alloc_custom(&chroma_ops, sizeof(smx_chroma_config *), 0, 1);
+  Chroma_val(v_handle) = c;
+  CAMLreturn(v_handle);
+}
+CAMLprim value soundml_amd_chroma_config_bc(value *argv, int argn) {
+  (void)argn;
+  return soundml_amd_chroma_config(argv[0], argv[1], argv[2], argv[3], argv[4], argv[5], argv[6]);
+}
+
+/* Chroma.apply (chroma.ml:285-317): v_norm 0 none, 1 inf, 2 the exponent v_p */
+CAMLprim value soundml_amd_chroma_apply(value v_cfg, value v_s, value v_out, value v_lead, value v_bins,
+                                        value v_frames, value v_norm, value v_p) {
+  CAMLparam5(v_cfg, v_s, v_out, v_lead, v_bins);
+  CAMLxparam3(v_frames, v_norm, v_p);
+  const smx_chroma_config *c = Chroma_val(v_cfg);
+  const int64_t lead = Long_val(v_lead), bins = Long_val(v_bins), frames = Long_val(v_frames);
+  const int64_t rows = smx_chroma_config_n_chroma(c);
+  const int kind = ba_kind(v_s);
+  if ((kind != CAML_BA_FLOAT32 && kind != CAML_BA_FLOAT64) || ba_kind(v_out) != kind)
+    caml_failwith("soundml_amd: unsupported or mixed dtypes");
+  if (lead < 0 || bins < 0 || frames < 0 || ba_dim(v_s) < lead * bins * frames || ba_dim(v_out) < lead * rows * frames)
+    caml_failwith("soundml_amd: buffer extents disagree with geometry");
+  void *s = Caml_ba_data_val(v_s), *out = Caml_ba_data_val(v_out);
+  const int norm = Int_val(v_norm);
+  const double p = Double_val(v_p);
+  int status;
+  caml_release_runtime_system();
+  status = kind == CAML_BA_FLOAT32 ? smx_chroma_apply_f32(c, (const float *)s, lead, bins, frames, norm, p, (float *)out)
+                                   : smx_chroma_apply_f64(c, (const double *)s, lead, bins, frames, norm, p, (double *)out);
+  caml_acquire_runtime_system();
+  smx_raise(status);
+  CAMLreturn(Val_unit);
+}
+CAMLprim value soundml_amd_chroma_apply_bc(value *argv, int argn) {
+  (void)argn;
+  return soundml_amd_chroma_apply(argv[0], argv[1], argv[2], argv[3], argv[4], argv[5], argv[6], argv[7]);
+}

@@ -96,3 +96,62 @@ let invert dtype (c : Stft.Config.t) ?length z =
     stft_invert_c (handle_of_config c) (flat z) (Nx_buffer.to_bigarray1 (Nx.to_buffer out)) lead bins frames
       (match length with Some n -> n | None -> -1) ;
   out
+
+(* ---- Spectral.* (spectral.ml:171-255) and Chroma.apply (chroma.ml:285-317) ------------------------------ *)
+
+external spectral_c :
+  int -> ('a, 'b, Bigarray.c_layout) Bigarray.Array1.t -> ('a, 'b, Bigarray.c_layout) Bigarray.Array1.t ->
+  int -> int -> int -> float -> float ->
+  (float, Bigarray.float64_elt, Bigarray.c_layout) Bigarray.Array1.t ->
+  ('a, 'b, Bigarray.c_layout) Bigarray.Array1.t -> int -> unit
+  = "soundml_amd_spectral_bc" "soundml_amd_spectral"
+
+let no_freqs = Bigarray.Array1.create Bigarray.float64 Bigarray.c_layout 0
+
+(* Replaces the tail of spectral.ml:171-177 [centroid] after its own checks ([check_rank], [grid]'s shape checks):
+   the reduction, the non-negativity check (same message, raised from C) and the cast.  bandwidth / rolloff /
+   flatness differ only in the tag and the two scalars. *)
+let spectral_feature tag ?(a = 0.) ?(b = 0.) ?freqs ~sample_rate s =
+  let shape = Nx.shape s in
+  let nd = Array.length shape in
+  let bins = shape.(nd - 2) and frames = shape.(nd - 1) in
+  let batch = Array.sub shape 0 (nd - 2) in
+  let lead = Array.fold_left ( * ) 1 batch in
+  let out = Nx.zeros (Nx.dtype s) (Array.append batch [|1; frames|]) in
+  let fq = match freqs with Some f -> flat (Nx.cast Nx.float64 f) | None -> no_freqs in
+  let none = Bigarray.Array1.sub (flat s) 0 0 in
+  if lead > 0 && bins > 0 && frames > 0 then
+    spectral_c tag (flat s) (Nx_buffer.to_bigarray1 (Nx.to_buffer out)) lead bins frames a b fq none sample_rate ;
+  out
+
+let spectral_centroid ?freqs ~sample_rate s = spectral_feature 0 ?freqs ~sample_rate s
+let spectral_rolloff ?(roll_percent = 0.85) ?freqs ~sample_rate s = spectral_feature 2 ~a:roll_percent ?freqs ~sample_rate s
+let spectral_flatness ?(amin = 1e-10) ?(power = 2.) s = spectral_feature 3 ~a:amin ~b:power ~sample_rate:1 s
+
+type chroma_handle
+
+external chroma_config_c : int -> float -> float -> float -> bool -> int -> int -> chroma_handle
+  = "soundml_amd_chroma_config_bc" "soundml_amd_chroma_config"
+
+external chroma_apply_c :
+  chroma_handle -> ('a, 'b, Bigarray.c_layout) Bigarray.Array1.t -> ('a, 'b, Bigarray.c_layout) Bigarray.Array1.t ->
+  int -> int -> int -> int -> float -> unit
+  = "soundml_amd_chroma_apply_bc" "soundml_amd_chroma_apply"
+
+(* Replaces chroma.ml:300-317 [apply] after [check_norm]: projection, per-frame norm and the cast in one call. *)
+let chroma_apply ?(norm = `Inf) (c : Chroma.Config.t) s =
+  let open Chroma.Config in
+  let h =
+    chroma_config_c (n_chroma c) (tuning c) (ctroct c)
+      (match octwidth c with Some w -> w | None -> -1.)
+      (base_c c) (sample_rate c) (fft_size c)
+  in
+  let shape = Nx.shape s in
+  let nd = Array.length shape in
+  let bins = shape.(nd - 2) and frames = shape.(nd - 1) in
+  let batch = Array.sub shape 0 (nd - 2) in
+  let lead = Array.fold_left ( * ) 1 batch in
+  let out = Nx.zeros (Nx.dtype s) (Array.append batch [|n_chroma c; frames|]) in
+  let kind, p = match norm with `None -> (0, 0.) | `Inf -> (1, 0.) | `P p -> (2, p) in
+  chroma_apply_c h (flat s) (Nx_buffer.to_bigarray1 (Nx.to_buffer out)) lead bins frames kind p ;
+  out
