@@ -168,6 +168,7 @@ struct SynArgs {
   const float2 *w_m, *w_n, *synth_window;
   const double *env_head, *env_period, *env_tail;
   int64_t head, stop;
+  int64_t blocks, per_xcd;   // per_xcd > 0: XCD-contiguous tile order over `blocks` tiles
 };
 
 __global__ void __launch_bounds__(1024) istft2048_kernel(SynArgs a) {
@@ -178,8 +179,15 @@ __global__ void __launch_bounds__(1024) istft2048_kernel(SynArgs a) {
   float2 *swin = reinterpret_cast<float2 *>(smem + ((kSynRegionA + 15) / 16) * 16);
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int64_t clip = blockIdx.x / a.tiles_per_clip;
-  const int tile = blockIdx.x % a.tiles_per_clip;
+  // workgroups are dealt to the 8 XCDs round robin: give each XCD one contiguous run of tiles, so that the two
+  // neighbours which share every straddled 128-byte line of a spectrum row meet in the same L2
+  int64_t logical = blockIdx.x;
+  if (a.per_xcd > 0) {
+    logical = (int64_t)(blockIdx.x & 7) * a.per_xcd + (blockIdx.x >> 3);
+    if (logical >= a.blocks) return;
+  }
+  const int64_t clip = logical / a.tiles_per_clip;
+  const int tile = (int)(logical % a.tiles_per_clip);
   const int64_t f_lo = (int64_t)kSynHops * tile - 3;
   const float2 *z = a.z + clip * (int64_t)(kSynM + 1) * a.frames;
   swin[tid] = a.synth_window[tid];
@@ -343,10 +351,14 @@ void launch_istft(const IstftJob &job) {
     sa.head = head_n;
     sa.stop = stop;
     const int64_t blocks = job.lead * tiles;
-    if (blocks <= 0x7fffffff) {
+    if (blocks <= 0x7ffffff0) {
+      const char *lin = std::getenv("SMX_ISTFT_LINEAR");
+      sa.blocks = blocks;
+      sa.per_xcd = (lin && lin[0] == '1') ? 0 : (blocks + 7) / 8;
+      const int64_t launched = sa.per_xcd > 0 ? sa.per_xcd * 8 : blocks;
       SMX_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(istft2048_kernel),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)kSynLds));
-      hipLaunchKernelGGL(istft2048_kernel, dim3((unsigned)blocks), dim3(1024), kSynLds, job.stream, sa);
+      hipLaunchKernelGGL(istft2048_kernel, dim3((unsigned)launched), dim3(1024), kSynLds, job.stream, sa);
       SMX_HIP_CHECK(hipGetLastError());
       SMX_HIP_CHECK(hipFreeAsync(d_env, job.stream));
       return;

@@ -16,6 +16,17 @@ def run():
     assert f(h, vp(z.data_ptr()), clips, 1025, frames, 1, n, vp(out.data_ptr()), None) == 0
 for _ in range(2): run()
 torch.cuda.synchronize()
+if os.environ.get("AB_ORDER"):   # interleaved A/B of the XCD-contiguous tile order against the linear one
+    res = {"0": [], "1": []}
+    for _ in range(10):
+        for mode in ("0", "1"):
+            os.environ["SMX_ISTFT_LINEAR"] = mode
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record(); run(); b.record(); torch.cuda.synchronize(); res[mode].append(a.elapsed_time(b))
+    for mode, name in (("0", "xcd-contiguous"), ("1", "linear")):
+        t = sorted(res[mode])
+        print("%s: median %.3f ms  min %.3f ms" % (name, t[len(t) // 2], t[0]))
+    os.environ["SMX_ISTFT_LINEAR"] = "0"
 ts = []
 for _ in range(8):
     a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
