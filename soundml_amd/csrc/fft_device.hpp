@@ -193,6 +193,11 @@ struct LastPass {   // radix / sub-size of the final pass of fft_passes<LOG2N>
 // smx_debug_read_stamps().  Never compiled into the shipped library; no output depends on it.
 constexpr int kStampSlots = 24;
 __device__ unsigned long long g_stamp_sums[4096 * 16 * kStampSlots];
+#ifdef SMX_STAMPS_COARSE
+// only the whole-loop clock check (slots 20 / 21: shader cycles and 100 MHz reference ticks around the tile loop):
+// the in-kernel clock without the per-phase stamps' own cost (MI355X_MICROARCH.md 'DVFS give-back' item 6)
+#define SMX_STAMP(i) do { (void)stamp_prev; } while (0)
+#else
 #define SMX_STAMP(i)                                                                      \
   do {                                                                                    \
     unsigned long long t__;                                                               \
@@ -202,6 +207,7 @@ __device__ unsigned long long g_stamp_sums[4096 * 16 * kStampSlots];
     stamp_sum[i] += t__ - stamp_prev;                                                     \
     stamp_prev = t__;                                                                     \
   } while (0)
+#endif
 #else
 #define SMX_STAMP(i) do { } while (0)
 #endif

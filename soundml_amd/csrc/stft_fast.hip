@@ -699,6 +699,7 @@ __global__ void __launch_bounds__(1024) stft2048_power_kernel(FastArgs a) {
 #ifdef SMX_STAMPS
   unsigned long long stamp_sum[kStampSlots] = {0}, stamp_prev;
   asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(stamp_prev)::"memory");
+  const unsigned long long clk_t0 = stamp_prev, clk_r0 = __builtin_amdgcn_s_memrealtime();
 #endif
   for (int it = 0; it < ntiles; ++it) {   // tile `it` of this workgroup lives in buffer it & 1
     const int b = it & 1;
@@ -737,6 +738,10 @@ __global__ void __launch_bounds__(1024) stft2048_power_kernel(FastArgs a) {
     tw.ft = ftnext;
   }
   flush_tile((ntiles - 1) & 1, ((unsigned)(ntiles - 1) >> 1) + 1);   // the last tile of this workgroup
+#ifdef SMX_STAMPS
+  stamp_sum[20] = __builtin_amdgcn_s_memtime() - clk_t0;
+  stamp_sum[21] = __builtin_amdgcn_s_memrealtime() - clk_r0;
+#endif
   // Border frames (the few per clip whose window reaches past either end of the signal): same frame code on
   // samples fetched through the padding rule, 16 (clip, frame) pairs per tile, results scattered to their
   // places.  A few dozen tiles in all, so plain barriers and element-wise stores do.

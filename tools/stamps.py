@@ -17,6 +17,13 @@ for _ in range(2):
     rc = lib.smx_stft_power_range_f32_dev(h, vp(x.data_ptr()), clips, n, n, 2, 936, 2.0, vp(out.data_ptr()), None)
     assert rc == 0
 torch.cuda.synchronize()
+ev = []
+for _ in range(6):
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    lib.smx_stft_power_range_f32_dev(h, vp(x.data_ptr()), clips, n, n, 2, 936, 2.0, vp(out.data_ptr()), None)
+    e1.record(); torch.cuda.synchronize(); ev.append(e0.elapsed_time(e1))
+wall_ms = sorted(ev)[len(ev) // 2]
 S = 24
 nwg = 256
 buf = np.zeros(nwg * 16 * S, dtype=np.uint64)
@@ -27,7 +34,8 @@ names = ["loop top", "window", "A pass1", "A pass2", "A twiddle", "X re (+ready)
          "C q<8", "C q>=8", "P q0-3 (+ready)", "P q4-7", "P q8-11", "P q12-15", "(hook15)", "nyquist+signal", "prefetch issue", "wait filled+flush"]
 mean = st.mean(axis=(0, 1))
 tiles = 256 * 934 / 16 / nwg
-print("s_memtime ticks per wave: total %.0f over %.1f tiles (%.0f per tile)" % (tot.mean(), tiles, tot.mean() / tiles))
+print("SMX_ABLATE=%s  wall %.3f ms per launch; s_memtime ticks per wave: total %.0f over %.1f tiles (%.0f per tile); ticks / wall = %.0f MHz"
+      % (os.environ.get("SMX_ABLATE", "0"), wall_ms, tot.mean(), tiles, tot.mean() / tiles, tot.mean() / wall_ms / 1e3))
 for i, nm in enumerate(names):
     print("  %-16s %9.0f  %5.1f%%   (per tile %.0f)" % (nm, mean[i], 100 * mean[i] / mean.sum(), mean[i] / tiles))
 print("per-wave totals (mean over WGs):", np.round(tot.mean(axis=0) / tiles))
