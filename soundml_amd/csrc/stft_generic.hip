@@ -12,6 +12,8 @@
 //     windowed frame against an N-entry twiddle table, O(N^2) per frame.
 // Results for the FT frames are staged in LDS and written frames-fastest so
 // the [bins; frames] layout is stored in runs of FT elements.
+#include <cstdlib>
+
 #include "fft_device.hpp"
 #include "smx_internal.hpp"
 
@@ -176,11 +178,19 @@ __global__ void __launch_bounds__(256) stft_generic_kernel(GenericArgs a) {
     }
   }
   // flush: frames fastest
-  const int64_t total = bins * nf;
+  const int total = (int)bins * nf;       // bins <= 8193 on this path, nf <= 16
   const int64_t obase = clip * bins * a.out_stride + a.out_offset + f0;
-  for (int64_t e = tid; e < total; e += blockDim.x) {
-    const int64_t k = e / nf;
-    const int f = (int)(e % nf);
+  const int shift = 31 - __builtin_clz((unsigned)a.ft);   // ft is a power of two: only a ragged last tile divides
+  for (int e = tid; e < total; e += blockDim.x) {
+    int64_t k;
+    int f;
+    if (nf == a.ft) {
+      k = e >> shift;
+      f = e & (a.ft - 1);
+    } else {
+      k = e / nf;
+      f = e - (int)k * nf;
+    }
     if (a.mode == OUT_COMPLEX)
       reinterpret_cast<CO *>(a.out)[obase + k * a.out_stride + f] =
           reinterpret_cast<const CO *>(stage)[k * sstride + f];
@@ -191,6 +201,29 @@ __global__ void __launch_bounds__(256) stft_generic_kernel(GenericArgs a) {
 }
 
 constexpr size_t kLdsLimit = 160 * 1024;
+
+// stage [bins][ft + 1] -> out[clip][bins][frames], frames fastest: runs of nf elements per bin row.  ft is a power
+// of two, so a full tile splits the element index with a shift; only a clip's last, ragged tile divides.
+__device__ __forceinline__ void flush_stage_f32(const GenericArgs &a, const unsigned char *stage, int64_t clip, int64_t f0, int nf) {
+  const int ft = a.ft, sstride = ft + 1;
+  const int total = (int)a.bins * nf;
+  const int64_t obase = clip * a.bins * a.out_stride + a.out_offset + f0;
+  const int shift = 31 - __builtin_clz((unsigned)ft);
+  for (int e = threadIdx.x; e < total; e += blockDim.x) {
+    int k, f;
+    if (nf == ft) {
+      k = e >> shift;
+      f = e & (ft - 1);
+    } else {
+      k = e / nf;
+      f = e - k * nf;
+    }
+    if (a.mode == OUT_COMPLEX)
+      reinterpret_cast<float2 *>(a.out)[obase + (int64_t)k * a.out_stride + f] = reinterpret_cast<const float2 *>(stage)[k * sstride + f];
+    else
+      reinterpret_cast<float *>(a.out)[obase + (int64_t)k * a.out_stride + f] = reinterpret_cast<const float *>(stage)[k * sstride + f];
+  }
+}
 
 // ---- power-of-two sizes 1024 .. 16384, float32 interior: Stockham passes of fft_device.hpp ---------------------
 // N/16 threads own one frame (16 points each in registers, 3-4 LDS round trips instead of log2 N radix-2 passes);
@@ -243,7 +276,7 @@ __global__ void __launch_bounds__((1 << LOG2N) / 16 < 256 ? 256 : (1 << LOG2N) /
       for (int m = 0; m < 16; ++m) r[m] = {0.0f, 0.0f};
     }
     // every thread takes part in the barriers of the passes; groups without a frame transform zeros
-    fft_passes<LOG2N, true>(r, work + (size_t)grp * N, tid, tw);
+    fft_passes<LOG2N, true, (T <= 64)>(r, work + (size_t)grp * N, tid, tw);   // groups of at most 64 threads are wave-private
     if (have) {
 #pragma unroll
       for (int i = 0; i < GL; ++i)
@@ -267,16 +300,7 @@ __global__ void __launch_bounds__((1 << LOG2N) / 16 < 256 ? 256 : (1 << LOG2N) /
     __syncthreads();   // the next round's first pass writes the work buffers again
   }
   if (a.direct) return;
-  const int64_t total = bins * nf;
-  const int64_t obase = clip * bins * a.out_stride + a.out_offset + f0;
-  for (int64_t e = threadIdx.x; e < total; e += blockDim.x) {
-    const int64_t k = e / nf;
-    const int f = (int)(e % nf);
-    if (a.mode == OUT_COMPLEX)
-      reinterpret_cast<float2 *>(a.out)[obase + k * a.out_stride + f] = reinterpret_cast<const float2 *>(stage)[k * sstride + f];
-    else
-      reinterpret_cast<float *>(a.out)[obase + k * a.out_stride + f] = reinterpret_cast<const float *>(stage)[k * sstride + f];
-  }
+  flush_stage_f32(a, stage, clip, f0, nf);
 }
 
 template <int LOG2N>
@@ -297,6 +321,124 @@ bool launch_stockham(const StftJob &job, GenericArgs a) {
   auto kernel = stft_stockham_kernel<LOG2N, float>;
   SMX_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   hipLaunchKernelGGL(kernel, dim3((unsigned)blocks), dim3(THREADS), lds, job.stream, a);
+  SMX_HIP_CHECK(hipGetLastError());
+  return true;
+}
+
+// ---- power-of-two sizes 512 .. 16384, float32 interior: the frame as ONE half-size complex transform ----------
+// z[i] = x[2i] w[2i] + i x[2i+1] w[2i+1] (M = N/2 points, the window pre-halved), Z = FFT_M(z), then
+//   X[k] = (Z[k] + conj Z[M-k]) - i W_N^k (Z[k] - conj Z[M-k]),  X[M] = Re Z[0] - Im Z[0]
+// -- half the passes' work of the kernel above for one more LDS round trip (the partner Z[M-k] lives in another
+// thread).  M/16 threads own a frame; transforms of at most 64 threads are wave-private (no workgroup barriers).
+template <int LOG2N, typename Tin>
+__global__ void __launch_bounds__((1 << LOG2N) / 32 < 256 ? 256 : (1 << LOG2N) / 32)
+    stft_stockham_real_kernel(GenericArgs a, const float2 *tw_m, const float2 *tw_n) {
+  using namespace fftdev;
+  constexpr int N = 1 << LOG2N, LOG2M = LOG2N - 1, M = N / 2, T = M / 16, G = T < 256 ? 256 / T : 1;
+  constexpr bool WAVE = T <= 64;
+  constexpr int RL = LastPass<LOG2M>::R, NSL = LastPass<LOG2M>::NS, GL = 16 / RL;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  float2 *work = reinterpret_cast<float2 *>(smem);                       // G buffers of M complex
+  unsigned char *stage = smem + (size_t)G * M * sizeof(float2);
+  const int ft = a.ft, sstride = ft + 1;
+  const int64_t tiles = (a.count + ft - 1) / ft;
+  const int64_t clip = blockIdx.x / tiles, tile = blockIdx.x % tiles;
+  const Tin *x = reinterpret_cast<const Tin *>(a.x) + clip * a.x_stride;
+  const float *window = reinterpret_cast<const float *>(a.window);       // 0.5 * analysis window
+  const int64_t bins = a.bins;
+  const int tid = threadIdx.x % T, grp = threadIdx.x / T;
+  float2 *z = work + (size_t)grp * M;
+  const int64_t f0 = tile * ft;
+  const int nf = (int)((a.count - f0) < ft ? (a.count - f0) : ft);
+  auto emit = [&](int f, int k, float re, float im) {
+    if (a.direct) {
+      const int64_t o = clip * bins * a.out_stride + a.out_offset + f0 + f + (int64_t)k * a.out_stride;
+      if (a.mode == OUT_COMPLEX) reinterpret_cast<float2 *>(a.out)[o] = make_float2(re, im);
+      else reinterpret_cast<float *>(a.out)[o] = magnitude_pow<float, float>(re, im, a.power);
+    } else if (a.mode == OUT_COMPLEX) {
+      reinterpret_cast<float2 *>(stage)[k * sstride + f] = make_float2(re, im);
+    } else {
+      reinterpret_cast<float *>(stage)[k * sstride + f] = magnitude_pow<float, float>(re, im, a.power);
+    }
+  };
+  for (int fb = 0; fb < nf; fb += G) {
+    const int f = fb + grp;
+    const bool have = f < nf;                          // uniform per group of T threads
+    c32 r[16];
+    if (have) {
+      const int64_t s0 = (a.p0 + f0 + f) * a.hop - a.left;
+      if (s0 >= 0 && s0 + N <= a.n) {   // the frame lies inside the signal (uniform per group): plain loads
+        const Tin *xs = x + s0;
+#pragma unroll
+        for (int m = 0; m < 16; ++m) {
+          const int i = 2 * (tid + T * m);
+          r[m] = {(float)xs[i] * window[i], (float)xs[i + 1] * window[i + 1]};
+        }
+      } else {
+#pragma unroll 1
+        for (int m = 0; m < 16; ++m) {
+          const int i = 2 * (tid + T * m);
+          const float v0 = (float)fetch_sample<Tin>(x, a.n, s0 + i, a.pad, a.pad_value) * window[i];
+          const float v1 = (float)fetch_sample<Tin>(x, a.n, s0 + i + 1, a.pad, a.pad_value) * window[i + 1];
+#pragma unroll
+          for (int mm = 0; mm < 16; ++mm)
+            if (mm == m) r[mm] = {v0, v1};
+        }
+      }
+    } else {
+#pragma unroll
+      for (int m = 0; m < 16; ++m) r[m] = {0.0f, 0.0f};
+    }
+    fft_passes<LOG2M, true, WAVE>(r, z, tid, tw_m);
+    // the last pass left its results in registers (its reads of z are behind a sync): Z in natural order
+#pragma unroll
+    for (int i = 0; i < GL; ++i)
+#pragma unroll
+      for (int j = 0; j < RL; ++j) z[swz(out_index<RL, NSL, T>(tid, i, j))] = make_float2(r[i * RL + j].x, r[i * RL + j].y);
+    stockham_sync<WAVE>();
+    if (have) {
+#pragma unroll
+      for (int m = 0; m < 16; ++m) {
+        const int k = tid + T * m;
+        const float2 zk = z[swz(k)], zm = z[swz((M - k) & (M - 1))];
+        const float er = zk.x + zm.x, ei = zk.y - zm.y;            // Z[k] + conj Z[M-k]
+        const float dr = zk.x - zm.x, di = zk.y + zm.y;            // Z[k] - conj Z[M-k]
+        const float2 w = tw_n[k];                                  // exp(-2 pi i k / N)
+        // -i w d = -i (w.x + i w.y)(dr + i di) = (w.x di + w.y dr) - i (w.x dr - w.y di)
+        emit(f, k, er + (w.x * di + w.y * dr), ei - (w.x * dr - w.y * di));
+      }
+      if (tid == 0) {
+        const float2 z0 = z[swz(0)];
+        emit(f, M, 2.0f * (z0.x - z0.y), 0.0f);
+      }
+    }
+    __syncthreads();   // the next round's first pass writes the work buffers again
+  }
+  if (a.direct) return;
+  flush_stage_f32(a, stage, clip, f0, nf);
+}
+
+template <int LOG2N>
+bool launch_stockham_real(const StftJob &job, GenericArgs a, const StftTables &t) {
+  constexpr int N = 1 << LOG2N, M = N / 2, T = M / 16, G = T < 256 ? 256 / T : 1, THREADS = T < 256 ? 256 : T;
+  if (!t.fast_window || !t.fast_w_m || !t.fast_w_n) return false;
+  const size_t elem_out = (job.mode == OUT_COMPLEX ? 2 : 1) * sizeof(float);
+  const size_t work = (size_t)G * M * sizeof(float2);
+  auto stage_bytes = [&](int ft) { return (size_t)a.bins * (size_t)(ft + 1) * elem_out + 16; };
+  int ft = 16;
+  while (ft > G && work + stage_bytes(ft) > kLdsLimit) ft >>= 1;
+  a.direct = work + stage_bytes(ft) > kLdsLimit ? 1 : 0;
+  if (a.direct) ft = G;
+  if (work > kLdsLimit) return false;
+  a.ft = ft;
+  a.window = t.fast_window;
+  const int64_t blocks = a.lead * ((a.count + ft - 1) / ft);
+  if (blocks > 2147483647LL) throw Failure("stft: too many frame tiles for one launch");
+  const size_t lds = a.direct ? work : work + stage_bytes(ft);
+  auto kernel = stft_stockham_real_kernel<LOG2N, float>;
+  SMX_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  hipLaunchKernelGGL(kernel, dim3((unsigned)blocks), dim3(THREADS), lds, job.stream, a, (const float2 *)t.fast_w_m,
+                     (const float2 *)t.fast_w_n);
   SMX_HIP_CHECK(hipGetLastError());
   return true;
 }
@@ -382,16 +524,7 @@ __global__ void __launch_bounds__((1 << LOG2M) / 16 < 256 ? 256 : (1 << LOG2M) /
     __syncthreads();
   }
   if (a.direct) return;
-  const int64_t total = bins * nf;
-  const int64_t obase = clip * bins * a.out_stride + a.out_offset + f0;
-  for (int64_t e = threadIdx.x; e < total; e += blockDim.x) {
-    const int64_t k = e / nf;
-    const int f = (int)(e % nf);
-    if (a.mode == OUT_COMPLEX)
-      reinterpret_cast<float2 *>(a.out)[obase + k * a.out_stride + f] = reinterpret_cast<const float2 *>(stage)[k * sstride + f];
-    else
-      reinterpret_cast<float *>(a.out)[obase + k * a.out_stride + f] = reinterpret_cast<const float *>(stage)[k * sstride + f];
-  }
+  flush_stage_f32(a, stage, clip, f0, nf);
 }
 
 template <int LOG2M>
@@ -478,14 +611,18 @@ void launch_stft_generic(const StftJob &job) {
   a.twiddle = f64_interior ? (const void *)t.twiddle_f64 : (const void *)t.twiddle_f32;
   if (job.in_bytes == 4 && !f64_interior && !fast_path_disabled()) {
     bool done = false;
+    // the half-size real form wins up to 2048 (fft 1024: 343 vs 315 Mframes/s, 512: 735 vs 687); from 4096 on both
+    // forms sit at one 256-thread workgroup per CU (the stage fills the LDS) and the full-size one measured faster
+    const char *cf = std::getenv("SMX_STOCKHAM_COMPLEX");   // diagnostic: force the full-size complex form
+    const bool real_form = !(cf && cf[0] == '1') && c.fft_size <= 2048;
     switch (c.fft_size) {
       case 256: done = launch_stockham<8>(job, a); break;
-      case 512: done = launch_stockham<9>(job, a); break;
-      case 1024: done = launch_stockham<10>(job, a); break;
-      case 2048: done = launch_stockham<11>(job, a); break;
-      case 4096: done = launch_stockham<12>(job, a); break;
-      case 8192: done = launch_stockham<13>(job, a); break;
-      case 16384: done = launch_stockham<14>(job, a); break;
+      case 512: done = real_form ? launch_stockham_real<9>(job, a, t) : launch_stockham<9>(job, a); break;
+      case 1024: done = real_form ? launch_stockham_real<10>(job, a, t) : launch_stockham<10>(job, a); break;
+      case 2048: done = real_form ? launch_stockham_real<11>(job, a, t) : launch_stockham<11>(job, a); break;
+      case 4096: done = real_form ? launch_stockham_real<12>(job, a, t) : launch_stockham<12>(job, a); break;
+      case 8192: done = real_form ? launch_stockham_real<13>(job, a, t) : launch_stockham<13>(job, a); break;
+      case 16384: done = real_form ? launch_stockham_real<14>(job, a, t) : launch_stockham<14>(job, a); break;
       default: break;
     }
     if (!done && t.blu_log2m >= 8) {   // not a power of two: chirp-z
