@@ -6,19 +6,28 @@
 namespace smx {
 namespace fftdev {
 
-struct c32 {
-  float x, y;
+// complex value of scalar type S in registers; c32 is what the float32 kernels use, c64 the float64 interior
+template <typename S>
+struct cpx {
+  S x, y;
 };
-__device__ __forceinline__ c32 operator+(c32 a, c32 b) { return {a.x + b.x, a.y + b.y}; }
-__device__ __forceinline__ c32 operator-(c32 a, c32 b) { return {a.x - b.x, a.y - b.y}; }
-__device__ __forceinline__ c32 cmul(c32 a, c32 w) {
+using c32 = cpx<float>;
+using c64 = cpx<double>;
+template <typename S> struct vec2_of;
+template <> struct vec2_of<float> { using type = float2; };
+template <> struct vec2_of<double> { using type = double2; };
+
+template <typename S> __device__ __forceinline__ cpx<S> operator+(cpx<S> a, cpx<S> b) { return {a.x + b.x, a.y + b.y}; }
+template <typename S> __device__ __forceinline__ cpx<S> operator-(cpx<S> a, cpx<S> b) { return {a.x - b.x, a.y - b.y}; }
+template <typename S> __device__ __forceinline__ cpx<S> cmul(cpx<S> a, cpx<S> w) {
   return {a.x * w.x - a.y * w.y, a.x * w.y + a.y * w.x};
 }
-__device__ __forceinline__ c32 mul_neg_i(c32 a) { return {a.y, -a.x}; }
+template <typename S> __device__ __forceinline__ cpx<S> mul_neg_i(cpx<S> a) { return {a.y, -a.x}; }
 
 // 4-point forward DFT in place: (a,b,c,d) -> (X0,X1,X2,X3)
-__device__ __forceinline__ void fft4(c32 &a, c32 &b, c32 &c, c32 &d) {
-  const c32 t0 = a + c, t1 = a - c, t2 = b + d, t3 = mul_neg_i(b - d);
+template <typename S>
+__device__ __forceinline__ void fft4(cpx<S> &a, cpx<S> &b, cpx<S> &c, cpx<S> &d) {
+  const cpx<S> t0 = a + c, t1 = a - c, t2 = b + d, t3 = mul_neg_i(b - d);
   a = t0 + t2;
   b = t1 + t3;
   c = t0 - t2;
@@ -27,27 +36,33 @@ __device__ __forceinline__ void fft4(c32 &a, c32 &b, c32 &c, c32 &d) {
 
 // 16-point forward DFT, natural order in and out, fully in registers (4 x 4), in two passes
 // (pass 1: four 4-point DFTs + inner twiddles; pass 2: four 4-point DFTs + index transpose).
-__device__ __forceinline__ void fft16_pass1(c32 (&v)[16]) {
-  constexpr float c1 = 0.92387953251128674f, s1 = 0.38268343236508977f;
-  constexpr float h = 0.70710678118654752f;
+static_assert((float)0.92387953251128674 == 0.92387953251128674f && (float)0.38268343236508977 == 0.38268343236508977f &&
+                  (float)0.70710678118654752 == 0.70710678118654752f,
+              "the float32 constants are the rounded float64 ones");
+template <typename S>
+__device__ __forceinline__ void fft16_pass1(cpx<S> (&v)[16]) {
+  constexpr S c1 = (S)0.92387953251128674, s1 = (S)0.38268343236508977;
+  constexpr S h = (S)0.70710678118654752;
+  using C = cpx<S>;
 #pragma unroll
   for (int n0 = 0; n0 < 4; ++n0) fft4(v[n0], v[4 + n0], v[8 + n0], v[12 + n0]);
   // u[n0][k0] sits at v[4 k0 + n0]; multiply by W16^(n0 k0)
-  v[4 * 1 + 1] = cmul(v[4 * 1 + 1], c32{c1, -s1});   // W^1
-  v[4 * 1 + 2] = cmul(v[4 * 1 + 2], c32{h, -h});     // W^2
-  v[4 * 1 + 3] = cmul(v[4 * 1 + 3], c32{s1, -c1});   // W^3
-  v[4 * 2 + 1] = cmul(v[4 * 2 + 1], c32{h, -h});     // W^2
-  v[4 * 2 + 2] = mul_neg_i(v[4 * 2 + 2]);            // W^4
-  v[4 * 2 + 3] = cmul(v[4 * 2 + 3], c32{-h, -h});    // W^6
-  v[4 * 3 + 1] = cmul(v[4 * 3 + 1], c32{s1, -c1});   // W^3
-  v[4 * 3 + 2] = cmul(v[4 * 3 + 2], c32{-h, -h});    // W^6
-  v[4 * 3 + 3] = cmul(v[4 * 3 + 3], c32{-c1, s1});   // W^9
+  v[4 * 1 + 1] = cmul(v[4 * 1 + 1], C{c1, -s1});   // W^1
+  v[4 * 1 + 2] = cmul(v[4 * 1 + 2], C{h, -h});     // W^2
+  v[4 * 1 + 3] = cmul(v[4 * 1 + 3], C{s1, -c1});   // W^3
+  v[4 * 2 + 1] = cmul(v[4 * 2 + 1], C{h, -h});     // W^2
+  v[4 * 2 + 2] = mul_neg_i(v[4 * 2 + 2]);          // W^4
+  v[4 * 2 + 3] = cmul(v[4 * 2 + 3], C{-h, -h});    // W^6
+  v[4 * 3 + 1] = cmul(v[4 * 3 + 1], C{s1, -c1});   // W^3
+  v[4 * 3 + 2] = cmul(v[4 * 3 + 2], C{-h, -h});    // W^6
+  v[4 * 3 + 3] = cmul(v[4 * 3 + 3], C{-c1, s1});   // W^9
 }
-__device__ __forceinline__ void fft16_pass2(c32 (&v)[16]) {
+template <typename S>
+__device__ __forceinline__ void fft16_pass2(cpx<S> (&v)[16]) {
 #pragma unroll
   for (int k0 = 0; k0 < 4; ++k0) fft4(v[4 * k0], v[4 * k0 + 1], v[4 * k0 + 2], v[4 * k0 + 3]);
   // X[k0 + 4 k1] sits at v[4 k0 + k1]: transpose the 4x4 index
-  c32 t[16];
+  cpx<S> t[16];
 #pragma unroll
   for (int k0 = 0; k0 < 4; ++k0)
 #pragma unroll
@@ -55,7 +70,8 @@ __device__ __forceinline__ void fft16_pass2(c32 (&v)[16]) {
 #pragma unroll
   for (int i = 0; i < 16; ++i) v[i] = t[i];
 }
-__device__ __forceinline__ void fft16(c32 (&v)[16]) {
+template <typename S>
+__device__ __forceinline__ void fft16(cpx<S> (&v)[16]) {
   fft16_pass1(v);
   fft16_pass2(v);
 }
@@ -65,12 +81,12 @@ __device__ __forceinline__ void fft16(c32 (&v)[16]) {
 // registers, so a pass is: read 16 (lane-contiguous, conflict free), sync, twiddle + register DFT, write 16 to
 // the autosort positions.  LDS addresses are XOR-swizzled (a ^ ((a >> 5) & 31)): reads conflict free, writes at
 // most 2-way (tools/sim_fir_fft.py).  Twiddles: one table read (exp(-2 pi i j / N), j < N/2) per pass and radix
-// group, powers by binary multiplication (depth <= 4).
+// group, powers by binary multiplication (depth <= 4).  The scalar type S (float / double) comes from the registers.
 __device__ __forceinline__ int swz(int a) { return a ^ ((a >> 5) & 31); }
 
 // powers w^1 .. w^(R-1) of a unit twiddle by binary multiplication (depth <= 4)
-template <int R>
-__device__ __forceinline__ void twiddle_powers(c32 w1, c32 (&w)[16]) {
+template <int R, typename S>
+__device__ __forceinline__ void twiddle_powers(cpx<S> w1, cpx<S> (&w)[16]) {
   w[1] = w1;
   if constexpr (R >= 4) {
     w[2] = cmul(w1, w1);
@@ -100,8 +116,10 @@ __device__ __forceinline__ void stockham_sync() {
   else __syncthreads();
 }
 
-template <int N, int R, int NS, bool READ, bool WRITE, bool WAVE = false>
-__device__ __forceinline__ void stockham_pass(c32 (&r)[16], float2 *z, int tid, const float2 *tw) {
+template <int N, int R, int NS, bool READ, bool WRITE, bool WAVE = false, typename S = float>
+__device__ __forceinline__ void stockham_pass(cpx<S> (&r)[16], typename vec2_of<S>::type *z, int tid,
+                                              const typename vec2_of<S>::type *tw) {
+  using V = typename vec2_of<S>::type;
   constexpr int T = N / 16, G = 16 / R;
   if constexpr (READ) {
     stockham_sync<WAVE>();   // the previous pass's writes are visible
@@ -109,7 +127,7 @@ __device__ __forceinline__ void stockham_pass(c32 (&r)[16], float2 *z, int tid, 
     for (int i = 0; i < G; ++i)
 #pragma unroll
       for (int j = 0; j < R; ++j) {
-        const float2 v = z[swz(tid + T * (i + G * j))];
+        const V v = z[swz(tid + T * (i + G * j))];
         r[i * R + j] = {v.x, v.y};
       }
     stockham_sync<WAVE>();   // everyone holds its points: the buffer may be overwritten
@@ -118,9 +136,9 @@ __device__ __forceinline__ void stockham_pass(c32 (&r)[16], float2 *z, int tid, 
   for (int i = 0; i < G; ++i) {
     if constexpr (NS > 1) {
       const int k = (tid + T * i) % NS;
-      const float2 w1 = tw[k * (N / (NS * R))];
-      c32 w[16];
-      twiddle_powers<R>(c32{w1.x, w1.y}, w);
+      const V w1 = tw[k * (N / (NS * R))];
+      cpx<S> w[16];
+      twiddle_powers<R>(cpx<S>{w1.x, w1.y}, w);
 #pragma unroll
       for (int j = 1; j < R; ++j) r[i * R + j] = cmul(r[i * R + j], w[j]);
     }
@@ -129,7 +147,7 @@ __device__ __forceinline__ void stockham_pass(c32 (&r)[16], float2 *z, int tid, 
     } else if constexpr (R == 4) {
       fft4(r[4 * i], r[4 * i + 1], r[4 * i + 2], r[4 * i + 3]);
     } else {
-      const c32 u = r[2 * i], v = r[2 * i + 1];
+      const cpx<S> u = r[2 * i], v = r[2 * i + 1];
       r[2 * i] = u + v;
       r[2 * i + 1] = u - v;
     }
@@ -140,7 +158,12 @@ __device__ __forceinline__ void stockham_pass(c32 (&r)[16], float2 *z, int tid, 
       const int t = tid + T * i, k = t % NS;
       const int j0 = (t / NS) * NS * R + k;
 #pragma unroll
-      for (int j = 0; j < R; ++j) z[swz(j0 + j * NS)] = make_float2(r[i * R + j].x, r[i * R + j].y);
+      for (int j = 0; j < R; ++j) {
+        V o;
+        o.x = r[i * R + j].x;
+        o.y = r[i * R + j].y;
+        z[swz(j0 + j * NS)] = o;
+      }
     }
   }
 }
@@ -153,8 +176,9 @@ __device__ __forceinline__ int out_index(int tid, int i, int j) {
 
 // forward FFT of the 16 points per thread; FIRST: registers already hold element tid + T*m in r[m].
 // On return r[i*R + j] (last radix R, its NS) holds natural-order element out_index<R, NS, T>(tid, i, j).
-template <int LOG2N, bool FIRST, bool WAVE = false>
-__device__ __forceinline__ void fft_passes(c32 (&r)[16], float2 *z, int tid, const float2 *tw) {
+template <int LOG2N, bool FIRST, bool WAVE = false, typename S = float>
+__device__ __forceinline__ void fft_passes(cpx<S> (&r)[16], typename vec2_of<S>::type *z, int tid,
+                                           const typename vec2_of<S>::type *tw) {
   constexpr int N = 1 << LOG2N;
   static_assert(LOG2N >= 8 && LOG2N <= 14, "transform sizes 256 .. 16384");
   stockham_pass<N, 16, 1, !FIRST, true, WAVE>(r, z, tid, tw);

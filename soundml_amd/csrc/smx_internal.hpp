@@ -58,6 +58,7 @@ struct StftTables {
   // fast kernels (N = 2048 family): half-scaled window + split twiddle tables
   float *fast_window = nullptr;    // 0.5 * window, f32
   float2 *fast_w_m = nullptr;      // exp(-2 pi i j / M), j < M   (M = N/2)
+  double2 *fast_w_m_f64 = nullptr; // the same in float64 (float64-interior Stockham form, fft 512 .. 4096)
   float2 *fast_w_n = nullptr;      // exp(-2 pi i k / N), k <= M
   // chirp-z (Bluestein) path of the generic float32 kernels for sizes that are not powers of two: an N-point DFT
   // as one circular convolution of length blu_m = 2^blu_log2m >= 2 N - 1

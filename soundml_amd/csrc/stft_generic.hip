@@ -204,7 +204,9 @@ constexpr size_t kLdsLimit = 160 * 1024;
 
 // stage [bins][ft + 1] -> out[clip][bins][frames], frames fastest: runs of nf elements per bin row.  ft is a power
 // of two, so a full tile splits the element index with a shift; only a clip's last, ragged tile divides.
-__device__ __forceinline__ void flush_stage_f32(const GenericArgs &a, const unsigned char *stage, int64_t clip, int64_t f0, int nf) {
+template <typename Tout>
+__device__ __forceinline__ void flush_stage(const GenericArgs &a, const unsigned char *stage, int64_t clip, int64_t f0, int nf) {
+  using CO = typename Vec2<Tout>::type;
   const int ft = a.ft, sstride = ft + 1;
   const int total = (int)a.bins * nf;
   const int64_t obase = clip * a.bins * a.out_stride + a.out_offset + f0;
@@ -219,9 +221,9 @@ __device__ __forceinline__ void flush_stage_f32(const GenericArgs &a, const unsi
       f = e - k * nf;
     }
     if (a.mode == OUT_COMPLEX)
-      reinterpret_cast<float2 *>(a.out)[obase + (int64_t)k * a.out_stride + f] = reinterpret_cast<const float2 *>(stage)[k * sstride + f];
+      reinterpret_cast<CO *>(a.out)[obase + (int64_t)k * a.out_stride + f] = reinterpret_cast<const CO *>(stage)[k * sstride + f];
     else
-      reinterpret_cast<float *>(a.out)[obase + (int64_t)k * a.out_stride + f] = reinterpret_cast<const float *>(stage)[k * sstride + f];
+      reinterpret_cast<Tout *>(a.out)[obase + (int64_t)k * a.out_stride + f] = reinterpret_cast<const Tout *>(stage)[k * sstride + f];
   }
 }
 
@@ -300,7 +302,7 @@ __global__ void __launch_bounds__((1 << LOG2N) / 16 < 256 ? 256 : (1 << LOG2N) /
     __syncthreads();   // the next round's first pass writes the work buffers again
   }
   if (a.direct) return;
-  flush_stage_f32(a, stage, clip, f0, nf);
+  flush_stage<float>(a, stage, clip, f0, nf);
 }
 
 template <int LOG2N>
@@ -330,41 +332,57 @@ bool launch_stockham(const StftJob &job, GenericArgs a) {
 //   X[k] = (Z[k] + conj Z[M-k]) - i W_N^k (Z[k] - conj Z[M-k]),  X[M] = Re Z[0] - Im Z[0]
 // -- half the passes' work of the kernel above for one more LDS round trip (the partner Z[M-k] lives in another
 // thread).  M/16 threads own a frame; transforms of at most 64 threads are wave-private (no workgroup barriers).
-template <int LOG2N, typename Tin>
+// S = double: the reference's float64 interior (float32 or float64 audio, results rounded once to Tout) on the same
+// passes, fft 512 .. 4096 (16 complex doubles per thread need the 256-register budget of a 256-thread workgroup).
+template <int LOG2N, typename Tin, typename S, typename Tout>
 __global__ void __launch_bounds__((1 << LOG2N) / 32 < 256 ? 256 : (1 << LOG2N) / 32)
-    stft_stockham_real_kernel(GenericArgs a, const float2 *tw_m, const float2 *tw_n) {
+    stft_stockham_real_kernel(GenericArgs a, const typename fftdev::vec2_of<S>::type *tw_m,
+                              const typename fftdev::vec2_of<S>::type *tw_n) {
   using namespace fftdev;
+  using V = typename vec2_of<S>::type;
+  using CO = typename Vec2<Tout>::type;
   constexpr int N = 1 << LOG2N, LOG2M = LOG2N - 1, M = N / 2, T = M / 16, G = T < 256 ? 256 / T : 1;
   constexpr bool WAVE = T <= 64;
   constexpr int RL = LastPass<LOG2M>::R, NSL = LastPass<LOG2M>::NS, GL = 16 / RL;
+  // float32: the window table is pre-halved; float64: the config's own window, halved here (exact either way)
+  constexpr S kHalf = sizeof(S) == 8 ? (S)0.5 : (S)1.0;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  float2 *work = reinterpret_cast<float2 *>(smem);                       // G buffers of M complex
-  unsigned char *stage = smem + (size_t)G * M * sizeof(float2);
+  V *work = reinterpret_cast<V *>(smem);                                 // G buffers of M complex
+  unsigned char *stage = smem + (size_t)G * M * sizeof(V);
   const int ft = a.ft, sstride = ft + 1;
   const int64_t tiles = (a.count + ft - 1) / ft;
   const int64_t clip = blockIdx.x / tiles, tile = blockIdx.x % tiles;
   const Tin *x = reinterpret_cast<const Tin *>(a.x) + clip * a.x_stride;
-  const float *window = reinterpret_cast<const float *>(a.window);       // 0.5 * analysis window
+  const S *window = reinterpret_cast<const S *>(a.window);
   const int64_t bins = a.bins;
   const int tid = threadIdx.x % T, grp = threadIdx.x / T;
-  float2 *z = work + (size_t)grp * M;
+  V *z = work + (size_t)grp * M;
   const int64_t f0 = tile * ft;
   const int nf = (int)((a.count - f0) < ft ? (a.count - f0) : ft);
-  auto emit = [&](int f, int k, float re, float im) {
+  auto emit = [&](int f, int k, S re, S im) {
     if (a.direct) {
       const int64_t o = clip * bins * a.out_stride + a.out_offset + f0 + f + (int64_t)k * a.out_stride;
-      if (a.mode == OUT_COMPLEX) reinterpret_cast<float2 *>(a.out)[o] = make_float2(re, im);
-      else reinterpret_cast<float *>(a.out)[o] = magnitude_pow<float, float>(re, im, a.power);
+      if (a.mode == OUT_COMPLEX) {
+        CO c;
+        c.x = (Tout)re;
+        c.y = (Tout)im;
+        reinterpret_cast<CO *>(a.out)[o] = c;
+      } else {
+        reinterpret_cast<Tout *>(a.out)[o] = magnitude_pow<S, Tout>(re, im, a.power);
+      }
     } else if (a.mode == OUT_COMPLEX) {
-      reinterpret_cast<float2 *>(stage)[k * sstride + f] = make_float2(re, im);
+      CO c;
+      c.x = (Tout)re;
+      c.y = (Tout)im;
+      reinterpret_cast<CO *>(stage)[k * sstride + f] = c;
     } else {
-      reinterpret_cast<float *>(stage)[k * sstride + f] = magnitude_pow<float, float>(re, im, a.power);
+      reinterpret_cast<Tout *>(stage)[k * sstride + f] = magnitude_pow<S, Tout>(re, im, a.power);
     }
   };
   for (int fb = 0; fb < nf; fb += G) {
     const int f = fb + grp;
     const bool have = f < nf;                          // uniform per group of T threads
-    c32 r[16];
+    cpx<S> r[16];
     if (have) {
       const int64_t s0 = (a.p0 + f0 + f) * a.hop - a.left;
       if (s0 >= 0 && s0 + N <= a.n) {   // the frame lies inside the signal (uniform per group): plain loads
@@ -372,14 +390,14 @@ __global__ void __launch_bounds__((1 << LOG2N) / 32 < 256 ? 256 : (1 << LOG2N) /
 #pragma unroll
         for (int m = 0; m < 16; ++m) {
           const int i = 2 * (tid + T * m);
-          r[m] = {(float)xs[i] * window[i], (float)xs[i + 1] * window[i + 1]};
+          r[m] = {(S)xs[i] * window[i] * kHalf, (S)xs[i + 1] * window[i + 1] * kHalf};
         }
       } else {
 #pragma unroll 1
         for (int m = 0; m < 16; ++m) {
           const int i = 2 * (tid + T * m);
-          const float v0 = (float)fetch_sample<Tin>(x, a.n, s0 + i, a.pad, a.pad_value) * window[i];
-          const float v1 = (float)fetch_sample<Tin>(x, a.n, s0 + i + 1, a.pad, a.pad_value) * window[i + 1];
+          const S v0 = (S)fetch_sample<Tin>(x, a.n, s0 + i, a.pad, a.pad_value) * window[i] * kHalf;
+          const S v1 = (S)fetch_sample<Tin>(x, a.n, s0 + i + 1, a.pad, a.pad_value) * window[i + 1] * kHalf;
 #pragma unroll
           for (int mm = 0; mm < 16; ++mm)
             if (mm == m) r[mm] = {v0, v1};
@@ -387,43 +405,54 @@ __global__ void __launch_bounds__((1 << LOG2N) / 32 < 256 ? 256 : (1 << LOG2N) /
       }
     } else {
 #pragma unroll
-      for (int m = 0; m < 16; ++m) r[m] = {0.0f, 0.0f};
+      for (int m = 0; m < 16; ++m) r[m] = {(S)0, (S)0};
     }
     fft_passes<LOG2M, true, WAVE>(r, z, tid, tw_m);
     // the last pass left its results in registers (its reads of z are behind a sync): Z in natural order
 #pragma unroll
     for (int i = 0; i < GL; ++i)
 #pragma unroll
-      for (int j = 0; j < RL; ++j) z[swz(out_index<RL, NSL, T>(tid, i, j))] = make_float2(r[i * RL + j].x, r[i * RL + j].y);
+      for (int j = 0; j < RL; ++j) {
+        V o;
+        o.x = r[i * RL + j].x;
+        o.y = r[i * RL + j].y;
+        z[swz(out_index<RL, NSL, T>(tid, i, j))] = o;
+      }
     stockham_sync<WAVE>();
     if (have) {
 #pragma unroll
       for (int m = 0; m < 16; ++m) {
         const int k = tid + T * m;
-        const float2 zk = z[swz(k)], zm = z[swz((M - k) & (M - 1))];
-        const float er = zk.x + zm.x, ei = zk.y - zm.y;            // Z[k] + conj Z[M-k]
-        const float dr = zk.x - zm.x, di = zk.y + zm.y;            // Z[k] - conj Z[M-k]
-        const float2 w = tw_n[k];                                  // exp(-2 pi i k / N)
+        const V zk = z[swz(k)], zm = z[swz((M - k) & (M - 1))];
+        const S er = zk.x + zm.x, ei = zk.y - zm.y;            // Z[k] + conj Z[M-k]
+        const S dr = zk.x - zm.x, di = zk.y + zm.y;            // Z[k] - conj Z[M-k]
+        const V w = tw_n[k];                                   // exp(-2 pi i k / N)
         // -i w d = -i (w.x + i w.y)(dr + i di) = (w.x di + w.y dr) - i (w.x dr - w.y di)
         emit(f, k, er + (w.x * di + w.y * dr), ei - (w.x * dr - w.y * di));
       }
       if (tid == 0) {
-        const float2 z0 = z[swz(0)];
-        emit(f, M, 2.0f * (z0.x - z0.y), 0.0f);
+        const V z0 = z[swz(0)];
+        emit(f, M, (S)2 * (z0.x - z0.y), (S)0);
       }
     }
     __syncthreads();   // the next round's first pass writes the work buffers again
   }
   if (a.direct) return;
-  flush_stage_f32(a, stage, clip, f0, nf);
+  flush_stage<Tout>(a, stage, clip, f0, nf);
 }
 
-template <int LOG2N>
+template <int LOG2N, typename Tin, typename S, typename Tout>
 bool launch_stockham_real(const StftJob &job, GenericArgs a, const StftTables &t) {
+  using V = typename fftdev::vec2_of<S>::type;
   constexpr int N = 1 << LOG2N, M = N / 2, T = M / 16, G = T < 256 ? 256 / T : 1, THREADS = T < 256 ? 256 : T;
-  if (!t.fast_window || !t.fast_w_m || !t.fast_w_n) return false;
-  const size_t elem_out = (job.mode == OUT_COMPLEX ? 2 : 1) * sizeof(float);
-  const size_t work = (size_t)G * M * sizeof(float2);
+  constexpr bool wide = sizeof(S) == 8;
+  static_assert(!wide || THREADS == 256, "the float64 form needs the register budget of a 256-thread workgroup");
+  const void *tw_m = wide ? (const void *)t.fast_w_m_f64 : (const void *)t.fast_w_m;
+  const void *tw_n = wide ? (const void *)t.twiddle_f64 : (const void *)t.fast_w_n;
+  const void *window = wide ? (const void *)t.window_f64 : (const void *)t.fast_window;
+  if (!window || !tw_m || !tw_n) return false;
+  const size_t elem_out = (job.mode == OUT_COMPLEX ? 2 : 1) * sizeof(Tout);
+  const size_t work = (size_t)G * M * sizeof(V);
   auto stage_bytes = [&](int ft) { return (size_t)a.bins * (size_t)(ft + 1) * elem_out + 16; };
   int ft = 16;
   while (ft > G && work + stage_bytes(ft) > kLdsLimit) ft >>= 1;
@@ -431,16 +460,27 @@ bool launch_stockham_real(const StftJob &job, GenericArgs a, const StftTables &t
   if (a.direct) ft = G;
   if (work > kLdsLimit) return false;
   a.ft = ft;
-  a.window = t.fast_window;
+  a.window = window;
   const int64_t blocks = a.lead * ((a.count + ft - 1) / ft);
   if (blocks > 2147483647LL) throw Failure("stft: too many frame tiles for one launch");
   const size_t lds = a.direct ? work : work + stage_bytes(ft);
-  auto kernel = stft_stockham_real_kernel<LOG2N, float>;
+  auto kernel = stft_stockham_real_kernel<LOG2N, Tin, S, Tout>;
   SMX_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  hipLaunchKernelGGL(kernel, dim3((unsigned)blocks), dim3(THREADS), lds, job.stream, a, (const float2 *)t.fast_w_m,
-                     (const float2 *)t.fast_w_n);
+  hipLaunchKernelGGL(kernel, dim3((unsigned)blocks), dim3(THREADS), lds, job.stream, a, (const V *)tw_m, (const V *)tw_n);
   SMX_HIP_CHECK(hipGetLastError());
   return true;
+}
+
+// the float64-interior form for one (audio, output) dtype pair: fft 512 .. 4096
+template <typename Tin, typename Tout>
+bool launch_stockham_wide(const StftJob &job, const GenericArgs &a, const StftTables &t, int64_t fft) {
+  switch (fft) {
+    case 512: return launch_stockham_real<9, Tin, double, Tout>(job, a, t);
+    case 1024: return launch_stockham_real<10, Tin, double, Tout>(job, a, t);
+    case 2048: return launch_stockham_real<11, Tin, double, Tout>(job, a, t);
+    case 4096: return launch_stockham_real<12, Tin, double, Tout>(job, a, t);
+    default: return false;
+  }
 }
 
 // ---- any other size up to 8192, float32 interior: chirp-z (Bluestein) on the same Stockham passes ------------
@@ -524,7 +564,7 @@ __global__ void __launch_bounds__((1 << LOG2M) / 16 < 256 ? 256 : (1 << LOG2M) /
     __syncthreads();
   }
   if (a.direct) return;
-  flush_stage_f32(a, stage, clip, f0, nf);
+  flush_stage<float>(a, stage, clip, f0, nf);
 }
 
 template <int LOG2M>
@@ -617,12 +657,12 @@ void launch_stft_generic(const StftJob &job) {
     const bool real_form = !(cf && cf[0] == '1') && c.fft_size <= 2048;
     switch (c.fft_size) {
       case 256: done = launch_stockham<8>(job, a); break;
-      case 512: done = real_form ? launch_stockham_real<9>(job, a, t) : launch_stockham<9>(job, a); break;
-      case 1024: done = real_form ? launch_stockham_real<10>(job, a, t) : launch_stockham<10>(job, a); break;
-      case 2048: done = real_form ? launch_stockham_real<11>(job, a, t) : launch_stockham<11>(job, a); break;
-      case 4096: done = real_form ? launch_stockham_real<12>(job, a, t) : launch_stockham<12>(job, a); break;
-      case 8192: done = real_form ? launch_stockham_real<13>(job, a, t) : launch_stockham<13>(job, a); break;
-      case 16384: done = real_form ? launch_stockham_real<14>(job, a, t) : launch_stockham<14>(job, a); break;
+      case 512: done = real_form ? launch_stockham_real<9, float, float, float>(job, a, t) : launch_stockham<9>(job, a); break;
+      case 1024: done = real_form ? launch_stockham_real<10, float, float, float>(job, a, t) : launch_stockham<10>(job, a); break;
+      case 2048: done = real_form ? launch_stockham_real<11, float, float, float>(job, a, t) : launch_stockham<11>(job, a); break;
+      case 4096: done = real_form ? launch_stockham_real<12, float, float, float>(job, a, t) : launch_stockham<12>(job, a); break;
+      case 8192: done = real_form ? launch_stockham_real<13, float, float, float>(job, a, t) : launch_stockham<13>(job, a); break;
+      case 16384: done = real_form ? launch_stockham_real<14, float, float, float>(job, a, t) : launch_stockham<14>(job, a); break;
       default: break;
     }
     if (!done && t.blu_log2m >= 8) {   // not a power of two: chirp-z
@@ -639,6 +679,11 @@ void launch_stft_generic(const StftJob &job) {
       }
     }
     if (done) return;
+  }
+  if (f64_interior && !fast_path_disabled()) {   // float64 interior on the Stockham passes (fft 512 .. 4096)
+    if (job.in_bytes == 8 ? launch_stockham_wide<double, double>(job, a, t, c.fft_size)
+                          : launch_stockham_wide<float, float>(job, a, t, c.fft_size))
+      return;
   }
   if (job.in_bytes == 8)
     launch_typed<double, double, double>(job, a);

@@ -130,6 +130,14 @@ const smx::StftTables &smx_stft_config::tables() const {
     for (int64_t j = 0; j < m; ++j)
       sw[(size_t)j] = make_float2((float)(analysis_window[(size_t)(2 * j)] / (double)(2 * m)),
                                   (float)(-analysis_window[(size_t)(2 * j + 1)] / (double)(2 * m)));
+    if (n >= 512 && n <= 4096) {
+      std::vector<double2> wm64((size_t)m);
+      for (int64_t j = 0; j < m; ++j) {
+        const double a = -2.0 * M_PI * (double)j / (double)m;
+        wm64[(size_t)j] = make_double2(std::cos(a), std::sin(a));
+      }
+      t.fast_w_m_f64 = smx::upload(wm64);
+    }
     t.fast_window = smx::upload(hw);
     t.fast_w_m = smx::upload(wm);
     t.fast_w_n = smx::upload(wn);
@@ -147,6 +155,7 @@ smx_stft_config::~smx_stft_config() {
     (void)hipFree(t.twiddle_f32);
     (void)hipFree(t.fast_window);
     (void)hipFree(t.fast_w_m);
+    (void)hipFree(t.fast_w_m_f64);
     (void)hipFree(t.fast_w_n);
     (void)hipFree(t.fast_synth_window);
     (void)hipFree(t.blu_chirp);
