@@ -197,6 +197,41 @@ def test_other_sizes_float32(fft, hop):
     assert np.array_equal(np.concatenate(parts, axis=-1), z)
 
 
+@pytest.mark.parametrize("fft,hop,alignment,pad", [(512, 128, "centered", "reflect"), (1024, 256, "left", "edge"),
+                                                   (2048, 512, "centered", "reflect"), (2048, 500, "right", ("constant", 0.5)),
+                                                   (4096, 1024, "centered", "reflect"), (1024, 1500, "centered", "edge")])
+def test_float64_interior_stockham_sizes(fft, hop, alignment, pad):
+    """The float64 interior on the Stockham passes (fft 512 .. 4096, stft_stockham_real_kernel<.., double, ..>):
+    float64 audio at the reference's float64 tolerance, float32 audio with `set_interior("float64")` at its float32
+    one (stft_goldens.ml:13-17), spectrum and power, borders and ragged tiles, a scaled window; frame ranges
+    reassemble the whole bit for bit."""
+    rng = np.random.default_rng(fft + hop)
+    n = 9 * fft + 123
+    x64 = rng.standard_normal((2, n))
+    kw = dict(hop=hop, alignment=alignment, scale="magnitude")
+    c = Stft.Config.create(fft_size=fft, pad=pad, **kw)
+    o = (O.stft_config(fft, pad=pad[0], pad_value=pad[1], **kw) if isinstance(pad, tuple) else O.stft_config(fft, pad=pad, **kw))
+    z, want = Stft.transform(c, x64), O.transform(o, x64)
+    assert z.dtype == np.complex128 and z.shape == want.shape
+    scale = float(np.max(np.abs(want)))
+    np.testing.assert_allclose(z, want, rtol=F64_RTOL, atol=1e-12 * scale)
+    np.testing.assert_allclose(Stft.power_spectrum(c, x64, power=1.0), O.power_spectrum(o, x64, 1.0), rtol=F64_RTOL, atol=1e-12 * scale)
+    x32 = x64.astype(np.float32)
+    S.set_interior("float64")
+    try:
+        z32, p32 = Stft.transform(c, x32), Stft.power_spectrum(c, x32)
+        total = Stft.frames(c, n)
+        cuts = [0, 1, 3, total // 2, total]
+        parts = [Stft.transform_range(c, x32, a, b) for a, b in zip(cuts[:-1], cuts[1:])]
+    finally:
+        S.set_interior("float32")
+    w32 = O.transform(o, x32)
+    assert z32.dtype == np.complex64 and p32.dtype == np.float32
+    np.testing.assert_allclose(z32, w32, rtol=F32_RTOL, atol=F32_ATOL * float(np.max(np.abs(w32))))
+    np.testing.assert_allclose(p32, O.power_spectrum(o, x32), rtol=2 * F32_RTOL, atol=F32_ATOL * float(np.max(np.abs(w32))) ** 2)
+    assert np.array_equal(np.concatenate(parts, axis=-1), z32)
+
+
 @pytest.mark.parametrize("alignment", ["centered", "left", "right"])
 @pytest.mark.parametrize("pad", ["reflect", "edge", ("constant", 0.25)])
 @pytest.mark.parametrize("fft,hop", [(2048, 512), (64, 16), (16, 20), (31, 5)])
