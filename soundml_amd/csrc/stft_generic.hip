@@ -483,6 +483,118 @@ bool launch_stockham_wide(const StftJob &job, const GenericArgs &a, const StftTa
   }
 }
 
+// ---- fft 512 / 1024, float32, power output: 16 frames per workgroup with NO separate stage ----------------------
+// The kernel above keeps a [bins][17] stage next to its work buffers, which leaves two 4-wave workgroups per CU at
+// fft 1024.  Here a workgroup owns 16 frames at once (16 x M/16 threads), and after the post-pass each frame's
+// |X|^p column goes back into that frame's own, now dead, work buffer (M + 1 floats in the room of M complex),
+// rotated by 2 f floats so that the flush -- 16 frames of one bin per 16 lanes -- reads 32 distinct banks per
+// half-wave.  LDS is the work buffers alone: 32 KB (fft 512, five workgroups per CU) / 64 KB (fft 1024, two
+// 8-wave workgroups).  Transforms are wave-private (at most 32 threads each): one workgroup barrier in all.
+template <int LOG2N, typename Tin>
+__global__ void __launch_bounds__(1 << (LOG2N - 1)) stft_stockham_power16_kernel(GenericArgs a, const float2 *tw_m, const float2 *tw_n) {
+  using namespace fftdev;
+  constexpr int N = 1 << LOG2N, LOG2M = LOG2N - 1, M = N / 2, T = M / 16, FT = 16;
+  static_assert(T <= 64, "wave-private transforms");
+  constexpr int RL = LastPass<LOG2M>::R, NSL = LastPass<LOG2M>::NS, GL = 16 / RL;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  float2 *work = reinterpret_cast<float2 *>(smem);                       // 16 buffers of M complex
+  const int64_t tiles = (a.count + FT - 1) / FT;
+  const int64_t clip = blockIdx.x / tiles, tile = blockIdx.x % tiles;
+  const Tin *x = reinterpret_cast<const Tin *>(a.x) + clip * a.x_stride;
+  const float *window = reinterpret_cast<const float *>(a.window);       // 0.5 * analysis window
+  const int tid = threadIdx.x % T, f = threadIdx.x / T;
+  float2 *z = work + (size_t)f * M;
+  const int64_t f0 = tile * FT;
+  const int nf = (int)((a.count - f0) < FT ? (a.count - f0) : FT);
+  const bool have = f < nf;                            // uniform per group of T threads
+  c32 r[16];
+  if (have) {
+    const int64_t s0 = (a.p0 + f0 + f) * a.hop - a.left;
+    if (s0 >= 0 && s0 + N <= a.n) {
+      const Tin *xs = x + s0;
+#pragma unroll
+      for (int m = 0; m < 16; ++m) {
+        const int i = 2 * (tid + T * m);
+        r[m] = {(float)xs[i] * window[i], (float)xs[i + 1] * window[i + 1]};
+      }
+    } else {
+#pragma unroll 1
+      for (int m = 0; m < 16; ++m) {
+        const int i = 2 * (tid + T * m);
+        const float v0 = (float)fetch_sample<Tin>(x, a.n, s0 + i, a.pad, a.pad_value) * window[i];
+        const float v1 = (float)fetch_sample<Tin>(x, a.n, s0 + i + 1, a.pad, a.pad_value) * window[i + 1];
+#pragma unroll
+        for (int mm = 0; mm < 16; ++mm)
+          if (mm == m) r[mm] = {v0, v1};
+      }
+    }
+  } else {
+#pragma unroll
+    for (int m = 0; m < 16; ++m) r[m] = {0.0f, 0.0f};
+  }
+  fft_passes<LOG2M, true, true>(r, z, tid, tw_m);
+#pragma unroll
+  for (int i = 0; i < GL; ++i)
+#pragma unroll
+    for (int j = 0; j < RL; ++j) z[swz(out_index<RL, NSL, T>(tid, i, j))] = make_float2(r[i * RL + j].x, r[i * RL + j].y);
+  stockham_sync<true>();
+  float val[16], nyq = 0.0f;
+#pragma unroll
+  for (int m = 0; m < 16; ++m) {
+    const int k = tid + T * m;
+    const float2 zk = z[swz(k)], zm = z[swz((M - k) & (M - 1))];
+    const float er = zk.x + zm.x, ei = zk.y - zm.y;
+    const float dr = zk.x - zm.x, di = zk.y + zm.y;
+    const float2 w = tw_n[k];
+    val[m] = magnitude_pow<float, float>(er + (w.x * di + w.y * dr), ei - (w.x * dr - w.y * di), a.power);
+  }
+  if (tid == 0) {
+    const float2 z0 = z[0];
+    nyq = magnitude_pow<float, float>(2.0f * (z0.x - z0.y), 0.0f, a.power);
+  }
+  stockham_sync<true>();   // every read of this frame's Z is done (the frame's threads share a wave): reuse its buffer
+  float *col = reinterpret_cast<float *>(z) + 2 * f;
+#pragma unroll
+  for (int m = 0; m < 16; ++m) col[tid + T * m] = val[m];
+  if (tid == 0) col[M] = nyq;
+  __syncthreads();
+  const int total = (M + 1) * nf;
+  const int64_t obase = clip * a.bins * a.out_stride + a.out_offset + f0;
+  float *out = reinterpret_cast<float *>(a.out);
+  const float *cols = reinterpret_cast<const float *>(work);
+  if (nf == FT) {   // a lane takes 4 frames of one bin: four conflict-free LDS reads, one 16-byte store (4-byte aligned)
+    using f32x4 = __attribute__((ext_vector_type(4))) float;
+    for (int e = threadIdx.x; e < (M + 1) * 4; e += blockDim.x) {
+      const int k = e >> 2, g = 4 * (e & 3);
+      const float *src = cols + g * (2 * M) + 2 * g + k;
+      const f32x4 v = {src[0], src[2 * M + 2], src[2 * (2 * M + 2)], src[3 * (2 * M + 2)]};
+      float *dst = out + obase + (int64_t)k * a.out_stride + g;
+      asm volatile("global_store_dwordx4 %0, %1, off" : : "v"(dst), "v"(v) : "memory");
+    }
+    return;
+  }
+  for (int e = threadIdx.x; e < total; e += blockDim.x) {   // a clip's ragged last tile
+    const int k = e / nf, g = e - k * nf;
+    out[obase + (int64_t)k * a.out_stride + g] = cols[g * (2 * M) + 2 * g + k];
+  }
+}
+
+template <int LOG2N>
+bool launch_stockham_power16(const StftJob &job, GenericArgs a, const StftTables &t) {
+  constexpr int M = (1 << LOG2N) / 2, THREADS = M;   // 16 frames x M/16 threads
+  if (!t.fast_window || !t.fast_w_m || !t.fast_w_n) return false;
+  a.window = t.fast_window;
+  const int64_t blocks = a.lead * ((a.count + 15) / 16);
+  if (blocks > 2147483647LL) throw Failure("stft: too many frame tiles for one launch");
+  const size_t lds = (size_t)16 * M * sizeof(float2);
+  auto kernel = stft_stockham_power16_kernel<LOG2N, float>;
+  SMX_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  hipLaunchKernelGGL(kernel, dim3((unsigned)blocks), dim3(THREADS), lds, job.stream, a, (const float2 *)t.fast_w_m,
+                     (const float2 *)t.fast_w_n);
+  SMX_HIP_CHECK(hipGetLastError());
+  return true;
+}
+
 // ---- any other size up to 8192, float32 interior: chirp-z (Bluestein) on the same Stockham passes ------------
 // X[k] = c_k sum_n (x[n] w[n] c_n) conj(c)_(k-n),  c_n = exp(-i pi n^2 / N): one circular convolution of length
 // M = 2^LOG2M >= 2 N - 1, i.e. FFT_M -> multiply by the filter's spectrum -> inverse FFT_M (as conj(FFT(conj .))),
@@ -655,7 +767,11 @@ void launch_stft_generic(const StftJob &job) {
     // forms sit at one 256-thread workgroup per CU (the stage fills the LDS) and the full-size one measured faster
     const char *cf = std::getenv("SMX_STOCKHAM_COMPLEX");   // diagnostic: force the full-size complex form
     const bool real_form = !(cf && cf[0] == '1') && c.fft_size <= 2048;
-    switch (c.fft_size) {
+    const char *sf = std::getenv("SMX_STOCKHAM_STAGED");   // diagnostic: the staged kernel for fft 512 / 1024 power too
+    const bool power16 = real_form && job.mode != OUT_COMPLEX && !(sf && sf[0] == '1');
+    if (power16 && c.fft_size == 512) done = launch_stockham_power16<9>(job, a, t);
+    if (power16 && c.fft_size == 1024) done = launch_stockham_power16<10>(job, a, t);
+    if (!done) switch (c.fft_size) {
       case 256: done = launch_stockham<8>(job, a); break;
       case 512: done = real_form ? launch_stockham_real<9, float, float, float>(job, a, t) : launch_stockham<9>(job, a); break;
       case 1024: done = real_form ? launch_stockham_real<10, float, float, float>(job, a, t) : launch_stockham<10>(job, a); break;
