@@ -67,6 +67,12 @@ struct StftTables {
   float2 *blu_filter = nullptr;    // FFT_M of exp(+i pi m^2 / N) (wrapped), times 1/M, natural order
   float2 *blu_tw = nullptr;        // exp(-2 pi i j / M), j < M/2
   int blu_log2m = 0;
+  // even sizes: chirp-z of length L = N/2 over (even, odd) sample pairs + the real-input post-pass
+  float2 *blu2_chirp = nullptr;    // exp(-i pi n^2 / L), n < L (input chirp and post factor)
+  float2 *blu2_filter = nullptr;   // FFT_M2 of exp(+i pi m^2 / L) (wrapped), times 1/M2
+  float2 *blu2_tw = nullptr;       // exp(-2 pi i j / M2), j < M2/2
+  float *blu2_window = nullptr;    // 0.5 * window, N entries
+  int blu2_log2m = 0;
   float2 *fast_synth_window = nullptr;   // (w[2j], -w[2j+1]) / (2M): synthesis window of the fast inverse kernel
 };
 

@@ -679,6 +679,136 @@ __global__ void __launch_bounds__((1 << LOG2M) / 16 < 256 ? 256 : (1 << LOG2M) /
   flush_stage<float>(a, stage, clip, f0, nf);
 }
 
+// Even N: z[i] = (x[2i], x[2i+1]) . half window, Z = DFT_L(z) (L = N/2) by chirp-z of length M >= 2 L - 1, then the
+// real-input post-pass X[k] = (Z[k] + conj Z[L-k]) - i W_N^k (Z[k] - conj Z[L-k]), X[L] = 2 (Re Z[0] - Im Z[0]):
+// a quarter of the convolution work of the kernel above (fft 400: two 512-point transforms instead of two 1024s).
+struct Blu2Args {
+  const float2 *chirp, *filter, *tw, *tw_n;
+};
+
+template <int LOG2M, typename Tin>
+__global__ void __launch_bounds__((1 << LOG2M) / 16 < 256 ? 256 : (1 << LOG2M) / 16) stft_bluestein_real_kernel(GenericArgs a, Blu2Args b) {
+  using namespace fftdev;
+  constexpr int M = 1 << LOG2M, T = M / 16, G = T < 256 ? 256 / T : 1;
+  constexpr bool WAVE = T <= 64;
+  constexpr int RL = LastPass<LOG2M>::R, NSL = LastPass<LOG2M>::NS, GL = 16 / RL;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  float2 *work = reinterpret_cast<float2 *>(smem);
+  unsigned char *stage = smem + (size_t)G * M * sizeof(float2);
+  const int ft = a.ft, sstride = ft + 1;
+  const int N = (int)a.fft, L = N / 2;
+  const int64_t tiles = (a.count + ft - 1) / ft;
+  const int64_t clip = blockIdx.x / tiles, tile = blockIdx.x % tiles;
+  const Tin *x = reinterpret_cast<const Tin *>(a.x) + clip * a.x_stride;
+  const float *window = reinterpret_cast<const float *>(a.window);       // 0.5 * analysis window
+  const int64_t bins = a.bins;
+  const int tid = threadIdx.x % T, grp = threadIdx.x / T;
+  float2 *z = work + (size_t)grp * M;
+  const int64_t f0 = tile * ft;
+  const int nf = (int)((a.count - f0) < ft ? (a.count - f0) : ft);
+  auto emit = [&](int f, int k, float re, float im) {
+    if (a.direct) {
+      const int64_t o = clip * bins * a.out_stride + a.out_offset + f0 + f + (int64_t)k * a.out_stride;
+      if (a.mode == OUT_COMPLEX) reinterpret_cast<float2 *>(a.out)[o] = make_float2(re, im);
+      else reinterpret_cast<float *>(a.out)[o] = magnitude_pow<float, float>(re, im, a.power);
+    } else if (a.mode == OUT_COMPLEX) {
+      reinterpret_cast<float2 *>(stage)[k * sstride + f] = make_float2(re, im);
+    } else {
+      reinterpret_cast<float *>(stage)[k * sstride + f] = magnitude_pow<float, float>(re, im, a.power);
+    }
+  };
+  for (int fb = 0; fb < nf; fb += G) {
+    const int f = fb + grp;
+    const bool have = f < nf;
+    c32 r[16];
+#pragma unroll
+    for (int m = 0; m < 16; ++m) r[m] = {0.0f, 0.0f};
+    if (have) {
+      const int64_t s0 = (a.p0 + f0 + f) * a.hop - a.left;
+      const bool inside = s0 >= 0 && s0 + N <= a.n;   // uniform per group: plain loads
+#pragma unroll
+      for (int m = 0; m < 16; ++m) {
+        const int i = tid + T * m;
+        if (i < L) {
+          const float v0 = inside ? (float)x[s0 + 2 * i] : (float)fetch_sample<Tin>(x, a.n, s0 + 2 * i, a.pad, a.pad_value);
+          const float v1 = inside ? (float)x[s0 + 2 * i + 1] : (float)fetch_sample<Tin>(x, a.n, s0 + 2 * i + 1, a.pad, a.pad_value);
+          const float2 c = b.chirp[i];
+          r[m] = cmul(c32{v0 * window[2 * i], v1 * window[2 * i + 1]}, c32{c.x, c.y});
+        }
+      }
+    }
+    fft_passes<LOG2M, true, WAVE>(r, z, tid, b.tw);
+    // product with the filter's spectrum (1/M folded in), conjugated for the inverse transform
+#pragma unroll
+    for (int i = 0; i < GL; ++i)
+#pragma unroll
+      for (int j = 0; j < RL; ++j) {
+        const int idx = out_index<RL, NSL, T>(tid, i, j);
+        const float2 h = b.filter[idx];
+        const c32 y = cmul(r[i * RL + j], c32{h.x, h.y});
+        z[swz(idx)] = make_float2(y.x, -y.y);
+      }
+    fft_passes<LOG2M, false, WAVE>(r, z, tid, b.tw);
+    // Z[k] = c_k conj(transform)[k], k < L, into the (now free) buffer in natural order
+#pragma unroll
+    for (int i = 0; i < GL; ++i)
+#pragma unroll
+      for (int j = 0; j < RL; ++j) {
+        const int k = out_index<RL, NSL, T>(tid, i, j);
+        if (k < L) {
+          const float2 c = b.chirp[k];
+          const c32 v = cmul(c32{r[i * RL + j].x, -r[i * RL + j].y}, c32{c.x, c.y});
+          z[swz(k)] = make_float2(v.x, v.y);
+        }
+      }
+    stockham_sync<WAVE>();
+    if (have) {
+#pragma unroll
+      for (int m = 0; m < 16; ++m) {
+        const int k = tid + T * m;
+        if (k < L) {
+          const float2 zk = z[swz(k)], zm = z[swz(k == 0 ? 0 : L - k)];
+          const float er = zk.x + zm.x, ei = zk.y - zm.y;
+          const float dr = zk.x - zm.x, di = zk.y + zm.y;
+          const float2 w = b.tw_n[k];                              // exp(-2 pi i k / N)
+          emit(f, k, er + (w.x * di + w.y * dr), ei - (w.x * dr - w.y * di));
+        }
+      }
+      if (tid == 0) {
+        const float2 z0 = z[0];
+        emit(f, L, 2.0f * (z0.x - z0.y), 0.0f);
+      }
+    }
+    __syncthreads();
+  }
+  if (a.direct) return;
+  flush_stage<float>(a, stage, clip, f0, nf);
+}
+
+template <int LOG2M>
+bool launch_bluestein_real(const StftJob &job, GenericArgs a, const StftTables &t) {
+  constexpr int M = 1 << LOG2M, T = M / 16, G = T < 256 ? 256 / T : 1, THREADS = T < 256 ? 256 : T;
+  const size_t elem_out = (job.mode == OUT_COMPLEX ? 2 : 1) * sizeof(float);
+  const size_t work = (size_t)G * M * sizeof(float2);
+  auto stage_bytes = [&](int ft) { return (size_t)a.bins * (size_t)(ft + 1) * elem_out + 16; };
+  int ft = 16;
+  while (ft > G && work + stage_bytes(ft) > kLdsLimit) ft >>= 1;
+  a.direct = work + stage_bytes(ft) > kLdsLimit ? 1 : 0;
+  if (a.direct) ft = G;
+  if (work > kLdsLimit) return false;
+  a.ft = ft;
+  a.window = t.blu2_window;
+  const Blu2Args b{t.blu2_chirp, t.blu2_filter, t.blu2_tw, (const float2 *)t.twiddle_f32};
+  const int64_t blocks = a.lead * ((a.count + ft - 1) / ft);
+  if (blocks > 2147483647LL) throw Failure("stft: too many frame tiles for one launch");
+  const size_t lds = a.direct ? work : work + stage_bytes(ft);
+  auto kernel = stft_bluestein_real_kernel<LOG2M, float>;
+  SMX_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  hipLaunchKernelGGL(kernel, dim3((unsigned)blocks), dim3(THREADS), lds, job.stream, a, b);
+  SMX_HIP_CHECK(hipGetLastError());
+  return true;
+}
+
 template <int LOG2M>
 bool launch_bluestein(const StftJob &job, GenericArgs a, const BluArgs &b) {
   constexpr int M = 1 << LOG2M, T = M / 16, G = T < 256 ? 256 / T : 1, THREADS = T < 256 ? 256 : T;
@@ -780,6 +910,18 @@ void launch_stft_generic(const StftJob &job) {
       case 8192: done = real_form ? launch_stockham_real<13, float, float, float>(job, a, t) : launch_stockham<13>(job, a); break;
       case 16384: done = real_form ? launch_stockham_real<14, float, float, float>(job, a, t) : launch_stockham<14>(job, a); break;
       default: break;
+    }
+    const char *bf = std::getenv("SMX_BLUESTEIN_FULL");   // diagnostic: the full-length chirp-z for even sizes too
+    if (!done && t.blu2_log2m >= 8 && !(bf && bf[0] == '1')) {   // even, not a power of two: half-length chirp-z
+      switch (t.blu2_log2m) {
+        case 8: done = launch_bluestein_real<8>(job, a, t); break;
+        case 9: done = launch_bluestein_real<9>(job, a, t); break;
+        case 10: done = launch_bluestein_real<10>(job, a, t); break;
+        case 11: done = launch_bluestein_real<11>(job, a, t); break;
+        case 12: done = launch_bluestein_real<12>(job, a, t); break;
+        case 13: done = launch_bluestein_real<13>(job, a, t); break;
+        default: break;
+      }
     }
     if (!done && t.blu_log2m >= 8) {   // not a power of two: chirp-z
       const BluArgs b{t.blu_chirp, t.blu_post, t.blu_filter, t.blu_tw};

@@ -109,6 +109,59 @@ const smx::StftTables &smx_stft_config::tables() const {
       t.blu_tw = smx::upload(tw);
       t.blu_log2m = log2m;
     }
+    // even sizes: the frame as ONE chirp-z transform of length L = N/2 over its (even, odd) sample pairs, then the
+    // real-input post-pass -- a quarter of the convolution work (fft 400: M = 512 instead of 1024)
+    if (n % 2 == 0 && n >= 4) {
+      const int64_t l = n / 2;
+      int log2m2 = 8;
+      while ((int64_t(1) << log2m2) < 2 * l - 1) ++log2m2;
+      if (log2m2 <= 14) {
+        const int64_t m = int64_t(1) << log2m2;
+        auto angle = [&](int64_t i) { return M_PI * (double)((i * i) % (2 * l)) / (double)l; };
+        std::vector<float2> chirp((size_t)l), tw((size_t)(m / 2));
+        std::vector<float> hw((size_t)n);
+        for (int64_t i = 0; i < n; ++i) hw[(size_t)i] = (float)(0.5 * analysis_window[(size_t)i]);
+        for (int64_t i = 0; i < l; ++i) chirp[(size_t)i] = make_float2((float)std::cos(angle(i)), (float)(-std::sin(angle(i))));
+        std::vector<double> re((size_t)m, 0.0), im((size_t)m, 0.0);
+        for (int64_t j = 0; j < l; ++j) {
+          re[(size_t)j] = std::cos(angle(j));
+          im[(size_t)j] = std::sin(angle(j));
+          if (j > 0) {
+            re[(size_t)(m - j)] = re[(size_t)j];
+            im[(size_t)(m - j)] = im[(size_t)j];
+          }
+        }
+        for (int64_t half = m >> 1; half >= 1; half >>= 1) {   // in-place float64 radix-2 DIF, bit-reversed output
+          const int64_t tstep = (m >> 1) / half;
+          for (int64_t b = 0; b < (m >> 1); ++b) {
+            const int64_t j = b & (half - 1);
+            const int64_t i0 = ((b - j) << 1) + j, i1 = i0 + half;
+            const double ang = -2.0 * M_PI * (double)(j * tstep) / (double)m;
+            const double wr = std::cos(ang), wi = std::sin(ang);
+            const double dr = re[(size_t)i0] - re[(size_t)i1], di = im[(size_t)i0] - im[(size_t)i1];
+            re[(size_t)i0] += re[(size_t)i1];
+            im[(size_t)i0] += im[(size_t)i1];
+            re[(size_t)i1] = dr * wr - di * wi;
+            im[(size_t)i1] = dr * wi + di * wr;
+          }
+        }
+        std::vector<float2> filt((size_t)m);
+        for (int64_t i = 0; i < m; ++i) {
+          unsigned k = 0;
+          for (int bit = 0; bit < log2m2; ++bit) k |= ((unsigned)(i >> bit) & 1u) << (log2m2 - 1 - bit);
+          filt[k] = make_float2((float)(re[(size_t)i] / (double)m), (float)(im[(size_t)i] / (double)m));
+        }
+        for (int64_t j = 0; j < m / 2; ++j) {
+          const double a = -2.0 * M_PI * (double)j / (double)m;
+          tw[(size_t)j] = make_float2((float)std::cos(a), (float)std::sin(a));
+        }
+        t.blu2_chirp = smx::upload(chirp);
+        t.blu2_filter = smx::upload(filt);
+        t.blu2_tw = smx::upload(tw);
+        t.blu2_window = smx::upload(hw);
+        t.blu2_log2m = log2m2;
+      }
+    }
   }
 
   // fast kernels (power-of-two N >= 64): half-scaled window and split tables
@@ -162,6 +215,10 @@ smx_stft_config::~smx_stft_config() {
     (void)hipFree(t.blu_post);
     (void)hipFree(t.blu_filter);
     (void)hipFree(t.blu_tw);
+    (void)hipFree(t.blu2_chirp);
+    (void)hipFree(t.blu2_filter);
+    (void)hipFree(t.blu2_tw);
+    (void)hipFree(t.blu2_window);
   }
 }
 
