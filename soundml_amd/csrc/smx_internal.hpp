@@ -280,6 +280,7 @@ struct MelSpecJob {
   const smx_mel_config *mel = nullptr;
   void *out = nullptr;           // device [lead; n_mels; count]
 };
-bool launch_mel_spectrogram_fused(const MelSpecJob &job);   // mel.hip; false = not eligible
+bool launch_mel_spectrogram_fused(const MelSpecJob &job);   // stft_fast.hip; false = not eligible
+bool launch_mel_spectrogram_16(const MelSpecJob &job);      // stft_generic.hip: fft 512 / 1024
 
 }  // namespace smx

@@ -1404,6 +1404,7 @@ bool launch_stft_fast(const StftJob &job) {
 }
 
 bool launch_mel_spectrogram_fused(const MelSpecJob &job) {
+  if (launch_mel_spectrogram_16(job)) return true;
   if (!fast_eligible(job.stft)) return false;
   if (job.stft.count <= 0 || job.stft.lead <= 0) return true;
   const MelFusedPlan &plan = job.mel->fused_plan();

@@ -490,8 +490,19 @@ bool launch_stockham_wide(const StftJob &job, const GenericArgs &a, const StftTa
 // rotated by 2 f floats so that the flush -- 16 frames of one bin per 16 lanes -- reads 32 distinct banks per
 // half-wave.  LDS is the work buffers alone: 32 KB (fft 512, five workgroups per CU) / 64 KB (fft 1024, two
 // 8-wave workgroups).  Transforms are wave-private (at most 32 threads each): one workgroup barrier in all.
-template <int LOG2N, typename Tin>
-__global__ void __launch_bounds__(1 << (LOG2N - 1)) stft_stockham_power16_kernel(GenericArgs a, const float2 *tw_m, const float2 *tw_n) {
+// MEL: the 16 power columns never leave the chip: W (banded, zero-padded float32 image of the float64 filterbank) x
+// columns on v_mfma_f32_16x16x4_f32, one 16-row tile of W per wave at a time over the tile's own band of bins, and
+// the [n_mels; 16 frames] block goes out as 64-byte row runs (Soundml.mel_spectrogram for fft 512 / 1024).
+struct MelTail {
+  const float *w;             // [n_mels_pad; k_pad]
+  const int *band_lo, *band_hi;
+  int n_mels, k_pad;
+  float *out;                 // [lead; n_mels; count]
+};
+
+template <int LOG2N, typename Tin, bool MEL>
+__global__ void __launch_bounds__(1 << (LOG2N - 1)) stft_stockham_power16_kernel(GenericArgs a, const float2 *tw_m, const float2 *tw_n,
+                                                                                 MelTail mt) {
   using namespace fftdev;
   constexpr int N = 1 << LOG2N, LOG2M = LOG2N - 1, M = N / 2, T = M / 16, FT = 16;
   static_assert(T <= 64, "wave-private transforms");
@@ -558,10 +569,59 @@ __global__ void __launch_bounds__(1 << (LOG2N - 1)) stft_stockham_power16_kernel
   for (int m = 0; m < 16; ++m) col[tid + T * m] = val[m];
   if (tid == 0) col[M] = nyq;
   __syncthreads();
+  const float *cols = reinterpret_cast<const float *>(work);
+  if constexpr (MEL) {
+    using f32x4 = __attribute__((ext_vector_type(4))) float;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
+    const int n = lane & 15, kk = lane >> 4;           // B[k = kk][n = frame], A[m = n][k = kk], D[4 kk + i][n]
+    const float *colb = cols + n * (2 * M) + 2 * n + kk;
+    for (int r0 = 16 * wave; r0 < mt.n_mels; r0 += 16 * nwaves) {
+      // bins any of the tile's 16 rows touches (rows without weights -- the padding -- do not count)
+      int lo = 0x7fffffff, hi = 0;
+      {
+        const int l = mt.band_lo[r0 + n], h = mt.band_hi[r0 + n];
+        if (h > l) {
+          lo = l;
+          hi = h;
+        }
+      }
+#pragma unroll
+      for (int d = 1; d < 16; d <<= 1) {
+        const int ol = __shfl_xor(lo, d), oh = __shfl_xor(hi, d);
+        lo = ol < lo ? ol : lo;
+        hi = oh > hi ? oh : hi;
+      }
+      lo = __builtin_amdgcn_readfirstlane(lo);
+      hi = __builtin_amdgcn_readfirstlane(hi);
+      f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+      const float *wa = mt.w + (int64_t)(r0 + n) * mt.k_pad + kk;
+      // four k-steps (16 bins) per trip, operands fetched first; the trips may run past the band: W is zero there
+      const int k_begin = lo & ~15;                          // 16-aligned trips never straddle the end of a padded row
+      int k_end = k_begin + (hi - k_begin + 15) / 16 * 16;
+      k_end = k_end < mt.k_pad ? k_end : mt.k_pad;          // k_pad is a multiple of 32
+      for (int k0 = k_begin; k0 < k_end; k0 += 16) {
+        float av[4], bv[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          av[j] = wa[k0 + 4 * j];
+          bv[j] = k0 + 4 * j + kk <= M ? colb[k0 + 4 * j] : 0.0f;   // past the Nyquist bin the column is not defined
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[j], bv[j], acc, 0, 0, 0);
+      }
+      if (n < nf) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int row = r0 + 4 * kk + i;
+          if (row < mt.n_mels) mt.out[(clip * mt.n_mels + row) * a.count + f0 + n] = acc[i];
+        }
+      }
+    }
+    return;
+  }
   const int total = (M + 1) * nf;
   const int64_t obase = clip * a.bins * a.out_stride + a.out_offset + f0;
   float *out = reinterpret_cast<float *>(a.out);
-  const float *cols = reinterpret_cast<const float *>(work);
   if (nf == FT) {   // a lane takes 4 frames of one bin: four conflict-free LDS reads, one 16-byte store (4-byte aligned)
     using f32x4 = __attribute__((ext_vector_type(4))) float;
     for (int e = threadIdx.x; e < (M + 1) * 4; e += blockDim.x) {
@@ -580,17 +640,24 @@ __global__ void __launch_bounds__(1 << (LOG2N - 1)) stft_stockham_power16_kernel
 }
 
 template <int LOG2N>
-bool launch_stockham_power16(const StftJob &job, GenericArgs a, const StftTables &t) {
+bool launch_stockham_power16(const StftJob &job, GenericArgs a, const StftTables &t, const MelTail *mel = nullptr) {
   constexpr int M = (1 << LOG2N) / 2, THREADS = M;   // 16 frames x M/16 threads
   if (!t.fast_window || !t.fast_w_m || !t.fast_w_n) return false;
   a.window = t.fast_window;
   const int64_t blocks = a.lead * ((a.count + 15) / 16);
   if (blocks > 2147483647LL) throw Failure("stft: too many frame tiles for one launch");
   const size_t lds = (size_t)16 * M * sizeof(float2);
-  auto kernel = stft_stockham_power16_kernel<LOG2N, float>;
-  SMX_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  hipLaunchKernelGGL(kernel, dim3((unsigned)blocks), dim3(THREADS), lds, job.stream, a, (const float2 *)t.fast_w_m,
-                     (const float2 *)t.fast_w_n);
+  if (mel) {
+    auto kernel = stft_stockham_power16_kernel<LOG2N, float, true>;
+    SMX_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(kernel, dim3((unsigned)blocks), dim3(THREADS), lds, job.stream, a, (const float2 *)t.fast_w_m,
+                       (const float2 *)t.fast_w_n, *mel);
+  } else {
+    auto kernel = stft_stockham_power16_kernel<LOG2N, float, false>;
+    SMX_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(kernel, dim3((unsigned)blocks), dim3(THREADS), lds, job.stream, a, (const float2 *)t.fast_w_m,
+                       (const float2 *)t.fast_w_n, MelTail{});
+  }
   SMX_HIP_CHECK(hipGetLastError());
   return true;
 }
@@ -865,6 +932,44 @@ void launch_typed(const StftJob &job, GenericArgs a) {
 }
 
 }  // namespace
+
+// Soundml.mel_spectrogram for fft 512 / 1024 (float32 audio and interior): framing, transform, |X|^p and the mel
+// product in one launch, the spectrogram never written.  false = not this geometry.
+bool launch_mel_spectrogram_16(const MelSpecJob &job) {
+  const StftJob &sj = job.stft;
+  const smx_stft_config &c = *sj.cfg;
+  if ((c.fft_size != 512 && c.fft_size != 1024) || sj.in_bytes != 4 || sj.interior == SMX_INTERIOR_F64 || sj.mode == OUT_COMPLEX ||
+      fast_path_disabled())
+    return false;
+  if (const char *e = std::getenv("SMX_MEL16_OFF"))
+    if (e[0] == '1') return false;
+  if (sj.count <= 0 || sj.lead <= 0) return true;
+  const StftTables &t = c.tables();
+  const smx_mel_config::Tables &mtab = job.mel->tables();
+  GenericArgs a{};
+  a.x = sj.x;
+  a.n = sj.n;
+  a.x_stride = sj.x_stride;
+  a.lead = sj.lead;
+  a.fft = c.fft_size;
+  a.hop = c.hop;
+  a.left = sj.left;
+  a.pad = sj.pad;
+  a.pad_value = sj.pad_value;
+  a.p0 = sj.p0;
+  a.count = sj.count;
+  a.mode = (int)sj.mode;
+  a.power = sj.power;
+  a.bins = c.bins();
+  MelTail mt{};
+  mt.w = mtab.w_f32;
+  mt.band_lo = mtab.band_lo;
+  mt.band_hi = mtab.band_hi;
+  mt.n_mels = (int)job.mel->n_mels;
+  mt.k_pad = (int)mtab.k_pad;
+  mt.out = reinterpret_cast<float *>(job.out);
+  return c.fft_size == 512 ? launch_stockham_power16<9>(sj, a, t, &mt) : launch_stockham_power16<10>(sj, a, t, &mt);
+}
 
 void launch_stft_generic(const StftJob &job) {
   if (job.count <= 0 || job.lead <= 0) return;

@@ -548,6 +548,37 @@ def test_fused_mel_spectrogram_vs_oracle(n_mels, sr, n, lead, power):
 
 
 
+@pytest.mark.parametrize("fft,hop,n_mels,sr,n,lead,power", [
+    (1024, 256, 80, 22050, 22050, 3, 2.0),      # the usual vocoder front end
+    (1024, 256, 128, 44100, 16 * 256 * 3 + 777, 2, 1.0),   # eight row tiles (one per wave), ragged last tile, magnitude
+    (512, 128, 40, 16000, 9000, 2, 2.0),        # four waves, three row tiles (one partly empty)
+    (512, 160, 13, 16000, 4000, 1, 2.0),        # a single partial row tile, hop that does not divide the size
+    (1024, 300, 136, 16000, 30000, 1, 2.0),     # nine row tiles over 8 waves
+])
+def test_fused_mel_spectrogram_512_1024(fft, hop, n_mels, sr, n, lead, power):
+    """Soundml.mel_spectrogram for fft 512 / 1024 (stft_stockham_power16_kernel<.., MEL>): the power columns stay in
+    LDS and meet the banded filterbank on the fp32 MFMA; against the oracle, against the unfused composition, slices
+    of a batch and the device-resident face bit for bit; dense caller-supplied weights through the same kernel."""
+    import torch
+    rng = np.random.default_rng(fft + n_mels + n)
+    x = rng.uniform(-1, 1, size=(lead, n)).astype(np.float32)
+    sc = Stft.Config.create(fft_size=fft, hop=hop)
+    mc = Mel.Config.create(n_mels=n_mels, sample_rate=sr, fft_size=fft)
+    got = S.mel_spectrogram(sc, mc, x, power)
+    want = O.mel_spectrogram(O.stft_config(fft, hop=hop), O.mel_config(n_mels, sr, fft), x, power)
+    assert got.shape == want.shape and got.dtype == np.float32
+    for i in range(lead):
+        check_fast(got[i], want[i], "mel clip %d" % i)
+        check_fast(Mel.apply(mc, Stft.power_spectrum(sc, x[i], power)), want[i], "composition clip %d" % i)
+    assert np.array_equal(got[0], S.mel_spectrogram(sc, mc, x[0], power))
+    assert np.array_equal(S.mel_spectrogram(sc, mc, torch.from_numpy(x).cuda(), power).cpu().numpy(), got)
+    w = np.abs(rng.standard_normal((12, fft // 2 + 1)))
+    dense = S.mel_spectrogram(sc, Mel.Config.from_weights(w, fft), x, power)
+    wd = np.einsum("mb,lbt->lmt", w, O.power_spectrum(O.stft_config(fft, hop=hop), x, power).astype(np.float64))
+    for i in range(lead):
+        check_fast(dense[i], wd[i], "dense weights clip %d" % i)
+
+
 def test_filterbank_from_weights():
     """Caller-supplied dense weights (the shape of Chroma.apply, chroma.ml:307: 12 rows over all bins) through the
     same entry points: W @ S in float64 for float64 spectrograms, the float32 MFMA kernel for float32 ones, and the
