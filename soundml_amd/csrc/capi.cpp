@@ -900,10 +900,13 @@ void griffin_lim_dev(const smx_stft_config &c, const void *d_s, int elem_bytes, 
     return;
   }
   const int z_bytes = 2 * elem_bytes;
-  auto synth = [&](const void *z, int has_len, int64_t len, void *out, int64_t olen) {
+  // S * angles: multiplied in by the fused synthesis kernel as it reads the spectrum, or materialised for the others
+  void *zbuf = nullptr;
+  const size_t cbytes = (size_t)std::max<int64_t>(total, 1) * (size_t)z_bytes;
+  auto synth = [&](const void *angles_in, int has_len, int64_t len, void *out, int64_t olen) {
     IstftJob job;
     job.cfg = &c;
-    job.z = z;
+    job.z = angles_in;
     job.z_bytes = z_bytes;
     job.interior = elem_bytes == 8 ? SMX_INTERIOR_F64 : g_interior.load();
     job.lead = lead;
@@ -912,12 +915,17 @@ void griffin_lim_dev(const smx_stft_config &c, const void *d_s, int elem_bytes, 
     job.out_len = olen;
     job.out = out;
     job.stream = stream;
+    if (istft_takes_factors(job)) {
+      job.mag = d_s;
+    } else {
+      if (!zbuf) SMX_HIP_CHECK(hipMallocAsync(&zbuf, cbytes, stream));
+      launch_gl_apply(d_s, angles_in, zbuf, total, elem_bytes, stream);
+      job.z = zbuf;
+    }
     launch_istft(job);
   };
-  void *angles = nullptr, *zbuf = nullptr, *rebuilt = nullptr, *previous = nullptr, *signal = nullptr;
-  const size_t cbytes = (size_t)std::max<int64_t>(total, 1) * (size_t)z_bytes;
+  void *angles = nullptr, *rebuilt = nullptr, *previous = nullptr, *signal = nullptr;
   SMX_HIP_CHECK(hipMallocAsync(&angles, cbytes, stream));
-  SMX_HIP_CHECK(hipMallocAsync(&zbuf, cbytes, stream));
   launch_gl_init(d_phase, angles, total, elem_bytes, stream);
   const bool iterate = natural > 0 && frames > 0;   // stft.ml:993-996
   if (iterate) {
@@ -927,16 +935,14 @@ void griffin_lim_dev(const smx_stft_config &c, const void *d_s, int elem_bytes, 
     const double beta = momentum / (1.0 + momentum);
     bool has_prev = false;
     for (int64_t k = 0; k < n_iter; ++k) {
-      launch_gl_apply(d_s, angles, zbuf, total, elem_bytes, stream);
-      synth(zbuf, 0, 0, signal, natural);
+      synth(angles, 0, 0, signal, natural);
       stft_range_dev(c, signal, elem_bytes, lead, natural, natural, 0, frames, OUT_COMPLEX, 0.0, rebuilt, stream);
       launch_gl_update(rebuilt, has_prev ? previous : nullptr, beta, angles, total, elem_bytes, stream);
       std::swap(rebuilt, previous);   // previous <- rebuilt
       has_prev = true;
     }
   }
-  launch_gl_apply(d_s, angles, zbuf, total, elem_bytes, stream);
-  synth(zbuf, has_length, length, d_out, out_len);
+  synth(angles, has_length, length, d_out, out_len);
   for (void *ptr : {angles, zbuf, rebuilt, previous, signal})
     if (ptr) SMX_HIP_CHECK(hipFreeAsync(ptr, stream));
 }

@@ -169,6 +169,7 @@ struct SynArgs {
   const double *env_head, *env_period, *env_tail;
   int64_t head, stop;
   int64_t blocks, per_xcd;   // per_xcd > 0: XCD-contiguous tile order over `blocks` tiles
+  const float *mag;          // optional [lead; bins; frames] factors of z (Griffin-Lim: magnitudes x unit phases)
 };
 
 __global__ void __launch_bounds__(1024) istft2048_kernel(SynArgs a) {
@@ -191,17 +192,44 @@ __global__ void __launch_bounds__(1024) istft2048_kernel(SynArgs a) {
   const int64_t f_lo = (int64_t)kSynHops * tile - 3;
   const float2 *z = a.z + clip * (int64_t)(kSynM + 1) * a.frames;
   swin[tid] = a.synth_window[tid];
-  // 1. stage: element e = (row, frame) with the frame fastest: 16 lanes read one 128-byte row piece
+  // 1. stage: element e = (row, frame) with the frame fastest: 16 lanes read one 128-byte row piece.  All loads of
+  // the thread are issued before the first use (the optional factors in their own batch: a branch inside the load
+  // loop would serialise them)
+  {
+    float2 v[17];
 #pragma unroll
-  for (int i = 0; i < 17; ++i) {
-    const int e = tid + 1024 * i;
-    const int row = e >> 4, f = e & 15;
-    if (row <= kSynM) {
-      const int64_t p = f_lo + f;
-      float2 v = make_float2(0.f, 0.f);
-      if (p >= 0 && p < a.count) v = z[(int64_t)row * a.frames + p];
-      re[row * kSynStride + f] = v.x;
-      im[row * kSynStride + f] = v.y;
+    for (int i = 0; i < 17; ++i) {
+      const int e = tid + 1024 * i;
+      const int row = e >> 4;
+      const int64_t p = f_lo + (e & 15);
+      v[i] = make_float2(0.f, 0.f);
+      if (row <= kSynM && p >= 0 && p < a.count) v[i] = z[(int64_t)row * a.frames + p];
+    }
+    if (a.mag) {   // uniform
+      const float *mg = a.mag + clip * (int64_t)(kSynM + 1) * a.frames;
+      float m[17];
+#pragma unroll
+      for (int i = 0; i < 17; ++i) {
+        const int e = tid + 1024 * i;
+        const int row = e >> 4;
+        const int64_t p = f_lo + (e & 15);
+        m[i] = 0.f;
+        if (row <= kSynM && p >= 0 && p < a.count) m[i] = mg[(int64_t)row * a.frames + p];
+      }
+#pragma unroll
+      for (int i = 0; i < 17; ++i) {
+        v[i].x *= m[i];
+        v[i].y *= m[i];
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < 17; ++i) {
+      const int e = tid + 1024 * i;
+      const int row = e >> 4, f = e & 15;
+      if (row <= kSynM) {
+        re[row * kSynStride + f] = v[i].x;
+        im[row * kSynStride + f] = v[i].y;
+      }
     }
   }
   __syncthreads();
@@ -300,8 +328,16 @@ void launch_frames(const IstftJob &job, IstftArgs a, hipStream_t stream) {
 
 }  // namespace
 
+// the fused kernel: fft 2048, hop 512, complex64 spectrum, float32 interior
+bool istft_takes_factors(const IstftJob &job) {
+  static const bool fast_off = std::getenv("SMX_DISABLE_FAST") != nullptr;
+  const bool f64 = job.z_bytes == 16 || job.interior == SMX_INTERIOR_F64;
+  return !fast_off && !f64 && job.cfg->fft_size == 2048 && job.cfg->hop == 512 && job.lead <= 0x7fffffff / 4096;
+}
+
 void launch_istft(const IstftJob &job) {
   const smx_stft_config &c = *job.cfg;
+  if (job.mag && !istft_takes_factors(job)) throw Failure("istft: factors are only taken by the fused kernel");
   if (job.lead <= 0 || job.out_len <= 0) return;
   const int64_t elem_out = job.z_bytes == 16 ? 8 : 4;
   if (job.count <= 0) {   // nothing reaches the output: zeros (stft.ml:922-924)
@@ -328,9 +364,9 @@ void launch_istft(const IstftJob &job) {
   SMX_HIP_CHECK(hipMemcpyAsync(d_env, packed.data(), packed.size() * sizeof(double), hipMemcpyHostToDevice, job.stream));
   SMX_HIP_CHECK(hipStreamSynchronize(job.stream));   // `packed` is pageable host memory that dies with this call
   // fused path: fft 2048, hop 512, complex64 spectrum, float32 interior
-  static const bool fast_off = std::getenv("SMX_DISABLE_FAST") != nullptr;
-  if (!fast_off && !f64 && fft == 2048 && hop == 512 && job.lead <= 0x7fffffff / 4096) {
+  if (istft_takes_factors(job)) {
     SynArgs sa{};
+    sa.mag = reinterpret_cast<const float *>(job.mag);
     sa.z = reinterpret_cast<const float2 *>(job.z);
     sa.out = reinterpret_cast<float *>(job.out);
     sa.frames = job.frames;

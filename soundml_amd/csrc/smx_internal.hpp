@@ -209,9 +209,13 @@ struct IstftJob {
   int64_t count = 0;             // frames that reach the output
   int64_t out_len = 0;
   void *out = nullptr;           // device [lead; out_len], float32 for complex64 input, float64 for complex128
+  // optional real factors [lead; bins; frames] (element type of z's components) multiplied into z as it is read:
+  // Griffin-Lim's S * angles without materialising the product.  Only where istft_takes_factors(job) says so.
+  const void *mag = nullptr;
   hipStream_t stream = nullptr;
 };
 void launch_istft(const IstftJob &job);           // istft.hip
+bool istft_takes_factors(const IstftJob &job);    // istft.hip: the fused fft-2048 / hop-512 kernel does
 
 // elementwise steps of Stft.griffin_lim (griffinlim.hip); elem_bytes 4 = float32 / complex64, 8 = float64 / complex128
 void launch_gl_widen(const float *src, double *dst, int64_t total, hipStream_t stream);    // float32 -> float64

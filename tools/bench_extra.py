@@ -106,6 +106,32 @@ print(json.dumps({"config": "C2 chroma (12 bands, inf norm)", "chroma_apply_ms":
                   "max_abs_err_vs_oracle": float(np.max(np.abs(out_ch[:2].cpu().numpy() - wc)))}))
 del p
 
+# other transform sizes (generic path): the usual vocoder front end (fft 1024 / hop 256, 80 mels, 22.05 kHz), fft 512,
+# whisper's fft 400 / hop 160, and the float64 interior at C2
+del x
+for fft, hop, n_mels, sr, n in ((1024, 256, 80, 22050, 441000), (512, 128, 80, 16000, 441000), (400, 160, 80, 16000, 160000)):
+    cs = Stft.Config.create(fft_size=fft, hop=hop)
+    ms_ = Mel.Config.create(n_mels=n_mels, sample_rate=sr, fft_size=fft)
+    fr = Stft.frames(cs, n)
+    xs_ = torch.rand(256, n, device="cuda") * 2 - 1
+    po = torch.empty(256, fft // 2 + 1, fr, device="cuda")
+    mo = torch.empty(256, n_mels, fr, device="cuda")
+    t_p, _ = timeit(lambda: check(lib.smx_stft_power_range_f32_dev(cs._h, vp(xs_.data_ptr()), 256, n, n, 0, fr, 2.0, vp(po.data_ptr()), None)), reps=10)
+    t_m, _ = timeit(lambda: check(lib.smx_mel_spectrogram_f32_dev(cs._h, ms_._h, vp(xs_.data_ptr()), 256, n, n, 2.0, vp(mo.data_ptr()), None)), reps=10)
+    wp = O.power_spectrum(O.stft_config(fft, hop=hop), xs_[:1, :20000].cpu().numpy())
+    gp = Stft.power_spectrum(cs, xs_[:1, :20000]).cpu().numpy()
+    print(json.dumps({"config": "fft %d hop %d, 256 clips x %d frames" % (fft, hop, fr), "power_ms": round(t_p, 4),
+                      "power_Mframes_per_s": round(256 * fr / t_p / 1e3, 1), "power_GBs_algorithmic": round(256 * fr * (hop + fft // 2 + 1) * 4 / t_p / 1e6, 1),
+                      "mel%d_ms" % n_mels: round(t_m, 4), "mel_Mframes_per_s": round(256 * fr / t_m / 1e3, 1), "max_rel_err_vs_oracle": rel_err(gp, wp)}))
+    del xs_, po, mo
+x = torch.rand(256, 480000, device="cuda") * 2 - 1
+out_p = torch.empty(256, 1025, frames, device="cuda")
+S.set_interior("float64")
+t_s, _ = timeit(lambda: check(lib.smx_stft_power_range_f32_dev(sc._h, vp(x.data_ptr()), 256, 480000, 480000, 0, frames, 2.0, vp(out_p.data_ptr()), None)), reps=5)
+S.set_interior("float32")
+print(json.dumps({"config": "C2 with the float64 interior (set_interior float64)", "power_ms": round(t_s, 4), "Mframes_per_s": round(256 * frames / t_s / 1e3, 1)}))
+del x, out_p
+
 # C4: 8192-tap lowpass on 8 ch x 60 s 48 kHz
 h = Fir.design_lowpass(8192, 0.25, 100.0)
 plan = Fir.Plan.create(h)
