@@ -155,6 +155,13 @@ int smx_stft_power_range_f64_dev(const smx_stft_config *c, const double *d_x, in
  * (0 = the reference's None).  frame_bound = stft.ml:1316-1317.               */
 int smx_stft_kernel_prepare(const smx_stft_config *c, int dtype_bytes, int64_t channels,
                             int64_t max_block, smx_stft_kernel **out);
+/* the same state machine emitting |spectrum|^power in the chunk's dtype ([channels; bins; capacity] real): the body
+ * of Stft.power_stage (stft.ml:1364-1409); stage_latency / frame_bound / stage_rate of stft.ml:1307-1348 are
+ * smx_stft_stage_latency, smx_stft_frame_bound and 1 / hop.                                                   */
+int smx_stft_kernel_prepare_power(const smx_stft_config *c, int dtype_bytes, int64_t channels, int64_t max_block,
+                                  double power, smx_stft_kernel **out);
+int64_t smx_stft_stage_latency(const smx_stft_config *c);                 /* stft.ml:1307-1308 */
+int64_t smx_stft_frame_bound(const smx_stft_config *c, int64_t max_items); /* stft.ml:1316-1317 */
 void smx_stft_kernel_destroy(smx_stft_kernel *k);
 int smx_stft_kernel_frame_bound(const smx_stft_kernel *k, int64_t *out);
 int smx_stft_kernel_step(smx_stft_kernel *k, const void *chunk /* host [channels; m] */, int64_t m,

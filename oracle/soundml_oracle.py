@@ -328,6 +328,19 @@ def power_spectrum(c: StftConfig, x: np.ndarray, power: float = 2.0) -> np.ndarr
 # Streaming kernel (stft.ml:366-622) -- restated for the partition law
 # ----------------------------------------------------------------------------
 
+def stage_latency(c: StftConfig) -> int:
+    """stft.ml:1307-1308: max (Config.latency c) (install_threshold c - 1); latency is fft/2 for `Centered, else 0
+    (stft.ml:144-145), install_threshold left + 1 under `Reflect, else 1 (stft.ml:447-452)."""
+    latency = c.fft_size // 2 if c.alignment == "centered" else 0
+    threshold = left_width(c) + 1 if c.pad == "reflect" else 1
+    return max(latency, threshold - 1)
+
+
+def frame_bound(c: StftConfig, b: int) -> int:
+    """stft.ml:1316-1317: ceil_div (b + stage_latency c) hop + 1."""
+    return -(-(b + stage_latency(c)) // c.hop) + 1
+
+
 class StreamKernel:
     """stft.ml:375-622: Mealy state machine that emits frames as chunks arrive.
     Chunks are [channels..., m]; ``step``/``flush`` return [..., bins, k] or None."""

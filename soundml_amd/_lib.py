@@ -119,6 +119,9 @@ SIGNATURES = {
     "smx_chroma_stft_f32": (cint, [vp, vp, vp, i64, i64, f64, cint, f64, vp]),
     "smx_chroma_stft_f64": (cint, [vp, vp, vp, i64, i64, f64, cint, f64, vp]),
     "smx_chroma_stft_f32_dev": (cint, [vp, vp, vp, i64, i64, i64, f64, cint, f64, vp, vp]),
+    "smx_stft_kernel_prepare_power": (cint, [vp, cint, i64, i64, f64, C.POINTER(vp)]),
+    "smx_stft_stage_latency": (i64, [vp]),
+    "smx_stft_frame_bound": (i64, [vp, i64]),
     "smx_stft_nola": (cint, [vp, C.POINTER(cint)]),
     "smx_stft_output_length": (cint, [vp, i64, pi64]),
     "smx_stft_invert_f32": (cint, [vp, vp, i64, i64, i64, cint, i64, vp]),

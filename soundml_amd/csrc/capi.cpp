@@ -417,6 +417,11 @@ struct smx_stft_kernel {
   int64_t pending_len = 0;
   void *d_out = nullptr;
   int64_t out_cap = 0;                  // frames
+  // what a step emits: the complex spectrum (Stft.Kernel / Stft.stage) or |.|^power of it in the chunk's dtype
+  // (Stft.power_stage, stft.ml:1364-1409)
+  OutMode mode = OUT_COMPLEX;
+  double power = 2.0;
+  int64_t values() const { return mode == OUT_COMPLEX ? 2 : 1; }   // scalars per emitted element
   ~smx_stft_kernel() {
     (void)hipFree(d_stream);
     (void)hipFree(d_out);
@@ -474,7 +479,7 @@ int64_t process(smx_stft_kernel &k, const unsigned char *extra, int64_t extra_le
     k.d_out = nullptr;
     int64_t cap = k.out_cap ? k.out_cap : 16;
     while (cap < count) cap *= 2;
-    SMX_HIP_CHECK(hipMalloc(&k.d_out, (size_t)k.channels * (size_t)bins * (size_t)cap * 2 * es));
+    SMX_HIP_CHECK(hipMalloc(&k.d_out, (size_t)k.channels * (size_t)bins * (size_t)cap * 2 * es));   // sized for either face
     k.out_cap = cap;
   }
   StftJob job;
@@ -490,14 +495,16 @@ int64_t process(smx_stft_kernel &k, const unsigned char *extra, int64_t extra_le
   job.pad_value = 0.0;
   job.p0 = 0;
   job.count = count;
-  job.mode = OUT_COMPLEX;
+  job.mode = k.mode;
+  job.power = k.power;
   job.out = k.d_out;
   job.out_stride = count;
   job.out_offset = 0;
   launch_stft(job);
   // [channels; bins; count] (dense) -> caller's [channels; bins; capacity] window
-  SMX_HIP_CHECK(hipMemcpy2D(out, (size_t)capacity * 2 * es, k.d_out, (size_t)count * 2 * es,
-                            (size_t)count * 2 * es, (size_t)(k.channels * bins), hipMemcpyDeviceToHost));
+  const size_t vs = (size_t)k.values() * es;
+  SMX_HIP_CHECK(hipMemcpy2D(out, (size_t)capacity * vs, k.d_out, (size_t)count * vs, (size_t)count * vs,
+                            (size_t)(k.channels * bins), hipMemcpyDeviceToHost));
   const int64_t next_start = count * hop;
   if (next_start >= total) {
     k.skip += next_start - total;
@@ -628,6 +635,24 @@ int smx_stft_kernel_prepare(const smx_stft_config *c, int dtype_bytes, int64_t c
     *out = k.release();
   });
 }
+
+int smx_stft_kernel_prepare_power(const smx_stft_config *c, int dtype_bytes, int64_t channels, int64_t max_block,
+                                  double power, smx_stft_kernel **out) {
+  const int status = smx_stft_kernel_prepare(c, dtype_bytes, channels, max_block, out);
+  if (status == SMX_OK) {
+    (*out)->mode = OUT_POWER;
+    (*out)->power = power;
+  }
+  return status;
+}
+
+int64_t smx_stft_stage_latency(const smx_stft_config *c) {   // max (Config.latency c) (install_threshold c - 1)
+  if (!c) return -1;
+  int64_t lat = c->alignment == SMX_ALIGN_CENTERED ? c->fft_size / 2 : 0;
+  if (c->pad == SMX_PAD_REFLECT && c->left_width() > lat) lat = c->left_width();
+  return lat;
+}
+int64_t smx_stft_frame_bound(const smx_stft_config *c, int64_t max_items) { return c ? frame_bound(*c, max_items) : -1; }
 
 void smx_stft_kernel_destroy(smx_stft_kernel *k) { delete k; }
 

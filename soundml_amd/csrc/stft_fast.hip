@@ -152,6 +152,9 @@ struct FastArgs {
 #define SMX_PRE 1
 #endif
 constexpr bool kPre = SMX_PRE != 0;   // power kernel: twiddle tables read one stage ahead
+#ifndef SMX_EPILOGUE_PRE
+#define SMX_EPILOGUE_PRE kPre
+#endif
 constexpr int kFT = 16;                         // frames per tile: one per wave, 16 waves per workgroup
 constexpr int kTileStride = kFT + 1;            // floats per tile row (pad column 16)
 // A tile holds bins 0..1023 as rows; bin 1024 (Nyquist) of frame f lives in the otherwise
@@ -770,7 +773,10 @@ __global__ void __launch_bounds__(1024) stft2048_power_kernel(FastArgs a) {
           braw[j] = make_float2(fetch_padded(xs, (int)a.n, s, a.pad, a.pad_value),
                                 fetch_padded(xs, (int)a.n, s + 1, a.pad, a.pad_value));
         }
-        frame_to_tile<SQUARE, false, false, false SMX_ABL_ZERO>(a, L, braw, bt_tile, wave, lane, NoHook{});
+        // the same PRE variant as the interior loop: with another instantiation the compiler contracts a few
+        // multiply-adds differently and a border frame would differ in the last bit from the same frame computed as
+        // an interior one (the streaming faces compute every frame as interior: partition law, stft_law.ml:79-164)
+        frame_to_tile<SQUARE, SMX_EPILOGUE_PRE, false, false SMX_ABL_ZERO>(a, L, braw, bt_tile, wave, lane, NoHook{});
       }
       __syncthreads();
       for (int e = tid; e < kBins * kFT; e += 1024) {

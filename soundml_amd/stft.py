@@ -331,6 +331,8 @@ class Kernel:
 
     def _emit(self, call, capacity):
         cdt = np.complex128 if self._dtype == np.float64 else np.complex64
+        if getattr(self, "_real", False):       # the power face of the state machine (power_stage)
+            cdt = self._dtype
         out = np.zeros((self._channels, self._cfg.bins, capacity), dtype=cdt)
         emitted = C.c_int64()
         check(call(C.c_void_p(out.ctypes.data), capacity, C.byref(emitted)))
@@ -357,3 +359,109 @@ class Kernel:
 
     def reset(self):
         check(lib.smx_stft_kernel_reset(self._h))
+
+
+# ---- Pipeline-stage faces (stft.ml:1301-1409) ---------------------------------------------------------------
+# The reference wraps the streaming state machine as Pipeline stages; the algebra of Pipeline itself is out of
+# scope here, but the numbers a stage declares and the step / flush / reset / concat bodies are these.
+
+def stage_latency(c: Config) -> int:
+    """``stage_latency`` (stft.ml:1307-1308): the geometric lookahead, or the reflected left border's reach."""
+    return int(lib.smx_stft_stage_latency(c._h))
+
+
+def stage_rate(c: Config):
+    """``stage_rate`` (stft.ml:1340): one frame per ``hop`` samples, as (num, den)."""
+    return (1, c.hop)
+
+
+def frame_bound(c: Config, max_items: int) -> int:
+    """``frame_bound c b`` (stft.ml:1316-1317): the most frames one step or drained tail can emit for chunks of at
+    most ``b`` samples."""
+    return int(lib.smx_stft_frame_bound(c._h, int(max_items)))
+
+
+class _Stage:
+    """A prepared stage: ``step`` returns a chunk or None, ``flush`` a list of chunks split at the threaded bound
+    (stft.ml:1322-1336), ``reset`` rewinds, ``concat`` joins chunks along the frame axis."""
+
+    def __init__(self, cfg, power, max_items):
+        self._cfg, self._power = cfg, power
+        self.latency = stage_latency(cfg)
+        self.rate = stage_rate(cfg)
+        self.bound = None if max_items is None else frame_bound(cfg, max_items)
+        self._max_items = max_items
+        self._k = None          # created at the first chunk: it fixes the element dtype and the channel count
+        self._dtype = None
+
+    def _kernel(self, a):
+        if self._k is None:
+            self._dtype = np.dtype(np.float64 if a.dtype == np.float64 else np.float32)
+            handle = C.c_void_p()
+            channels = int(np.prod(a.shape[:-1])) if a.ndim > 1 else 1
+            block = int(self._max_items) if self._max_items is not None else max(int(a.shape[-1]), 1)
+            if self._power is None:
+                check(lib.smx_stft_kernel_prepare(self._cfg._h, self._dtype.itemsize, channels, block, C.byref(handle)))
+            else:
+                check(lib.smx_stft_kernel_prepare_power(self._cfg._h, self._dtype.itemsize, channels, block,
+                                                        float(self._power), C.byref(handle)))
+            self._k = Kernel(handle, self._cfg, self._dtype, channels)
+            self._k._real = self._power is not None
+            self._lead = a.shape[:-1]
+        return self._k
+
+    def _shape(self, out):
+        return None if out is None else out.reshape(self._lead + out.shape[-2:])
+
+    def step(self, chunk):
+        a = np.asarray(chunk)
+        return self._shape(self._kernel(a).step(a))
+
+    def flush(self):
+        if self._k is None:
+            return []
+        out = self._shape(self._k.flush())
+        if out is None:
+            return []
+        if self.bound is None or out.shape[-1] <= self.bound:
+            return [out]
+        return [out[..., i:i + self.bound] for i in range(0, out.shape[-1], self.bound)]
+
+    def reset(self):
+        if self._k is not None:
+            self._k.reset()
+
+    def concat(self, parts):
+        if not parts:
+            if self._power is not None and self._dtype is None:
+                raise _lib.InvalidArgument("power_stage: cannot concatenate zero chunks before any chunk fixed the "
+                                           "element dtype")
+            dt = (np.complex128 if self._dtype == np.float64 else np.complex64) if self._power is None else self._dtype
+            return np.zeros((self._cfg.bins, 0), dtype=dt)
+        return np.concatenate(parts, axis=-1)
+
+
+class _StageFactory:
+    def __init__(self, cfg, power):
+        self._cfg, self._power = cfg, power
+        self.latency = stage_latency(cfg)
+        self.rate = stage_rate(cfg)
+
+    def prepare(self, max_items=None) -> _Stage:
+        """``~prepare`` of the stage: a fresh state; ``max_items`` is the input format's chunk bound (or None)."""
+        return _Stage(self._cfg, self._power, max_items)
+
+    def out_max_items(self, max_items):
+        """``stage_out_format``'s threaded bound (stft.ml:1318-1320, 1342-1348)."""
+        return None if max_items is None else frame_bound(self._cfg, max_items)
+
+
+def stage(c: Config) -> _StageFactory:
+    """``Stft.stage cdtype c`` (stft.ml:1350-1362): the complex spectrum, streaming."""
+    return _StageFactory(c, None)
+
+
+def power_stage(c: Config, power: float = 2.0) -> _StageFactory:
+    """``Stft.power_stage ?power c`` (stft.ml:1364-1409): |spectrum|^power in the chunks' dtype, streaming; the
+    magnitudes are taken on the device by the same kernels as ``power_spectrum``."""
+    return _StageFactory(c, float(power))

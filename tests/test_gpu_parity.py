@@ -597,6 +597,44 @@ def test_filterbank_from_weights():
     check_fast(S.mel_spectrogram(sc, bank, x), want, "chroma-like spectrogram")
 
 
+# ---- Pipeline-stage faces of the streaming kernel (stft.ml:1301-1409) -----------------------------------------------
+
+@pytest.mark.parametrize("fft,hop,alignment,pad", [(2048, 512, "centered", "reflect"), (64, 16, "right", "reflect"),
+                                                   (64, 100, "left", "edge"), (1024, 256, "centered", ("constant", 0.5))])
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_stage_and_power_stage_stream_the_offline_result(fft, hop, alignment, pad, dtype):
+    """Stft.stage / Stft.power_stage: whatever the chunking, the concatenated steps and flush chunks are the offline
+    transform / power_spectrum bit for bit (the partition law, stft_law.ml:79-164, through the stage bodies), every
+    emitted chunk honours the threaded frame bound, and reset rewinds."""
+    rng = np.random.default_rng(fft + hop)
+    n = 5 * fft + 3 * hop + 17
+    x = rng.standard_normal((2, n)).astype(dtype)
+    c = Stft.Config.create(fft_size=fft, hop=hop, alignment=alignment, pad=pad)
+    for factory, offline in ((Stft.stage(c), Stft.transform(c, x)), (Stft.power_stage(c, 1.0), Stft.power_spectrum(c, x, 1.0)),
+                             (Stft.power_stage(c), Stft.power_spectrum(c, x))):
+        for block in (n, 1000, 333):
+            st = factory.prepare(max_items=block)
+            assert st.latency == Stft.stage_latency(c) and st.bound == Stft.frame_bound(c, block)
+            for _ in range(2):                                   # second round after reset
+                parts = []
+                for i in range(0, n, block):
+                    out = st.step(x[:, i:i + block])
+                    if out is not None:
+                        assert out.shape[-1] <= st.bound
+                        parts.append(out)
+                tail = st.flush()
+                assert all(t.shape[-1] <= st.bound for t in tail)
+                got = st.concat(parts + tail)
+                assert got.dtype == offline.dtype and np.array_equal(got, offline)
+                st.reset()
+    fresh = Stft.power_stage(c).prepare()
+    assert fresh.flush() == []
+    with pytest.raises(S.InvalidArgument) as e:
+        fresh.concat([])
+    assert str(e.value) == "power_stage: cannot concatenate zero chunks before any chunk fixed the element dtype"
+    assert Stft.stage(c).prepare().concat([]).shape == (c.bins, 0)
+
+
 # ---- log-mel / MFCC tail -----------------------------------------------------------------------------------
 
 def test_mfcc_goldens():

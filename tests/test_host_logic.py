@@ -325,3 +325,18 @@ def test_spectral_parameter_messages():
         with pytest.raises(S.InvalidArgument) as e:
             call()
         assert str(e.value) == message
+
+
+def test_stage_numbers_match_the_oracle():
+    """stage_latency / frame_bound / stage_rate (stft.ml:1307-1340): integer exact, no device."""
+    import soundml_amd as S
+    from oracle import soundml_oracle as O
+    for fft, hop, alignment, pad in [(2048, 512, "centered", "reflect"), (64, 16, "right", "reflect"), (64, 16, "right", "edge"),
+                                     (31, 5, "left", "reflect"), (1024, 1500, "centered", ("constant", 0.0)), (16, 4, "centered", "edge")]:
+        c = S.Stft.Config.create(fft_size=fft, hop=hop, alignment=alignment, pad=pad)
+        o = O.stft_config(fft, hop=hop, alignment=alignment, pad=pad[0] if isinstance(pad, tuple) else pad)
+        assert S.Stft.stage_latency(c) == O.stage_latency(o)
+        assert S.Stft.stage_rate(c) == (1, hop)
+        for b in (1, 7, hop, 4096):
+            assert S.Stft.frame_bound(c, b) == O.frame_bound(o, b)
+        assert S.Stft.stage(c).out_max_items(None) is None and S.Stft.power_stage(c).out_max_items(100) == O.frame_bound(o, 100)
