@@ -17,7 +17,8 @@ from . import window as Window
 from . import fir as Fir
 from . import chroma as Chroma
 from .features import mel_spectrogram, mfcc, chroma_stft
-from .spectral import spectral_centroid, spectral_bandwidth, spectral_rolloff, spectral_flatness
+from .spectral import (spectral_centroid, spectral_bandwidth, spectral_rolloff, spectral_flatness,
+                       spectral_centroid_stage, spectral_bandwidth_stage, spectral_rolloff_stage, spectral_flatness_stage)
 from . import shard
 
 

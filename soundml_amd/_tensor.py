@@ -95,3 +95,23 @@ def prod(shape) -> int:
     for d in shape:
         n *= int(d)
     return n
+
+
+class Stateless:
+    """``Pipeline.stateless f`` (the memoryless stage of the reference): every chunk maps through ``f`` on its own;
+    nothing is withheld, so ``flush`` is empty and ``reset`` does nothing."""
+    latency = 0
+
+    def __init__(self, f):
+        self._f = f
+
+    def step(self, chunk):
+        return self._f(chunk)
+
+    __call__ = step
+
+    def flush(self):
+        return []
+
+    def reset(self):
+        pass

@@ -91,3 +91,9 @@ def apply(c: Config, s):
     fn = getattr(lib, "smx_mel_apply_%s" % sfx)
     check(fn(c._h, b.ptr(), lead, bins, frames, out_ptr(out)))
     return b.wrap(out)
+
+
+def stage(c: Config):
+    """``Mel.stage c`` (mel.ml:233): ``apply c`` as a memoryless Pipeline stage."""
+    from ._tensor import Stateless
+    return Stateless(lambda s: apply(c, s))

@@ -110,3 +110,65 @@ def spectral_flatness(s, amin: float = 1e-10, power: float = 2.0):
     b, lead_shape, bins, frames = _spectrogram(op, s)
     return _run(op, b, lead_shape, bins, frames, (lib.smx_spectral_flatness_f32, lib.smx_spectral_flatness_f64),
                 lib.smx_spectral_flatness_f32_dev, (float(amin), float(power)), ())
+
+
+# ---- memoryless Pipeline stages (spectral.ml:257-284): every chunk-independent parameter is validated where the
+# stage is built; the freqs / bins pairing and the non-negativity of the data are left to the first chunk ------------
+
+def _g(v: float) -> str:
+    return "%g" % v
+
+
+def _check_sample_rate(op, sample_rate):
+    if int(sample_rate) < 1:
+        raise _lib.InvalidArgument("%s: cannot use a sample rate of %d Hz (sample_rate must be at least 1)" % (op, int(sample_rate)))
+
+
+def _check_freqs_rank(op, freqs):
+    if freqs is not None and len(np.shape(freqs)) != 1:
+        raise _lib.InvalidArgument("%s: cannot use a rank-%d freqs tensor (freqs is rank-one, one frequency per bin)"
+                                   % (op, len(np.shape(freqs))))
+
+
+def _finite_positive(v) -> bool:
+    v = float(v)
+    return v > 0.0 and v != float("inf")
+
+
+def spectral_centroid_stage(sample_rate: int, freqs=None):
+    op = "spectral_centroid_stage"
+    _check_sample_rate(op, sample_rate)
+    _check_freqs_rank(op, freqs)
+    from ._tensor import Stateless
+    return Stateless(lambda s: spectral_centroid(s, sample_rate=sample_rate, freqs=freqs))
+
+
+def spectral_bandwidth_stage(sample_rate: int, p: float = 2.0, freqs=None):
+    op = "spectral_bandwidth_stage"
+    if not _finite_positive(p):
+        raise _lib.InvalidArgument("%s: cannot raise deviations to the power %s (p must be finite and positive)" % (op, _g(p)))
+    _check_sample_rate(op, sample_rate)
+    _check_freqs_rank(op, freqs)
+    from ._tensor import Stateless
+    return Stateless(lambda s: spectral_bandwidth(s, sample_rate=sample_rate, p=p, freqs=freqs))
+
+
+def spectral_rolloff_stage(sample_rate: int, roll_percent: float = 0.85, freqs=None):
+    op = "spectral_rolloff_stage"
+    if not (0.0 < float(roll_percent) < 1.0):
+        raise _lib.InvalidArgument("%s: cannot keep %s of the spectral energy (roll_percent must lie strictly between 0 "
+                                   "and 1)" % (op, _g(roll_percent)))
+    _check_sample_rate(op, sample_rate)
+    _check_freqs_rank(op, freqs)
+    from ._tensor import Stateless
+    return Stateless(lambda s: spectral_rolloff(s, sample_rate=sample_rate, roll_percent=roll_percent, freqs=freqs))
+
+
+def spectral_flatness_stage(amin: float = 1e-10, power: float = 2.0):
+    op = "spectral_flatness_stage"
+    if not _finite_positive(amin):
+        raise _lib.InvalidArgument("%s: cannot floor the spectrum at %s (amin must be finite and positive)" % (op, _g(amin)))
+    if not _finite_positive(power):
+        raise _lib.InvalidArgument("%s: cannot raise magnitudes to the power %s (power must be finite and positive)" % (op, _g(power)))
+    from ._tensor import Stateless
+    return Stateless(lambda s: spectral_flatness(s, amin=amin, power=power))

@@ -761,6 +761,22 @@ def test_spectral_vs_oracle(shape, dtype):
                                atol=atol * float(np.max(got)))
 
 
+def test_memoryless_stages_are_the_flat_functions():
+    """Mel.stage and the spectral *_stage constructors (mel.ml:233, spectral.ml:257-284): chunk by chunk they give
+    what the flat function gives on the chunk."""
+    rng = np.random.default_rng(3)
+    s = np.abs(rng.standard_normal((2, 257, 40))).astype(np.float32)
+    mc = Mel.Config.create(n_mels=20, sample_rate=16000, fft_size=512)
+    for st, fn in ((Mel.stage(mc), lambda a: Mel.apply(mc, a)),
+                   (S.spectral_centroid_stage(sample_rate=16000), lambda a: S.spectral_centroid(a, sample_rate=16000)),
+                   (S.spectral_bandwidth_stage(sample_rate=16000, p=3.0), lambda a: S.spectral_bandwidth(a, sample_rate=16000, p=3.0)),
+                   (S.spectral_rolloff_stage(sample_rate=16000, roll_percent=0.5), lambda a: S.spectral_rolloff(a, sample_rate=16000, roll_percent=0.5)),
+                   (S.spectral_flatness_stage(amin=1e-6), lambda a: S.spectral_flatness(a, amin=1e-6))):
+        for lo, hi in ((0, 13), (13, 40)):
+            assert np.array_equal(st.step(s[..., lo:hi]), fn(s[..., lo:hi]))
+        assert st.flush() == []
+
+
 def test_spectral_messages_and_edges():
     s = np.abs(np.random.default_rng(1).standard_normal((9, 12))).astype(np.float32)
     for fn, op in ((lambda a: S.spectral_centroid(a, sample_rate=22050), "spectral_centroid"),

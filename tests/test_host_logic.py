@@ -340,3 +340,20 @@ def test_stage_numbers_match_the_oracle():
         for b in (1, 7, hop, 4096):
             assert S.Stft.frame_bound(c, b) == O.frame_bound(o, b)
         assert S.Stft.stage(c).out_max_items(None) is None and S.Stft.power_stage(c).out_max_items(100) == O.frame_bound(o, 100)
+
+
+def test_stage_constructors_validate_where_they_are_built():
+    """spectral.ml:257-284: a misbuilt stage fails at construction, worded with the stage's own name."""
+    import soundml_amd as S
+    for call, message in [
+            (lambda: S.spectral_centroid_stage(sample_rate=0), "spectral_centroid_stage: cannot use a sample rate of 0 Hz (sample_rate must be at least 1)"),
+            (lambda: S.spectral_bandwidth_stage(sample_rate=8000, p=-1.0), "spectral_bandwidth_stage: cannot raise deviations to the power -1 (p must be finite and positive)"),
+            (lambda: S.spectral_rolloff_stage(sample_rate=8000, roll_percent=0.0), "spectral_rolloff_stage: cannot keep 0 of the spectral energy (roll_percent must lie strictly between 0 and 1)"),
+            (lambda: S.spectral_rolloff_stage(sample_rate=8000, freqs=np.ones((3, 3))), "spectral_rolloff_stage: cannot use a rank-2 freqs tensor (freqs is rank-one, one frequency per bin)"),
+            (lambda: S.spectral_flatness_stage(amin=float("nan")), "spectral_flatness_stage: cannot floor the spectrum at nan (amin must be finite and positive)"),
+            (lambda: S.spectral_flatness_stage(power=0.0), "spectral_flatness_stage: cannot raise magnitudes to the power 0 (power must be finite and positive)")]:
+        with pytest.raises(S.InvalidArgument) as e:
+            call()
+        assert str(e.value) == message
+    st = S.spectral_flatness_stage()
+    assert st.flush() == [] and st.latency == 0 and st.reset() is None
