@@ -348,21 +348,10 @@ void launch_istft(const IstftJob &job) {
   const bool f64 = job.z_bytes == 16 || job.interior == SMX_INTERIOR_F64;
   const int64_t fft = c.fft_size, hop = c.hop, count = job.count;
   const int64_t span = (count - 1) * hop + fft;
-  // envelope pieces (host, float64, the reference's summation order)
-  std::vector<double> head, period, tail;
-  int64_t head_n = 0, stop = 0;
-  stft_envelope(c, count, head, period, tail, head_n, stop);
-  const size_t env_doubles = head.size() + period.size() + tail.size();
-  double *d_env = nullptr;
-  SMX_HIP_CHECK(hipMallocAsync((void **)&d_env, (env_doubles + 1) * sizeof(double), job.stream));
-  std::vector<double> packed;
-  packed.reserve(env_doubles + 1);
-  packed.insert(packed.end(), head.begin(), head.end());
-  packed.insert(packed.end(), period.begin(), period.end());
-  packed.insert(packed.end(), tail.begin(), tail.end());
-  packed.push_back(1.0);
-  SMX_HIP_CHECK(hipMemcpyAsync(d_env, packed.data(), packed.size() * sizeof(double), hipMemcpyHostToDevice, job.stream));
-  SMX_HIP_CHECK(hipStreamSynchronize(job.stream));   // `packed` is pageable host memory that dies with this call
+  // envelope pieces: host float64 in the reference's summation order, cached on the device per (config, count)
+  const EnvelopeTable &env = c.envelope(count);
+  const double *d_env = env.dev;
+  const int64_t head_n = env.head_n, stop = env.stop;
   // fused path: fft 2048, hop 512, complex64 spectrum, float32 interior
   if (istft_takes_factors(job)) {
     SynArgs sa{};
@@ -382,8 +371,8 @@ void launch_istft(const IstftJob &job) {
     sa.w_n = t.fast_w_n;
     sa.synth_window = t.fast_synth_window;
     sa.env_head = d_env;
-    sa.env_period = d_env + head.size();
-    sa.env_tail = d_env + head.size() + period.size();
+    sa.env_period = d_env + env.head;
+    sa.env_tail = d_env + env.head + env.period;
     sa.head = head_n;
     sa.stop = stop;
     const int64_t blocks = job.lead * tiles;
@@ -396,7 +385,6 @@ void launch_istft(const IstftJob &job) {
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)kSynLds));
       hipLaunchKernelGGL(istft2048_kernel, dim3((unsigned)launched), dim3(1024), kSynLds, job.stream, sa);
       SMX_HIP_CHECK(hipGetLastError());
-      SMX_HIP_CHECK(hipFreeAsync(d_env, job.stream));
       return;
     }
   }
@@ -437,8 +425,8 @@ void launch_istft(const IstftJob &job) {
     oa.out_len = job.out_len;
     oa.span = span;
     oa.env_head = d_env;
-    oa.env_period = d_env + head.size();
-    oa.env_tail = d_env + head.size() + period.size();
+    oa.env_period = d_env + env.head;
+    oa.env_tail = d_env + env.head + env.period;
     oa.head = head_n;
     oa.stop = stop;
     dim3 grid((unsigned)((job.out_len + 255) / 256), (unsigned)nclips);
@@ -448,7 +436,6 @@ void launch_istft(const IstftJob &job) {
     SMX_HIP_CHECK(hipGetLastError());
   }
   SMX_HIP_CHECK(hipFreeAsync(d_y, job.stream));
-  SMX_HIP_CHECK(hipFreeAsync(d_env, job.stream));
 }
 
 }  // namespace smx

@@ -78,6 +78,15 @@ struct StftTables {
 
 }  // namespace smx
 
+namespace smx {
+// least-squares synthesis envelope of `count` frames (stft.ml:836-889) on the device: head | period | tail | 1.0
+struct EnvelopeTable {
+  double *dev = nullptr;
+  size_t head = 0, period = 0, tail = 0;   // doubles in each piece
+  int64_t head_n = 0, stop = 0;
+};
+}  // namespace smx
+
 // ---- opaque handle bodies (C ABI names) ----------------------------------------
 struct smx_stft_config {
   int64_t fft_size = 0, win_length = 0, hop = 0;
@@ -94,11 +103,15 @@ struct smx_stft_config {
   // lazily built device tables, keyed by HIP device ordinal; internally locked
   // (SURVEY 8b "Threading": a plan cache must be per-handle or locked).
   const smx::StftTables &tables() const;
+  // the envelope of a `count`-frame synthesis, built once per (device, count) on the host in float64 (the
+  // reference's summation order) and kept: repeated inversions of one geometry (Griffin-Lim) upload nothing
+  const smx::EnvelopeTable &envelope(int64_t count) const;   // tables.cpp
   ~smx_stft_config();
 
  private:
   mutable std::mutex mutex_;
   mutable std::map<int, smx::StftTables> tables_;
+  mutable std::map<std::pair<int, int64_t>, smx::EnvelopeTable> envelopes_;
 };
 
 namespace smx {

@@ -199,7 +199,35 @@ const smx::StftTables &smx_stft_config::tables() const {
   return tables_.emplace(device, t).first->second;
 }
 
+const smx::EnvelopeTable &smx_stft_config::envelope(int64_t count) const {
+  int device = 0;
+  SMX_HIP_CHECK(hipGetDevice(&device));
+  std::lock_guard<std::mutex> lock(mutex_);
+  const auto key = std::make_pair(device, count);
+  auto it = envelopes_.find(key);
+  if (it != envelopes_.end()) return it->second;
+  if (envelopes_.size() >= 64) {   // a caller cycling through many lengths: start over (hipFree waits for users)
+    for (auto &kv : envelopes_) (void)hipFree(kv.second.dev);
+    envelopes_.clear();
+  }
+  std::vector<double> head, period, tail;
+  smx::EnvelopeTable e;
+  smx::stft_envelope(*this, count, head, period, tail, e.head_n, e.stop);
+  std::vector<double> packed;
+  packed.reserve(head.size() + period.size() + tail.size() + 1);
+  packed.insert(packed.end(), head.begin(), head.end());
+  packed.insert(packed.end(), period.begin(), period.end());
+  packed.insert(packed.end(), tail.begin(), tail.end());
+  packed.push_back(1.0);
+  e.head = head.size();
+  e.period = period.size();
+  e.tail = tail.size();
+  e.dev = smx::upload(packed);
+  return envelopes_.emplace(key, e).first->second;
+}
+
 smx_stft_config::~smx_stft_config() {
+  for (auto &kv : envelopes_) (void)hipFree(kv.second.dev);
   for (auto &kv : tables_) {
     smx::StftTables &t = kv.second;
     (void)hipFree(t.window_f64);
