@@ -925,13 +925,12 @@ void griffin_lim_dev(const smx_stft_config &c, const void *d_s, int elem_bytes, 
     return;
   }
   const int z_bytes = 2 * elem_bytes;
-  // S * angles: multiplied in by the fused synthesis kernel as it reads the spectrum, or materialised for the others
   void *zbuf = nullptr;
   const size_t cbytes = (size_t)std::max<int64_t>(total, 1) * (size_t)z_bytes;
-  auto synth = [&](const void *angles_in, int has_len, int64_t len, void *out, int64_t olen) {
+  auto make_job = [&](const void *z, int has_len, int64_t len, void *out, int64_t olen) {
     IstftJob job;
     job.cfg = &c;
-    job.z = angles_in;
+    job.z = z;
     job.z_bytes = z_bytes;
     job.interior = elem_bytes == 8 ? SMX_INTERIOR_F64 : g_interior.load();
     job.lead = lead;
@@ -940,6 +939,11 @@ void griffin_lim_dev(const smx_stft_config &c, const void *d_s, int elem_bytes, 
     job.out_len = olen;
     job.out = out;
     job.stream = stream;
+    return job;
+  };
+  // S * angles: multiplied in by the fused synthesis kernel as it stages the spectrum, or materialised for the others
+  auto synth = [&](const void *angles_in, int has_len, int64_t len, void *out, int64_t olen) {
+    IstftJob job = make_job(angles_in, has_len, len, out, olen);
     if (istft_takes_factors(job)) {
       job.mag = d_s;
     } else {
@@ -953,21 +957,49 @@ void griffin_lim_dev(const smx_stft_config &c, const void *d_s, int elem_bytes, 
   SMX_HIP_CHECK(hipMallocAsync(&angles, cbytes, stream));
   launch_gl_init(d_phase, angles, total, elem_bytes, stream);
   const bool iterate = natural > 0 && frames > 0;   // stft.ml:993-996
-  if (iterate) {
+  const double beta = momentum / (1.0 + momentum);
+  const bool folded = iterate && istft_takes_factors(make_job(angles, 0, 0, nullptr, natural));
+  if (folded) {
+    // fused fft-2048 kernels: neither S * angles nor the angles themselves are materialised after the first pass --
+    // the synthesis kernel forms S * unit(c_k - beta c_(k-1)) from the two latest rebuilt spectra as it stages them
+    // (stft.ml:1003-1012), and the analysis of iteration k + 1 overwrites c_(k-1), which nothing reads any more
     SMX_HIP_CHECK(hipMallocAsync(&rebuilt, cbytes, stream));
     SMX_HIP_CHECK(hipMallocAsync(&previous, cbytes, stream));
     SMX_HIP_CHECK(hipMallocAsync(&signal, (size_t)lead * (size_t)natural * (size_t)elem_bytes, stream));
-    const double beta = momentum / (1.0 + momentum);
-    bool has_prev = false;
+    void *cur = nullptr, *old = nullptr;          // c_k, c_(k-1)
+    auto synth_unit = [&](int has_len, int64_t len, void *out, int64_t olen) {
+      IstftJob job = make_job(cur, has_len, len, out, olen);
+      job.mag = d_s;
+      job.unit = true;
+      job.prev = old;
+      job.beta = beta;
+      launch_istft(job);
+    };
     for (int64_t k = 0; k < n_iter; ++k) {
-      synth(angles, 0, 0, signal, natural);
-      stft_range_dev(c, signal, elem_bytes, lead, natural, natural, 0, frames, OUT_COMPLEX, 0.0, rebuilt, stream);
-      launch_gl_update(rebuilt, has_prev ? previous : nullptr, beta, angles, total, elem_bytes, stream);
-      std::swap(rebuilt, previous);   // previous <- rebuilt
-      has_prev = true;
+      if (!cur) synth(angles, 0, 0, signal, natural);
+      else synth_unit(0, 0, signal, natural);
+      void *target = !cur ? rebuilt : (old ? old : previous);
+      stft_range_dev(c, signal, elem_bytes, lead, natural, natural, 0, frames, OUT_COMPLEX, 0.0, target, stream);
+      old = cur;
+      cur = target;
     }
+    synth_unit(has_length, length, d_out, out_len);
+  } else {
+    if (iterate) {
+      SMX_HIP_CHECK(hipMallocAsync(&rebuilt, cbytes, stream));
+      SMX_HIP_CHECK(hipMallocAsync(&previous, cbytes, stream));
+      SMX_HIP_CHECK(hipMallocAsync(&signal, (size_t)lead * (size_t)natural * (size_t)elem_bytes, stream));
+      bool has_prev = false;
+      for (int64_t k = 0; k < n_iter; ++k) {
+        synth(angles, 0, 0, signal, natural);
+        stft_range_dev(c, signal, elem_bytes, lead, natural, natural, 0, frames, OUT_COMPLEX, 0.0, rebuilt, stream);
+        launch_gl_update(rebuilt, has_prev ? previous : nullptr, beta, angles, total, elem_bytes, stream);
+        std::swap(rebuilt, previous);   // previous <- rebuilt
+        has_prev = true;
+      }
+    }
+    synth(angles, has_length, length, d_out, out_len);
   }
-  synth(angles, has_length, length, d_out, out_len);
   for (void *ptr : {angles, zbuf, rebuilt, previous, signal})
     if (ptr) SMX_HIP_CHECK(hipFreeAsync(ptr, stream));
 }

@@ -11,7 +11,9 @@
 //                        stft.ml:806-831), divides by the envelope and trims / zero-extends.
 // No atomics: the sum is deterministic.  The envelope (partial sums on both borders, one period of the
 // folded squared window in between, stft.ml:836-889) is built on the host in float64 and uploaded.
+#include <cfloat>
 #include <cstdlib>
+#include <type_traits>
 
 #include "fft_device.hpp"
 #include "smx_internal.hpp"
@@ -170,6 +172,11 @@ struct SynArgs {
   int64_t head, stop;
   int64_t blocks, per_xcd;   // per_xcd > 0: XCD-contiguous tile order over `blocks` tiles
   const float *mag;          // optional [lead; bins; frames] factors of z (Griffin-Lim: magnitudes x unit phases)
+  // Griffin-Lim's phase update folded into the staging (stft.ml:1003-1012): with `unit`, z is the rebuilt spectrum
+  // c_k and what is inverted is mag * unit(c_k - beta * c_(k-1)), unit(e) = e / (|e| + min_float); prev may be null
+  const float2 *prev;
+  float beta;
+  int unit;
 };
 
 __global__ void __launch_bounds__(1024) istft2048_kernel(SynArgs a) {
@@ -195,42 +202,74 @@ __global__ void __launch_bounds__(1024) istft2048_kernel(SynArgs a) {
   // 1. stage: element e = (row, frame) with the frame fastest: 16 lanes read one 128-byte row piece.  All loads of
   // the thread are issued before the first use (the optional factors in their own batch: a branch inside the load
   // loop would serialise them)
-  {
-    float2 v[17];
+  auto stage_elements = [&](auto first, auto count) {   // elements [first, first + count) of this thread's 17
+    constexpr int I0 = decltype(first)::value, NI = decltype(count)::value;
+    float2 v[NI];
 #pragma unroll
-    for (int i = 0; i < 17; ++i) {
-      const int e = tid + 1024 * i;
+    for (int j = 0; j < NI; ++j) {
+      const int e = tid + 1024 * (I0 + j);
       const int row = e >> 4;
       const int64_t p = f_lo + (e & 15);
-      v[i] = make_float2(0.f, 0.f);
-      if (row <= kSynM && p >= 0 && p < a.count) v[i] = z[(int64_t)row * a.frames + p];
+      v[j] = make_float2(0.f, 0.f);
+      if (row <= kSynM && p >= 0 && p < a.count) v[j] = z[(int64_t)row * a.frames + p];
+    }
+    if (a.unit) {   // uniform: v is c_k; form unit(c_k - beta c_(k-1)) as the update kernel does
+      if (a.prev) {
+        const float2 *pv = a.prev + clip * (int64_t)(kSynM + 1) * a.frames;
+        float2 q[NI];
+#pragma unroll
+        for (int j = 0; j < NI; ++j) {
+          const int e = tid + 1024 * (I0 + j);
+          const int row = e >> 4;
+          const int64_t p = f_lo + (e & 15);
+          q[j] = make_float2(0.f, 0.f);
+          if (row <= kSynM && p >= 0 && p < a.count) q[j] = pv[(int64_t)row * a.frames + p];
+        }
+#pragma unroll
+        for (int j = 0; j < NI; ++j) {
+          v[j].x -= a.beta * q[j].x;
+          v[j].y -= a.beta * q[j].y;
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < NI; ++j) {
+        const float m = (float)hypot((double)v[j].x, (double)v[j].y) + FLT_MIN;
+        v[j].x /= m;
+        v[j].y /= m;
+      }
     }
     if (a.mag) {   // uniform
       const float *mg = a.mag + clip * (int64_t)(kSynM + 1) * a.frames;
-      float m[17];
+      float m[NI];
 #pragma unroll
-      for (int i = 0; i < 17; ++i) {
-        const int e = tid + 1024 * i;
+      for (int j = 0; j < NI; ++j) {
+        const int e = tid + 1024 * (I0 + j);
         const int row = e >> 4;
         const int64_t p = f_lo + (e & 15);
-        m[i] = 0.f;
-        if (row <= kSynM && p >= 0 && p < a.count) m[i] = mg[(int64_t)row * a.frames + p];
+        m[j] = 0.f;
+        if (row <= kSynM && p >= 0 && p < a.count) m[j] = mg[(int64_t)row * a.frames + p];
       }
 #pragma unroll
-      for (int i = 0; i < 17; ++i) {
-        v[i].x *= m[i];
-        v[i].y *= m[i];
+      for (int j = 0; j < NI; ++j) {
+        v[j].x *= m[j];
+        v[j].y *= m[j];
       }
     }
 #pragma unroll
-    for (int i = 0; i < 17; ++i) {
-      const int e = tid + 1024 * i;
+    for (int j = 0; j < NI; ++j) {
+      const int e = tid + 1024 * (I0 + j);
       const int row = e >> 4, f = e & 15;
       if (row <= kSynM) {
-        re[row * kSynStride + f] = v[i].x;
-        im[row * kSynStride + f] = v[i].y;
+        re[row * kSynStride + f] = v[j].x;
+        im[row * kSynStride + f] = v[j].y;
       }
     }
+  };
+  if (a.unit) {   // three load streams: two batches keep the registers in budget
+    stage_elements(std::integral_constant<int, 0>{}, std::integral_constant<int, 9>{});
+    stage_elements(std::integral_constant<int, 9>{}, std::integral_constant<int, 8>{});
+  } else {
+    stage_elements(std::integral_constant<int, 0>{}, std::integral_constant<int, 17>{});
   }
   __syncthreads();
   // 2. half-size spectrum of frame `wave`, conjugated for the conj(FFT(conj .)) inverse
@@ -356,6 +395,9 @@ void launch_istft(const IstftJob &job) {
   if (istft_takes_factors(job)) {
     SynArgs sa{};
     sa.mag = reinterpret_cast<const float *>(job.mag);
+    sa.unit = job.unit ? 1 : 0;
+    sa.prev = reinterpret_cast<const float2 *>(job.prev);
+    sa.beta = (float)job.beta;
     sa.z = reinterpret_cast<const float2 *>(job.z);
     sa.out = reinterpret_cast<float *>(job.out);
     sa.frames = job.frames;

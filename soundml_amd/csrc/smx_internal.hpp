@@ -225,6 +225,11 @@ struct IstftJob {
   // optional real factors [lead; bins; frames] (element type of z's components) multiplied into z as it is read:
   // Griffin-Lim's S * angles without materialising the product.  Only where istft_takes_factors(job) says so.
   const void *mag = nullptr;
+  // with `unit` (same condition): z is Griffin-Lim's rebuilt spectrum c_k and the kernel inverts
+  // mag * unit(c_k - beta * prev) -- the phase update of stft.ml:1003-1012 folded into the staging; prev may be null
+  bool unit = false;
+  const void *prev = nullptr;
+  double beta = 0.0;
   hipStream_t stream = nullptr;
 };
 void launch_istft(const IstftJob &job);           // istft.hip

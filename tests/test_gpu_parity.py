@@ -487,6 +487,31 @@ def test_griffin_lim_fast_path_and_messages():
     assert str(e.value).startswith("griffin_lim: cannot start from a [1; 1025; 40] phase for a [2; 1025; 40] spectrogram")
 
 
+@pytest.mark.parametrize("n_iter,momentum,length", [(1, 0.99, None), (2, 0.99, 17000), (3, 0.0, None), (5, 0.5, 23456)])
+def test_griffin_lim_folded_update_short_runs(n_iter, momentum, length):
+    """The fused loop never materialises S * angles nor the angles (the synthesis kernel forms S * unit(c_k - beta
+    c_(k-1)) while it stages the spectrum): one iteration (no previous spectrum at the end), two (none inside), zero
+    momentum, and an explicit output length, against the oracle and against the unfused loop
+    (SMX_DISABLE_FAST is read at load time, so the float64 interior stands in: the same loop, materialised)."""
+    rng = np.random.default_rng(n_iter)
+    x = rng.uniform(-1, 1, size=(2, 20000)).astype(np.float32)
+    c = Stft.Config.create(fft_size=2048, hop=512)
+    o = O.stft_config(2048, hop=512)
+    mag = np.abs(Stft.transform(c, x)).astype(np.float32)
+    want = O.griffin_lim(o, mag, n_iter, momentum, None, length)
+    got = Stft.griffin_lim(c, mag, n_iter=n_iter, momentum=momentum, length=length)
+    assert got.shape == want.shape and got.dtype == np.float32
+    peak = np.max(np.abs(want))
+    assert np.max(np.abs(got - want)[:, 2048:-2048]) < 2e-4 * peak
+    assert np.linalg.norm(got - want) < 1e-3 * np.linalg.norm(want)
+    S.set_interior("float64")
+    try:
+        strict = Stft.griffin_lim(c, mag, n_iter=n_iter, momentum=momentum, length=length)
+    finally:
+        S.set_interior("float32")
+    np.testing.assert_allclose(strict, want, rtol=1e-5, atol=1e-6 * peak)
+
+
 # ---- Mel -------------------------------------------------------------------------------------------
 
 @pytest.mark.parametrize("n_mels,sr,fft,frames,lead", [(128, 48000, 2048, 938, 2), (40, 22050, 512, 77, 3),
