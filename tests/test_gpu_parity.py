@@ -604,6 +604,28 @@ def test_fused_mel_spectrogram_512_1024(fft, hop, n_mels, sr, n, lead, power):
         check_fast(dense[i], wd[i], "dense weights clip %d" % i)
 
 
+@pytest.mark.parametrize("fft", [512, 1024])
+@pytest.mark.parametrize("alignment,pad", [("centered", "reflect"), ("left", "edge"), ("right", ("constant", 0.25)), ("right", "reflect")])
+def test_sixteen_frame_kernels_on_short_and_odd_inputs(fft, alignment, pad):
+    """The stage-free 16-frame kernels (fft 512 / 1024 power and mel) where every frame is a border frame: signals
+    shorter than the window, a single sample, hops larger than the size, every alignment and pad mode."""
+    rng = np.random.default_rng(fft)
+    mc = Mel.Config.create(n_mels=24, sample_rate=16000, fft_size=fft)
+    om = O.mel_config(24, 16000, fft)
+    for n, hop in ((1, 7), (fft // 3, fft // 4), (fft + 1, 3 * fft), (5 * fft + 11, fft // 4 + 1)):
+        x = rng.uniform(-1, 1, size=(2, n)).astype(np.float32)
+        c = Stft.Config.create(fft_size=fft, hop=hop, alignment=alignment, pad=pad)
+        o = (O.stft_config(fft, hop=hop, alignment=alignment, pad=pad[0], pad_value=pad[1]) if isinstance(pad, tuple)
+             else O.stft_config(fft, hop=hop, alignment=alignment, pad=pad))
+        want = O.power_spectrum(o, x)
+        got = Stft.power_spectrum(c, x)
+        assert got.shape == want.shape
+        if want.size:
+            for i in range(2):
+                check_fast(got[i], want[i], "power n=%d hop=%d" % (n, hop))
+                check_fast(S.mel_spectrogram(c, mc, x)[i], O.mel_spectrogram(o, om, x)[i], "mel n=%d hop=%d" % (n, hop))
+
+
 def test_filterbank_from_weights():
     """Caller-supplied dense weights (the shape of Chroma.apply, chroma.ml:307: 12 rows over all bins) through the
     same entry points: W @ S in float64 for float64 spectrograms, the float32 MFMA kernel for float32 ones, and the
