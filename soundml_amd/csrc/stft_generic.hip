@@ -500,12 +500,13 @@ struct MelTail {
   float *out;                 // [lead; n_mels; count]
 };
 
-template <int LOG2N, typename Tin, bool MEL>
-__global__ void __launch_bounds__(1 << (LOG2N - 1)) stft_stockham_power16_kernel(GenericArgs a, const float2 *tw_m, const float2 *tw_n,
+template <int LOG2N, typename Tin, bool MEL, int FT>
+__global__ void __launch_bounds__(FT * ((1 << LOG2N) / 32)) stft_stockham_power16_kernel(GenericArgs a, const float2 *tw_m, const float2 *tw_n,
                                                                                  MelTail mt) {
   using namespace fftdev;
-  constexpr int N = 1 << LOG2N, LOG2M = LOG2N - 1, M = N / 2, T = M / 16, FT = 16;
-  static_assert(T <= 64, "wave-private transforms");
+  constexpr int N = 1 << LOG2N, LOG2M = LOG2N - 1, M = N / 2, T = M / 16;
+  constexpr bool WAVE = T <= 64;   // wave-private transforms (fft 512 / 1024 / 2048); fft 4096 synchronises its 128 threads
+  static_assert(FT == 16 || FT == 8 || FT == 4, "16 frames per workgroup, 8 at fft 4096, 4 at fft 8192");
   constexpr int RL = LastPass<LOG2M>::R, NSL = LastPass<LOG2M>::NS, GL = 16 / RL;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   float2 *work = reinterpret_cast<float2 *>(smem);                       // 16 buffers of M complex
@@ -543,12 +544,12 @@ __global__ void __launch_bounds__(1 << (LOG2N - 1)) stft_stockham_power16_kernel
 #pragma unroll
     for (int m = 0; m < 16; ++m) r[m] = {0.0f, 0.0f};
   }
-  fft_passes<LOG2M, true, true>(r, z, tid, tw_m);
+  fft_passes<LOG2M, true, WAVE>(r, z, tid, tw_m);
 #pragma unroll
   for (int i = 0; i < GL; ++i)
 #pragma unroll
     for (int j = 0; j < RL; ++j) z[swz(out_index<RL, NSL, T>(tid, i, j))] = make_float2(r[i * RL + j].x, r[i * RL + j].y);
-  stockham_sync<true>();
+  stockham_sync<WAVE>();
   float val[16], nyq = 0.0f;
 #pragma unroll
   for (int m = 0; m < 16; ++m) {
@@ -563,7 +564,7 @@ __global__ void __launch_bounds__(1 << (LOG2N - 1)) stft_stockham_power16_kernel
     const float2 z0 = z[0];
     nyq = magnitude_pow<float, float>(2.0f * (z0.x - z0.y), 0.0f, a.power);
   }
-  stockham_sync<true>();   // every read of this frame's Z is done (the frame's threads share a wave): reuse its buffer
+  stockham_sync<WAVE>();   // every read of this frame's Z is done (the frame's threads share a wave, or a barrier): reuse its buffer
   float *col = reinterpret_cast<float *>(z) + 2 * f;
 #pragma unroll
   for (int m = 0; m < 16; ++m) col[tid + T * m] = val[m];
@@ -571,6 +572,7 @@ __global__ void __launch_bounds__(1 << (LOG2N - 1)) stft_stockham_power16_kernel
   __syncthreads();
   const float *cols = reinterpret_cast<const float *>(work);
   if constexpr (MEL) {
+    static_assert(!MEL || FT == 16, "the MFMA tile is 16 frames wide");
     using f32x4 = __attribute__((ext_vector_type(4))) float;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
     const int n = lane & 15, kk = lane >> 4;           // B[k = kk][n = frame], A[m = n][k = kk], D[4 kk + i][n]
@@ -624,8 +626,9 @@ __global__ void __launch_bounds__(1 << (LOG2N - 1)) stft_stockham_power16_kernel
   float *out = reinterpret_cast<float *>(a.out);
   if (nf == FT) {   // a lane takes 4 frames of one bin: four conflict-free LDS reads, one 16-byte store (4-byte aligned)
     using f32x4 = __attribute__((ext_vector_type(4))) float;
-    for (int e = threadIdx.x; e < (M + 1) * 4; e += blockDim.x) {
-      const int k = e >> 2, g = 4 * (e & 3);
+    constexpr int QF = FT / 4;                           // frame quads per bin
+    for (int e = threadIdx.x; e < (M + 1) * QF; e += blockDim.x) {
+      const int k = e / QF, g = 4 * (e % QF);
       const float *src = cols + g * (2 * M) + 2 * g + k;
       const f32x4 v = {src[0], src[2 * M + 2], src[2 * (2 * M + 2)], src[3 * (2 * M + 2)]};
       float *dst = out + obase + (int64_t)k * a.out_stride + g;
@@ -639,25 +642,29 @@ __global__ void __launch_bounds__(1 << (LOG2N - 1)) stft_stockham_power16_kernel
   }
 }
 
-template <int LOG2N>
+template <int LOG2N, int FT = 16>
 bool launch_stockham_power16(const StftJob &job, GenericArgs a, const StftTables &t, const MelTail *mel = nullptr) {
-  constexpr int M = (1 << LOG2N) / 2, THREADS = M;   // 16 frames x M/16 threads
+  constexpr int M = (1 << LOG2N) / 2, THREADS = FT * (M / 16);   // FT frames x M/16 threads
   if (!t.fast_window || !t.fast_w_m || !t.fast_w_n) return false;
   a.window = t.fast_window;
-  const int64_t blocks = a.lead * ((a.count + 15) / 16);
+  const int64_t blocks = a.lead * ((a.count + FT - 1) / FT);
   if (blocks > 2147483647LL) throw Failure("stft: too many frame tiles for one launch");
-  const size_t lds = (size_t)16 * M * sizeof(float2);
-  if (mel) {
-    auto kernel = stft_stockham_power16_kernel<LOG2N, float, true>;
-    SMX_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(kernel, dim3((unsigned)blocks), dim3(THREADS), lds, job.stream, a, (const float2 *)t.fast_w_m,
-                       (const float2 *)t.fast_w_n, *mel);
-  } else {
-    auto kernel = stft_stockham_power16_kernel<LOG2N, float, false>;
-    SMX_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(kernel, dim3((unsigned)blocks), dim3(THREADS), lds, job.stream, a, (const float2 *)t.fast_w_m,
-                       (const float2 *)t.fast_w_n, MelTail{});
+  const size_t lds = (size_t)FT * M * sizeof(float2);
+  if constexpr (FT == 16) {
+    if (mel) {
+      auto kernel = stft_stockham_power16_kernel<LOG2N, float, true, 16>;
+      SMX_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      hipLaunchKernelGGL(kernel, dim3((unsigned)blocks), dim3(THREADS), lds, job.stream, a, (const float2 *)t.fast_w_m,
+                         (const float2 *)t.fast_w_n, *mel);
+      SMX_HIP_CHECK(hipGetLastError());
+      return true;
+    }
   }
+  if (mel) return false;
+  auto kernel = stft_stockham_power16_kernel<LOG2N, float, false, FT>;
+  SMX_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  hipLaunchKernelGGL(kernel, dim3((unsigned)blocks), dim3(THREADS), lds, job.stream, a, (const float2 *)t.fast_w_m,
+                     (const float2 *)t.fast_w_n, MelTail{});
   SMX_HIP_CHECK(hipGetLastError());
   return true;
 }
@@ -1006,6 +1013,9 @@ void launch_stft_generic(const StftJob &job) {
     const bool power16 = real_form && job.mode != OUT_COMPLEX && !(sf && sf[0] == '1');
     if (power16 && c.fft_size == 512) done = launch_stockham_power16<9>(job, a, t);
     if (power16 && c.fft_size == 1024) done = launch_stockham_power16<10>(job, a, t);
+    if (power16 && c.fft_size == 2048) done = launch_stockham_power16<11>(job, a, t);      // where the fused kernels do not apply
+    if (job.mode != OUT_COMPLEX && !(sf && sf[0] == '1') && c.fft_size == 4096) done = launch_stockham_power16<12, 8>(job, a, t);
+    if (job.mode != OUT_COMPLEX && !(sf && sf[0] == '1') && c.fft_size == 8192) done = launch_stockham_power16<13, 4>(job, a, t);
     if (!done) switch (c.fft_size) {
       case 256: done = launch_stockham<8>(job, a); break;
       case 512: done = real_form ? launch_stockham_real<9, float, float, float>(job, a, t) : launch_stockham<9>(job, a); break;

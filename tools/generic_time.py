@@ -4,7 +4,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from soundml_amd import Stft
 from soundml_amd._lib import lib, check
 vp = ctypes.c_void_p
-for fft, hop, clips, n in ((1024, 256, 256, 441000), (512, 128, 256, 441000), (4096, 1024, 256, 480000), (400, 160, 256, 160000)):
+for fft, hop, clips, n in ((1024, 256, 256, 441000), (512, 128, 256, 441000), (4096, 1024, 256, 480000), (8192, 2048, 256, 480000), (256, 64, 256, 160000), (400, 160, 256, 160000)):
     c = Stft.Config.create(fft_size=fft, hop=hop)
     frames = Stft.frames(c, n)
     x = torch.rand(clips, n, device="cuda") * 2 - 1
