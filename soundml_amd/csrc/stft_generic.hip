@@ -500,6 +500,83 @@ struct MelTail {
   float *out;                 // [lead; n_mels; count]
 };
 
+// The common tail of the stage-free kernels: FT power columns lie in LDS, frame f at cols + f * BUF + 2 f (BUF floats
+// per frame buffer, `bins` values each).  MEL: banded filterbank x columns on the fp32 MFMA, [n_mels; 16] out;
+// otherwise the columns leave as 16-byte stores of 4 frames of one bin.
+template <int BUF, int FT, bool MEL>
+__device__ __forceinline__ void columns_out(const GenericArgs &a, const MelTail &mt, const float *cols, int bins, int nf,
+                                            int64_t clip, int64_t f0) {
+  if constexpr (MEL) {
+    static_assert(!MEL || FT == 16, "the MFMA tile is 16 frames wide");
+    using f32x4 = __attribute__((ext_vector_type(4))) float;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
+    const int n = lane & 15, kk = lane >> 4;           // B[k = kk][n = frame], A[m = n][k = kk], D[4 kk + i][n]
+    const float *colb = cols + n * (BUF) + 2 * n + kk;
+    for (int r0 = 16 * wave; r0 < mt.n_mels; r0 += 16 * nwaves) {
+      // bins any of the tile's 16 rows touches (rows without weights -- the padding -- do not count)
+      int lo = 0x7fffffff, hi = 0;
+      {
+        const int l = mt.band_lo[r0 + n], h = mt.band_hi[r0 + n];
+        if (h > l) {
+          lo = l;
+          hi = h;
+        }
+      }
+#pragma unroll
+      for (int d = 1; d < 16; d <<= 1) {
+        const int ol = __shfl_xor(lo, d), oh = __shfl_xor(hi, d);
+        lo = ol < lo ? ol : lo;
+        hi = oh > hi ? oh : hi;
+      }
+      lo = __builtin_amdgcn_readfirstlane(lo);
+      hi = __builtin_amdgcn_readfirstlane(hi);
+      f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+      const float *wa = mt.w + (int64_t)(r0 + n) * mt.k_pad + kk;
+      // four k-steps (16 bins) per trip, operands fetched first; the trips may run past the band: W is zero there
+      const int k_begin = lo & ~15;                          // 16-aligned trips never straddle the end of a padded row
+      int k_end = k_begin + (hi - k_begin + 15) / 16 * 16;
+      k_end = k_end < mt.k_pad ? k_end : mt.k_pad;          // k_pad is a multiple of 32
+      for (int k0 = k_begin; k0 < k_end; k0 += 16) {
+        float av[4], bv[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          av[j] = wa[k0 + 4 * j];
+          bv[j] = k0 + 4 * j + kk < bins ? colb[k0 + 4 * j] : 0.0f;   // past the Nyquist bin the column is not defined
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[j], bv[j], acc, 0, 0, 0);
+      }
+      if (n < nf) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int row = r0 + 4 * kk + i;
+          if (row < mt.n_mels) mt.out[(clip * mt.n_mels + row) * a.count + f0 + n] = acc[i];
+        }
+      }
+    }
+    return;
+  }
+  const int total = bins * nf;
+  const int64_t obase = clip * a.bins * a.out_stride + a.out_offset + f0;
+  float *out = reinterpret_cast<float *>(a.out);
+  if (nf == FT) {   // a lane takes 4 frames of one bin: four conflict-free LDS reads, one 16-byte store (4-byte aligned)
+    using f32x4 = __attribute__((ext_vector_type(4))) float;
+    constexpr int QF = FT / 4;                           // frame quads per bin
+    for (int e = threadIdx.x; e < bins * QF; e += blockDim.x) {
+      const int k = e / QF, g = 4 * (e % QF);
+      const float *src = cols + g * (BUF) + 2 * g + k;
+      const f32x4 v = {src[0], src[BUF + 2], src[2 * (BUF + 2)], src[3 * (BUF + 2)]};
+      float *dst = out + obase + (int64_t)k * a.out_stride + g;
+      asm volatile("global_store_dwordx4 %0, %1, off" : : "v"(dst), "v"(v) : "memory");
+    }
+    return;
+  }
+  for (int e = threadIdx.x; e < total; e += blockDim.x) {   // a clip's ragged last tile
+    const int k = e / nf, g = e - k * nf;
+    out[obase + (int64_t)k * a.out_stride + g] = cols[g * (BUF) + 2 * g + k];
+  }
+}
+
 template <int LOG2N, typename Tin, bool MEL, int FT>
 __global__ void __launch_bounds__(FT * ((1 << LOG2N) / 32)) stft_stockham_power16_kernel(GenericArgs a, const float2 *tw_m, const float2 *tw_n,
                                                                                  MelTail mt) {
@@ -570,76 +647,7 @@ __global__ void __launch_bounds__(FT * ((1 << LOG2N) / 32)) stft_stockham_power1
   for (int m = 0; m < 16; ++m) col[tid + T * m] = val[m];
   if (tid == 0) col[M] = nyq;
   __syncthreads();
-  const float *cols = reinterpret_cast<const float *>(work);
-  if constexpr (MEL) {
-    static_assert(!MEL || FT == 16, "the MFMA tile is 16 frames wide");
-    using f32x4 = __attribute__((ext_vector_type(4))) float;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
-    const int n = lane & 15, kk = lane >> 4;           // B[k = kk][n = frame], A[m = n][k = kk], D[4 kk + i][n]
-    const float *colb = cols + n * (2 * M) + 2 * n + kk;
-    for (int r0 = 16 * wave; r0 < mt.n_mels; r0 += 16 * nwaves) {
-      // bins any of the tile's 16 rows touches (rows without weights -- the padding -- do not count)
-      int lo = 0x7fffffff, hi = 0;
-      {
-        const int l = mt.band_lo[r0 + n], h = mt.band_hi[r0 + n];
-        if (h > l) {
-          lo = l;
-          hi = h;
-        }
-      }
-#pragma unroll
-      for (int d = 1; d < 16; d <<= 1) {
-        const int ol = __shfl_xor(lo, d), oh = __shfl_xor(hi, d);
-        lo = ol < lo ? ol : lo;
-        hi = oh > hi ? oh : hi;
-      }
-      lo = __builtin_amdgcn_readfirstlane(lo);
-      hi = __builtin_amdgcn_readfirstlane(hi);
-      f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-      const float *wa = mt.w + (int64_t)(r0 + n) * mt.k_pad + kk;
-      // four k-steps (16 bins) per trip, operands fetched first; the trips may run past the band: W is zero there
-      const int k_begin = lo & ~15;                          // 16-aligned trips never straddle the end of a padded row
-      int k_end = k_begin + (hi - k_begin + 15) / 16 * 16;
-      k_end = k_end < mt.k_pad ? k_end : mt.k_pad;          // k_pad is a multiple of 32
-      for (int k0 = k_begin; k0 < k_end; k0 += 16) {
-        float av[4], bv[4];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          av[j] = wa[k0 + 4 * j];
-          bv[j] = k0 + 4 * j + kk <= M ? colb[k0 + 4 * j] : 0.0f;   // past the Nyquist bin the column is not defined
-        }
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[j], bv[j], acc, 0, 0, 0);
-      }
-      if (n < nf) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          const int row = r0 + 4 * kk + i;
-          if (row < mt.n_mels) mt.out[(clip * mt.n_mels + row) * a.count + f0 + n] = acc[i];
-        }
-      }
-    }
-    return;
-  }
-  const int total = (M + 1) * nf;
-  const int64_t obase = clip * a.bins * a.out_stride + a.out_offset + f0;
-  float *out = reinterpret_cast<float *>(a.out);
-  if (nf == FT) {   // a lane takes 4 frames of one bin: four conflict-free LDS reads, one 16-byte store (4-byte aligned)
-    using f32x4 = __attribute__((ext_vector_type(4))) float;
-    constexpr int QF = FT / 4;                           // frame quads per bin
-    for (int e = threadIdx.x; e < (M + 1) * QF; e += blockDim.x) {
-      const int k = e / QF, g = 4 * (e % QF);
-      const float *src = cols + g * (2 * M) + 2 * g + k;
-      const f32x4 v = {src[0], src[2 * M + 2], src[2 * (2 * M + 2)], src[3 * (2 * M + 2)]};
-      float *dst = out + obase + (int64_t)k * a.out_stride + g;
-      asm volatile("global_store_dwordx4 %0, %1, off" : : "v"(dst), "v"(v) : "memory");
-    }
-    return;
-  }
-  for (int e = threadIdx.x; e < total; e += blockDim.x) {   // a clip's ragged last tile
-    const int k = e / nf, g = e - k * nf;
-    out[obase + (int64_t)k * a.out_stride + g] = cols[g * (2 * M) + 2 * g + k];
-  }
+  columns_out<2 * M, FT, MEL>(a, mt, reinterpret_cast<const float *>(work), M + 1, nf, clip, f0);
 }
 
 template <int LOG2N, int FT = 16>
@@ -859,6 +867,127 @@ __global__ void __launch_bounds__((1 << LOG2M) / 16 < 256 ? 256 : (1 << LOG2M) /
   flush_stage<float>(a, stage, clip, f0, nf);
 }
 
+// The same transform as a stage-free 16-frame kernel (power / mel output, M <= 1024, i.e. even sizes up to 1024 --
+// whisper's fft 400 among them): every frame's L + 1 values go back into its own work buffer and leave through
+// columns_out, with MEL straight through the fp32 MFMA.
+template <int LOG2M, typename Tin, bool MEL>
+__global__ void __launch_bounds__(1 << LOG2M) stft_bluestein_power16_kernel(GenericArgs a, Blu2Args b, MelTail mt) {
+  using namespace fftdev;
+  constexpr int M = 1 << LOG2M, T = M / 16, FT = 16;
+  static_assert(T <= 64, "wave-private transforms");
+  constexpr int RL = LastPass<LOG2M>::R, NSL = LastPass<LOG2M>::NS, GL = 16 / RL;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  float2 *work = reinterpret_cast<float2 *>(smem);
+  const int N = (int)a.fft, L = N / 2;
+  const int64_t tiles = (a.count + FT - 1) / FT;
+  const int64_t clip = blockIdx.x / tiles, tile = blockIdx.x % tiles;
+  const Tin *x = reinterpret_cast<const Tin *>(a.x) + clip * a.x_stride;
+  const float *window = reinterpret_cast<const float *>(a.window);       // 0.5 * analysis window
+  const int tid = threadIdx.x % T, f = threadIdx.x / T;
+  float2 *z = work + (size_t)f * M;
+  const int64_t f0 = tile * FT;
+  const int nf = (int)((a.count - f0) < FT ? (a.count - f0) : FT);
+  const bool have = f < nf;
+  c32 r[16];
+#pragma unroll
+  for (int m = 0; m < 16; ++m) r[m] = {0.0f, 0.0f};
+  if (have) {
+    const int64_t s0 = (a.p0 + f0 + f) * a.hop - a.left;
+    const bool inside = s0 >= 0 && s0 + N <= a.n;
+#pragma unroll
+    for (int m = 0; m < 16; ++m) {
+      const int i = tid + T * m;
+      if (i < L) {
+        const float v0 = inside ? (float)x[s0 + 2 * i] : (float)fetch_sample<Tin>(x, a.n, s0 + 2 * i, a.pad, a.pad_value);
+        const float v1 = inside ? (float)x[s0 + 2 * i + 1] : (float)fetch_sample<Tin>(x, a.n, s0 + 2 * i + 1, a.pad, a.pad_value);
+        const float2 c = b.chirp[i];
+        r[m] = cmul(c32{v0 * window[2 * i], v1 * window[2 * i + 1]}, c32{c.x, c.y});
+      }
+    }
+  }
+  fft_passes<LOG2M, true, true>(r, z, tid, b.tw);
+#pragma unroll
+  for (int i = 0; i < GL; ++i)
+#pragma unroll
+    for (int j = 0; j < RL; ++j) {
+      const int idx = out_index<RL, NSL, T>(tid, i, j);
+      const float2 h = b.filter[idx];
+      const c32 y = cmul(r[i * RL + j], c32{h.x, h.y});
+      z[swz(idx)] = make_float2(y.x, -y.y);
+    }
+  fft_passes<LOG2M, false, true>(r, z, tid, b.tw);
+#pragma unroll
+  for (int i = 0; i < GL; ++i)
+#pragma unroll
+    for (int j = 0; j < RL; ++j) {
+      const int k = out_index<RL, NSL, T>(tid, i, j);
+      if (k < L) {
+        const float2 c = b.chirp[k];
+        const c32 v = cmul(c32{r[i * RL + j].x, -r[i * RL + j].y}, c32{c.x, c.y});
+        z[swz(k)] = make_float2(v.x, v.y);
+      }
+    }
+  stockham_sync<true>();
+  float val[8], nyq = 0.0f;                      // L <= M / 2: a thread owns at most 8 bins below L
+#pragma unroll
+  for (int m = 0; m < 8; ++m) {
+    const int k = tid + T * m;
+    val[m] = 0.0f;
+    if (k < L) {
+      const float2 zk = z[swz(k)], zm = z[swz(k == 0 ? 0 : L - k)];
+      const float er = zk.x + zm.x, ei = zk.y - zm.y;
+      const float dr = zk.x - zm.x, di = zk.y + zm.y;
+      const float2 w = b.tw_n[k];
+      val[m] = magnitude_pow<float, float>(er + (w.x * di + w.y * dr), ei - (w.x * dr - w.y * di), a.power);
+    }
+  }
+  if (tid == 0) {
+    const float2 z0 = z[0];
+    nyq = magnitude_pow<float, float>(2.0f * (z0.x - z0.y), 0.0f, a.power);
+  }
+  stockham_sync<true>();
+  float *col = reinterpret_cast<float *>(z) + 2 * f;
+#pragma unroll
+  for (int m = 0; m < 8; ++m) {
+    const int k = tid + T * m;
+    if (k < L) col[k] = val[m];
+  }
+  if (tid == 0) col[L] = nyq;
+  __syncthreads();
+  columns_out<2 * M, FT, MEL>(a, mt, reinterpret_cast<const float *>(work), L + 1, nf, clip, f0);
+}
+
+template <int LOG2M>
+bool launch_bluestein_power16(const StftJob &job, GenericArgs a, const StftTables &t, const MelTail *mel) {
+  constexpr int M = 1 << LOG2M;
+  a.window = t.blu2_window;
+  const Blu2Args b{t.blu2_chirp, t.blu2_filter, t.blu2_tw, (const float2 *)t.twiddle_f32};
+  const int64_t blocks = a.lead * ((a.count + 15) / 16);
+  if (blocks > 2147483647LL) throw Failure("stft: too many frame tiles for one launch");
+  const size_t lds = (size_t)16 * M * sizeof(float2);
+  if (mel) {
+    auto kernel = stft_bluestein_power16_kernel<LOG2M, float, true>;
+    SMX_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(kernel, dim3((unsigned)blocks), dim3(M), lds, job.stream, a, b, *mel);
+  } else {
+    auto kernel = stft_bluestein_power16_kernel<LOG2M, float, false>;
+    SMX_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(kernel, dim3((unsigned)blocks), dim3(M), lds, job.stream, a, b, MelTail{});
+  }
+  SMX_HIP_CHECK(hipGetLastError());
+  return true;
+}
+
+// even non-power-of-two sizes up to 1024 (chirp-z length M <= 1024): power / mel through the 16-frame kernel
+bool launch_bluestein16_any(const StftJob &job, const GenericArgs &a, const StftTables &t, const MelTail *mel) {
+  switch (t.blu2_log2m) {
+    case 8: return launch_bluestein_power16<8>(job, a, t, mel);
+    case 9: return launch_bluestein_power16<9>(job, a, t, mel);
+    case 10: return launch_bluestein_power16<10>(job, a, t, mel);
+    default: return false;
+  }
+}
+
 template <int LOG2M>
 bool launch_bluestein_real(const StftJob &job, GenericArgs a, const StftTables &t) {
   constexpr int M = 1 << LOG2M, T = M / 16, G = T < 256 ? 256 / T : 1, THREADS = T < 256 ? 256 : T;
@@ -945,13 +1074,14 @@ void launch_typed(const StftJob &job, GenericArgs a) {
 bool launch_mel_spectrogram_16(const MelSpecJob &job) {
   const StftJob &sj = job.stft;
   const smx_stft_config &c = *sj.cfg;
-  if ((c.fft_size != 512 && c.fft_size != 1024) || sj.in_bytes != 4 || sj.interior == SMX_INTERIOR_F64 || sj.mode == OUT_COMPLEX ||
-      fast_path_disabled())
-    return false;
+  if (sj.in_bytes != 4 || sj.interior == SMX_INTERIOR_F64 || sj.mode == OUT_COMPLEX || fast_path_disabled()) return false;
+  const StftTables &t = c.tables();
+  const bool pow2_16 = c.fft_size == 512 || c.fft_size == 1024;
+  const bool chirp_16 = !pow2_16 && t.blu2_log2m >= 8 && t.blu2_log2m <= 10;   // even sizes up to 1024 (fft 400 ...)
+  if (!pow2_16 && !chirp_16) return false;
   if (const char *e = std::getenv("SMX_MEL16_OFF"))
     if (e[0] == '1') return false;
   if (sj.count <= 0 || sj.lead <= 0) return true;
-  const StftTables &t = c.tables();
   const smx_mel_config::Tables &mtab = job.mel->tables();
   GenericArgs a{};
   a.x = sj.x;
@@ -975,6 +1105,7 @@ bool launch_mel_spectrogram_16(const MelSpecJob &job) {
   mt.n_mels = (int)job.mel->n_mels;
   mt.k_pad = (int)mtab.k_pad;
   mt.out = reinterpret_cast<float *>(job.out);
+  if (chirp_16) return launch_bluestein16_any(sj, a, t, &mt);
   return c.fft_size == 512 ? launch_stockham_power16<9>(sj, a, t, &mt) : launch_stockham_power16<10>(sj, a, t, &mt);
 }
 
@@ -1027,6 +1158,8 @@ void launch_stft_generic(const StftJob &job) {
       default: break;
     }
     const char *bf = std::getenv("SMX_BLUESTEIN_FULL");   // diagnostic: the full-length chirp-z for even sizes too
+    if (!done && t.blu2_log2m >= 8 && t.blu2_log2m <= 10 && job.mode != OUT_COMPLEX && !(bf && bf[0] == '1') && !(sf && sf[0] == '1'))
+      done = launch_bluestein16_any(job, a, t, nullptr);
     if (!done && t.blu2_log2m >= 8 && !(bf && bf[0] == '1')) {   // even, not a power of two: half-length chirp-z
       switch (t.blu2_log2m) {
         case 8: done = launch_bluestein_real<8>(job, a, t); break;

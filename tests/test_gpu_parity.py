@@ -579,6 +579,9 @@ def test_fused_mel_spectrogram_vs_oracle(n_mels, sr, n, lead, power):
     (512, 128, 40, 16000, 9000, 2, 2.0),        # four waves, three row tiles (one partly empty)
     (512, 160, 13, 16000, 4000, 1, 2.0),        # a single partial row tile, hop that does not divide the size
     (1024, 300, 136, 16000, 30000, 1, 2.0),     # nine row tiles over 8 waves
+    (400, 160, 80, 16000, 16000 * 3, 2, 2.0),   # whisper's front end: chirp-z at M = 512, the same MFMA tail
+    (100, 33, 10, 8000, 3000, 1, 1.0),          # M = 256
+    (1000, 250, 64, 22050, 9000, 1, 2.0),       # M = 1024: one 1024-thread workgroup
 ])
 def test_fused_mel_spectrogram_512_1024(fft, hop, n_mels, sr, n, lead, power):
     """Soundml.mel_spectrogram for fft 512 / 1024 (stft_stockham_power16_kernel<.., MEL>): the power columns stay in

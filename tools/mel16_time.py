@@ -5,7 +5,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from soundml_amd import Stft, Mel
 from soundml_amd._lib import lib, check
 vp = ctypes.c_void_p
-for fft, hop, n_mels, sr, clips, n in ((1024, 256, 80, 22050, 256, 441000), (512, 128, 80, 16000, 256, 441000)):
+for fft, hop, n_mels, sr, clips, n in ((1024, 256, 80, 22050, 256, 441000), (512, 128, 80, 16000, 256, 441000), (400, 160, 80, 16000, 256, 480000)):
     c = Stft.Config.create(fft_size=fft, hop=hop)
     m = Mel.Config.create(n_mels=n_mels, sample_rate=sr, fft_size=fft)
     frames = Stft.frames(c, n)
