@@ -113,6 +113,110 @@ __global__ void __launch_bounds__(256) istft_frames_kernel(IstftArgs a) {
   }
 }
 
+// ---- powers of two 512 .. 4096, float32: the frames on the Stockham passes (real form) ------------------------
+// FT frames per workgroup, M/16 threads each (M = N/2).  The [M + 1; FT] block of the spectrum is staged through two
+// float planes (row pieces of FT x 8 bytes, every load of a thread issued before its first use); a frame's threads
+// form the half-size spectrum Z'[k] = E + i conj(w_k) D (the inverse of the analysis post-pass, as in the fused
+// kernel below), the planes then become the frames' work buffers, z = conj(FFT_M(conj Z')) on the passes of
+// fft_device.hpp, and x[2n] + i x[2n+1] = z[n] times the synthesis window (1/(2M) and the signs folded in) goes
+// straight to y[clip][frame][N] in 512-byte runs.  3-4 LDS round trips against log2 N barrier-separated passes.
+template <int LOG2N, int FT>
+__global__ void __launch_bounds__(FT * ((1 << LOG2N) / 32)) istft_stockham_frames_kernel(IstftArgs a, const float2 *w_m, const float2 *w_n,
+                                                                                        const float2 *synth_window) {
+  using namespace fftdev;
+  constexpr int N = 1 << LOG2N, LOG2M = LOG2N - 1, M = N / 2, T = M / 16, THREADS = FT * T;
+  constexpr bool WAVE = T <= 64;
+  constexpr int RL = LastPass<LOG2M>::R, NSL = LastPass<LOG2M>::NS, GL = 16 / RL;
+  constexpr int STRIDE = FT + 1, LOGFT = FT == 16 ? 4 : 3;
+  constexpr int PER = ((M + 1) * FT + THREADS - 1) / THREADS;     // staged elements per thread
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  float *re = reinterpret_cast<float *>(smem);
+  float *im = re + (M + 1) * STRIDE;
+  const int64_t tiles = (a.count + FT - 1) / FT;
+  const int64_t clip = blockIdx.x / tiles, tile = blockIdx.x % tiles;
+  const int64_t f0 = tile * FT;
+  const int nf = (int)((a.count - f0) < FT ? (a.count - f0) : FT);
+  const float2 *z = reinterpret_cast<const float2 *>(a.z) + clip * (int64_t)(M + 1) * a.frames + f0;
+  {
+    float2 v[PER];
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+      const int e = threadIdx.x + THREADS * i;
+      const int row = e >> LOGFT, f = e & (FT - 1);
+      v[i] = make_float2(0.f, 0.f);
+      if (row <= M && f < nf) v[i] = z[(int64_t)row * a.frames + f];
+    }
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+      const int e = threadIdx.x + THREADS * i;
+      const int row = e >> LOGFT, f = e & (FT - 1);
+      if (row <= M) {
+        re[row * STRIDE + f] = v[i].x;
+        im[row * STRIDE + f] = v[i].y;
+      }
+    }
+  }
+  __syncthreads();
+  const int tid = threadIdx.x % T, f = threadIdx.x / T;
+  const bool have = f < nf;                             // uniform per group of T threads
+  c32 r[16];
+#pragma unroll
+  for (int m = 0; m < 16; ++m) {
+    const int k = tid + T * m, km = M - k;
+    float zr = re[k * STRIDE + f], zi = im[k * STRIDE + f];
+    float pr = re[km * STRIDE + f], pi = im[km * STRIDE + f];
+    if (k == 0) { zi = 0.f; pi = 0.f; }                 // the imaginary parts of the DC and Nyquist bins do not take part
+    const float er = zr + pr, ei = zi - pi;             // E = Z[k] + conj Z[M-k]
+    const float dr = zr - pr, di = zi + pi;             // D = Z[k] - conj Z[M-k]
+    const float2 w = w_n[k];                            // exp(-2 pi i k / N)
+    const float tr = er - (w.x * di - w.y * dr);        // Z' = E + i conj(w) D
+    const float ti = ei + (w.x * dr + w.y * di);
+    r[m] = {tr, -ti};                                   // conj(Z')
+  }
+  __syncthreads();   // every column is in registers: the planes become the frames' work buffers
+  float2 *buf = reinterpret_cast<float2 *>(smem) + (size_t)f * M;
+  if (WAVE && !have) return;                            // wave-private transforms: nothing left to synchronise with
+  fft_passes<LOG2M, true, WAVE>(r, buf, tid, w_m);
+  if (!have) return;
+  float *y = reinterpret_cast<float *>(a.y) + (clip * a.count + f0 + f) * (int64_t)N;
+#pragma unroll
+  for (int i = 0; i < GL; ++i)
+#pragma unroll
+    for (int j = 0; j < RL; ++j) {
+      const int n = out_index<RL, NSL, T>(tid, i, j);
+      const float2 w = synth_window[n];
+      reinterpret_cast<float2 *>(y)[n] = make_float2(r[i * RL + j].x * w.x, r[i * RL + j].y * w.y);
+    }
+}
+
+template <int LOG2N, int FT>
+void launch_stockham_frames(const IstftArgs &a, const StftTables &t, hipStream_t stream) {
+  constexpr int M = (1 << LOG2N) / 2, THREADS = FT * (M / 16);
+  const size_t planes = 2 * (size_t)(M + 1) * (FT + 1) * sizeof(float), work = (size_t)FT * M * sizeof(float2);
+  const size_t lds = (planes > work ? planes : work) + 16;
+  const int64_t blocks = a.lead * ((a.count + FT - 1) / FT);
+  if (blocks > 2147483647LL) throw Failure("invert: too many frame tiles for one launch");
+  auto kernel = istft_stockham_frames_kernel<LOG2N, FT>;
+  SMX_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  hipLaunchKernelGGL(kernel, dim3((unsigned)blocks), dim3(THREADS), lds, stream, a, (const float2 *)t.fast_w_m, (const float2 *)t.fast_w_n,
+                     (const float2 *)t.fast_synth_window);
+  SMX_HIP_CHECK(hipGetLastError());
+}
+
+// float32 spectra, float32 interior, fft 512 .. 4096: true when the Stockham frames kernel took the launch
+bool launch_stockham_frames_any(const IstftArgs &a, const StftTables &t, hipStream_t stream) {
+  if (!t.fast_w_m || !t.fast_w_n || !t.fast_synth_window) return false;
+  static const bool fast_off = std::getenv("SMX_DISABLE_FAST") != nullptr;
+  if (fast_off) return false;
+  switch (a.fft) {
+    case 512: launch_stockham_frames<9, 16>(a, t, stream); return true;
+    case 1024: launch_stockham_frames<10, 16>(a, t, stream); return true;
+    case 2048: launch_stockham_frames<11, 16>(a, t, stream); return true;
+    case 4096: launch_stockham_frames<12, 8>(a, t, stream); return true;
+    default: return false;
+  }
+}
+
 struct OlaArgs {
   const void *y;        // [lead; count; fft]
   void *out;            // [lead; out_len]
@@ -455,7 +559,7 @@ void launch_istft(const IstftJob &job) {
     fa.y = d_y;
     if (job.z_bytes == 16) launch_frames<double, double>(job, fa, job.stream);
     else if (f64) launch_frames<float, double>(job, fa, job.stream);
-    else launch_frames<float, float>(job, fa, job.stream);
+    else if (!launch_stockham_frames_any(fa, t, job.stream)) launch_frames<float, float>(job, fa, job.stream);
     OlaArgs oa{};
     oa.y = d_y;
     oa.out = reinterpret_cast<unsigned char *>(job.out) + c0 * job.out_len * elem_out;

@@ -391,7 +391,9 @@ def test_invert_goldens(vectors):
 
 @pytest.mark.parametrize("fft,hop,win,alignment", [(2048, 512, None, "centered"), (2048, 512, 1200, "left"), (1024, 256, None, "right"),
                                                    (64, 16, None, "centered"), (48, 12, None, "centered"), (31, 5, None, "left"),
-                                                   (64, 60, None, "centered"), (100, 33, 64, "right")])
+                                                   (64, 60, None, "centered"), (100, 33, 64, "right"),
+                                                   (512, 128, None, "centered"), (1024, 256, 800, "left"), (2048, 500, None, "centered"),
+                                                   (4096, 1024, None, "centered")])
 @pytest.mark.parametrize("length_mode", ["default", "short", "long"])
 def test_invert_vs_oracle(fft, hop, win, alignment, length_mode):
     """Random (inconsistent) spectra: the least-squares solution itself, every alignment, power-of-two and other
