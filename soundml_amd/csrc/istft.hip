@@ -32,6 +32,12 @@ struct IstftArgs {
   const void *window, *twiddle;
   void *y;              // [lead; count; fft]
   int log2n, ft;
+  // Griffin-Lim folding (Stockham frames kernel only): optional real factors, and with `unit` the phase update
+  // unit(z - beta prev) formed on the way in (see SynArgs below)
+  const float *mag;
+  const float2 *prev;
+  float beta;
+  int unit;
 };
 
 inline __device__ unsigned bitrev_n(unsigned v, int bits) { return bits == 0 ? 0u : (__brev(v) >> (32 - bits)); }
@@ -137,24 +143,72 @@ __global__ void __launch_bounds__(FT * ((1 << LOG2N) / 32)) istft_stockham_frame
   const int64_t f0 = tile * FT;
   const int nf = (int)((a.count - f0) < FT ? (a.count - f0) : FT);
   const float2 *z = reinterpret_cast<const float2 *>(a.z) + clip * (int64_t)(M + 1) * a.frames + f0;
-  {
-    float2 v[PER];
+  auto stage_elements = [&](auto first, auto count) {   // elements [first, first + count) of this thread's PER
+    constexpr int I0 = decltype(first)::value, NI = decltype(count)::value;
+    float2 v[NI];
 #pragma unroll
-    for (int i = 0; i < PER; ++i) {
-      const int e = threadIdx.x + THREADS * i;
+    for (int j = 0; j < NI; ++j) {
+      const int e = threadIdx.x + THREADS * (I0 + j);
       const int row = e >> LOGFT, f = e & (FT - 1);
-      v[i] = make_float2(0.f, 0.f);
-      if (row <= M && f < nf) v[i] = z[(int64_t)row * a.frames + f];
+      v[j] = make_float2(0.f, 0.f);
+      if (row <= M && f < nf) v[j] = z[(int64_t)row * a.frames + f];
     }
+    if (a.unit) {   // uniform: v is c_k; form unit(c_k - beta c_(k-1)) as the update kernel does
+      if (a.prev) {
+        const float2 *pv = a.prev + clip * (int64_t)(M + 1) * a.frames + f0;
+        float2 q[NI];
 #pragma unroll
-    for (int i = 0; i < PER; ++i) {
-      const int e = threadIdx.x + THREADS * i;
-      const int row = e >> LOGFT, f = e & (FT - 1);
-      if (row <= M) {
-        re[row * STRIDE + f] = v[i].x;
-        im[row * STRIDE + f] = v[i].y;
+        for (int j = 0; j < NI; ++j) {
+          const int e = threadIdx.x + THREADS * (I0 + j);
+          const int row = e >> LOGFT, f = e & (FT - 1);
+          q[j] = make_float2(0.f, 0.f);
+          if (row <= M && f < nf) q[j] = pv[(int64_t)row * a.frames + f];
+        }
+#pragma unroll
+        for (int j = 0; j < NI; ++j) {
+          v[j].x -= a.beta * q[j].x;
+          v[j].y -= a.beta * q[j].y;
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < NI; ++j) {
+        const float m = (float)hypot((double)v[j].x, (double)v[j].y) + FLT_MIN;
+        v[j].x /= m;
+        v[j].y /= m;
       }
     }
+    if (a.mag) {   // uniform
+      const float *mg = a.mag + clip * (int64_t)(M + 1) * a.frames + f0;
+      float m[NI];
+#pragma unroll
+      for (int j = 0; j < NI; ++j) {
+        const int e = threadIdx.x + THREADS * (I0 + j);
+        const int row = e >> LOGFT, f = e & (FT - 1);
+        m[j] = 0.f;
+        if (row <= M && f < nf) m[j] = mg[(int64_t)row * a.frames + f];
+      }
+#pragma unroll
+      for (int j = 0; j < NI; ++j) {
+        v[j].x *= m[j];
+        v[j].y *= m[j];
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < NI; ++j) {
+      const int e = threadIdx.x + THREADS * (I0 + j);
+      const int row = e >> LOGFT, f = e & (FT - 1);
+      if (row <= M) {
+        re[row * STRIDE + f] = v[j].x;
+        im[row * STRIDE + f] = v[j].y;
+      }
+    }
+  };
+  if (a.unit) {   // three load streams: two batches keep the registers in budget
+    constexpr int H = (PER + 1) / 2;
+    stage_elements(std::integral_constant<int, 0>{}, std::integral_constant<int, H>{});
+    stage_elements(std::integral_constant<int, H>{}, std::integral_constant<int, PER - H>{});
+  } else {
+    stage_elements(std::integral_constant<int, 0>{}, std::integral_constant<int, PER>{});
   }
   __syncthreads();
   const int tid = threadIdx.x % T, f = threadIdx.x / T;
@@ -472,10 +526,19 @@ void launch_frames(const IstftJob &job, IstftArgs a, hipStream_t stream) {
 }  // namespace
 
 // the fused kernel: fft 2048, hop 512, complex64 spectrum, float32 interior
-bool istft_takes_factors(const IstftJob &job) {
+static bool istft_fused_2048(const IstftJob &job) {
   static const bool fast_off = std::getenv("SMX_DISABLE_FAST") != nullptr;
   const bool f64 = job.z_bytes == 16 || job.interior == SMX_INTERIOR_F64;
   return !fast_off && !f64 && job.cfg->fft_size == 2048 && job.cfg->hop == 512 && job.lead <= 0x7fffffff / 4096;
+}
+
+// the kernels that stage the spectrum themselves: the fused fft-2048 / hop-512 one and the Stockham frames kernel
+// (float32, fft 512 .. 4096)
+bool istft_takes_factors(const IstftJob &job) {
+  static const bool fast_off = std::getenv("SMX_DISABLE_FAST") != nullptr;
+  const bool f64 = job.z_bytes == 16 || job.interior == SMX_INTERIOR_F64;
+  const int64_t n = job.cfg->fft_size;
+  return istft_fused_2048(job) || (!fast_off && !f64 && (n == 512 || n == 1024 || n == 2048 || n == 4096));
 }
 
 void launch_istft(const IstftJob &job) {
@@ -496,7 +559,7 @@ void launch_istft(const IstftJob &job) {
   const double *d_env = env.dev;
   const int64_t head_n = env.head_n, stop = env.stop;
   // fused path: fft 2048, hop 512, complex64 spectrum, float32 interior
-  if (istft_takes_factors(job)) {
+  if (istft_fused_2048(job)) {
     SynArgs sa{};
     sa.mag = reinterpret_cast<const float *>(job.mag);
     sa.unit = job.unit ? 1 : 0;
@@ -557,6 +620,10 @@ void launch_istft(const IstftJob &job) {
     fa.window = f64 ? (const void *)t.window_f64 : (const void *)t.window_f32;
     fa.twiddle = f64 ? (const void *)t.twiddle_f64 : (const void *)t.twiddle_f32;
     fa.y = d_y;
+    fa.mag = job.mag ? reinterpret_cast<const float *>(job.mag) + c0 * c.bins() * job.frames : nullptr;
+    fa.prev = job.prev ? reinterpret_cast<const float2 *>(job.prev) + c0 * c.bins() * job.frames : nullptr;
+    fa.beta = (float)job.beta;
+    fa.unit = job.unit ? 1 : 0;
     if (job.z_bytes == 16) launch_frames<double, double>(job, fa, job.stream);
     else if (f64) launch_frames<float, double>(job, fa, job.stream);
     else if (!launch_stockham_frames_any(fa, t, job.stream)) launch_frames<float, float>(job, fa, job.stream);

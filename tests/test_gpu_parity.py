@@ -489,6 +489,25 @@ def test_griffin_lim_fast_path_and_messages():
     assert str(e.value).startswith("griffin_lim: cannot start from a [1; 1025; 40] phase for a [2; 1025; 40] spectrogram")
 
 
+@pytest.mark.parametrize("fft,hop", [(1024, 256), (512, 100), (4096, 1024)])
+def test_griffin_lim_other_sizes(fft, hop):
+    """The folded loop on the Stockham frames kernel (fft 512 .. 4096, any hop): against the oracle after 6 round
+    trips, with an initial phase and two leading axes."""
+    rng = np.random.default_rng(fft)
+    x = rng.uniform(-1, 1, size=(2, 2, 6 * fft + 321)).astype(np.float32)
+    c = Stft.Config.create(fft_size=fft, hop=hop)
+    o = O.stft_config(fft, hop=hop)
+    z = Stft.transform(c, x)
+    mag = np.abs(z).astype(np.float32)
+    phase = (np.angle(z) + 0.3 * rng.standard_normal(z.shape)).astype(np.float32)
+    want = O.griffin_lim(o, mag, 6, 0.99, phase, None)
+    got = Stft.griffin_lim(c, mag, n_iter=6, momentum=0.99, init=phase)
+    assert got.shape == want.shape and got.dtype == np.float32
+    peak = np.max(np.abs(want))
+    assert np.max(np.abs(got - want)[..., fft:-fft]) < 2e-4 * peak
+    assert np.linalg.norm(got - want) < 1e-3 * np.linalg.norm(want)
+
+
 @pytest.mark.parametrize("n_iter,momentum,length", [(1, 0.99, None), (2, 0.99, 17000), (3, 0.0, None), (5, 0.5, 23456)])
 def test_griffin_lim_folded_update_short_runs(n_iter, momentum, length):
     """The fused loop never materialises S * angles nor the angles (the synthesis kernel forms S * unit(c_k - beta
