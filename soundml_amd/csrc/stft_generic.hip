@@ -577,26 +577,30 @@ __device__ __forceinline__ void columns_out(const GenericArgs &a, const MelTail 
   }
 }
 
-template <int LOG2N, typename Tin, bool MEL, int FT>
-__global__ void __launch_bounds__(FT * ((1 << LOG2N) / 32)) stft_stockham_power16_kernel(GenericArgs a, const float2 *tw_m, const float2 *tw_n,
-                                                                                 MelTail mt) {
+// S = double: the float64 interior for float32 audio (window, transform and |.|^p in float64, one rounding into the
+// float32 column), fewer frames per workgroup since a frame's buffer is twice as large.
+template <int LOG2N, typename Tin, bool MEL, int FT, typename S = float>
+__global__ void __launch_bounds__(FT * ((1 << LOG2N) / 32)) stft_stockham_power16_kernel(GenericArgs a, const typename fftdev::vec2_of<S>::type *tw_m,
+                                                                                 const typename fftdev::vec2_of<S>::type *tw_n, MelTail mt) {
   using namespace fftdev;
+  using V = typename vec2_of<S>::type;
+  constexpr S kHalf = sizeof(S) == 8 ? (S)0.5 : (S)1.0;   // float32: the window table is pre-halved
   constexpr int N = 1 << LOG2N, LOG2M = LOG2N - 1, M = N / 2, T = M / 16;
   constexpr bool WAVE = T <= 64;   // wave-private transforms (fft 512 / 1024 / 2048); fft 4096 synchronises its 128 threads
   static_assert(FT == 16 || FT == 8 || FT == 4, "16 frames per workgroup, 8 at fft 4096, 4 at fft 8192");
   constexpr int RL = LastPass<LOG2M>::R, NSL = LastPass<LOG2M>::NS, GL = 16 / RL;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  float2 *work = reinterpret_cast<float2 *>(smem);                       // 16 buffers of M complex
+  V *work = reinterpret_cast<V *>(smem);                                 // FT buffers of M complex
   const int64_t tiles = (a.count + FT - 1) / FT;
   const int64_t clip = blockIdx.x / tiles, tile = blockIdx.x % tiles;
   const Tin *x = reinterpret_cast<const Tin *>(a.x) + clip * a.x_stride;
-  const float *window = reinterpret_cast<const float *>(a.window);       // 0.5 * analysis window
+  const S *window = reinterpret_cast<const S *>(a.window);
   const int tid = threadIdx.x % T, f = threadIdx.x / T;
-  float2 *z = work + (size_t)f * M;
+  V *z = work + (size_t)f * M;
   const int64_t f0 = tile * FT;
   const int nf = (int)((a.count - f0) < FT ? (a.count - f0) : FT);
   const bool have = f < nf;                            // uniform per group of T threads
-  c32 r[16];
+  cpx<S> r[16];
   if (have) {
     const int64_t s0 = (a.p0 + f0 + f) * a.hop - a.left;
     if (s0 >= 0 && s0 + N <= a.n) {
@@ -604,14 +608,14 @@ __global__ void __launch_bounds__(FT * ((1 << LOG2N) / 32)) stft_stockham_power1
 #pragma unroll
       for (int m = 0; m < 16; ++m) {
         const int i = 2 * (tid + T * m);
-        r[m] = {(float)xs[i] * window[i], (float)xs[i + 1] * window[i + 1]};
+        r[m] = {(S)xs[i] * window[i] * kHalf, (S)xs[i + 1] * window[i + 1] * kHalf};
       }
     } else {
 #pragma unroll 1
       for (int m = 0; m < 16; ++m) {
         const int i = 2 * (tid + T * m);
-        const float v0 = (float)fetch_sample<Tin>(x, a.n, s0 + i, a.pad, a.pad_value) * window[i];
-        const float v1 = (float)fetch_sample<Tin>(x, a.n, s0 + i + 1, a.pad, a.pad_value) * window[i + 1];
+        const S v0 = (S)fetch_sample<Tin>(x, a.n, s0 + i, a.pad, a.pad_value) * window[i] * kHalf;
+        const S v1 = (S)fetch_sample<Tin>(x, a.n, s0 + i + 1, a.pad, a.pad_value) * window[i + 1] * kHalf;
 #pragma unroll
         for (int mm = 0; mm < 16; ++mm)
           if (mm == m) r[mm] = {v0, v1};
@@ -619,27 +623,32 @@ __global__ void __launch_bounds__(FT * ((1 << LOG2N) / 32)) stft_stockham_power1
     }
   } else {
 #pragma unroll
-    for (int m = 0; m < 16; ++m) r[m] = {0.0f, 0.0f};
+    for (int m = 0; m < 16; ++m) r[m] = {(S)0, (S)0};
   }
   fft_passes<LOG2M, true, WAVE>(r, z, tid, tw_m);
 #pragma unroll
   for (int i = 0; i < GL; ++i)
 #pragma unroll
-    for (int j = 0; j < RL; ++j) z[swz(out_index<RL, NSL, T>(tid, i, j))] = make_float2(r[i * RL + j].x, r[i * RL + j].y);
+    for (int j = 0; j < RL; ++j) {
+      V o;
+      o.x = r[i * RL + j].x;
+      o.y = r[i * RL + j].y;
+      z[swz(out_index<RL, NSL, T>(tid, i, j))] = o;
+    }
   stockham_sync<WAVE>();
   float val[16], nyq = 0.0f;
 #pragma unroll
   for (int m = 0; m < 16; ++m) {
     const int k = tid + T * m;
-    const float2 zk = z[swz(k)], zm = z[swz((M - k) & (M - 1))];
-    const float er = zk.x + zm.x, ei = zk.y - zm.y;
-    const float dr = zk.x - zm.x, di = zk.y + zm.y;
-    const float2 w = tw_n[k];
-    val[m] = magnitude_pow<float, float>(er + (w.x * di + w.y * dr), ei - (w.x * dr - w.y * di), a.power);
+    const V zk = z[swz(k)], zm = z[swz((M - k) & (M - 1))];
+    const S er = zk.x + zm.x, ei = zk.y - zm.y;
+    const S dr = zk.x - zm.x, di = zk.y + zm.y;
+    const V w = tw_n[k];
+    val[m] = magnitude_pow<S, float>(er + (w.x * di + w.y * dr), ei - (w.x * dr - w.y * di), a.power);
   }
   if (tid == 0) {
-    const float2 z0 = z[0];
-    nyq = magnitude_pow<float, float>(2.0f * (z0.x - z0.y), 0.0f, a.power);
+    const V z0 = z[0];
+    nyq = magnitude_pow<S, float>((S)2 * (z0.x - z0.y), (S)0, a.power);
   }
   stockham_sync<WAVE>();   // every read of this frame's Z is done (the frame's threads share a wave, or a barrier): reuse its buffer
   float *col = reinterpret_cast<float *>(z) + 2 * f;
@@ -647,7 +656,7 @@ __global__ void __launch_bounds__(FT * ((1 << LOG2N) / 32)) stft_stockham_power1
   for (int m = 0; m < 16; ++m) col[tid + T * m] = val[m];
   if (tid == 0) col[M] = nyq;
   __syncthreads();
-  columns_out<2 * M, FT, MEL>(a, mt, reinterpret_cast<const float *>(work), M + 1, nf, clip, f0);
+  columns_out<(int)(M * sizeof(V) / sizeof(float)), FT, MEL>(a, mt, reinterpret_cast<const float *>(work), M + 1, nf, clip, f0);
 }
 
 template <int LOG2N, int FT = 16>
@@ -673,6 +682,24 @@ bool launch_stockham_power16(const StftJob &job, GenericArgs a, const StftTables
   SMX_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   hipLaunchKernelGGL(kernel, dim3((unsigned)blocks), dim3(THREADS), lds, job.stream, a, (const float2 *)t.fast_w_m,
                      (const float2 *)t.fast_w_n, MelTail{});
+  SMX_HIP_CHECK(hipGetLastError());
+  return true;
+}
+
+// float32 audio with the float64 interior, power output: the stage-free kernel on doubles (FT frames of M double2)
+template <int LOG2N, int FT>
+bool launch_stockham_power16_wide(const StftJob &job, GenericArgs a, const StftTables &t) {
+  constexpr int M = (1 << LOG2N) / 2, THREADS = FT * (M / 16);
+  static_assert(THREADS <= 512, "16 complex doubles per thread need the 256-register budget");
+  if (!t.window_f64 || !t.fast_w_m_f64 || !t.twiddle_f64) return false;
+  a.window = t.window_f64;
+  const int64_t blocks = a.lead * ((a.count + FT - 1) / FT);
+  if (blocks > 2147483647LL) throw Failure("stft: too many frame tiles for one launch");
+  const size_t lds = (size_t)FT * M * sizeof(double2);
+  auto kernel = stft_stockham_power16_kernel<LOG2N, float, false, FT, double>;
+  SMX_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  hipLaunchKernelGGL(kernel, dim3((unsigned)blocks), dim3(THREADS), lds, job.stream, a, (const double2 *)t.fast_w_m_f64,
+                     (const double2 *)t.twiddle_f64, MelTail{});
   SMX_HIP_CHECK(hipGetLastError());
   return true;
 }
@@ -1183,6 +1210,18 @@ void launch_stft_generic(const StftJob &job) {
         case 14: done = launch_bluestein<14>(job, a, b); break;
         default: break;
       }
+    }
+    if (done) return;
+  }
+  if (f64_interior && job.in_bytes == 4 && job.mode != OUT_COMPLEX && !fast_path_disabled()) {   // stage-free, float32 columns
+    const char *sfw = std::getenv("SMX_STOCKHAM_STAGED");
+    bool done = false;
+    if (!(sfw && sfw[0] == '1')) switch (c.fft_size) {
+      case 512: done = launch_stockham_power16_wide<9, 16>(job, a, t); break;
+      case 1024: done = launch_stockham_power16_wide<10, 16>(job, a, t); break;
+      case 2048: done = launch_stockham_power16_wide<11, 8>(job, a, t); break;
+      case 4096: done = launch_stockham_power16_wide<12, 4>(job, a, t); break;
+      default: break;
     }
     if (done) return;
   }
