@@ -89,6 +89,10 @@ int smx_version(void);
 int smx_device_count(int *count);
 int smx_set_device(int device);        /* device used by this thread's subsequent calls */
 int smx_set_interior(int interior);    /* SMX_INTERIOR_*, process-wide default for f32 audio */
+/* Scratch arrays (Griffin-Lim's spectra, scratch spectrograms, small tables) come from the device's stream-ordered
+ * memory pool; the library keeps up to `bytes` of freed scratch per device for reuse instead of returning it to the
+ * driver at every synchronisation (default: 1/8 of the device's memory; 0 = keep nothing; -1 = the default again). */
+int smx_set_scratch_retention(int64_t bytes);
 int smx_get_interior(void);
 int smx_synchronize(void *stream);
 

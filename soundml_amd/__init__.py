@@ -27,6 +27,11 @@ def set_interior(name: str) -> None:
     _lib.check(_lib.lib.smx_set_interior(_lib.INTERIOR[name]))
 
 
+def set_scratch_retention(nbytes: int) -> None:
+    """Bytes of freed scratch the library keeps per device for reuse (-1: the default, 1/8 of device memory)."""
+    _lib.check(_lib.lib.smx_set_scratch_retention(int(nbytes)))
+
+
 def device_count() -> int:
     import ctypes
     n = ctypes.c_int()
@@ -35,5 +40,5 @@ def device_count() -> int:
 
 
 __all__ = ["Stft", "Mel", "Chroma", "Window", "Fir", "mel_spectrogram", "mfcc", "chroma_stft", "spectral_centroid",
-           "spectral_bandwidth", "spectral_rolloff", "spectral_flatness", "shard", "set_interior", "device_count",
+           "spectral_bandwidth", "spectral_rolloff", "spectral_flatness", "shard", "set_interior", "set_scratch_retention", "device_count",
            "InvalidArgument", "Failure", "LIB_PATH"]

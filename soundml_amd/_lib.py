@@ -122,6 +122,7 @@ SIGNATURES = {
     "smx_stft_kernel_prepare_power": (cint, [vp, cint, i64, i64, f64, C.POINTER(vp)]),
     "smx_stft_stage_latency": (i64, [vp]),
     "smx_stft_frame_bound": (i64, [vp, i64]),
+    "smx_set_scratch_retention": (cint, [i64]),
     "smx_stft_nola": (cint, [vp, C.POINTER(cint)]),
     "smx_stft_output_length": (cint, [vp, i64, pi64]),
     "smx_stft_invert_f32": (cint, [vp, vp, i64, i64, i64, cint, i64, vp]),

@@ -215,6 +215,13 @@ int smx_set_device(int device) {
   return guarded([&] { SMX_HIP_CHECK(hipSetDevice(device)); });
 }
 
+int smx_set_scratch_retention(int64_t bytes) {
+  return guarded([&] {
+    if (bytes < -1) throw Failure("set_scratch_retention: bytes must be >= 0, or -1 for the default");
+    set_scratch_retention(bytes);
+  });
+}
+
 int smx_set_interior(int interior) {
   return guarded([&] {
     if (interior != SMX_INTERIOR_F32 && interior != SMX_INTERIOR_F64)

@@ -118,6 +118,7 @@ __global__ void __launch_bounds__((1 << LOG2N) / 16) fir_ols_kernel(FirArgs a) {
 }  // namespace smx
 
 const smx_fir_plan::Tables &smx_fir_plan::tables() const {
+  smx::init_device_pool();
   int device = 0;
   SMX_HIP_CHECK(hipGetDevice(&device));
   std::lock_guard<std::mutex> lock(mutex_);

@@ -126,9 +126,19 @@ __global__ void __launch_bounds__(256) istft_frames_kernel(IstftArgs a) {
 // kernel below), the planes then become the frames' work buffers, z = conj(FFT_M(conj Z')) on the passes of
 // fft_device.hpp, and x[2n] + i x[2n+1] = z[n] times the synthesis window (1/(2M) and the signs folded in) goes
 // straight to y[clip][frame][N] in 512-byte runs.  3-4 LDS round trips against log2 N barrier-separated passes.
-template <int LOG2N, int FT>
+// FUSED (hop = N / 4, FT = 16): the overlap-add happens here too, like the fft-2048 kernel below: tiles advance by 13
+// frames and start 3 early, the windowed frames stay in their LDS buffers, and the workgroup completes the 13 hops
+// of output no other frame reaches -- no scratch array, no second launch, the reference's summation order.
+struct FusedOla {
+  float *out;               // [lead; out_len]
+  int64_t out_len, left, span, head, stop;
+  const double *env_head, *env_period, *env_tail;
+  int tiles_per_clip;
+};
+
+template <int LOG2N, int FT, bool FUSED>
 __global__ void __launch_bounds__(FT * ((1 << LOG2N) / 32)) istft_stockham_frames_kernel(IstftArgs a, const float2 *w_m, const float2 *w_n,
-                                                                                        const float2 *synth_window) {
+                                                                                        const float2 *synth_window, FusedOla o) {
   using namespace fftdev;
   constexpr int N = 1 << LOG2N, LOG2M = LOG2N - 1, M = N / 2, T = M / 16, THREADS = FT * T;
   constexpr bool WAVE = T <= 64;
@@ -138,10 +148,11 @@ __global__ void __launch_bounds__(FT * ((1 << LOG2N) / 32)) istft_stockham_frame
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   float *re = reinterpret_cast<float *>(smem);
   float *im = re + (M + 1) * STRIDE;
-  const int64_t tiles = (a.count + FT - 1) / FT;
+  static_assert(!FUSED || FT == 16, "the fused tile is 16 frames: 13 complete hops");
+  const int64_t tiles = FUSED ? (int64_t)o.tiles_per_clip : (a.count + FT - 1) / FT;
   const int64_t clip = blockIdx.x / tiles, tile = blockIdx.x % tiles;
-  const int64_t f0 = tile * FT;
-  const int nf = (int)((a.count - f0) < FT ? (a.count - f0) : FT);
+  const int64_t f0 = FUSED ? 13 * tile - 3 : tile * FT;       // first frame of the tile (may be negative when fused)
+  auto valid = [&](int f) { return f0 + f >= 0 && f0 + f < a.count; };
   const float2 *z = reinterpret_cast<const float2 *>(a.z) + clip * (int64_t)(M + 1) * a.frames + f0;
   auto stage_elements = [&](auto first, auto count) {   // elements [first, first + count) of this thread's PER
     constexpr int I0 = decltype(first)::value, NI = decltype(count)::value;
@@ -151,7 +162,7 @@ __global__ void __launch_bounds__(FT * ((1 << LOG2N) / 32)) istft_stockham_frame
       const int e = threadIdx.x + THREADS * (I0 + j);
       const int row = e >> LOGFT, f = e & (FT - 1);
       v[j] = make_float2(0.f, 0.f);
-      if (row <= M && f < nf) v[j] = z[(int64_t)row * a.frames + f];
+      if (row <= M && valid(f)) v[j] = z[(int64_t)row * a.frames + f];
     }
     if (a.unit) {   // uniform: v is c_k; form unit(c_k - beta c_(k-1)) as the update kernel does
       if (a.prev) {
@@ -162,7 +173,7 @@ __global__ void __launch_bounds__(FT * ((1 << LOG2N) / 32)) istft_stockham_frame
           const int e = threadIdx.x + THREADS * (I0 + j);
           const int row = e >> LOGFT, f = e & (FT - 1);
           q[j] = make_float2(0.f, 0.f);
-          if (row <= M && f < nf) q[j] = pv[(int64_t)row * a.frames + f];
+          if (row <= M && valid(f)) q[j] = pv[(int64_t)row * a.frames + f];
         }
 #pragma unroll
         for (int j = 0; j < NI; ++j) {
@@ -185,7 +196,7 @@ __global__ void __launch_bounds__(FT * ((1 << LOG2N) / 32)) istft_stockham_frame
         const int e = threadIdx.x + THREADS * (I0 + j);
         const int row = e >> LOGFT, f = e & (FT - 1);
         m[j] = 0.f;
-        if (row <= M && f < nf) m[j] = mg[(int64_t)row * a.frames + f];
+        if (row <= M && valid(f)) m[j] = mg[(int64_t)row * a.frames + f];
       }
 #pragma unroll
       for (int j = 0; j < NI; ++j) {
@@ -212,7 +223,7 @@ __global__ void __launch_bounds__(FT * ((1 << LOG2N) / 32)) istft_stockham_frame
   }
   __syncthreads();
   const int tid = threadIdx.x % T, f = threadIdx.x / T;
-  const bool have = f < nf;                             // uniform per group of T threads
+  const bool have = valid(f);                           // uniform per group of T threads
   c32 r[16];
 #pragma unroll
   for (int m = 0; m < 16; ++m) {
@@ -229,18 +240,59 @@ __global__ void __launch_bounds__(FT * ((1 << LOG2N) / 32)) istft_stockham_frame
   }
   __syncthreads();   // every column is in registers: the planes become the frames' work buffers
   float2 *buf = reinterpret_cast<float2 *>(smem) + (size_t)f * M;
-  if (WAVE && !have) return;                            // wave-private transforms: nothing left to synchronise with
-  fft_passes<LOG2M, true, WAVE>(r, buf, tid, w_m);
-  if (!have) return;
-  float *y = reinterpret_cast<float *>(a.y) + (clip * a.count + f0 + f) * (int64_t)N;
+  if constexpr (!FUSED) {
+    if (WAVE && !have) return;                          // wave-private transforms: nothing left to synchronise with
+    fft_passes<LOG2M, true, WAVE>(r, buf, tid, w_m);
+    if (!have) return;
+    float *y = reinterpret_cast<float *>(a.y) + (clip * a.count + f0 + f) * (int64_t)N;
 #pragma unroll
-  for (int i = 0; i < GL; ++i)
+    for (int i = 0; i < GL; ++i)
 #pragma unroll
-    for (int j = 0; j < RL; ++j) {
-      const int n = out_index<RL, NSL, T>(tid, i, j);
-      const float2 w = synth_window[n];
-      reinterpret_cast<float2 *>(y)[n] = make_float2(r[i * RL + j].x * w.x, r[i * RL + j].y * w.y);
+      for (int j = 0; j < RL; ++j) {
+        const int n = out_index<RL, NSL, T>(tid, i, j);
+        const float2 w = synth_window[n];
+        reinterpret_cast<float2 *>(y)[n] = make_float2(r[i * RL + j].x * w.x, r[i * RL + j].y * w.y);
+      }
+  } else {
+    static_assert(!FUSED || WAVE, "fused tiles are for fft 512 .. 2048");
+    if (have) {
+      fft_passes<LOG2M, true, true>(r, buf, tid, w_m);
+      asm volatile("" ::: "memory");
+#pragma unroll
+      for (int i = 0; i < GL; ++i)
+#pragma unroll
+        for (int j = 0; j < RL; ++j) {
+          const int n = out_index<RL, NSL, T>(tid, i, j);
+          const float2 w = synth_window[n];
+          buf[n] = make_float2(r[i * RL + j].x * w.x, r[i * RL + j].y * w.y);   // samples 2n, 2n + 1 of the frame
+        }
     }
+    __syncthreads();
+    // overlap-add of the 13 complete hops: local position q in [3 hop, 16 hop), frame index descending (stft.ml:806-831)
+    constexpr int HOP = N / 4, LOGHOP = LOG2N - 2;
+    const float *slots = reinterpret_cast<const float *>(smem);   // frame f: N floats at f * N
+    float *out = o.out + clip * o.out_len;
+    const int64_t q0 = (int64_t)HOP * f0;
+    for (int q = 3 * HOP + (int)threadIdx.x; q < 16 * HOP; q += THREADS) {
+      const int64_t Q = q0 + q;                                   // padded position
+      const int64_t mo = Q - o.left;
+      if (mo >= 0 && mo < o.out_len) {
+        float v = 0.f;
+        if (Q < o.span) {
+          float acc = 0.f;
+          const int fh = q >> LOGHOP;
+#pragma unroll
+          for (int d = 0; d < 4; ++d) {
+            const int g = fh - d;
+            if (valid(g)) acc += slots[g * N + (q - HOP * g)];
+          }
+          const double env = Q < o.head ? o.env_head[Q] : (Q < o.stop ? o.env_period[Q & (HOP - 1)] : o.env_tail[Q - o.stop]);
+          v = (float)((double)acc / env);
+        }
+        out[mo] = v;
+      }
+    }
+  }
 }
 
 template <int LOG2N, int FT>
@@ -250,11 +302,27 @@ void launch_stockham_frames(const IstftArgs &a, const StftTables &t, hipStream_t
   const size_t lds = (planes > work ? planes : work) + 16;
   const int64_t blocks = a.lead * ((a.count + FT - 1) / FT);
   if (blocks > 2147483647LL) throw Failure("invert: too many frame tiles for one launch");
-  auto kernel = istft_stockham_frames_kernel<LOG2N, FT>;
+  auto kernel = istft_stockham_frames_kernel<LOG2N, FT, false>;
   SMX_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   hipLaunchKernelGGL(kernel, dim3((unsigned)blocks), dim3(THREADS), lds, stream, a, (const float2 *)t.fast_w_m, (const float2 *)t.fast_w_n,
-                     (const float2 *)t.fast_synth_window);
+                     (const float2 *)t.fast_synth_window, FusedOla{});
   SMX_HIP_CHECK(hipGetLastError());
+}
+
+// hop = N / 4: frames and overlap-add in one launch (fft 512 / 1024 / 2048)
+template <int LOG2N>
+bool launch_stockham_fused(const IstftArgs &a, const StftTables &t, const FusedOla &o, hipStream_t stream) {
+  constexpr int M = (1 << LOG2N) / 2, THREADS = 16 * (M / 16);
+  const size_t planes = 2 * (size_t)(M + 1) * 17 * sizeof(float), work = (size_t)16 * M * sizeof(float2);
+  const size_t lds = (planes > work ? planes : work) + 16;
+  const int64_t blocks = a.lead * (int64_t)o.tiles_per_clip;
+  if (blocks > 2147483647LL) return false;
+  auto kernel = istft_stockham_frames_kernel<LOG2N, 16, true>;
+  SMX_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  hipLaunchKernelGGL(kernel, dim3((unsigned)blocks), dim3(THREADS), lds, stream, a, (const float2 *)t.fast_w_m, (const float2 *)t.fast_w_n,
+                     (const float2 *)t.fast_synth_window, o);
+  SMX_HIP_CHECK(hipGetLastError());
+  return true;
 }
 
 // float32 spectra, float32 interior, fft 512 .. 4096: true when the Stockham frames kernel took the launch
@@ -559,7 +627,7 @@ void launch_istft(const IstftJob &job) {
   const double *d_env = env.dev;
   const int64_t head_n = env.head_n, stop = env.stop;
   // fused path: fft 2048, hop 512, complex64 spectrum, float32 interior
-  if (istft_fused_2048(job)) {
+  if (istft_fused_2048(job) && !std::getenv("SMX_ISTFT_NEW2048")) {
     SynArgs sa{};
     sa.mag = reinterpret_cast<const float *>(job.mag);
     sa.unit = job.unit ? 1 : 0;
@@ -596,6 +664,38 @@ void launch_istft(const IstftJob &job) {
       SMX_HIP_CHECK(hipGetLastError());
       return;
     }
+  }
+  // float32, fft 512 / 1024 / 2048 advanced by a quarter of the size: frames + overlap-add fused, no scratch array
+  if (!f64 && job.z_bytes == 8 && hop * 4 == fft && (fft == 512 || fft == 1024 || fft == 2048) && istft_takes_factors(job) &&
+      !std::getenv("SMX_ISTFT_UNFUSED")) {
+    IstftArgs fa{};
+    fa.z = job.z;
+    fa.lead = job.lead;
+    fa.frames = job.frames;
+    fa.bins = c.bins();
+    fa.count = count;
+    fa.fft = fft;
+    fa.hop = hop;
+    fa.mag = reinterpret_cast<const float *>(job.mag);
+    fa.prev = reinterpret_cast<const float2 *>(job.prev);
+    fa.beta = (float)job.beta;
+    fa.unit = job.unit ? 1 : 0;
+    FusedOla o{};
+    o.out = reinterpret_cast<float *>(job.out);
+    o.out_len = job.out_len;
+    o.left = c.left_width();
+    o.span = span;
+    o.head = head_n;
+    o.stop = stop;
+    o.env_head = d_env;
+    o.env_period = d_env + env.head;
+    o.env_tail = d_env + env.head + env.period;
+    const int64_t need = std::max<int64_t>(span, o.left + job.out_len);
+    o.tiles_per_clip = (int)((need + hop * 13 - 1) / (hop * 13));
+    const bool done = fft == 512 ? launch_stockham_fused<9>(fa, t, o, job.stream)
+                    : fft == 1024 ? launch_stockham_fused<10>(fa, t, o, job.stream)
+                                  : launch_stockham_fused<11>(fa, t, o, job.stream);
+    if (done) return;
   }
   // clips in chunks so that the windowed frames y stay within ~1 GiB
   const size_t acc_bytes = f64 ? 8 : 4;

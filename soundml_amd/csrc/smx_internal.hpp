@@ -211,6 +211,8 @@ void launch_stft(const StftJob &job);             // dispatch: fast path or gene
 void launch_stft_generic(const StftJob &job);     // stft_generic.hip
 bool launch_stft_fast(const StftJob &job);        // stft_fast.hip; false = not eligible
 bool fast_path_disabled();                        // env SMX_DISABLE_FAST=1 (tests)
+void init_device_pool();                          // tables.cpp: once per device, keeps freed scratch for reuse
+void set_scratch_retention(int64_t bytes);        // tables.cpp
 
 // Stft.invert (stft.ml:902-939) on device-resident data
 struct IstftJob {

@@ -21,9 +21,44 @@ T *upload(const std::vector<T> &host) {
 bool is_pow2(int64_t n) { return n >= 1 && (n & (n - 1)) == 0; }
 
 }  // namespace
+
+// Scratch arrays (Griffin-Lim's spectra, the scratch spectrogram of the unfused compositions, small tables) come
+// from the device's stream-ordered pool.  Left at its default the pool hands everything back to the driver at every
+// synchronisation, and the next call pays the mapping again (measured: Griffin-Lim on the C2 batch 315 ms instead of
+// 104).  Keep up to `bytes` of freed memory for reuse; the default, applied once per device, is 1/8 of its memory.
+static std::mutex g_pool_mutex;
+static std::map<int, bool> g_pool_done;
+static int64_t g_pool_bytes = -1;   // < 0: the default
+
+void set_scratch_retention(int64_t bytes) {
+  std::lock_guard<std::mutex> lock(g_pool_mutex);
+  g_pool_bytes = bytes;
+  g_pool_done.clear();
+}
+
+void init_device_pool() {
+  int device = 0;
+  if (hipGetDevice(&device) != hipSuccess) return;
+  std::lock_guard<std::mutex> lock(g_pool_mutex);
+  if (g_pool_done[device]) return;
+  g_pool_done[device] = true;
+  hipMemPool_t pool = nullptr;
+  if (hipDeviceGetDefaultMemPool(&pool, device) != hipSuccess || !pool) return;
+  uint64_t threshold = 0;
+  if (g_pool_bytes >= 0) {
+    threshold = (uint64_t)g_pool_bytes;
+  } else {
+    size_t free_b = 0, total_b = 0;
+    if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) return;
+    threshold = (uint64_t)total_b / 8;
+  }
+  (void)hipMemPoolSetAttribute(pool, hipMemPoolAttrReleaseThreshold, &threshold);
+}
+
 }  // namespace smx
 
 const smx::StftTables &smx_stft_config::tables() const {
+  smx::init_device_pool();
   int device = 0;
   SMX_HIP_CHECK(hipGetDevice(&device));
   std::lock_guard<std::mutex> lock(mutex_);
@@ -251,6 +286,7 @@ smx_stft_config::~smx_stft_config() {
 }
 
 const smx_mel_config::Tables &smx_mel_config::tables() const {
+  smx::init_device_pool();
   int device = 0;
   SMX_HIP_CHECK(hipGetDevice(&device));
   std::lock_guard<std::mutex> lock(mutex_);
@@ -299,6 +335,7 @@ smx_mel_config::~smx_mel_config() {
 }
 
 const double *smx_chroma_config::device_weights() const {
+  smx::init_device_pool();
   int device = 0;
   SMX_HIP_CHECK(hipGetDevice(&device));
   std::lock_guard<std::mutex> lock(mutex_);
