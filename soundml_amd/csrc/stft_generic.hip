@@ -686,6 +686,115 @@ bool launch_stockham_power16(const StftJob &job, GenericArgs a, const StftTables
   return true;
 }
 
+// ---- fft 512 / 1024, float32, complex output: the same stage-free scheme for Stft.transform ---------------------
+// A frame's spectrum is M + 1 complex values, one more than its work buffer holds -- but X[0] and X[M] are both real,
+// so X[M] rides in the imaginary slot of X[0].  There is no spare room to rotate the columns; position k of frame f
+// sits at k ^ f instead (f < 16 stays inside k's aligned group of 16), which leaves the flush -- a lane takes two
+// frames of one bin, 16 bytes -- with 2-way bank conflicts at worst.
+template <int LOG2N, typename Tin>
+__global__ void __launch_bounds__(1 << (LOG2N - 1)) stft_stockham_complex16_kernel(GenericArgs a, const float2 *tw_m, const float2 *tw_n) {
+  using namespace fftdev;
+  constexpr int N = 1 << LOG2N, LOG2M = LOG2N - 1, M = N / 2, T = M / 16, FT = 16;
+  static_assert(T <= 64, "wave-private transforms");
+  constexpr int RL = LastPass<LOG2M>::R, NSL = LastPass<LOG2M>::NS, GL = 16 / RL;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  float2 *work = reinterpret_cast<float2 *>(smem);
+  const int64_t tiles = (a.count + FT - 1) / FT;
+  const int64_t clip = blockIdx.x / tiles, tile = blockIdx.x % tiles;
+  const Tin *x = reinterpret_cast<const Tin *>(a.x) + clip * a.x_stride;
+  const float *window = reinterpret_cast<const float *>(a.window);       // 0.5 * analysis window
+  const int tid = threadIdx.x % T, f = threadIdx.x / T;
+  float2 *z = work + (size_t)f * M;
+  const int64_t f0 = tile * FT;
+  const int nf = (int)((a.count - f0) < FT ? (a.count - f0) : FT);
+  const bool have = f < nf;
+  c32 r[16];
+  if (have) {
+    const int64_t s0 = (a.p0 + f0 + f) * a.hop - a.left;
+    if (s0 >= 0 && s0 + N <= a.n) {
+      const Tin *xs = x + s0;
+#pragma unroll
+      for (int m = 0; m < 16; ++m) {
+        const int i = 2 * (tid + T * m);
+        r[m] = {(float)xs[i] * window[i], (float)xs[i + 1] * window[i + 1]};
+      }
+    } else {
+#pragma unroll 1
+      for (int m = 0; m < 16; ++m) {
+        const int i = 2 * (tid + T * m);
+        const float v0 = (float)fetch_sample<Tin>(x, a.n, s0 + i, a.pad, a.pad_value) * window[i];
+        const float v1 = (float)fetch_sample<Tin>(x, a.n, s0 + i + 1, a.pad, a.pad_value) * window[i + 1];
+#pragma unroll
+        for (int mm = 0; mm < 16; ++mm)
+          if (mm == m) r[mm] = {v0, v1};
+      }
+    }
+  } else {
+#pragma unroll
+    for (int m = 0; m < 16; ++m) r[m] = {0.0f, 0.0f};
+  }
+  fft_passes<LOG2M, true, true>(r, z, tid, tw_m);
+#pragma unroll
+  for (int i = 0; i < GL; ++i)
+#pragma unroll
+    for (int j = 0; j < RL; ++j) z[swz(out_index<RL, NSL, T>(tid, i, j))] = make_float2(r[i * RL + j].x, r[i * RL + j].y);
+  stockham_sync<true>();
+  float2 val[16];
+#pragma unroll
+  for (int m = 0; m < 16; ++m) {
+    const int k = tid + T * m;
+    const float2 zk = z[swz(k)], zm = z[swz((M - k) & (M - 1))];
+    const float er = zk.x + zm.x, ei = zk.y - zm.y;
+    const float dr = zk.x - zm.x, di = zk.y + zm.y;
+    const float2 w = tw_n[k];
+    val[m] = make_float2(er + (w.x * di + w.y * dr), ei - (w.x * dr - w.y * di));
+    if (k == 0) val[m] = make_float2(2.0f * (zk.x + zk.y), 2.0f * (zk.x - zk.y));   // (X[0], X[M]): both real
+  }
+  stockham_sync<true>();   // every read of this frame's Z is done: reuse its buffer
+#pragma unroll
+  for (int m = 0; m < 16; ++m) z[(tid + T * m) ^ f] = val[m];
+  __syncthreads();
+  float2 *out = reinterpret_cast<float2 *>(a.out);
+  const int64_t obase = clip * a.bins * a.out_stride + a.out_offset + f0;
+  if (nf == FT) {   // a lane takes two frames of one bin: two LDS reads, one 16-byte store; bins 0 and M unpack (X[0], X[M])
+    using f32x4 = __attribute__((ext_vector_type(4))) float;
+    for (int e = threadIdx.x; e < (M + 1) * 8; e += blockDim.x) {
+      const int k = e >> 3, g = 2 * (e & 7);
+      const int kk = k == M ? 0 : k;
+      float2 c0 = work[g * M + (kk ^ g)], c1 = work[(g + 1) * M + (kk ^ (g + 1))];
+      if (k == 0) { c0.y = 0.0f; c1.y = 0.0f; }
+      if (k == M) { c0 = make_float2(c0.y, 0.0f); c1 = make_float2(c1.y, 0.0f); }
+      const f32x4 v = {c0.x, c0.y, c1.x, c1.y};
+      float2 *dst = out + obase + (int64_t)k * a.out_stride + g;
+      asm volatile("global_store_dwordx4 %0, %1, off" : : "v"(dst), "v"(v) : "memory");
+    }
+    return;
+  }
+  for (int e = threadIdx.x; e < (M + 1) * nf; e += blockDim.x) {   // a clip's ragged last tile
+    const int k = e / nf, g = e - k * nf;
+    const int kk = k == M ? 0 : k;
+    float2 c = work[g * M + (kk ^ g)];
+    if (k == 0) c.y = 0.0f;
+    if (k == M) c = make_float2(c.y, 0.0f);
+    out[obase + (int64_t)k * a.out_stride + g] = c;
+  }
+}
+
+template <int LOG2N>
+bool launch_stockham_complex16(const StftJob &job, GenericArgs a, const StftTables &t) {
+  constexpr int M = (1 << LOG2N) / 2;
+  if (!t.fast_window || !t.fast_w_m || !t.fast_w_n) return false;
+  a.window = t.fast_window;
+  const int64_t blocks = a.lead * ((a.count + 15) / 16);
+  if (blocks > 2147483647LL) throw Failure("stft: too many frame tiles for one launch");
+  const size_t lds = (size_t)16 * M * sizeof(float2);
+  auto kernel = stft_stockham_complex16_kernel<LOG2N, float>;
+  SMX_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  hipLaunchKernelGGL(kernel, dim3((unsigned)blocks), dim3(M), lds, job.stream, a, (const float2 *)t.fast_w_m, (const float2 *)t.fast_w_n);
+  SMX_HIP_CHECK(hipGetLastError());
+  return true;
+}
+
 // float32 audio with the float64 interior, power output: the stage-free kernel on doubles (FT frames of M double2)
 template <int LOG2N, int FT>
 bool launch_stockham_power16_wide(const StftJob &job, GenericArgs a, const StftTables &t) {
@@ -1169,6 +1278,9 @@ void launch_stft_generic(const StftJob &job) {
     const bool real_form = !(cf && cf[0] == '1') && c.fft_size <= 2048;
     const char *sf = std::getenv("SMX_STOCKHAM_STAGED");   // diagnostic: the staged kernel for fft 512 / 1024 power too
     const bool power16 = real_form && job.mode != OUT_COMPLEX && !(sf && sf[0] == '1');
+    const bool complex16 = real_form && job.mode == OUT_COMPLEX && !(sf && sf[0] == '1');
+    if (complex16 && c.fft_size == 512) done = launch_stockham_complex16<9>(job, a, t);
+    if (complex16 && c.fft_size == 1024) done = launch_stockham_complex16<10>(job, a, t);
     if (power16 && c.fft_size == 512) done = launch_stockham_power16<9>(job, a, t);
     if (power16 && c.fft_size == 1024) done = launch_stockham_power16<10>(job, a, t);
     if (power16 && c.fft_size == 2048) done = launch_stockham_power16<11>(job, a, t);      // where the fused kernels do not apply
