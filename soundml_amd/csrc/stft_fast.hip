@@ -1350,6 +1350,8 @@ bool fast_eligible(const StftJob &job) {
   const smx_stft_config &c = *job.cfg;
   if (fast_path_disabled()) return false;
   if (c.fft_size != kN || job.in_bytes != 4 || job.interior != SMX_INTERIOR_F32) return false;
+  if (const char *e = std::getenv("SMX_GENERIC_2048"))   // diagnostic: time the stage-free generic kernels at fft 2048
+    if (e[0] == '1') return false;
   if (job.lead > 65535) return false;
   return true;
 }

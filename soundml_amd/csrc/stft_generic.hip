@@ -1281,6 +1281,7 @@ void launch_stft_generic(const StftJob &job) {
     const bool complex16 = real_form && job.mode == OUT_COMPLEX && !(sf && sf[0] == '1');
     if (complex16 && c.fft_size == 512) done = launch_stockham_complex16<9>(job, a, t);
     if (complex16 && c.fft_size == 1024) done = launch_stockham_complex16<10>(job, a, t);
+    if (complex16 && c.fft_size == 2048) done = launch_stockham_complex16<11>(job, a, t);   // where the fused kernels do not apply
     if (power16 && c.fft_size == 512) done = launch_stockham_power16<9>(job, a, t);
     if (power16 && c.fft_size == 1024) done = launch_stockham_power16<10>(job, a, t);
     if (power16 && c.fft_size == 2048) done = launch_stockham_power16<11>(job, a, t);      // where the fused kernels do not apply
