@@ -503,11 +503,11 @@ struct MelTail {
 // The common tail of the stage-free kernels: FT power columns lie in LDS, frame f at cols + f * BUF + 2 f (BUF floats
 // per frame buffer, `bins` values each).  MEL: banded filterbank x columns on the fp32 MFMA, [n_mels; 16] out;
 // otherwise the columns leave as 16-byte stores of 4 frames of one bin.
-template <int BUF, int FT, bool MEL>
-__device__ __forceinline__ void columns_out(const GenericArgs &a, const MelTail &mt, const float *cols, int bins, int nf,
+template <int BUF, int FT, bool MEL, typename Tout = float>
+__device__ __forceinline__ void columns_out(const GenericArgs &a, const MelTail &mt, const Tout *cols, int bins, int nf,
                                             int64_t clip, int64_t f0) {
   if constexpr (MEL) {
-    static_assert(!MEL || FT == 16, "the MFMA tile is 16 frames wide");
+    static_assert(!MEL || (FT == 16 && sizeof(Tout) == 4), "the MFMA tile is 16 float32 frames wide");
     using f32x4 = __attribute__((ext_vector_type(4))) float;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
     const int n = lane & 15, kk = lane >> 4;           // B[k = kk][n = frame], A[m = n][k = kk], D[4 kk + i][n]
@@ -558,16 +558,22 @@ __device__ __forceinline__ void columns_out(const GenericArgs &a, const MelTail 
   }
   const int total = bins * nf;
   const int64_t obase = clip * a.bins * a.out_stride + a.out_offset + f0;
-  float *out = reinterpret_cast<float *>(a.out);
-  if (nf == FT) {   // a lane takes 4 frames of one bin: four conflict-free LDS reads, one 16-byte store (4-byte aligned)
-    using f32x4 = __attribute__((ext_vector_type(4))) float;
-    constexpr int QF = FT / 4;                           // frame quads per bin
+  Tout *out = reinterpret_cast<Tout *>(a.out);
+  if (nf == FT) {   // a lane takes 16 bytes of one bin's row (4 float or 2 double frames): conflict-free LDS reads, one store
+    constexpr int PER = 16 / sizeof(Tout), QF = FT / PER;
     for (int e = threadIdx.x; e < bins * QF; e += blockDim.x) {
-      const int k = e / QF, g = 4 * (e % QF);
-      const float *src = cols + g * (BUF) + 2 * g + k;
-      const f32x4 v = {src[0], src[BUF + 2], src[2 * (BUF + 2)], src[3 * (BUF + 2)]};
-      float *dst = out + obase + (int64_t)k * a.out_stride + g;
-      asm volatile("global_store_dwordx4 %0, %1, off" : : "v"(dst), "v"(v) : "memory");
+      const int k = e / QF, g = PER * (e % QF);
+      const Tout *src = cols + g * (BUF) + 2 * g + k;
+      Tout *dst = out + obase + (int64_t)k * a.out_stride + g;
+      if constexpr (sizeof(Tout) == 4) {
+        using f32x4 = __attribute__((ext_vector_type(4))) float;
+        const f32x4 v = {src[0], src[BUF + 2], src[2 * (BUF + 2)], src[3 * (BUF + 2)]};
+        asm volatile("global_store_dwordx4 %0, %1, off" : : "v"(dst), "v"(v) : "memory");
+      } else {
+        using f64x2 = __attribute__((ext_vector_type(2))) double;
+        const f64x2 v = {src[0], src[BUF + 2]};
+        asm volatile("global_store_dwordx4 %0, %1, off" : : "v"(dst), "v"(v) : "memory");
+      }
     }
     return;
   }
@@ -579,7 +585,7 @@ __device__ __forceinline__ void columns_out(const GenericArgs &a, const MelTail 
 
 // S = double: the float64 interior for float32 audio (window, transform and |.|^p in float64, one rounding into the
 // float32 column), fewer frames per workgroup since a frame's buffer is twice as large.
-template <int LOG2N, typename Tin, bool MEL, int FT, typename S = float>
+template <int LOG2N, typename Tin, bool MEL, int FT, typename S = float, typename Tout = float>
 __global__ void __launch_bounds__(FT * ((1 << LOG2N) / 32)) stft_stockham_power16_kernel(GenericArgs a, const typename fftdev::vec2_of<S>::type *tw_m,
                                                                                  const typename fftdev::vec2_of<S>::type *tw_n, MelTail mt) {
   using namespace fftdev;
@@ -636,7 +642,7 @@ __global__ void __launch_bounds__(FT * ((1 << LOG2N) / 32)) stft_stockham_power1
       z[swz(out_index<RL, NSL, T>(tid, i, j))] = o;
     }
   stockham_sync<WAVE>();
-  float val[16], nyq = 0.0f;
+  Tout val[16], nyq = (Tout)0;
 #pragma unroll
   for (int m = 0; m < 16; ++m) {
     const int k = tid + T * m;
@@ -644,19 +650,19 @@ __global__ void __launch_bounds__(FT * ((1 << LOG2N) / 32)) stft_stockham_power1
     const S er = zk.x + zm.x, ei = zk.y - zm.y;
     const S dr = zk.x - zm.x, di = zk.y + zm.y;
     const V w = tw_n[k];
-    val[m] = magnitude_pow<S, float>(er + (w.x * di + w.y * dr), ei - (w.x * dr - w.y * di), a.power);
+    val[m] = magnitude_pow<S, Tout>(er + (w.x * di + w.y * dr), ei - (w.x * dr - w.y * di), a.power);
   }
   if (tid == 0) {
     const V z0 = z[0];
-    nyq = magnitude_pow<S, float>((S)2 * (z0.x - z0.y), (S)0, a.power);
+    nyq = magnitude_pow<S, Tout>((S)2 * (z0.x - z0.y), (S)0, a.power);
   }
   stockham_sync<WAVE>();   // every read of this frame's Z is done (the frame's threads share a wave, or a barrier): reuse its buffer
-  float *col = reinterpret_cast<float *>(z) + 2 * f;
+  Tout *col = reinterpret_cast<Tout *>(z) + 2 * f;
 #pragma unroll
   for (int m = 0; m < 16; ++m) col[tid + T * m] = val[m];
   if (tid == 0) col[M] = nyq;
   __syncthreads();
-  columns_out<(int)(M * sizeof(V) / sizeof(float)), FT, MEL>(a, mt, reinterpret_cast<const float *>(work), M + 1, nf, clip, f0);
+  columns_out<(int)(M * sizeof(V) / sizeof(Tout)), FT, MEL, Tout>(a, mt, reinterpret_cast<const Tout *>(work), M + 1, nf, clip, f0);
 }
 
 template <int LOG2N, int FT = 16>
@@ -795,8 +801,9 @@ bool launch_stockham_complex16(const StftJob &job, GenericArgs a, const StftTabl
   return true;
 }
 
-// float32 audio with the float64 interior, power output: the stage-free kernel on doubles (FT frames of M double2)
-template <int LOG2N, int FT>
+// the float64 interior, power output: the stage-free kernel on doubles (FT frames of M double2), float32 audio with
+// float32 columns or float64 audio with float64 ones
+template <int LOG2N, int FT, typename Tio>
 bool launch_stockham_power16_wide(const StftJob &job, GenericArgs a, const StftTables &t) {
   constexpr int M = (1 << LOG2N) / 2, THREADS = FT * (M / 16);
   static_assert(THREADS <= 512, "16 complex doubles per thread need the 256-register budget");
@@ -805,12 +812,23 @@ bool launch_stockham_power16_wide(const StftJob &job, GenericArgs a, const StftT
   const int64_t blocks = a.lead * ((a.count + FT - 1) / FT);
   if (blocks > 2147483647LL) throw Failure("stft: too many frame tiles for one launch");
   const size_t lds = (size_t)FT * M * sizeof(double2);
-  auto kernel = stft_stockham_power16_kernel<LOG2N, float, false, FT, double>;
+  auto kernel = stft_stockham_power16_kernel<LOG2N, Tio, false, FT, double, Tio>;
   SMX_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   hipLaunchKernelGGL(kernel, dim3((unsigned)blocks), dim3(THREADS), lds, job.stream, a, (const double2 *)t.fast_w_m_f64,
                      (const double2 *)t.twiddle_f64, MelTail{});
   SMX_HIP_CHECK(hipGetLastError());
   return true;
+}
+
+template <typename Tio>
+bool launch_stockham_power16_wide_any(const StftJob &job, const GenericArgs &a, const StftTables &t, int64_t fft) {
+  switch (fft) {
+    case 512: return launch_stockham_power16_wide<9, 16, Tio>(job, a, t);
+    case 1024: return launch_stockham_power16_wide<10, 16, Tio>(job, a, t);
+    case 2048: return launch_stockham_power16_wide<11, 8, Tio>(job, a, t);
+    case 4096: return launch_stockham_power16_wide<12, 4, Tio>(job, a, t);
+    default: return false;
+  }
 }
 
 // ---- any other size up to 8192, float32 interior: chirp-z (Bluestein) on the same Stockham passes ------------
@@ -1326,17 +1344,11 @@ void launch_stft_generic(const StftJob &job) {
     }
     if (done) return;
   }
-  if (f64_interior && job.in_bytes == 4 && job.mode != OUT_COMPLEX && !fast_path_disabled()) {   // stage-free, float32 columns
+  if (f64_interior && job.mode != OUT_COMPLEX && !fast_path_disabled()) {   // stage-free power kernel on doubles
     const char *sfw = std::getenv("SMX_STOCKHAM_STAGED");
-    bool done = false;
-    if (!(sfw && sfw[0] == '1')) switch (c.fft_size) {
-      case 512: done = launch_stockham_power16_wide<9, 16>(job, a, t); break;
-      case 1024: done = launch_stockham_power16_wide<10, 16>(job, a, t); break;
-      case 2048: done = launch_stockham_power16_wide<11, 8>(job, a, t); break;
-      case 4096: done = launch_stockham_power16_wide<12, 4>(job, a, t); break;
-      default: break;
-    }
-    if (done) return;
+    if (!(sfw && sfw[0] == '1') && (job.in_bytes == 8 ? launch_stockham_power16_wide_any<double>(job, a, t, c.fft_size)
+                                                        : launch_stockham_power16_wide_any<float>(job, a, t, c.fft_size)))
+      return;
   }
   if (f64_interior && !fast_path_disabled()) {   // float64 interior on the Stockham passes (fft 512 .. 4096)
     if (job.in_bytes == 8 ? launch_stockham_wide<double, double>(job, a, t, c.fft_size)

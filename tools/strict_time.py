@@ -22,3 +22,17 @@ for name in ("float32", "float64"):
         a.record(); run(); b.record(); torch.cuda.synchronize(); ts.append(a.elapsed_time(b))
     ms = sorted(ts)[2]
     print("interior %s: %.3f ms  %.1f Mframes/s" % (name, ms, clips * frames / ms / 1e3))
+
+# float64 audio (float64 spectrogram out): always the float64 interior
+x64 = x.double()
+out64 = torch.empty(clips, 1025, frames, device="cuda", dtype=torch.float64)
+def run64():
+    check(lib.smx_stft_power_range_f64_dev(c._h, vp(x64.data_ptr()), clips, n, n, 0, frames, 2.0, vp(out64.data_ptr()), None))
+for _ in range(2): run64()
+torch.cuda.synchronize()
+ts = []
+for _ in range(5):
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record(); run64(); b.record(); torch.cuda.synchronize(); ts.append(a.elapsed_time(b))
+ms = sorted(ts)[2]
+print("float64 audio: %.3f ms  %.1f Mframes/s" % (ms, clips * frames / ms / 1e3))
