@@ -135,6 +135,9 @@ struct smx_mel_config {
     int64_t n_mels_pad = 0, k_pad = 0;
     // banded form: first/last non-zero bin per mel row
     int *band_lo = nullptr, *band_hi = nullptr;
+    // the same per tile of 16 rows (rows without weights do not count; an empty tile is lo = hi = 0)
+    int *tile_lo = nullptr, *tile_hi = nullptr;
+    float *w_tile = nullptr;   // [n_mels_pad / 16][k_pad / 4][64]: w_f32 in MFMA A-operand order (16x16x4)
   };
   const Tables &tables() const;
   const smx::MelFusedPlan &fused_plan() const;   // stft_fast.hip

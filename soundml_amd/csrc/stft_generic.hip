@@ -494,8 +494,8 @@ bool launch_stockham_wide(const StftJob &job, const GenericArgs &a, const StftTa
 // columns on v_mfma_f32_16x16x4_f32, one 16-row tile of W per wave at a time over the tile's own band of bins, and
 // the [n_mels; 16 frames] block goes out as 64-byte row runs (Soundml.mel_spectrogram for fft 512 / 1024).
 struct MelTail {
-  const float *w;             // [n_mels_pad; k_pad]
-  const int *band_lo, *band_hi;
+  const float *w;             // [n_mels_pad / 16][k_pad / 4][64]: the weights in MFMA A-operand order
+  const int *band_lo, *band_hi;   // per 16-row tile: first / one-past-last bin any of its rows touches
   int n_mels, k_pad;
   float *out;                 // [lead; n_mels; count]
 };
@@ -503,49 +503,83 @@ struct MelTail {
 // The common tail of the stage-free kernels: FT power columns lie in LDS, frame f at cols + f * BUF + 2 f (BUF floats
 // per frame buffer, `bins` values each).  MEL: banded filterbank x columns on the fp32 MFMA, [n_mels; 16] out;
 // otherwise the columns leave as 16-byte stores of 4 frames of one bin.
+// the (lo, hi) bin range of the first two row tiles a wave will take, fetched at kernel entry so that the mel tail does
+// not start with a memory round trip (measured: that wait, per workgroup, was most of the tail)
+struct TileBands {
+  int lo[2], hi[2];
+};
+template <bool MEL>
+__device__ __forceinline__ TileBands load_tile_bands(const MelTail &mt) {
+  TileBands tb{{0, 0}, {0, 0}};
+  if constexpr (MEL) {
+    const int wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int t = wave + i * nwaves;
+      if (16 * t < mt.n_mels) {
+        tb.lo[i] = mt.band_lo[t];
+        tb.hi[i] = mt.band_hi[t];
+      }
+    }
+  }
+  return tb;
+}
+
 template <int BUF, int FT, bool MEL, typename Tout = float>
 __device__ __forceinline__ void columns_out(const GenericArgs &a, const MelTail &mt, const Tout *cols, int bins, int nf,
-                                            int64_t clip, int64_t f0) {
+                                            int64_t clip, int64_t f0, const TileBands &tb = TileBands{}) {
   if constexpr (MEL) {
     static_assert(!MEL || (FT == 16 && sizeof(Tout) == 4), "the MFMA tile is 16 float32 frames wide");
     using f32x4 = __attribute__((ext_vector_type(4))) float;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
     const int n = lane & 15, kk = lane >> 4;           // B[k = kk][n = frame], A[m = n][k = kk], D[4 kk + i][n]
     const float *colb = cols + n * (BUF) + 2 * n + kk;
-    for (int r0 = 16 * wave; r0 < mt.n_mels; r0 += 16 * nwaves) {
-      // bins any of the tile's 16 rows touches (rows without weights -- the padding -- do not count)
-      int lo = 0x7fffffff, hi = 0;
-      {
-        const int l = mt.band_lo[r0 + n], h = mt.band_hi[r0 + n];
-        if (h > l) {
-          lo = l;
-          hi = h;
-        }
-      }
-#pragma unroll
-      for (int d = 1; d < 16; d <<= 1) {
-        const int ol = __shfl_xor(lo, d), oh = __shfl_xor(hi, d);
-        lo = ol < lo ? ol : lo;
-        hi = oh > hi ? oh : hi;
-      }
+    int ti = 0;
+    for (int r0 = 16 * wave; r0 < mt.n_mels; r0 += 16 * nwaves, ++ti) {
+      // bins any of the tile's 16 rows touches (host-built per tile; the first two came in at kernel entry)
+      int lo, hi;
+      if (ti == 0) { lo = tb.lo[0]; hi = tb.hi[0]; }
+      else if (ti == 1) { lo = tb.lo[1]; hi = tb.hi[1]; }
+      else { lo = mt.band_lo[r0 >> 4]; hi = mt.band_hi[r0 >> 4]; }
       lo = __builtin_amdgcn_readfirstlane(lo);
       hi = __builtin_amdgcn_readfirstlane(hi);
       f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-      const float *wa = mt.w + (int64_t)(r0 + n) * mt.k_pad + kk;
-      // four k-steps (16 bins) per trip, operands fetched first; the trips may run past the band: W is zero there
+      const float *wt = mt.w + (int64_t)(r0 >> 4) * (mt.k_pad / 4) * 64 + lane;   // this tile's operands, this lane's slot
+      // four k-steps (16 bins) per trip, operands fetched first; the weights are in operand order (one 256-byte run per
+      // load); the trips may run past the band: W is zero there
       const int k_begin = lo & ~15;                          // 16-aligned trips never straddle the end of a padded row
       int k_end = k_begin + (hi - k_begin + 15) / 16 * 16;
       k_end = k_end < mt.k_pad ? k_end : mt.k_pad;          // k_pad is a multiple of 32
-      for (int k0 = k_begin; k0 < k_end; k0 += 16) {
-        float av[4], bv[4];
+      f32x4 acc1 = {0.f, 0.f, 0.f, 0.f};                    // two chains: half of the multiply-adds wait for each other
+      int k0 = k_begin;
+      for (; k0 + 32 <= k_end; k0 += 32) {                   // two trips' operands in flight together
+        float av[8], bv[8];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          av[j] = wa[k0 + 4 * j];
+        for (int j = 0; j < 8; ++j) {
+          av[j] = wt[(k0 / 4 + j) * 64];
           bv[j] = k0 + 4 * j + kk < bins ? colb[k0 + 4 * j] : 0.0f;   // past the Nyquist bin the column is not defined
         }
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[j], bv[j], acc, 0, 0, 0);
+        for (int j = 0; j < 8; j += 2) {
+          acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[j], bv[j], acc, 0, 0, 0);
+          acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[j + 1], bv[j + 1], acc1, 0, 0, 0);
+        }
       }
+      for (; k0 < k_end; k0 += 16) {
+        float av[4], bv[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          av[j] = wt[(k0 / 4 + j) * 64];
+          bv[j] = k0 + 4 * j + kk < bins ? colb[k0 + 4 * j] : 0.0f;
+        }
+#pragma unroll
+        for (int j = 0; j < 4; j += 2) {
+          acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[j], bv[j], acc, 0, 0, 0);
+          acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[j + 1], bv[j + 1], acc1, 0, 0, 0);
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i) acc[i] += acc1[i];
       if (n < nf) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
@@ -606,6 +640,7 @@ __global__ void __launch_bounds__(FT * ((1 << LOG2N) / 32)) stft_stockham_power1
   const int64_t f0 = tile * FT;
   const int nf = (int)((a.count - f0) < FT ? (a.count - f0) : FT);
   const bool have = f < nf;                            // uniform per group of T threads
+  const TileBands tb = load_tile_bands<MEL>(mt);
   cpx<S> r[16];
   if (have) {
     const int64_t s0 = (a.p0 + f0 + f) * a.hop - a.left;
@@ -662,7 +697,7 @@ __global__ void __launch_bounds__(FT * ((1 << LOG2N) / 32)) stft_stockham_power1
   for (int m = 0; m < 16; ++m) col[tid + T * m] = val[m];
   if (tid == 0) col[M] = nyq;
   __syncthreads();
-  columns_out<(int)(M * sizeof(V) / sizeof(Tout)), FT, MEL, Tout>(a, mt, reinterpret_cast<const Tout *>(work), M + 1, nf, clip, f0);
+  columns_out<(int)(M * sizeof(V) / sizeof(Tout)), FT, MEL, Tout>(a, mt, reinterpret_cast<const Tout *>(work), M + 1, nf, clip, f0, tb);
 }
 
 template <int LOG2N, int FT = 16>
@@ -1042,6 +1077,7 @@ __global__ void __launch_bounds__(1 << LOG2M) stft_bluestein_power16_kernel(Gene
   const int64_t f0 = tile * FT;
   const int nf = (int)((a.count - f0) < FT ? (a.count - f0) : FT);
   const bool have = f < nf;
+  const TileBands tb = load_tile_bands<MEL>(mt);
   c32 r[16];
 #pragma unroll
   for (int m = 0; m < 16; ++m) r[m] = {0.0f, 0.0f};
@@ -1108,7 +1144,7 @@ __global__ void __launch_bounds__(1 << LOG2M) stft_bluestein_power16_kernel(Gene
   }
   if (tid == 0) col[L] = nyq;
   __syncthreads();
-  columns_out<2 * M, FT, MEL>(a, mt, reinterpret_cast<const float *>(work), L + 1, nf, clip, f0);
+  columns_out<2 * M, FT, MEL>(a, mt, reinterpret_cast<const float *>(work), L + 1, nf, clip, f0, tb);
 }
 
 template <int LOG2M>
@@ -1253,10 +1289,12 @@ bool launch_mel_spectrogram_16(const MelSpecJob &job) {
   a.power = sj.power;
   a.bins = c.bins();
   MelTail mt{};
-  mt.w = mtab.w_f32;
-  mt.band_lo = mtab.band_lo;
-  mt.band_hi = mtab.band_hi;
+  mt.w = mtab.w_tile;
+  mt.band_lo = mtab.tile_lo;
+  mt.band_hi = mtab.tile_hi;
   mt.n_mels = (int)job.mel->n_mels;
+  if (const char *e = std::getenv("SMX_MEL16_NOTAIL"))   // diagnostic (timing only): the kernel without its MFMA tail
+    if (e[0] == '1') mt.n_mels = 0;
   mt.k_pad = (int)mtab.k_pad;
   mt.out = reinterpret_cast<float *>(job.out);
   if (chirp_16) return launch_bluestein16_any(sj, a, t, &mt);

@@ -316,8 +316,38 @@ const smx_mel_config::Tables &smx_mel_config::tables() const {
     hi[(size_t)m] = last < 0 ? 0 : last + 1;
   }
   t.w_f32 = smx::upload(w32);
+  {
+    // the same weights in MFMA-operand order for the 16-frame kernels' tail: per 16-row tile and 4-bin k-step the 64
+    // lane values of v_mfma_f32_16x16x4_f32's A operand (lane l: row l & 15, bin l >> 4) lie contiguously, so a wave's
+    // load is one 256-byte run instead of sixteen 16-byte pieces of sixteen rows
+    const int64_t tiles = t.n_mels_pad / 16, steps = t.k_pad / 4;
+    std::vector<float> wt((size_t)(tiles * steps * 64), 0.0f);
+    for (int64_t tt = 0; tt < tiles; ++tt)
+      for (int64_t k4 = 0; k4 < steps; ++k4)
+        for (int l = 0; l < 64; ++l)
+          wt[(size_t)((tt * steps + k4) * 64 + l)] = w32[(size_t)((16 * tt + (l & 15)) * t.k_pad + 4 * k4 + (l >> 4))];
+    t.w_tile = smx::upload(wt);
+  }
   t.band_lo = smx::upload(lo);
   t.band_hi = smx::upload(hi);
+  {
+    const int64_t tiles = t.n_mels_pad / 16;
+    std::vector<int> tlo((size_t)tiles, 0), thi((size_t)tiles, 0);
+    for (int64_t tt = 0; tt < tiles; ++tt) {
+      int l = 0x7fffffff, h = 0;
+      for (int64_t r = 16 * tt; r < 16 * tt + 16; ++r)
+        if (hi[(size_t)r] > lo[(size_t)r]) {
+          l = std::min(l, lo[(size_t)r]);
+          h = std::max(h, hi[(size_t)r]);
+        }
+      if (h > 0) {
+        tlo[(size_t)tt] = l;
+        thi[(size_t)tt] = h;
+      }
+    }
+    t.tile_lo = smx::upload(tlo);
+    t.tile_hi = smx::upload(thi);
+  }
   return tables_.emplace(device, t).first->second;
 }
 
@@ -327,6 +357,9 @@ smx_mel_config::~smx_mel_config() {
     (void)hipFree(kv.second.w_f32);
     (void)hipFree(kv.second.band_lo);
     (void)hipFree(kv.second.band_hi);
+    (void)hipFree(kv.second.tile_lo);
+    (void)hipFree(kv.second.w_tile);
+    (void)hipFree(kv.second.tile_hi);
   }
   for (auto &kv : fused_) {
     (void)hipFree(kv.second.items);
