@@ -19,7 +19,8 @@ using f32x16 = __attribute__((ext_vector_type(16))) float;
 struct MelArgs {
   const void *s;
   void *out;
-  const float *w32;      // [n_mels_pad][k_pad]
+  const float *w_block;  // [n_mels_pad / 32][k_pad / 2][64]: weights in MFMA A-operand order
+  const int *block_lo, *block_hi;
   const double *w64;     // [n_mels][bins]
   const int *band_lo, *band_hi;
   int64_t lead, frames;
@@ -39,25 +40,29 @@ __global__ void __launch_bounds__(256) mel_apply_mfma_kernel(MelArgs a) {
   const int64_t ta_c = ta < a.frames ? ta : a.frames - 1;
   const int64_t tb_c = tb < a.frames ? tb : a.frames - 1;
   for (int mb = wave; mb < a.mel_blocks; mb += 4) {
-    // union of the block's band supports (wave-uniform)
-    int klo = a.bins, khi = 0;
-    for (int m = mb * 32; m < mb * 32 + 32 && m < a.n_mels; ++m) {
-      const int lo = a.band_lo[m], hi = a.band_hi[m];
-      klo = lo < klo ? lo : klo;
-      khi = hi > khi ? hi : khi;
-    }
-    klo &= ~1;
+    // the block's band (host-built, wave-uniform) and its weights in operand order: one 256-byte run per k-step
+    const int klo = __builtin_amdgcn_readfirstlane(a.block_lo[mb]) & ~7;
+    const int khi = __builtin_amdgcn_readfirstlane(a.block_hi[mb]);
     f32x16 acc0 = {0}, acc1 = {0};
-    const float *wrow = a.w32 + (int64_t)(mb * 32 + col) * a.k_pad + half;
-    for (int k = klo; k < khi; k += 2) {
-      const int kk = k + half;
-      const float av = wrow[k];                                   // W[m0 + col][k + half] (zero padded)
-      const bool ok = kk < a.bins;
-      const int64_t row = (int64_t)(ok ? kk : 0) * a.frames;
-      const float b0 = ok ? S[row + ta_c] : 0.0f;                 // S[k + half][t0 + col]
-      const float b1 = ok ? S[row + tb_c] : 0.0f;
-      acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(av, b0, acc0, 0, 0, 0);
-      acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(av, b1, acc1, 0, 0, 0);
+    const float *wb = a.w_block + (int64_t)mb * (a.k_pad / 2) * 64 + lane;
+    // four k-steps (8 bins) per trip, every operand fetched before the first multiply-add; trips may run past the
+    // band (W is zero there; k_pad is a multiple of 32) but never past the spectrogram's last bin
+    for (int k = klo; k < khi; k += 8) {
+      float av[4], b0[4], b1[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int kk = k + 2 * j + half;
+        av[j] = wb[(int64_t)(k / 2 + j) * 64];                     // W[m0 + col][k + 2 j + half]
+        const bool ok = kk < a.bins;
+        const int64_t row = (int64_t)(ok ? kk : 0) * a.frames;
+        b0[j] = ok ? S[row + ta_c] : 0.0f;                         // S[kk][t0 + col]
+        b1[j] = ok ? S[row + tb_c] : 0.0f;
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(av[j], b0[j], acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(av[j], b1[j], acc1, 0, 0, 0);
+      }
     }
     // C/D map: col = lane & 31, row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5)
 #pragma unroll
@@ -96,7 +101,9 @@ void launch_mel_apply(const MelJob &job) {
   MelArgs a{};
   a.s = job.s;
   a.out = job.out;
-  a.w32 = t.w_f32;
+  a.w_block = t.w_block;
+  a.block_lo = t.block_lo;
+  a.block_hi = t.block_hi;
   a.w64 = t.w_f64;
   a.band_lo = t.band_lo;
   a.band_hi = t.band_hi;

@@ -138,6 +138,8 @@ struct smx_mel_config {
     // the same per tile of 16 rows (rows without weights do not count; an empty tile is lo = hi = 0)
     int *tile_lo = nullptr, *tile_hi = nullptr;
     float *w_tile = nullptr;   // [n_mels_pad / 16][k_pad / 4][64]: w_f32 in MFMA A-operand order (16x16x4)
+    float *w_block = nullptr;  // [n_mels_pad / 32][k_pad / 2][64]: the same for 32x32x2 (Mel.apply)
+    int *block_lo = nullptr, *block_hi = nullptr;   // band per 32-row block
   };
   const Tables &tables() const;
   const smx::MelFusedPlan &fused_plan() const;   // stft_fast.hip

@@ -328,6 +328,32 @@ const smx_mel_config::Tables &smx_mel_config::tables() const {
           wt[(size_t)((tt * steps + k4) * 64 + l)] = w32[(size_t)((16 * tt + (l & 15)) * t.k_pad + 4 * k4 + (l >> 4))];
     t.w_tile = smx::upload(wt);
   }
+  {
+    // and for Mel.apply's v_mfma_f32_32x32x2_f32 (lane l: row l & 31, bin l >> 5): per 32-row block and 2-bin k-step the
+    // 64 lane values contiguous, plus each block's band
+    const int64_t blocks = t.n_mels_pad / 32, steps = t.k_pad / 2;
+    std::vector<float> wb((size_t)(blocks * steps * 64), 0.0f);
+    for (int64_t bb = 0; bb < blocks; ++bb)
+      for (int64_t k2 = 0; k2 < steps; ++k2)
+        for (int l = 0; l < 64; ++l)
+          wb[(size_t)((bb * steps + k2) * 64 + l)] = w32[(size_t)((32 * bb + (l & 31)) * t.k_pad + 2 * k2 + (l >> 5))];
+    t.w_block = smx::upload(wb);
+    std::vector<int> blo((size_t)blocks, 0), bhi((size_t)blocks, 0);
+    for (int64_t bb = 0; bb < blocks; ++bb) {
+      int l = 0x7fffffff, h = 0;
+      for (int64_t r = 32 * bb; r < 32 * bb + 32; ++r)
+        if (hi[(size_t)r] > lo[(size_t)r]) {
+          l = std::min(l, lo[(size_t)r]);
+          h = std::max(h, hi[(size_t)r]);
+        }
+      if (h > 0) {
+        blo[(size_t)bb] = l;
+        bhi[(size_t)bb] = h;
+      }
+    }
+    t.block_lo = smx::upload(blo);
+    t.block_hi = smx::upload(bhi);
+  }
   t.band_lo = smx::upload(lo);
   t.band_hi = smx::upload(hi);
   {
@@ -359,6 +385,9 @@ smx_mel_config::~smx_mel_config() {
     (void)hipFree(kv.second.band_hi);
     (void)hipFree(kv.second.tile_lo);
     (void)hipFree(kv.second.w_tile);
+    (void)hipFree(kv.second.w_block);
+    (void)hipFree(kv.second.block_lo);
+    (void)hipFree(kv.second.block_hi);
     (void)hipFree(kv.second.tile_hi);
   }
   for (auto &kv : fused_) {
