@@ -136,7 +136,7 @@ struct FusedOla {
   int tiles_per_clip;
 };
 
-template <int LOG2N, int FT, bool FUSED>
+template <int LOG2N, int FT, int RATIO>   // RATIO = N / hop of the fused form (4 or 2), 0 = frames only
 __global__ void __launch_bounds__(FT * ((1 << LOG2N) / 32)) istft_stockham_frames_kernel(IstftArgs a, const float2 *w_m, const float2 *w_n,
                                                                                         const float2 *synth_window, FusedOla o) {
   using namespace fftdev;
@@ -148,10 +148,13 @@ __global__ void __launch_bounds__(FT * ((1 << LOG2N) / 32)) istft_stockham_frame
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   float *re = reinterpret_cast<float *>(smem);
   float *im = re + (M + 1) * STRIDE;
-  static_assert(!FUSED || FT == 16, "the fused tile is 16 frames: 13 complete hops");
+  constexpr bool FUSED = RATIO != 0;
+  constexpr int LAP = FUSED ? RATIO - 1 : 0, ADV = 16 - LAP;   // frames re-inverted per tile / complete hops per tile
+  static_assert(!FUSED || FT == 16, "the fused tile is 16 frames");
+  static_assert(RATIO == 0 || RATIO == 4 || RATIO == 2, "hop = N / 4 or N / 2");
   const int64_t tiles = FUSED ? (int64_t)o.tiles_per_clip : (a.count + FT - 1) / FT;
   const int64_t clip = blockIdx.x / tiles, tile = blockIdx.x % tiles;
-  const int64_t f0 = FUSED ? 13 * tile - 3 : tile * FT;       // first frame of the tile (may be negative when fused)
+  const int64_t f0 = FUSED ? ADV * tile - LAP : tile * FT;    // first frame of the tile (may be negative when fused)
   auto valid = [&](int f) { return f0 + f >= 0 && f0 + f < a.count; };
   const float2 *z = reinterpret_cast<const float2 *>(a.z) + clip * (int64_t)(M + 1) * a.frames + f0;
   auto stage_elements = [&](auto first, auto count) {   // elements [first, first + count) of this thread's PER
@@ -268,12 +271,12 @@ __global__ void __launch_bounds__(FT * ((1 << LOG2N) / 32)) istft_stockham_frame
         }
     }
     __syncthreads();
-    // overlap-add of the 13 complete hops: local position q in [3 hop, 16 hop), frame index descending (stft.ml:806-831)
-    constexpr int HOP = N / 4, LOGHOP = LOG2N - 2;
+    // overlap-add of the complete hops: local position q in [LAP hop, 16 hop), frame index descending (stft.ml:806-831)
+    constexpr int HOP = FUSED ? N / RATIO : N, LOGHOP = FUSED ? (RATIO == 4 ? LOG2N - 2 : LOG2N - 1) : LOG2N;
     const float *slots = reinterpret_cast<const float *>(smem);   // frame f: N floats at f * N
     float *out = o.out + clip * o.out_len;
     const int64_t q0 = (int64_t)HOP * f0;
-    for (int q = 3 * HOP + (int)threadIdx.x; q < 16 * HOP; q += THREADS) {
+    for (int q = LAP * HOP + (int)threadIdx.x; q < 16 * HOP; q += THREADS) {
       const int64_t Q = q0 + q;                                   // padded position
       const int64_t mo = Q - o.left;
       if (mo >= 0 && mo < o.out_len) {
@@ -282,7 +285,7 @@ __global__ void __launch_bounds__(FT * ((1 << LOG2N) / 32)) istft_stockham_frame
           float acc = 0.f;
           const int fh = q >> LOGHOP;
 #pragma unroll
-          for (int d = 0; d < 4; ++d) {
+          for (int d = 0; d <= LAP; ++d) {
             const int g = fh - d;
             if (valid(g)) acc += slots[g * N + (q - HOP * g)];
           }
@@ -302,22 +305,22 @@ void launch_stockham_frames(const IstftArgs &a, const StftTables &t, hipStream_t
   const size_t lds = (planes > work ? planes : work) + 16;
   const int64_t blocks = a.lead * ((a.count + FT - 1) / FT);
   if (blocks > 2147483647LL) throw Failure("invert: too many frame tiles for one launch");
-  auto kernel = istft_stockham_frames_kernel<LOG2N, FT, false>;
+  auto kernel = istft_stockham_frames_kernel<LOG2N, FT, 0>;
   SMX_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   hipLaunchKernelGGL(kernel, dim3((unsigned)blocks), dim3(THREADS), lds, stream, a, (const float2 *)t.fast_w_m, (const float2 *)t.fast_w_n,
                      (const float2 *)t.fast_synth_window, FusedOla{});
   SMX_HIP_CHECK(hipGetLastError());
 }
 
-// hop = N / 4: frames and overlap-add in one launch (fft 512 / 1024 / 2048)
-template <int LOG2N>
+// hop = N / 4 or N / 2: frames and overlap-add in one launch (fft 512 / 1024 / 2048)
+template <int LOG2N, int RATIO>
 bool launch_stockham_fused(const IstftArgs &a, const StftTables &t, const FusedOla &o, hipStream_t stream) {
   constexpr int M = (1 << LOG2N) / 2, THREADS = 16 * (M / 16);
   const size_t planes = 2 * (size_t)(M + 1) * 17 * sizeof(float), work = (size_t)16 * M * sizeof(float2);
   const size_t lds = (planes > work ? planes : work) + 16;
   const int64_t blocks = a.lead * (int64_t)o.tiles_per_clip;
   if (blocks > 2147483647LL) return false;
-  auto kernel = istft_stockham_frames_kernel<LOG2N, 16, true>;
+  auto kernel = istft_stockham_frames_kernel<LOG2N, 16, RATIO>;
   SMX_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   hipLaunchKernelGGL(kernel, dim3((unsigned)blocks), dim3(THREADS), lds, stream, a, (const float2 *)t.fast_w_m, (const float2 *)t.fast_w_n,
                      (const float2 *)t.fast_synth_window, o);
@@ -665,8 +668,8 @@ void launch_istft(const IstftJob &job) {
       return;
     }
   }
-  // float32, fft 512 / 1024 / 2048 advanced by a quarter of the size: frames + overlap-add fused, no scratch array
-  if (!f64 && job.z_bytes == 8 && hop * 4 == fft && (fft == 512 || fft == 1024 || fft == 2048) && istft_takes_factors(job) &&
+  // float32, fft 512 / 1024 / 2048 advanced by a quarter or a half of the size: frames + overlap-add fused, no scratch array
+  if (!f64 && job.z_bytes == 8 && (hop * 4 == fft || hop * 2 == fft) && (fft == 512 || fft == 1024 || fft == 2048) && istft_takes_factors(job) &&
       !std::getenv("SMX_ISTFT_UNFUSED")) {
     IstftArgs fa{};
     fa.z = job.z;
@@ -691,10 +694,12 @@ void launch_istft(const IstftJob &job) {
     o.env_period = d_env + env.head;
     o.env_tail = d_env + env.head + env.period;
     const int64_t need = std::max<int64_t>(span, o.left + job.out_len);
-    o.tiles_per_clip = (int)((need + hop * 13 - 1) / (hop * 13));
-    const bool done = fft == 512 ? launch_stockham_fused<9>(fa, t, o, job.stream)
-                    : fft == 1024 ? launch_stockham_fused<10>(fa, t, o, job.stream)
-                                  : launch_stockham_fused<11>(fa, t, o, job.stream);
+    const int64_t adv = hop * 4 == fft ? 13 : 15;      // complete hops per 16-frame tile
+    o.tiles_per_clip = (int)((need + hop * adv - 1) / (hop * adv));
+    const bool quarter = hop * 4 == fft;
+    const bool done = fft == 512 ? (quarter ? launch_stockham_fused<9, 4>(fa, t, o, job.stream) : launch_stockham_fused<9, 2>(fa, t, o, job.stream))
+                    : fft == 1024 ? (quarter ? launch_stockham_fused<10, 4>(fa, t, o, job.stream) : launch_stockham_fused<10, 2>(fa, t, o, job.stream))
+                                  : (quarter ? launch_stockham_fused<11, 4>(fa, t, o, job.stream) : launch_stockham_fused<11, 2>(fa, t, o, job.stream));
     if (done) return;
   }
   // clips in chunks so that the windowed frames y stay within ~1 GiB

@@ -393,7 +393,8 @@ def test_invert_goldens(vectors):
                                                    (64, 16, None, "centered"), (48, 12, None, "centered"), (31, 5, None, "left"),
                                                    (64, 60, None, "centered"), (100, 33, 64, "right"),
                                                    (512, 128, None, "centered"), (1024, 256, 800, "left"), (2048, 500, None, "centered"),
-                                                   (4096, 1024, None, "centered")])
+                                                   (4096, 1024, None, "centered"), (1024, 512, None, "centered"), (512, 256, 400, "left"),
+                                                   (2048, 1024, None, "right")])
 @pytest.mark.parametrize("length_mode", ["default", "short", "long"])
 def test_invert_vs_oracle(fft, hop, win, alignment, length_mode):
     """Random (inconsistent) spectra: the least-squares solution itself, every alignment, power-of-two and other
