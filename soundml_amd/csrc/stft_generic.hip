@@ -732,24 +732,30 @@ bool launch_stockham_power16(const StftJob &job, GenericArgs a, const StftTables
 // so X[M] rides in the imaginary slot of X[0].  There is no spare room to rotate the columns; position k of frame f
 // sits at k ^ f instead (f < 16 stays inside k's aligned group of 16), which leaves the flush -- a lane takes two
 // frames of one bin, 16 bytes -- with 2-way bank conflicts at worst.
-template <int LOG2N, typename Tin>
-__global__ void __launch_bounds__(1 << (LOG2N - 1)) stft_stockham_complex16_kernel(GenericArgs a, const float2 *tw_m, const float2 *tw_n) {
+template <int LOG2N, typename Tin, int FT = 16, typename S = float, typename Tout = float>
+__global__ void __launch_bounds__(FT * ((1 << LOG2N) / 32)) stft_stockham_complex16_kernel(GenericArgs a, const typename fftdev::vec2_of<S>::type *tw_m,
+                                                                                           const typename fftdev::vec2_of<S>::type *tw_n) {
   using namespace fftdev;
-  constexpr int N = 1 << LOG2N, LOG2M = LOG2N - 1, M = N / 2, T = M / 16, FT = 16;
-  static_assert(T <= 64, "wave-private transforms");
+  using V = typename vec2_of<S>::type;
+  using CO = typename Vec2<Tout>::type;
+  constexpr int N = 1 << LOG2N, LOG2M = LOG2N - 1, M = N / 2, T = M / 16;
+  constexpr bool WAVE = T <= 64;
+  constexpr S kHalf = sizeof(S) == 8 ? (S)0.5 : (S)1.0;   // float32: the window table is pre-halved
+  static_assert(FT == 16 || FT == 8 || FT == 4, "frames per workgroup");
   constexpr int RL = LastPass<LOG2M>::R, NSL = LastPass<LOG2M>::NS, GL = 16 / RL;
+  constexpr int CSTRIDE = (int)(M * sizeof(V) / sizeof(CO));    // output elements per frame buffer
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  float2 *work = reinterpret_cast<float2 *>(smem);
+  V *work = reinterpret_cast<V *>(smem);
   const int64_t tiles = (a.count + FT - 1) / FT;
   const int64_t clip = blockIdx.x / tiles, tile = blockIdx.x % tiles;
   const Tin *x = reinterpret_cast<const Tin *>(a.x) + clip * a.x_stride;
-  const float *window = reinterpret_cast<const float *>(a.window);       // 0.5 * analysis window
+  const S *window = reinterpret_cast<const S *>(a.window);
   const int tid = threadIdx.x % T, f = threadIdx.x / T;
-  float2 *z = work + (size_t)f * M;
+  V *z = work + (size_t)f * M;
   const int64_t f0 = tile * FT;
   const int nf = (int)((a.count - f0) < FT ? (a.count - f0) : FT);
   const bool have = f < nf;
-  c32 r[16];
+  cpx<S> r[16];
   if (have) {
     const int64_t s0 = (a.p0 + f0 + f) * a.hop - a.left;
     if (s0 >= 0 && s0 + N <= a.n) {
@@ -757,14 +763,14 @@ __global__ void __launch_bounds__(1 << (LOG2N - 1)) stft_stockham_complex16_kern
 #pragma unroll
       for (int m = 0; m < 16; ++m) {
         const int i = 2 * (tid + T * m);
-        r[m] = {(float)xs[i] * window[i], (float)xs[i + 1] * window[i + 1]};
+        r[m] = {(S)xs[i] * window[i] * kHalf, (S)xs[i + 1] * window[i + 1] * kHalf};
       }
     } else {
 #pragma unroll 1
       for (int m = 0; m < 16; ++m) {
         const int i = 2 * (tid + T * m);
-        const float v0 = (float)fetch_sample<Tin>(x, a.n, s0 + i, a.pad, a.pad_value) * window[i];
-        const float v1 = (float)fetch_sample<Tin>(x, a.n, s0 + i + 1, a.pad, a.pad_value) * window[i + 1];
+        const S v0 = (S)fetch_sample<Tin>(x, a.n, s0 + i, a.pad, a.pad_value) * window[i] * kHalf;
+        const S v1 = (S)fetch_sample<Tin>(x, a.n, s0 + i + 1, a.pad, a.pad_value) * window[i + 1] * kHalf;
 #pragma unroll
         for (int mm = 0; mm < 16; ++mm)
           if (mm == m) r[mm] = {v0, v1};
@@ -772,52 +778,71 @@ __global__ void __launch_bounds__(1 << (LOG2N - 1)) stft_stockham_complex16_kern
     }
   } else {
 #pragma unroll
-    for (int m = 0; m < 16; ++m) r[m] = {0.0f, 0.0f};
+    for (int m = 0; m < 16; ++m) r[m] = {(S)0, (S)0};
   }
-  fft_passes<LOG2M, true, true>(r, z, tid, tw_m);
+  fft_passes<LOG2M, true, WAVE>(r, z, tid, tw_m);
 #pragma unroll
   for (int i = 0; i < GL; ++i)
 #pragma unroll
-    for (int j = 0; j < RL; ++j) z[swz(out_index<RL, NSL, T>(tid, i, j))] = make_float2(r[i * RL + j].x, r[i * RL + j].y);
-  stockham_sync<true>();
-  float2 val[16];
+    for (int j = 0; j < RL; ++j) {
+      V o;
+      o.x = r[i * RL + j].x;
+      o.y = r[i * RL + j].y;
+      z[swz(out_index<RL, NSL, T>(tid, i, j))] = o;
+    }
+  stockham_sync<WAVE>();
+  CO val[16];
 #pragma unroll
   for (int m = 0; m < 16; ++m) {
     const int k = tid + T * m;
-    const float2 zk = z[swz(k)], zm = z[swz((M - k) & (M - 1))];
-    const float er = zk.x + zm.x, ei = zk.y - zm.y;
-    const float dr = zk.x - zm.x, di = zk.y + zm.y;
-    const float2 w = tw_n[k];
-    val[m] = make_float2(er + (w.x * di + w.y * dr), ei - (w.x * dr - w.y * di));
-    if (k == 0) val[m] = make_float2(2.0f * (zk.x + zk.y), 2.0f * (zk.x - zk.y));   // (X[0], X[M]): both real
+    const V zk = z[swz(k)], zm = z[swz((M - k) & (M - 1))];
+    const S er = zk.x + zm.x, ei = zk.y - zm.y;
+    const S dr = zk.x - zm.x, di = zk.y + zm.y;
+    const V w = tw_n[k];
+    val[m].x = (Tout)(er + (w.x * di + w.y * dr));
+    val[m].y = (Tout)(ei - (w.x * dr - w.y * di));
+    if (k == 0) {                                       // (X[0], X[M]): both real
+      val[m].x = (Tout)((S)2 * (zk.x + zk.y));
+      val[m].y = (Tout)((S)2 * (zk.x - zk.y));
+    }
   }
-  stockham_sync<true>();   // every read of this frame's Z is done: reuse its buffer
+  stockham_sync<WAVE>();   // every read of this frame's Z is done: reuse its buffer
+  CO *col = reinterpret_cast<CO *>(z);
 #pragma unroll
-  for (int m = 0; m < 16; ++m) z[(tid + T * m) ^ f] = val[m];
+  for (int m = 0; m < 16; ++m) col[(tid + T * m) ^ f] = val[m];
   __syncthreads();
-  float2 *out = reinterpret_cast<float2 *>(a.out);
+  const CO *cols = reinterpret_cast<const CO *>(work);
+  CO *out = reinterpret_cast<CO *>(a.out);
   const int64_t obase = clip * a.bins * a.out_stride + a.out_offset + f0;
-  if (nf == FT) {   // a lane takes two frames of one bin: two LDS reads, one 16-byte store; bins 0 and M unpack (X[0], X[M])
-    using f32x4 = __attribute__((ext_vector_type(4))) float;
-    for (int e = threadIdx.x; e < (M + 1) * 8; e += blockDim.x) {
-      const int k = e >> 3, g = 2 * (e & 7);
-      const int kk = k == M ? 0 : k;
-      float2 c0 = work[g * M + (kk ^ g)], c1 = work[(g + 1) * M + (kk ^ (g + 1))];
-      if (k == 0) { c0.y = 0.0f; c1.y = 0.0f; }
-      if (k == M) { c0 = make_float2(c0.y, 0.0f); c1 = make_float2(c1.y, 0.0f); }
-      const f32x4 v = {c0.x, c0.y, c1.x, c1.y};
-      float2 *dst = out + obase + (int64_t)k * a.out_stride + g;
-      asm volatile("global_store_dwordx4 %0, %1, off" : : "v"(dst), "v"(v) : "memory");
+  auto fetch = [&](int k, int g) {   // X[k] of frame g; bins 0 and M unpack (X[0], X[M])
+    const int kk = k == M ? 0 : k;
+    CO c = cols[g * CSTRIDE + (kk ^ g)];
+    if (k == 0) c.y = (Tout)0;
+    if (k == M) {
+      c.x = c.y;
+      c.y = (Tout)0;
+    }
+    return c;
+  };
+  if (nf == FT) {   // a lane takes 16 bytes of one bin's row: two complex64 frames or one complex128
+    constexpr int PER = 16 / sizeof(CO), QF = FT / PER;
+    for (int e = threadIdx.x; e < (M + 1) * QF; e += blockDim.x) {
+      const int k = e / QF, g = PER * (e % QF);
+      CO *dst = out + obase + (int64_t)k * a.out_stride + g;
+      if constexpr (sizeof(CO) == 8) {
+        using f32x4 = __attribute__((ext_vector_type(4))) float;
+        const CO c0 = fetch(k, g), c1 = fetch(k, g + 1);
+        const f32x4 v = {(float)c0.x, (float)c0.y, (float)c1.x, (float)c1.y};
+        asm volatile("global_store_dwordx4 %0, %1, off" : : "v"(dst), "v"(v) : "memory");
+      } else {
+        *dst = fetch(k, g);
+      }
     }
     return;
   }
   for (int e = threadIdx.x; e < (M + 1) * nf; e += blockDim.x) {   // a clip's ragged last tile
     const int k = e / nf, g = e - k * nf;
-    const int kk = k == M ? 0 : k;
-    float2 c = work[g * M + (kk ^ g)];
-    if (k == 0) c.y = 0.0f;
-    if (k == M) c = make_float2(c.y, 0.0f);
-    out[obase + (int64_t)k * a.out_stride + g] = c;
+    out[obase + (int64_t)k * a.out_stride + g] = fetch(k, g);
   }
 }
 
@@ -834,6 +859,35 @@ bool launch_stockham_complex16(const StftJob &job, GenericArgs a, const StftTabl
   hipLaunchKernelGGL(kernel, dim3((unsigned)blocks), dim3(M), lds, job.stream, a, (const float2 *)t.fast_w_m, (const float2 *)t.fast_w_n);
   SMX_HIP_CHECK(hipGetLastError());
   return true;
+}
+
+// the float64 interior, complex output: float32 audio -> complex64, float64 audio -> complex128
+template <int LOG2N, int FT, typename Tio>
+bool launch_stockham_complex16_wide(const StftJob &job, GenericArgs a, const StftTables &t) {
+  constexpr int M = (1 << LOG2N) / 2, THREADS = FT * (M / 16);
+  static_assert(THREADS <= 512, "16 complex doubles per thread need the 256-register budget");
+  if (!t.window_f64 || !t.fast_w_m_f64 || !t.twiddle_f64) return false;
+  a.window = t.window_f64;
+  const int64_t blocks = a.lead * ((a.count + FT - 1) / FT);
+  if (blocks > 2147483647LL) throw Failure("stft: too many frame tiles for one launch");
+  const size_t lds = (size_t)FT * M * sizeof(double2);
+  auto kernel = stft_stockham_complex16_kernel<LOG2N, Tio, FT, double, Tio>;
+  SMX_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  hipLaunchKernelGGL(kernel, dim3((unsigned)blocks), dim3(THREADS), lds, job.stream, a, (const double2 *)t.fast_w_m_f64,
+                     (const double2 *)t.twiddle_f64);
+  SMX_HIP_CHECK(hipGetLastError());
+  return true;
+}
+
+template <typename Tio>
+bool launch_stockham_complex16_wide_any(const StftJob &job, const GenericArgs &a, const StftTables &t, int64_t fft) {
+  switch (fft) {
+    case 512: return launch_stockham_complex16_wide<9, 16, Tio>(job, a, t);
+    case 1024: return launch_stockham_complex16_wide<10, 16, Tio>(job, a, t);
+    case 2048: return launch_stockham_complex16_wide<11, 8, Tio>(job, a, t);
+    case 4096: return launch_stockham_complex16_wide<12, 4, Tio>(job, a, t);
+    default: return false;
+  }
 }
 
 // the float64 interior, power output: the stage-free kernel on doubles (FT frames of M double2), float32 audio with
@@ -1381,6 +1435,12 @@ void launch_stft_generic(const StftJob &job) {
       }
     }
     if (done) return;
+  }
+  if (f64_interior && job.mode == OUT_COMPLEX && !fast_path_disabled()) {   // stage-free complex kernel on doubles
+    const char *sfw = std::getenv("SMX_STOCKHAM_STAGED");
+    if (!(sfw && sfw[0] == '1') && (job.in_bytes == 8 ? launch_stockham_complex16_wide_any<double>(job, a, t, c.fft_size)
+                                                        : launch_stockham_complex16_wide_any<float>(job, a, t, c.fft_size)))
+      return;
   }
   if (f64_interior && job.mode != OUT_COMPLEX && !fast_path_disabled()) {   // stage-free power kernel on doubles
     const char *sfw = std::getenv("SMX_STOCKHAM_STAGED");

@@ -36,3 +36,18 @@ for _ in range(5):
     a.record(); run64(); b.record(); torch.cuda.synchronize(); ts.append(a.elapsed_time(b))
 ms = sorted(ts)[2]
 print("float64 audio: %.3f ms  %.1f Mframes/s" % (ms, clips * frames / ms / 1e3))
+
+# complex spectra with the float64 interior (float32 audio -> complex64)
+outc = torch.empty(clips, 1025, frames, 2, device="cuda")
+S.set_interior("float64")
+def runc():
+    check(lib.smx_stft_transform_range_f32_dev(c._h, vp(x.data_ptr()), clips, n, n, 0, frames, vp(outc.data_ptr()), None))
+for _ in range(2): runc()
+torch.cuda.synchronize()
+ts = []
+for _ in range(5):
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record(); runc(); b.record(); torch.cuda.synchronize(); ts.append(a.elapsed_time(b))
+S.set_interior("float32")
+ms = sorted(ts)[2]
+print("transform, interior float64: %.3f ms  %.1f Mframes/s" % (ms, clips * frames / ms / 1e3))
