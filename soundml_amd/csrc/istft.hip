@@ -298,6 +298,107 @@ __global__ void __launch_bounds__(FT * ((1 << LOG2N) / 32)) istft_stockham_frame
   }
 }
 
+// The float64 interior (complex128 spectra, or complex64 under the float64 interior): the same frames kernel on
+// doubles, frames only -- the windowed frames go to the float64 scratch array and istft_ola_kernel adds them up.
+template <int LOG2N, int FT, typename Tz>
+__global__ void __launch_bounds__(FT * ((1 << LOG2N) / 32)) istft_stockham_frames_wide_kernel(IstftArgs a, const double2 *w_m, const double2 *w_n,
+                                                                                             const double2 *synth_window) {
+  using namespace fftdev;
+  using CZ = typename Vec2<Tz>::type;
+  constexpr int N = 1 << LOG2N, LOG2M = LOG2N - 1, M = N / 2, T = M / 16, THREADS = FT * T;
+  constexpr bool WAVE = T <= 64;
+  constexpr int RL = LastPass<LOG2M>::R, NSL = LastPass<LOG2M>::NS, GL = 16 / RL;
+  constexpr int STRIDE = FT + 1, LOGFT = FT == 16 ? 4 : (FT == 8 ? 3 : (FT == 4 ? 2 : 1));
+  constexpr int PER = ((M + 1) * FT + THREADS - 1) / THREADS;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  double *re = reinterpret_cast<double *>(smem);
+  double *im = re + (M + 1) * STRIDE;
+  const int64_t tiles = (a.count + FT - 1) / FT;
+  const int64_t clip = blockIdx.x / tiles, tile = blockIdx.x % tiles;
+  const int64_t f0 = tile * FT;
+  const int nf = (int)((a.count - f0) < FT ? (a.count - f0) : FT);
+  const CZ *z = reinterpret_cast<const CZ *>(a.z) + clip * (int64_t)(M + 1) * a.frames + f0;
+  {
+    CZ v[PER];
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+      const int e = threadIdx.x + THREADS * i;
+      const int row = e >> LOGFT, f = e & (FT - 1);
+      v[i].x = (Tz)0;
+      v[i].y = (Tz)0;
+      if (row <= M && f < nf) v[i] = z[(int64_t)row * a.frames + f];
+    }
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+      const int e = threadIdx.x + THREADS * i;
+      const int row = e >> LOGFT, f = e & (FT - 1);
+      if (row <= M) {
+        re[row * STRIDE + f] = (double)v[i].x;
+        im[row * STRIDE + f] = (double)v[i].y;
+      }
+    }
+  }
+  __syncthreads();
+  const int tid = threadIdx.x % T, f = threadIdx.x / T;
+  const bool have = f < nf;
+  c64 r[16];
+#pragma unroll
+  for (int m = 0; m < 16; ++m) {
+    const int k = tid + T * m, km = M - k;
+    double zr = re[k * STRIDE + f], zi = im[k * STRIDE + f];
+    double pr = re[km * STRIDE + f], pi = im[km * STRIDE + f];
+    if (k == 0) { zi = 0.0; pi = 0.0; }
+    const double er = zr + pr, ei = zi - pi;
+    const double dr = zr - pr, di = zi + pi;
+    const double2 w = w_n[k];
+    const double tr = er - (w.x * di - w.y * dr);
+    const double ti = ei + (w.x * dr + w.y * di);
+    r[m] = {tr, -ti};
+  }
+  __syncthreads();
+  double2 *buf = reinterpret_cast<double2 *>(smem) + (size_t)f * M;
+  if (WAVE && !have) return;
+  fft_passes<LOG2M, true, WAVE>(r, buf, tid, w_m);
+  if (!have) return;
+  double *y = reinterpret_cast<double *>(a.y) + (clip * a.count + f0 + f) * (int64_t)N;
+#pragma unroll
+  for (int i = 0; i < GL; ++i)
+#pragma unroll
+    for (int j = 0; j < RL; ++j) {
+      const int n = out_index<RL, NSL, T>(tid, i, j);
+      const double2 w = synth_window[n];
+      reinterpret_cast<double2 *>(y)[n] = make_double2(r[i * RL + j].x * w.x, r[i * RL + j].y * w.y);
+    }
+}
+
+template <int LOG2N, int FT, typename Tz>
+void launch_stockham_frames_wide(const IstftArgs &a, const StftTables &t, hipStream_t stream) {
+  constexpr int M = (1 << LOG2N) / 2, THREADS = FT * (M / 16);
+  static_assert(THREADS <= 512, "16 complex doubles per thread need the 256-register budget");
+  const size_t planes = 2 * (size_t)(M + 1) * (FT + 1) * sizeof(double), work = (size_t)FT * M * sizeof(double2);
+  const size_t lds = (planes > work ? planes : work) + 16;
+  const int64_t blocks = a.lead * ((a.count + FT - 1) / FT);
+  if (blocks > 2147483647LL) throw Failure("invert: too many frame tiles for one launch");
+  auto kernel = istft_stockham_frames_wide_kernel<LOG2N, FT, Tz>;
+  SMX_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  hipLaunchKernelGGL(kernel, dim3((unsigned)blocks), dim3(THREADS), lds, stream, a, (const double2 *)t.fast_w_m_f64, (const double2 *)t.twiddle_f64,
+                     (const double2 *)t.fast_synth_window_f64);
+  SMX_HIP_CHECK(hipGetLastError());
+}
+
+template <typename Tz>
+bool launch_stockham_frames_wide_any(const IstftArgs &a, const StftTables &t, hipStream_t stream) {
+  static const bool fast_off = std::getenv("SMX_DISABLE_FAST") != nullptr;
+  if (fast_off || std::getenv("SMX_ISTFT_RADIX2") || !t.fast_w_m_f64 || !t.twiddle_f64 || !t.fast_synth_window_f64) return false;
+  switch (a.fft) {
+    case 512: launch_stockham_frames_wide<9, 16, Tz>(a, t, stream); return true;
+    case 1024: launch_stockham_frames_wide<10, 8, Tz>(a, t, stream); return true;
+    case 2048: launch_stockham_frames_wide<11, 8, Tz>(a, t, stream); return true;
+    case 4096: launch_stockham_frames_wide<12, 2, Tz>(a, t, stream); return true;   // two float64 planes of 4 frames exceed the LDS
+    default: return false;
+  }
+}
+
 template <int LOG2N, int FT>
 void launch_stockham_frames(const IstftArgs &a, const StftTables &t, hipStream_t stream) {
   constexpr int M = (1 << LOG2N) / 2, THREADS = FT * (M / 16);
@@ -729,8 +830,11 @@ void launch_istft(const IstftJob &job) {
     fa.prev = job.prev ? reinterpret_cast<const float2 *>(job.prev) + c0 * c.bins() * job.frames : nullptr;
     fa.beta = (float)job.beta;
     fa.unit = job.unit ? 1 : 0;
-    if (job.z_bytes == 16) launch_frames<double, double>(job, fa, job.stream);
-    else if (f64) launch_frames<float, double>(job, fa, job.stream);
+    if (job.z_bytes == 16) {
+      if (!launch_stockham_frames_wide_any<double>(fa, t, job.stream)) launch_frames<double, double>(job, fa, job.stream);
+    } else if (f64) {
+      if (!launch_stockham_frames_wide_any<float>(fa, t, job.stream)) launch_frames<float, double>(job, fa, job.stream);
+    }
     else if (!launch_stockham_frames_any(fa, t, job.stream)) launch_frames<float, float>(job, fa, job.stream);
     OlaArgs oa{};
     oa.y = d_y;

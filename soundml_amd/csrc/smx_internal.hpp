@@ -74,6 +74,7 @@ struct StftTables {
   float *blu2_window = nullptr;    // 0.5 * window, N entries
   int blu2_log2m = 0;
   float2 *fast_synth_window = nullptr;   // (w[2j], -w[2j+1]) / (2M): synthesis window of the fast inverse kernel
+  double2 *fast_synth_window_f64 = nullptr;   // the same in float64 (fft 512 .. 4096)
 };
 
 }  // namespace smx

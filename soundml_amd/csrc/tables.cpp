@@ -225,6 +225,10 @@ const smx::StftTables &smx_stft_config::tables() const {
         wm64[(size_t)j] = make_double2(std::cos(a), std::sin(a));
       }
       t.fast_w_m_f64 = smx::upload(wm64);
+      std::vector<double2> sw64((size_t)m);
+      for (int64_t j = 0; j < m; ++j)
+        sw64[(size_t)j] = make_double2(analysis_window[(size_t)(2 * j)] / (double)(2 * m), -analysis_window[(size_t)(2 * j + 1)] / (double)(2 * m));
+      t.fast_synth_window_f64 = smx::upload(sw64);
     }
     t.fast_window = smx::upload(hw);
     t.fast_w_m = smx::upload(wm);
@@ -272,6 +276,7 @@ smx_stft_config::~smx_stft_config() {
     (void)hipFree(t.fast_window);
     (void)hipFree(t.fast_w_m);
     (void)hipFree(t.fast_w_m_f64);
+    (void)hipFree(t.fast_synth_window_f64);
     (void)hipFree(t.fast_w_n);
     (void)hipFree(t.fast_synth_window);
     (void)hipFree(t.blu_chirp);

@@ -16,6 +16,8 @@ if os.environ.get("MAG") == "stft":   # magnitudes of a real transform (what too
 else:
     mag = torch.rand(clips, FFT // 2 + 1, frames, device="cuda")
 out = torch.empty(clips, n, device="cuda")
+if os.environ.get("INTERIOR") == "float64":
+    check(lib.smx_set_interior(1))
 def run():
     check(lib.smx_stft_griffin_lim_f32_dev(c._h, vp(mag.data_ptr()), clips, FFT // 2 + 1, frames, 32, 0.99, None, 1, n, vp(out.data_ptr()), None))
 run(); torch.cuda.synchronize()

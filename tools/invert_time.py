@@ -11,6 +11,8 @@ out = torch.empty(clips, n, device="cuda")
 h = vp()
 lib.smx_stft_config_create.argtypes = [i64, i64, i64, ci, ci, ctypes.c_double, ci, ci, vp, ctypes.POINTER(vp)]
 assert lib.smx_stft_config_create(FFT, -(2**63), HOP, 0, 0, 0.0, 0, 0, None, ctypes.byref(h)) == 0
+if os.environ.get("INTERIOR") == "float64":
+    assert lib.smx_set_interior(1) == 0
 f = lib.smx_stft_invert_f32_dev
 f.argtypes = [vp, vp, i64, i64, i64, ci, i64, vp, vp]
 def run():
