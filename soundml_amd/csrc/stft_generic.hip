@@ -512,10 +512,11 @@ template <bool MEL>
 __device__ __forceinline__ TileBands load_tile_bands(const MelTail &mt) {
   TileBands tb{{0, 0}, {0, 0}};
   if constexpr (MEL) {
-    const int wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
+    const int wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6, ntiles = (mt.n_mels + 15) >> 4;
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
-      const int t = wave + i * nwaves;
+      int t = wave + i * nwaves;
+      if (i == 0 && wave >= ntiles && ntiles < nwaves) t = ntiles - 1 - ((wave - ntiles) % ntiles);   // a helper's tile
       if (16 * t < mt.n_mels) {
         tb.lo[i] = mt.band_lo[t];
         tb.hi[i] = mt.band_hi[t];
@@ -527,32 +528,21 @@ __device__ __forceinline__ TileBands load_tile_bands(const MelTail &mt) {
 
 template <int BUF, int FT, bool MEL, typename Tout = float>
 __device__ __forceinline__ void columns_out(const GenericArgs &a, const MelTail &mt, const Tout *cols, int bins, int nf,
-                                            int64_t clip, int64_t f0, const TileBands &tb = TileBands{}) {
+                                            int64_t clip, int64_t f0, const TileBands &tb = TileBands{}, float *partials = nullptr) {
   if constexpr (MEL) {
     static_assert(!MEL || (FT == 16 && sizeof(Tout) == 4), "the MFMA tile is 16 float32 frames wide");
     using f32x4 = __attribute__((ext_vector_type(4))) float;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
     const int n = lane & 15, kk = lane >> 4;           // B[k = kk][n = frame], A[m = n][k = kk], D[4 kk + i][n]
     const float *colb = cols + n * (BUF) + 2 * n + kk;
-    int ti = 0;
-    for (int r0 = 16 * wave; r0 < mt.n_mels; r0 += 16 * nwaves, ++ti) {
-      // bins any of the tile's 16 rows touches (host-built per tile; the first two came in at kernel entry)
-      int lo, hi;
-      if (ti == 0) { lo = tb.lo[0]; hi = tb.hi[0]; }
-      else if (ti == 1) { lo = tb.lo[1]; hi = tb.hi[1]; }
-      else { lo = mt.band_lo[r0 >> 4]; hi = mt.band_hi[r0 >> 4]; }
-      lo = __builtin_amdgcn_readfirstlane(lo);
-      hi = __builtin_amdgcn_readfirstlane(hi);
-      f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    // One 16-row tile of the weights over the bin range [k_begin, k_end) (16-aligned), into acc.  Four k-steps (16
+    // bins) per trip, two trips' operands in flight, two accumulator chains; the weights are in operand order (one
+    // 256-byte run per load); trips may run past the band: W is zero there.
+    auto tile_product = [&](int r0, int k_begin, int k_end) {
+      f32x4 acc = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
       const float *wt = mt.w + (int64_t)(r0 >> 4) * (mt.k_pad / 4) * 64 + lane;   // this tile's operands, this lane's slot
-      // four k-steps (16 bins) per trip, operands fetched first; the weights are in operand order (one 256-byte run per
-      // load); the trips may run past the band: W is zero there
-      const int k_begin = lo & ~15;                          // 16-aligned trips never straddle the end of a padded row
-      int k_end = k_begin + (hi - k_begin + 15) / 16 * 16;
-      k_end = k_end < mt.k_pad ? k_end : mt.k_pad;          // k_pad is a multiple of 32
-      f32x4 acc1 = {0.f, 0.f, 0.f, 0.f};                    // two chains: half of the multiply-adds wait for each other
       int k0 = k_begin;
-      for (; k0 + 32 <= k_end; k0 += 32) {                   // two trips' operands in flight together
+      for (; k0 + 32 <= k_end; k0 += 32) {
         float av[8], bv[8];
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
@@ -580,6 +570,14 @@ __device__ __forceinline__ void columns_out(const GenericArgs &a, const MelTail 
       }
 #pragma unroll
       for (int i = 0; i < 4; ++i) acc[i] += acc1[i];
+      return acc;
+    };
+    auto tile_range = [&](int lo, int hi, int &k_begin, int &k_end) {
+      k_begin = lo & ~15;                                    // 16-aligned trips never straddle the end of a padded row
+      k_end = k_begin + (hi - k_begin + 15) / 16 * 16;
+      k_end = k_end < mt.k_pad ? k_end : mt.k_pad;          // k_pad is a multiple of 32
+    };
+    auto store_tile = [&](int r0, const f32x4 &acc) {
       if (n < nf) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
@@ -587,6 +585,67 @@ __device__ __forceinline__ void columns_out(const GenericArgs &a, const MelTail 
           if (row < mt.n_mels) mt.out[(clip * mt.n_mels + row) * a.count + f0 + n] = acc[i];
         }
       }
+    };
+    const int ntiles = (mt.n_mels + 15) >> 4;
+    if (ntiles < nwaves && partials) {
+      // Fewer tiles than waves (80 mels on 8 waves; one tile of dense weights): the idle waves take shares of the
+      // widest -- for a mel bank the highest -- tiles' bin ranges.  Helper j serves tile ntiles - 1 - (j mod ntiles);
+      // a tile's range is cut into 1 + (its helpers) equal 16-aligned pieces, piece 0 is the owner's; helpers leave
+      // their 16 x 16 partial in LDS and the owner adds them in piece order: the same sum on every run.
+      const int helpers = nwaves - ntiles;
+      int tile, piece, pieces;
+      if (wave < ntiles) {
+        tile = wave;
+        piece = 0;
+        const int back = ntiles - 1 - tile;                  // helper indices back, back + ntiles, ... serve this tile
+        pieces = 1 + (back < helpers ? (helpers - 1 - back) / ntiles + 1 : 0);
+      } else {
+        const int j = wave - ntiles;
+        tile = ntiles - 1 - (j % ntiles);
+        piece = 1 + j / ntiles;
+        const int back = j % ntiles;
+        pieces = 1 + (helpers - 1 - back) / ntiles + 1;
+      }
+      const int r0 = 16 * tile;
+      int lo = tb.lo[0], hi = tb.hi[0];                      // owner's or helper's tile: fetched at kernel entry
+      lo = __builtin_amdgcn_readfirstlane(lo);
+      hi = __builtin_amdgcn_readfirstlane(hi);
+      int k_begin, k_end;
+      tile_range(lo, hi, k_begin, k_end);
+      const int trips = (k_end - k_begin) / 16, per = (trips + pieces - 1) / pieces;
+      int kb = k_begin + 16 * per * piece, ke = kb + 16 * per;
+      kb = kb < k_end ? kb : k_end;
+      ke = ke < k_end ? ke : k_end;
+      f32x4 acc = tile_product(r0, kb, ke);
+      if (piece > 0) {
+        float *slot = partials + (wave - ntiles) * 256;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) slot[i * 64 + lane] = acc[i];
+      }
+      __syncthreads();
+      if (piece == 0) {
+        const int back = ntiles - 1 - tile;
+        for (int j = back; j < helpers; j += ntiles) {       // piece order: helper back is piece 1, back + ntiles piece 2, ...
+          const float *slot = partials + j * 256;
+#pragma unroll
+          for (int i = 0; i < 4; ++i) acc[i] += slot[i * 64 + lane];
+        }
+        store_tile(r0, acc);
+      }
+      return;
+    }
+    int ti = 0;
+    for (int r0 = 16 * wave; r0 < mt.n_mels; r0 += 16 * nwaves, ++ti) {
+      // bins any of the tile's 16 rows touches (host-built per tile; the first two came in at kernel entry)
+      int lo, hi;
+      if (ti == 0) { lo = tb.lo[0]; hi = tb.hi[0]; }
+      else if (ti == 1) { lo = tb.lo[1]; hi = tb.hi[1]; }
+      else { lo = mt.band_lo[r0 >> 4]; hi = mt.band_hi[r0 >> 4]; }
+      lo = __builtin_amdgcn_readfirstlane(lo);
+      hi = __builtin_amdgcn_readfirstlane(hi);
+      int k_begin, k_end;
+      tile_range(lo, hi, k_begin, k_end);
+      store_tile(r0, tile_product(r0, k_begin, k_end));
     }
     return;
   }
@@ -697,7 +756,8 @@ __global__ void __launch_bounds__(FT * ((1 << LOG2N) / 32)) stft_stockham_power1
   for (int m = 0; m < 16; ++m) col[tid + T * m] = val[m];
   if (tid == 0) col[M] = nyq;
   __syncthreads();
-  columns_out<(int)(M * sizeof(V) / sizeof(Tout)), FT, MEL, Tout>(a, mt, reinterpret_cast<const Tout *>(work), M + 1, nf, clip, f0, tb);
+  columns_out<(int)(M * sizeof(V) / sizeof(Tout)), FT, MEL, Tout>(a, mt, reinterpret_cast<const Tout *>(work), M + 1, nf, clip, f0, tb,
+                                                                   MEL ? reinterpret_cast<float *>(smem + (size_t)FT * M * sizeof(V)) : nullptr);
 }
 
 template <int LOG2N, int FT = 16>
@@ -710,9 +770,10 @@ bool launch_stockham_power16(const StftJob &job, GenericArgs a, const StftTables
   const size_t lds = (size_t)FT * M * sizeof(float2);
   if constexpr (FT == 16) {
     if (mel) {
+      const size_t lds_mel = lds + (size_t)(THREADS / 64) * 1024;   // the helper waves' partial tiles (columns_out)
       auto kernel = stft_stockham_power16_kernel<LOG2N, float, true, 16>;
-      SMX_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-      hipLaunchKernelGGL(kernel, dim3((unsigned)blocks), dim3(THREADS), lds, job.stream, a, (const float2 *)t.fast_w_m,
+      SMX_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_mel));
+      hipLaunchKernelGGL(kernel, dim3((unsigned)blocks), dim3(THREADS), lds_mel, job.stream, a, (const float2 *)t.fast_w_m,
                          (const float2 *)t.fast_w_n, *mel);
       SMX_HIP_CHECK(hipGetLastError());
       return true;
@@ -1198,7 +1259,8 @@ __global__ void __launch_bounds__(1 << LOG2M) stft_bluestein_power16_kernel(Gene
   }
   if (tid == 0) col[L] = nyq;
   __syncthreads();
-  columns_out<2 * M, FT, MEL>(a, mt, reinterpret_cast<const float *>(work), L + 1, nf, clip, f0, tb);
+  columns_out<2 * M, FT, MEL>(a, mt, reinterpret_cast<const float *>(work), L + 1, nf, clip, f0, tb,
+                              MEL ? reinterpret_cast<float *>(smem + (size_t)FT * M * sizeof(float2)) : nullptr);
 }
 
 template <int LOG2M>
@@ -1210,9 +1272,10 @@ bool launch_bluestein_power16(const StftJob &job, GenericArgs a, const StftTable
   if (blocks > 2147483647LL) throw Failure("stft: too many frame tiles for one launch");
   const size_t lds = (size_t)16 * M * sizeof(float2);
   if (mel) {
+    const size_t lds_mel = lds + (size_t)(M / 64) * 1024;   // the helper waves' partial tiles (columns_out)
     auto kernel = stft_bluestein_power16_kernel<LOG2M, float, true>;
-    SMX_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(kernel, dim3((unsigned)blocks), dim3(M), lds, job.stream, a, b, *mel);
+    SMX_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_mel));
+    hipLaunchKernelGGL(kernel, dim3((unsigned)blocks), dim3(M), lds_mel, job.stream, a, b, *mel);
   } else {
     auto kernel = stft_bluestein_power16_kernel<LOG2M, float, false>;
     SMX_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
