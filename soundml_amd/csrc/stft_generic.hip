@@ -1,17 +1,22 @@
-// Generic STFT kernels: any fft_size, hop, alignment and pad mode, float32 or
-// float64 audio, float32 or float64 interior.  These are the completeness path
-// (reference semantics for every Stft.Config, stft.ml:356-364 + :670-674); the
-// tuned power-of-two kernels live in stft_fast.hip and the dispatcher prefers
-// them when the geometry is eligible.
+// STFT kernels for every geometry the fused fft-2048 kernels of stft_fast.hip do not serve: any fft_size, hop,
+// alignment and pad mode, float32 or float64 audio, float32 or float64 interior (reference semantics for every
+// Stft.Config, stft.ml:356-364 + :670-674).  In the order the dispatcher (launch_stft_generic, at the end) prefers them:
 //
-// One workgroup computes FT consecutive frames of one signal:
-//   - power-of-two N: windowed samples are written bit-reversed into an LDS
-//     buffer and transformed in place by log2(N) radix-2 passes (twiddles from a
-//     float64-built table);
-//   - any other N (or N too large for LDS): direct DFT from an LDS copy of the
-//     windowed frame against an N-entry twiddle table, O(N^2) per frame.
-// Results for the FT frames are staged in LDS and written frames-fastest so
-// the [bins; frames] layout is stored in runs of FT elements.
+//   stft_stockham_power16_kernel     fft 512 .. 8192, power output (and, MEL, the fused mel / projection tail): FT
+//                                    frames per workgroup on the Stockham passes of fft_device.hpp, real form
+//                                    (one half-size complex transform + post-pass), NO stage: each frame's column
+//                                    returns into its own work buffer and leaves through columns_out; float32, or
+//                                    double for the float64 interior;
+//   stft_stockham_complex16_kernel   the same for complex output (X[M] packed with X[0], XOR-placed columns);
+//   stft_bluestein_power16_kernel    even sizes up to 1024 that are not powers of two (fft 400 ...): chirp-z of
+//                                    length N/2 on the same passes, same column tail;
+//   stft_stockham_real_kernel        the staged form ([bins][FT + 1] stage in LDS) for what is left of fft 512 ..
+//   stft_stockham_kernel             16384 (full-size complex form for fft 256 and from 4096 on);
+//   stft_bluestein_real_kernel /     chirp-z, half length for even sizes, full length for odd ones, up to fft 8192;
+//   stft_bluestein_kernel
+//   stft_generic_kernel              everything else: radix-2 passes in LDS (power of two) or a direct DFT against an
+//                                    N-entry float64-built table, float32 or float64, FT frames staged and written
+//                                    frames-fastest.
 #include <cstdlib>
 
 #include "fft_device.hpp"
