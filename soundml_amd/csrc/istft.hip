@@ -9,8 +9,14 @@
 //   istft_ola_kernel     one thread per output sample gathers the <= ceil(fft/hop) frames that reach it, in
 //                        the order the reference's overlap_add adds them (frame index descending,
 //                        stft.ml:806-831), divides by the envelope and trims / zero-extends.
+// For fft 512 .. 4096 the frames come from the Stockham passes of fft_device.hpp instead
+// (istft_stockham_frames_kernel, float32; istft_stockham_frames_wide_kernel, the float64 interior), which for
+// hop = N/4 or N/2 also does the overlap-add in the same launch (no scratch array), and for fft 2048 / hop 512 the
+// hand-laid istft2048_kernel below does both.  Those kernels can form Griffin-Lim's S * unit(c_k - beta c_(k-1))
+// while they stage the spectrum (IstftJob::mag / unit / prev).
 // No atomics: the sum is deterministic.  The envelope (partial sums on both borders, one period of the
-// folded squared window in between, stft.ml:836-889) is built on the host in float64 and uploaded.
+// folded squared window in between, stft.ml:836-889) is built on the host in float64, cached on the device per
+// (config, frame count).
 #include <cfloat>
 #include <cstdlib>
 #include <type_traits>
