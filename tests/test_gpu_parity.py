@@ -651,6 +651,26 @@ def test_sixteen_frame_kernels_on_short_and_odd_inputs(fft, alignment, pad):
                 check_fast(S.mel_spectrogram(c, mc, x)[i], O.mel_spectrogram(o, om, x)[i], "mel n=%d hop=%d" % (n, hop))
 
 
+@pytest.mark.parametrize("fft,hop", [(1024, 256), (512, 100), (400, 160), (4096, 1024), (2048, 512)])
+@pytest.mark.parametrize("power", [0.5, 1.0, 3.0])
+def test_general_powers_on_every_power_path(fft, hop, power):
+    """|X|^p for exponents other than 2 (stft.ml:670-674: magnitude first, then the power) through the stage-free,
+    chirp-z and fused kernels, float32 interior and the float64 one."""
+    rng = np.random.default_rng(fft + int(10 * power))
+    x = rng.uniform(-1, 1, size=(2, 5 * fft + 77)).astype(np.float32)
+    c = Stft.Config.create(fft_size=fft, hop=hop)
+    want = O.power_spectrum(O.stft_config(fft, hop=hop), x, power)
+    got = Stft.power_spectrum(c, x, power)
+    for i in range(2):
+        check_fast(got[i], want[i], "float32 interior")
+    S.set_interior("float64")
+    try:
+        strict = Stft.power_spectrum(c, x, power)
+    finally:
+        S.set_interior("float32")
+    np.testing.assert_allclose(strict, want, rtol=4 * F32_RTOL, atol=F32_ATOL * float(np.max(want)))
+
+
 def test_filterbank_from_weights():
     """Caller-supplied dense weights (the shape of Chroma.apply, chroma.ml:307: 12 rows over all bins) through the
     same entry points: W @ S in float64 for float64 spectrograms, the float32 MFMA kernel for float32 ones, and the
