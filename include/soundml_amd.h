@@ -221,6 +221,24 @@ int smx_stft_griffin_lim_f32_dev(const smx_stft_config *c, const float *d_s, int
                                  int64_t frames, int64_t n_iter, double momentum, const float *d_init_phase,
                                  int has_length, int64_t length, float *d_out, void *stream);
 
+/* ---- Convert.power_to_db / amplitude_to_db (convert.ml:30-62): decibels in the data's own dtype -------
+ * db = scale * ln(max(v, amin)) - scale * ln(max(amin, reference)), scale = gain / ln 10 (gain 10 for powers, 20 for
+ * amplitudes, which take |s| first: a negative power sits at the floor); with has_top_db the result is clamped at
+ * (the maximum over the WHOLE tensor) - top_db.  `total` elements of any shape; out may alias s on the device.
+ * Invalid_argument (convert.ml:3-16): reference / amin not finite and positive, top_db negative or not finite. */
+int smx_power_to_db_f32(const float *s, int64_t total, double reference, double amin, int has_top_db, double top_db,
+                        float *out);
+int smx_power_to_db_f64(const double *s, int64_t total, double reference, double amin, int has_top_db, double top_db,
+                        double *out);
+int smx_power_to_db_f32_dev(const float *d_s, int64_t total, double reference, double amin, int has_top_db,
+                            double top_db, float *d_out, void *stream);
+int smx_amplitude_to_db_f32(const float *s, int64_t total, double reference, double amin, int has_top_db,
+                            double top_db, float *out);
+int smx_amplitude_to_db_f64(const double *s, int64_t total, double reference, double amin, int has_top_db,
+                            double top_db, double *out);
+int smx_amplitude_to_db_f32_dev(const float *d_s, int64_t total, double reference, double amin, int has_top_db,
+                                double top_db, float *d_out, void *stream);
+
 /* ---- Soundml.mfcc (soundml.ml:50-95): mel_spectrogram (power 2) -> power_to_db with the 80 dB clamp under
  * the maximum of the WHOLE tensor (convert.ml:30-50) -> orthonormal DCT-II along the mel axis, first n_mfcc
  * rows -> optional sinusoidal lifter.  float64 interior after the mel spectrogram, one rounding to the audio

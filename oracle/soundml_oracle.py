@@ -781,21 +781,40 @@ def mel_spectrogram(sc: StftConfig, mc: MelConfig, x: np.ndarray, power: float =
 # Log-mel / MFCC (convert.ml:30-50, soundml.ml:26-95)
 # ---------------------------------------------------------------------------
 
-def power_to_db(s: np.ndarray, reference: float = 1.0, amin: float = 1e-10,
-                top_db: Optional[float] = None) -> np.ndarray:
-    """convert.ml:30-50 ``to_db`` with gain 10 in the input's dtype: floor at amin, scale * ln, subtract the
-    reference offset, then clamp at (maximum of the whole tensor) - top_db."""
+def _to_db(fn: str, gain: float, magnitude: bool, s: np.ndarray, reference: float, amin: float,
+           top_db: Optional[float]) -> np.ndarray:
+    """convert.ml:3-50 ``to_db`` in the input's own dtype: (|s| first for amplitudes,) floor at amin, scale * ln,
+    subtract the reference offset, then clamp at (maximum of the whole tensor) - top_db."""
+    for name, value, ok in (("reference", reference, math.isfinite(reference) and reference > 0.0),
+                            ("amin", amin, math.isfinite(amin) and amin > 0.0)):
+        if not ok:
+            raise ValueError("Soundml.Convert.%s: %s must be finite and positive" % (fn, name))
+    if top_db is not None and not (math.isfinite(top_db) and top_db >= 0.0):
+        raise ValueError("Soundml.Convert.%s: top_db must be finite and non-negative" % fn)
     s = np.asarray(s)
     if s.size == 0:
         return s.copy()
     dt = s.dtype
-    scale = 10.0 / 10.0 * (10.0 / math.log(10.0))
-    floored = np.maximum(s, dt.type(amin))
+    scale = gain / 10.0 * (10.0 / math.log(10.0))
+    v = np.abs(s) if magnitude else s
+    floored = np.maximum(v, dt.type(amin))
     offset = scale * math.log(max(amin, reference))
     db = (np.log(floored) * dt.type(scale) - dt.type(offset)).astype(dt)
     if top_db is None:
         return db
     return np.maximum(db, dt.type(float(db.max()) - top_db))
+
+
+def power_to_db(s: np.ndarray, reference: float = 1.0, amin: float = 1e-10,
+                top_db: Optional[float] = None) -> np.ndarray:
+    """``Convert.power_to_db`` (convert.ml:52-56): gain 10, negative powers sit at the floor."""
+    return _to_db("power_to_db", 10.0, False, s, reference, amin, top_db)
+
+
+def amplitude_to_db(s: np.ndarray, reference: float = 1.0, amin: float = 1e-5,
+                    top_db: Optional[float] = None) -> np.ndarray:
+    """``Convert.amplitude_to_db`` (convert.ml:58-62): gain 20, magnitudes first."""
+    return _to_db("amplitude_to_db", 20.0, True, s, reference, amin, top_db)
 
 
 def mfcc(sc: StftConfig, mc: MelConfig, x: np.ndarray, n_mfcc: int = 20, lifter: Optional[float] = None) -> np.ndarray:

@@ -123,6 +123,12 @@ SIGNATURES = {
     "smx_stft_stage_latency": (i64, [vp]),
     "smx_stft_frame_bound": (i64, [vp, i64]),
     "smx_set_scratch_retention": (cint, [i64]),
+    "smx_power_to_db_f32": (cint, [vp, i64, f64, f64, cint, f64, vp]),
+    "smx_power_to_db_f64": (cint, [vp, i64, f64, f64, cint, f64, vp]),
+    "smx_power_to_db_f32_dev": (cint, [vp, i64, f64, f64, cint, f64, vp, vp]),
+    "smx_amplitude_to_db_f32": (cint, [vp, i64, f64, f64, cint, f64, vp]),
+    "smx_amplitude_to_db_f64": (cint, [vp, i64, f64, f64, cint, f64, vp]),
+    "smx_amplitude_to_db_f32_dev": (cint, [vp, i64, f64, f64, cint, f64, vp, vp]),
     "smx_stft_nola": (cint, [vp, C.POINTER(cint)]),
     "smx_stft_output_length": (cint, [vp, i64, pi64]),
     "smx_stft_invert_f32": (cint, [vp, vp, i64, i64, i64, cint, i64, vp]),

@@ -1093,6 +1093,52 @@ void mfcc_host(const smx_stft_config &sc, const smx_mel_config &mc, const void *
   SMX_HIP_CHECK(hipMemcpy(out, dout.ptr, out_total, hipMemcpyDeviceToHost));
 }
 
+// ---- Convert.power_to_db / amplitude_to_db (convert.ml:3-62) ------------------------------------------------
+void to_db_checks(const char *fn, double reference, double amin, int has_top_db, double top_db) {
+  if (!(std::isfinite(reference) && reference > 0.0))
+    throw InvalidArgument(format("Soundml.Convert.%s: reference must be finite and positive", fn));
+  if (!(std::isfinite(amin) && amin > 0.0))
+    throw InvalidArgument(format("Soundml.Convert.%s: amin must be finite and positive", fn));
+  if (has_top_db && !(std::isfinite(top_db) && top_db >= 0.0))
+    throw InvalidArgument(format("Soundml.Convert.%s: top_db must be finite and non-negative", fn));
+}
+
+void to_db_dev(bool amplitude, const void *d_s, int elem_bytes, int64_t total, double reference, double amin, int has_top_db,
+               double top_db, void *d_out, hipStream_t stream) {
+  const char *fn = amplitude ? "amplitude_to_db" : "power_to_db";
+  to_db_checks(fn, reference, amin, has_top_db, top_db);
+  if (total < 0) throw Failure(format("%s: negative extent", fn));
+  if (total == 0) return;
+  if (!d_s || !d_out) throw Failure(format("%s: null device pointer", fn));
+  ToDbJob job;
+  job.s = d_s;
+  job.out = d_out;
+  job.elem_bytes = elem_bytes;
+  job.total = total;
+  job.gain = amplitude ? 20.0 : 10.0;
+  job.magnitude = amplitude;
+  job.reference = reference;
+  job.amin = amin;
+  job.has_top_db = has_top_db != 0;
+  job.top_db = top_db;
+  job.stream = stream;
+  launch_to_db(job);
+}
+
+void to_db_host(bool amplitude, const void *s, int elem_bytes, int64_t total, double reference, double amin, int has_top_db,
+                double top_db, void *out) {
+  to_db_checks(amplitude ? "amplitude_to_db" : "power_to_db", reference, amin, has_top_db, top_db);
+  if (total <= 0) return;
+  if (!s || !out) throw Failure("to_db: null pointer");
+  require_device();
+  const size_t bytes = (size_t)total * (size_t)elem_bytes;
+  DeviceScratch d(bytes);
+  SMX_HIP_CHECK(hipMemcpy(d.ptr, s, bytes, hipMemcpyHostToDevice));
+  to_db_dev(amplitude, d.ptr, elem_bytes, total, reference, amin, has_top_db, top_db, d.ptr, nullptr);
+  SMX_HIP_CHECK(hipStreamSynchronize(nullptr));
+  SMX_HIP_CHECK(hipMemcpy(out, d.ptr, bytes, hipMemcpyDeviceToHost));
+}
+
 // ---- Spectral.* (spectral.ml:27-255): checks in the reference's order and words, then one launch -------------
 const char *spectral_op(int feature) {
   switch (feature) {
@@ -1607,6 +1653,29 @@ int smx_chroma_stft_f32_dev(const smx_stft_config *sc, const smx_chroma_config *
     check_config(cc, "chroma_stft");
     chroma_stft_dev(*sc, *cc, d_x, 4, lead, n, x_stride, power, norm, norm_p, d_out, (hipStream_t)stream);
   });
+}
+
+// ---- Convert.power_to_db / amplitude_to_db (convert.ml:52-62) ------------------------------------------
+int smx_power_to_db_f32(const float *s, int64_t total, double reference, double amin, int has_top_db, double top_db, float *out) {
+  return guarded([&] { to_db_host(false, s, 4, total, reference, amin, has_top_db, top_db, out); });
+}
+int smx_power_to_db_f64(const double *s, int64_t total, double reference, double amin, int has_top_db, double top_db, double *out) {
+  return guarded([&] { to_db_host(false, s, 8, total, reference, amin, has_top_db, top_db, out); });
+}
+int smx_power_to_db_f32_dev(const float *d_s, int64_t total, double reference, double amin, int has_top_db, double top_db,
+                            float *d_out, void *stream) {
+  return guarded([&] { to_db_dev(false, d_s, 4, total, reference, amin, has_top_db, top_db, d_out, (hipStream_t)stream); });
+}
+int smx_amplitude_to_db_f32(const float *s, int64_t total, double reference, double amin, int has_top_db, double top_db, float *out) {
+  return guarded([&] { to_db_host(true, s, 4, total, reference, amin, has_top_db, top_db, out); });
+}
+int smx_amplitude_to_db_f64(const double *s, int64_t total, double reference, double amin, int has_top_db, double top_db,
+                            double *out) {
+  return guarded([&] { to_db_host(true, s, 8, total, reference, amin, has_top_db, top_db, out); });
+}
+int smx_amplitude_to_db_f32_dev(const float *d_s, int64_t total, double reference, double amin, int has_top_db, double top_db,
+                                float *d_out, void *stream) {
+  return guarded([&] { to_db_dev(true, d_s, 4, total, reference, amin, has_top_db, top_db, d_out, (hipStream_t)stream); });
 }
 
 // ---- Soundml.mfcc (soundml.ml:50-95) --------------------------------------------------------------

@@ -70,7 +70,86 @@ __global__ void __launch_bounds__(256) mfcc_kernel(MfccArgs a) {
   }
 }
 
+// Convert.power_to_db / amplitude_to_db (convert.ml:30-62) in the data's own dtype: |s| first for amplitudes, floor at
+// amin, scale * ln, minus the reference offset; with top_db a second pass clamps under the maximum of the WHOLE tensor.
+// The maximum is kept as an order-preserving integer key of the value's bits (decibels are negative as often as not).
+template <typename T> struct OrderedKey;
+template <> struct OrderedKey<float> {
+  using U = unsigned;
+  static __device__ U of(float v) { const U b = __float_as_uint(v); return (b & 0x80000000u) ? ~b : (b | 0x80000000u); }
+  static __device__ float back(U k) { return __uint_as_float((k & 0x80000000u) ? (k & 0x7fffffffu) : ~k); }
+};
+template <> struct OrderedKey<double> {
+  using U = unsigned long long;
+  static __device__ U of(double v) {
+    const U b = (U)__double_as_longlong(v);
+    return (b >> 63) ? ~b : (b | 0x8000000000000000ull);
+  }
+  static __device__ double back(U k) {
+    return __longlong_as_double((long long)((k >> 63) ? (k & 0x7fffffffffffffffull) : ~k));
+  }
+};
+
+template <typename T>
+__global__ void __launch_bounds__(256) to_db_kernel(const T *s, T *out, int64_t total, T amin, T scale, T offset, int magnitude,
+                                                    typename OrderedKey<T>::U *max_key) {
+  using K = OrderedKey<T>;
+  typename K::U best = 0;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    T v = s[i];
+    if (magnitude) v = v < (T)0 ? -v : v;
+    const T floored = v > amin ? v : amin;          // maximum s amin: a NaN stays a NaN, as Nx.maximum leaves it
+    const T db = (v != v) ? v : (T)(log(floored) * scale - offset);
+    out[i] = db;
+    const typename K::U key = K::of(db);
+    best = key > best ? key : best;
+  }
+  if (max_key) {
+    for (int off = 32; off > 0; off >>= 1) {
+      const typename K::U o = __shfl_down(best, off);
+      best = o > best ? o : best;
+    }
+    if ((threadIdx.x & 63) == 0) atomicMax(max_key, best);
+  }
+}
+
+template <typename T>
+__global__ void __launch_bounds__(256) db_clamp_kernel(T *out, int64_t total, T range, const typename OrderedKey<T>::U *max_key) {
+  const T lowest = (T)(OrderedKey<T>::back(*max_key) - range);
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const T v = out[i];
+    out[i] = v > lowest ? v : (v != v ? v : lowest);
+  }
+}
+
+template <typename T>
+void run_to_db(const ToDbJob &job) {
+  using U = typename OrderedKey<T>::U;
+  const unsigned blocks = (unsigned)std::min<int64_t>((job.total + 255) / 256, 8192);
+  const double scale = job.gain / 10.0 * (10.0 / std::log(10.0));
+  const double offset = scale * std::log(std::max(job.amin, job.reference));
+  U *d_key = nullptr;
+  if (job.has_top_db) {
+    SMX_HIP_CHECK(hipMallocAsync((void **)&d_key, sizeof(U), job.stream));
+    SMX_HIP_CHECK(hipMemsetAsync(d_key, 0, sizeof(U), job.stream));
+  }
+  hipLaunchKernelGGL(to_db_kernel<T>, dim3(blocks), dim3(256), 0, job.stream, (const T *)job.s, (T *)job.out, job.total, (T)job.amin,
+                     (T)scale, (T)offset, job.magnitude ? 1 : 0, d_key);
+  SMX_HIP_CHECK(hipGetLastError());
+  if (job.has_top_db) {
+    hipLaunchKernelGGL(db_clamp_kernel<T>, dim3(blocks), dim3(256), 0, job.stream, (T *)job.out, job.total, (T)job.top_db, d_key);
+    SMX_HIP_CHECK(hipGetLastError());
+    SMX_HIP_CHECK(hipFreeAsync(d_key, job.stream));
+  }
+}
+
 }  // namespace
+
+void launch_to_db(const ToDbJob &job) {
+  if (job.total <= 0) return;
+  if (job.elem_bytes == 8) run_to_db<double>(job);
+  else run_to_db<float>(job);
+}
 
 void launch_mfcc(const MfccJob &job) {
   if (job.lead <= 0 || job.frames <= 0) return;

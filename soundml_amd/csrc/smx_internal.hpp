@@ -273,6 +273,20 @@ struct MfccJob {
 };
 void launch_mfcc(const MfccJob &job);             // mfcc.hip
 
+// Convert.power_to_db / amplitude_to_db (convert.ml:30-62) on device-resident data of either dtype
+struct ToDbJob {
+  const void *s = nullptr;
+  void *out = nullptr;           // same shape and dtype; may alias s
+  int elem_bytes = 4;
+  int64_t total = 0;
+  double gain = 10.0;            // 10 powers, 20 amplitudes
+  bool magnitude = false;        // |s| first (amplitudes)
+  double reference = 1.0, amin = 1e-10, top_db = 0.0;
+  bool has_top_db = false;
+  hipStream_t stream = nullptr;
+};
+void launch_to_db(const ToDbJob &job);            // mfcc.hip
+
 // spectral-shape features over a device-resident spectrogram [lead; bins; frames] (spectral.ml:171-255)
 enum SpectralFeature { SPECTRAL_CENTROID = 0, SPECTRAL_BANDWIDTH = 1, SPECTRAL_ROLLOFF = 2, SPECTRAL_FLATNESS = 3 };
 struct SpectralJob {

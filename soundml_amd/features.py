@@ -86,3 +86,34 @@ def chroma_stft(stft_config, chroma_config, x, power: float = 2.0, norm="inf"):
     fn = lib.smx_chroma_stft_f32 if b.bytes == 4 else lib.smx_chroma_stft_f64
     check(fn(stft_config._h, chroma_config._h, b.ptr(), lead, n, float(power), kind, p, out_ptr(out)))
     return b.wrap(out)
+
+
+def _to_db(which, s, reference, amin, top_db):
+    if not hasattr(s, "shape"):
+        import numpy as np
+        s = np.asarray(s)
+    b = Batch(s, which, min_rank=0)
+    total = prod(b.shape)
+    out = b.empty(b.shape)
+    has_top = top_db is not None
+    args = (total, float(reference), float(amin), 1 if has_top else 0, float(top_db) if has_top else 0.0)
+    if b.device:
+        if b.bytes != 4:
+            raise _lib.Failure("%s: device-resident float64 data is not supported; pass a host array" % which)
+        with b.device_guard():
+            check(getattr(lib, "smx_%s_f32_dev" % which)(b.ptr(), *args, out_ptr(out), b.stream()))
+        return out
+    fn = getattr(lib, "smx_%s_%s" % (which, "f32" if b.bytes == 4 else "f64"))
+    check(fn(b.ptr(), *args, out_ptr(out)))
+    return b.wrap(out)
+
+
+def power_to_db(s, reference: float = 1.0, amin: float = 1e-10, top_db=None):
+    """``Convert.power_to_db ?reference ?amin ?top_db s`` (convert.ml:52-56): 10 log10 of powers in s's own dtype,
+    floored at amin, relative to reference, optionally clamped top_db under the maximum of the whole tensor."""
+    return _to_db("power_to_db", s, reference, amin, top_db)
+
+
+def amplitude_to_db(s, reference: float = 1.0, amin: float = 1e-5, top_db=None):
+    """``Convert.amplitude_to_db`` (convert.ml:58-62): 20 log10 of magnitudes."""
+    return _to_db("amplitude_to_db", s, reference, amin, top_db)

@@ -727,6 +727,39 @@ def test_stage_and_power_stage_stream_the_offline_result(fft, hop, alignment, pa
     assert Stft.stage(c).prepare().concat([]).shape == (c.bins, 0)
 
 
+# ---- decibel conversions (power_to_db) ----------------------------------------------------------
+
+@pytest.mark.parametrize("which", ["power_to_db", "amplitude_to_db"])
+def test_db_goldens(which):
+    """librosa's power_to_db / amplitude_to_db vectors (soundml/test/db/test_golden.ml: float32 1e-4, float64 1e-10) on
+    the HIP path, host and device-resident."""
+    import torch
+    from test_oracle_goldens import db_golden_cases
+    fn = getattr(S, which)
+    for case, x, p, dt in db_golden_cases(which):
+        got = fn(x, reference=p["reference"], amin=p["amin"], top_db=p["top_db"])
+        assert got.dtype == dt and got.shape == x.shape
+        tol = 1e-4 if dt == np.float32 else 1e-10
+        check_close(got, case["values"], shape=case["shape"], rtol=tol, atol=tol, msg=case["name"])
+        if dt == np.float32:
+            gd = fn(torch.from_numpy(x).cuda(), reference=p["reference"], amin=p["amin"], top_db=p["top_db"])
+            assert gd.is_cuda and np.array_equal(gd.cpu().numpy(), got)
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_db_vs_oracle_large(dtype):
+    """A spectrogram-sized tensor: the clamp is under the maximum of the WHOLE tensor (one reduction over 4 M values),
+    negative powers sit at the floor, amplitudes take magnitudes first."""
+    rng = np.random.default_rng(9)
+    x = (rng.standard_normal((3, 1025, 1300)) * np.exp(rng.uniform(-20, 5, size=(3, 1025, 1300)))).astype(dtype)
+    tol = 2e-6 if dtype == np.float32 else 1e-12
+    for top_db in (None, 80.0, 0.0):
+        for fn, on in ((S.power_to_db, O.power_to_db), (S.amplitude_to_db, O.amplitude_to_db)):
+            got, want = fn(x, reference=2.0, top_db=top_db), on(x, reference=2.0, top_db=top_db)
+            assert got.dtype == dtype
+            np.testing.assert_allclose(got, want, rtol=tol, atol=tol * 100)
+
+
 # ---- log-mel / MFCC tail -----------------------------------------------------------------------------------
 
 def test_mfcc_goldens():

@@ -357,3 +357,18 @@ def test_stage_constructors_validate_where_they_are_built():
         assert str(e.value) == message
     st = S.spectral_flatness_stage()
     assert st.flush() == [] and st.latency == 0 and st.reset() is None
+
+
+def test_db_parameter_messages():
+    """convert.ml:3-16: validated before any device work, worded with the reference's module path."""
+    import soundml_amd as S
+    x = np.ones(4, np.float32)
+    for call, message in [
+            (lambda: S.power_to_db(x, reference=0.0), "Soundml.Convert.power_to_db: reference must be finite and positive"),
+            (lambda: S.power_to_db(x, amin=float("nan")), "Soundml.Convert.power_to_db: amin must be finite and positive"),
+            (lambda: S.amplitude_to_db(x, top_db=-1.0), "Soundml.Convert.amplitude_to_db: top_db must be finite and non-negative"),
+            (lambda: S.amplitude_to_db(x, reference=float("inf")), "Soundml.Convert.amplitude_to_db: reference must be finite and positive")]:
+        with pytest.raises(S.InvalidArgument) as e:
+            call()
+        assert str(e.value) == message
+    assert S.power_to_db(np.zeros((0, 3), np.float64)).shape == (0, 3)

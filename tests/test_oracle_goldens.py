@@ -357,3 +357,24 @@ def test_chroma_stft_goldens():
             check_close(got, case["values"], shape=case["shape"], rtol=F32_RTOL, atol=F32_ATOL, msg=case["name"])
         else:
             check_close(got, case["values"], shape=case["shape"], rtol=1e-12, atol=1e-13 * peak, msg=case["name"])
+
+
+# ---- decibel conversions (soundml/test/db/test_golden.ml) ---------------------------------------------------------
+
+def db_golden_cases(which):
+    for case in load_golden("db", which)["cases"]:
+        p = case["params"]
+        dt = np.float32 if p["dtype"] == "float32" else np.float64
+        yield case, np.asarray(p["input"], dtype=dt).reshape(case["shape"]), p, dt
+
+
+@pytest.mark.parametrize("which", ["power_to_db", "amplitude_to_db"])
+def test_db_goldens(which):
+    """Convert.power_to_db / amplitude_to_db restated against librosa's (test_golden.ml:39-57: float32 1e-4,
+    float64 1e-10); the inputs ride in the vector files."""
+    fn = getattr(O, which)
+    for case, x, p, dt in db_golden_cases(which):
+        got = fn(x, reference=p["reference"], amin=p["amin"], top_db=p["top_db"])
+        assert got.dtype == dt
+        tol = 1e-4 if dt == np.float32 else 1e-10
+        check_close(got, case["values"], shape=case["shape"], rtol=tol, atol=tol, msg=case["name"])
