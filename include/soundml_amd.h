@@ -63,6 +63,10 @@ extern "C" {
 #define SMX_WINDOW_BLACKMAN_HARRIS 4
 #define SMX_WINDOW_NUTTALL 5
 #define SMX_WINDOW_FLAT_TOP 6
+#define SMX_WINDOW_BARTLETT 7
+#define SMX_WINDOW_KAISER 8      /* shape parameter: beta, finite and non-negative      */
+#define SMX_WINDOW_GAUSSIAN 9    /* shape parameter: standard deviation in samples, > 0 */
+#define SMX_WINDOW_TUKEY 10      /* shape parameter: taper fraction in [0, 1]           */
 #define SMX_WINDOW_CUSTOM 100
 /* Mel.Config.scale / norm (mel.ml:26-27) */
 #define SMX_MEL_SLANEY 0
@@ -98,6 +102,8 @@ int smx_synchronize(void *stream);
 
 /* ---- Window.make (window.ml:374-405), float64, Hann & friends ------------ */
 int smx_window_make(int kind, int periodic, int64_t n, double *out);
+/* the parametric families too (window.ml:77-97 validate their shape parameter; ignored by the others) */
+int smx_window_make_param(int kind, double param, int periodic, int64_t n, double *out);
 
 /* ---- Stft.Config (stft.ml:48-129) --------------------------------------- */
 int smx_stft_config_create(int64_t fft_size, int64_t win_length /* SMX_DEFAULT = fft_size */,

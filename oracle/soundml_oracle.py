@@ -79,20 +79,76 @@ def _cosine_fill(length: int, coefficients: Sequence[float], m: int) -> np.ndarr
     return buf
 
 
-def window(kind: str, n: int, periodic: bool = True) -> np.ndarray:
-    """window.ml:374-405 ``make`` (float64) + ``fill_window`` (:366-372): a
-    one-point window is 1; the periodic window is the symmetric (n+1)-point
-    window with the last sample dropped."""
+def _bessel_i0_series(x: float) -> float:
+    """window.ml:99-112: the power series of I0, every term positive, stopped at 1e-17 of the running sum."""
+    q = 0.25 * x * x
+    if q == 0.0:
+        return 1.0
+    k, term, total = 1, 1.0, 1.0
+    while True:
+        term = term * q / float(k * k)
+        total = total + term
+        if term <= 1e-17 * total:
+            return total
+        k += 1
+
+
+def _mirror_fill(length: int, m: int, value) -> np.ndarray:
+    """The first half evaluated, every value stored at i and m - 1 - i (window.ml:121-136)."""
+    buf = np.zeros(length, dtype=np.float64)
+    for i in range((m - 1) // 2 + 1):
+        v = value(i)
+        if i < length:
+            buf[i] = v
+        if m - 1 - i < length:
+            buf[m - 1 - i] = v
+    return buf
+
+
+def window(kind: str, n: int, periodic: bool = True, param: Optional[float] = None) -> np.ndarray:
+    """window.ml:374-405 ``make`` (float64) + ``fill_window`` (:366-372): a one-point window is 1; the periodic
+    window is the symmetric (n+1)-point window with the last sample dropped.  ``param`` is the shape parameter of
+    "kaiser" (beta), "gaussian" (standard deviation in samples) and "tukey" (taper fraction), validated as
+    window.ml:77-97 does.  The Kaiser window is evaluated with the plain series of I0 (window.ml:99-112; the
+    reference's two minimax branches for I0 agree with it to a few units in the last place)."""
+    if kind == "kaiser" and not (param is not None and math.isfinite(param) and param >= 0.0):
+        raise ValueError("make: cannot use a kaiser window with beta %s (beta must be finite and non-negative)" % _g(param))
+    if kind == "gaussian" and not (param is not None and math.isfinite(param) and param > 0.0):
+        raise ValueError("make: cannot use a gaussian window with standard deviation %s (standard deviation must be "
+                         "finite and positive)" % _g(param))
+    if kind == "tukey" and not (param is not None and 0.0 <= param <= 1.0):
+        raise ValueError("make: cannot use a tukey window with taper %s (taper must lie in [0, 1])" % _g(param))
     if n < 1:
         raise ValueError(
             "make: cannot make a %d-point window (length must be at least 1)" % n)
     if n == 1:
         return np.ones(1, dtype=np.float64)
     m = n + 1 if periodic else n
-    if kind == "rectangular":
+    if kind == "rectangular" or (kind == "tukey" and param <= 0.0):
         return np.ones(n, dtype=np.float64)
+    if kind == "tukey" and param >= 1.0:
+        kind = "hann"
     if kind in _COSINE_COEFFS:
         return _cosine_fill(n, _COSINE_COEFFS[kind], m)
+    last = float(m - 1)
+    if kind == "bartlett":                               # window.ml:166-174
+        return _mirror_fill(n, m, lambda i: 2.0 * float(i) / last)
+    if kind == "gaussian":                               # window.ml:176-186
+        half, scale = last / 2.0, -1.0 / (2.0 * param * param)
+        return _mirror_fill(n, m, lambda i: math.exp((float(i) - half) * (float(i) - half) * scale))
+    if kind == "tukey":                                  # window.ml:188-205
+        width = int(math.floor(param * last / 2.0))
+        step = 2.0 / param / last
+        buf = _mirror_fill(n, m, lambda i: 0.5 * (1.0 + math.cos(math.pi * (-1.0 + step * float(i)))) if i <= width else 1.0)
+        return buf
+    if kind == "kaiser":                                 # window.ml:296-318, with the series for I0 throughout
+        alpha = last / 2.0
+        denominator = _bessel_i0_series(param)
+
+        def value(i):
+            r = (float(i) - alpha) / alpha
+            return _bessel_i0_series(param * math.sqrt(max(0.0, 1.0 - r * r))) / denominator
+        return _mirror_fill(n, m, value)
     raise ValueError("oracle: unsupported window family %r" % kind)
 
 

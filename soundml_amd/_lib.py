@@ -38,7 +38,8 @@ ALIGNMENT = {"centered": 0, "left": 1, "right": 2}
 PAD = {"reflect": 0, "constant": 1, "edge": 2}
 SCALE = {"none": 0, "magnitude": 1, "psd": 2}
 WINDOW = {"hann": 0, "rectangular": 1, "hamming": 2, "blackman": 3, "blackman_harris": 4,
-          "nuttall": 5, "flat_top": 6, "custom": 100}
+          "nuttall": 5, "flat_top": 6, "bartlett": 7, "kaiser": 8, "gaussian": 9, "tukey": 10, "custom": 100}
+WINDOW_PARAMETRIC = ("kaiser", "gaussian", "tukey")
 MEL_SCALE = {"slaney": 0, "htk": 1}
 MEL_NORM = {"slaney": 0, "none": 1}
 INTERIOR = {"float32": 0, "float64": 1}
@@ -129,6 +130,7 @@ SIGNATURES = {
     "smx_amplitude_to_db_f32": (cint, [vp, i64, f64, f64, cint, f64, vp]),
     "smx_amplitude_to_db_f64": (cint, [vp, i64, f64, f64, cint, f64, vp]),
     "smx_amplitude_to_db_f32_dev": (cint, [vp, i64, f64, f64, cint, f64, vp, vp]),
+    "smx_window_make_param": (cint, [cint, f64, cint, i64, vp]),
     "smx_stft_nola": (cint, [vp, C.POINTER(cint)]),
     "smx_stft_output_length": (cint, [vp, i64, pi64]),
     "smx_stft_invert_f32": (cint, [vp, vp, i64, i64, i64, cint, i64, vp]),

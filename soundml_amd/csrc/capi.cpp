@@ -243,6 +243,13 @@ int smx_window_make(int kind, int periodic, int64_t n, double *out) {
   });
 }
 
+int smx_window_make_param(int kind, double param, int periodic, int64_t n, double *out) {
+  return guarded([&] {
+    if (n >= 1 && !out) throw Failure("make: null output");
+    window_make_param(kind, param, periodic != 0, n, out);
+  });
+}
+
 // =============================== Stft.Config =================================
 int smx_stft_config_create(int64_t fft_size, int64_t win_length, int64_t hop, int alignment, int pad,
                            double pad_value, int scale, int window_kind, const double *custom_window,

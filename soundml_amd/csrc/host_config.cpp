@@ -54,7 +54,29 @@ void cosine_fill(double *buf, int64_t len, const double *coef, int order, int64_
 
 }  // namespace
 
-void window_make(int kind, bool periodic, int64_t n, double *out) {
+namespace {
+// the first half evaluated, every value stored at i and m - 1 - i; slots at or past `len` fall off (window.ml:121-136)
+template <typename F>
+void mirror_fill(double *out, int64_t len, int64_t m, F value) {
+  for (int64_t i = 0; i <= (m - 1) / 2; ++i) {
+    const double v = value(i);
+    if (i < len) out[i] = v;
+    if (m - 1 - i < len) out[m - 1 - i] = v;
+  }
+}
+}  // namespace
+
+void window_make(int kind, bool periodic, int64_t n, double *out) { window_make_param(kind, 0.0, periodic, n, out); }
+
+// the shape parameter: Kaiser beta, Gaussian standard deviation (samples), Tukey taper fraction (window.ml:77-97)
+void window_make_param(int kind, double param, bool periodic, int64_t n, double *out) {
+  if (kind == SMX_WINDOW_KAISER && !(std::isfinite(param) && param >= 0.0))
+    throw InvalidArgument(format("make: cannot use a kaiser window with beta %g (beta must be finite and non-negative)", param));
+  if (kind == SMX_WINDOW_GAUSSIAN && !(std::isfinite(param) && param > 0.0))
+    throw InvalidArgument(format(
+        "make: cannot use a gaussian window with standard deviation %g (standard deviation must be finite and positive)", param));
+  if (kind == SMX_WINDOW_TUKEY && !(param >= 0.0 && param <= 1.0))
+    throw InvalidArgument(format("make: cannot use a tukey window with taper %g (taper must lie in [0, 1])", param));
   if (n < 1)
     throw InvalidArgument(format(
         "make: cannot make a %lld-point window (length must be at least 1)", (long long)n));
@@ -69,10 +91,44 @@ void window_make(int kind, bool periodic, int64_t n, double *out) {
   static const double bh[] = {0.35875, 0.48829, 0.14128, 0.01168};
   static const double nuttall[] = {0.3635819, 0.4891775, 0.1365995, 0.0106411};
   static const double flat_top[] = {0.21557895, 0.41663158, 0.277263158, 0.083578947, 0.006947368};
+  const double last = (double)(m - 1);
+  if (kind == SMX_WINDOW_TUKEY) {               // window.ml:352-355: the ends of the family are the other two windows
+    if (param <= 0.0) kind = SMX_WINDOW_RECTANGULAR;
+    else if (param >= 1.0) kind = SMX_WINDOW_HANN;
+  }
   switch (kind) {
     case SMX_WINDOW_RECTANGULAR:
       for (int64_t i = 0; i < n; ++i) out[i] = 1.0;
       return;
+    case SMX_WINDOW_BARTLETT:                   // window.ml:166-174
+      mirror_fill(out, n, m, [&](int64_t i) { return 2.0 * (double)i / last; });
+      return;
+    case SMX_WINDOW_GAUSSIAN: {                 // window.ml:176-186
+      const double half = last / 2.0, scale = -1.0 / (2.0 * param * param);
+      mirror_fill(out, n, m, [&](int64_t i) {
+        const double x = (double)i - half;
+        return std::exp(x * x * scale);
+      });
+      return;
+    }
+    case SMX_WINDOW_TUKEY: {                    // window.ml:188-205
+      const int64_t width = (int64_t)std::floor(param * last / 2.0);
+      const double step = 2.0 / param / last;
+      mirror_fill(out, n, m, [&](int64_t i) {
+        return i <= width ? 0.5 * (1.0 + std::cos(M_PI * (-1.0 + step * (double)i))) : 1.0;
+      });
+      return;
+    }
+    case SMX_WINDOW_KAISER: {                   // window.ml:296-318; I0 by its power series throughout (bessel_i0 below:
+      const double alpha = last / 2.0;          // the reference's minimax branches agree with it to a few ulp)
+      const double denominator = bessel_i0(param);
+      mirror_fill(out, n, m, [&](int64_t i) {
+        const double r = ((double)i - alpha) / alpha;
+        const double inner = 1.0 - r * r;
+        return bessel_i0(param * std::sqrt(inner > 0.0 ? inner : 0.0)) / denominator;
+      });
+      return;
+    }
     case SMX_WINDOW_HANN: cosine_fill(out, n, hann, 2, m); return;
     case SMX_WINDOW_HAMMING: cosine_fill(out, n, hamming, 2, m); return;
     case SMX_WINDOW_BLACKMAN: cosine_fill(out, n, blackman, 3, m); return;

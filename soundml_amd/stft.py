@@ -42,6 +42,15 @@ class Config:
         if isinstance(pad, tuple):
             pad, pad_value = pad[0], float(pad[1])
         custom = None
+        if isinstance(window, tuple) or (isinstance(window, str) and window in ("bartlett",) + _lib.WINDOW_PARAMETRIC):
+            # the families the config's C face does not build itself: their float64 table (Window.make, periodic)
+            from . import window as Window
+            label = window if isinstance(window, str) else "%s(%g)" % (window[0], float(window[1]))
+            window = Window.make(np.float64, window, int(fft_size) if win_length is None else int(win_length))
+            if win_length is None:
+                win_length = int(fft_size)
+        else:
+            label = None
         if isinstance(window, str):
             if window not in _lib.WINDOW:
                 raise _lib.InvalidArgument("create: unknown window family %r" % window)
@@ -52,7 +61,7 @@ class Config:
                 win_length = int(table.shape[0])
             if table.shape[0] != win_length:
                 raise _lib.InvalidArgument("create: custom window table must have win_length points")
-            custom, kind, name = table, _lib.WINDOW["custom"], "custom"
+            custom, kind, name = table, _lib.WINDOW["custom"], (label or "custom")
         for value, table_, what in ((alignment, _lib.ALIGNMENT, "alignment"), (pad, _lib.PAD, "pad"),
                                     (scale, _lib.SCALE, "scale")):
             if value not in table_:

@@ -112,17 +112,47 @@ def test_coordinates_goldens():
         Stft.times(np.float64, c, 0, 10)
 
 
-@pytest.mark.parametrize("family", ["hann", "hamming", "blackman", "rectangular"])
+@pytest.mark.parametrize("family", ["hann", "hamming", "blackman", "rectangular", "blackman_harris", "nuttall", "flat_top", "bartlett",
+                                    "gaussian", "kaiser", "tukey"])
 def test_window_goldens(family):
+    """All eleven families of Window.t (window.ml:34-57) as the library builds them, against scipy's vectors
+    (test_window.ml:66-80) and the oracle (bit-identical for the closed forms; the Kaiser window's I0 series stops at
+    machine epsilon here and at 1e-17 there)."""
+    from test_oracle_goldens import window_param
     for case in load_golden("window", family)["cases"]:
         p = case["params"]
-        got = Window.make(np.float64, p["window"], p["n"], periodic=p["periodic"])
+        param = window_param(p)
+        spec = p["window"] if param is None else (p["window"], param)
+        got = Window.make(np.float64, spec, p["n"], periodic=p["periodic"])
         check_close(got, case["values"], case["shape"], msg=case["name"])
-        assert np.array_equal(got, O.window(p["window"], p["n"], p["periodic"]))   # bit-identical to the oracle
-        check_close(Window.make(np.float32, p["window"], p["n"], periodic=p["periodic"]), case["values"],
+        want = O.window(p["window"], p["n"], p["periodic"], param)
+        if family == "kaiser":
+            np.testing.assert_allclose(got, want, rtol=1e-15, atol=0)
+        else:
+            assert np.array_equal(got, want)   # bit-identical to the oracle
+        check_close(Window.make(np.float32, spec, p["n"], periodic=p["periodic"]), case["values"],
                     case["shape"], F32_RTOL, F32_ATOL, case["name"] + "/float32")
+    spec = family if family not in ("kaiser", "gaussian", "tukey") else (family, 0.5)
     with pytest.raises(S.InvalidArgument, match="make: cannot make a 0-point window"):
-        Window.make(np.float64, family, 0)
+        Window.make(np.float64, spec, 0)
+
+
+def test_window_shape_parameters():
+    """window.ml:77-97: the shape parameters are validated where the window is used; a config takes any family."""
+    for spec, message in [(("kaiser", -1.0), "make: cannot use a kaiser window with beta -1 (beta must be finite and non-negative)"),
+                          (("gaussian", 0.0), "make: cannot use a gaussian window with standard deviation 0 (standard deviation must be finite and positive)"),
+                          (("tukey", 1.5), "make: cannot use a tukey window with taper 1.5 (taper must lie in [0, 1])")]:
+        with pytest.raises(S.InvalidArgument) as e:
+            Window.make(np.float64, spec, 16)
+        assert str(e.value) == message
+    with pytest.raises(S.InvalidArgument, match="needs its shape parameter"):
+        Window.make(np.float64, "kaiser", 16)
+    for spec in ("bartlett", ("kaiser", 6.0), ("gaussian", 40.0), ("tukey", 0.5)):
+        c = Stft.Config.create(fft_size=256, win_length=200, hop=64, window=spec)
+        kind, param = (spec, None) if isinstance(spec, str) else spec
+        w = np.zeros(256)
+        w[28:228] = O.window(kind, 200, True, param)
+        np.testing.assert_allclose(c.analysis_window, w, rtol=1e-15, atol=0)
 
 
 @pytest.mark.parametrize("scale", ["none", "magnitude", "psd"])

@@ -64,11 +64,21 @@ def test_coordinates():
                     case["name"] + "/float32")
 
 
-@pytest.mark.parametrize("family", ["hann", "hamming", "blackman", "rectangular"])
+WINDOW_FAMILIES = ["hann", "hamming", "blackman", "rectangular", "blackman_harris", "nuttall", "flat_top", "bartlett", "gaussian",
+                   "kaiser", "tukey"]
+
+
+def window_param(p):
+    """The shape parameter of the parametric families as the vector files name it."""
+    return p.get("beta", p.get("std", p.get("taper")))
+
+
+@pytest.mark.parametrize("family", WINDOW_FAMILIES)
 def test_windows(family):
+    """All eleven families of Window.t against scipy's (test_window.ml:66-80)."""
     for case in load_golden("window", family)["cases"]:
         p = case["params"]
-        got = O.window(p["window"], p["n"], periodic=p["periodic"])
+        got = O.window(p["window"], p["n"], periodic=p["periodic"], param=window_param(p))
         check_close(got, case["values"], case["shape"], msg=case["name"])
 
 
