@@ -104,6 +104,8 @@ int smx_synchronize(void *stream);
 int smx_window_make(int kind, int periodic, int64_t n, double *out);
 /* the parametric families too (window.ml:77-97 validate their shape parameter; ignored by the others) */
 int smx_window_make_param(int kind, double param, int periodic, int64_t n, double *out);
+/* Window.cola (window.ml:407-434): 1 iff the `length`-point periodic window overlap-adds to a constant at `hop` */
+int smx_window_cola(int kind, double param, int64_t length, int64_t hop, int *cola);
 
 /* ---- Stft.Config (stft.ml:48-129) --------------------------------------- */
 int smx_stft_config_create(int64_t fft_size, int64_t win_length /* SMX_DEFAULT = fft_size */,

@@ -152,6 +152,23 @@ def window(kind: str, n: int, periodic: bool = True, param: Optional[float] = No
     raise ValueError("oracle: unsupported window family %r" % kind)
 
 
+def cola(kind: str, length: int, hop: int, param: Optional[float] = None) -> bool:
+    """window.ml:407-434 ``cola``: the periodic window's shifts by ``hop`` sum to a constant within 1e-10 of the mean."""
+    if length < 1:
+        raise ValueError("cola: cannot check overlap-add of a %d-point window (length must be at least 1)" % length)
+    if hop < 1 or hop > length:
+        raise ValueError("cola: cannot check overlap-add at hop %d (hop must lie in [1, %d])" % (hop, length))
+    w = window(kind, length, True, param)
+    sums = [0.0] * hop
+    for i in range(length):
+        sums[i % hop] = sums[i % hop] + float(w[i])
+    mean = 0.0
+    for v in sums:
+        mean = mean + v
+    mean = mean / float(hop)
+    return mean > 0.0 and all(abs(v - mean) <= 1e-10 * mean for v in sums)
+
+
 # ----------------------------------------------------------------------------
 # Stft.Config and the frame grid (stft.ml:48-261)
 # ----------------------------------------------------------------------------

@@ -250,6 +250,13 @@ int smx_window_make_param(int kind, double param, int periodic, int64_t n, doubl
   });
 }
 
+int smx_window_cola(int kind, double param, int64_t length, int64_t hop, int *cola) {
+  return guarded([&] {
+    if (!cola) throw Failure("cola: null output");
+    *cola = window_cola(kind, param, length, hop) ? 1 : 0;
+  });
+}
+
 // =============================== Stft.Config =================================
 int smx_stft_config_create(int64_t fft_size, int64_t win_length, int64_t hop, int alignment, int pad,
                            double pad_value, int scale, int window_kind, const double *custom_window,

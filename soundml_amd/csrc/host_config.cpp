@@ -140,6 +140,26 @@ void window_make_param(int kind, double param, bool periodic, int64_t n, double 
   }
 }
 
+// window.ml:407-434 cola: the periodic window's shifts by `hop` sum to a constant within 1e-10 of their mean
+bool window_cola(int kind, double param, int64_t length, int64_t hop) {
+  if (length < 1)
+    throw InvalidArgument(format("cola: cannot check overlap-add of a %lld-point window (length must be at least 1)",
+                                 (long long)length));
+  if (hop < 1 || hop > length)
+    throw InvalidArgument(format("cola: cannot check overlap-add at hop %lld (hop must lie in [1, %lld])", (long long)hop,
+                                 (long long)length));
+  std::vector<double> w((size_t)length), sums((size_t)hop, 0.0);
+  window_make_param(kind, param, true, length, w.data());
+  for (int64_t i = 0; i < length; ++i) sums[(size_t)(i % hop)] += w[(size_t)i];
+  double mean = 0.0;
+  for (double v : sums) mean += v;
+  mean /= (double)hop;
+  if (!(mean > 0.0)) return false;
+  for (double v : sums)
+    if (!(std::fabs(v - mean) <= 1e-10 * mean)) return false;
+  return true;
+}
+
 // ---- Stft.Config (stft.ml:61-111) -------------------------------------------------
 
 smx_stft_config *stft_config_create(int64_t fft_size, int64_t win_length, int64_t hop,

@@ -172,6 +172,7 @@ namespace smx {
 // ---- host logic (host_config.cpp) ----------------------------------------------
 void window_make(int kind, bool periodic, int64_t n, double *out);             // window.ml:374-405
 void window_make_param(int kind, double param, bool periodic, int64_t n, double *out);   // Kaiser / Gaussian / Tukey too
+bool window_cola(int kind, double param, int64_t length, int64_t hop);          // window.ml:407-434
 smx_stft_config *stft_config_create(int64_t fft_size, int64_t win_length, int64_t hop,
                                     int alignment, int pad, double pad_value, int scale,
                                     int window_kind, const double *custom_window);

@@ -32,3 +32,11 @@ def make(dtype, kind, n: int, periodic: bool = True) -> np.ndarray:
     check(lib.smx_window_make_param(_lib.WINDOW[name], 0.0 if param is None else param, 1 if periodic else 0, int(n),
                                     C.c_void_p(out.ctypes.data)))
     return out[:n].astype(dtype)
+
+
+def cola(kind, length: int, hop: int) -> bool:
+    """``Window.cola w ~length ~hop`` (window.ml:407-434): the periodic window's shifts by ``hop`` sum to a constant."""
+    name, param = family(kind)
+    flag = C.c_int()
+    check(lib.smx_window_cola(_lib.WINDOW[name], 0.0 if param is None else param, int(length), int(hop), C.byref(flag)))
+    return bool(flag.value)

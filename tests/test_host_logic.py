@@ -402,3 +402,18 @@ def test_db_parameter_messages():
             call()
         assert str(e.value) == message
     assert S.power_to_db(np.zeros((0, 3), np.float64)).shape == (0, 3)
+
+
+def test_cola_goldens_and_messages():
+    from test_oracle_goldens import window_param
+    for case in load_golden("window", "cola")["cases"]:
+        p = case["params"]
+        param = window_param(p)
+        spec = p["window"] if param is None else (p["window"], param)
+        assert Window.cola(spec, p["length"], p["hop"]) == case["expected"], case["name"]
+    with pytest.raises(S.InvalidArgument) as e:
+        Window.cola("hann", 0, 1)
+    assert str(e.value) == "cola: cannot check overlap-add of a 0-point window (length must be at least 1)"
+    with pytest.raises(S.InvalidArgument) as e:
+        Window.cola("hann", 8, 9)
+    assert str(e.value) == "cola: cannot check overlap-add at hop 9 (hop must lie in [1, 8])"

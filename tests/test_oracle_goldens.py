@@ -388,3 +388,10 @@ def test_db_goldens(which):
         assert got.dtype == dt
         tol = 1e-4 if dt == np.float32 else 1e-10
         check_close(got, case["values"], shape=case["shape"], rtol=tol, atol=tol, msg=case["name"])
+
+
+def test_cola_goldens():
+    """Window.cola against scipy.signal.check_COLA (test_window.ml)."""
+    for case in load_golden("window", "cola")["cases"]:
+        p = case["params"]
+        assert O.cola(p["window"], p["length"], p["hop"], window_param(p)) == case["expected"], case["name"]
