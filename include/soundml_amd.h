@@ -182,6 +182,9 @@ int smx_stft_kernel_flush(smx_stft_kernel *k, void *out_complex, int64_t capacit
 int smx_stft_kernel_reset(smx_stft_kernel *k);
 
 /* ---- Mel.Config / Mel.apply (mel.ml:22-233) ------------------------------- */
+/* Convert.hz_to_mel / mel_to_hz (convert.ml:70-102): the scalar maps behind the filterbank's breakpoints; host float64 */
+int smx_hz_to_mel(int scale /* SMX_MEL_* */, const double *f, int64_t n, double *out);
+int smx_mel_to_hz(int scale, const double *m, int64_t n, double *out);
 int smx_mel_config_create(int64_t n_mels, int64_t sample_rate, int64_t fft_size, double f_min,
                           int has_f_max, double f_max, int scale, int norm, smx_mel_config **out);
 /* A filterbank handle over caller-supplied float64 weights [rows; fft_size/2 + 1] (copied): every projection of

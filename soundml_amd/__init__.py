@@ -16,6 +16,7 @@ from . import mel as Mel
 from . import window as Window
 from . import fir as Fir
 from . import chroma as Chroma
+from . import convert as Convert
 from .features import mel_spectrogram, mfcc, chroma_stft, power_to_db, amplitude_to_db
 from .spectral import (spectral_centroid, spectral_bandwidth, spectral_rolloff, spectral_flatness,
                        spectral_centroid_stage, spectral_bandwidth_stage, spectral_rolloff_stage, spectral_flatness_stage)
@@ -39,6 +40,6 @@ def device_count() -> int:
     return n.value
 
 
-__all__ = ["Stft", "Mel", "Chroma", "Window", "Fir", "mel_spectrogram", "mfcc", "chroma_stft", "power_to_db", "amplitude_to_db", "spectral_centroid",
+__all__ = ["Stft", "Mel", "Chroma", "Convert", "Window", "Fir", "mel_spectrogram", "mfcc", "chroma_stft", "power_to_db", "amplitude_to_db", "spectral_centroid",
            "spectral_bandwidth", "spectral_rolloff", "spectral_flatness", "shard", "set_interior", "set_scratch_retention", "device_count",
            "InvalidArgument", "Failure", "LIB_PATH"]

@@ -132,6 +132,8 @@ SIGNATURES = {
     "smx_amplitude_to_db_f32_dev": (cint, [vp, i64, f64, f64, cint, f64, vp, vp]),
     "smx_window_make_param": (cint, [cint, f64, cint, i64, vp]),
     "smx_window_cola": (cint, [cint, f64, i64, i64, C.POINTER(cint)]),
+    "smx_hz_to_mel": (cint, [cint, vp, i64, vp]),
+    "smx_mel_to_hz": (cint, [cint, vp, i64, vp]),
     "smx_stft_nola": (cint, [vp, C.POINTER(cint)]),
     "smx_stft_output_length": (cint, [vp, i64, pi64]),
     "smx_stft_invert_f32": (cint, [vp, vp, i64, i64, i64, cint, i64, vp]),

@@ -257,6 +257,22 @@ int smx_window_cola(int kind, double param, int64_t length, int64_t hop, int *co
   });
 }
 
+// Convert.hz_to_mel / mel_to_hz (convert.ml:70-102): the scalar maps the mel breakpoints are built from, on host values
+int smx_hz_to_mel(int scale, const double *f, int64_t n, double *out) {
+  return guarded([&] {
+    if (scale != SMX_MEL_SLANEY && scale != SMX_MEL_HTK) throw InvalidArgument(format("hz_to_mel: unknown mel scale %d", scale));
+    if (n > 0 && (!f || !out)) throw Failure("hz_to_mel: null pointer");
+    for (int64_t i = 0; i < n; ++i) out[i] = hz_to_mel(f[i], scale);
+  });
+}
+int smx_mel_to_hz(int scale, const double *m, int64_t n, double *out) {
+  return guarded([&] {
+    if (scale != SMX_MEL_SLANEY && scale != SMX_MEL_HTK) throw InvalidArgument(format("mel_to_hz: unknown mel scale %d", scale));
+    if (n > 0 && (!m || !out)) throw Failure("mel_to_hz: null pointer");
+    for (int64_t i = 0; i < n; ++i) out[i] = mel_to_hz(m[i], scale);
+  });
+}
+
 // =============================== Stft.Config =================================
 int smx_stft_config_create(int64_t fft_size, int64_t win_length, int64_t hop, int alignment, int pad,
                            double pad_value, int scale, int window_kind, const double *custom_window,

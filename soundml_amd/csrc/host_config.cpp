@@ -345,6 +345,8 @@ const double kMinLogHz = 1000.0;            // convert.ml:74
 const double kMinLogMel = kMinLogHz / kFsp; // convert.ml:76
 const double kLogStep = std::log(6.4) / 27.0;  // convert.ml:78
 
+}  // namespace
+
 double hz_to_mel(double f, int scale) {  // convert.ml:80-90
   if (scale == SMX_MEL_HTK) return std::log(f / 700.0 + 1.0) * (2595.0 / std::log(10.0));
   if (f < kMinLogHz) return f / kFsp;
@@ -356,8 +358,6 @@ double mel_to_hz(double m, int scale) {  // convert.ml:92-102
   if (m < kMinLogMel) return m * kFsp;
   return std::exp((m - kMinLogMel) * kLogStep) * kMinLogHz;
 }
-
-}  // namespace
 
 smx_mel_config *mel_config_create(int64_t n_mels, int64_t sample_rate, int64_t fft_size,
                                   double f_min, bool has_f_max, double f_max, int scale, int norm) {

@@ -190,6 +190,8 @@ int64_t stft_output_length(const smx_stft_config &c, int64_t frames);           
 // tap, one period of the folded squared window for [head, stop) (stft.ml:836-889); all guarded against 0
 void stft_envelope(const smx_stft_config &c, int64_t frames, std::vector<double> &head, std::vector<double> &period,
                    std::vector<double> &tail, int64_t &head_n, int64_t &stop);
+double hz_to_mel(double f, int scale);                                           // convert.ml:80-90
+double mel_to_hz(double m, int scale);                                           // convert.ml:92-102
 double kaiser_beta(double att);                                                  // resample.ml:105-109
 double bessel_i0(double x);                                                      // resample.ml:128-139
 void design_lowpass(int64_t taps, double fc, double beta, double *h);

@@ -417,3 +417,16 @@ def test_cola_goldens_and_messages():
     with pytest.raises(S.InvalidArgument) as e:
         Window.cola("hann", 8, 9)
     assert str(e.value) == "cola: cannot check overlap-add at hop 9 (hop must lie in [1, 8])"
+
+
+def test_mel_scale_maps_match_the_oracle():
+    """Convert.hz_to_mel / mel_to_hz (convert.ml:70-102) through the ABI: both scales, the break at 1 kHz, round trips."""
+    from oracle import soundml_oracle as O
+    f = np.array([0.0, 1.0, 440.0, 999.999, 1000.0, 1000.001, 8000.0, 24000.0])
+    for scale in ("slaney", "htk"):
+        m = S.Convert.hz_to_mel(f, scale)
+        np.testing.assert_allclose(m, O.hz_to_mel(f, scale), rtol=1e-15, atol=0)
+        np.testing.assert_allclose(S.Convert.mel_to_hz(m, scale), f, rtol=1e-12, atol=1e-12)
+    assert S.Convert.hz_to_mel(np.float32([440.0])).dtype == np.float32
+    with pytest.raises(S.InvalidArgument):
+        S.Convert.hz_to_mel(f, "bark")
