@@ -1135,3 +1135,19 @@ np.savez(sys.argv[2], **out)
         check_fast(fused["p%d" % i], generic["p%d" % i], "power %s" % c)
         check_fast(fused["z%d" % i].real, generic["z%d" % i].real, "re %s" % c)
         check_fast(fused["z%d" % i].imag, generic["z%d" % i].imag, "im %s" % c)
+
+
+def test_c_abi_from_plain_c(tmp_path):
+    """The boundary is a C ABI: examples/power_spectrum.c (no Python, no torch) compiled with gcc against the header and
+    the shared library finds the 440 Hz tone in bin 10 of a fft-1024 power spectrogram and computes its mel spectrogram."""
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "power_spectrum")
+    libdir = os.path.join(root, "soundml_amd", "lib")
+    subprocess.check_call(["gcc", "-O2", "-Wall", "-Werror", "-I", os.path.join(root, "include"),
+                           os.path.join(root, "examples", "power_spectrum.c"), "-L", libdir, "-lsoundml_amd",
+                           "-Wl,-rpath," + libdir, "-lm", "-o", exe])
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "peak bin 10" in out.stdout
