@@ -372,3 +372,33 @@ CAMLprim value soundml_amd_chroma_apply_bc(value *argv, int argn) {
   (void)argn;
   return soundml_amd_chroma_apply(argv[0], argv[1], argv[2], argv[3], argv[4], argv[5], argv[6], argv[7]);
 }
+
+/* Convert.power_to_db / amplitude_to_db (convert.ml:52-62): v_amplitude selects the amplitude form; top_db < 0 = None
+ * (the OCaml side validates the user's values first, with the reference's messages; the C side repeats the checks). */
+CAMLprim value soundml_amd_to_db(value v_amplitude, value v_s, value v_out, value v_reference, value v_amin, value v_top_db) {
+  CAMLparam5(v_amplitude, v_s, v_out, v_reference, v_amin);
+  CAMLxparam1(v_top_db);
+  const int kind = ba_kind(v_s);
+  if ((kind != CAML_BA_FLOAT32 && kind != CAML_BA_FLOAT64) || ba_kind(v_out) != kind)
+    caml_failwith("soundml_amd: unsupported or mixed dtypes");
+  const int64_t total = ba_dim(v_s);
+  if (ba_dim(v_out) < total) caml_failwith("soundml_amd: buffer extents disagree with geometry");
+  const double reference = Double_val(v_reference), amin = Double_val(v_amin), top_db = Double_val(v_top_db);
+  const int has_top = top_db >= 0.0, amplitude = Bool_val(v_amplitude);
+  void *s = Caml_ba_data_val(v_s), *out = Caml_ba_data_val(v_out);
+  int status;
+  caml_release_runtime_system();
+  if (kind == CAML_BA_FLOAT32)
+    status = amplitude ? smx_amplitude_to_db_f32((const float *)s, total, reference, amin, has_top, top_db, (float *)out)
+                       : smx_power_to_db_f32((const float *)s, total, reference, amin, has_top, top_db, (float *)out);
+  else
+    status = amplitude ? smx_amplitude_to_db_f64((const double *)s, total, reference, amin, has_top, top_db, (double *)out)
+                       : smx_power_to_db_f64((const double *)s, total, reference, amin, has_top, top_db, (double *)out);
+  caml_acquire_runtime_system();
+  smx_raise(status);
+  CAMLreturn(Val_unit);
+}
+CAMLprim value soundml_amd_to_db_bc(value *argv, int argn) {
+  (void)argn;
+  return soundml_amd_to_db(argv[0], argv[1], argv[2], argv[3], argv[4], argv[5]);
+}

@@ -155,3 +155,21 @@ let chroma_apply ?(norm = `Inf) (c : Chroma.Config.t) s =
   let kind, p = match norm with `None -> (0, 0.) | `Inf -> (1, 0.) | `P p -> (2, p) in
   chroma_apply_c h (flat s) (Nx_buffer.to_bigarray1 (Nx.to_buffer out)) lead bins frames kind p ;
   out
+
+(* ---- Convert.power_to_db / amplitude_to_db (convert.ml:52-62) ------------------------------------------- *)
+
+external to_db_c :
+  bool -> ('a, 'b, Bigarray.c_layout) Bigarray.Array1.t -> ('a, 'b, Bigarray.c_layout) Bigarray.Array1.t ->
+  float -> float -> float -> unit
+  = "soundml_amd_to_db_bc" "soundml_amd_to_db"
+
+(* Replaces the body of convert.ml:30-50 [to_db] after the three [check_*] calls: the floor, the logarithm, the reference
+   offset and the clamp under the tensor's maximum in one call, in the tensor's own dtype. *)
+let to_db ~amplitude ~reference ~amin ~top_db s =
+  if Nx.numel s = 0 then Nx.copy s
+  else begin
+    let out = Nx.empty (Nx.dtype s) (Nx.shape s) in
+    to_db_c amplitude (flat s) (Nx_buffer.to_bigarray1 (Nx.to_buffer out)) reference amin
+      (match top_db with Some r -> r | None -> -1.) ;
+    out
+  end
