@@ -113,7 +113,7 @@ def main():
     elapsed = S.shard.timed_region_max(elapsed, device=dev)
     step_ms = sorted(a.elapsed_time(b) for a, b in ev)
     avg_step_ms = sum(step_ms) / len(step_ms)
-    # One step is ONE launch of the fused kernel (stft2048_power_kernel<true, true, false, false>: the interior
+    # One step is ONE launch of the fused kernel (stft2048_power_kernel<true, true, false>: the interior
     # tiles, then the few border frames of every clip through the same frame code), so the HIP events recorded
     # on the launch stream around each step of the timed region are that kernel's launch durations: their
     # average is what `rocprofv3 --kernel-trace --stats` of this command reports for it (profiles/).
@@ -142,7 +142,7 @@ def main():
                        "frames_per_gpu": clips * frames, "sharding": "clips over ranks, no collective"},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-                         "kernel": "stft2048_power_kernel<true,true,false,false> (one launch per step: all %d frames of %d clips)" % (frames, clips),
+                         "kernel": "stft2048_power_kernel<true, true, false> (one launch per step: all %d frames of %d clips)" % (frames, clips),
                          "kernel_ms_avg": round(avg_kernel_ms, 4), "kernel_ms_min": round(kernel_ms[0], 4),
                          "algorithmic_bytes_per_frame": ALGO_BYTES_PER_FRAME},
         }
