@@ -5,6 +5,8 @@
 // The interior is float64 whatever the audio dtype (the reference's contract).  Two launches: a max reduction
 // of the mel spectrogram (the logarithm is monotonic, so the maximum of db is db of the maximum), then one
 // thread per (clip, frame) walking the mel axis with frames across lanes (coalesced).
+#include <tuple>
+
 #include "smx_internal.hpp"
 
 namespace smx {
@@ -151,10 +153,24 @@ void launch_to_db(const ToDbJob &job) {
   else run_to_db<float>(job);
 }
 
-void launch_mfcc(const MfccJob &job) {
-  if (job.lead <= 0 || job.frames <= 0) return;
-  const int n_mels = job.n_mels, n_mfcc = job.n_mfcc;
-  // tables: raw DCT-II rows, orthonormal scales (soundml.ml:26-33), lifter weights (soundml.ml:35-42)
+namespace {
+struct MfccKey {
+  int device, n_mels, n_mfcc;
+  double lifter;
+  bool operator<(const MfccKey &o) const {
+    return std::tie(device, n_mels, n_mfcc, lifter) < std::tie(o.device, o.n_mels, o.n_mfcc, o.lifter);
+  }
+};
+std::mutex g_mfcc_mutex;
+std::map<MfccKey, double *> g_mfcc_tables;
+
+// [n_mfcc; n_mels] raw type-II rows, then [n_mfcc; 2] (orthonormal scale, lifter weight), device resident
+const double *mfcc_tables(int n_mels, int n_mfcc, double lifter) {
+  MfccKey key{0, n_mels, n_mfcc, lifter};
+  SMX_HIP_CHECK(hipGetDevice(&key.device));
+  std::lock_guard<std::mutex> lock(g_mfcc_mutex);
+  auto it = g_mfcc_tables.find(key);
+  if (it != g_mfcc_tables.end()) return it->second;
   std::vector<double> host((size_t)n_mfcc * n_mels + 2 * (size_t)n_mfcc);
   const double pi = 3.14159265358979323846;
   for (int k = 0; k < n_mfcc; ++k)
@@ -163,14 +179,25 @@ void launch_mfcc(const MfccJob &job) {
   double *post = host.data() + (size_t)n_mfcc * n_mels;
   for (int k = 0; k < n_mfcc; ++k) {
     post[2 * k] = k == 0 ? 1.0 / std::sqrt(4.0 * n_mels) : 1.0 / std::sqrt(2.0 * n_mels);
-    post[2 * k + 1] = job.lifter > 0.0 ? 1.0 + job.lifter / 2.0 * std::sin(pi * (double)(k + 1) / job.lifter) : 1.0;
+    post[2 * k + 1] = lifter > 0.0 ? 1.0 + lifter / 2.0 * std::sin(pi * (double)(k + 1) / lifter) : 1.0;
   }
-  double *d_tab = nullptr;
-  SMX_HIP_CHECK(hipMallocAsync((void **)&d_tab, (host.size() + 1) * sizeof(double), job.stream));
-  SMX_HIP_CHECK(hipMemcpyAsync(d_tab, host.data(), host.size() * sizeof(double), hipMemcpyHostToDevice, job.stream));
-  unsigned long long *d_max = reinterpret_cast<unsigned long long *>(d_tab + host.size());
+  double *dev = nullptr;
+  SMX_HIP_CHECK(hipMalloc((void **)&dev, host.size() * sizeof(double)));
+  SMX_HIP_CHECK(hipMemcpy(dev, host.data(), host.size() * sizeof(double), hipMemcpyHostToDevice));
+  g_mfcc_tables.emplace(key, dev);
+  return dev;
+}
+}  // namespace
+
+void launch_mfcc(const MfccJob &job) {
+  if (job.lead <= 0 || job.frames <= 0) return;
+  const int n_mels = job.n_mels, n_mfcc = job.n_mfcc;
+  // tables: raw DCT-II rows, orthonormal scales (soundml.ml:26-33), lifter weights (soundml.ml:35-42) -- built once per
+  // (device, n_mels, n_mfcc, lifter) and kept, so a call uploads nothing and never synchronises its stream
+  const double *d_tab = mfcc_tables(n_mels, n_mfcc, job.lifter);
+  unsigned long long *d_max = nullptr;
+  SMX_HIP_CHECK(hipMallocAsync((void **)&d_max, sizeof(unsigned long long), job.stream));
   SMX_HIP_CHECK(hipMemsetAsync(d_max, 0, sizeof(unsigned long long), job.stream));
-  SMX_HIP_CHECK(hipStreamSynchronize(job.stream));   // `host` is pageable memory that dies with this call
   const int64_t total = job.lead * (int64_t)n_mels * job.frames;
   const unsigned blocks = (unsigned)std::min<int64_t>((total + 255) / 256, 4096);
   if (job.elem_bytes == 8)
@@ -193,7 +220,7 @@ void launch_mfcc(const MfccJob &job) {
   if (job.elem_bytes == 8) hipLaunchKernelGGL(mfcc_kernel<double>, grid, dim3(256), 0, job.stream, a);
   else hipLaunchKernelGGL(mfcc_kernel<float>, grid, dim3(256), 0, job.stream, a);
   SMX_HIP_CHECK(hipGetLastError());
-  SMX_HIP_CHECK(hipFreeAsync(d_tab, job.stream));
+  SMX_HIP_CHECK(hipFreeAsync(d_max, job.stream));
 }
 
 }  // namespace smx
