@@ -80,6 +80,18 @@ flop = 2.0 * 128 * 1025 * 256 * frames
 print(json.dumps({"config": "C3", "mel_spectrogram_ms": round(med, 4), "mel_apply_only_ms": round(med_apply, 4),
                   "Mframes_per_s": round(256 * frames / med / 1e3, 1), "GBs_algorithmic_fused": round(256 * frames * 2560 / med / 1e6, 1), "dense_equiv_TFLOPs_apply": round(flop / med_apply / 1e9, 2),
                   "apply_GBs": round((256 * frames * (4100 + 512)) / med_apply / 1e6, 1), "max_rel_err_vs_oracle": rel_err(m.cpu().numpy(), wm)}))
+# log-mel tail: Soundml.mfcc from audio (20 coefficients) and Convert.power_to_db of the C2 power spectrogram
+out_cep = torch.empty(256, 20, frames, device="cuda")
+med_mfcc, _ = timeit(lambda: check(lib.smx_mfcc_f32_dev(sc._h, mc._h, vp(x.data_ptr()), 256, 480000, 480000, 20, 0, 0.0,
+                                                        vp(out_cep.data_ptr()), None)), reps=10)
+out_db = torch.empty_like(p)
+med_db, _ = timeit(lambda: check(lib.smx_power_to_db_f32_dev(vp(p.data_ptr()), p.numel(), 1.0, 1e-10, 1, 80.0, vp(out_db.data_ptr()), None)), reps=10)
+wdb = O.power_to_db(p[:1].cpu().numpy(), top_db=None)
+gdb = S.power_to_db(p[:1])
+print(json.dumps({"config": "C2 log-mel tail", "mfcc20_from_audio_ms": round(med_mfcc, 4), "mfcc_Mframes_per_s": round(256 * frames / med_mfcc / 1e3, 1),
+                  "power_to_db_top80_ms": round(med_db, 4), "power_to_db_GBs": round(2 * p.numel() * 4 / med_db / 1e6, 1),
+                  "power_to_db_max_abs_err_dB": float(np.max(np.abs(gdb.cpu().numpy() - wdb)))}))
+del out_db
 # spectral-shape features and chroma on the C2 spectrogram (256 x 1025 x 938 float32, 984 MB read once per pass)
 spec_bytes = 256 * frames * 1025 * 4
 feat_out = torch.empty(256, 1, frames, device="cuda")
