@@ -58,7 +58,7 @@ __device__ inline double fetch_sample(const Tin *x, int64_t n, int64_t s, int pa
     return (double)x[m < n ? m : period - m];
   }
   if (pad == SMX_PAD_EDGE) return (double)x[s < 0 ? 0 : n - 1];
-  return pad_value;
+  return (double)(Tin)pad_value;   // the padded signal is built in the input dtype (stft.ml:318-338), then widened
 }
 
 // |z|^p with the reference's rounding order (stft.ml:670-674): the spectrum is

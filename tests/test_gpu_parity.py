@@ -232,6 +232,25 @@ def test_float64_interior_stockham_sizes(fft, hop, alignment, pad):
     assert np.array_equal(np.concatenate(parts, axis=-1), z32)
 
 
+@pytest.mark.parametrize("fft,hop", [(2048, 512), (1024, 256), (400, 160), (64, 16)])
+def test_constant_padding_is_rounded_to_the_input_dtype(fft, hop):
+    """The padded signal is built in the INPUT dtype before the float64 interior widens it (stft.ml:318-338): a pad
+    value float32 cannot hold reaches the transform as its float32 rounding, also under `set_interior("float64")`
+    (found by tools/fuzz_parity.py).  A short right-aligned clip makes the padding dominate every frame."""
+    value = 0.9733277781322542
+    x = np.random.default_rng(fft).uniform(-1, 1, size=(2, fft // 2 + 11)).astype(np.float32)
+    c = Stft.Config.create(fft_size=fft, hop=hop, alignment="right", pad=("constant", value))
+    o = O.stft_config(fft, hop=hop, alignment="right", pad="constant", pad_value=value)
+    want = O.transform(o, x)
+    S.set_interior("float64")
+    try:
+        z = Stft.transform(c, x)
+    finally:
+        S.set_interior("float32")
+    np.testing.assert_allclose(z, want, rtol=2e-6, atol=2e-7 * float(np.max(np.abs(want))))
+    np.testing.assert_allclose(Stft.transform(c, x), want, rtol=F32_RTOL, atol=F32_ATOL * float(np.max(np.abs(want))))
+
+
 @pytest.mark.parametrize("alignment", ["centered", "left", "right"])
 @pytest.mark.parametrize("pad", ["reflect", "edge", ("constant", 0.25)])
 @pytest.mark.parametrize("fft,hop", [(2048, 512), (64, 16), (16, 20), (31, 5)])
