@@ -1,6 +1,8 @@
 """Randomised parity sweep (diagnostic; the committed tests are deterministic): random geometries through transform,
 power_spectrum, mel_spectrogram, invert and the streaming faces, each against the oracle.  Prints every failure with the
-drawn parameters; exit code = number of failures.   python tools/fuzz_parity.py [cases] [seed]"""
+drawn parameters; exit code = number of failures.   python tools/fuzz_parity.py [cases] [seed] [stft|features]
+"features" draws the callers either side instead: Mel.apply, mfcc, to-dB, the spectral features, Chroma, the FIR
+filter and Griffin-Lim."""
 import os, sys, traceback
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
@@ -24,7 +26,118 @@ def close(a, e, rtol, atol_rel, what):
         what, int(bad.sum()), e.size, float(np.max(np.abs(a.astype(np.complex128) - e))), peak)
 
 
+def feature_case(rng):
+    """One draw of the callers around the STFT; returns the parameters it used (for the failure line)."""
+    which = str(rng.choice(["mel_apply", "mfcc", "db", "spectral", "chroma", "fir", "griffin_lim"]))
+    fft = int(rng.choice([64, 256, 400, 512, 1024, 2048]))
+    lead = tuple(int(v) for v in rng.integers(1, 4, size=int(rng.integers(0, 3))))
+    frames = int(rng.integers(1, 200))
+    bins = fft // 2 + 1
+    params = dict(which=which, fft=fft, lead=lead, frames=frames)
+    try:
+        if which == "mel_apply":
+            n_mels = int(rng.integers(2, 64))
+            norm = str(rng.choice(["slaney", "none"]))
+            scale = str(rng.choice(["slaney", "htk"]))
+            params.update(n_mels=n_mels, norm=norm, scale=scale)
+            try:
+                mc = Mel.Config.create(n_mels=n_mels, sample_rate=22050, fft_size=fft, norm=norm, scale=scale)
+            except S.InvalidArgument:
+                return None
+            om = O.mel_config(n_mels, 22050, fft, norm=norm, scale=scale)
+            s_ = rng.uniform(0, 4, size=lead + (bins, frames)).astype(np.float32)
+            close(Mel.apply(mc, s_), O.mel_apply(om, s_), 1e-5, 1e-6, "Mel.apply")
+        elif which == "mfcc":
+            n_mels = int(rng.integers(8, 64))
+            n_mfcc = int(rng.integers(1, n_mels + 1))
+            lifter = None if rng.random() < 0.5 else float(rng.integers(0, 40))
+            hop = max(1, fft // int(rng.choice([2, 4])))
+            n = int(rng.integers(fft, 12 * fft))
+            params.update(n_mels=n_mels, n_mfcc=n_mfcc, lifter=lifter, hop=hop, n=n)
+            try:
+                mc = Mel.Config.create(n_mels=n_mels, sample_rate=22050, fft_size=fft)
+            except S.InvalidArgument:
+                return None
+            c, o = Stft.Config.create(fft_size=fft, hop=hop), O.stft_config(fft, hop=hop)
+            x = rng.uniform(-1, 1, size=lead + (n,)).astype(np.float32)
+            want = O.mfcc(o, O.mel_config(n_mels, 22050, fft), x, n_mfcc, lifter)
+            # dB of a near-zero band amplifies the float32 interior: absolute floor in dB units
+            got = S.mfcc(c, mc, x, n_mfcc, lifter)
+            assert got.shape == want.shape and np.max(np.abs(got - want)) <= 2e-3 * max(1.0, float(np.max(np.abs(want)))), \
+                "mfcc: max err %.3g (peak %.3g)" % (float(np.max(np.abs(got - want))), float(np.max(np.abs(want))))
+        elif which == "db":
+            top = None if rng.random() < 0.4 else float(rng.uniform(0, 100))
+            amp = rng.random() < 0.5
+            s_ = (rng.uniform(0, 1, size=lead + (bins, frames)) ** 8).astype(np.float32)
+            params.update(top_db=top, amplitude=amp)
+            fn, on = (S.amplitude_to_db, O.amplitude_to_db) if amp else (S.power_to_db, O.power_to_db)
+            got, want = fn(s_, top_db=top), on(s_, top_db=top)
+            assert got.shape == want.shape and np.max(np.abs(got - want)) <= 2e-5 * 100, "to_db: max err %.3g" % float(np.max(np.abs(got - want)))
+        elif which == "spectral":
+            sr = int(rng.choice([8000, 16000, 22050, 44100]))
+            s_ = rng.uniform(0, 2, size=lead + (bins, frames)).astype(np.float32 if rng.random() < 0.7 else np.float64)
+            if rng.random() < 0.3:
+                s_[..., :, int(rng.integers(0, frames))] = 0.0      # a silent frame
+            pb = float(rng.choice([1.0, 2.0, 3.0, 1.5]))
+            roll = float(rng.uniform(0.01, 0.99))
+            params.update(sr=sr, p=pb, roll=roll, dtype=str(s_.dtype))
+            tol = 1e-5 if s_.dtype == np.float32 else 1e-9
+            close(S.spectral_centroid(s_, sr), O.spectral_centroid(s_, sr), tol, tol, "centroid")
+            close(S.spectral_bandwidth(s_, sr, pb), O.spectral_bandwidth(s_, sr, pb), 4 * tol, 4 * tol, "bandwidth")
+            assert np.array_equal(S.spectral_rolloff(s_, sr, roll), O.spectral_rolloff(s_, sr, roll)), "rolloff bin differs"
+            close(S.spectral_flatness(s_), O.spectral_flatness(s_), 4 * tol, 4 * tol, "flatness")
+        elif which == "chroma":
+            n_chroma = int(rng.choice([12, 12, 24, 6]))
+            norm = [None, "inf", 1.0, 2.0, 3.0][int(rng.integers(0, 5))]
+            tuning = float(rng.uniform(-0.5, 0.5))
+            octw = None if rng.random() < 0.3 else 2.0
+            params.update(n_chroma=n_chroma, norm=norm, tuning=tuning, octwidth=octw)
+            cc = S.Chroma.Config.create(22050, fft, n_chroma=n_chroma, tuning=tuning, octwidth=octw)
+            oc = O.chroma_config(22050, fft, n_chroma=n_chroma, tuning=tuning, octwidth=octw)
+            s_ = rng.uniform(0, 2, size=lead + (bins, frames)).astype(np.float32)
+            close(S.Chroma.apply(cc, s_, norm), O.chroma_apply(oc, s_, norm), 1e-5, 1e-5, "Chroma.apply")
+        elif which == "fir":
+            taps = int(rng.choice([1, 2, 3, 17, 64, 255, 1024, 4097, 8192]))
+            n = int(rng.integers(1, 60000))
+            params.update(taps=taps, n=n)
+            h = rng.standard_normal(taps) / max(1.0, np.sqrt(taps))
+            x = rng.uniform(-1, 1, size=lead + (n,)).astype(np.float32)
+            close(S.Fir.apply(S.Fir.Plan.create(h), x), O.fir_filter(h, x), 1e-5, 1e-5, "fir")
+        else:
+            hop = fft // 4
+            n_iter = int(rng.integers(1, 6))
+            mom = float(rng.choice([0.0, 0.5, 0.99]))
+            params.update(hop=hop, n_iter=n_iter, momentum=mom)
+            c, o = Stft.Config.create(fft_size=fft, hop=hop), O.stft_config(fft, hop=hop)
+            x = rng.uniform(-1, 1, size=lead + (hop * frames,)).astype(np.float32)
+            mag = np.abs(O.transform(o, x)).astype(np.float32)
+            init = rng.uniform(-np.pi, np.pi, size=mag.shape).astype(np.float32)
+            got = Stft.griffin_lim(c, mag, n_iter=n_iter, momentum=mom, init=init)
+            want = O.griffin_lim(o, mag, n_iter=n_iter, momentum=mom, init=init)
+            # the unit-modulus step is ill-conditioned where a bin is nearly silent: the float32 interior is held to
+            # the norm bound of tests/test_gpu_parity.py, the float64 one to the pointwise one
+            assert got.shape == want.shape and np.linalg.norm(got - want) < 1e-3 * np.linalg.norm(want), \
+                "griffin_lim: relative l2 error %.3g" % (np.linalg.norm(got - want) / np.linalg.norm(want))
+            S.set_interior("float64")
+            try:
+                close(Stft.griffin_lim(c, mag, n_iter=n_iter, momentum=mom, init=init), want, 1e-5, 1e-5, "griffin_lim (float64 interior)")
+            finally:
+                S.set_interior("float32")
+    except Exception as e:   # noqa: BLE001
+        print("FAIL", params, "->", "".join(traceback.format_exception_only(type(e), e)).strip()[:400])
+        return False
+    return True
+
+
 fails = 0
+if len(sys.argv) > 3 and sys.argv[3] == "features":
+    skipped = 0
+    for case in range(cases):
+        r = feature_case(rng)
+        fails += r is False
+        skipped += r is None
+    print("%d feature cases (%d drew a filterbank the reference rejects), %d failures" % (cases, skipped, fails))
+    sys.exit(min(fails, 100))
 for case in range(cases):
     fft = int(rng.choice(FFTS))
     hop = int(rng.integers(1, 2 * fft))
