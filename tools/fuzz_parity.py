@@ -162,6 +162,17 @@ for case in range(cases):
         S.set_interior(interior)
         z, wz = Stft.transform(c, x), O.transform(o, x)
         close(z, wz, rt, at, "transform")
+        if not f64 and rng.random() < 0.4:
+            # the device-resident entry points (torch tensors in, torch tensors out) are the same kernels: bit-equal
+            import torch
+            xd = torch.from_numpy(x).cuda()
+            zd = Stft.transform(c, xd)
+            assert zd.is_cuda and np.array_equal(zd.cpu().numpy(), z), "device transform differs from the host entry point"
+            pd = Stft.power_spectrum(c, xd, power)
+            assert np.array_equal(pd.cpu().numpy(), Stft.power_spectrum(c, x, power)), "device power differs from the host entry point"
+            if Stft.nola(c) and Stft.frames(c, n) > 0:
+                xi = Stft.invert(c, zd)
+                assert np.array_equal(xi.cpu().numpy(), Stft.invert(c, z)), "device invert differs from the host entry point"
         # |X|^p with p < 1 turns an absolute error d near a zero of the spectrum into d^p: looser floor there
         close(Stft.power_spectrum(c, x, power), O.power_spectrum(o, x, power), 4 * rt, at if power >= 1.0 else max(at, 1e-5) ** power, "power")
         total = Stft.frames(c, n)
