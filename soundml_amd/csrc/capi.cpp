@@ -4,6 +4,7 @@
 // mirroring the discipline of the reference's stub layer
 // (resample_stubs.c:228-276).  There is no CPU compute path here: the host
 // entry points upload, launch the HIP kernels and download.
+#include <chrono>
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
@@ -55,13 +56,14 @@ void require_device() {
     throw Failure("soundml_amd: no HIP device is available (this library has no CPU fallback)");
 }
 
-struct DeviceScratch {  // RAII device allocation for the host-pointer entry points
-  void *ptr = nullptr;
+struct DeviceScratch {  // RAII device allocation for the host-pointer entry points, from the stream-ordered pool:
+  void *ptr = nullptr;  // hipFree of a GB-sized array costs more than the kernels; the pool keeps it for the next call
   explicit DeviceScratch(size_t bytes) {
     if (bytes == 0) bytes = 16;
-    SMX_HIP_CHECK(hipMalloc(&ptr, bytes));
+    init_device_pool();
+    SMX_HIP_CHECK(hipMallocAsync(&ptr, bytes, nullptr));
   }
-  ~DeviceScratch() { (void)hipFree(ptr); }
+  ~DeviceScratch() { (void)hipFreeAsync(ptr, nullptr); }
   DeviceScratch(const DeviceScratch &) = delete;
   DeviceScratch &operator=(const DeviceScratch &) = delete;
 };
@@ -125,12 +127,21 @@ void stft_range_host(const smx_stft_config &c, const void *x, int in_bytes, int6
   if (count == 0 || lead == 0) return;
   if (!x || !out) throw Failure("transform: null pointer");
   require_device();
+  static const bool trace = getenv("SMX_HOST_TRACE") != nullptr;   // diagnostic: where a host call's time goes
+  auto now = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+  const double t0 = now();
   DeviceScratch dx((size_t)lead * (size_t)n * (size_t)in_bytes);
   DeviceScratch dout(out_elems * (size_t)in_bytes);
-  SMX_HIP_CHECK(hipMemcpy(dx.ptr, x, (size_t)lead * (size_t)n * (size_t)in_bytes, hipMemcpyHostToDevice));
+  const double t1 = now();
+  copy_to_device(dx.ptr, x, (size_t)lead * (size_t)n * (size_t)in_bytes);
+  const double t2 = now();
   stft_range_dev(c, dx.ptr, in_bytes, lead, n, n, p0, p1, mode, power, dout.ptr, nullptr);
   SMX_HIP_CHECK(hipStreamSynchronize(nullptr));
-  SMX_HIP_CHECK(hipMemcpy(out, dout.ptr, out_elems * (size_t)in_bytes, hipMemcpyDeviceToHost));
+  const double t3 = now();
+  copy_to_host(out, dout.ptr, out_elems * (size_t)in_bytes);
+  if (trace)
+    fprintf(stderr, "[smx] host transform: allocate %.2f ms, upload %.2f, kernels %.2f, download %.2f\n", t1 - t0, t2 - t1,
+            t3 - t2, now() - t3);
 }
 
 
@@ -186,10 +197,10 @@ void invert_host(const smx_stft_config &c, const void *z, int z_bytes, int64_t l
   const size_t zb = (size_t)lead * (size_t)bins * (size_t)frames * (size_t)z_bytes;
   const size_t ob = (size_t)lead * (size_t)out_len * (size_t)(z_bytes / 2);
   DeviceScratch dz(zb), dout(ob);
-  if (zb) SMX_HIP_CHECK(hipMemcpy(dz.ptr, z, zb, hipMemcpyHostToDevice));
+  if (zb) copy_to_device(dz.ptr, z, zb);
   invert_dev(c, dz.ptr, z_bytes, lead, bins, frames, has_length, length, dout.ptr, nullptr);
   SMX_HIP_CHECK(hipStreamSynchronize(nullptr));
-  SMX_HIP_CHECK(hipMemcpy(out, dout.ptr, ob, hipMemcpyDeviceToHost));
+  copy_to_host(out, dout.ptr, ob);
 }
 
 }  // namespace
@@ -840,10 +851,10 @@ void mel_apply_host(const smx_mel_config &c, const void *s, int elem_bytes, int6
   const size_t in_bytes = (size_t)lead * (size_t)bins * (size_t)frames * (size_t)elem_bytes;
   const size_t out_bytes = (size_t)lead * (size_t)c.n_mels * (size_t)frames * (size_t)elem_bytes;
   DeviceScratch ds(in_bytes), dout(out_bytes);
-  SMX_HIP_CHECK(hipMemcpy(ds.ptr, s, in_bytes, hipMemcpyHostToDevice));
+  copy_to_device(ds.ptr, s, in_bytes);
   mel_apply_dev(c, ds.ptr, elem_bytes, lead, bins, frames, dout.ptr, nullptr);
   SMX_HIP_CHECK(hipStreamSynchronize(nullptr));
-  SMX_HIP_CHECK(hipMemcpy(out, dout.ptr, out_bytes, hipMemcpyDeviceToHost));
+  copy_to_host(out, dout.ptr, out_bytes);
 }
 
 void check_fft_sizes(const smx_stft_config &sc, const smx_mel_config &mc) {  // soundml.ml:12-20
@@ -908,10 +919,10 @@ void mel_spectrogram_host(const smx_stft_config &sc, const smx_mel_config &mc, c
   const size_t in_total = (size_t)lead * (size_t)n * (size_t)in_bytes;
   const size_t out_total = (size_t)lead * (size_t)mc.n_mels * (size_t)count * (size_t)in_bytes;
   DeviceScratch dx(in_total), dout(out_total);
-  SMX_HIP_CHECK(hipMemcpy(dx.ptr, x, in_total, hipMemcpyHostToDevice));
+  copy_to_device(dx.ptr, x, in_total);
   mel_spectrogram_dev(sc, mc, dx.ptr, in_bytes, lead, n, n, power, dout.ptr, nullptr);
   SMX_HIP_CHECK(hipStreamSynchronize(nullptr));
-  SMX_HIP_CHECK(hipMemcpy(out, dout.ptr, out_total, hipMemcpyDeviceToHost));
+  copy_to_host(out, dout.ptr, out_total);
 }
 
 
@@ -1057,12 +1068,12 @@ void griffin_lim_host(const smx_stft_config &c, const void *s, int elem_bytes, i
   const size_t sb = (size_t)lead * (size_t)bins * (size_t)frames * (size_t)elem_bytes;
   const size_t ob = (size_t)lead * (size_t)out_len * (size_t)elem_bytes;
   DeviceScratch ds(sb), dp(phase ? sb : 16), dout(ob);
-  if (sb) SMX_HIP_CHECK(hipMemcpy(ds.ptr, s, sb, hipMemcpyHostToDevice));
-  if (phase && sb) SMX_HIP_CHECK(hipMemcpy(dp.ptr, phase, sb, hipMemcpyHostToDevice));
+  if (sb) copy_to_device(ds.ptr, s, sb);
+  if (phase && sb) copy_to_device(dp.ptr, phase, sb);
   griffin_lim_dev(c, ds.ptr, elem_bytes, lead, bins, frames, n_iter, momentum, phase ? dp.ptr : nullptr, has_length,
                   length, dout.ptr, nullptr);
   SMX_HIP_CHECK(hipStreamSynchronize(nullptr));
-  SMX_HIP_CHECK(hipMemcpy(out, dout.ptr, ob, hipMemcpyDeviceToHost));
+  copy_to_host(out, dout.ptr, ob);
 }
 
 // Soundml.mfcc (soundml.ml:50-95): checks in the reference's order and words, then mel_spectrogram + the tail
@@ -1117,10 +1128,10 @@ void mfcc_host(const smx_stft_config &sc, const smx_mel_config &mc, const void *
   const size_t in_total = (size_t)lead * (size_t)n * (size_t)in_bytes;
   const size_t out_total = (size_t)lead * (size_t)n_mfcc * (size_t)count * (size_t)in_bytes;
   DeviceScratch dx(in_total), dout(out_total);
-  SMX_HIP_CHECK(hipMemcpy(dx.ptr, x, in_total, hipMemcpyHostToDevice));
+  copy_to_device(dx.ptr, x, in_total);
   mfcc_dev(sc, mc, dx.ptr, in_bytes, lead, n, n, n_mfcc, has_lifter, lifter, dout.ptr, nullptr);
   SMX_HIP_CHECK(hipStreamSynchronize(nullptr));
-  SMX_HIP_CHECK(hipMemcpy(out, dout.ptr, out_total, hipMemcpyDeviceToHost));
+  copy_to_host(out, dout.ptr, out_total);
 }
 
 // ---- Convert.power_to_db / amplitude_to_db (convert.ml:3-62) ------------------------------------------------
@@ -1163,10 +1174,10 @@ void to_db_host(bool amplitude, const void *s, int elem_bytes, int64_t total, do
   require_device();
   const size_t bytes = (size_t)total * (size_t)elem_bytes;
   DeviceScratch d(bytes);
-  SMX_HIP_CHECK(hipMemcpy(d.ptr, s, bytes, hipMemcpyHostToDevice));
+  copy_to_device(d.ptr, s, bytes);
   to_db_dev(amplitude, d.ptr, elem_bytes, total, reference, amin, has_top_db, top_db, d.ptr, nullptr);
   SMX_HIP_CHECK(hipStreamSynchronize(nullptr));
-  SMX_HIP_CHECK(hipMemcpy(out, d.ptr, bytes, hipMemcpyDeviceToHost));
+  copy_to_host(out, d.ptr, bytes);
 }
 
 // ---- Spectral.* (spectral.ml:27-255): checks in the reference's order and words, then one launch -------------
@@ -1267,11 +1278,11 @@ void spectral_host(const SpectralParams &q, const void *s, int elem_bytes, int64
   const size_t in_total = (size_t)lead * (size_t)bins * (size_t)frames * (size_t)elem_bytes;
   const size_t out_total = (size_t)lead * (size_t)frames * (size_t)elem_bytes;
   DeviceScratch ds(in_total), dout(out_total), dc(q.has_centroid ? out_total : 0);
-  SMX_HIP_CHECK(hipMemcpy(ds.ptr, s, in_total, hipMemcpyHostToDevice));
-  if (q.has_centroid) SMX_HIP_CHECK(hipMemcpy(dc.ptr, centroid, out_total, hipMemcpyHostToDevice));
+  copy_to_device(ds.ptr, s, in_total);
+  if (q.has_centroid) copy_to_device(dc.ptr, centroid, out_total);
   spectral_dev(q, ds.ptr, elem_bytes, lead, bins, frames, dc.ptr, dout.ptr, nullptr);
   SMX_HIP_CHECK(hipStreamSynchronize(nullptr));
-  SMX_HIP_CHECK(hipMemcpy(out, dout.ptr, out_total, hipMemcpyDeviceToHost));
+  copy_to_host(out, dout.ptr, out_total);
 }
 
 // ---- Chroma.apply / Soundml.chroma_stft (chroma.ml:285-317, soundml.ml:97-107) ------------------------------
@@ -1320,10 +1331,10 @@ void chroma_apply_host(const smx_chroma_config &c, const void *s, int elem_bytes
   const size_t in_total = (size_t)lead * (size_t)bins * (size_t)frames * (size_t)elem_bytes;
   const size_t out_total = (size_t)lead * (size_t)c.n_chroma * (size_t)frames * (size_t)elem_bytes;
   DeviceScratch ds(in_total), dout(out_total);
-  SMX_HIP_CHECK(hipMemcpy(ds.ptr, s, in_total, hipMemcpyHostToDevice));
+  copy_to_device(ds.ptr, s, in_total);
   chroma_apply_dev(c, ds.ptr, elem_bytes, lead, bins, frames, norm, norm_p, dout.ptr, nullptr);
   SMX_HIP_CHECK(hipStreamSynchronize(nullptr));
-  SMX_HIP_CHECK(hipMemcpy(out, dout.ptr, out_total, hipMemcpyDeviceToHost));
+  copy_to_host(out, dout.ptr, out_total);
 }
 
 void check_chroma_stft(const smx_stft_config &sc, const smx_chroma_config &cc) {   // soundml.ml:98-106
@@ -1361,10 +1372,10 @@ void chroma_stft_host(const smx_stft_config &sc, const smx_chroma_config &cc, co
   const size_t in_total = (size_t)lead * (size_t)n * (size_t)in_bytes;
   const size_t out_total = (size_t)lead * (size_t)cc.n_chroma * (size_t)count * (size_t)in_bytes;
   DeviceScratch dx(in_total), dout(out_total);
-  SMX_HIP_CHECK(hipMemcpy(dx.ptr, x, in_total, hipMemcpyHostToDevice));
+  copy_to_device(dx.ptr, x, in_total);
   chroma_stft_dev(sc, cc, dx.ptr, in_bytes, lead, n, n, power, norm, norm_p, dout.ptr, nullptr);
   SMX_HIP_CHECK(hipStreamSynchronize(nullptr));
-  SMX_HIP_CHECK(hipMemcpy(out, dout.ptr, out_total, hipMemcpyDeviceToHost));
+  copy_to_host(out, dout.ptr, out_total);
 }
 
 }  // namespace

@@ -169,6 +169,11 @@ struct smx_chroma_config {
 
 namespace smx {
 
+// ---- host <-> device transfers of the host-pointer entry points (transfer.cpp) ----
+// Blocking; large copies are staged through pinned buffers with the DMA and a few host threads overlapped.
+void copy_to_device(void *d_dst, const void *src, size_t bytes);
+void copy_to_host(void *dst, const void *d_src, size_t bytes);
+
 // ---- host logic (host_config.cpp) ----------------------------------------------
 void window_make(int kind, bool periodic, int64_t n, double *out);             // window.ml:374-405
 void window_make_param(int kind, double param, bool periodic, int64_t n, double *out);   // Kaiser / Gaussian / Tukey too
