@@ -19,7 +19,8 @@ except Exception:  # pragma: no cover
     torch = None
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libsoundml_amd.so")
+# SOUNDML_AMD_LIB: another build of the same library (tools/ A/B timing of `make VARIANT=...` builds)
+LIB_PATH = os.environ.get("SOUNDML_AMD_LIB") or os.path.join(_HERE, "lib", "libsoundml_amd.so")
 
 
 class InvalidArgument(ValueError):

@@ -15,6 +15,9 @@ namespace smx {
 namespace {
 
 using f32x16 = __attribute__((ext_vector_type(16))) float;
+#ifndef SMX_MEL_DEPTH
+#define SMX_MEL_DEPTH 2   // k-steps whose operands are fetched together (C3: 1: 0.34 ms, 2: 0.29, 4: 0.30; next trip prefetched: 0.35)
+#endif
 
 struct MelArgs {
   const void *s;
@@ -28,26 +31,64 @@ struct MelArgs {
   int mel_blocks, frame_tiles;
 };
 
-// grid: lead * frame_tiles workgroups of 4 waves; wave w walks mel blocks w, w+4, ...
+// BY_BLOCK = false: grid = lead * frame_tiles workgroups of 4 waves; wave w walks mel blocks w, w+4, ...
+// BY_BLOCK = true: a workgroup's 4 waves take 4 neighbouring frame tiles of ONE mel block (equal work per wave), and
+// the blocks are dealt longest band first (the highest mels), so the launch ends on the short ones.
+template <bool BY_BLOCK>
 __global__ void __launch_bounds__(256) mel_apply_mfma_kernel(MelArgs a) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int64_t clip = blockIdx.x / a.frame_tiles;
-  const int64_t t0 = (int64_t)(blockIdx.x % a.frame_tiles) * 64;
+  int64_t tile = blockIdx.x;
+  int mb_first = wave, mb_step = 4, mb_end = a.mel_blocks;
+  if (BY_BLOCK) {
+    const int64_t groups = (a.lead * a.frame_tiles + 3) / 4;
+    mb_first = a.mel_blocks - 1 - (int)(blockIdx.x / groups);
+    mb_end = mb_first + 1;
+    mb_step = 1;
+    tile = (blockIdx.x % groups) * 4 + wave;
+    if (tile >= a.lead * a.frame_tiles) return;
+  }
+  const int64_t clip = tile / a.frame_tiles;
+  const int64_t t0 = (tile % a.frame_tiles) * 64;
   const float *S = reinterpret_cast<const float *>(a.s) + clip * (int64_t)a.bins * a.frames;
   float *O = reinterpret_cast<float *>(a.out) + clip * (int64_t)a.n_mels * a.frames;
   const int col = lane & 31, half = lane >> 5;
   const int64_t ta = t0 + col, tb = t0 + 32 + col;
   const int64_t ta_c = ta < a.frames ? ta : a.frames - 1;
   const int64_t tb_c = tb < a.frames ? tb : a.frames - 1;
-  for (int mb = wave; mb < a.mel_blocks; mb += 4) {
+  for (int mb = mb_first; mb < mb_end; mb += mb_step) {
     // the block's band (host-built, wave-uniform) and its weights in operand order: one 256-byte run per k-step
     const int klo = __builtin_amdgcn_readfirstlane(a.block_lo[mb]) & ~7;
     const int khi = __builtin_amdgcn_readfirstlane(a.block_hi[mb]);
     f32x16 acc0 = {0}, acc1 = {0};
     const float *wb = a.w_block + (int64_t)mb * (a.k_pad / 2) * 64 + lane;
     // four k-steps (8 bins) per trip, every operand fetched before the first multiply-add; trips may run past the
-    // band (W is zero there; k_pad is a multiple of 32) but never past the spectrogram's last bin
-    for (int k = klo; k < khi; k += 8) {
+    // band (W is zero there; k_pad is a multiple of 32) but never past the spectrogram's last bin: whole trips walk a
+    // uniform row pointer with no guards and no 64-bit multiplies, the one trip that can cross the last bin is guarded
+    const int whole_end = khi < (a.bins & ~7) ? khi : (a.bins & ~7);
+    const int64_t lane_a = (int64_t)half * a.frames + ta_c, lane_b = (int64_t)half * a.frames + tb_c;
+    const int64_t two_rows = 2 * a.frames;
+    const float *rows = S + (int64_t)klo * a.frames;     // wave-uniform
+    int k = klo;
+    for (; k + 8 <= whole_end; k += 8, rows += 4 * two_rows) {
+#pragma unroll
+      for (int h = 0; h < 4; h += SMX_MEL_DEPTH) {
+        float av[SMX_MEL_DEPTH], b0[SMX_MEL_DEPTH], b1[SMX_MEL_DEPTH];
+#pragma unroll
+        for (int j = 0; j < SMX_MEL_DEPTH; ++j) {
+          av[j] = wb[(int64_t)(k / 2 + h + j) * 64];
+          b0[j] = rows[(h + j) * two_rows + lane_a];
+          b1[j] = rows[(h + j) * two_rows + lane_b];
+        }
+        __builtin_amdgcn_sched_barrier(0);   // keep the loads ahead of the first multiply-add
+#pragma unroll
+        for (int j = 0; j < SMX_MEL_DEPTH; ++j) {
+          acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(av[j], b0[j], acc0, 0, 0, 0);
+          acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(av[j], b1[j], acc1, 0, 0, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+    for (; k < khi; k += 8) {
       float av[4], b0[4], b1[4];
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
@@ -117,9 +158,16 @@ void launch_mel_apply(const MelJob &job) {
   a.frame_tiles = (int)((job.frames + 63) / 64);
   const bool f64_interior = job.elem_bytes == 8 || smx_get_interior() == SMX_INTERIOR_F64;
   if (!f64_interior) {
-    const int64_t blocks = job.lead * a.frame_tiles;
-    if (blocks > 0x7fffffff) throw Failure("apply: too many frame tiles for one launch");
-    hipLaunchKernelGGL(mel_apply_mfma_kernel, dim3((unsigned)blocks), dim3(256), 0, job.stream, a);
+    static const bool by_tile = getenv("SMX_MEL_APPLY_BY_TILE") != nullptr;   // diagnostic: all blocks in one workgroup
+    if (by_tile) {
+      const int64_t blocks = job.lead * a.frame_tiles;
+      if (blocks > 0x7fffffff) throw Failure("apply: too many frame tiles for one launch");
+      hipLaunchKernelGGL(mel_apply_mfma_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, job.stream, a);
+    } else {
+      const int64_t blocks = (job.lead * a.frame_tiles + 3) / 4 * a.mel_blocks;
+      if (blocks > 0x7fffffff) throw Failure("apply: too many frame tiles for one launch");
+      hipLaunchKernelGGL(mel_apply_mfma_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, job.stream, a);
+    }
   } else {
     if (job.lead > 65535) throw Failure("apply: too many leading slices for one launch");
     dim3 grid((unsigned)((job.frames + 255) / 256), (unsigned)job.lead);
