@@ -93,56 +93,111 @@ template <> struct OrderedKey<double> {
 };
 
 template <typename T>
-__global__ void __launch_bounds__(256) to_db_kernel(const T *s, T *out, int64_t total, T amin, T scale, T offset, int magnitude,
-                                                    typename OrderedKey<T>::U *max_key) {
-  using K = OrderedKey<T>;
-  typename K::U best = 0;
-  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
-    T v = s[i];
-    if (magnitude) v = v < (T)0 ? -v : v;
-    const T floored = v > amin ? v : amin;          // maximum s amin: a NaN stays a NaN, as Nx.maximum leaves it
-    const T db = (v != v) ? v : (T)(log(floored) * scale - offset);
-    out[i] = db;
-    const typename K::U key = K::of(db);
-    best = key > best ? key : best;
-  }
-  if (max_key) {
-    for (int off = 32; off > 0; off >>= 1) {
-      const typename K::U o = __shfl_down(best, off);
-      best = o > best ? o : best;
-    }
-    if ((threadIdx.x & 63) == 0) atomicMax(max_key, best);
-  }
+__device__ __forceinline__ T db_of(T v, T amin, T scale, T offset, int magnitude) {
+  if (magnitude) v = v < (T)0 ? -v : v;
+  const T floored = v > amin ? v : amin;          // maximum s amin: a NaN stays a NaN, as Nx.maximum leaves it
+  return (v != v) ? v : (T)(log(floored) * scale - offset);
 }
 
+// 16 bytes per lane and access; two accesses in flight per trip
+template <typename T> struct alignas(16) DbVec { T v[16 / sizeof(T)]; };
+
+// Pass 1 (only with top_db): the maximum of the WHOLE tensor.  Decibels are a non-decreasing function of the (absolute)
+// value, so the maximum decibel is the decibel of the maximum value: this pass only reads and compares keys.
 template <typename T>
-__global__ void __launch_bounds__(256) db_clamp_kernel(T *out, int64_t total, T range, const typename OrderedKey<T>::U *max_key) {
-  const T lowest = (T)(OrderedKey<T>::back(*max_key) - range);
-  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
-    const T v = out[i];
-    out[i] = v > lowest ? v : (v != v ? v : lowest);
+__global__ void __launch_bounds__(256) db_max_kernel(const T *s, int64_t total, int magnitude, typename OrderedKey<T>::U *max_key) {
+  using K = OrderedKey<T>;
+  using Vec = DbVec<T>;
+  constexpr int V = 16 / sizeof(T);
+  typename K::U best = 0;
+  auto see = [&](T v) {
+    if (magnitude) v = v < (T)0 ? -v : v;
+    const typename K::U key = K::of(v);
+    best = key > best ? key : best;
+  };
+  const int64_t tid = (int64_t)blockIdx.x * 256 + threadIdx.x, nthreads = (int64_t)gridDim.x * 256;
+  const int64_t head = std::min<int64_t>(total, (int64_t)((16 - ((uintptr_t)s & 15)) & 15) / (int64_t)sizeof(T));
+  const int64_t nvec = (total - head) / V;
+  const Vec *sv = reinterpret_cast<const Vec *>(s + head);
+  int64_t i = tid;
+  for (; i + nthreads < nvec; i += 2 * nthreads) {
+    const Vec a = sv[i], b = sv[i + nthreads];
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int e = 0; e < V; ++e) see(a.v[e]), see(b.v[e]);
   }
+  if (i < nvec) {
+    const Vec a = sv[i];
+#pragma unroll
+    for (int e = 0; e < V; ++e) see(a.v[e]);
+  }
+  if (tid < head) see(s[tid]);
+  if (tid < total - head - nvec * V) see(s[head + nvec * V + tid]);
+  for (int off = 32; off > 0; off >>= 1) {
+    const typename K::U o = __shfl_down(best, off);
+    best = o > best ? o : best;
+  }
+  if ((threadIdx.x & 63) == 0) atomicMax(max_key, best);
+}
+
+// Pass 2: decibels, clamped under (maximum - range) when max_key is given.  Every element is read and written by
+// the same lane, so out may be s.
+template <typename T>
+__global__ void __launch_bounds__(256) to_db_kernel(const T *s, T *out, int64_t total, T amin, T scale, T offset, int magnitude,
+                                                    const typename OrderedKey<T>::U *max_key, T range) {
+  using Vec = DbVec<T>;
+  constexpr int V = 16 / sizeof(T);
+  const bool clamp = max_key != nullptr;
+  // the largest decibel is the decibel of the largest value, by the same arithmetic as everywhere else
+  const T top = clamp ? db_of<T>(OrderedKey<T>::back(*max_key), amin, scale, offset, 0) : (T)0;
+  const T lowest = (T)(top - range);
+  auto one = [&](T v) {
+    const T db = db_of<T>(v, amin, scale, offset, magnitude);
+    return !clamp || db > lowest ? db : (db != db ? db : lowest);
+  };
+  const int64_t tid = (int64_t)blockIdx.x * 256 + threadIdx.x, nthreads = (int64_t)gridDim.x * 256;
+  const bool aligned = (((uintptr_t)s ^ (uintptr_t)out) & 15) == 0;
+  const int64_t head = !aligned ? total : std::min<int64_t>(total, (int64_t)((16 - ((uintptr_t)s & 15)) & 15) / (int64_t)sizeof(T));
+  const int64_t nvec = (total - head) / V;
+  const Vec *sv = reinterpret_cast<const Vec *>(s + head);
+  Vec *ov = reinterpret_cast<Vec *>(out + head);
+  int64_t i = tid;
+  for (; i + nthreads < nvec; i += 2 * nthreads) {
+    Vec a = sv[i], b = sv[i + nthreads];
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int e = 0; e < V; ++e) a.v[e] = one(a.v[e]), b.v[e] = one(b.v[e]);
+    ov[i] = a;
+    ov[i + nthreads] = b;
+  }
+  if (i < nvec) {
+    Vec a = sv[i];
+#pragma unroll
+    for (int e = 0; e < V; ++e) a.v[e] = one(a.v[e]);
+    ov[i] = a;
+  }
+  for (int64_t j = tid; j < head; j += nthreads) out[j] = one(s[j]);
+  for (int64_t j = head + nvec * V + tid; j < total; j += nthreads) out[j] = one(s[j]);
 }
 
 template <typename T>
 void run_to_db(const ToDbJob &job) {
   using U = typename OrderedKey<T>::U;
-  const unsigned blocks = (unsigned)std::min<int64_t>((job.total + 255) / 256, 8192);
+  constexpr int64_t per_block = 256 * 2 * (16 / (int64_t)sizeof(T));
+  const unsigned blocks = (unsigned)std::min<int64_t>((job.total + per_block - 1) / per_block, 4096);
   const double scale = job.gain / 10.0 * (10.0 / std::log(10.0));
   const double offset = scale * std::log(std::max(job.amin, job.reference));
   U *d_key = nullptr;
   if (job.has_top_db) {
     SMX_HIP_CHECK(hipMallocAsync((void **)&d_key, sizeof(U), job.stream));
     SMX_HIP_CHECK(hipMemsetAsync(d_key, 0, sizeof(U), job.stream));
+    hipLaunchKernelGGL(db_max_kernel<T>, dim3(blocks), dim3(256), 0, job.stream, (const T *)job.s, job.total, job.magnitude ? 1 : 0, d_key);
+    SMX_HIP_CHECK(hipGetLastError());
   }
   hipLaunchKernelGGL(to_db_kernel<T>, dim3(blocks), dim3(256), 0, job.stream, (const T *)job.s, (T *)job.out, job.total, (T)job.amin,
-                     (T)scale, (T)offset, job.magnitude ? 1 : 0, d_key);
+                     (T)scale, (T)offset, job.magnitude ? 1 : 0, (const U *)d_key, (T)job.top_db);
   SMX_HIP_CHECK(hipGetLastError());
-  if (job.has_top_db) {
-    hipLaunchKernelGGL(db_clamp_kernel<T>, dim3(blocks), dim3(256), 0, job.stream, (T *)job.out, job.total, (T)job.top_db, d_key);
-    SMX_HIP_CHECK(hipGetLastError());
-    SMX_HIP_CHECK(hipFreeAsync(d_key, job.stream));
-  }
+  if (d_key) SMX_HIP_CHECK(hipFreeAsync(d_key, job.stream));
 }
 
 }  // namespace
