@@ -50,12 +50,19 @@ __device__ __forceinline__ void for_bins(const T *col, int64_t frames, int64_t k
   for (; k < k1; ++k) f(k, (double)col[k * frames]);
 }
 
+// A workgroup = four waves: the Q bin ranges of one 64-frame tile, or (Q = 1, the sequential roll-off walk) four
+// neighbouring tiles, whose 256-byte row pieces are then one contiguous run per row and workgroup (0.46 -> 0.38 ms at
+// C2; sixteen-wave workgroups of 4 tiles x 4 ranges measured slower for the other three features).
+template <int Q> constexpr int tiles_of = Q == 1 ? 4 : 1;
 template <typename T, int FEATURE, int Q>
-__global__ void __launch_bounds__(64 * Q) spectral_kernel(SpectralArgs a) {
-  __shared__ double red[2][Q][64];
-  const int fx = threadIdx.x & 63, q = threadIdx.x >> 6;
-  const int64_t clip = blockIdx.x / a.ftiles, tile = blockIdx.x % a.ftiles;
-  const int64_t t = tile * 64 + fx;
+__global__ void __launch_bounds__(64 * Q * tiles_of<Q>) spectral_kernel(SpectralArgs a) {
+  constexpr int kTiles = tiles_of<Q>;
+  __shared__ double red_all[kTiles][2][Q][64];
+  const int fx = threadIdx.x & 63, q = (threadIdx.x >> 6) % Q, sub = threadIdx.x / (64 * Q);
+  double (*red)[Q][64] = red_all[sub];
+  const int64_t groups = (a.ftiles + kTiles - 1) / kTiles;
+  const int64_t clip = blockIdx.x / groups, tile = (blockIdx.x % groups) * kTiles + sub;
+  const int64_t t = tile * 64 + fx;                    // a tile past the last one shadows the last frame too
   const bool live = t < a.frames;
   const int64_t tc = live ? t : a.frames - 1;          // idle lanes shadow the last frame (no stores)
   const T *col = reinterpret_cast<const T *>(a.s) + clip * a.bins * a.frames + tc;
@@ -135,9 +142,10 @@ __global__ void __launch_bounds__(64 * Q) spectral_kernel(SpectralArgs a) {
 
 template <typename T, int FEATURE, int Q>
 void launch_feature(const SpectralArgs &a, hipStream_t stream) {
-  const int64_t blocks = a.lead * a.ftiles;
+  constexpr int kTiles = tiles_of<Q>;
+  const int64_t blocks = a.lead * ((a.ftiles + kTiles - 1) / kTiles);
   if (blocks > 2147483647LL) throw Failure("spectral: too many frame tiles for one launch");
-  hipLaunchKernelGGL((spectral_kernel<T, FEATURE, Q>), dim3((unsigned)blocks), dim3(64 * Q), 0, stream, a);
+  hipLaunchKernelGGL((spectral_kernel<T, FEATURE, Q>), dim3((unsigned)blocks), dim3(64 * Q * kTiles), 0, stream, a);
   SMX_HIP_CHECK(hipGetLastError());
 }
 
