@@ -47,6 +47,11 @@ struct GenericArgs {
   int direct;  // Stockham kernel: results go straight from registers to memory (no room for an LDS stage)
 };
 
+// two neighbouring samples as one access; only element alignment is promised (frames start anywhere)
+template <typename T> struct Pair;
+template <> struct Pair<float> { typedef float type __attribute__((ext_vector_type(2), aligned(4))); };
+template <> struct Pair<double> { typedef double type __attribute__((ext_vector_type(2), aligned(8))); };
+
 template <typename Tin>
 __device__ inline double fetch_sample(const Tin *x, int64_t n, int64_t s, int pad, double pad_value) {
   if (s >= 0 && s < n) return (double)x[s];
@@ -395,7 +400,10 @@ __global__ void __launch_bounds__((1 << LOG2N) / 32 < 256 ? 256 : (1 << LOG2N) /
 #pragma unroll
         for (int m = 0; m < 16; ++m) {
           const int i = 2 * (tid + T * m);
-          r[m] = {(S)xs[i] * window[i] * kHalf, (S)xs[i + 1] * window[i + 1] * kHalf};
+          // one 8-byte access for the two samples (element-aligned only) and one for their window values
+        const auto xv = *reinterpret_cast<const typename Pair<Tin>::type *>(xs + i);
+        const V wv = reinterpret_cast<const V *>(window)[tid + T * m];
+        r[m] = {(S)xv.x * wv.x * kHalf, (S)xv.y * wv.y * kHalf};
         }
       } else {
 #pragma unroll 1
@@ -713,7 +721,10 @@ __global__ void __launch_bounds__(FT * ((1 << LOG2N) / 32)) stft_stockham_power1
 #pragma unroll
       for (int m = 0; m < 16; ++m) {
         const int i = 2 * (tid + T * m);
-        r[m] = {(S)xs[i] * window[i] * kHalf, (S)xs[i + 1] * window[i + 1] * kHalf};
+        // one 8-byte access for the two samples (element-aligned only) and one for their window values
+        const auto xv = *reinterpret_cast<const typename Pair<Tin>::type *>(xs + i);
+        const V wv = reinterpret_cast<const V *>(window)[tid + T * m];
+        r[m] = {(S)xv.x * wv.x * kHalf, (S)xv.y * wv.y * kHalf};
       }
     } else {
 #pragma unroll 1
@@ -829,7 +840,10 @@ __global__ void __launch_bounds__(FT * ((1 << LOG2N) / 32)) stft_stockham_comple
 #pragma unroll
       for (int m = 0; m < 16; ++m) {
         const int i = 2 * (tid + T * m);
-        r[m] = {(S)xs[i] * window[i] * kHalf, (S)xs[i + 1] * window[i + 1] * kHalf};
+        // one 8-byte access for the two samples (element-aligned only) and one for their window values
+        const auto xv = *reinterpret_cast<const typename Pair<Tin>::type *>(xs + i);
+        const V wv = reinterpret_cast<const V *>(window)[tid + T * m];
+        r[m] = {(S)xv.x * wv.x * kHalf, (S)xv.y * wv.y * kHalf};
       }
     } else {
 #pragma unroll 1
