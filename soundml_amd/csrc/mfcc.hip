@@ -45,8 +45,15 @@ __global__ void __launch_bounds__(256) mel_max_kernel(const T *mel, int64_t tota
     const double o = __shfl_down(m, off);
     m = o > m ? o : m;
   }
-  // non-negative doubles order like their bit patterns
-  if ((threadIdx.x & 63) == 0) atomicMax(result, (unsigned long long)__double_as_longlong(m));
+  // one atomic per workgroup: thousands of atomics on one address cost more than the pass over the data
+  __shared__ double part[4];
+  if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int w = 1; w < 4; ++w) m = part[w] > m ? part[w] : m;
+    // non-negative doubles order like their bit patterns
+    atomicMax(result, (unsigned long long)__double_as_longlong(m));
+  }
 }
 
 struct MfccArgs {
@@ -159,7 +166,13 @@ __global__ void __launch_bounds__(256) db_max_kernel(const T *s, int64_t total, 
     const typename K::U o = __shfl_down(best, off);
     best = o > best ? o : best;
   }
-  if ((threadIdx.x & 63) == 0) atomicMax(max_key, best);
+  __shared__ typename K::U part[4];   // one atomic per workgroup (see mel_max_kernel)
+  if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = best;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int w = 1; w < 4; ++w) best = part[w] > best ? part[w] : best;
+    atomicMax(max_key, best);
+  }
 }
 
 // Pass 2: decibels, clamped under (maximum - range) when max_key is given.  Every element is read and written by
@@ -206,7 +219,7 @@ template <typename T>
 void run_to_db(const ToDbJob &job) {
   using U = typename OrderedKey<T>::U;
   constexpr int64_t per_block = 256 * 2 * (16 / (int64_t)sizeof(T));
-  const unsigned blocks = (unsigned)std::min<int64_t>((job.total + per_block - 1) / per_block, 4096);
+  const unsigned blocks = (unsigned)std::min<int64_t>((job.total + per_block - 1) / per_block, 2048);
   const double scale = job.gain / 10.0 * (10.0 / std::log(10.0));
   const double offset = scale * std::log(std::max(job.amin, job.reference));
   U *d_key = nullptr;
