@@ -186,7 +186,7 @@ for case in range(cases):
                 mc = None
             if mc is not None:
                 om = O.mel_config(mc.n_mels, 16000, fft)
-                close(S.mel_spectrogram(c, mc, x, power), O.mel_spectrogram(o, om, x, power), 1e-5, 1e-5 if power >= 1.0 else 2 * 1e-5 ** power, "mel")
+                close(S.mel_spectrogram(c, mc, x, power), O.mel_spectrogram(o, om, x, power), 1e-5, 1e-5 if power >= 1.0 else 4 * 1e-5 ** power, "mel")
         if Stft.nola(c) and total > 0:
             length = None if rng.random() < 0.5 else int(rng.integers(1, n + fft))
             zz = wz.astype(np.complex128 if f64 else np.complex64)
