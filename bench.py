@@ -4,62 +4,128 @@ float32, on synthetic device-resident audio (BASELINE.json metric).
 
   python bench.py --gpus N --steps K --warmup W
 
-One process per GPU.  A step = one pass of Stft.power_spectrum (through the C
-ABI, device pointers) over this rank's resident batch: BASELINE config C2,
-256 clips x 10 s x 48 kHz per GPU (weak scaling: clips shard embarrassingly, no
-collective on the data path; the only communication is the timing barrier).
-Rank 0 prints ONE JSON line with the whole-job Mframes/s, the HBM roofline of
-the dominant kernel (HIP events on the launch stream) and, at N=1, a CPU
-baseline (the oracle's C restatement, float64 interior, all host cores) on a
-bounded sample of the same workload.
+One process per GPU.  Started without RANK in the environment and with N > 1, this
+process is only a launcher: it starts N fresh rank processes (RANK / LOCAL_RANK /
+WORLD_SIZE / MASTER_* set, rendezvous on 127.0.0.1) BEFORE importing torch or the
+library -- the parent makes no GPU call -- forwards rank 0's JSON line and exits
+with the worst child status.  Under `torch.distributed.run` (RANK set) it is a rank.
+
+Workloads (BASELINE.json `configs`):
+  N = 1   C2: 256 clips x 10 s x 48 kHz resident on the GPU; a step = one
+          Stft.power_spectrum pass over the batch through the C ABI = ONE launch of
+          stft2048_power_kernel (asserted through the library's launch counter).
+          `extra` carries C3 (fused mel, 128 mels), C4 (FIR 8192 taps, 8 x 60 s) and
+          the one-GPU point of C5, each timed with HIP events the same way.
+  N > 1   C5: 4096 clips x 30 s, contiguous clip ranges per rank
+          (soundml_amd.shard.clip_range; 512 clips per GPU at 8), no collective on the
+          data path: `scaling` = "strong".  `extra.c2_weak` is the weak-scaled C2 figure
+          (256 clips per GPU) of the same ranks.
+The only communication is the timing barrier and the MAX-over-ranks reduction of
+the clock (RCCL when every rank has its own GPU; gloo when ranks share a device,
+which RCCL refuses -- the 2-rank test on a 1-GPU box).
+
+Rank 0 prints ONE JSON line: whole-job Mframes/s, the HBM roofline of the dominant
+kernel (HIP events on the launch stream) and, at N = 1, the CPU baseline: the
+oracle's C restatement (float64 interior, all host cores) on the SAME C2 batch, whose
+output also checks every frame of the GPU result.
 """
 import argparse
 import ctypes
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-ALGO_BYTES_PER_FRAME = 512 * 4 + 1025 * 4      # SURVEY 8d: hop*4 read + bins*4 written = 6148 B
+FFT, HOP, SR, BINS = 2048, 512, 48000, 1025
+ALGO_BYTES_PER_FRAME = HOP * 4 + BINS * 4      # SURVEY 8d: hop*4 read + bins*4 written = 6148 B
+MEL_BYTES_PER_FRAME = HOP * 4 + 128 * 4        # fused mel from audio: 2560 B
+FIR_BYTES_PER_SAMPLE = 8                       # 4 in + 4 out
 HBM_PEAK_GBS = 8000.0                          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+MFMA_F32_PEAK_TFLOPS = 157.3                   # MI355X_MICROARCH.md: v_mfma_f32_*_f32
 
 
-def cpu_baseline(fft, hop, n, target_seconds=12.0):
-    """Times the oracle's C port (float64 interior, clip-parallel pthreads) on a
-    bounded sample of the workload: as many 10 s clips as fit ~target_seconds."""
-    import numpy as np
-    from oracle import c_oracle, soundml_oracle as O
-    cores = os.cpu_count() or 1
-    c = O.stft_config(fft, hop=hop)
-    rng = np.random.default_rng(42)
-    probe = rng.uniform(-1, 1, size=(cores, n)).astype(np.float32)
-    t0 = time.perf_counter()
-    c_oracle.stft(c, probe, 2.0, threads=cores)
-    dt = time.perf_counter() - t0
-    rounds = max(1, min(64, int(target_seconds / max(dt, 1e-3))))
-    clips = cores * rounds
-    x = rng.uniform(-1, 1, size=(clips, n)).astype(np.float32)
-    t0 = time.perf_counter()
-    c_oracle.stft(c, x, 2.0, threads=cores)
-    dt = time.perf_counter() - t0
-    frames = clips * O.frames(c, n)
-    return {"value": round(frames / dt / 1e6, 4), "unit": "Mframes/s", "cores": cores, "kind": "port",
-            "sample": "%d clips x %d samples (%d frames) of the C2 workload, oracle/oracle_stft.c f64 "
-                      "interior, %d threads, %.1f s" % (clips, n, frames, cores, dt)}
-
-
-def main():
+def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--clips", type=int, default=256, help="clips per GPU (C2: 256)")
-    ap.add_argument("--seconds", type=float, default=10.0)
+    ap.add_argument("--workload", choices=("auto", "c2", "c5"), default="auto",
+                    help="auto: C2 at one GPU, C5 sharded above (BASELINE configs[1] / configs[4])")
+    ap.add_argument("--clips", type=int, default=0,
+                    help="override the clip count (C2: per GPU, default 256; C5: whole job, default 4096)")
+    ap.add_argument("--seconds", type=float, default=0.0, help="override the clip length (C2: 10 s, C5: 30 s)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    args = ap.parse_args()
+    ap.add_argument("--no-extras", action="store_true")
+    ap.add_argument("--dry-run", action="store_true",
+                    help="rank plumbing only (no GPU, no library): rendezvous over gloo, barrier, MAX-reduce, one JSON line")
+    ap.add_argument("--verify-shards", action="store_true",
+                    help="every rank also computes the whole batch and checks shard == slice bit for bit (small sizes)")
+    return ap.parse_args()
+
+
+# ---- launcher (no torch, no GPU call) ---------------------------------------------------------------
+def launch_ranks(n):
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ)
+        env.update(RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    out, _ = procs[0].communicate()
+    worst = procs[0].returncode
+    deadline = time.time() + 120
+    for p in procs[1:]:
+        try:
+            p.wait(timeout=max(1.0, deadline - time.time()))
+        except subprocess.TimeoutExpired:
+            p.kill()          # the exact child we started
+            p.wait()
+        worst = worst or p.returncode
+    sys.stdout.write(out.decode())
+    sys.stdout.flush()
+    return worst             # a failed rank is a failed run: no retry, never a re-exec
+
+
+# ---- CPU baseline + full parity (rank 0, N = 1) ---------------------------------------------------------
+def cpu_baseline(x_host, gpu_out_host):
+    """oracle/oracle_stft.c (float64 interior, clip-parallel pthreads) on the whole C2 batch that the GPU
+    just processed; its output checks every frame of the GPU result (north_star: 1e-5 relative)."""
+    import numpy as np
+    from oracle import c_oracle, soundml_oracle as O
+    cores = os.cpu_count() or 1
+    c = O.stft_config(FFT, hop=HOP)
+    clips, n = x_host.shape
+    c_oracle.stft(c, x_host[:min(clips, cores)], 2.0, threads=cores)      # page in the library, spawn once
+    t0 = time.perf_counter()
+    want = c_oracle.stft(c, x_host, 2.0, threads=cores)
+    dt = time.perf_counter() - t0
+    frames = clips * O.frames(c, n)
+    worst = 0.0
+    for i in range(clips):   # clip by clip: bounded temporaries
+        peak = float(want[i].max())
+        err = float(np.max(np.abs(gpu_out_host[i].astype(np.float64) - want[i])))
+        worst = max(worst, err / peak)
+    return {"value": round(frames / dt / 1e6, 4), "unit": "Mframes/s", "cores": cores, "kind": "port",
+            "sample": "the whole C2 batch once: %d clips x %d samples (%d frames), oracle/oracle_stft.c f64 interior, "
+                      "%d threads, %.2f s" % (clips, n, frames, cores, dt),
+            "gpu_vs_oracle_max_err_over_peak": float("%.3g" % worst), "gpu_vs_oracle_frames_checked": frames,
+            "gate": 1e-5}
+
+
+def main():
+    args = parse_args()
+    if args.gpus > 1 and "RANK" not in os.environ:
+        sys.exit(launch_ranks(args.gpus))
 
     import torch
     import torch.distributed as dist
@@ -67,87 +133,236 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    if args.dry_run:   # CPU check of the launcher and of the rank environment (tests/test_sharding_gloo.py)
+        from soundml_amd import shard
+        if world > 1:
+            dist.init_process_group("gloo")
+        shard.barrier()
+        t = shard.timed_region_max(1.0 + rank)
+        lo, hi = shard.clip_range(args.clips or 4096, world, rank)
+        if rank == 0:
+            print(json.dumps({"dry_run": True, "n_gpus": world, "max_clock": t, "rank0_clips": [lo, hi],
+                              "local_rank": local_rank, "master": os.environ.get("MASTER_ADDR")}), flush=True)
+        if world > 1:
+            dist.destroy_process_group()
+        return
+    ndev = torch.cuda.device_count()
+    if ndev < 1:
+        raise SystemExit("bench.py: no HIP device visible (there is no CPU path)")
+    dev = torch.device("cuda", local_rank % ndev)
+    torch.cuda.set_device(dev)
+    backend = "none"
     if world > 1:
-        dist.init_process_group("nccl", device_id=dev)
+        backend = "nccl" if ndev >= world else "gloo"      # RCCL refuses two ranks on one device
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group("gloo")
+    red_dev = dev if backend == "nccl" else None
 
     import soundml_amd as S
-    from soundml_amd import Stft
+    from soundml_amd import Fir, Mel, Stft
     from soundml_amd._lib import check, lib
+    vp = ctypes.c_void_p
 
-    fft, hop, sr = 2048, 512, 48000
-    n = int(round(args.seconds * sr))
-    clips = args.clips
-    cfg = Stft.Config.create(fft_size=fft, hop=hop)          # Hann, centered, reflect (librosa defaults)
-    frames = Stft.frames(cfg, n)
-    # synthetic audio: uniform[-1,1), seeded per rank so any shard is regenerable on-device
-    gen = torch.Generator(device=dev)
-    gen.manual_seed(42 + rank)
-    x = torch.rand(clips, n, device=dev, generator=gen, dtype=torch.float32) * 2 - 1
-    out = torch.empty(clips, cfg.bins, frames, device=dev, dtype=torch.float32)
     stream = torch.cuda.current_stream(dev)
-    sptr = ctypes.c_void_p(stream.cuda_stream)
+    sptr = vp(stream.cuda_stream)
+    cfg = Stft.Config.create(fft_size=FFT, hop=HOP)          # Hann, centered, reflect (librosa defaults)
 
-    def step():
-        check(lib.smx_stft_power_range_f32_dev(cfg._h, ctypes.c_void_p(x.data_ptr()), clips, n, n, 0, frames,
-                                               2.0, ctypes.c_void_p(out.data_ptr()), sptr))
+    def barrier():
+        torch.cuda.synchronize(dev)
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
 
-    for _ in range(args.warmup):
-        step()
-    torch.cuda.synchronize(dev)
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize(dev)
-    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
-    t0 = time.perf_counter()
-    for a, b in ev:
-        a.record(stream)
-        step()
-        b.record(stream)
-    torch.cuda.synchronize(dev)
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize(dev)
-    elapsed = time.perf_counter() - t0
-    elapsed = S.shard.timed_region_max(elapsed, device=dev)
-    step_ms = sorted(a.elapsed_time(b) for a, b in ev)
-    avg_step_ms = sum(step_ms) / len(step_ms)
-    # One step is ONE launch of the fused kernel (stft2048_power_kernel<true, true, false>: the interior
-    # tiles, then the few border frames of every clip through the same frame code), so the HIP events recorded
-    # on the launch stream around each step of the timed region are that kernel's launch durations: their
-    # average is what `rocprofv3 --kernel-trace --stats` of this command reports for it (profiles/).
-    kernel_ms = step_ms
-    avg_kernel_ms = avg_step_ms
+    def make_clip_batch(lo, hi, n):
+        """clips [lo, hi) of the job: uniform[-1,1), clip g seeded 42 + g, so any shard is regenerable anywhere"""
+        x = torch.empty(hi - lo, n, device=dev, dtype=torch.float32)
+        gen = torch.Generator(device=dev)
+        for g in range(lo, hi):
+            gen.manual_seed(42 + g)
+            x[g - lo].uniform_(-1.0, 1.0, generator=gen)
+        return x
+
+    def timed(step, steps, warmup):
+        """W warm-up steps, then K steps between barriers; HIP events on the launch stream around every step.
+        Returns (elapsed seconds, MAX over ranks; sorted per-step ms of this rank; launches per step)."""
+        for _ in range(warmup):
+            step()
+        barrier()
+        ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
+        l0 = lib.smx_debug_kernel_launches()
+        t0 = time.perf_counter()
+        for a, b in ev:
+            a.record(stream)
+            step()
+            b.record(stream)
+        barrier()
+        elapsed = time.perf_counter() - t0
+        launches = (lib.smx_debug_kernel_launches() - l0) / max(steps, 1)
+        elapsed = S.shard.timed_region_max(elapsed, device=red_dev)
+        return elapsed, sorted(a.elapsed_time(b) for a, b in ev), launches
+
+    def power_step(x, out, clips, n, frames):
+        return lambda: check(lib.smx_stft_power_range_f32_dev(cfg._h, vp(x.data_ptr()), clips, n, n, 0, frames, 2.0,
+                                                              vp(out.data_ptr()), sptr))
+
+    workload = args.workload if args.workload != "auto" else ("c2" if world == 1 else "c5")
+    line = {"metric": "STFT Mframes/sec (n_fft=2048 hop=512)", "unit": "Mframes/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "higher_is_better": True, "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic"}
+    extra = {}
+
+    # ---- the main workload ------------------------------------------------------------------------------
+    if workload == "c2":
+        clips = args.clips or 256
+        n = int(round((args.seconds or 10.0) * SR))
+        lo, hi = rank * clips, (rank + 1) * clips
+        total_clips = clips * world
+        scaling = "weak"
+        wname = "C2 per GPU: %d clips x %.0f s mono 48 kHz fp32" % (clips, n / SR)
+    else:
+        total_clips = args.clips or 4096
+        n = int(round((args.seconds or 30.0) * SR))
+        lo, hi = S.shard.clip_range(total_clips, world, rank)
+        clips = hi - lo
+        scaling = "strong"
+        wname = "C5: %d clips x %.0f s mono 48 kHz fp32 sharded by contiguous clip ranges (%d per GPU)" % (
+            total_clips, n / SR, (total_clips + world - 1) // world)
+    frames = Stft.frames(cfg, n)
+    x = make_clip_batch(lo, hi, n)
+    out = torch.empty(clips, BINS, frames, device=dev, dtype=torch.float32)
+    elapsed, step_ms, launches = timed(power_step(x, out, clips, n, frames), args.steps, args.warmup)
+    # One step is ONE launch of the fused kernel (interior tiles, then the few border frames of every clip through
+    # the same frame code), so the HIP events around a step are that kernel's launch durations: their average is
+    # what `rocprofv3 --kernel-trace --stats` of this command reports for it (profiles/).
+    if clips > 0 and launches != 1:
+        raise SystemExit("bench.py: a step of the hot path issued %.2f kernel launches, expected 1 -- the step events "
+                         "are no longer one kernel's duration" % launches)
+    avg_ms = sum(step_ms) / len(step_ms)
+
+    shard_check = None
+    if args.verify_shards:   # the reference's per-slice law (stft_grid.ml:180-205) across ranks, on the HIP path
+        full = Stft.power_spectrum(cfg, make_clip_batch(0, total_clips, n))
+        ok = bool(torch.equal(full[lo:hi], out))
+        t = torch.tensor([1.0 if ok else 0.0], dtype=torch.float64, device=red_dev)
+        if world > 1:
+            dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        shard_check = {"ranks_bit_exact": int(t.item()), "ranks": world, "world_size_seen": dist.get_world_size() if world > 1 else 1,
+                       "backend": backend}
+        del full
 
     if rank == 0:
-        total_frames = clips * frames * world
-        value = total_frames * args.steps / elapsed / 1e6
-        achieved = clips * frames * ALGO_BYTES_PER_FRAME / (avg_kernel_ms * 1e-3) / 1e9
+        total_frames = total_clips * frames
+        achieved = clips * frames * ALGO_BYTES_PER_FRAME / (avg_ms * 1e-3) / 1e9
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
-        if os.path.exists(tpath):
+        if workload == "c2" and clips == 256 and os.path.exists(tpath):
             try:
                 traffic = json.load(open(tpath)).get("bytes_per_launch")
             except Exception:
                 traffic = None
-        line = {
-            "metric": "STFT Mframes/sec (n_fft=2048 hop=512)", "value": round(value, 3), "unit": "Mframes/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "C2 per GPU: %d clips x %.0f s mono 48 kHz fp32 (uniform[-1,1) seed 42+rank), "
-                                   "STFT n_fft=2048 hop=512 Hann centered/reflect power=2 -> [clips;1025;%d], "
-                                   "device-resident in and out" % (clips, args.seconds, frames),
-                       "frames_per_gpu": clips * frames, "sharding": "clips over ranks, no collective"},
+        line.update({
+            "value": round(total_frames * args.steps / elapsed / 1e6, 3),
+            "ms_per_step": round(elapsed / args.steps * 1e3, 4), "scaling": scaling,
+            "config": {"workload": "%s (uniform[-1,1), clip g seeded 42+g), STFT n_fft=2048 hop=512 Hann centered/reflect "
+                                   "power=2 -> [clips;1025;%d], device-resident in and out" % (wname, frames),
+                       "frames_per_gpu": clips * frames, "sharding": "clips over ranks, no collective",
+                       "timing_backend": backend},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-                         "kernel": "stft2048_power_kernel<true, true, false> (one launch per step: all %d frames of %d clips)" % (frames, clips),
-                         "kernel_ms_avg": round(avg_kernel_ms, 4), "kernel_ms_min": round(kernel_ms[0], 4),
+                         "kernel": "stft2048_power_kernel<true, true, false> (one launch per step: all %d frames of %d clips)"
+                                   % (frames, clips),
+                         "launches_per_step": launches,
+                         "kernel_ms_avg": round(avg_ms, 4), "kernel_ms_min": round(step_ms[0], 4),
                          "algorithmic_bytes_per_frame": ALGO_BYTES_PER_FRAME},
-        }
-        if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(fft, hop, n)
+        })
+        if shard_check:
+            line["shard_check"] = shard_check
+
+    # ---- CPU baseline on the same batch (rank 0, one GPU) ------------------------------------------------------
+    if world == 1 and workload == "c2" and not args.no_cpu_baseline:
+        line["cpu_baseline"] = cpu_baseline(x.cpu().numpy(), out.cpu().numpy())
+
+    # ---- extras: the other BASELINE configurations, same HIP-event method ---------------------------------------
+    if not args.no_extras:
+        k, w = max(5, min(args.steps, 20)), max(2, min(args.warmup, 5))
+        if world == 1 and workload == "c2" and clips == 256:
+            # C3: fused mel spectrogram (128 mels) of the same batch
+            mc = Mel.Config.create(n_mels=128, sample_rate=SR, fft_size=FFT)
+            mout = torch.empty(clips, 128, frames, device=dev, dtype=torch.float32)
+            _, ms, nl = timed(lambda: check(lib.smx_mel_spectrogram_f32_dev(cfg._h, mc._h, vp(x.data_ptr()), clips, n, n, 2.0,
+                                                                            vp(mout.data_ptr()), sptr)), k, w)
+            a = sum(ms) / len(ms)
+            mfma = None
+            ppath = os.path.join(ROOT, "profiles", "mfma_util.json")
+            if os.path.exists(ppath):
+                try:
+                    mfma = json.load(open(ppath))
+                except Exception:
+                    mfma = None
+            extra["c3_mel"] = {"workload": "C3: mel spectrogram (128 mels, Slaney) fused from audio on the C2 batch",
+                               "value": round(clips * frames / a / 1e3, 1), "unit": "Mframes/s", "ms": round(a, 4),
+                               "ms_min": round(ms[0], 4), "launches_per_step": nl,
+                               "roofline": {"bound": "hbm", "achieved": round(clips * frames * MEL_BYTES_PER_FRAME / a / 1e6, 1),
+                                            "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                            "frac": round(clips * frames * MEL_BYTES_PER_FRAME / a / 1e6 / HBM_PEAK_GBS, 4),
+                                            "algorithmic_bytes_per_frame": MEL_BYTES_PER_FRAME},
+                               "dense_equiv_tflops": round(2.0 * 128 * BINS * clips * frames / a / 1e9, 1),
+                               "mfma": mfma}
+            del mout
+            # C4: FIR 8192 taps on 8 channels x 60 s
+            h = Fir.design_lowpass(8192, 0.25, 100.0)
+            plan = Fir.Plan.create(h)
+            ch, ns = 8, 60 * SR
+            xs = make_clip_batch(10000, 10000 + ch, ns)
+            ys = torch.empty_like(xs)
+            _, ms, nl = timed(lambda: check(lib.smx_fir_apply_f32_dev(plan._h, vp(xs.data_ptr()), ch, ns, ns, vp(ys.data_ptr()),
+                                                                      ns, sptr)), k, w)
+            a = sum(ms) / len(ms)
+            extra["c4_fir"] = {"workload": "C4: 8192-tap Kaiser lowpass, overlap-save N=%d, 8 ch x 60 s 48 kHz" % plan.block,
+                               "value": round(ch * ns / a / 1e6, 2), "unit": "Gsamples/s", "ms": round(a, 4),
+                               "ms_min": round(ms[0], 4), "launches_per_step": nl,
+                               "roofline": {"bound": "hbm", "achieved": round(ch * ns * FIR_BYTES_PER_SAMPLE / a / 1e6, 1),
+                                            "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                            "frac": round(ch * ns * FIR_BYTES_PER_SAMPLE / a / 1e6 / HBM_PEAK_GBS, 4),
+                                            "algorithmic_bytes_per_sample": FIR_BYTES_PER_SAMPLE}}
+            del xs, ys
+            # C5 on ONE GPU: the N = 1 point of BASELINE configs[4] (71 GB resident)
+            free_b, _ = torch.cuda.mem_get_info(dev)
+            del x, out
+            c5_clips, n5 = 4096, 30 * SR
+            f5 = Stft.frames(cfg, n5)
+            need = c5_clips * (n5 + BINS * f5) * 4
+            if free_b > need + (8 << 30):
+                x5 = make_clip_batch(0, c5_clips, n5)
+                o5 = torch.empty(c5_clips, BINS, f5, device=dev, dtype=torch.float32)
+                _, ms, nl = timed(power_step(x5, o5, c5_clips, n5, f5), 5, 2)
+                a = sum(ms) / len(ms)
+                extra["c5_one_gpu"] = {"workload": "C5 on one GPU: 4096 clips x 30 s, %d frames, one call" % (c5_clips * f5),
+                                       "value": round(c5_clips * f5 / a / 1e3, 1), "unit": "Mframes/s", "ms": round(a, 3),
+                                       "launches_per_step": nl,
+                                       "roofline": {"bound": "hbm", "achieved": round(c5_clips * f5 * ALGO_BYTES_PER_FRAME / a / 1e6, 1),
+                                                    "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                                    "frac": round(c5_clips * f5 * ALGO_BYTES_PER_FRAME / a / 1e6 / HBM_PEAK_GBS, 4)}}
+                del x5, o5
+        elif world > 1 and workload == "c5" and not args.clips:
+            # the weak-scaled C2 figure of the same ranks: 256 clips x 10 s per GPU
+            del x, out
+            n2 = 10 * SR
+            f2 = Stft.frames(cfg, n2)
+            x2 = make_clip_batch(100000 + 256 * rank, 100000 + 256 * (rank + 1), n2)
+            o2 = torch.empty(256, BINS, f2, device=dev, dtype=torch.float32)
+            el, ms, nl = timed(power_step(x2, o2, 256, n2, f2), k, w)
+            a = sum(ms) / len(ms)
+            extra["c2_weak"] = {"workload": "C2 per GPU (256 clips x 10 s), weak scaling over the same ranks",
+                                "value": round(256 * f2 * world * k / el / 1e6, 1), "unit": "Mframes/s",
+                                "ms_per_step": round(el / k * 1e3, 4), "rank0_kernel_ms_avg": round(a, 4), "scaling": "weak"}
+            del x2, o2
+
+    if rank == 0:
+        if extra:
+            line["extra"] = extra
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.destroy_process_group()

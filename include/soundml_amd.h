@@ -90,6 +90,9 @@ typedef struct smx_fir_plan smx_fir_plan;
 /* ---- library ------------------------------------------------------------ */
 const char *smx_last_error(void);      /* message of the last failing call on this thread */
 int smx_version(void);
+/* diagnostics: kernel launches issued by this process through the library so far (bench.py asserts that one step
+ * of the hot path is one launch, so that HIP events around a step time that kernel) */
+unsigned long long smx_debug_kernel_launches(void);
 int smx_device_count(int *count);
 int smx_set_device(int device);        /* device used by this thread's subsequent calls */
 int smx_set_interior(int interior);    /* SMX_INTERIOR_*, process-wide default for f32 audio */

@@ -31,6 +31,8 @@ def load():
         fn.argtypes = [vp, i64, i64, ci, ci, vp, i64, ci, d, i64, ci, d, vp, ci]
     lib.oracle_mel_apply_f32.restype = ci
     lib.oracle_mel_apply_f32.argtypes = [vp, ci, ci, vp, i64, i64, vp]
+    lib.oracle_mel_apply_f32_mt.restype = ci
+    lib.oracle_mel_apply_f32_mt.argtypes = [vp, ci, ci, vp, i64, i64, vp, ci]
     return lib
 
 
@@ -56,12 +58,13 @@ def stft(c: O.StftConfig, x: np.ndarray, power=2.0, complex_out=False, threads=1
     return out
 
 
-def mel_apply(mc: O.MelConfig, s: np.ndarray) -> np.ndarray:
+def mel_apply(mc: O.MelConfig, s: np.ndarray, threads: int = 1) -> np.ndarray:
     lib = load()
     s = np.ascontiguousarray(s, dtype=np.float32)
     lead_shape, frames = s.shape[:-2], s.shape[-1]
     lead = int(np.prod(lead_shape)) if lead_shape else 1
     out = np.zeros(lead_shape + (mc.n_mels, frames), dtype=np.float32)
     w = np.ascontiguousarray(mc.weights, dtype=np.float64)
-    lib.oracle_mel_apply_f32(w.ctypes.data, mc.n_mels, mc.bins, s.ctypes.data, lead, frames, out.ctypes.data)
+    lib.oracle_mel_apply_f32_mt(w.ctypes.data, mc.n_mels, mc.bins, s.ctypes.data, lead, frames, out.ctypes.data,
+                                int(threads))
     return out

@@ -217,15 +217,49 @@ int oracle_stft_f64(const double *x, int64_t lead, int64_t n, int fft, int hop, 
   return run(j, threads);
 }
 
-/* mel.ml:231: out[l][m][t] = (float) sum_b W[m][b] * (double) S[l][b][t] */
+/* mel.ml:231: out[l][m][t] = (float) sum_b W[m][b] * (double) S[l][b][t], bins in ascending order.
+ * Clip-parallel; the inner loop runs along the frame axis (contiguous).  Exact-zero weights are skipped: for
+ * finite spectrograms adding W*S = +-0 never changes a sum, so the values are those of the dense product. */
+typedef struct {
+  const double *w; int n_mels, bins; const float *s; int64_t lead, frames; float *out; int thread, threads;
+} mel_job_t;
+
+static void *mel_worker(void *arg) {
+  mel_job_t *j = (mel_job_t *)arg;
+  double *acc = (double *)malloc(sizeof(double) * (size_t)(j->frames > 0 ? j->frames : 1));
+  for (int64_t u = j->thread; u < j->lead * j->n_mels; u += j->threads) {
+    const int64_t l = u / j->n_mels;
+    const int m = (int)(u % j->n_mels);
+    for (int64_t t = 0; t < j->frames; ++t) acc[t] = 0.0;
+    for (int b = 0; b < j->bins; ++b) {
+      const double wv = j->w[(int64_t)m * j->bins + b];
+      if (wv == 0.0) continue;
+      const float *row = j->s + (l * j->bins + b) * j->frames;
+      for (int64_t t = 0; t < j->frames; ++t) acc[t] += wv * (double)row[t];
+    }
+    float *o = j->out + (l * j->n_mels + m) * j->frames;
+    for (int64_t t = 0; t < j->frames; ++t) o[t] = (float)acc[t];
+  }
+  free(acc);
+  return NULL;
+}
+
+int oracle_mel_apply_f32_mt(const double *w, int n_mels, int bins, const float *s, int64_t lead, int64_t frames,
+                            float *out, int threads) {
+  if (threads < 1) threads = 1;
+  if (threads > 256) threads = 256;
+  pthread_t tid[256];
+  mel_job_t jobs[256];
+  for (int t = 0; t < threads; ++t) {
+    mel_job_t j = {w, n_mels, bins, s, lead, frames, out, t, threads};
+    jobs[t] = j;
+    pthread_create(&tid[t], NULL, mel_worker, &jobs[t]);
+  }
+  for (int t = 0; t < threads; ++t) pthread_join(tid[t], NULL);
+  return 0;
+}
+
 int oracle_mel_apply_f32(const double *w, int n_mels, int bins, const float *s, int64_t lead, int64_t frames,
                          float *out) {
-  for (int64_t l = 0; l < lead; ++l)
-    for (int m = 0; m < n_mels; ++m)
-      for (int64_t t = 0; t < frames; ++t) {
-        double acc = 0.0;
-        for (int b = 0; b < bins; ++b) acc += w[(int64_t)m * bins + b] * (double)s[(l * bins + b) * frames + t];
-        out[(l * n_mels + m) * frames + t] = (float)acc;
-      }
-  return 0;
+  return oracle_mel_apply_f32_mt(w, n_mels, bins, s, lead, frames, out, 1);
 }

@@ -1269,6 +1269,222 @@ def fir_filter_direct(h: np.ndarray, x: np.ndarray) -> np.ndarray:
 
 
 # ----------------------------------------------------------------------------
+# Overlap-save (OLS) executor of the resample stages: the one piece of FIR block
+# convolution the reference HAS (resample.ml:279-300, 856-867, 1309-1319,
+# 1456-1599, 1745-1755; resample_stubs.c:314-372).  Parity is still "unpinned" in
+# the golden-vector sense (the reference tests Resample by dB thresholds only,
+# test/resample/resample_quality.ml), so these restatements are checked against
+# their defining direct sums (tests/test_fir_oracle_pins.py).
+# ----------------------------------------------------------------------------
+
+OLS_CEILING_MS = 130    # resample.ml:273
+
+
+def ols_block_n(rate: int, f_div: int, k: int) -> Optional[int]:
+    """resample.ml:279-286: smallest 2^j (times 3 when 3 | F) with N >= max 64 (10 K), or None past the ceiling."""
+    target = max(64, 10 * k)
+    n = 3 if f_div % 3 == 0 else 1
+    while n < target:
+        n *= 2
+    return n if n * 1000 <= OLS_CEILING_MS * rate else None
+
+
+def ols_geom(rate: int, l: int, m: int, k: int):
+    """resample.ml:292-300: (N, B, delta) or None."""
+    f_div = m if l == 1 else 1
+    n = ols_block_n(rate, f_div, k)
+    if n is None:
+        return None
+    b = (n - 2 * k) // f_div * f_div
+    delta = (f_div - (3 * k % f_div)) % f_div
+    return None if b < 1 else (n, b, delta)
+
+
+def ols_folds_inverse(w: int) -> bool:
+    """resample.ml:309: the inverse transform's 1/W rides in the plan spectrum iff W is a power of two."""
+    return w & (w - 1) == 0
+
+
+def resample_prototype(l: int, k: int, fc: float, beta: float) -> np.ndarray:
+    """resample.ml:145-163 `design_prototype`: 2 K L + 1 taps, right half evaluated and mirrored, sum = L."""
+    mid = k * l
+    n = 2 * mid + 1
+    i0_beta = bessel_i0(beta)
+    h = np.zeros(n, dtype=np.float64)
+    for i in range(mid, n):
+        z = float(i - mid)
+        s = fc if i == mid else math.sin(math.pi * fc * z) / (math.pi * z)
+        r = z / float(mid) if mid > 0 else 0.0
+        v = s * (bessel_i0(beta * math.sqrt(1.0 - r * r)) / i0_beta)
+        h[i] = v
+        h[n - 1 - i] = v
+    total = 0.0
+    for v in h:               # Array.fold_left ( +. ) 0. h
+        total += float(v)
+    return h * (float(l) / total)
+
+
+def ols_plan_spectrum(proto: np.ndarray, n: int, l: int, m: int) -> np.ndarray:
+    """resample.ml:856-867 `oh`: rfft (complex128) of the zero-padded prototype on the transform grid, carrying 1/M
+    (the alias-fold weight) and, where `ols_folds_inverse` admits it, the inverse transform's 1/W."""
+    length = n * l if l > 1 else n
+    w = n * l if l > 1 else n // m
+    padded = np.zeros(length, dtype=np.float64)
+    padded[:len(proto)] = proto
+    spec = np.fft.rfft(padded)
+    scale = (1.0 / float(m) if m > 1 else 1.0) * (1.0 / float(w) if ols_folds_inverse(w) else 1.0)
+    return spec if scale == 1.0 else spec * scale
+
+
+def ols_shape(xs: np.ndarray, h: np.ndarray, n: int, sl: int, sm: int) -> np.ndarray:
+    """resample_stubs.c:329-372 `soundml_resample_shape_run`: from the length-N half spectra `xs` [lines; N/2+1] to
+    the half grid of the inverse transform of length W.  xL: periodic extension times h[k]; /M: product on the half
+    grid, alias fold onto W = N/M bins in ascending fold order; otherwise the plain product."""
+    w = n * sl if sl > 1 else (n // sm if sm > 1 else n)
+    half, obins = n // 2, w // 2 + 1
+    lines = xs.shape[0]
+    ys = np.zeros((lines, obins), dtype=np.complex128)
+    if sl > 1:
+        kk = np.arange(obins)
+        j = kk % n
+        src = np.where(j <= half, j, n - j)
+        val = xs[:, src]
+        val = np.where((j <= half)[None, :], val, np.conj(val))
+        ys[:] = val * h[None, :obins]
+    elif sm > 1:
+        for k in range(obins):
+            acc = xs[:, k] * h[k]
+            j = k
+            for _ in range(1, sm):
+                j += w
+                if j <= half:
+                    p = xs[:, j] * h[j]
+                else:
+                    p = np.conj(xs[:, n - j] * h[n - j])
+                acc = acc + p
+            ys[:, k] = acc
+    else:
+        ys[:] = xs[:, :obins] * h[None, :obins]
+    return ys
+
+
+def ols_transform(x: np.ndarray, oh: np.ndarray, n: int, l: int, m: int) -> np.ndarray:
+    """resample.ml:1500-1512 `transform`: rfft (complex128) -> shape -> irfft at the kernel dtype, last axis W."""
+    w = n * l if l > 1 else n // m
+    spec = np.fft.rfft(np.asarray(x, dtype=np.float64), axis=-1)
+    shaped = ols_shape(spec, oh, n, l, m)
+    return np.fft.irfft(shaped, n=w, axis=-1, norm="forward" if ols_folds_inverse(w) else "backward")
+
+
+def ols_hi(l: int, m: int, k: int, geom, b: int) -> int:
+    """resample.ml:1313-1315: the last output block b makes computable."""
+    n, bb, delta = geom
+    if l > 1:
+        return l * (b * bb + n - 3 * k) - 1
+    return (b * bb + n - 3 * k - delta - 1) // m
+
+
+def ols_avail(l: int, m: int, k: int, geom, fed: int) -> int:
+    """resample.ml:1309-1319 `ols_blocks` / `ols_avail`."""
+    n, bb, delta = geom
+    need0 = n - 2 * k - delta
+    nb = 0 if fed < need0 else (fed - need0) // bb + 1
+    return 0 if nb == 0 else ols_hi(l, m, k, geom, nb - 1) + 1
+
+
+class OlsStageState:
+    """resample.ml:1230-1243 + 1456-1599: carry (grid tail), blocks executed, totals fed / emitted."""
+
+    def __init__(self, proto, l, m, k, geom, channels, dtype=np.float64):
+        self.l, self.m, self.k, self.geom = l, m, k, geom
+        n, b, delta = geom
+        self.oh = ols_plan_spectrum(np.asarray(proto, dtype=np.float64), n, l, m)
+        self.carry = np.zeros((channels, n), dtype=dtype)     # starts as the 2K + delta virtual zeros
+        self.oblocks = self.fed = self.emitted = 0
+        self.dtype = dtype
+
+    def run(self, src, cnt: int, n_out: int) -> np.ndarray:
+        """`ols_run`: feeds `cnt` samples (`src` [ch; cnt], or None = silence), executes every block that completes,
+        returns this call's n_out outputs per channel.  The caller advances `fed` (resample.ml:1790-1793)."""
+        l, m, k = self.l, self.m, self.k
+        n, bb, delta = self.geom
+        ch = self.carry.shape[0]
+        lead = 2 * k + delta
+        pend = self.fed + lead - self.oblocks * bb
+        alen = pend + cnt
+        feed = np.zeros((ch, cnt), dtype=self.dtype) if src is None else np.asarray(src, dtype=self.dtype)
+        y = np.zeros((ch, n_out), dtype=self.dtype)
+        if alen < n:
+            self.carry[:, pend:alen] = feed
+            assert n_out == 0
+            return y
+        t = (alen - n) // bb + 1
+        av = np.concatenate([self.carry[:, :pend], feed], axis=-1)
+        w = n * l if l > 1 else n // m
+        out_pos = 0
+        for j in range(t):
+            r = ols_transform(av[:, j * bb: j * bb + n], self.oh, n, l, m).astype(self.dtype)
+            b = self.oblocks + j
+            i0 = self.emitted + out_pos
+            c = min(ols_hi(l, m, k, self.geom, b) + 1 - i0, n_out - out_pos)
+            if c > 0:
+                pos = i0 + l * (3 * k - b * bb) if l > 1 else (i0 * m + 3 * k + delta - b * bb) // m
+                assert 0 <= pos and pos + c <= w
+                y[:, out_pos: out_pos + c] = r[:, pos: pos + c]
+                out_pos += c
+        assert out_pos == n_out
+        pend2 = alen - t * bb
+        self.carry[:, :pend2] = av[:, t * bb:]
+        self.oblocks += t
+        self.emitted += n_out
+        return y
+
+
+def ols_stage(proto, l: int, m: int, k: int, geom, x: np.ndarray, chunks=None) -> np.ndarray:
+    """One OLS stage over a whole signal [ch; n]: `run` per chunk (resample.ml:1786-1793), then the virtual-silence
+    drain (resample.ml:1745-1755); ceil(n L / M) outputs per channel."""
+    x = np.asarray(x)
+    ch, total_in = x.shape
+    st = OlsStageState(proto, l, m, k, geom, ch, dtype=x.dtype)
+    outs = []
+    pos = 0
+    for c in (chunks or [total_in]):
+        c = min(c, total_in - pos)
+        if c <= 0:
+            break
+        n_out = ols_avail(l, m, k, geom, st.fed + c) - st.emitted
+        outs.append(st.run(x[:, pos: pos + c], c, n_out))
+        st.fed += c
+        pos += c
+    assert pos == total_in, "chunks do not cover the signal"
+    n_out = -(-st.fed * l // m) - st.emitted
+    if n_out > 0:
+        n, bb, delta = geom
+        target = st.emitted + n_out
+        b = st.oblocks
+        while ols_hi(l, m, k, geom, b) < target - 1:
+            b += 1
+        zeros = b * bb + n - 2 * k - delta - st.fed
+        outs.append(st.run(None, zeros, n_out))
+    return np.concatenate(outs, axis=-1) if outs else np.zeros((ch, 0), dtype=x.dtype)
+
+
+def resample_stage_direct(proto, l: int, m: int, k: int, x: np.ndarray) -> np.ndarray:
+    """The stage by its definition (what the direct executor computes, resample.ml:1318-1326 `ready`): output i reads
+    the zero-stuffed input around position i M with the group delay K L compensated,
+    y[i] = sum_t proto[t] xu[i M + K L - t], xu[q L] = x[q], zeros outside; ceil(n L / M) outputs."""
+    x64 = np.asarray(x, dtype=np.float64)
+    ch, n = x64.shape
+    xu = np.zeros((ch, n * l), dtype=np.float64)
+    xu[:, ::l] = x64
+    full = np.stack([np.convolve(xu[c], np.asarray(proto, dtype=np.float64)) for c in range(ch)])   # full[s] = sum_t proto[t] xu[s - t]
+    n_out = -(-n * l // m)
+    idx = np.arange(n_out) * m + k * l
+    full = np.concatenate([full, np.zeros((ch, max(0, int(idx[-1]) + 1 - full.shape[1]) if n_out else 0))], axis=-1)
+    return full[:, idx].astype(x.dtype)
+
+
+# ----------------------------------------------------------------------------
 # Test-signal generators of the reference's suites
 # ----------------------------------------------------------------------------
 

@@ -60,6 +60,7 @@ pf32, pf64, pi64 = C.POINTER(C.c_float), C.POINTER(C.c_double), C.POINTER(C.c_in
 SIGNATURES = {
     "smx_last_error": (C.c_char_p, []),
     "smx_version": (cint, []),
+    "smx_debug_kernel_launches": (C.c_ulonglong, []),
     "smx_device_count": (cint, [C.POINTER(cint)]),
     "smx_set_device": (cint, [cint]),
     "smx_set_interior": (cint, [cint]),

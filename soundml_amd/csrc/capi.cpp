@@ -22,6 +22,8 @@ static std::atomic<int> g_interior{SMX_INTERIOR_F32};
 
 void set_last_error(const std::string &message) { g_last_error = message; }
 
+std::atomic<unsigned long long> g_kernel_launches{0};
+
 bool fast_path_disabled() {
   const char *e = std::getenv("SMX_DISABLE_FAST");
   return e && e[0] == '1';
@@ -213,6 +215,7 @@ extern "C" {
 
 const char *smx_last_error(void) { return g_last_error.c_str(); }
 int smx_version(void) { return 100; }
+unsigned long long smx_debug_kernel_launches(void) { return g_kernel_launches.load(); }
 
 int smx_device_count(int *count) {
   return guarded([&] {

@@ -210,7 +210,7 @@ void fir_apply_dev(const smx_fir_plan &p, const float *d_x, int64_t channels, in
   auto launch = [&](auto kernel, int threads) {
     SMX_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kernel),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(kernel, dim3((unsigned)grid), dim3(threads), lds, stream, a);
+    SMX_LAUNCH(kernel, dim3((unsigned)grid), dim3(threads), lds, stream, a);
   };
   switch (p.log2n) {
     case 10: launch(fir_ols_kernel<10>, 64); break;

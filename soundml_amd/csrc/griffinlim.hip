@@ -71,30 +71,30 @@ unsigned grid_for(int64_t total) { return (unsigned)std::min<int64_t>((total + 2
 
 void launch_gl_widen(const float *src, double *dst, int64_t total, hipStream_t stream) {
   if (total <= 0) return;
-  hipLaunchKernelGGL((gl_convert_kernel<float, double>), dim3(grid_for(total)), dim3(256), 0, stream, src, dst, total);
+  SMX_LAUNCH((gl_convert_kernel<float, double>), dim3(grid_for(total)), dim3(256), 0, stream, src, dst, total);
   SMX_HIP_CHECK(hipGetLastError());
 }
 void launch_gl_narrow(const double *src, float *dst, int64_t total, hipStream_t stream) {
   if (total <= 0) return;
-  hipLaunchKernelGGL((gl_convert_kernel<double, float>), dim3(grid_for(total)), dim3(256), 0, stream, src, dst, total);
+  SMX_LAUNCH((gl_convert_kernel<double, float>), dim3(grid_for(total)), dim3(256), 0, stream, src, dst, total);
   SMX_HIP_CHECK(hipGetLastError());
 }
 
 void launch_gl_init(const void *phase, void *angles, int64_t total, int elem_bytes, hipStream_t stream) {
   if (total <= 0) return;
   if (elem_bytes == 8)
-    hipLaunchKernelGGL(gl_init_kernel<double>, dim3(grid_for(total)), dim3(256), 0, stream, (const double *)phase, (double2 *)angles, total);
+    SMX_LAUNCH(gl_init_kernel<double>, dim3(grid_for(total)), dim3(256), 0, stream, (const double *)phase, (double2 *)angles, total);
   else
-    hipLaunchKernelGGL(gl_init_kernel<float>, dim3(grid_for(total)), dim3(256), 0, stream, (const float *)phase, (float2 *)angles, total);
+    SMX_LAUNCH(gl_init_kernel<float>, dim3(grid_for(total)), dim3(256), 0, stream, (const float *)phase, (float2 *)angles, total);
   SMX_HIP_CHECK(hipGetLastError());
 }
 
 void launch_gl_apply(const void *mag, const void *angles, void *z, int64_t total, int elem_bytes, hipStream_t stream) {
   if (total <= 0) return;
   if (elem_bytes == 8)
-    hipLaunchKernelGGL(gl_apply_kernel<double>, dim3(grid_for(total)), dim3(256), 0, stream, (const double *)mag, (const double2 *)angles, (double2 *)z, total);
+    SMX_LAUNCH(gl_apply_kernel<double>, dim3(grid_for(total)), dim3(256), 0, stream, (const double *)mag, (const double2 *)angles, (double2 *)z, total);
   else
-    hipLaunchKernelGGL(gl_apply_kernel<float>, dim3(grid_for(total)), dim3(256), 0, stream, (const float *)mag, (const float2 *)angles, (float2 *)z, total);
+    SMX_LAUNCH(gl_apply_kernel<float>, dim3(grid_for(total)), dim3(256), 0, stream, (const float *)mag, (const float2 *)angles, (float2 *)z, total);
   SMX_HIP_CHECK(hipGetLastError());
 }
 
@@ -102,9 +102,9 @@ void launch_gl_update(const void *rebuilt, const void *previous, double beta, vo
                       int elem_bytes, hipStream_t stream) {
   if (total <= 0) return;
   if (elem_bytes == 8)
-    hipLaunchKernelGGL(gl_update_kernel<double>, dim3(grid_for(total)), dim3(256), 0, stream, (const double2 *)rebuilt, (const double2 *)previous, beta, (double2 *)angles, total);
+    SMX_LAUNCH(gl_update_kernel<double>, dim3(grid_for(total)), dim3(256), 0, stream, (const double2 *)rebuilt, (const double2 *)previous, beta, (double2 *)angles, total);
   else
-    hipLaunchKernelGGL(gl_update_kernel<float>, dim3(grid_for(total)), dim3(256), 0, stream, (const float2 *)rebuilt, (const float2 *)previous, (float)beta, (float2 *)angles, total);
+    SMX_LAUNCH(gl_update_kernel<float>, dim3(grid_for(total)), dim3(256), 0, stream, (const float2 *)rebuilt, (const float2 *)previous, (float)beta, (float2 *)angles, total);
   SMX_HIP_CHECK(hipGetLastError());
 }
 

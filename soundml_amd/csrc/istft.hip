@@ -387,14 +387,14 @@ void launch_stockham_frames_wide(const IstftArgs &a, const StftTables &t, hipStr
   if (blocks > 2147483647LL) throw Failure("invert: too many frame tiles for one launch");
   auto kernel = istft_stockham_frames_wide_kernel<LOG2N, FT, Tz>;
   SMX_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  hipLaunchKernelGGL(kernel, dim3((unsigned)blocks), dim3(THREADS), lds, stream, a, (const double2 *)t.fast_w_m_f64, (const double2 *)t.twiddle_f64,
+  SMX_LAUNCH(kernel, dim3((unsigned)blocks), dim3(THREADS), lds, stream, a, (const double2 *)t.fast_w_m_f64, (const double2 *)t.twiddle_f64,
                      (const double2 *)t.fast_synth_window_f64);
   SMX_HIP_CHECK(hipGetLastError());
 }
 
 template <typename Tz>
 bool launch_stockham_frames_wide_any(const IstftArgs &a, const StftTables &t, hipStream_t stream) {
-  static const bool fast_off = std::getenv("SMX_DISABLE_FAST") != nullptr;
+  const bool fast_off = fast_path_disabled();
   if (fast_off || std::getenv("SMX_ISTFT_RADIX2") || !t.fast_w_m_f64 || !t.twiddle_f64 || !t.fast_synth_window_f64) return false;
   switch (a.fft) {
     case 512: launch_stockham_frames_wide<9, 16, Tz>(a, t, stream); return true;
@@ -414,7 +414,7 @@ void launch_stockham_frames(const IstftArgs &a, const StftTables &t, hipStream_t
   if (blocks > 2147483647LL) throw Failure("invert: too many frame tiles for one launch");
   auto kernel = istft_stockham_frames_kernel<LOG2N, FT, 0>;
   SMX_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  hipLaunchKernelGGL(kernel, dim3((unsigned)blocks), dim3(THREADS), lds, stream, a, (const float2 *)t.fast_w_m, (const float2 *)t.fast_w_n,
+  SMX_LAUNCH(kernel, dim3((unsigned)blocks), dim3(THREADS), lds, stream, a, (const float2 *)t.fast_w_m, (const float2 *)t.fast_w_n,
                      (const float2 *)t.fast_synth_window, FusedOla{});
   SMX_HIP_CHECK(hipGetLastError());
 }
@@ -429,7 +429,7 @@ bool launch_stockham_fused(const IstftArgs &a, const StftTables &t, const FusedO
   if (blocks > 2147483647LL) return false;
   auto kernel = istft_stockham_frames_kernel<LOG2N, 16, RATIO>;
   SMX_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  hipLaunchKernelGGL(kernel, dim3((unsigned)blocks), dim3(THREADS), lds, stream, a, (const float2 *)t.fast_w_m, (const float2 *)t.fast_w_n,
+  SMX_LAUNCH(kernel, dim3((unsigned)blocks), dim3(THREADS), lds, stream, a, (const float2 *)t.fast_w_m, (const float2 *)t.fast_w_n,
                      (const float2 *)t.fast_synth_window, o);
   SMX_HIP_CHECK(hipGetLastError());
   return true;
@@ -438,7 +438,7 @@ bool launch_stockham_fused(const IstftArgs &a, const StftTables &t, const FusedO
 // float32 spectra, float32 interior, fft 512 .. 4096: true when the Stockham frames kernel took the launch
 bool launch_stockham_frames_any(const IstftArgs &a, const StftTables &t, hipStream_t stream) {
   if (!t.fast_w_m || !t.fast_w_n || !t.fast_synth_window) return false;
-  static const bool fast_off = std::getenv("SMX_DISABLE_FAST") != nullptr;
+  const bool fast_off = fast_path_disabled();
   if (fast_off) return false;
   switch (a.fft) {
     case 512: launch_stockham_frames<9, 16>(a, t, stream); return true;
@@ -696,7 +696,7 @@ void launch_frames(const IstftJob &job, IstftArgs a, hipStream_t stream) {
   auto kernel = use_pow2 ? istft_frames_kernel<Tz, Tacc, true> : istft_frames_kernel<Tz, Tacc, false>;
   const size_t lds = lds_bytes(ft, use_pow2);
   SMX_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  hipLaunchKernelGGL(kernel, dim3((unsigned)blocks), dim3(256), lds, stream, a);
+  SMX_LAUNCH(kernel, dim3((unsigned)blocks), dim3(256), lds, stream, a);
   SMX_HIP_CHECK(hipGetLastError());
   (void)job;
 }
@@ -705,7 +705,7 @@ void launch_frames(const IstftJob &job, IstftArgs a, hipStream_t stream) {
 
 // the fused kernel: fft 2048, hop 512, complex64 spectrum, float32 interior
 static bool istft_fused_2048(const IstftJob &job) {
-  static const bool fast_off = std::getenv("SMX_DISABLE_FAST") != nullptr;
+  const bool fast_off = fast_path_disabled();
   const bool f64 = job.z_bytes == 16 || job.interior == SMX_INTERIOR_F64;
   return !fast_off && !f64 && job.cfg->fft_size == 2048 && job.cfg->hop == 512 && job.lead <= 0x7fffffff / 4096;
 }
@@ -713,7 +713,7 @@ static bool istft_fused_2048(const IstftJob &job) {
 // the kernels that stage the spectrum themselves: the fused fft-2048 / hop-512 one and the Stockham frames kernel
 // (float32, fft 512 .. 4096)
 bool istft_takes_factors(const IstftJob &job) {
-  static const bool fast_off = std::getenv("SMX_DISABLE_FAST") != nullptr;
+  const bool fast_off = fast_path_disabled();
   const bool f64 = job.z_bytes == 16 || job.interior == SMX_INTERIOR_F64;
   const int64_t n = job.cfg->fft_size;
   return istft_fused_2048(job) || (!fast_off && !f64 && (n == 512 || n == 1024 || n == 2048 || n == 4096));
@@ -770,7 +770,7 @@ void launch_istft(const IstftJob &job) {
       const int64_t launched = sa.per_xcd > 0 ? sa.per_xcd * 8 : blocks;
       SMX_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(istft2048_kernel),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)kSynLds));
-      hipLaunchKernelGGL(istft2048_kernel, dim3((unsigned)launched), dim3(1024), kSynLds, job.stream, sa);
+      SMX_LAUNCH(istft2048_kernel, dim3((unsigned)launched), dim3(1024), kSynLds, job.stream, sa);
       SMX_HIP_CHECK(hipGetLastError());
       return;
     }
@@ -858,9 +858,9 @@ void launch_istft(const IstftJob &job) {
     oa.head = head_n;
     oa.stop = stop;
     dim3 grid((unsigned)((job.out_len + 255) / 256), (unsigned)nclips);
-    if (job.z_bytes == 16) hipLaunchKernelGGL((istft_ola_kernel<double, double>), grid, dim3(256), 0, job.stream, oa);
-    else if (f64) hipLaunchKernelGGL((istft_ola_kernel<double, float>), grid, dim3(256), 0, job.stream, oa);
-    else hipLaunchKernelGGL((istft_ola_kernel<float, float>), grid, dim3(256), 0, job.stream, oa);
+    if (job.z_bytes == 16) SMX_LAUNCH((istft_ola_kernel<double, double>), grid, dim3(256), 0, job.stream, oa);
+    else if (f64) SMX_LAUNCH((istft_ola_kernel<double, float>), grid, dim3(256), 0, job.stream, oa);
+    else SMX_LAUNCH((istft_ola_kernel<float, float>), grid, dim3(256), 0, job.stream, oa);
     SMX_HIP_CHECK(hipGetLastError());
   }
   SMX_HIP_CHECK(hipFreeAsync(d_y, job.stream));

@@ -162,19 +162,19 @@ void launch_mel_apply(const MelJob &job) {
     if (by_tile) {
       const int64_t blocks = job.lead * a.frame_tiles;
       if (blocks > 0x7fffffff) throw Failure("apply: too many frame tiles for one launch");
-      hipLaunchKernelGGL(mel_apply_mfma_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, job.stream, a);
+      SMX_LAUNCH(mel_apply_mfma_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, job.stream, a);
     } else {
       const int64_t blocks = (job.lead * a.frame_tiles + 3) / 4 * a.mel_blocks;
       if (blocks > 0x7fffffff) throw Failure("apply: too many frame tiles for one launch");
-      hipLaunchKernelGGL(mel_apply_mfma_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, job.stream, a);
+      SMX_LAUNCH(mel_apply_mfma_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, job.stream, a);
     }
   } else {
     if (job.lead > 65535) throw Failure("apply: too many leading slices for one launch");
     dim3 grid((unsigned)((job.frames + 255) / 256), (unsigned)job.lead);
     if (job.elem_bytes == 8)
-      hipLaunchKernelGGL(mel_apply_f64_kernel<double>, grid, dim3(256), 0, job.stream, a);
+      SMX_LAUNCH(mel_apply_f64_kernel<double>, grid, dim3(256), 0, job.stream, a);
     else
-      hipLaunchKernelGGL(mel_apply_f64_kernel<float>, grid, dim3(256), 0, job.stream, a);
+      SMX_LAUNCH(mel_apply_f64_kernel<float>, grid, dim3(256), 0, job.stream, a);
   }
   SMX_HIP_CHECK(hipGetLastError());
 }

@@ -226,10 +226,10 @@ void run_to_db(const ToDbJob &job) {
   if (job.has_top_db) {
     SMX_HIP_CHECK(hipMallocAsync((void **)&d_key, sizeof(U), job.stream));
     SMX_HIP_CHECK(hipMemsetAsync(d_key, 0, sizeof(U), job.stream));
-    hipLaunchKernelGGL(db_max_kernel<T>, dim3(blocks), dim3(256), 0, job.stream, (const T *)job.s, job.total, job.magnitude ? 1 : 0, d_key);
+    SMX_LAUNCH(db_max_kernel<T>, dim3(blocks), dim3(256), 0, job.stream, (const T *)job.s, job.total, job.magnitude ? 1 : 0, d_key);
     SMX_HIP_CHECK(hipGetLastError());
   }
-  hipLaunchKernelGGL(to_db_kernel<T>, dim3(blocks), dim3(256), 0, job.stream, (const T *)job.s, (T *)job.out, job.total, (T)job.amin,
+  SMX_LAUNCH(to_db_kernel<T>, dim3(blocks), dim3(256), 0, job.stream, (const T *)job.s, (T *)job.out, job.total, (T)job.amin,
                      (T)scale, (T)offset, job.magnitude ? 1 : 0, (const U *)d_key, (T)job.top_db);
   SMX_HIP_CHECK(hipGetLastError());
   if (d_key) SMX_HIP_CHECK(hipFreeAsync(d_key, job.stream));
@@ -291,9 +291,9 @@ void launch_mfcc(const MfccJob &job) {
   const int64_t total = job.lead * (int64_t)n_mels * job.frames;
   const unsigned blocks = (unsigned)std::min<int64_t>((total + 2047) / 2048, 2048);
   if (job.elem_bytes == 8)
-    hipLaunchKernelGGL(mel_max_kernel<double>, dim3(blocks), dim3(256), 0, job.stream, (const double *)job.mel, total, d_max);
+    SMX_LAUNCH(mel_max_kernel<double>, dim3(blocks), dim3(256), 0, job.stream, (const double *)job.mel, total, d_max);
   else
-    hipLaunchKernelGGL(mel_max_kernel<float>, dim3(blocks), dim3(256), 0, job.stream, (const float *)job.mel, total, d_max);
+    SMX_LAUNCH(mel_max_kernel<float>, dim3(blocks), dim3(256), 0, job.stream, (const float *)job.mel, total, d_max);
   SMX_HIP_CHECK(hipGetLastError());
   if (job.lead > 65535) throw Failure("mfcc: too many leading slices for one launch");
   MfccArgs a{};
@@ -307,8 +307,8 @@ void launch_mfcc(const MfccJob &job) {
   a.n_mels = n_mels;
   a.n_mfcc = n_mfcc;
   dim3 grid((unsigned)((job.frames + 255) / 256), (unsigned)job.lead);
-  if (job.elem_bytes == 8) hipLaunchKernelGGL(mfcc_kernel<double>, grid, dim3(256), 0, job.stream, a);
-  else hipLaunchKernelGGL(mfcc_kernel<float>, grid, dim3(256), 0, job.stream, a);
+  if (job.elem_bytes == 8) SMX_LAUNCH(mfcc_kernel<double>, grid, dim3(256), 0, job.stream, a);
+  else SMX_LAUNCH(mfcc_kernel<float>, grid, dim3(256), 0, job.stream, a);
   SMX_HIP_CHECK(hipGetLastError());
   SMX_HIP_CHECK(hipFreeAsync(d_max, job.stream));
 }

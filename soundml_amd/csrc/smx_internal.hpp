@@ -5,6 +5,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <cstdint>
 #include <map>
@@ -39,6 +40,16 @@ void set_last_error(const std::string &message);
       throw ::smx::Failure(::smx::format("%s: HIP error %d (%s) at %s:%d", #expr,        \
                                          (int)err__, hipGetErrorString(err__), __FILE__, \
                                          __LINE__));                                     \
+  } while (0)
+
+// Every kernel launch of the library goes through SMX_LAUNCH, which counts it: smx_debug_kernel_launches() lets a
+// caller assert how many launches one entry point costs (bench.py: one step of the hot path = ONE launch, so the
+// HIP events around a step are that kernel's duration).
+extern std::atomic<unsigned long long> g_kernel_launches;
+#define SMX_LAUNCH(...)                                                       \
+  do {                                                                        \
+    ::smx::g_kernel_launches.fetch_add(1ull, std::memory_order_relaxed);      \
+    hipLaunchKernelGGL(__VA_ARGS__);                                          \
   } while (0)
 
 // ---- device-resident tables owned by a config, one set per HIP device ------

@@ -145,7 +145,7 @@ void launch_feature(const SpectralArgs &a, hipStream_t stream) {
   constexpr int kTiles = tiles_of<Q>;
   const int64_t blocks = a.lead * ((a.ftiles + kTiles - 1) / kTiles);
   if (blocks > 2147483647LL) throw Failure("spectral: too many frame tiles for one launch");
-  hipLaunchKernelGGL((spectral_kernel<T, FEATURE, Q>), dim3((unsigned)blocks), dim3(64 * Q * kTiles), 0, stream, a);
+  SMX_LAUNCH((spectral_kernel<T, FEATURE, Q>), dim3((unsigned)blocks), dim3(64 * Q * kTiles), 0, stream, a);
   SMX_HIP_CHECK(hipGetLastError());
 }
 
@@ -294,11 +294,11 @@ void launch_chroma(const ChromaJob &job) {
   SMX_HIP_CHECK(hipMallocAsync((void **)&a.raw, (size_t)job.lead * (size_t)c.n_chroma * (size_t)job.frames * sizeof(double),
                                job.stream));
   if (job.elem_bytes == 8) {
-    hipLaunchKernelGGL(chroma_project_kernel<double>, dim3((unsigned)blocks, (unsigned)chunks), dim3(256), 0, job.stream, a);
-    hipLaunchKernelGGL(chroma_normalise_kernel<double>, dim3((unsigned)blocks), dim3(256), 0, job.stream, a);
+    SMX_LAUNCH(chroma_project_kernel<double>, dim3((unsigned)blocks, (unsigned)chunks), dim3(256), 0, job.stream, a);
+    SMX_LAUNCH(chroma_normalise_kernel<double>, dim3((unsigned)blocks), dim3(256), 0, job.stream, a);
   } else {
-    hipLaunchKernelGGL(chroma_project_kernel<float>, dim3((unsigned)blocks, (unsigned)chunks), dim3(256), 0, job.stream, a);
-    hipLaunchKernelGGL(chroma_normalise_kernel<float>, dim3((unsigned)blocks), dim3(256), 0, job.stream, a);
+    SMX_LAUNCH(chroma_project_kernel<float>, dim3((unsigned)blocks, (unsigned)chunks), dim3(256), 0, job.stream, a);
+    SMX_LAUNCH(chroma_normalise_kernel<float>, dim3((unsigned)blocks), dim3(256), 0, job.stream, a);
   }
   SMX_HIP_CHECK(hipGetLastError());
   SMX_HIP_CHECK(hipFreeAsync(a.raw, job.stream));

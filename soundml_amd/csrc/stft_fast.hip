@@ -1288,7 +1288,7 @@ void launch_interior(const StftJob &job, const FastTarget &tg, const float *x, i
     auto kernel = strip ? pick(std::true_type{}) : pick(std::false_type{});
     SMX_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kernel),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)kFastLds));
-    hipLaunchKernelGGL(kernel, dim3((unsigned)a.blocks), dim3(1024), kFastLds, job.stream, a, m);
+    SMX_LAUNCH(kernel, dim3((unsigned)a.blocks), dim3(1024), kFastLds, job.stream, a, m);
     SMX_HIP_CHECK(hipGetLastError());
     return;
   }
@@ -1297,7 +1297,7 @@ void launch_interior(const StftJob &job, const FastTarget &tg, const float *x, i
                         : (aligned ? stft2048_complex_kernel<true, false> : stft2048_complex_kernel<false, false>);
     SMX_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kernel),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)kFastLds));
-    hipLaunchKernelGGL(kernel, dim3((unsigned)a.blocks), dim3(1024), kFastLds, job.stream, a);
+    SMX_LAUNCH(kernel, dim3((unsigned)a.blocks), dim3(1024), kFastLds, job.stream, a);
     SMX_HIP_CHECK(hipGetLastError());
     return;
   }
@@ -1324,7 +1324,7 @@ void launch_interior(const StftJob &job, const FastTarget &tg, const float *x, i
 #endif
   SMX_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kernel),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)kFastLds));
-  hipLaunchKernelGGL(kernel, dim3((unsigned)a.blocks), dim3(1024), kFastLds, job.stream, a);
+  SMX_LAUNCH(kernel, dim3((unsigned)a.blocks), dim3(1024), kFastLds, job.stream, a);
   SMX_HIP_CHECK(hipGetLastError());
 }
 
@@ -1338,7 +1338,7 @@ void launch_border(const StftJob &job, const FastTarget &tg, int64_t pa, int64_t
   float *strip = nullptr;
   SMX_HIP_CHECK(hipMallocAsync((void **)&strip, (size_t)job.lead * (size_t)stride * sizeof(float), job.stream));
   dim3 grid((unsigned)((len + 255) / 256 < 64 ? (len + 255) / 256 : 64), (unsigned)job.lead);
-  hipLaunchKernelGGL(gather_padded_kernel, grid, dim3(256), 0, job.stream,
+  SMX_LAUNCH(gather_padded_kernel, grid, dim3(256), 0, job.stream,
                      reinterpret_cast<const float *>(job.x), job.n, job.x_stride, pos0, len, job.pad,
                      (float)job.pad_value, strip, stride);
   SMX_HIP_CHECK(hipGetLastError());
@@ -1526,10 +1526,12 @@ const smx::MelFusedPlan &smx_mel_config::fused_plan() const {
   }
   for (const auto &it : items)
     if (it.k4_count > kMelMaxSteps) return plan;   // the A operands of an item must fit its wave's registers
-  if (std::getenv("SMX_MEL_ONESTEP"))  // diagnostic: one MFMA step per item (wrong results): the cost of the protocol alone
+#ifdef SMX_DIAG   // result-altering timing switches exist in diagnostic builds only (make DIAG=1)
+  if (std::getenv("SMX_MEL_ONESTEP"))  // one MFMA step per item (wrong results): the cost of the protocol alone
     for (auto &it : items) it.k4_count = it.k4_count > 0 ? 1 : 0;
-  if (std::getenv("SMX_MEL_NOMFMA"))   // diagnostic: plan without MFMA work (results are zeros)
+  if (std::getenv("SMX_MEL_NOMFMA"))   // plan without MFMA work (results are zeros)
     for (auto &it : items) it.k4_count = 0;
+#endif
   wm.resize(wm.size() + 64 * (size_t)kMelMaxSteps, 0.0f);   // every item can be read kMelMaxSteps rows deep
   SMX_HIP_CHECK(hipMalloc(&plan.items, items.size() * sizeof(MelItem)));
   SMX_HIP_CHECK(hipMemcpy(plan.items, items.data(), items.size() * sizeof(MelItem), hipMemcpyHostToDevice));

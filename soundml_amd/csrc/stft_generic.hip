@@ -332,7 +332,7 @@ bool launch_stockham(const StftJob &job, GenericArgs a) {
   const size_t lds = a.direct ? work : work + stage_bytes(ft);
   auto kernel = stft_stockham_kernel<LOG2N, float>;
   SMX_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  hipLaunchKernelGGL(kernel, dim3((unsigned)blocks), dim3(THREADS), lds, job.stream, a);
+  SMX_LAUNCH(kernel, dim3((unsigned)blocks), dim3(THREADS), lds, job.stream, a);
   SMX_HIP_CHECK(hipGetLastError());
   return true;
 }
@@ -479,7 +479,7 @@ bool launch_stockham_real(const StftJob &job, GenericArgs a, const StftTables &t
   const size_t lds = a.direct ? work : work + stage_bytes(ft);
   auto kernel = stft_stockham_real_kernel<LOG2N, Tin, S, Tout>;
   SMX_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  hipLaunchKernelGGL(kernel, dim3((unsigned)blocks), dim3(THREADS), lds, job.stream, a, (const V *)tw_m, (const V *)tw_n);
+  SMX_LAUNCH(kernel, dim3((unsigned)blocks), dim3(THREADS), lds, job.stream, a, (const V *)tw_m, (const V *)tw_n);
   SMX_HIP_CHECK(hipGetLastError());
   return true;
 }
@@ -789,7 +789,7 @@ bool launch_stockham_power16(const StftJob &job, GenericArgs a, const StftTables
       const size_t lds_mel = lds + (size_t)(THREADS / 64) * 1024;   // the helper waves' partial tiles (columns_out)
       auto kernel = stft_stockham_power16_kernel<LOG2N, float, true, 16>;
       SMX_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_mel));
-      hipLaunchKernelGGL(kernel, dim3((unsigned)blocks), dim3(THREADS), lds_mel, job.stream, a, (const float2 *)t.fast_w_m,
+      SMX_LAUNCH(kernel, dim3((unsigned)blocks), dim3(THREADS), lds_mel, job.stream, a, (const float2 *)t.fast_w_m,
                          (const float2 *)t.fast_w_n, *mel);
       SMX_HIP_CHECK(hipGetLastError());
       return true;
@@ -798,7 +798,7 @@ bool launch_stockham_power16(const StftJob &job, GenericArgs a, const StftTables
   if (mel) return false;
   auto kernel = stft_stockham_power16_kernel<LOG2N, float, false, FT>;
   SMX_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  hipLaunchKernelGGL(kernel, dim3((unsigned)blocks), dim3(THREADS), lds, job.stream, a, (const float2 *)t.fast_w_m,
+  SMX_LAUNCH(kernel, dim3((unsigned)blocks), dim3(THREADS), lds, job.stream, a, (const float2 *)t.fast_w_m,
                      (const float2 *)t.fast_w_n, MelTail{});
   SMX_HIP_CHECK(hipGetLastError());
   return true;
@@ -936,7 +936,7 @@ bool launch_stockham_complex16(const StftJob &job, GenericArgs a, const StftTabl
   const size_t lds = (size_t)16 * M * sizeof(float2);
   auto kernel = stft_stockham_complex16_kernel<LOG2N, float>;
   SMX_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  hipLaunchKernelGGL(kernel, dim3((unsigned)blocks), dim3(M), lds, job.stream, a, (const float2 *)t.fast_w_m, (const float2 *)t.fast_w_n);
+  SMX_LAUNCH(kernel, dim3((unsigned)blocks), dim3(M), lds, job.stream, a, (const float2 *)t.fast_w_m, (const float2 *)t.fast_w_n);
   SMX_HIP_CHECK(hipGetLastError());
   return true;
 }
@@ -953,7 +953,7 @@ bool launch_stockham_complex16_wide(const StftJob &job, GenericArgs a, const Stf
   const size_t lds = (size_t)FT * M * sizeof(double2);
   auto kernel = stft_stockham_complex16_kernel<LOG2N, Tio, FT, double, Tio>;
   SMX_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  hipLaunchKernelGGL(kernel, dim3((unsigned)blocks), dim3(THREADS), lds, job.stream, a, (const double2 *)t.fast_w_m_f64,
+  SMX_LAUNCH(kernel, dim3((unsigned)blocks), dim3(THREADS), lds, job.stream, a, (const double2 *)t.fast_w_m_f64,
                      (const double2 *)t.twiddle_f64);
   SMX_HIP_CHECK(hipGetLastError());
   return true;
@@ -983,7 +983,7 @@ bool launch_stockham_power16_wide(const StftJob &job, GenericArgs a, const StftT
   const size_t lds = (size_t)FT * M * sizeof(double2);
   auto kernel = stft_stockham_power16_kernel<LOG2N, Tio, false, FT, double, Tio>;
   SMX_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  hipLaunchKernelGGL(kernel, dim3((unsigned)blocks), dim3(THREADS), lds, job.stream, a, (const double2 *)t.fast_w_m_f64,
+  SMX_LAUNCH(kernel, dim3((unsigned)blocks), dim3(THREADS), lds, job.stream, a, (const double2 *)t.fast_w_m_f64,
                      (const double2 *)t.twiddle_f64, MelTail{});
   SMX_HIP_CHECK(hipGetLastError());
   return true;
@@ -1294,11 +1294,11 @@ bool launch_bluestein_power16(const StftJob &job, GenericArgs a, const StftTable
     const size_t lds_mel = lds + (size_t)(M / 64) * 1024;   // the helper waves' partial tiles (columns_out)
     auto kernel = stft_bluestein_power16_kernel<LOG2M, float, true>;
     SMX_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_mel));
-    hipLaunchKernelGGL(kernel, dim3((unsigned)blocks), dim3(M), lds_mel, job.stream, a, b, *mel);
+    SMX_LAUNCH(kernel, dim3((unsigned)blocks), dim3(M), lds_mel, job.stream, a, b, *mel);
   } else {
     auto kernel = stft_bluestein_power16_kernel<LOG2M, float, false>;
     SMX_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(kernel, dim3((unsigned)blocks), dim3(M), lds, job.stream, a, b, MelTail{});
+    SMX_LAUNCH(kernel, dim3((unsigned)blocks), dim3(M), lds, job.stream, a, b, MelTail{});
   }
   SMX_HIP_CHECK(hipGetLastError());
   return true;
@@ -1333,7 +1333,7 @@ bool launch_bluestein_real(const StftJob &job, GenericArgs a, const StftTables &
   const size_t lds = a.direct ? work : work + stage_bytes(ft);
   auto kernel = stft_bluestein_real_kernel<LOG2M, float>;
   SMX_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  hipLaunchKernelGGL(kernel, dim3((unsigned)blocks), dim3(THREADS), lds, job.stream, a, b);
+  SMX_LAUNCH(kernel, dim3((unsigned)blocks), dim3(THREADS), lds, job.stream, a, b);
   SMX_HIP_CHECK(hipGetLastError());
   return true;
 }
@@ -1355,7 +1355,7 @@ bool launch_bluestein(const StftJob &job, GenericArgs a, const BluArgs &b) {
   const size_t lds = a.direct ? work : work + stage_bytes(ft);
   auto kernel = stft_bluestein_kernel<LOG2M, float>;
   SMX_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  hipLaunchKernelGGL(kernel, dim3((unsigned)blocks), dim3(THREADS), lds, job.stream, a, b);
+  SMX_LAUNCH(kernel, dim3((unsigned)blocks), dim3(THREADS), lds, job.stream, a, b);
   SMX_HIP_CHECK(hipGetLastError());
   return true;
 }
@@ -1389,7 +1389,7 @@ void launch_typed(const StftJob &job, GenericArgs a) {
   auto kernel = use_pow2 ? stft_generic_kernel<Tin, Tacc, Tout, true> : stft_generic_kernel<Tin, Tacc, Tout, false>;
   SMX_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kernel),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  hipLaunchKernelGGL(kernel, dim3((unsigned)blocks), dim3(256), lds, job.stream, a);
+  SMX_LAUNCH(kernel, dim3((unsigned)blocks), dim3(256), lds, job.stream, a);
   SMX_HIP_CHECK(hipGetLastError());
 }
 
@@ -1429,8 +1429,10 @@ bool launch_mel_spectrogram_16(const MelSpecJob &job) {
   mt.band_lo = mtab.tile_lo;
   mt.band_hi = mtab.tile_hi;
   mt.n_mels = (int)job.mel->n_mels;
-  if (const char *e = std::getenv("SMX_MEL16_NOTAIL"))   // diagnostic (timing only): the kernel without its MFMA tail
+#ifdef SMX_DIAG   // result-altering timing switch: diagnostic builds only (make DIAG=1)
+  if (const char *e = std::getenv("SMX_MEL16_NOTAIL"))   // the kernel without its MFMA tail
     if (e[0] == '1') mt.n_mels = 0;
+#endif
   mt.k_pad = (int)mtab.k_pad;
   mt.out = reinterpret_cast<float *>(job.out);
   if (chirp_16) return launch_bluestein16_any(sj, a, t, &mt);

@@ -63,3 +63,28 @@ def test_two_ranks_gloo(tmp_path):
     world = 2
     mp.spawn(_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
     assert all((tmp_path / ("ok%d" % r)).exists() for r in range(world))
+
+
+def test_bench_launcher_starts_the_ranks(tmp_path):
+    """`python bench.py --gpus 2` (no RANK in the environment: the driver's command) must itself start two rank
+    processes with RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set and a 127.0.0.1 rendezvous, forward rank 0's one
+    JSON line and return the worst child status.  `--dry-run` stops each rank before any GPU call (gloo barrier and
+    MAX-reduce only), so the plumbing is covered on CPU; the product path of two ranks runs in
+    tests/test_gpu_baseline_configs.py::test_bench_two_ranks_one_box."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--dry-run"], capture_output=True,
+                         text=True, timeout=600, env=env)
+    assert out.returncode == 0, out.stdout + out.stderr
+    line = json.loads(out.stdout.strip().splitlines()[-1])
+    assert line["n_gpus"] == 2 and line["max_clock"] == 2.0 and line["rank0_clips"] == [0, 2048]
+    assert line["master"] == "127.0.0.1"
+    # a failing rank is a failing run (here: no HIP device in this container -> every rank exits non-zero)
+    import torch
+    if not torch.cuda.is_available():
+        bad = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1"], capture_output=True,
+                             text=True, timeout=600, env=env)
+        assert bad.returncode != 0
