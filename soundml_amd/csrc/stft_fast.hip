@@ -111,10 +111,6 @@ __device__ __forceinline__ void store4_unaligned(float *base /* wave-uniform */,
   asm volatile("global_store_dwordx4 %0, %1, %2\n\ts_nop 1" : : "v"(byte_off), "v"(v), "s"(base) : "memory");
 }
 
-__device__ __forceinline__ float bperm(int byte_addr, float v) {
-  return __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(byte_addr, __builtin_bit_cast(int, v)));
-}
-
 constexpr int kN = 2048, kM = 1024, kBins = 1025;
 
 struct FastArgs {
@@ -140,6 +136,7 @@ struct FastArgs {
   int interleave;       // power kernel: workgroups of an XCD share a chunk of the sequence tile by tile
   int pmode;            // 2: power 2, 1: power 1, 0: general
   int abl_nostore;      // diagnostic builds only
+  int abl_noskew;       // diagnostic builds only (ring kernel: rows not moved to their 64-byte boundaries)
   float half_power;
 };
 
@@ -275,12 +272,25 @@ __device__ __forceinline__ void flush_part(const FastArgs &a, const float *tile,
 #define SMX_ABL(n) false
 #endif
 
+// Where one frame's results go in the LDS tile(s), per lane.  Register q of a lane belongs to tile row
+// tile_row0 + 64 q, so its cell is own + kCellStep q.  Before the results are written, the same cells carry the
+// post-pass exchange: a lane parks Z[k] there and reads Z[M - k] out of its partner lane's cells (same wave, and
+// the LDS executes one wave's operations in order) -- see step P of frame_to_tile.
+constexpr int kCellStep = 64 * (kFT + 1);   // floats between the cells of registers q and q + 1
+struct Cells {
+  float *own;         // cell of register 0
+  const float *pg;    // partner lane's cell of ITS register 0 (one register further for the k1 = 0 lanes, whose
+                      // register q pairs with register 16 - q): register q >= 1 reads pg + kCellStep (15 - q)
+  const float *p0;    // the cell register 0 pairs with (k1 = 0 lanes: register 0 of lane bitrev2((4 - r) & 3))
+  float *nyq;         // lane 0: where the frame's Nyquist bin goes
+};
+
 // Per-lane constants of the frame pipeline (see the header comment for the digit layout).
 struct LaneConst {
   int k1, qa, r;
   float s12, kap1, kap2;    // quad radix-4: sign folded into the data, butterfly multipliers
   bool rot, low4;
-  int addr_g, addr_0;       // ds_bpermute byte addresses of the post-pass partner lane
+  int prow_g, prow_0;       // tile rows of the post-pass partners: of register q >= 1 (prow_g + 64 (15 - q)) and of register 0
   int tile_row0;            // tile row of register q is tile_row0 + 64 q
   const float2 *tabA_l, *winL_l, *tabP_l, *tabB_l;
   const float2 *tabP_g;     // the same twiddles in global memory: exp(-2 pi i k / N), k = k1 + 256 r + 16 q
@@ -300,6 +310,9 @@ __device__ __forceinline__ Lds carve_lds(unsigned char *smem) {
   l.winL = reinterpret_cast<float2 *>(smem + 2 * kTileBytes + kTabABytes + kTabPBytes + kTabBBytes);
   return l;
 }
+
+// The cells of the frame that owns column `wave` of `tile` (the unskewed kernels: complex, mel, border frames).
+__device__ __forceinline__ Cells cells_of_column(const LaneConst &L, float *tile, int wave);
 
 // Fills the workgroup-shared LDS tables (wave w writes row w of each) and returns this lane's constants.
 // The caller must __syncthreads() before the tables are read.
@@ -331,16 +344,28 @@ __device__ __forceinline__ LaneConst setup_lane(const FastArgs &a, const Lds &ld
   L.kap1 = -s1;
   L.kap2 = -s2;
   L.rot = L.qa == 3;
-  if (lane >= 4) {
-    L.addr_g = L.addr_0 = (67 - lane) * 4;
-  } else {
-    L.addr_g = (3 - lane) * 4;
-    const int r0 = (4 - L.r) & 3;                            // partner r for q = 0
-    L.addr_0 = ((((r0 & 1) << 1) | (r0 >> 1))) * 4;          // its lane = bitrev2(r0)
-  }
   L.low4 = lane < 4;
   L.tile_row0 = 4 * L.k1 + L.r;                              // row' = 4 (k1 + 16 q) + r
+  // partner of bin k = k1 + 16 q + 256 r is M - k: lane 67 - l, register 15 - q  (k1' = 16 - k1, r' = 3 - r);
+  // in the k1 = 0 column: register 16 - q of the lane with r' = 3 - r, and for q = 0 register 0 of r' = (4 - r) & 3
+  if (lane >= 4) {
+    L.prow_g = 4 * (16 - L.k1) + (3 - L.r);
+    L.prow_0 = L.prow_g + 64 * 15;
+  } else {
+    L.prow_g = (3 - L.r) + 64;
+    L.prow_0 = (4 - L.r) & 3;
+  }
   return L;
+}
+
+__device__ __forceinline__ Cells cells_of_column(const LaneConst &L, float *tile, int wave) {
+  Cells c;
+  float *col = tile + wave;
+  c.own = col + L.tile_row0 * kTileStride;
+  c.pg = col + L.prow_g * kTileStride;
+  c.p0 = col + L.prow_0 * kTileStride;
+  c.nyq = tile + nyquist_row(wave) * kTileStride + kFT;
+  return c;
 }
 
 // Persistent workgroups: block b owns a contiguous range of the flat (clip, tile) sequence.
@@ -428,7 +453,8 @@ struct TileWalk {
 };
 
 // One frame: raw samples (registers) -> window -> FFT(1024 complex) -> real post-pass -> |X|^p
-// written as column `wave` of `tile`.  `hook.at<P>()` is called at 16 points between the stages;
+// written to the frame's cells in the LDS tile (`cells`; for the unskewed kernels column `wave` of a tile:
+// cells_of_column).  `hook.at<P>()` is called at 16 points between the stages;
 // the power kernel uses them to trickle out the previous tile's stores.
 // PRE: each twiddle table is read from LDS one stage before it is used (30 more live registers),
 // so its latency -- long when 16 waves queue on the LDS pipe -- hides behind the stage in between.
@@ -437,7 +463,7 @@ struct TileWalk {
 //        for the kernel that uses the LDS space of that table for something else (mel).
 template <bool SQUARE, bool PRE, bool CPLX, bool TABPG SMX_ABL_PARAM, class Hook>
 __device__ __forceinline__ void frame_to_tile(const FastArgs &a, const LaneConst &L, float2 (&raw)[16],
-                                              float *tile, int wave, int lane, const Hook &hook) {
+                                              Cells cells, int lane, const Hook &hook) {
   c32 v[16];
   float2 win[16], tw[16];
 #pragma unroll
@@ -449,9 +475,10 @@ __device__ __forceinline__ void frame_to_tile(const FastArgs &a, const LaneConst
 #pragma unroll
   for (int j = 0; j < 16; ++j) v[j] = {raw[j].x * win[j].x, raw[j].y * win[j].y};
   if constexpr (SMX_ABL(6) || SMX_ABL(9)) {   // timing-only: memory traffic and synchronisation without the FFT (9: no loads either)
-    hook.ready();
+    hook.template at<0>(); hook.template at<2>(); hook.template at<5>(); hook.template at<8>(); hook.template at<11>();
+    hook.ready(cells);
 #pragma unroll
-    for (int q = 0; q < 16; ++q) (tile + wave)[(L.tile_row0 + 64 * q) * kTileStride] = v[q].x + v[q].y;
+    for (int q = 0; q < 16; ++q) cells.own[kCellStep * q] = v[q].x + v[q].y;
     return;
   }
   hook.template at<0>();
@@ -480,9 +507,9 @@ __device__ __forceinline__ void frame_to_tile(const FastArgs &a, const LaneConst
     float re[16], im[16];
 #pragma unroll
     for (int k = 0; k < 16; ++k) { re[k] = v[k].x; im[k] = v[k].y; }
-    if constexpr (!SMX_ABL(5)) transpose16(re);
+    if constexpr (!SMX_ABL(5) && !SMX_ABL(11)) transpose16(re);
     hook.template at<4>();
-    if constexpr (!SMX_ABL(5)) transpose16(im);
+    if constexpr (!SMX_ABL(5) && !SMX_ABL(11)) transpose16(im);
 #pragma unroll
     for (int k = 0; k < 16; ++k) v[k] = {re[k], im[k]};
   }
@@ -528,60 +555,60 @@ __device__ __forceinline__ void frame_to_tile(const FastArgs &a, const LaneConst
   SMX_FMAC_DPP8("[1,0,3,2]", v + 8, L.kap2);
   hook.template at<10>();
   SMX_FENCE();
-  // P: real-FFT post-pass.  provider rotation for the k1 = 0 lanes.
-  hook.ready();
-  float *col = tile + wave;
+  // P: real-FFT post-pass X[k] = E - i w_k D, E = Z[k] + conj Z[M-k], D = Z[k] - conj Z[M-k] (the 1/2 is in the
+  // window).  Z[M-k] sits in another lane (67 - l, register 15 - q).  The exchange goes through the frame's own
+  // cells of the tile, which are free from here on: every lane parks its 16 real parts, reads its partners',
+  // then the same with the imaginary parts -- 64 plain LDS accesses (2-4 cycles of the LDS pipe each) where
+  // 32 ds_bpermute_b32 (~24 cycles each) were the single largest load on that pipe.  One wave's LDS operations
+  // execute in order, so no wait separates the rounds.
+  hook.ready(cells);   // waits until the frame's cells are free; the ring kernel derives them here
   const float nyq = 2.0f * (v[0].x - v[0].y);   // X[M] = Re Z0 - Im Z0 (true scale), lane 0
-  auto partner = [&](int q, float &px, float &py) {   // Z[M - k] of register q's bin k
-    const int addr = q == 0 ? L.addr_0 : L.addr_g;
-    const int m = 15 - q;
-    const float sx = L.low4 ? v[(m + 1) & 15].x : v[m].x;
-    const float sy = L.low4 ? v[(m + 1) & 15].y : v[m].y;
-    px = SMX_ABL(4) ? sx : bperm(addr, sx);
-    py = SMX_ABL(4) ? sy : bperm(addr, sy);
-  };
-  auto finish_bin = [&](int q, float px, float py, float2 w) {
-    const c32 e = {v[q].x + px, v[q].y - py};
-    const c32 d = {v[q].x - px, v[q].y + py};
-    const float tr = e.x + w.x * d.y + w.y * d.x;
-    const float ti = e.y - w.x * d.x + w.y * d.y;
-    if constexpr (CPLX) {
-      col[(L.tile_row0 + 64 * q) * kTileStride] = tr;
-      col[(L.tile_row0 + 64 * q) * kTileStride + kTileBytes / sizeof(float)] = ti;
-    } else {
-      float pw = tr * tr + ti * ti;
-      if constexpr (!SQUARE) pw = a.pmode == 1 ? sqrtf(pw) : __powf(pw, a.half_power);
-      col[(L.tile_row0 + 64 * q) * kTileStride] = pw;
-    }
-  };
-  if constexpr (PRE) {
-    // all 32 lane exchanges in flight before the first result is needed
-    float px[16], py[16];
+  float px[16], py[16];
+  constexpr int kPlane = kTileBytes / sizeof(float);   // CPLX: the imaginary plane
+  if constexpr (SMX_ABL(4)) {   // timing-only: no exchange
 #pragma unroll
-    for (int q = 0; q < 16; ++q) partner(q, px[q], py[q]);
-    SMX_FENCE();
+    for (int q = 0; q < 16; ++q) { px[q] = v[15 - q].x; py[q] = v[15 - q].y; }
+  } else if constexpr (CPLX) {   // both planes are this tile's: one round
+#pragma unroll
+    for (int q = 0; q < 16; ++q) { cells.own[kCellStep * q] = v[q].x; cells.own[kCellStep * q + kPlane] = v[q].y; }
 #pragma unroll
     for (int q = 0; q < 16; ++q) {
-      finish_bin(q, px[q], py[q], tw[q]);
-      if (q == 3) hook.template at<11>();
-      if (q == 7) hook.template at<12>();
-      if (q == 11) hook.template at<13>();
-      if (q == 15) { hook.template at<14>(); hook.template at<15>(); }
+      const float *src = q == 0 ? cells.p0 : cells.pg + kCellStep * (15 - q);
+      px[q] = src[0];
+      py[q] = src[kPlane];
     }
   } else {
 #pragma unroll
-    for (int q = 0; q < 16; ++q) {
-      float px, py;
-      partner(q, px, py);
-      finish_bin(q, px, py, TABPG ? tw[q] : L.tabP_l[64 * q]);
-      if ((q & 3) == 3) {
-        SMX_FENCE();
-        if (q == 3) hook.template at<11>();
-        if (q == 7) hook.template at<12>();
-        if (q == 11) hook.template at<13>();
-        if (q == 15) { hook.template at<14>(); hook.template at<15>(); }
-      }
+    for (int q = 0; q < 16; ++q) cells.own[kCellStep * q] = v[q].x;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) px[q] = q == 0 ? cells.p0[0] : cells.pg[kCellStep * (15 - q)];
+#pragma unroll
+    for (int q = 0; q < 16; ++q) cells.own[kCellStep * q] = v[q].y;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) py[q] = q == 0 ? cells.p0[0] : cells.pg[kCellStep * (15 - q)];
+  }
+  SMX_FENCE();
+  auto finish_bin = [&](int q, float2 w) {
+    const c32 e = {v[q].x + px[q], v[q].y - py[q]};
+    const c32 d = {v[q].x - px[q], v[q].y + py[q]};
+    const float tr = e.x + w.x * d.y + w.y * d.x;
+    const float ti = e.y - w.x * d.x + w.y * d.y;
+    if constexpr (CPLX) {
+      cells.own[kCellStep * q] = tr;
+      cells.own[kCellStep * q + kPlane] = ti;
+    } else {
+      float pw = tr * tr + ti * ti;
+      if constexpr (!SQUARE) pw = a.pmode == 1 ? sqrtf(pw) : __powf(pw, a.half_power);
+      cells.own[kCellStep * q] = pw;
     }
+  };
+#pragma unroll
+  for (int q = 0; q < 16; ++q) {
+    finish_bin(q, (PRE || TABPG) ? tw[q] : L.tabP_l[64 * q]);
+    if (q == 3) hook.template at<11>();
+    if (q == 7) hook.template at<12>();
+    if (q == 11) hook.template at<13>();
+    if (q == 15) { hook.template at<14>(); hook.template at<15>(); }
   }
   if (lane == 0) {
     float pw = nyq;                       // CPLX: X[M] is real
@@ -589,7 +616,7 @@ __device__ __forceinline__ void frame_to_tile(const FastArgs &a, const LaneConst
       pw = nyq * nyq;
       if constexpr (!SQUARE) pw = a.pmode == 1 ? fabsf(nyq) : __powf(pw, a.half_power);
     }
-    tile[nyquist_row(wave) * kTileStride + kFT] = pw;   // Nyquist bin of frame `wave`: a pad slot
+    *cells.nyq = pw;   // Nyquist bin of this frame: a pad slot
   }
 }
 
@@ -598,6 +625,12 @@ __device__ __forceinline__ void prefetch_frame(const FastArgs &a, const float *s
   if constexpr (SMX_ABL(2) || SMX_ABL(3) || SMX_ABL(9)) {
 #pragma unroll
     for (int j = 0; j < 16; ++j) raw[j] = make_float2((float)(lane + j) + raw[j].x * 0.0f, (float)(lane - j));
+  } else if constexpr (SMX_ABL(10) || SMX_ABL(11)) {   // timing-only: 4 of the 16 loads (what re-using the 75 % overlap of consecutive frames would leave)
+    const float2 *b = reinterpret_cast<const float2 *>(src);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) raw[j] = b[(unsigned)lane + 64u * j];
+#pragma unroll
+    for (int j = 4; j < 16; ++j) raw[j] = make_float2(raw[j & 3].x + (float)j, raw[j & 3].y - (float)j);
   } else {
     load_frame<ALIGNED>(src, lane, raw);
   }
@@ -617,19 +650,25 @@ __device__ __forceinline__ void prefetch_frame(const FastArgs &a, const float *s
 struct Counters {
   unsigned *filled, *drained;   // [2] each, in the unused q = 0 row of the W_64 table
 };
+#ifndef SMX_WAIT_SLEEP
+#define SMX_WAIT_SLEEP 2
+#endif
+#ifndef SMX_RING_PRIO
+#define SMX_RING_PRIO 0
+#endif
 __device__ __forceinline__ void lds_signal(unsigned *c, int lane) {
   if (lane == 0) __hip_atomic_fetch_add(c, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
 __device__ __forceinline__ void lds_wait(unsigned *c, unsigned target) {
   while ((unsigned)__builtin_amdgcn_readfirstlane(
              (int)__hip_atomic_load(c, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP)) < target)
-    __builtin_amdgcn_s_sleep(2);
+    __builtin_amdgcn_s_sleep(SMX_WAIT_SLEEP);
 }
 
 struct NoHook {
   template <int P>
   __device__ __forceinline__ void at() const {}
-  __device__ __forceinline__ void ready() const {}
+  __device__ __forceinline__ void ready(Cells &) const {}
 };
 
 struct SyncHook {
@@ -639,7 +678,7 @@ struct SyncHook {
   unsigned long long *stamp_sum, *stamp_prev_p;
 #endif
   // the tile buffer about to be written has been read out by every wave
-  __device__ __forceinline__ void ready() const { lds_wait(drained, target); }
+  __device__ __forceinline__ void ready(Cells &) const { lds_wait(drained, target); }
   template <int P>
   __device__ __forceinline__ void at() const {
 #ifdef SMX_STAMPS
@@ -723,7 +762,7 @@ __global__ void __launch_bounds__(1024) stft2048_power_kernel(FastArgs a) {
 #else
       const SyncHook hook{cnt.drained + b, 16u * ((unsigned)it >> 1)};
 #endif
-      frame_to_tile<SQUARE, kPre, false, false SMX_ABL_ARG>(a, L, raw, lds.tiles + b * kTileFloats, wave, lane, hook);
+      frame_to_tile<SQUARE, kPre, false, false SMX_ABL_ARG>(a, L, raw, cells_of_column(L, lds.tiles + b * kTileFloats, wave), lane, hook);
     }
     lds_signal(cnt.filled + b, lane);
     SMX_STAMP(17);
@@ -776,7 +815,7 @@ __global__ void __launch_bounds__(1024) stft2048_power_kernel(FastArgs a) {
         // the same PRE variant as the interior loop: with another instantiation the compiler contracts a few
         // multiply-adds differently and a border frame would differ in the last bit from the same frame computed as
         // an interior one (the streaming faces compute every frame as interior: partition law, stft_law.ml:79-164)
-        frame_to_tile<SQUARE, SMX_EPILOGUE_PRE, false, false SMX_ABL_ZERO>(a, L, braw, bt_tile, wave, lane, NoHook{});
+        frame_to_tile<SQUARE, SMX_EPILOGUE_PRE, false, false SMX_ABL_ZERO>(a, L, braw, cells_of_column(L, bt_tile, wave), lane, NoHook{});
       }
       __syncthreads();
       for (int e = tid; e < kBins * kFT; e += 1024) {
@@ -796,6 +835,254 @@ __global__ void __launch_bounds__(1024) stft2048_power_kernel(FastArgs a) {
   if (lane == 0 && blockIdx.x < 4096)
     for (int i = 0; i < kStampSlots; ++i) g_stamp_sums[(blockIdx.x * 16 + wave) * kStampSlots + i] = stamp_sum[i];
 #endif
+}
+
+// ---- power spectrogram kernel, ring form ----------------------------------------------------------------------
+// The same frame pipeline; what changes is where the results wait in LDS and how they leave.
+//   * A workgroup walks a CONTIGUOUS range of the flat (clip, tile) sequence, i.e. consecutive tiles of one clip.
+//   * The two tile buffers form a ring of 32 frame positions per bin row.  Frame o of the segment goes to ring
+//     position (o + A_k) mod 32 of row k, where A_k = (address of out[clip][k][first frame] / 4) mod 16 is the row's
+//     own misalignment.  A block of 16 ring positions is therefore exactly one 64-byte-ALIGNED run of the output
+//     row: every full store is one whole 64-byte block, whatever the row pitch (3752 bytes at C2: only one row in
+//     eight starts on a 64-byte boundary, and an unaligned run costs two partial blocks -- 1.33x write traffic
+//     and the read-modify-writes behind it, profiles/r03/pmc.json).
+//     16 q pitch = 0 (mod 16 floats), so A_k is ONE value per lane for its 16 rows: the skew costs nothing per bin.
+//   * Block j (ring positions 16 j .. 16 j + 15) is complete once tile j is in, holds the last A_k frames of tile
+//     j - 1 and the first 16 - A_k of tile j, lives in buffer j & 1, and is stored while tile j + 1 is computed
+//     (at hook point kRingFlushAt of that frame).  The first block of a segment is masked below A_k, the last
+//     ones above the segment's end; those few partial runs use element stores.
+// Synchronisation: the monotonic LDS counters of the kernel above; a segment (the tiles of one clip in the range)
+// ends with its last two blocks flushed and a workgroup barrier.
+#ifndef SMX_RING_FLUSH_AT
+#define SMX_RING_FLUSH_AT 2
+#endif
+
+struct RingSeg {            // wave-uniform
+  const float *x0;          // first sample of the segment's first frame
+  char *S;                  // 64-byte-aligned address at or below out[clip][0][first frame of the segment]
+  unsigned d;               // bytes from S to that element (0 .. 60)
+  int nfr, tiles;           // frames and tiles (of 16) in the segment
+};
+
+// A lane's value that the optimiser must re-derive where it is used instead of carrying it in a register across the
+// FFT (the frame pipeline needs 120+ of the 128 registers a 16-wave workgroup allows): the asm pins the computation
+// behind it to this point of the program.
+__device__ __forceinline__ int opaque(int v) {
+  asm volatile("" : "+v"(v));
+  return v;
+}
+
+template <int FLUSH_AT, class Flush, class Ready>
+struct RingHook {
+  const Flush &flush;
+  const Ready &ready_fn;
+  template <int P>
+  __device__ __forceinline__ void at() const {
+    if constexpr (P == FLUSH_AT) flush();
+  }
+  __device__ __forceinline__ void ready(Cells &c) const { ready_fn(c); }
+};
+
+template <bool ALIGNED, bool SQUARE, bool STRIP, int FLUSH_AT SMX_ABL_PARAM>
+__global__ void __launch_bounds__(1024) stft2048_power_ring_kernel(FastArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const Lds lds = carve_lds(smem);
+  const LaneConst L = setup_lane(a, lds, tid, lane, wave);
+  unsigned *const c_filled = reinterpret_cast<unsigned *>(lds.tabB), *const c_drained = c_filled + 2;
+  constexpr int kTileFloats = kTileBytes / sizeof(float);
+  int64_t tau, tau_end;
+  block_to_range(a, tau, tau_end);
+  const unsigned pitch4 = (unsigned)a.out_stride * 4u;
+
+  auto seg_at = [&](int64_t t0) {   // the clip-contiguous run of this workgroup's tiles that starts at flat tile t0
+    RingSeg sg;
+    const int64_t clip = t0 / a.tiles_per_clip;
+    const int ft0 = (int)(t0 - clip * a.tiles_per_clip);
+    int64_t tiles = a.tiles_per_clip - ft0;
+    if (tiles > tau_end - t0) tiles = tau_end - t0;
+    const int64_t left = a.count - (int64_t)ft0 * kFT;
+    sg.tiles = (int)tiles;
+    sg.nfr = (int)(left < tiles * kFT ? left : tiles * kFT);
+    sg.x0 = a.x + clip * a.x_stride + ((a.p0 + (int64_t)ft0 * kFT) * a.hop - a.left);
+    const uintptr_t o = reinterpret_cast<uintptr_t>(a.out + a.out_offset + clip * (int64_t)kBins * a.out_stride + (int64_t)ft0 * kFT);
+    sg.S = reinterpret_cast<char *>(o & ~uintptr_t(63));
+    sg.d = (unsigned)(o & 63);
+    return sg;
+  };
+  // ring skew of bin row `bin` in segment sg: (byte address of out[clip][bin][first frame] mod 64) / 4
+  auto skew = [&](const RingSeg &sg, int bin) {
+#ifdef SMX_DIAG
+    if (a.abl_noskew) return 0;
+#endif
+    return (int)(((sg.d + (unsigned)bin * (pitch4 & 63u)) & 63u) >> 2);
+  };
+  // this wave's frame of tile `it` of a segment (a wave without a frame re-reads the tile's first frame and ignores it)
+  auto frame_src = [&](const RingSeg &sg, int it) {
+    const int f = it * kFT + wave;
+    return sg.x0 + (int64_t)(f < sg.nfr ? f : it * kFT) * a.hop;
+  };
+  // block j of a segment -> HBM: this wave's 64 rows (4 parts of 16 rows x 64 bytes).  Tile rows {0-3, 16-19} + 4 h
+  // per half-wave keep the LDS reads conflict free; a 4-lane group owns one row's 16 positions.
+  auto flush_block = [&](const RingSeg &sg, int j) {
+    const int l = opaque(lane);
+    const int fg = l & 3, hsel = l >> 5, jj = (l & 31) >> 2;
+    const int frow0 = 32 * wave + (jj & 3) + 16 * (jj >> 2) + 4 * hsel;
+    const int fbin0 = (frow0 & 3) * 256 + (frow0 >> 2);         // bin(row + 8) = bin + 2, bin(row + 512) = bin + 128
+    const unsigned t0 = sg.d + (unsigned)fbin0 * pitch4;
+    const float *buf = lds.tiles + (j & 1) * kTileFloats;
+    float *Sj = reinterpret_cast<float *>(sg.S + (int64_t)64 * j);
+    const int c0 = 4 * fg;
+    const int first = j == 0, left = sg.nfr - kFT * j;           // valid ring positions of a row: [first ? A : 0, A + left)
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+      const int row = frow0 + 512 * (p >> 1) + 8 * (p & 1);
+      const float *src = buf + row * kTileStride + c0;
+      const float v0 = src[0], v1 = src[1], v2 = src[2], v3 = src[3];
+      const unsigned t = t0 + (unsigned)(2 * (p & 1) + 128 * (p >> 1)) * pitch4;
+#ifdef SMX_DIAG
+      const unsigned goff = (a.abl_noskew ? t : (t & ~63u)) + 16u * (unsigned)fg;
+      const int A = a.abl_noskew ? 0 : (int)((t & 63u) >> 2);
+#else
+      const unsigned goff = (t & ~63u) + 16u * (unsigned)fg;
+      const int A = (int)((t & 63u) >> 2);
+#endif
+      const int lo = first ? A : 0, hi = A + left;
+#ifdef SMX_DIAG
+      if (a.abl_nostore == 1) { asm volatile("" ::"v"(v0), "v"(v1), "v"(v2), "v"(v3)); continue; }
+#endif
+      if (c0 >= lo && c0 + 4 <= hi) {
+        store4_unaligned(Sj, goff, v0, v1, v2, v3);
+      } else {
+        float *dst = reinterpret_cast<float *>(reinterpret_cast<char *>(Sj) + goff);
+        if (c0 >= lo && c0 < hi) dst[0] = v0;
+        if (c0 + 1 >= lo && c0 + 1 < hi) dst[1] = v1;
+        if (c0 + 2 >= lo && c0 + 2 < hi) dst[2] = v2;
+        if (c0 + 3 >= lo && c0 + 3 < hi) dst[3] = v3;
+      }
+    }
+    if (wave == 0 && l < 16) {   // bin 1024: its 16 positions sit in the pad slots of rows 0..15
+      const unsigned t = sg.d + (unsigned)kM * pitch4;
+      const int A = (int)((t & 63u) >> 2);
+      const int lo = first ? A : 0, hi = A + left;
+      if (l >= lo && l < hi)
+        *reinterpret_cast<float *>(reinterpret_cast<char *>(Sj) + (t & ~63u) + 4u * (unsigned)l) = buf[l * kTileStride + kFT];
+    }
+  };
+  auto nth = [](int j) { return 16u * (((unsigned)j >> 1) + 1u); };   // counter value once tile / block j is through
+
+  float2 raw[16];
+#pragma unroll
+  for (int j = 0; j < 16; ++j) raw[j] = make_float2(0.f, 0.f);
+  RingSeg sg = seg_at(tau < tau_end ? tau : 0);
+  if (tau < tau_end) prefetch_frame<ALIGNED SMX_ABL_ARG>(a, frame_src(sg, 0), lane, raw);
+  __syncthreads();   // tables and zeroed counters visible
+
+  while (tau < tau_end) {   // one segment per trip (uniform for the workgroup)
+    const int64_t tau_next = tau + sg.tiles;
+    RingSeg sg_next = sg;
+    if (tau_next < tau_end) sg_next = seg_at(tau_next);
+    for (int it = 0; it < sg.tiles; ++it) {
+      const bool have = it * kFT + wave < sg.nfr;   // wave-uniform
+      auto flush_prev = [&]() {   // block it - 1: complete once every wave has written tile it - 1
+        if (it < 1) return;
+        lds_wait(c_filled + ((it - 1) & 1), nth(it - 1));
+        flush_block(sg, it - 1);
+        lds_signal(c_drained + ((it - 1) & 1), lane);
+      };
+      auto ready = [&]() {        // the cells of tile `it` lie in blocks it (buffer of block it - 2) and it + 1 (of block it - 1)
+        if (it >= 2) lds_wait(c_drained + (it & 1), nth(it - 2));
+        if (it >= 1) lds_wait(c_drained + ((it + 1) & 1), nth(it - 1));
+      };
+      if (have) {
+        // The frame's cells, derived where the post-pass needs them (nothing of this lives across the FFT): ring
+        // position of the frame in a row = 16 it + wave + the row's skew.
+        auto cell = [&](int row, int bin) {
+          const unsigned pos = 16u * (unsigned)it + (unsigned)wave + (unsigned)skew(sg, bin);
+          return lds.tiles + ((pos >> 4) & 1u) * kTileFloats + row * kTileStride + (pos & 15u);
+        };
+        auto ready_cells = [&](Cells &c) {
+          if constexpr (SMX_RING_PRIO != 0) __builtin_amdgcn_s_setprio(SMX_RING_PRIO);   // the end of a frame goes first: the others wait for it
+          ready();
+          const int l = opaque(lane);
+          const int k1 = l >> 2, qa = l & 3, r = ((qa & 1) << 1) | (qa >> 1);
+          c.own = cell(4 * k1 + r, k1 + 256 * r);
+          if (l >= 4) {   // partner lane 67 - l: k1' = 16 - k1, r' = 3 - r
+            c.pg = cell(4 * (16 - k1) + (3 - r), (16 - k1) + 256 * (3 - r));
+            c.p0 = c.pg + kCellStep * 15;
+          } else {        // the k1 = 0 column pairs inside itself (setup_lane)
+            c.pg = cell((3 - r) + 64, 256 * (3 - r));
+            c.p0 = cell((4 - r) & 3, 256 * ((4 - r) & 3));
+          }
+          const unsigned pos = 16u * (unsigned)it + (unsigned)wave + (unsigned)skew(sg, kM);
+          c.nyq = lds.tiles + ((pos >> 4) & 1u) * kTileFloats + (pos & 15u) * kTileStride + kFT;
+        };
+        const RingHook<FLUSH_AT, decltype(flush_prev), decltype(ready_cells)> hook{flush_prev, ready_cells};
+        frame_to_tile<SQUARE, kPre, false, false SMX_ABL_ARG>(a, L, raw, Cells{}, lane, hook);
+      } else {
+        flush_prev();
+      }
+      lds_signal(c_filled + (it & 1), lane);
+      if constexpr (SMX_RING_PRIO != 0) __builtin_amdgcn_s_setprio(0);
+      // next frame: the segment's next tile, else the first tile of the next segment, else (the end) a dummy re-read
+      const float *src = it + 1 < sg.tiles ? frame_src(sg, it + 1) : (tau_next < tau_end ? frame_src(sg_next, 0) : frame_src(sg, it));
+      prefetch_frame<ALIGNED SMX_ABL_ARG>(a, src, lane, raw);
+    }
+    // drain: the last full block and the partial one behind it
+    lds_wait(c_filled + ((sg.tiles - 1) & 1), nth(sg.tiles - 1));
+    flush_block(sg, sg.tiles - 1);
+    flush_block(sg, sg.tiles);
+    __syncthreads();             // every wave has read both buffers: counters and ring restart with the next segment
+    if (tid < 4) c_filled[tid] = 0u;
+    __syncthreads();
+    tau = tau_next;
+    sg = sg_next;
+  }
+
+  // Border frames: as in stft2048_power_kernel (same frame code, unskewed tile, element stores)
+  if (a.border_left + a.border_right > 0) {
+    const int per = a.border_left + a.border_right;
+    const int64_t lead = a.total_tiles / a.tiles_per_clip;
+    const int64_t total = lead * per;
+    auto locate = [&](int64_t beta, int64_t &clip, int64_t &p) {
+      clip = beta / per;
+      const int r = (int)(beta % per);
+      p = r < a.border_left ? a.border_p0 + r : a.border_i1 + (r - a.border_left);
+    };
+    float *bt_tile = lds.tiles;
+    for (int64_t bt = blockIdx.x; bt * kFT < total; bt += gridDim.x) {
+      __syncthreads();
+      const int64_t beta = bt * kFT + wave;
+      if (beta < total) {   // wave-uniform
+        int64_t clip, p;
+        locate(beta, clip, p);
+        const float *xs = a.x + clip * a.x_stride;
+        const int s0 = (int)(p * a.hop - a.left);
+        float2 braw[16];
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+          const int s = s0 + 2 * (lane + 64 * j);
+          braw[j] = make_float2(fetch_padded(xs, (int)a.n, s, a.pad, a.pad_value),
+                                fetch_padded(xs, (int)a.n, s + 1, a.pad, a.pad_value));
+        }
+        frame_to_tile<SQUARE, SMX_EPILOGUE_PRE, false, false SMX_ABL_ZERO>(a, L, braw, cells_of_column(L, bt_tile, wave), lane, NoHook{});
+      }
+      __syncthreads();
+      for (int e = tid; e < kBins * kFT; e += 1024) {
+        const int k = e / kFT, f = e % kFT;
+        const int64_t bf = bt * kFT + f;
+        if (bf < total) {
+          int64_t clip, p;
+          locate(bf, clip, p);
+          const float v = k < kM ? bt_tile[(4 * (k & 255) + (k >> 8)) * kTileStride + f]
+                                 : bt_tile[nyquist_row(f) * kTileStride + kFT];
+          a.out[(clip * kBins + k) * a.out_stride + a.border_out_offset + (p - a.border_p0)] = v;
+        }
+      }
+    }
+  }
 }
 
 // ---- complex spectrum kernel (Stft.transform / transform_range, stft.ml:632-666) ------------------
@@ -854,7 +1141,7 @@ struct CplxHook {
   __device__ __forceinline__ void at() const {
     if constexpr (P == 5) flush_previous();
   }
-  __device__ __forceinline__ void ready() const { lds_wait(drained, 16u * tiles_before); }
+  __device__ __forceinline__ void ready(Cells &) const { lds_wait(drained, 16u * tiles_before); }
 };
 
 template <bool ALIGNED, bool STRIP>
@@ -894,7 +1181,7 @@ __global__ void __launch_bounds__(1024) stft2048_complex_kernel(FastArgs a) {
   for (int it = 0; it < ntiles; ++it) {
     const CplxHook<ALIGNED> hook{a, c_filled, c_drained, (unsigned)it, lds.tiles, fl, pend_out, pend_left, wave, lane};
     if (have) {
-      frame_to_tile<true, false, true, false SMX_ABL_ZERO>(a, L, raw, lds.tiles, wave, lane, hook);
+      frame_to_tile<true, false, true, false SMX_ABL_ZERO>(a, L, raw, cells_of_column(L, lds.tiles, wave), lane, hook);
     } else {
       hook.flush_previous();
     }
@@ -962,7 +1249,7 @@ struct ReadyHook {   // frame_to_tile calls ready() just before the powers overw
   unsigned target;
   template <int P>
   __device__ __forceinline__ void at() const {}
-  __device__ __forceinline__ void ready() const { lds_wait(c, target); }
+  __device__ __forceinline__ void ready(Cells &) const { lds_wait(c, target); }
 };
 
 template <bool ALIGNED, bool SQUARE, bool STRIP>
@@ -1136,7 +1423,7 @@ __global__ void __launch_bounds__(1024) stft2048_mel_kernel(FastArgs a, MelFused
     if (t < ntiles) {
       // every MFMA read of tile t-2 (same buffer) must be over before the powers of tile t land
       if (have) {
-        frame_to_tile<SQUARE, false, false, false SMX_ABL_ZERO>(a, L, raw, tcur, wave, lane,
+        frame_to_tile<SQUARE, false, false, false SMX_ABL_ZERO>(a, L, raw, cells_of_column(L, tcur, wave), lane,
                                                                         ReadyHook{c_mdone + b, t >= 2 ? nth(t - 2) : 0u});
       }
       lds_signal(c_filled + b, lane);
@@ -1305,18 +1592,43 @@ void launch_interior(const StftJob &job, const FastTarget &tg, const float *x, i
   const char *abl_env = std::getenv("SMX_ABLATE");
   const int abl = abl_env ? std::atoi(abl_env) : 0;
   a.abl_nostore = (abl == 1 || abl == 3 || abl == 7) ? 1 : abl == 8 ? 2 : 0;
+  if (std::getenv("SMX_NOSTORE")) a.abl_nostore = 1;
   if (const char *w = std::getenv("SMX_ABL_RUN")) a.abl_nostore = std::atoi(w);   // 2: 128 B, 3: 256 B, 4: 512 B runs
-  auto kernel = abl == 2 ? stft2048_power_kernel<true, true, false, 2>
+  const char *ring_env = std::getenv("SMX_POWER_RING");
+  const bool ring = ring_env && ring_env[0] == '1';
+  const char *fl_env = std::getenv("SMX_RING_FLUSH");
+  const int fl_at = fl_env ? std::atoi(fl_env) : 2;
+  a.abl_noskew = std::getenv("SMX_RING_NOSKEW") ? 1 : 0;
+  auto kernel = ring ? (abl == 4 ? stft2048_power_ring_kernel<true, true, false, 2, 4>
+                        : abl == 5 ? stft2048_power_ring_kernel<true, true, false, 2, 5>
+                        : (abl == 6 || abl == 7) ? stft2048_power_ring_kernel<true, true, false, 2, 6>
+                        : abl == 9 ? stft2048_power_ring_kernel<true, true, false, 2, 9>
+                        : abl == 10 ? stft2048_power_ring_kernel<true, true, false, 2, 10>
+                        : abl == 11 ? stft2048_power_ring_kernel<true, true, false, 2, 11>
+                        : fl_at == 5 ? stft2048_power_ring_kernel<true, true, false, 5, 0>
+                        : fl_at == 1 ? stft2048_power_ring_kernel<true, true, false, 1, 0>
+                        : fl_at == 3 ? stft2048_power_ring_kernel<true, true, false, 3, 0>
+                                     : stft2048_power_ring_kernel<true, true, false, 2, 0>)
+              : abl == 2 ? stft2048_power_kernel<true, true, false, 2>
               : abl == 3 ? stft2048_power_kernel<true, true, false, 3>
               : abl == 4 ? stft2048_power_kernel<true, true, false, 4>
               : abl == 5 ? stft2048_power_kernel<true, true, false, 5>
               : (abl == 6 || abl == 7 || abl == 8) ? stft2048_power_kernel<true, true, false, 6>
               : abl == 9 ? stft2048_power_kernel<true, true, false, 9>
+              : abl == 10 ? stft2048_power_kernel<true, true, false, 10>
+              : abl == 11 ? stft2048_power_kernel<true, true, false, 11>
                          : stft2048_power_kernel<true, true, false, 0>;
   (void)aligned; (void)square; (void)strip;
 #else
+  // SMX_POWER_RING=0: the column-per-frame kernel with unaligned 64-byte runs (A/B timing; same values bit for bit)
+  const char *ring_env = std::getenv("SMX_POWER_RING");
+  const bool ring = !(ring_env && ring_env[0] == '0');
   auto pick = [&](auto strip_tag) {
     constexpr bool S = decltype(strip_tag)::value;
+    constexpr int F = SMX_RING_FLUSH_AT;
+    if (ring)
+      return aligned ? (square ? stft2048_power_ring_kernel<true, true, S, F> : stft2048_power_ring_kernel<true, false, S, F>)
+                     : (square ? stft2048_power_ring_kernel<false, true, S, F> : stft2048_power_ring_kernel<false, false, S, F>);
     return aligned ? (square ? stft2048_power_kernel<true, true, S> : stft2048_power_kernel<true, false, S>)
                    : (square ? stft2048_power_kernel<false, true, S> : stft2048_power_kernel<false, false, S>);
   };
