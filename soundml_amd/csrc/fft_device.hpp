@@ -116,9 +116,12 @@ __device__ __forceinline__ void stockham_sync() {
   else __syncthreads();
 }
 
+// `wpre`: the pass's table twiddles already in registers (fft_passes<.., PRE>: every pass's table read is issued before
+// the first pass, so its global-memory latency is paid once per transform instead of once per pass); nullptr = read here.
 template <int N, int R, int NS, bool READ, bool WRITE, bool WAVE = false, typename S = float>
 __device__ __forceinline__ void stockham_pass(cpx<S> (&r)[16], typename vec2_of<S>::type *z, int tid,
-                                              const typename vec2_of<S>::type *tw) {
+                                              const typename vec2_of<S>::type *tw,
+                                              const typename vec2_of<S>::type *wpre = nullptr) {
   using V = typename vec2_of<S>::type;
   constexpr int T = N / 16, G = 16 / R;
   if constexpr (READ) {
@@ -136,7 +139,7 @@ __device__ __forceinline__ void stockham_pass(cpx<S> (&r)[16], typename vec2_of<
   for (int i = 0; i < G; ++i) {
     if constexpr (NS > 1) {
       const int k = (tid + T * i) % NS;
-      const V w1 = tw[k * (N / (NS * R))];
+      const V w1 = wpre ? wpre[i] : tw[k * (N / (NS * R))];
       cpx<S> w[16];
       twiddle_powers<R>(cpx<S>{w1.x, w1.y}, w);
 #pragma unroll
@@ -176,11 +179,37 @@ __device__ __forceinline__ int out_index(int tid, int i, int j) {
 
 // forward FFT of the 16 points per thread; FIRST: registers already hold element tid + T*m in r[m].
 // On return r[i*R + j] (last radix R, its NS) holds natural-order element out_index<R, NS, T>(tid, i, j).
-template <int LOG2N, bool FIRST, bool WAVE = false, typename S = float>
+template <int LOG2N, bool FIRST, bool WAVE = false, typename S = float, bool PRE = false>
 __device__ __forceinline__ void fft_passes(cpx<S> (&r)[16], typename vec2_of<S>::type *z, int tid,
                                            const typename vec2_of<S>::type *tw) {
   constexpr int N = 1 << LOG2N;
   static_assert(LOG2N >= 8 && LOG2N <= 14, "transform sizes 256 .. 16384");
+  if constexpr (PRE) {   // same passes, same arithmetic; the table reads of passes 2.. are issued up front
+    using V = typename vec2_of<S>::type;
+    constexpr int T = N / 16;
+    constexpr int R3 = LOG2N == 8 ? 1 : (LOG2N == 9 ? 2 : (LOG2N == 10 || LOG2N == 11) ? 4 : 16);       // third pass
+    constexpr int R4 = (LOG2N == 11 || LOG2N == 13) ? 2 : (LOG2N == 14 ? 4 : 1);                          // fourth pass
+    constexpr int NS4 = LOG2N == 11 ? 1024 : 4096;
+    V w2[1], w3[R3 > 1 ? 16 / R3 : 1], w4[R4 > 1 ? 16 / R4 : 1];
+    w2[0] = tw[(tid % 16) * (N / 256)];
+    if constexpr (R3 > 1) {
+#pragma unroll
+      for (int i = 0; i < 16 / R3; ++i) w3[i] = tw[((tid + T * i) % 256) * (N / (256 * R3))];
+    }
+    stockham_pass<N, 16, 1, !FIRST, true, WAVE>(r, z, tid, tw);
+    if constexpr (LOG2N == 8) {
+      stockham_pass<N, 16, 16, true, false, WAVE>(r, z, tid, tw, w2);
+    } else {
+      stockham_pass<N, 16, 16, true, true, WAVE>(r, z, tid, tw, w2);
+      if constexpr (R4 > 1) {   // the last pass's (up to 8) values one pass ahead only: 16 registers less across the first two passes
+#pragma unroll
+        for (int i = 0; i < 16 / R4; ++i) w4[i] = tw[((tid + T * i) % NS4) * (N / (NS4 * R4))];
+      }
+      stockham_pass<N, R3, 256, true, (R4 > 1), WAVE>(r, z, tid, tw, w3);
+      if constexpr (R4 > 1) stockham_pass<N, R4, NS4, true, false, WAVE>(r, z, tid, tw, w4);
+    }
+    return;
+  }
   stockham_pass<N, 16, 1, !FIRST, true, WAVE>(r, z, tid, tw);
   if constexpr (LOG2N == 8) {
     stockham_pass<N, 16, 16, true, false, WAVE>(r, z, tid, tw);

@@ -1041,7 +1041,8 @@ def test_chroma_messages():
 
 # ---- FIR ---------------------------------------------------------------------------------------------
 
-@pytest.mark.parametrize("taps,n,ch", [(63, 5000, 2), (1, 100, 1), (8192, 60000, 2), (1000, 1, 1), (257, 16384 * 3, 3)])
+@pytest.mark.parametrize("taps,n,ch", [(63, 5000, 2), (1, 100, 1), (8192, 60000, 2), (1000, 1, 1), (257, 16384 * 3, 3),
+                                       (16384, 70001, 1), (4097, 49153, 2), (2048, 8191, 1), (600, 3001, 2)])
 def test_fir_vs_oracle(taps, n, ch):
     rng = np.random.default_rng(taps + n)
     h = Fir.design_lowpass(taps, 0.25, 80.0)

@@ -258,8 +258,10 @@ def test_fir_design_matches_oracle():
         h = Fir.design_lowpass(taps, fc, att)
         np.testing.assert_allclose(h, O.design_lowpass(taps, fc, O.kaiser_beta(att)), rtol=1e-12, atol=1e-18)
     with pytest.raises(S.InvalidArgument):
-        Fir.Plan.create(np.ones(9000))
-    assert Fir.Plan.create(np.ones(8192) / 8192).block == 16384
+        Fir.Plan.create(np.ones(16385))
+    assert Fir.Plan.create(np.ones(8192) / 8192).block == 32768      # 4 x taps: 75 % of every block is kept
+    assert Fir.Plan.create(np.ones(16384) / 16384).block == 32768
+    assert Fir.Plan.create(np.ones(255) / 255).block == 1024
 
 
 # ---- least-squares synthesis bookkeeping (host side of Stft.invert; no device needed) ----------------

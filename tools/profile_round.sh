@@ -1,0 +1,59 @@
+#!/bin/bash
+# Runs ON THE GPU BOX (via gpurun): the round's profile set.
+#   tools/profile_round.sh <tag>     ->  gpurun_out/<tag>/{kernel_stats.csv, bench_n1.json, pmc.json, hot_kernel_stats.csv}
+# 1. rocprofv3 --kernel-trace --stats of the bench command (the roofline's kernel duration must agree with it)
+# 2. PMC passes (one counter group per pass, --pmc alone) over tools/pmc_driver.py: every hot kernel of C2 / C3 / C4
+set -u
+TAG=${1:-prof}
+ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
+OUT=$ROOT/gpurun_out/$TAG
+mkdir -p "$OUT"
+cd /tmp && export TMPDIR=/tmp
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -- python3 $ROOT/bench.py --no-cpu-baseline --steps 20 --warmup 3 > "$OUT/bench_n1.json" 2> "$OUT/trace.err"
+find "$OUT/trace" -name '*kernel_stats.csv' | head -1 | xargs -r -I{} cp {} "$OUT/kernel_stats.csv"
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace_hot" -- python3 $ROOT/tools/pmc_driver.py > "$OUT/trace_hot.log" 2>&1
+find "$OUT/trace_hot" -name '*kernel_stats.csv' | head -1 | xargs -r -I{} cp {} "$OUT/hot_kernel_stats.csv"
+i=0
+while read -r group; do
+  i=$((i+1))
+  timeout 300 rocprofv3 --pmc $group --output-format csv -d "$OUT/pmc_g$i" -- python3 $ROOT/tools/pmc_driver.py > "$OUT/pmc_g$i.log" 2>&1 || echo "group $i failed"
+done <<'GROUPS'
+SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_WAVES
+SQ_ACTIVE_INST_LDS SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SALU
+SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_F32 SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_INSTS_SMEM
+FETCH_SIZE
+WRITE_SIZE
+TCC_HIT_sum TCC_MISS_sum TCC_EA0_RDREQ_sum TCC_EA0_WRREQ_sum
+GRBM_GUI_ACTIVE GRBM_COUNT
+TCP_PENDING_STALL_CYCLES_sum TCP_TCC_WRITE_REQ_sum TCP_TCC_READ_REQ_sum TCP_GATE_EN1_sum
+GROUPS
+python3 - "$OUT" <<'PY'
+import csv, glob, sys, collections, json, re
+out_dir = sys.argv[1]
+rows = collections.defaultdict(lambda: collections.defaultdict(list))
+for f in glob.glob(out_dir + '/pmc_g*/**/*counter_collection.csv', recursive=True):
+    for r in csv.DictReader(open(f)):
+        k = r['Kernel_Name']
+        if not re.search(r'stft2048|mel_apply|fir_ols', k):
+            continue
+        k = re.sub(r'\(smx::.*', '', k.replace('void smx::(anonymous namespace)::', ''))
+        rows[k][r['Counter_Name']].append(float(r['Counter_Value']))
+dur = {}
+for f in glob.glob(out_dir + '/hot_kernel_stats.csv'):
+    for r in csv.DictReader(open(f)):
+        k = re.sub(r'\(smx::.*', '', r['Name'].replace('void smx::(anonymous namespace)::', ''))
+        dur[k] = {"calls": int(r['Calls']), "avg_us": float(r['AverageNs']) / 1e3, "min_us": float(r['MinNs']) / 1e3}
+res = {"source": "tools/profile_round.sh: rocprofv3 --pmc, one counter group per pass over tools/pmc_driver.py (C2 256 x 480000 fft 2048 / hop 512; "
+                 "C3 128 mels; C4 8192 taps on 8 x 2880000); per launch, average over the launches after the first; durations from a "
+                 "--kernel-trace --stats pass of the same driver; FETCH_SIZE / WRITE_SIZE in KB as reported (FETCH_SIZE counts half the bytes "
+                 "of wide coalesced reads on gfx950: MI355X_MICROARCH.md)", "kernels": {}}
+for k, cs in rows.items():
+    res["kernels"][k] = {"duration": dur.get(k), "counters": {c: (sum(v[1:]) / max(1, len(v) - 1) if len(v) > 1 else v[0]) for c, v in sorted(cs.items())}}
+json.dump(res, open(out_dir + '/pmc.json', 'w'), indent=1)
+for k, v in res["kernels"].items():
+    c = v["counters"]
+    print(k, v["duration"])
+    print("   ", {n: round(c[n]) for n in ("SQ_INSTS_VALU", "SQ_INSTS_LDS", "SQ_WAVE_CYCLES", "SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_VALU", "SQ_LDS_BANK_CONFLICT", "FETCH_SIZE", "WRITE_SIZE", "TCC_EA0_WRREQ_sum", "SQ_VALU_MFMA_BUSY_CYCLES", "GRBM_GUI_ACTIVE") if n in c})
+PY
+rm -rf "$OUT"/pmc_g*/ "$OUT"/trace "$OUT"/trace_hot 2>/dev/null
+echo done
