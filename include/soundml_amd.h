@@ -86,6 +86,7 @@ typedef struct smx_mel_config smx_mel_config;
 typedef struct smx_chroma_config smx_chroma_config;
 typedef struct smx_stft_kernel smx_stft_kernel;
 typedef struct smx_fir_plan smx_fir_plan;
+typedef struct smx_resample_stage smx_resample_stage;
 
 /* ---- library ------------------------------------------------------------ */
 const char *smx_last_error(void);      /* message of the last failing call on this thread */
@@ -371,6 +372,37 @@ int64_t smx_fir_plan_block(const smx_fir_plan *p);                      /* FFT l
 int smx_fir_apply_f32(const smx_fir_plan *p, const float *x, int64_t channels, int64_t n, float *y);
 int smx_fir_apply_f32_dev(const smx_fir_plan *p, const float *d_x, int64_t channels, int64_t n,
                           int64_t x_stride, float *d_y, int64_t y_stride, void *stream);
+
+
+/* ---- Resample: the overlap-save executor's pieces ------------------------------------------------
+ * The reference's planner, polyphase bank and cascade logic (resample.ml, 2100 lines) stay in OCaml; what moves to the
+ * device is the block convolution of a stage and the block identity its own C stub computes.
+ *
+ * smx_resample_ols_geom    resample.ml:279-300 `ols_block_n` / `ols_geom`: (N, B, delta) of a xL or /M stage of group
+ *                          delay K consuming `rate` Hz; *eligible = 0 past the 130 ms emission ceiling.
+ * smx_resample_prototype   resample.ml:145-163 `design_prototype`: the 2 K L + 1 tap Kaiser-sinc, float64, sum = L.
+ * smx_resample_shape_c128  replaces `soundml_resample_shape` (resample_stubs.c:329-422; bound in resample.ml:1186-1196
+ *                          as `resample_shape_c`): interleaved complex128 half spectra x [lines; N/2+1] and plan
+ *                          spectrum h -> y [lines; W/2+1], W = N sl | N / sm | N.  xL: periodic extension times h[k];
+ *                          /M: product on the half grid, alias fold in ascending order.  Same operations in the same
+ *                          order in float64 (no fused multiply-add): bit for bit the stub's result.  Geometry errors
+ *                          are Failure with the stub's message ("soundml_resample_shape: invalid geometry").
+ * smx_resample_stage_*     one stage y[i] = sum_t proto[t] xu[i M + K L - t], xu = x zero-stuffed by L, ceil(n L / M)
+ *                          outputs (what `ols_run` + the virtual-silence drain emit, resample.ml:1456-1599,1745-1755),
+ *                          as one block convolution at the interpolated rate on the FIR kernel, float32 interior.  Any
+ *                          L, M >= 1 (the reference's OLS stages are L or M in {2, 3, 4}); 2 K L + 1 <= 16384 taps.      */
+int smx_resample_ols_geom(int64_t rate, int64_t l, int64_t m, int64_t k, int64_t *n, int64_t *b, int64_t *delta,
+                          int *eligible);
+int smx_resample_prototype(int64_t l, int64_t k, double fc, double beta, double *h /* 2 K L + 1 */);
+int smx_resample_shape_c128(const double *x, const double *h, double *y, int64_t lines, int64_t n, int64_t sl, int64_t sm);
+int smx_resample_shape_c128_dev(const double *d_x, const double *d_h, double *d_y, int64_t lines, int64_t n, int64_t sl,
+                                int64_t sm, void *stream);
+int smx_resample_stage_create(const double *proto /* 2 K L + 1 */, int64_t l, int64_t m, int64_t k, smx_resample_stage **out);
+void smx_resample_stage_destroy(smx_resample_stage *s);
+int64_t smx_resample_stage_out_length(const smx_resample_stage *s, int64_t n);       /* ceil(n L / M) */
+int smx_resample_stage_apply_f32(const smx_resample_stage *s, const float *x, int64_t channels, int64_t n, float *y);
+int smx_resample_stage_apply_f32_dev(const smx_resample_stage *s, const float *d_x, int64_t channels, int64_t n,
+                                     int64_t x_stride, float *d_y, int64_t y_stride, void *stream);
 
 #ifdef __cplusplus
 }

@@ -31,6 +31,8 @@ def load():
         fn.argtypes = [vp, i64, i64, ci, ci, vp, i64, ci, d, i64, ci, d, vp, ci]
     lib.oracle_mel_apply_f32.restype = ci
     lib.oracle_mel_apply_f32.argtypes = [vp, ci, ci, vp, i64, i64, vp]
+    lib.oracle_resample_shape.restype = ci
+    lib.oracle_resample_shape.argtypes = [vp, vp, vp, i64, i64, i64, i64]
     lib.oracle_mel_apply_f32_mt.restype = ci
     lib.oracle_mel_apply_f32_mt.argtypes = [vp, ci, ci, vp, i64, i64, vp, ci]
     return lib
@@ -67,4 +69,17 @@ def mel_apply(mc: O.MelConfig, s: np.ndarray, threads: int = 1) -> np.ndarray:
     w = np.ascontiguousarray(mc.weights, dtype=np.float64)
     lib.oracle_mel_apply_f32_mt(w.ctypes.data, mc.n_mels, mc.bins, s.ctypes.data, lead, frames, out.ctypes.data,
                                 int(threads))
+    return out
+
+
+def resample_shape(xs: np.ndarray, h: np.ndarray, n: int, sl: int, sm: int) -> np.ndarray:
+    """the C restatement of resample_stubs.c:329-372 on complex128 [lines; n/2+1]"""
+    lib = load()
+    xs = np.ascontiguousarray(xs, dtype=np.complex128)
+    h = np.ascontiguousarray(h, dtype=np.complex128)
+    w = n * sl if sl > 1 else (n // sm if sm > 1 else n)
+    out = np.zeros((xs.shape[0], w // 2 + 1), dtype=np.complex128)
+    rc = lib.oracle_resample_shape(xs.ctypes.data, h.ctypes.data, out.ctypes.data, xs.shape[0], n, sl, sm)
+    if rc != 0:
+        raise ValueError("resample_shape: invalid geometry")
     return out

@@ -263,3 +263,53 @@ int oracle_mel_apply_f32(const double *w, int n_mels, int bins, const float *s, 
                          float *out) {
   return oracle_mel_apply_f32_mt(w, n_mels, bins, s, lead, frames, out, 1);
 }
+
+/* resample_stubs.c:329-372 `soundml_resample_shape_run`, restated (interleaved complex128 arrays): the block identity
+ * between the two transforms of the overlap-save resample executor.  Built with -ffp-contract=off like the rest. */
+static void cx_mul(const double *a, const double *b, double *r) {
+  r[0] = (a[0] * b[0]) - (a[1] * b[1]);
+  r[1] = (a[0] * b[1]) + (a[1] * b[0]);
+}
+
+int oracle_resample_shape(const double *x, const double *h, double *y, int64_t lines, int64_t n, int64_t sl, int64_t sm) {
+  if (lines < 0 || n < 2 || (n % 2) != 0 || sl < 1 || sm < 1 || (sl > 1 && sm > 1)) return -1;
+  const int64_t w = sl > 1 ? n * sl : (sm > 1 ? n / sm : n);
+  if (w < 2 || (sm > 1 && (n % sm) != 0)) return -1;
+  const int64_t bins = n / 2 + 1, obins = w / 2 + 1, half = n / 2;
+  for (int64_t line = 0; line < lines; ++line) {
+    const double *xs = x + 2 * line * bins;
+    double *ys = y + 2 * line * obins;
+    if (sl > 1) {
+      int64_t k = 0;
+      while (k < obins) {
+        for (int64_t j = 0; j <= half && k < obins; ++j, ++k) cx_mul(xs + 2 * j, h + 2 * k, ys + 2 * k);
+        for (int64_t j = half + 1; j < n && k < obins; ++j, ++k) {
+          const double z[2] = {xs[2 * (n - j)], -xs[2 * (n - j) + 1]};
+          cx_mul(z, h + 2 * k, ys + 2 * k);
+        }
+      }
+    } else if (sm > 1) {
+      for (int64_t k = 0; k < obins; ++k) {
+        int64_t j = k;
+        double acc[2], p[2];
+        cx_mul(xs + 2 * k, h + 2 * k, acc);
+        for (int64_t r = 1; r < sm; ++r) {
+          j += w;
+          if (j <= half) {
+            cx_mul(xs + 2 * j, h + 2 * j, p);
+          } else {
+            cx_mul(xs + 2 * (n - j), h + 2 * (n - j), p);
+            p[1] = -p[1];
+          }
+          acc[0] += p[0];
+          acc[1] += p[1];
+        }
+        ys[2 * k] = acc[0];
+        ys[2 * k + 1] = acc[1];
+      }
+    } else {
+      for (int64_t k = 0; k < obins; ++k) cx_mul(xs + 2 * k, h + 2 * k, ys + 2 * k);
+    }
+  }
+  return 0;
+}

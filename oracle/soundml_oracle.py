@@ -1336,36 +1336,41 @@ def ols_plan_spectrum(proto: np.ndarray, n: int, l: int, m: int) -> np.ndarray:
     return spec if scale == 1.0 else spec * scale
 
 
+def _cx_mul(ar, ai, br, bi):
+    """resample_stubs.c:315-320 `soundml_cx_mul`: the plain four-multiply product, each operation rounded on its own
+    (separate numpy operations: no fused multiply-add)."""
+    return (ar * br) - (ai * bi), (ar * bi) + (ai * br)
+
+
 def ols_shape(xs: np.ndarray, h: np.ndarray, n: int, sl: int, sm: int) -> np.ndarray:
-    """resample_stubs.c:329-372 `soundml_resample_shape_run`: from the length-N half spectra `xs` [lines; N/2+1] to
-    the half grid of the inverse transform of length W.  xL: periodic extension times h[k]; /M: product on the half
-    grid, alias fold onto W = N/M bins in ascending fold order; otherwise the plain product."""
+    """resample_stubs.c:329-372 `soundml_resample_shape_run`, operation for operation: from the length-N half spectra
+    `xs` [lines; N/2+1] to the half grid of the inverse transform of length W.  xL: periodic extension times h[k];
+    /M: product on the half grid, alias fold onto W = N/M bins in ascending fold order; otherwise the plain product."""
     w = n * sl if sl > 1 else (n // sm if sm > 1 else n)
     half, obins = n // 2, w // 2 + 1
-    lines = xs.shape[0]
-    ys = np.zeros((lines, obins), dtype=np.complex128)
+    xr, xi = np.ascontiguousarray(xs.real), np.ascontiguousarray(xs.imag)
+    hr, hi = np.ascontiguousarray(h.real), np.ascontiguousarray(h.imag)
     if sl > 1:
         kk = np.arange(obins)
         j = kk % n
-        src = np.where(j <= half, j, n - j)
-        val = xs[:, src]
-        val = np.where((j <= half)[None, :], val, np.conj(val))
-        ys[:] = val * h[None, :obins]
+        direct = j <= half
+        src = np.where(direct, j, n - j)
+        zr, zi = xr[:, src], np.where(direct[None, :], xi[:, src], -xi[:, src])
+        yr, yi = _cx_mul(zr, zi, hr[None, :obins], hi[None, :obins])
     elif sm > 1:
-        for k in range(obins):
-            acc = xs[:, k] * h[k]
-            j = k
-            for _ in range(1, sm):
-                j += w
-                if j <= half:
-                    p = xs[:, j] * h[j]
-                else:
-                    p = np.conj(xs[:, n - j] * h[n - j])
-                acc = acc + p
-            ys[:, k] = acc
+        kk = np.arange(obins)
+        yr, yi = _cx_mul(xr[:, kk], xi[:, kk], hr[None, kk], hi[None, kk])
+        j = kk.copy()
+        for _ in range(1, sm):
+            j = j + w
+            direct = j <= half
+            src = np.where(direct, j, n - j)
+            pr, pi = _cx_mul(xr[:, src], xi[:, src], hr[None, src], hi[None, src])
+            pi = np.where(direct[None, :], pi, -pi)
+            yr, yi = yr + pr, yi + pi
     else:
-        ys[:] = xs[:, :obins] * h[None, :obins]
-    return ys
+        yr, yi = _cx_mul(xr[:, :obins], xi[:, :obins], hr[None, :obins], hi[None, :obins])
+    return yr + 1j * yi
 
 
 def ols_transform(x: np.ndarray, oh: np.ndarray, n: int, l: int, m: int) -> np.ndarray:

@@ -15,6 +15,7 @@ from . import stft as Stft
 from . import mel as Mel
 from . import window as Window
 from . import fir as Fir
+from . import resample as Resample
 from . import chroma as Chroma
 from . import convert as Convert
 from .features import mel_spectrogram, mfcc, chroma_stft, power_to_db, amplitude_to_db
@@ -40,6 +41,6 @@ def device_count() -> int:
     return n.value
 
 
-__all__ = ["Stft", "Mel", "Chroma", "Convert", "Window", "Fir", "mel_spectrogram", "mfcc", "chroma_stft", "power_to_db", "amplitude_to_db", "spectral_centroid",
+__all__ = ["Stft", "Mel", "Chroma", "Convert", "Window", "Fir", "Resample", "mel_spectrogram", "mfcc", "chroma_stft", "power_to_db", "amplitude_to_db", "spectral_centroid",
            "spectral_bandwidth", "spectral_rolloff", "spectral_flatness", "shard", "set_interior", "set_scratch_retention", "device_count",
            "InvalidArgument", "Failure", "LIB_PATH"]

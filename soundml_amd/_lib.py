@@ -163,6 +163,15 @@ SIGNATURES = {
     "smx_mel_spectrogram_f32": (cint, [vp, vp, vp, i64, i64, f64, vp]),
     "smx_mel_spectrogram_f64": (cint, [vp, vp, vp, i64, i64, f64, vp]),
     "smx_mel_spectrogram_f32_dev": (cint, [vp, vp, vp, i64, i64, i64, f64, vp, vp]),
+    "smx_resample_ols_geom": (cint, [i64, i64, i64, i64, pi64, pi64, pi64, C.POINTER(cint)]),
+    "smx_resample_prototype": (cint, [i64, i64, f64, f64, vp]),
+    "smx_resample_shape_c128": (cint, [vp, vp, vp, i64, i64, i64, i64]),
+    "smx_resample_shape_c128_dev": (cint, [vp, vp, vp, i64, i64, i64, i64, vp]),
+    "smx_resample_stage_create": (cint, [vp, i64, i64, i64, C.POINTER(vp)]),
+    "smx_resample_stage_destroy": (None, [vp]),
+    "smx_resample_stage_out_length": (i64, [vp, i64]),
+    "smx_resample_stage_apply_f32": (cint, [vp, vp, i64, i64, vp]),
+    "smx_resample_stage_apply_f32_dev": (cint, [vp, vp, i64, i64, i64, vp, i64, vp]),
     "smx_fir_kaiser_beta": (cint, [f64, pf64]),
     "smx_fir_design_lowpass": (cint, [i64, f64, f64, vp]),
     "smx_fir_plan_create": (cint, [vp, i64, C.POINTER(vp)]),

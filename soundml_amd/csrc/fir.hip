@@ -63,7 +63,8 @@ unsigned brev_host(unsigned v, int bits) {
 struct FirArgs {
   const float *x;
   float *y;
-  int64_t n, x_stride, y_stride;
+  int64_t n, x_stride, y_stride;   // n: input samples per channel
+  int64_t n_out, out_shift;         // convolution outputs [out_shift, out_shift + n_out) land at y[0 .. n_out)
   int64_t taps, nfft, valid;
   int log2n;
   int64_t pairs_per_channel;
@@ -119,8 +120,9 @@ __global__ void __launch_bounds__((1 << LOG2N) / 16) fir_ols_kernel(FirArgs a) {
     for (int j = 0; j < RL; ++j) {
       const int idx = out_index<RL, NSL, T>(tid, i, j) - skip;   // position inside the valid span
       if (idx >= 0) {
-        if (out_a + idx < a.n) y[out_a + idx] = r[i * RL + j].x;      // Re(conj(.)) =  Re
-        if (out_b + idx < a.n) y[out_b + idx] = -r[i * RL + j].y;     // Im(conj(.)) = -Im
+        const int64_t oa = out_a + idx - a.out_shift, ob = out_b + idx - a.out_shift;
+        if (oa >= 0 && oa < a.n_out) y[oa] = r[i * RL + j].x;      // Re(conj(.)) =  Re
+        if (ob >= 0 && ob < a.n_out) y[ob] = -r[i * RL + j].y;     // Im(conj(.)) = -Im
       }
     }
 }
@@ -204,10 +206,10 @@ __global__ void __launch_bounds__((1 << LOG2M) / 16, 4) fir_ols_real_kernel(FirA
   int ti = tid;
   asm volatile("" : "+v"(ti));   // the inverse re-derives its LDS addresses instead of carrying the forward transform's in (spilled) registers
   fft_passes<LOG2M, false, false, float, true>(r, z, ti, a.tw_m);
-  const int64_t out0 = blk * a.step;
+  const int64_t out0 = blk * a.step - a.out_shift;   // y index of the block's first kept sample
   int to = tid;
   asm volatile("" : "+v"(to));
-  const bool whole = out0 + a.step <= a.n;   // every kept sample of this block exists (block-uniform)
+  const bool whole = out0 >= 0 && out0 + a.step <= a.n_out;   // every kept sample of this block is wanted (block-uniform)
 #pragma unroll
   for (int i = 0; i < GL; ++i)
 #pragma unroll
@@ -219,11 +221,79 @@ __global__ void __launch_bounds__((1 << LOG2M) / 16, 4) fir_ols_real_kernel(FirA
         if (ALIGNED && whole) {
           *reinterpret_cast<float2 *>(y + o) = make_float2(re, im);
         } else {
-          if (o < a.n) y[o] = re;
-          if (o + 1 < a.n) y[o + 1] = im;
+          if (o >= 0 && o < a.n_out) y[o] = re;
+          if (o + 1 >= 0 && o + 1 < a.n_out) y[o + 1] = im;
         }
       }
     }
+}
+
+// ---- resample stages ("Resample OLS stages -- true rate conversion on the FIR kernel") ----------
+// xu[c][q L] = x[c][q], zeros between: the interpolated-rate input of a xL stage
+__global__ void __launch_bounds__(256) zero_stuff_kernel(const float *x, int64_t n, int64_t x_stride, int l, float *xu,
+                                                         int64_t u_stride) {
+  const int64_t c = blockIdx.y;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n * l; i += (int64_t)gridDim.x * 256)
+    xu[c * u_stride + i] = (i % l == 0) ? x[c * x_stride + i / l] : 0.0f;
+}
+// y[c][i] = v[c][i M]: the kept phase of a /M stage
+__global__ void __launch_bounds__(256) decimate_kernel(const float *v, int64_t v_stride, int m, float *y, int64_t n_out,
+                                                       int64_t y_stride) {
+  const int64_t c = blockIdx.y;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n_out; i += (int64_t)gridDim.x * 256)
+    y[c * y_stride + i] = v[c * v_stride + i * m];
+}
+
+// The block identity of the reference's overlap-save executor, `soundml_resample_shape_run`
+// (resample_stubs.c:329-372), operation for operation in float64: one thread per output bin.  Every product is the
+// plain four-multiply form with each operation rounded on its own (see cx_mul_exact for what keeps hipcc
+// from contracting them into fused multiply-adds), and the /M fold adds its terms in ascending fold order, so the result is bit for
+// bit what the C stub computes.
+struct cx128 { double re, im; };
+__device__ __forceinline__ cx128 cx_mul_exact(cx128 a, cx128 b) {
+  // The library is built with -ffp-contract=fast, under which the backend fuses a product into the following add whatever
+  // the source says (HIP's __dmul_rn / __dadd_rn are plain operators, `#pragma clang fp contract(off)` does not survive
+  // inlining): the empty asm makes each rounded product opaque, so it cannot become half of a fused multiply-add.
+  cx128 r;
+  double p0 = a.re * b.re, p1 = a.im * b.im, p2 = a.re * b.im, p3 = a.im * b.re;
+  asm volatile("" : "+v"(p0), "+v"(p1), "+v"(p2), "+v"(p3));
+  r.re = p0 - p1;
+  r.im = p2 + p3;
+  return r;
+}
+__global__ void __launch_bounds__(256) resample_shape_kernel(const cx128 *x, const cx128 *h, cx128 *y, int64_t lines,
+                                                             int64_t n, int64_t sl, int64_t sm, int64_t w) {
+  const int64_t bins = n / 2 + 1, obins = w / 2 + 1, half = n / 2;
+  const int64_t total = lines * obins;
+  for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
+    const int64_t line = e / obins, k = e - line * obins;
+    const cx128 *xs = x + line * bins;
+    cx128 out;
+    if (sl > 1) {                       // xL: bin k reads full-grid bin k mod N of the block's spectrum
+      const int64_t j = k % n;
+      cx128 z = j <= half ? xs[j] : xs[n - j];
+      if (j > half) z.im = -z.im;
+      out = cx_mul_exact(z, h[k]);
+    } else if (sm > 1) {                // /M: product on the half grid, alias fold in ascending order
+      int64_t j = k;
+      out = cx_mul_exact(xs[k], h[k]);
+      for (int64_t r = 1; r < sm; ++r) {
+        j += w;
+        cx128 p;
+        if (j <= half) {
+          p = cx_mul_exact(xs[j], h[j]);
+        } else {
+          p = cx_mul_exact(xs[n - j], h[n - j]);
+          p.im = -p.im;
+        }
+        out.re = out.re + p.re;
+        out.im = out.im + p.im;
+      }
+    } else {
+      out = cx_mul_exact(xs[k], h[k]);
+    }
+    y[e] = out;
+  }
 }
 
 }  // namespace
@@ -313,17 +383,23 @@ int guarded_fir(F &&body) {
   }
 }
 
-void fir_apply_dev(const smx_fir_plan &p, const float *d_x, int64_t channels, int64_t n, int64_t x_stride,
-                   float *d_y, int64_t y_stride, hipStream_t stream) {
-  if (channels < 0 || n < 0) throw Failure("fir_apply: negative extent");
-  if (channels == 0 || n == 0) return;
-  if (x_stride < n || y_stride < n) throw Failure("fir_apply: stride smaller than the signal length");
+}  // namespace
+
+namespace smx {
+// y[c][i] = (h * x[c])[out_shift + i], i in [0, n_out): the convolution of n input samples (zeros outside), any window of it
+void fir_apply_window_dev(const smx_fir_plan &p, const float *d_x, int64_t channels, int64_t n, int64_t x_stride,
+                          float *d_y, int64_t y_stride, int64_t n_out, int64_t out_shift, hipStream_t stream) {
+  if (channels < 0 || n < 0 || n_out < 0 || out_shift < 0) throw Failure("fir_apply: negative extent");
+  if (channels == 0 || n_out == 0) return;
+  if (x_stride < n || y_stride < n_out) throw Failure("fir_apply: stride smaller than the signal length");
   if (!d_x || !d_y) throw Failure("fir_apply: null device pointer");
   const smx_fir_plan::Tables &t = p.tables();
   FirArgs a{};
   a.x = d_x;
   a.y = d_y;
   a.n = n;
+  a.n_out = n_out;
+  a.out_shift = out_shift;
   a.x_stride = x_stride;
   a.y_stride = y_stride;
   a.taps = p.taps;
@@ -339,12 +415,12 @@ void fir_apply_dev(const smx_fir_plan &p, const float *d_x, int64_t channels, in
   if (!packed) {   // one real block per workgroup, half-size transform
     a.lead = (p.taps - 1 + 1) & ~int64_t(1);                 // even, >= taps - 1
     a.step = p.nfft - a.lead;
-    a.blocks_per_channel = (n + a.step - 1) / a.step;
+    a.blocks_per_channel = (out_shift + n_out + a.step - 1) / a.step;
     const int64_t grid = channels * a.blocks_per_channel;
     if (grid > 0x7fffffff) throw Failure("fir_apply: too many blocks for one launch");
     const size_t lds = (size_t)(p.nfft / 2) * sizeof(float2);
-    const bool aligned = x_stride % 2 == 0 && y_stride % 2 == 0 && reinterpret_cast<uintptr_t>(d_x) % 8 == 0 &&
-                         reinterpret_cast<uintptr_t>(d_y) % 8 == 0;
+    const bool aligned = x_stride % 2 == 0 && y_stride % 2 == 0 && out_shift % 2 == 0 &&
+                         reinterpret_cast<uintptr_t>(d_x) % 8 == 0 && reinterpret_cast<uintptr_t>(d_y) % 8 == 0;
     auto launch = [&](auto kernel, int threads) {
       SMX_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kernel),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -362,7 +438,7 @@ void fir_apply_dev(const smx_fir_plan &p, const float *d_x, int64_t channels, in
     SMX_HIP_CHECK(hipGetLastError());
     return;
   }
-  const int64_t blocks = (n + p.valid - 1) / p.valid;
+  const int64_t blocks = (out_shift + n_out + p.valid - 1) / p.valid;
   a.pairs_per_channel = (blocks + 1) / 2;
   const int64_t grid = channels * a.pairs_per_channel;
   if (grid > 0x7fffffff) throw Failure("fir_apply: too many blocks for one launch");
@@ -381,6 +457,16 @@ void fir_apply_dev(const smx_fir_plan &p, const float *d_x, int64_t channels, in
     default: throw Failure("fir_apply: unsupported block size");
   }
   SMX_HIP_CHECK(hipGetLastError());
+}
+}  // namespace smx
+
+namespace {
+void fir_apply_dev(const smx_fir_plan &p, const float *d_x, int64_t channels, int64_t n, int64_t x_stride,
+                   float *d_y, int64_t y_stride, hipStream_t stream) {
+  if (!d_x || !d_y) {
+    if (channels > 0 && n > 0) throw Failure("fir_apply: null device pointer");
+  }
+  fir_apply_window_dev(p, d_x, channels, n, x_stride, d_y, y_stride, n, 0, stream);
 }
 }  // namespace
 
@@ -464,6 +550,220 @@ int smx_fir_apply_f32(const smx_fir_plan *p, const float *x, int64_t channels, i
     }
     (void)hipFree(dx);
     (void)hipFree(dy);
+  });
+}
+
+
+/* ---- Resample stages ------------------------------------------------------------------------------------------- */
+}  // extern "C"
+
+struct smx_resample_stage {
+  int64_t l = 1, m = 1, k = 0;
+  smx_fir_plan *fir = nullptr;
+  ~smx_resample_stage() { delete fir; }
+};
+
+namespace {
+// resample.ml:279-300
+bool ols_geom_host(int64_t rate, int64_t l, int64_t m, int64_t k, int64_t &n, int64_t &b, int64_t &delta) {
+  const int64_t f_div = l == 1 ? m : 1;
+  const int64_t target = std::max<int64_t>(64, 10 * k);
+  n = f_div % 3 == 0 ? 3 : 1;
+  while (n < target) n *= 2;
+  if (n * 1000 > 130 * rate) return false;          // ols_ceiling_ms
+  b = (n - 2 * k) / f_div * f_div;
+  delta = (f_div - (3 * k % f_div)) % f_div;
+  return b >= 1;
+}
+
+void shape_check(int64_t lines, int64_t n, int64_t sl, int64_t sm, int64_t &w) {   // resample_stubs.c:383-389
+  if (lines < 0 || n < 2 || (n % 2) != 0 || sl < 1 || sm < 1 || (sl > 1 && sm > 1))
+    throw Failure("soundml_resample_shape: invalid geometry");
+  w = sl > 1 ? n * sl : (sm > 1 ? n / sm : n);
+  if (w < 2 || (sm > 1 && (n % sm) != 0)) throw Failure("soundml_resample_shape: invalid geometry");
+}
+
+void shape_dev(const double *d_x, const double *d_h, double *d_y, int64_t lines, int64_t n, int64_t sl, int64_t sm,
+               hipStream_t stream) {
+  int64_t w = 0;
+  shape_check(lines, n, sl, sm, w);
+  const int64_t total = lines * (w / 2 + 1);
+  if (total == 0) return;
+  if (!d_x || !d_h || !d_y) throw Failure("soundml_resample_shape: null device pointer");
+  const int64_t blocks = std::min<int64_t>((total + 255) / 256, 4096);
+  SMX_LAUNCH(smx::resample_shape_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, reinterpret_cast<const smx::cx128 *>(d_x),
+             reinterpret_cast<const smx::cx128 *>(d_h), reinterpret_cast<smx::cx128 *>(d_y), lines, n, sl, sm, w);
+  SMX_HIP_CHECK(hipGetLastError());
+}
+
+int64_t stage_out_length(const smx_resample_stage &s, int64_t n) { return (n * s.l + s.m - 1) / s.m; }   // ceil(n L / M)
+
+// y[c][i] = sum_t proto[t] xu[c][i M + K L - t], xu = x zero-stuffed by L (resample.ml:1318-1326): the stage's
+// definition, run as ONE block convolution at the interpolated rate on the FIR kernel, windowed at the group delay
+void stage_apply_dev(const smx_resample_stage &s, const float *d_x, int64_t channels, int64_t n, int64_t x_stride,
+                     float *d_y, int64_t y_stride, hipStream_t stream) {
+  if (channels < 0 || n < 0) throw Failure("resample_stage: negative extent");
+  const int64_t n_out = stage_out_length(s, n);
+  if (channels == 0 || n_out == 0) return;
+  if (x_stride < n || y_stride < n_out) throw Failure("resample_stage: stride smaller than the signal length");
+  if (!d_x || !d_y) throw Failure("resample_stage: null device pointer");
+  smx::init_device_pool();
+  const float *xin = d_x;
+  int64_t n_in = n, in_stride = x_stride;
+  float *xu = nullptr, *v = nullptr;
+  if (s.l > 1) {
+    n_in = n * s.l;
+    in_stride = (n_in + 1) & ~int64_t(1);
+    SMX_HIP_CHECK(hipMallocAsync((void **)&xu, (size_t)channels * (size_t)in_stride * sizeof(float), stream));
+    const int64_t gx = std::min<int64_t>((n_in + 255) / 256, 2048);
+    SMX_LAUNCH(smx::zero_stuff_kernel, dim3((unsigned)gx, (unsigned)channels), dim3(256), 0, stream, d_x, n, x_stride, (int)s.l, xu,
+               in_stride);
+    xin = xu;
+  }
+  const int64_t shift = s.k * s.l;
+  if (s.m == 1) {
+    smx::fir_apply_window_dev(*s.fir, xin, channels, n_in, in_stride, d_y, y_stride, n_out, shift, stream);
+  } else {
+    const int64_t nv = (n_out - 1) * s.m + 1, v_stride = (nv + 1) & ~int64_t(1);
+    SMX_HIP_CHECK(hipMallocAsync((void **)&v, (size_t)channels * (size_t)v_stride * sizeof(float), stream));
+    smx::fir_apply_window_dev(*s.fir, xin, channels, n_in, in_stride, v, v_stride, nv, shift, stream);
+    const int64_t gy = std::min<int64_t>((n_out + 255) / 256, 2048);
+    SMX_LAUNCH(smx::decimate_kernel, dim3((unsigned)gy, (unsigned)channels), dim3(256), 0, stream, v, v_stride, (int)s.m, d_y, n_out,
+               y_stride);
+  }
+  SMX_HIP_CHECK(hipGetLastError());
+  if (xu) SMX_HIP_CHECK(hipFreeAsync(xu, stream));
+  if (v) SMX_HIP_CHECK(hipFreeAsync(v, stream));
+}
+
+void require_hip_device() {
+  int count = 0;
+  if (hipGetDeviceCount(&count) != hipSuccess || count < 1)
+    throw Failure("soundml_amd: no HIP device is available (this library has no CPU fallback)");
+}
+}  // namespace
+
+extern "C" {
+
+int smx_resample_ols_geom(int64_t rate, int64_t l, int64_t m, int64_t k, int64_t *n, int64_t *b, int64_t *delta,
+                          int *eligible) {
+  return guarded_fir([&] {
+    if (rate < 1 || l < 1 || m < 1 || k < 0) throw Failure("ols_geom: invalid stage");
+    int64_t nn = 0, bb = 0, dd = 0;
+    const bool ok = ols_geom_host(rate, l, m, k, nn, bb, dd);
+    if (eligible) *eligible = ok ? 1 : 0;
+    if (n) *n = ok ? nn : 0;
+    if (b) *b = ok ? bb : 0;
+    if (delta) *delta = ok ? dd : 0;
+  });
+}
+
+int smx_resample_prototype(int64_t l, int64_t k, double fc, double beta, double *h) {
+  return guarded_fir([&] {   // resample.ml:145-163 `design_prototype`: right half evaluated, left half mirrored, sum = L
+    if (l < 1 || k < 0) throw Failure("design_prototype: invalid stage");
+    if (!h) throw Failure("design_prototype: null output");
+    const int64_t mid = k * l, n = 2 * mid + 1;
+    const double i0_beta = bessel_i0(beta);
+    for (int64_t i = mid; i < n; ++i) {
+      const double z = (double)(i - mid);
+      const double sv = i == mid ? fc : std::sin(M_PI * fc * z) / (M_PI * z);
+      const double r = mid > 0 ? z / (double)mid : 0.0;
+      const double v = sv * (bessel_i0(beta * std::sqrt(1.0 - r * r)) / i0_beta);
+      h[i] = v;
+      h[n - 1 - i] = v;
+    }
+    double sum = 0.0;
+    for (int64_t i = 0; i < n; ++i) sum += h[i];
+    const double gain = (double)l / sum;
+    for (int64_t i = 0; i < n; ++i) h[i] = h[i] * gain;
+  });
+}
+
+int smx_resample_shape_c128_dev(const double *d_x, const double *d_h, double *d_y, int64_t lines, int64_t n, int64_t sl,
+                                int64_t sm, void *stream) {
+  return guarded_fir([&] { shape_dev(d_x, d_h, d_y, lines, n, sl, sm, (hipStream_t)stream); });
+}
+
+int smx_resample_shape_c128(const double *x, const double *h, double *y, int64_t lines, int64_t n, int64_t sl, int64_t sm) {
+  return guarded_fir([&] {
+    int64_t w = 0;
+    shape_check(lines, n, sl, sm, w);
+    if (lines == 0) return;
+    if (!x || !h || !y) throw Failure("soundml_resample_shape: null pointer");
+    require_hip_device();
+    const size_t xb = (size_t)lines * (size_t)(n / 2 + 1) * 16, hb = (size_t)(sl > 1 ? w / 2 + 1 : n / 2 + 1) * 16,
+                 yb = (size_t)lines * (size_t)(w / 2 + 1) * 16;
+    double *dx = nullptr, *dh = nullptr, *dy = nullptr;
+    SMX_HIP_CHECK(hipMalloc((void **)&dx, xb));
+    SMX_HIP_CHECK(hipMalloc((void **)&dh, hb));
+    SMX_HIP_CHECK(hipMalloc((void **)&dy, yb));
+    try {
+      SMX_HIP_CHECK(hipMemcpy(dx, x, xb, hipMemcpyHostToDevice));
+      SMX_HIP_CHECK(hipMemcpy(dh, h, hb, hipMemcpyHostToDevice));
+      shape_dev(dx, dh, dy, lines, n, sl, sm, nullptr);
+      SMX_HIP_CHECK(hipStreamSynchronize(nullptr));
+      SMX_HIP_CHECK(hipMemcpy(y, dy, yb, hipMemcpyDeviceToHost));
+    } catch (...) {
+      (void)hipFree(dx); (void)hipFree(dh); (void)hipFree(dy);
+      throw;
+    }
+    (void)hipFree(dx); (void)hipFree(dh); (void)hipFree(dy);
+  });
+}
+
+int smx_resample_stage_create(const double *proto, int64_t l, int64_t m, int64_t k, smx_resample_stage **out) {
+  return guarded_fir([&] {
+    if (!out) throw Failure("resample_stage_create: null output handle");
+    if (l < 1 || m < 1 || k < 0)
+      throw InvalidArgument(format("resample_stage_create: cannot build a x%lld / %lld stage of group delay %lld "
+                                   "(factors must be at least 1, the delay non-negative)", (long long)l, (long long)m, (long long)k));
+    const int64_t taps = 2 * k * l + 1;
+    if (taps > 16384)
+      throw InvalidArgument(format("resample_stage_create: cannot run a %lld-tap prototype (this device path holds at "
+                                   "most 16384 taps per 32768-sample block)", (long long)taps));
+    if (!proto) throw Failure("resample_stage_create: null prototype");
+    smx_fir_plan *fir = nullptr;
+    if (smx_fir_plan_create(proto, taps, &fir) != SMX_OK) throw Failure(smx_last_error());
+    auto *s = new smx_resample_stage();
+    s->l = l; s->m = m; s->k = k; s->fir = fir;
+    *out = s;
+  });
+}
+void smx_resample_stage_destroy(smx_resample_stage *s) { delete s; }
+int64_t smx_resample_stage_out_length(const smx_resample_stage *s, int64_t n) { return s && n >= 0 ? stage_out_length(*s, n) : -1; }
+
+int smx_resample_stage_apply_f32_dev(const smx_resample_stage *s, const float *d_x, int64_t channels, int64_t n,
+                                     int64_t x_stride, float *d_y, int64_t y_stride, void *stream) {
+  return guarded_fir([&] {
+    if (!s) throw Failure("resample_stage: null stage");
+    stage_apply_dev(*s, d_x, channels, n, x_stride, d_y, y_stride, (hipStream_t)stream);
+  });
+}
+
+int smx_resample_stage_apply_f32(const smx_resample_stage *s, const float *x, int64_t channels, int64_t n, float *y) {
+  return guarded_fir([&] {
+    if (!s) throw Failure("resample_stage: null stage");
+    if (channels < 0 || n < 0) throw Failure("resample_stage: negative extent");
+    const int64_t n_out = stage_out_length(*s, n);
+    if (channels == 0 || n_out == 0) return;
+    if (!x || !y) throw Failure("resample_stage: null pointer");
+    require_hip_device();
+    float *dx = nullptr, *dy = nullptr;
+    SMX_HIP_CHECK(hipMalloc((void **)&dx, (size_t)channels * (size_t)n * sizeof(float)));
+    if (hipMalloc((void **)&dy, (size_t)channels * (size_t)n_out * sizeof(float)) != hipSuccess) {
+      (void)hipFree(dx);
+      throw Failure("resample_stage: device allocation failed");
+    }
+    try {
+      SMX_HIP_CHECK(hipMemcpy(dx, x, (size_t)channels * (size_t)n * sizeof(float), hipMemcpyHostToDevice));
+      stage_apply_dev(*s, dx, channels, n, n, dy, n_out, nullptr);
+      SMX_HIP_CHECK(hipStreamSynchronize(nullptr));
+      SMX_HIP_CHECK(hipMemcpy(y, dy, (size_t)channels * (size_t)n_out * sizeof(float), hipMemcpyDeviceToHost));
+    } catch (...) {
+      (void)hipFree(dx); (void)hipFree(dy);
+      throw;
+    }
+    (void)hipFree(dx); (void)hipFree(dy);
   });
 }
 

@@ -1,0 +1,91 @@
+"""Resample: the overlap-save executor's pieces on the device.
+
+The reference's planner / polyphase bank / cascade logic stay where they are (resample.ml); this mirrors the three
+internal pieces a maintainer would route to the device: the OLS geometry, the prototype design, the block identity of
+``soundml_resample_shape`` (resample_stubs.c:329-422) and one whole stage (``ols_run`` + drain) as a block convolution.
+
+    proto = Resample.prototype(l=2, k=160, fc=0.45 / 2, beta=Fir.kaiser_beta(100.0))
+    st = Resample.Stage.create(proto, l=2, m=1, k=160)
+    y = Resample.Stage.apply(st, x)            # [...; n] -> [...; ceil(n L / M)]
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from ._lib import check, lib
+from ._tensor import Batch, out_ptr, prod
+
+
+def ols_geom(rate: int, l: int, m: int, k: int):
+    """resample.ml:292-300: (N, B, delta), or None when the stage is not OLS-eligible."""
+    n, b, d, ok = C.c_int64(), C.c_int64(), C.c_int64(), C.c_int()
+    check(lib.smx_resample_ols_geom(int(rate), int(l), int(m), int(k), C.byref(n), C.byref(b), C.byref(d), C.byref(ok)))
+    return (n.value, b.value, d.value) if ok.value else None
+
+
+def prototype(l: int, k: int, fc: float, beta: float) -> np.ndarray:
+    """resample.ml:145-163 `design_prototype`: 2 K L + 1 taps, float64, sum = L."""
+    h = np.empty(2 * int(k) * int(l) + 1, dtype=np.float64)
+    check(lib.smx_resample_prototype(int(l), int(k), float(fc), float(beta), C.c_void_p(h.ctypes.data)))
+    return h
+
+
+def shape(x: np.ndarray, h: np.ndarray, n: int, sl: int = 1, sm: int = 1) -> np.ndarray:
+    """`soundml_resample_shape` (resample_stubs.c:329-422): complex128 half spectra [lines; n/2+1] -> [lines; w/2+1]."""
+    x = np.ascontiguousarray(x, dtype=np.complex128)
+    h = np.ascontiguousarray(h, dtype=np.complex128)
+    lines = int(np.prod(x.shape[:-1])) if x.ndim > 1 else 1
+    if n < 2 or n % 2 or sl < 1 or sm < 1 or (sl > 1 and sm > 1) or (sm > 1 and n % sm) or (n // sm if sm > 1 else n) < 2:
+        raise _lib.Failure("soundml_resample_shape: invalid geometry")      # resample_stubs.c:383-389, checked first
+    w = n * sl if sl > 1 else (n // sm if sm > 1 else n)
+    if x.shape[-1] < n // 2 + 1 or h.shape[-1] < (w // 2 + 1 if sl > 1 else n // 2 + 1):
+        raise _lib.Failure("soundml_resample_shape: buffer extents disagree")
+    out = np.empty(x.shape[:-1] + (max(w, 0) // 2 + 1,), dtype=np.complex128)
+    check(lib.smx_resample_shape_c128(C.c_void_p(x.ctypes.data), C.c_void_p(h.ctypes.data), C.c_void_p(out.ctypes.data),
+                                      lines, int(n), int(sl), int(sm)))
+    return out
+
+
+class Stage:
+    def __init__(self, handle, l, m, k):
+        self._h, self.l, self.m, self.k = handle, l, m, k
+
+    @staticmethod
+    def create(proto, l: int, m: int, k: int) -> "Stage":
+        proto = np.ascontiguousarray(np.asarray(proto, dtype=np.float64))
+        if proto.shape != (2 * int(k) * int(l) + 1,):
+            raise _lib.InvalidArgument("resample_stage_create: cannot use a %d-tap prototype for l = %d, k = %d (the "
+                                       "prototype has 2 K L + 1 taps)" % (proto.shape[0], l, k))
+        handle = C.c_void_p()
+        check(lib.smx_resample_stage_create(C.c_void_p(proto.ctypes.data), int(l), int(m), int(k), C.byref(handle)))
+        return Stage(handle, int(l), int(m), int(k))
+
+    def __del__(self):
+        h, self._h = getattr(self, "_h", None), None
+        if h and lib is not None:
+            try:
+                lib.smx_resample_stage_destroy(h)
+            except Exception:
+                pass
+
+    def out_length(self, n: int) -> int:
+        return lib.smx_resample_stage_out_length(self._h, int(n))
+
+    @staticmethod
+    def apply(st: "Stage", x):
+        b = Batch(x, "resample_stage")
+        if b.bytes != 4:
+            raise _lib.InvalidArgument("resample_stage: cannot resample float64 audio (this path is float32)")
+        n = int(b.shape[-1])
+        lead = prod(b.shape[:-1])
+        n_out = st.out_length(n)
+        out = b.empty(tuple(b.shape[:-1]) + (n_out,))
+        if b.device:
+            with b.device_guard():
+                check(lib.smx_resample_stage_apply_f32_dev(st._h, b.ptr(), lead, n, n, out_ptr(out), n_out, b.stream()))
+            return out
+        check(lib.smx_resample_stage_apply_f32(st._h, b.ptr(), lead, n, out_ptr(out)))
+        return b.wrap(out)

@@ -1071,6 +1071,53 @@ def test_fir_known_answers():
     np.testing.assert_allclose(ys[0, :255], np.cumsum(h), rtol=0, atol=2e-6)
 
 
+# ---- Resample: the overlap-save executor's pieces ----------------------------------------------------
+
+@pytest.mark.parametrize("l,m", [(1, 1), (2, 1), (3, 1), (4, 1), (1, 2), (1, 3), (1, 4)])
+def test_resample_shape_is_the_reference_stub_bit_for_bit(l, m):
+    """smx_resample_shape_c128 against the restated `soundml_resample_shape_run` (resample_stubs.c:329-372): float64,
+    same operations in the same order -> identical bits; lines are independent (a stack == its lines)."""
+    from soundml_amd import Resample
+    from oracle import c_oracle
+    rng = np.random.default_rng(7 * l + m)
+    n = 96 if m == 3 else 2048
+    k = 5
+    proto = rng.uniform(-1, 1, size=2 * k * l + 1)
+    oh = O.ols_plan_spectrum(proto, n, l, m)
+    spec = np.fft.rfft(rng.uniform(-1, 1, size=(9, n)), axis=-1)
+    got = Resample.shape(spec, oh, n, l, m)
+    assert np.array_equal(got, c_oracle.resample_shape(spec, oh, n, l, m))
+    assert np.array_equal(got, O.ols_shape(spec, oh, n, l, m))
+    assert np.array_equal(Resample.shape(spec[3:4], oh, n, l, m), got[3:4])
+
+
+@pytest.mark.parametrize("l,m,k,n", [(1, 1, 40, 50000), (2, 1, 160, 30001), (1, 2, 161, 60000), (1, 3, 100, 70001), (4, 1, 37, 15000),
+                                     (1, 4, 101, 90000), (3, 1, 50, 20000), (3, 2, 60, 40000), (1, 1, 40, 10), (2, 1, 40, 1),
+                                     (2, 1, 4095, 50000)])
+def test_resample_stage_vs_oracle(l, m, k, n):
+    """One stage on the device against its definition (the direct polyphase sum) AND against the restated overlap-save
+    executor on the reference's own block grid (ols_run + drain): ceil(n L / M) outputs.  float32 interior: the error of
+    an FFT convolution scales with the prototype's L1 gain (Resample is pinned by dB thresholds only in the reference,
+    test/resample/resample_quality.ml -- "parity unpinned")."""
+    from soundml_amd import Resample
+    rng = np.random.default_rng(k + n)
+    proto = Resample.prototype(l, k, 0.45 / max(l, m), O.kaiser_beta(100.0))
+    x = rng.uniform(-1, 1, size=(2, n)).astype(np.float32)
+    st = Resample.Stage.create(proto, l, m, k)
+    got = Resample.Stage.apply(st, x)
+    want = O.resample_stage_direct(proto, l, m, k, x.astype(np.float64))
+    assert got.shape == want.shape == (2, -(-n * l // m)) and got.dtype == np.float32
+    bound = 1e-5 * np.sum(np.abs(proto))
+    assert np.max(np.abs(got.astype(np.float64) - want)) <= bound
+    geom = O.ols_geom(10 ** 9, l, m, k) if (l == 1 or m == 1) and max(l, m) <= 4 else None
+    if geom is not None and n > 1000:
+        exe = O.ols_stage(proto, l, m, k, geom, x.astype(np.float64))
+        assert np.max(np.abs(got.astype(np.float64) - exe)) <= bound
+    import torch
+    xd = torch.from_numpy(x).cuda()
+    assert np.array_equal(Resample.Stage.apply(st, xd).cpu().numpy(), got)       # device path == host path
+
+
 # ---- BASELINE sizes: size-independent properties -------------------------------------------------------
 
 def test_c2_full_size_properties():

@@ -432,3 +432,24 @@ def test_mel_scale_maps_match_the_oracle():
     assert S.Convert.hz_to_mel(np.float32([440.0])).dtype == np.float32
     with pytest.raises(S.InvalidArgument):
         S.Convert.hz_to_mel(f, "bark")
+
+
+# ---- Resample: host pieces of the overlap-save executor (no device needed) --------------------------------------------
+
+def test_resample_geometry_and_prototype_match_the_oracle():
+    from soundml_amd import Resample
+    for rate, l, m, k in [(96000, 2, 1, 160), (96000, 1, 2, 161), (96000, 1, 3, 100), (96000, 1, 4, 101), (48000, 1, 3, 100),
+                          (8000, 1, 1, 1000), (44100, 4, 1, 37), (1, 1, 1, 5)]:
+        assert Resample.ols_geom(rate, l, m, k) == O.ols_geom(rate, l, m, k)
+    for l, k, fc, att in [(1, 40, 0.45, 80.0), (2, 160, 0.225, 100.0), (3, 50, 0.15, 60.0), (4, 20, 0.11, 120.0), (1, 0, 0.5, 80.0)]:
+        beta = O.kaiser_beta(att)
+        h = Resample.prototype(l, k, fc, beta)
+        want = O.resample_prototype(l, k, fc, beta)
+        np.testing.assert_allclose(h, want, rtol=1e-13, atol=1e-18)
+        np.testing.assert_array_equal(h, h[::-1])            # exact mirror (resample.ml:145-163)
+        assert abs(h.sum() - l) <= 1e-12 * l
+    with pytest.raises(S.InvalidArgument):
+        Resample.Stage.create(np.ones(5), 2, 1, 3)           # 2 K L + 1 = 13 taps expected
+    with pytest.raises(S.Failure) as e:
+        Resample.shape(np.zeros((1, 4), np.complex128), np.zeros(4, np.complex128), 6, 2, 2)
+    assert str(e.value) == "soundml_resample_shape: invalid geometry"
