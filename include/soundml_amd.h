@@ -97,9 +97,11 @@ unsigned long long smx_debug_kernel_launches(void);
 int smx_device_count(int *count);
 int smx_set_device(int device);        /* device used by this thread's subsequent calls */
 int smx_set_interior(int interior);    /* SMX_INTERIOR_*, process-wide default for f32 audio */
-/* Scratch arrays (Griffin-Lim's spectra, scratch spectrograms, small tables) come from the device's stream-ordered
- * memory pool; the library keeps up to `bytes` of freed scratch per device for reuse instead of returning it to the
- * driver at every synchronisation (default: 1/8 of the device's memory; 0 = keep nothing; -1 = the default again). */
+/* Scratch arrays (Griffin-Lim's spectra, scratch spectrograms, small tables) come from a stream-ordered memory pool
+ * that the library creates for itself on each device (the process-wide default pool is never touched); it keeps up to
+ * `bytes` of freed scratch per device for reuse instead of returning it to the driver at every synchronisation
+ * (default: 1/8 of the device's memory, at most 16 GiB; 0 = keep nothing; -1 = the default again).  Memory held this
+ * way is not visible to another allocator in the process (e.g. torch's): lower it when embedding. */
 int smx_set_scratch_retention(int64_t bytes);
 int smx_get_interior(void);
 int smx_synchronize(void *stream);
@@ -150,6 +152,11 @@ int smx_stft_power_spectrum_f32(const smx_stft_config *c, const float *x, int64_
                                 double power, float *out);
 int smx_stft_power_spectrum_f64(const smx_stft_config *c, const double *x, int64_t lead, int64_t n,
                                 double power, double *out);
+/* |frames [p0, p1)|^power: transform_range (stft.ml:652-666) followed by magnitude_pow (stft.ml:670-674) */
+int smx_stft_power_range_f32(const smx_stft_config *c, const float *x, int64_t lead, int64_t n, int64_t p0,
+                             int64_t p1, double power, float *out);
+int smx_stft_power_range_f64(const smx_stft_config *c, const double *x, int64_t lead, int64_t n, int64_t p0,
+                             int64_t p1, double power, double *out);
 /* device-resident forms (the batch API the benchmark and the sharded driver use) */
 int smx_stft_transform_range_f32_dev(const smx_stft_config *c, const float *d_x, int64_t lead,
                                      int64_t n, int64_t x_stride, int64_t p0, int64_t p1,

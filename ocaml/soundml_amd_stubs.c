@@ -63,7 +63,10 @@ CAMLprim value soundml_amd_stft_config(value v_fft, value v_win_length, value v_
   smx_raise(smx_stft_config_create(Long_val(v_fft), win_length, Long_val(v_hop), Int_val(v_alignment),
                                    Int_val(v_pad), Double_val(v_pad_value), Int_val(v_scale),
                                    SMX_WINDOW_CUSTOM, (const double *)Caml_ba_data_val(v_window), &c));
-  v_handle = caml_alloc_custom(&stft_ops, sizeof(smx_stft_config *), 0, 1);
+  /* out-of-heap footprint of a handle: the float64 window and, once used, ~10 device tables (window, twiddles;
+   * 100 - 300 KB for the usual sizes): tell the GC, so that dropped handles are finalised (device memory returned)
+   * at a rate that matches what they hold */
+  v_handle = caml_alloc_custom_mem(&stft_ops, sizeof(smx_stft_config *), (mlsize_t)(64 * 1024 + 40 * Long_val(v_fft)));
   Stft_val(v_handle) = c;
   CAMLreturn(v_handle);
 }
@@ -102,10 +105,10 @@ CAMLprim value soundml_amd_stft_range(value v_cfg, value v_x, value v_out, value
     status = kind == CAML_BA_FLOAT32
                  ? smx_stft_transform_range_f32(c, (const float *)x, lead, n, p0, p1, (float *)out)
                  : smx_stft_transform_range_f64(c, (const double *)x, lead, n, p0, p1, (double *)out);
-  else   /* the host entry points analyse every frame; [p0, p1) must be the whole grid here */
+  else   /* the same frame range, |.|^power fused on the device: out holds exactly [lead; bins; p1 - p0] */
     status = kind == CAML_BA_FLOAT32
-                 ? smx_stft_power_spectrum_f32(c, (const float *)x, lead, n, power, (float *)out)
-                 : smx_stft_power_spectrum_f64(c, (const double *)x, lead, n, power, (double *)out);
+                 ? smx_stft_power_range_f32(c, (const float *)x, lead, n, p0, p1, power, (float *)out)
+                 : smx_stft_power_range_f64(c, (const double *)x, lead, n, p0, p1, power, (double *)out);
   caml_acquire_runtime_system();
   smx_raise(status);
   CAMLreturn(Val_unit);
@@ -126,7 +129,8 @@ CAMLprim value soundml_amd_mel_config(value v_n_mels, value v_sample_rate, value
   smx_raise(smx_mel_config_create(Long_val(v_n_mels), Long_val(v_sample_rate), Long_val(v_fft),
                                   Double_val(v_f_min), 1, Double_val(v_f_max), Int_val(v_scale),
                                   Int_val(v_norm), &c));
-  v_handle = caml_alloc_custom(&mel_ops, sizeof(smx_mel_config *), 0, 1);
+  v_handle = caml_alloc_custom_mem(&mel_ops, sizeof(smx_mel_config *),
+                                   (mlsize_t)(20 * Long_val(v_n_mels) * (Long_val(v_fft) / 2 + 1)));   /* f64 + f32 weights */
   Mel_val(v_handle) = c;
   CAMLreturn(v_handle);
 }
@@ -335,7 +339,8 @@ CAMLprim value soundml_amd_chroma_config(value v_n_chroma, value v_tuning, value
   smx_chroma_config *c = NULL;
   smx_raise(smx_chroma_config_create(Long_val(v_n_chroma), Double_val(v_tuning), Double_val(v_ctroct), octwidth >= 0.0,
                                      octwidth, Bool_val(v_base_c), Long_val(v_sample_rate), Long_val(v_fft), &c));
-  v_handle = caml_alloc_custom(&chroma_ops, sizeof(smx_chroma_config *), 0, 1);
+  v_handle = caml_alloc_custom_mem(&chroma_ops, sizeof(smx_chroma_config *),
+                                   (mlsize_t)(20 * Long_val(v_n_chroma) * (Long_val(v_fft) / 2 + 1)));
   Chroma_val(v_handle) = c;
   CAMLreturn(v_handle);
 }
@@ -401,4 +406,259 @@ CAMLprim value soundml_amd_to_db(value v_amplitude, value v_s, value v_out, valu
 CAMLprim value soundml_amd_to_db_bc(value *argv, int argn) {
   (void)argn;
   return soundml_amd_to_db(argv[0], argv[1], argv[2], argv[3], argv[4], argv[5]);
+}
+
+
+/* ---- Stft.Kernel (stft.ml:366-622) and Stft.power_stage's body (stft.ml:1364-1409): the streaming face --------------
+ * The device-resident state machine of the library: carry, prelude and tail live in device memory; a step uploads one
+ * chunk and downloads the frames that completed.  Mutable and single-owner like the reference's kernels
+ * (stft.mli:436-437): the OCaml value owns it, the finaliser destroys it.  power < 0 = the complex face. */
+#define Kernel_val(v) (*((smx_stft_kernel **)Data_custom_val(v)))
+static void kernel_finalize(value v) { smx_stft_kernel_destroy(Kernel_val(v)); }
+static struct custom_operations kernel_ops = {"soundml.amd.stft_kernel", kernel_finalize, custom_compare_default,
+                                              custom_hash_default, custom_serialize_default,
+                                              custom_deserialize_default, custom_compare_ext_default,
+                                              custom_fixed_length_default};
+
+CAMLprim value soundml_amd_kernel_prepare(value v_cfg, value v_wide, value v_channels, value v_max_block, value v_power) {
+  CAMLparam5(v_cfg, v_wide, v_channels, v_max_block, v_power);
+  CAMLlocal1(v_handle);
+  const smx_stft_config *c = Stft_val(v_cfg);
+  const int dtype_bytes = Bool_val(v_wide) ? 8 : 4;
+  const double power = Double_val(v_power);
+  smx_stft_kernel *k = NULL;
+  if (power < 0.0)
+    smx_raise(smx_stft_kernel_prepare(c, dtype_bytes, Long_val(v_channels), Long_val(v_max_block), &k));
+  else
+    smx_raise(smx_stft_kernel_prepare_power(c, dtype_bytes, Long_val(v_channels), Long_val(v_max_block), power, &k));
+  v_handle = caml_alloc_custom_mem(&kernel_ops, sizeof(smx_stft_kernel *),
+                                   (mlsize_t)(Long_val(v_channels) * 4 * smx_stft_config_fft_size(c) * dtype_bytes));
+  Kernel_val(v_handle) = k;
+  CAMLreturn(v_handle);
+}
+
+CAMLprim value soundml_amd_kernel_frame_bound(value v_k) {
+  CAMLparam1(v_k);
+  int64_t bound = 0;
+  smx_raise(smx_stft_kernel_frame_bound(Kernel_val(v_k), &bound));
+  CAMLreturn(Val_long(bound));
+}
+
+/* Kernel.step / Kernel.flush: chunk [channels; m] (m = 0 and is_flush = true for the drain) -> frames written into
+ * out [channels; bins; capacity] (complex or real by the kernel's face); returns the number of frames emitted, which the
+ * OCaml side slices off (0 = the reference's None). */
+CAMLprim value soundml_amd_kernel_step(value v_k, value v_chunk, value v_out, value v_channels, value v_m,
+                                       value v_capacity, value v_is_flush) {
+  CAMLparam5(v_k, v_chunk, v_out, v_channels, v_m);
+  CAMLxparam2(v_capacity, v_is_flush);
+  smx_stft_kernel *k = Kernel_val(v_k);
+  const int64_t channels = Long_val(v_channels), m = Long_val(v_m), capacity = Long_val(v_capacity);
+  const int is_flush = Bool_val(v_is_flush);
+  if (channels < 1 || m < 0 || capacity < 0) caml_failwith("soundml_amd: invalid geometry");
+  if (!is_flush && ba_dim(v_chunk) < channels * m) caml_failwith("soundml_amd: buffer extents disagree with geometry");
+  int64_t bound = 0;
+  smx_raise(smx_stft_kernel_frame_bound(k, &bound));
+  if (capacity < bound) caml_failwith("soundml_amd: output capacity below the kernel's frame bound");
+  /* out is complex (2 components per element) or real; either way a Bigarray element is one spectrum value */
+  void *chunk = is_flush ? NULL : Caml_ba_data_val(v_chunk);
+  void *out = Caml_ba_data_val(v_out);
+  int64_t emitted = 0;
+  int status;
+  caml_release_runtime_system();
+  status = is_flush ? smx_stft_kernel_flush(k, out, capacity, &emitted) : smx_stft_kernel_step(k, chunk, m, out, capacity, &emitted);
+  caml_acquire_runtime_system();
+  smx_raise(status);
+  CAMLreturn(Val_long(emitted));
+}
+CAMLprim value soundml_amd_kernel_step_bc(value *argv, int argn) {
+  (void)argn;
+  return soundml_amd_kernel_step(argv[0], argv[1], argv[2], argv[3], argv[4], argv[5], argv[6]);
+}
+
+CAMLprim value soundml_amd_kernel_reset(value v_k) {
+  CAMLparam1(v_k);
+  smx_raise(smx_stft_kernel_reset(Kernel_val(v_k)));
+  CAMLreturn(Val_unit);
+}
+
+CAMLprim value soundml_amd_stage_numbers(value v_cfg, value v_max_items) {   /* (stage_latency, frame_bound max_items) */
+  CAMLparam2(v_cfg, v_max_items);
+  CAMLlocal1(v_pair);
+  const smx_stft_config *c = Stft_val(v_cfg);
+  v_pair = caml_alloc_tuple(2);
+  Store_field(v_pair, 0, Val_long(smx_stft_stage_latency(c)));
+  Store_field(v_pair, 1, Val_long(smx_stft_frame_bound(c, Long_val(v_max_items))));
+  CAMLreturn(v_pair);
+}
+
+/* Stft.griffin_lim (stft.ml:941-1017): magnitudes s [lead; bins; frames] -> signal [lead; out_len]; the whole loop on the
+ * device.  init: an empty Bigarray = the reference's default random phase; length < 0 = not given. */
+CAMLprim value soundml_amd_griffin_lim(value v_cfg, value v_s, value v_init, value v_out, value v_lead, value v_bins,
+                                       value v_frames, value v_n_iter, value v_momentum, value v_length) {
+  CAMLparam5(v_cfg, v_s, v_init, v_out, v_lead);
+  CAMLxparam5(v_bins, v_frames, v_n_iter, v_momentum, v_length);
+  const smx_stft_config *c = Stft_val(v_cfg);
+  const int64_t lead = Long_val(v_lead), bins = Long_val(v_bins), frames = Long_val(v_frames);
+  const int64_t n_iter = Long_val(v_n_iter), length = Long_val(v_length);
+  const double momentum = Double_val(v_momentum);
+  const int has_length = length >= 0;
+  const int kind = ba_kind(v_s);
+  if ((kind != CAML_BA_FLOAT32 && kind != CAML_BA_FLOAT64) || ba_kind(v_out) != kind)
+    caml_failwith("soundml_amd: unsupported or mixed dtypes");
+  int64_t out_len = length;
+  if (!has_length) smx_raise(smx_stft_output_length(c, frames < 0 ? 0 : frames, &out_len));
+  const int has_init = ba_dim(v_init) > 0;
+  if (lead < 0 || bins < 0 || frames < 0 || ba_dim(v_s) < lead * bins * frames || ba_dim(v_out) < lead * out_len ||
+      (has_init && (ba_kind(v_init) != kind || ba_dim(v_init) < lead * bins * frames)))
+    caml_failwith("soundml_amd: buffer extents disagree with geometry");
+  void *s = Caml_ba_data_val(v_s), *out = Caml_ba_data_val(v_out);
+  void *init = has_init ? Caml_ba_data_val(v_init) : NULL;
+  int status;
+  caml_release_runtime_system();
+  status = kind == CAML_BA_FLOAT32
+               ? smx_stft_griffin_lim_f32(c, (const float *)s, lead, bins, frames, n_iter, momentum, (const float *)init,
+                                          has_length, length, (float *)out)
+               : smx_stft_griffin_lim_f64(c, (const double *)s, lead, bins, frames, n_iter, momentum, (const double *)init,
+                                          has_length, length, (double *)out);
+  caml_acquire_runtime_system();
+  smx_raise(status);
+  CAMLreturn(Val_unit);
+}
+CAMLprim value soundml_amd_griffin_lim_bc(value *argv, int argn) {
+  (void)argn;
+  return soundml_amd_griffin_lim(argv[0], argv[1], argv[2], argv[3], argv[4], argv[5], argv[6], argv[7], argv[8], argv[9]);
+}
+
+/* Soundml.chroma_stft (soundml.ml:97-107), fused power spectrogram + projection + norm */
+CAMLprim value soundml_amd_chroma_stft(value v_stft, value v_chroma, value v_x, value v_out, value v_lead, value v_n,
+                                       value v_power, value v_norm, value v_p) {
+  CAMLparam5(v_stft, v_chroma, v_x, v_out, v_lead);
+  CAMLxparam4(v_n, v_power, v_norm, v_p);
+  const smx_stft_config *sc = Stft_val(v_stft);
+  const smx_chroma_config *cc = Chroma_val(v_chroma);
+  const int64_t lead = Long_val(v_lead), n = Long_val(v_n);
+  const int kind = ba_kind(v_x);
+  if ((kind != CAML_BA_FLOAT32 && kind != CAML_BA_FLOAT64) || ba_kind(v_out) != kind)
+    caml_failwith("soundml_amd: unsupported or mixed dtypes");
+  int64_t frames = 0;
+  smx_raise(smx_stft_frames(sc, n, &frames));
+  if (lead < 0 || ba_dim(v_x) < lead * n || ba_dim(v_out) < lead * smx_chroma_config_n_chroma(cc) * frames)
+    caml_failwith("soundml_amd: buffer extents disagree with geometry");
+  void *x = Caml_ba_data_val(v_x), *out = Caml_ba_data_val(v_out);
+  const double power = Double_val(v_power), p = Double_val(v_p);
+  const int norm = Int_val(v_norm);
+  int status;
+  caml_release_runtime_system();
+  status = kind == CAML_BA_FLOAT32 ? smx_chroma_stft_f32(sc, cc, (const float *)x, lead, n, power, norm, p, (float *)out)
+                                   : smx_chroma_stft_f64(sc, cc, (const double *)x, lead, n, power, norm, p, (double *)out);
+  caml_acquire_runtime_system();
+  smx_raise(status);
+  CAMLreturn(Val_unit);
+}
+CAMLprim value soundml_amd_chroma_stft_bc(value *argv, int argn) {
+  (void)argn;
+  return soundml_amd_chroma_stft(argv[0], argv[1], argv[2], argv[3], argv[4], argv[5], argv[6], argv[7], argv[8]);
+}
+
+/* ---- FIR block convolution (BASELINE config 4; the reference lists the module as planned) ---------------------------- */
+#define Fir_val(v) (*((smx_fir_plan **)Data_custom_val(v)))
+static void fir_finalize(value v) { smx_fir_plan_destroy(Fir_val(v)); }
+static struct custom_operations fir_ops = {"soundml.amd.fir_plan", fir_finalize, custom_compare_default,
+                                           custom_hash_default, custom_serialize_default,
+                                           custom_deserialize_default, custom_compare_ext_default,
+                                           custom_fixed_length_default};
+CAMLprim value soundml_amd_fir_plan(value v_taps) {   /* taps: float64 Bigarray */
+  CAMLparam1(v_taps);
+  CAMLlocal1(v_handle);
+  if (ba_kind(v_taps) != CAML_BA_FLOAT64) caml_failwith("soundml_amd: taps must be float64");
+  smx_fir_plan *p = NULL;
+  smx_raise(smx_fir_plan_create((const double *)Caml_ba_data_val(v_taps), ba_dim(v_taps), &p));
+  v_handle = caml_alloc_custom_mem(&fir_ops, sizeof(smx_fir_plan *), (mlsize_t)(16 * smx_fir_plan_block(p)));
+  Fir_val(v_handle) = p;
+  CAMLreturn(v_handle);
+}
+CAMLprim value soundml_amd_fir_apply(value v_plan, value v_x, value v_y, value v_channels, value v_n) {
+  CAMLparam5(v_plan, v_x, v_y, v_channels, v_n);
+  const smx_fir_plan *p = Fir_val(v_plan);
+  const int64_t channels = Long_val(v_channels), n = Long_val(v_n);
+  if (ba_kind(v_x) != CAML_BA_FLOAT32 || ba_kind(v_y) != CAML_BA_FLOAT32) caml_failwith("soundml_amd: unsupported dtype");
+  if (channels < 0 || n < 0 || ba_dim(v_x) < channels * n || ba_dim(v_y) < channels * n)
+    caml_failwith("soundml_amd: buffer extents disagree with geometry");
+  const float *x = (const float *)Caml_ba_data_val(v_x);
+  float *y = (float *)Caml_ba_data_val(v_y);
+  int status;
+  caml_release_runtime_system();
+  status = smx_fir_apply_f32(p, x, channels, n, y);
+  caml_acquire_runtime_system();
+  smx_raise(status);
+  CAMLreturn(Val_unit);
+}
+
+/* ---- Resample: the executor's two numeric pieces (resample.ml:1186-1196, 1456-1599) ----------------------------------
+ * soundml_amd_resample_shape has EXACTLY the signature of the reference's soundml_resample_shape (resample_stubs.c:377-
+ * 415): spectra, plan spectrum, destination (complex64-kind Bigarrays = interleaved complex128), lines, N, L, M -- so
+ *     external resample_shape_c : ... = "soundml_amd_resample_shape_bc" "soundml_amd_resample_shape"
+ * is the whole change in resample.ml.  Same validation, same messages, same bits. */
+CAMLprim value soundml_amd_resample_shape(value v_x, value v_h, value v_y, value v_lines, value v_n, value v_sl, value v_sm) {
+  CAMLparam5(v_x, v_h, v_y, v_lines, v_n);
+  CAMLxparam2(v_sl, v_sm);
+  const int64_t lines = Long_val(v_lines), n = Long_val(v_n), sl = Long_val(v_sl), sm = Long_val(v_sm);
+  if (lines < 0 || n < 2 || (n % 2) != 0 || sl < 1 || sm < 1 || (sl > 1 && sm > 1))
+    caml_failwith("soundml_resample_shape: invalid geometry");
+  const int64_t w = sl > 1 ? n * sl : (sm > 1 ? n / sm : n);
+  if (w < 2 || (sm > 1 && (n % sm) != 0)) caml_failwith("soundml_resample_shape: invalid geometry");
+  if (ba_kind(v_x) != CAML_BA_COMPLEX64 || ba_kind(v_h) != CAML_BA_COMPLEX64 || ba_kind(v_y) != CAML_BA_COMPLEX64)
+    caml_failwith("soundml_resample_shape: unsupported dtype");
+  const int64_t bins = (n / 2) + 1, obins = (w / 2) + 1;
+  if (ba_dim(v_x) < lines * bins || ba_dim(v_h) < (sl > 1 ? obins : bins) || ba_dim(v_y) < lines * obins)
+    caml_failwith("soundml_resample_shape: buffer extents disagree");
+  const double *x = (const double *)Caml_ba_data_val(v_x), *h = (const double *)Caml_ba_data_val(v_h);
+  double *y = (double *)Caml_ba_data_val(v_y);
+  int status;
+  caml_release_runtime_system();
+  status = smx_resample_shape_c128(x, h, y, lines, n, sl, sm);
+  caml_acquire_runtime_system();
+  smx_raise(status);
+  CAMLreturn(Val_unit);
+}
+CAMLprim value soundml_amd_resample_shape_bc(value *argv, int argn) {
+  (void)argn;
+  return soundml_amd_resample_shape(argv[0], argv[1], argv[2], argv[3], argv[4], argv[5], argv[6]);
+}
+
+#define Stage_val(v) (*((smx_resample_stage **)Data_custom_val(v)))
+static void stage_finalize(value v) { smx_resample_stage_destroy(Stage_val(v)); }
+static struct custom_operations stage_ops = {"soundml.amd.resample_stage", stage_finalize, custom_compare_default,
+                                             custom_hash_default, custom_serialize_default,
+                                             custom_deserialize_default, custom_compare_ext_default,
+                                             custom_fixed_length_default};
+CAMLprim value soundml_amd_resample_stage(value v_proto, value v_l, value v_m, value v_k) {   /* proto: float64, 2 K L + 1 */
+  CAMLparam4(v_proto, v_l, v_m, v_k);
+  CAMLlocal1(v_handle);
+  const int64_t l = Long_val(v_l), m = Long_val(v_m), k = Long_val(v_k);
+  if (ba_kind(v_proto) != CAML_BA_FLOAT64 || l < 1 || k < 0 || ba_dim(v_proto) != 2 * k * l + 1)
+    caml_failwith("soundml_amd: prototype disagrees with the stage");
+  smx_resample_stage *s = NULL;
+  smx_raise(smx_resample_stage_create((const double *)Caml_ba_data_val(v_proto), l, m, k, &s));
+  v_handle = caml_alloc_custom_mem(&stage_ops, sizeof(smx_resample_stage *), (mlsize_t)(32 * (2 * k * l + 1)));
+  Stage_val(v_handle) = s;
+  CAMLreturn(v_handle);
+}
+/* one whole stage over planar [channels; n] -> [channels; ceil(n L / M)] (what ols_run + drain emit for an offline apply) */
+CAMLprim value soundml_amd_resample_stage_apply(value v_stage, value v_x, value v_y, value v_channels, value v_n) {
+  CAMLparam5(v_stage, v_x, v_y, v_channels, v_n);
+  const smx_resample_stage *s = Stage_val(v_stage);
+  const int64_t channels = Long_val(v_channels), n = Long_val(v_n);
+  if (ba_kind(v_x) != CAML_BA_FLOAT32 || ba_kind(v_y) != CAML_BA_FLOAT32) caml_failwith("soundml_amd: unsupported dtype");
+  const int64_t n_out = smx_resample_stage_out_length(s, n < 0 ? 0 : n);
+  if (channels < 0 || n < 0 || ba_dim(v_x) < channels * n || ba_dim(v_y) < channels * n_out)
+    caml_failwith("soundml_amd: buffer extents disagree with geometry");
+  const float *x = (const float *)Caml_ba_data_val(v_x);
+  float *y = (float *)Caml_ba_data_val(v_y);
+  int status;
+  caml_release_runtime_system();
+  status = smx_resample_stage_apply_f32(s, x, channels, n, y);
+  caml_acquire_runtime_system();
+  smx_raise(status);
+  CAMLreturn(Val_unit);
 }

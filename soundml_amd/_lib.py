@@ -88,6 +88,8 @@ SIGNATURES = {
     "smx_stft_transform_range_f64": (cint, [vp, vp, i64, i64, i64, i64, vp]),
     "smx_stft_power_spectrum_f32": (cint, [vp, vp, i64, i64, f64, vp]),
     "smx_stft_power_spectrum_f64": (cint, [vp, vp, i64, i64, f64, vp]),
+    "smx_stft_power_range_f32": (cint, [vp, vp, i64, i64, i64, i64, f64, vp]),
+    "smx_stft_power_range_f64": (cint, [vp, vp, i64, i64, i64, i64, f64, vp]),
     "smx_stft_transform_range_f32_dev": (cint, [vp, vp, i64, i64, i64, i64, i64, vp, vp]),
     "smx_stft_transform_range_f64_dev": (cint, [vp, vp, i64, i64, i64, i64, i64, vp, vp]),
     "smx_stft_power_range_f32_dev": (cint, [vp, vp, i64, i64, i64, i64, i64, f64, vp, vp]),

@@ -63,7 +63,7 @@ struct DeviceScratch {  // RAII device allocation for the host-pointer entry poi
   explicit DeviceScratch(size_t bytes) {
     if (bytes == 0) bytes = 16;
     init_device_pool();
-    SMX_HIP_CHECK(hipMallocAsync(&ptr, bytes, nullptr));
+    SMX_HIP_CHECK(smx::pool_malloc_async(&ptr, bytes, nullptr));
   }
   ~DeviceScratch() { (void)hipFreeAsync(ptr, nullptr); }
   DeviceScratch(const DeviceScratch &) = delete;
@@ -405,6 +405,23 @@ int smx_stft_power_spectrum_f64(const smx_stft_config *c, const double *x, int64
     check_config(c, "power_spectrum");
     check_rank_extents("power_spectrum", lead, n);
     stft_range_host(*c, x, 8, lead, n, 0, c->frames(n), OUT_POWER, power, out);
+  });
+}
+
+// |frames [p0, p1)|^power from host memory: what an nx-tensor caller of a ranged power face gets (the OCaml stub's
+// mode 1 honours its range through these instead of writing every frame)
+int smx_stft_power_range_f32(const smx_stft_config *c, const float *x, int64_t lead, int64_t n, int64_t p0, int64_t p1,
+                             double power, float *out) {
+  return guarded([&] {
+    check_config(c, "transform_range");
+    stft_range_host(*c, x, 4, lead, n, p0, p1, OUT_POWER, power, out);
+  });
+}
+int smx_stft_power_range_f64(const smx_stft_config *c, const double *x, int64_t lead, int64_t n, int64_t p0, int64_t p1,
+                             double power, double *out) {
+  return guarded([&] {
+    check_config(c, "transform_range");
+    stft_range_host(*c, x, 8, lead, n, p0, p1, OUT_POWER, power, out);
   });
 }
 
@@ -902,7 +919,7 @@ void mel_spectrogram_dev(const smx_stft_config &sc, const smx_mel_config &mc, co
   // two-step form; scratch is stream-ordered
   void *scratch = nullptr;
   const size_t bytes = (size_t)lead * (size_t)sc.bins() * (size_t)count * (size_t)in_bytes;
-  SMX_HIP_CHECK(hipMallocAsync(&scratch, bytes, stream));
+  SMX_HIP_CHECK(smx::pool_malloc_async(&scratch, bytes, stream));
   job.stft.out = scratch;
   job.stft.out_stride = count;
   job.stft.out_offset = 0;
@@ -962,13 +979,13 @@ void griffin_lim_dev(const smx_stft_config &c, const void *d_s, int elem_bytes, 
     // the reference's loop is float64 throughout whatever the dtype of s (stft.ml:977, 1017): widen, run, narrow
     double *s64 = nullptr, *p64 = nullptr, *o64 = nullptr;
     const size_t n64 = (size_t)std::max<int64_t>(total, 1) * sizeof(double);
-    SMX_HIP_CHECK(hipMallocAsync((void **)&s64, n64, stream));
+    SMX_HIP_CHECK(smx::pool_malloc_async((void **)&s64, n64, stream));
     launch_gl_widen((const float *)d_s, s64, total, stream);
     if (d_phase) {
-      SMX_HIP_CHECK(hipMallocAsync((void **)&p64, n64, stream));
+      SMX_HIP_CHECK(smx::pool_malloc_async((void **)&p64, n64, stream));
       launch_gl_widen((const float *)d_phase, p64, total, stream);
     }
-    SMX_HIP_CHECK(hipMallocAsync((void **)&o64, (size_t)lead * (size_t)out_len * sizeof(double), stream));
+    SMX_HIP_CHECK(smx::pool_malloc_async((void **)&o64, (size_t)lead * (size_t)out_len * sizeof(double), stream));
     griffin_lim_dev(c, s64, 8, lead, bins, frames, n_iter, momentum, p64, has_length, length, o64, stream);
     launch_gl_narrow(o64, (float *)d_out, lead * out_len, stream);
     for (void *ptr : {(void *)s64, (void *)p64, (void *)o64})
@@ -998,14 +1015,14 @@ void griffin_lim_dev(const smx_stft_config &c, const void *d_s, int elem_bytes, 
     if (istft_takes_factors(job)) {
       job.mag = d_s;
     } else {
-      if (!zbuf) SMX_HIP_CHECK(hipMallocAsync(&zbuf, cbytes, stream));
+      if (!zbuf) SMX_HIP_CHECK(smx::pool_malloc_async(&zbuf, cbytes, stream));
       launch_gl_apply(d_s, angles_in, zbuf, total, elem_bytes, stream);
       job.z = zbuf;
     }
     launch_istft(job);
   };
   void *angles = nullptr, *rebuilt = nullptr, *previous = nullptr, *signal = nullptr;
-  SMX_HIP_CHECK(hipMallocAsync(&angles, cbytes, stream));
+  SMX_HIP_CHECK(smx::pool_malloc_async(&angles, cbytes, stream));
   launch_gl_init(d_phase, angles, total, elem_bytes, stream);
   const bool iterate = natural > 0 && frames > 0;   // stft.ml:993-996
   const double beta = momentum / (1.0 + momentum);
@@ -1014,9 +1031,9 @@ void griffin_lim_dev(const smx_stft_config &c, const void *d_s, int elem_bytes, 
     // fused fft-2048 kernels: neither S * angles nor the angles themselves are materialised after the first pass --
     // the synthesis kernel forms S * unit(c_k - beta c_(k-1)) from the two latest rebuilt spectra as it stages them
     // (stft.ml:1003-1012), and the analysis of iteration k + 1 overwrites c_(k-1), which nothing reads any more
-    SMX_HIP_CHECK(hipMallocAsync(&rebuilt, cbytes, stream));
-    SMX_HIP_CHECK(hipMallocAsync(&previous, cbytes, stream));
-    SMX_HIP_CHECK(hipMallocAsync(&signal, (size_t)lead * (size_t)natural * (size_t)elem_bytes, stream));
+    SMX_HIP_CHECK(smx::pool_malloc_async(&rebuilt, cbytes, stream));
+    SMX_HIP_CHECK(smx::pool_malloc_async(&previous, cbytes, stream));
+    SMX_HIP_CHECK(smx::pool_malloc_async(&signal, (size_t)lead * (size_t)natural * (size_t)elem_bytes, stream));
     void *cur = nullptr, *old = nullptr;          // c_k, c_(k-1)
     auto synth_unit = [&](int has_len, int64_t len, void *out, int64_t olen) {
       IstftJob job = make_job(cur, has_len, len, out, olen);
@@ -1037,9 +1054,9 @@ void griffin_lim_dev(const smx_stft_config &c, const void *d_s, int elem_bytes, 
     synth_unit(has_length, length, d_out, out_len);
   } else {
     if (iterate) {
-      SMX_HIP_CHECK(hipMallocAsync(&rebuilt, cbytes, stream));
-      SMX_HIP_CHECK(hipMallocAsync(&previous, cbytes, stream));
-      SMX_HIP_CHECK(hipMallocAsync(&signal, (size_t)lead * (size_t)natural * (size_t)elem_bytes, stream));
+      SMX_HIP_CHECK(smx::pool_malloc_async(&rebuilt, cbytes, stream));
+      SMX_HIP_CHECK(smx::pool_malloc_async(&previous, cbytes, stream));
+      SMX_HIP_CHECK(smx::pool_malloc_async(&signal, (size_t)lead * (size_t)natural * (size_t)elem_bytes, stream));
       bool has_prev = false;
       for (int64_t k = 0; k < n_iter; ++k) {
         synth(angles, 0, 0, signal, natural);
@@ -1104,7 +1121,7 @@ void mfcc_dev(const smx_stft_config &sc, const smx_mel_config &mc, const void *d
   if (lead == 0 || count == 0) return;
   if (!d_x || !d_out) throw Failure("mfcc: null device pointer");
   void *mel = nullptr;
-  SMX_HIP_CHECK(hipMallocAsync(&mel, (size_t)lead * (size_t)mc.n_mels * (size_t)count * (size_t)in_bytes, stream));
+  SMX_HIP_CHECK(smx::pool_malloc_async(&mel, (size_t)lead * (size_t)mc.n_mels * (size_t)count * (size_t)in_bytes, stream));
   mel_spectrogram_dev(sc, mc, d_x, in_bytes, lead, n, x_stride, 2.0, mel, stream);
   MfccJob job;
   job.mel = mel;
@@ -1357,7 +1374,7 @@ void chroma_stft_dev(const smx_stft_config &sc, const smx_chroma_config &cc, con
   if (lead == 0 || count == 0) return;
   if (!d_x || !d_out) throw Failure("chroma_stft: null device pointer");
   void *spec = nullptr;
-  SMX_HIP_CHECK(hipMallocAsync(&spec, (size_t)lead * (size_t)sc.bins() * (size_t)count * (size_t)in_bytes, stream));
+  SMX_HIP_CHECK(smx::pool_malloc_async(&spec, (size_t)lead * (size_t)sc.bins() * (size_t)count * (size_t)in_bytes, stream));
   stft_range_dev(sc, d_x, in_bytes, lead, n, x_stride, 0, count, OUT_POWER, power, spec, stream);
   chroma_apply_dev(cc, spec, in_bytes, lead, sc.bins(), count, norm, norm_p, d_out, stream);
   SMX_HIP_CHECK(hipFreeAsync(spec, stream));

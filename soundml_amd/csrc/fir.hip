@@ -614,7 +614,7 @@ void stage_apply_dev(const smx_resample_stage &s, const float *d_x, int64_t chan
   if (s.l > 1) {
     n_in = n * s.l;
     in_stride = (n_in + 1) & ~int64_t(1);
-    SMX_HIP_CHECK(hipMallocAsync((void **)&xu, (size_t)channels * (size_t)in_stride * sizeof(float), stream));
+    SMX_HIP_CHECK(smx::pool_malloc_async((void **)&xu, (size_t)channels * (size_t)in_stride * sizeof(float), stream));
     const int64_t gx = std::min<int64_t>((n_in + 255) / 256, 2048);
     SMX_LAUNCH(smx::zero_stuff_kernel, dim3((unsigned)gx, (unsigned)channels), dim3(256), 0, stream, d_x, n, x_stride, (int)s.l, xu,
                in_stride);
@@ -625,7 +625,7 @@ void stage_apply_dev(const smx_resample_stage &s, const float *d_x, int64_t chan
     smx::fir_apply_window_dev(*s.fir, xin, channels, n_in, in_stride, d_y, y_stride, n_out, shift, stream);
   } else {
     const int64_t nv = (n_out - 1) * s.m + 1, v_stride = (nv + 1) & ~int64_t(1);
-    SMX_HIP_CHECK(hipMallocAsync((void **)&v, (size_t)channels * (size_t)v_stride * sizeof(float), stream));
+    SMX_HIP_CHECK(smx::pool_malloc_async((void **)&v, (size_t)channels * (size_t)v_stride * sizeof(float), stream));
     smx::fir_apply_window_dev(*s.fir, xin, channels, n_in, in_stride, v, v_stride, nv, shift, stream);
     const int64_t gy = std::min<int64_t>((n_out + 255) / 256, 2048);
     SMX_LAUNCH(smx::decimate_kernel, dim3((unsigned)gy, (unsigned)channels), dim3(256), 0, stream, v, v_stride, (int)s.m, d_y, n_out,

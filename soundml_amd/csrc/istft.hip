@@ -733,7 +733,7 @@ void launch_istft(const IstftJob &job) {
   const int64_t fft = c.fft_size, hop = c.hop, count = job.count;
   const int64_t span = (count - 1) * hop + fft;
   // envelope pieces: host float64 in the reference's summation order, cached on the device per (config, count)
-  const EnvelopeTable &env = c.envelope(count);
+  const EnvelopeTable env = c.envelope(count);
   const double *d_env = env.dev;
   const int64_t head_n = env.head_n, stop = env.stop;
   // fused path: fft 2048, hop 512, complex64 spectrum, float32 interior
@@ -817,7 +817,7 @@ void launch_istft(const IstftJob &job) {
   if (chunk > job.lead) chunk = job.lead;
   if (chunk > 65535) chunk = 65535;
   void *d_y = nullptr;
-  SMX_HIP_CHECK(hipMallocAsync(&d_y, (size_t)chunk * per_clip, job.stream));
+  SMX_HIP_CHECK(smx::pool_malloc_async(&d_y, (size_t)chunk * per_clip, job.stream));
   const int64_t z_clip = c.bins() * job.frames * (job.z_bytes / 1);   // bytes per clip of z
   for (int64_t c0 = 0; c0 < job.lead; c0 += chunk) {
     const int64_t nclips = job.lead - c0 < chunk ? job.lead - c0 : chunk;

@@ -224,7 +224,7 @@ void run_to_db(const ToDbJob &job) {
   const double offset = scale * std::log(std::max(job.amin, job.reference));
   U *d_key = nullptr;
   if (job.has_top_db) {
-    SMX_HIP_CHECK(hipMallocAsync((void **)&d_key, sizeof(U), job.stream));
+    SMX_HIP_CHECK(smx::pool_malloc_async((void **)&d_key, sizeof(U), job.stream));
     SMX_HIP_CHECK(hipMemsetAsync(d_key, 0, sizeof(U), job.stream));
     SMX_LAUNCH(db_max_kernel<T>, dim3(blocks), dim3(256), 0, job.stream, (const T *)job.s, job.total, job.magnitude ? 1 : 0, d_key);
     SMX_HIP_CHECK(hipGetLastError());
@@ -286,7 +286,7 @@ void launch_mfcc(const MfccJob &job) {
   // (device, n_mels, n_mfcc, lifter) and kept, so a call uploads nothing and never synchronises its stream
   const double *d_tab = mfcc_tables(n_mels, n_mfcc, job.lifter);
   unsigned long long *d_max = nullptr;
-  SMX_HIP_CHECK(hipMallocAsync((void **)&d_max, sizeof(unsigned long long), job.stream));
+  SMX_HIP_CHECK(smx::pool_malloc_async((void **)&d_max, sizeof(unsigned long long), job.stream));
   SMX_HIP_CHECK(hipMemsetAsync(d_max, 0, sizeof(unsigned long long), job.stream));
   const int64_t total = job.lead * (int64_t)n_mels * job.frames;
   const unsigned blocks = (unsigned)std::min<int64_t>((total + 2047) / 2048, 2048);

@@ -96,6 +96,7 @@ struct EnvelopeTable {
   double *dev = nullptr;
   size_t head = 0, period = 0, tail = 0;   // doubles in each piece
   int64_t head_n = 0, stop = 0;
+  uint64_t serial = 0;   // insertion order in the owning config's cache
 };
 }  // namespace smx
 
@@ -117,13 +118,14 @@ struct smx_stft_config {
   const smx::StftTables &tables() const;
   // the envelope of a `count`-frame synthesis, built once per (device, count) on the host in float64 (the
   // reference's summation order) and kept: repeated inversions of one geometry (Griffin-Lim) upload nothing
-  const smx::EnvelopeTable &envelope(int64_t count) const;   // tables.cpp
+  smx::EnvelopeTable envelope(int64_t count) const;   // tables.cpp; by value: the cache may evict the entry later
   ~smx_stft_config();
 
  private:
   mutable std::mutex mutex_;
   mutable std::map<int, smx::StftTables> tables_;
   mutable std::map<std::pair<int, int64_t>, smx::EnvelopeTable> envelopes_;
+  mutable uint64_t envelope_serial_ = 0;
 };
 
 namespace smx {
@@ -237,7 +239,8 @@ void launch_stft(const StftJob &job);             // dispatch: fast path or gene
 void launch_stft_generic(const StftJob &job);     // stft_generic.hip
 bool launch_stft_fast(const StftJob &job);        // stft_fast.hip; false = not eligible
 bool fast_path_disabled();                        // env SMX_DISABLE_FAST=1 (tests)
-void init_device_pool();                          // tables.cpp: once per device, keeps freed scratch for reuse
+void init_device_pool();                          // tables.cpp: the library's own stream-ordered pool of the current device
+hipError_t pool_malloc_async(void **ptr, size_t bytes, hipStream_t stream);   // tables.cpp: scratch from that pool
 void set_scratch_retention(int64_t bytes);        // tables.cpp
 
 // Stft.invert (stft.ml:902-939) on device-resident data

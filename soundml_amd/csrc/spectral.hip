@@ -254,7 +254,7 @@ bool launch_spectral(const SpectralJob &job) {
   // scratch: the invalid-entry flag, then the caller's frequency grid
   const size_t grid_bytes = job.freqs ? (size_t)job.bins * sizeof(double) : 0;
   unsigned char *scratch = nullptr;
-  SMX_HIP_CHECK(hipMallocAsync((void **)&scratch, 16 + grid_bytes, job.stream));
+  SMX_HIP_CHECK(smx::pool_malloc_async((void **)&scratch, 16 + grid_bytes, job.stream));
   a.invalid = reinterpret_cast<int *>(scratch);
   SMX_HIP_CHECK(hipMemsetAsync(scratch, 0, 16, job.stream));
   if (job.freqs) {
@@ -291,7 +291,7 @@ void launch_chroma(const ChromaJob &job) {
   const int64_t blocks = a.lead * a.ftiles;
   const int64_t chunks = (c.n_chroma + kChromaChunk - 1) / kChromaChunk;
   if (blocks > 2147483647LL || chunks > 65535) throw Failure("chroma: too many tiles for one launch");
-  SMX_HIP_CHECK(hipMallocAsync((void **)&a.raw, (size_t)job.lead * (size_t)c.n_chroma * (size_t)job.frames * sizeof(double),
+  SMX_HIP_CHECK(smx::pool_malloc_async((void **)&a.raw, (size_t)job.lead * (size_t)c.n_chroma * (size_t)job.frames * sizeof(double),
                                job.stream));
   if (job.elem_bytes == 8) {
     SMX_LAUNCH(chroma_project_kernel<double>, dim3((unsigned)blocks, (unsigned)chunks), dim3(256), 0, job.stream, a);

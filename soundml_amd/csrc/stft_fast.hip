@@ -1650,7 +1650,7 @@ void launch_border(const StftJob &job, const FastTarget &tg, int64_t pa, int64_t
   const int64_t len = (pb - pa - 1) * c.hop + kN;
   const int64_t stride = (len + 1) & ~int64_t(1);            // even: keeps 8-byte aligned rows
   float *strip = nullptr;
-  SMX_HIP_CHECK(hipMallocAsync((void **)&strip, (size_t)job.lead * (size_t)stride * sizeof(float), job.stream));
+  SMX_HIP_CHECK(smx::pool_malloc_async((void **)&strip, (size_t)job.lead * (size_t)stride * sizeof(float), job.stream));
   dim3 grid((unsigned)((len + 255) / 256 < 64 ? (len + 255) / 256 : 64), (unsigned)job.lead);
   SMX_LAUNCH(gather_padded_kernel, grid, dim3(256), 0, job.stream,
                      reinterpret_cast<const float *>(job.x), job.n, job.x_stride, pos0, len, job.pad,
@@ -1743,7 +1743,7 @@ bool launch_mel_spectrogram_fused(const MelSpecJob &job) {
       if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return 256;
       return prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     }();
-    SMX_HIP_CHECK(hipMallocAsync((void **)&m.scratch, (size_t)cus * 2 * (kMelHelpers - kMelPadSlots) * 256 * sizeof(float),
+    SMX_HIP_CHECK(smx::pool_malloc_async((void **)&m.scratch, (size_t)cus * 2 * (kMelHelpers - kMelPadSlots) * 256 * sizeof(float),
                                  job.stft.stream));
   }
   m.out = reinterpret_cast<float *>(job.out);

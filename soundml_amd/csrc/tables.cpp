@@ -36,23 +36,57 @@ void set_scratch_retention(int64_t bytes) {
   g_pool_done.clear();
 }
 
+// The library's OWN stream-ordered pool, one per device (never the process-wide default pool, whose release threshold an
+// embedding application may rely on): scratch arrays come from it and go back to it, and it keeps up to `threshold`
+// bytes of freed scratch for the next call instead of returning them to the driver at every synchronisation.
+static std::map<int, hipMemPool_t> g_pools;
+
+static uint64_t pool_threshold_locked() {
+  if (g_pool_bytes >= 0) return (uint64_t)g_pool_bytes;
+  size_t free_b = 0, total_b = 0;
+  if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) return 0;
+  const uint64_t eighth = (uint64_t)total_b / 8, cap = 16ull << 30;    // default: 1/8 of the device, at most 16 GiB
+  return eighth < cap ? eighth : cap;
+}
+
+static hipMemPool_t device_pool_locked(int device) {
+  auto it = g_pools.find(device);
+  if (it == g_pools.end()) {
+    hipMemPoolProps props = {};
+    props.allocType = hipMemAllocationTypePinned;
+    props.handleTypes = hipMemHandleTypeNone;
+    props.location.type = hipMemLocationTypeDevice;
+    props.location.id = device;
+    hipMemPool_t pool = nullptr;
+    if (hipMemPoolCreate(&pool, &props) != hipSuccess) pool = nullptr;   // fall back to plain stream-ordered allocation
+    it = g_pools.emplace(device, pool).first;
+    g_pool_done[device] = false;
+  }
+  if (it->second && !g_pool_done[device]) {
+    uint64_t threshold = pool_threshold_locked();
+    (void)hipMemPoolSetAttribute(it->second, hipMemPoolAttrReleaseThreshold, &threshold);
+    g_pool_done[device] = true;
+  }
+  return it->second;
+}
+
 void init_device_pool() {
   int device = 0;
   if (hipGetDevice(&device) != hipSuccess) return;
   std::lock_guard<std::mutex> lock(g_pool_mutex);
-  if (g_pool_done[device]) return;
-  g_pool_done[device] = true;
+  (void)device_pool_locked(device);
+}
+
+hipError_t pool_malloc_async(void **ptr, size_t bytes, hipStream_t stream) {
+  int device = 0;
+  hipError_t e = hipGetDevice(&device);
+  if (e != hipSuccess) return e;
   hipMemPool_t pool = nullptr;
-  if (hipDeviceGetDefaultMemPool(&pool, device) != hipSuccess || !pool) return;
-  uint64_t threshold = 0;
-  if (g_pool_bytes >= 0) {
-    threshold = (uint64_t)g_pool_bytes;
-  } else {
-    size_t free_b = 0, total_b = 0;
-    if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) return;
-    threshold = (uint64_t)total_b / 8;
+  {
+    std::lock_guard<std::mutex> lock(g_pool_mutex);
+    pool = device_pool_locked(device);
   }
-  (void)hipMemPoolSetAttribute(pool, hipMemPoolAttrReleaseThreshold, &threshold);
+  return pool ? hipMallocFromPoolAsync(ptr, bytes, pool, stream) : hipMallocAsync(ptr, bytes, stream);
 }
 
 }  // namespace smx
@@ -238,16 +272,19 @@ const smx::StftTables &smx_stft_config::tables() const {
   return tables_.emplace(device, t).first->second;
 }
 
-const smx::EnvelopeTable &smx_stft_config::envelope(int64_t count) const {
+smx::EnvelopeTable smx_stft_config::envelope(int64_t count) const {
   int device = 0;
   SMX_HIP_CHECK(hipGetDevice(&device));
   std::lock_guard<std::mutex> lock(mutex_);
   const auto key = std::make_pair(device, count);
   auto it = envelopes_.find(key);
   if (it != envelopes_.end()) return it->second;
-  if (envelopes_.size() >= 64) {   // a caller cycling through many lengths: start over (hipFree waits for users)
-    for (auto &kv : envelopes_) (void)hipFree(kv.second.dev);
-    envelopes_.clear();
+  if (envelopes_.size() >= 64) {   // a caller cycling through many lengths: drop the oldest table (hipFree waits for the
+    auto oldest = envelopes_.begin();   // device, so a launch that still reads it has finished; callers hold copies of
+    for (auto jt = envelopes_.begin(); jt != envelopes_.end(); ++jt)   // the descriptor, never a reference into the map)
+      if (jt->second.serial < oldest->second.serial) oldest = jt;
+    (void)hipFree(oldest->second.dev);
+    envelopes_.erase(oldest);
   }
   std::vector<double> head, period, tail;
   smx::EnvelopeTable e;
@@ -262,6 +299,7 @@ const smx::EnvelopeTable &smx_stft_config::envelope(int64_t count) const {
   e.period = period.size();
   e.tail = tail.size();
   e.dev = smx::upload(packed);
+  e.serial = ++envelope_serial_;
   return envelopes_.emplace(key, e).first->second;
 }
 

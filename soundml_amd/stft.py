@@ -163,10 +163,12 @@ def _range(c: Config, x, p0, p1, power, op):
         fn = getattr(lib, "smx_stft_transform_range_%s" % sfx)
         check(fn(c._h, b.ptr(), lead, n, p0, p1, out_ptr(out)))
     else:
-        if (p0, p1) != (0, total):
-            raise _lib.Failure("power_spectrum: frame ranges are a device-path feature")
-        fn = getattr(lib, "smx_stft_power_spectrum_%s" % sfx)
-        check(fn(c._h, b.ptr(), lead, n, float(power), out_ptr(out)))
+        if (p0, p1) == (0, total):
+            fn = getattr(lib, "smx_stft_power_spectrum_%s" % sfx)
+            check(fn(c._h, b.ptr(), lead, n, float(power), out_ptr(out)))
+        else:
+            fn = getattr(lib, "smx_stft_power_range_%s" % sfx)
+            check(fn(c._h, b.ptr(), lead, n, p0, p1, float(power), out_ptr(out)))
     return b.wrap(out)
 
 
@@ -188,8 +190,8 @@ def power_spectrum(c: Config, x, power: float = 2.0):
 
 
 def power_range(c: Config, x, p0: int, p1: int, power: float = 2.0):
-    """Frames [p0, p1) of ``power_spectrum`` for device-resident audio: the seam
-    clip/frame-range sharding uses."""
+    """Frames [p0, p1) of ``power_spectrum`` (host or device-resident audio): the seam clip / frame-range
+    sharding uses."""
     return _range(c, x, int(p0), int(p1), float(power), "power_spectrum")
 
 

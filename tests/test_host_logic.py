@@ -453,3 +453,75 @@ def test_resample_geometry_and_prototype_match_the_oracle():
     with pytest.raises(S.Failure) as e:
         Resample.shape(np.zeros((1, 4), np.complex128), np.zeros(4, np.complex128), 6, 2, 2)
     assert str(e.value) == "soundml_resample_shape: invalid geometry"
+
+
+# ---- the OCaml side of the boundary (source only: no OCaml toolchain in the image) ----------------------------------
+
+def _call_arity(text, pos):
+    """number of top-level arguments of the call whose '(' is at text[pos]"""
+    depth, args, i, seen = 0, 0, pos, False
+    while True:
+        ch = text[i]
+        if ch == "(":
+            depth += 1
+        elif ch == ")":
+            depth -= 1
+            if depth == 0:
+                return args + (1 if seen else 0)
+        elif ch == "," and depth == 1:
+            args += 1
+        elif depth >= 1 and not ch.isspace():
+            seen = True
+        i += 1
+
+
+def test_ocaml_stubs_agree_with_the_header_and_the_externals():
+    """ocaml/soundml_amd_stubs.c may only call entry points include/soundml_amd.h declares, with the declared number of
+    arguments; every `external` of ocaml/stft_amd.ml names a CAMLprim of the stubs with as many parameters as the
+    external's type has arguments, plus the bytecode shim above five (the reference's convention, resample.ml:1162-1196);
+    every row of INTEGRATION.md's table names entry points that exist."""
+    strip = lambda t: re.sub(r"/\*.*?\*/", "", t, flags=re.S)
+    header = strip(open(os.path.join(ROOT, "include", "soundml_amd.h")).read())
+    declared = {}
+    for m in re.finditer(r"\b(smx_[a-z0-9_]+)\s*\(", header):
+        params = header[m.end() - 1:]
+        n = _call_arity(params, 0)
+        inner = params[1:params.index(")")].strip()
+        declared[m.group(1)] = 0 if inner == "void" else n
+    stubs = strip(open(os.path.join(ROOT, "ocaml", "soundml_amd_stubs.c")).read())
+    used = set()
+    for m in re.finditer(r"\b(smx_[a-z0-9_]+)\s*\(", stubs):
+        name = m.group(1)
+        if name == "smx_raise":
+            continue
+        assert name in declared, "%s is not declared in soundml_amd.h" % name
+        assert _call_arity(stubs, m.end() - 1) == declared[name], "%s: arity differs from the header" % name
+        used.add(name)
+    for need in ("smx_stft_power_range_f32", "smx_stft_kernel_step", "smx_stft_kernel_flush", "smx_stft_kernel_prepare_power",
+                 "smx_stft_griffin_lim_f32", "smx_fir_apply_f32", "smx_chroma_stft_f32", "smx_mfcc_f32", "smx_mel_apply_f32",
+                 "smx_mel_spectrogram_f32", "smx_resample_shape_c128", "smx_resample_stage_apply_f32", "smx_stft_invert_f32"):
+        assert need in used, "%s is not bound by the stubs" % need
+    # CAMLprims and their parameter counts
+    prims = {m.group(1): _call_arity(stubs, m.end() - 1) for m in re.finditer(r"CAMLprim value (soundml_amd_[a-z0-9_]+)\s*\(", stubs)}
+    ml = re.sub(r"\(\*.*?\*\)", "", open(os.path.join(ROOT, "ocaml", "stft_amd.ml")).read(), flags=re.S)
+    externals = re.findall(r"external\s+(\w+)\s*:(.*?)=\s*((?:\"[a-z0-9_]+\"\s*)+)", ml, flags=re.S)
+    assert len(externals) >= 20
+    for name, typ, names in externals:
+        names = re.findall(r"\"([a-z0-9_]+)\"", names)
+        depth, arrows = 0, 0
+        for i, ch in enumerate(typ):          # arrows outside parentheses = arguments
+            depth += ch == "("
+            depth -= ch == ")"
+            arrows += depth == 0 and typ[i:i + 2] == "->"
+        native = names[-1]
+        assert native in prims, "%s: %s is not a CAMLprim of the stubs" % (name, native)
+        assert prims[native] == arrows, "%s: %d arguments, the stub takes %d" % (name, arrows, prims[native])
+        if arrows > 5:
+            assert len(names) == 2 and names[0] == native + "_bc" and names[0] in prims, "%s: bytecode shim missing" % name
+        else:
+            assert len(names) == 1
+    # the integration table names real entry points
+    doc = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    for m in re.finditer(r"`(smx_[a-z0-9_]+?)(?:_\{f32,f64\})?`", doc):
+        base = m.group(1)
+        assert any(d == base or d.startswith(base) for d in declared), "INTEGRATION.md names %s" % base
