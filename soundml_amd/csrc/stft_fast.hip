@@ -466,6 +466,7 @@ __device__ __forceinline__ void frame_to_tile(const FastArgs &a, const LaneConst
                                               Cells cells, int lane, const Hook &hook) {
   c32 v[16];
   float2 win[16], tw[16];
+  constexpr bool kNoLds = SMX_ABL(12) || SMX_ABL(13) || SMX_ABL(14);   // timing-only: the arithmetic and its table reads alone (no exchange, no tile, no memory, no waits)
 #pragma unroll
   for (int j = 0; j < 16; ++j) win[j] = L.winL_l[64 * j];
   if constexpr (PRE) {
@@ -507,9 +508,9 @@ __device__ __forceinline__ void frame_to_tile(const FastArgs &a, const LaneConst
     float re[16], im[16];
 #pragma unroll
     for (int k = 0; k < 16; ++k) { re[k] = v[k].x; im[k] = v[k].y; }
-    if constexpr (!SMX_ABL(5) && !SMX_ABL(11)) transpose16(re);
+    if constexpr (!SMX_ABL(5) && !SMX_ABL(11) && !SMX_ABL(13)) transpose16(re);
     hook.template at<4>();
-    if constexpr (!SMX_ABL(5) && !SMX_ABL(11)) transpose16(im);
+    if constexpr (!SMX_ABL(5) && !SMX_ABL(11) && !SMX_ABL(13)) transpose16(im);
 #pragma unroll
     for (int k = 0; k < 16; ++k) v[k] = {re[k], im[k]};
   }
@@ -541,6 +542,7 @@ __device__ __forceinline__ void frame_to_tile(const FastArgs &a, const LaneConst
   // W_64 table (and into v[0]), which turns each butterfly into x += kappa * partner(x) with
   // kappa1 = -s1, kappa2 = -s2: one v_fmac_f32_dpp per component.  Sign flips are exact, so the values
   // are those of the plain formulation bit for bit.
+  if constexpr (!SMX_ABL(14)) {
   v[0].x *= L.s12;
   v[0].y *= L.s12;
   SMX_FMAC_DPP8("[2,3,0,1]", v, L.kap1);
@@ -553,6 +555,7 @@ __device__ __forceinline__ void frame_to_tile(const FastArgs &a, const LaneConst
   }
   SMX_FMAC_DPP8("[1,0,3,2]", v, L.kap2);
   SMX_FMAC_DPP8("[1,0,3,2]", v + 8, L.kap2);
+  }
   hook.template at<10>();
   SMX_FENCE();
   // P: real-FFT post-pass X[k] = E - i w_k D, E = Z[k] + conj Z[M-k], D = Z[k] - conj Z[M-k] (the 1/2 is in the
@@ -565,7 +568,7 @@ __device__ __forceinline__ void frame_to_tile(const FastArgs &a, const LaneConst
   const float nyq = 2.0f * (v[0].x - v[0].y);   // X[M] = Re Z0 - Im Z0 (true scale), lane 0
   float px[16], py[16];
   constexpr int kPlane = kTileBytes / sizeof(float);   // CPLX: the imaginary plane
-  if constexpr (SMX_ABL(4)) {   // timing-only: no exchange
+  if constexpr (SMX_ABL(4) || kNoLds) {   // timing-only: no exchange
 #pragma unroll
     for (int q = 0; q < 16; ++q) { px[q] = v[15 - q].x; py[q] = v[15 - q].y; }
   } else if constexpr (CPLX) {   // both planes are this tile's: one round
@@ -599,7 +602,8 @@ __device__ __forceinline__ void frame_to_tile(const FastArgs &a, const LaneConst
     } else {
       float pw = tr * tr + ti * ti;
       if constexpr (!SQUARE) pw = a.pmode == 1 ? sqrtf(pw) : __powf(pw, a.half_power);
-      cells.own[kCellStep * q] = pw;
+      if constexpr (kNoLds) asm volatile("" ::"v"(pw));
+      else cells.own[kCellStep * q] = pw;
     }
   };
 #pragma unroll
@@ -610,7 +614,7 @@ __device__ __forceinline__ void frame_to_tile(const FastArgs &a, const LaneConst
     if (q == 11) hook.template at<13>();
     if (q == 15) { hook.template at<14>(); hook.template at<15>(); }
   }
-  if (lane == 0) {
+  if (lane == 0 && !kNoLds) {
     float pw = nyq;                       // CPLX: X[M] is real
     if constexpr (!CPLX) {
       pw = nyq * nyq;
@@ -622,7 +626,7 @@ __device__ __forceinline__ void frame_to_tile(const FastArgs &a, const LaneConst
 
 template <bool ALIGNED SMX_ABL_PARAM>
 __device__ __forceinline__ void prefetch_frame(const FastArgs &a, const float *src, int lane, float2 (&raw)[16]) {
-  if constexpr (SMX_ABL(2) || SMX_ABL(3) || SMX_ABL(9)) {
+  if constexpr (SMX_ABL(2) || SMX_ABL(3) || SMX_ABL(9) || SMX_ABL(12) || SMX_ABL(13) || SMX_ABL(14)) {
 #pragma unroll
     for (int j = 0; j < 16; ++j) raw[j] = make_float2((float)(lane + j) + raw[j].x * 0.0f, (float)(lane - j));
   } else if constexpr (SMX_ABL(10) || SMX_ABL(11)) {   // timing-only: 4 of the 16 loads (what re-using the 75 % overlap of consecutive frames would leave)
@@ -762,13 +766,15 @@ __global__ void __launch_bounds__(1024) stft2048_power_kernel(FastArgs a) {
 #else
       const SyncHook hook{cnt.drained + b, 16u * ((unsigned)it >> 1)};
 #endif
-      frame_to_tile<SQUARE, kPre, false, false SMX_ABL_ARG>(a, L, raw, cells_of_column(L, lds.tiles + b * kTileFloats, wave), lane, hook);
+      if constexpr (SMX_ABL(12) || SMX_ABL(13) || SMX_ABL(14)) frame_to_tile<SQUARE, kPre, false, false SMX_ABL_ARG>(a, L, raw, cells_of_column(L, lds.tiles + b * kTileFloats, wave), lane, NoHook{});
+      else frame_to_tile<SQUARE, kPre, false, false SMX_ABL_ARG>(a, L, raw, cells_of_column(L, lds.tiles + b * kTileFloats, wave), lane, hook);
     }
-    lds_signal(cnt.filled + b, lane);
+    if constexpr (!(SMX_ABL(12) || SMX_ABL(13) || SMX_ABL(14))) lds_signal(cnt.filled + b, lane);
     SMX_STAMP(17);
     prefetch_frame<ALIGNED SMX_ABL_ARG>(a, src, lane, raw);
     SMX_STAMP(18);
-    if (it > 0) flush_tile(b ^ 1, ((unsigned)(it - 1) >> 1) + 1);   // tile it - 1
+    if constexpr (!(SMX_ABL(12) || SMX_ABL(13) || SMX_ABL(14)))
+      if (it > 0) flush_tile(b ^ 1, ((unsigned)(it - 1) >> 1) + 1);   // tile it - 1
     SMX_STAMP(19);
     pend_out = tw.oclip + tw.ft * kFT;   // wave-uniform
     pend_ft = tw.ft;
@@ -779,7 +785,7 @@ __global__ void __launch_bounds__(1024) stft2048_power_kernel(FastArgs a) {
     tw.oclip = onext;
     tw.ft = ftnext;
   }
-  flush_tile((ntiles - 1) & 1, ((unsigned)(ntiles - 1) >> 1) + 1);   // the last tile of this workgroup
+  if constexpr (!(SMX_ABL(12) || SMX_ABL(13) || SMX_ABL(14))) flush_tile((ntiles - 1) & 1, ((unsigned)(ntiles - 1) >> 1) + 1);   // the last tile of this workgroup
 #ifdef SMX_STAMPS
   stamp_sum[20] = __builtin_amdgcn_s_memtime() - clk_t0;
   stamp_sum[21] = __builtin_amdgcn_s_memrealtime() - clk_r0;
@@ -1617,6 +1623,9 @@ void launch_interior(const StftJob &job, const FastTarget &tg, const float *x, i
               : abl == 9 ? stft2048_power_kernel<true, true, false, 9>
               : abl == 10 ? stft2048_power_kernel<true, true, false, 10>
               : abl == 11 ? stft2048_power_kernel<true, true, false, 11>
+              : abl == 12 ? stft2048_power_kernel<true, true, false, 12>
+              : abl == 13 ? stft2048_power_kernel<true, true, false, 13>
+              : abl == 14 ? stft2048_power_kernel<true, true, false, 14>
                          : stft2048_power_kernel<true, true, false, 0>;
   (void)aligned; (void)square; (void)strip;
 #else
@@ -1638,7 +1647,11 @@ void launch_interior(const StftJob &job, const FastTarget &tg, const float *x, i
 #endif
   SMX_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kernel),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)kFastLds));
-  SMX_LAUNCH(kernel, dim3((unsigned)a.blocks), dim3(1024), kFastLds, job.stream, a);
+  unsigned threads = 1024;
+#ifdef SMX_DIAG
+  if (const char *t = std::getenv("SMX_ABL_THREADS")) threads = (unsigned)std::atoi(t);   // ABLATE=12 only: fewer waves per SIMD, same work per wave
+#endif
+  SMX_LAUNCH(kernel, dim3((unsigned)a.blocks), dim3(threads), kFastLds, job.stream, a);
   SMX_HIP_CHECK(hipGetLastError());
 }
 
