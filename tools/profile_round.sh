@@ -9,7 +9,8 @@ ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out/$TAG
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
-timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -- python3 $ROOT/bench.py --no-cpu-baseline --steps 20 --warmup 3 > "$OUT/bench_n1.json" 2> "$OUT/trace.err"
+# --no-extras: C5's one-GPU point launches the same kernel name on a 48x larger batch and would pollute the average
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -- python3 $ROOT/bench.py --no-cpu-baseline --no-extras --steps 20 --warmup 3 > "$OUT/bench_n1.json" 2> "$OUT/trace.err"
 find "$OUT/trace" -name '*kernel_stats.csv' | head -1 | xargs -r -I{} cp {} "$OUT/kernel_stats.csv"
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace_hot" -- python3 $ROOT/tools/pmc_driver.py > "$OUT/trace_hot.log" 2>&1
 find "$OUT/trace_hot" -name '*kernel_stats.csv' | head -1 | xargs -r -I{} cp {} "$OUT/hot_kernel_stats.csv"
