@@ -179,7 +179,10 @@ __device__ __forceinline__ int out_index(int tid, int i, int j) {
 
 // forward FFT of the 16 points per thread; FIRST: registers already hold element tid + T*m in r[m].
 // On return r[i*R + j] (last radix R, its NS) holds natural-order element out_index<R, NS, T>(tid, i, j).
-template <int LOG2N, bool FIRST, bool WAVE = false, typename S = float, bool PRE = false>
+#ifndef SMX_FFT_PRE_DEFAULT
+#define SMX_FFT_PRE_DEFAULT false
+#endif
+template <int LOG2N, bool FIRST, bool WAVE = false, typename S = float, bool PRE = SMX_FFT_PRE_DEFAULT>
 __device__ __forceinline__ void fft_passes(cpx<S> (&r)[16], typename vec2_of<S>::type *z, int tid,
                                            const typename vec2_of<S>::type *tw) {
   constexpr int N = 1 << LOG2N;

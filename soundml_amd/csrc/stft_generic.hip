@@ -1045,7 +1045,7 @@ __global__ void __launch_bounds__((1 << LOG2M) / 16 < 256 ? 256 : (1 << LOG2M) /
         }
       }
     }
-    fft_passes<LOG2M, true>(r, z, tid, b.tw);
+    fft_passes<LOG2M, true, false, float, true>(r, z, tid, b.tw);
     // product with the filter's spectrum (1/M folded in), conjugated for the inverse transform
 #pragma unroll
     for (int i = 0; i < GL; ++i)
@@ -1056,7 +1056,7 @@ __global__ void __launch_bounds__((1 << LOG2M) / 16 < 256 ? 256 : (1 << LOG2M) /
         const c32 y = cmul(r[i * RL + j], c32{h.x, h.y});
         z[swz(idx)] = make_float2(y.x, -y.y);
       }
-    fft_passes<LOG2M, false>(r, z, tid, b.tw);
+    fft_passes<LOG2M, false, false, float, true>(r, z, tid, b.tw);
     if (have) {
 #pragma unroll
       for (int i = 0; i < GL; ++i)
@@ -1142,7 +1142,7 @@ __global__ void __launch_bounds__((1 << LOG2M) / 16 < 256 ? 256 : (1 << LOG2M) /
         }
       }
     }
-    fft_passes<LOG2M, true, WAVE>(r, z, tid, b.tw);
+    fft_passes<LOG2M, true, WAVE, float, true>(r, z, tid, b.tw);
     // product with the filter's spectrum (1/M folded in), conjugated for the inverse transform
 #pragma unroll
     for (int i = 0; i < GL; ++i)
@@ -1153,7 +1153,7 @@ __global__ void __launch_bounds__((1 << LOG2M) / 16 < 256 ? 256 : (1 << LOG2M) /
         const c32 y = cmul(r[i * RL + j], c32{h.x, h.y});
         z[swz(idx)] = make_float2(y.x, -y.y);
       }
-    fft_passes<LOG2M, false, WAVE>(r, z, tid, b.tw);
+    fft_passes<LOG2M, false, WAVE, float, true>(r, z, tid, b.tw);
     // Z[k] = c_k conj(transform)[k], k < L, into the (now free) buffer in natural order
 #pragma unroll
     for (int i = 0; i < GL; ++i)
@@ -1229,7 +1229,7 @@ __global__ void __launch_bounds__(1 << LOG2M) stft_bluestein_power16_kernel(Gene
       }
     }
   }
-  fft_passes<LOG2M, true, true>(r, z, tid, b.tw);
+  fft_passes<LOG2M, true, true, float, true>(r, z, tid, b.tw);
 #pragma unroll
   for (int i = 0; i < GL; ++i)
 #pragma unroll
@@ -1239,7 +1239,7 @@ __global__ void __launch_bounds__(1 << LOG2M) stft_bluestein_power16_kernel(Gene
       const c32 y = cmul(r[i * RL + j], c32{h.x, h.y});
       z[swz(idx)] = make_float2(y.x, -y.y);
     }
-  fft_passes<LOG2M, false, true>(r, z, tid, b.tw);
+  fft_passes<LOG2M, false, true, float, true>(r, z, tid, b.tw);
 #pragma unroll
   for (int i = 0; i < GL; ++i)
 #pragma unroll
