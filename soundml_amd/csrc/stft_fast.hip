@@ -76,13 +76,18 @@ __device__ __forceinline__ void swap16(float &a, float &b) {
 // lane (i, a) register k  ->  lane (k, a) register i.  Four butterfly exchanges at lane
 // distances 32, 16 (permlane swaps) and 8, 4 (DPP row rotate / shift with bank masks);
 // no LDS.  Verified on hardware by tools/probes/transpose_probe.hip.
+// eight swaps in ONE statement: the 2 wait states a v_permlane* read needs after a VALU write are paid once per
+// batch (an s_nop costs a wave an issue slot like a vector instruction does); inside the batch no swap reads a
+// register another one has just written
+#define SMX_SWAP8(OP, V, A0, B0, A1, B1, A2, B2, A3, B3, A4, B4, A5, B5, A6, B6, A7, B7)                              \
+  asm("s_nop 1\n\t" OP " %0, %1\n\t" OP " %2, %3\n\t" OP " %4, %5\n\t" OP " %6, %7\n\t" OP " %8, %9\n\t" OP            \
+      " %10, %11\n\t" OP " %12, %13\n\t" OP " %14, %15"                                                             \
+      : "+v"((V)[A0]), "+v"((V)[B0]), "+v"((V)[A1]), "+v"((V)[B1]), "+v"((V)[A2]), "+v"((V)[B2]), "+v"((V)[A3]),     \
+        "+v"((V)[B3]), "+v"((V)[A4]), "+v"((V)[B4]), "+v"((V)[A5]), "+v"((V)[B5]), "+v"((V)[A6]), "+v"((V)[B6]),     \
+        "+v"((V)[A7]), "+v"((V)[B7]))
 __device__ __forceinline__ void transpose16(float (&v)[16]) {
-#pragma unroll
-  for (int k = 0; k < 16; ++k)
-    if (!(k & 8)) swap32(v[k], v[k | 8]);
-#pragma unroll
-  for (int k = 0; k < 16; ++k)
-    if (!(k & 4)) swap16(v[k], v[k | 4]);
+  SMX_SWAP8("v_permlane32_swap_b32", v, 0, 8, 1, 9, 2, 10, 3, 11, 4, 12, 5, 13, 6, 14, 7, 15);
+  SMX_SWAP8("v_permlane16_swap_b32", v, 0, 4, 1, 5, 2, 6, 3, 7, 8, 12, 9, 13, 10, 14, 11, 15);
 #pragma unroll
   for (int k = 0; k < 16; ++k)
     if (!(k & 2)) {
