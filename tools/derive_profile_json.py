@@ -1,0 +1,32 @@
+#!/usr/bin/env python3
+"""From profiles/<round>/pmc_hot_kernels.json (tools/profile_round.sh) to the two small files bench.py quotes:
+  profiles/hbm_traffic.json   HBM bytes per launch of the headline kernel (roofline.traffic), counters corrected as
+                              MI355X_MICROARCH.md prescribes (FETCH_SIZE x 2 on gfx950 for wide coalesced reads; WRITE_SIZE as is)
+  profiles/mfma_util.json     MFMA-pipe utilisation of the two mel kernels (north_star: "MFMA utilisation for the mel GEMM")
+Usage: python tools/derive_profile_json.py r04"""
+import json, os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+rnd = sys.argv[1] if len(sys.argv) > 1 else "r04"
+src = os.path.join(ROOT, "profiles", rnd, "pmc_hot_kernels.json")
+k = json.load(open(src))["kernels"]
+head = k["stft2048_power_kernel<true, true, false>"]
+c = head["counters"]
+read_b, write_b = int(c["FETCH_SIZE"] * 1024 * 2), int(c["WRITE_SIZE"] * 1024)
+algo = 256 * 938 * 6148
+json.dump({"bytes_per_launch": read_b + write_b, "read_bytes": read_b, "write_bytes": write_b, "algorithmic_bytes": algo,
+           "write_amplification": round(write_b / (256 * 938 * 4100), 3),
+           "note": "one launch of the C2 workload (938 frames per clip); FETCH_SIZE doubled per the gfx950 correction (calibrated for "
+                   "16 B/lane streams; these loads are 8 B/lane, so the read side is an upper estimate between 1x and 2x FETCH_SIZE); "
+                   "WRITE_SIZE as reported",
+           "profile": "profiles/%s/pmc_hot_kernels.json" % rnd}, open(os.path.join(ROOT, "profiles", "hbm_traffic.json"), "w"), indent=1)
+out = {"profile": "profiles/%s/pmc_hot_kernels.json" % rnd,
+       "definition": "SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 XCDs x 1024 SIMDs); fp32 MFMA peak 157.3 TFLOP/s (MI355X_MICROARCH.md)"}
+for name, key, flop_per_mfma in (("fused_audio_to_mel", "stft2048_mel_kernel<true, true, false>", 2048), ("mel_apply", "mel_apply_mfma_kernel<true>", 4096)):
+    cc, dur = k[key]["counters"], k[key]["duration"]
+    util = cc["SQ_VALU_MFMA_BUSY_CYCLES"] / (cc["GRBM_GUI_ACTIVE"] / 8.0 * 1024.0)
+    flops = cc["SQ_INSTS_VALU_MFMA_F32"] * flop_per_mfma
+    out[name] = {"kernel": key, "mfma_pipe_busy": round(util, 4), "executed_tflops": round(flops / (dur["avg_us"] * 1e-6) / 1e12, 1),
+                 "avg_us": round(dur["avg_us"], 1)}
+json.dump(out, open(os.path.join(ROOT, "profiles", "mfma_util.json"), "w"), indent=1)
+print(open(os.path.join(ROOT, "profiles", "hbm_traffic.json")).read())
+print(json.dumps(out, indent=1))
