@@ -192,3 +192,39 @@ def test_regression_gate_fast_kernels(fft, hop):
     z = torch.view_as_real(Stft.transform(cfg, x)).cpu().numpy()
     w = c_oracle.stft(ocfg, xh, complex_out=True, threads=CORES)
     check_clips(z, np.stack([w.real, w.imag], axis=-1), "transform %d" % fft)
+
+
+@pytest.mark.timeout(600)
+def test_ring_kernel_is_bit_identical_to_the_column_kernel():
+    """SMX_POWER_RING=1 (whole 64-byte-aligned stores from a ring of the last 32 frames of every bin row) must produce the
+    column kernel's values bit for bit: same frame code, only the way the tile leaves LDS differs.  Geometries: ranges that
+    start mid-clip, partial last tiles, segments that cross clips, odd row pitches, every alignment, general powers."""
+    code = """
+import json, sys, numpy as np
+sys.path.insert(0, %r)
+import torch
+from soundml_amd import Stft
+out = {}
+rng = np.random.default_rng(3)
+cases = [(3, 70000, 512, "centered", 2.0), (17, 33333, 512, "left", 2.0), (5, 9000, 300, "right", 1.0), (300, 5000, 512, "centered", 2.0),
+         (2, 480000, 512, "centered", 2.0), (1, 2048, 512, "left", 2.0), (7, 20001, 77, "centered", 0.7), (64, 48000, 1024, "centered", 2.0)]
+for i, (lead, n, hop, al, power) in enumerate(cases):
+    x = torch.from_numpy(rng.uniform(-1, 1, size=(lead, n)).astype(np.float32)).cuda()
+    c = Stft.Config.create(fft_size=2048, hop=hop, alignment=al)
+    out["p%%d" %% i] = Stft.power_spectrum(c, x, power).cpu().numpy()
+    total = Stft.frames(c, n)
+    if total > 40:
+        out["r%%d" %% i] = Stft.power_range(c, x, 3, total - 5, power).cpu().numpy()
+np.savez(sys.argv[1], **out)
+""" % ROOT
+    import tempfile
+    res = []
+    for ring in ("0", "1"):
+        env = dict(os.environ, SMX_POWER_RING=ring)
+        path = tempfile.mktemp(suffix=".npz")
+        subprocess.run([sys.executable, "-c", code, path], check=True, env=env, timeout=500)
+        res.append(dict(np.load(path)))
+        os.remove(path)
+    assert res[0].keys() == res[1].keys() and len(res[0]) >= 12
+    for k in res[0]:
+        assert np.array_equal(res[0][k], res[1][k]), k
