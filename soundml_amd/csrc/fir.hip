@@ -42,6 +42,10 @@ struct smx_fir_plan {
     float2 *h_half = nullptr; // H[k] / (4 M), k = 0 .. M  (the 1/2 of the real post-pass, the 1/2 of the inverse
                               // pre-pass and the inverse transform's 1/M folded in)
     float2 *tw_m = nullptr;   // exp(-2 pi i j / M), j < M/2
+    // wave-split kernel (N = 32768: sixteen 1024-point sub-transforms, one per wave): tables in the order its lanes read
+    float2 *h_split = nullptr;  // h_half[16 k' + r] at [1024 r + k'], h_half[M] at [M]
+    float2 *w_split = nullptr;  // exp(-2 pi i (16 k' + r) / N) at [1024 r + k']
+    float2 *tw_1k = nullptr;    // exp(-2 pi i j / 1024), j < 512
   };
   const Tables &tables() const;
   ~smx_fir_plan();
@@ -73,9 +77,11 @@ struct FirArgs {
   // half-size kernel
   const float2 *h_half; // H[k] / (4 M), k <= M
   const float2 *tw_m;   // exp(-2 pi i j / M), j < M/2
+  const float2 *h_split, *w_split, *tw_1k;   // wave-split kernel
   int64_t lead;         // samples of every circular result that are discarded (even, >= taps - 1)
   int64_t step;         // block advance = N - lead (even)
   int64_t blocks_per_channel;
+  int64_t channels;
 };
 
 using namespace fftdev;
@@ -228,6 +234,156 @@ __global__ void __launch_bounds__((1 << LOG2M) / 16, 4) fir_ols_real_kernel(FirA
     }
 }
 
+// ---- N = 32768: the half-size transform split over the workgroup's sixteen waves ---------------------------------
+// M = 16384 = 16 x 1024.  One radix-16 pass over the whole block (element n = n' + 1024 q: thread n' holds q = 0..15,
+// lane-contiguous 8-byte reads), then sixteen independent 1024-point transforms: bins k = 16 k' + r belong to sub-transform r,
+//   X[16 k' + r] = sum_n' w_1024^(n' k') [ w_M^(n' r) sum_q x[n' + 1024 q] w_16^(q r) ].
+// Sub-transform r is the work of WAVE r alone: its three passes exchange through the wave's own 8 KB of LDS with no workgroup
+// barrier (DS operations of a wave complete in order), so the sixteen waves drift out of phase and one wave's LDS round trips
+// overlap the others' butterflies.  The inverse mirrors it (decimation in time: the waves' sub-transforms first, then the
+// twiddles and ONE radix-16 pass across waves whose outputs are lane-contiguous sample pairs again).  Five workgroup barriers per
+// block where the pass-by-pass kernel has sixteen (it spends 42 % of its wave time waiting at them).  Measured on C4 (one box,
+// alternating processes): pass-by-pass 0.107 ms, wave-split 0.104, wave-split + persistent workgroups that request the next
+// block's samples before the last pass 0.098.  The pointwise stage
+// takes pairs (k, M - k) = (r, k') and (16 - r, 1023 - k') from two waves' regions; its tables are stored in that order.
+template <bool ALIGNED>
+__global__ void __launch_bounds__(1024, 4) fir_ols_split_kernel(FirArgs a) {
+  constexpr int M = 16384, T = 1024;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  float2 *z = reinterpret_cast<float2 *>(smem);
+  const int tid = threadIdx.x;
+  // Persistent: one workgroup per CU (128 KB of LDS) walks blocks blockIdx.x, + gridDim.x, ...; the NEXT block's sixteen sample
+  // pairs are requested before the current block's last pass and stores, so a block no longer opens with an exposed trip to HBM.
+  auto load_block = [&](int64_t b, c32 (&v)[16]) {
+    const int64_t channel = b / a.blocks_per_channel, blk = b % a.blocks_per_channel;
+    const float *x = a.x + channel * a.x_stride;
+    const int64_t base = blk * a.step - a.lead;      // first sample of the window (even)
+    int tl = threadIdx.x;
+    asm volatile("" : "+v"(tl));
+    if (ALIGNED && base >= 0 && base + 2 * M <= a.n) {     // the whole window lies inside the stream (block-uniform)
+      const float2 *src = reinterpret_cast<const float2 *>(x + base) + tl;
+#pragma unroll
+      for (int q = 0; q < 16; ++q) {
+        const float2 t = src[T * q];
+        v[q] = {t.x, t.y};
+      }
+    } else {
+#pragma unroll
+      for (int q = 0; q < 16; ++q) {
+        const int64_t g = base + 2 * (int64_t)(tl + T * q);
+        v[q].x = (g >= 0 && g < a.n) ? x[g] : 0.0f;
+        v[q].y = (g + 1 >= 0 && g + 1 < a.n) ? x[g + 1] : 0.0f;
+      }
+    }
+  };
+  const int64_t total = a.channels * a.blocks_per_channel;
+  c32 r[16], nxt[16];
+  load_block(blockIdx.x, nxt);
+  for (int64_t b = blockIdx.x; b < total; b += gridDim.x) {
+#pragma unroll
+    for (int q = 0; q < 16; ++q) r[q] = nxt[q];
+    {   // the radix-16 pass across the block, then w_M^(n' r)
+      const float2 w1 = a.tw_m[tid];
+      fft16(r);
+      c32 w[16];
+      twiddle_powers<16>(c32{w1.x, w1.y}, w);
+#pragma unroll
+      for (int j = 1; j < 16; ++j) r[j] = cmul(r[j], w[j]);
+      const int pos = swz(tid);
+#pragma unroll
+      for (int j = 0; j < 16; ++j) z[1024 * j + pos] = make_float2(r[j].x, r[j].y);
+    }
+    __syncthreads();
+    int lane = tid & 63, wave = tid >> 6;
+    asm volatile("" : "+v"(lane));
+    float2 *zr = z + 1024 * wave;
+    fft_passes<10, false, true, float, true>(r, zr, lane, a.tw_1k);
+    // r[4 i + j] = bin k' = lane + 64 i + 256 j of this wave's sub-transform
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) zr[swz(lane + 64 * i + 256 * j)] = make_float2(r[4 * i + j].x, r[4 * i + j].y);
+    __syncthreads();
+    // pointwise stage (real post-pass, product with H, inverse pre-pass) over the pairs (k, M - k)
+    auto pair = [&](int rr, int kq, bool self) {
+      const int rp = (16 - rr) & 15, kp = rr ? 1023 - kq : ((1024 - kq) & 1023);
+      float2 *pa = z + 1024 * rr + swz(kq), *pb = z + 1024 * rp + swz(kp);
+      const float2 A = *pa, B = *pb;
+      const float2 w = a.w_split[1024 * rr + kq];
+      const float2 hk = a.h_split[1024 * rr + kq];
+      const float2 hp = (rr == 0 && kq == 0) ? a.h_split[M] : a.h_split[1024 * rp + kp];
+      const c32 E = {A.x + B.x, A.y - B.y}, D = {A.x - B.x, A.y + B.y};
+      const c32 t = cmul(D, c32{w.x, w.y});
+      const c32 Xk = {E.x + t.y, E.y - t.x};                  // E - i w D          (= 2 X[k])
+      const c32 Xp = {E.x - t.y, -(E.y + t.x)};               // conj(E + i w D)    (= 2 X[M-k])
+      const c32 Yk = cmul(Xk, c32{hk.x, hk.y}), Yp = cmul(Xp, c32{hp.x, hp.y});
+      const c32 P = {Yk.x + Yp.x, Yk.y - Yp.y}, Q = {Yk.x - Yp.x, Yk.y + Yp.y};
+      const c32 u = cmul(Q, c32{w.x, -w.y});                  // conj(w) Q
+      // the inverse runs as conj(FFT(conj .)): store the conjugates of Z'[k] = P + i conj(w) Q, Z'[M-k] = conj(P - i conj(w) Q)
+      *pa = make_float2(P.x - u.y, -(P.y + u.x));
+      if (!self) *pb = make_float2(P.x + u.y, P.y - u.x);
+    };
+    int tp = tid;
+    asm volatile("" : "+v"(tp));
+#pragma unroll
+    for (int m = 1; m < 8; ++m) {
+      pair(m, tp, false);
+      if (m == 4) __builtin_amdgcn_sched_barrier(0);
+    }
+    if (tp < 512) pair(8, tp, false);          // (8, k') with (8, 1023 - k')
+    else pair(0, tp - 512, tp == 512);         // (0, k') with (0, 1024 - k'), k' < 512; k' = 0 pairs with itself and carries bin M
+    if (tid == 0) pair(0, 512, true);          // k = M/2
+    __syncthreads();
+    int li = tid & 63;
+    asm volatile("" : "+v"(li));
+    float2 *zi = z + 1024 * (tid >> 6);
+    fft_passes<10, false, true, float, true>(r, zi, li, a.tw_1k);
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) zi[swz(li + 64 * i + 256 * j)] = make_float2(r[4 * i + j].x, r[4 * i + j].y);
+    __syncthreads();
+    int to = tid;
+    asm volatile("" : "+v"(to));
+    {
+      const int pos = swz(to);
+#pragma unroll
+      for (int j = 0; j < 16; ++j) {
+        const float2 v = z[1024 * j + pos];
+        r[j] = {v.x, v.y};
+      }
+    }
+    __syncthreads();   // every wave holds its points: the next block's first pass may overwrite the buffer
+    if (b + gridDim.x < total) load_block(b + gridDim.x, nxt);   // in flight across the last pass and the stores (issuing it after the twiddles measured the same)
+    {
+      const float2 w1 = a.tw_m[to];
+      c32 w[16];
+      twiddle_powers<16>(c32{w1.x, w1.y}, w);
+#pragma unroll
+      for (int j = 1; j < 16; ++j) r[j] = cmul(r[j], w[j]);
+      fft16(r);
+    }
+    const int64_t channel = b / a.blocks_per_channel, blk = b % a.blocks_per_channel;
+    float *y = a.y + channel * a.y_stride;
+    const int64_t out0 = blk * a.step - a.out_shift;   // y index of the block's first kept sample
+    const bool whole = out0 >= 0 && out0 + a.step <= a.n_out;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+      const int64_t s = 2 * (int64_t)(to + T * q) - a.lead;   // position inside the kept span (even)
+      if (s >= 0 && s < a.step) {
+        const int64_t o = out0 + s;
+        const float re = r[q].x, im = -r[q].y;   // conj(FFT(conj .))
+        if (ALIGNED && whole) {
+          *reinterpret_cast<float2 *>(y + o) = make_float2(re, im);
+        } else {
+          if (o >= 0 && o < a.n_out) y[o] = re;
+          if (o + 1 >= 0 && o + 1 < a.n_out) y[o + 1] = im;
+        }
+      }
+    }
+  }
+}
+
 // ---- resample stages ("Resample OLS stages -- true rate conversion on the FIR kernel") ----------
 // xu[c][q L] = x[c][q], zeros between: the interpolated-rate input of a xL stage
 __global__ void __launch_bounds__(256) zero_stuff_kernel(const float *x, int64_t n, int64_t x_stride, int l, float *xu,
@@ -349,6 +505,26 @@ const smx_fir_plan::Tables &smx_fir_plan::tables() const {
     SMX_HIP_CHECK(hipMemcpy(t.h_half, hh.data(), hh.size() * sizeof(float2), hipMemcpyHostToDevice));
     SMX_HIP_CHECK(hipMalloc((void **)&t.tw_m, twm.size() * sizeof(float2)));
     SMX_HIP_CHECK(hipMemcpy(t.tw_m, twm.data(), twm.size() * sizeof(float2), hipMemcpyHostToDevice));
+    if (log2n == 15) {   // the wave-split kernel's tables, in the order its lanes read them
+      std::vector<float2> hs((size_t)M + 1), ws((size_t)M), t1k(512);
+      for (int64_t k = 0; k < M; ++k) {
+        const size_t at = (size_t)((k % 16) * 1024 + k / 16);
+        hs[at] = hh[(size_t)k];
+        const double ang = -2.0 * M_PI * (double)k / (double)N;
+        ws[at] = make_float2((float)std::cos(ang), (float)std::sin(ang));
+      }
+      hs[(size_t)M] = hh[(size_t)M];
+      for (int j = 0; j < 512; ++j) {
+        const double ang = -2.0 * M_PI * (double)j / 1024.0;
+        t1k[(size_t)j] = make_float2((float)std::cos(ang), (float)std::sin(ang));
+      }
+      SMX_HIP_CHECK(hipMalloc((void **)&t.h_split, hs.size() * sizeof(float2)));
+      SMX_HIP_CHECK(hipMemcpy(t.h_split, hs.data(), hs.size() * sizeof(float2), hipMemcpyHostToDevice));
+      SMX_HIP_CHECK(hipMalloc((void **)&t.w_split, ws.size() * sizeof(float2)));
+      SMX_HIP_CHECK(hipMemcpy(t.w_split, ws.data(), ws.size() * sizeof(float2), hipMemcpyHostToDevice));
+      SMX_HIP_CHECK(hipMalloc((void **)&t.tw_1k, t1k.size() * sizeof(float2)));
+      SMX_HIP_CHECK(hipMemcpy(t.tw_1k, t1k.data(), t1k.size() * sizeof(float2), hipMemcpyHostToDevice));
+    }
   }
   SMX_HIP_CHECK(hipMalloc((void **)&t.h_nat, hb.size() * sizeof(float2)));
   SMX_HIP_CHECK(hipMemcpy(t.h_nat, hb.data(), hb.size() * sizeof(float2), hipMemcpyHostToDevice));
@@ -363,6 +539,9 @@ smx_fir_plan::~smx_fir_plan() {
     (void)hipFree(kv.second.tw);
     (void)hipFree(kv.second.h_half);
     (void)hipFree(kv.second.tw_m);
+    (void)hipFree(kv.second.h_split);
+    (void)hipFree(kv.second.w_split);
+    (void)hipFree(kv.second.tw_1k);
   }
 }
 
@@ -386,6 +565,18 @@ int guarded_fir(F &&body) {
 }  // namespace
 
 namespace smx {
+static int64_t device_cu_count() {
+  static int64_t cached[64] = {};
+  int device = 0;
+  SMX_HIP_CHECK(hipGetDevice(&device));
+  if (device < 0 || device >= 64) return 256;
+  if (cached[device] == 0) {
+    hipDeviceProp_t prop;
+    SMX_HIP_CHECK(hipGetDeviceProperties(&prop, device));
+    cached[device] = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+  }
+  return cached[device];
+}
 // y[c][i] = (h * x[c])[out_shift + i], i in [0, n_out): the convolution of n input samples (zeros outside), any window of it
 void fir_apply_window_dev(const smx_fir_plan &p, const float *d_x, int64_t channels, int64_t n, int64_t x_stride,
                           float *d_y, int64_t y_stride, int64_t n_out, int64_t out_shift, hipStream_t stream) {
@@ -410,6 +601,9 @@ void fir_apply_window_dev(const smx_fir_plan &p, const float *d_x, int64_t chann
   a.tw = t.tw;
   a.h_half = t.h_half;
   a.tw_m = t.tw_m;
+  a.h_split = t.h_split;
+  a.w_split = t.w_split;
+  a.tw_1k = t.tw_1k;
   static const bool packed_env = [] { const char *e = std::getenv("SMX_FIR_PACKED"); return e && e[0] == '1'; }();
   const bool packed = packed_env && p.log2n <= 14;
   if (!packed) {   // one real block per workgroup, half-size transform
@@ -432,7 +626,22 @@ void fir_apply_window_dev(const smx_fir_plan &p, const float *d_x, int64_t chann
       case 12: aligned ? launch(fir_ols_real_kernel<11, true>, 128) : launch(fir_ols_real_kernel<11, false>, 128); break;
       case 13: aligned ? launch(fir_ols_real_kernel<12, true>, 256) : launch(fir_ols_real_kernel<12, false>, 256); break;
       case 14: aligned ? launch(fir_ols_real_kernel<13, true>, 512) : launch(fir_ols_real_kernel<13, false>, 512); break;
-      case 15: aligned ? launch(fir_ols_real_kernel<14, true>, 1024) : launch(fir_ols_real_kernel<14, false>, 1024); break;
+      case 15: {
+        static const bool pass_by_pass = [] { const char *e = std::getenv("SMX_FIR_SPLIT"); return e && e[0] == '0'; }();   // A/B timing
+        if (pass_by_pass) aligned ? launch(fir_ols_real_kernel<14, true>, 1024) : launch(fir_ols_real_kernel<14, false>, 1024);
+        else {
+          a.channels = channels;
+          const int64_t cus = device_cu_count();
+          const unsigned g = (unsigned)(grid < cus ? grid : cus);   // persistent: one workgroup per CU walks the blocks
+          auto launch_p = [&](auto kernel) {
+            SMX_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kernel),
+                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            SMX_LAUNCH(kernel, dim3(g), dim3(1024), lds, stream, a);
+          };
+          aligned ? launch_p(fir_ols_split_kernel<true>) : launch_p(fir_ols_split_kernel<false>);
+        }
+        break;
+      }
       default: throw Failure("fir_apply: unsupported block size");
     }
     SMX_HIP_CHECK(hipGetLastError());

@@ -2,8 +2,9 @@
 // over a device-resident spectrogram [lead; bins; frames] (frames fastest).
 //
 // Both are reductions along the bin axis with a float64 interior and one rounding to the spectrogram's dtype,
-// in the reference's operation order (normalise the frame, then weight, then reduce; s^power floored, then the
-// two means).  Frames sit across lanes, so every load of a bin row is one coalesced run of 64 frames; the
+// in the reference's operation order for float64 input (normalise the frame, then weight, then reduce; s^power floored,
+// then the two means); float32 input divides by the frame's sum after the weighted reduction instead of before it (one
+// walk over the spectrogram less; the same value to a rounding of the float64 interior).  Frames sit across lanes, so every load of a bin row is one coalesced run of 64 frames; the
 // features are HBM-bound (one to three passes over the spectrogram, the later ones mostly from L2 / MALL).
 //
 //   features:  a workgroup owns 64 frames; its Q = 4 waves each walk a quarter of the bins and the partial
@@ -82,14 +83,30 @@ __global__ void __launch_bounds__(64 * Q * tiles_of<Q>) spectral_kernel(Spectral
   double result = 0.0;
 
   if constexpr (FEATURE == SPECTRAL_FLATNESS) {
-    double sl = 0.0, sa = 0.0;
-    for_bins(col, a.frames, k0, k1, [&](int64_t, double v) {
+    // sum of logs as the log of a product: mantissas multiply (renormalised every 8 factors, so the product stays
+    // above 2^-9), exponents add as integers; one log per wave instead of one per bin (the float64 log was what this
+    // feature spent its time on: 246 M of them at C2).  Same value to a few ulp of the float64 sum.
+    double prod = 1.0, sa = 0.0;
+    int64_t esum = 0;
+    for_bins(col, a.frames, k0, k1, [&](int64_t k, double v) {
       bad |= !(v >= 0.0);
       const double pw = pow_fixed(v, a.power);
-      const double f = pw > a.p ? pw : a.p;            // a.p = amin
-      sl += log(f);
+      const double f = pw > a.p ? pw : a.p;            // a.p = amin > 0
       sa += f;
+      if (f < INFINITY) {
+        prod *= __builtin_amdgcn_frexp_mant(f);
+        esum += __builtin_amdgcn_frexp_exp(f);
+      } else {
+        prod = f;                                       // an infinite (or NaN) bin: the sum of logs is that too
+      }
+      if (((k - k0) & 7) == 7) {                        // wave-uniform
+        if (prod < INFINITY) {
+          esum += __builtin_amdgcn_frexp_exp(prod);
+          prod = __builtin_amdgcn_frexp_mant(prod);
+        }
+      }
     });
+    double sl = log(prod) + (double)esum * 0.693147180559945309417232121458;
     sl = combine(sl, 0);
     sa = combine(sa, 1);
     result = exp(sl / (double)a.bins) / (sa / (double)a.bins);
@@ -109,20 +126,28 @@ __global__ void __launch_bounds__(64 * Q * tiles_of<Q>) spectral_kernel(Spectral
     });
     result = best;
   } else {
-    double len = 0.0;
-    for_bins(col, a.frames, k0, k1, [&](int64_t, double v) {
+    // one walk gives the frame's sum and its first moment: sum(f_k (v_k / len)) is evaluated as sum(f_k v_k) / len, the
+    // same value to a rounding of the float64 interior (the reference normalises first: spectral.ml:155-163, 171-196)
+    // float32 spectrograms only: with float64 input f_k v_k can overflow where f_k (v_k / len) does not, so that dtype
+    // keeps the reference's order and its extra walk
+    constexpr bool kFused = sizeof(T) == 4;
+    double len = 0.0, m1 = 0.0;
+    const bool need_c = !(FEATURE == SPECTRAL_BANDWIDTH && a.centroid);
+    for_bins(col, a.frames, k0, k1, [&](int64_t k, double v) {
       bad |= !(v >= 0.0);
       len += v;
+      if (kFused && need_c) m1 += fq(k) * v;
     });
     len = combine(len, 0);
     const double safe = len < DBL_MIN ? 1.0 : len;     // spectral.ml:155-163
     double c64;
-    if (FEATURE == SPECTRAL_BANDWIDTH && a.centroid) {
+    if (!need_c) {
       c64 = (double)reinterpret_cast<const T *>(a.centroid)[clip * a.frames + tc];
+    } else if constexpr (kFused) {
+      c64 = combine(m1, 1) / safe;
     } else {
-      double c = 0.0;
-      for_bins(col, a.frames, k0, k1, [&](int64_t k, double v) { c += fq(k) * (v / safe); });
-      c64 = combine(c, 1);
+      for_bins(col, a.frames, k0, k1, [&](int64_t k, double v) { m1 += fq(k) * (v / safe); });
+      c64 = combine(m1, 1);
     }
     if constexpr (FEATURE == SPECTRAL_CENTROID) {
       result = c64;
@@ -130,9 +155,10 @@ __global__ void __launch_bounds__(64 * Q * tiles_of<Q>) spectral_kernel(Spectral
       double w = 0.0;
       for_bins(col, a.frames, k0, k1, [&](int64_t k, double v) {
         const double deviation = fabs(c64 - fq(k));
-        w += (v / safe) * pow_fixed(deviation, a.p);
+        w += (kFused ? v : v / safe) * pow_fixed(deviation, a.p);
       });
       w = combine(w, 0);
+      if (kFused) w /= safe;
       result = a.p == 2.0 ? sqrt(w) : (a.p == 1.0 ? w : pow(w, a.inv_p));
     }
   }
