@@ -88,6 +88,8 @@ __device__ __forceinline__ void swap16(float &a, float &b) {
 __device__ __forceinline__ void transpose16(float (&v)[16]) {
   SMX_SWAP8("v_permlane32_swap_b32", v, 0, 8, 1, 9, 2, 10, 3, 11, 4, 12, 5, 13, 6, 14, 7, 15);
   SMX_SWAP8("v_permlane16_swap_b32", v, 0, 4, 1, 5, 2, 6, 3, 7, 8, 12, 9, 13, 10, 14, 11, 15);
+  // (the two DPP steps as one asm block per eight pairs -- no per-pair s_nop from hipcc's hazard recogniser, 34 -> 15 per
+  // frame -- measured the same: 0.5705 vs 0.5701 / 0.5732 ms, profiles/r04/ab_dpp_batch.log)
 #pragma unroll
   for (int k = 0; k < 16; ++k)
     if (!(k & 2)) {
@@ -486,7 +488,7 @@ __device__ __forceinline__ void frame_to_tile(const FastArgs &a, const LaneConst
     for (int k = 1; k < 16; ++k) tw[k] = L.tabA_l[64 * k];
   }
 #pragma unroll
-  for (int j = 0; j < 16; ++j) v[j] = {raw[j].x * win[j].x, raw[j].y * win[j].y};
+  for (int j = 0; j < 16; ++j) v[j] = {raw[j].x * win[j].x, raw[j].y * win[j].y};   // hipcc fuses these into the first butterflies (a w_a +- c w_c: one product, two fmas)
   if constexpr (SMX_ABL(6) || SMX_ABL(9)) {   // timing-only: memory traffic and synchronisation without the FFT (9: no loads either)
     hook.template at<0>(); hook.template at<2>(); hook.template at<5>(); hook.template at<8>(); hook.template at<11>();
     hook.ready(cells);
