@@ -1666,11 +1666,13 @@ void launch_interior(const StftJob &job, const FastTarget &tg, const float *x, i
                          : stft2048_power_kernel<true, true, false, 0>;
   (void)aligned; (void)square; (void)strip;
 #else
-  // SMX_POWER_RING=1: the ring-form kernel (whole 64-byte-aligned blocks: write traffic 1.07x instead of 1.33x the
-  // algorithmic bytes; same values bit for bit).  Measured 3 % behind the column kernel at C2 and 7 % ahead on the
-  // 71 GB C5 batch, so the column kernel stays the default.
+  // The ring-form kernel (whole 64-byte-aligned blocks: write traffic 1.07x instead of 1.3-1.4x the algorithmic bytes; same
+  // values bit for bit).  Measured 3 % behind the column kernel at C2 (1.5 GB), level with it at 8.9 GB (512 thirty-second
+  // clips) and steady at 430-450 Mframes/s from there to the 71 GB C5 batch, where the column kernel falls to 330-430 depending
+  // on the box (profiles/r04/c5_ring_sizes.log): it takes the launches whose input + output pass 8 GB.  SMX_POWER_RING=1 / 0 forces it.
   const char *ring_env = std::getenv("SMX_POWER_RING");
-  const bool ring = ring_env && ring_env[0] == '1';
+  const double ring_footprint = (double)job.lead * ((double)n + (double)kBins * (double)count) * 4.0;
+  const bool ring = ring_env ? ring_env[0] == '1' : (!strip && ring_footprint > 8.0e9);
   auto pick = [&](auto strip_tag) {
     constexpr bool S = decltype(strip_tag)::value;
     constexpr int F = SMX_RING_FLUSH_AT;
