@@ -38,8 +38,9 @@ def load():
     return lib
 
 
-def stft(c: O.StftConfig, x: np.ndarray, power=2.0, complex_out=False, threads=1) -> np.ndarray:
-    """power_spectrum / transform of the C oracle for power-of-two fft sizes."""
+def stft(c: O.StftConfig, x: np.ndarray, power=2.0, complex_out=False, threads=1, out=None) -> np.ndarray:
+    """power_spectrum / transform of the C oracle for power-of-two fft sizes.  `out`: a C-contiguous array of the result's
+    shape and dtype to fill (bench.py's cpu_baseline times the call on pages that are already mapped)."""
     lib = load()
     x = np.ascontiguousarray(x)
     assert x.dtype in (np.float32, np.float64)
@@ -47,10 +48,11 @@ def stft(c: O.StftConfig, x: np.ndarray, power=2.0, complex_out=False, threads=1
     lead = int(np.prod(lead_shape)) if lead_shape else 1
     count = O.frames(c, n)
     f32 = x.dtype == np.float32
-    if complex_out:
-        out = np.zeros(lead_shape + (c.bins, count), dtype=np.complex64 if f32 else np.complex128)
-    else:
-        out = np.zeros(lead_shape + (c.bins, count), dtype=x.dtype)
+    shape = lead_shape + (c.bins, count)
+    dtype = (np.complex64 if f32 else np.complex128) if complex_out else x.dtype
+    if out is None:
+        out = np.zeros(shape, dtype=dtype)
+    assert out.shape == shape and out.dtype == dtype and out.flags["C_CONTIGUOUS"]
     w = np.ascontiguousarray(c.analysis_window, dtype=np.float64)
     fn = lib.oracle_stft_f32 if f32 else lib.oracle_stft_f64
     rc = fn(x.ctypes.data, lead, n, c.fft_size, c.hop, w.ctypes.data, O.left_width(c), _PAD[c.pad],
