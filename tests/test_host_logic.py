@@ -5,6 +5,7 @@ frame grid, coordinates, mel filterbank, FIR design) matches the reference's
 golden vectors and the oracle.  No compute entry point is called here."""
 import os
 import re
+import subprocess
 
 import numpy as np
 import pytest
@@ -525,3 +526,16 @@ def test_ocaml_stubs_agree_with_the_header_and_the_externals():
     for m in re.finditer(r"`(smx_[a-z0-9_]+?)(?:_\{f32,f64\})?`", doc):
         base = m.group(1)
         assert any(d == base or d.startswith(base) for d in declared), "INTEGRATION.md names %s" % base
+
+
+def test_ocaml_stubs_compile_against_the_c_abi():
+    """ocaml/soundml_amd_stubs.c through `gcc -fsyntax-only` with include/soundml_amd.h and stand-in declarations of the
+    OCaml runtime's C interface (tests/ocaml_shim: there is no OCaml toolchain in the image): every smx_* call has the
+    header's argument count and types, every CAMLprim is well-formed C."""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cmd = ["gcc", "-std=c11", "-fsyntax-only", "-Wall", "-Wextra", "-Wno-unused-parameter",
+           "-Werror=implicit-function-declaration", "-Werror=incompatible-pointer-types", "-Werror=int-conversion",
+           "-I", os.path.join(root, "tests", "ocaml_shim"), "-I", os.path.join(root, "include"),
+           os.path.join(root, "ocaml", "soundml_amd_stubs.c")]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0 and "warning" not in r.stderr, r.stderr
