@@ -38,6 +38,31 @@ def load():
     return lib
 
 
+def effective_cpus() -> int:
+    """CPUs this process may really use: the affinity mask capped by the cgroup's CPU quota (the GPU boxes show 256 logical
+    CPUs and a quota of 16: more threads than that only buy throttling)."""
+    import math
+    import os
+    n = os.cpu_count() or 1
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except AttributeError:
+        pass
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, math.ceil(int(quota) / int(period))))
+    except (OSError, ValueError):
+        try:
+            quota = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            period = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if quota > 0:
+                n = min(n, max(1, math.ceil(quota / period)))
+        except (OSError, ValueError):
+            pass
+    return max(1, n)
+
+
 def stft(c: O.StftConfig, x: np.ndarray, power=2.0, complex_out=False, threads=1, out=None) -> np.ndarray:
     """power_spectrum / transform of the C oracle for power-of-two fft sizes.  `out`: a C-contiguous array of the result's
     shape and dtype to fill (bench.py's cpu_baseline times the call on pages that are already mapped)."""

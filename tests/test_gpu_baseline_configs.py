@@ -30,7 +30,7 @@ from soundml_amd import Fir, Mel, Stft
 pytestmark = pytest.mark.gpu
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-CORES = os.cpu_count() or 1
+CORES = c_oracle.effective_cpus()
 CONTRACT = 1e-5        # north_star
 REGRESSION = 2e-6      # of the peak; measured 2-8e-7
 
