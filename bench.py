@@ -91,7 +91,8 @@ def launch_ranks(n):
             p.kill()          # the exact child we started
             p.wait()
         worst = worst or p.returncode
-    sys.stdout.write(out.decode())
+    for ln in out.decode().splitlines():   # ONE JSON line on stdout; whatever else a library printed there (gloo's banner) goes to stderr
+        (sys.stdout if ln.lstrip().startswith("{") else sys.stderr).write(ln + "\n")
     sys.stdout.flush()
     return worst             # a failed rank is a failed run: no retry, never a re-exec
 
