@@ -1304,6 +1304,197 @@ bool launch_bluestein_power16(const StftJob &job, GenericArgs a, const StftTable
   return true;
 }
 
+// ---- even sizes whose half length L = N / 2 is 2^a 3^b 5^c (fft 400, 480, 640, 800, 960, 1000, ...): a direct mixed-radix
+// transform instead of the chirp-z convolution (two power-of-two transforms of length >= 2 L - 1 and three pointwise
+// products: five times the arithmetic at fft 400).  One wave owns a frame: the windowed (even, odd) sample pairs go to the
+// frame's buffer in LDS, Stockham (autosort) passes of radix 4 / 2 / 5 / 3 ping-pong between its two buffers -- butterfly j of a
+// pass with sub-transform length Ns reads j + t L / R, multiplies by exp(-2 pi i t (j mod Ns) / (Ns R)) from ONE table of
+// exp(-2 pi i j / L), and writes (j - j mod Ns) R + j mod Ns + t Ns -- wave-private, no workgroup barrier; then the real
+// post-pass and |X|^p as in the power-of-two kernel, and the columns leave through columns_out (MEL: straight through the
+// float32 MFMA).  Same interface and tile shape as stft_bluestein_power16_kernel, which it replaces for these sizes.
+struct MixedPlan {
+  int npass;
+  int radix[10];
+  const float2 *tw_l;   // exp(-2 pi i j / L), j < L
+  const float2 *tw_n;   // exp(-2 pi i k / N), k <= L
+};
+
+template <int R>
+__device__ __forceinline__ void dft_small(fftdev::c32 (&v)[5]) {
+  using namespace fftdev;
+  if constexpr (R == 2) {
+    const c32 a = v[0], b = v[1];
+    v[0] = a + b;
+    v[1] = a - b;
+  } else if constexpr (R == 4) {
+    fft4(v[0], v[1], v[2], v[3]);
+  } else if constexpr (R == 3) {
+    constexpr float s = 0.86602540378443865f;
+    const c32 t1 = v[1] + v[2], d = v[1] - v[2];
+    const c32 t2 = {v[0].x - 0.5f * t1.x, v[0].y - 0.5f * t1.y};
+    const c32 r = {s * d.y, -s * d.x};            // -i s d
+    v[0] = v[0] + t1;
+    v[1] = t2 + r;
+    v[2] = t2 - r;
+  } else {
+    constexpr float c1 = 0.30901699437494742f, c2 = -0.80901699437494742f;   // cos(2 pi / 5), cos(4 pi / 5)
+    constexpr float s1 = 0.95105651629515357f, s2 = 0.58778525229247313f;    // sin(2 pi / 5), sin(4 pi / 5)
+    const c32 a1 = v[1] + v[4], a2 = v[2] + v[3], b1 = v[1] - v[4], b2 = v[2] - v[3];
+    const c32 x0 = v[0];
+    const c32 e1 = {x0.x + c1 * a1.x + c2 * a2.x, x0.y + c1 * a1.y + c2 * a2.y};
+    const c32 e2 = {x0.x + c2 * a1.x + c1 * a2.x, x0.y + c2 * a1.y + c1 * a2.y};
+    const c32 d1 = {s1 * b1.x + s2 * b2.x, s1 * b1.y + s2 * b2.y};
+    const c32 d2 = {s2 * b1.x - s1 * b2.x, s2 * b1.y - s1 * b2.y};
+    v[0] = x0 + a1 + a2;
+    v[1] = {e1.x + d1.y, e1.y - d1.x};            // e1 - i d1
+    v[4] = {e1.x - d1.y, e1.y + d1.x};
+    v[2] = {e2.x + d2.y, e2.y - d2.x};
+    v[3] = {e2.x - d2.y, e2.y + d2.x};
+  }
+}
+
+template <int R>
+__device__ __forceinline__ void mixed_pass(const float2 *src, float2 *dst, int L, int ns, int lane, const float2 *tw_l) {
+  using namespace fftdev;
+  const int nb = L / R, stride = L / (ns * R);
+  for (int j = lane; j < nb; j += 64) {
+    const int k = j % ns;
+    c32 v[5];
+#pragma unroll
+    for (int t = 0; t < R; ++t) {
+      const float2 u = src[j + t * nb];
+      v[t] = {u.x, u.y};
+    }
+    if (ns > 1) {
+      const int step = k * stride;              // t * step < R * L / R = L: no wrap
+#pragma unroll
+      for (int t = 1; t < R; ++t) {
+        const float2 w = tw_l[t * step];
+        v[t] = cmul(v[t], c32{w.x, w.y});
+      }
+    }
+    dft_small<R>(v);
+    const int o = (j - k) * R + k;
+#pragma unroll
+    for (int t = 0; t < R; ++t) dst[o + t * ns] = make_float2(v[t].x, v[t].y);
+  }
+}
+
+template <int LOG2LP, typename Tin, bool MEL>   // LP = frame buffer capacity in complex values (>= L)
+__global__ void __launch_bounds__(1024) stft_mixed_power16_kernel(GenericArgs a, MixedPlan pl, MelTail mt) {
+  using namespace fftdev;
+  constexpr int LP = 1 << LOG2LP, FT = 16, BUF = 4 * LP;   // two buffers of LP float2 per frame
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  float2 *work = reinterpret_cast<float2 *>(smem);
+  const int N = (int)a.fft, L = N / 2;
+  const int64_t tiles = (a.count + FT - 1) / FT;
+  const int64_t clip = blockIdx.x / tiles, tile = blockIdx.x % tiles;
+  const Tin *x = reinterpret_cast<const Tin *>(a.x) + clip * a.x_stride;
+  const float *window = reinterpret_cast<const float *>(a.window);       // 0.5 * analysis window
+  const int lane = threadIdx.x & 63, f = threadIdx.x >> 6;
+  float2 *za = work + (size_t)f * (2 * LP), *zb = za + LP;
+  const int64_t f0 = tile * FT;
+  const int nf = (int)((a.count - f0) < FT ? (a.count - f0) : FT);
+  const bool have = f < nf;
+  const TileBands tb = load_tile_bands<MEL>(mt);
+  float val[LP / 64], nyq = 0.0f;
+#pragma unroll
+  for (int m = 0; m < LP / 64; ++m) val[m] = 0.0f;
+  if (have) {   // wave-uniform
+    const int64_t s0 = (a.p0 + f0 + f) * a.hop - a.left;
+    const bool inside = s0 >= 0 && s0 + N <= a.n;
+    for (int i = lane; i < L; i += 64) {
+      const float v0 = inside ? (float)x[s0 + 2 * i] : (float)fetch_sample<Tin>(x, a.n, s0 + 2 * i, a.pad, a.pad_value);
+      const float v1 = inside ? (float)x[s0 + 2 * i + 1] : (float)fetch_sample<Tin>(x, a.n, s0 + 2 * i + 1, a.pad, a.pad_value);
+      za[i] = make_float2(v0 * window[2 * i], v1 * window[2 * i + 1]);
+    }
+    stockham_sync<true>();
+    const float2 *src = za;
+    float2 *dst = zb;
+    int ns = 1;
+    for (int p = 0; p < pl.npass; ++p) {
+      const int r = pl.radix[p];                // uniform
+      if (r == 4) mixed_pass<4>(src, dst, L, ns, lane, pl.tw_l);
+      else if (r == 2) mixed_pass<2>(src, dst, L, ns, lane, pl.tw_l);
+      else if (r == 5) mixed_pass<5>(src, dst, L, ns, lane, pl.tw_l);
+      else mixed_pass<3>(src, dst, L, ns, lane, pl.tw_l);
+      ns *= r;
+      stockham_sync<true>();
+      const float2 *sw = src;
+      src = dst;
+      dst = const_cast<float2 *>(sw);
+    }
+    const float2 *z = src;                       // the transform, natural order
+#pragma unroll
+    for (int m = 0; m < LP / 64; ++m) {
+      const int k = lane + 64 * m;
+      if (k < L) {
+        const float2 zk = z[k], zm = z[k == 0 ? 0 : L - k];
+        const float er = zk.x + zm.x, ei = zk.y - zm.y;
+        const float dr = zk.x - zm.x, di = zk.y + zm.y;
+        const float2 w = pl.tw_n[k];
+        val[m] = magnitude_pow<float, float>(er + (w.x * di + w.y * dr), ei - (w.x * dr - w.y * di), a.power);
+      }
+    }
+    if (lane == 0) {
+      const float2 z0 = z[0];
+      nyq = magnitude_pow<float, float>(2.0f * (z0.x - z0.y), 0.0f, a.power);
+    }
+    stockham_sync<true>();
+  } else {   // no frame: a column of zeros (the MFMA tail reads a few values past bin L, times zero weights: keep them finite)
+    for (int i = lane; i < LP; i += 64) za[i] = make_float2(0.0f, 0.0f);
+    stockham_sync<true>();
+  }
+  float *col = reinterpret_cast<float *>(za) + 2 * f;   // column f of the tile: L + 1 floats in the frame's own region
+#pragma unroll
+  for (int m = 0; m < LP / 64; ++m) {
+    const int k = lane + 64 * m;
+    if (k < L) col[k] = val[m];
+  }
+  if (lane == 0) col[L] = nyq;
+  __syncthreads();
+  columns_out<BUF, FT, MEL>(a, mt, reinterpret_cast<const float *>(work), L + 1, nf, clip, f0, tb,
+                            MEL ? reinterpret_cast<float *>(smem + (size_t)FT * BUF * sizeof(float)) : nullptr);
+}
+
+template <int LOG2LP>
+bool launch_mixed_power16(const StftJob &job, GenericArgs a, const StftTables &t, const MixedPlan &pl, const MelTail *mel) {
+  constexpr int LP = 1 << LOG2LP;
+  a.window = t.blu2_window;
+  const int64_t blocks = a.lead * ((a.count + 15) / 16);
+  if (blocks > 2147483647LL) throw Failure("stft: too many frame tiles for one launch");
+  const size_t lds = (size_t)16 * 4 * LP * sizeof(float);
+  if (mel) {
+    const size_t lds_mel = lds + (size_t)16 * 1024;   // the helper waves' partial tiles (columns_out): one KB per wave
+    auto kernel = stft_mixed_power16_kernel<LOG2LP, float, true>;
+    SMX_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_mel));
+    SMX_LAUNCH(kernel, dim3((unsigned)blocks), dim3(1024), lds_mel, job.stream, a, pl, *mel);
+  } else {
+    auto kernel = stft_mixed_power16_kernel<LOG2LP, float, false>;
+    SMX_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    SMX_LAUNCH(kernel, dim3((unsigned)blocks), dim3(1024), lds, job.stream, a, pl, MelTail{});
+  }
+  SMX_HIP_CHECK(hipGetLastError());
+  return true;
+}
+
+// true when the size has a mixed-radix plan (StftTables::mixed_npass > 0) and the kernel took the launch
+bool launch_mixed16_any(const StftJob &job, const GenericArgs &a, const StftTables &t, const MelTail *mel) {
+  if (t.mixed_npass <= 0 || !t.mixed_tw || !t.blu2_window || !t.twiddle_f32) return false;
+  static const bool off = [] { const char *e = std::getenv("SMX_MIXED_OFF"); return e && e[0] == '1'; }();   // A/B timing: chirp-z instead
+  if (off) return false;
+  MixedPlan pl{};
+  pl.npass = t.mixed_npass;
+  for (int i = 0; i < t.mixed_npass; ++i) pl.radix[i] = t.mixed_radix[i];
+  pl.tw_l = t.mixed_tw;
+  pl.tw_n = (const float2 *)t.twiddle_f32;
+  const int64_t l = a.fft / 2;
+  if (l <= 128) return launch_mixed_power16<7>(job, a, t, pl, mel);
+  if (l <= 256) return launch_mixed_power16<8>(job, a, t, pl, mel);
+  if (l <= 512) return launch_mixed_power16<9>(job, a, t, pl, mel);
+  return false;
+}
+
 // even non-power-of-two sizes up to 1024 (chirp-z length M <= 1024): power / mel through the 16-frame kernel
 bool launch_bluestein16_any(const StftJob &job, const GenericArgs &a, const StftTables &t, const MelTail *mel) {
   switch (t.blu2_log2m) {
@@ -1435,7 +1626,7 @@ bool launch_mel_spectrogram_16(const MelSpecJob &job) {
 #endif
   mt.k_pad = (int)mtab.k_pad;
   mt.out = reinterpret_cast<float *>(job.out);
-  if (chirp_16) return launch_bluestein16_any(sj, a, t, &mt);
+  if (chirp_16) return launch_mixed16_any(sj, a, t, &mt) || launch_bluestein16_any(sj, a, t, &mt);
   return c.fft_size == 512 ? launch_stockham_power16<9>(sj, a, t, &mt) : launch_stockham_power16<10>(sj, a, t, &mt);
 }
 
@@ -1493,7 +1684,7 @@ void launch_stft_generic(const StftJob &job) {
     }
     const char *bf = std::getenv("SMX_BLUESTEIN_FULL");   // diagnostic: the full-length chirp-z for even sizes too
     if (!done && t.blu2_log2m >= 8 && t.blu2_log2m <= 10 && job.mode != OUT_COMPLEX && !(bf && bf[0] == '1') && !(sf && sf[0] == '1'))
-      done = launch_bluestein16_any(job, a, t, nullptr);
+      done = launch_mixed16_any(job, a, t, nullptr) || launch_bluestein16_any(job, a, t, nullptr);
     if (!done && t.blu2_log2m >= 8 && !(bf && bf[0] == '1')) {   // even, not a power of two: half-length chirp-z
       switch (t.blu2_log2m) {
         case 8: done = launch_bluestein_real<8>(job, a, t); break;

@@ -229,6 +229,25 @@ const smx::StftTables &smx_stft_config::tables() const {
         t.blu2_tw = smx::upload(tw);
         t.blu2_window = smx::upload(hw);
         t.blu2_log2m = log2m2;
+        // L = 2^a 3^b 5^c <= 512 (and not a power of two: those have the Stockham kernels): radices 4, 2, 5, 3
+        if (l <= 512 && (l & (l - 1)) != 0) {
+          int64_t rest = l;
+          int np = 0, radix[10];
+          while (rest % 4 == 0 && np < 10) { radix[np++] = 4; rest /= 4; }
+          while (rest % 2 == 0 && np < 10) { radix[np++] = 2; rest /= 2; }
+          while (rest % 5 == 0 && np < 10) { radix[np++] = 5; rest /= 5; }
+          while (rest % 3 == 0 && np < 10) { radix[np++] = 3; rest /= 3; }
+          if (rest == 1 && np > 0) {
+            std::vector<float2> twl((size_t)l);
+            for (int64_t j = 0; j < l; ++j) {
+              const double a = -2.0 * M_PI * (double)j / (double)l;
+              twl[(size_t)j] = make_float2((float)std::cos(a), (float)std::sin(a));
+            }
+            t.mixed_tw = smx::upload(twl);
+            t.mixed_npass = np;
+            for (int i = 0; i < np; ++i) t.mixed_radix[i] = radix[i];
+          }
+        }
       }
     }
   }
@@ -325,6 +344,7 @@ smx_stft_config::~smx_stft_config() {
     (void)hipFree(t.blu2_filter);
     (void)hipFree(t.blu2_tw);
     (void)hipFree(t.blu2_window);
+    (void)hipFree(t.mixed_tw);
   }
 }
 
