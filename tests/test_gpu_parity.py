@@ -10,10 +10,12 @@ Tolerances
   * float32 interior (the fast path): north_star's 1e-5 relative, evaluated as
     |a - e| <= 1e-5 * max|e| + 1e-5 * |e| per signal (BASELINE.md "Parity gate").
 """
+import os
+
 import numpy as np
 import pytest
 
-from conftest import (F32_ATOL, F32_RTOL, F64_ATOL, F64_RTOL, check_close, load_golden)
+from conftest import (F32_ATOL, F32_RTOL, F64_ATOL, F64_RTOL, ROOT, check_close, load_golden)
 from oracle import soundml_oracle as O
 
 # every synthesis vector file of the reference (soundml/test/istft/vectors; Griffin-Lim files apart)
@@ -195,6 +197,59 @@ def test_other_sizes_float32(fft, hop):
     cuts = [0, 1, 5, total // 2, total - 1, total]
     parts = [Stft.transform_range(c, x, a, b) for a, b in zip(cuts[:-1], cuts[1:])]
     assert np.array_equal(np.concatenate(parts, axis=-1), z)
+
+
+@pytest.mark.parametrize("fft", [12, 20, 24, 30, 36, 40, 48, 60, 100, 120, 160, 200, 240, 320, 400, 480, 600, 640, 800, 960, 1000])
+def test_mixed_radix_sizes(fft):
+    """Even sizes whose half length is 2^a 3^b 5^c (not a power of two, <= 512): the power spectrogram and the fused mel
+    spectrogram come from the direct mixed-radix kernel (stft_mixed_power16_kernel: radix 4 / 2 / 5 / 3 passes), every
+    radix combination up to fft 1000; against the oracle, with a regression gate (the kernel's measured error is
+    2-4e-7 of the peak), ragged last tile, reflected borders, a general power, and the chirp-z kernel it replaces as a
+    second opinion (SMX_MIXED_OFF is read once per process, so that comparison runs in a child process)."""
+    rng = np.random.default_rng(fft)
+    hop = max(1, fft // 3)
+    n = 37 * hop + fft // 2 + 5
+    x = rng.uniform(-1, 1, size=(3, n)).astype(np.float32)
+    c, o = Stft.Config.create(fft_size=fft, hop=hop), O.stft_config(fft, hop=hop)
+    for power in (2.0, 1.0):
+        got, want = Stft.power_spectrum(c, x, power), O.power_spectrum(o, x, power)
+        check_fast(got, want, "power %g" % power)
+        assert np.max(np.abs(got - want)) <= 2e-6 * np.max(np.abs(want)), "regression gate"
+    total = Stft.frames(c, n)
+    a, b = total // 3, total - 2
+    assert np.array_equal(Stft.power_range(c, x, a, b), Stft.power_spectrum(c, x)[..., a:b])
+    if fft >= 64:
+        try:
+            mc = Mel.Config.create(n_mels=20, sample_rate=16000, fft_size=fft)
+        except S.InvalidArgument:
+            mc = None
+        if mc is not None:
+            check_fast(S.mel_spectrogram(c, mc, x), O.mel_spectrogram(o, O.mel_config(20, 16000, fft), x), "mel")
+
+
+def test_mixed_radix_kernel_agrees_with_chirp_z():
+    code = """
+import sys, numpy as np
+sys.path.insert(0, %r)
+from soundml_amd import Stft
+rng = np.random.default_rng(5)
+out = {}
+for fft in (100, 400, 960):
+    x = rng.uniform(-1, 1, size=(2, 9 * fft + 17)).astype(np.float32)
+    out[str(fft)] = Stft.power_spectrum(Stft.Config.create(fft_size=fft, hop=fft // 4), x)
+np.savez(sys.argv[1], **out)
+""" % ROOT
+    import subprocess, sys, tempfile
+    res = []
+    for off in ("0", "1"):
+        path = tempfile.mktemp(suffix=".npz")
+        subprocess.run([sys.executable, "-c", code, path], check=True, env=dict(os.environ, SMX_MIXED_OFF=off), timeout=300)
+        res.append(dict(np.load(path)))
+        os.remove(path)
+    for k in res[0]:
+        peak = float(np.max(res[0][k]))
+        assert np.max(np.abs(res[0][k] - res[1][k])) <= 2e-6 * peak, k
+        assert not np.array_equal(res[0][k], res[1][k]), "both runs took the same kernel"
 
 
 @pytest.mark.parametrize("fft,hop,alignment,pad", [(512, 128, "centered", "reflect"), (1024, 256, "left", "edge"),
