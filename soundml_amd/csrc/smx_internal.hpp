@@ -84,7 +84,7 @@ struct StftTables {
   float2 *blu2_tw = nullptr;       // exp(-2 pi i j / M2), j < M2/2
   float *blu2_window = nullptr;    // 0.5 * window, N entries
   int blu2_log2m = 0;
-  // even sizes with N / 2 = 2^a 3^b 5^c <= 512, not a power of two: the mixed-radix kernel's plan (stft_mixed_power16_kernel)
+  // even sizes with N / 2 = 2^a 3^b 5^c <= 1024, not a power of two: the mixed-radix kernel's plan (stft_mixed_power16_kernel)
   float2 *mixed_tw = nullptr;      // exp(-2 pi i j / L), j < L = N / 2
   int mixed_npass = 0;
   int mixed_radix[10] = {};

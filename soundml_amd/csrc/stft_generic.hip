@@ -1380,10 +1380,10 @@ __device__ __forceinline__ void mixed_pass(const float2 *src, float2 *dst, int L
   }
 }
 
-template <int LOG2LP, typename Tin, bool MEL>   // LP = frame buffer capacity in complex values (>= L)
-__global__ void __launch_bounds__(1024) stft_mixed_power16_kernel(GenericArgs a, MixedPlan pl, MelTail mt) {
+template <int LOG2LP, typename Tin, bool MEL, int FT = 16>   // LP = frame buffer capacity in complex values (>= L)
+__global__ void __launch_bounds__(64 * FT) stft_mixed_power16_kernel(GenericArgs a, MixedPlan pl, MelTail mt) {
   using namespace fftdev;
-  constexpr int LP = 1 << LOG2LP, FT = 16, BUF = 4 * LP;   // two buffers of LP float2 per frame
+  constexpr int LP = 1 << LOG2LP, BUF = 4 * LP;   // two buffers of LP float2 per frame
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   float2 *work = reinterpret_cast<float2 *>(smem);
   const int N = (int)a.fft, L = N / 2;
@@ -1457,13 +1457,21 @@ __global__ void __launch_bounds__(1024) stft_mixed_power16_kernel(GenericArgs a,
                             MEL ? reinterpret_cast<float *>(smem + (size_t)FT * BUF * sizeof(float)) : nullptr);
 }
 
-template <int LOG2LP>
+template <int LOG2LP, int FT = 16>
 bool launch_mixed_power16(const StftJob &job, GenericArgs a, const StftTables &t, const MixedPlan &pl, const MelTail *mel) {
   constexpr int LP = 1 << LOG2LP;
   a.window = t.blu2_window;
-  const int64_t blocks = a.lead * ((a.count + 15) / 16);
+  const int64_t blocks = a.lead * ((a.count + FT - 1) / FT);
   if (blocks > 2147483647LL) throw Failure("stft: too many frame tiles for one launch");
-  const size_t lds = (size_t)16 * 4 * LP * sizeof(float);
+  const size_t lds = (size_t)FT * 4 * LP * sizeof(float);
+  if constexpr (FT != 16) {
+    if (mel) return false;   // the MFMA tail is 16 frames wide
+    auto kernel = stft_mixed_power16_kernel<LOG2LP, float, false, FT>;
+    SMX_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    SMX_LAUNCH(kernel, dim3((unsigned)blocks), dim3(64 * FT), lds, job.stream, a, pl, MelTail{});
+    SMX_HIP_CHECK(hipGetLastError());
+    return true;
+  } else
   if (mel) {
     const size_t lds_mel = lds + (size_t)16 * 1024;   // the helper waves' partial tiles (columns_out): one KB per wave
     auto kernel = stft_mixed_power16_kernel<LOG2LP, float, true>;
@@ -1492,6 +1500,7 @@ bool launch_mixed16_any(const StftJob &job, const GenericArgs &a, const StftTabl
   if (l <= 128) return launch_mixed_power16<7>(job, a, t, pl, mel);
   if (l <= 256) return launch_mixed_power16<8>(job, a, t, pl, mel);
   if (l <= 512) return launch_mixed_power16<9>(job, a, t, pl, mel);
+  if (l <= 1024) return launch_mixed_power16<10, 8>(job, a, t, pl, mel);   // 128 KB of LDS: eight frames per workgroup, power only
   return false;
 }
 
@@ -1683,8 +1692,10 @@ void launch_stft_generic(const StftJob &job) {
       default: break;
     }
     const char *bf = std::getenv("SMX_BLUESTEIN_FULL");   // diagnostic: the full-length chirp-z for even sizes too
+    if (!done && job.mode != OUT_COMPLEX && !(bf && bf[0] == '1') && !(sf && sf[0] == '1'))   // N / 2 = 2^a 3^b 5^c <= 1024: direct mixed-radix transform
+      done = launch_mixed16_any(job, a, t, nullptr);
     if (!done && t.blu2_log2m >= 8 && t.blu2_log2m <= 10 && job.mode != OUT_COMPLEX && !(bf && bf[0] == '1') && !(sf && sf[0] == '1'))
-      done = launch_mixed16_any(job, a, t, nullptr) || launch_bluestein16_any(job, a, t, nullptr);
+      done = launch_bluestein16_any(job, a, t, nullptr);
     if (!done && t.blu2_log2m >= 8 && !(bf && bf[0] == '1')) {   // even, not a power of two: half-length chirp-z
       switch (t.blu2_log2m) {
         case 8: done = launch_bluestein_real<8>(job, a, t); break;

@@ -229,8 +229,8 @@ const smx::StftTables &smx_stft_config::tables() const {
         t.blu2_tw = smx::upload(tw);
         t.blu2_window = smx::upload(hw);
         t.blu2_log2m = log2m2;
-        // L = 2^a 3^b 5^c <= 512 (and not a power of two: those have the Stockham kernels): radices 4, 2, 5, 3
-        if (l <= 512 && (l & (l - 1)) != 0) {
+        // L = 2^a 3^b 5^c <= 1024 (and not a power of two: those have the Stockham kernels): radices 4, 2, 5, 3
+        if (l <= 1024 && (l & (l - 1)) != 0) {
           int64_t rest = l;
           int np = 0, radix[10];
           while (rest % 4 == 0 && np < 10) { radix[np++] = 4; rest /= 4; }

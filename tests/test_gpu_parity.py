@@ -199,7 +199,7 @@ def test_other_sizes_float32(fft, hop):
     assert np.array_equal(np.concatenate(parts, axis=-1), z)
 
 
-@pytest.mark.parametrize("fft", [12, 20, 24, 30, 36, 40, 48, 60, 100, 120, 160, 200, 240, 320, 400, 480, 600, 640, 800, 960, 1000])
+@pytest.mark.parametrize("fft", [12, 20, 24, 30, 36, 40, 48, 60, 100, 120, 160, 200, 240, 320, 400, 480, 600, 640, 800, 960, 1000, 1200, 1920, 2000])
 def test_mixed_radix_sizes(fft):
     """Even sizes whose half length is 2^a 3^b 5^c (not a power of two, <= 512): the power spectrogram and the fused mel
     spectrogram come from the direct mixed-radix kernel (stft_mixed_power16_kernel: radix 4 / 2 / 5 / 3 passes), every

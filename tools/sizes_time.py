@@ -13,7 +13,10 @@ def t(fn, reps=15):
         a.record(); fn(); b.record(); torch.cuda.synchronize(); ts.append(a.elapsed_time(b))
     return sorted(ts)[len(ts) // 2]
 line = []
-for fft, hop, n in ((1024, 256, 441000), (512, 128, 441000), (400, 160, 160000), (4096, 1024, 480000), (2048, 512, 480000)):
+SIZES = ((1024, 256, 441000), (512, 128, 441000), (400, 160, 160000), (4096, 1024, 480000), (2048, 512, 480000))
+if len(sys.argv) > 1:   # fft:hop:n ...
+    SIZES = tuple(tuple(int(v) for v in a.split(":")) for a in sys.argv[1:])
+for fft, hop, n in SIZES:
     c = Stft.Config.create(fft_size=fft, hop=hop)
     frames = Stft.frames(c, n)
     x = torch.rand(256, n, device="cuda") * 2 - 1
