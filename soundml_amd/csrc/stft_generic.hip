@@ -1380,8 +1380,9 @@ __device__ __forceinline__ void mixed_pass(const float2 *src, float2 *dst, int L
   }
 }
 
-template <int LOG2LP, typename Tin, bool MEL, int FT = 16>   // LP = frame buffer capacity in complex values (>= L)
+template <int LOG2LP, typename Tin, bool MEL, int FT = 16, bool CPLX = false>   // LP = frame buffer capacity in complex values (>= L)
 __global__ void __launch_bounds__(64 * FT) stft_mixed_power16_kernel(GenericArgs a, MixedPlan pl, MelTail mt) {
+  static_assert(!(MEL && CPLX), "the mel tail takes powers");
   using namespace fftdev;
   constexpr int LP = 1 << LOG2LP, BUF = 4 * LP;   // two buffers of LP float2 per frame
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -1397,9 +1398,12 @@ __global__ void __launch_bounds__(64 * FT) stft_mixed_power16_kernel(GenericArgs
   const int nf = (int)((a.count - f0) < FT ? (a.count - f0) : FT);
   const bool have = f < nf;
   const TileBands tb = load_tile_bands<MEL>(mt);
-  float val[LP / 64], nyq = 0.0f;
+  float val[LP / 64], vim[CPLX ? LP / 64 : 1], nyq = 0.0f;
 #pragma unroll
-  for (int m = 0; m < LP / 64; ++m) val[m] = 0.0f;
+  for (int m = 0; m < LP / 64; ++m) {
+    val[m] = 0.0f;
+    if constexpr (CPLX) vim[m] = 0.0f;
+  }
   if (have) {   // wave-uniform
     const int64_t s0 = (a.p0 + f0 + f) * a.hop - a.left;
     const bool inside = s0 >= 0 && s0 + N <= a.n;
@@ -1433,17 +1437,54 @@ __global__ void __launch_bounds__(64 * FT) stft_mixed_power16_kernel(GenericArgs
         const float er = zk.x + zm.x, ei = zk.y - zm.y;
         const float dr = zk.x - zm.x, di = zk.y + zm.y;
         const float2 w = pl.tw_n[k];
-        val[m] = magnitude_pow<float, float>(er + (w.x * di + w.y * dr), ei - (w.x * dr - w.y * di), a.power);
+        const float xr = er + (w.x * di + w.y * dr), xi = ei - (w.x * dr - w.y * di);
+        if constexpr (CPLX) {
+          val[m] = k == 0 ? 2.0f * (zk.x + zk.y) : xr;     // X[0] is real
+          vim[m] = k == 0 ? 0.0f : xi;
+        } else {
+          val[m] = magnitude_pow<float, float>(xr, xi, a.power);
+        }
       }
     }
     if (lane == 0) {
       const float2 z0 = z[0];
-      nyq = magnitude_pow<float, float>(2.0f * (z0.x - z0.y), 0.0f, a.power);
+      nyq = CPLX ? 2.0f * (z0.x - z0.y) : magnitude_pow<float, float>(2.0f * (z0.x - z0.y), 0.0f, a.power);   // X[L] is real
     }
     stockham_sync<true>();
   } else {   // no frame: a column of zeros (the MFMA tail reads a few values past bin L, times zero weights: keep them finite)
     for (int i = lane; i < LP; i += 64) za[i] = make_float2(0.0f, 0.0f);
     stockham_sync<true>();
+  }
+  if constexpr (CPLX) {   // Stft.transform: complex columns of L + 1 values, rows leave as 16-byte pieces (two frames of one bin)
+    float2 *ccol = za + 2 * f;
+#pragma unroll
+    for (int m = 0; m < LP / 64; ++m) {
+      const int k = lane + 64 * m;
+      if (k < L) ccol[k] = make_float2(val[m], vim[m]);
+    }
+    if (lane == 0) ccol[L] = make_float2(nyq, 0.0f);
+    __syncthreads();
+    const float2 *cols = work;
+    float2 *out = reinterpret_cast<float2 *>(a.out);
+    const int64_t obase = clip * a.bins * a.out_stride + a.out_offset + f0;
+    constexpr int CS = 2 * LP;
+    if (nf == FT) {
+      constexpr int QF = FT / 2;
+      using f32x4 = __attribute__((ext_vector_type(4))) float;
+      for (int e = threadIdx.x; e < (L + 1) * QF; e += blockDim.x) {
+        const int k = e / QF, g = 2 * (e % QF);
+        const float2 c0 = cols[g * CS + 2 * g + k], c1 = cols[(g + 1) * CS + 2 * (g + 1) + k];
+        float2 *dst = out + obase + (int64_t)k * a.out_stride + g;
+        const f32x4 v = {c0.x, c0.y, c1.x, c1.y};
+        asm volatile("global_store_dwordx4 %0, %1, off" : : "v"(dst), "v"(v) : "memory");
+      }
+      return;
+    }
+    for (int e = threadIdx.x; e < (L + 1) * nf; e += blockDim.x) {   // a clip's ragged last tile
+      const int k = e / nf, g = e - k * nf;
+      out[obase + (int64_t)k * a.out_stride + g] = cols[g * CS + 2 * g + k];
+    }
+    return;
   }
   float *col = reinterpret_cast<float *>(za) + 2 * f;   // column f of the tile: L + 1 floats in the frame's own region
 #pragma unroll
@@ -1464,6 +1505,14 @@ bool launch_mixed_power16(const StftJob &job, GenericArgs a, const StftTables &t
   const int64_t blocks = a.lead * ((a.count + FT - 1) / FT);
   if (blocks > 2147483647LL) throw Failure("stft: too many frame tiles for one launch");
   const size_t lds = (size_t)FT * 4 * LP * sizeof(float);
+  if (job.mode == OUT_COMPLEX) {
+    if (mel) return false;
+    auto kernel = stft_mixed_power16_kernel<LOG2LP, float, false, FT, true>;
+    SMX_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    SMX_LAUNCH(kernel, dim3((unsigned)blocks), dim3(64 * FT), lds, job.stream, a, pl, MelTail{});
+    SMX_HIP_CHECK(hipGetLastError());
+    return true;
+  }
   if constexpr (FT != 16) {
     if (mel) return false;   // the MFMA tail is 16 frames wide
     auto kernel = stft_mixed_power16_kernel<LOG2LP, float, false, FT>;
@@ -1692,7 +1741,7 @@ void launch_stft_generic(const StftJob &job) {
       default: break;
     }
     const char *bf = std::getenv("SMX_BLUESTEIN_FULL");   // diagnostic: the full-length chirp-z for even sizes too
-    if (!done && job.mode != OUT_COMPLEX && !(bf && bf[0] == '1') && !(sf && sf[0] == '1'))   // N / 2 = 2^a 3^b 5^c <= 1024: direct mixed-radix transform
+    if (!done && !(bf && bf[0] == '1') && !(sf && sf[0] == '1'))   // N / 2 = 2^a 3^b 5^c <= 1024: direct mixed-radix transform (power or complex)
       done = launch_mixed16_any(job, a, t, nullptr);
     if (!done && t.blu2_log2m >= 8 && t.blu2_log2m <= 10 && job.mode != OUT_COMPLEX && !(bf && bf[0] == '1') && !(sf && sf[0] == '1'))
       done = launch_bluestein16_any(job, a, t, nullptr);
