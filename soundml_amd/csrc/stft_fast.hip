@@ -1250,7 +1250,7 @@ using f32x4v = __attribute__((ext_vector_type(4))) float;
 // Partial 16x16 sums travel from helper to owner through LDS: slots 0-2 in the pad column of the tile's
 // own buffer, slots 3-6 in the space of the post-pass twiddle table (which this kernel reads from global
 // memory instead), one set per buffer parity.
-constexpr int kMelHelpers = 7, kMelPadSlots = 3, kMelMaxSteps = 24;
+constexpr int kMelHelpers = 11, kMelPadSlots = 3, kMelMaxSteps = 24;   // 11 helper pieces: 20 .. 128 mels all get a plan (7 covered 128 only)
 struct MelItem {          // one per wave; wave-uniform, read through scalar loads
   int block;              // 16-mel block index
   int k4_begin, k4_count; // MFMA steps: bins [4 k4_begin, 4 (k4_begin + k4_count))
