@@ -727,7 +727,14 @@ __global__ void __launch_bounds__(1024) stft2048_power_kernel(FastArgs a) {
   auto frame_ptr = [&](const float *xc, int t, bool &hv) {
     const int64_t f0 = (int64_t)t * kFT;
     hv = f0 + wave < a.count;
-    return xc + ((a.p0 + f0 + (hv ? wave : 0)) * a.hop - a.left);
+    const int64_t p = a.p0 + f0 + (hv ? wave : 0);
+    // batches of many short clips (launch_ranges): the launch covers every frame and border frames come from gathered strips
+    if (a.fold_frames && (p < a.border_i0 || p >= a.border_i1)) {   // wave-uniform
+      const int64_t clip = (xc - a.x) / a.x_stride;
+      return p < a.border_i0 ? a.strip_l + clip * a.strip_l_stride + (p - a.p0) * a.hop
+                             : a.strip_r + clip * a.strip_r_stride + (p - a.border_i1) * a.hop;
+    }
+    return xc + (p * a.hop - a.left);
   };
 
   float2 raw[16];
@@ -1638,7 +1645,7 @@ void launch_interior(const StftJob &job, const FastTarget &tg, const float *x, i
   if (std::getenv("SMX_NOSTORE")) a.abl_nostore = 1;
   if (const char *w = std::getenv("SMX_ABL_RUN")) a.abl_nostore = std::atoi(w);   // 2: 128 B, 3: 256 B, 4: 512 B runs
   const char *ring_env = std::getenv("SMX_POWER_RING");
-  const bool ring = ring_env && ring_env[0] == '1';
+  const bool ring = ring_env && ring_env[0] == '1' && !tg.fold_frames;
   const char *fl_env = std::getenv("SMX_RING_FLUSH");
   const int fl_at = fl_env ? std::atoi(fl_env) : 2;
   a.abl_noskew = std::getenv("SMX_RING_NOSKEW") ? 1 : 0;
@@ -1672,7 +1679,7 @@ void launch_interior(const StftJob &job, const FastTarget &tg, const float *x, i
   // on the box (profiles/r04/c5_ring_sizes.log): it takes the launches whose input + output pass 8 GB.  SMX_POWER_RING=1 / 0 forces it.
   const char *ring_env = std::getenv("SMX_POWER_RING");
   const double ring_footprint = (double)job.lead * ((double)n + (double)kBins * (double)count) * 4.0;
-  const bool ring = ring_env ? ring_env[0] == '1' : (!strip && ring_footprint > 8.0e9);
+  const bool ring = !tg.fold_frames && (ring_env ? ring_env[0] == '1' : (!strip && ring_footprint > 8.0e9));   // the ring kernel has no strip reader
   auto pick = [&](auto strip_tag) {
     constexpr bool S = decltype(strip_tag)::value;
     constexpr int F = SMX_RING_FLUSH_AT;
@@ -1738,8 +1745,13 @@ void launch_ranges(const StftJob &job, const FastTarget &tg) {
   // power spectrogram: the border frames ride in the interior launch (no gathers, no extra launches) whenever
   // 32-bit sample positions suffice for the padding rule
   static const bool fold_off = std::getenv("SMX_NO_BORDER_FOLD") != nullptr;
+  // ... while the border frames of the whole batch are few (C2: 1024 of 240 128).  Batches of many short clips (16 384 one-second
+  // clips: 65 536 border frames of 524 288) take the gathered strips below instead: the epilogue's barrier-separated tiles and
+  // element-wise stores cost them more than the whole interior (2.76 ms against 1.1).
+  const int64_t border_total = job.lead * ((i0 - p0) + (p1 - i1));
+  static const int64_t epilogue_max = [] { const char *e = std::getenv("SMX_BORDER_EPILOGUE_MAX"); return e ? (int64_t)std::atoll(e) : (int64_t)20000; }();
   if (!tg.mel && !tg.complex_out && !fold_off && job.n < (int64_t(1) << 30) && (i0 - p0) + (p1 - i1) > 0 &&
-      (i0 - p0) + (p1 - i1) < 4096) {
+      (i0 - p0) + (p1 - i1) < 4096 && border_total <= epilogue_max) {
     FastTarget folded = tg;
     folded.border_left = (int)(i0 - p0);
     folded.border_right = (int)(p1 - i1);
@@ -1751,7 +1763,7 @@ void launch_ranges(const StftJob &job, const FastTarget &tg) {
   }
   // complex spectrogram / fused mel: ONE launch of the fused kernel over the whole request; the border frames' padded
   // spans are gathered first (two small launches) and the kernel takes those frames from the strips (C3: 0.66 -> 0.60 ms)
-  if ((tg.mel || tg.complex_out) && !fold_off && (i0 - p0) + (p1 - i1) > 0) {
+  if (!fold_off && (i0 - p0) + (p1 - i1) > 0) {   // (the power kernel too when the epilogue above was not taken)
     FastTarget folded = tg;
     folded.fold_frames = true;
     folded.border_p0 = i0;
