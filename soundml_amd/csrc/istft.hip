@@ -673,6 +673,83 @@ __global__ void __launch_bounds__(1024) istft2048_kernel(SynArgs a) {
   }
 }
 
+// ---- even sizes whose half length L = N / 2 is 2^a 3^b 5^c, float32 (fft 400, 480, 960, 1000, 1200 ...) ------------------------
+// The direct real inverse DFT of istft_frames_kernel is O(N^2) per frame (fft 400 / hop 160 on 256 x 30 s: 103 ms).  Here one wave
+// owns a frame: it reads its column of the spectrum (the 16 waves of a workgroup read the 16 neighbouring frames of the same
+// 128-byte lines), forms the half-size spectrum Z'[k] = E + i conj(w_k) D as the Stockham frames kernel does, runs the mixed-radix
+// passes of fft_device.hpp (conj(FFT_L(conj Z')), wave-private) and writes x[2n] + i x[2n+1] = z[n] times the synthesis window
+// into y[clip][frame][N]; istft_ola_kernel adds the frames up as before.
+struct MixedInv {
+  int npass;
+  int radix[10];
+  const float2 *tw_l;   // exp(-2 pi i j / L)
+  const float2 *tw_n;   // exp(-2 pi i k / N)
+};
+template <int LOG2LP, int FT>
+__global__ void __launch_bounds__(64 * FT) istft_mixed_frames_kernel(IstftArgs a, MixedInv pl) {
+  using namespace fftdev;
+  constexpr int LP = 1 << LOG2LP;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int lane = threadIdx.x & 63, f = threadIdx.x >> 6;
+  float2 *za = reinterpret_cast<float2 *>(smem) + (size_t)f * (2 * LP), *zb = za + LP;
+  const int N = (int)a.fft, L = N / 2;
+  const int64_t tiles = (a.count + FT - 1) / FT;
+  const int64_t clip = blockIdx.x / tiles, frame = (blockIdx.x % tiles) * FT + f;
+  if (frame >= a.count) return;                    // wave-uniform; no workgroup barrier below
+  const float2 *zin = reinterpret_cast<const float2 *>(a.z) + clip * (int64_t)(L + 1) * a.frames + frame;
+  for (int k = lane; k <= L; k += 64) zb[k] = zin[(int64_t)k * a.frames];
+  asm volatile("" ::: "memory");
+  for (int k = lane; k < L; k += 64) {
+    float2 zk = zb[k], zp = zb[L - k];
+    if (k == 0) { zk.y = 0.f; zp.y = 0.f; }         // the imaginary parts of the DC and Nyquist bins do not take part
+    const float er = zk.x + zp.x, ei = zk.y - zp.y; // E = Z[k] + conj Z[L-k]
+    const float dr = zk.x - zp.x, di = zk.y + zp.y; // D = Z[k] - conj Z[L-k]
+    const float2 w = pl.tw_n[k];
+    const float tr = er - (w.x * di - w.y * dr);    // Z' = E + i conj(w) D
+    const float ti = ei + (w.x * dr + w.y * di);
+    za[k] = make_float2(tr, -ti);                   // conj(Z')
+  }
+  asm volatile("" ::: "memory");
+  const float2 *r = mixed_transform(za, zb, L, pl.npass, pl.radix, lane, pl.tw_l);
+  const float *window = reinterpret_cast<const float *>(a.window);
+  const float inv_n = 1.0f / (float)N;
+  float2 *y = reinterpret_cast<float2 *>(reinterpret_cast<float *>(a.y) + (clip * a.count + frame) * (int64_t)N);
+  for (int n = lane; n < L; n += 64) {
+    const float2 v = r[n];
+    y[n] = make_float2(v.x * inv_n * window[2 * n], -v.y * inv_n * window[2 * n + 1]);
+  }
+}
+
+template <int LOG2LP, int FT>
+void launch_mixed_frames(const IstftArgs &a, const MixedInv &pl, hipStream_t stream) {
+  const int64_t blocks = a.lead * ((a.count + FT - 1) / FT);
+  if (blocks > 2147483647LL) throw Failure("invert: too many frame tiles for one launch");
+  const size_t lds = (size_t)FT * 2 * (size_t(1) << LOG2LP) * sizeof(float2);
+  auto kernel = istft_mixed_frames_kernel<LOG2LP, FT>;
+  SMX_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  SMX_LAUNCH(kernel, dim3((unsigned)blocks), dim3(64 * FT), lds, stream, a, pl);
+  SMX_HIP_CHECK(hipGetLastError());
+}
+
+// float32 spectra and interior, no Griffin-Lim factors: true when the mixed-radix frames kernel took the launch
+bool launch_mixed_frames_any(const IstftArgs &a, const StftTables &t, hipStream_t stream) {
+  if (t.mixed_npass <= 0 || !t.mixed_tw || !t.twiddle_f32 || a.mag || a.unit || a.fft % 2 != 0) return false;
+  static const bool off = [] { const char *e = std::getenv("SMX_MIXED_OFF"); return e && e[0] == '1'; }();
+  if (off) return false;
+  MixedInv pl{};
+  pl.npass = t.mixed_npass;
+  for (int i = 0; i < t.mixed_npass; ++i) pl.radix[i] = t.mixed_radix[i];
+  pl.tw_l = t.mixed_tw;
+  pl.tw_n = (const float2 *)t.twiddle_f32;
+  const int64_t l = a.fft / 2;
+  if (l < 128) launch_mixed_frames<7, 16>(a, pl, stream);
+  else if (l < 256) launch_mixed_frames<8, 16>(a, pl, stream);
+  else if (l < 512) launch_mixed_frames<9, 16>(a, pl, stream);
+  else if (l < 1024) launch_mixed_frames<10, 8>(a, pl, stream);
+  else return false;
+  return true;
+}
+
 constexpr size_t kLdsLimit = 160 * 1024;
 
 template <typename Tz, typename Tacc>
@@ -841,7 +918,7 @@ void launch_istft(const IstftJob &job) {
     } else if (f64) {
       if (!launch_stockham_frames_wide_any<float>(fa, t, job.stream)) launch_frames<float, double>(job, fa, job.stream);
     }
-    else if (!launch_stockham_frames_any(fa, t, job.stream)) launch_frames<float, float>(job, fa, job.stream);
+    else if (!launch_stockham_frames_any(fa, t, job.stream) && !launch_mixed_frames_any(fa, t, job.stream)) launch_frames<float, float>(job, fa, job.stream);
     OlaArgs oa{};
     oa.y = d_y;
     oa.out = reinterpret_cast<unsigned char *>(job.out) + c0 * job.out_len * elem_out;

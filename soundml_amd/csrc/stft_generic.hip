@@ -1319,67 +1319,6 @@ struct MixedPlan {
   const float2 *tw_n;   // exp(-2 pi i k / N), k <= L
 };
 
-template <int R>
-__device__ __forceinline__ void dft_small(fftdev::c32 (&v)[5]) {
-  using namespace fftdev;
-  if constexpr (R == 2) {
-    const c32 a = v[0], b = v[1];
-    v[0] = a + b;
-    v[1] = a - b;
-  } else if constexpr (R == 4) {
-    fft4(v[0], v[1], v[2], v[3]);
-  } else if constexpr (R == 3) {
-    constexpr float s = 0.86602540378443865f;
-    const c32 t1 = v[1] + v[2], d = v[1] - v[2];
-    const c32 t2 = {v[0].x - 0.5f * t1.x, v[0].y - 0.5f * t1.y};
-    const c32 r = {s * d.y, -s * d.x};            // -i s d
-    v[0] = v[0] + t1;
-    v[1] = t2 + r;
-    v[2] = t2 - r;
-  } else {
-    constexpr float c1 = 0.30901699437494742f, c2 = -0.80901699437494742f;   // cos(2 pi / 5), cos(4 pi / 5)
-    constexpr float s1 = 0.95105651629515357f, s2 = 0.58778525229247313f;    // sin(2 pi / 5), sin(4 pi / 5)
-    const c32 a1 = v[1] + v[4], a2 = v[2] + v[3], b1 = v[1] - v[4], b2 = v[2] - v[3];
-    const c32 x0 = v[0];
-    const c32 e1 = {x0.x + c1 * a1.x + c2 * a2.x, x0.y + c1 * a1.y + c2 * a2.y};
-    const c32 e2 = {x0.x + c2 * a1.x + c1 * a2.x, x0.y + c2 * a1.y + c1 * a2.y};
-    const c32 d1 = {s1 * b1.x + s2 * b2.x, s1 * b1.y + s2 * b2.y};
-    const c32 d2 = {s2 * b1.x - s1 * b2.x, s2 * b1.y - s1 * b2.y};
-    v[0] = x0 + a1 + a2;
-    v[1] = {e1.x + d1.y, e1.y - d1.x};            // e1 - i d1
-    v[4] = {e1.x - d1.y, e1.y + d1.x};
-    v[2] = {e2.x + d2.y, e2.y - d2.x};
-    v[3] = {e2.x - d2.y, e2.y + d2.x};
-  }
-}
-
-template <int R>
-__device__ __forceinline__ void mixed_pass(const float2 *src, float2 *dst, int L, int ns, int lane, const float2 *tw_l) {
-  using namespace fftdev;
-  const int nb = L / R, stride = L / (ns * R);
-  for (int j = lane; j < nb; j += 64) {
-    const int k = j % ns;
-    c32 v[5];
-#pragma unroll
-    for (int t = 0; t < R; ++t) {
-      const float2 u = src[j + t * nb];
-      v[t] = {u.x, u.y};
-    }
-    if (ns > 1) {
-      const int step = k * stride;              // t * step < R * L / R = L: no wrap
-#pragma unroll
-      for (int t = 1; t < R; ++t) {
-        const float2 w = tw_l[t * step];
-        v[t] = cmul(v[t], c32{w.x, w.y});
-      }
-    }
-    dft_small<R>(v);
-    const int o = (j - k) * R + k;
-#pragma unroll
-    for (int t = 0; t < R; ++t) dst[o + t * ns] = make_float2(v[t].x, v[t].y);
-  }
-}
-
 template <int LOG2LP, typename Tin, bool MEL, int FT = 16, bool CPLX = false>   // LP = frame buffer capacity in complex values (>= L)
 __global__ void __launch_bounds__(64 * FT) stft_mixed_power16_kernel(GenericArgs a, MixedPlan pl, MelTail mt) {
   static_assert(!(MEL && CPLX), "the mel tail takes powers");
@@ -1413,21 +1352,7 @@ __global__ void __launch_bounds__(64 * FT) stft_mixed_power16_kernel(GenericArgs
       za[i] = make_float2(v0 * window[2 * i], v1 * window[2 * i + 1]);
     }
     stockham_sync<true>();
-    const float2 *src = za;
-    float2 *dst = zb;
-    int ns = 1;
-    for (int p = 0; p < pl.npass; ++p) {
-      const int r = pl.radix[p];                // uniform
-      if (r == 4) mixed_pass<4>(src, dst, L, ns, lane, pl.tw_l);
-      else if (r == 2) mixed_pass<2>(src, dst, L, ns, lane, pl.tw_l);
-      else if (r == 5) mixed_pass<5>(src, dst, L, ns, lane, pl.tw_l);
-      else mixed_pass<3>(src, dst, L, ns, lane, pl.tw_l);
-      ns *= r;
-      stockham_sync<true>();
-      const float2 *sw = src;
-      src = dst;
-      dst = const_cast<float2 *>(sw);
-    }
+    const float2 *src = mixed_transform(za, zb, L, pl.npass, pl.radix, lane, pl.tw_l);
     const float2 *z = src;                       // the transform, natural order
 #pragma unroll
     for (int m = 0; m < LP / 64; ++m) {
