@@ -252,6 +252,21 @@ const smx::StftTables &smx_stft_config::tables() const {
     }
   }
 
+  // small powers of two (N = 4 .. 256, below the Stockham frames kernels of istft.hip): the same plan, for the inverse only
+  if (smx::is_pow2(n) && n >= 4 && n <= 256) {
+    int64_t rest = n / 2;
+    int np = 0;
+    while (rest % 4 == 0 && np < 10) { t.mixed_radix[np++] = 4; rest /= 4; }
+    while (rest % 2 == 0 && np < 10) { t.mixed_radix[np++] = 2; rest /= 2; }
+    std::vector<float2> twl((size_t)(n / 2));
+    for (int64_t j = 0; j < n / 2; ++j) {
+      const double a = -2.0 * M_PI * (double)j / (double)(n / 2);
+      twl[(size_t)j] = make_float2((float)std::cos(a), (float)std::sin(a));
+    }
+    t.mixed_tw = smx::upload(twl);
+    t.mixed_npass = np;
+  }
+
   // fast kernels (power-of-two N >= 64): half-scaled window and split tables
   if (smx::is_pow2(n) && n >= 64) {
     const int64_t m = n / 2;
