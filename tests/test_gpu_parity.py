@@ -227,10 +227,10 @@ def test_mixed_radix_sizes(fft):
             check_fast(S.mel_spectrogram(c, mc, x), O.mel_spectrogram(o, O.mel_config(20, 16000, fft), x), "mel")
 
 
-@pytest.mark.parametrize("fft", [12, 60, 100, 240, 400, 480, 800, 960, 1000, 1200, 2000])
+@pytest.mark.parametrize("fft", [4, 8, 12, 16, 60, 64, 100, 128, 240, 256, 400, 480, 800, 960, 1000, 1200, 2000])
 def test_mixed_radix_invert(fft):
     """Stft.invert at the same sizes: the frames come from the mixed-radix inverse kernel (istft_mixed_frames_kernel) instead
-    of the O(N^2) direct inverse DFT; against the oracle on the spectrum of a seeded signal (so the round trip is checked
+    of the O(N^2) direct inverse DFT (and, for the powers of two up to 256, instead of the radix-2 kernel); against the oracle on the spectrum of a seeded signal (so the round trip is checked
     too), complex64 spectra, float32 interior."""
     rng = np.random.default_rng(fft + 1)
     hop = fft // 4
