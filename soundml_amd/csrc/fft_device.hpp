@@ -248,31 +248,32 @@ struct LastPass {   // radix / sub-size of the final pass of fft_passes<LOG2N>
 // Butterfly j of a pass with sub-transform length ns reads j + t L / R from `src`, multiplies by exp(-2 pi i t (j mod ns) / (ns R))
 // taken from ONE table tw_l[j] = exp(-2 pi i j / L), and writes (j - j mod ns) R + j mod ns + t ns to `dst` (autosort: natural
 // order in, natural order out).  Used by stft_mixed_power16_kernel (stft_generic.hip) and istft_mixed_frames_kernel (istft.hip).
-template <int R>
-__device__ __forceinline__ void dft_small(c32 (&v)[5]) {
+template <int R, typename S>
+__device__ __forceinline__ void dft_small(cpx<S> (&v)[5]) {
+  using C = cpx<S>;
   if constexpr (R == 2) {
-    const c32 a = v[0], b = v[1];
+    const C a = v[0], b = v[1];
     v[0] = a + b;
     v[1] = a - b;
   } else if constexpr (R == 4) {
     fft4(v[0], v[1], v[2], v[3]);
   } else if constexpr (R == 3) {
-    constexpr float s = 0.86602540378443865f;
-    const c32 t1 = v[1] + v[2], d = v[1] - v[2];
-    const c32 t2 = {v[0].x - 0.5f * t1.x, v[0].y - 0.5f * t1.y};
-    const c32 r = {s * d.y, -s * d.x};            // -i s d
+    constexpr S s = (S)0.86602540378443865, h = (S)0.5;
+    const C t1 = v[1] + v[2], d = v[1] - v[2];
+    const C t2 = {v[0].x - h * t1.x, v[0].y - h * t1.y};
+    const C r = {s * d.y, -s * d.x};            // -i s d
     v[0] = v[0] + t1;
     v[1] = t2 + r;
     v[2] = t2 - r;
   } else {
-    constexpr float c1 = 0.30901699437494742f, c2 = -0.80901699437494742f;   // cos(2 pi / 5), cos(4 pi / 5)
-    constexpr float s1 = 0.95105651629515357f, s2 = 0.58778525229247313f;    // sin(2 pi / 5), sin(4 pi / 5)
-    const c32 a1 = v[1] + v[4], a2 = v[2] + v[3], b1 = v[1] - v[4], b2 = v[2] - v[3];
-    const c32 x0 = v[0];
-    const c32 e1 = {x0.x + c1 * a1.x + c2 * a2.x, x0.y + c1 * a1.y + c2 * a2.y};
-    const c32 e2 = {x0.x + c2 * a1.x + c1 * a2.x, x0.y + c2 * a1.y + c1 * a2.y};
-    const c32 d1 = {s1 * b1.x + s2 * b2.x, s1 * b1.y + s2 * b2.y};
-    const c32 d2 = {s2 * b1.x - s1 * b2.x, s2 * b1.y - s1 * b2.y};
+    constexpr S c1 = (S)0.30901699437494742, c2 = (S)-0.80901699437494742;   // cos(2 pi / 5), cos(4 pi / 5)
+    constexpr S s1 = (S)0.95105651629515357, s2 = (S)0.58778525229247313;    // sin(2 pi / 5), sin(4 pi / 5)
+    const C a1 = v[1] + v[4], a2 = v[2] + v[3], b1 = v[1] - v[4], b2 = v[2] - v[3];
+    const C x0 = v[0];
+    const C e1 = {x0.x + c1 * a1.x + c2 * a2.x, x0.y + c1 * a1.y + c2 * a2.y};
+    const C e2 = {x0.x + c2 * a1.x + c1 * a2.x, x0.y + c2 * a1.y + c1 * a2.y};
+    const C d1 = {s1 * b1.x + s2 * b2.x, s1 * b1.y + s2 * b2.y};
+    const C d2 = {s2 * b1.x - s1 * b2.x, s2 * b1.y - s1 * b2.y};
     v[0] = x0 + a1 + a2;
     v[1] = {e1.x + d1.y, e1.y - d1.x};            // e1 - i d1
     v[4] = {e1.x - d1.y, e1.y + d1.x};
@@ -281,47 +282,57 @@ __device__ __forceinline__ void dft_small(c32 (&v)[5]) {
   }
 }
 
-template <int R>
-__device__ __forceinline__ void mixed_pass(const float2 *src, float2 *dst, int L, int ns, int lane, const float2 *tw_l) {
+template <int R, typename S>
+__device__ __forceinline__ void mixed_pass(const typename vec2_of<S>::type *src, typename vec2_of<S>::type *dst, int L, int ns, int lane,
+                                           const typename vec2_of<S>::type *tw_l) {
+  using V = typename vec2_of<S>::type;
   const int nb = L / R, stride = L / (ns * R);
   for (int j = lane; j < nb; j += 64) {
     const int k = j % ns;
-    c32 v[5];
+    cpx<S> v[5];
 #pragma unroll
     for (int t = 0; t < R; ++t) {
-      const float2 u = src[j + t * nb];
+      const V u = src[j + t * nb];
       v[t] = {u.x, u.y};
     }
     if (ns > 1) {
       const int step = k * stride;              // t * step < R * L / R = L: no wrap
 #pragma unroll
       for (int t = 1; t < R; ++t) {
-        const float2 w = tw_l[t * step];
-        v[t] = cmul(v[t], c32{w.x, w.y});
+        const V w = tw_l[t * step];
+        v[t] = cmul(v[t], cpx<S>{w.x, w.y});
       }
     }
-    dft_small<R>(v);
+    dft_small<R, S>(v);
     const int o = (j - k) * R + k;
 #pragma unroll
-    for (int t = 0; t < R; ++t) dst[o + t * ns] = make_float2(v[t].x, v[t].y);
+    for (int t = 0; t < R; ++t) {
+      V q;
+      q.x = v[t].x;
+      q.y = v[t].y;
+      dst[o + t * ns] = q;
+    }
   }
 }
 
-// every pass of a plan (radices in pl_radix[0 .. npass)), ping-pong between two buffers of L values; returns the buffer that
+// every pass of a plan (radices in radix[0 .. npass)), ping-pong between two buffers of L values; returns the buffer that
 // holds the transform.  `lane` is the lane of the owning wave; DS operations of a wave complete in order, so the passes need
-// only compiler fences between them.
-__device__ __forceinline__ float2 *mixed_transform(float2 *a, float2 *b, int L, int npass, const int *radix, int lane, const float2 *tw_l) {
-  float2 *src = a, *dst = b;
+// only compiler fences between them.  S = float or double (the float64 interior).
+template <typename S>
+__device__ __forceinline__ typename vec2_of<S>::type *mixed_transform(typename vec2_of<S>::type *a, typename vec2_of<S>::type *b, int L, int npass,
+                                                                     const int *radix, int lane, const typename vec2_of<S>::type *tw_l) {
+  using V = typename vec2_of<S>::type;
+  V *src = a, *dst = b;
   int ns = 1;
   for (int p = 0; p < npass; ++p) {
     const int r = radix[p];                // uniform
-    if (r == 4) mixed_pass<4>(src, dst, L, ns, lane, tw_l);
-    else if (r == 2) mixed_pass<2>(src, dst, L, ns, lane, tw_l);
-    else if (r == 5) mixed_pass<5>(src, dst, L, ns, lane, tw_l);
-    else mixed_pass<3>(src, dst, L, ns, lane, tw_l);
+    if (r == 4) mixed_pass<4, S>(src, dst, L, ns, lane, tw_l);
+    else if (r == 2) mixed_pass<2, S>(src, dst, L, ns, lane, tw_l);
+    else if (r == 5) mixed_pass<5, S>(src, dst, L, ns, lane, tw_l);
+    else mixed_pass<3, S>(src, dst, L, ns, lane, tw_l);
     ns *= r;
     asm volatile("" ::: "memory");
-    float2 *sw = src;
+    V *sw = src;
     src = dst;
     dst = sw;
   }

@@ -679,73 +679,97 @@ __global__ void __launch_bounds__(1024) istft2048_kernel(SynArgs a) {
 // 128-byte lines), forms the half-size spectrum Z'[k] = E + i conj(w_k) D as the Stockham frames kernel does, runs the mixed-radix
 // passes of fft_device.hpp (conj(FFT_L(conj Z')), wave-private) and writes x[2n] + i x[2n+1] = z[n] times the synthesis window
 // into y[clip][frame][N]; istft_ola_kernel adds the frames up as before.
+template <typename S>
 struct MixedInv {
   int npass;
   int radix[10];
-  const float2 *tw_l;   // exp(-2 pi i j / L)
-  const float2 *tw_n;   // exp(-2 pi i k / N)
+  const typename fftdev::vec2_of<S>::type *tw_l;   // exp(-2 pi i j / L)
+  const typename fftdev::vec2_of<S>::type *tw_n;   // exp(-2 pi i k / N)
 };
-template <int LOG2LP, int FT>
-__global__ void __launch_bounds__(64 * FT) istft_mixed_frames_kernel(IstftArgs a, MixedInv pl) {
+// Tz: the spectrum's scalar type (complex64 / complex128); S: the interior (float, or double = the float64 interior; y is S)
+template <int LOG2LP, int FT, typename Tz, typename S>
+__global__ void __launch_bounds__(64 * FT) istft_mixed_frames_kernel(IstftArgs a, MixedInv<S> pl) {
   using namespace fftdev;
+  using V = typename vec2_of<S>::type;
+  using CZ = typename Vec2<Tz>::type;
   constexpr int LP = 1 << LOG2LP;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int lane = threadIdx.x & 63, f = threadIdx.x >> 6;
-  float2 *za = reinterpret_cast<float2 *>(smem) + (size_t)f * (2 * LP), *zb = za + LP;
+  V *za = reinterpret_cast<V *>(smem) + (size_t)f * (2 * LP), *zb = za + LP;
   const int N = (int)a.fft, L = N / 2;
   const int64_t tiles = (a.count + FT - 1) / FT;
   const int64_t clip = blockIdx.x / tiles, frame = (blockIdx.x % tiles) * FT + f;
   if (frame >= a.count) return;                    // wave-uniform; no workgroup barrier below
-  const float2 *zin = reinterpret_cast<const float2 *>(a.z) + clip * (int64_t)(L + 1) * a.frames + frame;
-  for (int k = lane; k <= L; k += 64) zb[k] = zin[(int64_t)k * a.frames];
-  asm volatile("" ::: "memory");
-  for (int k = lane; k < L; k += 64) {
-    float2 zk = zb[k], zp = zb[L - k];
-    if (k == 0) { zk.y = 0.f; zp.y = 0.f; }         // the imaginary parts of the DC and Nyquist bins do not take part
-    const float er = zk.x + zp.x, ei = zk.y - zp.y; // E = Z[k] + conj Z[L-k]
-    const float dr = zk.x - zp.x, di = zk.y + zp.y; // D = Z[k] - conj Z[L-k]
-    const float2 w = pl.tw_n[k];
-    const float tr = er - (w.x * di - w.y * dr);    // Z' = E + i conj(w) D
-    const float ti = ei + (w.x * dr + w.y * di);
-    za[k] = make_float2(tr, -ti);                   // conj(Z')
+  const CZ *zin = reinterpret_cast<const CZ *>(a.z) + clip * (int64_t)(L + 1) * a.frames + frame;
+  for (int k = lane; k <= L; k += 64) {
+    const CZ c = zin[(int64_t)k * a.frames];
+    V q;
+    q.x = (S)c.x;
+    q.y = (S)c.y;
+    zb[k] = q;
   }
   asm volatile("" ::: "memory");
-  const float2 *r = mixed_transform(za, zb, L, pl.npass, pl.radix, lane, pl.tw_l);
-  const float *window = reinterpret_cast<const float *>(a.window);
-  const float inv_n = 1.0f / (float)N;
-  float2 *y = reinterpret_cast<float2 *>(reinterpret_cast<float *>(a.y) + (clip * a.count + frame) * (int64_t)N);
+  for (int k = lane; k < L; k += 64) {
+    V zk = zb[k], zp = zb[L - k];
+    if (k == 0) { zk.y = (S)0; zp.y = (S)0; }       // the imaginary parts of the DC and Nyquist bins do not take part
+    const S er = zk.x + zp.x, ei = zk.y - zp.y;     // E = Z[k] + conj Z[L-k]
+    const S dr = zk.x - zp.x, di = zk.y + zp.y;     // D = Z[k] - conj Z[L-k]
+    const V w = pl.tw_n[k];
+    V q;
+    q.x = er - (w.x * di - w.y * dr);               // Z' = E + i conj(w) D
+    q.y = -(ei + (w.x * dr + w.y * di));            // stored conjugated
+    za[k] = q;
+  }
+  asm volatile("" ::: "memory");
+  const V *r = mixed_transform<S>(za, zb, L, pl.npass, pl.radix, lane, pl.tw_l);
+  const S *window = reinterpret_cast<const S *>(a.window);
+  const S inv_n = (S)1 / (S)N;
+  V *y = reinterpret_cast<V *>(reinterpret_cast<S *>(a.y) + (clip * a.count + frame) * (int64_t)N);
   for (int n = lane; n < L; n += 64) {
-    const float2 v = r[n];
-    y[n] = make_float2(v.x * inv_n * window[2 * n], -v.y * inv_n * window[2 * n + 1]);
+    const V v = r[n];
+    V q;
+    q.x = v.x * inv_n * window[2 * n];
+    q.y = -v.y * inv_n * window[2 * n + 1];
+    y[n] = q;
   }
 }
 
-template <int LOG2LP, int FT>
-void launch_mixed_frames(const IstftArgs &a, const MixedInv &pl, hipStream_t stream) {
+template <int LOG2LP, int FT, typename Tz, typename S>
+void launch_mixed_frames(const IstftArgs &a, const MixedInv<S> &pl, hipStream_t stream) {
   const int64_t blocks = a.lead * ((a.count + FT - 1) / FT);
   if (blocks > 2147483647LL) throw Failure("invert: too many frame tiles for one launch");
-  const size_t lds = (size_t)FT * 2 * (size_t(1) << LOG2LP) * sizeof(float2);
-  auto kernel = istft_mixed_frames_kernel<LOG2LP, FT>;
+  const size_t lds = (size_t)FT * 2 * (size_t(1) << LOG2LP) * sizeof(typename fftdev::vec2_of<S>::type);
+  auto kernel = istft_mixed_frames_kernel<LOG2LP, FT, Tz, S>;
   SMX_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   SMX_LAUNCH(kernel, dim3((unsigned)blocks), dim3(64 * FT), lds, stream, a, pl);
   SMX_HIP_CHECK(hipGetLastError());
 }
 
-// float32 spectra and interior, no Griffin-Lim factors: true when the mixed-radix frames kernel took the launch
+// no Griffin-Lim factors: true when the mixed-radix frames kernel took the launch.  <float, float>: complex64 spectra, float32
+// interior; <float, double>: complex64 under the float64 interior; <double, double>: complex128.
+template <typename Tz, typename S>
 bool launch_mixed_frames_any(const IstftArgs &a, const StftTables &t, hipStream_t stream) {
-  if (t.mixed_npass <= 0 || !t.mixed_tw || !t.twiddle_f32 || a.mag || a.unit || a.fft % 2 != 0) return false;
+  if (t.mixed_npass <= 0 || a.mag || a.unit || a.fft % 2 != 0) return false;
   static const bool off = [] { const char *e = std::getenv("SMX_MIXED_OFF"); return e && e[0] == '1'; }();
   if (off) return false;
-  MixedInv pl{};
+  MixedInv<S> pl{};
   pl.npass = t.mixed_npass;
   for (int i = 0; i < t.mixed_npass; ++i) pl.radix[i] = t.mixed_radix[i];
-  pl.tw_l = t.mixed_tw;
-  pl.tw_n = (const float2 *)t.twiddle_f32;
+  if constexpr (sizeof(S) == 4) {
+    if (!t.mixed_tw || !t.twiddle_f32) return false;
+    pl.tw_l = t.mixed_tw;
+    pl.tw_n = (const float2 *)t.twiddle_f32;
+  } else {
+    if (!t.mixed_tw_f64 || !t.twiddle_f64) return false;
+    pl.tw_l = t.mixed_tw_f64;
+    pl.tw_n = (const double2 *)t.twiddle_f64;
+  }
   const int64_t l = a.fft / 2;
-  if (l < 128) launch_mixed_frames<7, 16>(a, pl, stream);
-  else if (l < 256) launch_mixed_frames<8, 16>(a, pl, stream);
-  else if (l < 512) launch_mixed_frames<9, 16>(a, pl, stream);
-  else if (l < 1024) launch_mixed_frames<10, 8>(a, pl, stream);
+  constexpr int W = sizeof(S) == 8 ? 2 : 1;        // a double frame is twice the LDS: half the frames per workgroup
+  if (l < 128) launch_mixed_frames<7, 16, Tz, S>(a, pl, stream);
+  else if (l < 256) launch_mixed_frames<8, 16 / W, Tz, S>(a, pl, stream);
+  else if (l < 512) launch_mixed_frames<9, 16 / W, Tz, S>(a, pl, stream);
+  else if (l < 1024) launch_mixed_frames<10, 8 / W, Tz, S>(a, pl, stream);
   else return false;
   return true;
 }
@@ -914,11 +938,13 @@ void launch_istft(const IstftJob &job) {
     fa.beta = (float)job.beta;
     fa.unit = job.unit ? 1 : 0;
     if (job.z_bytes == 16) {
-      if (!launch_stockham_frames_wide_any<double>(fa, t, job.stream)) launch_frames<double, double>(job, fa, job.stream);
+      if (!launch_stockham_frames_wide_any<double>(fa, t, job.stream) && !launch_mixed_frames_any<double, double>(fa, t, job.stream))
+        launch_frames<double, double>(job, fa, job.stream);
     } else if (f64) {
-      if (!launch_stockham_frames_wide_any<float>(fa, t, job.stream)) launch_frames<float, double>(job, fa, job.stream);
+      if (!launch_stockham_frames_wide_any<float>(fa, t, job.stream) && !launch_mixed_frames_any<float, double>(fa, t, job.stream))
+        launch_frames<float, double>(job, fa, job.stream);
     }
-    else if (!launch_stockham_frames_any(fa, t, job.stream) && !launch_mixed_frames_any(fa, t, job.stream)) launch_frames<float, float>(job, fa, job.stream);
+    else if (!launch_stockham_frames_any(fa, t, job.stream) && !launch_mixed_frames_any<float, float>(fa, t, job.stream)) launch_frames<float, float>(job, fa, job.stream);
     OlaArgs oa{};
     oa.y = d_y;
     oa.out = reinterpret_cast<unsigned char *>(job.out) + c0 * job.out_len * elem_out;

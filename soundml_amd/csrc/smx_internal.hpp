@@ -86,6 +86,7 @@ struct StftTables {
   int blu2_log2m = 0;
   // even sizes with N / 2 = 2^a 3^b 5^c <= 1024, not a power of two: the mixed-radix kernel's plan (stft_mixed_power16_kernel)
   float2 *mixed_tw = nullptr;      // exp(-2 pi i j / L), j < L = N / 2
+  double2 *mixed_tw_f64 = nullptr; // the same in float64 (the float64 interior)
   int mixed_npass = 0;
   int mixed_radix[10] = {};
   float2 *fast_synth_window = nullptr;   // (w[2j], -w[2j+1]) / (2M): synthesis window of the fast inverse kernel

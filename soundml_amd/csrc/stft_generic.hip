@@ -1312,96 +1312,123 @@ bool launch_bluestein_power16(const StftJob &job, GenericArgs a, const StftTable
 // exp(-2 pi i j / L), and writes (j - j mod Ns) R + j mod Ns + t Ns -- wave-private, no workgroup barrier; then the real
 // post-pass and |X|^p as in the power-of-two kernel, and the columns leave through columns_out (MEL: straight through the
 // float32 MFMA).  Same interface and tile shape as stft_bluestein_power16_kernel, which it replaces for these sizes.
+template <typename S>
 struct MixedPlan {
   int npass;
   int radix[10];
-  const float2 *tw_l;   // exp(-2 pi i j / L), j < L
-  const float2 *tw_n;   // exp(-2 pi i k / N), k <= L
+  const typename fftdev::vec2_of<S>::type *tw_l;   // exp(-2 pi i j / L), j < L
+  const typename fftdev::vec2_of<S>::type *tw_n;   // exp(-2 pi i k / N), k <= L
 };
 
-template <int LOG2LP, typename Tin, bool MEL, int FT = 16, bool CPLX = false>   // LP = frame buffer capacity in complex values (>= L)
-__global__ void __launch_bounds__(64 * FT) stft_mixed_power16_kernel(GenericArgs a, MixedPlan pl, MelTail mt) {
+// S = double: the float64 interior (float32 audio -> float32 / complex64 output rounded once, float64 audio -> float64 / complex128):
+// window, transform and |.|^p in float64, like stft_stockham_power16_kernel<.., double>.
+template <int LOG2LP, typename Tin, bool MEL, int FT = 16, bool CPLX = false, typename S = float, typename Tout = float>   // LP = frame buffer capacity in complex values (>= L)
+__global__ void __launch_bounds__(64 * FT) stft_mixed_power16_kernel(GenericArgs a, MixedPlan<S> pl, MelTail mt) {
   static_assert(!(MEL && CPLX), "the mel tail takes powers");
+  static_assert(!MEL || (sizeof(S) == 4 && sizeof(Tout) == 4), "the MFMA tail is float32");
   using namespace fftdev;
-  constexpr int LP = 1 << LOG2LP, BUF = 4 * LP;   // two buffers of LP float2 per frame
+  using V = typename vec2_of<S>::type;
+  using CO = typename Vec2<Tout>::type;
+  constexpr S kHalf = sizeof(S) == 8 ? (S)0.5 : (S)1.0;   // float32: the window table is pre-halved
+  constexpr int LP = 1 << LOG2LP;
+  constexpr int BUF = (int)(2 * LP * sizeof(V) / sizeof(Tout));   // Tout elements per frame region (two buffers of LP complex values)
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  float2 *work = reinterpret_cast<float2 *>(smem);
+  V *work = reinterpret_cast<V *>(smem);
   const int N = (int)a.fft, L = N / 2;
   const int64_t tiles = (a.count + FT - 1) / FT;
   const int64_t clip = blockIdx.x / tiles, tile = blockIdx.x % tiles;
   const Tin *x = reinterpret_cast<const Tin *>(a.x) + clip * a.x_stride;
-  const float *window = reinterpret_cast<const float *>(a.window);       // 0.5 * analysis window
+  const S *window = reinterpret_cast<const S *>(a.window);       // float32: 0.5 * analysis window; float64: the analysis window
   const int lane = threadIdx.x & 63, f = threadIdx.x >> 6;
-  float2 *za = work + (size_t)f * (2 * LP), *zb = za + LP;
+  V *za = work + (size_t)f * (2 * LP), *zb = za + LP;
   const int64_t f0 = tile * FT;
   const int nf = (int)((a.count - f0) < FT ? (a.count - f0) : FT);
   const bool have = f < nf;
   const TileBands tb = load_tile_bands<MEL>(mt);
-  float val[LP / 64], vim[CPLX ? LP / 64 : 1], nyq = 0.0f;
+  Tout val[LP / 64], vim[CPLX ? LP / 64 : 1], nyq = (Tout)0;
 #pragma unroll
   for (int m = 0; m < LP / 64; ++m) {
-    val[m] = 0.0f;
-    if constexpr (CPLX) vim[m] = 0.0f;
+    val[m] = (Tout)0;
+    if constexpr (CPLX) vim[m] = (Tout)0;
   }
   if (have) {   // wave-uniform
     const int64_t s0 = (a.p0 + f0 + f) * a.hop - a.left;
     const bool inside = s0 >= 0 && s0 + N <= a.n;
     for (int i = lane; i < L; i += 64) {
-      const float v0 = inside ? (float)x[s0 + 2 * i] : (float)fetch_sample<Tin>(x, a.n, s0 + 2 * i, a.pad, a.pad_value);
-      const float v1 = inside ? (float)x[s0 + 2 * i + 1] : (float)fetch_sample<Tin>(x, a.n, s0 + 2 * i + 1, a.pad, a.pad_value);
-      za[i] = make_float2(v0 * window[2 * i], v1 * window[2 * i + 1]);
+      const S v0 = inside ? (S)x[s0 + 2 * i] : (S)fetch_sample<Tin>(x, a.n, s0 + 2 * i, a.pad, a.pad_value);
+      const S v1 = inside ? (S)x[s0 + 2 * i + 1] : (S)fetch_sample<Tin>(x, a.n, s0 + 2 * i + 1, a.pad, a.pad_value);
+      V q;
+      q.x = v0 * window[2 * i] * kHalf;
+      q.y = v1 * window[2 * i + 1] * kHalf;
+      za[i] = q;
     }
     stockham_sync<true>();
-    const float2 *src = mixed_transform(za, zb, L, pl.npass, pl.radix, lane, pl.tw_l);
-    const float2 *z = src;                       // the transform, natural order
+    const V *z = mixed_transform<S>(za, zb, L, pl.npass, pl.radix, lane, pl.tw_l);   // the transform, natural order
 #pragma unroll
     for (int m = 0; m < LP / 64; ++m) {
       const int k = lane + 64 * m;
       if (k < L) {
-        const float2 zk = z[k], zm = z[k == 0 ? 0 : L - k];
-        const float er = zk.x + zm.x, ei = zk.y - zm.y;
-        const float dr = zk.x - zm.x, di = zk.y + zm.y;
-        const float2 w = pl.tw_n[k];
-        const float xr = er + (w.x * di + w.y * dr), xi = ei - (w.x * dr - w.y * di);
+        const V zk = z[k], zm = z[k == 0 ? 0 : L - k];
+        const S er = zk.x + zm.x, ei = zk.y - zm.y;
+        const S dr = zk.x - zm.x, di = zk.y + zm.y;
+        const V w = pl.tw_n[k];
+        const S xr = er + (w.x * di + w.y * dr), xi = ei - (w.x * dr - w.y * di);
         if constexpr (CPLX) {
-          val[m] = k == 0 ? 2.0f * (zk.x + zk.y) : xr;     // X[0] is real
-          vim[m] = k == 0 ? 0.0f : xi;
+          val[m] = (Tout)(k == 0 ? (S)2 * (zk.x + zk.y) : xr);     // X[0] is real
+          vim[m] = (Tout)(k == 0 ? (S)0 : xi);
         } else {
-          val[m] = magnitude_pow<float, float>(xr, xi, a.power);
+          val[m] = magnitude_pow<S, Tout>(xr, xi, a.power);
         }
       }
     }
     if (lane == 0) {
-      const float2 z0 = z[0];
-      nyq = CPLX ? 2.0f * (z0.x - z0.y) : magnitude_pow<float, float>(2.0f * (z0.x - z0.y), 0.0f, a.power);   // X[L] is real
+      const V z0 = z[0];
+      nyq = CPLX ? (Tout)((S)2 * (z0.x - z0.y)) : magnitude_pow<S, Tout>((S)2 * (z0.x - z0.y), (S)0, a.power);   // X[L] is real
     }
     stockham_sync<true>();
   } else {   // no frame: a column of zeros (the MFMA tail reads a few values past bin L, times zero weights: keep them finite)
-    for (int i = lane; i < LP; i += 64) za[i] = make_float2(0.0f, 0.0f);
+    V zero;
+    zero.x = (S)0;
+    zero.y = (S)0;
+    for (int i = lane; i < LP; i += 64) za[i] = zero;
     stockham_sync<true>();
   }
-  if constexpr (CPLX) {   // Stft.transform: complex columns of L + 1 values, rows leave as 16-byte pieces (two frames of one bin)
-    float2 *ccol = za + 2 * f;
+  if constexpr (CPLX) {   // Stft.transform: complex columns of L + 1 values, rows leave as 16-byte pieces
+    CO *ccol = reinterpret_cast<CO *>(za) + 2 * f;
 #pragma unroll
     for (int m = 0; m < LP / 64; ++m) {
       const int k = lane + 64 * m;
-      if (k < L) ccol[k] = make_float2(val[m], vim[m]);
+      if (k < L) {
+        CO c;
+        c.x = val[m];
+        c.y = vim[m];
+        ccol[k] = c;
+      }
     }
-    if (lane == 0) ccol[L] = make_float2(nyq, 0.0f);
+    if (lane == 0) {
+      CO c;
+      c.x = nyq;
+      c.y = (Tout)0;
+      ccol[L] = c;
+    }
     __syncthreads();
-    const float2 *cols = work;
-    float2 *out = reinterpret_cast<float2 *>(a.out);
+    const CO *cols = reinterpret_cast<const CO *>(work);
+    CO *out = reinterpret_cast<CO *>(a.out);
     const int64_t obase = clip * a.bins * a.out_stride + a.out_offset + f0;
-    constexpr int CS = 2 * LP;
+    constexpr int CS = (int)(2 * LP * sizeof(V) / sizeof(CO));   // CO elements per frame region
     if (nf == FT) {
-      constexpr int QF = FT / 2;
-      using f32x4 = __attribute__((ext_vector_type(4))) float;
+      constexpr int PER = 16 / sizeof(CO), QF = FT / PER;   // two complex64 frames or one complex128 per 16-byte piece
       for (int e = threadIdx.x; e < (L + 1) * QF; e += blockDim.x) {
-        const int k = e / QF, g = 2 * (e % QF);
-        const float2 c0 = cols[g * CS + 2 * g + k], c1 = cols[(g + 1) * CS + 2 * (g + 1) + k];
-        float2 *dst = out + obase + (int64_t)k * a.out_stride + g;
-        const f32x4 v = {c0.x, c0.y, c1.x, c1.y};
-        asm volatile("global_store_dwordx4 %0, %1, off" : : "v"(dst), "v"(v) : "memory");
+        const int k = e / QF, g = PER * (e % QF);
+        CO *dst = out + obase + (int64_t)k * a.out_stride + g;
+        if constexpr (sizeof(CO) == 8) {
+          using f32x4 = __attribute__((ext_vector_type(4))) float;
+          const CO c0 = cols[g * CS + 2 * g + k], c1 = cols[(g + 1) * CS + 2 * (g + 1) + k];
+          const f32x4 v = {(float)c0.x, (float)c0.y, (float)c1.x, (float)c1.y};
+          asm volatile("global_store_dwordx4 %0, %1, off" : : "v"(dst), "v"(v) : "memory");
+        } else {
+          *dst = cols[g * CS + 2 * g + k];
+        }
       }
       return;
     }
@@ -1411,7 +1438,7 @@ __global__ void __launch_bounds__(64 * FT) stft_mixed_power16_kernel(GenericArgs
     }
     return;
   }
-  float *col = reinterpret_cast<float *>(za) + 2 * f;   // column f of the tile: L + 1 floats in the frame's own region
+  Tout *col = reinterpret_cast<Tout *>(za) + 2 * f;   // column f of the tile: L + 1 values in the frame's own region
 #pragma unroll
   for (int m = 0; m < LP / 64; ++m) {
     const int k = lane + 64 * m;
@@ -1419,12 +1446,12 @@ __global__ void __launch_bounds__(64 * FT) stft_mixed_power16_kernel(GenericArgs
   }
   if (lane == 0) col[L] = nyq;
   __syncthreads();
-  columns_out<BUF, FT, MEL>(a, mt, reinterpret_cast<const float *>(work), L + 1, nf, clip, f0, tb,
-                            MEL ? reinterpret_cast<float *>(smem + (size_t)FT * BUF * sizeof(float)) : nullptr);
+  columns_out<BUF, FT, MEL, Tout>(a, mt, reinterpret_cast<const Tout *>(work), L + 1, nf, clip, f0, tb,
+                                  MEL ? reinterpret_cast<float *>(smem + (size_t)FT * 2 * LP * sizeof(V)) : nullptr);
 }
 
 template <int LOG2LP, int FT = 16>
-bool launch_mixed_power16(const StftJob &job, GenericArgs a, const StftTables &t, const MixedPlan &pl, const MelTail *mel) {
+bool launch_mixed_power16(const StftJob &job, GenericArgs a, const StftTables &t, const MixedPlan<float> &pl, const MelTail *mel) {
   constexpr int LP = 1 << LOG2LP;
   a.window = t.blu2_window;
   const int64_t blocks = a.lead * ((a.count + FT - 1) / FT);
@@ -1460,12 +1487,48 @@ bool launch_mixed_power16(const StftJob &job, GenericArgs a, const StftTables &t
   return true;
 }
 
+// the float64 interior: Tio = float (float32 audio, float32 / complex64 out) or double (float64 audio, float64 / complex128 out)
+template <int LOG2LP, int FT, typename Tio>
+bool launch_mixed_power16_wide(const StftJob &job, GenericArgs a, const StftTables &t, const MixedPlan<double> &pl) {
+  constexpr int LP = 1 << LOG2LP;
+  a.window = t.window_f64;
+  const int64_t blocks = a.lead * ((a.count + FT - 1) / FT);
+  if (blocks > 2147483647LL) throw Failure("stft: too many frame tiles for one launch");
+  const size_t lds = (size_t)FT * 2 * LP * sizeof(double2);
+  auto launch = [&](auto kernel) {
+    SMX_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    SMX_LAUNCH(kernel, dim3((unsigned)blocks), dim3(64 * FT), lds, job.stream, a, pl, MelTail{});
+    SMX_HIP_CHECK(hipGetLastError());
+  };
+  if (job.mode == OUT_COMPLEX) launch(stft_mixed_power16_kernel<LOG2LP, Tio, false, FT, true, double, Tio>);
+  else launch(stft_mixed_power16_kernel<LOG2LP, Tio, false, FT, false, double, Tio>);
+  return true;
+}
+
+template <typename Tio>
+bool launch_mixed16_wide_any(const StftJob &job, const GenericArgs &a, const StftTables &t) {
+  if (t.mixed_npass <= 0 || !t.mixed_tw_f64 || !t.window_f64 || !t.twiddle_f64 || !t.blu2_window) return false;   // (blu2_window: the forward plan's sizes)
+  static const bool off = [] { const char *e = std::getenv("SMX_MIXED_OFF"); return e && e[0] == '1'; }();
+  if (off) return false;
+  MixedPlan<double> pl{};
+  pl.npass = t.mixed_npass;
+  for (int i = 0; i < t.mixed_npass; ++i) pl.radix[i] = t.mixed_radix[i];
+  pl.tw_l = t.mixed_tw_f64;
+  pl.tw_n = (const double2 *)t.twiddle_f64;
+  const int64_t l = a.fft / 2;
+  if (l <= 128) return launch_mixed_power16_wide<7, 16, Tio>(job, a, t, pl);
+  if (l <= 256) return launch_mixed_power16_wide<8, 16, Tio>(job, a, t, pl);
+  if (l <= 512) return launch_mixed_power16_wide<9, 8, Tio>(job, a, t, pl);
+  if (l <= 1024) return launch_mixed_power16_wide<10, 4, Tio>(job, a, t, pl);
+  return false;
+}
+
 // true when the size has a mixed-radix plan (StftTables::mixed_npass > 0) and the kernel took the launch
 bool launch_mixed16_any(const StftJob &job, const GenericArgs &a, const StftTables &t, const MelTail *mel) {
   if (t.mixed_npass <= 0 || !t.mixed_tw || !t.blu2_window || !t.twiddle_f32) return false;
   static const bool off = [] { const char *e = std::getenv("SMX_MIXED_OFF"); return e && e[0] == '1'; }();   // A/B timing: chirp-z instead
   if (off) return false;
-  MixedPlan pl{};
+  MixedPlan<float> pl{};
   pl.npass = t.mixed_npass;
   for (int i = 0; i < t.mixed_npass; ++i) pl.radix[i] = t.mixed_radix[i];
   pl.tw_l = t.mixed_tw;
@@ -1707,6 +1770,9 @@ void launch_stft_generic(const StftJob &job) {
     if (!(sfw && sfw[0] == '1') && (job.in_bytes == 8 ? launch_stockham_power16_wide_any<double>(job, a, t, c.fft_size)
                                                         : launch_stockham_power16_wide_any<float>(job, a, t, c.fft_size)))
       return;
+  }
+  if (f64_interior && !fast_path_disabled()) {   // even sizes with N / 2 = 2^a 3^b 5^c: the mixed-radix kernel on doubles
+    if (job.in_bytes == 8 ? launch_mixed16_wide_any<double>(job, a, t) : launch_mixed16_wide_any<float>(job, a, t)) return;
   }
   if (f64_interior && !fast_path_disabled()) {   // float64 interior on the Stockham passes (fft 512 .. 4096)
     if (job.in_bytes == 8 ? launch_stockham_wide<double, double>(job, a, t, c.fft_size)

@@ -244,6 +244,12 @@ const smx::StftTables &smx_stft_config::tables() const {
               twl[(size_t)j] = make_float2((float)std::cos(a), (float)std::sin(a));
             }
             t.mixed_tw = smx::upload(twl);
+            std::vector<double2> twd((size_t)l);
+            for (int64_t j = 0; j < l; ++j) {
+              const double a = -2.0 * M_PI * (double)j / (double)l;
+              twd[(size_t)j] = make_double2(std::cos(a), std::sin(a));
+            }
+            t.mixed_tw_f64 = smx::upload(twd);
             t.mixed_npass = np;
             for (int i = 0; i < np; ++i) t.mixed_radix[i] = radix[i];
           }
@@ -264,6 +270,12 @@ const smx::StftTables &smx_stft_config::tables() const {
       twl[(size_t)j] = make_float2((float)std::cos(a), (float)std::sin(a));
     }
     t.mixed_tw = smx::upload(twl);
+    std::vector<double2> twd((size_t)(n / 2));
+    for (int64_t j = 0; j < n / 2; ++j) {
+      const double a = -2.0 * M_PI * (double)j / (double)(n / 2);
+      twd[(size_t)j] = make_double2(std::cos(a), std::sin(a));
+    }
+    t.mixed_tw_f64 = smx::upload(twd);
     t.mixed_npass = np;
   }
 
@@ -360,6 +372,7 @@ smx_stft_config::~smx_stft_config() {
     (void)hipFree(t.blu2_tw);
     (void)hipFree(t.blu2_window);
     (void)hipFree(t.mixed_tw);
+    (void)hipFree(t.mixed_tw_f64);
   }
 }
 
