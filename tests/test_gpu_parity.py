@@ -244,6 +244,36 @@ def test_mixed_radix_invert(fft):
     check_fast(got, x, "round trip")
 
 
+@pytest.mark.parametrize("fft", [12, 100, 400, 480, 960, 1000, 1200, 2000])
+def test_mixed_radix_float64_interior(fft):
+    """The same sizes with the reference's float64 interior (stft_mixed_power16_kernel / istft_mixed_frames_kernel on doubles):
+    float64 audio at the reference's float64 tolerance (complex128 / float64 out), float32 audio at its float32 tolerance
+    (complex64 / float32 out, rounded once); transform, power and invert."""
+    rng = np.random.default_rng(fft + 2)
+    hop = fft // 4
+    n = 19 * hop + 3
+    o = O.stft_config(fft, hop=hop)
+    c = Stft.Config.create(fft_size=fft, hop=hop)
+    x64 = rng.uniform(-1, 1, size=(2, n))
+    z = Stft.transform(c, x64)
+    assert z.dtype == np.complex128
+    want = O.transform(o, x64)
+    check_close(z.real, want.real, rtol=F64_RTOL, atol=1e-11, msg="re")
+    check_close(z.imag, want.imag, rtol=F64_RTOL, atol=1e-11, msg="im")
+    check_close(Stft.power_spectrum(c, x64), O.power_spectrum(o, x64), rtol=4 * F64_RTOL, atol=1e-10, msg="power")
+    check_close(Stft.invert(c, z, n), O.invert(o, want, n), rtol=1e-8, atol=1e-11, msg="invert")
+    x32 = x64.astype(np.float32)
+    S.set_interior("float64")
+    z32, w32 = Stft.transform(c, x32), O.transform(o, x32)
+    assert z32.dtype == np.complex64
+    peak = float(np.max(np.abs(w32)))
+    assert np.max(np.abs(z32 - w32)) <= 2e-7 * peak                      # one rounding of a float64 result
+    p32, wp = Stft.power_spectrum(c, x32), O.power_spectrum(o, x32)
+    assert np.max(np.abs(p32 - wp)) <= 4e-7 * float(np.max(wp))
+    xi, wi = Stft.invert(c, z32, n), O.invert(o, z32, n)
+    assert xi.dtype == np.float32 and np.max(np.abs(xi - wi)) <= 4e-7 * float(np.max(np.abs(wi)))
+
+
 def test_mixed_radix_kernel_agrees_with_chirp_z():
     code = """
 import sys, numpy as np
