@@ -1474,7 +1474,8 @@ bool launch_mixed_power16(const StftJob &job, GenericArgs a, const StftTables &t
     return true;
   } else
   if (mel) {
-    const size_t lds_mel = lds + (size_t)16 * 1024;   // the helper waves' partial tiles (columns_out): one KB per wave
+    const size_t lds_mel = lds + (size_t)15 * 1024;   // the helper waves' partial tiles (columns_out): one KB per helper, at most 15 of the 16 waves
+                                                       // (79 KB at L <= 256: two workgroups per CU; 80 KB would leave one)
     auto kernel = stft_mixed_power16_kernel<LOG2LP, float, true>;
     SMX_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_mel));
     SMX_LAUNCH(kernel, dim3((unsigned)blocks), dim3(1024), lds_mel, job.stream, a, pl, *mel);
