@@ -320,12 +320,13 @@ __device__ __forceinline__ void mixed_pass(const typename vec2_of<S>::type *src,
 // only compiler fences between them.  S = float or double (the float64 interior).
 template <typename S>
 __device__ __forceinline__ typename vec2_of<S>::type *mixed_transform(typename vec2_of<S>::type *a, typename vec2_of<S>::type *b, int L, int npass,
-                                                                     const int *radix, int lane, const typename vec2_of<S>::type *tw_l) {
+                                                                     unsigned long long radices /* 4 bits per pass */, int lane,
+                                                                     const typename vec2_of<S>::type *tw_l) {
   using V = typename vec2_of<S>::type;
   V *src = a, *dst = b;
   int ns = 1;
   for (int p = 0; p < npass; ++p) {
-    const int r = radix[p];                // uniform
+    const int r = (int)((radices >> (4 * p)) & 15ull);   // uniform; packed, so that the plan is scalars and not an indexed array in memory
     if (r == 4) mixed_pass<4, S>(src, dst, L, ns, lane, tw_l);
     else if (r == 2) mixed_pass<2, S>(src, dst, L, ns, lane, tw_l);
     else if (r == 5) mixed_pass<5, S>(src, dst, L, ns, lane, tw_l);

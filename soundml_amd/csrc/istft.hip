@@ -682,7 +682,7 @@ __global__ void __launch_bounds__(1024) istft2048_kernel(SynArgs a) {
 template <typename S>
 struct MixedInv {
   int npass;
-  int radix[10];
+  unsigned long long radices;   // 4 bits per pass
   const typename fftdev::vec2_of<S>::type *tw_l;   // exp(-2 pi i j / L)
   const typename fftdev::vec2_of<S>::type *tw_n;   // exp(-2 pi i k / N)
 };
@@ -721,7 +721,7 @@ __global__ void __launch_bounds__(64 * FT) istft_mixed_frames_kernel(IstftArgs a
     za[k] = q;
   }
   asm volatile("" ::: "memory");
-  const V *r = mixed_transform<S>(za, zb, L, pl.npass, pl.radix, lane, pl.tw_l);
+  const V *r = mixed_transform<S>(za, zb, L, pl.npass, pl.radices, lane, pl.tw_l);
   const S *window = reinterpret_cast<const S *>(a.window);
   const S inv_n = (S)1 / (S)N;
   V *y = reinterpret_cast<V *>(reinterpret_cast<S *>(a.y) + (clip * a.count + frame) * (int64_t)N);
@@ -754,7 +754,7 @@ bool launch_mixed_frames_any(const IstftArgs &a, const StftTables &t, hipStream_
   if (off) return false;
   MixedInv<S> pl{};
   pl.npass = t.mixed_npass;
-  for (int i = 0; i < t.mixed_npass; ++i) pl.radix[i] = t.mixed_radix[i];
+  for (int i = 0; i < t.mixed_npass; ++i) pl.radices |= (unsigned long long)t.mixed_radix[i] << (4 * i);
   if constexpr (sizeof(S) == 4) {
     if (!t.mixed_tw || !t.twiddle_f32) return false;
     pl.tw_l = t.mixed_tw;

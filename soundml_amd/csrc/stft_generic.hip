@@ -541,7 +541,8 @@ __device__ __forceinline__ TileBands load_tile_bands(const MelTail &mt) {
 
 template <int BUF, int FT, bool MEL, typename Tout = float>
 __device__ __forceinline__ void columns_out(const GenericArgs &a, const MelTail &mt, const Tout *cols, int bins, int nf,
-                                            int64_t clip, int64_t f0, const TileBands &tb = TileBands{}, float *partials = nullptr) {
+                                            int64_t clip, int64_t f0, const TileBands &tb = TileBands{}, float *partials = nullptr,
+                                            int pstride = 256 /* floats between the helper waves' partial tiles */) {
   if constexpr (MEL) {
     static_assert(!MEL || (FT == 16 && sizeof(Tout) == 4), "the MFMA tile is 16 float32 frames wide");
     using f32x4 = __attribute__((ext_vector_type(4))) float;
@@ -600,6 +601,7 @@ __device__ __forceinline__ void columns_out(const GenericArgs &a, const MelTail 
       }
     };
     const int ntiles = (mt.n_mels + 15) >> 4;
+    if (ntiles == 0) return;
     if (ntiles < nwaves && partials) {
       // Fewer tiles than waves (80 mels on 8 waves; one tile of dense weights): the idle waves take shares of the
       // widest -- for a mel bank the highest -- tiles' bin ranges.  Helper j serves tile ntiles - 1 - (j mod ntiles);
@@ -631,7 +633,7 @@ __device__ __forceinline__ void columns_out(const GenericArgs &a, const MelTail 
       ke = ke < k_end ? ke : k_end;
       f32x4 acc = tile_product(r0, kb, ke);
       if (piece > 0) {
-        float *slot = partials + (wave - ntiles) * 256;
+        float *slot = partials + (wave - ntiles) * pstride;
 #pragma unroll
         for (int i = 0; i < 4; ++i) slot[i * 64 + lane] = acc[i];
       }
@@ -639,7 +641,7 @@ __device__ __forceinline__ void columns_out(const GenericArgs &a, const MelTail 
       if (piece == 0) {
         const int back = ntiles - 1 - tile;
         for (int j = back; j < helpers; j += ntiles) {       // piece order: helper back is piece 1, back + ntiles piece 2, ...
-          const float *slot = partials + j * 256;
+          const float *slot = partials + j * pstride;
 #pragma unroll
           for (int i = 0; i < 4; ++i) acc[i] += slot[i * 64 + lane];
         }
@@ -1315,7 +1317,7 @@ bool launch_bluestein_power16(const StftJob &job, GenericArgs a, const StftTable
 template <typename S>
 struct MixedPlan {
   int npass;
-  int radix[10];
+  unsigned long long radices;   // 4 bits per pass
   const typename fftdev::vec2_of<S>::type *tw_l;   // exp(-2 pi i j / L), j < L
   const typename fftdev::vec2_of<S>::type *tw_n;   // exp(-2 pi i k / N), k <= L
 };
@@ -1363,7 +1365,7 @@ __global__ void __launch_bounds__(64 * FT) stft_mixed_power16_kernel(GenericArgs
       za[i] = q;
     }
     stockham_sync<true>();
-    const V *z = mixed_transform<S>(za, zb, L, pl.npass, pl.radix, lane, pl.tw_l);   // the transform, natural order
+    const V *z = mixed_transform<S>(za, zb, L, pl.npass, pl.radices, lane, pl.tw_l);   // the transform, natural order
 #pragma unroll
     for (int m = 0; m < LP / 64; ++m) {
       const int k = lane + 64 * m;
@@ -1446,8 +1448,9 @@ __global__ void __launch_bounds__(64 * FT) stft_mixed_power16_kernel(GenericArgs
   }
   if (lane == 0) col[L] = nyq;
   __syncthreads();
+  // the helper waves' partial tiles (1 KB each) go into the frames' second buffers, which are free by now: no LDS beyond the frames' own
   columns_out<BUF, FT, MEL, Tout>(a, mt, reinterpret_cast<const Tout *>(work), L + 1, nf, clip, f0, tb,
-                                  MEL ? reinterpret_cast<float *>(smem + (size_t)FT * 2 * LP * sizeof(V)) : nullptr);
+                                  MEL ? reinterpret_cast<float *>(work + LP) : nullptr, (int)(2 * LP * sizeof(V) / sizeof(float)));
 }
 
 template <int LOG2LP, int FT = 16>
@@ -1474,8 +1477,7 @@ bool launch_mixed_power16(const StftJob &job, GenericArgs a, const StftTables &t
     return true;
   } else
   if (mel) {
-    const size_t lds_mel = lds + (size_t)15 * 1024;   // the helper waves' partial tiles (columns_out): one KB per helper, at most 15 of the 16 waves
-                                                       // (79 KB at L <= 256: two workgroups per CU; 80 KB would leave one)
+    const size_t lds_mel = lds;   // the helper waves' partial tiles live in the frames' second buffers
     auto kernel = stft_mixed_power16_kernel<LOG2LP, float, true>;
     SMX_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_mel));
     SMX_LAUNCH(kernel, dim3((unsigned)blocks), dim3(1024), lds_mel, job.stream, a, pl, *mel);
@@ -1513,7 +1515,7 @@ bool launch_mixed16_wide_any(const StftJob &job, const GenericArgs &a, const Stf
   if (off) return false;
   MixedPlan<double> pl{};
   pl.npass = t.mixed_npass;
-  for (int i = 0; i < t.mixed_npass; ++i) pl.radix[i] = t.mixed_radix[i];
+  for (int i = 0; i < t.mixed_npass; ++i) pl.radices |= (unsigned long long)t.mixed_radix[i] << (4 * i);
   pl.tw_l = t.mixed_tw_f64;
   pl.tw_n = (const double2 *)t.twiddle_f64;
   const int64_t l = a.fft / 2;
@@ -1531,7 +1533,7 @@ bool launch_mixed16_any(const StftJob &job, const GenericArgs &a, const StftTabl
   if (off) return false;
   MixedPlan<float> pl{};
   pl.npass = t.mixed_npass;
-  for (int i = 0; i < t.mixed_npass; ++i) pl.radix[i] = t.mixed_radix[i];
+  for (int i = 0; i < t.mixed_npass; ++i) pl.radices |= (unsigned long long)t.mixed_radix[i] << (4 * i);
   pl.tw_l = t.mixed_tw;
   pl.tw_n = (const float2 *)t.twiddle_f32;
   const int64_t l = a.fft / 2;
@@ -1673,7 +1675,15 @@ bool launch_mel_spectrogram_16(const MelSpecJob &job) {
 #endif
   mt.k_pad = (int)mtab.k_pad;
   mt.out = reinterpret_cast<float *>(job.out);
-  if (chirp_16) return launch_mixed16_any(sj, a, t, &mt) || launch_bluestein16_any(sj, a, t, &mt);
+  if (chirp_16) {
+    // Sizes with a mixed-radix plan: above a few tiles per CU the composition power kernel + Mel.apply is ahead of the fused
+    // launch (fft 400 / hop 160, 80 mels, 256 x 30 s: 1.03 + 0.22 ms against 1.50 -- the fused instantiation of that kernel runs
+    // its transform part 20 % slower than the power one, tools/mel16_time.py; not understood), so the fused form keeps the small
+    // batches, where one launch is what counts.  SMX_MEL16_FUSED=1 forces it.
+    static const bool force = [] { const char *e = std::getenv("SMX_MEL16_FUSED"); return e && e[0] == '1'; }();
+    if (t.mixed_npass > 0 && !force && sj.lead * sj.count > 65536) return false;
+    return launch_mixed16_any(sj, a, t, &mt) || launch_bluestein16_any(sj, a, t, &mt);
+  }
   return c.fft_size == 512 ? launch_stockham_power16<9>(sj, a, t, &mt) : launch_stockham_power16<10>(sj, a, t, &mt);
 }
 
