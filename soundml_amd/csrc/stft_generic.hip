@@ -1356,13 +1356,23 @@ __global__ void __launch_bounds__(64 * FT) stft_mixed_power16_kernel(GenericArgs
   if (have) {   // wave-uniform
     const int64_t s0 = (a.p0 + f0 + f) * a.hop - a.left;
     const bool inside = s0 >= 0 && s0 + N <= a.n;
-    for (int i = lane; i < L; i += 64) {
-      const S v0 = inside ? (S)x[s0 + 2 * i] : (S)fetch_sample<Tin>(x, a.n, s0 + 2 * i, a.pad, a.pad_value);
-      const S v1 = inside ? (S)x[s0 + 2 * i + 1] : (S)fetch_sample<Tin>(x, a.n, s0 + 2 * i + 1, a.pad, a.pad_value);
-      V q;
-      q.x = v0 * window[2 * i] * kHalf;
-      q.y = v1 * window[2 * i + 1] * kHalf;
-      za[i] = q;
+    if (inside) {   // one 8-byte access for the two samples (element-aligned only) and one for their window values
+      using P = typename Pair<Tin>::type;
+      for (int i = lane; i < L; i += 64) {
+        const P xv = *reinterpret_cast<const P *>(x + s0 + 2 * i);
+        const V wv = reinterpret_cast<const V *>(window)[i];
+        V q;
+        q.x = (S)xv.x * wv.x * kHalf;
+        q.y = (S)xv.y * wv.y * kHalf;
+        za[i] = q;
+      }
+    } else {
+      for (int i = lane; i < L; i += 64) {
+        V q;
+        q.x = (S)fetch_sample<Tin>(x, a.n, s0 + 2 * i, a.pad, a.pad_value) * window[2 * i] * kHalf;
+        q.y = (S)fetch_sample<Tin>(x, a.n, s0 + 2 * i + 1, a.pad, a.pad_value) * window[2 * i + 1] * kHalf;
+        za[i] = q;
+      }
     }
     stockham_sync<true>();
     const V *z = mixed_transform<S>(za, zb, L, pl.npass, pl.radices, lane, pl.tw_l);   // the transform, natural order
