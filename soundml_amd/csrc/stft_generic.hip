@@ -1347,6 +1347,14 @@ __global__ void __launch_bounds__(64 * FT) stft_mixed_power16_kernel(GenericArgs
   const int nf = (int)((a.count - f0) < FT ? (a.count - f0) : FT);
   const bool have = f < nf;
   const TileBands tb = load_tile_bands<MEL>(mt);
+  // both twiddle tables (L values each) move to LDS once per workgroup: every butterfly of every pass reads R - 1 of them, and from
+  // global memory each of those reads was a dependent trip to L1 / L2 in the middle of a pass
+  V *tw_l = work + (size_t)FT * (2 * LP), *tw_n = tw_l + LP;
+  for (int i = threadIdx.x; i < L; i += 64 * FT) {
+    tw_l[i] = pl.tw_l[i];
+    tw_n[i] = pl.tw_n[i];
+  }
+  __syncthreads();
   Tout val[LP / 64], vim[CPLX ? LP / 64 : 1], nyq = (Tout)0;
 #pragma unroll
   for (int m = 0; m < LP / 64; ++m) {
@@ -1375,7 +1383,7 @@ __global__ void __launch_bounds__(64 * FT) stft_mixed_power16_kernel(GenericArgs
       }
     }
     stockham_sync<true>();
-    const V *z = mixed_transform<S>(za, zb, L, pl.npass, pl.radices, lane, pl.tw_l);   // the transform, natural order
+    const V *z = mixed_transform<S>(za, zb, L, pl.npass, pl.radices, lane, tw_l);   // the transform, natural order
 #pragma unroll
     for (int m = 0; m < LP / 64; ++m) {
       const int k = lane + 64 * m;
@@ -1383,7 +1391,7 @@ __global__ void __launch_bounds__(64 * FT) stft_mixed_power16_kernel(GenericArgs
         const V zk = z[k], zm = z[k == 0 ? 0 : L - k];
         const S er = zk.x + zm.x, ei = zk.y - zm.y;
         const S dr = zk.x - zm.x, di = zk.y + zm.y;
-        const V w = pl.tw_n[k];
+        const V w = tw_n[k];
         const S xr = er + (w.x * di + w.y * dr), xi = ei - (w.x * dr - w.y * di);
         if constexpr (CPLX) {
           val[m] = (Tout)(k == 0 ? (S)2 * (zk.x + zk.y) : xr);     // X[0] is real
@@ -1469,7 +1477,7 @@ bool launch_mixed_power16(const StftJob &job, GenericArgs a, const StftTables &t
   a.window = t.blu2_window;
   const int64_t blocks = a.lead * ((a.count + FT - 1) / FT);
   if (blocks > 2147483647LL) throw Failure("stft: too many frame tiles for one launch");
-  const size_t lds = (size_t)FT * 4 * LP * sizeof(float);
+  const size_t lds = (size_t)FT * 4 * LP * sizeof(float) + (size_t)2 * LP * sizeof(float2);   // frames + the two twiddle tables
   if (job.mode == OUT_COMPLEX) {
     if (mel) return false;
     auto kernel = stft_mixed_power16_kernel<LOG2LP, float, false, FT, true>;
@@ -1507,7 +1515,7 @@ bool launch_mixed_power16_wide(const StftJob &job, GenericArgs a, const StftTabl
   a.window = t.window_f64;
   const int64_t blocks = a.lead * ((a.count + FT - 1) / FT);
   if (blocks > 2147483647LL) throw Failure("stft: too many frame tiles for one launch");
-  const size_t lds = (size_t)FT * 2 * LP * sizeof(double2);
+  const size_t lds = (size_t)FT * 2 * LP * sizeof(double2) + (size_t)2 * LP * sizeof(double2);   // frames + the two twiddle tables
   auto launch = [&](auto kernel) {
     SMX_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     SMX_LAUNCH(kernel, dim3((unsigned)blocks), dim3(64 * FT), lds, job.stream, a, pl, MelTail{});
