@@ -699,6 +699,12 @@ __global__ void __launch_bounds__(64 * FT) istft_mixed_frames_kernel(IstftArgs a
   const int N = (int)a.fft, L = N / 2;
   const int64_t tiles = (a.count + FT - 1) / FT;
   const int64_t clip = blockIdx.x / tiles, frame = (blockIdx.x % tiles) * FT + f;
+  V *tw_l = reinterpret_cast<V *>(smem) + (size_t)FT * (2 * LP), *tw_n = tw_l + LP;   // both twiddle tables in LDS, once per workgroup
+  for (int i = threadIdx.x; i < L; i += 64 * FT) {
+    tw_l[i] = pl.tw_l[i];
+    tw_n[i] = pl.tw_n[i];
+  }
+  __syncthreads();
   if (frame >= a.count) return;                    // wave-uniform; no workgroup barrier below
   const CZ *zin = reinterpret_cast<const CZ *>(a.z) + clip * (int64_t)(L + 1) * a.frames + frame;
   for (int k = lane; k <= L; k += 64) {
@@ -714,14 +720,14 @@ __global__ void __launch_bounds__(64 * FT) istft_mixed_frames_kernel(IstftArgs a
     if (k == 0) { zk.y = (S)0; zp.y = (S)0; }       // the imaginary parts of the DC and Nyquist bins do not take part
     const S er = zk.x + zp.x, ei = zk.y - zp.y;     // E = Z[k] + conj Z[L-k]
     const S dr = zk.x - zp.x, di = zk.y + zp.y;     // D = Z[k] - conj Z[L-k]
-    const V w = pl.tw_n[k];
+    const V w = tw_n[k];
     V q;
     q.x = er - (w.x * di - w.y * dr);               // Z' = E + i conj(w) D
     q.y = -(ei + (w.x * dr + w.y * di));            // stored conjugated
     za[k] = q;
   }
   asm volatile("" ::: "memory");
-  const V *r = mixed_transform<S>(za, zb, L, pl.npass, pl.radices, lane, pl.tw_l);
+  const V *r = mixed_transform<S>(za, zb, L, pl.npass, pl.radices, lane, tw_l);
   const S *window = reinterpret_cast<const S *>(a.window);
   const S inv_n = (S)1 / (S)N;
   V *y = reinterpret_cast<V *>(reinterpret_cast<S *>(a.y) + (clip * a.count + frame) * (int64_t)N);
@@ -738,7 +744,7 @@ template <int LOG2LP, int FT, typename Tz, typename S>
 void launch_mixed_frames(const IstftArgs &a, const MixedInv<S> &pl, hipStream_t stream) {
   const int64_t blocks = a.lead * ((a.count + FT - 1) / FT);
   if (blocks > 2147483647LL) throw Failure("invert: too many frame tiles for one launch");
-  const size_t lds = (size_t)FT * 2 * (size_t(1) << LOG2LP) * sizeof(typename fftdev::vec2_of<S>::type);
+  const size_t lds = (size_t)(FT + 1) * 2 * (size_t(1) << LOG2LP) * sizeof(typename fftdev::vec2_of<S>::type);   // frames + the two twiddle tables
   auto kernel = istft_mixed_frames_kernel<LOG2LP, FT, Tz, S>;
   SMX_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   SMX_LAUNCH(kernel, dim3((unsigned)blocks), dim3(64 * FT), lds, stream, a, pl);
