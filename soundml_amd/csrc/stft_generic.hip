@@ -928,17 +928,17 @@ __global__ void __launch_bounds__(FT * ((1 << LOG2N) / 32)) stft_stockham_comple
   }
 }
 
-template <int LOG2N>
+template <int LOG2N, int FT = 16>
 bool launch_stockham_complex16(const StftJob &job, GenericArgs a, const StftTables &t) {
-  constexpr int M = (1 << LOG2N) / 2;
+  constexpr int M = (1 << LOG2N) / 2, THREADS = FT * (M / 16);
   if (!t.fast_window || !t.fast_w_m || !t.fast_w_n) return false;
   a.window = t.fast_window;
-  const int64_t blocks = a.lead * ((a.count + 15) / 16);
+  const int64_t blocks = a.lead * ((a.count + FT - 1) / FT);
   if (blocks > 2147483647LL) throw Failure("stft: too many frame tiles for one launch");
-  const size_t lds = (size_t)16 * M * sizeof(float2);
-  auto kernel = stft_stockham_complex16_kernel<LOG2N, float>;
+  const size_t lds = (size_t)FT * M * sizeof(float2);
+  auto kernel = stft_stockham_complex16_kernel<LOG2N, float, FT>;
   SMX_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  SMX_LAUNCH(kernel, dim3((unsigned)blocks), dim3(M), lds, job.stream, a, (const float2 *)t.fast_w_m, (const float2 *)t.fast_w_n);
+  SMX_LAUNCH(kernel, dim3((unsigned)blocks), dim3(THREADS), lds, job.stream, a, (const float2 *)t.fast_w_m, (const float2 *)t.fast_w_n);
   SMX_HIP_CHECK(hipGetLastError());
   return true;
 }
@@ -1742,6 +1742,7 @@ void launch_stft_generic(const StftJob &job) {
     if (complex16 && c.fft_size == 512) done = launch_stockham_complex16<9>(job, a, t);
     if (complex16 && c.fft_size == 1024) done = launch_stockham_complex16<10>(job, a, t);
     if (complex16 && c.fft_size == 2048) done = launch_stockham_complex16<11>(job, a, t);   // where the fused kernels do not apply
+    if (job.mode == OUT_COMPLEX && !(sf && sf[0] == '1') && !(cf && cf[0] == '1') && c.fft_size == 4096) done = launch_stockham_complex16<12, 8>(job, a, t);   // eight frames per workgroup (128 KB)
     if (power16 && c.fft_size == 512) done = launch_stockham_power16<9>(job, a, t);
     if (power16 && c.fft_size == 1024) done = launch_stockham_power16<10>(job, a, t);
     if (power16 && c.fft_size == 2048) done = launch_stockham_power16<11>(job, a, t);      // where the fused kernels do not apply
