@@ -1743,6 +1743,7 @@ void launch_stft_generic(const StftJob &job) {
     if (complex16 && c.fft_size == 1024) done = launch_stockham_complex16<10>(job, a, t);
     if (complex16 && c.fft_size == 2048) done = launch_stockham_complex16<11>(job, a, t);   // where the fused kernels do not apply
     if (job.mode == OUT_COMPLEX && !(sf && sf[0] == '1') && !(cf && cf[0] == '1') && c.fft_size == 4096) done = launch_stockham_complex16<12, 8>(job, a, t);   // eight frames per workgroup (128 KB)
+    if (job.mode == OUT_COMPLEX && !(sf && sf[0] == '1') && !(cf && cf[0] == '1') && c.fft_size == 8192) done = launch_stockham_complex16<13, 4>(job, a, t);   // four
     if (power16 && c.fft_size == 512) done = launch_stockham_power16<9>(job, a, t);
     if (power16 && c.fft_size == 1024) done = launch_stockham_power16<10>(job, a, t);
     if (power16 && c.fft_size == 2048) done = launch_stockham_power16<11>(job, a, t);      // where the fused kernels do not apply
