@@ -244,12 +244,12 @@ struct LastPass {   // radix / sub-size of the final pass of fft_passes<LOG2N>
 };
 
 
-// ---- mixed-radix Stockham passes (radix 2 / 3 / 4 / 5) for lengths 2^a 3^b 5^c: one wave owns a transform ------------------
+// ---- mixed-radix Stockham passes (radix 2 / 3 / 4 / 5 / 7) for lengths 2^a 3^b 5^c 7^d: one wave owns a transform ------------------
 // Butterfly j of a pass with sub-transform length ns reads j + t L / R from `src`, multiplies by exp(-2 pi i t (j mod ns) / (ns R))
 // taken from ONE table tw_l[j] = exp(-2 pi i j / L), and writes (j - j mod ns) R + j mod ns + t ns to `dst` (autosort: natural
 // order in, natural order out).  Used by stft_mixed_power16_kernel (stft_generic.hip) and istft_mixed_frames_kernel (istft.hip).
 template <int R, typename S>
-__device__ __forceinline__ void dft_small(cpx<S> (&v)[5]) {
+__device__ __forceinline__ void dft_small(cpx<S> (&v)[7]) {
   using C = cpx<S>;
   if constexpr (R == 2) {
     const C a = v[0], b = v[1];
@@ -265,6 +265,25 @@ __device__ __forceinline__ void dft_small(cpx<S> (&v)[5]) {
     v[0] = v[0] + t1;
     v[1] = t2 + r;
     v[2] = t2 - r;
+  } else if constexpr (R == 7) {
+    // x_j +- x_(7-j) once, then three cosine and three sine combinations (forward kernel exp(-2 pi i j k / 7))
+    constexpr S c1 = (S)0.62348980185873353, c2 = (S)-0.22252093395631440, c3 = (S)-0.90096886790241913;   // cos(2 pi k / 7)
+    constexpr S s1 = (S)0.78183148246802981, s2 = (S)0.97492791218182361, s3 = (S)0.43388373911755812;    // sin(2 pi k / 7)
+    const C a1 = v[1] + v[6], a2 = v[2] + v[5], a3 = v[3] + v[4], b1 = v[1] - v[6], b2 = v[2] - v[5], b3 = v[3] - v[4];
+    const C x0 = v[0];
+    const C e1 = {x0.x + c1 * a1.x + c2 * a2.x + c3 * a3.x, x0.y + c1 * a1.y + c2 * a2.y + c3 * a3.y};
+    const C e2 = {x0.x + c2 * a1.x + c3 * a2.x + c1 * a3.x, x0.y + c2 * a1.y + c3 * a2.y + c1 * a3.y};
+    const C e3 = {x0.x + c3 * a1.x + c1 * a2.x + c2 * a3.x, x0.y + c3 * a1.y + c1 * a2.y + c2 * a3.y};
+    const C d1 = {s1 * b1.x + s2 * b2.x + s3 * b3.x, s1 * b1.y + s2 * b2.y + s3 * b3.y};
+    const C d2 = {s2 * b1.x - s3 * b2.x - s1 * b3.x, s2 * b1.y - s3 * b2.y - s1 * b3.y};
+    const C d3 = {s3 * b1.x - s1 * b2.x + s2 * b3.x, s3 * b1.y - s1 * b2.y + s2 * b3.y};
+    v[0] = x0 + a1 + a2 + a3;
+    v[1] = {e1.x + d1.y, e1.y - d1.x};            // e - i d
+    v[6] = {e1.x - d1.y, e1.y + d1.x};
+    v[2] = {e2.x + d2.y, e2.y - d2.x};
+    v[5] = {e2.x - d2.y, e2.y + d2.x};
+    v[3] = {e3.x + d3.y, e3.y - d3.x};
+    v[4] = {e3.x - d3.y, e3.y + d3.x};
   } else {
     constexpr S c1 = (S)0.30901699437494742, c2 = (S)-0.80901699437494742;   // cos(2 pi / 5), cos(4 pi / 5)
     constexpr S s1 = (S)0.95105651629515357, s2 = (S)0.58778525229247313;    // sin(2 pi / 5), sin(4 pi / 5)
@@ -289,7 +308,7 @@ __device__ __forceinline__ void mixed_pass(const typename vec2_of<S>::type *src,
   const int nb = L / R, stride = L / (ns * R);
   for (int j = lane; j < nb; j += 64) {
     const int k = j % ns;
-    cpx<S> v[5];
+    cpx<S> v[7];
 #pragma unroll
     for (int t = 0; t < R; ++t) {
       const V u = src[j + t * nb];
@@ -330,6 +349,7 @@ __device__ __forceinline__ typename vec2_of<S>::type *mixed_transform(typename v
     if (r == 4) mixed_pass<4, S>(src, dst, L, ns, lane, tw_l);
     else if (r == 2) mixed_pass<2, S>(src, dst, L, ns, lane, tw_l);
     else if (r == 5) mixed_pass<5, S>(src, dst, L, ns, lane, tw_l);
+    else if (r == 7) mixed_pass<7, S>(src, dst, L, ns, lane, tw_l);
     else mixed_pass<3, S>(src, dst, L, ns, lane, tw_l);
     ns *= r;
     asm volatile("" ::: "memory");

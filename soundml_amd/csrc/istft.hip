@@ -687,7 +687,8 @@ struct MixedInv {
   const typename fftdev::vec2_of<S>::type *tw_n;   // exp(-2 pi i k / N)
 };
 // Tz: the spectrum's scalar type (complex64 / complex128); S: the interior (float, or double = the float64 interior; y is S)
-template <int LOG2LP, int FT, typename Tz, typename S>
+// FULL (odd N): the Hermitian extension of the bins as a complex signal of N points, transformed whole; the real parts are the frame.
+template <int LOG2LP, int FT, typename Tz, typename S, bool FULL = false>
 __global__ void __launch_bounds__(64 * FT) istft_mixed_frames_kernel(IstftArgs a, MixedInv<S> pl) {
   using namespace fftdev;
   using V = typename vec2_of<S>::type;
@@ -696,17 +697,39 @@ __global__ void __launch_bounds__(64 * FT) istft_mixed_frames_kernel(IstftArgs a
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int lane = threadIdx.x & 63, f = threadIdx.x >> 6;
   V *za = reinterpret_cast<V *>(smem) + (size_t)f * (2 * LP), *zb = za + LP;
-  const int N = (int)a.fft, L = N / 2;
+  const int N = (int)a.fft, L = FULL ? N : N / 2;  // L: length of the complex transform
+  const int nbins = N / 2 + 1;
   const int64_t tiles = (a.count + FT - 1) / FT;
   const int64_t clip = blockIdx.x / tiles, frame = (blockIdx.x % tiles) * FT + f;
   V *tw_l = reinterpret_cast<V *>(smem) + (size_t)FT * (2 * LP), *tw_n = tw_l + LP;   // both twiddle tables in LDS, once per workgroup
   for (int i = threadIdx.x; i < L; i += 64 * FT) {
     tw_l[i] = pl.tw_l[i];
-    tw_n[i] = pl.tw_n[i];
+    if constexpr (!FULL) tw_n[i] = pl.tw_n[i];
   }
   __syncthreads();
   if (frame >= a.count) return;                    // wave-uniform; no workgroup barrier below
-  const CZ *zin = reinterpret_cast<const CZ *>(a.z) + clip * (int64_t)(L + 1) * a.frames + frame;
+  const CZ *zin = reinterpret_cast<const CZ *>(a.z) + clip * (int64_t)nbins * a.frames + frame;
+  if constexpr (FULL) {
+    // conj(Z_full): bins 0 .. N/2 conjugated, the mirrored half is conj(conj Z[N - k]) = Z[k]; then x = Re FFT_N(conj Z_full) / N
+    for (int k = lane; k < nbins; k += 64) {
+      const CZ c = zin[(int64_t)k * a.frames];
+      V q;
+      q.x = (S)c.x;
+      q.y = k == 0 ? (S)0 : -(S)c.y;                // the imaginary part of the DC bin does not take part
+      za[k] = q;
+      if (k > 0) {
+        q.y = (S)c.y;
+        za[N - k] = q;
+      }
+    }
+    asm volatile("" ::: "memory");
+    const V *r = mixed_transform<S>(za, zb, L, pl.npass, pl.radices, lane, tw_l);
+    const S *window = reinterpret_cast<const S *>(a.window);
+    const S inv_n = (S)1 / (S)N;
+    S *y = reinterpret_cast<S *>(a.y) + (clip * a.count + frame) * (int64_t)N;
+    for (int n = lane; n < N; n += 64) y[n] = r[n].x * inv_n * window[n];
+    return;
+  }
   for (int k = lane; k <= L; k += 64) {
     const CZ c = zin[(int64_t)k * a.frames];
     V q;
@@ -740,12 +763,12 @@ __global__ void __launch_bounds__(64 * FT) istft_mixed_frames_kernel(IstftArgs a
   }
 }
 
-template <int LOG2LP, int FT, typename Tz, typename S>
+template <int LOG2LP, int FT, typename Tz, typename S, bool FULL = false>
 void launch_mixed_frames(const IstftArgs &a, const MixedInv<S> &pl, hipStream_t stream) {
   const int64_t blocks = a.lead * ((a.count + FT - 1) / FT);
   if (blocks > 2147483647LL) throw Failure("invert: too many frame tiles for one launch");
   const size_t lds = (size_t)(FT + 1) * 2 * (size_t(1) << LOG2LP) * sizeof(typename fftdev::vec2_of<S>::type);   // frames + the two twiddle tables
-  auto kernel = istft_mixed_frames_kernel<LOG2LP, FT, Tz, S>;
+  auto kernel = istft_mixed_frames_kernel<LOG2LP, FT, Tz, S, FULL>;
   SMX_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   SMX_LAUNCH(kernel, dim3((unsigned)blocks), dim3(64 * FT), lds, stream, a, pl);
   SMX_HIP_CHECK(hipGetLastError());
@@ -755,7 +778,7 @@ void launch_mixed_frames(const IstftArgs &a, const MixedInv<S> &pl, hipStream_t 
 // interior; <float, double>: complex64 under the float64 interior; <double, double>: complex128.
 template <typename Tz, typename S>
 bool launch_mixed_frames_any(const IstftArgs &a, const StftTables &t, hipStream_t stream) {
-  if (t.mixed_npass <= 0 || a.mag || a.unit || a.fft % 2 != 0) return false;
+  if (t.mixed_npass <= 0 || a.mag || a.unit || (a.fft % 2 != 0) != (t.mixed_full != 0)) return false;
   static const bool off = [] { const char *e = std::getenv("SMX_MIXED_OFF"); return e && e[0] == '1'; }();
   if (off) return false;
   MixedInv<S> pl{};
@@ -770,8 +793,17 @@ bool launch_mixed_frames_any(const IstftArgs &a, const StftTables &t, hipStream_
     pl.tw_l = t.mixed_tw_f64;
     pl.tw_n = (const double2 *)t.twiddle_f64;
   }
-  const int64_t l = a.fft / 2;
   constexpr int W = sizeof(S) == 8 ? 2 : 1;        // a double frame is twice the LDS: half the frames per workgroup
+  if (t.mixed_full) {   // odd N: a transform of N points
+    const int64_t n = a.fft;
+    if (n <= 128) launch_mixed_frames<7, 16, Tz, S, true>(a, pl, stream);
+    else if (n <= 256) launch_mixed_frames<8, 16 / W, Tz, S, true>(a, pl, stream);
+    else if (n <= 512) launch_mixed_frames<9, 16 / W, Tz, S, true>(a, pl, stream);
+    else if (n <= 1024) launch_mixed_frames<10, 8 / W, Tz, S, true>(a, pl, stream);
+    else return false;
+    return true;
+  }
+  const int64_t l = a.fft / 2;
   if (l < 128) launch_mixed_frames<7, 16, Tz, S>(a, pl, stream);
   else if (l < 256) launch_mixed_frames<8, 16 / W, Tz, S>(a, pl, stream);
   else if (l < 512) launch_mixed_frames<9, 16 / W, Tz, S>(a, pl, stream);

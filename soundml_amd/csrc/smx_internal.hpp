@@ -88,6 +88,7 @@ struct StftTables {
   float2 *mixed_tw = nullptr;      // exp(-2 pi i j / L), j < L = N / 2
   double2 *mixed_tw_f64 = nullptr; // the same in float64 (the float64 interior)
   int mixed_npass = 0;
+  int mixed_full = 0;              // odd N: the plan is for a complex transform of N points (no half-size trick)
   int mixed_radix[10] = {};
   float2 *fast_synth_window = nullptr;   // (w[2j], -w[2j+1]) / (2M): synthesis window of the fast inverse kernel
   double2 *fast_synth_window_f64 = nullptr;   // the same in float64 (fft 512 .. 4096)

@@ -1324,19 +1324,22 @@ struct MixedPlan {
 
 // S = double: the float64 interior (float32 audio -> float32 / complex64 output rounded once, float64 audio -> float64 / complex128):
 // window, transform and |.|^p in float64, like stft_stockham_power16_kernel<.., double>.
-template <int LOG2LP, typename Tin, bool MEL, int FT = 16, bool CPLX = false, typename S = float, typename Tout = float>   // LP = frame buffer capacity in complex values (>= L)
+// FULL (odd N): the frame itself is the complex signal (imaginary parts zero), a transform of N points, bins 0 .. N / 2 read off
+// directly -- no half-size trick, no post-pass; the window table is the plain analysis window.
+template <int LOG2LP, typename Tin, bool MEL, int FT = 16, bool CPLX = false, typename S = float, typename Tout = float, bool FULL = false>   // LP = frame buffer capacity in complex values
 __global__ void __launch_bounds__(64 * FT) stft_mixed_power16_kernel(GenericArgs a, MixedPlan<S> pl, MelTail mt) {
   static_assert(!(MEL && CPLX), "the mel tail takes powers");
   static_assert(!MEL || (sizeof(S) == 4 && sizeof(Tout) == 4), "the MFMA tail is float32");
   using namespace fftdev;
   using V = typename vec2_of<S>::type;
   using CO = typename Vec2<Tout>::type;
-  constexpr S kHalf = sizeof(S) == 8 ? (S)0.5 : (S)1.0;   // float32: the window table is pre-halved
+  constexpr S kHalf = (sizeof(S) == 8 && !FULL) ? (S)0.5 : (S)1.0;   // float32: the window table is pre-halved; FULL: no halving at all
   constexpr int LP = 1 << LOG2LP;
   constexpr int BUF = (int)(2 * LP * sizeof(V) / sizeof(Tout));   // Tout elements per frame region (two buffers of LP complex values)
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   V *work = reinterpret_cast<V *>(smem);
-  const int N = (int)a.fft, L = N / 2;
+  const int N = (int)a.fft, L = FULL ? N : N / 2;        // L: length of the complex transform
+  const int nb = FULL ? N / 2 + 1 : L;                   // bins the lanes form below (the half-size form adds bin L from Z[0])
   const int64_t tiles = (a.count + FT - 1) / FT;
   const int64_t clip = blockIdx.x / tiles, tile = blockIdx.x % tiles;
   const Tin *x = reinterpret_cast<const Tin *>(a.x) + clip * a.x_stride;
@@ -1352,7 +1355,7 @@ __global__ void __launch_bounds__(64 * FT) stft_mixed_power16_kernel(GenericArgs
   V *tw_l = work + (size_t)FT * (2 * LP), *tw_n = tw_l + LP;
   for (int i = threadIdx.x; i < L; i += 64 * FT) {
     tw_l[i] = pl.tw_l[i];
-    tw_n[i] = pl.tw_n[i];
+    if constexpr (!FULL) tw_n[i] = pl.tw_n[i];
   }
   __syncthreads();
   Tout val[LP / 64], vim[CPLX ? LP / 64 : 1], nyq = (Tout)0;
@@ -1364,7 +1367,15 @@ __global__ void __launch_bounds__(64 * FT) stft_mixed_power16_kernel(GenericArgs
   if (have) {   // wave-uniform
     const int64_t s0 = (a.p0 + f0 + f) * a.hop - a.left;
     const bool inside = s0 >= 0 && s0 + N <= a.n;
-    if (inside) {   // one 8-byte access for the two samples (element-aligned only) and one for their window values
+    if constexpr (FULL) {
+      for (int i = lane; i < L; i += 64) {
+        const S v0 = inside ? (S)x[s0 + i] : (S)fetch_sample<Tin>(x, a.n, s0 + i, a.pad, a.pad_value);
+        V q;
+        q.x = v0 * window[i];
+        q.y = (S)0;
+        za[i] = q;
+      }
+    } else if (inside) {   // one 8-byte access for the two samples (element-aligned only) and one for their window values
       using P = typename Pair<Tin>::type;
       for (int i = lane; i < L; i += 64) {
         const P xv = *reinterpret_cast<const P *>(x + s0 + 2 * i);
@@ -1387,7 +1398,17 @@ __global__ void __launch_bounds__(64 * FT) stft_mixed_power16_kernel(GenericArgs
 #pragma unroll
     for (int m = 0; m < LP / 64; ++m) {
       const int k = lane + 64 * m;
-      if (k < L) {
+      if constexpr (FULL) {
+        if (k < nb) {
+          const V zk = z[k];
+          if constexpr (CPLX) {
+            val[m] = (Tout)zk.x;
+            vim[m] = (Tout)(k == 0 ? (S)0 : zk.y);                 // X[0] is real
+          } else {
+            val[m] = magnitude_pow<S, Tout>(zk.x, k == 0 ? (S)0 : zk.y, a.power);
+          }
+        }
+      } else if (k < L) {
         const V zk = z[k], zm = z[k == 0 ? 0 : L - k];
         const S er = zk.x + zm.x, ei = zk.y - zm.y;
         const S dr = zk.x - zm.x, di = zk.y + zm.y;
@@ -1401,7 +1422,7 @@ __global__ void __launch_bounds__(64 * FT) stft_mixed_power16_kernel(GenericArgs
         }
       }
     }
-    if (lane == 0) {
+    if (!FULL && lane == 0) {
       const V z0 = z[0];
       nyq = CPLX ? (Tout)((S)2 * (z0.x - z0.y)) : magnitude_pow<S, Tout>((S)2 * (z0.x - z0.y), (S)0, a.power);   // X[L] is real
     }
@@ -1418,14 +1439,14 @@ __global__ void __launch_bounds__(64 * FT) stft_mixed_power16_kernel(GenericArgs
 #pragma unroll
     for (int m = 0; m < LP / 64; ++m) {
       const int k = lane + 64 * m;
-      if (k < L) {
+      if (k < nb) {
         CO c;
         c.x = val[m];
         c.y = vim[m];
         ccol[k] = c;
       }
     }
-    if (lane == 0) {
+    if (!FULL && lane == 0) {
       CO c;
       c.x = nyq;
       c.y = (Tout)0;
@@ -1438,7 +1459,7 @@ __global__ void __launch_bounds__(64 * FT) stft_mixed_power16_kernel(GenericArgs
     constexpr int CS = (int)(2 * LP * sizeof(V) / sizeof(CO));   // CO elements per frame region
     if (nf == FT) {
       constexpr int PER = 16 / sizeof(CO), QF = FT / PER;   // two complex64 frames or one complex128 per 16-byte piece
-      for (int e = threadIdx.x; e < (L + 1) * QF; e += blockDim.x) {
+      for (int e = threadIdx.x; e < (int)a.bins * QF; e += blockDim.x) {
         const int k = e / QF, g = PER * (e % QF);
         CO *dst = out + obase + (int64_t)k * a.out_stride + g;
         if constexpr (sizeof(CO) == 8) {
@@ -1452,64 +1473,50 @@ __global__ void __launch_bounds__(64 * FT) stft_mixed_power16_kernel(GenericArgs
       }
       return;
     }
-    for (int e = threadIdx.x; e < (L + 1) * nf; e += blockDim.x) {   // a clip's ragged last tile
+    for (int e = threadIdx.x; e < (int)a.bins * nf; e += blockDim.x) {   // a clip's ragged last tile
       const int k = e / nf, g = e - k * nf;
       out[obase + (int64_t)k * a.out_stride + g] = cols[g * CS + 2 * g + k];
     }
     return;
   }
-  Tout *col = reinterpret_cast<Tout *>(za) + 2 * f;   // column f of the tile: L + 1 values in the frame's own region
+  Tout *col = reinterpret_cast<Tout *>(za) + 2 * f;   // column f of the tile: a.bins values in the frame's own region
 #pragma unroll
   for (int m = 0; m < LP / 64; ++m) {
     const int k = lane + 64 * m;
-    if (k < L) col[k] = val[m];
+    if (k < nb) col[k] = val[m];
   }
-  if (lane == 0) col[L] = nyq;
+  if (!FULL && lane == 0) col[L] = nyq;
   __syncthreads();
   // the helper waves' partial tiles (1 KB each) go into the frames' second buffers, which are free by now: no LDS beyond the frames' own
-  columns_out<BUF, FT, MEL, Tout>(a, mt, reinterpret_cast<const Tout *>(work), L + 1, nf, clip, f0, tb,
+  columns_out<BUF, FT, MEL, Tout>(a, mt, reinterpret_cast<const Tout *>(work), (int)a.bins, nf, clip, f0, tb,
                                   MEL ? reinterpret_cast<float *>(work + LP) : nullptr, (int)(2 * LP * sizeof(V) / sizeof(float)));
 }
 
-template <int LOG2LP, int FT = 16>
+template <int LOG2LP, int FT = 16, bool FULL = false>
 bool launch_mixed_power16(const StftJob &job, GenericArgs a, const StftTables &t, const MixedPlan<float> &pl, const MelTail *mel) {
   constexpr int LP = 1 << LOG2LP;
-  a.window = t.blu2_window;
+  a.window = FULL ? (const void *)t.window_f32 : (const void *)t.blu2_window;
   const int64_t blocks = a.lead * ((a.count + FT - 1) / FT);
   if (blocks > 2147483647LL) throw Failure("stft: too many frame tiles for one launch");
   const size_t lds = (size_t)FT * 4 * LP * sizeof(float) + (size_t)2 * LP * sizeof(float2);   // frames + the two twiddle tables
-  if (job.mode == OUT_COMPLEX) {
-    if (mel) return false;
-    auto kernel = stft_mixed_power16_kernel<LOG2LP, float, false, FT, true>;
+  auto launch = [&](auto kernel, const MelTail &tail) {
     SMX_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    SMX_LAUNCH(kernel, dim3((unsigned)blocks), dim3(64 * FT), lds, job.stream, a, pl, MelTail{});
+    SMX_LAUNCH(kernel, dim3((unsigned)blocks), dim3(64 * FT), lds, job.stream, a, pl, tail);
     SMX_HIP_CHECK(hipGetLastError());
     return true;
-  }
-  if constexpr (FT != 16) {
-    if (mel) return false;   // the MFMA tail is 16 frames wide
-    auto kernel = stft_mixed_power16_kernel<LOG2LP, float, false, FT>;
-    SMX_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    SMX_LAUNCH(kernel, dim3((unsigned)blocks), dim3(64 * FT), lds, job.stream, a, pl, MelTail{});
-    SMX_HIP_CHECK(hipGetLastError());
-    return true;
-  } else
-  if (mel) {
-    const size_t lds_mel = lds;   // the helper waves' partial tiles live in the frames' second buffers
-    auto kernel = stft_mixed_power16_kernel<LOG2LP, float, true>;
-    SMX_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_mel));
-    SMX_LAUNCH(kernel, dim3((unsigned)blocks), dim3(1024), lds_mel, job.stream, a, pl, *mel);
+  };
+  if (job.mode == OUT_COMPLEX) return mel ? false : launch(stft_mixed_power16_kernel<LOG2LP, float, false, FT, true, float, float, FULL>, MelTail{});
+  if constexpr (FT != 16 || FULL) {   // the MFMA tail is 16 frames wide (and the odd sizes have no fused mel face)
+    return mel ? false : launch(stft_mixed_power16_kernel<LOG2LP, float, false, FT, false, float, float, FULL>, MelTail{});
   } else {
-    auto kernel = stft_mixed_power16_kernel<LOG2LP, float, false>;
-    SMX_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    SMX_LAUNCH(kernel, dim3((unsigned)blocks), dim3(1024), lds, job.stream, a, pl, MelTail{});
+    // (the helper waves' partial tiles live in the frames' second buffers: no LDS beyond lds)
+    if (mel) return launch(stft_mixed_power16_kernel<LOG2LP, float, true>, *mel);
+    return launch(stft_mixed_power16_kernel<LOG2LP, float, false>, MelTail{});
   }
-  SMX_HIP_CHECK(hipGetLastError());
-  return true;
 }
 
 // the float64 interior: Tio = float (float32 audio, float32 / complex64 out) or double (float64 audio, float64 / complex128 out)
-template <int LOG2LP, int FT, typename Tio>
+template <int LOG2LP, int FT, typename Tio, bool FULL = false>
 bool launch_mixed_power16_wide(const StftJob &job, GenericArgs a, const StftTables &t, const MixedPlan<double> &pl) {
   constexpr int LP = 1 << LOG2LP;
   a.window = t.window_f64;
@@ -1521,14 +1528,14 @@ bool launch_mixed_power16_wide(const StftJob &job, GenericArgs a, const StftTabl
     SMX_LAUNCH(kernel, dim3((unsigned)blocks), dim3(64 * FT), lds, job.stream, a, pl, MelTail{});
     SMX_HIP_CHECK(hipGetLastError());
   };
-  if (job.mode == OUT_COMPLEX) launch(stft_mixed_power16_kernel<LOG2LP, Tio, false, FT, true, double, Tio>);
-  else launch(stft_mixed_power16_kernel<LOG2LP, Tio, false, FT, false, double, Tio>);
+  if (job.mode == OUT_COMPLEX) launch(stft_mixed_power16_kernel<LOG2LP, Tio, false, FT, true, double, Tio, FULL>);
+  else launch(stft_mixed_power16_kernel<LOG2LP, Tio, false, FT, false, double, Tio, FULL>);
   return true;
 }
 
 template <typename Tio>
 bool launch_mixed16_wide_any(const StftJob &job, const GenericArgs &a, const StftTables &t) {
-  if (t.mixed_npass <= 0 || !t.mixed_tw_f64 || !t.window_f64 || !t.twiddle_f64 || !t.blu2_window) return false;   // (blu2_window: the forward plan's sizes)
+  if (t.mixed_npass <= 0 || !t.mixed_tw_f64 || !t.window_f64 || !t.twiddle_f64 || !(t.blu2_window || t.mixed_full)) return false;   // (the forward plan's sizes)
   static const bool off = [] { const char *e = std::getenv("SMX_MIXED_OFF"); return e && e[0] == '1'; }();
   if (off) return false;
   MixedPlan<double> pl{};
@@ -1536,6 +1543,14 @@ bool launch_mixed16_wide_any(const StftJob &job, const GenericArgs &a, const Stf
   for (int i = 0; i < t.mixed_npass; ++i) pl.radices |= (unsigned long long)t.mixed_radix[i] << (4 * i);
   pl.tw_l = t.mixed_tw_f64;
   pl.tw_n = (const double2 *)t.twiddle_f64;
+  if (t.mixed_full) {   // odd N: a transform of N points
+    const int64_t n = a.fft;
+    if (n <= 128) return launch_mixed_power16_wide<7, 16, Tio, true>(job, a, t, pl);
+    if (n <= 256) return launch_mixed_power16_wide<8, 16, Tio, true>(job, a, t, pl);
+    if (n <= 512) return launch_mixed_power16_wide<9, 8, Tio, true>(job, a, t, pl);
+    if (n <= 1024) return launch_mixed_power16_wide<10, 4, Tio, true>(job, a, t, pl);
+    return false;
+  }
   const int64_t l = a.fft / 2;
   if (l <= 128) return launch_mixed_power16_wide<7, 16, Tio>(job, a, t, pl);
   if (l <= 256) return launch_mixed_power16_wide<8, 16, Tio>(job, a, t, pl);
@@ -1546,7 +1561,7 @@ bool launch_mixed16_wide_any(const StftJob &job, const GenericArgs &a, const Stf
 
 // true when the size has a mixed-radix plan (StftTables::mixed_npass > 0) and the kernel took the launch
 bool launch_mixed16_any(const StftJob &job, const GenericArgs &a, const StftTables &t, const MelTail *mel) {
-  if (t.mixed_npass <= 0 || !t.mixed_tw || !t.blu2_window || !t.twiddle_f32) return false;
+  if (t.mixed_npass <= 0 || !t.mixed_tw || !(t.blu2_window || (t.mixed_full && t.window_f32)) || !t.twiddle_f32) return false;
   static const bool off = [] { const char *e = std::getenv("SMX_MIXED_OFF"); return e && e[0] == '1'; }();   // A/B timing: chirp-z instead
   if (off) return false;
   MixedPlan<float> pl{};
@@ -1554,6 +1569,14 @@ bool launch_mixed16_any(const StftJob &job, const GenericArgs &a, const StftTabl
   for (int i = 0; i < t.mixed_npass; ++i) pl.radices |= (unsigned long long)t.mixed_radix[i] << (4 * i);
   pl.tw_l = t.mixed_tw;
   pl.tw_n = (const float2 *)t.twiddle_f32;
+  if (t.mixed_full) {   // odd N: a transform of N points
+    const int64_t n = a.fft;
+    if (n <= 128) return launch_mixed_power16<7, 16, true>(job, a, t, pl, mel);
+    if (n <= 256) return launch_mixed_power16<8, 16, true>(job, a, t, pl, mel);
+    if (n <= 512) return launch_mixed_power16<9, 16, true>(job, a, t, pl, mel);
+    if (n <= 1024) return launch_mixed_power16<10, 8, true>(job, a, t, pl, mel);
+    return false;
+  }
   const int64_t l = a.fft / 2;
   if (l <= 128) return launch_mixed_power16<7>(job, a, t, pl, mel);
   if (l <= 256) return launch_mixed_power16<8>(job, a, t, pl, mel);

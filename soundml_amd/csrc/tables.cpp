@@ -229,7 +229,7 @@ const smx::StftTables &smx_stft_config::tables() const {
         t.blu2_tw = smx::upload(tw);
         t.blu2_window = smx::upload(hw);
         t.blu2_log2m = log2m2;
-        // L = 2^a 3^b 5^c <= 1024 (and not a power of two: those have the Stockham kernels): radices 4, 2, 5, 3
+        // L = 2^a 3^b 5^c 7^d <= 1024 (and not a power of two: those have the Stockham kernels): radices 4, 2, 5, 3, 7
         if (l <= 1024 && (l & (l - 1)) != 0) {
           int64_t rest = l;
           int np = 0, radix[10];
@@ -237,6 +237,7 @@ const smx::StftTables &smx_stft_config::tables() const {
           while (rest % 2 == 0 && np < 10) { radix[np++] = 2; rest /= 2; }
           while (rest % 5 == 0 && np < 10) { radix[np++] = 5; rest /= 5; }
           while (rest % 3 == 0 && np < 10) { radix[np++] = 3; rest /= 3; }
+          while (rest % 7 == 0 && np < 10) { radix[np++] = 7; rest /= 7; }
           if (rest == 1 && np > 0) {
             std::vector<float2> twl((size_t)l);
             for (int64_t j = 0; j < l; ++j) {
@@ -255,6 +256,30 @@ const smx::StftTables &smx_stft_config::tables() const {
           }
         }
       }
+    }
+  }
+
+  // odd sizes N = 3^b 5^c 7^d <= 1024 (441, 225, 375, 675, 945 ...): the same kernels on the frame itself as a complex signal of
+  // N points (no half-size trick), plan for N, twiddles exp(-2 pi i j / N)
+  if (n % 2 == 1 && n >= 3 && n <= 1024) {
+    int64_t rest = n;
+    int np = 0, radix[10];
+    while (rest % 5 == 0 && np < 10) { radix[np++] = 5; rest /= 5; }
+    while (rest % 3 == 0 && np < 10) { radix[np++] = 3; rest /= 3; }
+    while (rest % 7 == 0 && np < 10) { radix[np++] = 7; rest /= 7; }
+    if (rest == 1 && np > 0) {
+      std::vector<float2> twl((size_t)n);
+      std::vector<double2> twd((size_t)n);
+      for (int64_t j = 0; j < n; ++j) {
+        const double a = -2.0 * M_PI * (double)j / (double)n;
+        twl[(size_t)j] = make_float2((float)std::cos(a), (float)std::sin(a));
+        twd[(size_t)j] = make_double2(std::cos(a), std::sin(a));
+      }
+      t.mixed_tw = smx::upload(twl);
+      t.mixed_tw_f64 = smx::upload(twd);
+      t.mixed_npass = np;
+      t.mixed_full = 1;
+      for (int i = 0; i < np; ++i) t.mixed_radix[i] = radix[i];
     }
   }
 

@@ -274,6 +274,33 @@ def test_mixed_radix_float64_interior(fft):
     assert xi.dtype == np.float32 and np.max(np.abs(xi - wi)) <= 4e-7 * float(np.max(np.abs(wi)))
 
 
+@pytest.mark.parametrize("fft", [9, 15, 21, 45, 49, 105, 225, 315, 441, 675, 945])
+def test_mixed_radix_odd_sizes(fft):
+    """Odd sizes 3^b 5^c 7^d: the same kernels on the frame as a complex signal of N points (radix 5 / 3 / 7 passes, no half-size
+    trick), forward (power, complex) and inverse, float32 and the float64 interior, against the oracle."""
+    rng = np.random.default_rng(fft + 3)
+    hop = max(1, fft // 4)
+    n = 21 * hop + fft + 2
+    x = rng.uniform(-1, 1, size=(2, n)).astype(np.float32)
+    c, o = Stft.Config.create(fft_size=fft, hop=hop), O.stft_config(fft, hop=hop)
+    z, want = Stft.transform(c, x), O.transform(o, x)
+    check_fast(z.real, want.real, "re")
+    check_fast(z.imag, want.imag, "im")
+    got, wp = Stft.power_spectrum(c, x), O.power_spectrum(o, x)
+    check_fast(got, wp, "power")
+    assert np.max(np.abs(got - wp)) <= 2e-6 * np.max(np.abs(wp)), "regression gate"
+    if Stft.nola(c):
+        zz = want.astype(np.complex64)
+        check_fast(Stft.invert(c, zz, n), O.invert(o, zz, n), "invert")
+    x64 = x.astype(np.float64)
+    z64, w64 = Stft.transform(c, x64), O.transform(o, x64)
+    assert z64.dtype == np.complex128
+    check_close(z64.real, w64.real, rtol=F64_RTOL, atol=1e-11, msg="re f64")
+    check_close(z64.imag, w64.imag, rtol=F64_RTOL, atol=1e-11, msg="im f64")
+    if Stft.nola(c):
+        check_close(Stft.invert(c, z64, n), O.invert(o, w64, n), rtol=1e-8, atol=1e-11, msg="invert f64")
+
+
 def test_mixed_radix_kernel_agrees_with_chirp_z():
     code = """
 import sys, numpy as np
