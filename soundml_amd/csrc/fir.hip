@@ -384,45 +384,63 @@ __global__ void __launch_bounds__(1024, 4) fir_ols_split_kernel(FirArgs a) {
   }
 }
 
-// ---- short filters (taps <= 40: pre-emphasis, DC blockers, smoothers): the sum itself ----------------------------------------
-// An FFT block of 1024 samples costs these the same 0.077 ms as a 256-tap filter (C4-shaped input: 0.30 of the roof).  Direct
-// form: a workgroup stages 4096 + taps - 1 input samples in LDS (zeros outside the stream), every thread forms 16 consecutive
-// outputs from a sliding register window, taps in ascending order with fused multiply-adds in float32 (h rounded to float32, as
-// the FFT path rounds H).  y[c][i] = sum_k h[k] x[c][out_shift + i - k].
+// ---- short filters (taps <= 128: pre-emphasis, DC blockers, smoothers, short anti-alias filters): the sum itself ----------------
+// An FFT block of 1024 samples costs these the same 0.077 - 0.10 ms as a 256-tap filter (C4-shaped input: 0.30 of the roof).
+// Direct form: a workgroup stages 2048 + taps - 1 input samples in LDS (zeros outside the stream); every thread forms EIGHT
+// CONSECUTIVE outputs from a 16-value register window that slides down the taps eight at a time (two 16-byte LDS reads per 64
+// multiply-adds), taps in ascending order, float32 fused multiply-adds (h rounded to float32, as the FFT path rounds H).
+//   y[c][i] = sum_k h[k] x[c][out_shift + i - k]
 struct FirDirectArgs {
   const float *x;
   float *y;
   int64_t n, x_stride, y_stride, n_out, out_shift;
   int taps;
-  float h[64];
+  float h[128];        // zero beyond taps (the loop runs over whole groups of eight)
 };
 __global__ void __launch_bounds__(256) fir_direct_kernel(FirDirectArgs a) {
-  constexpr int PER = 16, TILE = 256 * PER;
-  __shared__ float xs[TILE + 64];
+  constexpr int PER = 8, TILE = 256 * PER;
+  __shared__ __attribute__((aligned(16))) float xs[TILE + 128 + 16];
   const int64_t c = blockIdx.y, o0 = (int64_t)blockIdx.x * TILE;      // first output of the tile
   const float *x = a.x + c * a.x_stride;
-  const int64_t base = a.out_shift + o0 - (a.taps - 1);               // input sample behind xs[0]
-  for (int i = threadIdx.x; i < TILE + a.taps - 1; i += 256) {
+  const int groups = (a.taps + 7) >> 3, halo = 8 * groups;            // xs[0] is input sample out_shift + o0 - halo
+  const int64_t base = a.out_shift + o0 - halo;
+  for (int i = threadIdx.x; i < TILE + halo; i += 256) {
     const int64_t g = base + i;
     xs[i] = (g >= 0 && g < a.n) ? x[g] : 0.0f;
   }
   __syncthreads();
-  // thread t: outputs o0 + t + 256 j, j < 16 (lane-contiguous stores, conflict-free LDS reads); xs index of x[out - k] is
-  // (out - o0) + taps - 1 - k
-  float acc[PER];
+  // thread t: outputs o0 + 8 t + j, j < 8.  x[out_j - k] sits at xs[8 t + j - k + halo].  Window for taps 8 g .. 8 g + 7:
+  // W[i] = xs[8 t + halo - 8 g - 8 + i], i < 16, and x[out_j - (8 g + kk)] = W[j - kk + 8].
+  using f32x4 = __attribute__((ext_vector_type(4))) float;
+  const float *p = xs + 8 * threadIdx.x + halo;
+  float acc[PER], w[16];
 #pragma unroll
   for (int j = 0; j < PER; ++j) acc[j] = 0.0f;
-  for (int k = 0; k < a.taps; ++k) {
-    const float hk = a.h[k];                                          // uniform: scalar load from the kernel arguments
-    const float *p = xs + threadIdx.x + (a.taps - 1 - k);
+  {
+    const f32x4 u0 = *reinterpret_cast<const f32x4 *>(p), u1 = *reinterpret_cast<const f32x4 *>(p + 4);
+    w[8] = u0[0]; w[9] = u0[1]; w[10] = u0[2]; w[11] = u0[3]; w[12] = u1[0]; w[13] = u1[1]; w[14] = u1[2]; w[15] = u1[3];
+  }
+  for (int g = 0; g < groups; ++g) {
+    const f32x4 u0 = *reinterpret_cast<const f32x4 *>(p - 8 * g - 8), u1 = *reinterpret_cast<const f32x4 *>(p - 8 * g - 4);
+    w[0] = u0[0]; w[1] = u0[1]; w[2] = u0[2]; w[3] = u0[3]; w[4] = u1[0]; w[5] = u1[1]; w[6] = u1[2]; w[7] = u1[3];
 #pragma unroll
-    for (int j = 0; j < PER; ++j) acc[j] = __builtin_fmaf(hk, p[256 * j], acc[j]);
+    for (int kk = 0; kk < 8; ++kk) {
+      const float hk = a.h[8 * g + kk];                               // uniform: scalar load from the kernel arguments
+#pragma unroll
+      for (int j = 0; j < PER; ++j) acc[j] = __builtin_fmaf(hk, w[j - kk + 8], acc[j]);
+    }
+#pragma unroll
+    for (int i = 15; i >= 8; --i) w[i] = w[i - 8];                    // the window slides down by eight taps
   }
   float *y = a.y + c * a.y_stride;
+  const int64_t o = o0 + 8 * (int64_t)threadIdx.x;
+  if (o + 8 <= a.n_out && ((reinterpret_cast<uintptr_t>(y + o) & 15) == 0)) {
+    *reinterpret_cast<f32x4 *>(y + o) = f32x4{acc[0], acc[1], acc[2], acc[3]};
+    *reinterpret_cast<f32x4 *>(y + o + 4) = f32x4{acc[4], acc[5], acc[6], acc[7]};
+  } else {
 #pragma unroll
-  for (int j = 0; j < PER; ++j) {
-    const int64_t o = o0 + threadIdx.x + 256 * j;
-    if (o < a.n_out) y[o] = acc[j];
+    for (int j = 0; j < PER; ++j)
+      if (o + j < a.n_out) y[o + j] = acc[j];
   }
 }
 
@@ -647,7 +665,8 @@ void fir_apply_window_dev(const smx_fir_plan &p, const float *d_x, int64_t chann
   a.w_split = t.w_split;
   a.tw_1k = t.tw_1k;
   static const bool direct_off = [] { const char *e = std::getenv("SMX_FIR_DIRECT"); return e && e[0] == '0'; }();   // A/B timing: FFT blocks for short filters too
-  if (p.taps <= 40 && !direct_off && channels <= 65535) {   // measured crossover with the FFT blocks: ~43 taps
+  static const int64_t direct_max = [] { const char *e = std::getenv("SMX_FIR_DIRECT_MAX"); return e ? (int64_t)std::atoll(e) : (int64_t)80; }();
+  if (p.taps <= direct_max && p.taps <= 128 && !direct_off && channels <= 65535) {   // measured crossover with the FFT blocks: see DESIGN 4.5
     FirDirectArgs da{};
     da.x = d_x;
     da.y = d_y;
@@ -658,7 +677,7 @@ void fir_apply_window_dev(const smx_fir_plan &p, const float *d_x, int64_t chann
     da.out_shift = out_shift;
     da.taps = (int)p.taps;
     for (int64_t k = 0; k < p.taps; ++k) da.h[k] = (float)p.h[(size_t)k];
-    const int64_t tiles = (n_out + 4095) / 4096;
+    const int64_t tiles = (n_out + 2047) / 2048;
     if (tiles > 0x7fffffff) throw Failure("fir_apply: too many blocks for one launch");
     SMX_LAUNCH(fir_direct_kernel, dim3((unsigned)tiles, (unsigned)channels), dim3(256), 0, stream, da);
     SMX_HIP_CHECK(hipGetLastError());
