@@ -156,7 +156,12 @@ def main():
     if world > 1:
         backend = "nccl" if ndev >= world else "gloo"      # RCCL refuses two ranks on one device
         if backend == "nccl":
-            dist.init_process_group("nccl", device_id=dev)
+            try:
+                dist.init_process_group("nccl", device_id=dev)
+            except Exception as e:          # the clock's barrier and MAX-reduce are the only collectives: gloo carries them as well
+                sys.stderr.write("bench.py: RCCL process group failed (%s); timing collectives over gloo\n" % e)
+                backend = "gloo"
+                dist.init_process_group("gloo")
         else:
             dist.init_process_group("gloo")
     red_dev = dev if backend == "nccl" else None
