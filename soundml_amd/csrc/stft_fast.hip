@@ -1508,12 +1508,17 @@ namespace {
 // Border strips: out[clip][j] = padded sample at signal position pos0 + j
 // (reflect / edge / constant extension of stft.ml:300-338), so that border
 // frames run through the SAME kernel and arithmetic as interior frames.
-__global__ void __launch_bounds__(256) gather_padded_kernel(const float *x, int64_t n, int64_t x_stride,
-                                                            int64_t pos0, int64_t len, int pad,
-                                                            float pad_value, float *out, int64_t out_stride) {
-  const int64_t clip = blockIdx.y;
+struct GatherSpan {   // one strip: len samples from signal position pos0 on, rows of out_stride floats
+  int64_t pos0, len, out_stride;
+  float *out;
+};
+// blockIdx.z picks the strip (left border / right border of the clips): both in one launch
+__global__ void __launch_bounds__(256) gather_padded_kernel(const float *x, int64_t n, int64_t x_stride, GatherSpan s0, GatherSpan s1,
+                                                            int pad, float pad_value) {
+  const GatherSpan sp = blockIdx.z == 0 ? s0 : s1;
+  const int64_t clip = blockIdx.y, pos0 = sp.pos0, len = sp.len;
   const float *src = x + clip * x_stride;
-  float *dst = out + clip * out_stride;
+  float *dst = sp.out + clip * sp.out_stride;
   for (int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x; j < len; j += (int64_t)gridDim.x * 256) {
     int64_t s = pos0 + j;
     float v;
@@ -1711,9 +1716,9 @@ void launch_border(const StftJob &job, const FastTarget &tg, int64_t pa, int64_t
   float *strip = nullptr;
   SMX_HIP_CHECK(smx::pool_malloc_async((void **)&strip, (size_t)job.lead * (size_t)stride * sizeof(float), job.stream));
   dim3 grid((unsigned)((len + 255) / 256 < 64 ? (len + 255) / 256 : 64), (unsigned)job.lead);
-  SMX_LAUNCH(gather_padded_kernel, grid, dim3(256), 0, job.stream,
-                     reinterpret_cast<const float *>(job.x), job.n, job.x_stride, pos0, len, job.pad,
-                     (float)job.pad_value, strip, stride);
+  const GatherSpan span{pos0, len, stride, strip};
+  SMX_LAUNCH(gather_padded_kernel, grid, dim3(256), 0, job.stream, reinterpret_cast<const float *>(job.x), job.n, job.x_stride, span, span,
+             job.pad, (float)job.pad_value);
   SMX_HIP_CHECK(hipGetLastError());
   launch_interior(job, tg, strip, len, stride, 0, 0, pb - pa, tg.out_offset + (pa - job.p0), /*strip=*/true);
   SMX_HIP_CHECK(hipFreeAsync(strip, job.stream));
@@ -1769,20 +1774,25 @@ void launch_ranges(const StftJob &job, const FastTarget &tg) {
     folded.border_p0 = i0;
     folded.border_i1 = i1;
     float *strips[2] = {nullptr, nullptr};
-    auto gather = [&](int which, int64_t pa, int64_t pb, const float *&dst, int64_t &dst_stride) {
+    GatherSpan spans[2] = {};
+    auto plan = [&](int which, int64_t pa, int64_t pb, const float *&dst, int64_t &dst_stride) {
       if (pb <= pa) return;
       const int64_t pos0 = pa * c.hop - job.left, len = (pb - pa - 1) * c.hop + kN;
       const int64_t stride = (len + 1) & ~int64_t(1);            // even: keeps 8-byte aligned rows
       SMX_HIP_CHECK(smx::pool_malloc_async((void **)&strips[which], (size_t)job.lead * (size_t)stride * sizeof(float), job.stream));
-      dim3 grid((unsigned)((len + 255) / 256 < 64 ? (len + 255) / 256 : 64), (unsigned)job.lead);
-      SMX_LAUNCH(gather_padded_kernel, grid, dim3(256), 0, job.stream, reinterpret_cast<const float *>(job.x), job.n,
-                 job.x_stride, pos0, len, job.pad, (float)job.pad_value, strips[which], stride);
-      SMX_HIP_CHECK(hipGetLastError());
+      spans[which] = GatherSpan{pos0, len, stride, strips[which]};
       dst = strips[which];
       dst_stride = stride;
     };
-    gather(0, p0, i0, folded.strip_l, folded.strip_l_stride);
-    gather(1, i1, p1, folded.strip_r, folded.strip_r_stride);
+    plan(0, p0, i0, folded.strip_l, folded.strip_l_stride);
+    plan(1, i1, p1, folded.strip_r, folded.strip_r_stride);
+    {   // both strips in ONE launch (a span of length 0 has no work)
+      const int64_t longest = spans[0].len > spans[1].len ? spans[0].len : spans[1].len;
+      dim3 grid((unsigned)((longest + 255) / 256 < 64 ? (longest + 255) / 256 : 64), (unsigned)job.lead, 2);
+      SMX_LAUNCH(gather_padded_kernel, grid, dim3(256), 0, job.stream, reinterpret_cast<const float *>(job.x), job.n, job.x_stride,
+                 spans[0], spans[1], job.pad, (float)job.pad_value);
+      SMX_HIP_CHECK(hipGetLastError());
+    }
     launch_interior(job, folded, reinterpret_cast<const float *>(job.x), job.n, job.x_stride, job.left, p0, p1 - p0, tg.out_offset);
     for (float *sp : strips)
       if (sp) SMX_HIP_CHECK(hipFreeAsync(sp, job.stream));
