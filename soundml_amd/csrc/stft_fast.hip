@@ -864,6 +864,8 @@ __global__ void __launch_bounds__(1024) stft2048_power_kernel(FastArgs a) {
 #endif
 }
 
+#include "stft_fast_p32.hpp"   // the 32-lane frame pipeline: stft2048_power32_kernel
+
 // ---- power spectrogram kernel, ring form ----------------------------------------------------------------------
 // The same frame pipeline; what changes is where the results wait in LDS and how they leave.
 //   * A workgroup walks a CONTIGUOUS range of the flat (clip, tile) sequence, i.e. consecutive tiles of one clip.
@@ -1684,7 +1686,8 @@ void launch_interior(const StftJob &job, const FastTarget &tg, const float *x, i
   // on the box (profiles/r04/c5_ring_sizes.log): it takes the launches whose input + output pass 8 GB.  SMX_POWER_RING=1 / 0 forces it.
   const char *ring_env = std::getenv("SMX_POWER_RING");
   const double ring_footprint = (double)job.lead * ((double)n + (double)kBins * (double)count) * 4.0;
-  const bool ring = !tg.fold_frames && (ring_env ? ring_env[0] == '1' : (!strip && ring_footprint > 8.0e9));   // the ring kernel has no strip reader
+  (void)ring_footprint;
+  const bool ring = !tg.fold_frames && !strip && ring_env && ring_env[0] == '1';   // the ring kernel (64-lane pipeline) only on request: its frames round differently from the 32-lane pipeline's
   auto pick = [&](auto strip_tag) {
     constexpr bool S = decltype(strip_tag)::value;
     constexpr int F = SMX_RING_FLUSH_AT;
@@ -1696,6 +1699,21 @@ void launch_interior(const StftJob &job, const FastTarget &tg, const float *x, i
   };
   auto kernel = strip ? pick(std::true_type{}) : pick(std::false_type{});
 #endif
+  // The 32-lane pipeline (stft_fast_p32.hpp) is the power kernel; SMX_POWER_V1=1 keeps the 64-lane kernels above for A/B timing.
+  const char *v1_env = std::getenv("SMX_POWER_V1");
+  const bool v1 = v1_env && v1_env[0] == '1';
+  if (!v1 && !ring) {
+    auto pick32 = [&](auto strip_tag) {
+      constexpr bool S = decltype(strip_tag)::value;
+      return aligned ? (square ? stft2048_power32_kernel<true, true, S> : stft2048_power32_kernel<true, false, S>)
+                     : (square ? stft2048_power32_kernel<false, true, S> : stft2048_power32_kernel<false, false, S>);
+    };
+    auto k32 = strip ? pick32(std::true_type{}) : pick32(std::false_type{});
+    SMX_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k32), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kFast32Lds));
+    SMX_LAUNCH(k32, dim3((unsigned)a.blocks), dim3(512), kFast32Lds, job.stream, a);
+    SMX_HIP_CHECK(hipGetLastError());
+    return;
+  }
   SMX_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kernel),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)kFastLds));
   unsigned threads = 1024;
