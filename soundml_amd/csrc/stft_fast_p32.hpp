@@ -160,6 +160,7 @@ struct NoMid32 {
   __device__ __forceinline__ void before_cells() const {}
   __device__ __forceinline__ void after_transposition() const {}
   __device__ __forceinline__ void after_stage_b() const {}
+  template <int I> __device__ __forceinline__ void stamp() const {}
 };
 
 // Two frames (one per lane-half): raw samples (registers) -> window -> FFT(1024 complex) -> post-pass -> |X|^p in the
@@ -179,6 +180,7 @@ __device__ __forceinline__ void frame32_to_tile(const FastArgs &a, const Lane32 
 #pragma unroll
     for (int j = 0; j < 32; ++j) v[j] = {raw[j].x * win[j].x, raw[j].y * win[j].y};
   }
+  mid.template stamp<1>();
   SMX_FENCE();
   // A: radix-32 over j, then twiddle W_M^(l k1)
   {
@@ -192,7 +194,9 @@ __device__ __forceinline__ void frame32_to_tile(const FastArgs &a, const Lane32 
   SMX_FENCE();
   // X: lane l register k1 -> lane k1 register l through the frame's column, real parts then imaginary parts.
   // One wave's LDS operations execute in order, so no wait separates the rounds.
+  mid.template stamp<2>();
   mid.before_cells();
+  mid.template stamp<3>();
   float *const wr = tile + L.own;
   float *const wr_hi = wr + 16 * kCellPitch32;   // (ds offsets are 16 bits: 31 x 2244 bytes does not fit)
   const float *const rd = tile + L.rd;
@@ -204,12 +208,16 @@ __device__ __forceinline__ void frame32_to_tile(const FastArgs &a, const Lane32 
   for (int j = 0; j < 32; ++j) (j < 16 ? wr : wr_hi)[kCellPitch32 * (j & 15)] = v[j].y;
 #pragma unroll
   for (int i = 0; i < 32; ++i) t[i].y = rd[kTileStride * i];
+  mid.template stamp<4>();
   mid.after_transposition();
+  mid.template stamp<5>();
   SMX_FENCE();
   // B: radix-32 over l
   fft32(t);
   SMX_FENCE();
+  mid.template stamp<6>();
   mid.after_stage_b();
+  mid.template stamp<7>();
   // P: partners through the cells.  Every lane parks registers 16..31 (cell l + 33 (q - 16)) and reads, for slot s,
   // register 31 - s of lane 32 - l (lanes 0 and 16: their own; lane 0: register 32 - s, and itself for s = 0).
   float px[16], py[16];
@@ -226,6 +234,7 @@ __device__ __forceinline__ void frame32_to_tile(const FastArgs &a, const Lane32 
 #pragma unroll
   for (int s = 0; s < 16; ++s) tw[s] = L.twP_l[32 * s];
   if (L.l == 0) { px[0] = t[0].x; py[0] = t[0].y; }   // bin 0 pairs with itself: X[0] and the Nyquist bin
+  mid.template stamp<8>();
   SMX_FENCE();
   auto power_of = [&](float re, float im) {
     float pw = __builtin_fmaf(re, re, im * im);
@@ -248,6 +257,7 @@ __device__ __forceinline__ void frame32_to_tile(const FastArgs &a, const Lane32 
     rk[kRowPitch32 * s] = power_of(e.x + tr, e.y + ti);
     rm[kRowPitch32 * (15 - s)] = power_of(e.x - tr, e.y - ti);
   }
+  mid.template stamp<9>();
 }
 
 // raw samples of the lane's frame: z[n] = (x[2n], x[2n+1]), n = l + 32 j; `src` is the frame's first sample (per lane:
@@ -312,6 +322,35 @@ __device__ __forceinline__ void flush32_part(const FastArgs &a, const float *til
 #define SMX_P32_PREFETCH_AT 1   // 1: the next frames' loads are issued after the transposition, 2: after the post-pass
 #endif
 
+// what the power kernel does between the stages of a frame pair (see frame32_to_tile)
+template <bool ALIGNED, class Flush>
+struct PowerMid32 {
+  const Lds32 &lds;
+  const Flush &flush;
+  float2 (&raw)[32];
+  const float *src;
+  int l, b, it;
+#ifdef SMX_STAMPS
+  unsigned long long *stamp_sum, *stamp_prev_p;
+  template <int I> __device__ __forceinline__ void stamp() const {
+    unsigned long long &stamp_prev = *stamp_prev_p;
+    SMX_STAMP(I);
+  }
+#else
+  template <int I> __device__ __forceinline__ void stamp() const {}
+#endif
+  __device__ __forceinline__ void before_cells() const {
+    // buffer b last held tile it - 2, the (it >> 1)-th tile written there
+    lds_wait(lds.drained + b * kTileStride, 8u * ((unsigned)it >> 1));
+  }
+  __device__ __forceinline__ void after_transposition() const {
+    if constexpr (SMX_P32_PREFETCH_AT == 1) load_frame32<ALIGNED>(src, l, raw);
+  }
+  __device__ __forceinline__ void after_stage_b() const {
+    if (it > 0) flush(b ^ 1, ((unsigned)(it - 1) >> 1) + 1);   // tile it - 1
+  }
+};
+
 template <bool ALIGNED, bool SQUARE, bool STRIP>
 __global__ void __launch_bounds__(512) stft2048_power32_kernel(FastArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -359,9 +398,15 @@ __global__ void __launch_bounds__(512) stft2048_power32_kernel(FastArgs a) {
     fl.row0 = 128 * wave + (jj & 3) + 16 * (jj >> 2) + 4 * hsel;
     fl.goff0 = ((unsigned)fl.row0 * (unsigned)a.out_stride + 4u * fl.g) * 4u;
   }
+#ifdef SMX_STAMPS
+  unsigned long long stamp_sum[kStampSlots] = {0}, stamp_prev;
+  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(stamp_prev)::"memory");
+  const unsigned long long clk_t0 = stamp_prev, clk_r0 = __builtin_amdgcn_s_memrealtime();
+#endif
   // this wave's share of the tile in buffer b (the `fills`-th tile written there), once every column is in
   auto flush_tile = [&](int b, unsigned fills) {
     lds_wait(lds.filled + b * kTileStride, kWaves * fills);
+    SMX_STAMP(11);
     const float *ptile = lds.tiles + b * kTile32Floats;
 #pragma unroll
     for (int part = 0; part < 8; ++part) flush32_part(a, ptile, part, fl, pend_out, pend_left, wave, lane);
@@ -377,24 +422,12 @@ __global__ void __launch_bounds__(512) stft2048_power32_kernel(FastArgs a) {
     const bool more = it + 1 < ntiles;
     const float *src = frame_ptr(more ? xnext : tw.xclip, more ? ftnext : tw.ft);
     const bool have = (int64_t)tw.ft * kFT + 2 * wave < a.count;   // wave-uniform: at least the first half has a frame
-    struct Mid {
-      const Lds32 &lds;
-      const decltype(flush_tile) &flush;
-      float2 (&raw)[32];
-      const float *src;
-      int l, b, it;
-      __device__ __forceinline__ void before_cells() const {
-        // buffer b last held tile it - 2, the (it >> 1)-th tile written there
-        lds_wait(lds.drained + b * kTileStride, kWaves * ((unsigned)it >> 1));
-      }
-      __device__ __forceinline__ void after_transposition() const {
-        if constexpr (SMX_P32_PREFETCH_AT == 1) load_frame32<ALIGNED>(src, l, raw);
-      }
-      __device__ __forceinline__ void after_stage_b() const {
-        if (it > 0) flush(b ^ 1, ((unsigned)(it - 1) >> 1) + 1);   // tile it - 1
-      }
-    };
-    const Mid mid{lds, flush_tile, raw, src, L.l, b, it};
+#ifdef SMX_STAMPS
+    const PowerMid32<ALIGNED, decltype(flush_tile)> mid{lds, flush_tile, raw, src, L.l, b, it, stamp_sum, &stamp_prev};
+#else
+    const PowerMid32<ALIGNED, decltype(flush_tile)> mid{lds, flush_tile, raw, src, L.l, b, it};
+#endif
+    mid.template stamp<0>();
     if (have) {
       frame32_to_tile<SQUARE>(a, L, raw, lds.tiles + b * kTile32Floats, mid);
     } else {
@@ -403,6 +436,7 @@ __global__ void __launch_bounds__(512) stft2048_power32_kernel(FastArgs a) {
       mid.after_stage_b();
     }
     lds_signal(lds.filled + b * kTileStride, lane);
+    mid.template stamp<10>();
     if constexpr (SMX_P32_PREFETCH_AT != 1) load_frame32<ALIGNED>(src, L.l, raw);
     pend_out = tw.oclip + tw.ft * kFT;   // wave-uniform
     const int64_t left = a.count - (int64_t)tw.ft * kFT;
@@ -412,6 +446,12 @@ __global__ void __launch_bounds__(512) stft2048_power32_kernel(FastArgs a) {
     tw.ft = ftnext;
   }
   if (ntiles > 0) flush_tile((ntiles - 1) & 1, ((unsigned)(ntiles - 1) >> 1) + 1);   // the last tile of this workgroup
+#ifdef SMX_STAMPS
+  stamp_sum[20] = __builtin_amdgcn_s_memtime() - clk_t0;
+  stamp_sum[21] = __builtin_amdgcn_s_memrealtime() - clk_r0;
+  if (lane == 0 && blockIdx.x < 4096)
+    for (int i = 0; i < kStampSlots; ++i) g_stamp_sums[(blockIdx.x * 16 + wave) * kStampSlots + i] = stamp_sum[i];
+#endif
 
   // Border frames (the few per clip whose window reaches past either end of the signal): same frame code on samples
   // fetched through the padding rule, 16 (clip, frame) pairs per tile, results scattered to their places.
@@ -451,6 +491,316 @@ __global__ void __launch_bounds__(512) stft2048_power32_kernel(FastArgs a) {
           int64_t clip, p;
           locate(bf, clip, p);
           a.out[(clip * kBins + k) * a.out_stride + a.border_out_offset + (p - a.border_p0)] = bt_tile[k * kTileStride + f];
+        }
+      }
+    }
+  }
+}
+
+// ---- the same pipeline at four waves per SIMD: stft2048_power32g_kernel ---------------------------------------------
+// At two waves per SIMD a wave's own instruction stream bounds the tile (one instruction of any kind per ~4.2 cycles and
+// wave, every LDS round trip exposed: profiles/r05/stamps32*.log -- 15.5 k cycles per tile, the vector pipe 43 % busy).
+// Here the frame pair lives in at most 128 registers (the transposition and both radix-32 passes work in place, tables are
+// streamed a few rows at a time, samples are loaded when needed instead of a frame ahead), so a workgroup holds 16 waves:
+// two GROUPS of 8, each with ONE tile buffer and its own tile sequence.  A group computes its 16 frames, meets
+// (counter `filled`), stores the tile, meets again (`drained`) before the columns are reused; while one group stores or
+// waits the other one computes, and every SIMD always has four waves to pick from.
+// LDS pointers with their address space in the type, and a way to pin a table read behind a value: hipcc otherwise
+// hoists every table read of the frame to its top (and spills them: the frame pair must fit 128 registers here)
+typedef __attribute__((address_space(3))) const float2 lds_cf2;
+typedef __attribute__((address_space(3))) const float lds_cf;
+typedef __attribute__((address_space(3))) float lds_f;
+__device__ __forceinline__ lds_cf2 *pin_after(lds_cf2 *p, float dep) {
+  asm volatile("" : "+v"(p) : "v"(dep));
+  return p;
+}
+// All 32 complex registers pass through three empty asm statements: nothing computed from them can be scheduled above,
+// nothing that feeds them below -- the phases of the frame stay apart (hipcc otherwise overlaps them until the frame
+// pair no longer fits its 128 registers).
+#define SMX_RB10(V, B) "+v"((V)[B].x), "+v"((V)[B].y), "+v"((V)[B + 1].x), "+v"((V)[B + 1].y), "+v"((V)[B + 2].x), "+v"((V)[B + 2].y), \
+    "+v"((V)[B + 3].x), "+v"((V)[B + 3].y), "+v"((V)[B + 4].x), "+v"((V)[B + 4].y), "+v"((V)[B + 5].x), "+v"((V)[B + 5].y),             \
+    "+v"((V)[B + 6].x), "+v"((V)[B + 6].y), "+v"((V)[B + 7].x), "+v"((V)[B + 7].y), "+v"((V)[B + 8].x), "+v"((V)[B + 8].y),             \
+    "+v"((V)[B + 9].x), "+v"((V)[B + 9].y)
+__device__ __forceinline__ void reg_barrier32(c32 (&v)[32]) {
+  asm volatile("" : SMX_RB10(v, 0));
+  asm volatile("" : SMX_RB10(v, 10));
+  asm volatile("" : SMX_RB10(v, 20), "+v"(v[30].x), "+v"(v[30].y), "+v"(v[31].x), "+v"(v[31].y));
+}
+// a table pointer that becomes usable only once eight complex values exist
+__device__ __forceinline__ lds_cf2 *pin_after8(lds_cf2 *p, const c32 *w) {
+  asm volatile("" : "+v"(p) : "v"(w[0].x), "v"(w[0].y), "v"(w[1].x), "v"(w[1].y), "v"(w[2].x), "v"(w[2].y), "v"(w[3].x), "v"(w[3].y),
+               "v"(w[4].x), "v"(w[4].y), "v"(w[5].x), "v"(w[5].y), "v"(w[6].x), "v"(w[6].y), "v"(w[7].x), "v"(w[7].y));
+  return p;
+}
+struct NoStamp32 {
+  template <int I> __device__ __forceinline__ void stamp() const {}
+};
+#ifdef SMX_STAMPS
+struct Stamp32 {
+  unsigned long long *stamp_sum, *stamp_prev_p;
+  template <int I> __device__ __forceinline__ void stamp() const {
+    unsigned long long &stamp_prev = *stamp_prev_p;
+    SMX_STAMP(I);
+  }
+};
+#endif
+template <bool SQUARE, class St>
+__device__ __forceinline__ void frame32g_to_tile(const FastArgs &a, const Lane32 &L, c32 (&v)[32], float *tile,
+                                                 unsigned *drained, unsigned drained_target, const St &st) {
+#pragma clang fp contract(off)
+  // window, eight points at a time
+  {
+    lds_cf2 *wp = (lds_cf2 *)L.win_l;
+#pragma unroll
+    for (int j0 = 0; j0 < 32; j0 += 8) {
+      float2 win[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { win[j].x = wp[32 * (j0 + j)].x; win[j].y = wp[32 * (j0 + j)].y; }
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j0 + j] = {v[j0 + j].x * win[j].x, v[j0 + j].y * win[j].y};
+      wp = pin_after8(wp, &v[j0]);
+    }
+  }
+  reg_barrier32(v);
+  st.template stamp<1>();
+  // A: radix-32 over j, then twiddle W_M^(l k1)
+  fft32(v);
+  reg_barrier32(v);
+  {
+    lds_cf2 *tp = pin_after((lds_cf2 *)L.twA_l, v[31].y);
+#pragma unroll
+    for (int k0 = 0; k0 < 32; k0 += 8) {
+      float2 tw[8];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const int kk = k0 + k == 0 ? 1 : k0 + k;
+        tw[k].x = tp[32 * kk].x;
+        tw[k].y = tp[32 * kk].y;
+      }
+#pragma unroll
+      for (int k = 0; k < 8; ++k)
+        if (k0 + k > 0) v[k0 + k] = p32_cmul(v[k0 + k], tw[k].x, tw[k].y);
+      tp = pin_after8(tp, &v[k0]);
+    }
+  }
+  reg_barrier32(v);
+  st.template stamp<2>();
+  // X: lane l register k1 -> lane k1 register l through the frame's column, in place, real parts then imaginary parts
+  lds_wait(drained, drained_target);   // the group has stored the tile that was in this buffer
+  st.template stamp<3>();
+  lds_f *const wr = (lds_f *)(tile + L.own);
+  lds_f *const wr_hi = wr + 16 * kCellPitch32;
+  lds_cf *const rd = (lds_cf *)(tile + L.rd);
+#pragma unroll
+  for (int j = 0; j < 32; ++j) (j < 16 ? wr : wr_hi)[kCellPitch32 * (j & 15)] = v[j].x;
+#pragma unroll
+  for (int i = 0; i < 32; ++i) v[i].x = rd[kTileStride * i];
+#pragma unroll
+  for (int j = 0; j < 32; ++j) (j < 16 ? wr : wr_hi)[kCellPitch32 * (j & 15)] = v[j].y;
+#pragma unroll
+  for (int i = 0; i < 32; ++i) v[i].y = rd[kTileStride * i];
+  SMX_FENCE();
+  // B: radix-32 over l
+  fft32(v);
+  SMX_FENCE();
+  // P: registers 16..31 go to the partner lane through the cells and are dead afterwards (bin M/2 first)
+  auto power_of = [&](float re, float im) {
+    float pw = __builtin_fmaf(re, re, im * im);
+    if constexpr (!SQUARE) pw = a.pmode == 1 ? sqrtf(pw) : __powf(pw, a.half_power);
+    return pw;
+  };
+  const float self_pw = power_of(v[16].x + v[16].x, v[16].y + v[16].y);   // bin M/2 (lane 0): X = 2 conj(Z)
+  lds_cf *const xr = (lds_cf *)(tile + L.xr);
+  float px[16], py[16];
+#pragma unroll
+  for (int q = 16; q < 32; ++q) wr[kCellPitch32 * (q - 16)] = v[q].x;
+#pragma unroll
+  for (int s = 0; s < 16; ++s) px[s] = xr[kCellPitch32 * (15 - s)];
+#pragma unroll
+  for (int q = 16; q < 32; ++q) wr[kCellPitch32 * (q - 16)] = v[q].y;
+#pragma unroll
+  for (int s = 0; s < 16; ++s) py[s] = xr[kCellPitch32 * (15 - s)];
+  if (L.l == 0) { px[0] = v[0].x; py[0] = v[0].y; }   // bin 0 pairs with itself: X[0] and the Nyquist bin
+  st.template stamp<6>();
+  SMX_FENCE();
+  *(lds_f *)(tile + L.self) = self_pw;
+  lds_f *const rk = wr;                         // row l + 32 s
+  lds_f *const rm = (lds_f *)(tile + L.rm);     // row (32 - l) + 32 (31 - s) = rm base + 32 (15 - s)
+  lds_cf2 *pp = pin_after((lds_cf2 *)L.twP_l, py[15]);
+#pragma unroll
+  for (int s0 = 0; s0 < 16; s0 += 4) {
+    float2 tw[4];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) { tw[s].x = pp[32 * (s0 + s)].x; tw[s].y = pp[32 * (s0 + s)].y; }
+    float last = 0.f;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int s = s0 + u;
+      const c32 e = {v[s].x + px[s], v[s].y - py[s]};
+      const c32 d = {v[s].x - px[s], v[s].y + py[s]};
+      const float tr = __builtin_fmaf(tw[u].x, d.y, tw[u].y * d.x);
+      const float ti = __builtin_fmaf(tw[u].y, d.y, -(tw[u].x * d.x));
+      rk[kRowPitch32 * s] = power_of(e.x + tr, e.y + ti);
+      rm[kRowPitch32 * (15 - s)] = last = power_of(e.x - tr, e.y - ti);
+    }
+    pp = pin_after(pp, last);
+  }
+  st.template stamp<7>();
+}
+
+template <bool ALIGNED>
+__device__ __forceinline__ void load_frame32c(const float *src, int l, c32 (&v)[32]) {
+  float2 raw[32];
+  load_frame32<ALIGNED>(src, l, raw);
+#pragma unroll
+  for (int j = 0; j < 32; ++j) v[j] = {raw[j].x, raw[j].y};
+}
+
+template <bool ALIGNED, bool SQUARE, bool STRIP>
+__global__ void __launch_bounds__(1024) stft2048_power32g_kernel(FastArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave16 = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int g = wave16 >> 3, wave = wave16 & 7;   // group, wave inside the group
+  const Lds32 lds = carve_lds32(smem);
+  const Lane32 L = setup_lane32(lds, lane, wave);
+  lds.win[tid] = reinterpret_cast<const float2 *>(a.hwin)[tid];
+  if (tid < 31 * 32) lds.twA[tid] = a.w_m[(tid & 31) * ((tid >> 5) + 1)];
+  if (tid < 512) lds.twP[tid] = a.w_n[tid];
+  if (tid < 2) { lds.filled[tid * kTileStride] = 0u; lds.drained[tid * kTileStride] = 0u; }
+  float *const tile = lds.tiles + g * kTile32Floats;
+  unsigned *const c_filled = lds.filled + g * kTileStride, *const c_drained = lds.drained + g * kTileStride;
+  // this group's tiles: the groups are 2 x blocks virtual workgroups, those of one XCD side by side (TileWalk::init)
+  TileWalk tw;
+  {
+    int64_t tau0;
+    int step;
+    const int64_t nb = a.blocks, xcd = blockIdx.x % 8, idx = 2 * (blockIdx.x / 8) + g;
+    const int64_t q = nb / 8, r = nb % 8;
+    if (a.interleave == 2 || a.interleave == 0) {
+      tau0 = 2 * (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+      step = (int)(2 * nb);
+      tw.ntiles = tau0 < a.total_tiles ? (int)((a.total_tiles - tau0 + 2 * nb - 1) / (2 * nb)) : 0;
+    } else {
+      const int64_t nx = 2 * ((nb - xcd + 7) / 8);
+      const int64_t nxcd = nb < 8 ? nb : 8;
+      const int64_t x0 = a.total_tiles * xcd / nxcd, x1 = a.total_tiles * (xcd + 1) / nxcd;
+      tau0 = x0 + idx;
+      step = (int)nx;
+      tw.ntiles = tau0 < x1 ? (int)((x1 - tau0 + nx - 1) / nx) : 0;
+    }
+    if (tw.ntiles < 0) tw.ntiles = 0;
+    tw.ft = (int)(tau0 % a.tiles_per_clip);
+    tw.x_step = a.x_stride;
+    tw.o_step = kBins * a.out_stride;
+    tw.xclip = a.x + (tau0 / a.tiles_per_clip) * tw.x_step;
+    tw.oclip = a.out + a.out_offset + (tau0 / a.tiles_per_clip) * tw.o_step;
+    tw.step_clips = step / a.tiles_per_clip;
+    tw.step_tiles = step % a.tiles_per_clip;
+  }
+  const int ntiles = tw.ntiles;
+  Flush32 fl;
+  {
+    const int hsel = lane >> 5, jj = (lane & 31) >> 2;
+    fl.g = lane & 3;
+    fl.row0 = 128 * wave + (jj & 3) + 16 * (jj >> 2) + 4 * hsel;
+    fl.goff0 = ((unsigned)fl.row0 * (unsigned)a.out_stride + 4u * fl.g) * 4u;
+  }
+  __syncthreads();   // tables and zeroed counters visible: the only workgroup barrier of the main loop
+#ifdef SMX_STAMPS
+  unsigned long long stamp_sum[kStampSlots] = {0}, stamp_prev;
+  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(stamp_prev)::"memory");
+  const unsigned long long clk_t0 = stamp_prev, clk_r0 = __builtin_amdgcn_s_memrealtime();
+  const Stamp32 st{stamp_sum, &stamp_prev};
+#else
+  const NoStamp32 st{};
+#endif
+
+  for (int it = 0; it < ntiles; ++it) {
+    const int64_t f0 = (int64_t)tw.ft * kFT;
+    const bool have = f0 + 2 * wave < a.count;   // wave-uniform: at least the first half has a frame
+    if (have) {
+      const int64_t f = f0 + 2 * wave + L.h;
+      const int64_t p = a.p0 + (f < a.count ? f : f0 + 2 * wave);
+      const float *src = tw.xclip + (p * a.hop - a.left);
+      if (a.fold_frames && (p < a.border_i0 || p >= a.border_i1)) {
+        const int64_t clip = (tw.xclip - a.x) / a.x_stride;
+        src = p < a.border_i0 ? a.strip_l + clip * a.strip_l_stride + (p - a.p0) * a.hop
+                              : a.strip_r + clip * a.strip_r_stride + (p - a.border_i1) * a.hop;
+      }
+      c32 v[32];
+      load_frame32c<ALIGNED>(src, L.l, v);
+      st.template stamp<0>();
+      frame32g_to_tile<SQUARE>(a, L, v, tile, c_drained, 8u * (unsigned)it, st);
+    }
+    lds_signal(c_filled, lane);
+    lds_wait(c_filled, 8u * (unsigned)(it + 1));   // every column of the tile is in
+    st.template stamp<8>();
+    {
+      float *obase = tw.oclip + f0;
+      const int64_t left = a.count - f0;
+      const int frames_left = left < kFT ? (int)left : kFT;
+#pragma unroll
+      for (int part = 0; part < 8; ++part) flush32_part(a, tile, part, fl, obase, frames_left, wave, lane);
+    }
+    st.template stamp<9>();
+    lds_signal(c_drained, lane);
+    int ftnext;
+    const float *xnext;
+    float *onext;
+    tw.peek(a, ftnext, xnext, onext);
+    tw.xclip = xnext;
+    tw.oclip = onext;
+    tw.ft = ftnext;
+    st.template stamp<10>();
+  }
+#ifdef SMX_STAMPS
+  stamp_sum[20] = __builtin_amdgcn_s_memtime() - clk_t0;
+  stamp_sum[21] = __builtin_amdgcn_s_memrealtime() - clk_r0;
+  if (lane == 0 && blockIdx.x < 4096)
+    for (int i = 0; i < kStampSlots; ++i) g_stamp_sums[(blockIdx.x * 16 + wave16) * kStampSlots + i] = stamp_sum[i];
+#endif
+
+  // Border frames: same frame code on samples fetched through the padding rule, 32 (clip, frame) pairs per step
+  // (16 per group), results scattered to their places.
+  if (a.border_left + a.border_right > 0) {
+    const int per = a.border_left + a.border_right;
+    const int64_t lead = a.total_tiles / a.tiles_per_clip;
+    const int64_t total = lead * per;
+    auto locate = [&](int64_t beta, int64_t &clip, int64_t &p) {
+      clip = beta / per;
+      const int r = (int)(beta % per);
+      p = r < a.border_left ? a.border_p0 + r : a.border_i1 + (r - a.border_left);
+    };
+    for (int64_t bt = blockIdx.x; bt * 32 < total; bt += gridDim.x) {
+      __syncthreads();   // both buffers are free
+      const int64_t base = bt * 32 + 16 * g;
+      if (base + 2 * wave < total) {   // wave-uniform
+        int64_t beta = base + 2 * wave + L.h;
+        if (beta >= total) beta = base + 2 * wave;   // a half without a pair repeats the first one (never stored)
+        int64_t clip, p;
+        locate(beta, clip, p);
+        const float *xs = a.x + clip * a.x_stride;
+        const int s0 = (int)(p * a.hop - a.left);
+        c32 v[32];
+#pragma unroll
+        for (int j = 0; j < 32; ++j) {
+          const int s = s0 + 2 * (L.l + 32 * j);
+          v[j] = {fetch_padded(xs, (int)a.n, s, a.pad, a.pad_value), fetch_padded(xs, (int)a.n, s + 1, a.pad, a.pad_value)};
+        }
+        frame32g_to_tile<SQUARE>(a, L, v, tile, c_drained, 0u, NoStamp32{});
+      }
+      __syncthreads();
+      for (int e = tid; e < 2 * kBins * kFT; e += 1024) {
+        const int gg = e / (kBins * kFT), ee = e % (kBins * kFT);
+        const int k = ee / kFT, f = ee % kFT;
+        const int64_t bf = bt * 32 + 16 * gg + f;
+        if (bf < total) {
+          int64_t clip, p;
+          locate(bf, clip, p);
+          a.out[(clip * kBins + k) * a.out_stride + a.border_out_offset + (p - a.border_p0)] =
+              lds.tiles[gg * kTile32Floats + k * kTileStride + f];
         }
       }
     }
