@@ -1703,23 +1703,14 @@ void launch_interior(const StftJob &job, const FastTarget &tg, const float *x, i
   const char *v1_env = std::getenv("SMX_POWER_V1");
   const bool v1 = v1_env && v1_env[0] == '1';
   if (!v1 && !ring) {
-    const char *g_env = std::getenv("SMX_POWER_G");   // 0: the eight-wave form (two waves per SIMD)
-    const bool grouped = !(g_env && g_env[0] == '0');
     auto pick32 = [&](auto strip_tag) {
       constexpr bool S = decltype(strip_tag)::value;
-      if (grouped)
-        return aligned ? (square ? stft2048_power32g_kernel<true, true, S> : stft2048_power32g_kernel<true, false, S>)
-                       : (square ? stft2048_power32g_kernel<false, true, S> : stft2048_power32g_kernel<false, false, S>);
       return aligned ? (square ? stft2048_power32_kernel<true, true, S> : stft2048_power32_kernel<true, false, S>)
                      : (square ? stft2048_power32_kernel<false, true, S> : stft2048_power32_kernel<false, false, S>);
     };
     auto k32 = strip ? pick32(std::true_type{}) : pick32(std::false_type{});
-    if (grouped) {   // two groups per workgroup: a launch needs half as many workgroups for the same tiles
-      const int64_t pairs = (a.total_tiles + 1) / 2;
-      a.blocks = pairs < cu_count ? pairs : cu_count;
-    }
     SMX_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k32), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kFast32Lds));
-    SMX_LAUNCH(k32, dim3((unsigned)a.blocks), dim3(grouped ? 1024 : 512), kFast32Lds, job.stream, a);
+    SMX_LAUNCH(k32, dim3((unsigned)a.blocks), dim3(512), kFast32Lds, job.stream, a);
     SMX_HIP_CHECK(hipGetLastError());
     return;
   }

@@ -36,15 +36,21 @@ constexpr int kRowPitch32 = 32 * kTileStride;      // floats between rows r and 
 
 struct Lds32 {
   float *tiles;
-  float2 *win, *twA, *twP;
+  // tables, read two complex values (16 bytes) per lane and instruction:
+  //   win4[m][l] = window pairs of points l + 32 (2m), l + 32 (2m + 1)                     m < 16
+  //   twA4[m][l] = W_M^(l k1) for k1 = 2m + 1, 2m + 2 (m < 15), then one row of k1 = 31    (15 x 32 float4 + 32 float2)
+  //   twP4[m][l] = exp(-2 pi i k / N) for k = l + 32 (2m), l + 32 (2m + 1)                 m < 8
+  float4 *win4, *twA4, *twP4;
+  float2 *twA31;
   unsigned *filled, *drained;   // [2] each, kTileStride floats apart (pad cells of rows 1040..1043 of buffer 0)
 };
 __device__ __forceinline__ Lds32 carve_lds32(unsigned char *smem) {
   Lds32 l;
   l.tiles = reinterpret_cast<float *>(smem);
-  l.win = reinterpret_cast<float2 *>(smem + 2 * kTile32Bytes);
-  l.twA = reinterpret_cast<float2 *>(smem + 2 * kTile32Bytes + kWinBytes);
-  l.twP = reinterpret_cast<float2 *>(smem + 2 * kTile32Bytes + kWinBytes + kTwA32Bytes);
+  l.win4 = reinterpret_cast<float4 *>(smem + 2 * kTile32Bytes);
+  l.twA4 = reinterpret_cast<float4 *>(smem + 2 * kTile32Bytes + kWinBytes);
+  l.twA31 = reinterpret_cast<float2 *>(smem + 2 * kTile32Bytes + kWinBytes + 15 * 32 * sizeof(float4));
+  l.twP4 = reinterpret_cast<float4 *>(smem + 2 * kTile32Bytes + kWinBytes + kTwA32Bytes);
   l.filled = reinterpret_cast<unsigned *>(l.tiles + 1040 * kTileStride + kFT);
   l.drained = reinterpret_cast<unsigned *>(l.tiles + 1042 * kTileStride + kFT);
   return l;
@@ -58,7 +64,8 @@ struct Lane32 {
   int xr;         // exchange reads: cell p + 33 (15 - s) of slot s, p = 32 - l (l = 0: 33, i.e. its own register 32 - s)
   int rm;         // results of bins M - k: row (32 - l) + 32 (31 - s)  (l = 0: 32 (32 - s); s = 0 is row 1024 = Nyquist)
   int self;       // lane 0: row 512 (bin M/2); other lanes: a cell they overwrite afterwards
-  const float2 *win_l, *twA_l, *twP_l;
+  const float4 *win_l, *twA_l, *twP_l;
+  const float2 *twA31_l;
 };
 __device__ __forceinline__ Lane32 setup_lane32(const Lds32 &lds, int lane, int wave) {
   Lane32 L;
@@ -70,10 +77,60 @@ __device__ __forceinline__ Lane32 setup_lane32(const Lds32 &lds, int lane, int w
   L.xr = (L.l == 0 ? 33 : 32 - L.l) * kTileStride + col;
   L.rm = ((L.l == 0 ? 32 : 32 - L.l) + 32 * 16) * kTileStride + col;
   L.self = (L.l == 0 ? 512 : L.l) * kTileStride + col;
-  L.win_l = lds.win + L.l;
-  L.twA_l = lds.twA + L.l - 32;   // row k1 - 1
-  L.twP_l = lds.twP + L.l;
+  L.win_l = lds.win4 + L.l;
+  L.twA_l = lds.twA4 + L.l;
+  L.twA31_l = lds.twA31 + L.l;
+  L.twP_l = lds.twP4 + L.l;
   return L;
+}
+
+// A lane's loop-invariant value that must be re-derived where it is used: hipcc otherwise hoists every address built from it
+// (one per tile buffer and store part) out of the tile loop, runs out of registers and parks them in scratch memory --
+// and every reload waits for ALL of the wave's outstanding memory operations.
+__device__ __forceinline__ int opaque32(int v) {
+  asm volatile("" : "+v"(v));
+  return v;
+}
+__device__ __forceinline__ unsigned opaque32(unsigned v) {
+  asm volatile("" : "+v"(v));
+  return v;
+}
+
+// Counter traffic of this kernel.  The LDS executes one wave's operations in order, so a signal needs no wait for the
+// wave's earlier LDS accesses (a release would drain them: a ~1000-cycle round trip while eight waves keep the queue
+// full), and a counter can be READ long before it is needed: peek32() issues the read, the value is looked at a stage
+// later, and only a wave that finds it short falls back to polling.
+__device__ __forceinline__ void lds_signal32(unsigned *c, int lane) {
+  if (lane == 0) __hip_atomic_fetch_add(c, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+__device__ __forceinline__ unsigned peek32(unsigned *c) {
+  return __hip_atomic_load(c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+__device__ __forceinline__ void lds_wait32(unsigned *c, unsigned target, unsigned peeked) {
+  if ((unsigned)__builtin_amdgcn_readfirstlane((int)peeked) >= target) return;
+  lds_wait(c, target);
+}
+
+// fills the workgroup's tables (any number of threads); the caller synchronises before they are read
+__device__ __forceinline__ void fill_tables32(const FastArgs &a, const Lds32 &lds, int tid, int nthreads) {
+  const float2 *hw = reinterpret_cast<const float2 *>(a.hwin);
+  for (int e = tid; e < 16 * 32; e += nthreads) {
+    const int m = e >> 5, l = e & 31;
+    const float2 w0 = hw[l + 32 * (2 * m)], w1 = hw[l + 32 * (2 * m + 1)];
+    lds.win4[e] = make_float4(w0.x, w0.y, w1.x, w1.y);
+  }
+  for (int e = tid; e < 15 * 32; e += nthreads) {
+    const int m = e >> 5, l = e & 31;
+    const float2 w0 = a.w_m[l * (2 * m + 1)], w1 = a.w_m[l * (2 * m + 2)];
+    lds.twA4[e] = make_float4(w0.x, w0.y, w1.x, w1.y);
+  }
+  for (int e = tid; e < 32; e += nthreads) lds.twA31[e] = a.w_m[e * 31];
+  for (int e = tid; e < 8 * 32; e += nthreads) {
+    const int m = e >> 5, l = e & 31;
+    const float2 w0 = a.w_n[l + 32 * (2 * m)], w1 = a.w_n[l + 32 * (2 * m + 1)];
+    lds.twP4[e] = make_float4(w0.x, w0.y, w1.x, w1.y);
+  }
+  if (tid < 2) { lds.filled[tid * kTileStride] = 0u; lds.drained[tid * kTileStride] = 0u; }
 }
 
 // The arithmetic of this pipeline is written out operation by operation (explicit fused multiply-adds, contraction off
@@ -157,84 +214,144 @@ __device__ __forceinline__ void fft32(c32 (&v)[32]) {
 }
 
 struct NoMid32 {
+  __device__ __forceinline__ void early() const {}
   __device__ __forceinline__ void before_cells() const {}
-  __device__ __forceinline__ void after_transposition() const {}
-  __device__ __forceinline__ void after_stage_b() const {}
+  __device__ __forceinline__ void after_transposition_issue() const {}
+  __device__ __forceinline__ void after_exchange_issue() const {}
+  __device__ __forceinline__ void mid_postpass() const {}
   template <int I> __device__ __forceinline__ void stamp() const {}
 };
 
 // Two frames (one per lane-half): raw samples (registers) -> window -> FFT(1024 complex) -> post-pass -> |X|^p in the
-// frames' columns of `tile`.  mid.before_cells() is called before the first access to the columns (the power kernel
-// waits there until the buffer has been read out), mid.after_transposition() once the raw-sample registers and the
-// first half of the pipeline are dead (the next frames' loads go there), mid.after_stage_b() between the second
-// radix-32 and the post-pass (the previous tile's stores).
+// frames' columns of `tile`.  The caller's `mid` is given the three places where the wave would otherwise only wait for
+// the LDS (a round trip takes ~1000 cycles while eight waves keep its queue full):
+//   before_cells()               before the first access to the columns (the power kernel waits until the buffer is free);
+//   after_transposition_issue()  the transposition's reads are in flight;
+//   after_exchange_issue()       the partner reads are in flight: the previous tile's LDS reads are issued behind them;
+//   mid_postpass()               half of the post-pass is done and its registers are free: the previous tile's stores,
+//                                then the next frames' loads.
+// (The power kernel needs the previous tile complete only at the third point and its buffer free only at the first one:
+// the two waves of a SIMD run half a frame apart by themselves -- one computes while the other waits for the LDS -- and
+// every wait that asks for less slack than that turns the counters into a barrier: 0.56 -> 0.58 ms when the tile's reads
+// sat behind the transposition, profiles/r05.)
+#ifndef SMX_P32_WINPRE
+#define SMX_P32_WINPRE 0   // 1: the window rows are read at the END of a frame pair for the next one (64 registers across the loop edge)
+#endif
+#ifndef SMX_P32_TWI
+#define SMX_P32_TWI 1      // 1: the transposition's first plane is written while the twiddle products are formed (shorter LDS bursts)
+#endif
+__device__ __forceinline__ void load_window32(const Lane32 &L, float4 (&win)[16]) {
+#pragma unroll
+  for (int m = 0; m < 16; ++m) win[m] = L.win_l[32 * m];
+}
 template <bool SQUARE, class Mid>
 __device__ __forceinline__ void frame32_to_tile(const FastArgs &a, const Lane32 &L, float2 (&raw)[32], float *tile,
-                                                const Mid &mid) {
+                                                const Mid &mid, float4 (&winpre)[16]) {
 #pragma clang fp contract(off)
   c32 v[32], t[32];
-  {
-    float2 win[32];
+  if constexpr (SMX_P32_WINPRE) {
 #pragma unroll
-    for (int j = 0; j < 32; ++j) win[j] = L.win_l[32 * j];
+    for (int m = 0; m < 16; ++m) {
+      v[2 * m] = {raw[2 * m].x * winpre[m].x, raw[2 * m].y * winpre[m].y};
+      v[2 * m + 1] = {raw[2 * m + 1].x * winpre[m].z, raw[2 * m + 1].y * winpre[m].w};
+    }
+  } else
 #pragma unroll
-    for (int j = 0; j < 32; ++j) v[j] = {raw[j].x * win[j].x, raw[j].y * win[j].y};
+  for (int m0 = 0; m0 < 16; m0 += 8) {   // two batches: the window rows are not all in registers at once
+    float4 win[8];
+#pragma unroll
+    for (int m = 0; m < 8; ++m) win[m] = L.win_l[32 * (m0 + m)];
+#pragma unroll
+    for (int m = 0; m < 8; ++m) {
+      v[2 * (m0 + m)] = {raw[2 * (m0 + m)].x * win[m].x, raw[2 * (m0 + m)].y * win[m].y};
+      v[2 * (m0 + m) + 1] = {raw[2 * (m0 + m) + 1].x * win[m].z, raw[2 * (m0 + m) + 1].y * win[m].w};
+    }
+    SMX_FENCE();
   }
   mid.template stamp<1>();
   SMX_FENCE();
   // A: radix-32 over j, then twiddle W_M^(l k1)
   {
-    float2 tw[32];
+    float4 tw[15];
 #pragma unroll
-    for (int k = 1; k < 32; ++k) tw[k] = L.twA_l[32 * k];
+    for (int m = 0; m < 15; ++m) tw[m] = L.twA_l[32 * m];
+    const float2 tw31 = L.twA31_l[0];
+    mid.early();
     fft32(v);
+    if constexpr (!SMX_P32_TWI) {
 #pragma unroll
-    for (int k = 1; k < 32; ++k) v[k] = p32_cmul(v[k], tw[k].x, tw[k].y);
+      for (int m = 0; m < 15; ++m) {
+        v[2 * m + 1] = p32_cmul(v[2 * m + 1], tw[m].x, tw[m].y);
+        v[2 * m + 2] = p32_cmul(v[2 * m + 2], tw[m].z, tw[m].w);
+      }
+      v[31] = p32_cmul(v[31], tw31.x, tw31.y);
+    }
+    SMX_FENCE();
+    // X: lane l register k1 -> lane k1 register l through the frame's column, real parts then imaginary parts.
+    // One wave's LDS operations execute in order, so no wait separates the rounds.
+    mid.template stamp<2>();
+    mid.before_cells();
+    mid.template stamp<3>();
+    if constexpr (SMX_P32_TWI) {
+      float *const wr = tile + opaque32(L.own);
+      float *const wr_hi = wr + 16 * kCellPitch32;
+      wr[0] = v[0].x;
+#pragma unroll
+      for (int m = 0; m < 15; ++m) {
+        v[2 * m + 1] = p32_cmul(v[2 * m + 1], tw[m].x, tw[m].y);
+        v[2 * m + 2] = p32_cmul(v[2 * m + 2], tw[m].z, tw[m].w);
+        (2 * m + 1 < 16 ? wr : wr_hi)[kCellPitch32 * ((2 * m + 1) & 15)] = v[2 * m + 1].x;
+        (2 * m + 2 < 16 ? wr : wr_hi)[kCellPitch32 * ((2 * m + 2) & 15)] = v[2 * m + 2].x;
+        if ((m & 1) == 1) SMX_FENCE();
+      }
+      v[31] = p32_cmul(v[31], tw31.x, tw31.y);
+      wr_hi[kCellPitch32 * 15] = v[31].x;
+    }
   }
   SMX_FENCE();
-  // X: lane l register k1 -> lane k1 register l through the frame's column, real parts then imaginary parts.
-  // One wave's LDS operations execute in order, so no wait separates the rounds.
-  mid.template stamp<2>();
-  mid.before_cells();
-  mid.template stamp<3>();
-  float *const wr = tile + L.own;
+  float *const wr = tile + opaque32(L.own);
   float *const wr_hi = wr + 16 * kCellPitch32;   // (ds offsets are 16 bits: 31 x 2244 bytes does not fit)
-  const float *const rd = tile + L.rd;
+  const float *const rd = tile + opaque32(L.rd);
+  if constexpr (!SMX_P32_TWI) {
 #pragma unroll
-  for (int j = 0; j < 32; ++j) (j < 16 ? wr : wr_hi)[kCellPitch32 * (j & 15)] = v[j].x;
+    for (int j = 0; j < 32; ++j) (j < 16 ? wr : wr_hi)[kCellPitch32 * (j & 15)] = v[j].x;
+  }
 #pragma unroll
   for (int i = 0; i < 32; ++i) t[i].x = rd[kTileStride * i];
 #pragma unroll
   for (int j = 0; j < 32; ++j) (j < 16 ? wr : wr_hi)[kCellPitch32 * (j & 15)] = v[j].y;
 #pragma unroll
   for (int i = 0; i < 32; ++i) t[i].y = rd[kTileStride * i];
+  SMX_FENCE();
+  mid.after_transposition_issue();
   mid.template stamp<4>();
-  mid.after_transposition();
-  mid.template stamp<5>();
   SMX_FENCE();
   // B: radix-32 over l
   fft32(t);
   SMX_FENCE();
-  mid.template stamp<6>();
-  mid.after_stage_b();
-  mid.template stamp<7>();
+  mid.template stamp<5>();
   // P: partners through the cells.  Every lane parks registers 16..31 (cell l + 33 (q - 16)) and reads, for slot s,
   // register 31 - s of lane 32 - l (lanes 0 and 16: their own; lane 0: register 32 - s, and itself for s = 0).
   float px[16], py[16];
-  const float *const xr = tile + L.xr;
+  const float *const xr = tile + opaque32(L.xr);
+  // (register 0 goes to cell l + 33 x 16 as well: that is where lane 0 looks for the partner of bin 0 -- itself; slot 0
+  // of that lane yields X[0] and the Nyquist bin.  A select instead would be two v_cndmask_b32 on vcc, 19 cycles each.)
 #pragma unroll
   for (int q = 16; q < 32; ++q) wr[kCellPitch32 * (q - 16)] = t[q].x;
+  wr_hi[0] = t[0].x;
 #pragma unroll
   for (int s = 0; s < 16; ++s) px[s] = xr[kCellPitch32 * (15 - s)];
 #pragma unroll
   for (int q = 16; q < 32; ++q) wr[kCellPitch32 * (q - 16)] = t[q].y;
+  wr_hi[0] = t[0].y;
 #pragma unroll
   for (int s = 0; s < 16; ++s) py[s] = xr[kCellPitch32 * (15 - s)];
-  float2 tw[16];
+  float4 tw[8];
 #pragma unroll
-  for (int s = 0; s < 16; ++s) tw[s] = L.twP_l[32 * s];
-  if (L.l == 0) { px[0] = t[0].x; py[0] = t[0].y; }   // bin 0 pairs with itself: X[0] and the Nyquist bin
-  mid.template stamp<8>();
+  for (int m = 0; m < 8; ++m) tw[m] = L.twP_l[32 * m];
+  SMX_FENCE();
+  mid.after_exchange_issue();
+  mid.template stamp<6>();
   SMX_FENCE();
   auto power_of = [&](float re, float im) {
     float pw = __builtin_fmaf(re, re, im * im);
@@ -243,21 +360,24 @@ __device__ __forceinline__ void frame32_to_tile(const FastArgs &a, const Lane32 
   };
   {   // bin M/2 (lane 0, register 16): X = 2 conj(Z)
     const float zx = t[16].x + t[16].x, zy = t[16].y + t[16].y;
-    tile[L.self] = power_of(zx, zy);
+    tile[opaque32(L.self)] = power_of(zx, zy);
   }
   float *const rk = wr;                 // row l + 32 s
-  float *const rm = tile + L.rm;        // row (32 - l) + 32 (31 - s) = rm base + 32 (15 - s)
+  float *const rm = tile + opaque32(L.rm);        // row (32 - l) + 32 (31 - s) = rm base + 32 (15 - s)
 #pragma unroll
   for (int s = 0; s < 16; ++s) {
+    const float wx = (s & 1) ? tw[s >> 1].z : tw[s >> 1].x, wy = (s & 1) ? tw[s >> 1].w : tw[s >> 1].y;
     const c32 e = {t[s].x + px[s], t[s].y - py[s]};
     const c32 d = {t[s].x - px[s], t[s].y + py[s]};
     // T = -i w D
-    const float tr = __builtin_fmaf(tw[s].x, d.y, tw[s].y * d.x);
-    const float ti = __builtin_fmaf(tw[s].y, d.y, -(tw[s].x * d.x));
+    const float tr = __builtin_fmaf(wx, d.y, wy * d.x);
+    const float ti = __builtin_fmaf(wy, d.y, -(wx * d.x));
     rk[kRowPitch32 * s] = power_of(e.x + tr, e.y + ti);
     rm[kRowPitch32 * (15 - s)] = power_of(e.x - tr, e.y - ti);
+    if (s == 7) { SMX_FENCE(); mid.mid_postpass(); SMX_FENCE(); }
   }
-  mid.template stamp<9>();
+  if constexpr (SMX_P32_WINPRE) { SMX_FENCE(); load_window32(L, winpre); }   // for the next frame pair: lands while the loop turns
+  mid.template stamp<7>();
 }
 
 // raw samples of the lane's frame: z[n] = (x[2n], x[2n+1]), n = l + 32 j; `src` is the frame's first sample (per lane:
@@ -285,51 +405,73 @@ __device__ __forceinline__ void load_frame32(const float *src, int l, float2 (&r
   }
 }
 
-// One eighth of a wave's share of a finished tile: 16 rows (bins) x 4 frames per lane -> out[clip][bin][f0 + 4 g ..].
+// A wave's share of a finished tile: 8 parts of 16 rows (bins) x 4 frames per lane -> out[clip][bin][f0 + 4 g ..].
 // Rows {0-3, 16-19} + 4 h per half-wave keep the LDS reads conflict free; a 4-lane group stores one 64-byte run.
+// The tile is read into registers at one point of the frame and stored at a later one (see frame32_to_tile).
 struct Flush32 {
-  int row0;         // tile row (= bin) of part 0
-  unsigned goff0;   // byte offset of out[bin0][4 g] from the tile's origin
+  int src0;         // float offset in the tile of part 0: row0 * 17 + 4 g, row0 = 128 wave + (jj & 3) + 16 (jj >> 2) + 4 h
+  unsigned goff0;   // byte offset of out[row0][4 g] from the tile's origin
   int g;
 };
-__device__ __forceinline__ void flush32_part(const FastArgs &a, const float *tile, int it, const Flush32 &fl, float *obase,
-                                             int frames_left, int wave, int lane) {
-  const int drow = 32 * (it >> 1) + 8 * (it & 1);
-  const float *src = tile + (fl.row0 + drow) * kTileStride + 4 * fl.g;
-  const float v0 = src[0], v1 = src[1], v2 = src[2], v3 = src[3];
-  const unsigned goff = fl.goff0 + (unsigned)drow * (unsigned)a.out_stride * 4u;
-  const int fleft = frames_left - 4 * fl.g;
+struct FlushRegs {
+  float v[8][4];
+  float nyq;        // bin 1024 (wave 0, lanes 0..15)
+};
+__device__ __forceinline__ void flush32_read(const float *tile, const Flush32 &fl, int wave, int lane, FlushRegs &r) {
+  const float *src0 = tile + opaque32(fl.src0);
+#pragma unroll
+  for (int it = 0; it < 8; ++it) {
+    const float *src = src0 + (32 * (it >> 1) + 8 * (it & 1)) * kTileStride;
+    r.v[it][0] = src[0]; r.v[it][1] = src[1]; r.v[it][2] = src[2]; r.v[it][3] = src[3];
+  }
+  r.nyq = tile[kM * kTileStride + (lane & 15)];   // row 1024 = Nyquist bin (every wave reads it, wave 0 stores it)
+}
+__device__ __forceinline__ void flush32_store(const FastArgs &a, const Flush32 &fl, float *obase, int frames_left, int wave,
+                                              int lane, const FlushRegs &r) {
 #ifdef SMX_DIAG
   if (a.abl_nostore == 1) {   // timing-only ablation: keep the LDS reads alive, drop the HBM stores
-    asm volatile("" ::"v"(v0), "v"(v1), "v"(v2), "v"(v3));
+#pragma unroll
+    for (int it = 0; it < 8; ++it) asm volatile("" ::"v"(r.v[it][0]), "v"(r.v[it][1]), "v"(r.v[it][2]), "v"(r.v[it][3]));
+    asm volatile("" ::"v"(r.nyq));
     return;
   }
 #endif
-  if (fleft >= 4) {
-    store4_unaligned(obase, goff, v0, v1, v2, v3);
+  const unsigned pitch = (unsigned)a.out_stride * 4u;
+  const unsigned goff0 = opaque32(fl.goff0);
+  if (frames_left >= kFT) {   // wave-uniform: a whole tile, no masks
+#pragma unroll
+    for (int it = 0; it < 8; ++it)
+      store4_unaligned(obase, goff0 + (unsigned)(32 * (it >> 1) + 8 * (it & 1)) * pitch, r.v[it][0], r.v[it][1], r.v[it][2], r.v[it][3]);
   } else {
-    float *dst = reinterpret_cast<float *>(reinterpret_cast<char *>(obase) + goff);
-    if (fleft > 0) dst[0] = v0;
-    if (fleft > 1) dst[1] = v1;
-    if (fleft > 2) dst[2] = v2;
+    const int fleft = frames_left - 4 * fl.g;
+#pragma unroll
+    for (int it = 0; it < 8; ++it) {
+      const unsigned goff = goff0 + (unsigned)(32 * (it >> 1) + 8 * (it & 1)) * pitch;
+      if (fleft >= 4) {
+        store4_unaligned(obase, goff, r.v[it][0], r.v[it][1], r.v[it][2], r.v[it][3]);
+      } else {
+        float *dst = reinterpret_cast<float *>(reinterpret_cast<char *>(obase) + goff);
+        if (fleft > 0) dst[0] = r.v[it][0];
+        if (fleft > 1) dst[1] = r.v[it][1];
+        if (fleft > 2) dst[2] = r.v[it][2];
+      }
+    }
   }
-  if (it == 7 && wave == 0 && lane < 16) {   // bin 1024 = row 1024
-    if (lane < frames_left) obase[(int64_t)kM * a.out_stride + lane] = tile[kM * kTileStride + lane];
-  }
+  if (wave == 0 && lane < 16 && lane < frames_left) obase[(int64_t)kM * a.out_stride + lane] = r.nyq;
 }
 
-#ifndef SMX_P32_PREFETCH_AT
-#define SMX_P32_PREFETCH_AT 1   // 1: the next frames' loads are issued after the transposition, 2: after the post-pass
-#endif
-
 // what the power kernel does between the stages of a frame pair (see frame32_to_tile)
-template <bool ALIGNED, class Flush>
+template <bool ALIGNED>
 struct PowerMid32 {
+  const FastArgs &a;
   const Lds32 &lds;
-  const Flush &flush;
+  const Flush32 &fl;
+  FlushRegs &fr;
   float2 (&raw)[32];
-  const float *src;
-  int l, b, it;
+  const float *src;      // the next frames' samples (per lane)
+  float *pend_out;       // output origin and frames of the previous tile
+  int pend_left;
+  int lane, wave, b, it;
 #ifdef SMX_STAMPS
   unsigned long long *stamp_sum, *stamp_prev_p;
   template <int I> __device__ __forceinline__ void stamp() const {
@@ -339,15 +481,45 @@ struct PowerMid32 {
 #else
   template <int I> __device__ __forceinline__ void stamp() const {}
 #endif
+  unsigned &pk_drained, &pk_filled;
+  __device__ __forceinline__ void early() const {   // the counter is read a radix-32 pass before it is needed
+    pk_drained = peek32(lds.drained + b * kTileStride);
+  }
   __device__ __forceinline__ void before_cells() const {
-    // buffer b last held tile it - 2, the (it >> 1)-th tile written there
-    lds_wait(lds.drained + b * kTileStride, 8u * ((unsigned)it >> 1));
+    // buffer b last held tile it - 2, the (it >> 1)-th tile written there: every wave has read its share out
+#ifdef SMX_STAMPS
+    const unsigned long long w0 = __builtin_amdgcn_s_memtime();
+#endif
+    lds_wait32(lds.drained + b * kTileStride, 8u * ((unsigned)it >> 1), pk_drained);
+#ifdef SMX_STAMPS
+    stamp_sum[12] += __builtin_amdgcn_s_memtime() - w0;   // time in the wait itself (the stamps around it also hold sunk arithmetic)
+#endif
   }
-  __device__ __forceinline__ void after_transposition() const {
-    if constexpr (SMX_P32_PREFETCH_AT == 1) load_frame32<ALIGNED>(src, l, raw);
+  __device__ __forceinline__ void after_transposition_issue() const {
+    if (it > 0) pk_filled = peek32(lds.filled + (b ^ 1) * kTileStride);   // looked at after the second radix-32 pass
   }
-  __device__ __forceinline__ void after_stage_b() const {
-    if (it > 0) flush(b ^ 1, ((unsigned)(it - 1) >> 1) + 1);   // tile it - 1
+  __device__ __forceinline__ void after_exchange_issue() const {
+    if (it > 0) {
+      // tile it - 1 (buffer b ^ 1, the ((it - 1) >> 1) + 1-th written there) is complete: every column is in
+#ifdef SMX_STAMPS
+      const unsigned long long w0 = __builtin_amdgcn_s_memtime();
+#endif
+      lds_wait32(lds.filled + (b ^ 1) * kTileStride, 8u * (((unsigned)(it - 1) >> 1) + 1), pk_filled);
+#ifdef SMX_STAMPS
+      stamp_sum[13] += __builtin_amdgcn_s_memtime() - w0;
+#endif
+      flush32_read(lds.tiles + (b ^ 1) * kTile32Floats, fl, wave, lane, fr);
+      // "read out" may be signalled as soon as the reads are ISSUED: the counter's add executes behind them in this wave's
+      // LDS order, and nobody writes the buffer before seeing it.  Every frame fraction the signal comes earlier is slack
+      // for the wave that waits for it: the two waves of a SIMD settle half a frame apart, and with the signal behind the
+      // stores (0.8 of a frame, needed at 0.3 of the next) they spent 3500 cycles per tile polling (profiles/r05).
+      lds_signal32(lds.drained + (b ^ 1) * kTileStride, lane);
+    }
+  }
+  __device__ __forceinline__ void mid_postpass() const {
+    if (it > 0) flush32_store(a, fl, pend_out, pend_left, wave, lane, fr);
+    SMX_FENCE();
+    load_frame32<ALIGNED>(src, lane & 31, raw);   // the next frames' samples (half of the frame's registers are free by now)
   }
 };
 
@@ -359,23 +531,18 @@ __global__ void __launch_bounds__(512) stft2048_power32_kernel(FastArgs a) {
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const Lds32 lds = carve_lds32(smem);
   const Lane32 L = setup_lane32(lds, lane, wave);
-  // tables (once per workgroup)
-  lds.win[tid] = reinterpret_cast<const float2 *>(a.hwin)[tid];
-  lds.win[tid + 512] = reinterpret_cast<const float2 *>(a.hwin)[tid + 512];
-  for (int e = tid; e < 31 * 32; e += 512) lds.twA[e] = a.w_m[(e & 31) * ((e >> 5) + 1)];
-  lds.twP[tid] = a.w_n[tid];
-  if (tid < 2) { lds.filled[tid * kTileStride] = 0u; lds.drained[tid * kTileStride] = 0u; }
+  fill_tables32(a, lds, tid, 512);
   TileWalk tw;
   tw.init(a, a.out + a.out_offset, kBins * a.out_stride);
   const int ntiles = tw.ntiles > 0 ? tw.ntiles : 0;
-  constexpr unsigned kWaves = 8;
 
   // first sample of this lane's frame in tile t of the clip at xc (a lane-half without a frame re-reads the tile's
   // first frame and its results are never stored)
   auto frame_ptr = [&](const float *xc, int t) {
     const int64_t f0 = (int64_t)t * kFT;
-    const int64_t f = f0 + 2 * wave + L.h;
-    const int64_t p = a.p0 + (f < a.count ? f : f0);
+    const int avail = (int)(a.count - f0 < kFT ? a.count - f0 : kFT) - 1;   // last frame of the tile that exists (wave-uniform)
+    const int fi = 2 * wave + L.h;
+    const int64_t p = a.p0 + f0 + (fi <= avail ? fi : 0);
     if (a.fold_frames && (p < a.border_i0 || p >= a.border_i1)) {
       const int64_t clip = (xc - a.x) / a.x_stride;
       return p < a.border_i0 ? a.strip_l + clip * a.strip_l_stride + (p - a.p0) * a.hop
@@ -395,24 +562,19 @@ __global__ void __launch_bounds__(512) stft2048_power32_kernel(FastArgs a) {
   {
     const int hsel = lane >> 5, jj = (lane & 31) >> 2;
     fl.g = lane & 3;
-    fl.row0 = 128 * wave + (jj & 3) + 16 * (jj >> 2) + 4 * hsel;
-    fl.goff0 = ((unsigned)fl.row0 * (unsigned)a.out_stride + 4u * fl.g) * 4u;
+    const int row0 = 128 * wave + (jj & 3) + 16 * (jj >> 2) + 4 * hsel;
+    fl.src0 = row0 * kTileStride + 4 * fl.g;
+    fl.goff0 = ((unsigned)row0 * (unsigned)a.out_stride + 4u * fl.g) * 4u;
   }
+  FlushRegs fr;
+  float4 winpre[16];
+  if constexpr (SMX_P32_WINPRE) load_window32(L, winpre);
+  unsigned pk_drained = 0, pk_filled = 0;
 #ifdef SMX_STAMPS
   unsigned long long stamp_sum[kStampSlots] = {0}, stamp_prev;
   asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(stamp_prev)::"memory");
   const unsigned long long clk_t0 = stamp_prev, clk_r0 = __builtin_amdgcn_s_memrealtime();
 #endif
-  // this wave's share of the tile in buffer b (the `fills`-th tile written there), once every column is in
-  auto flush_tile = [&](int b, unsigned fills) {
-    lds_wait(lds.filled + b * kTileStride, kWaves * fills);
-    SMX_STAMP(11);
-    const float *ptile = lds.tiles + b * kTile32Floats;
-#pragma unroll
-    for (int part = 0; part < 8; ++part) flush32_part(a, ptile, part, fl, pend_out, pend_left, wave, lane);
-    lds_signal(lds.drained + b * kTileStride, lane);
-  };
-
   for (int it = 0; it < ntiles; ++it) {   // tile `it` of this workgroup lives in buffer it & 1
     const int b = it & 1;
     int ftnext;
@@ -423,21 +585,22 @@ __global__ void __launch_bounds__(512) stft2048_power32_kernel(FastArgs a) {
     const float *src = frame_ptr(more ? xnext : tw.xclip, more ? ftnext : tw.ft);
     const bool have = (int64_t)tw.ft * kFT + 2 * wave < a.count;   // wave-uniform: at least the first half has a frame
 #ifdef SMX_STAMPS
-    const PowerMid32<ALIGNED, decltype(flush_tile)> mid{lds, flush_tile, raw, src, L.l, b, it, stamp_sum, &stamp_prev};
+    const PowerMid32<ALIGNED> mid{a, lds, fl, fr, raw, src, pend_out, pend_left, lane, wave, b, it, stamp_sum, &stamp_prev, pk_drained, pk_filled};
 #else
-    const PowerMid32<ALIGNED, decltype(flush_tile)> mid{lds, flush_tile, raw, src, L.l, b, it};
+    const PowerMid32<ALIGNED> mid{a, lds, fl, fr, raw, src, pend_out, pend_left, lane, wave, b, it, pk_drained, pk_filled};
 #endif
     mid.template stamp<0>();
     if (have) {
-      frame32_to_tile<SQUARE>(a, L, raw, lds.tiles + b * kTile32Floats, mid);
+      frame32_to_tile<SQUARE>(a, L, raw, lds.tiles + b * kTile32Floats, mid, winpre);
     } else {
+      mid.early();
       mid.before_cells();
-      mid.after_transposition();
-      mid.after_stage_b();
+      mid.after_transposition_issue();
+      mid.after_exchange_issue();
+      mid.mid_postpass();
     }
-    lds_signal(lds.filled + b * kTileStride, lane);
-    mid.template stamp<10>();
-    if constexpr (SMX_P32_PREFETCH_AT != 1) load_frame32<ALIGNED>(src, L.l, raw);
+    lds_signal32(lds.filled + b * kTileStride, lane);
+    mid.template stamp<8>();
     pend_out = tw.oclip + tw.ft * kFT;   // wave-uniform
     const int64_t left = a.count - (int64_t)tw.ft * kFT;
     pend_left = left < kFT ? (int)left : kFT;
@@ -445,7 +608,12 @@ __global__ void __launch_bounds__(512) stft2048_power32_kernel(FastArgs a) {
     tw.oclip = onext;
     tw.ft = ftnext;
   }
-  if (ntiles > 0) flush_tile((ntiles - 1) & 1, ((unsigned)(ntiles - 1) >> 1) + 1);   // the last tile of this workgroup
+  if (ntiles > 0) {   // the last tile of this workgroup
+    const int b = (ntiles - 1) & 1;
+    lds_wait(lds.filled + b * kTileStride, 8u * (((unsigned)(ntiles - 1) >> 1) + 1));
+    flush32_read(lds.tiles + b * kTile32Floats, fl, wave, lane, fr);
+    flush32_store(a, fl, pend_out, pend_left, wave, lane, fr);
+  }
 #ifdef SMX_STAMPS
   stamp_sum[20] = __builtin_amdgcn_s_memtime() - clk_t0;
   stamp_sum[21] = __builtin_amdgcn_s_memrealtime() - clk_r0;
@@ -481,7 +649,9 @@ __global__ void __launch_bounds__(512) stft2048_power32_kernel(FastArgs a) {
           braw[j] = make_float2(fetch_padded(xs, (int)a.n, s, a.pad, a.pad_value),
                                 fetch_padded(xs, (int)a.n, s + 1, a.pad, a.pad_value));
         }
-        frame32_to_tile<SQUARE>(a, L, braw, bt_tile, NoMid32{});
+        float4 bwin[16];
+        if constexpr (SMX_P32_WINPRE) load_window32(L, bwin);
+        frame32_to_tile<SQUARE>(a, L, braw, bt_tile, NoMid32{}, bwin);
       }
       __syncthreads();
       for (int e = tid; e < kBins * kFT; e += 512) {
@@ -491,316 +661,6 @@ __global__ void __launch_bounds__(512) stft2048_power32_kernel(FastArgs a) {
           int64_t clip, p;
           locate(bf, clip, p);
           a.out[(clip * kBins + k) * a.out_stride + a.border_out_offset + (p - a.border_p0)] = bt_tile[k * kTileStride + f];
-        }
-      }
-    }
-  }
-}
-
-// ---- the same pipeline at four waves per SIMD: stft2048_power32g_kernel ---------------------------------------------
-// At two waves per SIMD a wave's own instruction stream bounds the tile (one instruction of any kind per ~4.2 cycles and
-// wave, every LDS round trip exposed: profiles/r05/stamps32*.log -- 15.5 k cycles per tile, the vector pipe 43 % busy).
-// Here the frame pair lives in at most 128 registers (the transposition and both radix-32 passes work in place, tables are
-// streamed a few rows at a time, samples are loaded when needed instead of a frame ahead), so a workgroup holds 16 waves:
-// two GROUPS of 8, each with ONE tile buffer and its own tile sequence.  A group computes its 16 frames, meets
-// (counter `filled`), stores the tile, meets again (`drained`) before the columns are reused; while one group stores or
-// waits the other one computes, and every SIMD always has four waves to pick from.
-// LDS pointers with their address space in the type, and a way to pin a table read behind a value: hipcc otherwise
-// hoists every table read of the frame to its top (and spills them: the frame pair must fit 128 registers here)
-typedef __attribute__((address_space(3))) const float2 lds_cf2;
-typedef __attribute__((address_space(3))) const float lds_cf;
-typedef __attribute__((address_space(3))) float lds_f;
-__device__ __forceinline__ lds_cf2 *pin_after(lds_cf2 *p, float dep) {
-  asm volatile("" : "+v"(p) : "v"(dep));
-  return p;
-}
-// All 32 complex registers pass through three empty asm statements: nothing computed from them can be scheduled above,
-// nothing that feeds them below -- the phases of the frame stay apart (hipcc otherwise overlaps them until the frame
-// pair no longer fits its 128 registers).
-#define SMX_RB10(V, B) "+v"((V)[B].x), "+v"((V)[B].y), "+v"((V)[B + 1].x), "+v"((V)[B + 1].y), "+v"((V)[B + 2].x), "+v"((V)[B + 2].y), \
-    "+v"((V)[B + 3].x), "+v"((V)[B + 3].y), "+v"((V)[B + 4].x), "+v"((V)[B + 4].y), "+v"((V)[B + 5].x), "+v"((V)[B + 5].y),             \
-    "+v"((V)[B + 6].x), "+v"((V)[B + 6].y), "+v"((V)[B + 7].x), "+v"((V)[B + 7].y), "+v"((V)[B + 8].x), "+v"((V)[B + 8].y),             \
-    "+v"((V)[B + 9].x), "+v"((V)[B + 9].y)
-__device__ __forceinline__ void reg_barrier32(c32 (&v)[32]) {
-  asm volatile("" : SMX_RB10(v, 0));
-  asm volatile("" : SMX_RB10(v, 10));
-  asm volatile("" : SMX_RB10(v, 20), "+v"(v[30].x), "+v"(v[30].y), "+v"(v[31].x), "+v"(v[31].y));
-}
-// a table pointer that becomes usable only once eight complex values exist
-__device__ __forceinline__ lds_cf2 *pin_after8(lds_cf2 *p, const c32 *w) {
-  asm volatile("" : "+v"(p) : "v"(w[0].x), "v"(w[0].y), "v"(w[1].x), "v"(w[1].y), "v"(w[2].x), "v"(w[2].y), "v"(w[3].x), "v"(w[3].y),
-               "v"(w[4].x), "v"(w[4].y), "v"(w[5].x), "v"(w[5].y), "v"(w[6].x), "v"(w[6].y), "v"(w[7].x), "v"(w[7].y));
-  return p;
-}
-struct NoStamp32 {
-  template <int I> __device__ __forceinline__ void stamp() const {}
-};
-#ifdef SMX_STAMPS
-struct Stamp32 {
-  unsigned long long *stamp_sum, *stamp_prev_p;
-  template <int I> __device__ __forceinline__ void stamp() const {
-    unsigned long long &stamp_prev = *stamp_prev_p;
-    SMX_STAMP(I);
-  }
-};
-#endif
-template <bool SQUARE, class St>
-__device__ __forceinline__ void frame32g_to_tile(const FastArgs &a, const Lane32 &L, c32 (&v)[32], float *tile,
-                                                 unsigned *drained, unsigned drained_target, const St &st) {
-#pragma clang fp contract(off)
-  // window, eight points at a time
-  {
-    lds_cf2 *wp = (lds_cf2 *)L.win_l;
-#pragma unroll
-    for (int j0 = 0; j0 < 32; j0 += 8) {
-      float2 win[8];
-#pragma unroll
-      for (int j = 0; j < 8; ++j) { win[j].x = wp[32 * (j0 + j)].x; win[j].y = wp[32 * (j0 + j)].y; }
-#pragma unroll
-      for (int j = 0; j < 8; ++j) v[j0 + j] = {v[j0 + j].x * win[j].x, v[j0 + j].y * win[j].y};
-      wp = pin_after8(wp, &v[j0]);
-    }
-  }
-  reg_barrier32(v);
-  st.template stamp<1>();
-  // A: radix-32 over j, then twiddle W_M^(l k1)
-  fft32(v);
-  reg_barrier32(v);
-  {
-    lds_cf2 *tp = pin_after((lds_cf2 *)L.twA_l, v[31].y);
-#pragma unroll
-    for (int k0 = 0; k0 < 32; k0 += 8) {
-      float2 tw[8];
-#pragma unroll
-      for (int k = 0; k < 8; ++k) {
-        const int kk = k0 + k == 0 ? 1 : k0 + k;
-        tw[k].x = tp[32 * kk].x;
-        tw[k].y = tp[32 * kk].y;
-      }
-#pragma unroll
-      for (int k = 0; k < 8; ++k)
-        if (k0 + k > 0) v[k0 + k] = p32_cmul(v[k0 + k], tw[k].x, tw[k].y);
-      tp = pin_after8(tp, &v[k0]);
-    }
-  }
-  reg_barrier32(v);
-  st.template stamp<2>();
-  // X: lane l register k1 -> lane k1 register l through the frame's column, in place, real parts then imaginary parts
-  lds_wait(drained, drained_target);   // the group has stored the tile that was in this buffer
-  st.template stamp<3>();
-  lds_f *const wr = (lds_f *)(tile + L.own);
-  lds_f *const wr_hi = wr + 16 * kCellPitch32;
-  lds_cf *const rd = (lds_cf *)(tile + L.rd);
-#pragma unroll
-  for (int j = 0; j < 32; ++j) (j < 16 ? wr : wr_hi)[kCellPitch32 * (j & 15)] = v[j].x;
-#pragma unroll
-  for (int i = 0; i < 32; ++i) v[i].x = rd[kTileStride * i];
-#pragma unroll
-  for (int j = 0; j < 32; ++j) (j < 16 ? wr : wr_hi)[kCellPitch32 * (j & 15)] = v[j].y;
-#pragma unroll
-  for (int i = 0; i < 32; ++i) v[i].y = rd[kTileStride * i];
-  SMX_FENCE();
-  // B: radix-32 over l
-  fft32(v);
-  SMX_FENCE();
-  // P: registers 16..31 go to the partner lane through the cells and are dead afterwards (bin M/2 first)
-  auto power_of = [&](float re, float im) {
-    float pw = __builtin_fmaf(re, re, im * im);
-    if constexpr (!SQUARE) pw = a.pmode == 1 ? sqrtf(pw) : __powf(pw, a.half_power);
-    return pw;
-  };
-  const float self_pw = power_of(v[16].x + v[16].x, v[16].y + v[16].y);   // bin M/2 (lane 0): X = 2 conj(Z)
-  lds_cf *const xr = (lds_cf *)(tile + L.xr);
-  float px[16], py[16];
-#pragma unroll
-  for (int q = 16; q < 32; ++q) wr[kCellPitch32 * (q - 16)] = v[q].x;
-#pragma unroll
-  for (int s = 0; s < 16; ++s) px[s] = xr[kCellPitch32 * (15 - s)];
-#pragma unroll
-  for (int q = 16; q < 32; ++q) wr[kCellPitch32 * (q - 16)] = v[q].y;
-#pragma unroll
-  for (int s = 0; s < 16; ++s) py[s] = xr[kCellPitch32 * (15 - s)];
-  if (L.l == 0) { px[0] = v[0].x; py[0] = v[0].y; }   // bin 0 pairs with itself: X[0] and the Nyquist bin
-  st.template stamp<6>();
-  SMX_FENCE();
-  *(lds_f *)(tile + L.self) = self_pw;
-  lds_f *const rk = wr;                         // row l + 32 s
-  lds_f *const rm = (lds_f *)(tile + L.rm);     // row (32 - l) + 32 (31 - s) = rm base + 32 (15 - s)
-  lds_cf2 *pp = pin_after((lds_cf2 *)L.twP_l, py[15]);
-#pragma unroll
-  for (int s0 = 0; s0 < 16; s0 += 4) {
-    float2 tw[4];
-#pragma unroll
-    for (int s = 0; s < 4; ++s) { tw[s].x = pp[32 * (s0 + s)].x; tw[s].y = pp[32 * (s0 + s)].y; }
-    float last = 0.f;
-#pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const int s = s0 + u;
-      const c32 e = {v[s].x + px[s], v[s].y - py[s]};
-      const c32 d = {v[s].x - px[s], v[s].y + py[s]};
-      const float tr = __builtin_fmaf(tw[u].x, d.y, tw[u].y * d.x);
-      const float ti = __builtin_fmaf(tw[u].y, d.y, -(tw[u].x * d.x));
-      rk[kRowPitch32 * s] = power_of(e.x + tr, e.y + ti);
-      rm[kRowPitch32 * (15 - s)] = last = power_of(e.x - tr, e.y - ti);
-    }
-    pp = pin_after(pp, last);
-  }
-  st.template stamp<7>();
-}
-
-template <bool ALIGNED>
-__device__ __forceinline__ void load_frame32c(const float *src, int l, c32 (&v)[32]) {
-  float2 raw[32];
-  load_frame32<ALIGNED>(src, l, raw);
-#pragma unroll
-  for (int j = 0; j < 32; ++j) v[j] = {raw[j].x, raw[j].y};
-}
-
-template <bool ALIGNED, bool SQUARE, bool STRIP>
-__global__ void __launch_bounds__(1024) stft2048_power32g_kernel(FastArgs a) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const int wave16 = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int g = wave16 >> 3, wave = wave16 & 7;   // group, wave inside the group
-  const Lds32 lds = carve_lds32(smem);
-  const Lane32 L = setup_lane32(lds, lane, wave);
-  lds.win[tid] = reinterpret_cast<const float2 *>(a.hwin)[tid];
-  if (tid < 31 * 32) lds.twA[tid] = a.w_m[(tid & 31) * ((tid >> 5) + 1)];
-  if (tid < 512) lds.twP[tid] = a.w_n[tid];
-  if (tid < 2) { lds.filled[tid * kTileStride] = 0u; lds.drained[tid * kTileStride] = 0u; }
-  float *const tile = lds.tiles + g * kTile32Floats;
-  unsigned *const c_filled = lds.filled + g * kTileStride, *const c_drained = lds.drained + g * kTileStride;
-  // this group's tiles: the groups are 2 x blocks virtual workgroups, those of one XCD side by side (TileWalk::init)
-  TileWalk tw;
-  {
-    int64_t tau0;
-    int step;
-    const int64_t nb = a.blocks, xcd = blockIdx.x % 8, idx = 2 * (blockIdx.x / 8) + g;
-    const int64_t q = nb / 8, r = nb % 8;
-    if (a.interleave == 2 || a.interleave == 0) {
-      tau0 = 2 * (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
-      step = (int)(2 * nb);
-      tw.ntiles = tau0 < a.total_tiles ? (int)((a.total_tiles - tau0 + 2 * nb - 1) / (2 * nb)) : 0;
-    } else {
-      const int64_t nx = 2 * ((nb - xcd + 7) / 8);
-      const int64_t nxcd = nb < 8 ? nb : 8;
-      const int64_t x0 = a.total_tiles * xcd / nxcd, x1 = a.total_tiles * (xcd + 1) / nxcd;
-      tau0 = x0 + idx;
-      step = (int)nx;
-      tw.ntiles = tau0 < x1 ? (int)((x1 - tau0 + nx - 1) / nx) : 0;
-    }
-    if (tw.ntiles < 0) tw.ntiles = 0;
-    tw.ft = (int)(tau0 % a.tiles_per_clip);
-    tw.x_step = a.x_stride;
-    tw.o_step = kBins * a.out_stride;
-    tw.xclip = a.x + (tau0 / a.tiles_per_clip) * tw.x_step;
-    tw.oclip = a.out + a.out_offset + (tau0 / a.tiles_per_clip) * tw.o_step;
-    tw.step_clips = step / a.tiles_per_clip;
-    tw.step_tiles = step % a.tiles_per_clip;
-  }
-  const int ntiles = tw.ntiles;
-  Flush32 fl;
-  {
-    const int hsel = lane >> 5, jj = (lane & 31) >> 2;
-    fl.g = lane & 3;
-    fl.row0 = 128 * wave + (jj & 3) + 16 * (jj >> 2) + 4 * hsel;
-    fl.goff0 = ((unsigned)fl.row0 * (unsigned)a.out_stride + 4u * fl.g) * 4u;
-  }
-  __syncthreads();   // tables and zeroed counters visible: the only workgroup barrier of the main loop
-#ifdef SMX_STAMPS
-  unsigned long long stamp_sum[kStampSlots] = {0}, stamp_prev;
-  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(stamp_prev)::"memory");
-  const unsigned long long clk_t0 = stamp_prev, clk_r0 = __builtin_amdgcn_s_memrealtime();
-  const Stamp32 st{stamp_sum, &stamp_prev};
-#else
-  const NoStamp32 st{};
-#endif
-
-  for (int it = 0; it < ntiles; ++it) {
-    const int64_t f0 = (int64_t)tw.ft * kFT;
-    const bool have = f0 + 2 * wave < a.count;   // wave-uniform: at least the first half has a frame
-    if (have) {
-      const int64_t f = f0 + 2 * wave + L.h;
-      const int64_t p = a.p0 + (f < a.count ? f : f0 + 2 * wave);
-      const float *src = tw.xclip + (p * a.hop - a.left);
-      if (a.fold_frames && (p < a.border_i0 || p >= a.border_i1)) {
-        const int64_t clip = (tw.xclip - a.x) / a.x_stride;
-        src = p < a.border_i0 ? a.strip_l + clip * a.strip_l_stride + (p - a.p0) * a.hop
-                              : a.strip_r + clip * a.strip_r_stride + (p - a.border_i1) * a.hop;
-      }
-      c32 v[32];
-      load_frame32c<ALIGNED>(src, L.l, v);
-      st.template stamp<0>();
-      frame32g_to_tile<SQUARE>(a, L, v, tile, c_drained, 8u * (unsigned)it, st);
-    }
-    lds_signal(c_filled, lane);
-    lds_wait(c_filled, 8u * (unsigned)(it + 1));   // every column of the tile is in
-    st.template stamp<8>();
-    {
-      float *obase = tw.oclip + f0;
-      const int64_t left = a.count - f0;
-      const int frames_left = left < kFT ? (int)left : kFT;
-#pragma unroll
-      for (int part = 0; part < 8; ++part) flush32_part(a, tile, part, fl, obase, frames_left, wave, lane);
-    }
-    st.template stamp<9>();
-    lds_signal(c_drained, lane);
-    int ftnext;
-    const float *xnext;
-    float *onext;
-    tw.peek(a, ftnext, xnext, onext);
-    tw.xclip = xnext;
-    tw.oclip = onext;
-    tw.ft = ftnext;
-    st.template stamp<10>();
-  }
-#ifdef SMX_STAMPS
-  stamp_sum[20] = __builtin_amdgcn_s_memtime() - clk_t0;
-  stamp_sum[21] = __builtin_amdgcn_s_memrealtime() - clk_r0;
-  if (lane == 0 && blockIdx.x < 4096)
-    for (int i = 0; i < kStampSlots; ++i) g_stamp_sums[(blockIdx.x * 16 + wave16) * kStampSlots + i] = stamp_sum[i];
-#endif
-
-  // Border frames: same frame code on samples fetched through the padding rule, 32 (clip, frame) pairs per step
-  // (16 per group), results scattered to their places.
-  if (a.border_left + a.border_right > 0) {
-    const int per = a.border_left + a.border_right;
-    const int64_t lead = a.total_tiles / a.tiles_per_clip;
-    const int64_t total = lead * per;
-    auto locate = [&](int64_t beta, int64_t &clip, int64_t &p) {
-      clip = beta / per;
-      const int r = (int)(beta % per);
-      p = r < a.border_left ? a.border_p0 + r : a.border_i1 + (r - a.border_left);
-    };
-    for (int64_t bt = blockIdx.x; bt * 32 < total; bt += gridDim.x) {
-      __syncthreads();   // both buffers are free
-      const int64_t base = bt * 32 + 16 * g;
-      if (base + 2 * wave < total) {   // wave-uniform
-        int64_t beta = base + 2 * wave + L.h;
-        if (beta >= total) beta = base + 2 * wave;   // a half without a pair repeats the first one (never stored)
-        int64_t clip, p;
-        locate(beta, clip, p);
-        const float *xs = a.x + clip * a.x_stride;
-        const int s0 = (int)(p * a.hop - a.left);
-        c32 v[32];
-#pragma unroll
-        for (int j = 0; j < 32; ++j) {
-          const int s = s0 + 2 * (L.l + 32 * j);
-          v[j] = {fetch_padded(xs, (int)a.n, s, a.pad, a.pad_value), fetch_padded(xs, (int)a.n, s + 1, a.pad, a.pad_value)};
-        }
-        frame32g_to_tile<SQUARE>(a, L, v, tile, c_drained, 0u, NoStamp32{});
-      }
-      __syncthreads();
-      for (int e = tid; e < 2 * kBins * kFT; e += 1024) {
-        const int gg = e / (kBins * kFT), ee = e % (kBins * kFT);
-        const int k = ee / kFT, f = ee % kFT;
-        const int64_t bf = bt * 32 + 16 * gg + f;
-        if (bf < total) {
-          int64_t clip, p;
-          locate(bf, clip, p);
-          a.out[(clip * kBins + k) * a.out_stride + a.border_out_offset + (p - a.border_p0)] =
-              lds.tiles[gg * kTile32Floats + k * kTileStride + f];
         }
       }
     }

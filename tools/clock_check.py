@@ -27,7 +27,7 @@ for _ in range(20):
 S, nwg = 24, 256
 buf = np.zeros(nwg * 16 * S, dtype=np.uint64)
 assert lib.smx_debug_read_stamps(buf.ctypes.data_as(ctypes.POINTER(ctypes.c_ulonglong)), buf.size) == 0
-st = buf.reshape(nwg, 16, S).astype(np.float64)
+st = buf.reshape(nwg, 16, S).astype(np.float64)[:, :int(os.environ.get('WAVES', '16')), :]
 cyc, ref = st[:, :, 20], st[:, :, 21]
 clock = np.median(cyc / ref) * 100.0
 tiles = 256 * 934 / 16 / nwg

@@ -15,7 +15,7 @@
       "v80", "v81", "v82", "v83", "v84", "v85", "v86", "v87", "v88", "v89", "v90", "v91", "v92", "v93", "v94", "v95", \
       "v96", "v97", "v98", "v99", "v100", "v101", "v102", "v103", "v104", "v105", "v106", "v107", "v108", "v109",     \
       "v110", "v111", "v112", "v113", "v114", "v115", "v116", "v117", "v118", "v119", "v120", "v121", "v122", "v123", \
-      "v124", "v125", "v126", "v127", "s40", "s41", "s42", "s43", "vcc", "scc"
+      "v124", "v125", "v126", "v127", "s40", "s41", "s42", "s43", "s44", "s45", "vcc", "scc"
 
 // 16 instructions: I(d, a, b, c) with d = 64 + i, sources rotated so that the operand banks differ (DB) or coincide (SB)
 #define R16_DB(I)                                                                                                      \
@@ -43,6 +43,9 @@
 #define SWAP32(d, a, b, c) "v_permlane32_swap_b32 v" S(d) ", v" S(a) "\n\t"
 #define SWAP16(d, a, b, c) "v_permlane16_swap_b32 v" S(d) ", v" S(a) "\n\t"
 #define CNDM(d, a, b, c) "v_cndmask_b32_e32 v" S(d) ", v" S(a) ", v" S(b) ", vcc\n\t"
+#define CNDM64(d, a, b, c) "v_cndmask_b32_e64 v" S(d) ", v" S(a) ", v" S(b) ", s[44:45]\n\t"
+#define CNDM64N(d, a, b, c) "v_cndmask_b32_e64 v" S(d) ", v" S(a) ", -v" S(b) ", s[44:45]\n\t"
+#define CNDM0(d, a, b, c) "v_cndmask_b32_e32 v" S(d) ", v" S(a) ", v" S(b) ", vcc\n\t"
 #define MOV(d, a, b, c) "v_mov_b32_e32 v" S(d) ", v" S(a) "\n\t"
 #define DEP(d, a, b, c) "v_add_f32_e32 v64, v64, v" S(a) "\n\t"
 #define DEP2(d, a, b, c) "v_add_f32_e32 v64, v64, v" S(a) "\n\tv_add_f32_e32 v65, v65, v" S(b) "\n\t"
@@ -62,7 +65,7 @@
 enum {
   T_ADD32_DB, T_ADD32_SB, T_ADD64_DB, T_FMA_DB, T_FMA_SB, T_FMAD_DB, T_FMAC_DB, T_FMAC_SB, T_MULK, T_MULS, T_MIX_ADD_FMA,
   T_DEP, T_DEP2, T_ADD_SALU1, T_ADD_2SALU, T_ADD_SMUL, T_ADD_SMULHI, T_ADD_NOP, T_ADD_NOP1, T_ADD_WAIT, T_ADD_NOP_Q, T_ADD_WAIT_Q, T_ADD_BR_Q,
-  T_DPPROR, T_DPPQP, T_FMACDPP, T_ADDDPP, T_SWAP32, T_SWAP16, T_CNDM, T_MOV, T_ADD_MOV, T_LDS12, T_LDS4, T_KMIX, T_COUNT
+  T_DPPROR, T_DPPQP, T_FMACDPP, T_ADDDPP, T_SWAP32, T_SWAP16, T_CNDM, T_CNDM64, T_CNDM64N, T_CNDM_FULL, T_MOV, T_ADD_MOV, T_LDS12, T_LDS4, T_KMIX, T_COUNT
 };
 
 // quarter-rate companions: one scalar instruction per 4 vector instructions
@@ -91,7 +94,8 @@ __global__ void __launch_bounds__(1024) k(unsigned long long *cyc, int reps, flo
   asm volatile(
       "v_and_b32 v63, 63, v0\n\tv_lshlrev_b32 v63, 3, v63\n\t"
       "s_mov_b32 s40, 0\n\ts_mov_b32 s41, 0x3f7fff00\n\ts_mov_b32 s42, 0x7fffffff\n\ts_mov_b32 s43, 0\n\t"
-      "v_cmp_gt_u32 vcc, 32, v63\n\t" ::: "v63", CLOB);
+      "v_cmp_gt_u32 vcc, 32, v63\n\ts_mov_b64 s[44:45], vcc\n\t" ::: "v63", CLOB);
+  if constexpr (T == T_CNDM_FULL) asm volatile("s_mov_b64 vcc, -1" ::: "vcc");
 #define INIT(d, a, b, c) "v_mov_b32 v" S(d) ", 1.0\n\tv_mov_b32 v" S(a) ", 0.5\n\tv_mov_b32 v" S(b) ", 0.25\n\tv_mov_b32 v" S(c) ", 0.125\n\t"
   asm volatile(R16_SB(INIT)::: CLOB);
   __syncthreads();
@@ -127,6 +131,9 @@ __global__ void __launch_bounds__(1024) k(unsigned long long *cyc, int reps, flo
     if constexpr (T == T_SWAP32) asm volatile(X16(R16_DB(SWAP32))::: CLOB);
     if constexpr (T == T_SWAP16) asm volatile(X16(R16_DB(SWAP16))::: CLOB);
     if constexpr (T == T_CNDM) asm volatile(X16(R16_DB(CNDM))::: CLOB);
+    if constexpr (T == T_CNDM64) asm volatile(X16(R16_DB(CNDM64))::: CLOB);
+    if constexpr (T == T_CNDM64N) asm volatile(X16(R16_DB(CNDM64N))::: CLOB);
+    if constexpr (T == T_CNDM_FULL) asm volatile(X16(R16_DB(CNDM0))::: CLOB);
     if constexpr (T == T_MOV) asm volatile(X16(R16_DB(MOV))::: CLOB);
     if constexpr (T == T_ADD_MOV) asm volatile(X4(R16_DB(ADD_MOV) R16_DB(ADD_MOV))::: CLOB);   // 256 vector: 128 add + 128 mov
     if constexpr (T == T_LDS12) asm volatile(X16(L12 ADD32(76, 93, 110, 0) ADD32(77, 94, 111, 0) ADD32(78, 95, 96, 0) ADD32(79, 80, 97, 0)) "s_waitcnt lgkmcnt(0)\n\t" ::: CLOB, "memory");
@@ -196,6 +203,9 @@ int main() {
   run<T_SWAP32>("v_permlane32_swap_b32", 256);
   run<T_SWAP16>("v_permlane16_swap_b32", 256);
   run<T_CNDM>("v_cndmask_b32 e32 (vcc)", 256);
+  run<T_CNDM64>("v_cndmask_b32 e64 (sgpr pair)", 256);
+  run<T_CNDM64N>("v_cndmask_b32 e64 (sgpr pair, neg)", 256);
+  run<T_CNDM_FULL>("v_cndmask_b32 e32, vcc all ones", 256);
   run<T_MOV>("v_mov_b32", 256);
   run<T_ADD_MOV>("add + mov alternating", 256);
   run<T_LDS12>("16 add + 1 ds_read_b64 (x16), wait at end", 256);

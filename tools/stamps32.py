@@ -25,12 +25,13 @@ S, nwg = 24, 256
 buf = np.zeros(nwg * 16 * S, dtype=np.uint64)
 assert lib.smx_debug_read_stamps(buf.ctypes.data_as(ctypes.POINTER(ctypes.c_ulonglong)), buf.size) == 0
 st = buf.reshape(nwg, 16, S).astype(np.float64)[:, :8, :]
-names = ["loop top", "window", "A radix-32 + twiddle", "wait drained", "transposition", "prefetch issue", "B radix-32",
-         "flush (after the wait)", "exchange", "post-pass + results", "signal", "wait filled"]
+names = ["0 loop top", "1 window", "2 A radix-32 + twiddle", "3 wait drained", "4 transposition issue", "5 B radix-32 (+ wait for the transposition)",
+         "6 exchange issue, wait filled, flush reads", "7 post-pass + results (+ flush stores, prefetch issue)", "8 signal"]
 mean = st.mean(axis=(0, 1))
 tiles = 256 * 59 / nwg   # 934 frames -> 59 tiles per clip
-tot = mean[:12].sum()
+tot = mean[:9].sum()
 print("wall %.3f ms per launch; ticks per wave in the loop %.0f over %.1f tiles (%.0f per tile); whole loop %.0f ticks, %.0f x 10 ns -> clock %.2f GHz"
       % (wall_ms, tot, tiles, tot / tiles, mean[20], mean[21], mean[20] / mean[21] / 10.0 if mean[21] else 0))
+print("  inside the counter waits: drained %.0f per tile, filled %.0f per tile" % (mean[12] / tiles, mean[13] / tiles))
 for i, nm in enumerate(names):
     print("  %-24s %9.0f  %5.1f%%   (per tile %.0f)" % (nm, mean[i], 100 * mean[i] / tot, mean[i] / tiles))
