@@ -13,7 +13,7 @@ with the worst child status.  Under `torch.distributed.run` (RANK set) it is a r
 Workloads (BASELINE.json `configs`):
   N = 1   C2: 256 clips x 10 s x 48 kHz resident on the GPU; a step = one
           Stft.power_spectrum pass over the batch through the C ABI = ONE launch of
-          stft2048_power_kernel (asserted through the library's launch counter).
+          stft2048_power32_kernel (asserted through the library's launch counter).
           `extra` carries C3 (fused mel, 128 mels), C4 (FIR 8192 taps, 8 x 60 s) and
           the one-GPU point of C5, each timed with HIP events the same way.
   N > 1   C5: 4096 clips x 30 s, contiguous clip ranges per rank
@@ -46,6 +46,7 @@ ALGO_BYTES_PER_FRAME = HOP * 4 + BINS * 4      # hop*4 read + bins*4 
 MEL_BYTES_PER_FRAME = HOP * 4 + 128 * 4        # fused mel from audio: 2560 B
 FIR_BYTES_PER_SAMPLE = 8                       # 4 in + 4 out
 HBM_PEAK_GBS = 8000.0                          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+HBM_MEASURED_GBS = 6290.0                      # MI355X_MICROARCH.md: what a float4 copy reaches (79 % of the spec)
 MFMA_F32_PEAK_TFLOPS = 157.3                   # MI355X_MICROARCH.md: v_mfma_f32_*_f32
 
 
@@ -81,16 +82,30 @@ def launch_ranks(n):
         env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
                                       stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
-    out, _ = procs[0].communicate()
-    worst = procs[0].returncode
-    deadline = time.time() + 120
-    for p in procs[1:]:
-        try:
-            p.wait(timeout=max(1.0, deadline - time.time()))
-        except subprocess.TimeoutExpired:
-            p.kill()          # the exact child we started
-            p.wait()
-        worst = worst or p.returncode
+    # rank 0's stdout is drained by a thread; every child is polled, and the first failure ends the others (a rank that
+    # died before or inside a collective would otherwise leave the rest in a 10-30 minute collective timeout)
+    import threading
+    chunks = []
+    reader = threading.Thread(target=lambda: chunks.append(procs[0].stdout.read()), daemon=True)
+    reader.start()
+    worst = 0
+    deadline = time.time() + float(os.environ.get("SMX_BENCH_RANK_TIMEOUT", "3000"))
+    alive = list(procs)
+    while alive:
+        for p in list(alive):
+            rc = p.poll()
+            if rc is not None:
+                alive.remove(p)
+                worst = worst or rc
+        if worst or time.time() > deadline:
+            for p in alive:
+                p.kill()          # the exact children we started
+                p.wait()
+            worst = worst or 124
+            break
+        time.sleep(0.05)
+    reader.join(timeout=10)
+    out = b"".join(c for c in chunks if c)
     for ln in out.decode().splitlines():   # ONE JSON line on stdout; whatever else a library printed there (gloo's banner) goes to stderr
         (sys.stdout if ln.lstrip().startswith("{") else sys.stderr).write(ln + "\n")
     sys.stdout.flush()
@@ -116,7 +131,28 @@ def cpu_baseline(x_host, gpu_out_host):
         peak = float(want[i].max())
         err = float(np.max(np.abs(gpu_out_host[i].astype(np.float64) - want[i])))
         worst = max(worst, err / peak)
-    return {"value": round(frames / dt / 1e6, 4), "unit": "Mframes/s", "cores": cores, "kind": "port",
+    # comparators: the same restatement on ONE thread, and numpy's pocketfft (float64 frames x window ->
+    # rfft -> |.|^2, one thread) -- each on a bounded sample of the same batch
+    k1 = min(clips, 4)
+    t0 = time.perf_counter()
+    c_oracle.stft(c, x_host[:k1], 2.0, threads=1)
+    dt1 = time.perf_counter() - t0
+    win = np.asarray(c.analysis_window, dtype=np.float64)
+    k2 = min(clips, 2)
+    t0 = time.perf_counter()
+    fr_np = 0
+    for i in range(k2):
+        xp = np.pad(x_host[i].astype(np.float64), (FFT // 2, FFT // 2), mode="reflect")
+        idx = np.arange(0, xp.size - FFT + 1, HOP)[:, None] + np.arange(FFT)[None, :]
+        spec = np.fft.rfft(xp[idx] * win[None, :], axis=1)
+        pw = spec.real ** 2 + spec.imag ** 2
+        fr_np += pw.shape[0]
+    dtn = time.perf_counter() - t0
+    comparators = {"single_thread": {"value": round(k1 * O.frames(c, n) / dt1 / 1e6, 4), "unit": "Mframes/s", "cores": 1, "kind": "port",
+                                     "sample": "%d clips, oracle/oracle_stft.c on one thread, %.2f s" % (k1, dt1)},
+                   "numpy_rfft": {"value": round(fr_np / dtn / 1e6, 4), "unit": "Mframes/s", "cores": 1, "kind": "comparator",
+                                  "sample": "%d clips, numpy.fft.rfft (pocketfft, float64) of the windowed frames + |.|^2 on one thread, %.2f s" % (k2, dtn)}}
+    return {"value": round(frames / dt / 1e6, 4), "unit": "Mframes/s", "cores": cores, "kind": "port", "comparators": comparators,
             "sample": "the whole C2 batch once: %d clips x %d samples (%d frames), oracle/oracle_stft.c f64 interior, "
                       "%d threads (os.cpu_count() %d), %.2f s" % (clips, n, frames, cores, os.cpu_count() or 1, dt),
             "gpu_vs_oracle_max_err_over_peak": float("%.3g" % worst), "gpu_vs_oracle_frames_checked": frames,
@@ -154,14 +190,11 @@ def main():
     torch.cuda.set_device(dev)
     backend = "none"
     if world > 1:
-        backend = "nccl" if ndev >= world else "gloo"      # RCCL refuses two ranks on one device
+        # chosen from the device count alone, identically on every rank (RCCL refuses two ranks on one device); a group that
+        # fails to form fails the run -- re-initialising over a half-built store can leave ranks on different backends
+        backend = os.environ.get("SMX_BENCH_BACKEND") or ("nccl" if ndev >= world else "gloo")
         if backend == "nccl":
-            try:
-                dist.init_process_group("nccl", device_id=dev)
-            except Exception as e:          # the clock's barrier and MAX-reduce are the only collectives: gloo carries them as well
-                sys.stderr.write("bench.py: RCCL process group failed (%s); timing collectives over gloo\n" % e)
-                backend = "gloo"
-                dist.init_process_group("gloo")
+            dist.init_process_group("nccl", device_id=dev)
         else:
             dist.init_process_group("gloo")
     red_dev = dev if backend == "nccl" else None
@@ -261,11 +294,15 @@ def main():
     if rank == 0:
         total_frames = total_clips * frames
         achieved = clips * frames * ALGO_BYTES_PER_FRAME / (avg_ms * 1e-3) / 1e9
-        traffic = None
+        # `traffic` is NOT measured by this run: it is the PMC figure of the committed profile (separate --pmc passes of
+        # rocprofv3, tools/profile_round.sh), quoted with the commit and kernel duration it was taken at
+        traffic, traffic_source = None, None
         tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
         if workload == "c2" and clips == 256 and os.path.exists(tpath):
             try:
-                traffic = json.load(open(tpath)).get("bytes_per_launch")
+                tj = json.load(open(tpath))
+                traffic = tj.get("bytes_per_launch")
+                traffic_source = {k: tj.get(k) for k in ("source", "commit", "kernel", "kernel_us_in_profile", "box") if tj.get(k) is not None}
             except Exception:
                 traffic = None
         line.update({
@@ -276,11 +313,13 @@ def main():
                        "frames_per_gpu": clips * frames, "sharding": "clips over ranks, no collective",
                        "timing_backend": backend},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-                         "kernel": "stft2048_power_kernel<true, true, false> (one launch per step: all %d frames of %d clips)"
+                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_source,
+                         "frac_of_measured": round(achieved / HBM_MEASURED_GBS, 4), "measured_peak": HBM_MEASURED_GBS,
+                         "kernel": "stft2048_power32_kernel<true, true, false> (one launch per step: all %d frames of %d clips)"
                                    % (frames, clips),
                          "launches_per_step": launches,
-                         "kernel_ms_avg": round(avg_ms, 4), "kernel_ms_min": round(step_ms[0], 4),
+                         "kernel_ms_avg": round(avg_ms, 4), "kernel_ms_median": round(step_ms[len(step_ms) // 2], 4),
+                         "kernel_ms_min": round(step_ms[0], 4),
                          "algorithmic_bytes_per_frame": ALGO_BYTES_PER_FRAME},
         })
         if shard_check:

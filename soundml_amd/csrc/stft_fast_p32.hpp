@@ -179,7 +179,12 @@ __device__ __forceinline__ void p32_fft16(c32 (&v)[16]) {
 }
 // 32-point forward DFT, natural order in and out, in registers: two 16-point DFTs (even / odd inputs) and one
 // combining pass X[k] = E[k] + W32^k O[k], X[k + 16] = E[k] - W32^k O[k]
-__device__ __forceinline__ void fft32(c32 (&v)[32]) {
+struct NoHalf32 {
+  __device__ __forceinline__ void operator()() const {}
+};
+// `half()` is called between the two 16-point transforms (the power kernel reads a counter there)
+template <class Half = NoHalf32>
+__device__ __forceinline__ void fft32(c32 (&v)[32], const Half &half = Half{}) {
 #pragma clang fp contract(off)
   constexpr float c1 = (float)0.98078528040323043, s1 = (float)0.19509032201612825;
   constexpr float c2 = (float)0.92387953251128674, s2 = (float)0.38268343236508977;
@@ -189,6 +194,7 @@ __device__ __forceinline__ void fft32(c32 (&v)[32]) {
 #pragma unroll
   for (int m = 0; m < 16; ++m) { e[m] = v[2 * m]; o[m] = v[2 * m + 1]; }
   p32_fft16(e);
+  half();
   p32_fft16(o);
   o[1] = p32_cmul(o[1], c1, -s1);
   o[2] = p32_cmul(o[2], c2, -s2);
@@ -234,28 +240,14 @@ struct NoMid32 {
 // the two waves of a SIMD run half a frame apart by themselves -- one computes while the other waits for the LDS -- and
 // every wait that asks for less slack than that turns the counters into a barrier: 0.56 -> 0.58 ms when the tile's reads
 // sat behind the transposition, profiles/r05.)
-#ifndef SMX_P32_WINPRE
-#define SMX_P32_WINPRE 0   // 1: the window rows are read at the END of a frame pair for the next one (64 registers across the loop edge)
-#endif
 #ifndef SMX_P32_TWI
 #define SMX_P32_TWI 1      // 1: the transposition's first plane is written while the twiddle products are formed (shorter LDS bursts)
 #endif
-__device__ __forceinline__ void load_window32(const Lane32 &L, float4 (&win)[16]) {
-#pragma unroll
-  for (int m = 0; m < 16; ++m) win[m] = L.win_l[32 * m];
-}
 template <bool SQUARE, class Mid>
 __device__ __forceinline__ void frame32_to_tile(const FastArgs &a, const Lane32 &L, float2 (&raw)[32], float *tile,
-                                                const Mid &mid, float4 (&winpre)[16]) {
+                                                const Mid &mid) {
 #pragma clang fp contract(off)
   c32 v[32], t[32];
-  if constexpr (SMX_P32_WINPRE) {
-#pragma unroll
-    for (int m = 0; m < 16; ++m) {
-      v[2 * m] = {raw[2 * m].x * winpre[m].x, raw[2 * m].y * winpre[m].y};
-      v[2 * m + 1] = {raw[2 * m + 1].x * winpre[m].z, raw[2 * m + 1].y * winpre[m].w};
-    }
-  } else
 #pragma unroll
   for (int m0 = 0; m0 < 16; m0 += 8) {   // two batches: the window rows are not all in registers at once
     float4 win[8];
@@ -276,8 +268,7 @@ __device__ __forceinline__ void frame32_to_tile(const FastArgs &a, const Lane32 
 #pragma unroll
     for (int m = 0; m < 15; ++m) tw[m] = L.twA_l[32 * m];
     const float2 tw31 = L.twA31_l[0];
-    mid.early();
-    fft32(v);
+    fft32(v, [&] { SMX_FENCE(); mid.early(); SMX_FENCE(); });
     if constexpr (!SMX_P32_TWI) {
 #pragma unroll
       for (int m = 0; m < 15; ++m) {
@@ -376,7 +367,6 @@ __device__ __forceinline__ void frame32_to_tile(const FastArgs &a, const Lane32 
     rm[kRowPitch32 * (15 - s)] = power_of(e.x - tr, e.y - ti);
     if (s == 7) { SMX_FENCE(); mid.mid_postpass(); SMX_FENCE(); }
   }
-  if constexpr (SMX_P32_WINPRE) { SMX_FENCE(); load_window32(L, winpre); }   // for the next frame pair: lands while the loop turns
   mid.template stamp<7>();
 }
 
@@ -567,8 +557,6 @@ __global__ void __launch_bounds__(512) stft2048_power32_kernel(FastArgs a) {
     fl.goff0 = ((unsigned)row0 * (unsigned)a.out_stride + 4u * fl.g) * 4u;
   }
   FlushRegs fr;
-  float4 winpre[16];
-  if constexpr (SMX_P32_WINPRE) load_window32(L, winpre);
   unsigned pk_drained = 0, pk_filled = 0;
 #ifdef SMX_STAMPS
   unsigned long long stamp_sum[kStampSlots] = {0}, stamp_prev;
@@ -590,8 +578,11 @@ __global__ void __launch_bounds__(512) stft2048_power32_kernel(FastArgs a) {
     const PowerMid32<ALIGNED> mid{a, lds, fl, fr, raw, src, pend_out, pend_left, lane, wave, b, it, pk_drained, pk_filled};
 #endif
     mid.template stamp<0>();
+#ifdef SMX_STAMPS
+    if (it == 32) stamp_sum[14] = __builtin_amdgcn_s_memtime();   // when this wave starts its 33rd tile (wave offsets inside a workgroup)
+#endif
     if (have) {
-      frame32_to_tile<SQUARE>(a, L, raw, lds.tiles + b * kTile32Floats, mid, winpre);
+      frame32_to_tile<SQUARE>(a, L, raw, lds.tiles + b * kTile32Floats, mid);
     } else {
       mid.early();
       mid.before_cells();
@@ -649,9 +640,7 @@ __global__ void __launch_bounds__(512) stft2048_power32_kernel(FastArgs a) {
           braw[j] = make_float2(fetch_padded(xs, (int)a.n, s, a.pad, a.pad_value),
                                 fetch_padded(xs, (int)a.n, s + 1, a.pad, a.pad_value));
         }
-        float4 bwin[16];
-        if constexpr (SMX_P32_WINPRE) load_window32(L, bwin);
-        frame32_to_tile<SQUARE>(a, L, braw, bt_tile, NoMid32{}, bwin);
+        frame32_to_tile<SQUARE>(a, L, braw, bt_tile, NoMid32{});
       }
       __syncthreads();
       for (int e = tid; e < kBins * kFT; e += 512) {

@@ -196,7 +196,8 @@ def test_regression_gate_fast_kernels(fft, hop):
 
 @pytest.mark.timeout(600)
 def test_ring_kernel_is_bit_identical_to_the_column_kernel():
-    """SMX_POWER_RING=1 (whole 64-byte-aligned stores from a ring of the last 32 frames of every bin row) must produce the
+    """The two forms of the 64-lane pipeline (SMX_POWER_V1=1; kept for A/B timing beside the 32-lane power kernel):
+    SMX_POWER_RING=1 (whole 64-byte-aligned stores from a ring of the last 32 frames of every bin row) must produce the
     column kernel's values bit for bit: same frame code, only the way the tile leaves LDS differs.  Geometries: ranges that
     start mid-clip, partial last tiles, segments that cross clips, odd row pitches, every alignment, general powers."""
     code = """
@@ -220,7 +221,7 @@ np.savez(sys.argv[1], **out)
     import tempfile
     res = []
     for ring in ("0", "1"):
-        env = dict(os.environ, SMX_POWER_RING=ring)
+        env = dict(os.environ, SMX_POWER_RING=ring, SMX_POWER_V1="1")
         path = tempfile.mktemp(suffix=".npz")
         subprocess.run([sys.executable, "-c", code, path], check=True, env=env, timeout=500)
         res.append(dict(np.load(path)))

@@ -32,6 +32,11 @@ tiles = 256 * 59 / nwg   # 934 frames -> 59 tiles per clip
 tot = mean[:9].sum()
 print("wall %.3f ms per launch; ticks per wave in the loop %.0f over %.1f tiles (%.0f per tile); whole loop %.0f ticks, %.0f x 10 ns -> clock %.2f GHz"
       % (wall_ms, tot, tiles, tot / tiles, mean[20], mean[21], mean[20] / mean[21] / 10.0 if mean[21] else 0))
+print("  drained wait per tile by wave:", " ".join("%.0f" % (st[:, w, 12].mean() / tiles) for w in range(st.shape[1])))
+print("  whole loop ticks by wave:     ", " ".join("%.0f" % (st[:, w, 20].mean() / tiles) for w in range(st.shape[1])))
+t14 = st[:, :, 14]
+rel = t14 - t14.min(axis=1, keepdims=True)
+print("  start of tile 33 relative to the workgroup's first wave, cycles, mean by wave:", " ".join("%.0f" % rel[:, w].mean() for w in range(st.shape[1])), " (max spread mean %.0f)" % rel.max(axis=1).mean())
 print("  inside the counter waits: drained %.0f per tile, filled %.0f per tile" % (mean[12] / tiles, mean[13] / tiles))
 for i, nm in enumerate(names):
     print("  %-24s %9.0f  %5.1f%%   (per tile %.0f)" % (nm, mean[i], 100 * mean[i] / tot, mean[i] / tiles))
