@@ -191,6 +191,14 @@ int smx_stft_kernel_step(smx_stft_kernel *k, const void *chunk /* host [channels
                          void *out_complex, int64_t capacity, int64_t *emitted);
 int smx_stft_kernel_flush(smx_stft_kernel *k, void *out_complex, int64_t capacity, int64_t *emitted);
 int smx_stft_kernel_reset(smx_stft_kernel *k);
+/* The reference's state takes its leading shape from the chunks it is fed (stft.ml:521-559: only `channels >= 1` is checked
+ * at prepare, stft.ml:603-617), so a binding must be able to follow the first chunk: channels() reports the count the
+ * kernel was prepared for (step / flush read and write exactly that many rows: a caller passes buffers of that extent),
+ * set_channels() re-shapes a kernel that has not received a sample since prepare / reset and refuses one that has
+ * (SMX_INVALID_ARGUMENT: the stream's chunks disagree in their leading shape).                                      */
+int smx_stft_kernel_channels(const smx_stft_kernel *k, int64_t *out);
+int smx_stft_kernel_set_channels(smx_stft_kernel *k, int64_t channels);
+const smx_stft_config *smx_stft_kernel_config(const smx_stft_kernel *k);   /* the configuration it was prepared with (borrowed) */
 
 /* ---- Mel.Config / Mel.apply (mel.ml:22-233) ------------------------------- */
 /* Convert.hz_to_mel / mel_to_hz (convert.ml:70-102): the scalar maps behind the filterbank's breakpoints; host float64 */

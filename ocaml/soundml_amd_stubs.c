@@ -455,10 +455,21 @@ CAMLprim value soundml_amd_kernel_step(value v_k, value v_chunk, value v_out, va
   const int64_t channels = Long_val(v_channels), m = Long_val(v_m), capacity = Long_val(v_capacity);
   const int is_flush = Bool_val(v_is_flush);
   if (channels < 1 || m < 0 || capacity < 0) caml_failwith("soundml_amd: invalid geometry");
+  /* The library reads and writes the rows of the channel count the KERNEL holds, whatever the caller passes: follow the
+   * first chunk of a stream as the reference's state does (stft.ml:521-559), refuse a later disagreement (the reference
+   * fails in its concatenation), and only then trust the extents. */
+  int64_t have = 0;
+  smx_raise(smx_stft_kernel_channels(k, &have));
+  if (have != channels) {
+    if (is_flush) caml_invalid_argument("flush: the kernel's stream has another channel count");
+    smx_raise(smx_stft_kernel_set_channels(k, channels));   /* SMX_INVALID_ARGUMENT -> Invalid_argument once samples were fed */
+  }
   if (!is_flush && ba_dim(v_chunk) < channels * m) caml_failwith("soundml_amd: buffer extents disagree with geometry");
   int64_t bound = 0;
   smx_raise(smx_stft_kernel_frame_bound(k, &bound));
   if (capacity < bound) caml_failwith("soundml_amd: output capacity below the kernel's frame bound");
+  if (ba_dim(v_out) < channels * smx_stft_config_bins(smx_stft_kernel_config(k)) * capacity)
+    caml_failwith("soundml_amd: output extents disagree with geometry");
   /* out is complex (2 components per element) or real; either way a Bigarray element is one spectrum value */
   void *chunk = is_flush ? NULL : Caml_ba_data_val(v_chunk);
   void *out = Caml_ba_data_val(v_out);

@@ -264,6 +264,8 @@ module Kernel = struct
   let step t chunk =
     let batch, m = split_last chunk in
     let channels = product batch in
+    (* the stub re-shapes a fresh kernel to the chunk's channel count and raises Invalid_argument when a stream that
+       already holds samples is fed another one; [out] below is sized from the same count, which the stub checks *)
     t.leading <- batch ;
     let out = Nx.empty t.cdtype [|channels; t.bins; t.capacity|] in
     let emitted = kernel_step_c t.k (flat chunk) (flat_out out) channels m t.capacity false in

@@ -150,6 +150,9 @@ SIGNATURES = {
     "smx_stft_kernel_step": (cint, [vp, vp, i64, vp, i64, pi64]),
     "smx_stft_kernel_flush": (cint, [vp, vp, i64, pi64]),
     "smx_stft_kernel_reset": (cint, [vp]),
+    "smx_stft_kernel_channels": (cint, [vp, pi64]),
+    "smx_stft_kernel_set_channels": (cint, [vp, i64]),
+    "smx_stft_kernel_config": (vp, [vp]),
     "smx_mel_config_create": (cint, [i64, i64, i64, f64, cint, f64, cint, cint, C.POINTER(vp)]),
     "smx_mel_config_from_weights": (cint, [i64, i64, vp, C.POINTER(vp)]),
     "smx_mel_config_destroy": (None, [vp]),

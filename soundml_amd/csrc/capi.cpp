@@ -731,6 +731,34 @@ int smx_stft_kernel_frame_bound(const smx_stft_kernel *k, int64_t *out) {
   });
 }
 
+int smx_stft_kernel_channels(const smx_stft_kernel *k, int64_t *out) {
+  return guarded([&] {
+    if (!k || !out) throw Failure("channels: null argument");
+    *out = k->channels;
+  });
+}
+
+const smx_stft_config *smx_stft_kernel_config(const smx_stft_kernel *k) { return k ? k->cfg : nullptr; }
+
+int smx_stft_kernel_set_channels(smx_stft_kernel *k, int64_t channels) {
+  return guarded([&] {
+    if (!k) throw Failure("set_channels: null kernel");
+    if (channels < 1)  // stft.ml:604-608
+      throw InvalidArgument(format(
+          "prepare: cannot analyse %lld channels (channels must be at least 1)", (long long)channels));
+    if (channels == k->channels) return;
+    if (k->received != 0 || k->started || k->drained)
+      throw InvalidArgument(format("step: cannot feed %lld channels to a stream of %lld (the chunks of one stream share their "
+                                   "leading shape; reset before changing it)", (long long)channels, (long long)k->channels));
+    // nothing carried yet: the device buffers are sized on first use
+    SMX_HIP_CHECK(hipFree(k->d_stream));
+    SMX_HIP_CHECK(hipFree(k->d_out));
+    k->d_stream = k->d_out = nullptr;
+    k->cap = k->out_cap = 0;
+    k->channels = channels;
+  });
+}
+
 int smx_stft_kernel_reset(smx_stft_kernel *k) {  // stft.ml:401-409
   return guarded([&] {
     if (!k) throw Failure("reset: null kernel");

@@ -1717,12 +1717,13 @@ bool launch_mel_spectrogram_16(const MelSpecJob &job) {
   mt.k_pad = (int)mtab.k_pad;
   mt.out = reinterpret_cast<float *>(job.out);
   if (chirp_16) {
-    // Sizes with a mixed-radix plan: above a few tiles per CU the composition power kernel + Mel.apply is ahead of the fused
-    // launch (fft 400 / hop 160, 80 mels, 256 x 30 s: 1.03 + 0.22 ms against 1.50 -- the fused instantiation of that kernel runs
-    // its transform part 20 % slower than the power one, tools/mel16_time.py; not understood), so the fused form keeps the small
-    // batches, where one launch is what counts.  SMX_MEL16_FUSED=1 forces it.
+    // Sizes with a mixed-radix plan take the composition power kernel + Mel.apply at EVERY batch size.  The fused launch is
+    // ahead only below a few tiles per CU (one launch instead of two; above, fft 400 / hop 160, 80 mels, 256 x 30 s:
+    // 1.03 + 0.22 ms against 1.50), and its MFMA tail sums in another order than Mel.apply -- a switch by batch size made a
+    // clip's values depend on what it was batched with (the reference's slice law, mel_props.ml:136-155).
+    // SMX_MEL16_FUSED=1 selects the fused form, again for every batch.
     static const bool force = [] { const char *e = std::getenv("SMX_MEL16_FUSED"); return e && e[0] == '1'; }();
-    if (t.mixed_npass > 0 && !force && sj.lead * sj.count > 65536) return false;
+    if (t.mixed_npass > 0 && !force) return false;
     return launch_mixed16_any(sj, a, t, &mt) || launch_bluestein16_any(sj, a, t, &mt);
   }
   return c.fft_size == 512 ? launch_stockham_power16<9>(sj, a, t, &mt) : launch_stockham_power16<10>(sj, a, t, &mt);

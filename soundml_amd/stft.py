@@ -356,6 +356,12 @@ class Kernel:
         if a.ndim >= 1 and 0 in a.shape[:-1]:
             raise _lib.InvalidArgument(
                 "step: cannot analyse a chunk with a zero-size leading axis (channels must be at least 1)")
+        lead = int(np.prod(a.shape[:-1], dtype=np.int64)) if a.ndim >= 1 else 1
+        if lead != self._channels:
+            # the reference's state takes its leading shape from the chunks (stft.ml:521-559): a fresh kernel follows the
+            # first one, a stream that already holds samples refuses another count
+            check(lib.smx_stft_kernel_set_channels(self._h, lead))
+            self._channels = lead
         a = np.ascontiguousarray(a.astype(self._dtype, copy=False)).reshape(self._channels, -1)
         m = a.shape[-1]
         cfg = self._cfg

@@ -499,6 +499,31 @@ def test_streaming_partition_law(alignment, pad, fft, hop):
             k.reset()
 
 
+def test_streaming_kernel_follows_the_first_chunks_leading_shape():
+    """stft.ml:603-617 checks only `channels >= 1` at prepare and the state takes its leading shape from the chunks
+    (stft.ml:521-559): a kernel prepared for 4 channels analyses a 1-channel stream, bit for bit the 1-channel transform,
+    and a stream that already holds samples refuses another count (the library reads and writes exactly the rows of the
+    count it holds: a binding must never pass buffers of another extent -- ADVICE round 2)."""
+    rng = np.random.default_rng(77)
+    c = Stft.Config.create(fft_size=32, hop=8)
+    x = rng.standard_normal((1, 300))
+    k = Stft.Kernel.prepare(c, np.float64, channels=4, max_block=300)
+    parts = [o for o in (k.step(x[:, :100]), k.step(x[:, 100:]), k.flush()) if o is not None]
+    got = np.concatenate(parts, axis=-1)
+    want = Stft.transform(c, x)
+    assert got.shape == want.shape == (1, c.bins, Stft.frames(c, 300))
+    assert np.array_equal(got, want)
+    k.reset()
+    k.step(rng.standard_normal((3, 50)))                              # a fresh stream may take another shape ...
+    with pytest.raises(S.InvalidArgument, match="step: cannot feed 2 channels to a stream of 3"):
+        k.step(rng.standard_normal((2, 50)))                          # ... one that holds samples may not
+    import ctypes
+    from soundml_amd._lib import check, lib
+    have = ctypes.c_int64()
+    check(lib.smx_stft_kernel_channels(k._h, ctypes.byref(have)))
+    assert have.value == 3
+
+
 def test_streaming_2048_float32():
     rng = np.random.default_rng(9)
     x = rng.uniform(-1, 1, size=(2, 30000)).astype(np.float32)
@@ -741,6 +766,26 @@ def test_fused_mel_spectrogram_vs_oracle(n_mels, sr, n, lead, power):
     import torch
     assert np.array_equal(S.mel_spectrogram(sc, mc, torch.from_numpy(x).cuda(), power).cpu().numpy(), got)
 
+
+
+def test_mel_spectrogram_mixed_radix_large_batch_equals_its_slices():
+    """mel_props.ml:136-155 at a size with a mixed-radix plan (fft 400 / hop 160, 80 mels: whisper's front end) on a batch of
+    more than 65 536 frames, where round 2's launcher switched from the fused kernel to power + Mel.apply: a clip's values
+    must not depend on what it is batched with -- slices of the large batch, computed alone and in a small
+    batch, are the large batch's rows bit for bit."""
+    rng = np.random.default_rng(400)
+    lead, n = 700, 16000                     # 101 frames per clip -> 70 700 frames
+    x = rng.uniform(-1, 1, size=(lead, n)).astype(np.float32)
+    sc = Stft.Config.create(fft_size=400, hop=160)
+    mc = Mel.Config.create(n_mels=80, sample_rate=16000, fft_size=400)
+    big = S.mel_spectrogram(sc, mc, x)
+    assert big.shape == (lead, 80, Stft.frames(sc, n)) and lead * big.shape[2] > 65536
+    for i in (0, 1, 349, 699):
+        assert np.array_equal(big[i], S.mel_spectrogram(sc, mc, x[i])), i
+    assert np.array_equal(big[10:13], S.mel_spectrogram(sc, mc, x[10:13]))
+    want = O.mel_spectrogram(O.stft_config(400, hop=160), O.mel_config(80, 16000, 400), x[:2])
+    for i in range(2):
+        check_fast(big[i], want[i], "clip %d" % i)
 
 
 @pytest.mark.parametrize("fft,hop,n_mels,sr,n,lead,power", [
