@@ -884,6 +884,29 @@ void shape_dev(const double *d_x, const double *d_h, double *d_y, int64_t lines,
   SMX_HIP_CHECK(hipGetLastError());
 }
 
+// Device scratch that is released on every way out of a function (a throwing launch or check included): stream-ordered
+// (the retained pool) when a stream is given, plain hipMalloc / hipFree otherwise.
+struct DeviceScratch {
+  void *p = nullptr;
+  hipStream_t stream = nullptr;
+  bool pooled = false;
+  DeviceScratch() = default;
+  DeviceScratch(const DeviceScratch &) = delete;
+  DeviceScratch &operator=(const DeviceScratch &) = delete;
+  void alloc_async(size_t bytes, hipStream_t st) {
+    stream = st;
+    pooled = true;
+    SMX_HIP_CHECK(smx::pool_malloc_async(&p, bytes, st));
+  }
+  void alloc(size_t bytes) { SMX_HIP_CHECK(hipMalloc(&p, bytes)); }
+  template <class T> T *as() const { return reinterpret_cast<T *>(p); }
+  ~DeviceScratch() {
+    if (!p) return;
+    if (pooled) (void)hipFreeAsync(p, stream);
+    else (void)hipFree(p);
+  }
+};
+
 int64_t stage_out_length(const smx_resample_stage &s, int64_t n) { return (n * s.l + s.m - 1) / s.m; }   // ceil(n L / M)
 
 // y[c][i] = sum_t proto[t] xu[c][i M + K L - t], xu = x zero-stuffed by L (resample.ml:1318-1326): the stage's
@@ -895,33 +918,34 @@ void stage_apply_dev(const smx_resample_stage &s, const float *d_x, int64_t chan
   if (channels == 0 || n_out == 0) return;
   if (x_stride < n || y_stride < n_out) throw Failure("resample_stage: stride smaller than the signal length");
   if (!d_x || !d_y) throw Failure("resample_stage: null device pointer");
+  if (channels > 65535)   // the zero-stuffing and decimation launches put the channel in grid.y
+    throw Failure("resample_stage: more than 65535 channels in one call");
   smx::init_device_pool();
   const float *xin = d_x;
   int64_t n_in = n, in_stride = x_stride;
-  float *xu = nullptr, *v = nullptr;
+  DeviceScratch xu, v;   // freed on the stream whichever way this function is left
   if (s.l > 1) {
     n_in = n * s.l;
     in_stride = (n_in + 1) & ~int64_t(1);
-    SMX_HIP_CHECK(smx::pool_malloc_async((void **)&xu, (size_t)channels * (size_t)in_stride * sizeof(float), stream));
+    xu.alloc_async((size_t)channels * (size_t)in_stride * sizeof(float), stream);
     const int64_t gx = std::min<int64_t>((n_in + 255) / 256, 2048);
-    SMX_LAUNCH(smx::zero_stuff_kernel, dim3((unsigned)gx, (unsigned)channels), dim3(256), 0, stream, d_x, n, x_stride, (int)s.l, xu,
-               in_stride);
-    xin = xu;
+    SMX_LAUNCH(smx::zero_stuff_kernel, dim3((unsigned)gx, (unsigned)channels), dim3(256), 0, stream, d_x, n, x_stride, (int)s.l,
+               xu.as<float>(), in_stride);
+    SMX_HIP_CHECK(hipGetLastError());
+    xin = xu.as<float>();
   }
   const int64_t shift = s.k * s.l;
   if (s.m == 1) {
     smx::fir_apply_window_dev(*s.fir, xin, channels, n_in, in_stride, d_y, y_stride, n_out, shift, stream);
   } else {
     const int64_t nv = (n_out - 1) * s.m + 1, v_stride = (nv + 1) & ~int64_t(1);
-    SMX_HIP_CHECK(smx::pool_malloc_async((void **)&v, (size_t)channels * (size_t)v_stride * sizeof(float), stream));
-    smx::fir_apply_window_dev(*s.fir, xin, channels, n_in, in_stride, v, v_stride, nv, shift, stream);
+    v.alloc_async((size_t)channels * (size_t)v_stride * sizeof(float), stream);
+    smx::fir_apply_window_dev(*s.fir, xin, channels, n_in, in_stride, v.as<float>(), v_stride, nv, shift, stream);
     const int64_t gy = std::min<int64_t>((n_out + 255) / 256, 2048);
-    SMX_LAUNCH(smx::decimate_kernel, dim3((unsigned)gy, (unsigned)channels), dim3(256), 0, stream, v, v_stride, (int)s.m, d_y, n_out,
-               y_stride);
+    SMX_LAUNCH(smx::decimate_kernel, dim3((unsigned)gy, (unsigned)channels), dim3(256), 0, stream, v.as<float>(), v_stride, (int)s.m, d_y,
+               n_out, y_stride);
   }
   SMX_HIP_CHECK(hipGetLastError());
-  if (xu) SMX_HIP_CHECK(hipFreeAsync(xu, stream));
-  if (v) SMX_HIP_CHECK(hipFreeAsync(v, stream));
 }
 
 void require_hip_device() {
@@ -981,21 +1005,15 @@ int smx_resample_shape_c128(const double *x, const double *h, double *y, int64_t
     require_hip_device();
     const size_t xb = (size_t)lines * (size_t)(n / 2 + 1) * 16, hb = (size_t)(sl > 1 ? w / 2 + 1 : n / 2 + 1) * 16,
                  yb = (size_t)lines * (size_t)(w / 2 + 1) * 16;
-    double *dx = nullptr, *dh = nullptr, *dy = nullptr;
-    SMX_HIP_CHECK(hipMalloc((void **)&dx, xb));
-    SMX_HIP_CHECK(hipMalloc((void **)&dh, hb));
-    SMX_HIP_CHECK(hipMalloc((void **)&dy, yb));
-    try {
-      SMX_HIP_CHECK(hipMemcpy(dx, x, xb, hipMemcpyHostToDevice));
-      SMX_HIP_CHECK(hipMemcpy(dh, h, hb, hipMemcpyHostToDevice));
-      shape_dev(dx, dh, dy, lines, n, sl, sm, nullptr);
-      SMX_HIP_CHECK(hipStreamSynchronize(nullptr));
-      SMX_HIP_CHECK(hipMemcpy(y, dy, yb, hipMemcpyDeviceToHost));
-    } catch (...) {
-      (void)hipFree(dx); (void)hipFree(dh); (void)hipFree(dy);
-      throw;
-    }
-    (void)hipFree(dx); (void)hipFree(dh); (void)hipFree(dy);
+    DeviceScratch dx, dh, dy;   // a failed second or third allocation releases the earlier ones
+    dx.alloc(xb);
+    dh.alloc(hb);
+    dy.alloc(yb);
+    SMX_HIP_CHECK(hipMemcpy(dx.p, x, xb, hipMemcpyHostToDevice));
+    SMX_HIP_CHECK(hipMemcpy(dh.p, h, hb, hipMemcpyHostToDevice));
+    shape_dev(dx.as<double>(), dh.as<double>(), dy.as<double>(), lines, n, sl, sm, nullptr);
+    SMX_HIP_CHECK(hipStreamSynchronize(nullptr));
+    SMX_HIP_CHECK(hipMemcpy(y, dy.p, yb, hipMemcpyDeviceToHost));
   });
 }
 

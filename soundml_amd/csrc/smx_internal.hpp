@@ -9,6 +9,7 @@
 #include <cmath>
 #include <cstdint>
 #include <map>
+#include <memory>
 #include <mutex>
 #include <stdexcept>
 #include <string>
@@ -100,6 +101,10 @@ namespace smx {
 // least-squares synthesis envelope of `count` frames (stft.ml:836-889) on the device: head | period | tail | 1.0
 struct EnvelopeTable {
   double *dev = nullptr;
+  // keeps the device copy alive: the cache and every caller that took a descriptor share it, so an eviction by another
+  // thread cannot free a table a launch is about to read; the last holder's hipFree waits for the device, i.e. for every
+  // launch enqueued while a holder existed
+  std::shared_ptr<void> owner;
   size_t head = 0, period = 0, tail = 0;   // doubles in each piece
   int64_t head_n = 0, stop = 0;
   uint64_t serial = 0;   // insertion order in the owning config's cache

@@ -350,11 +350,10 @@ smx::EnvelopeTable smx_stft_config::envelope(int64_t count) const {
   const auto key = std::make_pair(device, count);
   auto it = envelopes_.find(key);
   if (it != envelopes_.end()) return it->second;
-  if (envelopes_.size() >= 64) {   // a caller cycling through many lengths: drop the oldest table (hipFree waits for the
-    auto oldest = envelopes_.begin();   // device, so a launch that still reads it has finished; callers hold copies of
-    for (auto jt = envelopes_.begin(); jt != envelopes_.end(); ++jt)   // the descriptor, never a reference into the map)
+  if (envelopes_.size() >= 64) {   // a caller cycling through many lengths: drop the oldest table.  The cache only gives up
+    auto oldest = envelopes_.begin();   // ITS share: a caller that took the descriptor before keeps the device copy alive
+    for (auto jt = envelopes_.begin(); jt != envelopes_.end(); ++jt)   // until its launch is enqueued (EnvelopeTable::owner)
       if (jt->second.serial < oldest->second.serial) oldest = jt;
-    (void)hipFree(oldest->second.dev);
     envelopes_.erase(oldest);
   }
   std::vector<double> head, period, tail;
@@ -370,12 +369,13 @@ smx::EnvelopeTable smx_stft_config::envelope(int64_t count) const {
   e.period = period.size();
   e.tail = tail.size();
   e.dev = smx::upload(packed);
+  e.owner = std::shared_ptr<void>(e.dev, [](void *p) { (void)hipFree(p); });
   e.serial = ++envelope_serial_;
   return envelopes_.emplace(key, e).first->second;
 }
 
 smx_stft_config::~smx_stft_config() {
-  for (auto &kv : envelopes_) (void)hipFree(kv.second.dev);
+  envelopes_.clear();   // the cache's shares (the device copies go with their last holder)
   for (auto &kv : tables_) {
     smx::StftTables &t = kv.second;
     (void)hipFree(t.window_f64);
