@@ -200,6 +200,28 @@ int smx_stft_kernel_channels(const smx_stft_kernel *k, int64_t *out);
 int smx_stft_kernel_set_channels(smx_stft_kernel *k, int64_t channels);
 const smx_stft_config *smx_stft_kernel_config(const smx_stft_kernel *k);   /* the configuration it was prepared with (borrowed) */
 
+/* ---- Stft.Synthesis (stft.ml:1271-1298; stft.mli:519-591) and the body of synthesis_stage (stft.ml:1417-1442):
+ * incremental least-squares synthesis with the state in device memory.  dtype_bytes 4: complex64 frames in, float32
+ * samples out; 8: complex128 / float64.  step takes k frames [channels; bins; k] (frames fastest) and releases every sample
+ * they settle into out [channels; capacity] (row stride = capacity), reporting how many per channel (0 = the reference's
+ * None); flush drains the trimmed tail.  Any chunking of a stream totals smx_stft_invert of the whole stream, bit for
+ * bit.  sample_bound = the most samples one step of max_block frames or the flush can release (synthesis_stage's
+ * max_items, stft.ml:1421-1427); smx_stft_synthesis_latency = Config.synthesis_latency (stft.ml:152-153).            */
+typedef struct smx_stft_synthesis smx_stft_synthesis;
+int smx_stft_synthesis_prepare(const smx_stft_config *c, int dtype_bytes, int64_t channels, int64_t max_block,
+                               smx_stft_synthesis **out);
+void smx_stft_synthesis_destroy(smx_stft_synthesis *s);
+int64_t smx_stft_synthesis_latency(const smx_stft_config *c);
+int smx_stft_synthesis_sample_bound(const smx_stft_synthesis *s, int64_t *out);
+int smx_stft_synthesis_step(smx_stft_synthesis *s, const void *z, int64_t bins, int64_t k, void *out, int64_t capacity,
+                            int64_t *emitted);
+int smx_stft_synthesis_flush(smx_stft_synthesis *s, void *out, int64_t capacity, int64_t *emitted);
+int smx_stft_synthesis_reset(smx_stft_synthesis *s);
+/* the same on device-resident chunks and outputs (no host copy per push) */
+int smx_stft_synthesis_step_dev(smx_stft_synthesis *s, const void *d_z, int64_t bins, int64_t k, void *d_out,
+                                int64_t capacity, int64_t *emitted, void *stream);
+int smx_stft_synthesis_flush_dev(smx_stft_synthesis *s, void *d_out, int64_t capacity, int64_t *emitted, void *stream);
+
 /* ---- Mel.Config / Mel.apply (mel.ml:22-233) ------------------------------- */
 /* Convert.hz_to_mel / mel_to_hz (convert.ml:70-102): the scalar maps behind the filterbank's breakpoints; host float64 */
 int smx_hz_to_mel(int scale /* SMX_MEL_* */, const double *f, int64_t n, double *out);

@@ -153,6 +153,15 @@ SIGNATURES = {
     "smx_stft_kernel_channels": (cint, [vp, pi64]),
     "smx_stft_kernel_set_channels": (cint, [vp, i64]),
     "smx_stft_kernel_config": (vp, [vp]),
+    "smx_stft_synthesis_prepare": (cint, [vp, cint, i64, i64, C.POINTER(vp)]),
+    "smx_stft_synthesis_destroy": (None, [vp]),
+    "smx_stft_synthesis_latency": (i64, [vp]),
+    "smx_stft_synthesis_sample_bound": (cint, [vp, pi64]),
+    "smx_stft_synthesis_step": (cint, [vp, vp, i64, i64, vp, i64, pi64]),
+    "smx_stft_synthesis_flush": (cint, [vp, vp, i64, pi64]),
+    "smx_stft_synthesis_reset": (cint, [vp]),
+    "smx_stft_synthesis_step_dev": (cint, [vp, vp, i64, i64, vp, i64, pi64, vp]),
+    "smx_stft_synthesis_flush_dev": (cint, [vp, vp, i64, pi64, vp]),
     "smx_mel_config_create": (cint, [i64, i64, i64, f64, cint, f64, cint, cint, C.POINTER(vp)]),
     "smx_mel_config_from_weights": (cint, [i64, i64, vp, C.POINTER(vp)]),
     "smx_mel_config_destroy": (None, [vp]),

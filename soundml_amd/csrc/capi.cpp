@@ -460,6 +460,33 @@ int smx_stft_power_range_f64_dev(const smx_stft_config *c, const double *d_x, in
 
 }  // extern "C"
 
+// ---- Stft.Synthesis (stft.ml:1029-1298): incremental least-squares synthesis ---------------------------------------------
+// The reference keeps the last blocks - 1 WINDOWED frames; here the state is the last blocks - 1 SPECTRA (device,
+// [channels; bins; blocks - 1], frames fastest) and a step runs the offline synthesis kernels over [history ++ new frames]
+// with the envelope of the whole stream (IstftJob::env_q0 / env_open): a frame is inverted by the code that inverts it
+// offline and a position sums its taps in the offline order, so any chunking of a stream totals Stft.invert bit for bit
+// (the reference's law, soundml/test/istft/istft_law.ml) at the price of re-inverting blocks - 1 frames per step.
+// The held quotients (`carry`, stft.ml:1063) and the head-trim counter are as in the reference; absent frames before the
+// stream are zero spectra, whose frames are the exact zeros the reference's overlap-add pads with.
+struct smx_stft_synthesis {
+  const smx_stft_config *cfg = nullptr;
+  int z_bytes = 8;                     // 8 = complex64 in / float32 out, 16 = complex128 / float64
+  int64_t channels = 0, max_block = 0;
+  int64_t left = 0, hold = 0, blocks = 0;
+  int64_t fed = 0, drop = 0;
+  bool drained = false;
+  void *d_hist = nullptr;              // [channels; bins; blocks - 1] complex
+  void *d_local = nullptr;             // [channels; bins; blocks - 1 + cap] complex
+  void *d_quot = nullptr;              // [channels; cap * hop] real
+  void *d_carry = nullptr;             // [channels; hold] real (valid when carry_len == hold)
+  void *d_stage = nullptr;             // host-pointer steps: the chunk and the released samples
+  int64_t cap = 0, carry_len = 0, stage_bytes = 0;
+  int64_t elem() const { return z_bytes / 2; }
+  ~smx_stft_synthesis() {
+    (void)hipFree(d_hist); (void)hipFree(d_local); (void)hipFree(d_quot); (void)hipFree(d_carry); (void)hipFree(d_stage);
+  }
+};
+
 // =============================== Stft.Kernel ==================================
 // Streaming analysis (stft.ml:366-622).  The state machine is the reference's:
 // a prelude until the left extension is computable, the pending padded suffix,
@@ -856,6 +883,220 @@ int smx_stft_kernel_flush(smx_stft_kernel *k, void *out, int64_t capacity, int64
       }
     }
     k->pending_len = 0;
+  });
+}
+
+}  // extern "C"
+
+// =============================== Stft.Synthesis (stft.ml:1029-1298) ============
+namespace smx {
+namespace {
+
+void synth_grow(smx_stft_synthesis &s, int64_t k) {
+  if (k <= s.cap) return;
+  const int64_t cap = std::max<int64_t>(k, std::max<int64_t>(s.max_block, s.blocks));
+  const int64_t bins = s.cfg->bins();
+  SMX_HIP_CHECK(hipFree(s.d_local));
+  SMX_HIP_CHECK(hipFree(s.d_quot));
+  s.d_local = s.d_quot = nullptr;
+  SMX_HIP_CHECK(hipMalloc(&s.d_local, (size_t)s.channels * (size_t)bins * (size_t)(2 * s.blocks + cap) * (size_t)s.z_bytes));
+  SMX_HIP_CHECK(hipMalloc(&s.d_quot, (size_t)s.channels * (size_t)(cap * s.cfg->hop + s.cfg->fft_size) * (size_t)s.elem()));
+  s.cap = cap;
+}
+
+void synth_clear(smx_stft_synthesis &s, hipStream_t stream) {   // stft.ml:1091-1096 `synthesis_reset`
+  s.fed = 0;
+  s.drop = s.left;
+  s.drained = false;
+  s.carry_len = 0;
+  if (s.blocks > 1)   // absent frames before the stream: zero spectra
+    SMX_HIP_CHECK(hipMemsetAsync(s.d_hist, 0, (size_t)s.channels * (size_t)s.cfg->bins() * (size_t)(s.blocks - 1) * (size_t)s.z_bytes, stream));
+}
+
+// quotients of the array's hops [blocks - 1, blocks - 1 + count_out / hop) -> d_quot, released through the carry into d_out
+int64_t synth_emit(smx_stft_synthesis &s, int64_t frames_local, int64_t nq, int64_t env_count, bool open_end, int64_t keep, void *d_out,
+                   int64_t capacity, hipStream_t stream) {
+  const smx_stft_config &c = *s.cfg;
+  IstftJob job;
+  job.cfg = &c;
+  job.z = s.d_local;
+  job.z_bytes = s.z_bytes;
+  job.interior = s.z_bytes == 16 ? SMX_INTERIOR_F64 : g_interior.load();
+  job.lead = s.channels;
+  job.frames = frames_local;
+  job.count = frames_local;
+  job.out_len = nq;
+  job.out = s.d_quot;
+  job.stream = stream;
+  job.left = (s.blocks - 1) * c.hop;
+  job.env_q0 = (s.fed - (s.blocks - 1)) * c.hop;
+  job.env_count = env_count;
+  job.env_open = open_end;
+  launch_istft(job);
+  const int64_t total = s.carry_len + nq, release = total - keep;
+  const int64_t dropped = std::min<int64_t>(s.drop, release);
+  s.drop -= dropped;
+  const int64_t emit = release - dropped;
+  if (emit > capacity) throw Failure("synthesis: output capacity below the samples this call releases");
+  void *carry_next = nullptr;
+  if (keep > 0) SMX_HIP_CHECK(smx::pool_malloc_async(&carry_next, (size_t)s.channels * (size_t)s.hold * (size_t)s.elem(), stream));
+  launch_synthesis_release(s.d_carry, s.carry_len, s.d_quot, nq, s.channels, dropped, release, s.hold > 0 ? s.hold : 1, d_out, capacity,
+                           carry_next, (int)s.elem(), stream);
+  if (keep > 0) {
+    SMX_HIP_CHECK(hipMemcpyAsync(s.d_carry, carry_next, (size_t)s.channels * (size_t)s.hold * (size_t)s.elem(), hipMemcpyDeviceToDevice, stream));
+    SMX_HIP_CHECK(hipFreeAsync(carry_next, stream));
+  }
+  s.carry_len = keep;
+  return emit;
+}
+
+int64_t synth_step_dev(smx_stft_synthesis &s, const void *d_z, int64_t bins, int64_t k, void *d_out, int64_t capacity, hipStream_t stream) {
+  const smx_stft_config &c = *s.cfg;
+  if (s.drained)   // stft.ml:1182-1186
+    throw InvalidArgument("step: cannot feed a drained kernel (flush consumed the tail; reset before reusing)");
+  if (bins != c.bins())   // check_frames "step", stft.ml:753-766
+    throw InvalidArgument(format("step: cannot invert %lld frequency bins of a %lld-point transform (the bin axis must hold "
+                                 "fft_size / 2 + 1 = %lld values)", (long long)bins, (long long)c.fft_size, (long long)c.bins()));
+  if (k < 0) throw Failure("step: negative frame count");
+  if (k == 0) return 0;
+  if (!d_z || !d_out) throw Failure("step: null device pointer");
+  synth_grow(s, k);
+  const int64_t b = s.blocks, rows = s.channels * c.bins();
+  const size_t zb = (size_t)s.z_bytes, lpitch = (size_t)(b - 1 + k) * zb;
+  if (b > 1)
+    SMX_HIP_CHECK(hipMemcpy2DAsync(s.d_local, lpitch, s.d_hist, (size_t)(b - 1) * zb, (size_t)(b - 1) * zb, (size_t)rows, hipMemcpyDeviceToDevice, stream));
+  SMX_HIP_CHECK(hipMemcpy2DAsync(reinterpret_cast<unsigned char *>(s.d_local) + (size_t)(b - 1) * zb, lpitch, d_z, (size_t)k * zb, (size_t)k * zb,
+                                 (size_t)rows, hipMemcpyDeviceToDevice, stream));
+  const int64_t emit = synth_emit(s, b - 1 + k, k * c.hop, 2 * b + 2, true, s.hold, d_out, capacity, stream);
+  if (b > 1)   // the last blocks - 1 spectra of [history ++ chunk]
+    SMX_HIP_CHECK(hipMemcpy2DAsync(s.d_hist, (size_t)(b - 1) * zb, reinterpret_cast<unsigned char *>(s.d_local) + (size_t)k * zb, lpitch,
+                                   (size_t)(b - 1) * zb, (size_t)rows, hipMemcpyDeviceToDevice, stream));
+  s.fed += k;
+  return emit;
+}
+
+int64_t synth_flush_dev(smx_stft_synthesis &s, void *d_out, int64_t capacity, hipStream_t stream) {   // stft.ml:1243-1269
+  if (s.drained) return 0;
+  s.drained = true;
+  const smx_stft_config &c = *s.cfg;
+  const int64_t b = s.blocks, cut = std::max<int64_t>(0, c.fft_size - c.hop - c.right_width());
+  s.carry_len = 0;   // a held tail is a tail the trim discards
+  if (s.fed == 0 || cut == 0) return 0;
+  if (!d_out) throw Failure("flush: null device pointer");
+  synth_grow(s, b);
+  const int64_t rows = s.channels * c.bins();
+  const size_t zb = (size_t)s.z_bytes, lpitch = (size_t)(2 * (b - 1)) * zb;
+  SMX_HIP_CHECK(hipMemsetAsync(s.d_local, 0, lpitch * (size_t)rows, stream));
+  SMX_HIP_CHECK(hipMemcpy2DAsync(s.d_local, lpitch, s.d_hist, (size_t)(b - 1) * zb, (size_t)(b - 1) * zb, (size_t)rows, hipMemcpyDeviceToDevice, stream));
+  return synth_emit(s, 2 * (b - 1), cut, s.fed, false, 0, d_out, capacity, stream);
+}
+
+}  // namespace
+}  // namespace smx
+
+extern "C" {
+
+int smx_stft_synthesis_prepare(const smx_stft_config *c, int dtype_bytes, int64_t channels, int64_t max_block, smx_stft_synthesis **out) {
+  return guarded([&] {
+    check_config(c, "prepare");
+    if (channels < 1)   // stft.ml:1278-1283
+      throw InvalidArgument(format("prepare: cannot synthesise %lld channels (channels must be at least 1)", (long long)channels));
+    if (max_block < 1)  // stft.ml:1284-1289
+      throw InvalidArgument(format("prepare: cannot accept blocks of %lld frames (max_block must be at least 1)", (long long)max_block));
+    if (!stft_nola(*c))  // check_invertible "prepare", stft.ml:742-749
+      throw InvalidArgument(format(
+          "prepare: cannot invert a %lld-point window advanced by %lld samples inside a %lld-point frame (the "
+          "overlap-added squared window must stay above 1e-10 of its largest value at every position)",
+          (long long)c->win_length, (long long)c->hop, (long long)c->fft_size));
+    if (dtype_bytes != 4 && dtype_bytes != 8) throw Failure("prepare: dtype_bytes must be 4 or 8");
+    if (!out) throw Failure("prepare: null output handle");
+    require_device();
+    auto s = std::make_unique<smx_stft_synthesis>();
+    s->cfg = c;
+    s->z_bytes = 2 * dtype_bytes;
+    s->channels = channels;
+    s->max_block = max_block;
+    s->left = c->left_width();
+    s->hold = std::max<int64_t>(0, c->hop + c->right_width() - c->fft_size);   // stft.ml:1073
+    s->blocks = (c->fft_size + c->hop - 1) / c->hop;
+    if (s->blocks > 1)
+      SMX_HIP_CHECK(hipMalloc(&s->d_hist, (size_t)channels * (size_t)c->bins() * (size_t)(s->blocks - 1) * (size_t)s->z_bytes));
+    if (s->hold > 0) SMX_HIP_CHECK(hipMalloc(&s->d_carry, (size_t)channels * (size_t)s->hold * (size_t)s->elem()));
+    synth_clear(*s, nullptr);
+    SMX_HIP_CHECK(hipStreamSynchronize(nullptr));
+    *out = s.release();
+  });
+}
+
+void smx_stft_synthesis_destroy(smx_stft_synthesis *s) { delete s; }
+
+int64_t smx_stft_synthesis_latency(const smx_stft_config *c) {   // Config.synthesis_latency, stft.ml:152-153
+  return c ? c->left_width() + std::max<int64_t>(0, c->hop + c->right_width() - c->fft_size) : -1;
+}
+
+int smx_stft_synthesis_sample_bound(const smx_stft_synthesis *s, int64_t *out) {   // synthesis_stage's out_format, stft.ml:1421-1427
+  return guarded([&] {
+    if (!s || !out) throw Failure("sample_bound: null argument");
+    *out = std::max<int64_t>(s->max_block * s->cfg->hop, s->cfg->fft_size - s->cfg->hop);
+  });
+}
+
+int smx_stft_synthesis_reset(smx_stft_synthesis *s) {
+  return guarded([&] {
+    if (!s) throw Failure("reset: null kernel");
+    synth_clear(*s, nullptr);
+  });
+}
+
+int smx_stft_synthesis_step_dev(smx_stft_synthesis *s, const void *d_z, int64_t bins, int64_t k, void *d_out, int64_t capacity,
+                                int64_t *emitted, void *stream) {
+  return guarded([&] {
+    if (!s || !emitted) throw Failure("step: null argument");
+    *emitted = 0;
+    *emitted = synth_step_dev(*s, d_z, bins, k, d_out, capacity, (hipStream_t)stream);
+  });
+}
+
+int smx_stft_synthesis_flush_dev(smx_stft_synthesis *s, void *d_out, int64_t capacity, int64_t *emitted, void *stream) {
+  return guarded([&] {
+    if (!s || !emitted) throw Failure("flush: null argument");
+    *emitted = 0;
+    *emitted = synth_flush_dev(*s, d_out, capacity, (hipStream_t)stream);
+  });
+}
+
+// host chunks: [channels; bins; k] complex in, [channels; capacity] real out (row stride = capacity)
+int smx_stft_synthesis_step(smx_stft_synthesis *s, const void *z, int64_t bins, int64_t k, void *out, int64_t capacity, int64_t *emitted) {
+  return guarded([&] {
+    if (!s || !emitted) throw Failure("step: null argument");
+    *emitted = 0;
+    if (k > 0 && (!z || !out)) throw Failure("step: null pointer");
+    if (k <= 0 || bins != s->cfg->bins() || s->drained) {   // nothing to move: the device entry states the error or the empty result
+      *emitted = synth_step_dev(*s, z, bins, k, out, capacity, nullptr);
+      return;
+    }
+    const size_t zb = (size_t)s->channels * (size_t)bins * (size_t)k * (size_t)s->z_bytes;
+    const size_t ob = (size_t)s->channels * (size_t)capacity * (size_t)s->elem();
+    DeviceScratch dz(zb), dout(ob);
+    copy_to_device(dz.ptr, z, zb);
+    *emitted = synth_step_dev(*s, dz.ptr, bins, k, dout.ptr, capacity, nullptr);
+    SMX_HIP_CHECK(hipStreamSynchronize(nullptr));
+    if (*emitted > 0) copy_to_host(out, dout.ptr, ob);
+  });
+}
+
+int smx_stft_synthesis_flush(smx_stft_synthesis *s, void *out, int64_t capacity, int64_t *emitted) {
+  return guarded([&] {
+    if (!s || !emitted) throw Failure("flush: null argument");
+    *emitted = 0;
+    const size_t ob = (size_t)s->channels * (size_t)std::max<int64_t>(capacity, 1) * (size_t)s->elem();
+    DeviceScratch dout(ob);
+    *emitted = synth_flush_dev(*s, dout.ptr, capacity, nullptr);
+    SMX_HIP_CHECK(hipStreamSynchronize(nullptr));
+    if (*emitted > 0) {
+      if (!out) throw Failure("flush: null pointer");
+      copy_to_host(out, dout.ptr, ob);
+    }
   });
 }
 

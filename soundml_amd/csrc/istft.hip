@@ -136,6 +136,7 @@ __global__ void __launch_bounds__(256) istft_frames_kernel(IstftArgs a) {
 // frames and start 3 early, the windowed frames stay in their LDS buffers, and the workgroup completes the 13 hops
 // of output no other frame reaches -- no scratch array, no second launch, the reference's summation order.
 struct FusedOla {
+  int64_t env_q0 = 0;   // envelope position of padded position 0 (streaming synthesis: IstftJob::env_q0)
   float *out;               // [lead; out_len]
   int64_t out_len, left, span, head, stop;
   const double *env_head, *env_period, *env_tail;
@@ -295,7 +296,8 @@ __global__ void __launch_bounds__(FT * ((1 << LOG2N) / 32)) istft_stockham_frame
             const int g = fh - d;
             if (valid(g)) acc += slots[g * N + (q - HOP * g)];
           }
-          const double env = Q < o.head ? o.env_head[Q] : (Q < o.stop ? o.env_period[Q & (HOP - 1)] : o.env_tail[Q - o.stop]);
+          const int64_t E = Q + o.env_q0;
+          const double env = E < o.head ? o.env_head[E] : (E < o.stop ? o.env_period[E & (HOP - 1)] : o.env_tail[E - o.stop]);
           v = (float)((double)acc / env);
         }
         out[mo] = v;
@@ -450,6 +452,7 @@ bool launch_stockham_frames_any(const IstftArgs &a, const StftTables &t, hipStre
 }
 
 struct OlaArgs {
+  int64_t env_q0 = 0;   // envelope position of padded position 0 (streaming synthesis: IstftJob::env_q0)
   const void *y;        // [lead; count; fft]
   void *out;            // [lead; out_len]
   int64_t lead, count, fft, hop, left, out_len, span;
@@ -474,7 +477,8 @@ __global__ void __launch_bounds__(256) istft_ola_kernel(OlaArgs a) {
   int64_t p_lo = q - a.fft + 1 <= 0 ? 0 : (q - a.fft + 1 + a.hop - 1) / a.hop;
   Tacc acc = (Tacc)0;
   for (int64_t p = p_hi; p >= p_lo; --p) acc += y[p * a.fft + (q - p * a.hop)];
-  const double env = q < a.head ? a.env_head[q] : (q < a.stop ? a.env_period[q % a.hop] : a.env_tail[q - a.stop]);
+  const int64_t e = q + a.env_q0;
+  const double env = e < a.head ? a.env_head[e] : (e < a.stop ? a.env_period[e % a.hop] : a.env_tail[e - a.stop]);
   out[m] = (Tout)((double)acc / env);
 }
 
@@ -499,6 +503,7 @@ constexpr size_t kSynRegionA = 2 * kSynPlane > (size_t)kSynFrames * kSynM * 8 ? 
 constexpr size_t kSynLds = ((kSynRegionA + 15) / 16) * 16 + (size_t)kSynM * sizeof(float2);
 
 struct SynArgs {
+  int64_t env_q0 = 0;   // envelope position of padded position 0 (streaming synthesis: IstftJob::env_q0)
   const float2 *z;       // [lead; 1025; frames]
   float *out;            // [lead; out_len]
   int64_t frames, count, out_len, left, span;
@@ -664,7 +669,8 @@ __global__ void __launch_bounds__(1024) istft2048_kernel(SynArgs a) {
             const int64_t p = f_lo + f;
             if (p >= 0 && p < a.count) acc += slots[f * 2048 + (q - 512 * f)];
           }
-          const double env = Q < a.head ? a.env_head[Q] : (Q < a.stop ? a.env_period[Q & 511] : a.env_tail[Q - a.stop]);
+          const int64_t E = Q + a.env_q0;
+          const double env = E < a.head ? a.env_head[E] : (E < a.stop ? a.env_period[E & 511] : a.env_tail[E - a.stop]);
           v = (float)((double)acc / env);
         }
         out[mo] = v;
@@ -858,6 +864,35 @@ bool istft_takes_factors(const IstftJob &job) {
   return istft_fused_2048(job) || (!fast_off && !f64 && (n == 512 || n == 1024 || n == 2048 || n == 4096));
 }
 
+template <typename T>
+__global__ void __launch_bounds__(256) synthesis_release_kernel(const T *carry, int64_t carry_len, const T *quot, int64_t nq, int64_t drop,
+                                                                int64_t release, int64_t hold, T *out, int64_t out_stride, T *carry_out) {
+  const int64_t ch = blockIdx.y, total = carry_len + nq;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const T v = i < carry_len ? carry[ch * hold + i] : quot[ch * nq + (i - carry_len)];
+    if (i >= release) carry_out[ch * hold + (i - release)] = v;
+    else if (i >= drop) out[ch * out_stride + (i - drop)] = v;
+  }
+}
+
+void launch_synthesis_release(const void *carry, int64_t carry_len, const void *quot, int64_t nq, int64_t channels, int64_t drop,
+                              int64_t release, int64_t hold, void *out, int64_t out_stride, void *carry_out, int elem_bytes,
+                              hipStream_t stream) {
+  const int64_t total = carry_len + nq;
+  if (channels <= 0 || total <= 0) return;
+  if (channels > 65535) throw Failure("synthesis: more than 65535 channels in one call");
+  dim3 grid((unsigned)std::min<int64_t>((total + 255) / 256, 1024), (unsigned)channels);
+  if (elem_bytes == 8)
+    SMX_LAUNCH(synthesis_release_kernel<double>, grid, dim3(256), 0, stream, reinterpret_cast<const double *>(carry), carry_len,
+               reinterpret_cast<const double *>(quot), nq, drop, release, hold, reinterpret_cast<double *>(out), out_stride,
+               reinterpret_cast<double *>(carry_out));
+  else
+    SMX_LAUNCH(synthesis_release_kernel<float>, grid, dim3(256), 0, stream, reinterpret_cast<const float *>(carry), carry_len,
+               reinterpret_cast<const float *>(quot), nq, drop, release, hold, reinterpret_cast<float *>(out), out_stride,
+               reinterpret_cast<float *>(carry_out));
+  SMX_HIP_CHECK(hipGetLastError());
+}
+
 void launch_istft(const IstftJob &job) {
   const smx_stft_config &c = *job.cfg;
   if (job.mag && !istft_takes_factors(job)) throw Failure("istft: factors are only taken by the fused kernel");
@@ -872,9 +907,10 @@ void launch_istft(const IstftJob &job) {
   const int64_t fft = c.fft_size, hop = c.hop, count = job.count;
   const int64_t span = (count - 1) * hop + fft;
   // envelope pieces: host float64 in the reference's summation order, cached on the device per (config, count)
-  const EnvelopeTable env = c.envelope(count);
+  const EnvelopeTable env = c.envelope(job.env_count > 0 ? job.env_count : count);
   const double *d_env = env.dev;
-  const int64_t head_n = env.head_n, stop = env.stop;
+  const int64_t head_n = env.head_n, stop = job.env_open ? (int64_t(1) << 60) : env.stop;
+  const int64_t left = job.left >= 0 ? job.left : c.left_width();
   // fused path: fft 2048, hop 512, complex64 spectrum, float32 interior
   if (istft_fused_2048(job) && !std::getenv("SMX_ISTFT_NEW2048")) {
     SynArgs sa{};
@@ -887,7 +923,8 @@ void launch_istft(const IstftJob &job) {
     sa.frames = job.frames;
     sa.count = count;
     sa.out_len = job.out_len;
-    sa.left = c.left_width();
+    sa.left = left;
+    sa.env_q0 = job.env_q0;
     sa.span = span;
     // tiles cover padded positions [0, 512 * 13 * tiles): everything the output can ask for
     const int64_t need = std::max<int64_t>(span, sa.left + job.out_len);
@@ -932,7 +969,8 @@ void launch_istft(const IstftJob &job) {
     FusedOla o{};
     o.out = reinterpret_cast<float *>(job.out);
     o.out_len = job.out_len;
-    o.left = c.left_width();
+    o.left = left;
+    o.env_q0 = job.env_q0;
     o.span = span;
     o.head = head_n;
     o.stop = stop;
@@ -990,7 +1028,8 @@ void launch_istft(const IstftJob &job) {
     oa.count = count;
     oa.fft = fft;
     oa.hop = hop;
-    oa.left = c.left_width();
+    oa.left = left;
+    oa.env_q0 = job.env_q0;
     oa.out_len = job.out_len;
     oa.span = span;
     oa.env_head = d_env;

@@ -273,8 +273,20 @@ struct IstftJob {
   const void *prev = nullptr;
   double beta = 0.0;
   hipStream_t stream = nullptr;
+  // Streaming synthesis (Stft.Synthesis, stft.ml:1181-1269) runs the same kernels on the LAST frames of a longer synthesis:
+  // the array's padded position 0 is position env_q0 of that synthesis (a multiple of the hop, negative while the stream is
+  // younger than a frame), out[0] is the array's padded position `left` (default: the configuration's left width), the
+  // envelope is that of an env_count-frame synthesis (default: count), and with env_open the synthesis goes on after these
+  // frames (no tail region: every position read is settled, stft.ml:1137-1142)
+  int64_t left = -1, env_q0 = 0, env_count = 0;
+  bool env_open = false;
 };
 void launch_istft(const IstftJob &job);           // istft.hip
+// Stft.Synthesis' release (stft.ml:1172-1179, 1229-1241): stream = carry ++ quot per channel; out gets stream[drop, release),
+// carry_out gets stream[release, carry_len + nq).  Rows: carry / carry_out `hold` apart, quot `nq` apart, out `out_stride` apart.
+void launch_synthesis_release(const void *carry, int64_t carry_len, const void *quot, int64_t nq, int64_t channels, int64_t drop,
+                              int64_t release, int64_t hold, void *out, int64_t out_stride, void *carry_out, int elem_bytes,
+                              hipStream_t stream);   // istft.hip
 bool istft_takes_factors(const IstftJob &job);    // istft.hip: the fused fft-2048 / hop-512 kernel does
 
 // elementwise steps of Stft.griffin_lim (griffinlim.hip); elem_bytes 4 = float32 / complex64, 8 = float64 / complex128

@@ -378,6 +378,82 @@ class Kernel:
         check(lib.smx_stft_kernel_reset(self._h))
 
 
+class Synthesis:
+    """``Stft.Synthesis`` (stft.ml:1271-1298, stft.mli:519-591): incremental least-squares synthesis, the state (the last
+    ``ceil(fft/hop) - 1`` spectra and the held samples) in device memory.  ``step`` takes frames ``[channels; bins; k]``
+    (numpy complex64 / complex128, or a device-resident torch tensor: then nothing crosses the host) and returns the
+    samples they settle ``[channels; m]`` or ``None``; ``flush`` drains the trimmed tail.  Any chunking of a stream
+    totals ``Stft.invert`` of the whole stream, bit for bit.  Mutable, single-owner."""
+
+    def __init__(self, handle, cfg, dtype, channels):
+        self._h, self._cfg, self._dtype, self._channels = handle, cfg, np.dtype(dtype), channels
+        bound = C.c_int64()
+        check(lib.smx_stft_synthesis_sample_bound(self._h, C.byref(bound)))
+        self.sample_bound = bound.value
+
+    @staticmethod
+    def prepare(c: Config, dtype, channels: int, max_block: int) -> "Synthesis":
+        handle = C.c_void_p()
+        dt = np.dtype(dtype)
+        wide = dt in (np.dtype(np.float64), np.dtype(np.complex128))
+        check(lib.smx_stft_synthesis_prepare(c._h, 8 if wide else 4, int(channels), int(max_block), C.byref(handle)))
+        return Synthesis(handle, c, np.float64 if wide else np.float32, int(channels))
+
+    def __del__(self):
+        h, self._h = getattr(self, "_h", None), None
+        if h and lib is not None:
+            try:
+                lib.smx_stft_synthesis_destroy(h)
+            except Exception:
+                pass
+
+    @staticmethod
+    def latency(c: Config) -> int:
+        """``Config.synthesis_latency`` (stft.ml:152-153), in output samples."""
+        return int(lib.smx_stft_synthesis_latency(c._h))
+
+    def _capacity(self, k):
+        cfg = self._cfg
+        return max(k * cfg.hop, cfg.fft_size) + cfg.hop
+
+    def step(self, z):
+        from ._tensor import is_device, is_torch
+        shape = tuple(z.shape)
+        if len(shape) < 2:   # check_frames, stft.ml:753-759
+            raise _lib.InvalidArgument("step: cannot invert a rank-%d tensor (the bin and frame axes must exist)" % len(shape))
+        if 0 in shape[:-2]:  # stft.ml:1189-1193
+            raise _lib.InvalidArgument("step: cannot synthesise frames with a zero-size leading axis (channels must be at least 1)")
+        bins, k = int(shape[-2]), int(shape[-1])
+        cdt = np.complex128 if self._dtype == np.float64 else np.complex64
+        cap = self._capacity(k)
+        emitted = C.c_int64()
+        if is_device(z):
+            import torch
+            tz = z.to(torch.complex128 if self._dtype == np.float64 else torch.complex64).contiguous()
+            zr = torch.view_as_real(tz)
+            out = torch.empty((self._channels, cap), device=z.device, dtype=torch.float64 if self._dtype == np.float64 else torch.float32)
+            with torch.cuda.device(z.device):
+                stream = C.c_void_p(torch.cuda.current_stream(z.device).cuda_stream)
+                check(lib.smx_stft_synthesis_step_dev(self._h, C.c_void_p(zr.data_ptr()), bins, k, C.c_void_p(out.data_ptr()), cap,
+                                                      C.byref(emitted), stream))
+            return None if emitted.value == 0 else out[:, :emitted.value].contiguous()
+        a = z.detach().cpu().numpy() if is_torch(z) else np.asarray(z)
+        a = np.ascontiguousarray(a.astype(cdt, copy=False)).reshape(self._channels, bins, k)
+        out = np.zeros((self._channels, cap), dtype=self._dtype)
+        check(lib.smx_stft_synthesis_step(self._h, C.c_void_p(a.ctypes.data), bins, k, C.c_void_p(out.ctypes.data), cap, C.byref(emitted)))
+        return None if emitted.value == 0 else np.ascontiguousarray(out[:, :emitted.value])
+
+    def flush(self):
+        cap = self._capacity(0)
+        out = np.zeros((self._channels, cap), dtype=self._dtype)
+        emitted = C.c_int64()
+        check(lib.smx_stft_synthesis_flush(self._h, C.c_void_p(out.ctypes.data), cap, C.byref(emitted)))
+        return None if emitted.value == 0 else np.ascontiguousarray(out[:, :emitted.value])
+
+    def reset(self):
+        check(lib.smx_stft_synthesis_reset(self._h))
+
+
 # ---- Pipeline-stage faces (stft.ml:1301-1409) ---------------------------------------------------------------
 # The reference wraps the streaming state machine as Pipeline stages; the algebra of Pipeline itself is out of
 # scope here, but the numbers a stage declares and the step / flush / reset / concat bodies are these.
