@@ -191,6 +191,12 @@ int smx_stft_kernel_step(smx_stft_kernel *k, const void *chunk /* host [channels
                          void *out_complex, int64_t capacity, int64_t *emitted);
 int smx_stft_kernel_flush(smx_stft_kernel *k, void *out_complex, int64_t capacity, int64_t *emitted);
 int smx_stft_kernel_reset(smx_stft_kernel *k);
+/* the same state machine fed from and emitting into DEVICE memory (chunk rows x_stride samples apart; the window
+ * [channels; bins; capacity] as above): a push moves nothing over the host link.  The frame count comes back on the host
+ * (it is bookkeeping of lengths, known before any kernel runs); the frames are ready in stream order.                */
+int smx_stft_kernel_step_dev(smx_stft_kernel *k, const void *d_chunk, int64_t m, int64_t x_stride, void *d_out,
+                             int64_t capacity, int64_t *emitted, void *stream);
+int smx_stft_kernel_flush_dev(smx_stft_kernel *k, void *d_out, int64_t capacity, int64_t *emitted, void *stream);
 /* The reference's state takes its leading shape from the chunks it is fed (stft.ml:521-559: only `channels >= 1` is checked
  * at prepare, stft.ml:603-617), so a binding must be able to follow the first chunk: channels() reports the count the
  * kernel was prepared for (step / flush read and write exactly that many rows: a caller passes buffers of that extent),

@@ -150,6 +150,8 @@ SIGNATURES = {
     "smx_stft_kernel_step": (cint, [vp, vp, i64, vp, i64, pi64]),
     "smx_stft_kernel_flush": (cint, [vp, vp, i64, pi64]),
     "smx_stft_kernel_reset": (cint, [vp]),
+    "smx_stft_kernel_step_dev": (cint, [vp, vp, i64, i64, vp, i64, pi64, vp]),
+    "smx_stft_kernel_flush_dev": (cint, [vp, vp, i64, pi64, vp]),
     "smx_stft_kernel_channels": (cint, [vp, pi64]),
     "smx_stft_kernel_set_channels": (cint, [vp, i64]),
     "smx_stft_kernel_config": (vp, [vp]),

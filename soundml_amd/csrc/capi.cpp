@@ -501,11 +501,11 @@ struct smx_stft_kernel {
   bool started = false, drained = false;
   int64_t received = 0;
   int64_t skip = 0;
-  // host-side mirrors of the small carried pieces (prelude and tail are at most
-  // left+1 / right+1 samples per channel); the pending padded suffix is on device
-  std::vector<unsigned char> prelude;   // [channels][prelude_len]
-  int64_t prelude_len = 0;
-  std::vector<unsigned char> tail;      // [channels][tail_len]
+  // the small carried pieces live on the device too (prelude and tail are at most left + 1 / right + 1 samples per
+  // channel), so a step on a device-resident chunk moves nothing over the host link
+  void *d_prelude = nullptr;            // [channels][prelude_cap], prelude_len valid
+  int64_t prelude_len = 0, prelude_cap = 0;
+  void *d_tail = nullptr;               // [channels][right + 1], tail_len valid
   int64_t tail_len = 0;
   void *d_stream = nullptr;             // device [channels][cap]: pending ++ new padded samples
   int64_t cap = 0;
@@ -520,6 +520,8 @@ struct smx_stft_kernel {
   ~smx_stft_kernel() {
     (void)hipFree(d_stream);
     (void)hipFree(d_out);
+    (void)hipFree(d_prelude);
+    (void)hipFree(d_tail);
   }
 };
 
@@ -547,29 +549,91 @@ void ensure_stream(smx_stft_kernel &k, int64_t need) {
   k.cap = cap;
 }
 
-// stft.ml:415-442 `process`: append `extra` ([channels][extra_len] host, stream
-// order) to the pending padded stream and emit every frame that became complete.
-int64_t process(smx_stft_kernel &k, const unsigned char *extra, int64_t extra_len, void *out,
-                int64_t capacity) {
+// One row-wise copy between device arrays: len elements per channel from src[ch][src_off ..] to dst[ch][dst_off ..]
+// (strides in elements).  Ranges of one array may not overlap.
+void rows_copy(void *dst, int64_t dst_stride, int64_t dst_off, const void *src, int64_t src_stride, int64_t src_off, int64_t len,
+               int64_t channels, size_t es, hipStream_t stream) {
+  if (len <= 0 || channels <= 0) return;
+  SMX_HIP_CHECK(hipMemcpy2DAsync(reinterpret_cast<unsigned char *>(dst) + (size_t)dst_off * es, (size_t)dst_stride * es,
+                                 reinterpret_cast<const unsigned char *>(src) + (size_t)src_off * es, (size_t)src_stride * es,
+                                 (size_t)len * es, (size_t)channels, hipMemcpyDeviceToDevice, stream));
+}
+
+// The three border gathers of the state machine, on the device (kind 0: the left extension at install, stft.ml:457-471
+// `left_pad`: reflect reads x[left - j], edge x[0]; kind 1: `pad_signal` of a stream that never reached the install
+// threshold, stft.ml:318-338; kind 2: the right extension at the drain, stft.ml:506-519 `right_pad`: reflect reads
+// tail[len - 2 - i], edge tail[len - 1]); constant padding writes the value.
+template <typename T>
+__global__ void __launch_bounds__(256) stream_pad_kernel(T *dst, int64_t dst_stride, int64_t count, const T *src, int64_t src_stride,
+                                                         int64_t src_len, int kind, int pad, T value, int64_t left) {
+  const int64_t ch = blockIdx.y;
+  for (int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x; j < count; j += (int64_t)gridDim.x * 256) {
+    int64_t idx = -1;
+    if (pad != SMX_PAD_CONSTANT) {
+      if (kind == 0) idx = pad == SMX_PAD_REFLECT ? left - j : 0;
+      else if (kind == 2) idx = pad == SMX_PAD_REFLECT ? src_len - 2 - j : src_len - 1;
+      else {
+        const int64_t q = j - left;
+        if (q >= 0 && q < src_len) idx = q;
+        else if (pad == SMX_PAD_REFLECT) {
+          if (src_len == 1) idx = 0;
+          else {
+            const int64_t period = 2 * (src_len - 1);
+            const int64_t m = ((q % period) + period) % period;
+            idx = m < src_len ? m : period - m;
+          }
+        } else idx = q < 0 ? 0 : src_len - 1;
+      }
+    } else if (kind == 1) {
+      const int64_t q = j - left;
+      if (q >= 0 && q < src_len) idx = q;
+    }
+    dst[ch * dst_stride + j] = idx < 0 ? value : src[ch * src_stride + idx];
+  }
+}
+
+void stream_pad(smx_stft_kernel &k, void *dst, int64_t dst_stride, int64_t count, const void *src, int64_t src_stride, int64_t src_len,
+                int kind, hipStream_t stream) {
+  if (count <= 0) return;
+  if (k.channels > 65535) throw Failure("step: more than 65535 channels in one stream");
+  dim3 grid((unsigned)std::min<int64_t>((count + 255) / 256, 256), (unsigned)k.channels);
+  if (k.dtype_bytes == 4)
+    SMX_LAUNCH(stream_pad_kernel<float>, grid, dim3(256), 0, stream, reinterpret_cast<float *>(dst), dst_stride, count,
+               reinterpret_cast<const float *>(src), src_stride, src_len, kind, k.cfg->pad, (float)k.cfg->pad_value, k.left);
+  else
+    SMX_LAUNCH(stream_pad_kernel<double>, grid, dim3(256), 0, stream, reinterpret_cast<double *>(dst), dst_stride, count,
+               reinterpret_cast<const double *>(src), src_stride, src_len, kind, k.cfg->pad, (double)k.cfg->pad_value, k.left);
+  SMX_HIP_CHECK(hipGetLastError());
+}
+
+// where a call's frames go: the caller's window [channels; bins; capacity], in host or device memory
+struct StreamOut {
+  void *ptr;
+  int64_t capacity;
+  bool on_device;
+};
+
+// stft.ml:415-442 `process`: append `extra` (device rows, extra_stride apart, from element extra_off) to the pending padded
+// stream and emit every frame that became complete.
+int64_t process(smx_stft_kernel &k, const void *extra, int64_t extra_stride, int64_t extra_off, int64_t extra_len, const StreamOut &out,
+                hipStream_t stream) {
   const smx_stft_config &c = *k.cfg;
   const int64_t fft = c.fft_size, hop = c.hop;
   const size_t es = (size_t)k.dtype_bytes;
   const int64_t total = k.pending_len + extra_len;
   ensure_stream(k, total);
-  if (extra_len > 0)
-    SMX_HIP_CHECK(hipMemcpy2D((unsigned char *)k.d_stream + (size_t)k.pending_len * es, (size_t)k.cap * es,
-                              extra, (size_t)extra_len * es, (size_t)extra_len * es, (size_t)k.channels,
-                              hipMemcpyHostToDevice));
+  rows_copy(k.d_stream, k.cap, k.pending_len, extra, extra_stride, extra_off, extra_len, k.channels, es, stream);
   const int64_t count = total < fft ? 0 : 1 + (total - fft) / hop;
   if (count == 0) {
     k.pending_len = total;
     return 0;
   }
-  if (count > capacity)
+  if (count > out.capacity)
     throw Failure(format("step: %lld frames do not fit the caller's %lld-frame output window",
-                         (long long)count, (long long)capacity));
+                         (long long)count, (long long)out.capacity));
   const int64_t bins = c.bins();
   if (count > k.out_cap) {
+    SMX_HIP_CHECK(hipStreamSynchronize(stream));
     (void)hipFree(k.d_out);
     k.d_out = nullptr;
     int64_t cap = k.out_cap ? k.out_cap : 16;
@@ -595,11 +659,18 @@ int64_t process(smx_stft_kernel &k, const unsigned char *extra, int64_t extra_le
   job.out = k.d_out;
   job.out_stride = count;
   job.out_offset = 0;
+  job.stream = stream;
   launch_stft(job);
   // [channels; bins; count] (dense) -> caller's [channels; bins; capacity] window
   const size_t vs = (size_t)k.values() * es;
-  SMX_HIP_CHECK(hipMemcpy2D(out, (size_t)capacity * vs, k.d_out, (size_t)count * vs, (size_t)count * vs,
-                            (size_t)(k.channels * bins), hipMemcpyDeviceToHost));
+  if (out.on_device) {
+    SMX_HIP_CHECK(hipMemcpy2DAsync(out.ptr, (size_t)out.capacity * vs, k.d_out, (size_t)count * vs, (size_t)count * vs,
+                                   (size_t)(k.channels * bins), hipMemcpyDeviceToDevice, stream));
+  } else {
+    SMX_HIP_CHECK(hipStreamSynchronize(stream));
+    SMX_HIP_CHECK(hipMemcpy2D(out.ptr, (size_t)out.capacity * vs, k.d_out, (size_t)count * vs, (size_t)count * vs,
+                              (size_t)(k.channels * bins), hipMemcpyDeviceToHost));
+  }
   const int64_t next_start = count * hop;
   if (next_start >= total) {
     k.skip += next_start - total;
@@ -607,98 +678,145 @@ int64_t process(smx_stft_kernel &k, const unsigned char *extra, int64_t extra_le
   } else {
     const int64_t keep = total - next_start;
     // move the suffix to the front (rows are independent; overlapping ranges -> staged copy)
-    DeviceScratch tmp((size_t)k.channels * (size_t)keep * es);
-    SMX_HIP_CHECK(hipMemcpy2D(tmp.ptr, (size_t)keep * es,
-                              (unsigned char *)k.d_stream + (size_t)next_start * es, (size_t)k.cap * es,
-                              (size_t)keep * es, (size_t)k.channels, hipMemcpyDeviceToDevice));
-    SMX_HIP_CHECK(hipMemcpy2D(k.d_stream, (size_t)k.cap * es, tmp.ptr, (size_t)keep * es,
-                              (size_t)keep * es, (size_t)k.channels, hipMemcpyDeviceToDevice));
+    void *tmp = nullptr;
+    SMX_HIP_CHECK(smx::pool_malloc_async(&tmp, (size_t)k.channels * (size_t)keep * es, stream));
+    rows_copy(tmp, keep, 0, k.d_stream, k.cap, next_start, keep, k.channels, es, stream);
+    rows_copy(k.d_stream, k.cap, 0, tmp, keep, 0, keep, k.channels, es, stream);
+    SMX_HIP_CHECK(hipFreeAsync(tmp, stream));
     k.pending_len = keep;
   }
   return count;
-}
-
-template <typename T>
-void gather_rows(std::vector<unsigned char> &dst, const unsigned char *src, int64_t channels,
-                 int64_t src_len, const std::vector<int64_t> &idx, double constant, bool use_constant) {
-  dst.resize((size_t)channels * idx.size() * sizeof(T));
-  T *d = reinterpret_cast<T *>(dst.data());
-  const T *s = reinterpret_cast<const T *>(src);
-  for (int64_t ch = 0; ch < channels; ++ch)
-    for (size_t j = 0; j < idx.size(); ++j)
-      d[(size_t)ch * idx.size() + j] =
-          (use_constant || idx[j] < 0) ? (T)constant : s[(size_t)ch * (size_t)src_len + (size_t)idx[j]];
-}
-
-void gather(smx_stft_kernel &k, std::vector<unsigned char> &dst, const unsigned char *src, int64_t src_len,
-            const std::vector<int64_t> &idx) {
-  const bool constant = k.cfg->pad == SMX_PAD_CONSTANT;
-  if (k.dtype_bytes == 4)
-    gather_rows<float>(dst, src, k.channels, src_len, idx, k.cfg->pad_value, constant);
-  else
-    gather_rows<double>(dst, src, k.channels, src_len, idx, k.cfg->pad_value, constant);
-}
-
-// rows [channels][a_len] ++ [channels][b_len] -> [channels][a_len + b_len]
-std::vector<unsigned char> concat_rows(const unsigned char *a, int64_t a_len, const unsigned char *b,
-                                       int64_t b_len, int64_t channels, size_t es) {
-  std::vector<unsigned char> out((size_t)channels * (size_t)(a_len + b_len) * es);
-  for (int64_t ch = 0; ch < channels; ++ch) {
-    unsigned char *row = out.data() + (size_t)ch * (size_t)(a_len + b_len) * es;
-    if (a_len) std::memcpy(row, a + (size_t)ch * (size_t)a_len * es, (size_t)a_len * es);
-    if (b_len) std::memcpy(row + (size_t)a_len * es, b + (size_t)ch * (size_t)b_len * es, (size_t)b_len * es);
-  }
-  return out;
-}
-
-std::vector<unsigned char> slice_rows(const unsigned char *a, int64_t a_len, int64_t start, int64_t stop,
-                                      int64_t channels, size_t es) {
-  const int64_t len = stop - start;
-  std::vector<unsigned char> out((size_t)channels * (size_t)len * es);
-  for (int64_t ch = 0; ch < channels; ++ch)
-    std::memcpy(out.data() + (size_t)ch * (size_t)len * es,
-                a + ((size_t)ch * (size_t)a_len + (size_t)start) * es, (size_t)len * es);
-  return out;
 }
 
 int64_t install_threshold(const smx_stft_config &c) {  // stft.ml:447-452
   return c.pad == SMX_PAD_REFLECT ? c.left_width() + 1 : 1;
 }
 
-void update_tail(smx_stft_kernel &k, const unsigned char *chunk, int64_t m) {  // stft.ml:492-502
+// the last `right + 1` samples of [old tail ++ chunk] (stft.ml:492-502 `update_tail`; stft.ml:480-483 at install)
+void update_tail(smx_stft_kernel &k, const void *chunk, int64_t chunk_stride, int64_t m, hipStream_t stream) {
   const size_t es = (size_t)k.dtype_bytes;
   const int64_t keep = k.right + 1;
+  if (!k.d_tail) SMX_HIP_CHECK(hipMalloc(&k.d_tail, (size_t)k.channels * (size_t)keep * es));
   if (m >= keep) {
-    k.tail = slice_rows(chunk, m, m - keep, m, k.channels, es);
+    rows_copy(k.d_tail, keep, 0, chunk, chunk_stride, m - keep, keep, k.channels, es, stream);
     k.tail_len = keep;
-  } else {
-    std::vector<unsigned char> combined = concat_rows(k.tail.data(), k.tail_len, chunk, m, k.channels, es);
-    const int64_t cm = k.tail_len + m;
-    const int64_t start = cm - keep > 0 ? cm - keep : 0;
-    k.tail = slice_rows(combined.data(), cm, start, cm, k.channels, es);
-    k.tail_len = cm - start;
+    return;
   }
+  const int64_t cm = k.tail_len + m, start = cm - keep > 0 ? cm - keep : 0, kept_old = k.tail_len - start;
+  if (start > 0 && kept_old > 0) {   // shift the surviving part of the old tail to the front (staged: the ranges overlap)
+    void *tmp = nullptr;
+    SMX_HIP_CHECK(smx::pool_malloc_async(&tmp, (size_t)k.channels * (size_t)kept_old * es, stream));
+    rows_copy(tmp, kept_old, 0, k.d_tail, keep, start, kept_old, k.channels, es, stream);
+    rows_copy(k.d_tail, keep, 0, tmp, kept_old, 0, kept_old, k.channels, es, stream);
+    SMX_HIP_CHECK(hipFreeAsync(tmp, stream));
+  }
+  const int64_t old = kept_old > 0 ? kept_old : 0;
+  // (start >= tail_len cannot happen: then m >= keep)
+  rows_copy(k.d_tail, keep, old, chunk, chunk_stride, 0, m, k.channels, es, stream);
+  k.tail_len = old + m;
 }
 
-int64_t install(smx_stft_kernel &k, const unsigned char *x, int64_t n, void *out, int64_t capacity) {
-  // stft.ml:476-488
+// stft.ml:476-488 `install`: x = [prelude ++ chunk] (device rows, x_stride apart), n samples
+int64_t install(smx_stft_kernel &k, const void *x, int64_t x_stride, int64_t n, const StreamOut &out, hipStream_t stream) {
   const size_t es = (size_t)k.dtype_bytes;
   if (k.right > 0) {
+    k.tail_len = 0;
     const int64_t keep = k.right + 1 < n ? k.right + 1 : n;
-    k.tail = slice_rows(x, n, n - keep, n, k.channels, es);
+    if (!k.d_tail) SMX_HIP_CHECK(hipMalloc(&k.d_tail, (size_t)k.channels * (size_t)(k.right + 1) * es));
+    rows_copy(k.d_tail, k.right + 1, 0, x, x_stride, n - keep, keep, k.channels, es, stream);
     k.tail_len = keep;
   }
   k.started = true;
-  k.prelude.clear();
   k.prelude_len = 0;
-  if (k.left == 0) return process(k, x, n, out, capacity);
-  std::vector<int64_t> idx((size_t)k.left);  // stft.ml:457-471 left_pad
-  for (int64_t j = 0; j < k.left; ++j)
-    idx[(size_t)j] = k.cfg->pad == SMX_PAD_REFLECT ? k.left - j : 0;
-  std::vector<unsigned char> lp;
-  gather(k, lp, x, n, idx);
-  std::vector<unsigned char> both = concat_rows(lp.data(), k.left, x, n, k.channels, es);
-  return process(k, both.data(), k.left + n, out, capacity);
+  if (k.left == 0) return process(k, x, x_stride, 0, n, out, stream);
+  void *both = nullptr;   // [left extension ++ x]
+  const int64_t bl = k.left + n;
+  SMX_HIP_CHECK(smx::pool_malloc_async(&both, (size_t)k.channels * (size_t)bl * es, stream));
+  stream_pad(k, both, bl, k.left, x, x_stride, n, 0, stream);
+  rows_copy(both, bl, k.left, x, x_stride, 0, n, k.channels, es, stream);
+  const int64_t emitted = process(k, both, bl, 0, bl, out, stream);
+  SMX_HIP_CHECK(hipFreeAsync(both, stream));
+  return emitted;
+}
+
+// Kernel.step on a device-resident chunk [channels][m] (rows chunk_stride apart): stft.ml:521-559
+int64_t step_core(smx_stft_kernel &k, const void *chunk, int64_t chunk_stride, int64_t m, const StreamOut &out, hipStream_t stream) {
+  if (k.drained)
+    throw InvalidArgument("step: cannot feed a drained kernel (flush consumed the tail; reset before reusing)");
+  if (m < 0) throw Failure("step: negative chunk length");
+  if (m == 0) return 0;
+  if (!chunk) throw Failure("step: null chunk");
+  const size_t es = (size_t)k.dtype_bytes;
+  k.received += m;
+  if (!k.started) {
+    const int64_t n = k.prelude_len + m;
+    if (k.received >= install_threshold(*k.cfg)) {
+      if (k.prelude_len == 0) return install(k, chunk, chunk_stride, m, out, stream);
+      void *x = nullptr;
+      SMX_HIP_CHECK(smx::pool_malloc_async(&x, (size_t)k.channels * (size_t)n * es, stream));
+      rows_copy(x, n, 0, k.d_prelude, k.prelude_cap, 0, k.prelude_len, k.channels, es, stream);
+      rows_copy(x, n, k.prelude_len, chunk, chunk_stride, 0, m, k.channels, es, stream);
+      const int64_t emitted = install(k, x, n, n, out, stream);
+      SMX_HIP_CHECK(hipFreeAsync(x, stream));
+      return emitted;
+    }
+    if (n > k.prelude_cap) {   // below the install threshold: at most left samples ever wait here
+      const int64_t cap = std::max<int64_t>(n, k.left + 1);
+      void *fresh = nullptr;
+      SMX_HIP_CHECK(hipMalloc(&fresh, (size_t)k.channels * (size_t)cap * es));
+      rows_copy(fresh, cap, 0, k.d_prelude, k.prelude_cap, 0, k.prelude_len, k.channels, es, stream);
+      SMX_HIP_CHECK(hipStreamSynchronize(stream));
+      (void)hipFree(k.d_prelude);
+      k.d_prelude = fresh;
+      k.prelude_cap = cap;
+    }
+    rows_copy(k.d_prelude, k.prelude_cap, k.prelude_len, chunk, chunk_stride, 0, m, k.channels, es, stream);
+    k.prelude_len = n;
+    return 0;
+  }
+  if (k.right > 0) update_tail(k, chunk, chunk_stride, m, stream);
+  if (k.skip >= m) {
+    k.skip -= m;
+    return 0;
+  }
+  const int64_t dropped = k.skip;
+  k.skip = 0;
+  return process(k, chunk, chunk_stride, dropped, m - dropped, out, stream);
+}
+
+// Kernel.flush: stft.ml:561-595
+int64_t flush_core(smx_stft_kernel &k, const StreamOut &out, hipStream_t stream) {
+  if (k.drained) return 0;
+  k.drained = true;
+  const size_t es = (size_t)k.dtype_bytes;
+  int64_t emitted = 0;
+  if (!k.started) {
+    if (k.received != 0) {   // the whole stream sits in the prelude: pad_signal, stft.ml:318-338
+      const int64_t n = k.prelude_len, pl = k.left + n + k.right;
+      void *padded = nullptr;
+      SMX_HIP_CHECK(smx::pool_malloc_async(&padded, (size_t)k.channels * (size_t)pl * es, stream));
+      stream_pad(k, padded, pl, pl, k.d_prelude, k.prelude_cap, n, 1, stream);
+      k.started = true;
+      k.prelude_len = 0;
+      emitted = process(k, padded, pl, 0, pl, out, stream);
+      SMX_HIP_CHECK(hipFreeAsync(padded, stream));
+    }
+  } else if (k.right > 0) {
+    const int64_t r = k.right;
+    if (k.skip >= r) {
+      k.skip -= r;
+    } else {
+      void *rp = nullptr;   // stft.ml:506-519 right_pad
+      SMX_HIP_CHECK(smx::pool_malloc_async(&rp, (size_t)k.channels * (size_t)r * es, stream));
+      stream_pad(k, rp, r, r, k.d_tail, k.right + 1, k.tail_len, 2, stream);
+      const int64_t dropped = k.skip;
+      k.skip = 0;
+      emitted = process(k, rp, r, dropped, r - dropped, out, stream);
+      SMX_HIP_CHECK(hipFreeAsync(rp, stream));
+    }
+  }
+  k.pending_len = 0;
+  return emitted;
 }
 
 }  // namespace
@@ -780,8 +898,10 @@ int smx_stft_kernel_set_channels(smx_stft_kernel *k, int64_t channels) {
     // nothing carried yet: the device buffers are sized on first use
     SMX_HIP_CHECK(hipFree(k->d_stream));
     SMX_HIP_CHECK(hipFree(k->d_out));
-    k->d_stream = k->d_out = nullptr;
-    k->cap = k->out_cap = 0;
+    SMX_HIP_CHECK(hipFree(k->d_prelude));
+    SMX_HIP_CHECK(hipFree(k->d_tail));
+    k->d_stream = k->d_out = k->d_prelude = k->d_tail = nullptr;
+    k->cap = k->out_cap = k->prelude_cap = 0;
     k->channels = channels;
   });
 }
@@ -791,51 +911,27 @@ int smx_stft_kernel_reset(smx_stft_kernel *k) {  // stft.ml:401-409
     if (!k) throw Failure("reset: null kernel");
     k->started = k->drained = false;
     k->received = k->skip = 0;
-    k->prelude.clear();
     k->prelude_len = 0;
-    k->tail.clear();
     k->tail_len = 0;
     k->pending_len = 0;
   });
 }
 
+// host chunk [channels; m] -> frames in the caller's host window [channels; bins; capacity]
 int smx_stft_kernel_step(smx_stft_kernel *k, const void *chunk, int64_t m, void *out, int64_t capacity,
                          int64_t *emitted) {
   return guarded([&] {  // stft.ml:521-559
     if (!k || !emitted) throw Failure("step: null argument");
     *emitted = 0;
-    if (k->drained)
-      throw InvalidArgument(
-          "step: cannot feed a drained kernel (flush consumed the tail; reset before reusing)");
-    if (m < 0) throw Failure("step: negative chunk length");
-    if (m == 0) return;
-    if (!chunk) throw Failure("step: null chunk");
-    const size_t es = (size_t)k->dtype_bytes;
-    const unsigned char *bytes = reinterpret_cast<const unsigned char *>(chunk);
-    k->received += m;
-    if (!k->started) {
-      if (k->received >= install_threshold(*k->cfg)) {
-        std::vector<unsigned char> x = concat_rows(k->prelude.data(), k->prelude_len, bytes, m, k->channels, es);
-        *emitted = install(*k, x.data(), k->prelude_len + m, out, capacity);
-      } else {
-        k->prelude = concat_rows(k->prelude.data(), k->prelude_len, bytes, m, k->channels, es);
-        k->prelude_len += m;
-      }
+    if (m > 0 && !chunk) throw Failure("step: null chunk");
+    if (m <= 0 || k->drained) {   // nothing to move: the core states the error or the empty result
+      *emitted = step_core(*k, chunk, m, m, StreamOut{out, capacity, false}, nullptr);
       return;
     }
-    if (k->right > 0) update_tail(*k, bytes, m);
-    if (k->skip >= m) {
-      k->skip -= m;
-      return;
-    }
-    const int64_t dropped = k->skip;
-    k->skip = 0;
-    if (dropped == 0) {
-      *emitted = process(*k, bytes, m, out, capacity);
-    } else {
-      std::vector<unsigned char> rest = slice_rows(bytes, m, dropped, m, k->channels, es);
-      *emitted = process(*k, rest.data(), m - dropped, out, capacity);
-    }
+    DeviceScratch d((size_t)k->channels * (size_t)m * (size_t)k->dtype_bytes);
+    copy_to_device(d.ptr, chunk, (size_t)k->channels * (size_t)m * (size_t)k->dtype_bytes);
+    *emitted = step_core(*k, d.ptr, m, m, StreamOut{out, capacity, false}, nullptr);
+    SMX_HIP_CHECK(hipStreamSynchronize(nullptr));
   });
 }
 
@@ -843,46 +939,27 @@ int smx_stft_kernel_flush(smx_stft_kernel *k, void *out, int64_t capacity, int64
   return guarded([&] {  // stft.ml:561-595
     if (!k || !emitted) throw Failure("flush: null argument");
     *emitted = 0;
-    if (k->drained) return;
-    k->drained = true;
-    const smx_stft_config &c = *k->cfg;
-    if (!k->started) {
-      if (k->received != 0) {
-        const int64_t n = k->prelude_len;
-        std::vector<int64_t> idx((size_t)(k->left + n + k->right));  // pad_signal, stft.ml:318-338
-        for (int64_t q = 0; q < k->left + n + k->right; ++q)
-          idx[(size_t)q] = source_index(c, n, q - k->left);
-        std::vector<unsigned char> padded;
-        // constant padding only replaces the borders: gather with per-index constants
-        if (k->dtype_bytes == 4)
-          gather_rows<float>(padded, k->prelude.data(), k->channels, n, idx, c.pad_value, false);
-        else
-          gather_rows<double>(padded, k->prelude.data(), k->channels, n, idx, c.pad_value, false);
-        k->started = true;
-        k->prelude.clear();
-        k->prelude_len = 0;
-        *emitted = process(*k, padded.data(), (int64_t)idx.size(), out, capacity);
-      }
-    } else if (k->right > 0) {
-      const int64_t tl = k->tail_len, r = k->right;
-      std::vector<int64_t> idx((size_t)r);  // stft.ml:506-519 right_pad
-      for (int64_t i = 0; i < r; ++i) idx[(size_t)i] = c.pad == SMX_PAD_REFLECT ? tl - 2 - i : tl - 1;
-      std::vector<unsigned char> rp;
-      gather(*k, rp, k->tail.data(), tl, idx);
-      if (k->skip >= r) {
-        k->skip -= r;
-      } else {
-        const int64_t dropped = k->skip;
-        k->skip = 0;
-        if (dropped == 0) {
-          *emitted = process(*k, rp.data(), r, out, capacity);
-        } else {
-          std::vector<unsigned char> rest = slice_rows(rp.data(), r, dropped, r, k->channels, (size_t)k->dtype_bytes);
-          *emitted = process(*k, rest.data(), r - dropped, out, capacity);
-        }
-      }
-    }
-    k->pending_len = 0;
+    *emitted = flush_core(*k, StreamOut{out, capacity, false}, nullptr);
+    SMX_HIP_CHECK(hipStreamSynchronize(nullptr));
+  });
+}
+
+// the same on a device-resident chunk (rows x_stride samples apart) and a device-resident window: nothing crosses the host link
+int smx_stft_kernel_step_dev(smx_stft_kernel *k, const void *d_chunk, int64_t m, int64_t x_stride, void *d_out, int64_t capacity,
+                             int64_t *emitted, void *stream) {
+  return guarded([&] {
+    if (!k || !emitted) throw Failure("step: null argument");
+    *emitted = 0;
+    if (m > 0 && x_stride < m) throw Failure("step: stride smaller than the chunk length");
+    *emitted = step_core(*k, d_chunk, x_stride, m, StreamOut{d_out, capacity, true}, (hipStream_t)stream);
+  });
+}
+
+int smx_stft_kernel_flush_dev(smx_stft_kernel *k, void *d_out, int64_t capacity, int64_t *emitted, void *stream) {
+  return guarded([&] {
+    if (!k || !emitted) throw Failure("flush: null argument");
+    *emitted = 0;
+    *emitted = flush_core(*k, StreamOut{d_out, capacity, true}, (hipStream_t)stream);
   });
 }
 

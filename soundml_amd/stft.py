@@ -351,7 +351,37 @@ class Kernel:
             return None
         return np.ascontiguousarray(out[:, :, :emitted.value])
 
+    def _emit_dev(self, call, capacity, device):
+        """the same into a device-resident window (smx_stft_kernel_step_dev / flush_dev): nothing crosses the host"""
+        import torch
+        real = torch.float64 if self._dtype == np.float64 else torch.float32
+        cplx = torch.complex128 if self._dtype == np.float64 else torch.complex64
+        out = torch.empty((self._channels, self._cfg.bins, capacity), device=device, dtype=real if getattr(self, "_real", False) else cplx)
+        emitted = C.c_int64()
+        with torch.cuda.device(device):
+            stream = C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+            check(call(C.c_void_p(out.data_ptr()), capacity, C.byref(emitted), stream))
+        return None if emitted.value == 0 else out[:, :, :emitted.value].contiguous()
+
     def step(self, chunk):
+        from ._tensor import is_device
+        if is_device(chunk):
+            import torch
+            t = chunk.to(torch.float64 if self._dtype == np.float64 else torch.float32)
+            if t.dim() >= 1 and 0 in t.shape[:-1]:
+                raise _lib.InvalidArgument(
+                    "step: cannot analyse a chunk with a zero-size leading axis (channels must be at least 1)")
+            lead = int(np.prod(t.shape[:-1], dtype=np.int64)) if t.dim() >= 1 else 1
+            if lead != self._channels:
+                check(lib.smx_stft_kernel_set_channels(self._h, lead))
+                self._channels = lead
+            t = t.contiguous().reshape(self._channels, -1)
+            m = int(t.shape[-1])
+            cfg = self._cfg
+            capacity = (m + cfg.fft_size + left_width(cfg) + right_width(cfg)) // cfg.hop + 2
+            self._device = t.device
+            return self._emit_dev(lambda o, cap, e, st: lib.smx_stft_kernel_step_dev(
+                self._h, C.c_void_p(t.data_ptr()), m, m, o, cap, e, st), capacity, t.device)
         a = np.asarray(chunk)
         if a.ndim >= 1 and 0 in a.shape[:-1]:
             raise _lib.InvalidArgument(
@@ -372,9 +402,13 @@ class Kernel:
     def flush(self):
         cfg = self._cfg
         capacity = (2 * cfg.fft_size + left_width(cfg) + right_width(cfg)) // cfg.hop + 2
+        dev = getattr(self, "_device", None)
+        if dev is not None:   # the stream was fed from device memory: the drain stays there
+            return self._emit_dev(lambda o, cap, e, st: lib.smx_stft_kernel_flush_dev(self._h, o, cap, e, st), capacity, dev)
         return self._emit(lambda o, cap, e: lib.smx_stft_kernel_flush(self._h, o, cap, e), capacity)
 
     def reset(self):
+        self._device = None
         check(lib.smx_stft_kernel_reset(self._h))
 
 

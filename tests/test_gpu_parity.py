@@ -524,6 +524,36 @@ def test_streaming_kernel_follows_the_first_chunks_leading_shape():
     assert have.value == 3
 
 
+@pytest.mark.parametrize("fft,hop,alignment,pad", [(2048, 512, "centered", "reflect"), (64, 16, "right", "edge"), (32, 7, "left", ("constant", 0.25)),
+                                                   (16, 20, "centered", "reflect"), (1024, 256, "centered", ("constant", 0.0))])
+def test_streaming_on_device_resident_chunks(fft, hop, alignment, pad):
+    """smx_stft_kernel_step_dev / flush_dev: the state machine fed from and emitting into device memory (prelude, tail and
+    the border gathers live on the device) gives the host-chunk stream -- and therefore Stft.transform -- bit for bit,
+    under the partition law's chunkings (stft_law.ml:79-164), both faces."""
+    import torch
+    rng = np.random.default_rng(fft + hop)
+    c = Stft.Config.create(fft_size=fft, hop=hop, alignment=alignment, pad=pad)
+    for n in (1, fft // 2, fft // 2 + 1, 3 * fft + 5, 20000 if fft >= 1024 else 700):
+        x = rng.uniform(-1, 1, size=(2, n)).astype(np.float32)
+        want = Stft.transform(c, x)
+        xd = torch.from_numpy(x).cuda()
+        for trial in range(3):
+            k = Stft.Kernel.prepare(c, np.float32, channels=2, max_block=max(1, n))
+            parts, pos = [], 0
+            while pos < n:
+                m = min([n, 1, int(rng.integers(1, 3000))][trial], n - pos)
+                out = k.step(xd[:, pos:pos + m])
+                pos += m
+                if out is not None:
+                    assert out.is_cuda
+                    parts.append(out.cpu().numpy())
+            out = k.flush()
+            if out is not None:
+                parts.append(out.cpu().numpy())
+            got = np.concatenate(parts, axis=-1) if parts else np.zeros((2, c.bins, 0), np.complex64)
+            assert got.shape == want.shape and np.array_equal(got, want), (n, trial)
+
+
 def test_streaming_2048_float32():
     rng = np.random.default_rng(9)
     x = rng.uniform(-1, 1, size=(2, 30000)).astype(np.float32)
