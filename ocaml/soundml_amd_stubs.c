@@ -492,6 +492,75 @@ CAMLprim value soundml_amd_kernel_reset(value v_k) {
   CAMLreturn(Val_unit);
 }
 
+/* ---- Stft.Synthesis (stft.ml:1271-1298) and the body of synthesis_stage (stft.ml:1417-1442): incremental synthesis -------
+ * State (the last ceil(fft/hop) - 1 spectra, the held samples) lives in device memory; a step uploads one chunk of frames
+ * [channels; bins; k] and downloads the samples they settle.  Mutable and single-owner like the reference's kernel
+ * (stft.mli:520-522): the OCaml value owns it, the finaliser destroys it. */
+#define Synthesis_val(v) (*((smx_stft_synthesis **)Data_custom_val(v)))
+static void synthesis_finalize(value v) { smx_stft_synthesis_destroy(Synthesis_val(v)); }
+static struct custom_operations synthesis_ops = {"soundml.amd.stft_synthesis", synthesis_finalize, custom_compare_default,
+                                                 custom_hash_default, custom_serialize_default,
+                                                 custom_deserialize_default, custom_compare_ext_default,
+                                                 custom_fixed_length_default};
+
+CAMLprim value soundml_amd_synthesis_prepare(value v_cfg, value v_wide, value v_channels, value v_max_block) {
+  CAMLparam4(v_cfg, v_wide, v_channels, v_max_block);
+  CAMLlocal1(v_handle);
+  const smx_stft_config *c = Stft_val(v_cfg);
+  smx_stft_synthesis *s = NULL;
+  smx_raise(smx_stft_synthesis_prepare(c, Bool_val(v_wide) ? 8 : 4, Long_val(v_channels), Long_val(v_max_block), &s));
+  v_handle = caml_alloc_custom_mem(&synthesis_ops, sizeof(smx_stft_synthesis *),
+                                   (mlsize_t)(Long_val(v_channels) * 8 * smx_stft_config_fft_size(c) * (Bool_val(v_wide) ? 8 : 4)));
+  Synthesis_val(v_handle) = s;
+  CAMLreturn(v_handle);
+}
+
+CAMLprim value soundml_amd_synthesis_numbers(value v_cfg, value v_s) {   /* (Config.synthesis_latency, sample bound of a step) */
+  CAMLparam2(v_cfg, v_s);
+  CAMLlocal1(v_pair);
+  int64_t bound = 0;
+  smx_raise(smx_stft_synthesis_sample_bound(Synthesis_val(v_s), &bound));
+  v_pair = caml_alloc_tuple(2);
+  Store_field(v_pair, 0, Val_long(smx_stft_synthesis_latency(Stft_val(v_cfg))));
+  Store_field(v_pair, 1, Val_long(bound));
+  CAMLreturn(v_pair);
+}
+
+/* Synthesis.step / flush: frames z [channels; bins; k] (k = 0 and is_flush = true for the drain) -> samples written into
+ * out [channels; capacity]; returns how many per channel (0 = the reference's None).  The prepared channel count is the
+ * extent both buffers are checked against (the library reads and writes exactly that many rows). */
+CAMLprim value soundml_amd_synthesis_step(value v_s, value v_z, value v_out, value v_channels, value v_bins, value v_k,
+                                          value v_capacity, value v_is_flush) {
+  CAMLparam5(v_s, v_z, v_out, v_channels, v_bins);
+  CAMLxparam3(v_k, v_capacity, v_is_flush);
+  smx_stft_synthesis *s = Synthesis_val(v_s);
+  const int64_t channels = Long_val(v_channels), bins = Long_val(v_bins), k = Long_val(v_k), capacity = Long_val(v_capacity);
+  const int is_flush = Bool_val(v_is_flush);
+  if (channels < 1 || bins < 0 || k < 0 || capacity < 0) caml_failwith("soundml_amd: invalid geometry");
+  if (!is_flush && ba_dim(v_z) < channels * bins * k) caml_failwith("soundml_amd: buffer extents disagree with geometry");
+  if (ba_dim(v_out) < channels * capacity) caml_failwith("soundml_amd: output extents disagree with geometry");
+  void *z = is_flush ? NULL : Caml_ba_data_val(v_z);
+  void *out = Caml_ba_data_val(v_out);
+  int64_t emitted = 0;
+  int status;
+  caml_release_runtime_system();
+  status = is_flush ? smx_stft_synthesis_flush(s, out, capacity, &emitted)
+                    : smx_stft_synthesis_step(s, z, bins, k, out, capacity, &emitted);
+  caml_acquire_runtime_system();
+  smx_raise(status);
+  CAMLreturn(Val_long(emitted));
+}
+CAMLprim value soundml_amd_synthesis_step_bc(value *argv, int argn) {
+  (void)argn;
+  return soundml_amd_synthesis_step(argv[0], argv[1], argv[2], argv[3], argv[4], argv[5], argv[6], argv[7]);
+}
+
+CAMLprim value soundml_amd_synthesis_reset(value v_s) {
+  CAMLparam1(v_s);
+  smx_raise(smx_stft_synthesis_reset(Synthesis_val(v_s)));
+  CAMLreturn(Val_unit);
+}
+
 CAMLprim value soundml_amd_stage_numbers(value v_cfg, value v_max_items) {   /* (stage_latency, frame_bound max_items) */
   CAMLparam2(v_cfg, v_max_items);
   CAMLlocal1(v_pair);

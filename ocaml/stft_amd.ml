@@ -297,6 +297,57 @@ let power_stage_kernel ?(power = 2.) (c : Stft.Config.t) dtype ~channels ~max_bl
   let flush () = run (Bigarray.Array1.create (Nx_buffer.kind_of_dtype dtype) Bigarray.c_layout 0) 0 true in
   (step, flush, fun () -> kernel_reset_c k)
 
+(* ---- Stft.Synthesis (stft.ml:1271-1298) and synthesis_stage's body (stft.ml:1417-1442) --------------------------------
+   The same signatures and messages; the kernel's state is on the device.  The library checks the prepared channel
+   count against every chunk, so a stream keeps the leading shape it was prepared for (the reference fails in its
+   concatenation when a later chunk disagrees). *)
+type synthesis_handle
+
+external synthesis_prepare_c : stft_handle -> bool -> int -> int -> synthesis_handle = "soundml_amd_synthesis_prepare"
+
+external synthesis_numbers_c : stft_handle -> synthesis_handle -> int * int = "soundml_amd_synthesis_numbers"
+
+external synthesis_step_c :
+  synthesis_handle -> ('a, 'b) flat -> ('c, 'd) flat -> int -> int -> int -> int -> bool -> int
+  = "soundml_amd_synthesis_step_bc" "soundml_amd_synthesis_step"
+
+external synthesis_reset_c : synthesis_handle -> unit = "soundml_amd_synthesis_reset"
+
+module Synthesis = struct
+  type ('a, 'c) t =
+    { s: synthesis_handle
+    ; sdtype: (float, 'a) Nx.dtype
+    ; channels: int
+    ; bins: int
+    ; hop: int
+    ; capacity: int  (* what one step of [max_block] frames or the drain can release, plus a hop *) }
+
+  let prepare dtype cfg (_cdtype : (Complex.t, 'c) Nx.dtype) ~channels ~max_block =
+    (* the reference's checks and messages (channels, max_block, check_invertible "prepare") are smx_stft_synthesis_prepare's *)
+    let wide = Nx.dtype_equal dtype Nx.float64 in
+    let s = synthesis_prepare_c (handle_of_config cfg) wide channels max_block in
+    let _, bound = synthesis_numbers_c (handle_of_config cfg) s in
+    {s; sdtype= dtype; channels; bins= Stft.Config.bins cfg; hop= Stft.Config.hop cfg; capacity= bound + Stft.Config.hop cfg}
+
+  let emit t ~emitted out =
+    if emitted = 0 then None else Some (Nx.shrink [|(0, t.channels); (0, emitted)|] out)
+
+  let step t z =
+    let k = (Nx.shape z).(Nx.ndim z - 1) and bins = (Nx.shape z).(Nx.ndim z - 2) in
+    let capacity = Stdlib.max t.capacity ((k * t.hop) + t.hop) in
+    let out = Nx.empty t.sdtype [|t.channels; capacity|] in
+    let emitted = synthesis_step_c t.s (flat z) (flat_out out) t.channels bins k capacity false in
+    emit t ~emitted out
+
+  let flush t =
+    let out = Nx.empty t.sdtype [|t.channels; t.capacity|] in
+    let none = Bigarray.Array1.sub (flat_out out) 0 0 in
+    let emitted = synthesis_step_c t.s none (flat_out out) t.channels t.bins 0 t.capacity true in
+    emit t ~emitted out
+
+  let reset t = synthesis_reset_c t.s
+end
+
 let stage_latency c = fst (stage_numbers_c (handle_of_config c) 1)
 let frame_bound c ~max_items = snd (stage_numbers_c (handle_of_config c) max_items)
 
