@@ -24,10 +24,18 @@ void set_last_error(const std::string &message) { g_last_error = message; }
 
 std::atomic<unsigned long long> g_kernel_launches{0};
 
-bool fast_path_disabled() {
-  const char *e = std::getenv("SMX_DISABLE_FAST");
-  return e && e[0] == '1';
+int env_flag(const char *name) {
+  const char *e = std::getenv(name);
+  if (!e) return -1;
+  if (e[0] == '\0' || !std::strcmp(e, "0") || !std::strcmp(e, "false") || !std::strcmp(e, "off")) return 0;
+  return 1;
 }
+long env_int(const char *name, long fallback) {
+  const char *e = std::getenv(name);
+  return e && e[0] ? std::atol(e) : fallback;
+}
+
+bool fast_path_disabled() { return env_flag("SMX_DISABLE_FAST") == 1; }
 
 void launch_stft(const StftJob &job) {
   if (job.count <= 0 || job.lead <= 0) return;
@@ -129,7 +137,7 @@ void stft_range_host(const smx_stft_config &c, const void *x, int in_bytes, int6
   if (count == 0 || lead == 0) return;
   if (!x || !out) throw Failure("transform: null pointer");
   require_device();
-  static const bool trace = getenv("SMX_HOST_TRACE") != nullptr;   // diagnostic: where a host call's time goes
+  static const bool trace = env_flag("SMX_HOST_TRACE") == 1;   // diagnostic: where a host call's time goes
   auto now = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
   const double t0 = now();
   DeviceScratch dx((size_t)lead * (size_t)n * (size_t)in_bytes);

@@ -664,8 +664,8 @@ void fir_apply_window_dev(const smx_fir_plan &p, const float *d_x, int64_t chann
   a.h_split = t.h_split;
   a.w_split = t.w_split;
   a.tw_1k = t.tw_1k;
-  static const bool direct_off = [] { const char *e = std::getenv("SMX_FIR_DIRECT"); return e && e[0] == '0'; }();   // A/B timing: FFT blocks for short filters too
-  static const int64_t direct_max = [] { const char *e = std::getenv("SMX_FIR_DIRECT_MAX"); return e ? (int64_t)std::atoll(e) : (int64_t)80; }();
+  static const bool direct_off = diag_flag("SMX_FIR_DIRECT") == 0;   // A/B timing: FFT blocks for short filters too
+  static const int64_t direct_max = (int64_t)diag_int("SMX_FIR_DIRECT_MAX", 80);
   if (p.taps <= direct_max && p.taps <= 128 && !direct_off && channels <= 65535) {   // measured crossover with the FFT blocks: see DESIGN 4.5
     FirDirectArgs da{};
     da.x = d_x;
@@ -683,7 +683,7 @@ void fir_apply_window_dev(const smx_fir_plan &p, const float *d_x, int64_t chann
     SMX_HIP_CHECK(hipGetLastError());
     return;
   }
-  static const bool packed_env = [] { const char *e = std::getenv("SMX_FIR_PACKED"); return e && e[0] == '1'; }();
+  static const bool packed_env = diag_flag("SMX_FIR_PACKED") == 1;
   const bool packed = packed_env && p.log2n <= 14;
   if (!packed) {   // one real block per workgroup, half-size transform
     a.lead = (p.taps - 1 + 1) & ~int64_t(1);                 // even, >= taps - 1
@@ -706,7 +706,7 @@ void fir_apply_window_dev(const smx_fir_plan &p, const float *d_x, int64_t chann
       case 13: aligned ? launch(fir_ols_real_kernel<12, true>, 256) : launch(fir_ols_real_kernel<12, false>, 256); break;
       case 14: aligned ? launch(fir_ols_real_kernel<13, true>, 512) : launch(fir_ols_real_kernel<13, false>, 512); break;
       case 15: {
-        static const bool pass_by_pass = [] { const char *e = std::getenv("SMX_FIR_SPLIT"); return e && e[0] == '0'; }();   // A/B timing
+        static const bool pass_by_pass = diag_flag("SMX_FIR_SPLIT") == 0;   // A/B timing
         if (pass_by_pass) aligned ? launch(fir_ols_real_kernel<14, true>, 1024) : launch(fir_ols_real_kernel<14, false>, 1024);
         else {
           a.channels = channels;
@@ -786,7 +786,7 @@ int smx_fir_plan_create(const double *h, int64_t taps, smx_fir_plan **out) {
     auto *p = new smx_fir_plan();
     p->taps = taps;
     // block length: at least 4 x taps (75 % of every block is kept), at most 32768 real samples = 16384 complex points
-    static const bool big = [] { const char *e = std::getenv("SMX_FIR_BIG"); return !(e && e[0] == '0'); }();
+    static const bool big = diag_flag("SMX_FIR_BIG") != 0;
     int64_t n = 1024;
     while (n < 4 * taps && n < (big ? 32768 : 16384)) n *= 2;
     while (n < 2 * taps) n *= 2;

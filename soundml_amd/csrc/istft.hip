@@ -397,7 +397,7 @@ void launch_stockham_frames_wide(const IstftArgs &a, const StftTables &t, hipStr
 template <typename Tz>
 bool launch_stockham_frames_wide_any(const IstftArgs &a, const StftTables &t, hipStream_t stream) {
   const bool fast_off = fast_path_disabled();
-  if (fast_off || std::getenv("SMX_ISTFT_RADIX2") || !t.fast_w_m_f64 || !t.twiddle_f64 || !t.fast_synth_window_f64) return false;
+  if (fast_off || diag_flag("SMX_ISTFT_RADIX2") == 1 || !t.fast_w_m_f64 || !t.twiddle_f64 || !t.fast_synth_window_f64) return false;
   switch (a.fft) {
     case 512: launch_stockham_frames_wide<9, 16, Tz>(a, t, stream); return true;
     case 1024: launch_stockham_frames_wide<10, 8, Tz>(a, t, stream); return true;
@@ -785,7 +785,7 @@ void launch_mixed_frames(const IstftArgs &a, const MixedInv<S> &pl, hipStream_t 
 template <typename Tz, typename S>
 bool launch_mixed_frames_any(const IstftArgs &a, const StftTables &t, hipStream_t stream) {
   if (t.mixed_npass <= 0 || a.mag || a.unit || (a.fft % 2 != 0) != (t.mixed_full != 0)) return false;
-  static const bool off = [] { const char *e = std::getenv("SMX_MIXED_OFF"); return e && e[0] == '1'; }();
+  static const bool off = env_flag("SMX_MIXED_OFF") == 1;
   if (off) return false;
   MixedInv<S> pl{};
   pl.npass = t.mixed_npass;
@@ -912,7 +912,7 @@ void launch_istft(const IstftJob &job) {
   const int64_t head_n = env.head_n, stop = job.env_open ? (int64_t(1) << 60) : env.stop;
   const int64_t left = job.left >= 0 ? job.left : c.left_width();
   // fused path: fft 2048, hop 512, complex64 spectrum, float32 interior
-  if (istft_fused_2048(job) && !std::getenv("SMX_ISTFT_NEW2048")) {
+  if (istft_fused_2048(job) && diag_flag("SMX_ISTFT_NEW2048") != 1) {
     SynArgs sa{};
     sa.mag = reinterpret_cast<const float *>(job.mag);
     sa.unit = job.unit ? 1 : 0;
@@ -940,9 +940,9 @@ void launch_istft(const IstftJob &job) {
     sa.stop = stop;
     const int64_t blocks = job.lead * tiles;
     if (blocks <= 0x7ffffff0) {
-      const char *lin = std::getenv("SMX_ISTFT_LINEAR");
+      const bool linear = diag_flag("SMX_ISTFT_LINEAR") == 1;
       sa.blocks = blocks;
-      sa.per_xcd = (lin && lin[0] == '1') ? 0 : (blocks + 7) / 8;
+      sa.per_xcd = linear ? 0 : (blocks + 7) / 8;
       const int64_t launched = sa.per_xcd > 0 ? sa.per_xcd * 8 : blocks;
       SMX_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(istft2048_kernel),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)kSynLds));
@@ -953,7 +953,7 @@ void launch_istft(const IstftJob &job) {
   }
   // float32, fft 512 / 1024 / 2048 advanced by a quarter or a half of the size: frames + overlap-add fused, no scratch array
   if (!f64 && job.z_bytes == 8 && (hop * 4 == fft || hop * 2 == fft) && (fft == 512 || fft == 1024 || fft == 2048) && istft_takes_factors(job) &&
-      !std::getenv("SMX_ISTFT_UNFUSED")) {
+      diag_flag("SMX_ISTFT_UNFUSED") != 1) {
     IstftArgs fa{};
     fa.z = job.z;
     fa.lead = job.lead;

@@ -158,7 +158,7 @@ void launch_mel_apply(const MelJob &job) {
   a.frame_tiles = (int)((job.frames + 63) / 64);
   const bool f64_interior = job.elem_bytes == 8 || smx_get_interior() == SMX_INTERIOR_F64;
   if (!f64_interior) {
-    static const bool by_tile = getenv("SMX_MEL_APPLY_BY_TILE") != nullptr;   // diagnostic: all blocks in one workgroup
+    static const bool by_tile = diag_flag("SMX_MEL_APPLY_BY_TILE") == 1;   // diagnostic: all blocks in one workgroup
     if (by_tile) {
       const int64_t blocks = job.lead * a.frame_tiles;
       if (blocks > 0x7fffffff) throw Failure("apply: too many frame tiles for one launch");

@@ -43,6 +43,27 @@ void set_last_error(const std::string &message);
                                          __LINE__));                                     \
   } while (0)
 
+// ---- environment switches ------------------------------------------------------------------------------------------
+// The shipped library reads seven variables, each once per use and parsed ONE way (env_flag: unset -> -1, "0" / "" /
+// "false" / "off" -> 0, anything else -> 1); none alters results except by selecting another kernel of the same contract:
+//   SMX_DISABLE_FAST   the generic kernels instead of the hand-laid ones (tests: two implementations of one contract)
+//   SMX_POWER_V1       the 64-lane fft-2048 power kernel instead of the 32-lane one (A/B timing, tests)
+//   SMX_POWER_RING     with SMX_POWER_V1: its ring form (whole 64-byte-aligned stores)
+//   SMX_MIXED_OFF      chirp-z instead of the mixed-radix kernels (tests: the two agree)
+//   SMX_HOST_TRACE     print where a host-pointer call's time goes
+//   SMX_COPY_THREADS / SMX_COPY_PLAIN   host <-> device staging of the host-pointer entry points
+// Every other switch (kernel selection for timing, ablations) exists in diagnostic builds only (make DIAG=1): diag_flag /
+// diag_int answer "unset" in the shipped build, so what a launcher picks there is a function of the call alone.
+int env_flag(const char *name);
+long env_int(const char *name, long fallback);
+#ifdef SMX_DIAG
+inline int diag_flag(const char *name) { return env_flag(name); }
+inline long diag_int(const char *name, long fallback) { return env_int(name, fallback); }
+#else
+inline int diag_flag(const char *) { return -1; }
+inline long diag_int(const char *, long fallback) { return fallback; }
+#endif
+
 // Every kernel launch of the library goes through SMX_LAUNCH, which counts it: smx_debug_kernel_launches() lets a
 // caller assert how many launches one entry point costs (bench.py: one step of the hot path = ONE launch, so the
 // HIP events around a step are that kernel's duration).

@@ -1601,9 +1601,8 @@ void launch_interior(const StftJob &job, const FastTarget &tg, const float *x, i
     // Tile order (TileWalk::init).  Measured on whole batches: while input + output stay within ~2 GB the
     // chip-wide order (2) is 0-3 % ahead; beyond that the per-XCD chunks (1) win by 3-33 % (C5, 71 GB:
     // 409 vs 308 Mframes/s) -- every XCD then stays inside one clip's pages for several tiles.
-    const char *e = std::getenv("SMX_INTERLEAVE");
     const double footprint = (double)job.lead * ((double)n + (double)kBins * (double)count) * 4.0;
-    a.interleave = e ? std::atoi(e) : (footprint <= 2.0e9 ? 2 : 1);
+    a.interleave = (int)diag_int("SMX_INTERLEAVE", footprint <= 2.0e9 ? 2 : 1);
   }
   a.pmode = job.power == 2.0 ? 2 : (job.power == 1.0 ? 1 : 0);
   a.half_power = (float)(0.5 * job.power);
@@ -1646,16 +1645,13 @@ void launch_interior(const StftJob &job, const FastTarget &tg, const float *x, i
     return;
   }
 #ifdef SMX_DIAG
-  const char *abl_env = std::getenv("SMX_ABLATE");
-  const int abl = abl_env ? std::atoi(abl_env) : 0;
+  const int abl = (int)diag_int("SMX_ABLATE", 0);
   a.abl_nostore = (abl == 1 || abl == 3 || abl == 7) ? 1 : abl == 8 ? 2 : 0;
-  if (std::getenv("SMX_NOSTORE")) a.abl_nostore = 1;
-  if (const char *w = std::getenv("SMX_ABL_RUN")) a.abl_nostore = std::atoi(w);   // 2: 128 B, 3: 256 B, 4: 512 B runs
-  const char *ring_env = std::getenv("SMX_POWER_RING");
-  const bool ring = ring_env && ring_env[0] == '1' && !tg.fold_frames;
-  const char *fl_env = std::getenv("SMX_RING_FLUSH");
-  const int fl_at = fl_env ? std::atoi(fl_env) : 2;
-  a.abl_noskew = std::getenv("SMX_RING_NOSKEW") ? 1 : 0;
+  if (diag_flag("SMX_NOSTORE") == 1) a.abl_nostore = 1;
+  if (diag_flag("SMX_ABL_RUN") >= 0) a.abl_nostore = (int)diag_int("SMX_ABL_RUN", 0);   // 2: 128 B, 3: 256 B, 4: 512 B runs
+  const bool ring = env_flag("SMX_POWER_RING") == 1 && !tg.fold_frames;
+  const int fl_at = (int)diag_int("SMX_RING_FLUSH", 2);
+  a.abl_noskew = diag_flag("SMX_RING_NOSKEW") == 1 ? 1 : 0;
   auto kernel = ring ? (abl == 4 ? stft2048_power_ring_kernel<true, true, false, 2, 4>
                         : abl == 5 ? stft2048_power_ring_kernel<true, true, false, 2, 5>
                         : (abl == 6 || abl == 7) ? stft2048_power_ring_kernel<true, true, false, 2, 6>
@@ -1684,10 +1680,7 @@ void launch_interior(const StftJob &job, const FastTarget &tg, const float *x, i
   // values bit for bit).  Measured 3 % behind the column kernel at C2 (1.5 GB), level with it at 8.9 GB (512 thirty-second
   // clips) and steady at 430-450 Mframes/s from there to the 71 GB C5 batch, where the column kernel falls to 330-430 depending
   // on the box (profiles/r04/c5_ring_sizes.log): it takes the launches whose input + output pass 8 GB.  SMX_POWER_RING=1 / 0 forces it.
-  const char *ring_env = std::getenv("SMX_POWER_RING");
-  const double ring_footprint = (double)job.lead * ((double)n + (double)kBins * (double)count) * 4.0;
-  (void)ring_footprint;
-  const bool ring = !tg.fold_frames && !strip && ring_env && ring_env[0] == '1';   // the ring kernel (64-lane pipeline) only on request: its frames round differently from the 32-lane pipeline's
+  const bool ring = !tg.fold_frames && !strip && env_flag("SMX_POWER_RING") == 1;   // the ring kernel (64-lane pipeline) only on request: its frames round differently from the 32-lane pipeline's
   auto pick = [&](auto strip_tag) {
     constexpr bool S = decltype(strip_tag)::value;
     constexpr int F = SMX_RING_FLUSH_AT;
@@ -1700,8 +1693,7 @@ void launch_interior(const StftJob &job, const FastTarget &tg, const float *x, i
   auto kernel = strip ? pick(std::true_type{}) : pick(std::false_type{});
 #endif
   // The 32-lane pipeline (stft_fast_p32.hpp) is the power kernel; SMX_POWER_V1=1 keeps the 64-lane kernels above for A/B timing.
-  const char *v1_env = std::getenv("SMX_POWER_V1");
-  const bool v1 = v1_env && v1_env[0] == '1';
+  const bool v1 = env_flag("SMX_POWER_V1") == 1;
   if (!v1 && !ring) {
     auto pick32 = [&](auto strip_tag) {
       constexpr bool S = decltype(strip_tag)::value;
@@ -1718,7 +1710,7 @@ void launch_interior(const StftJob &job, const FastTarget &tg, const float *x, i
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)kFastLds));
   unsigned threads = 1024;
 #ifdef SMX_DIAG
-  if (const char *t = std::getenv("SMX_ABL_THREADS")) threads = (unsigned)std::atoi(t);   // ABLATE=12 only: fewer waves per SIMD, same work per wave
+  threads = (unsigned)diag_int("SMX_ABL_THREADS", 1024);   // ABLATE=12 only: fewer waves per SIMD, same work per wave
 #endif
   SMX_LAUNCH(kernel, dim3((unsigned)a.blocks), dim3(threads), kFastLds, job.stream, a);
   SMX_HIP_CHECK(hipGetLastError());
@@ -1746,8 +1738,7 @@ bool fast_eligible(const StftJob &job) {
   const smx_stft_config &c = *job.cfg;
   if (fast_path_disabled()) return false;
   if (c.fft_size != kN || job.in_bytes != 4 || job.interior != SMX_INTERIOR_F32) return false;
-  if (const char *e = std::getenv("SMX_GENERIC_2048"))   // diagnostic: time the stage-free generic kernels at fft 2048
-    if (e[0] == '1') return false;
+  if (diag_flag("SMX_GENERIC_2048") == 1) return false;   // diagnostic: time the stage-free generic kernels at fft 2048
   if (job.lead > 65535) return false;
   return true;
 }
@@ -1767,12 +1758,12 @@ void launch_ranges(const StftJob &job, const FastTarget &tg) {
   }
   // power spectrogram: the border frames ride in the interior launch (no gathers, no extra launches) whenever
   // 32-bit sample positions suffice for the padding rule
-  static const bool fold_off = std::getenv("SMX_NO_BORDER_FOLD") != nullptr;
+  static const bool fold_off = diag_flag("SMX_NO_BORDER_FOLD") == 1;
   // ... while the border frames of the whole batch are few (C2: 1024 of 240 128).  Batches of many short clips (16 384 one-second
   // clips: 65 536 border frames of 524 288) take the gathered strips below instead: the epilogue's barrier-separated tiles and
   // element-wise stores cost them more than the whole interior (2.76 ms against 1.1).
   const int64_t border_total = job.lead * ((i0 - p0) + (p1 - i1));
-  static const int64_t epilogue_max = [] { const char *e = std::getenv("SMX_BORDER_EPILOGUE_MAX"); return e ? (int64_t)std::atoll(e) : (int64_t)20000; }();
+  static const int64_t epilogue_max = (int64_t)diag_int("SMX_BORDER_EPILOGUE_MAX", 20000);
   if (!tg.mel && !tg.complex_out && !fold_off && job.n < (int64_t(1) << 30) && (i0 - p0) + (p1 - i1) > 0 &&
       (i0 - p0) + (p1 - i1) < 4096 && border_total <= epilogue_max) {
     FastTarget folded = tg;
@@ -1960,9 +1951,9 @@ const smx::MelFusedPlan &smx_mel_config::fused_plan() const {
   for (const auto &it : items)
     if (it.k4_count > kMelMaxSteps) return plan;   // the A operands of an item must fit its wave's registers
 #ifdef SMX_DIAG   // result-altering timing switches exist in diagnostic builds only (make DIAG=1)
-  if (std::getenv("SMX_MEL_ONESTEP"))  // one MFMA step per item (wrong results): the cost of the protocol alone
+  if (diag_flag("SMX_MEL_ONESTEP") == 1)  // one MFMA step per item (wrong results): the cost of the protocol alone
     for (auto &it : items) it.k4_count = it.k4_count > 0 ? 1 : 0;
-  if (std::getenv("SMX_MEL_NOMFMA"))   // plan without MFMA work (results are zeros)
+  if (diag_flag("SMX_MEL_NOMFMA") == 1)   // plan without MFMA work (results are zeros)
     for (auto &it : items) it.k4_count = 0;
 #endif
   wm.resize(wm.size() + 64 * (size_t)kMelMaxSteps, 0.0f);   // every item can be read kMelMaxSteps rows deep

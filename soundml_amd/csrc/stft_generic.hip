@@ -1536,7 +1536,7 @@ bool launch_mixed_power16_wide(const StftJob &job, GenericArgs a, const StftTabl
 template <typename Tio>
 bool launch_mixed16_wide_any(const StftJob &job, const GenericArgs &a, const StftTables &t) {
   if (t.mixed_npass <= 0 || !t.mixed_tw_f64 || !t.window_f64 || !t.twiddle_f64 || !(t.blu2_window || t.mixed_full)) return false;   // (the forward plan's sizes)
-  static const bool off = [] { const char *e = std::getenv("SMX_MIXED_OFF"); return e && e[0] == '1'; }();
+  static const bool off = env_flag("SMX_MIXED_OFF") == 1;
   if (off) return false;
   MixedPlan<double> pl{};
   pl.npass = t.mixed_npass;
@@ -1562,7 +1562,7 @@ bool launch_mixed16_wide_any(const StftJob &job, const GenericArgs &a, const Stf
 // true when the size has a mixed-radix plan (StftTables::mixed_npass > 0) and the kernel took the launch
 bool launch_mixed16_any(const StftJob &job, const GenericArgs &a, const StftTables &t, const MelTail *mel) {
   if (t.mixed_npass <= 0 || !t.mixed_tw || !(t.blu2_window || (t.mixed_full && t.window_f32)) || !t.twiddle_f32) return false;
-  static const bool off = [] { const char *e = std::getenv("SMX_MIXED_OFF"); return e && e[0] == '1'; }();   // A/B timing: chirp-z instead
+  static const bool off = env_flag("SMX_MIXED_OFF") == 1;   // tests / A/B timing: chirp-z instead
   if (off) return false;
   MixedPlan<float> pl{};
   pl.npass = t.mixed_npass;
@@ -1686,8 +1686,7 @@ bool launch_mel_spectrogram_16(const MelSpecJob &job) {
   const bool pow2_16 = c.fft_size == 512 || c.fft_size == 1024;
   const bool chirp_16 = !pow2_16 && t.blu2_log2m >= 8 && t.blu2_log2m <= 10;   // even sizes up to 1024 (fft 400 ...)
   if (!pow2_16 && !chirp_16) return false;
-  if (const char *e = std::getenv("SMX_MEL16_OFF"))
-    if (e[0] == '1') return false;
+  if (diag_flag("SMX_MEL16_OFF") == 1) return false;
   if (sj.count <= 0 || sj.lead <= 0) return true;
   const smx_mel_config::Tables &mtab = job.mel->tables();
   GenericArgs a{};
@@ -1711,8 +1710,7 @@ bool launch_mel_spectrogram_16(const MelSpecJob &job) {
   mt.band_hi = mtab.tile_hi;
   mt.n_mels = (int)job.mel->n_mels;
 #ifdef SMX_DIAG   // result-altering timing switch: diagnostic builds only (make DIAG=1)
-  if (const char *e = std::getenv("SMX_MEL16_NOTAIL"))   // the kernel without its MFMA tail
-    if (e[0] == '1') mt.n_mels = 0;
+  if (diag_flag("SMX_MEL16_NOTAIL") == 1) mt.n_mels = 0;   // the kernel without its MFMA tail
 #endif
   mt.k_pad = (int)mtab.k_pad;
   mt.out = reinterpret_cast<float *>(job.out);
@@ -1722,7 +1720,7 @@ bool launch_mel_spectrogram_16(const MelSpecJob &job) {
     // 1.03 + 0.22 ms against 1.50), and its MFMA tail sums in another order than Mel.apply -- a switch by batch size made a
     // clip's values depend on what it was batched with (the reference's slice law, mel_props.ml:136-155).
     // SMX_MEL16_FUSED=1 selects the fused form, again for every batch.
-    static const bool force = [] { const char *e = std::getenv("SMX_MEL16_FUSED"); return e && e[0] == '1'; }();
+    static const bool force = diag_flag("SMX_MEL16_FUSED") == 1;
     if (t.mixed_npass > 0 && !force) return false;
     return launch_mixed16_any(sj, a, t, &mt) || launch_bluestein16_any(sj, a, t, &mt);
   }
@@ -1758,21 +1756,21 @@ void launch_stft_generic(const StftJob &job) {
     bool done = false;
     // the half-size real form wins up to 2048 (fft 1024: 343 vs 315 Mframes/s, 512: 735 vs 687); from 4096 on both
     // forms sit at one 256-thread workgroup per CU (the stage fills the LDS) and the full-size one measured faster
-    const char *cf = std::getenv("SMX_STOCKHAM_COMPLEX");   // diagnostic: force the full-size complex form
-    const bool real_form = !(cf && cf[0] == '1') && c.fft_size <= 2048;
-    const char *sf = std::getenv("SMX_STOCKHAM_STAGED");   // diagnostic: the staged kernel for fft 512 / 1024 power too
-    const bool power16 = real_form && job.mode != OUT_COMPLEX && !(sf && sf[0] == '1');
-    const bool complex16 = real_form && job.mode == OUT_COMPLEX && !(sf && sf[0] == '1');
+    const bool full_complex = diag_flag("SMX_STOCKHAM_COMPLEX") == 1;   // diagnostic: force the full-size complex form
+    const bool real_form = !full_complex && c.fft_size <= 2048;
+    const bool staged = diag_flag("SMX_STOCKHAM_STAGED") == 1;   // diagnostic: the staged kernel for fft 512 / 1024 power too
+    const bool power16 = real_form && job.mode != OUT_COMPLEX && !staged;
+    const bool complex16 = real_form && job.mode == OUT_COMPLEX && !staged;
     if (complex16 && c.fft_size == 512) done = launch_stockham_complex16<9>(job, a, t);
     if (complex16 && c.fft_size == 1024) done = launch_stockham_complex16<10>(job, a, t);
     if (complex16 && c.fft_size == 2048) done = launch_stockham_complex16<11>(job, a, t);   // where the fused kernels do not apply
-    if (job.mode == OUT_COMPLEX && !(sf && sf[0] == '1') && !(cf && cf[0] == '1') && c.fft_size == 4096) done = launch_stockham_complex16<12, 8>(job, a, t);   // eight frames per workgroup (128 KB)
-    if (job.mode == OUT_COMPLEX && !(sf && sf[0] == '1') && !(cf && cf[0] == '1') && c.fft_size == 8192) done = launch_stockham_complex16<13, 4>(job, a, t);   // four
+    if (job.mode == OUT_COMPLEX && !staged && !full_complex && c.fft_size == 4096) done = launch_stockham_complex16<12, 8>(job, a, t);   // eight frames per workgroup (128 KB)
+    if (job.mode == OUT_COMPLEX && !staged && !full_complex && c.fft_size == 8192) done = launch_stockham_complex16<13, 4>(job, a, t);   // four
     if (power16 && c.fft_size == 512) done = launch_stockham_power16<9>(job, a, t);
     if (power16 && c.fft_size == 1024) done = launch_stockham_power16<10>(job, a, t);
     if (power16 && c.fft_size == 2048) done = launch_stockham_power16<11>(job, a, t);      // where the fused kernels do not apply
-    if (job.mode != OUT_COMPLEX && !(sf && sf[0] == '1') && c.fft_size == 4096) done = launch_stockham_power16<12, 8>(job, a, t);
-    if (job.mode != OUT_COMPLEX && !(sf && sf[0] == '1') && c.fft_size == 8192) done = launch_stockham_power16<13, 4>(job, a, t);
+    if (job.mode != OUT_COMPLEX && !staged && c.fft_size == 4096) done = launch_stockham_power16<12, 8>(job, a, t);
+    if (job.mode != OUT_COMPLEX && !staged && c.fft_size == 8192) done = launch_stockham_power16<13, 4>(job, a, t);
     if (!done) switch (c.fft_size) {
       case 256: done = launch_stockham<8>(job, a); break;
       case 512: done = real_form ? launch_stockham_real<9, float, float, float>(job, a, t) : launch_stockham<9>(job, a); break;
@@ -1783,12 +1781,12 @@ void launch_stft_generic(const StftJob &job) {
       case 16384: done = real_form ? launch_stockham_real<14, float, float, float>(job, a, t) : launch_stockham<14>(job, a); break;
       default: break;
     }
-    const char *bf = std::getenv("SMX_BLUESTEIN_FULL");   // diagnostic: the full-length chirp-z for even sizes too
-    if (!done && !(bf && bf[0] == '1') && !(sf && sf[0] == '1'))   // N / 2 = 2^a 3^b 5^c <= 1024: direct mixed-radix transform (power or complex)
+    const bool blu_full = diag_flag("SMX_BLUESTEIN_FULL") == 1;   // diagnostic: the full-length chirp-z for even sizes too
+    if (!done && !blu_full && !staged)   // N / 2 = 2^a 3^b 5^c <= 1024: direct mixed-radix transform (power or complex)
       done = launch_mixed16_any(job, a, t, nullptr);
-    if (!done && t.blu2_log2m >= 8 && t.blu2_log2m <= 10 && job.mode != OUT_COMPLEX && !(bf && bf[0] == '1') && !(sf && sf[0] == '1'))
+    if (!done && t.blu2_log2m >= 8 && t.blu2_log2m <= 10 && job.mode != OUT_COMPLEX && !blu_full && !staged)
       done = launch_bluestein16_any(job, a, t, nullptr);
-    if (!done && t.blu2_log2m >= 8 && !(bf && bf[0] == '1')) {   // even, not a power of two: half-length chirp-z
+    if (!done && t.blu2_log2m >= 8 && !blu_full) {   // even, not a power of two: half-length chirp-z
       switch (t.blu2_log2m) {
         case 8: done = launch_bluestein_real<8>(job, a, t); break;
         case 9: done = launch_bluestein_real<9>(job, a, t); break;
@@ -1815,14 +1813,12 @@ void launch_stft_generic(const StftJob &job) {
     if (done) return;
   }
   if (f64_interior && job.mode == OUT_COMPLEX && !fast_path_disabled()) {   // stage-free complex kernel on doubles
-    const char *sfw = std::getenv("SMX_STOCKHAM_STAGED");
-    if (!(sfw && sfw[0] == '1') && (job.in_bytes == 8 ? launch_stockham_complex16_wide_any<double>(job, a, t, c.fft_size)
+    if (diag_flag("SMX_STOCKHAM_STAGED") != 1 && (job.in_bytes == 8 ? launch_stockham_complex16_wide_any<double>(job, a, t, c.fft_size)
                                                         : launch_stockham_complex16_wide_any<float>(job, a, t, c.fft_size)))
       return;
   }
   if (f64_interior && job.mode != OUT_COMPLEX && !fast_path_disabled()) {   // stage-free power kernel on doubles
-    const char *sfw = std::getenv("SMX_STOCKHAM_STAGED");
-    if (!(sfw && sfw[0] == '1') && (job.in_bytes == 8 ? launch_stockham_power16_wide_any<double>(job, a, t, c.fft_size)
+    if (diag_flag("SMX_STOCKHAM_STAGED") != 1 && (job.in_bytes == 8 ? launch_stockham_power16_wide_any<double>(job, a, t, c.fft_size)
                                                         : launch_stockham_power16_wide_any<float>(job, a, t, c.fft_size)))
       return;
   }

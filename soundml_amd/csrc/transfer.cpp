@@ -37,7 +37,7 @@ Ring g_ring;
 
 int worker_count() {
   static const int n = [] {
-    if (const char *e = getenv("SMX_COPY_THREADS")) return std::max(1, std::min(64, atoi(e)));
+    if (env_flag("SMX_COPY_THREADS") >= 0) return std::max(1, std::min(64, (int)env_int("SMX_COPY_THREADS", 16)));
     const unsigned hw = std::thread::hardware_concurrency();
     return (int)std::max(1u, std::min(16u, hw / 2));
   }();
@@ -153,7 +153,7 @@ void staged(void *dst, const void *src, size_t bytes, bool to_host) {
 
 void copy_to_device(void *d_dst, const void *src, size_t bytes) {
   if (bytes == 0) return;
-  if (bytes < kDirect || getenv("SMX_COPY_PLAIN")) {
+  if (bytes < kDirect || env_flag("SMX_COPY_PLAIN") == 1) {
     SMX_HIP_CHECK(hipMemcpy(d_dst, src, bytes, hipMemcpyHostToDevice));
     return;
   }
@@ -162,7 +162,7 @@ void copy_to_device(void *d_dst, const void *src, size_t bytes) {
 
 void copy_to_host(void *dst, const void *d_src, size_t bytes) {
   if (bytes == 0) return;
-  if (bytes < kDirect || getenv("SMX_COPY_PLAIN")) {
+  if (bytes < kDirect || env_flag("SMX_COPY_PLAIN") == 1) {
     SMX_HIP_CHECK(hipMemcpy(dst, d_src, bytes, hipMemcpyDeviceToHost));
     return;
   }

@@ -6,10 +6,11 @@
 Usage: python tools/derive_profile_json.py r04"""
 import json, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-rnd = sys.argv[1] if len(sys.argv) > 1 else "r04"
+rnd = sys.argv[1] if len(sys.argv) > 1 else "r05"
 src = os.path.join(ROOT, "profiles", rnd, "pmc_hot_kernels.json")
 k = json.load(open(src))["kernels"]
-head = k["stft2048_power_kernel<true, true, false>"]
+hkey = "stft2048_power32_kernel<true, true, false>" if "stft2048_power32_kernel<true, true, false>" in k else "stft2048_power_kernel<true, true, false>"
+head = k[hkey]
 c = head["counters"]
 read_b, write_b = int(c["FETCH_SIZE"] * 1024 * 2), int(c["WRITE_SIZE"] * 1024)
 algo = 256 * 938 * 6148
@@ -18,7 +19,12 @@ json.dump({"bytes_per_launch": read_b + write_b, "read_bytes": read_b, "write_by
            "note": "one launch of the C2 workload (938 frames per clip); FETCH_SIZE doubled per the gfx950 correction (calibrated for "
                    "16 B/lane streams; these loads are 8 B/lane, so the read side is an upper estimate between 1x and 2x FETCH_SIZE); "
                    "WRITE_SIZE as reported",
-           "profile": "profiles/%s/pmc_hot_kernels.json" % rnd}, open(os.path.join(ROOT, "profiles", "hbm_traffic.json"), "w"), indent=1)
+           "profile": "profiles/%s/pmc_hot_kernels.json" % rnd,
+           # what the figure was taken at: bench.py quotes it beside the run it did NOT measure it in
+           "source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes (tools/profile_round.sh) -> profiles/%s/pmc_hot_kernels.json" % rnd,
+           "kernel": hkey, "kernel_us_in_profile": round(head["duration"]["avg_us"], 1) if head.get("duration") else None,
+           "commit": os.popen("git -C %s rev-parse --short HEAD 2>/dev/null" % ROOT).read().strip() or None,
+           "box": "one MI355X gpurun box (fresh lease; boxes differ by +-10 % in kernel time)"}, open(os.path.join(ROOT, "profiles", "hbm_traffic.json"), "w"), indent=1)
 out = {"profile": "profiles/%s/pmc_hot_kernels.json" % rnd,
        "definition": "SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 XCDs x 1024 SIMDs); fp32 MFMA peak 157.3 TFLOP/s (MI355X_MICROARCH.md)"}
 for name, key, flop_per_mfma in (("fused_audio_to_mel", "stft2048_mel_kernel<true, true, false>", 2048), ("mel_apply", "mel_apply_mfma_kernel<true>", 4096)):

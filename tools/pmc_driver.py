@@ -21,9 +21,9 @@ reps = int(os.environ.get("REPS", "4"))
 for _ in range(reps):
     os.environ.pop("SMX_POWER_RING", None)
     check(lib.smx_stft_power_range_f32_dev(sc._h, vp(x.data_ptr()), 256, 480000, 480000, 0, frames, 2.0, vp(out.data_ptr()), None))
-    os.environ["SMX_POWER_RING"] = "1"
+    os.environ["SMX_POWER_V1"] = "1"      # the 64-lane kernel, for the record beside the 32-lane one
     check(lib.smx_stft_power_range_f32_dev(sc._h, vp(x.data_ptr()), 256, 480000, 480000, 0, frames, 2.0, vp(out.data_ptr()), None))
-    os.environ.pop("SMX_POWER_RING", None)
+    os.environ.pop("SMX_POWER_V1", None)
     check(lib.smx_mel_spectrogram_f32_dev(sc._h, mc._h, vp(x.data_ptr()), 256, 480000, 480000, 2.0, vp(mout.data_ptr()), None))
     check(lib.smx_mel_apply_f32_dev(mc._h, vp(out.data_ptr()), 256, 1025, frames, vp(mout.data_ptr()), None))
     check(lib.smx_fir_apply_f32_dev(plan._h, vp(xs.data_ptr()), 8, 2880000, 2880000, vp(ys.data_ptr()), 2880000, None))
