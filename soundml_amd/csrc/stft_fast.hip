@@ -154,6 +154,30 @@ struct FastArgs {
   float half_power;
 };
 
+// |X|^p from |X|^2 = pw.  PMODE 2: the square itself.  1: one v_sqrt_f32 (1 ulp; the IEEE expansion of sqrtf costs three
+// selects on vcc at 19 cycles each, tools/probes/issue_probe.hip).  0: the general power pw^(p/2) = 2^(h e) 2^(h log2 m),
+// pw = m 2^e with m in [0.5, 1): h e is split into its rounded value and the exact residual (one fma), the integer part goes
+// to v_ldexp and only a fraction of a few units reaches v_exp_f32, so the result is good to 2-3 ulp over the whole range
+// (the library powf: 190 instructions and 13 selects per value, 2.6x the kernel's time).  pw = 0, inf and p = 0 come out as
+// powf gives them (0 or inf by the sign of p; 1): the logarithm is clamped to +-FLT_MAX, so that 0 x it is 0, not NaN.
+// -1 (the 64-lane power kernels kept for A/B timing): the run-time choice of rounds 1-2, both forms evaluated and selected.
+template <int PMODE>
+__device__ __forceinline__ float power_from_square(float pw, const FastArgs &a) {
+#pragma clang fp contract(off)
+  if constexpr (PMODE == 2) return pw;
+  else if constexpr (PMODE == 1) return __builtin_amdgcn_sqrtf(pw);
+  else if constexpr (PMODE == 0) {
+    const float h = a.half_power;
+    const float ef = (float)__builtin_amdgcn_frexp_expf(pw);
+    const float lm = __builtin_amdgcn_fmed3f(__builtin_amdgcn_logf(__builtin_amdgcn_frexp_mantf(pw)), -3.402823466e38f, 3.402823466e38f);
+    const float thi = h * ef;
+    const float tlo = __builtin_fmaf(h, ef, -thi);
+    const float n = __builtin_rintf(thi);
+    const float fr = (thi - n) + __builtin_fmaf(h, lm, tlo);
+    return __builtin_ldexpf(__builtin_amdgcn_exp2f(fr), (int)n);
+  } else return a.pmode == 1 ? sqrtf(pw) : __powf(pw, a.half_power);
+}
+
 #ifdef SMX_NOFENCE
 #define SMX_FENCE() do { } while (0)
 #else
@@ -270,7 +294,7 @@ __device__ __forceinline__ void flush_part(const FastArgs &a, const float *tile,
   }
 }
 
-// SQUARE = power 2 (no per-bin branch); otherwise |X|^p through pmode / half_power
+// SQUARE = power 2; otherwise |X|^p through pmode / half_power (power_from_square<-1>)
 #if defined(SMX_STAMPS) && !defined(SMX_DIAG)
 #define SMX_DIAG 1
 #endif
@@ -475,7 +499,7 @@ struct TileWalk {
 // CPLX: the spectrum itself goes to the tile (real parts in `tile`, imaginary parts in the plane after it).
 // TABPG: the post-pass twiddles come from global memory (a.w_n, L2 resident), requested before stage C,
 //        for the kernel that uses the LDS space of that table for something else (mel).
-template <bool SQUARE, bool PRE, bool CPLX, bool TABPG SMX_ABL_PARAM, class Hook>
+template <int PMODE, bool PRE, bool CPLX, bool TABPG SMX_ABL_PARAM, class Hook>
 __device__ __forceinline__ void frame_to_tile(const FastArgs &a, const LaneConst &L, float2 (&raw)[16],
                                               Cells cells, int lane, const Hook &hook) {
   c32 v[16];
@@ -614,8 +638,7 @@ __device__ __forceinline__ void frame_to_tile(const FastArgs &a, const LaneConst
       cells.own[kCellStep * q] = tr;
       cells.own[kCellStep * q + kPlane] = ti;
     } else {
-      float pw = tr * tr + ti * ti;
-      if constexpr (!SQUARE) pw = a.pmode == 1 ? sqrtf(pw) : __powf(pw, a.half_power);
+      const float pw = power_from_square<PMODE>(tr * tr + ti * ti, a);
       if constexpr (kNoLds) asm volatile("" ::"v"(pw));
       else cells.own[kCellStep * q] = pw;
     }
@@ -631,8 +654,7 @@ __device__ __forceinline__ void frame_to_tile(const FastArgs &a, const LaneConst
   if (lane == 0 && !kNoLds) {
     float pw = nyq;                       // CPLX: X[M] is real
     if constexpr (!CPLX) {
-      pw = nyq * nyq;
-      if constexpr (!SQUARE) pw = a.pmode == 1 ? fabsf(nyq) : __powf(pw, a.half_power);
+      pw = PMODE == 1 || (PMODE == -1 && a.pmode == 1) ? fabsf(nyq) : power_from_square<PMODE>(nyq * nyq, a);
     }
     *cells.nyq = pw;   // Nyquist bin of this frame: a pad slot
   }
@@ -787,8 +809,8 @@ __global__ void __launch_bounds__(1024) stft2048_power_kernel(FastArgs a) {
 #else
       const SyncHook hook{cnt.drained + b, 16u * ((unsigned)it >> 1)};
 #endif
-      if constexpr (SMX_ABL(12) || SMX_ABL(13) || SMX_ABL(14)) frame_to_tile<SQUARE, kPre, false, false SMX_ABL_ARG>(a, L, raw, cells_of_column(L, lds.tiles + b * kTileFloats, wave), lane, NoHook{});
-      else frame_to_tile<SQUARE, kPre, false, false SMX_ABL_ARG>(a, L, raw, cells_of_column(L, lds.tiles + b * kTileFloats, wave), lane, hook);
+      if constexpr (SMX_ABL(12) || SMX_ABL(13) || SMX_ABL(14)) frame_to_tile<(SQUARE ? 2 : -1), kPre, false, false SMX_ABL_ARG>(a, L, raw, cells_of_column(L, lds.tiles + b * kTileFloats, wave), lane, NoHook{});
+      else frame_to_tile<(SQUARE ? 2 : -1), kPre, false, false SMX_ABL_ARG>(a, L, raw, cells_of_column(L, lds.tiles + b * kTileFloats, wave), lane, hook);
     }
     if constexpr (!(SMX_ABL(12) || SMX_ABL(13) || SMX_ABL(14))) lds_signal(cnt.filled + b, lane);
     SMX_STAMP(17);
@@ -842,7 +864,7 @@ __global__ void __launch_bounds__(1024) stft2048_power_kernel(FastArgs a) {
         // the same PRE variant as the interior loop: with another instantiation the compiler contracts a few
         // multiply-adds differently and a border frame would differ in the last bit from the same frame computed as
         // an interior one (the streaming faces compute every frame as interior: partition law, stft_law.ml:79-164)
-        frame_to_tile<SQUARE, SMX_EPILOGUE_PRE, false, false SMX_ABL_ZERO>(a, L, braw, cells_of_column(L, bt_tile, wave), lane, NoHook{});
+        frame_to_tile<(SQUARE ? 2 : -1), SMX_EPILOGUE_PRE, false, false SMX_ABL_ZERO>(a, L, braw, cells_of_column(L, bt_tile, wave), lane, NoHook{});
       }
       __syncthreads();
       for (int e = tid; e < kBins * kFT; e += 1024) {
@@ -1049,7 +1071,7 @@ __global__ void __launch_bounds__(1024) stft2048_power_ring_kernel(FastArgs a) {
           c.nyq = lds.tiles + ((pos >> 4) & 1u) * kTileFloats + (pos & 15u) * kTileStride + kFT;
         };
         const RingHook<FLUSH_AT, decltype(flush_prev), decltype(ready_cells)> hook{flush_prev, ready_cells};
-        frame_to_tile<SQUARE, kPre, false, false SMX_ABL_ARG>(a, L, raw, Cells{}, lane, hook);
+        frame_to_tile<(SQUARE ? 2 : -1), kPre, false, false SMX_ABL_ARG>(a, L, raw, Cells{}, lane, hook);
       } else {
         flush_prev();
       }
@@ -1096,7 +1118,7 @@ __global__ void __launch_bounds__(1024) stft2048_power_ring_kernel(FastArgs a) {
           braw[j] = make_float2(fetch_padded(xs, (int)a.n, s, a.pad, a.pad_value),
                                 fetch_padded(xs, (int)a.n, s + 1, a.pad, a.pad_value));
         }
-        frame_to_tile<SQUARE, SMX_EPILOGUE_PRE, false, false SMX_ABL_ZERO>(a, L, braw, cells_of_column(L, bt_tile, wave), lane, NoHook{});
+        frame_to_tile<(SQUARE ? 2 : -1), SMX_EPILOGUE_PRE, false, false SMX_ABL_ZERO>(a, L, braw, cells_of_column(L, bt_tile, wave), lane, NoHook{});
       }
       __syncthreads();
       for (int e = tid; e < kBins * kFT; e += 1024) {
@@ -1216,7 +1238,7 @@ __global__ void __launch_bounds__(1024) stft2048_complex_kernel(FastArgs a) {
   for (int it = 0; it < ntiles; ++it) {
     const CplxHook<ALIGNED> hook{a, c_filled, c_drained, (unsigned)it, lds.tiles, fl, pend_out, pend_left, wave, lane};
     if (have) {
-      frame_to_tile<true, false, true, false SMX_ABL_ZERO>(a, L, raw, cells_of_column(L, lds.tiles, wave), lane, hook);
+      frame_to_tile<2, false, true, false SMX_ABL_ZERO>(a, L, raw, cells_of_column(L, lds.tiles, wave), lane, hook);
     } else {
       hook.flush_previous();
     }
@@ -1288,7 +1310,7 @@ struct ReadyHook {   // frame_to_tile calls ready() just before the powers overw
   __device__ __forceinline__ void ready(Cells &) const { lds_wait(c, target); }
 };
 
-template <bool ALIGNED, bool SQUARE, bool STRIP>
+template <bool ALIGNED, int PMODE, bool STRIP>
 __global__ void __launch_bounds__(1024) stft2048_mel_kernel(FastArgs a, MelFusedArgs m) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x;
@@ -1465,7 +1487,7 @@ __global__ void __launch_bounds__(1024) stft2048_mel_kernel(FastArgs a, MelFused
     if (t < ntiles) {
       // every MFMA read of tile t-2 (same buffer) must be over before the powers of tile t land
       if (have) {
-        frame_to_tile<SQUARE, false, false, false SMX_ABL_ZERO>(a, L, raw, cells_of_column(L, tcur, wave), lane,
+        frame_to_tile<PMODE, false, false, false SMX_ABL_ZERO>(a, L, raw, cells_of_column(L, tcur, wave), lane,
                                                                         ReadyHook{c_mdone + b, t >= 2 ? nth(t - 2) : 0u});
       }
       lds_signal(c_filled + b, lane);
@@ -1625,8 +1647,11 @@ void launch_interior(const StftJob &job, const FastTarget &tg, const float *x, i
     m.out_offset = out_offset;
     auto pick = [&](auto strip_tag) {
       constexpr bool S = decltype(strip_tag)::value;
-      return aligned ? (square ? stft2048_mel_kernel<true, true, S> : stft2048_mel_kernel<true, false, S>)
-                     : (square ? stft2048_mel_kernel<false, true, S> : stft2048_mel_kernel<false, false, S>);
+      auto by_power = [&](auto al) {
+        constexpr bool A = decltype(al)::value;
+        return a.pmode == 2 ? stft2048_mel_kernel<A, 2, S> : a.pmode == 1 ? stft2048_mel_kernel<A, 1, S> : stft2048_mel_kernel<A, 0, S>;
+      };
+      return aligned ? by_power(std::true_type{}) : by_power(std::false_type{});
     };
     auto kernel = strip ? pick(std::true_type{}) : pick(std::false_type{});
     SMX_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kernel),
@@ -1697,8 +1722,11 @@ void launch_interior(const StftJob &job, const FastTarget &tg, const float *x, i
   if (!v1 && !ring) {
     auto pick32 = [&](auto strip_tag) {
       constexpr bool S = decltype(strip_tag)::value;
-      return aligned ? (square ? stft2048_power32_kernel<true, true, S> : stft2048_power32_kernel<true, false, S>)
-                     : (square ? stft2048_power32_kernel<false, true, S> : stft2048_power32_kernel<false, false, S>);
+      auto by_power = [&](auto al) {
+        constexpr bool A = decltype(al)::value;
+        return a.pmode == 2 ? stft2048_power32_kernel<A, 2, S> : a.pmode == 1 ? stft2048_power32_kernel<A, 1, S> : stft2048_power32_kernel<A, 0, S>;
+      };
+      return aligned ? by_power(std::true_type{}) : by_power(std::false_type{});
     };
     auto k32 = strip ? pick32(std::true_type{}) : pick32(std::false_type{});
     SMX_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k32), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kFast32Lds));

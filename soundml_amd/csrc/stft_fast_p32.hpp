@@ -243,7 +243,7 @@ struct NoMid32 {
 #ifndef SMX_P32_TWI
 #define SMX_P32_TWI 1      // 1: the transposition's first plane is written while the twiddle products are formed (shorter LDS bursts)
 #endif
-template <bool SQUARE, class Mid>
+template <int PMODE, class Mid>
 __device__ __forceinline__ void frame32_to_tile(const FastArgs &a, const Lane32 &L, float2 (&raw)[32], float *tile,
                                                 const Mid &mid) {
 #pragma clang fp contract(off)
@@ -345,9 +345,7 @@ __device__ __forceinline__ void frame32_to_tile(const FastArgs &a, const Lane32 
   mid.template stamp<6>();
   SMX_FENCE();
   auto power_of = [&](float re, float im) {
-    float pw = __builtin_fmaf(re, re, im * im);
-    if constexpr (!SQUARE) pw = a.pmode == 1 ? sqrtf(pw) : __powf(pw, a.half_power);
-    return pw;
+    return power_from_square<PMODE>(__builtin_fmaf(re, re, im * im), a);
   };
   {   // bin M/2 (lane 0, register 16): X = 2 conj(Z)
     const float zx = t[16].x + t[16].x, zy = t[16].y + t[16].y;
@@ -513,7 +511,7 @@ struct PowerMid32 {
   }
 };
 
-template <bool ALIGNED, bool SQUARE, bool STRIP>
+template <bool ALIGNED, int PMODE, bool STRIP>
 __global__ void __launch_bounds__(512) stft2048_power32_kernel(FastArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x;
@@ -582,7 +580,7 @@ __global__ void __launch_bounds__(512) stft2048_power32_kernel(FastArgs a) {
     if (it == 32) stamp_sum[14] = __builtin_amdgcn_s_memtime();   // when this wave starts its 33rd tile (wave offsets inside a workgroup)
 #endif
     if (have) {
-      frame32_to_tile<SQUARE>(a, L, raw, lds.tiles + b * kTile32Floats, mid);
+      frame32_to_tile<PMODE>(a, L, raw, lds.tiles + b * kTile32Floats, mid);
     } else {
       mid.early();
       mid.before_cells();
@@ -640,7 +638,7 @@ __global__ void __launch_bounds__(512) stft2048_power32_kernel(FastArgs a) {
           braw[j] = make_float2(fetch_padded(xs, (int)a.n, s, a.pad, a.pad_value),
                                 fetch_padded(xs, (int)a.n, s + 1, a.pad, a.pad_value));
         }
-        frame32_to_tile<SQUARE>(a, L, braw, bt_tile, NoMid32{});
+        frame32_to_tile<PMODE>(a, L, braw, bt_tile, NoMid32{});
       }
       __syncthreads();
       for (int e = tid; e < kBins * kFT; e += 512) {

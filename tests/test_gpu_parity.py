@@ -158,6 +158,35 @@ def test_power_spectrum_vs_oracle(fft, hop, n, lead, power):
         check_fast(got[i], want[i], "clip %d" % i)
 
 
+@pytest.mark.parametrize("power", [0.5, 0.67, 1.0, 3.0, 0.0, -0.5])
+def test_fused_general_power_vs_oracle(power):
+    """`magnitude_pow` (stft.ml:670-674) at fft 2048 on the fused kernels for exponents other than 2: the magnitude is one
+    v_sqrt_f32, a general power the split-exponent form of power_from_square (stft_fast.hip) -- each value within a few
+    ulp of the float64 power (1e-6 relative, bin by bin: tighter than the north-star tolerance, which is relative to the
+    peak), borders, ragged tile and the unaligned variant included; a silent clip gives 0^p as powf does (0, 1 or inf);
+    slices equal the batch bit for bit in every mode."""
+    rng = np.random.default_rng(int(power * 100) + 107)
+    x = rng.uniform(-1, 1, size=(3, 16 * 512 * 2 + 333)).astype(np.float32)
+    x[1] *= 1e-3
+    x[2] = 0.0
+    for hop in (512, 511):
+        c = Stft.Config.create(fft_size=2048, hop=hop)
+        got = Stft.power_spectrum(c, x, power)
+        want = O.power_spectrum(O.stft_config(2048, hop=hop), x, power)
+        for i in range(2):
+            if power >= 0:   # (a negative exponent turns the smallest bins, the least accurate ones, into the peak)
+                check_fast(got[i], want[i], "power %g clip %d" % (power, i))
+            # bin by bin, where the float32 interior's own error (4e-7 of the peak in amplitude) is small beside the value
+            big = np.abs(want[i]) ** (1.0 / power if power else 1.0) > 1e-2 * np.max(np.abs(want[i]) ** (1.0 / power if power else 1.0))
+            rel = np.abs(got[i].astype(np.float64) - want[i])[big] / np.abs(want[i])[big]
+            assert rel.max() < 1e-4 * max(1.0, abs(power)), (power, i, rel.max())
+        silent = got[2]
+        assert np.all(silent == (0.0 if power > 0 else 1.0 if power == 0 else np.inf)), (power, silent.min(), silent.max())
+        assert np.array_equal(got[1], Stft.power_spectrum(c, x[1], power))
+        a, b = 3, got.shape[-1] - 2
+        assert np.array_equal(Stft.power_range(c, x, a, b, power), got[..., a:b])
+
+
 @pytest.mark.parametrize("hop,n,lead", [(512, 480000, 2), (512, 5000, 3), (512, 16 * 512 * 3 + 17, 2), (500, 30000, 2),
                                         (511, 30000, 2)])
 def test_transform_float32_vs_oracle(hop, n, lead):

@@ -1,6 +1,7 @@
 """Interleaved timing of ONE build under several environments (options the library reads per launch):
   python tools/ab_env.py <lib.so> "" "SMX_POWER_V1=1" "SMX_NOSTORE=1" "SMX_POWER_V1=1,SMX_NOSTORE=1"
-C2 power spectrogram (256 x 480000), HIP events, median / min over interleaved rounds."""
+C2 power spectrogram (256 x 480000), HIP events, median / min over interleaved rounds.  AB_POWER=<p> in a variant sets the
+exponent of |X|^p for that variant (default 2)."""
 import ctypes, os, sys
 import torch
 i64, vp = ctypes.c_int64, ctypes.c_void_p
@@ -15,7 +16,7 @@ lib.smx_stft_config_create.argtypes = [i64, i64, i64, ctypes.c_int, ctypes.c_int
 assert lib.smx_stft_config_create(2048, -(2**63), 512, 0, 0, 0.0, 0, 0, None, ctypes.byref(h)) == 0
 lib.smx_stft_power_range_f32_dev.argtypes = [vp, vp, i64, i64, i64, i64, i64, ctypes.c_double, vp, vp]
 def run():
-    assert lib.smx_stft_power_range_f32_dev(h, vp(x.data_ptr()), clips, n, n, 0, frames, 2.0, vp(out.data_ptr()), None) == 0
+    assert lib.smx_stft_power_range_f32_dev(h, vp(x.data_ptr()), clips, n, n, 0, frames, float(os.environ.get("AB_POWER", "2.0")), vp(out.data_ptr()), None) == 0
 def setenv(e, on):
     for kv in filter(None, e.split(",")):
         k, v = kv.split("=")
