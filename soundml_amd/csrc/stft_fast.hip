@@ -151,6 +151,7 @@ struct FastArgs {
   int pmode;            // 2: power 2, 1: power 1, 0: general
   int abl_nostore;      // diagnostic builds only
   int abl_noskew;       // diagnostic builds only (ring kernel: rows not moved to their 64-byte boundaries)
+  int abl_p32;          // diagnostic builds only (32-lane kernel, timing: 1 loads from one resident tile, 2 stores moved to 64-byte boundaries, 4 stores into one resident tile)
   float half_power;
 };
 
@@ -1677,6 +1678,7 @@ void launch_interior(const StftJob &job, const FastTarget &tg, const float *x, i
   const bool ring = env_flag("SMX_POWER_RING") == 1 && !tg.fold_frames;
   const int fl_at = (int)diag_int("SMX_RING_FLUSH", 2);
   a.abl_noskew = diag_flag("SMX_RING_NOSKEW") == 1 ? 1 : 0;
+  a.abl_p32 = (int)diag_int("SMX_P32_ABL", 0);
   auto kernel = ring ? (abl == 4 ? stft2048_power_ring_kernel<true, true, false, 2, 4>
                         : abl == 5 ? stft2048_power_ring_kernel<true, true, false, 2, 5>
                         : (abl == 6 || abl == 7) ? stft2048_power_ring_kernel<true, true, false, 2, 6>

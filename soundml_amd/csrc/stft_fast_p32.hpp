@@ -224,7 +224,7 @@ struct NoMid32 {
   __device__ __forceinline__ void before_cells() const {}
   __device__ __forceinline__ void after_transposition_issue() const {}
   __device__ __forceinline__ void after_exchange_issue() const {}
-  __device__ __forceinline__ void mid_postpass() const {}
+  __device__ __forceinline__ void postpass_at(int) const {}
   template <int I> __device__ __forceinline__ void stamp() const {}
 };
 
@@ -234,12 +234,27 @@ struct NoMid32 {
 //   before_cells()               before the first access to the columns (the power kernel waits until the buffer is free);
 //   after_transposition_issue()  the transposition's reads are in flight;
 //   after_exchange_issue()       the partner reads are in flight: the previous tile's LDS reads are issued behind them;
-//   mid_postpass()               half of the post-pass is done and its registers are free: the previous tile's stores,
-//                                then the next frames' loads.
+//   postpass_at(s)               slot s of the post-pass is done: the previous tile's stores go out behind slot 1 and the next
+//                                frames' loads behind slot 5, each as ONE run of instructions (measured, profiles/r05: stores
+//                                and loads together behind slot 7 +2 %; loads before stores no better; one store and two loads
+//                                behind every slot +18 % -- a memory instruction between arithmetic holds the wave at its issue
+//                                every time, a run of them once).
 // (The power kernel needs the previous tile complete only at the third point and its buffer free only at the first one:
 // the two waves of a SIMD run half a frame apart by themselves -- one computes while the other waits for the LDS -- and
 // every wait that asks for less slack than that turns the counters into a barrier: 0.56 -> 0.58 ms when the tile's reads
 // sat behind the transposition, profiles/r05.)
+#ifndef SMX_P32_HAVE_BRANCH
+#define SMX_P32_HAVE_BRANCH 0
+#endif
+#ifndef SMX_P32_STORE_AT
+#define SMX_P32_STORE_AT 1
+#endif
+#ifndef SMX_P32_LOAD_AT
+#define SMX_P32_LOAD_AT 5
+#endif
+#ifndef SMX_P32_LOADS_FIRST
+#define SMX_P32_LOADS_FIRST 0
+#endif
 #ifndef SMX_P32_TWI
 #define SMX_P32_TWI 1      // 1: the transposition's first plane is written while the twiddle products are formed (shorter LDS bursts)
 #endif
@@ -363,7 +378,7 @@ __device__ __forceinline__ void frame32_to_tile(const FastArgs &a, const Lane32 
     const float ti = __builtin_fmaf(wy, d.y, -(wx * d.x));
     rk[kRowPitch32 * s] = power_of(e.x + tr, e.y + ti);
     rm[kRowPitch32 * (15 - s)] = power_of(e.x - tr, e.y - ti);
-    if (s == 7) { SMX_FENCE(); mid.mid_postpass(); SMX_FENCE(); }
+    if (s == SMX_P32_STORE_AT || s == SMX_P32_LOAD_AT) { SMX_FENCE(); mid.postpass_at(s); SMX_FENCE(); }
   }
   mid.template stamp<7>();
 }
@@ -426,6 +441,18 @@ __device__ __forceinline__ void flush32_store(const FastArgs &a, const Flush32 &
 #endif
   const unsigned pitch = (unsigned)a.out_stride * 4u;
   const unsigned goff0 = opaque32(fl.goff0);
+#ifdef SMX_DIAG
+  if (a.abl_p32 & 6) {   // timing only (wrong places): runs on 64-byte boundaries / everything into the first tile's rows
+    char *base = reinterpret_cast<char *>((a.abl_p32 & 4) ? a.out + a.out_offset : obase);
+#pragma unroll
+    for (int it = 0; it < 8; ++it) {
+      uintptr_t ad = reinterpret_cast<uintptr_t>(base) + goff0 + (unsigned)(32 * (it >> 1) + 8 * (it & 1)) * pitch;
+      if (a.abl_p32 & 2) ad = ((ad - 16u * fl.g) & ~(uintptr_t)63) + 16u * fl.g;
+      *reinterpret_cast<float4 *>(ad) = make_float4(r.v[it][0], r.v[it][1], r.v[it][2], r.v[it][3]);
+    }
+    return;
+  }
+#endif
   if (frames_left >= kFT) {   // wave-uniform: a whole tile, no masks
 #pragma unroll
     for (int it = 0; it < 8; ++it)
@@ -504,10 +531,14 @@ struct PowerMid32 {
       lds_signal32(lds.drained + (b ^ 1) * kTileStride, lane);
     }
   }
-  __device__ __forceinline__ void mid_postpass() const {
-    if (it > 0) flush32_store(a, fl, pend_out, pend_left, wave, lane, fr);
+  // slot s of the post-pass is done (SMX_P32_STORE_AT / SMX_P32_LOAD_AT: where the previous tile's stores and the next
+  // frames' loads are issued; the same slot: SMX_P32_LOADS_FIRST says which goes first)
+  __device__ __forceinline__ void postpass_at(int s) const {
+    const bool same = SMX_P32_STORE_AT == SMX_P32_LOAD_AT;
+    if (s == SMX_P32_LOAD_AT && same && SMX_P32_LOADS_FIRST) { load_frame32<ALIGNED>(src, lane & 31, raw); SMX_FENCE(); }
+    if (s == SMX_P32_STORE_AT && it > 0) flush32_store(a, fl, pend_out, pend_left, wave, lane, fr);
     SMX_FENCE();
-    load_frame32<ALIGNED>(src, lane & 31, raw);   // the next frames' samples (half of the frame's registers are free by now)
+    if (s == SMX_P32_LOAD_AT && !(same && SMX_P32_LOADS_FIRST)) load_frame32<ALIGNED>(src, lane & 31, raw);   // (half of the frame's registers are free by now)
   }
 };
 
@@ -569,6 +600,9 @@ __global__ void __launch_bounds__(512) stft2048_power32_kernel(FastArgs a) {
     tw.peek(a, ftnext, xnext, onext);
     const bool more = it + 1 < ntiles;
     const float *src = frame_ptr(more ? xnext : tw.xclip, more ? ftnext : tw.ft);
+#ifdef SMX_DIAG
+    if (a.abl_p32 & 1) src = frame_ptr(a.x, 1);   // timing only: every tile reads the same resident samples
+#endif
     const bool have = (int64_t)tw.ft * kFT + 2 * wave < a.count;   // wave-uniform: at least the first half has a frame
 #ifdef SMX_STAMPS
     const PowerMid32<ALIGNED> mid{a, lds, fl, fr, raw, src, pend_out, pend_left, lane, wave, b, it, stamp_sum, &stamp_prev, pk_drained, pk_filled};
@@ -579,6 +613,7 @@ __global__ void __launch_bounds__(512) stft2048_power32_kernel(FastArgs a) {
 #ifdef SMX_STAMPS
     if (it == 32) stamp_sum[14] = __builtin_amdgcn_s_memtime();   // when this wave starts its 33rd tile (wave offsets inside a workgroup)
 #endif
+#if SMX_P32_HAVE_BRANCH
     if (have) {
       frame32_to_tile<PMODE>(a, L, raw, lds.tiles + b * kTile32Floats, mid);
     } else {
@@ -586,8 +621,15 @@ __global__ void __launch_bounds__(512) stft2048_power32_kernel(FastArgs a) {
       mid.before_cells();
       mid.after_transposition_issue();
       mid.after_exchange_issue();
-      mid.mid_postpass();
+      mid.postpass_at(SMX_P32_STORE_AT);
+      if (SMX_P32_LOAD_AT != SMX_P32_STORE_AT) mid.postpass_at(SMX_P32_LOAD_AT);
     }
+#else
+    // (a wave without a frame in a clip's last tile runs the frame code all the same, on the tile's first frame; its columns
+    // are never stored.  One path through the loop body: the branch cost ~130 register copies per tile at its join.)
+    (void)have;
+    frame32_to_tile<PMODE>(a, L, raw, lds.tiles + b * kTile32Floats, mid);
+#endif
     lds_signal32(lds.filled + b * kTileStride, lane);
     mid.template stamp<8>();
     pend_out = tw.oclip + tw.ft * kFT;   // wave-uniform
