@@ -112,10 +112,13 @@ __device__ __forceinline__ void transpose16(float (&v)[16]) {
 // registers intact until the store has read them (asm stores are invisible to hipcc's
 // hazard and waitcnt bookkeeping; an uncounted younger store only makes its waits stricter).
 using f32x4 = __attribute__((ext_vector_type(4))) float;
+#ifndef SMX_STORE_MOD
+#define SMX_STORE_MOD ""   // cache-policy bits of the tile stores (" nt", " sc1", ...): A/B builds
+#endif
 __device__ __forceinline__ void store4_unaligned(float *base /* wave-uniform */, unsigned byte_off, float a,
                                                  float b, float c, float d) {
   const f32x4 v = {a, b, c, d};
-  asm volatile("global_store_dwordx4 %0, %1, %2\n\ts_nop 1" : : "v"(byte_off), "v"(v), "s"(base) : "memory");
+  asm volatile("global_store_dwordx4 %0, %1, %2" SMX_STORE_MOD "\n\ts_nop 1" : : "v"(byte_off), "v"(v), "s"(base) : "memory");
 }
 
 constexpr int kN = 2048, kM = 1024, kBins = 1025;
