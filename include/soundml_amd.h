@@ -87,6 +87,7 @@ typedef struct smx_chroma_config smx_chroma_config;
 typedef struct smx_stft_kernel smx_stft_kernel;
 typedef struct smx_fir_plan smx_fir_plan;
 typedef struct smx_resample_stage smx_resample_stage;
+typedef struct smx_resample_kernel smx_resample_kernel;
 
 /* ---- library ------------------------------------------------------------ */
 const char *smx_last_error(void);      /* message of the last failing call on this thread */
@@ -432,8 +433,19 @@ int smx_fir_apply_f32_dev(const smx_fir_plan *p, const float *d_x, int64_t chann
  *                          are Failure with the stub's message ("soundml_resample_shape: invalid geometry").
  * smx_resample_stage_*     one stage y[i] = sum_t proto[t] xu[i M + K L - t], xu = x zero-stuffed by L, ceil(n L / M)
  *                          outputs (what `ols_run` + the virtual-silence drain emit, resample.ml:1456-1599,1745-1755),
- *                          as one block convolution at the interpolated rate on the FIR kernel, float32 interior.  Any
- *                          L, M >= 1 (the reference's OLS stages are L or M in {2, 3, 4}); 2 K L + 1 <= 16384 taps.      */
+ *                          float32 interior.  A pure xL or /M stage (the overlap-save eligible ones, resample.ml:279-300)
+ *                          runs in its polyphase form block by block in the frequency domain -- L filters of the input at
+ *                          the input rate / the sum of M filters of the input's phases at the output rate: the arithmetic
+ *                          of the reference's spectral shortcut (resample_stubs.c:329-372) regrouped into power-of-two
+ *                          transforms at the low rate; any other L / M as one block convolution at the interpolated
+ *                          rate on the FIR kernel.  2 K L + 1 <= 16384 taps.
+ * smx_resample_kernel_*    `Resample.Kernel.{prepare,step,flush,reset}` (resample.mli:270-319, executor `ols_run`
+ *                          resample.ml:1456-1599) of ONE pure xL or /M stage: all channels in one state, the unconsumed
+ *                          input (the block carry) on the device; a step emits the block pairs its samples complete
+ *                          (burst emission, possibly nothing), flush the virtual-silence tail, and every partition of a
+ *                          signal totals smx_resample_stage_apply bit for bit.  Errors as the reference's: a chunk
+ *                          longer than max_block, a step after flush (reset first), channels or max_block < 1 are
+ *                          SMX_INVALID_ARGUMENT.  The stage must outlive the kernel.  A second flush emits nothing.     */
 int smx_resample_ols_geom(int64_t rate, int64_t l, int64_t m, int64_t k, int64_t *n, int64_t *b, int64_t *delta,
                           int *eligible);
 int smx_resample_prototype(int64_t l, int64_t k, double fc, double beta, double *h /* 2 K L + 1 */);
@@ -446,6 +458,18 @@ int64_t smx_resample_stage_out_length(const smx_resample_stage *s, int64_t n);  
 int smx_resample_stage_apply_f32(const smx_resample_stage *s, const float *x, int64_t channels, int64_t n, float *y);
 int smx_resample_stage_apply_f32_dev(const smx_resample_stage *s, const float *d_x, int64_t channels, int64_t n,
                                      int64_t x_stride, float *d_y, int64_t y_stride, void *stream);
+int smx_resample_kernel_prepare(const smx_resample_stage *s, int64_t channels, int64_t max_block, smx_resample_kernel **out);
+void smx_resample_kernel_destroy(smx_resample_kernel *k);
+int smx_resample_kernel_reset(smx_resample_kernel *k);
+int64_t smx_resample_kernel_out_bound(const smx_resample_kernel *k, int64_t n);   /* most samples per channel a step of n can emit */
+int64_t smx_resample_kernel_pending(const smx_resample_kernel *k);                /* samples per channel the next flush emits */
+/* x [channels; n] (row stride x_stride) -> y [channels; *n_out] (row stride y_stride >= out_bound(n) / pending) */
+int smx_resample_kernel_step_f32(smx_resample_kernel *k, const float *x, int64_t n, int64_t x_stride, float *y, int64_t y_stride,
+                                 int64_t *n_out);
+int smx_resample_kernel_flush_f32(smx_resample_kernel *k, float *y, int64_t y_stride, int64_t *n_out);
+int smx_resample_kernel_step_f32_dev(smx_resample_kernel *k, const float *d_x, int64_t n, int64_t x_stride, float *d_y,
+                                     int64_t y_stride, int64_t *n_out, void *stream);
+int smx_resample_kernel_flush_f32_dev(smx_resample_kernel *k, float *d_y, int64_t y_stride, int64_t *n_out, void *stream);
 
 #ifdef __cplusplus
 }

@@ -188,6 +188,15 @@ SIGNATURES = {
     "smx_resample_stage_out_length": (i64, [vp, i64]),
     "smx_resample_stage_apply_f32": (cint, [vp, vp, i64, i64, vp]),
     "smx_resample_stage_apply_f32_dev": (cint, [vp, vp, i64, i64, i64, vp, i64, vp]),
+    "smx_resample_kernel_prepare": (cint, [vp, i64, i64, C.POINTER(vp)]),
+    "smx_resample_kernel_destroy": (None, [vp]),
+    "smx_resample_kernel_reset": (cint, [vp]),
+    "smx_resample_kernel_out_bound": (i64, [vp, i64]),
+    "smx_resample_kernel_pending": (i64, [vp]),
+    "smx_resample_kernel_step_f32": (cint, [vp, vp, i64, i64, vp, i64, pi64]),
+    "smx_resample_kernel_flush_f32": (cint, [vp, vp, i64, pi64]),
+    "smx_resample_kernel_step_f32_dev": (cint, [vp, vp, i64, i64, vp, i64, pi64, vp]),
+    "smx_resample_kernel_flush_f32_dev": (cint, [vp, vp, i64, pi64, vp]),
     "smx_fir_kaiser_beta": (cint, [f64, pf64]),
     "smx_fir_design_lowpass": (cint, [i64, f64, f64, vp]),
     "smx_fir_plan_create": (cint, [vp, i64, C.POINTER(vp)]),

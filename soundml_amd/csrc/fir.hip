@@ -25,6 +25,7 @@
 // Algorithmic HBM bytes: 8 B per sample (4 in + 4 out) plus the (taps-1)/L halo.
 #include <cmath>
 #include <cstdlib>
+#include <memory>
 
 #include "fft_device.hpp"
 #include "smx_internal.hpp"
@@ -460,6 +461,147 @@ __global__ void __launch_bounds__(256) decimate_kernel(const float *v, int64_t v
     y[c * y_stride + i] = v[c * v_stride + i * m];
 }
 
+// ---- a pure xL or /M stage in its polyphase form, block by block in the frequency domain ----------------------------
+// The stage is y[i] = sum_t proto[t] xu[i M + K L - t], xu = x zero-stuffed by L.  Split t = p + j F (F = L or M):
+//   xL:  y[i L + p] = sum_j h_p[j] x[i + K - j],                 h_p[j] = proto[p + j L]   (2 K + 1 taps per phase)
+//   /M:  y[i] = sum_p sum_j h_p[j] x_p[i - j], x_p[q] = x[q M + K - p], h_p[j] = proto[p + j M]   (2 K / M + 1 taps)
+// i.e. L filters of the input at the input rate, or the sum of M filters of the input's phases at the output rate: the
+// same arithmetic as the reference's spectral shortcut (one spectrum replicated L times against the prototype's on the fine
+// grid / folded M times, resample_stubs.c:329-372) regrouped so that every transform is a power of two at the LOW rate --
+// 1/L (1/M) of the flops of filtering the zero-stuffed signal, and no interpolated-rate scratch.
+// Overlap-save blocks of N points at the low rate, two real blocks per complex transform (the packed pair of
+// fir_ols_kernel): block pair P owns low-rate outputs [2 P V, 2 P V + 2 V), V = N - taps + 1, on a grid fixed to the stream's
+// first sample -- so a streaming caller that runs pair P whenever its inputs are in computes the very values the offline
+// call does (the partition law of Resample.Kernel, resample.mli:296-317).
+struct PolyArgs {
+  const float *x;            // x[s - x0] is sample s of the stream for x_lo <= s < x_hi (x_lo >= x0: the buffer starts at x0); zero elsewhere
+  float *y;                  // y[o - o0] for outputs o0 <= o < o0 + n_out
+  int64_t x0, x_lo, x_hi, x_stride, y_stride, o0, n_out;
+  int64_t pair0, pairs;      // block pairs [pair0, pair0 + pairs) of every channel
+  int l, m, k, taps, valid;
+  const float2 *h;           // [phases][N] spectra of the phase filters, natural order, 1/N folded in
+  const float2 *tw;          // exp(-2 pi i j / N), j < N/2
+};
+
+template <int LOG2N, bool UP>
+__global__ void __launch_bounds__((1 << LOG2N) / 16) resample_poly_kernel(PolyArgs a) {
+  constexpr int N = 1 << LOG2N, T = N / 16;
+  constexpr int RL = LastPass<LOG2N>::R, NSL = LastPass<LOG2N>::NS, GL = 16 / RL;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  float2 *z = reinterpret_cast<float2 *>(smem);
+  float2 *zf = z + N;   // the pair's spectrum (xL) / the sum over the phases (/M): every thread touches its own 16 cells only
+  const int tid = threadIdx.x;
+  const int64_t channel = blockIdx.x / a.pairs;
+  const int64_t pair = a.pair0 + blockIdx.x % a.pairs;
+  const int64_t i_a = 2 * pair * a.valid;   // first low-rate output of block a; block b: + valid
+  const int skip = a.taps - 1;
+  const int F = UP ? a.l : a.m;
+  // 32-bit arithmetic relative to two origins, sample q0 of the stream (the first one block a's window may touch) and block
+  // a's first output; offset e is inside the stream (the call's outputs) <=> lo <= e < hi.  Loads and stores address
+  // base + unsigned offset from the first valid element: one code path for interior and border blocks, no 64-bit lanes.
+  auto clamp32 = [](int64_t v) { return (int)(v < -(1 << 30) ? -(1 << 30) : (v > (1 << 30) ? (1 << 30) : v)); };
+  const int64_t q0 = UP ? i_a + a.k - skip : (i_a - skip) * a.m + a.k - (a.m - 1);
+  const int lo = clamp32(a.x_lo - q0), hi = clamp32(a.x_hi - q0);
+  const bool some = hi > lo;                                                // block-uniform: the pair sees a sample at all
+  const float *xb = a.x + channel * a.x_stride + (q0 - a.x0) + (some ? lo : 0);   // the first valid sample
+  const unsigned xn = some ? (unsigned)(hi - lo) : 0u;
+  auto sample = [&](int e) {
+    const unsigned u = (unsigned)(e - lo);
+    const float v = xb[u < xn ? u : 0u];
+    return u < xn ? v : 0.0f;
+  };
+  const int64_t o_a = (UP ? i_a * a.l : i_a) - a.o0;
+  const int olo = clamp32(-o_a), ohi = clamp32(a.n_out - o_a);
+  float *yb = a.y + channel * a.y_stride + o_a + olo;
+  const unsigned yn = ohi > olo ? (unsigned)(ohi - olo) : 0u;
+  auto emit = [&](int e, float v) {
+    const unsigned u = (unsigned)(e - olo);
+    if (u < yn) yb[u] = v;
+  };
+  const int ob = UP ? a.valid * a.l : a.valid;                              // block b's outputs start ob after block a's
+  c32 r[16];
+  if constexpr (UP) {
+    if (some) {
+#pragma unroll
+      for (int m = 0; m < 16; ++m) r[m] = {sample(tid + T * m), sample(a.valid + tid + T * m)};
+    } else {
+#pragma unroll
+      for (int m = 0; m < 16; ++m) r[m] = {0.0f, 0.0f};
+    }
+    fft_passes<LOG2N, true>(r, z, tid, a.tw);
+#pragma unroll
+    for (int i = 0; i < GL; ++i)
+#pragma unroll
+      for (int j = 0; j < RL; ++j) zf[swz(out_index<RL, NSL, T>(tid, i, j))] = make_float2(r[i * RL + j].x, r[i * RL + j].y);
+#pragma unroll 1
+    for (int p = 0; p < F; ++p) {
+      __builtin_amdgcn_sched_barrier(0);
+      const float2 *hp = a.h + p * N;
+#pragma unroll
+      for (int i = 0; i < GL; ++i)
+#pragma unroll
+        for (int j = 0; j < RL; ++j) {   // Y = Z H_p; the inverse runs as conj(FFT(conj Y))
+          const int idx = out_index<RL, NSL, T>(tid, i, j);
+          const float2 hv = hp[idx], zv = zf[swz(idx)];
+          const c32 yv = cmul(c32{zv.x, zv.y}, c32{hv.x, hv.y});
+          z[swz(idx)] = make_float2(yv.x, -yv.y);
+        }
+      __builtin_amdgcn_sched_barrier(0);
+      fft_passes<LOG2N, false>(r, z, tid, a.tw);
+#pragma unroll
+      for (int i = 0; i < GL; ++i)
+#pragma unroll
+        for (int j = 0; j < RL; ++j) {
+          const int idx = out_index<RL, NSL, T>(tid, i, j) - skip;
+          if (idx >= 0) {
+            emit(idx * F + p, r[i * RL + j].x);
+            emit(idx * F + p + ob, -r[i * RL + j].y);
+          }
+        }
+    }
+  } else {
+    const int bo = a.valid * F;                                             // block b's window starts bo samples after block a's
+#pragma unroll 1
+    for (int p = 0; p < F; ++p) {
+      const int ph = F - 1 - p;                                             // x_p[q] = x[q M + K - p]: offset M - 1 - p from q0
+      if (some) {
+#pragma unroll
+        for (int m = 0; m < 16; ++m) r[m] = {sample((tid + T * m) * F + ph), sample((tid + T * m) * F + ph + bo)};
+      } else {
+#pragma unroll
+        for (int m = 0; m < 16; ++m) r[m] = {0.0f, 0.0f};
+      }
+      fft_passes<LOG2N, true>(r, z, tid, a.tw);
+      __builtin_amdgcn_sched_barrier(0);   // (the table reads below stay below: hoisted above the transform they cost 60 registers)
+      const float2 *hp = a.h + p * N;
+      float2 *dst = p == F - 1 ? z : zf;   // the last phase leaves the sum where the inverse reads it
+#pragma unroll
+      for (int i = 0; i < GL; ++i)
+#pragma unroll
+        for (int j = 0; j < RL; ++j) {
+          const int idx = out_index<RL, NSL, T>(tid, i, j);
+          const float2 hv = hp[idx];
+          const c32 yv = cmul(r[i * RL + j], c32{hv.x, hv.y});
+          // the sum over the phases, conjugated for the inverse (conj(FFT(conj Y)))
+          float2 acc = make_float2(0.0f, 0.0f);
+          if (p > 0) acc = zf[swz(idx)];
+          dst[swz(idx)] = make_float2(acc.x + yv.x, acc.y - yv.y);
+        }
+    }
+    fft_passes<LOG2N, false>(r, z, tid, a.tw);
+#pragma unroll
+    for (int i = 0; i < GL; ++i)
+#pragma unroll
+      for (int j = 0; j < RL; ++j) {
+        const int e = out_index<RL, NSL, T>(tid, i, j) - skip;
+        if (e >= 0) {
+          emit(e, r[i * RL + j].x);
+          emit(e + ob, -r[i * RL + j].y);
+        }
+      }
+  }
+}
+
 // The block identity of the reference's overlap-save executor, `soundml_resample_shape_run`
 // (resample_stubs.c:329-372), operation for operation in float64: one thread per output bin.  Every product is the
 // plain four-multiply form with each operation rounded on its own (see cx_mul_exact for what keeps hipcc
@@ -847,9 +989,103 @@ int smx_fir_apply_f32(const smx_fir_plan *p, const float *x, int64_t channels, i
 
 struct smx_resample_stage {
   int64_t l = 1, m = 1, k = 0;
-  smx_fir_plan *fir = nullptr;
-  ~smx_resample_stage() { delete fir; }
+  smx_fir_plan *fir = nullptr;      // a general L / M stage (and 1 / 1): one block convolution at the interpolated rate
+  // a pure xL or /M stage (the overlap-save eligible ones, resample.ml:279-300): polyphase blocks (resample_poly_kernel)
+  bool poly = false;
+  int phases = 0, log2n = 0;
+  int64_t taps = 0, nfft = 0, valid = 0;   // per phase: taps, block length N, kept outputs V = N - taps + 1
+  std::vector<double> proto;
+  struct Tables {
+    float2 *h = nullptr;    // [phases][N]
+    float2 *tw = nullptr;
+  };
+  const Tables &tables() const;
+  ~smx_resample_stage() {
+    delete fir;
+    for (auto &kv : tables_) {
+      (void)hipFree(kv.second.h);
+      (void)hipFree(kv.second.tw);
+    }
+  }
+
+ private:
+  mutable std::mutex mutex_;
+  mutable std::map<int, Tables> tables_;
 };
+
+// Resample.Kernel (resample.mli:270-319) of ONE overlap-save stage: all channels in one state, the unconsumed input on the
+// device, block pairs executed as their inputs complete (always whole pairs on the stream's grid: the partition law)
+struct smx_resample_kernel {
+  const smx_resample_stage *stage = nullptr;   // borrowed: outlives the kernel
+  int64_t channels = 0, max_block = 0;
+  int64_t fed = 0, emitted = 0, pairs_done = 0;
+  int64_t carry_from = 0, carry_cap = 0;       // carry[c][i] = sample carry_from + i of channel c, i < fed - carry_from
+  float *carry = nullptr;
+  bool drained = false;
+  int device = 0;
+  ~smx_resample_kernel() {
+    if (carry) (void)hipFree(carry);
+  }
+};
+
+// in-place radix-2 DFT of 2^bits complex points in float64 (natural order in and out): the phase filters' spectra
+static void dft_pow2_host(std::vector<double> &re, std::vector<double> &im, int bits) {
+  const size_t n = (size_t)1 << bits;
+  for (size_t i = 0; i < n; ++i) {
+    const size_t j = smx::brev_host((unsigned)i, bits);
+    if (i < j) {
+      std::swap(re[i], re[j]);
+      std::swap(im[i], im[j]);
+    }
+  }
+  for (size_t len = 2; len <= n; len <<= 1) {
+    const size_t half = len >> 1;
+    for (size_t j = 0; j < half; ++j) {
+      const double ang = -2.0 * M_PI * (double)j / (double)len, wr = std::cos(ang), wi = std::sin(ang);
+      for (size_t i0 = j; i0 < n; i0 += len) {
+        const size_t i1 = i0 + half;
+        const double tr = re[i1] * wr - im[i1] * wi, ti = re[i1] * wi + im[i1] * wr;
+        re[i1] = re[i0] - tr;
+        im[i1] = im[i0] - ti;
+        re[i0] += tr;
+        im[i0] += ti;
+      }
+    }
+  }
+}
+
+const smx_resample_stage::Tables &smx_resample_stage::tables() const {
+  smx::init_device_pool();
+  int device = 0;
+  SMX_HIP_CHECK(hipGetDevice(&device));
+  std::lock_guard<std::mutex> lock(mutex_);
+  auto it = tables_.find(device);
+  if (it != tables_.end()) return it->second;
+  const int64_t N = nfft, f = phases;
+  std::vector<float2> hb((size_t)(f * N)), tw((size_t)(N / 2));
+  std::vector<double> re((size_t)N), im((size_t)N);
+  for (int64_t p = 0; p < f; ++p) {   // h_p[j] = proto[p + j F], zero beyond the prototype; H_p / N in natural order
+    std::fill(re.begin(), re.end(), 0.0);
+    std::fill(im.begin(), im.end(), 0.0);
+    for (int64_t j = 0; j < taps; ++j) {
+      const int64_t t = p + j * f;
+      if (t < (int64_t)proto.size()) re[(size_t)j] = proto[(size_t)t];
+    }
+    dft_pow2_host(re, im, log2n);
+    for (int64_t i = 0; i < N; ++i)
+      hb[(size_t)(p * N + i)] = make_float2((float)(re[(size_t)i] / (double)N), (float)(im[(size_t)i] / (double)N));
+  }
+  for (int64_t j = 0; j < N / 2; ++j) {
+    const double ang = -2.0 * M_PI * (double)j / (double)N;
+    tw[(size_t)j] = make_float2((float)std::cos(ang), (float)std::sin(ang));
+  }
+  Tables t;
+  SMX_HIP_CHECK(hipMalloc((void **)&t.h, hb.size() * sizeof(float2)));
+  SMX_HIP_CHECK(hipMemcpy(t.h, hb.data(), hb.size() * sizeof(float2), hipMemcpyHostToDevice));
+  SMX_HIP_CHECK(hipMalloc((void **)&t.tw, tw.size() * sizeof(float2)));
+  SMX_HIP_CHECK(hipMemcpy(t.tw, tw.data(), tw.size() * sizeof(float2), hipMemcpyHostToDevice));
+  return tables_.emplace(device, t).first->second;
+}
 
 namespace {
 // resample.ml:279-300
@@ -909,6 +1145,135 @@ struct DeviceScratch {
 
 int64_t stage_out_length(const smx_resample_stage &s, int64_t n) { return (n * s.l + s.m - 1) / s.m; }   // ceil(n L / M)
 
+// blocks of the polyphase form: pairs [pair0, pair0 + pairs) of every channel; x[s - x0] = sample s for x_lo <= s < x_hi
+void poly_run(const smx_resample_stage &s, const float *d_x, int64_t x0, int64_t x_lo, int64_t x_hi, int64_t x_stride,
+              int64_t channels, float *d_y, int64_t y_stride, int64_t o0, int64_t n_out, int64_t pair0, int64_t pairs,
+              hipStream_t stream) {
+  if (channels <= 0 || pairs <= 0 || n_out <= 0) return;
+  const smx_resample_stage::Tables &t = s.tables();
+  smx::PolyArgs a{};
+  a.x = d_x;
+  a.y = d_y;
+  a.x0 = x0;
+  a.x_lo = x_lo;
+  a.x_hi = x_hi;
+  a.x_stride = x_stride;
+  a.y_stride = y_stride;
+  a.o0 = o0;
+  a.n_out = n_out;
+  a.pair0 = pair0;
+  a.pairs = pairs;
+  a.l = (int)s.l;
+  a.m = (int)s.m;
+  a.k = (int)s.k;
+  a.taps = (int)s.taps;
+  a.valid = (int)s.valid;
+  a.h = t.h;
+  a.tw = t.tw;
+  const int64_t grid = channels * pairs;
+  if (grid > 0x7fffffff) throw Failure("resample_stage: too many blocks for one launch");
+  const size_t lds = 2 * (size_t)s.nfft * sizeof(float2);
+  const bool up = s.l > 1;
+  auto launch = [&](auto kernel, int threads) {
+    SMX_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    SMX_LAUNCH(kernel, dim3((unsigned)grid), dim3(threads), lds, stream, a);
+  };
+  switch (s.log2n) {
+    case 10: up ? launch(smx::resample_poly_kernel<10, true>, 64) : launch(smx::resample_poly_kernel<10, false>, 64); break;
+    case 11: up ? launch(smx::resample_poly_kernel<11, true>, 128) : launch(smx::resample_poly_kernel<11, false>, 128); break;
+    case 12: up ? launch(smx::resample_poly_kernel<12, true>, 256) : launch(smx::resample_poly_kernel<12, false>, 256); break;
+    case 13: up ? launch(smx::resample_poly_kernel<13, true>, 512) : launch(smx::resample_poly_kernel<13, false>, 512); break;
+    default: throw Failure("resample_stage: unsupported block length");
+  }
+  SMX_HIP_CHECK(hipGetLastError());
+}
+// block pairs whose low-rate outputs cover the first `count` ones
+int64_t poly_pairs_for(const smx_resample_stage &s, int64_t count) { return (count + 2 * s.valid - 1) / (2 * s.valid); }
+
+// ---- Resample.Kernel of one stage ------------------------------------------------------------------------------------------
+// pairs whose every input lies below `fed`: xL: last input (2 P + 2) V - 1 + K; /M: ((2 P + 2) V - 1) M + K
+int64_t kernel_pairs_ready(const smx_resample_stage &s, int64_t fed) {
+  if (s.l > 1) return fed >= s.k ? (fed - s.k) / (2 * s.valid) : 0;
+  return fed - 1 - s.k >= 0 ? (((fed - 1 - s.k) / s.m) + 1) / (2 * s.valid) : 0;
+}
+// first input pair P reads (never negative: what lies before the stream is zero)
+int64_t kernel_first_input(const smx_resample_stage &s, int64_t pair) {
+  const int64_t skip = s.taps - 1;
+  const int64_t q = s.l > 1 ? 2 * pair * s.valid + s.k - skip : (2 * pair * s.valid - skip) * s.m + s.k - (s.m - 1);
+  return q > 0 ? q : 0;
+}
+int64_t kernel_low_rate_count(const smx_resample_stage &s, int64_t total_out) { return s.l > 1 ? (total_out + s.l - 1) / s.l : total_out; }
+
+void copy_rows(float *dst, int64_t dst_stride, const float *src, int64_t src_stride, int64_t cols, int64_t rows, hipStream_t stream) {
+  if (cols <= 0 || rows <= 0) return;
+  SMX_HIP_CHECK(hipMemcpy2DAsync(dst, (size_t)dst_stride * sizeof(float), src, (size_t)src_stride * sizeof(float),
+                                 (size_t)cols * sizeof(float), (size_t)rows, hipMemcpyDeviceToDevice, stream));
+}
+
+void kernel_check(const smx_resample_kernel *k) {
+  if (!k || !k->stage) throw Failure("resample_kernel: null kernel");
+  int device = 0;
+  SMX_HIP_CHECK(hipGetDevice(&device));
+  if (device != k->device) throw Failure("resample_kernel: the kernel was prepared on another device");
+}
+
+int64_t kernel_step_dev(smx_resample_kernel &k, const float *d_x, int64_t n, int64_t x_stride, float *d_y, int64_t y_stride,
+                        hipStream_t stream) {
+  const smx_resample_stage &s = *k.stage;
+  if (k.drained)
+    throw InvalidArgument("resample_kernel_step: cannot feed a kernel drained by flush (reset it before a new signal)");
+  if (n < 0) throw Failure("resample_kernel_step: negative extent");
+  if (n > k.max_block)
+    throw InvalidArgument(format("resample_kernel_step: cannot feed a chunk of %lld samples to a kernel prepared for at most %lld",
+                                 (long long)n, (long long)k.max_block));
+  if (n == 0) return 0;
+  if (!d_x || x_stride < n) throw Failure("resample_kernel_step: null chunk or stride smaller than the chunk");
+  const int64_t pend = k.fed - k.carry_from, alen = pend + n;
+  const int64_t ready = kernel_pairs_ready(s, k.fed + n);
+  if (ready == k.pairs_done) {   // no block completes: the samples only extend the carry (resample.ml:1468-1484)
+    if (alen > k.carry_cap) throw Failure("resample_kernel_step: carry overflow");
+    copy_rows(k.carry + pend, k.carry_cap, d_x, x_stride, n, k.channels, stream);
+    k.fed += n;
+    return 0;
+  }
+  const int64_t a_stride = (alen + 1) & ~int64_t(1);
+  DeviceScratch av;   // [carry ++ chunk], as ols_run assembles it (resample.ml:1487-1507)
+  av.alloc_async((size_t)k.channels * (size_t)a_stride * sizeof(float), stream);
+  copy_rows(av.as<float>(), a_stride, k.carry, k.carry_cap, pend, k.channels, stream);
+  copy_rows(av.as<float>() + pend, a_stride, d_x, x_stride, n, k.channels, stream);
+  k.fed += n;
+  const int64_t o_end = ready * 2 * s.valid * (s.l > 1 ? s.l : 1), n_out = o_end - k.emitted;
+  if (!d_y || y_stride < n_out) throw Failure("resample_kernel_step: null output or stride smaller than the emitted run");
+  poly_run(s, av.as<float>(), k.carry_from, k.carry_from, k.fed, a_stride, k.channels, d_y, y_stride, k.emitted, n_out, k.pairs_done,
+           ready - k.pairs_done, stream);
+  const int64_t keep = kernel_first_input(s, ready), left = k.fed - keep;
+  if (left > k.carry_cap) throw Failure("resample_kernel_step: carry overflow");
+  copy_rows(k.carry, k.carry_cap, av.as<float>() + (keep - k.carry_from), a_stride, left, k.channels, stream);
+  k.carry_from = keep;
+  k.pairs_done = ready;
+  k.emitted = o_end;
+  return n_out;
+}
+
+int64_t kernel_flush_pending(const smx_resample_kernel &k) {
+  return k.drained ? 0 : stage_out_length(*k.stage, k.fed) - k.emitted;
+}
+
+int64_t kernel_flush_dev(smx_resample_kernel &k, float *d_y, int64_t y_stride, hipStream_t stream) {
+  const smx_resample_stage &s = *k.stage;
+  if (k.drained) return 0;   // draining consumed the tail: a second flush has nothing (resample.mli:313-317)
+  const int64_t total = stage_out_length(s, k.fed), n_out = total - k.emitted;
+  k.drained = true;
+  if (n_out <= 0) return 0;
+  if (!d_y || y_stride < n_out) throw Failure("resample_kernel_flush: null output or stride smaller than the tail");
+  const int64_t fin = poly_pairs_for(s, kernel_low_rate_count(s, total));   // virtual silence past the stream's end (resample.ml:1745-1755)
+  poly_run(s, k.carry, k.carry_from, k.carry_from, k.fed, k.carry_cap, k.channels, d_y, y_stride, k.emitted, n_out, k.pairs_done,
+           fin - k.pairs_done, stream);
+  k.pairs_done = fin;
+  k.emitted = total;
+  return n_out;
+}
+
 // y[c][i] = sum_t proto[t] xu[c][i M + K L - t], xu = x zero-stuffed by L (resample.ml:1318-1326): the stage's
 // definition, run as ONE block convolution at the interpolated rate on the FIR kernel, windowed at the group delay
 void stage_apply_dev(const smx_resample_stage &s, const float *d_x, int64_t channels, int64_t n, int64_t x_stride,
@@ -921,6 +1286,10 @@ void stage_apply_dev(const smx_resample_stage &s, const float *d_x, int64_t chan
   if (channels > 65535)   // the zero-stuffing and decimation launches put the channel in grid.y
     throw Failure("resample_stage: more than 65535 channels in one call");
   smx::init_device_pool();
+  if (s.poly) {   // a pure xL or /M stage: low-rate outputs i < n (xL: y[i L + p]) or i < n_out (/M)
+    poly_run(s, d_x, 0, 0, n, x_stride, channels, d_y, y_stride, 0, n_out, 0, poly_pairs_for(s, s.l > 1 ? n : n_out), stream);
+    return;
+  }
   const float *xin = d_x;
   int64_t n_in = n, in_stride = x_stride;
   DeviceScratch xu, v;   // freed on the stream whichever way this function is left
@@ -1028,6 +1397,24 @@ int smx_resample_stage_create(const double *proto, int64_t l, int64_t m, int64_t
       throw InvalidArgument(format("resample_stage_create: cannot run a %lld-tap prototype (this device path holds at "
                                    "most 16384 taps per 32768-sample block)", (long long)taps));
     if (!proto) throw Failure("resample_stage_create: null prototype");
+    const bool pure = (l > 1) != (m > 1);
+    const int64_t f = l > 1 ? l : m, taps_p = l > 1 ? 2 * k + 1 : (2 * k) / f + 1;
+    if (pure && taps_p <= 4096 && diag_flag("SMX_RESAMPLE_POLY") != 0) {   // polyphase blocks: at least 4 x taps per block (75 % of a block kept), 1024 .. 8192 points
+      auto st = std::make_unique<smx_resample_stage>();
+      st->l = l; st->m = m; st->k = k;
+      st->poly = true;
+      st->phases = (int)f;
+      st->taps = taps_p;
+      int64_t n = 1024;
+      while (n < 4 * taps_p && n < 8192) n *= 2;
+      while (n < 2 * taps_p) n *= 2;
+      st->nfft = n;
+      st->valid = n - taps_p + 1;
+      while ((int64_t(1) << st->log2n) < n) ++st->log2n;
+      st->proto.assign(proto, proto + taps);
+      *out = st.release();
+      return;
+    }
     smx_fir_plan *fir = nullptr;
     if (smx_fir_plan_create(proto, taps, &fir) != SMX_OK) throw Failure(smx_last_error());
     auto *s = new smx_resample_stage();
@@ -1072,5 +1459,109 @@ int smx_resample_stage_apply_f32(const smx_resample_stage *s, const float *x, in
     (void)hipFree(dx); (void)hipFree(dy);
   });
 }
+
+/* ---- Resample.Kernel of one overlap-save stage (resample.mli:270-319) ---- */
+int smx_resample_kernel_prepare(const smx_resample_stage *s, int64_t channels, int64_t max_block, smx_resample_kernel **out) {
+  return guarded_fir([&] {
+    if (!out) throw Failure("resample_kernel_prepare: null output handle");
+    if (!s) throw Failure("resample_kernel_prepare: null stage");
+    if (channels < 1 || max_block < 1)
+      throw InvalidArgument(format("resample_kernel_prepare: cannot prepare a kernel for %lld channels and chunks of %lld samples "
+                                   "(both must be at least 1)", (long long)channels, (long long)max_block));
+    if (!s->poly)
+      throw InvalidArgument(format("resample_kernel_prepare: cannot stream a x%lld / %lld stage block by block (only a pure xL or /M "
+                                   "stage is overlap-save eligible)", (long long)s->l, (long long)s->m));
+    require_hip_device();
+    auto k = std::make_unique<smx_resample_kernel>();
+    k->stage = s;
+    k->channels = channels;
+    k->max_block = max_block;
+    SMX_HIP_CHECK(hipGetDevice(&k->device));
+    // what a step may have to hold: the inputs of one unfinished pair (two windows at the input rate) plus a chunk
+    const int64_t f = s->m > 1 ? s->m : 1;
+    k->carry_cap = ((2 * s->nfft + 2) * f + s->k + max_block + 17) & ~int64_t(1);
+    SMX_HIP_CHECK(hipMalloc((void **)&k->carry, (size_t)channels * (size_t)k->carry_cap * sizeof(float)));
+    *out = k.release();
+  });
+}
+void smx_resample_kernel_destroy(smx_resample_kernel *k) { delete k; }
+int smx_resample_kernel_reset(smx_resample_kernel *k) {
+  return guarded_fir([&] {
+    if (!k) throw Failure("resample_kernel: null kernel");
+    k->fed = k->emitted = k->pairs_done = k->carry_from = 0;
+    k->drained = false;
+  });
+}
+/* most samples per channel one step of n input samples can emit (burst emission: whole block pairs) */
+int64_t smx_resample_kernel_out_bound(const smx_resample_kernel *k, int64_t n) {
+  if (!k || !k->stage || n < 0) return -1;
+  const smx_resample_stage &s = *k->stage;
+  return s.l > 1 ? (n + 2 * s.valid) * s.l : n / s.m + 2 * s.valid + 1;
+}
+/* samples per channel the next flush emits */
+int64_t smx_resample_kernel_pending(const smx_resample_kernel *k) { return k && k->stage ? kernel_flush_pending(*k) : -1; }
+
+int smx_resample_kernel_step_f32_dev(smx_resample_kernel *k, const float *d_x, int64_t n, int64_t x_stride, float *d_y,
+                                     int64_t y_stride, int64_t *n_out, void *stream) {
+  return guarded_fir([&] {
+    kernel_check(k);
+    const int64_t got = kernel_step_dev(*k, d_x, n, x_stride, d_y, y_stride, (hipStream_t)stream);
+    if (n_out) *n_out = got;
+  });
+}
+int smx_resample_kernel_flush_f32_dev(smx_resample_kernel *k, float *d_y, int64_t y_stride, int64_t *n_out, void *stream) {
+  return guarded_fir([&] {
+    kernel_check(k);
+    const int64_t got = kernel_flush_dev(*k, d_y, y_stride, (hipStream_t)stream);
+    if (n_out) *n_out = got;
+  });
+}
+/* host chunks [channels; n] (row stride x_stride) -> y [channels; *n_out] (row stride y_stride >= out_bound(n)) */
+int smx_resample_kernel_step_f32(smx_resample_kernel *k, const float *x, int64_t n, int64_t x_stride, float *y, int64_t y_stride,
+                                 int64_t *n_out) {
+  return guarded_fir([&] {
+    kernel_check(k);
+    if (n_out) *n_out = 0;
+    if (n > 0 && (!x || x_stride < n)) throw Failure("resample_kernel_step: null chunk or stride smaller than the chunk");
+    if (n <= 0 || n > k->max_block || k->drained) {   // the checks and their messages live in one place
+      (void)kernel_step_dev(*k, nullptr, n, x_stride, nullptr, 0, nullptr);
+      return;
+    }
+    const int64_t bound = smx_resample_kernel_out_bound(k, n);
+    DeviceScratch dx, dy;
+    dx.alloc((size_t)k->channels * (size_t)n * sizeof(float));
+    dy.alloc((size_t)k->channels * (size_t)bound * sizeof(float));
+    SMX_HIP_CHECK(hipMemcpy2D(dx.p, (size_t)n * sizeof(float), x, (size_t)x_stride * sizeof(float), (size_t)n * sizeof(float),
+                              (size_t)k->channels, hipMemcpyHostToDevice));
+    const int64_t got = kernel_step_dev(*k, dx.as<float>(), n, n, dy.as<float>(), bound, nullptr);
+    SMX_HIP_CHECK(hipStreamSynchronize(nullptr));
+    if (got > 0) {
+      if (!y || y_stride < got) throw Failure("resample_kernel_step: null output or stride smaller than the emitted run");
+      SMX_HIP_CHECK(hipMemcpy2D(y, (size_t)y_stride * sizeof(float), dy.p, (size_t)bound * sizeof(float), (size_t)got * sizeof(float),
+                                (size_t)k->channels, hipMemcpyDeviceToHost));
+    }
+    if (n_out) *n_out = got;
+  });
+}
+int smx_resample_kernel_flush_f32(smx_resample_kernel *k, float *y, int64_t y_stride, int64_t *n_out) {
+  return guarded_fir([&] {
+    kernel_check(k);
+    if (n_out) *n_out = 0;
+    const int64_t pending = kernel_flush_pending(*k);
+    if (pending <= 0) {
+      (void)kernel_flush_dev(*k, nullptr, 0, nullptr);
+      return;
+    }
+    if (!y || y_stride < pending) throw Failure("resample_kernel_flush: null output or stride smaller than the tail");
+    DeviceScratch dy;
+    dy.alloc((size_t)k->channels * (size_t)pending * sizeof(float));
+    const int64_t got = kernel_flush_dev(*k, dy.as<float>(), pending, nullptr);
+    SMX_HIP_CHECK(hipStreamSynchronize(nullptr));
+    SMX_HIP_CHECK(hipMemcpy2D(y, (size_t)y_stride * sizeof(float), dy.p, (size_t)pending * sizeof(float), (size_t)got * sizeof(float),
+                              (size_t)k->channels, hipMemcpyDeviceToHost));
+    if (n_out) *n_out = got;
+  });
+}
+
 
 }  // extern "C"

@@ -89,3 +89,77 @@ class Stage:
             return out
         check(lib.smx_resample_stage_apply_f32(st._h, b.ptr(), lead, n, out_ptr(out)))
         return b.wrap(out)
+
+
+class Kernel:
+    """``Resample.Kernel`` (resample.mli:270-319) of one pure xL or /M stage: ``prepare`` / ``step`` / ``flush`` / ``reset``.
+    One state carries all channels; the block carry lives on the device.  ``step`` returns the newly computable samples
+    ``[channels; k]`` or None (burst emission: whole block pairs), ``flush`` the tail or None; the concatenation of every
+    step plus flush equals ``Stage.apply`` on the concatenated input bit for bit.  Host chunks give host arrays,
+    device-resident (torch CUDA) chunks stay on the device."""
+
+    def __init__(self, handle, stage, channels, max_block):
+        self._h, self._stage, self.channels, self.max_block = handle, stage, channels, max_block
+
+    @staticmethod
+    def prepare(stage: Stage, channels: int, max_block: int) -> "Kernel":
+        handle = C.c_void_p()
+        check(lib.smx_resample_kernel_prepare(stage._h, int(channels), int(max_block), C.byref(handle)))
+        return Kernel(handle, stage, int(channels), int(max_block))     # (the stage must outlive the kernel: held here)
+
+    def __del__(self):
+        h, self._h = getattr(self, "_h", None), None
+        if h and lib is not None:
+            try:
+                lib.smx_resample_kernel_destroy(h)
+            except Exception:
+                pass
+
+    def reset(self) -> None:
+        check(lib.smx_resample_kernel_reset(self._h))
+
+    def _check(self, shape, what):
+        lead = prod(shape[:-1]) if len(shape) > 1 else 1
+        if len(shape) < 1 or lead != self.channels:      # resample.mli:309-311
+            raise _lib.InvalidArgument("%s: cannot feed a chunk of shape %s to a kernel of %d channels (the leading axes must hold "
+                                       "the channels)" % (what, tuple(shape), self.channels))
+
+    def step(self, chunk):
+        from ._tensor import is_device, is_torch
+        self._check(tuple(chunk.shape), "step")
+        n = int(chunk.shape[-1])
+        got = C.c_int64()
+        bound = max(1, lib.smx_resample_kernel_out_bound(self._h, n))
+        if is_device(chunk):
+            import torch
+            x = chunk.to(torch.float32).reshape(self.channels, n).contiguous()
+            out = torch.empty((self.channels, bound), device=chunk.device, dtype=torch.float32)
+            with torch.cuda.device(chunk.device):
+                stream = C.c_void_p(torch.cuda.current_stream(chunk.device).cuda_stream)
+                check(lib.smx_resample_kernel_step_f32_dev(self._h, C.c_void_p(x.data_ptr()), n, max(n, 1), C.c_void_p(out.data_ptr()),
+                                                           bound, C.byref(got), stream))
+            return None if got.value == 0 else out[:, :got.value].contiguous()
+        a = chunk.detach().cpu().numpy() if is_torch(chunk) else np.asarray(chunk)
+        if a.dtype != np.float32:
+            raise _lib.InvalidArgument("step: cannot resample float64 audio (this path is float32)")
+        a = np.ascontiguousarray(a).reshape(self.channels, n)
+        out = np.empty((self.channels, bound), dtype=np.float32)
+        check(lib.smx_resample_kernel_step_f32(self._h, C.c_void_p(a.ctypes.data), n, max(n, 1), C.c_void_p(out.ctypes.data), bound,
+                                               C.byref(got)))
+        return None if got.value == 0 else np.ascontiguousarray(out[:, :got.value])
+
+    def flush(self, device=None):
+        """The delayed tail (None when there is none, and on a second flush).  ``device``: a torch device to receive it there."""
+        got = C.c_int64()
+        pending = lib.smx_resample_kernel_pending(self._h)
+        cap = max(1, pending)
+        if device is not None:
+            import torch
+            out = torch.empty((self.channels, cap), device=device, dtype=torch.float32)
+            with torch.cuda.device(device):
+                stream = C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+                check(lib.smx_resample_kernel_flush_f32_dev(self._h, C.c_void_p(out.data_ptr()), cap, C.byref(got), stream))
+            return None if got.value == 0 else out[:, :got.value].contiguous()
+        out = np.empty((self.channels, cap), dtype=np.float32)
+        check(lib.smx_resample_kernel_flush_f32(self._h, C.c_void_p(out.ctypes.data), cap, C.byref(got)))
+        return None if got.value == 0 else np.ascontiguousarray(out[:, :got.value])
