@@ -891,6 +891,7 @@ __global__ void __launch_bounds__(1024) stft2048_power_kernel(FastArgs a) {
 }
 
 #include "stft_fast_p32.hpp"   // the 32-lane frame pipeline: stft2048_power32_kernel
+#include "stft_fast_p16.hpp"   // the same pipeline with a frame in 16 lanes: stft1024_power16_kernel (power spectrogram at fft 1024)
 
 // ---- power spectrogram kernel, ring form ----------------------------------------------------------------------
 // The same frame pipeline; what changes is where the results wait in LDS and how they leave.
@@ -1608,7 +1609,9 @@ void launch_interior(const StftJob &job, const FastTarget &tg, const float *x, i
   a.hwin = t.fast_window;
   a.w_m = t.fast_w_m;
   a.w_n = t.fast_w_n;
-  const int64_t tiles = (count + kFT - 1) / kFT;
+  const bool p16 = c.fft_size == kN16;   // the power spectrogram at fft 1024 (launch_stft_fast admits nothing else of that size)
+  const int64_t ft = p16 ? kFT16 : kFT, bins = p16 ? kBins16 : kBins;
+  const int64_t tiles = (count + ft - 1) / ft;
   if (tiles > 0x7fffffff) throw Failure("stft: too many frame tiles for one launch");
   a.tiles_per_clip = (int)tiles;
   // persistent workgroups: one per CU (160 KB of LDS each), every one walks a contiguous range of the
@@ -1627,7 +1630,7 @@ void launch_interior(const StftJob &job, const FastTarget &tg, const float *x, i
     // Tile order (TileWalk::init).  Measured on whole batches: while input + output stay within ~2 GB the
     // chip-wide order (2) is 0-3 % ahead; beyond that the per-XCD chunks (1) win by 3-33 % (C5, 71 GB:
     // 409 vs 308 Mframes/s) -- every XCD then stays inside one clip's pages for several tiles.
-    const double footprint = (double)job.lead * ((double)n + (double)kBins * (double)count) * 4.0;
+    const double footprint = (double)job.lead * ((double)n + (double)bins * (double)count) * 4.0;
     a.interleave = (int)diag_int("SMX_INTERLEAVE", footprint <= 2.0e9 ? 2 : 1);
   }
   a.pmode = job.power == 2.0 ? 2 : (job.power == 1.0 ? 1 : 0);
@@ -1646,6 +1649,21 @@ void launch_interior(const StftJob &job, const FastTarget &tg, const float *x, i
   const bool aligned = (c.hop % 2 == 0) && (left % 2 == 0) && (x_stride % 2 == 0) &&
                        (reinterpret_cast<uintptr_t>(x) % 8 == 0);
   const bool square = a.pmode == 2;
+  if (p16) {
+    auto pick16 = [&](auto strip_tag) {
+      constexpr bool S = decltype(strip_tag)::value;
+      auto by_power = [&](auto al) {
+        constexpr bool A = decltype(al)::value;
+        return a.pmode == 2 ? stft1024_power16_kernel<A, 2, S> : a.pmode == 1 ? stft1024_power16_kernel<A, 1, S> : stft1024_power16_kernel<A, 0, S>;
+      };
+      return aligned ? by_power(std::true_type{}) : by_power(std::false_type{});
+    };
+    auto k16 = strip ? pick16(std::true_type{}) : pick16(std::false_type{});
+    SMX_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k16), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kFast16Lds));
+    SMX_LAUNCH(k16, dim3((unsigned)a.blocks), dim3(512), kFast16Lds, job.stream, a);
+    SMX_HIP_CHECK(hipGetLastError());
+    return;
+  }
   if (tg.mel) {
     MelFusedArgs m = *tg.mel;
     m.out_offset = out_offset;
@@ -1754,7 +1772,7 @@ void launch_border(const StftJob &job, const FastTarget &tg, int64_t pa, int64_t
   if (pb <= pa) return;
   const smx_stft_config &c = *job.cfg;
   const int64_t pos0 = pa * c.hop - job.left;               // signal position of the strip's first sample
-  const int64_t len = (pb - pa - 1) * c.hop + kN;
+  const int64_t len = (pb - pa - 1) * c.hop + c.fft_size;
   const int64_t stride = (len + 1) & ~int64_t(1);            // even: keeps 8-byte aligned rows
   float *strip = nullptr;
   SMX_HIP_CHECK(smx::pool_malloc_async((void **)&strip, (size_t)job.lead * (size_t)stride * sizeof(float), job.stream));
@@ -1767,10 +1785,11 @@ void launch_border(const StftJob &job, const FastTarget &tg, int64_t pa, int64_t
   SMX_HIP_CHECK(hipFreeAsync(strip, job.stream));
 }
 
-bool fast_eligible(const StftJob &job) {
+bool fast_eligible(const StftJob &job, bool power_face = false) {
   const smx_stft_config &c = *job.cfg;
   if (fast_path_disabled()) return false;
-  if (c.fft_size != kN || job.in_bytes != 4 || job.interior != SMX_INTERIOR_F32) return false;
+  const bool size_ok = c.fft_size == kN || (power_face && c.fft_size == kN16 && job.mode == OUT_POWER && diag_flag("SMX_POWER16_OFF") != 1);
+  if (!size_ok || job.in_bytes != 4 || job.interior != SMX_INTERIOR_F32) return false;
   if (diag_flag("SMX_GENERIC_2048") == 1) return false;   // diagnostic: time the stage-free generic kernels at fft 2048
   if (job.lead > 65535) return false;
   return true;
@@ -1782,7 +1801,7 @@ void launch_ranges(const StftJob &job, const FastTarget &tg) {
   // frame p lies inside the signal iff 0 <= p*hop - left and p*hop - left + N <= n
   const int64_t p0 = job.p0, p1 = job.p0 + job.count;
   int64_t i0 = job.left > 0 ? (job.left + c.hop - 1) / c.hop : 0;
-  int64_t i1 = job.n + job.left - kN >= 0 ? (job.n + job.left - kN) / c.hop + 1 : 0;
+  int64_t i1 = job.n + job.left - c.fft_size >= 0 ? (job.n + job.left - c.fft_size) / c.hop + 1 : 0;
   if (i0 < p0) i0 = p0;
   if (i1 > p1) i1 = p1;
   if (i1 <= i0) {          // no interior frame in range: one strip for everything
@@ -1819,7 +1838,7 @@ void launch_ranges(const StftJob &job, const FastTarget &tg) {
     GatherSpan spans[2] = {};
     auto plan = [&](int which, int64_t pa, int64_t pb, const float *&dst, int64_t &dst_stride) {
       if (pb <= pa) return;
-      const int64_t pos0 = pa * c.hop - job.left, len = (pb - pa - 1) * c.hop + kN;
+      const int64_t pos0 = pa * c.hop - job.left, len = (pb - pa - 1) * c.hop + c.fft_size;
       const int64_t stride = (len + 1) & ~int64_t(1);            // even: keeps 8-byte aligned rows
       SMX_HIP_CHECK(smx::pool_malloc_async((void **)&strips[which], (size_t)job.lead * (size_t)stride * sizeof(float), job.stream));
       spans[which] = GatherSpan{pos0, len, stride, strips[which]};
@@ -1855,10 +1874,10 @@ extern "C" int smx_debug_read_stamps(unsigned long long *out, int count) {
 #endif
 
 bool launch_stft_fast(const StftJob &job) {
-  if (!fast_eligible(job)) return false;
+  if (!fast_eligible(job, /*power_face=*/true)) return false;
   if (job.count <= 0 || job.lead <= 0) return true;
   const int64_t elem = job.mode == OUT_COMPLEX ? 8 : 4;
-  if ((int64_t)kBins * job.out_stride * elem >= (int64_t(1) << 32)) return false;   // 32-bit row offsets
+  if ((job.cfg->fft_size / 2 + 1) * job.out_stride * elem >= (int64_t(1) << 32)) return false;   // 32-bit row offsets
   FastTarget tg;
   tg.complex_out = job.mode == OUT_COMPLEX;
   tg.out = job.out;

@@ -1,0 +1,141 @@
+"""The power spectrogram at fft 1024 on the 16-lane register pipeline (stft1024_power16_kernel, stft_fast_p16.hpp):
+BASELINE C1's geometry (fft 1024 / hop 256) and its neighbours against the float64 oracle, and the reference's structural
+laws bit for bit -- frame-range tiling across tile boundaries (stft_grid.ml:32-73), batch == stack of slices (:180-205),
+the streaming partition law through the power stage (stft_law.ml:79-164) --, border frames by the kernel's epilogue and by
+gathered strips, ragged tiles, clips shorter than a frame, unaligned samples, every exponent of magnitude_pow."""
+import numpy as np
+import pytest
+
+import soundml_amd as S
+from soundml_amd import Stft
+from oracle import soundml_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+REGRESSION = 2e-6     # of the spectrogram's peak, in amplitude terms (the gate of test_gpu_baseline_configs.py)
+
+
+def _check(got, want, power, msg):
+    got, want = np.asarray(got, dtype=np.float64), np.asarray(want, dtype=np.float64)
+    assert got.shape == want.shape, (msg, got.shape, want.shape)
+    peak = float(np.max(np.abs(want))) if want.size else 0.0
+    tol = 1e-5 * peak + 1e-5 * np.abs(want)                 # north-star contract
+    assert np.all(np.abs(got - want) <= tol), (msg, float(np.max(np.abs(got - want))), peak)
+
+
+@pytest.mark.parametrize("kw,n,lead", [
+    (dict(hop=256), 441000, 1),                              # C1: 1 x 441 000 samples -> 513 x 1723
+    (dict(hop=256), 44100, 3),
+    (dict(hop=256), 32 * 256 * 2 + 17, 2),                   # ragged last tile
+    (dict(hop=255), 30000, 2),                               # odd hop: the unaligned load variant
+    (dict(hop=200), 30000, 2),
+    (dict(hop=256, win_length=800), 20000, 2),
+    (dict(hop=256, alignment="left"), 20000, 2),
+    (dict(hop=256, alignment="right", pad="edge"), 20000, 2),
+    (dict(hop=256, pad=("constant", 0.25)), 20000, 2),
+    (dict(hop=1024), 50000, 2),                              # no overlap
+    (dict(hop=256), 700, 3),                                 # shorter than a frame: every frame touches both borders
+    (dict(hop=256), 1, 2),
+])
+@pytest.mark.parametrize("power", [2.0, 1.0])
+def test_against_the_oracle(kw, n, lead, power):
+    rng = np.random.default_rng(n + int(power))
+    x = rng.uniform(-1, 1, size=(lead, n)).astype(np.float32)
+    c = Stft.Config.create(fft_size=1024, **kw)
+    okw = dict(kw)
+    if isinstance(okw.get("pad"), tuple):
+        okw["pad"], okw["pad_value"] = okw["pad"]
+    o = O.stft_config(1024, **okw)
+    got = Stft.power_spectrum(c, x, power)
+    want = O.power_spectrum(o, x, power)
+    assert got.dtype == np.float32
+    for i in range(lead):
+        _check(got[i], want[i], power, (kw, n, i))
+
+
+def test_regression_gate_on_a_c1_batch():
+    """8 clips of C1's length: every value within 2e-6 of the peak in amplitude (power: twice that of the power peak)."""
+    import torch
+    rng = np.random.default_rng(1)
+    x = rng.uniform(-1, 1, size=(8, 441000)).astype(np.float32)
+    c = Stft.Config.create(fft_size=1024, hop=256)
+    got = Stft.power_spectrum(c, torch.from_numpy(x).cuda()).cpu().numpy()
+    assert got.shape == (8, 513, 1723)
+    o = O.stft_config(1024, hop=256)
+    for i in (0, 7):
+        want = O.power_spectrum(o, x[i])
+        assert np.max(np.abs(got[i] - want)) <= 2 * REGRESSION * float(np.max(want)), i
+
+
+def test_ranges_tile_exactly_across_tile_boundaries():
+    import torch
+    x = torch.rand(3, 70000, device="cuda") * 2 - 1
+    c = Stft.Config.create(fft_size=1024, hop=256)
+    full = Stft.power_spectrum(c, x)
+    total = Stft.frames(c, x.shape[-1])
+    cuts = [0, 1, 2, 31, 32, 33, 64, 100, total - 33, total - 2, total]
+    parts = [Stft.power_range(c, x, a, b) for a, b in zip(cuts[:-1], cuts[1:])]
+    assert torch.equal(torch.cat(parts, dim=-1), full)
+    assert np.array_equal(full.cpu().numpy(), Stft.power_spectrum(c, x.cpu().numpy()))      # device path == host path
+    for power in (1.0, 0.5):
+        f = Stft.power_spectrum(c, x, power)
+        assert torch.equal(torch.cat([Stft.power_range(c, x, a, b, power) for a, b in zip(cuts[:-1], cuts[1:])], dim=-1), f)
+
+
+def test_batch_is_the_stack_of_its_slices():
+    rng = np.random.default_rng(3)
+    x = rng.uniform(-1, 1, size=(2, 3, 4 * 1024 + 5)).astype(np.float32)
+    for hop in (256, 255):
+        c = Stft.Config.create(fft_size=1024, hop=hop)
+        full = Stft.power_spectrum(c, x)
+        for i in range(2):
+            for j in range(3):
+                assert np.array_equal(full[i, j], Stft.power_spectrum(c, x[i, j]))
+
+
+def test_many_short_clips_take_the_strip_path_and_agree():
+    """8000 clips of 2000 samples: 8 frames each, 4 touching a border -- above the launcher's epilogue threshold, so the kernel
+    reads the border frames from gathered strips; the same clips in a batch of 50 take the epilogue: identical frame code."""
+    import torch
+    rng = np.random.default_rng(11)
+    x = torch.from_numpy(rng.uniform(-1, 1, size=(8000, 2000)).astype(np.float32)).cuda()
+    c = Stft.Config.create(fft_size=1024, hop=256)
+    p = Stft.power_spectrum(c, x)
+    assert tuple(p.shape) == (8000, 513, 8)
+    for lo in (0, 3950, 7950):
+        assert torch.equal(p[lo:lo + 50], Stft.power_spectrum(c, x[lo:lo + 50])), lo
+    o = O.stft_config(1024, hop=256)
+    for clip in (0, 4321, 7999):
+        want = O.power_spectrum(o, x[clip].cpu().numpy())
+        assert np.max(np.abs(p[clip].cpu().numpy() - want)) <= 2 * REGRESSION * float(np.max(want)), clip
+
+
+@pytest.mark.parametrize("alignment,pad", [("centered", "reflect"), ("left", "edge"), ("right", ("constant", 0.5))])
+def test_power_stage_streams_the_offline_result(alignment, pad):
+    rng = np.random.default_rng(5)
+    n = 40 * 1024 + 333
+    x = rng.standard_normal((2, n)).astype(np.float32)
+    c = Stft.Config.create(fft_size=1024, hop=256, alignment=alignment, pad=pad)
+    for power in (2.0, 1.0):
+        offline = Stft.power_spectrum(c, x, power)
+        for block in (n, 9000, 1000, 257):
+            st = Stft.power_stage(c, power).prepare(max_items=block)
+            parts = []
+            for i in range(0, n, block):
+                out = st.step(x[:, i:i + block])
+                if out is not None:
+                    parts.append(out)
+            got = st.concat(parts + st.flush())
+            assert np.array_equal(got, offline), (alignment, power, block)
+
+
+@pytest.mark.parametrize("power", [0.5, 3.0, 0.0])
+def test_general_powers(power):
+    rng = np.random.default_rng(int(power * 10) + 3)
+    x = rng.uniform(-1, 1, size=(2, 20000)).astype(np.float32)
+    x[1] = 0.0
+    c = Stft.Config.create(fft_size=1024, hop=256)
+    got = Stft.power_spectrum(c, x, power)
+    want = O.power_spectrum(O.stft_config(1024, hop=256), x, power)
+    _check(got[0], want[0], power, power)
+    assert np.all(got[1] == (0.0 if power > 0 else 1.0))
