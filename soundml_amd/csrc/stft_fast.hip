@@ -891,7 +891,7 @@ __global__ void __launch_bounds__(1024) stft2048_power_kernel(FastArgs a) {
 }
 
 #include "stft_fast_p32.hpp"   // the 32-lane frame pipeline: stft2048_power32_kernel
-#include "stft_fast_p16.hpp"   // the same pipeline with a frame in 16 lanes: stft1024_power16_kernel (power spectrogram at fft 1024)
+#include "stft_fast_p16.hpp"   // the same pipeline with a frame in 16 / 8 lanes: stft_power_lanes_kernel (power spectrogram at fft 1024 / 512)
 
 // ---- power spectrogram kernel, ring form ----------------------------------------------------------------------
 // The same frame pipeline; what changes is where the results wait in LDS and how they leave.
@@ -1609,8 +1609,8 @@ void launch_interior(const StftJob &job, const FastTarget &tg, const float *x, i
   a.hwin = t.fast_window;
   a.w_m = t.fast_w_m;
   a.w_n = t.fast_w_n;
-  const bool p16 = c.fft_size == kN16;   // the power spectrogram at fft 1024 (launch_stft_fast admits nothing else of that size)
-  const int64_t ft = p16 ? kFT16 : kFT, bins = p16 ? kBins16 : kBins;
+  const int lanes = c.fft_size == kN16 ? 16 : c.fft_size == kN8 ? 8 : 0;   // the power spectrogram at fft 1024 / 512 (launch_stft_fast admits nothing else of these sizes)
+  const int64_t ft = lanes == 16 ? PL<16>::FT : lanes == 8 ? PL<8>::FT : kFT, bins = c.fft_size / 2 + 1;
   const int64_t tiles = (count + ft - 1) / ft;
   if (tiles > 0x7fffffff) throw Failure("stft: too many frame tiles for one launch");
   a.tiles_per_clip = (int)tiles;
@@ -1649,18 +1649,23 @@ void launch_interior(const StftJob &job, const FastTarget &tg, const float *x, i
   const bool aligned = (c.hop % 2 == 0) && (left % 2 == 0) && (x_stride % 2 == 0) &&
                        (reinterpret_cast<uintptr_t>(x) % 8 == 0);
   const bool square = a.pmode == 2;
-  if (p16) {
-    auto pick16 = [&](auto strip_tag) {
-      constexpr bool S = decltype(strip_tag)::value;
-      auto by_power = [&](auto al) {
-        constexpr bool A = decltype(al)::value;
-        return a.pmode == 2 ? stft1024_power16_kernel<A, 2, S> : a.pmode == 1 ? stft1024_power16_kernel<A, 1, S> : stft1024_power16_kernel<A, 0, S>;
+  if (lanes) {
+    auto launch_lanes = [&](auto ll) {
+      constexpr int LL = decltype(ll)::value;
+      auto pick = [&](auto strip_tag) {
+        constexpr bool S = decltype(strip_tag)::value;
+        auto by_power = [&](auto al) {
+          constexpr bool A = decltype(al)::value;
+          return a.pmode == 2 ? stft_power_lanes_kernel<LL, A, 2, S> : a.pmode == 1 ? stft_power_lanes_kernel<LL, A, 1, S> : stft_power_lanes_kernel<LL, A, 0, S>;
+        };
+        return aligned ? by_power(std::true_type{}) : by_power(std::false_type{});
       };
-      return aligned ? by_power(std::true_type{}) : by_power(std::false_type{});
+      auto kl = strip ? pick(std::true_type{}) : pick(std::false_type{});
+      SMX_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kl), hipFuncAttributeMaxDynamicSharedMemorySize, (int)PL<LL>::Lds));
+      SMX_LAUNCH(kl, dim3((unsigned)a.blocks), dim3(512), PL<LL>::Lds, job.stream, a);
     };
-    auto k16 = strip ? pick16(std::true_type{}) : pick16(std::false_type{});
-    SMX_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k16), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kFast16Lds));
-    SMX_LAUNCH(k16, dim3((unsigned)a.blocks), dim3(512), kFast16Lds, job.stream, a);
+    if (lanes == 16) launch_lanes(std::integral_constant<int, 16>{});
+    else launch_lanes(std::integral_constant<int, 8>{});
     SMX_HIP_CHECK(hipGetLastError());
     return;
   }
@@ -1788,7 +1793,7 @@ void launch_border(const StftJob &job, const FastTarget &tg, int64_t pa, int64_t
 bool fast_eligible(const StftJob &job, bool power_face = false) {
   const smx_stft_config &c = *job.cfg;
   if (fast_path_disabled()) return false;
-  const bool size_ok = c.fft_size == kN || (power_face && c.fft_size == kN16 && job.mode == OUT_POWER && diag_flag("SMX_POWER16_OFF") != 1);
+  const bool size_ok = c.fft_size == kN || (power_face && (c.fft_size == kN16 || c.fft_size == kN8) && job.mode == OUT_POWER && diag_flag("SMX_POWER16_OFF") != 1);
   if (!size_ok || job.in_bytes != 4 || job.interior != SMX_INTERIOR_F32) return false;
   if (diag_flag("SMX_GENERIC_2048") == 1) return false;   // diagnostic: time the stage-free generic kernels at fft 2048
   if (job.lead > 65535) return false;

@@ -1,78 +1,98 @@
-// stft1024_power16_kernel -- the power spectrogram at fft 1024 on the register frame pipeline of stft_fast_p32.hpp, with a
-// frame in 16 lanes (included by stft_fast.hip after stft_fast_p32.hpp, inside its anonymous namespace).  Replaces the
-// reference's hot call for Stft.power_spectrum at BASELINE C1's geometry (fft 1024 / hop 256), stft.ml:356-364 + 670-691.
+// stft_power_lanes_kernel<LL> -- the power spectrogram at fft 1024 (LL = 16) and fft 512 (LL = 8) on the register frame pipeline
+// of stft_fast_p32.hpp with a frame in LL lanes (included by stft_fast.hip after stft_fast_p32.hpp, inside its anonymous
+// namespace).  Replaces the reference's hot call for Stft.power_spectrum at BASELINE C1's geometry (fft 1024 / hop 256) and
+// at fft 512, stft.ml:356-364 + 670-691.
 //
-// M = N/2 = 512 = 16 x 32 complex points, z[n] = x[2n] + i x[2n+1]:
-//   A. n = l + 16 j  : radix-32 over j in registers (fft32 of the 32-lane pipeline)      -> y_l[k1], twiddle W_M^(l k1)
-//   X. 16 x 32 transposition through the frame's own column of the output tile: lane l register k1 -> cell l + 17 k1 ->
-//      lane k1 mod 16, registers (k1 div 16, l); one plane at a time, base(lane) + immediate on both sides
-//   B. two radix-16 over l in registers (k1 = lam, lam + 16)                               -> lane lam, register u: Z[lam + 16 u]
-//   P. real-FFT post-pass, one slot per pair (k, M - k): lane lam owns slots s = 0..15 (k = lam + 16 s, its registers 0..15
-//      against registers 31..16 of lane 16 - lam, fetched through the cells); lanes 0 and 8 pair inside themselves, slot
-//      k = 0 yields X[0] and the Nyquist bin, bin M/2 = 256 (lane 0, register 16) is one extra product.
-// A wave carries FOUR frames (16 lanes each), a workgroup is 8 waves = 32 frames = one tile [544 rows = bins][32 frames + pad],
-// 33 floats per row.  The frames of a wave sit in columns w, w + 16, w + 8, w + 24 (lane quarters 0..3): the two frames of a
-// 32-lane half are 16 columns = 16 banks apart, which keeps every transposition and exchange access conflict free at a
-// cell pitch of 17 rows (bank = row + column mod 32).  Per frame the instruction stream is the 32-lane kernel's with the
-// second radix-32 replaced by two radix-16, i.e. half the work per point; every function rounds operation by operation
+// M = N/2 = 32 LL complex points, z[n] = x[2n] + i x[2n+1]:
+//   A. n = l + LL j  : radix-32 over j in registers (fft32 of the 32-lane pipeline)       -> y_l[k1], twiddle W_M^(l k1)
+//   X. LL x 32 transposition through the frame's own column of the output tile: lane l register k1 -> cell l + (LL+1) k1 ->
+//      lane k1 mod LL, registers (k1 div LL, l); one plane at a time, base(lane) + immediate on both sides
+//   B. 32 / LL radix-LL transforms over l in registers (k1 = lam + LL a)                    -> lane lam, register u: Z[lam + LL u]
+//   P. real-FFT post-pass, one slot per pair (k, M - k): lane lam owns slots s = 0..15 (k = lam + LL s, its registers 0..15
+//      against registers 31..16 of lane LL - lam, fetched through the cells); lanes 0 and LL/2 pair inside themselves, slot
+//      k = 0 yields X[0] and the Nyquist bin, bin M/2 (lane 0, register 16) is one extra product.
+// A wave carries 64 / LL frames, a workgroup is 8 waves = one tile [rows = bins][FT frames + pad], FT = 32 (64), FT + 1 floats
+// per row (= 1 mod 32: bank = row + column).  The frames of a 32-lane half sit LL columns apart, which keeps every
+// transposition and exchange access conflict free at a cell pitch of LL + 1 rows.  Per frame the instruction stream is the
+// 32-lane kernel's with the second radix-32 replaced by radix-LL transforms; every function rounds operation by operation
 // (contraction off), so a frame gets the same bits wherever it sits.
-// LDS: 2 x 71,808 (tiles of 544 rows x 33) + 4,096 (window) + 3,968 (W_M^(l k1)) + 2,048 (post-pass twiddles) = 153,728 B;
-// the counters sit in the pad column (rows 528..531 of buffer 0).
+// LDS (LL = 16): 2 x 71,808 (tiles of 544 rows x 33) + 4,096 (window) + 3,968 (W_M^(l k1)) + 2,048 (post-pass twiddles);
+// (LL = 8): 2 x 74,880 (288 rows x 65) + half the tables.  The counters sit in the pad column.
 
-constexpr int kN16 = 1024, kM16 = 512, kBins16 = 513;
-constexpr int kFT16 = 32;                          // frames per tile
-constexpr int kTS16 = kFT16 + 1;                   // floats per tile row
-constexpr int kRows16 = 544;
-constexpr int kTile16Floats = kRows16 * kTS16;
-constexpr size_t kTile16Bytes = (size_t)kTile16Floats * sizeof(float);     // 71,808
-constexpr size_t kWin16Bytes = 16 * 16 * sizeof(float4);                    // window pairs of points l + 16 (2m), l + 16 (2m + 1)
-constexpr size_t kTwA16Bytes = 15 * 16 * sizeof(float4) + 16 * sizeof(float2);
-constexpr size_t kTwP16Bytes = 8 * 16 * sizeof(float4);
-constexpr size_t kFast16Lds = 2 * kTile16Bytes + kWin16Bytes + kTwA16Bytes + kTwP16Bytes;
-static_assert(kFast16Lds <= 160 * 1024, "LDS budget");
-constexpr int kCellPitch16 = 17 * kTS16;           // floats between cells c and c + 17
-constexpr int kRowPitch16 = 16 * kTS16;            // floats between rows r and r + 16
-
-struct Lds16 {
+constexpr int kN16 = 1024, kN8 = 512;
+template <int LL>
+struct PL {
+  static constexpr int N = 64 * LL, M = 32 * LL, Bins = M + 1;
+  static constexpr int FT = 8 * (64 / LL);               // frames per tile
+  static constexpr int TS = FT + 1;                      // floats per tile row
+  static constexpr int CP = LL + 1;                      // rows between cells c and c + 1 of a lane
+  static constexpr int Rows = ((LL - 1 + CP * 31 + 1 + 15) / 16) * 16;
+  static constexpr int TileFloats = Rows * TS;
+  static constexpr size_t TileBytes = (size_t)TileFloats * sizeof(float);
+  static constexpr size_t WinBytes = 16 * LL * sizeof(float4);
+  static constexpr size_t TwABytes = 15 * LL * sizeof(float4) + LL * sizeof(float2);
+  static constexpr size_t TwPBytes = 8 * LL * sizeof(float4);
+  static constexpr size_t Lds = 2 * TileBytes + WinBytes + TwABytes + TwPBytes;
+  static constexpr int CellPitch = CP * TS;              // floats between cells c and c + CP
+  static constexpr int RowPitch = LL * TS;               // floats between rows r and r + LL
+  static constexpr int CounterRow = M + 16;
+  static_assert(Lds <= 160 * 1024, "LDS budget");
+  static_assert(Rows > M + 19, "counter rows");
+};
+template <int LL>
+struct LdsL {
   float *tiles;
+  // tables, read two complex values (16 bytes) per lane and instruction:
+  //   win4[m][l] = window pairs of points l + LL (2m), l + LL (2m + 1)                     m < 16
+  //   twA4[m][l] = W_M^(l k1) for k1 = 2m + 1, 2m + 2 (m < 15), then one row of k1 = 31
+  //   twP4[m][l] = exp(-2 pi i k / N) for k = l + LL (2m), l + LL (2m + 1)                 m < 8
   float4 *win4, *twA4, *twP4;
   float2 *twA31;
-  unsigned *filled, *drained;   // [2] each, kTS16 floats apart
+  unsigned *filled, *drained;   // [2] each, TS floats apart
 };
-__device__ __forceinline__ Lds16 carve_lds16(unsigned char *smem) {
-  Lds16 l;
+template <int LL>
+__device__ __forceinline__ LdsL<LL> carve_ldsL(unsigned char *smem) {
+  using P = PL<LL>;
+  LdsL<LL> l;
   l.tiles = reinterpret_cast<float *>(smem);
-  l.win4 = reinterpret_cast<float4 *>(smem + 2 * kTile16Bytes);
-  l.twA4 = reinterpret_cast<float4 *>(smem + 2 * kTile16Bytes + kWin16Bytes);
-  l.twA31 = reinterpret_cast<float2 *>(smem + 2 * kTile16Bytes + kWin16Bytes + 15 * 16 * sizeof(float4));
-  l.twP4 = reinterpret_cast<float4 *>(smem + 2 * kTile16Bytes + kWin16Bytes + kTwA16Bytes);
-  l.filled = reinterpret_cast<unsigned *>(l.tiles + 528 * kTS16 + kFT16);
-  l.drained = reinterpret_cast<unsigned *>(l.tiles + 530 * kTS16 + kFT16);
+  l.win4 = reinterpret_cast<float4 *>(smem + 2 * P::TileBytes);
+  l.twA4 = reinterpret_cast<float4 *>(smem + 2 * P::TileBytes + P::WinBytes);
+  l.twA31 = reinterpret_cast<float2 *>(smem + 2 * P::TileBytes + P::WinBytes + 15 * LL * sizeof(float4));
+  l.twP4 = reinterpret_cast<float4 *>(smem + 2 * P::TileBytes + P::WinBytes + P::TwABytes);
+  l.filled = reinterpret_cast<unsigned *>(l.tiles + P::CounterRow * P::TS + P::FT);
+  l.drained = reinterpret_cast<unsigned *>(l.tiles + (P::CounterRow + 2) * P::TS + P::FT);
   return l;
 }
 
-// the column (= frame of the tile) of a lane quarter of wave w
-__device__ __forceinline__ int column16(int wave, int quarter) { return wave + 16 * (quarter & 1) + 8 * (quarter >> 1); }
+// the column (= frame of the tile) of lane `lane` of wave w: the 32 / LL frames of a 32-lane half sit LL columns apart
+// (LL = 16: w + 8 h + 16 r; LL = 8: w + 8 r + 32 h; h = lane half, r = frame inside the half)
+template <int LL>
+__device__ __forceinline__ int columnL(int wave, int lane) {
+  const int h = lane >> 5, r = (lane & 31) / LL;
+  return wave + 8 * (LL == 16 ? h + 2 * r : r + 4 * h);
+}
 
-struct Lane16 {
+struct LaneL {
   int l, col;
-  int own;        // cell l of the frame's column: transposition / exchange writes (cell l + 17 j), results of bins l + 16 s
-  int rd;         // cell 17 l: transposition reads (cell i + 17 (l + 16 a))
-  int xr;         // exchange reads: cell p + 17 (15 - s) of slot s, p = 16 - l (l = 0: 17, i.e. its own register 32 - s)
-  int rm;         // results of bins M - k: row (16 - l) + 16 (31 - s)  (l = 0: 16 (32 - s); s = 0 is row 512 = Nyquist)
-  int self;       // lane 0: row 256 (bin M/2); other lanes: a cell they overwrite afterwards
+  int own;        // cell l of the frame's column: transposition / exchange writes (cell l + CP j), results of bins l + LL s
+  int rd;         // cell CP l: transposition reads (cell i + CP (l + LL a))
+  int xr;         // exchange reads: cell p + CP (15 - s) of slot s, p = LL - l (l = 0: CP, i.e. its own register 32 - s)
+  int rm;         // results of bins M - k: row (LL - l) + LL (31 - s)  (l = 0: LL (32 - s); s = 0 is row M = Nyquist)
+  int self;       // lane 0: row M/2; other lanes: a cell they overwrite afterwards
   const float4 *win_l, *twA_l, *twP_l;
   const float2 *twA31_l;
 };
-__device__ __forceinline__ Lane16 setup_lane16(const Lds16 &lds, int lane, int wave) {
-  Lane16 L;
-  L.l = lane & 15;
-  L.col = column16(wave, lane >> 4);
-  L.own = L.l * kTS16 + L.col;
-  L.rd = 17 * L.l * kTS16 + L.col;
-  L.xr = (L.l == 0 ? 17 : 16 - L.l) * kTS16 + L.col;
-  L.rm = ((L.l == 0 ? 16 : 16 - L.l) + 16 * 16) * kTS16 + L.col;
-  L.self = (L.l == 0 ? 256 : L.l) * kTS16 + L.col;
+template <int LL>
+__device__ __forceinline__ LaneL setup_laneL(const LdsL<LL> &lds, int lane, int wave) {
+  using P = PL<LL>;
+  LaneL L;
+  L.l = lane & (LL - 1);
+  L.col = columnL<LL>(wave, lane);
+  L.own = L.l * P::TS + L.col;
+  L.rd = P::CP * L.l * P::TS + L.col;
+  L.xr = (L.l == 0 ? P::CP : LL - L.l) * P::TS + L.col;
+  L.rm = ((L.l == 0 ? LL : LL - L.l) + LL * 16) * P::TS + L.col;
+  L.self = (L.l == 0 ? P::M / 2 : L.l) * P::TS + L.col;
   L.win_l = lds.win4 + L.l;
   L.twA_l = lds.twA4 + L.l;
   L.twA31_l = lds.twA31 + L.l;
@@ -80,38 +100,61 @@ __device__ __forceinline__ Lane16 setup_lane16(const Lds16 &lds, int lane, int w
   return L;
 }
 
-__device__ __forceinline__ void fill_tables16(const FastArgs &a, const Lds16 &lds, int tid, int nthreads) {
+template <int LL>
+__device__ __forceinline__ void fill_tablesL(const FastArgs &a, const LdsL<LL> &lds, int tid, int nthreads) {
+  using P = PL<LL>;
   const float2 *hw = reinterpret_cast<const float2 *>(a.hwin);
-  for (int e = tid; e < 16 * 16; e += nthreads) {
-    const int m = e >> 4, l = e & 15;
-    const float2 w0 = hw[l + 16 * (2 * m)], w1 = hw[l + 16 * (2 * m + 1)];
+  for (int e = tid; e < 16 * LL; e += nthreads) {
+    const int m = e / LL, l = e % LL;
+    const float2 w0 = hw[l + LL * (2 * m)], w1 = hw[l + LL * (2 * m + 1)];
     lds.win4[e] = make_float4(w0.x, w0.y, w1.x, w1.y);
   }
-  for (int e = tid; e < 15 * 16; e += nthreads) {
-    const int m = e >> 4, l = e & 15;
+  for (int e = tid; e < 15 * LL; e += nthreads) {
+    const int m = e / LL, l = e % LL;
     const float2 w0 = a.w_m[l * (2 * m + 1)], w1 = a.w_m[l * (2 * m + 2)];
     lds.twA4[e] = make_float4(w0.x, w0.y, w1.x, w1.y);
   }
-  for (int e = tid; e < 16; e += nthreads) lds.twA31[e] = a.w_m[e * 31];
-  for (int e = tid; e < 8 * 16; e += nthreads) {
-    const int m = e >> 4, l = e & 15;
-    const float2 w0 = a.w_n[l + 16 * (2 * m)], w1 = a.w_n[l + 16 * (2 * m + 1)];
+  for (int e = tid; e < LL; e += nthreads) lds.twA31[e] = a.w_m[e * 31];
+  for (int e = tid; e < 8 * LL; e += nthreads) {
+    const int m = e / LL, l = e % LL;
+    const float2 w0 = a.w_n[l + LL * (2 * m)], w1 = a.w_n[l + LL * (2 * m + 1)];
     lds.twP4[e] = make_float4(w0.x, w0.y, w1.x, w1.y);
   }
-  if (tid < 2) { lds.filled[tid * kTS16] = 0u; lds.drained[tid * kTS16] = 0u; }
+  if (tid < 2) { lds.filled[tid * P::TS] = 0u; lds.drained[tid * P::TS] = 0u; }
 }
 
-// Four frames (one per lane quarter): raw samples -> window -> FFT(512 complex) -> post-pass -> |X|^p in the frames' columns
-// of `tile`; the hooks of `mid` are those of frame32_to_tile.
-template <int PMODE, class Mid>
-__device__ __forceinline__ void frame16_to_tile(const FastArgs &a, const Lane16 &L, float2 (&raw)[32], float *tile, const Mid &mid) {
+// 8-point forward DFT, natural order in and out (operation by operation, as p32_fft16)
+__device__ __forceinline__ void p32_fft8(c32 (&v)[8]) {
 #pragma clang fp contract(off)
+  constexpr float hh = (float)0.70710678118654752;
+  p32_fft4(v[0], v[2], v[4], v[6]);
+  p32_fft4(v[1], v[3], v[5], v[7]);
+  const c32 o1 = p32_cmul(v[3], hh, -hh);     // W8^1
+  const c32 o2 = {v[5].y, -v[5].x};           // W8^2 = -i
+  const c32 o3 = p32_cmul(v[7], -hh, -hh);    // W8^3
+  const c32 e0 = v[0], e1 = v[2], e2 = v[4], e3 = v[6], o0 = v[1];
+  v[0] = {e0.x + o0.x, e0.y + o0.y};
+  v[4] = {e0.x - o0.x, e0.y - o0.y};
+  v[1] = {e1.x + o1.x, e1.y + o1.y};
+  v[5] = {e1.x - o1.x, e1.y - o1.y};
+  v[2] = {e2.x + o2.x, e2.y + o2.y};
+  v[6] = {e2.x - o2.x, e2.y - o2.y};
+  v[3] = {e3.x + o3.x, e3.y + o3.y};
+  v[7] = {e3.x - o3.x, e3.y - o3.y};
+}
+
+// 64 / LL frames (one per LL lanes): raw samples -> window -> FFT(M complex) -> post-pass -> |X|^p in the frames' columns of
+// `tile`; the hooks of `mid` are those of frame32_to_tile.
+template <int LL, int PMODE, class Mid>
+__device__ __forceinline__ void frameL_to_tile(const FastArgs &a, const LaneL &L, float2 (&raw)[32], float *tile, const Mid &mid) {
+#pragma clang fp contract(off)
+  using P = PL<LL>;
   c32 v[32], t[32];
 #pragma unroll
   for (int m0 = 0; m0 < 16; m0 += 8) {
     float4 win[8];
 #pragma unroll
-    for (int m = 0; m < 8; ++m) win[m] = L.win_l[16 * (m0 + m)];
+    for (int m = 0; m < 8; ++m) win[m] = L.win_l[LL * (m0 + m)];
 #pragma unroll
     for (int m = 0; m < 8; ++m) {
       v[2 * (m0 + m)] = {raw[2 * (m0 + m)].x * win[m].x, raw[2 * (m0 + m)].y * win[m].y};
@@ -123,41 +166,41 @@ __device__ __forceinline__ void frame16_to_tile(const FastArgs &a, const Lane16 
   {   // A: radix-32 over j, then twiddle W_M^(l k1), the first plane of the transposition written between the products
     float4 tw[15];
 #pragma unroll
-    for (int m = 0; m < 15; ++m) tw[m] = L.twA_l[16 * m];
+    for (int m = 0; m < 15; ++m) tw[m] = L.twA_l[LL * m];
     const float2 tw31 = L.twA31_l[0];
     fft32(v, [&] { SMX_FENCE(); mid.early(); SMX_FENCE(); });
     SMX_FENCE();
     mid.before_cells();
     float *const wr = tile + opaque32(L.own);
-    float *const wr_hi = wr + 16 * kCellPitch16;
+    float *const wr_hi = wr + 16 * P::CellPitch;
     wr[0] = v[0].x;
 #pragma unroll
     for (int m = 0; m < 15; ++m) {
       v[2 * m + 1] = p32_cmul(v[2 * m + 1], tw[m].x, tw[m].y);
       v[2 * m + 2] = p32_cmul(v[2 * m + 2], tw[m].z, tw[m].w);
-      (2 * m + 1 < 16 ? wr : wr_hi)[kCellPitch16 * ((2 * m + 1) & 15)] = v[2 * m + 1].x;
-      (2 * m + 2 < 16 ? wr : wr_hi)[kCellPitch16 * ((2 * m + 2) & 15)] = v[2 * m + 2].x;
+      (2 * m + 1 < 16 ? wr : wr_hi)[P::CellPitch * ((2 * m + 1) & 15)] = v[2 * m + 1].x;
+      (2 * m + 2 < 16 ? wr : wr_hi)[P::CellPitch * ((2 * m + 2) & 15)] = v[2 * m + 2].x;
       if ((m & 1) == 1) SMX_FENCE();
     }
     v[31] = p32_cmul(v[31], tw31.x, tw31.y);
-    wr_hi[kCellPitch16 * 15] = v[31].x;
+    wr_hi[P::CellPitch * 15] = v[31].x;
   }
   SMX_FENCE();
   float *const wr = tile + opaque32(L.own);
-  float *const wr_hi = wr + 16 * kCellPitch16;   // (ds offsets are 16 bits)
+  float *const wr_hi = wr + 16 * P::CellPitch;   // (ds offsets are 16 bits)
   const float *const rd = tile + opaque32(L.rd);
-  // X: lane lam takes V[i][lam + 16 a], i < 16, a < 2: cell i + 17 (lam + 16 a); t[16 a + i]
+  // X: lane lam takes V[i][lam + LL a], i < LL, a < 32 / LL: cell i + CP (lam + LL a); t[LL a + i]
 #pragma unroll
-  for (int i = 0; i < 32; ++i) t[i].x = rd[kTS16 * (i & 15) + 16 * kCellPitch16 * (i >> 4)];
+  for (int i = 0; i < 32; ++i) t[i].x = rd[P::TS * (i % LL) + LL * P::CellPitch * (i / LL)];
 #pragma unroll
-  for (int j = 0; j < 32; ++j) (j < 16 ? wr : wr_hi)[kCellPitch16 * (j & 15)] = v[j].y;
+  for (int j = 0; j < 32; ++j) (j < 16 ? wr : wr_hi)[P::CellPitch * (j & 15)] = v[j].y;
 #pragma unroll
-  for (int i = 0; i < 32; ++i) t[i].y = rd[kTS16 * (i & 15) + 16 * kCellPitch16 * (i >> 4)];
+  for (int i = 0; i < 32; ++i) t[i].y = rd[P::TS * (i % LL) + LL * P::CellPitch * (i / LL)];
   SMX_FENCE();
   mid.after_transposition_issue();
   SMX_FENCE();
-  // B: two radix-16 over l; register u = a + 2 q holds Z[lam + 16 u]
-  {
+  // B: 32 / LL radix-LL transforms over l; register u = a + (32 / LL) q holds Z[lam + LL u]
+  if constexpr (LL == 16) {
     c32 e[16], o[16];
 #pragma unroll
     for (int i = 0; i < 16; ++i) { e[i] = t[i]; o[i] = t[16 + i]; }
@@ -165,24 +208,36 @@ __device__ __forceinline__ void frame16_to_tile(const FastArgs &a, const Lane16 
     p32_fft16(o);
 #pragma unroll
     for (int q = 0; q < 16; ++q) { t[2 * q] = e[q]; t[2 * q + 1] = o[q]; }
+  } else {
+    c32 g[4][8];
+#pragma unroll
+    for (int aa = 0; aa < 4; ++aa) {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) g[aa][i] = t[8 * aa + i];
+      p32_fft8(g[aa]);
+    }
+#pragma unroll
+    for (int q = 0; q < 8; ++q)
+#pragma unroll
+      for (int aa = 0; aa < 4; ++aa) t[aa + 4 * q] = g[aa][q];
   }
   SMX_FENCE();
-  // P: partners through the cells (as frame32_to_tile, 16 lanes)
+  // P: partners through the cells (as frame32_to_tile, LL lanes)
   float px[16], py[16];
   const float *const xr = tile + opaque32(L.xr);
 #pragma unroll
-  for (int q = 16; q < 32; ++q) wr[kCellPitch16 * (q - 16)] = t[q].x;
+  for (int q = 16; q < 32; ++q) wr[P::CellPitch * (q - 16)] = t[q].x;
   wr_hi[0] = t[0].x;
 #pragma unroll
-  for (int s = 0; s < 16; ++s) px[s] = xr[kCellPitch16 * (15 - s)];
+  for (int s = 0; s < 16; ++s) px[s] = xr[P::CellPitch * (15 - s)];
 #pragma unroll
-  for (int q = 16; q < 32; ++q) wr[kCellPitch16 * (q - 16)] = t[q].y;
+  for (int q = 16; q < 32; ++q) wr[P::CellPitch * (q - 16)] = t[q].y;
   wr_hi[0] = t[0].y;
 #pragma unroll
-  for (int s = 0; s < 16; ++s) py[s] = xr[kCellPitch16 * (15 - s)];
+  for (int s = 0; s < 16; ++s) py[s] = xr[P::CellPitch * (15 - s)];
   float4 tw[8];
 #pragma unroll
-  for (int m = 0; m < 8; ++m) tw[m] = L.twP_l[16 * m];
+  for (int m = 0; m < 8; ++m) tw[m] = L.twP_l[LL * m];
   SMX_FENCE();
   mid.after_exchange_issue();
   SMX_FENCE();
@@ -191,8 +246,8 @@ __device__ __forceinline__ void frame16_to_tile(const FastArgs &a, const Lane16 
     const float zx = t[16].x + t[16].x, zy = t[16].y + t[16].y;
     tile[opaque32(L.self)] = power_of(zx, zy);
   }
-  float *const rk = wr;                        // row l + 16 s
-  float *const rm = tile + opaque32(L.rm);     // row (16 - l) + 16 (31 - s) = rm base + 16 (15 - s)
+  float *const rk = wr;                        // row l + LL s
+  float *const rm = tile + opaque32(L.rm);     // row (LL - l) + LL (31 - s) = rm base + LL (15 - s)
 #pragma unroll
   for (int s = 0; s < 16; ++s) {
     const float wx = (s & 1) ? tw[s >> 1].z : tw[s >> 1].x, wy = (s & 1) ? tw[s >> 1].w : tw[s >> 1].y;
@@ -200,52 +255,72 @@ __device__ __forceinline__ void frame16_to_tile(const FastArgs &a, const Lane16 
     const c32 d = {t[s].x - px[s], t[s].y + py[s]};
     const float tr = __builtin_fmaf(wx, d.y, wy * d.x);
     const float ti = __builtin_fmaf(wy, d.y, -(wx * d.x));
-    rk[kRowPitch16 * s] = power_of(e.x + tr, e.y + ti);
-    rm[kRowPitch16 * (15 - s)] = power_of(e.x - tr, e.y - ti);
+    rk[P::RowPitch * s] = power_of(e.x + tr, e.y + ti);
+    rm[P::RowPitch * (15 - s)] = power_of(e.x - tr, e.y - ti);
     if (s == SMX_P32_STORE_AT || s == SMX_P32_LOAD_AT) { SMX_FENCE(); mid.postpass_at(s); SMX_FENCE(); }
   }
 }
 
-// raw samples of the lane's frame: z[n] = (x[2n], x[2n+1]), n = l + 16 j; `src` is the frame's first sample (per lane)
-template <bool ALIGNED>
-__device__ __forceinline__ void load_frame16(const float *src, int l, float2 (&raw)[32]) {
+// raw samples of the lane's frame: z[n] = (x[2n], x[2n+1]), n = l + LL j; `src` is the frame's first sample (per lane)
+template <int LL, bool ALIGNED>
+__device__ __forceinline__ void load_frameL(const float *src, int l, float2 (&raw)[32]) {
   if constexpr (ALIGNED) {
     const float2 *p = reinterpret_cast<const float2 *>(src) + l;
 #pragma unroll
-    for (int j = 0; j < 32; ++j) raw[j] = p[16 * j];
+    for (int j = 0; j < 32; ++j) raw[j] = p[LL * j];
   } else {
     const float *p = src + 2 * l;
 #pragma unroll
-    for (int j = 0; j < 32; ++j) raw[j] = make_float2(p[32 * j], p[32 * j + 1]);
+    for (int j = 0; j < 32; ++j) raw[j] = make_float2(p[2 * LL * j], p[2 * LL * j + 1]);
   }
 }
 
-// A wave's share of a finished tile: 8 parts of 8 rows (bins) x 4 frames per lane -> out[clip][bin][f0 + 4 g ..]; a row is
-// one 128-byte run of 8 lanes.  Rows 4 h + r' (r' < 4) per 32-lane half keep the LDS reads conflict free.
-struct Flush16 {
-  int src0;         // float offset in the tile of part 0: row0 * 33 + 4 g, row0 = 8 wave + (lane >> 3)
-  unsigned goff0;   // byte offset of out[row0][4 g] from the tile's origin
-  int g;
+// A wave's share of a finished tile: 8 parts of (LL = 16: 8 rows; LL = 8: 4 rows of one 32-frame half of the tile per lane
+// half) x 4 frames per lane -> out[clip][bin][f0 + cb + 4 g ..]; 8 lanes store one 128-byte run.  Rows r' (r' < 4) and
+// frame groups g < 8 per 32-lane half keep the LDS reads conflict free.
+struct FlushL {
+  int src0;         // float offset in the tile of part 0: row0 * TS + cb + 4 g
+  unsigned goff0;   // byte offset of out[row0][cb + 4 g] from the tile's origin
+  int f0;           // cb + 4 g: the lane's first frame
+  bool nyq;         // this lane stores 4 frames of the Nyquist row
 };
-struct FlushRegs16 {
+struct FlushRegsL {
   float v[8][4];
-  float nyq[4];     // bin 512 (wave 0, lanes 0..7)
+  float nyq[4];
 };
-__device__ __forceinline__ void flush16_read(const float *tile, const Flush16 &fl, FlushRegs16 &r) {
+template <int LL>
+__device__ __forceinline__ FlushL setup_flushL(const FastArgs &a, int lane, int wave) {
+  using P = PL<LL>;
+  constexpr int RW = LL == 16 ? 8 : 4;                       // rows per wave and part
+  FlushL fl;
+  const int g = lane & 7, cb = LL == 16 ? 0 : 32 * (lane >> 5);
+  const int row0 = RW * wave + ((lane >> 3) & (RW - 1));
+  fl.f0 = cb + 4 * g;
+  fl.src0 = row0 * P::TS + fl.f0;
+  fl.goff0 = ((unsigned)row0 * (unsigned)a.out_stride + (unsigned)fl.f0) * 4u;
+  fl.nyq = wave == 0 && (lane & 31) < 8 && (LL == 8 || lane < 32);
+  return fl;
+}
+template <int LL>
+__device__ __forceinline__ void flushL_read(const float *tile, const FlushL &fl, FlushRegsL &r) {
+  using P = PL<LL>;
+  constexpr int RW = LL == 16 ? 8 : 4;
   const float *src0 = tile + opaque32(fl.src0);
 #pragma unroll
   for (int it = 0; it < 8; ++it) {
-    const float *src = src0 + 64 * it * kTS16;
+    const float *src = src0 + 8 * RW * it * P::TS;
     r.v[it][0] = src[0]; r.v[it][1] = src[1]; r.v[it][2] = src[2]; r.v[it][3] = src[3];
   }
-  const float *ny = tile + kM16 * kTS16 + 4 * fl.g;   // row 512 = Nyquist bin (every wave reads it, wave 0 lanes 0..7 store it)
+  const float *ny = tile + P::M * P::TS + opaque32(fl.f0);   // the Nyquist row (every lane reads, FT / 4 lanes of wave 0 store)
   r.nyq[0] = ny[0]; r.nyq[1] = ny[1]; r.nyq[2] = ny[2]; r.nyq[3] = ny[3];
 }
-__device__ __forceinline__ void flush16_store(const FastArgs &a, const Flush16 &fl, float *obase, int frames_left, int wave, int lane,
-                                              const FlushRegs16 &r) {
+template <int LL>
+__device__ __forceinline__ void flushL_store(const FastArgs &a, const FlushL &fl, float *obase, int frames_left, const FlushRegsL &r) {
+  using P = PL<LL>;
+  constexpr int RW = LL == 16 ? 8 : 4;
   const unsigned pitch = (unsigned)a.out_stride * 4u;
   const unsigned goff0 = opaque32(fl.goff0);
-  const int fleft = frames_left - 4 * fl.g;
+  const int fleft = frames_left - fl.f0;
   auto put = [&](unsigned goff, const float (&v)[4]) {
     if (fleft >= 4) {
       store4_unaligned(obase, goff, v[0], v[1], v[2], v[3]);
@@ -256,69 +331,72 @@ __device__ __forceinline__ void flush16_store(const FastArgs &a, const Flush16 &
       if (fleft > 2) dst[2] = v[2];
     }
   };
-  if (frames_left >= kFT16) {   // wave-uniform: a whole tile, no masks
+  if (frames_left >= P::FT) {   // wave-uniform: a whole tile, no masks
 #pragma unroll
-    for (int it = 0; it < 8; ++it) store4_unaligned(obase, goff0 + (unsigned)(64 * it) * pitch, r.v[it][0], r.v[it][1], r.v[it][2], r.v[it][3]);
+    for (int it = 0; it < 8; ++it)
+      store4_unaligned(obase, goff0 + (unsigned)(8 * RW * it) * pitch, r.v[it][0], r.v[it][1], r.v[it][2], r.v[it][3]);
   } else {
 #pragma unroll
-    for (int it = 0; it < 8; ++it) put(goff0 + (unsigned)(64 * it) * pitch, r.v[it]);
+    for (int it = 0; it < 8; ++it) put(goff0 + (unsigned)(8 * RW * it) * pitch, r.v[it]);
   }
-  if (wave == 0 && lane < 8) put((unsigned)kM16 * pitch + 16u * (unsigned)fl.g, r.nyq);
+  if (fl.nyq) put((unsigned)P::M * pitch + 4u * (unsigned)fl.f0, r.nyq);
 }
 
-template <bool ALIGNED>
-struct PowerMid16 {
+template <int LL, bool ALIGNED>
+struct PowerMidL {
+  using P = PL<LL>;
   const FastArgs &a;
-  const Lds16 &lds;
-  const Flush16 &fl;
-  FlushRegs16 &fr;
+  const LdsL<LL> &lds;
+  const FlushL &fl;
+  FlushRegsL &fr;
   float2 (&raw)[32];
   const float *src;      // the next frames' samples (per lane)
   float *pend_out;       // output origin and frames of the previous tile
   int pend_left;
   int lane, wave, b, it;
   unsigned &pk_drained, &pk_filled;
-  __device__ __forceinline__ void early() const { pk_drained = peek32(lds.drained + b * kTS16); }
+  __device__ __forceinline__ void early() const { pk_drained = peek32(lds.drained + b * P::TS); }
   __device__ __forceinline__ void before_cells() const {
-    lds_wait32(lds.drained + b * kTS16, 8u * ((unsigned)it >> 1), pk_drained);
+    lds_wait32(lds.drained + b * P::TS, 8u * ((unsigned)it >> 1), pk_drained);
   }
   __device__ __forceinline__ void after_transposition_issue() const {
-    if (it > 0) pk_filled = peek32(lds.filled + (b ^ 1) * kTS16);
+    if (it > 0) pk_filled = peek32(lds.filled + (b ^ 1) * P::TS);
   }
   __device__ __forceinline__ void after_exchange_issue() const {
     if (it > 0) {
-      lds_wait32(lds.filled + (b ^ 1) * kTS16, 8u * (((unsigned)(it - 1) >> 1) + 1), pk_filled);
-      flush16_read(lds.tiles + (b ^ 1) * kTile16Floats, fl, fr);
-      lds_signal32(lds.drained + (b ^ 1) * kTS16, lane);   // "read out" as soon as the reads are issued (in-order LDS)
+      lds_wait32(lds.filled + (b ^ 1) * P::TS, 8u * (((unsigned)(it - 1) >> 1) + 1), pk_filled);
+      flushL_read<LL>(lds.tiles + (b ^ 1) * P::TileFloats, fl, fr);
+      lds_signal32(lds.drained + (b ^ 1) * P::TS, lane);   // "read out" as soon as the reads are issued (in-order LDS)
     }
   }
   __device__ __forceinline__ void postpass_at(int s) const {
     const bool same = SMX_P32_STORE_AT == SMX_P32_LOAD_AT;
-    if (s == SMX_P32_LOAD_AT && same && SMX_P32_LOADS_FIRST) { load_frame16<ALIGNED>(src, lane & 15, raw); SMX_FENCE(); }
-    if (s == SMX_P32_STORE_AT && it > 0) flush16_store(a, fl, pend_out, pend_left, wave, lane, fr);
+    if (s == SMX_P32_LOAD_AT && same && SMX_P32_LOADS_FIRST) { load_frameL<LL, ALIGNED>(src, lane & (LL - 1), raw); SMX_FENCE(); }
+    if (s == SMX_P32_STORE_AT && it > 0) flushL_store<LL>(a, fl, pend_out, pend_left, fr);
     SMX_FENCE();
-    if (s == SMX_P32_LOAD_AT && !(same && SMX_P32_LOADS_FIRST)) load_frame16<ALIGNED>(src, lane & 15, raw);
+    if (s == SMX_P32_LOAD_AT && !(same && SMX_P32_LOADS_FIRST)) load_frameL<LL, ALIGNED>(src, lane & (LL - 1), raw);
   }
 };
 
-template <bool ALIGNED, int PMODE, bool STRIP>
-__global__ void __launch_bounds__(512) stft1024_power16_kernel(FastArgs a) {
+template <int LL, bool ALIGNED, int PMODE, bool STRIP>
+__global__ void __launch_bounds__(512) stft_power_lanes_kernel(FastArgs a) {
+  using P = PL<LL>;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const Lds16 lds = carve_lds16(smem);
-  const Lane16 L = setup_lane16(lds, lane, wave);
-  fill_tables16(a, lds, tid, 512);
+  const LdsL<LL> lds = carve_ldsL<LL>(smem);
+  const LaneL L = setup_laneL<LL>(lds, lane, wave);
+  fill_tablesL<LL>(a, lds, tid, 512);
   TileWalk tw;
-  tw.init(a, a.out + a.out_offset, kBins16 * a.out_stride);
+  tw.init(a, a.out + a.out_offset, P::Bins * a.out_stride);
   const int ntiles = tw.ntiles > 0 ? tw.ntiles : 0;
 
-  // first sample of this lane's frame in tile t of the clip at xc (a lane quarter without a frame re-reads the tile's first
-  // frame and its results are never stored)
+  // first sample of this lane's frame in tile t of the clip at xc (lanes without a frame re-read the tile's first frame and
+  // their results are never stored)
   auto frame_ptr = [&](const float *xc, int t) {
-    const int64_t f0 = (int64_t)t * kFT16;
-    const int avail = (int)(a.count - f0 < kFT16 ? a.count - f0 : kFT16) - 1;   // last frame of the tile that exists (wave-uniform)
+    const int64_t f0 = (int64_t)t * P::FT;
+    const int avail = (int)(a.count - f0 < P::FT ? a.count - f0 : P::FT) - 1;   // last frame of the tile that exists (wave-uniform)
     const int fi = L.col;
     const int64_t p = a.p0 + f0 + (fi <= avail ? fi : 0);
     if (a.fold_frames && (p < a.border_i0 || p >= a.border_i1)) {
@@ -332,18 +410,12 @@ __global__ void __launch_bounds__(512) stft1024_power16_kernel(FastArgs a) {
   float2 raw[32];
 #pragma unroll
   for (int j = 0; j < 32; ++j) raw[j] = make_float2(0.f, 0.f);
-  if (ntiles > 0) load_frame16<ALIGNED>(frame_ptr(tw.xclip, tw.ft), L.l, raw);
+  if (ntiles > 0) load_frameL<LL, ALIGNED>(frame_ptr(tw.xclip, tw.ft), L.l, raw);
   __syncthreads();   // tables and zeroed counters visible: the only workgroup barrier of the main loop
   float *pend_out = nullptr;
   int pend_left = 0;
-  Flush16 fl;
-  {
-    fl.g = lane & 7;
-    const int row0 = 8 * wave + (lane >> 3);
-    fl.src0 = row0 * kTS16 + 4 * fl.g;
-    fl.goff0 = ((unsigned)row0 * (unsigned)a.out_stride + 4u * fl.g) * 4u;
-  }
-  FlushRegs16 fr;
+  const FlushL fl = setup_flushL<LL>(a, lane, wave);
+  FlushRegsL fr;
   unsigned pk_drained = 0, pk_filled = 0;
   for (int it = 0; it < ntiles; ++it) {   // tile `it` of this workgroup lives in buffer it & 1
     const int b = it & 1;
@@ -353,25 +425,25 @@ __global__ void __launch_bounds__(512) stft1024_power16_kernel(FastArgs a) {
     tw.peek(a, ftnext, xnext, onext);
     const bool more = it + 1 < ntiles;
     const float *src = frame_ptr(more ? xnext : tw.xclip, more ? ftnext : tw.ft);
-    const PowerMid16<ALIGNED> mid{a, lds, fl, fr, raw, src, pend_out, pend_left, lane, wave, b, it, pk_drained, pk_filled};
-    frame16_to_tile<PMODE>(a, L, raw, lds.tiles + b * kTile16Floats, mid);
-    lds_signal32(lds.filled + b * kTS16, lane);
-    pend_out = tw.oclip + tw.ft * kFT16;   // wave-uniform
-    const int64_t left = a.count - (int64_t)tw.ft * kFT16;
-    pend_left = left < kFT16 ? (int)left : kFT16;
+    const PowerMidL<LL, ALIGNED> mid{a, lds, fl, fr, raw, src, pend_out, pend_left, lane, wave, b, it, pk_drained, pk_filled};
+    frameL_to_tile<LL, PMODE>(a, L, raw, lds.tiles + b * P::TileFloats, mid);
+    lds_signal32(lds.filled + b * P::TS, lane);
+    pend_out = tw.oclip + tw.ft * P::FT;   // wave-uniform
+    const int64_t left = a.count - (int64_t)tw.ft * P::FT;
+    pend_left = left < P::FT ? (int)left : P::FT;
     tw.xclip = xnext;
     tw.oclip = onext;
     tw.ft = ftnext;
   }
   if (ntiles > 0) {   // the last tile of this workgroup
     const int b = (ntiles - 1) & 1;
-    lds_wait(lds.filled + b * kTS16, 8u * (((unsigned)(ntiles - 1) >> 1) + 1));
-    flush16_read(lds.tiles + b * kTile16Floats, fl, fr);
-    flush16_store(a, fl, pend_out, pend_left, wave, lane, fr);
+    lds_wait(lds.filled + b * P::TS, 8u * (((unsigned)(ntiles - 1) >> 1) + 1));
+    flushL_read<LL>(lds.tiles + b * P::TileFloats, fl, fr);
+    flushL_store<LL>(a, fl, pend_out, pend_left, fr);
   }
 
   // Border frames (the few per clip whose window reaches past either end of the signal): same frame code on samples fetched
-  // through the padding rule, 32 (clip, frame) pairs per tile, results scattered to their places.
+  // through the padding rule, FT (clip, frame) pairs per tile, results scattered to their places.
   if (a.border_left + a.border_right > 0) {
     const int per = a.border_left + a.border_right;
     const int64_t lead = a.total_tiles / a.tiles_per_clip;
@@ -382,11 +454,11 @@ __global__ void __launch_bounds__(512) stft1024_power16_kernel(FastArgs a) {
       p = r < a.border_left ? a.border_p0 + r : a.border_i1 + (r - a.border_left);
     };
     float *bt_tile = lds.tiles;
-    for (int64_t bt = blockIdx.x; bt * kFT16 < total; bt += gridDim.x) {
+    for (int64_t bt = blockIdx.x; bt * P::FT < total; bt += gridDim.x) {
       __syncthreads();   // the buffer is free: every wave is past its last flush / the previous border tile
       {
-        int64_t beta = bt * kFT16 + L.col;
-        if (beta >= total) beta = bt * kFT16;   // a quarter without a pair repeats the tile's first one (never stored)
+        int64_t beta = bt * P::FT + L.col;
+        if (beta >= total) beta = bt * P::FT;   // lanes without a pair repeat the tile's first one (never stored)
         int64_t clip, p;
         locate(beta, clip, p);
         const float *xs = a.x + clip * a.x_stride;
@@ -394,19 +466,19 @@ __global__ void __launch_bounds__(512) stft1024_power16_kernel(FastArgs a) {
         float2 braw[32];
 #pragma unroll
         for (int j = 0; j < 32; ++j) {
-          const int s = s0 + 2 * (L.l + 16 * j);
+          const int s = s0 + 2 * (L.l + LL * j);
           braw[j] = make_float2(fetch_padded(xs, (int)a.n, s, a.pad, a.pad_value), fetch_padded(xs, (int)a.n, s + 1, a.pad, a.pad_value));
         }
-        frame16_to_tile<PMODE>(a, L, braw, bt_tile, NoMid32{});
+        frameL_to_tile<LL, PMODE>(a, L, braw, bt_tile, NoMid32{});
       }
       __syncthreads();
-      for (int e = tid; e < kBins16 * kFT16; e += 512) {
-        const int k = e / kFT16, f = e % kFT16;
-        const int64_t bf = bt * kFT16 + f;
+      for (int e = tid; e < P::Bins * P::FT; e += 512) {
+        const int k = e / P::FT, f = e % P::FT;
+        const int64_t bf = bt * P::FT + f;
         if (bf < total) {
           int64_t clip, p;
           locate(bf, clip, p);
-          a.out[(clip * kBins16 + k) * a.out_stride + a.border_out_offset + (p - a.border_p0)] = bt_tile[k * kTS16 + f];
+          a.out[(clip * P::Bins + k) * a.out_stride + a.border_out_offset + (p - a.border_p0)] = bt_tile[k * P::TS + f];
         }
       }
     }

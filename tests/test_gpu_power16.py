@@ -1,5 +1,6 @@
-"""The power spectrogram at fft 1024 on the 16-lane register pipeline (stft1024_power16_kernel, stft_fast_p16.hpp):
-BASELINE C1's geometry (fft 1024 / hop 256) and its neighbours against the float64 oracle, and the reference's structural
+"""The power spectrogram at fft 1024 and fft 512 on the register pipeline with a frame in 16 / 8 lanes
+(stft_power_lanes_kernel, stft_fast_p16.hpp): BASELINE C1's geometry (fft 1024 / hop 256), fft 512 / hop 128 and their
+neighbours against the float64 oracle, and the reference's structural
 laws bit for bit -- frame-range tiling across tile boundaries (stft_grid.ml:32-73), batch == stack of slices (:180-205),
 the streaming partition law through the power stage (stft_law.ml:79-164) --, border frames by the kernel's epilogue and by
 gathered strips, ragged tiles, clips shorter than a frame, unaligned samples, every exponent of magnitude_pow."""
@@ -38,14 +39,21 @@ def _check(got, want, power, msg):
     (dict(hop=256), 1, 2),
 ])
 @pytest.mark.parametrize("power", [2.0, 1.0])
-def test_against_the_oracle(kw, n, lead, power):
+@pytest.mark.parametrize("fft", [1024, 512])
+def test_against_the_oracle(fft, kw, n, lead, power):
     rng = np.random.default_rng(n + int(power))
+    kw = dict(kw)
+    if fft == 512:                                          # the same shapes at half the size
+        kw["hop"] = max(1, kw["hop"] // 2) if kw["hop"] % 2 == 0 else kw["hop"] // 2 | 1
+        if "win_length" in kw:
+            kw["win_length"] //= 2
+        n = n if n < 1000 else n // 2
     x = rng.uniform(-1, 1, size=(lead, n)).astype(np.float32)
-    c = Stft.Config.create(fft_size=1024, **kw)
+    c = Stft.Config.create(fft_size=fft, **kw)
     okw = dict(kw)
     if isinstance(okw.get("pad"), tuple):
         okw["pad"], okw["pad_value"] = okw["pad"]
-    o = O.stft_config(1024, **okw)
+    o = O.stft_config(fft, **okw)
     got = Stft.power_spectrum(c, x, power)
     want = O.power_spectrum(o, x, power)
     assert got.dtype == np.float32
@@ -67,13 +75,14 @@ def test_regression_gate_on_a_c1_batch():
         assert np.max(np.abs(got[i] - want)) <= 2 * REGRESSION * float(np.max(want)), i
 
 
-def test_ranges_tile_exactly_across_tile_boundaries():
+@pytest.mark.parametrize("fft", [1024, 512])
+def test_ranges_tile_exactly_across_tile_boundaries(fft):
     import torch
     x = torch.rand(3, 70000, device="cuda") * 2 - 1
-    c = Stft.Config.create(fft_size=1024, hop=256)
+    c = Stft.Config.create(fft_size=fft, hop=fft // 4)
     full = Stft.power_spectrum(c, x)
     total = Stft.frames(c, x.shape[-1])
-    cuts = [0, 1, 2, 31, 32, 33, 64, 100, total - 33, total - 2, total]
+    cuts = [0, 1, 2, 31, 32, 33, 63, 64, 65, 100, total - 65, total - 33, total - 2, total]
     parts = [Stft.power_range(c, x, a, b) for a, b in zip(cuts[:-1], cuts[1:])]
     assert torch.equal(torch.cat(parts, dim=-1), full)
     assert np.array_equal(full.cpu().numpy(), Stft.power_spectrum(c, x.cpu().numpy()))      # device path == host path
@@ -82,40 +91,43 @@ def test_ranges_tile_exactly_across_tile_boundaries():
         assert torch.equal(torch.cat([Stft.power_range(c, x, a, b, power) for a, b in zip(cuts[:-1], cuts[1:])], dim=-1), f)
 
 
-def test_batch_is_the_stack_of_its_slices():
+@pytest.mark.parametrize("fft", [1024, 512])
+def test_batch_is_the_stack_of_its_slices(fft):
     rng = np.random.default_rng(3)
     x = rng.uniform(-1, 1, size=(2, 3, 4 * 1024 + 5)).astype(np.float32)
-    for hop in (256, 255):
-        c = Stft.Config.create(fft_size=1024, hop=hop)
+    for hop in (fft // 4, fft // 4 - 1):
+        c = Stft.Config.create(fft_size=fft, hop=hop)
         full = Stft.power_spectrum(c, x)
         for i in range(2):
             for j in range(3):
                 assert np.array_equal(full[i, j], Stft.power_spectrum(c, x[i, j]))
 
 
-def test_many_short_clips_take_the_strip_path_and_agree():
-    """8000 clips of 2000 samples: 8 frames each, 4 touching a border -- above the launcher's epilogue threshold, so the kernel
-    reads the border frames from gathered strips; the same clips in a batch of 50 take the epilogue: identical frame code."""
+@pytest.mark.parametrize("fft", [1024, 512])
+def test_many_short_clips_take_the_strip_path_and_agree(fft):
+    """8000 clips of 8 frames each, 4 touching a border -- above the launcher's epilogue threshold, so the kernel reads the
+    border frames from gathered strips; the same clips in a batch of 50 take the epilogue: identical frame code."""
     import torch
     rng = np.random.default_rng(11)
-    x = torch.from_numpy(rng.uniform(-1, 1, size=(8000, 2000)).astype(np.float32)).cuda()
-    c = Stft.Config.create(fft_size=1024, hop=256)
+    x = torch.from_numpy(rng.uniform(-1, 1, size=(8000, 2000 * fft // 1024)).astype(np.float32)).cuda()
+    c = Stft.Config.create(fft_size=fft, hop=fft // 4)
     p = Stft.power_spectrum(c, x)
-    assert tuple(p.shape) == (8000, 513, 8)
+    assert tuple(p.shape) == (8000, fft // 2 + 1, 8)
     for lo in (0, 3950, 7950):
         assert torch.equal(p[lo:lo + 50], Stft.power_spectrum(c, x[lo:lo + 50])), lo
-    o = O.stft_config(1024, hop=256)
+    o = O.stft_config(fft, hop=fft // 4)
     for clip in (0, 4321, 7999):
         want = O.power_spectrum(o, x[clip].cpu().numpy())
         assert np.max(np.abs(p[clip].cpu().numpy() - want)) <= 2 * REGRESSION * float(np.max(want)), clip
 
 
 @pytest.mark.parametrize("alignment,pad", [("centered", "reflect"), ("left", "edge"), ("right", ("constant", 0.5))])
-def test_power_stage_streams_the_offline_result(alignment, pad):
+@pytest.mark.parametrize("fft", [1024, 512])
+def test_power_stage_streams_the_offline_result(fft, alignment, pad):
     rng = np.random.default_rng(5)
     n = 40 * 1024 + 333
     x = rng.standard_normal((2, n)).astype(np.float32)
-    c = Stft.Config.create(fft_size=1024, hop=256, alignment=alignment, pad=pad)
+    c = Stft.Config.create(fft_size=fft, hop=fft // 4, alignment=alignment, pad=pad)
     for power in (2.0, 1.0):
         offline = Stft.power_spectrum(c, x, power)
         for block in (n, 9000, 1000, 257):
@@ -130,12 +142,13 @@ def test_power_stage_streams_the_offline_result(alignment, pad):
 
 
 @pytest.mark.parametrize("power", [0.5, 3.0, 0.0])
-def test_general_powers(power):
+@pytest.mark.parametrize("fft", [1024, 512])
+def test_general_powers(fft, power):
     rng = np.random.default_rng(int(power * 10) + 3)
     x = rng.uniform(-1, 1, size=(2, 20000)).astype(np.float32)
     x[1] = 0.0
-    c = Stft.Config.create(fft_size=1024, hop=256)
+    c = Stft.Config.create(fft_size=fft, hop=fft // 4)
     got = Stft.power_spectrum(c, x, power)
-    want = O.power_spectrum(O.stft_config(1024, hop=256), x, power)
+    want = O.power_spectrum(O.stft_config(fft, hop=fft // 4), x, power)
     _check(got[0], want[0], power, power)
     assert np.all(got[1] == (0.0 if power > 0 else 1.0))
