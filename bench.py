@@ -315,7 +315,7 @@ def main():
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_source,
                          "frac_of_measured": round(achieved / HBM_MEASURED_GBS, 4), "measured_peak": HBM_MEASURED_GBS,
-                         "kernel": "stft2048_power32_kernel<true, true, false> (one launch per step: all %d frames of %d clips)"
+                         "kernel": "stft2048_power32_kernel<true, 2, false> (one launch per step: all %d frames of %d clips)"
                                    % (frames, clips),
                          "launches_per_step": launches,
                          "kernel_ms_avg": round(avg_ms, 4), "kernel_ms_median": round(step_ms[len(step_ms) // 2], 4),

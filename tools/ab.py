@@ -7,7 +7,7 @@ i64, vp = ctypes.c_int64, ctypes.c_void_p
 paths = sys.argv[1:]
 N_ENV = int(os.environ.get("AB_N", "480000"))   # AB_N=482816 gives 944 frames: 64-byte aligned output rows
 libs = []
-clips, n = 256, N_ENV
+clips, n = int(os.environ.get("AB_CLIPS", "256")), N_ENV
 frames = 1 + n // 512
 x = torch.rand(clips, n, device="cuda") * 2 - 1
 out = torch.empty(clips, 1025, frames, device="cuda")

@@ -1,5 +1,6 @@
 """Driver for tools/profile_round.sh: a few launches of every hot kernel of the BASELINE configurations, nothing else on
-the device (C2 power spectrogram, C2 with the ring-form kernel, C2 complex, C3 fused mel, Mel.apply, C4 FIR)."""
+the device (C2 power spectrogram on the 32-lane and the 64-lane kernel, C3 fused mel, Mel.apply, the power spectrogram at fft 1024 and
+512 on 256 clips of C1's length, C4 FIR)."""
 import ctypes, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -15,6 +16,12 @@ out = torch.empty(256, 1025, frames, device="cuda")
 mout = torch.empty(256, 128, frames, device="cuda")
 h = Fir.design_lowpass(8192, 0.25, 100.0)
 plan = Fir.Plan.create(h)
+c1k = Stft.Config.create(fft_size=1024, hop=256)      # the lanes kernels at the sizes of tools/bench_extra.py
+c512 = Stft.Config.create(fft_size=512, hop=128)
+f1k, f512 = Stft.frames(c1k, 441000), Stft.frames(c512, 441000)
+x1 = torch.rand(256, 441000, device="cuda") * 2 - 1
+o1k = torch.empty(256, 513, f1k, device="cuda")
+o512 = torch.empty(256, 257, f512, device="cuda")
 xs = torch.rand(8, 2880000, device="cuda") * 2 - 1
 ys = torch.empty_like(xs)
 reps = int(os.environ.get("REPS", "4"))
@@ -26,5 +33,7 @@ for _ in range(reps):
     os.environ.pop("SMX_POWER_V1", None)
     check(lib.smx_mel_spectrogram_f32_dev(sc._h, mc._h, vp(x.data_ptr()), 256, 480000, 480000, 2.0, vp(mout.data_ptr()), None))
     check(lib.smx_mel_apply_f32_dev(mc._h, vp(out.data_ptr()), 256, 1025, frames, vp(mout.data_ptr()), None))
+    check(lib.smx_stft_power_range_f32_dev(c1k._h, vp(x1.data_ptr()), 256, 441000, 441000, 0, f1k, 2.0, vp(o1k.data_ptr()), None))
+    check(lib.smx_stft_power_range_f32_dev(c512._h, vp(x1.data_ptr()), 256, 441000, 441000, 0, f512, 2.0, vp(o512.data_ptr()), None))
     check(lib.smx_fir_apply_f32_dev(plan._h, vp(xs.data_ptr()), 8, 2880000, 2880000, vp(ys.data_ptr()), 2880000, None))
 torch.cuda.synchronize()
