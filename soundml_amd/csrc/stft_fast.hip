@@ -441,6 +441,7 @@ __device__ __forceinline__ float fetch_padded(const float *x, int n, int s, int 
 // instructions; the only ones are in init()).
 struct TileWalk {
   int ntiles, ft, step_clips, step_tiles;   // ft: tile index inside the clip
+  int uid;                                  // this workgroup's rank among the launch's workgroups in tile order (its first tile when it has one)
   const float *xclip;                       // first sample of the current clip
   float *oclip;                             // output origin of the current clip
   int64_t x_step, o_step;                   // per-clip strides of input and output
@@ -448,6 +449,7 @@ struct TileWalk {
   __device__ __forceinline__ void init(const FastArgs &a, float *out, int64_t out_clip_floats) {
     int64_t tau0;
     int step;
+    uid = (int)blockIdx.x;
     if (a.interleave) {
       // The workgroups of one XCD walk a contiguous chunk of the sequence side by side: at any time the
       // XCD is writing ~32 neighbouring tiles of the same clip, i.e. for every bin one contiguous run of
@@ -456,6 +458,7 @@ struct TileWalk {
       if (a.interleave == 2) {   // all workgroups side by side; an XCD holds 32 neighbouring tiles of every 256
         const int64_t q = nb / 8, r = nb % 8;
         tau0 = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+        uid = (int)tau0;
         step = (int)nb;
         ntiles = tau0 < a.total_tiles ? (int)((a.total_tiles - tau0 + nb - 1) / nb) : 0;
       } else {
@@ -1626,6 +1629,12 @@ void launch_interior(const StftJob &job, const FastTarget &tg, const float *x, i
     cu_count = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
   }
   a.blocks = a.total_tiles < cu_count ? a.total_tiles : cu_count;
+  if (!strip && !tg.mel && !tg.complex_out && tg.border_left + tg.border_right > 0 && a.blocks < cu_count) {
+    // a small launch: the border tiles of the 32- / 16- / 8-lane kernels' epilogue go to workgroups of their own (they are
+    // handed out from the last workgroup down), so that a short clip does not pay two tile latencies in a row
+    const int64_t border_tiles = (job.lead * (tg.border_left + tg.border_right) + ft - 1) / ft;
+    a.blocks = a.blocks + border_tiles < cu_count ? a.blocks + border_tiles : cu_count;
+  }
   {
     // Tile order (TileWalk::init).  Measured on whole batches: while input + output stay within ~2 GB the
     // chip-wide order (2) is 0-3 % ahead; beyond that the per-XCD chunks (1) win by 3-33 % (C5, 71 GB:

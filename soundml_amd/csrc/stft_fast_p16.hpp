@@ -454,7 +454,7 @@ __global__ void __launch_bounds__(512) stft_power_lanes_kernel(FastArgs a) {
       p = r < a.border_left ? a.border_p0 + r : a.border_i1 + (r - a.border_left);
     };
     float *bt_tile = lds.tiles;
-    for (int64_t bt = blockIdx.x; bt * P::FT < total; bt += gridDim.x) {
+    for (int64_t bt = (int64_t)gridDim.x - 1 - tw.uid; bt * P::FT < total; bt += gridDim.x) {   // from the last workgroup down: idle ones first
       __syncthreads();   // the buffer is free: every wave is past its last flush / the previous border tile
       {
         int64_t beta = bt * P::FT + L.col;

@@ -664,7 +664,7 @@ __global__ void __launch_bounds__(512) stft2048_power32_kernel(FastArgs a) {
       p = r < a.border_left ? a.border_p0 + r : a.border_i1 + (r - a.border_left);
     };
     float *bt_tile = lds.tiles;
-    for (int64_t bt = blockIdx.x; bt * kFT < total; bt += gridDim.x) {
+    for (int64_t bt = (int64_t)gridDim.x - 1 - tw.uid; bt * kFT < total; bt += gridDim.x) {   // from the last workgroup down: idle ones first
       __syncthreads();   // the buffer is free: every wave is past its last flush / the previous border tile
       if (bt * kFT + 2 * wave < total) {   // wave-uniform
         int64_t beta = bt * kFT + 2 * wave + L.h;
