@@ -894,6 +894,7 @@ __global__ void __launch_bounds__(1024) stft2048_power_kernel(FastArgs a) {
 }
 
 #include "stft_fast_p32.hpp"   // the 32-lane frame pipeline: stft2048_power32_kernel
+#include "stft_fast_mel32.hpp" // the fused audio -> mel kernel on the 32-lane pipeline: stft2048_mel32_kernel
 #include "stft_fast_p16.hpp"   // the same pipeline with a frame in 16 / 8 lanes: stft_power_lanes_kernel (power spectrogram at fft 1024 / 512)
 
 // ---- power spectrogram kernel, ring form ----------------------------------------------------------------------
@@ -1581,6 +1582,7 @@ struct FastTarget {
   int64_t out_stride = 0;       // frames dimension of the output
   int64_t out_offset = 0;       // frame offset of this job's first frame
   const MelFusedArgs *mel = nullptr;
+  const Mel32Args *mel32 = nullptr;   // with mel: the 32-lane kernel's plan (nullptr: the 64-lane kernel)
   bool complex_out = false;     // Stft.transform: interleaved (re, im)
   // power kernel only: border frames folded into the interior launch (see stft2048_power_kernel's epilogue)
   int border_left = 0, border_right = 0;
@@ -1675,6 +1677,19 @@ void launch_interior(const StftJob &job, const FastTarget &tg, const float *x, i
     };
     if (lanes == 16) launch_lanes(std::integral_constant<int, 16>{});
     else launch_lanes(std::integral_constant<int, 8>{});
+    SMX_HIP_CHECK(hipGetLastError());
+    return;
+  }
+  if (tg.mel && tg.mel32) {
+    Mel32Args m = *tg.mel32;
+    m.out_offset = out_offset;
+    auto by_power = [&](auto al) {
+      constexpr bool A = decltype(al)::value;
+      return a.pmode == 2 ? stft2048_mel32_kernel<A, 2> : a.pmode == 1 ? stft2048_mel32_kernel<A, 1> : stft2048_mel32_kernel<A, 0>;
+    };
+    auto k32 = aligned ? by_power(std::true_type{}) : by_power(std::false_type{});
+    SMX_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k32), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kFast32Lds));
+    SMX_LAUNCH(k32, dim3((unsigned)a.blocks), dim3(512), kFast32Lds, job.stream, a, m);
     SMX_HIP_CHECK(hipGetLastError());
     return;
   }
@@ -1931,6 +1946,19 @@ bool launch_mel_spectrogram_fused(const MelSpecJob &job) {
   tg.out_stride = job.stft.count;
   tg.out_offset = 0;
   tg.mel = &m;
+  Mel32Args m32{};
+  if (env_flag("SMX_MEL_V1") != 1) {   // SMX_MEL_V1=1: the 64-lane kernel (A/B timing, tests: two implementations of one contract)
+    const MelFusedPlan &p32 = job.mel->fused32_plan();
+    if (p32.state == 1) {
+      m32.items = reinterpret_cast<const Mel32Item *>(p32.items);
+      m32.w = p32.w_mfma;
+      m32.out = m.out;
+      m32.out_stride = m.out_stride;
+      m32.out_offset = 0;
+      m32.n_mels = m.n_mels;
+      tg.mel32 = &m32;
+    }
+  }
   launch_ranges(job.stft, tg);
   SMX_HIP_CHECK(hipFreeAsync(m.scratch, job.stft.stream));
   return true;
@@ -2025,6 +2053,91 @@ const smx::MelFusedPlan &smx_mel_config::fused_plan() const {
   wm.resize(wm.size() + 64 * (size_t)kMelMaxSteps, 0.0f);   // every item can be read kMelMaxSteps rows deep
   SMX_HIP_CHECK(hipMalloc(&plan.items, items.size() * sizeof(MelItem)));
   SMX_HIP_CHECK(hipMemcpy(plan.items, items.data(), items.size() * sizeof(MelItem), hipMemcpyHostToDevice));
+  SMX_HIP_CHECK(hipMalloc((void **)&plan.w_mfma, wm.size() * sizeof(float)));
+  SMX_HIP_CHECK(hipMemcpy(plan.w_mfma, wm.data(), wm.size() * sizeof(float), hipMemcpyHostToDevice));
+  plan.state = 1;
+  return plan;
+}
+
+// ---- work plan of the 32-lane fused mel kernel (stft_fast_mel32.hpp): items of up to 16 mel rows, each summed over its own
+// band by one wave; the longest items are split by rows until no wave holds much more than an eighth of the MFMA steps
+const smx::MelFusedPlan &smx_mel_config::fused32_plan() const {
+  using namespace smx;
+  int device = 0;
+  SMX_HIP_CHECK(hipGetDevice(&device));
+  std::lock_guard<std::mutex> lock(mutex_);
+  MelFusedPlan &plan = fused32_[device];
+  if (plan.state != 0) return plan;
+  plan.state = -1;
+  const int64_t nb = bins();
+  if (fft_size != kN || n_mels < 1 || n_mels > 256) return plan;
+  std::vector<int> lo((size_t)n_mels, (int)nb), hi((size_t)n_mels, 0);
+  for (int64_t mm = 0; mm < n_mels; ++mm)
+    for (int64_t k = 0; k < nb; ++k)
+      if ((float)weights[(size_t)(mm * nb + k)] != 0.0f) {
+        if (k < lo[(size_t)mm]) lo[(size_t)mm] = (int)k;
+        hi[(size_t)mm] = (int)k + 1;
+      }
+  struct Piece { int row0, nrows, k4b, k4n; };   // k4n: steps, a multiple of 4
+  auto make = [&](int row0, int nrows) {
+    int l = (int)nb, h = 0;
+    for (int r = row0; r < row0 + nrows; ++r)
+      if (hi[(size_t)r] > lo[(size_t)r]) {
+        l = std::min(l, lo[(size_t)r]);
+        h = std::max(h, hi[(size_t)r]);
+      }
+    Piece p{row0, nrows, 0, 4};                    // rows without a weight: four steps over zeros write their zeros
+    if (h > l) {
+      p.k4b = l / 4;
+      p.k4n = (((h + 3) / 4 - l / 4) + 3) / 4 * 4;
+    }
+    return p;
+  };
+  std::vector<Piece> pieces;
+  for (int row0 = 0; row0 < n_mels; row0 += 16) pieces.push_back(make(row0, (int)std::min<int64_t>(16, n_mels - row0)));
+  auto total = [&] { int t = 0; for (const auto &p : pieces) t += p.k4n; return t; };
+  for (;;) {   // split the longest piece by rows while that shortens the longest wave
+    size_t big = 0;
+    for (size_t i = 1; i < pieces.size(); ++i)
+      if (pieces[i].k4n > pieces[big].k4n) big = i;
+    const int target = (total() + 7) / 8;
+    if (pieces[big].k4n <= target + target / 4 || pieces[big].nrows < 2 || pieces.size() >= 8 * kMel32MaxItems) break;
+    const Piece p = pieces[big];
+    const Piece a1 = make(p.row0, p.nrows / 2), a2 = make(p.row0 + p.nrows / 2, p.nrows - p.nrows / 2);
+    if (std::max(a1.k4n, a2.k4n) >= p.k4n) break;   // rows with one common band: nothing to gain
+    pieces[big] = a1;
+    pieces.push_back(a2);
+  }
+  if (total() > 1024) return plan;   // a dense filterbank: the 64-lane kernel's K-split plan (or the composition) serves it
+  std::sort(pieces.begin(), pieces.end(), [](const Piece &x, const Piece &y) { return x.k4n > y.k4n; });   // longest first onto the least loaded wave
+  std::vector<Mel32Item> items(8 * kMel32MaxItems, Mel32Item{});
+  int load[8] = {0}, count[8] = {0};
+  std::vector<float> wm;
+  for (const auto &p : pieces) {
+    int w = -1;
+    for (int i = 0; i < 8; ++i)
+      if (count[i] < kMel32MaxItems && (w < 0 || load[i] < load[w])) w = i;
+    if (w < 0) return plan;
+    Mel32Item &it = items[(size_t)(w * kMel32MaxItems + count[w]++)];
+    it.row0 = p.row0;
+    it.nrows = p.nrows;
+    it.k4_begin = p.k4b;
+    it.k4_count = p.k4n;
+    it.a_offset = (int)(wm.size() / 64);
+    it.last_bin = (int)nb - 1;
+    load[w] += p.k4n;
+    for (int i = 0; i < p.k4n; ++i)
+      for (int lane = 0; lane < 64; ++lane) {
+        const int64_t mm = p.row0 + (lane & 15), k = 4 * (int64_t)(p.k4b + i) + (lane >> 4);
+        wm.push_back(((lane & 15) < p.nrows && k < nb) ? (float)weights[(size_t)(mm * nb + k)] : 0.0f);
+      }
+  }
+  // Measured against the 64-lane kernel (profiles/r05/ab_mel32.log): ahead by 6 % at 40 steps on the longest wave (128 mels at
+  // 48 kHz), by 4.5 % at 48 (80 mels at 16 kHz), behind by 5 % at 72 (40 mels at 22.05 kHz: a mel's own band cannot be split by rows)
+  for (int i = 0; i < 8; ++i)
+    if (load[i] > 52) return plan;
+  SMX_HIP_CHECK(hipMalloc(&plan.items, items.size() * sizeof(Mel32Item)));
+  SMX_HIP_CHECK(hipMemcpy(plan.items, items.data(), items.size() * sizeof(Mel32Item), hipMemcpyHostToDevice));
   SMX_HIP_CHECK(hipMalloc((void **)&plan.w_mfma, wm.size() * sizeof(float)));
   SMX_HIP_CHECK(hipMemcpy(plan.w_mfma, wm.data(), wm.size() * sizeof(float), hipMemcpyHostToDevice));
   plan.state = 1;

@@ -510,6 +510,10 @@ smx_mel_config::~smx_mel_config() {
     (void)hipFree(kv.second.items);
     (void)hipFree(kv.second.w_mfma);
   }
+  for (auto &kv : fused32_) {
+    (void)hipFree(kv.second.items);
+    (void)hipFree(kv.second.w_mfma);
+  }
 }
 
 const double *smx_chroma_config::device_weights() const {

@@ -27,7 +27,7 @@ json.dump({"bytes_per_launch": read_b + write_b, "read_bytes": read_b, "write_by
            "box": "one MI355X gpurun box (fresh lease; boxes differ by +-10 % in kernel time)"}, open(os.path.join(ROOT, "profiles", "hbm_traffic.json"), "w"), indent=1)
 out = {"profile": "profiles/%s/pmc_hot_kernels.json" % rnd,
        "definition": "SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 XCDs x 1024 SIMDs); fp32 MFMA peak 157.3 TFLOP/s (MI355X_MICROARCH.md)"}
-for name, key, flop_per_mfma in (("fused_audio_to_mel", "stft2048_mel_kernel<true, 2, false>" if "stft2048_mel_kernel<true, 2, false>" in k else "stft2048_mel_kernel<true, true, false>", 2048), ("mel_apply", "mel_apply_mfma_kernel<true>", 4096)):
+for name, key, flop_per_mfma in (("fused_audio_to_mel", next((n for n in ("stft2048_mel32_kernel<true, 2>", "stft2048_mel_kernel<true, 2, false>") if n in k), "stft2048_mel_kernel<true, true, false>"), 2048), ("mel_apply", "mel_apply_mfma_kernel<true>", 4096)):
     cc, dur = k[key]["counters"], k[key]["duration"]
     util = cc["SQ_VALU_MFMA_BUSY_CYCLES"] / (cc["GRBM_GUI_ACTIVE"] / 8.0 * 1024.0)
     flops = cc["SQ_INSTS_VALU_MFMA_F32"] * flop_per_mfma
