@@ -380,6 +380,22 @@ def main():
                                             "frac": round(ch * ns * FIR_BYTES_PER_SAMPLE / a / 1e6 / HBM_PEAK_GBS, 4),
                                             "algorithmic_bytes_per_sample": FIR_BYTES_PER_SAMPLE}}
             del xs, ys
+            # C1's geometry (fft 1024 / hop 256, 441 000 samples) as a batch of 256 clips: the 16-lane form of the frame pipeline
+            c1cfg = Stft.Config.create(fft_size=1024, hop=256)
+            n1 = 441000
+            f1 = Stft.frames(c1cfg, n1)
+            x1 = make_clip_batch(20000, 20000 + 256, n1)
+            o1 = torch.empty(256, 513, f1, device=dev, dtype=torch.float32)
+            _, ms, nl = timed(lambda: check(lib.smx_stft_power_range_f32_dev(c1cfg._h, vp(x1.data_ptr()), 256, n1, n1, 0, f1, 2.0,
+                                                                             vp(o1.data_ptr()), sptr)), k, w)
+            a = sum(ms) / len(ms)
+            b1 = 256 * 4 + 513 * 4   # hop x 4 read + 513 x 4 written per frame
+            extra["c1_batch"] = {"workload": "C1's geometry as a batch: 256 clips x 441000 samples, fft 1024 / hop 256 (%d frames)" % (256 * f1),
+                                 "value": round(256 * f1 / a / 1e3, 1), "unit": "Mframes/s", "ms": round(a, 4), "ms_min": round(ms[0], 4),
+                                 "launches_per_step": nl,
+                                 "roofline": {"bound": "hbm", "achieved": round(256 * f1 * b1 / a / 1e6, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                              "frac": round(256 * f1 * b1 / a / 1e6 / HBM_PEAK_GBS, 4), "algorithmic_bytes_per_frame": b1}}
+            del x1, o1
             # C5 on ONE GPU: the N = 1 point of BASELINE configs[4] (71 GB resident)
             free_b, _ = torch.cuda.mem_get_info(dev)
             del x, out
