@@ -17,6 +17,9 @@ constexpr int kMel32MaxItems = 8;      // per wave
 #define SMX_MEL32_CHUNK 8
 #endif
 constexpr int kMel32Chunk = SMX_MEL32_CHUNK;
+#ifndef SMX_MEL32_PIPE
+#define SMX_MEL32_PIPE 1   // two chunks of operands in flight (0.566 -> 0.551 ms at C3)
+#endif
 struct Mel32Item {
   int row0, nrows;        // mel rows [row0, row0 + nrows), nrows <= 16 (nrows = 0: no item)
   int k4_begin, k4_count; // bins 4 k4_begin .. 4 (k4_begin + k4_count); k4_count is padded to a multiple of 4 with zero weights
@@ -64,8 +67,43 @@ __device__ __forceinline__ void mel32_items(const Mel32Args &m, int iv, const fl
     const float *ap = m.w + (int64_t)__builtin_amdgcn_readlane(iv, 8 * i + 4) * 64 + lane;
     f32x4m acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
     int j = 0;
+#if SMX_MEL32_PIPE
+    {   // two chunks in flight: the operands of chunk c + 1 are requested before chunk c is multiplied
+      constexpr int CH = kMel32Chunk;
+      float av[2][CH], bv[2][CH];
+      auto request = [&](int slot, int jj) {
+#pragma unroll
+        for (int u = 0; u < CH; ++u) {
+          av[slot][u] = ap[64 * (jj + u)];
+          const int row = 4 * (k4b + jj + u) + kk;
+          bv[slot][u] = tile[(row < last ? row : last) * kTileStride + f];
+        }
+      };
+      auto multiply = [&](int slot) {
+#pragma unroll
+        for (int u = 0; u < CH; u += 2) {
+          acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[slot][u], bv[slot][u], acc0, 0, 0, 0);
+          acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[slot][u + 1], bv[slot][u + 1], acc1, 0, 0, 0);
+        }
+      };
+      const int nch = k4n / CH;   // whole chunks
+      if (nch > 0) {
+        request(0, 0);
+#pragma unroll 1
+        for (int c = 0; c + 2 <= nch; c += 2) {   // slots alternate with static indices
+          request(1, CH * (c + 1));
+          multiply(0);
+          if (c + 2 < nch) request(0, CH * (c + 2));
+          multiply(1);
+        }
+        if (nch & 1) multiply(0);
+        j = nch * CH;
+      }
+    }
+#else
 #pragma unroll 1
     for (; j + kMel32Chunk <= k4n; j += kMel32Chunk) mel32_chunk<kMel32Chunk>(ap + 64 * j, tile, k4b + j, kk, f, last, acc0, acc1);
+#endif
 #pragma unroll 1
     for (; j < k4n; j += 4) mel32_chunk<4>(ap + 64 * j, tile, k4b + j, kk, f, last, acc0, acc1);
     const f32x4m acc = acc0 + acc1;
