@@ -742,3 +742,62 @@ CAMLprim value soundml_amd_resample_stage_apply(value v_stage, value v_x, value 
   smx_raise(status);
   CAMLreturn(Val_unit);
 }
+
+/* Resample.Kernel of one overlap-save stage (resample.mli:270-319): the block carry lives on the device.  The kernel value keeps
+ * its stage alive (field 1 of the pair the OCaml side holds). */
+#define Rkernel_val(v) (*((smx_resample_kernel **)Data_custom_val(v)))
+static void rkernel_finalize(value v) { smx_resample_kernel_destroy(Rkernel_val(v)); }
+static struct custom_operations rkernel_ops = {"soundml.amd.resample_kernel", rkernel_finalize, custom_compare_default,
+                                               custom_hash_default, custom_serialize_default,
+                                               custom_deserialize_default, custom_compare_ext_default,
+                                               custom_fixed_length_default};
+CAMLprim value soundml_amd_resample_kernel_prepare(value v_stage, value v_channels, value v_max_block) {
+  CAMLparam3(v_stage, v_channels, v_max_block);
+  CAMLlocal1(v_handle);
+  smx_resample_kernel *k = NULL;
+  smx_raise(smx_resample_kernel_prepare(Stage_val(v_stage), Long_val(v_channels), Long_val(v_max_block), &k));
+  v_handle = caml_alloc_custom_mem(&rkernel_ops, sizeof(smx_resample_kernel *), (mlsize_t)4096);
+  Rkernel_val(v_handle) = k;
+  CAMLreturn(v_handle);
+}
+/* (out_bound n, pending): the capacities the OCaml side allocates for a step of n samples and for the flush */
+CAMLprim value soundml_amd_resample_kernel_bounds(value v_k, value v_n) {
+  CAMLparam2(v_k, v_n);
+  CAMLlocal1(v_pair);
+  v_pair = caml_alloc_tuple(2);
+  Store_field(v_pair, 0, Val_long(smx_resample_kernel_out_bound(Rkernel_val(v_k), Long_val(v_n))));
+  Store_field(v_pair, 1, Val_long(smx_resample_kernel_pending(Rkernel_val(v_k))));
+  CAMLreturn(v_pair);
+}
+/* step (is_flush = false): x [channels; n] -> out [channels; capacity]; returns the samples emitted per channel */
+CAMLprim value soundml_amd_resample_kernel_step(value v_k, value v_x, value v_out, value v_channels, value v_n, value v_capacity,
+                                                value v_is_flush) {
+  CAMLparam5(v_k, v_x, v_out, v_channels, v_n);
+  CAMLxparam2(v_capacity, v_is_flush);
+  smx_resample_kernel *k = Rkernel_val(v_k);
+  const int64_t channels = Long_val(v_channels), n = Long_val(v_n), capacity = Long_val(v_capacity);
+  const int is_flush = Bool_val(v_is_flush);
+  if (ba_kind(v_out) != CAML_BA_FLOAT32 || (!is_flush && ba_kind(v_x) != CAML_BA_FLOAT32)) caml_failwith("soundml_amd: unsupported dtype");
+  if (channels < 1 || n < 0 || capacity < 0) caml_failwith("soundml_amd: invalid geometry");
+  if (!is_flush && ba_dim(v_x) < channels * n) caml_failwith("soundml_amd: buffer extents disagree with geometry");
+  if (ba_dim(v_out) < channels * capacity) caml_failwith("soundml_amd: output extents disagree with geometry");
+  const float *x = is_flush ? NULL : (const float *)Caml_ba_data_val(v_x);
+  float *out = (float *)Caml_ba_data_val(v_out);
+  int64_t emitted = 0;
+  int status;
+  caml_release_runtime_system();
+  status = is_flush ? smx_resample_kernel_flush_f32(k, out, capacity, &emitted)
+                    : smx_resample_kernel_step_f32(k, x, n, n > 0 ? n : 1, out, capacity, &emitted);
+  caml_acquire_runtime_system();
+  smx_raise(status);
+  CAMLreturn(Val_long(emitted));
+}
+CAMLprim value soundml_amd_resample_kernel_step_bc(value *argv, int argn) {
+  (void)argn;
+  return soundml_amd_resample_kernel_step(argv[0], argv[1], argv[2], argv[3], argv[4], argv[5], argv[6]);
+}
+CAMLprim value soundml_amd_resample_kernel_reset(value v_k) {
+  CAMLparam1(v_k);
+  smx_raise(smx_resample_kernel_reset(Rkernel_val(v_k)));
+  CAMLreturn(Val_unit);
+}

@@ -98,6 +98,19 @@ external resample_stage_apply_c :
   stage_handle -> (float, Bigarray.float32_elt) flat -> (float, Bigarray.float32_elt) flat -> int -> int -> unit
   = "soundml_amd_resample_stage_apply"
 
+type rkernel_handle
+
+external resample_kernel_prepare_c : stage_handle -> int -> int -> rkernel_handle = "soundml_amd_resample_kernel_prepare"
+
+external resample_kernel_bounds_c : rkernel_handle -> int -> int * int = "soundml_amd_resample_kernel_bounds"
+
+external resample_kernel_step_c :
+  rkernel_handle -> (float, Bigarray.float32_elt) flat -> (float, Bigarray.float32_elt) flat -> int -> int -> int -> bool -> int
+  = "soundml_amd_resample_kernel_step_bc" "soundml_amd_resample_kernel_step"
+
+external resample_kernel_reset_c : rkernel_handle -> unit = "soundml_amd_resample_kernel_reset"
+
+
 (* ---- helpers ---------------------------------------------------------------------------------------------------- *)
 
 let flat t = Nx_buffer.to_bigarray1 (Nx.to_buffer (Nx.contiguous t))
@@ -476,4 +489,31 @@ module Resample_stage = struct
     let out = Nx.zeros Nx.float32 (Array.append batch [|n_out|]) in
     if channels > 0 && n_out > 0 then resample_stage_apply_c s.h (flat x) (flat_out out) channels n ;
     out
+end
+
+(* [Resample.Kernel] (resample.mli:270-319) of one pure xL or /M stage: what [ols_run] does call after call, with the block
+   carry on the device.  [step] is the run of completed blocks or [None]; [flush] the virtual-silence tail or [None]; every
+   partition of a signal totals [Resample_stage.apply] bit for bit. *)
+module Resample_kernel = struct
+  type t = {h: rkernel_handle; stage: Resample_stage.t; channels: int; max_block: int}
+
+  let prepare (stage : Resample_stage.t) ~channels ~max_block =
+    {h= resample_kernel_prepare_c stage.Resample_stage.h channels max_block; stage; channels; max_block}
+
+  let emit (k : t) x n is_flush =
+    let bound, pending = resample_kernel_bounds_c k.h n in
+    let capacity = Stdlib.max 1 (if is_flush then pending else bound) in
+    let out = Nx.zeros Nx.float32 [|k.channels; capacity|] in
+    let got = resample_kernel_step_c k.h x (flat_out out) k.channels n capacity is_flush in
+    if got = 0 then None else Some (Nx.contiguous (Nx.shrink [|(0, k.channels); (0, got)|] out))
+
+  let step (k : t) chunk =
+    let batch, n = split_last chunk in
+    if product batch <> k.channels then
+      invalid_arg "step: cannot feed a chunk whose leading axes disagree with the kernel's channels" ;
+    emit k (flat chunk) n false
+
+  let flush (k : t) = emit k (flat (Nx.zeros Nx.float32 [|1|])) 0 true
+
+  let reset (k : t) = resample_kernel_reset_c k.h
 end
