@@ -1660,6 +1660,19 @@ void launch_interior(const StftJob &job, const FastTarget &tg, const float *x, i
   const bool aligned = (c.hop % 2 == 0) && (left % 2 == 0) && (x_stride % 2 == 0) &&
                        (reinterpret_cast<uintptr_t>(x) % 8 == 0);
   const bool square = a.pmode == 2;
+  if (lanes == 16 && tg.mel32) {   // fused mel at fft 1024
+    Mel32Args m = *tg.mel32;
+    m.out_offset = out_offset;
+    auto by_power = [&](auto al) {
+      constexpr bool A = decltype(al)::value;
+      return a.pmode == 2 ? stft_mel_lanes_kernel<16, A, 2> : a.pmode == 1 ? stft_mel_lanes_kernel<16, A, 1> : stft_mel_lanes_kernel<16, A, 0>;
+    };
+    auto kl = aligned ? by_power(std::true_type{}) : by_power(std::false_type{});
+    SMX_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kl), hipFuncAttributeMaxDynamicSharedMemorySize, (int)PL<16>::Lds));
+    SMX_LAUNCH(kl, dim3((unsigned)a.blocks), dim3(512), PL<16>::Lds, job.stream, a, m);
+    SMX_HIP_CHECK(hipGetLastError());
+    return;
+  }
   if (lanes) {
     auto launch_lanes = [&](auto ll) {
       constexpr int LL = decltype(ll)::value;
@@ -1917,6 +1930,34 @@ bool launch_stft_fast(const StftJob &job) {
 }
 
 bool launch_mel_spectrogram_fused(const MelSpecJob &job) {
+  {   // fft 1024: the 16-lane frame pipeline with the filterbank product over its tiles (stft_mel_lanes_kernel)
+    const StftJob &sj = job.stft;
+    if (sj.cfg->fft_size == kN16 && sj.in_bytes == 4 && sj.interior == SMX_INTERIOR_F32 && sj.mode != OUT_COMPLEX && !fast_path_disabled() &&
+        sj.lead <= 65535 && env_flag("SMX_MEL_V1") != 1 && (int64_t)job.mel->n_mels * sj.count * 4 < (int64_t(1) << 32)) {
+      const MelFusedPlan &pl = job.mel->fused32_plan();
+      if (pl.state == 1) {
+        if (sj.count <= 0 || sj.lead <= 0) return true;
+        MelFusedArgs m{};
+        m.out = reinterpret_cast<float *>(job.out);
+        m.out_stride = sj.count;
+        m.n_mels = (int)job.mel->n_mels;
+        Mel32Args m32{};
+        m32.items = reinterpret_cast<const Mel32Item *>(pl.items);
+        m32.w = pl.w_mfma;
+        m32.out = m.out;
+        m32.out_stride = m.out_stride;
+        m32.n_mels = m.n_mels;
+        FastTarget tg;
+        tg.out = job.out;
+        tg.out_stride = sj.count;
+        tg.out_offset = 0;
+        tg.mel = &m;
+        tg.mel32 = &m32;
+        launch_ranges(sj, tg);
+        return true;
+      }
+    }
+  }
   if (launch_mel_spectrogram_16(job)) return true;
   if (!fast_eligible(job.stft)) return false;
   if (job.stft.count <= 0 || job.stft.lead <= 0) return true;
@@ -2070,7 +2111,7 @@ const smx::MelFusedPlan &smx_mel_config::fused32_plan() const {
   if (plan.state != 0) return plan;
   plan.state = -1;
   const int64_t nb = bins();
-  if (fft_size != kN || n_mels < 1 || n_mels > 256) return plan;
+  if ((fft_size != kN && fft_size != kN16) || n_mels < 1 || n_mels > 256) return plan;
   std::vector<int> lo((size_t)n_mels, (int)nb), hi((size_t)n_mels, 0);
   for (int64_t mm = 0; mm < n_mels; ++mm)
     for (int64_t k = 0; k < nb; ++k)

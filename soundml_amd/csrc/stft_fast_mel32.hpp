@@ -38,14 +38,14 @@ struct Mel32Args {
 // the wave's items over the finished tile `tile` (rows = bins, 17 floats apart): out[mel][f0 + f] for its mels.
 // `iv`: the wave's eight items, one int per lane (item i's field q in lane 8 i + q), read once per kernel: a field is one
 // v_readlane away, where a load from the plan in global memory would put its latency into every tile.
-template <int CH, class Acc>
+template <int CH, int TS, class Acc>
 __device__ __forceinline__ void mel32_chunk(const float *ap, const float *tile, int k4, int kk, int f, int last, Acc &acc0, Acc &acc1) {
   float av[CH], bv[CH];
 #pragma unroll
   for (int u = 0; u < CH; ++u) {
     av[u] = ap[64 * u];
     const int row = 4 * (k4 + u) + kk;
-    bv[u] = tile[(row < last ? row : last) * kTileStride + f];   // rows past the band multiply zero weights, but must be spectrum
+    bv[u] = tile[(row < last ? row : last) * TS + f];   // rows past the band multiply zero weights, but must be spectrum
   }
 #pragma unroll
   for (int u = 0; u < CH; u += 2) {
@@ -53,6 +53,8 @@ __device__ __forceinline__ void mel32_chunk(const float *ap, const float *tile, 
     acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u + 1], bv[u + 1], acc1, 0, 0, 0);
   }
 }
+// TS: floats per tile row; `tile` points at the first of the 16 frame columns multiplied, `obase` at their outputs
+template <int TS = kTileStride>
 __device__ __forceinline__ void mel32_items(const Mel32Args &m, int iv, const float *tile, float *obase, int frames_left, int lane) {
   using f32x4m = __attribute__((ext_vector_type(4))) float;
   const int kk = lane >> 4, f = lane & 15;
@@ -76,7 +78,7 @@ __device__ __forceinline__ void mel32_items(const Mel32Args &m, int iv, const fl
         for (int u = 0; u < CH; ++u) {
           av[slot][u] = ap[64 * (jj + u)];
           const int row = 4 * (k4b + jj + u) + kk;
-          bv[slot][u] = tile[(row < last ? row : last) * kTileStride + f];
+          bv[slot][u] = tile[(row < last ? row : last) * TS + f];
         }
       };
       auto multiply = [&](int slot) {
@@ -102,10 +104,10 @@ __device__ __forceinline__ void mel32_items(const Mel32Args &m, int iv, const fl
     }
 #else
 #pragma unroll 1
-    for (; j + kMel32Chunk <= k4n; j += kMel32Chunk) mel32_chunk<kMel32Chunk>(ap + 64 * j, tile, k4b + j, kk, f, last, acc0, acc1);
+    for (; j + kMel32Chunk <= k4n; j += kMel32Chunk) mel32_chunk<kMel32Chunk, TS>(ap + 64 * j, tile, k4b + j, kk, f, last, acc0, acc1);
 #endif
 #pragma unroll 1
-    for (; j < k4n; j += 4) mel32_chunk<4>(ap + 64 * j, tile, k4b + j, kk, f, last, acc0, acc1);
+    for (; j < k4n; j += 4) mel32_chunk<4, TS>(ap + 64 * j, tile, k4b + j, kk, f, last, acc0, acc1);
     const f32x4m acc = acc0 + acc1;
     if (f < frames_left) {
 #pragma unroll

@@ -484,3 +484,101 @@ __global__ void __launch_bounds__(512) stft_power_lanes_kernel(FastArgs a) {
     }
   }
 }
+
+// ---- the fused audio -> mel spectrogram on the same pipeline (fft 1024: LL = 16) -------------------------------------------
+// stft_fast_mel32.hpp's scheme on the LL-lane tiles: where the power kernel reads the previous tile out, every wave multiplies
+// its filterbank items into it, one group of 16 frame columns after the other (the MFMA's N = 16).
+template <int LL, bool ALIGNED>
+struct MelMidL {
+  using P = PL<LL>;
+  const FastArgs &a;
+  const Mel32Args &m;
+  int iv;
+  const LdsL<LL> &lds;
+  float2 (&raw)[32];
+  const float *src;
+  float *pend_out;
+  int pend_left;
+  int lane, wave, b, it;
+  unsigned &pk_drained, &pk_filled;
+  __device__ __forceinline__ void early() const { pk_drained = peek32(lds.drained + b * P::TS); }
+  __device__ __forceinline__ void before_cells() const {
+    lds_wait32(lds.drained + b * P::TS, 8u * ((unsigned)it >> 1), pk_drained);
+  }
+  __device__ __forceinline__ void after_transposition_issue() const {
+    if (it > 0) pk_filled = peek32(lds.filled + (b ^ 1) * P::TS);
+  }
+  __device__ __forceinline__ void after_exchange_issue() const {
+    if (it > 0) {
+      lds_wait32(lds.filled + (b ^ 1) * P::TS, 8u * (((unsigned)(it - 1) >> 1) + 1), pk_filled);
+#pragma unroll 1
+      for (int cg = 0; cg < P::FT / 16; ++cg)
+        mel32_items<P::TS>(m, iv, lds.tiles + (b ^ 1) * P::TileFloats + 16 * cg, pend_out + 16 * cg, pend_left - 16 * cg, lane);
+      lds_signal32(lds.drained + (b ^ 1) * P::TS, lane);
+    }
+  }
+  __device__ __forceinline__ void postpass_at(int s) const {
+    if (s == SMX_P32_LOAD_AT) load_frameL<LL, ALIGNED>(src, lane & (LL - 1), raw);
+  }
+};
+
+template <int LL, bool ALIGNED, int PMODE>
+__global__ void __launch_bounds__(512) stft_mel_lanes_kernel(FastArgs a, Mel32Args m) {
+  using P = PL<LL>;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const LdsL<LL> lds = carve_ldsL<LL>(smem);
+  const LaneL L = setup_laneL<LL>(lds, lane, wave);
+  fill_tablesL<LL>(a, lds, tid, 512);
+  TileWalk tw;
+  tw.init(a, m.out + m.out_offset, (int64_t)m.n_mels * m.out_stride);
+  const int ntiles = tw.ntiles > 0 ? tw.ntiles : 0;
+  auto frame_ptr = [&](const float *xc, int t) {   // as stft_power_lanes_kernel
+    const int64_t f0 = (int64_t)t * P::FT;
+    const int avail = (int)(a.count - f0 < P::FT ? a.count - f0 : P::FT) - 1;
+    const int fi = L.col;
+    const int64_t p = a.p0 + f0 + (fi <= avail ? fi : 0);
+    if (a.fold_frames && (p < a.border_i0 || p >= a.border_i1)) {
+      const int64_t clip = (xc - a.x) / a.x_stride;
+      return p < a.border_i0 ? a.strip_l + clip * a.strip_l_stride + (p - a.p0) * a.hop
+                             : a.strip_r + clip * a.strip_r_stride + (p - a.border_i1) * a.hop;
+    }
+    return xc + (p * a.hop - a.left);
+  };
+  float2 raw[32];
+#pragma unroll
+  for (int j = 0; j < 32; ++j) raw[j] = make_float2(0.f, 0.f);
+  if (ntiles > 0) load_frameL<LL, ALIGNED>(frame_ptr(tw.xclip, tw.ft), L.l, raw);
+  __syncthreads();
+  float *pend_out = nullptr;
+  int pend_left = 0;
+  unsigned pk_drained = 0, pk_filled = 0;
+  const int iv = reinterpret_cast<const int *>(m.items + wave * kMel32MaxItems)[lane];   // this wave's items (8 x 8 ints)
+  for (int it = 0; it < ntiles; ++it) {
+    const int b = it & 1;
+    int ftnext;
+    const float *xnext;
+    float *onext;
+    tw.peek(a, ftnext, xnext, onext);
+    const bool more = it + 1 < ntiles;
+    const float *src = frame_ptr(more ? xnext : tw.xclip, more ? ftnext : tw.ft);
+    const MelMidL<LL, ALIGNED> mid{a, m, iv, lds, raw, src, pend_out, pend_left, lane, wave, b, it, pk_drained, pk_filled};
+    frameL_to_tile<LL, PMODE>(a, L, raw, lds.tiles + b * P::TileFloats, mid);
+    lds_signal32(lds.filled + b * P::TS, lane);
+    pend_out = tw.oclip + tw.ft * P::FT;
+    const int64_t left = a.count - (int64_t)tw.ft * P::FT;
+    pend_left = left < P::FT ? (int)left : P::FT;
+    tw.xclip = xnext;
+    tw.oclip = onext;
+    tw.ft = ftnext;
+  }
+  if (ntiles > 0) {
+    const int b = (ntiles - 1) & 1;
+    lds_wait(lds.filled + b * P::TS, 8u * (((unsigned)(ntiles - 1) >> 1) + 1));
+#pragma unroll 1
+    for (int cg = 0; cg < P::FT / 16; ++cg)
+      mel32_items<P::TS>(m, iv, lds.tiles + b * P::TileFloats + 16 * cg, pend_out + 16 * cg, pend_left - 16 * cg, lane);
+  }
+}

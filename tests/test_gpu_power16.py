@@ -152,3 +152,47 @@ def test_general_powers(fft, power):
     want = O.power_spectrum(O.stft_config(fft, hop=fft // 4), x, power)
     _check(got[0], want[0], power, power)
     assert np.all(got[1] == (0.0 if power > 0 else 1.0))
+
+
+# ---- the fused mel spectrogram on the same pipeline (fft 1024: stft_mel_lanes_kernel) ---------------------------------------
+
+@pytest.mark.parametrize("n_mels,sr,n,lead,power", [
+    (80, 22050, 441000 // 4, 3, 2.0),            # the vocoder front end: fft 1024 / hop 256 / 80 mels / 22.05 kHz
+    (128, 44100, 60000, 2, 2.0),
+    (80, 22050, 32 * 256 * 2 + 17, 2, 1.0),      # ragged last tile, magnitude
+    (64, 16000, 700, 3, 2.0),                    # shorter than a frame: the strip path only
+    (20, 16000, 30000, 2, 2.0),                  # a plan with a long wave: stays on the 16-frame kernels of stft_generic.hip
+    (96, 32000, 50000, 1, 0.7),
+])
+def test_fused_mel_at_fft_1024(n_mels, sr, n, lead, power):
+    """Soundml.mel_spectrogram = Mel.apply . power_spectrum (soundml.ml:12-24) at fft 1024 / hop 256 against the oracle, batch ==
+    stack of slices bit for bit (mel_props.ml:136-155), device path == host path."""
+    import torch
+    from soundml_amd import Mel
+    rng = np.random.default_rng(n_mels + n)
+    x = rng.uniform(-1, 1, size=(lead, n)).astype(np.float32)
+    sc = Stft.Config.create(fft_size=1024, hop=256)
+    mc = Mel.Config.create(n_mels=n_mels, sample_rate=sr, fft_size=1024)
+    got = S.mel_spectrogram(sc, mc, x, power)
+    want = O.mel_spectrogram(O.stft_config(1024, hop=256), O.mel_config(n_mels, sr, 1024), x, power)
+    assert got.shape == want.shape and got.dtype == np.float32
+    for i in range(lead):
+        _check(got[i], want[i], power, (n_mels, sr, n, i))
+        assert np.array_equal(got[i], S.mel_spectrogram(sc, mc, x[i], power))
+    assert np.array_equal(S.mel_spectrogram(sc, mc, torch.from_numpy(x).cuda(), power).cpu().numpy(), got)
+
+
+def test_fused_mel_at_fft_1024_many_short_clips():
+    """4000 clips of 8 frames: border frames from gathered strips in a big batch; the same clips in a batch of 50 agree bit for bit."""
+    import torch
+    from soundml_amd import Mel
+    rng = np.random.default_rng(12)
+    x = torch.from_numpy(rng.uniform(-1, 1, size=(4000, 2000)).astype(np.float32)).cuda()
+    sc = Stft.Config.create(fft_size=1024, hop=256)
+    mc = Mel.Config.create(n_mels=80, sample_rate=22050, fft_size=1024)
+    m = S.mel_spectrogram(sc, mc, x)
+    assert tuple(m.shape) == (4000, 80, 8)
+    for lo in (0, 1950, 3950):
+        assert torch.equal(m[lo:lo + 50], S.mel_spectrogram(sc, mc, x[lo:lo + 50])), lo
+    want = O.mel_spectrogram(O.stft_config(1024, hop=256), O.mel_config(80, 22050, 1024), x[1234].cpu().numpy())
+    _check(m[1234].cpu().numpy(), want, 2.0, "clip 1234")

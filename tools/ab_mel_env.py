@@ -1,5 +1,5 @@
 """Interleaved timing of the fused mel spectrogram (C3: 256 x 480000, 128 mels) under several environments:
-  python tools/ab_mel_env.py "" "SMX_MEL_V1=1"      (AB_MELS, AB_SR: other filterbanks; switches as the build reads them)"""
+  python tools/ab_mel_env.py "" "SMX_MEL_V1=1"      (AB_MELS, AB_SR: other filterbanks; AB_FFT, AB_N: other sizes; switches as the build reads them)"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import ctypes, torch
@@ -7,14 +7,16 @@ from soundml_amd import Mel, Stft
 from soundml_amd._lib import check, lib
 vp = ctypes.c_void_p
 envs = sys.argv[1:] or [""]
-x = torch.rand(256, 480000, device="cuda") * 2 - 1
-sc = Stft.Config.create(fft_size=2048, hop=512)
+fft = int(os.environ.get("AB_FFT", "2048"))
+n = int(os.environ.get("AB_N", "480000"))
+x = torch.rand(256, n, device="cuda") * 2 - 1
+sc = Stft.Config.create(fft_size=fft, hop=fft // 4)
 n_mels, sr = int(os.environ.get("AB_MELS", "128")), int(os.environ.get("AB_SR", "48000"))
-mc = Mel.Config.create(n_mels=n_mels, sample_rate=sr, fft_size=2048)
-frames = Stft.frames(sc, 480000)
+mc = Mel.Config.create(n_mels=n_mels, sample_rate=sr, fft_size=fft)
+frames = Stft.frames(sc, n)
 out = torch.empty(256, n_mels, frames, device="cuda")
 def run():
-    check(lib.smx_mel_spectrogram_f32_dev(sc._h, mc._h, vp(x.data_ptr()), 256, 480000, 480000, 2.0, vp(out.data_ptr()), None))
+    check(lib.smx_mel_spectrogram_f32_dev(sc._h, mc._h, vp(x.data_ptr()), 256, n, n, 2.0, vp(out.data_ptr()), None))
 def setenv(e, on):
     for kv in filter(None, e.split(",")):
         k, v = kv.split("=")
