@@ -1660,16 +1660,21 @@ void launch_interior(const StftJob &job, const FastTarget &tg, const float *x, i
   const bool aligned = (c.hop % 2 == 0) && (left % 2 == 0) && (x_stride % 2 == 0) &&
                        (reinterpret_cast<uintptr_t>(x) % 8 == 0);
   const bool square = a.pmode == 2;
-  if (lanes == 16 && tg.mel32) {   // fused mel at fft 1024
+  if (lanes && tg.mel32) {   // fused mel at fft 1024 / 512
     Mel32Args m = *tg.mel32;
     m.out_offset = out_offset;
-    auto by_power = [&](auto al) {
-      constexpr bool A = decltype(al)::value;
-      return a.pmode == 2 ? stft_mel_lanes_kernel<16, A, 2> : a.pmode == 1 ? stft_mel_lanes_kernel<16, A, 1> : stft_mel_lanes_kernel<16, A, 0>;
+    auto launch_mel_lanes = [&](auto ll) {
+      constexpr int LL = decltype(ll)::value;
+      auto by_power = [&](auto al) {
+        constexpr bool A = decltype(al)::value;
+        return a.pmode == 2 ? stft_mel_lanes_kernel<LL, A, 2> : a.pmode == 1 ? stft_mel_lanes_kernel<LL, A, 1> : stft_mel_lanes_kernel<LL, A, 0>;
+      };
+      auto kl = aligned ? by_power(std::true_type{}) : by_power(std::false_type{});
+      SMX_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kl), hipFuncAttributeMaxDynamicSharedMemorySize, (int)PL<LL>::Lds));
+      SMX_LAUNCH(kl, dim3((unsigned)a.blocks), dim3(512), PL<LL>::Lds, job.stream, a, m);
     };
-    auto kl = aligned ? by_power(std::true_type{}) : by_power(std::false_type{});
-    SMX_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kl), hipFuncAttributeMaxDynamicSharedMemorySize, (int)PL<16>::Lds));
-    SMX_LAUNCH(kl, dim3((unsigned)a.blocks), dim3(512), PL<16>::Lds, job.stream, a, m);
+    if (lanes == 16) launch_mel_lanes(std::integral_constant<int, 16>{});
+    else launch_mel_lanes(std::integral_constant<int, 8>{});
     SMX_HIP_CHECK(hipGetLastError());
     return;
   }
@@ -1930,9 +1935,9 @@ bool launch_stft_fast(const StftJob &job) {
 }
 
 bool launch_mel_spectrogram_fused(const MelSpecJob &job) {
-  {   // fft 1024: the 16-lane frame pipeline with the filterbank product over its tiles (stft_mel_lanes_kernel)
+  {   // fft 1024 / 512: the 16- / 8-lane frame pipeline with the filterbank product over its tiles (stft_mel_lanes_kernel)
     const StftJob &sj = job.stft;
-    if (sj.cfg->fft_size == kN16 && sj.in_bytes == 4 && sj.interior == SMX_INTERIOR_F32 && sj.mode != OUT_COMPLEX && !fast_path_disabled() &&
+    if ((sj.cfg->fft_size == kN16 || sj.cfg->fft_size == kN8) && sj.in_bytes == 4 && sj.interior == SMX_INTERIOR_F32 && sj.mode != OUT_COMPLEX && !fast_path_disabled() &&
         sj.lead <= 65535 && env_flag("SMX_MEL_V1") != 1 && (int64_t)job.mel->n_mels * sj.count * 4 < (int64_t(1) << 32)) {
       const MelFusedPlan &pl = job.mel->fused32_plan();
       if (pl.state == 1) {
@@ -2111,7 +2116,7 @@ const smx::MelFusedPlan &smx_mel_config::fused32_plan() const {
   if (plan.state != 0) return plan;
   plan.state = -1;
   const int64_t nb = bins();
-  if ((fft_size != kN && fft_size != kN16) || n_mels < 1 || n_mels > 256) return plan;
+  if ((fft_size != kN && fft_size != kN16 && fft_size != kN8) || n_mels < 1 || n_mels > 256) return plan;
   std::vector<int> lo((size_t)n_mels, (int)nb), hi((size_t)n_mels, 0);
   for (int64_t mm = 0; mm < n_mels; ++mm)
     for (int64_t k = 0; k < nb; ++k)
