@@ -44,12 +44,13 @@ void set_last_error(const std::string &message);
   } while (0)
 
 // ---- environment switches ------------------------------------------------------------------------------------------
-// The shipped library reads eight variables, each once per use and parsed ONE way (env_flag: unset -> -1, "0" / "" /
+// The shipped library reads nine variables, each once per use and parsed ONE way (env_flag: unset -> -1, "0" / "" /
 // "false" / "off" -> 0, anything else -> 1); none alters results except by selecting another kernel of the same contract:
 //   SMX_DISABLE_FAST   the generic kernels instead of the hand-laid ones (tests: two implementations of one contract)
 //   SMX_POWER_V1       the 64-lane fft-2048 power kernel instead of the 32-lane one (A/B timing, tests)
 //   SMX_POWER_RING     with SMX_POWER_V1: its ring form (whole 64-byte-aligned stores)
 //   SMX_MEL_V1         the 64-lane fused mel kernel instead of the 32-lane one (A/B timing, tests)
+//   SMX_COMPLEX_V1     the 64-lane complex kernel instead of the 32-lane one (A/B timing)
 //   SMX_MIXED_OFF      chirp-z instead of the mixed-radix kernels (tests: the two agree)
 //   SMX_HOST_TRACE     print where a host-pointer call's time goes
 //   SMX_COPY_THREADS / SMX_COPY_PLAIN   host <-> device staging of the host-pointer entry points

@@ -1729,6 +1729,13 @@ void launch_interior(const StftJob &job, const FastTarget &tg, const float *x, i
     SMX_HIP_CHECK(hipGetLastError());
     return;
   }
+  if (tg.complex_out && env_flag("SMX_COMPLEX_V1") != 1) {   // the 32-lane frame pipeline; SMX_COMPLEX_V1=1: the 64-lane kernel (A/B timing)
+    auto k32 = aligned ? stft2048_complex32_kernel<true> : stft2048_complex32_kernel<false>;
+    SMX_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k32), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kFast32Lds));
+    SMX_LAUNCH(k32, dim3((unsigned)a.blocks), dim3(512), kFast32Lds, job.stream, a);
+    SMX_HIP_CHECK(hipGetLastError());
+    return;
+  }
   if (tg.complex_out) {
     auto kernel = strip ? (aligned ? stft2048_complex_kernel<true, true> : stft2048_complex_kernel<false, true>)
                         : (aligned ? stft2048_complex_kernel<true, false> : stft2048_complex_kernel<false, false>);

@@ -258,7 +258,7 @@ struct NoMid32 {
 #ifndef SMX_P32_TWI
 #define SMX_P32_TWI 1      // 1: the transposition's first plane is written while the twiddle products are formed (shorter LDS bursts)
 #endif
-template <int PMODE, class Mid>
+template <int PMODE, class Mid, bool CPLX = false>
 __device__ __forceinline__ void frame32_to_tile(const FastArgs &a, const Lane32 &L, float2 (&raw)[32], float *tile,
                                                 const Mid &mid) {
 #pragma clang fp contract(off)
@@ -362,9 +362,15 @@ __device__ __forceinline__ void frame32_to_tile(const FastArgs &a, const Lane32 
   auto power_of = [&](float re, float im) {
     return power_from_square<PMODE>(__builtin_fmaf(re, re, im * im), a);
   };
+  // CPLX: the spectrum itself, real parts in `tile`, imaginary parts in the plane after it (the other tile buffer)
   {   // bin M/2 (lane 0, register 16): X = 2 conj(Z)
     const float zx = t[16].x + t[16].x, zy = t[16].y + t[16].y;
-    tile[opaque32(L.self)] = power_of(zx, zy);
+    if constexpr (CPLX) {
+      tile[opaque32(L.self)] = zx;
+      tile[kTile32Floats + opaque32(L.self)] = -zy;
+    } else {
+      tile[opaque32(L.self)] = power_of(zx, zy);
+    }
   }
   float *const rk = wr;                 // row l + 32 s
   float *const rm = tile + opaque32(L.rm);        // row (32 - l) + 32 (31 - s) = rm base + 32 (15 - s)
@@ -376,8 +382,15 @@ __device__ __forceinline__ void frame32_to_tile(const FastArgs &a, const Lane32 
     // T = -i w D
     const float tr = __builtin_fmaf(wx, d.y, wy * d.x);
     const float ti = __builtin_fmaf(wy, d.y, -(wx * d.x));
+    if constexpr (CPLX) {   // X[k] = E + T, X[M - k] = conj(E - T)
+      rk[kRowPitch32 * s] = e.x + tr;
+      rk[kTile32Floats + kRowPitch32 * s] = e.y + ti;
+      rm[kRowPitch32 * (15 - s)] = e.x - tr;
+      rm[kTile32Floats + kRowPitch32 * (15 - s)] = ti - e.y;
+    } else {
     rk[kRowPitch32 * s] = power_of(e.x + tr, e.y + ti);
     rm[kRowPitch32 * (15 - s)] = power_of(e.x - tr, e.y - ti);
+    }
     if (s == SMX_P32_STORE_AT || s == SMX_P32_LOAD_AT) { SMX_FENCE(); mid.postpass_at(s); SMX_FENCE(); }
   }
   mid.template stamp<7>();
@@ -693,5 +706,130 @@ __global__ void __launch_bounds__(512) stft2048_power32_kernel(FastArgs a) {
         }
       }
     }
+  }
+}
+
+// ---- Stft.transform at fft 2048 on the same frame code (stft.ml:632-666): the spectrum's two planes fill both tile buffers, so
+// the tile is single-buffered -- a wave reads the previous tile out in the middle of its next frame's first radix-32 (its
+// stores then run under the rest of the frame) and nobody writes a cell before every wave has done so.
+struct CplxFlush32 {
+  int src0;          // float offset of (row0, frame 2 g) in a plane
+  unsigned goff0;    // byte offset of out[row0][2 g] from the tile's origin (complex64: 8 bytes)
+  int g;             // frames 2 g, 2 g + 1
+};
+__device__ __forceinline__ CplxFlush32 setup_cplx_flush32(const FastArgs &a, int lane, int wave) {
+  // one store = 8 rows x 128 bytes; rows {0, 1, 16, 17} (+ 2 for the upper half-wave) keep a lane's LDS reads conflict free
+  CplxFlush32 fl;
+  const int half = lane >> 5, ridx = (lane & 31) >> 3;
+  fl.g = lane & 7;
+  const int row0 = 128 * wave + (ridx & 1) + 16 * (ridx >> 1) + 2 * half;
+  fl.src0 = row0 * kTileStride + 2 * fl.g;
+  fl.goff0 = ((unsigned)row0 * (unsigned)a.out_stride + 2u * fl.g) * 8u;
+  return fl;
+}
+__device__ __forceinline__ void cplx_flush32(const FastArgs &a, const float *re, const CplxFlush32 &fl, float *obase, int frames_left,
+                                             int wave, int lane) {
+  const float *pr0 = re + opaque32(fl.src0);
+  const int fleft = frames_left - 2 * fl.g;
+  const unsigned pitch = (unsigned)a.out_stride * 8u, goff0 = opaque32(fl.goff0);
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {   // rows row0 + 32 (i >> 2) + 4 (i & 3)
+    const float *pr = pr0 + (32 * (i >> 2) + 4 * (i & 3)) * kTileStride, *pi = pr + kTile32Floats;
+    const float r0 = pr[0], r1 = pr[1], i0 = pi[0], i1 = pi[1];
+    const unsigned goff = goff0 + (unsigned)(32 * (i >> 2) + 4 * (i & 3)) * pitch;
+    if (fleft >= 2) {
+      store4_unaligned(obase, goff, r0, i0, r1, i1);
+    } else if (fleft == 1) {
+      float *dst = reinterpret_cast<float *>(reinterpret_cast<char *>(obase) + goff);
+      dst[0] = r0;
+      dst[1] = i0;
+    }
+  }
+  if (wave == 0 && lane < 16 && lane < frames_left) {   // bin 1024: real
+    float *dst = obase + ((int64_t)kM * a.out_stride + lane) * 2;
+    dst[0] = re[kM * kTileStride + lane];
+    dst[1] = 0.0f;
+  }
+}
+template <bool ALIGNED>
+struct CplxMid32 {
+  const FastArgs &a;
+  const Lds32 &lds;
+  const CplxFlush32 &fl;
+  float2 (&raw)[32];
+  const float *src;
+  float *pend_out;
+  int pend_left;
+  int lane, wave, it;
+  template <int I> __device__ __forceinline__ void stamp() const {}
+  __device__ __forceinline__ void early() const {   // between the two 16-point transforms of the first radix-32
+    if (it > 0) {
+      lds_wait(lds.filled, 8u * (unsigned)it);       // every wave's columns of the previous tile are in
+      cplx_flush32(a, lds.tiles, fl, pend_out, pend_left, wave, lane);
+      lds_signal32(lds.drained, lane);               // behind this wave's reads in LDS order
+    }
+  }
+  __device__ __forceinline__ void before_cells() const {
+    if (it > 0) lds_wait(lds.drained, 8u * (unsigned)it);   // every wave has read the previous tile out
+  }
+  __device__ __forceinline__ void after_transposition_issue() const {}
+  __device__ __forceinline__ void after_exchange_issue() const {}
+  __device__ __forceinline__ void postpass_at(int s) const {
+    if (s == SMX_P32_LOAD_AT) load_frame32<ALIGNED>(src, lane & 31, raw);
+  }
+};
+
+template <bool ALIGNED>
+__global__ void __launch_bounds__(512) stft2048_complex32_kernel(FastArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const Lds32 lds = carve_lds32(smem);
+  const Lane32 L = setup_lane32(lds, lane, wave);
+  fill_tables32(a, lds, tid, 512);
+  TileWalk tw;
+  tw.init(a, a.out + 2 * a.out_offset, 2 * kBins * a.out_stride);
+  const int ntiles = tw.ntiles > 0 ? tw.ntiles : 0;
+  auto frame_ptr = [&](const float *xc, int t) {   // as stft2048_power32_kernel
+    const int64_t f0 = (int64_t)t * kFT;
+    const int avail = (int)(a.count - f0 < kFT ? a.count - f0 : kFT) - 1;
+    const int fi = 2 * wave + L.h;
+    const int64_t p = a.p0 + f0 + (fi <= avail ? fi : 0);
+    if (a.fold_frames && (p < a.border_i0 || p >= a.border_i1)) {
+      const int64_t clip = (xc - a.x) / a.x_stride;
+      return p < a.border_i0 ? a.strip_l + clip * a.strip_l_stride + (p - a.p0) * a.hop
+                             : a.strip_r + clip * a.strip_r_stride + (p - a.border_i1) * a.hop;
+    }
+    return xc + (p * a.hop - a.left);
+  };
+  float2 raw[32];
+#pragma unroll
+  for (int j = 0; j < 32; ++j) raw[j] = make_float2(0.f, 0.f);
+  if (ntiles > 0) load_frame32<ALIGNED>(frame_ptr(tw.xclip, tw.ft), L.l, raw);
+  __syncthreads();
+  const CplxFlush32 fl = setup_cplx_flush32(a, lane, wave);
+  float *pend_out = nullptr;
+  int pend_left = 0;
+  for (int it = 0; it < ntiles; ++it) {
+    int ftnext;
+    const float *xnext;
+    float *onext;
+    tw.peek(a, ftnext, xnext, onext);
+    const bool more = it + 1 < ntiles;
+    const float *src = frame_ptr(more ? xnext : tw.xclip, more ? ftnext : tw.ft);
+    const CplxMid32<ALIGNED> mid{a, lds, fl, raw, src, pend_out, pend_left, lane, wave, it};
+    frame32_to_tile<2, CplxMid32<ALIGNED>, true>(a, L, raw, lds.tiles, mid);
+    lds_signal32(lds.filled, lane);
+    pend_out = tw.oclip + 2 * tw.ft * kFT;
+    const int64_t left = a.count - (int64_t)tw.ft * kFT;
+    pend_left = left < kFT ? (int)left : kFT;
+    tw.xclip = xnext;
+    tw.oclip = onext;
+    tw.ft = ftnext;
+  }
+  if (ntiles > 0) {
+    lds_wait(lds.filled, 8u * (unsigned)ntiles);
+    cplx_flush32(a, lds.tiles, fl, pend_out, pend_left, wave, lane);
   }
 }
