@@ -1660,6 +1660,18 @@ void launch_interior(const StftJob &job, const FastTarget &tg, const float *x, i
   const bool aligned = (c.hop % 2 == 0) && (left % 2 == 0) && (x_stride % 2 == 0) &&
                        (reinterpret_cast<uintptr_t>(x) % 8 == 0);
   const bool square = a.pmode == 2;
+  if (lanes && tg.complex_out) {   // Stft.transform at fft 1024 / 512
+    auto launch_cplx_lanes = [&](auto ll) {
+      constexpr int LL = decltype(ll)::value;
+      auto kl = aligned ? stft_complex_lanes_kernel<LL, true> : stft_complex_lanes_kernel<LL, false>;
+      SMX_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kl), hipFuncAttributeMaxDynamicSharedMemorySize, (int)PL<LL>::Lds));
+      SMX_LAUNCH(kl, dim3((unsigned)a.blocks), dim3(512), PL<LL>::Lds, job.stream, a);
+    };
+    if (lanes == 16) launch_cplx_lanes(std::integral_constant<int, 16>{});
+    else launch_cplx_lanes(std::integral_constant<int, 8>{});
+    SMX_HIP_CHECK(hipGetLastError());
+    return;
+  }
   if (lanes && tg.mel32) {   // fused mel at fft 1024 / 512
     Mel32Args m = *tg.mel32;
     m.out_offset = out_offset;
@@ -1842,7 +1854,8 @@ void launch_border(const StftJob &job, const FastTarget &tg, int64_t pa, int64_t
 bool fast_eligible(const StftJob &job, bool power_face = false) {
   const smx_stft_config &c = *job.cfg;
   if (fast_path_disabled()) return false;
-  const bool size_ok = c.fft_size == kN || (power_face && (c.fft_size == kN16 || c.fft_size == kN8) && job.mode == OUT_POWER && diag_flag("SMX_POWER16_OFF") != 1);
+  const bool size_ok = c.fft_size == kN || (power_face && (c.fft_size == kN16 || c.fft_size == kN8) && diag_flag("SMX_POWER16_OFF") != 1 &&
+                                              (job.mode == OUT_POWER || env_flag("SMX_COMPLEX_V1") != 1));
   if (!size_ok || job.in_bytes != 4 || job.interior != SMX_INTERIOR_F32) return false;
   if (diag_flag("SMX_GENERIC_2048") == 1) return false;   // diagnostic: time the stage-free generic kernels at fft 2048
   if (job.lead > 65535) return false;

@@ -145,7 +145,7 @@ __device__ __forceinline__ void p32_fft8(c32 (&v)[8]) {
 
 // 64 / LL frames (one per LL lanes): raw samples -> window -> FFT(M complex) -> post-pass -> |X|^p in the frames' columns of
 // `tile`; the hooks of `mid` are those of frame32_to_tile.
-template <int LL, int PMODE, class Mid>
+template <int LL, int PMODE, class Mid, bool CPLX = false>
 __device__ __forceinline__ void frameL_to_tile(const FastArgs &a, const LaneL &L, float2 (&raw)[32], float *tile, const Mid &mid) {
 #pragma clang fp contract(off)
   using P = PL<LL>;
@@ -242,9 +242,15 @@ __device__ __forceinline__ void frameL_to_tile(const FastArgs &a, const LaneL &L
   mid.after_exchange_issue();
   SMX_FENCE();
   auto power_of = [&](float re, float im) { return power_from_square<PMODE>(__builtin_fmaf(re, re, im * im), a); };
+  // CPLX: the spectrum itself, real parts in `tile`, imaginary parts in the plane after it (the other tile buffer)
   {   // bin M/2 (lane 0, register 16): X = 2 conj(Z)
     const float zx = t[16].x + t[16].x, zy = t[16].y + t[16].y;
-    tile[opaque32(L.self)] = power_of(zx, zy);
+    if constexpr (CPLX) {
+      tile[opaque32(L.self)] = zx;
+      tile[P::TileFloats + opaque32(L.self)] = -zy;
+    } else {
+      tile[opaque32(L.self)] = power_of(zx, zy);
+    }
   }
   float *const rk = wr;                        // row l + LL s
   float *const rm = tile + opaque32(L.rm);     // row (LL - l) + LL (31 - s) = rm base + LL (15 - s)
@@ -255,8 +261,15 @@ __device__ __forceinline__ void frameL_to_tile(const FastArgs &a, const LaneL &L
     const c32 d = {t[s].x - px[s], t[s].y + py[s]};
     const float tr = __builtin_fmaf(wx, d.y, wy * d.x);
     const float ti = __builtin_fmaf(wy, d.y, -(wx * d.x));
+    if constexpr (CPLX) {   // X[k] = E + T, X[M - k] = conj(E - T)
+      rk[P::RowPitch * s] = e.x + tr;
+      rk[P::TileFloats + P::RowPitch * s] = e.y + ti;
+      rm[P::RowPitch * (15 - s)] = e.x - tr;
+      rm[P::TileFloats + P::RowPitch * (15 - s)] = ti - e.y;
+    } else {
     rk[P::RowPitch * s] = power_of(e.x + tr, e.y + ti);
     rm[P::RowPitch * (15 - s)] = power_of(e.x - tr, e.y - ti);
+    }
     if (s == SMX_P32_STORE_AT || s == SMX_P32_LOAD_AT) { SMX_FENCE(); mid.postpass_at(s); SMX_FENCE(); }
   }
 }
@@ -580,5 +593,139 @@ __global__ void __launch_bounds__(512) stft_mel_lanes_kernel(FastArgs a, Mel32Ar
 #pragma unroll 1
     for (int cg = 0; cg < P::FT / 16; ++cg)
       mel32_items<P::TS>(m, iv, lds.tiles + b * P::TileFloats + 16 * cg, pend_out + 16 * cg, pend_left - 16 * cg, lane);
+  }
+}
+
+// ---- Stft.transform at fft 1024 / 512 on the same frame code: as stft2048_complex32_kernel (the spectrum's planes fill both
+// tile buffers; the previous tile is read out in the middle of the next frame's first radix-32) ------------------------------
+struct CplxFlushL {
+  int src0;          // float offset of (row0, frame 2 g) in a plane
+  unsigned goff0;    // byte offset of out[row0][2 g] from the tile's origin (complex64)
+  int g;             // frames 2 g, 2 g + 1
+};
+template <int LL>
+__device__ __forceinline__ CplxFlushL setup_cplx_flushL(const FastArgs &a, int lane, int wave) {
+  using P = PL<LL>;
+  constexpr int LPR = P::FT / 2, RPI = 64 / LPR;   // lanes per row, rows per store instruction (4 / 2)
+  CplxFlushL fl;
+  fl.g = lane % LPR;
+  const int row0 = RPI * 16 * wave + lane / LPR;
+  fl.src0 = row0 * P::TS + 2 * fl.g;
+  fl.goff0 = ((unsigned)row0 * (unsigned)a.out_stride + 2u * fl.g) * 8u;
+  return fl;
+}
+template <int LL>
+__device__ __forceinline__ void cplx_flushL(const FastArgs &a, const float *re, const CplxFlushL &fl, float *obase, int frames_left,
+                                            int wave, int lane) {
+  using P = PL<LL>;
+  constexpr int LPR = P::FT / 2, RPI = 64 / LPR;
+  const float *pr0 = re + opaque32(fl.src0);
+  const int fleft = frames_left - 2 * fl.g;
+  const unsigned pitch = (unsigned)a.out_stride * 8u, goff0 = opaque32(fl.goff0);
+  auto put = [&](const float *pr, unsigned goff) {
+    const float *pi = pr + P::TileFloats;
+    const float r0 = pr[0], r1 = pr[1], i0 = pi[0], i1 = pi[1];
+    if (fleft >= 2) {
+      store4_unaligned(obase, goff, r0, i0, r1, i1);
+    } else if (fleft == 1) {
+      float *dst = reinterpret_cast<float *>(reinterpret_cast<char *>(obase) + goff);
+      dst[0] = r0;
+      dst[1] = i0;
+    }
+  };
+#pragma unroll
+  for (int i = 0; i < 16; ++i) put(pr0 + RPI * i * P::TS, goff0 + (unsigned)(RPI * i) * pitch);   // rows RPI (16 wave + i) + lane / LPR
+  if (wave == 0 && lane < LPR && fleft >= 1) {   // bin M: real
+    float *dst = reinterpret_cast<float *>(reinterpret_cast<char *>(obase) + (unsigned)P::M * pitch + 16u * (unsigned)fl.g);
+    const float *pr = re + P::M * P::TS + 2 * fl.g;
+    dst[0] = pr[0];
+    dst[1] = 0.0f;
+    if (fleft >= 2) {
+      dst[2] = pr[1];
+      dst[3] = 0.0f;
+    }
+  }
+}
+template <int LL, bool ALIGNED>
+struct CplxMidL {
+  using P = PL<LL>;
+  const FastArgs &a;
+  const LdsL<LL> &lds;
+  const CplxFlushL &fl;
+  float2 (&raw)[32];
+  const float *src;
+  float *pend_out;
+  int pend_left;
+  int lane, wave, it;
+  __device__ __forceinline__ void early() const {
+    if (it > 0) {
+      lds_wait(lds.filled, 8u * (unsigned)it);
+      cplx_flushL<LL>(a, lds.tiles, fl, pend_out, pend_left, wave, lane);
+      lds_signal32(lds.drained, lane);
+    }
+  }
+  __device__ __forceinline__ void before_cells() const {
+    if (it > 0) lds_wait(lds.drained, 8u * (unsigned)it);
+  }
+  __device__ __forceinline__ void after_transposition_issue() const {}
+  __device__ __forceinline__ void after_exchange_issue() const {}
+  __device__ __forceinline__ void postpass_at(int s) const {
+    if (s == SMX_P32_LOAD_AT) load_frameL<LL, ALIGNED>(src, lane & (LL - 1), raw);
+  }
+};
+
+template <int LL, bool ALIGNED>
+__global__ void __launch_bounds__(512) stft_complex_lanes_kernel(FastArgs a) {
+  using P = PL<LL>;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const LdsL<LL> lds = carve_ldsL<LL>(smem);
+  const LaneL L = setup_laneL<LL>(lds, lane, wave);
+  fill_tablesL<LL>(a, lds, tid, 512);
+  TileWalk tw;
+  tw.init(a, a.out + 2 * a.out_offset, 2 * (int64_t)P::Bins * a.out_stride);
+  const int ntiles = tw.ntiles > 0 ? tw.ntiles : 0;
+  auto frame_ptr = [&](const float *xc, int t) {   // as stft_power_lanes_kernel
+    const int64_t f0 = (int64_t)t * P::FT;
+    const int avail = (int)(a.count - f0 < P::FT ? a.count - f0 : P::FT) - 1;
+    const int fi = L.col;
+    const int64_t p = a.p0 + f0 + (fi <= avail ? fi : 0);
+    if (a.fold_frames && (p < a.border_i0 || p >= a.border_i1)) {
+      const int64_t clip = (xc - a.x) / a.x_stride;
+      return p < a.border_i0 ? a.strip_l + clip * a.strip_l_stride + (p - a.p0) * a.hop
+                             : a.strip_r + clip * a.strip_r_stride + (p - a.border_i1) * a.hop;
+    }
+    return xc + (p * a.hop - a.left);
+  };
+  float2 raw[32];
+#pragma unroll
+  for (int j = 0; j < 32; ++j) raw[j] = make_float2(0.f, 0.f);
+  if (ntiles > 0) load_frameL<LL, ALIGNED>(frame_ptr(tw.xclip, tw.ft), L.l, raw);
+  __syncthreads();
+  const CplxFlushL fl = setup_cplx_flushL<LL>(a, lane, wave);
+  float *pend_out = nullptr;
+  int pend_left = 0;
+  for (int it = 0; it < ntiles; ++it) {
+    int ftnext;
+    const float *xnext;
+    float *onext;
+    tw.peek(a, ftnext, xnext, onext);
+    const bool more = it + 1 < ntiles;
+    const float *src = frame_ptr(more ? xnext : tw.xclip, more ? ftnext : tw.ft);
+    const CplxMidL<LL, ALIGNED> mid{a, lds, fl, raw, src, pend_out, pend_left, lane, wave, it};
+    frameL_to_tile<LL, 2, CplxMidL<LL, ALIGNED>, true>(a, L, raw, lds.tiles, mid);
+    lds_signal32(lds.filled, lane);
+    pend_out = tw.oclip + 2 * tw.ft * P::FT;
+    const int64_t left = a.count - (int64_t)tw.ft * P::FT;
+    pend_left = left < P::FT ? (int)left : P::FT;
+    tw.xclip = xnext;
+    tw.oclip = onext;
+    tw.ft = ftnext;
+  }
+  if (ntiles > 0) {
+    lds_wait(lds.filled, 8u * (unsigned)ntiles);
+    cplx_flushL<LL>(a, lds.tiles, fl, pend_out, pend_left, wave, lane);
   }
 }

@@ -196,3 +196,73 @@ def test_fused_mel_at_fft_1024_many_short_clips():
         assert torch.equal(m[lo:lo + 50], S.mel_spectrogram(sc, mc, x[lo:lo + 50])), lo
     want = O.mel_spectrogram(O.stft_config(1024, hop=256), O.mel_config(80, 22050, 1024), x[1234].cpu().numpy())
     _check(m[1234].cpu().numpy(), want, 2.0, "clip 1234")
+
+
+# ---- Stft.transform on the same pipeline (fft 2048: stft2048_complex32_kernel; fft 1024 / 512: stft_complex_lanes_kernel) -----
+
+def _check_c(got, want, msg):
+    got, want = np.asarray(got, dtype=np.complex128), np.asarray(want, dtype=np.complex128)
+    assert got.shape == want.shape, (msg, got.shape, want.shape)
+    peak = float(np.max(np.abs(want))) if want.size else 0.0
+    assert np.all(np.abs(got - want) <= 1e-5 * peak + 1e-5 * np.abs(want)), (msg, float(np.max(np.abs(got - want))), peak)
+
+
+@pytest.mark.parametrize("fft", [2048, 1024, 512])
+@pytest.mark.parametrize("kw,n,lead", [
+    (dict(), 60000, 2),
+    (dict(hop_odd=True), 30000, 2),                          # odd hop: the unaligned load variant
+    (dict(alignment="left", pad="edge"), 20011, 2),
+    (dict(alignment="right", pad=("constant", 0.25)), 20000, 1),
+    (dict(), 300, 3),                                        # shorter than a frame
+])
+def test_transform_against_the_oracle(fft, kw, n, lead):
+    rng = np.random.default_rng(fft + n)
+    kw = dict(kw)
+    hop = fft // 4 - 1 if kw.pop("hop_odd", False) else fft // 4
+    x = rng.uniform(-1, 1, size=(lead, n)).astype(np.float32)
+    c = Stft.Config.create(fft_size=fft, hop=hop, **kw)
+    okw = dict(kw)
+    if isinstance(okw.get("pad"), tuple):
+        okw["pad"], okw["pad_value"] = okw["pad"]
+    want = O.transform(O.stft_config(fft, hop=hop, **okw), x)
+    got = Stft.transform(c, x)
+    assert got.dtype == np.complex64
+    for i in range(lead):
+        _check_c(got[i], want[i], (fft, kw, n, i))
+        assert np.array_equal(got[i], Stft.transform(c, x[i]))                               # batch == stack of slices
+    assert np.all(got[..., 0, :].imag == 0) and np.all(got[..., -1, :].imag == 0)            # DC and Nyquist bins are real
+
+
+@pytest.mark.parametrize("fft", [2048, 1024, 512])
+def test_transform_ranges_streaming_and_device(fft):
+    import torch
+    rng = np.random.default_rng(fft)
+    n = 30 * fft + 77
+    x = rng.standard_normal((2, n)).astype(np.float32)
+    c = Stft.Config.create(fft_size=fft, hop=fft // 4)
+    full = Stft.transform(c, x)
+    total = Stft.frames(c, n)
+    cuts = [0, 1, 15, 16, 17, 31, 32, 33, 64, 65, total - 3, total]
+    parts = [Stft.transform_range(c, x, a, b) for a, b in zip(cuts[:-1], cuts[1:])]
+    assert np.array_equal(np.concatenate(parts, axis=-1), full)                              # stft_grid.ml:32-73
+    assert np.array_equal(Stft.transform(c, torch.from_numpy(x).cuda()).cpu().numpy(), full)  # device path == host path
+    for block in (n, 5000, 777):                                                             # stft_law.ml:79-164 through Stft.stage
+        st = Stft.stage(c).prepare(max_items=block)
+        got = []
+        for i in range(0, n, block):
+            out = st.step(x[:, i:i + block])
+            if out is not None:
+                got.append(out)
+        assert np.array_equal(st.concat(got + st.flush()), full), block
+
+
+def test_transform_many_short_clips():
+    import torch
+    rng = np.random.default_rng(13)
+    for fft in (2048, 1024, 512):
+        x = torch.from_numpy(rng.uniform(-1, 1, size=(3000, 2 * fft - 48)).astype(np.float32)).cuda()
+        c = Stft.Config.create(fft_size=fft, hop=fft // 4)
+        z = Stft.transform(c, x)
+        for lo in (0, 1475, 2950):
+            assert torch.equal(z[lo:lo + 50], Stft.transform(c, x[lo:lo + 50])), (fft, lo)
+        _check_c(z[777].cpu().numpy(), O.transform(O.stft_config(fft, hop=fft // 4), x[777].cpu().numpy()), (fft, 777))

@@ -1,5 +1,5 @@
 """Interleaved timing of Stft.transform (C2: 256 x 480000, fft 2048 / hop 512, complex64 out) under several environments:
-  python tools/ab_transform_env.py "" "SMX_COMPLEX_V1=1"     (AB_N: other clip lengths)"""
+  python tools/ab_transform_env.py "" "SMX_COMPLEX_V1=1"     (AB_N: other clip lengths, AB_FFT: 1024 / 512)"""
 import os, sys, ctypes
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -7,7 +7,8 @@ from soundml_amd import Stft
 envs = sys.argv[1:] or [""]
 n = int(os.environ.get("AB_N", "480000"))
 x = torch.rand(256, n, device="cuda") * 2 - 1
-c = Stft.Config.create(fft_size=2048, hop=512)
+fft = int(os.environ.get("AB_FFT", "2048"))
+c = Stft.Config.create(fft_size=fft, hop=fft // 4)
 def setenv(e, on):
     for kv in filter(None, e.split(",")):
         k, v = kv.split("=")
