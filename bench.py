@@ -396,6 +396,18 @@ def main():
                                  "roofline": {"bound": "hbm", "achieved": round(256 * f1 * b1 / a / 1e6, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                               "frac": round(256 * f1 * b1 / a / 1e6 / HBM_PEAK_GBS, 4), "algorithmic_bytes_per_frame": b1}}
             del x1, o1
+            # Stft.transform of the C2 batch (complex64 out: 10 248 algorithmic bytes per frame)
+            zc = torch.empty(clips, BINS, frames, 2, device=dev, dtype=torch.float32)
+            _, ms, nl = timed(lambda: check(lib.smx_stft_transform_range_f32_dev(cfg._h, vp(x.data_ptr()), clips, n, n, 0, frames,
+                                                                                 vp(zc.data_ptr()), sptr)), k, w)
+            a = sum(ms) / len(ms)
+            bc = HOP * 4 + BINS * 8
+            extra["c2_complex"] = {"workload": "Stft.transform of the C2 batch (complex64 spectrogram)", "value": round(clips * frames / a / 1e3, 1),
+                                   "unit": "Mframes/s", "ms": round(a, 4), "ms_min": round(ms[0], 4), "launches_per_step": nl,
+                                   "roofline": {"bound": "hbm", "achieved": round(clips * frames * bc / a / 1e6, 1), "peak": HBM_PEAK_GBS,
+                                                "unit": "GB/s", "frac": round(clips * frames * bc / a / 1e6 / HBM_PEAK_GBS, 4),
+                                                "algorithmic_bytes_per_frame": bc}}
+            del zc
             # C5 on ONE GPU: the N = 1 point of BASELINE configs[4] (71 GB resident)
             free_b, _ = torch.cuda.mem_get_info(dev)
             del x, out
