@@ -2200,8 +2200,9 @@ const smx::MelFusedPlan &smx_mel_config::fused32_plan() const {
   }
   // Measured against the 64-lane kernel (profiles/r05/ab_mel32.log): ahead by 6 % at 40 steps on the longest wave (128 mels at
   // 48 kHz), by 4.5 % at 48 (80 mels at 16 kHz), behind by 5 % at 72 (40 mels at 22.05 kHz: a mel's own band cannot be split by rows)
+  const int max_load = (int)diag_int("SMX_MEL32_MAXLOAD", 52);
   for (int i = 0; i < 8; ++i)
-    if (load[i] > 52) return plan;
+    if (load[i] > max_load) return plan;
   SMX_HIP_CHECK(hipMalloc(&plan.items, items.size() * sizeof(Mel32Item)));
   SMX_HIP_CHECK(hipMemcpy(plan.items, items.data(), items.size() * sizeof(Mel32Item), hipMemcpyHostToDevice));
   SMX_HIP_CHECK(hipMalloc((void **)&plan.w_mfma, wm.size() * sizeof(float)));
