@@ -119,6 +119,63 @@ __device__ __forceinline__ void mel32_items(const Mel32Args &m, int iv, const fl
   }
 }
 
+// the same over NCG groups of 16 frame columns at once (the tiles of the 16- / 8-lane kernels hold 32 / 64 frames): an item's
+// A operands are requested once per chunk and multiplied into every group; two chunks of CH steps in flight
+template <int TS, int NCG, int CH>
+__device__ __forceinline__ void mel32_items_multi(const Mel32Args &m, int iv, const float *tile, float *obase, int frames_left, int lane) {
+  using f32x4m = __attribute__((ext_vector_type(4))) float;
+  const int kk = lane >> 4, f = lane & 15;
+#pragma unroll 1
+  for (int i = 0; i < kMel32MaxItems; ++i) {
+    const int nrows = __builtin_amdgcn_readlane(iv, 8 * i + 1);
+    if (nrows == 0) break;
+    const int row0 = __builtin_amdgcn_readlane(iv, 8 * i);
+    const int k4b = __builtin_amdgcn_readlane(iv, 8 * i + 2);
+    const int k4n = __builtin_amdgcn_readlane(iv, 8 * i + 3);
+    const int last = __builtin_amdgcn_readlane(iv, 8 * i + 5);
+    const float *ap = m.w + (int64_t)__builtin_amdgcn_readlane(iv, 8 * i + 4) * 64 + lane;
+    f32x4m acc[NCG];
+#pragma unroll
+    for (int c = 0; c < NCG; ++c) acc[c] = f32x4m{0.f, 0.f, 0.f, 0.f};
+    float av[2][CH], bv[2][CH][NCG];
+    auto request = [&](int slot, int jj) {
+#pragma unroll
+      for (int u = 0; u < CH; ++u) {
+        av[slot][u] = ap[64 * (jj + u)];
+        const int row = 4 * (k4b + jj + u) + kk;
+        const float *bp = tile + (row < last ? row : last) * TS + f;
+#pragma unroll
+        for (int c = 0; c < NCG; ++c) bv[slot][u][c] = bp[16 * c];
+      }
+    };
+    auto multiply = [&](int slot) {
+#pragma unroll
+      for (int u = 0; u < CH; ++u)
+#pragma unroll
+        for (int c = 0; c < NCG; ++c) acc[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[slot][u], bv[slot][u][c], acc[c], 0, 0, 0);
+    };
+    const int nch = k4n / CH;   // k4n is a multiple of 4 and CH divides 4
+    request(0, 0);
+#pragma unroll 1
+    for (int c = 0; c + 2 <= nch; c += 2) {
+      request(1, CH * (c + 1));
+      multiply(0);
+      if (c + 2 < nch) request(0, CH * (c + 2));
+      multiply(1);
+    }
+    if (nch & 1) multiply(0);
+#pragma unroll
+    for (int c = 0; c < NCG; ++c)
+      if (16 * c + f < frames_left) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int row = 4 * kk + r;
+          if (row < nrows) obase[(int64_t)(row0 + row) * m.out_stride + 16 * c + f] = acc[c][r];
+        }
+      }
+  }
+}
+
 // what the mel kernel does between the stages of a frame pair (see frame32_to_tile / PowerMid32)
 template <bool ALIGNED>
 struct MelMid32 {
