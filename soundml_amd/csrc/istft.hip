@@ -500,7 +500,7 @@ constexpr int kSynM = 1024, kSynFrames = 16, kSynHops = 13;
 constexpr int kSynStride = kSynFrames + 1;                       // plane row stride (floats)
 constexpr size_t kSynPlane = (size_t)(kSynM + 1) * kSynStride * sizeof(float);          // 69,700
 constexpr size_t kSynRegionA = 2 * kSynPlane > (size_t)kSynFrames * kSynM * 8 ? 2 * kSynPlane : (size_t)kSynFrames * kSynM * 8;
-constexpr size_t kSynLds = ((kSynRegionA + 15) / 16) * 16 + (size_t)kSynM * sizeof(float2);
+constexpr size_t kSynLds = ((kSynRegionA + 15) / 16) * 16 + (size_t)kSynM * sizeof(float2) + 512 * sizeof(double);   // planes / slots, window, envelope reciprocals
 
 struct SynArgs {
   int64_t env_q0 = 0;   // envelope position of padded position 0 (streaming synthesis: IstftJob::env_q0)
@@ -540,6 +540,10 @@ __global__ void __launch_bounds__(1024) istft2048_kernel(SynArgs a) {
   const int64_t f_lo = (int64_t)kSynHops * tile - 3;
   const float2 *z = a.z + clip * (int64_t)(kSynM + 1) * a.frames;
   swin[tid] = a.synth_window[tid];
+  // the periodic part of the envelope as reciprocals: the overlap-add multiplies (one float64 product per sample where a division
+  // costs ~35 float64 operations; the quotients agree on every sample of the C2 round trip)
+  double *renv = reinterpret_cast<double *>(swin + kSynM);
+  if (tid < 512) renv[tid] = 1.0 / a.env_period[tid];
   // 1. stage: element e = (row, frame) with the frame fastest: 16 lanes read one 128-byte row piece.  All loads of
   // the thread are issued before the first use (the optional factors in their own batch: a branch inside the load
   // loop would serialise them)
@@ -670,8 +674,12 @@ __global__ void __launch_bounds__(1024) istft2048_kernel(SynArgs a) {
             if (p >= 0 && p < a.count) acc += slots[f * 2048 + (q - 512 * f)];
           }
           const int64_t E = Q + a.env_q0;
-          const double env = E < a.head ? a.env_head[E] : (E < a.stop ? a.env_period[E & 511] : a.env_tail[E - a.stop]);
-          v = (float)((double)acc / env);
+          if (E >= a.head && E < a.stop) {
+            v = (float)((double)acc * renv[E & 511]);
+          } else {   // the clip's first and last hops
+            const double env = E < a.head ? a.env_head[E] : a.env_tail[E - a.stop];
+            v = (float)((double)acc / env);
+          }
         }
         out[mo] = v;
       }
