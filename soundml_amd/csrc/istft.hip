@@ -140,6 +140,7 @@ struct FusedOla {
   float *out;               // [lead; out_len]
   int64_t out_len, left, span, head, stop;
   const double *env_head, *env_period, *env_tail;
+  const double *env_rperiod;   // 1 / env_period: a float64 product per sample instead of a division (same quotients after the rounding to float32)
   int tiles_per_clip;
 };
 
@@ -297,8 +298,12 @@ __global__ void __launch_bounds__(FT * ((1 << LOG2N) / 32)) istft_stockham_frame
             if (valid(g)) acc += slots[g * N + (q - HOP * g)];
           }
           const int64_t E = Q + o.env_q0;
-          const double env = E < o.head ? o.env_head[E] : (E < o.stop ? o.env_period[E & (HOP - 1)] : o.env_tail[E - o.stop]);
-          v = (float)((double)acc / env);
+          if (E >= o.head && E < o.stop) {
+            v = (float)((double)acc * o.env_rperiod[E & (HOP - 1)]);
+          } else {   // the clip's first and last hops
+            const double env = E < o.head ? o.env_head[E] : o.env_tail[E - o.stop];
+            v = (float)((double)acc / env);
+          }
         }
         out[mo] = v;
       }
@@ -985,6 +990,7 @@ void launch_istft(const IstftJob &job) {
     o.env_head = d_env;
     o.env_period = d_env + env.head;
     o.env_tail = d_env + env.head + env.period;
+    o.env_rperiod = d_env + env.head + env.period + env.tail;
     const int64_t need = std::max<int64_t>(span, o.left + job.out_len);
     const int64_t adv = hop * 4 == fft ? 13 : 15;      // complete hops per 16-frame tile
     o.tiles_per_clip = (int)((need + hop * adv - 1) / (hop * adv));

@@ -360,10 +360,11 @@ smx::EnvelopeTable smx_stft_config::envelope(int64_t count) const {
   smx::EnvelopeTable e;
   smx::stft_envelope(*this, count, head, period, tail, e.head_n, e.stop);
   std::vector<double> packed;
-  packed.reserve(head.size() + period.size() + tail.size() + 1);
+  packed.reserve(head.size() + 2 * period.size() + tail.size() + 1);
   packed.insert(packed.end(), head.begin(), head.end());
   packed.insert(packed.end(), period.begin(), period.end());
   packed.insert(packed.end(), tail.begin(), tail.end());
+  for (double v : period) packed.push_back(1.0 / v);   // the periodic part's reciprocals, behind the three pieces (the fused kernels multiply)
   packed.push_back(1.0);
   e.head = head.size();
   e.period = period.size();

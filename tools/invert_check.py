@@ -7,7 +7,8 @@ from soundml_amd import Stft
 torch.manual_seed(0)
 clips, n = int(os.environ.get("CLIPS", "256")), int(os.environ.get("N", "480000"))
 x = torch.rand(clips, n, device="cuda") * 2 - 1
-c = Stft.Config.create(fft_size=2048, hop=512)
+fft = int(os.environ.get("FFT", "2048"))
+c = Stft.Config.create(fft_size=fft, hop=int(os.environ.get("HOP", str(fft // 4))))
 z = Stft.transform(c, x)
 for _ in range(3): y = Stft.invert(c, z, length=n)
 torch.cuda.synchronize()
