@@ -25,8 +25,9 @@ def timeit(fn, reps=20, warm=3):
 
 
 def rel_err(got, want):
-    want = np.asarray(want, np.float64)
-    return float(np.max(np.abs(np.asarray(got, np.float64) - want)) / np.max(np.abs(want)))
+    kind = np.complex128 if np.iscomplexobj(want) or np.iscomplexobj(got) else np.float64
+    want = np.asarray(want, kind)
+    return float(np.max(np.abs(np.asarray(got, kind) - want)) / np.max(np.abs(want)))
 
 
 # C1: one 10 s mono 44.1 kHz 440 Hz sine, fft 1024 hop 256 (the reference's example / plumbing config)
