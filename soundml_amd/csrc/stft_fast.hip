@@ -1817,6 +1817,38 @@ void launch_interior(const StftJob &job, const FastTarget &tg, const float *x, i
       };
       return aligned ? by_power(std::true_type{}) : by_power(std::false_type{});
     };
+    // (the form with the output path on four waves of its own: SMX_POWER_P32H=1, A/B timing only)
+    if (env_flag("SMX_POWER_P32H") == 1) {
+      auto pick32h = [&](auto strip_tag) {
+        constexpr bool S = decltype(strip_tag)::value;
+        auto by_power = [&](auto al) {
+          constexpr bool A = decltype(al)::value;
+          return a.pmode == 2 ? stft2048_power32h_kernel<A, 2, S> : a.pmode == 1 ? stft2048_power32h_kernel<A, 1, S> : stft2048_power32h_kernel<A, 0, S>;
+        };
+        return aligned ? by_power(std::true_type{}) : by_power(std::false_type{});
+      };
+      auto k32h = strip ? pick32h(std::true_type{}) : pick32h(std::false_type{});
+      SMX_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k32h), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kFast32Lds));
+      SMX_LAUNCH(k32h, dim3((unsigned)a.blocks), dim3(768), kFast32Lds, job.stream, a);
+      SMX_HIP_CHECK(hipGetLastError());
+      return;
+    }
+    // The flush in whole aligned 64-byte blocks (stft_fast_p32.hpp, SKEW): needs even block offsets in every row -- an even row
+    // pitch and an origin on an 8-byte boundary -- and consecutive tiles of a clip on one workgroup (contiguous ranges).
+    const bool skew = !strip && a.out_stride % 2 == 0 && ((reinterpret_cast<uintptr_t>(a.out) >> 2) + (uintptr_t)a.out_offset) % 2 == 0 &&
+                      reinterpret_cast<uintptr_t>(a.out) % 4 == 0 && env_flag("SMX_POWER_SKEW") != 0;
+    if (skew) {
+      a.interleave = 0;
+      auto by_power = [&](auto al) {
+        constexpr bool A = decltype(al)::value;
+        return a.pmode == 2 ? stft2048_power32_kernel<A, 2, false, true> : a.pmode == 1 ? stft2048_power32_kernel<A, 1, false, true> : stft2048_power32_kernel<A, 0, false, true>;
+      };
+      auto k32s = aligned ? by_power(std::true_type{}) : by_power(std::false_type{});
+      SMX_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k32s), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kFast32Lds));
+      SMX_LAUNCH(k32s, dim3((unsigned)a.blocks), dim3(512), kFast32Lds, job.stream, a);
+      SMX_HIP_CHECK(hipGetLastError());
+      return;
+    }
     auto k32 = strip ? pick32(std::true_type{}) : pick32(std::false_type{});
     SMX_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k32), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kFast32Lds));
     SMX_LAUNCH(k32, dim3((unsigned)a.blocks), dim3(512), kFast32Lds, job.stream, a);

@@ -219,6 +219,28 @@ __device__ __forceinline__ void fft32(c32 (&v)[32], const Half &half = Half{}) {
   }
 }
 
+// ---- the same arithmetic on packed pairs (v_pk_add_f32 / v_pk_mul_f32 / v_pk_fma_f32; round 4) -------------------------------
+// A complex value is an aligned register pair (re, im).  One wave issues one instruction per ~4.2 cycles whatever it is
+// (profiles/r05/issue_probe.log) and two waves per SIMD leave the vector pipe idle more than half the time, so what bounds
+// the frame pipeline is the length of a wave's own instruction stream: a packed instruction does two of the operations
+// above in one issue slot.  Every packed operation is the IEEE operation of its two halves (v_pk_fma_f32 is a fused
+// multiply-add per half), the operations and their order are those of p32_cmul / p32_fft4 / p32_fft16 / fft32 above, and a
+// product by -i is folded into the operand selects of the instruction that consumes it: the results are the same bits.
+// The stages are generated as one inline-assembly statement each (tools/gen/gen_pk_fft.py says why).
+using f2 = float __attribute__((ext_vector_type(2)));
+#include "stft_pk_fft.inc"
+template <class Half = NoHalf32>
+__device__ __forceinline__ void pk_fft32(f2 (&v)[32], const Half &half = Half{}) {
+  f2 e[16], o[16];
+#pragma unroll
+  for (int m = 0; m < 16; ++m) { e[m] = v[2 * m]; o[m] = v[2 * m + 1]; }
+  pk_fft16(e);
+  half();
+  pk_fft16(o);
+  pk_fft32_combine0(v, e, o);
+  pk_fft32_combine1(v, e, o);
+}
+
 struct NoMid32 {
   __device__ __forceinline__ void early() const {}
   __device__ __forceinline__ void before_cells() const {}
@@ -258,6 +280,164 @@ struct NoMid32 {
 #ifndef SMX_P32_TWI
 #define SMX_P32_TWI 1      // 1: the transposition's first plane is written while the twiddle products are formed (shorter LDS bursts)
 #endif
+#ifndef SMX_P32_PK
+#define SMX_P32_PK 1       // 1: the frame's arithmetic on packed pairs (the same operations, the same bits, half the issue slots)
+#endif
+#ifndef SMX_P32_WAIT0
+#define SMX_P32_WAIT0 0
+#endif
+#if SMX_P32_PK
+template <int PMODE, class Mid, bool CPLX = false>
+__device__ __forceinline__ void frame32_to_tile(const FastArgs &a, const Lane32 &L, float2 (&raw)[32], float *tile,
+                                                const Mid &mid) {
+#pragma clang fp contract(off)
+  f2 v[32], t[32];
+#if SMX_P32_WAIT0
+  // the samples were requested most of a tile ago: one wait for all of them instead of one per product (a wait is an issue slot)
+  __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0)
+#endif
+#pragma unroll
+  for (int m0 = 0; m0 < 16; m0 += 8) {   // two batches: the window rows are not all in registers at once
+    float4 win[8];
+#pragma unroll
+    for (int m = 0; m < 8; ++m) win[m] = L.win_l[32 * (m0 + m)];
+#pragma unroll
+    for (int m = 0; m < 8; ++m) {
+      v[2 * (m0 + m)] = f2{raw[2 * (m0 + m)].x, raw[2 * (m0 + m)].y} * f2{win[m].x, win[m].y};
+      v[2 * (m0 + m) + 1] = f2{raw[2 * (m0 + m) + 1].x, raw[2 * (m0 + m) + 1].y} * f2{win[m].z, win[m].w};
+    }
+    SMX_FENCE();
+  }
+  mid.template stamp<1>();
+  SMX_FENCE();
+  // A: radix-32 over j, then twiddle W_M^(l k1)
+  {
+    float4 tw[15];
+#pragma unroll
+    for (int m = 0; m < 15; ++m) tw[m] = L.twA_l[32 * m];
+    const float2 tw31 = L.twA31_l[0];
+    pk_fft32(v, [&] { SMX_FENCE(); mid.early(); SMX_FENCE(); });
+    SMX_FENCE();
+    // X: lane l register k1 -> lane k1 register l through the frame's column, real parts then imaginary parts.
+    // One wave's LDS operations execute in order, so no wait separates the rounds.
+    mid.template stamp<2>();
+    mid.before_cells();
+    mid.template stamp<3>();
+    float *const wr = tile + opaque32(L.own);
+    float *const wr_hi = wr + 16 * kCellPitch32;
+    // the first plane is written while the twiddle products are formed (shorter LDS bursts)
+    auto put = [&](int j) { (j < 16 ? wr : wr_hi)[kCellPitch32 * (j & 15)] = v[j].x; };
+#define SMX_TWV(m) f2{tw[m].x, tw[m].y}, f2{tw[m].z, tw[m].w}
+    put(0);
+    pk_twiddle8(v[1], v[2], v[3], v[4], v[5], v[6], v[7], v[8], SMX_TWV(0), SMX_TWV(1), SMX_TWV(2), SMX_TWV(3));
+#pragma unroll
+    for (int j = 1; j <= 8; ++j) put(j);
+    SMX_FENCE();
+    pk_twiddle8(v[9], v[10], v[11], v[12], v[13], v[14], v[15], v[16], SMX_TWV(4), SMX_TWV(5), SMX_TWV(6), SMX_TWV(7));
+#pragma unroll
+    for (int j = 9; j <= 16; ++j) put(j);
+    SMX_FENCE();
+    pk_twiddle8(v[17], v[18], v[19], v[20], v[21], v[22], v[23], v[24], SMX_TWV(8), SMX_TWV(9), SMX_TWV(10), SMX_TWV(11));
+#pragma unroll
+    for (int j = 17; j <= 24; ++j) put(j);
+    SMX_FENCE();
+    pk_twiddle7(v[25], v[26], v[27], v[28], v[29], v[30], v[31], SMX_TWV(12), SMX_TWV(13), SMX_TWV(14), f2{tw31.x, tw31.y});
+#pragma unroll
+    for (int j = 25; j <= 31; ++j) put(j);
+#undef SMX_TWV
+  }
+  SMX_FENCE();
+  float *const wr = tile + opaque32(L.own);
+  float *const wr_hi = wr + 16 * kCellPitch32;   // (ds offsets are 16 bits: 31 x 2244 bytes does not fit)
+  const float *const rd = tile + opaque32(L.rd);
+#pragma unroll
+  for (int i = 0; i < 32; ++i) t[i].x = rd[kTileStride * i];
+#pragma unroll
+  for (int j = 0; j < 32; ++j) (j < 16 ? wr : wr_hi)[kCellPitch32 * (j & 15)] = v[j].y;
+#pragma unroll
+  for (int i = 0; i < 32; ++i) t[i].y = rd[kTileStride * i];
+  SMX_FENCE();
+  mid.after_transposition_issue();
+  mid.template stamp<4>();
+  SMX_FENCE();
+  // B: radix-32 over l
+  pk_fft32(t);
+  SMX_FENCE();
+  mid.template stamp<5>();
+  // P: partners through the cells.  Every lane parks registers 16..31 (cell l + 33 (q - 16)) and reads, for slot s,
+  // register 31 - s of lane 32 - l (lanes 0 and 16: their own; lane 0: register 32 - s, and itself for s = 0).
+  f2 pp[16];
+  const float *const xr = tile + opaque32(L.xr);
+  // (register 0 goes to cell l + 33 x 16 as well: that is where lane 0 looks for the partner of bin 0 -- itself; slot 0
+  // of that lane yields X[0] and the Nyquist bin.  A select instead would be two v_cndmask_b32 on vcc, 19 cycles each.)
+#pragma unroll
+  for (int q = 16; q < 32; ++q) wr[kCellPitch32 * (q - 16)] = t[q].x;
+  wr_hi[0] = t[0].x;
+#pragma unroll
+  for (int s = 0; s < 16; ++s) pp[s].x = xr[kCellPitch32 * (15 - s)];
+#pragma unroll
+  for (int q = 16; q < 32; ++q) wr[kCellPitch32 * (q - 16)] = t[q].y;
+  wr_hi[0] = t[0].y;
+#pragma unroll
+  for (int s = 0; s < 16; ++s) pp[s].y = xr[kCellPitch32 * (15 - s)];
+  float4 tw[8];
+#pragma unroll
+  for (int m = 0; m < 8; ++m) tw[m] = L.twP_l[32 * m];
+  SMX_FENCE();
+  mid.after_exchange_issue();
+  mid.template stamp<6>();
+  SMX_FENCE();
+  // CPLX: the spectrum itself, real parts in `tile`, imaginary parts in the plane after it (the other tile buffer)
+  {   // bin M/2 (lane 0, register 16): X = 2 conj(Z)
+    const f2 z = t[16] + t[16];
+    if constexpr (CPLX) {
+      tile[opaque32(L.self)] = z.x;
+      tile[kTile32Floats + opaque32(L.self)] = -z.y;
+    } else {
+      tile[opaque32(L.self)] = power_from_square<PMODE>(__builtin_fmaf(z.x, z.x, z.y * z.y), a);
+    }
+  }
+  float *const rk = wr;                 // row l + 32 s
+  float *const rm = tile + opaque32(L.rm);        // row (32 - l) + 32 (31 - s) = rm base + 32 (15 - s)
+  // slot s: E = Z[k] + conj Z[M-k], D = Z[k] - conj Z[M-k], T = -i w D, X[k] = E + T, X[M-k] = conj(E - T); the generated
+  // blocks return them as planes (re_k, re_(M-k)), (im_k, im_(M-k)) or as (|X_k|^2, |X_(M-k)|^2) = fma(re, re, im im) per half
+  auto wtw = [&](int s) { return (s & 1) ? f2{tw[s >> 1].z, tw[s >> 1].w} : f2{tw[s >> 1].x, tw[s >> 1].y}; };
+  auto put = [&](int s, f2 re, f2 im) {
+    if constexpr (CPLX) {
+      rk[kRowPitch32 * s] = re.x;
+      rk[kTile32Floats + kRowPitch32 * s] = im.x;
+      rm[kRowPitch32 * (15 - s)] = re.y;
+      rm[kTile32Floats + kRowPitch32 * (15 - s)] = im.y;
+    } else {
+      rk[kRowPitch32 * s] = power_from_square<PMODE>(re.x, a);
+      rm[kRowPitch32 * (15 - s)] = power_from_square<PMODE>(re.y, a);
+    }
+  };
+#define SMX_PA(s) t[s], pp[s], wtw(s)
+  static_assert(SMX_P32_STORE_AT == 1 && SMX_P32_LOAD_AT == 5, "the post-pass blocks end at slots 1, 5, 10, 15");
+  f2 r[6], q[6];
+  if constexpr (CPLX) pk_post_cplx2(SMX_PA(0), SMX_PA(1), r[0], q[0], r[1], q[1]);
+  else pk_post_power2(SMX_PA(0), SMX_PA(1), r[0], r[1]);
+#pragma unroll
+  for (int i = 0; i < 2; ++i) put(i, r[i], q[i]);
+  SMX_FENCE(); mid.postpass_at(1); SMX_FENCE();
+  if constexpr (CPLX) pk_post_cplx4(SMX_PA(2), SMX_PA(3), SMX_PA(4), SMX_PA(5), r[0], q[0], r[1], q[1], r[2], q[2], r[3], q[3]);
+  else pk_post_power4(SMX_PA(2), SMX_PA(3), SMX_PA(4), SMX_PA(5), r[0], r[1], r[2], r[3]);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) put(2 + i, r[i], q[i]);
+  SMX_FENCE(); mid.postpass_at(5); SMX_FENCE();
+  if constexpr (CPLX) pk_post_cplx5(SMX_PA(6), SMX_PA(7), SMX_PA(8), SMX_PA(9), SMX_PA(10), r[0], q[0], r[1], q[1], r[2], q[2], r[3], q[3], r[4], q[4]);
+  else pk_post_power5(SMX_PA(6), SMX_PA(7), SMX_PA(8), SMX_PA(9), SMX_PA(10), r[0], r[1], r[2], r[3], r[4]);
+#pragma unroll
+  for (int i = 0; i < 5; ++i) put(6 + i, r[i], q[i]);
+  if constexpr (CPLX) pk_post_cplx5(SMX_PA(11), SMX_PA(12), SMX_PA(13), SMX_PA(14), SMX_PA(15), r[0], q[0], r[1], q[1], r[2], q[2], r[3], q[3], r[4], q[4]);
+  else pk_post_power5(SMX_PA(11), SMX_PA(12), SMX_PA(13), SMX_PA(14), SMX_PA(15), r[0], r[1], r[2], r[3], r[4]);
+#pragma unroll
+  for (int i = 0; i < 5; ++i) put(11 + i, r[i], q[i]);
+#undef SMX_PA
+  mid.template stamp<7>();
+}
+#else
 template <int PMODE, class Mid, bool CPLX = false>
 __device__ __forceinline__ void frame32_to_tile(const FastArgs &a, const Lane32 &L, float2 (&raw)[32], float *tile,
                                                 const Mid &mid) {
@@ -395,6 +575,7 @@ __device__ __forceinline__ void frame32_to_tile(const FastArgs &a, const Lane32 
   }
   mid.template stamp<7>();
 }
+#endif
 
 // raw samples of the lane's frame: z[n] = (x[2n], x[2n+1]), n = l + 32 j; `src` is the frame's first sample (per lane:
 // the two halves of a wave read different frames)
@@ -488,13 +669,127 @@ __device__ __forceinline__ void flush32_store(const FastArgs &a, const Flush32 &
   if (wave == 0 && lane < 16 && lane < frames_left) obase[(int64_t)kM * a.out_stride + lane] = r.nyq;
 }
 
+// ---- the flush in whole, aligned 64-byte blocks (round 4; `SKEW` kernels) --------------------------------------------
+// Measured with nothing else running (tools/probes/store_shape_probe, profiles/r06/store_shape_probe.log): the 0.97 GB of a
+// C2 spectrogram written as the tiles above write it -- a 64-byte run per row and tile, rows 3752 bytes apart, so that seven
+// runs of eight straddle a 64-byte boundary -- take 0.42-0.46 ms: the memory side completes every partial 32-byte sector by
+// a read-modify-write.  The same bytes in whole aligned 64-byte blocks take 0.27-0.29 ms (aligned 128-byte blocks 0.185).
+// The kernel's 0.51 ms were that floor, not its arithmetic.  So a row's run of a tile is held back until it completes a
+// block: row r's blocks begin e(r) frames into a tile (e even when the row pitch and the origin are: the launcher checks),
+// the lanes of the first e frames of a row store the tile's values at once, the lanes of frames e..15 store what they
+// carried from the previous tile 64 bytes further down -- one instruction, one whole block per row -- and carry theirs.
+// A lane holds a pair of frames (8 lanes a row, 8 rows an instruction: rows {0,1,16,17} (+2 for the upper half-wave) keep
+// the LDS reads conflict free); its 16 parts are rows row0 + 4 (p & 1) + 8 ((p >> 1) & 1) + 32 (p >> 2), and rows 8 apart
+// share an alignment when the pitch is even, so a lane has two block offsets (p & 1), set once per clip.
+// The workgroup must walk consecutive tiles of a clip (TileWalk's contiguous ranges); where a range or a clip begins there
+// is nothing carried (those lanes store nothing), where it ends the carried pairs go out as the partial block they are.
+struct Skew32 {
+  int src0;                    // float offset in a tile of part 0's pair: row0 * 17 + 2 g2
+  int g2, row0;
+  unsigned goffL;              // byte offset of out[row0][2 g2] from a tile's origin
+  unsigned goffc[2];           // part class c, from 64 bytes BEFORE a tile's origin (the offset register of a store is unsigned): goffL + 4 c pitch, plus 64 for the lanes that store the current pair
+  unsigned long long sel[2];   // part class c: the lanes whose pair of the current tile completes the block
+};
+struct SkewRegs {
+  float2 cur[16];
+  float nyq;
+};
+__device__ __forceinline__ Skew32 setup_skew32(const FastArgs &a, int lane, int wave) {
+  Skew32 sk;
+  const int rsel = lane >> 3;
+  sk.g2 = lane & 7;
+  sk.row0 = 128 * wave + (rsel & 1) + 16 * ((rsel >> 1) & 1) + 2 * (rsel >> 2);
+  sk.src0 = sk.row0 * kTileStride + 2 * sk.g2;
+  sk.goffL = ((unsigned)sk.row0 * (unsigned)a.out_stride + 2u * sk.g2) * 4u;
+  sk.goffc[0] = sk.goffc[1] = 0;
+  sk.sel[0] = sk.sel[1] = 0;
+  return sk;
+}
+// the block offsets of the clip whose output begins at oclip (every tile origin of a clip is oclip + 16 t floats)
+__device__ __forceinline__ void skew32_clip(const FastArgs &a, Skew32 &sk, const float *oclip) {
+  const unsigned pitch = (unsigned)a.out_stride * 4u;
+#pragma unroll
+  for (int c = 0; c < 2; ++c) {
+    const unsigned at = (unsigned)((reinterpret_cast<uintptr_t>(oclip) >> 2) + (uintptr_t)(sk.row0 + 4 * c) * (uintptr_t)a.out_stride) & 15u;
+    const unsigned e = at ? 16u - at : 16u;          // frames of a tile that end the row's open block
+    const bool now = 2u * sk.g2 < e;
+    sk.sel[c] = __ballot(now);
+    sk.goffc[c] = sk.goffL + 4u * c * pitch + (now ? 64u : 0u);
+  }
+}
+__device__ __forceinline__ constexpr int skew32_part_rows(int p) { return 8 * ((p >> 1) & 1) + 32 * (p >> 2); }
+__device__ __forceinline__ void skew32_read(const float *tile, const Skew32 &sk, int lane, SkewRegs &r) {
+  const float *src0 = tile + opaque32(sk.src0);
+#pragma unroll
+  for (int p = 0; p < 16; ++p) {
+    const float *src = src0 + (4 * (p & 1) + skew32_part_rows(p)) * kTileStride;
+    r.cur[p] = make_float2(src[0], src[1]);
+  }
+  r.nyq = tile[kM * kTileStride + (lane & 15)];   // row 1024 = Nyquist bin (every wave reads it, wave 0 stores it)
+}
+__device__ __forceinline__ void store2_at(float *base /* wave-uniform */, unsigned byte_off, float x, float y) {
+  using f32x2 = __attribute__((ext_vector_type(2))) float;
+  const f32x2 v = {x, y};
+  asm volatile("global_store_dwordx2 %0, %1, %2" SMX_STORE_MOD "\n\ts_nop 1" : : "v"(byte_off), "v"(v), "s"(base) : "memory");
+}
+__device__ __forceinline__ float select_lanes(float other, float chosen, unsigned long long lanes) {   // lanes ? chosen : other
+  float d;
+  asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(d) : "v"(other), "v"(chosen), "s"(lanes));
+  return d;
+}
+// obase: origin of the tile that `r` holds; fresh: nothing is carried into it; closing: nothing follows it in its clip (or
+// in this workgroup's range); frames_left: its frames that exist (16 unless it is a clip's last tile)
+__device__ __forceinline__ void skew32_store(const FastArgs &a, const Skew32 &sk, float *obase, int frames_left, bool fresh, bool closing,
+                                             int wave, int lane, const SkewRegs &r, float2 (&carry)[16]) {
+  const unsigned pitch = (unsigned)a.out_stride * 4u;
+#ifdef SMX_DIAG
+  if (a.abl_nostore == 1) {   // timing-only ablation: keep the LDS reads alive, drop the HBM stores
+#pragma unroll
+    for (int p = 0; p < 16; ++p) { asm volatile("" ::"v"(r.cur[p].x), "v"(r.cur[p].y)); carry[p] = r.cur[p]; }
+    asm volatile("" ::"v"(r.nyq));
+    return;
+  }
+#endif
+  if (frames_left >= kFT && !fresh && !closing) {   // wave-uniform: one whole block per row and part
+    const unsigned g0 = opaque32(sk.goffc[0]), g1 = opaque32(sk.goffc[1]);
+#pragma unroll
+    for (int p = 0; p < 16; ++p) {
+      const int c = p & 1;
+      store2_at(obase - kFT, (c ? g1 : g0) + (unsigned)skew32_part_rows(p) * pitch, select_lanes(carry[p].x, r.cur[p].x, sk.sel[c]),
+                select_lanes(carry[p].y, r.cur[p].y, sk.sel[c]));
+      carry[p] = r.cur[p];
+    }
+  } else {
+    const unsigned gl = opaque32(sk.goffL);
+    const int f = 2 * sk.g2;
+#pragma unroll
+    for (int p = 0; p < 16; ++p) {
+      const int c = p & 1;
+      const bool now = (sk.sel[c] >> lane) & 1;
+      const unsigned off = gl + (unsigned)(4 * c + skew32_part_rows(p)) * pitch;
+      float *dst = reinterpret_cast<float *>(reinterpret_cast<char *>(obase) + off);
+      if (now || closing) {
+        if (f < frames_left) dst[0] = r.cur[p].x;
+        if (f + 1 < frames_left) dst[1] = r.cur[p].y;
+      }
+      if (!now && !fresh) { dst[-16] = carry[p].x; dst[-15] = carry[p].y; }
+      carry[p] = r.cur[p];
+    }
+  }
+  if (wave == 0 && lane < 16 && lane < frames_left) obase[(int64_t)kM * a.out_stride + lane] = r.nyq;
+}
+
 // what the power kernel does between the stages of a frame pair (see frame32_to_tile)
-template <bool ALIGNED>
+template <bool ALIGNED, bool SKEW = false>
 struct PowerMid32 {
   const FastArgs &a;
   const Lds32 &lds;
   const Flush32 &fl;
   FlushRegs &fr;
+  const Skew32 &sk;      // SKEW: the flush in aligned blocks
+  SkewRegs &sr;
+  float2 (&carry)[16];
+  bool pend_fresh, pend_closing;
   float2 (&raw)[32];
   const float *src;      // the next frames' samples (per lane)
   float *pend_out;       // output origin and frames of the previous tile
@@ -536,7 +831,8 @@ struct PowerMid32 {
 #ifdef SMX_STAMPS
       stamp_sum[13] += __builtin_amdgcn_s_memtime() - w0;
 #endif
-      flush32_read(lds.tiles + (b ^ 1) * kTile32Floats, fl, wave, lane, fr);
+      if constexpr (SKEW) skew32_read(lds.tiles + (b ^ 1) * kTile32Floats, sk, lane, sr);
+      else flush32_read(lds.tiles + (b ^ 1) * kTile32Floats, fl, wave, lane, fr);
       // "read out" may be signalled as soon as the reads are ISSUED: the counter's add executes behind them in this wave's
       // LDS order, and nobody writes the buffer before seeing it.  Every frame fraction the signal comes earlier is slack
       // for the wave that waits for it: the two waves of a SIMD settle half a frame apart, and with the signal behind the
@@ -549,13 +845,16 @@ struct PowerMid32 {
   __device__ __forceinline__ void postpass_at(int s) const {
     const bool same = SMX_P32_STORE_AT == SMX_P32_LOAD_AT;
     if (s == SMX_P32_LOAD_AT && same && SMX_P32_LOADS_FIRST) { load_frame32<ALIGNED>(src, lane & 31, raw); SMX_FENCE(); }
-    if (s == SMX_P32_STORE_AT && it > 0) flush32_store(a, fl, pend_out, pend_left, wave, lane, fr);
+    if (s == SMX_P32_STORE_AT && it > 0) {
+      if constexpr (SKEW) skew32_store(a, sk, pend_out, pend_left, pend_fresh, pend_closing, wave, lane, sr, carry);
+      else flush32_store(a, fl, pend_out, pend_left, wave, lane, fr);
+    }
     SMX_FENCE();
     if (s == SMX_P32_LOAD_AT && !(same && SMX_P32_LOADS_FIRST)) load_frame32<ALIGNED>(src, lane & 31, raw);   // (half of the frame's registers are free by now)
   }
 };
 
-template <bool ALIGNED, int PMODE, bool STRIP>
+template <bool ALIGNED, int PMODE, bool STRIP, bool SKEW = false>
 __global__ void __launch_bounds__(512) stft2048_power32_kernel(FastArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x;
@@ -599,6 +898,13 @@ __global__ void __launch_bounds__(512) stft2048_power32_kernel(FastArgs a) {
     fl.goff0 = ((unsigned)row0 * (unsigned)a.out_stride + 4u * fl.g) * 4u;
   }
   FlushRegs fr;
+  Skew32 sk = setup_skew32(a, lane, wave);
+  SkewRegs sr;
+  float2 carry[16];
+#pragma unroll
+  for (int p = 0; p < 16; ++p) carry[p] = make_float2(0.f, 0.f);
+  bool pend_fresh = true, pend_closing = false;
+  const float *pend_oclip = nullptr;
   unsigned pk_drained = 0, pk_filled = 0;
 #ifdef SMX_STAMPS
   unsigned long long stamp_sum[kStampSlots] = {0}, stamp_prev;
@@ -617,10 +923,13 @@ __global__ void __launch_bounds__(512) stft2048_power32_kernel(FastArgs a) {
     if (a.abl_p32 & 1) src = frame_ptr(a.x, 1);   // timing only: every tile reads the same resident samples
 #endif
     const bool have = (int64_t)tw.ft * kFT + 2 * wave < a.count;   // wave-uniform: at least the first half has a frame
+    if constexpr (SKEW) {
+      if (it > 0 && pend_fresh) skew32_clip(a, sk, pend_oclip);   // (wave-uniform) the pending tile begins a clip or this workgroup's range
+    }
 #ifdef SMX_STAMPS
-    const PowerMid32<ALIGNED> mid{a, lds, fl, fr, raw, src, pend_out, pend_left, lane, wave, b, it, stamp_sum, &stamp_prev, pk_drained, pk_filled};
+    const PowerMid32<ALIGNED, SKEW> mid{a, lds, fl, fr, sk, sr, carry, pend_fresh, pend_closing, raw, src, pend_out, pend_left, lane, wave, b, it, stamp_sum, &stamp_prev, pk_drained, pk_filled};
 #else
-    const PowerMid32<ALIGNED> mid{a, lds, fl, fr, raw, src, pend_out, pend_left, lane, wave, b, it, pk_drained, pk_filled};
+    const PowerMid32<ALIGNED, SKEW> mid{a, lds, fl, fr, sk, sr, carry, pend_fresh, pend_closing, raw, src, pend_out, pend_left, lane, wave, b, it, pk_drained, pk_filled};
 #endif
     mid.template stamp<0>();
 #ifdef SMX_STAMPS
@@ -648,6 +957,9 @@ __global__ void __launch_bounds__(512) stft2048_power32_kernel(FastArgs a) {
     pend_out = tw.oclip + tw.ft * kFT;   // wave-uniform
     const int64_t left = a.count - (int64_t)tw.ft * kFT;
     pend_left = left < kFT ? (int)left : kFT;
+    pend_oclip = tw.oclip;
+    pend_fresh = it == 0 || tw.ft == 0;
+    pend_closing = tw.ft == a.tiles_per_clip - 1;
     tw.xclip = xnext;
     tw.oclip = onext;
     tw.ft = ftnext;
@@ -655,8 +967,14 @@ __global__ void __launch_bounds__(512) stft2048_power32_kernel(FastArgs a) {
   if (ntiles > 0) {   // the last tile of this workgroup
     const int b = (ntiles - 1) & 1;
     lds_wait(lds.filled + b * kTileStride, 8u * (((unsigned)(ntiles - 1) >> 1) + 1));
-    flush32_read(lds.tiles + b * kTile32Floats, fl, wave, lane, fr);
-    flush32_store(a, fl, pend_out, pend_left, wave, lane, fr);
+    if constexpr (SKEW) {
+      if (pend_fresh) skew32_clip(a, sk, pend_oclip);
+      skew32_read(lds.tiles + b * kTile32Floats, sk, lane, sr);
+      skew32_store(a, sk, pend_out, pend_left, pend_fresh, true, wave, lane, sr, carry);
+    } else {
+      flush32_read(lds.tiles + b * kTile32Floats, fl, wave, lane, fr);
+      flush32_store(a, fl, pend_out, pend_left, wave, lane, fr);
+    }
   }
 #ifdef SMX_STAMPS
   stamp_sum[20] = __builtin_amdgcn_s_memtime() - clk_t0;
@@ -697,6 +1015,172 @@ __global__ void __launch_bounds__(512) stft2048_power32_kernel(FastArgs a) {
       }
       __syncthreads();
       for (int e = tid; e < kBins * kFT; e += 512) {
+        const int k = e / kFT, f = e % kFT;
+        const int64_t bf = bt * kFT + f;
+        if (bf < total) {
+          int64_t clip, p;
+          locate(bf, clip, p);
+          a.out[(clip * kBins + k) * a.out_stride + a.border_out_offset + (p - a.border_p0)] = bt_tile[k * kTileStride + f];
+        }
+      }
+    }
+  }
+}
+
+// ---- stft2048_power32h_kernel: the same tiles with the output path on waves of its own (round 4) -----------------------
+// 12 waves per workgroup: waves 0-7 run the frame code as above but issue no store and read no finished tile; waves 8-11
+// ("flush waves", one per SIMD) do nothing but read finished tiles out of LDS and store them.  Why: the ablations of round
+// 3 (profiles/r05/NOTES.md 3b) put 0.14 of the kernel's 0.51 ms on the stores although they are 9 instructions per wave
+// and tile -- a store issues only when the memory pipeline takes it, the wave that issues it is one of the eight that all
+// others wait for at the counters, and its 33 tile registers are live from the exchange to the store.  On waves of their
+// own the stores wait for nobody: a flush wave has a whole tile's time to get 2 x 9 instructions out.  Three waves per
+// SIMD need <= 168 registers, which the packed arithmetic (200 with the tile registers, 168 without) makes possible.
+// Counters per buffer: filled += 1 per compute wave and tile (8), drained += 1 per flush wave and tile (4).
+#ifndef SMX_P32H_PRIO
+#define SMX_P32H_PRIO 2
+#endif
+template <bool ALIGNED>
+struct PowerMid32H {
+  const Lds32 &lds;
+  float2 (&raw)[32];
+  const float *src;      // the next frames' samples (per lane)
+  int lane, b, it;
+  unsigned &pk_drained;
+  template <int I> __device__ __forceinline__ void stamp() const {}
+  __device__ __forceinline__ void early() const { pk_drained = peek32(lds.drained + b * kTileStride); }
+  __device__ __forceinline__ void before_cells() const {
+    // buffer b last held tile it - 2, the (it >> 1)-th tile written there: the four flush waves have read it out
+    lds_wait32(lds.drained + b * kTileStride, 4u * ((unsigned)it >> 1), pk_drained);
+  }
+  __device__ __forceinline__ void after_transposition_issue() const {}
+  __device__ __forceinline__ void after_exchange_issue() const {}
+  __device__ __forceinline__ void postpass_at(int s) const {
+    if (s == SMX_P32_LOAD_AT) load_frame32<ALIGNED>(src, lane & 31, raw);
+  }
+};
+
+template <bool ALIGNED, int PMODE, bool STRIP>
+__global__ void __launch_bounds__(768) stft2048_power32h_kernel(FastArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const Lds32 lds = carve_lds32(smem);
+  fill_tables32(a, lds, tid, 768);
+  TileWalk tw;
+  tw.init(a, a.out + a.out_offset, kBins * a.out_stride);
+  const int ntiles = tw.ntiles > 0 ? tw.ntiles : 0;
+  const Lane32 L = setup_lane32(lds, lane, wave & 7);
+
+  if (wave < 8) {
+    // first sample of this lane's frame in tile t of the clip at xc (a lane-half without a frame re-reads the tile's
+    // first frame and its results are never stored)
+    auto frame_ptr = [&](const float *xc, int t) {
+      const int64_t f0 = (int64_t)t * kFT;
+      const int avail = (int)(a.count - f0 < kFT ? a.count - f0 : kFT) - 1;   // last frame of the tile that exists (wave-uniform)
+      const int fi = 2 * wave + L.h;
+      const int64_t p = a.p0 + f0 + (fi <= avail ? fi : 0);
+      if (a.fold_frames && (p < a.border_i0 || p >= a.border_i1)) {
+        const int64_t clip = (xc - a.x) / a.x_stride;
+        return p < a.border_i0 ? a.strip_l + clip * a.strip_l_stride + (p - a.p0) * a.hop
+                               : a.strip_r + clip * a.strip_r_stride + (p - a.border_i1) * a.hop;
+      }
+      return xc + (p * a.hop - a.left);
+    };
+    float2 raw[32];
+#pragma unroll
+    for (int j = 0; j < 32; ++j) raw[j] = make_float2(0.f, 0.f);
+    if (ntiles > 0) load_frame32<ALIGNED>(frame_ptr(tw.xclip, tw.ft), L.l, raw);
+    __syncthreads();   // tables and zeroed counters visible
+    unsigned pk_drained = 0;
+    for (int it = 0; it < ntiles; ++it) {   // tile `it` of this workgroup lives in buffer it & 1
+      const int b = it & 1;
+      int ftnext;
+      const float *xnext;
+      float *onext;
+      tw.peek(a, ftnext, xnext, onext);
+      const bool more = it + 1 < ntiles;
+      const float *src = frame_ptr(more ? xnext : tw.xclip, more ? ftnext : tw.ft);
+#ifdef SMX_DIAG
+      if (a.abl_p32 & 1) src = frame_ptr(a.x, 1);   // timing only: every tile reads the same resident samples
+#endif
+      const PowerMid32H<ALIGNED> mid{lds, raw, src, lane, b, it, pk_drained};
+      frame32_to_tile<PMODE>(a, L, raw, lds.tiles + b * kTile32Floats, mid);
+      lds_signal32(lds.filled + b * kTileStride, lane);
+      tw.xclip = xnext;
+      tw.oclip = onext;
+      tw.ft = ftnext;
+    }
+  } else {
+    // flush wave h: the shares of (former) waves 2 h and 2 h + 1 of every finished tile -- 2 x 8 parts of 16 rows x 4 frames
+    __builtin_amdgcn_s_setprio(SMX_P32H_PRIO);
+    const int h = wave - 8;
+    Flush32 fl0, fl1;
+    {
+      const int hsel = lane >> 5, jj = (lane & 31) >> 2;
+      fl0.g = fl1.g = lane & 3;
+      const int row0 = 128 * (2 * h) + (jj & 3) + 16 * (jj >> 2) + 4 * hsel;
+      fl0.src0 = row0 * kTileStride + 4 * fl0.g;
+      fl0.goff0 = ((unsigned)row0 * (unsigned)a.out_stride + 4u * fl0.g) * 4u;
+      fl1.src0 = fl0.src0 + 128 * kTileStride;
+      fl1.goff0 = fl0.goff0 + 128u * (unsigned)a.out_stride * 4u;
+    }
+    __syncthreads();
+    for (int it = 0; it < ntiles; ++it) {
+      const int b = it & 1;
+      int ftnext;
+      const float *xnext;
+      float *onext;
+      tw.peek(a, ftnext, xnext, onext);
+      float *const pend_out = tw.oclip + tw.ft * kFT;   // wave-uniform
+      const int64_t left = a.count - (int64_t)tw.ft * kFT;
+      const int pend_left = left < kFT ? (int)left : kFT;
+      FlushRegs r0, r1;
+      lds_wait(lds.filled + b * kTileStride, 8u * (((unsigned)it >> 1) + 1));   // every column of the tile is in
+      const float *tile = lds.tiles + b * kTile32Floats;
+      flush32_read(tile, fl0, 2 * h, lane, r0);
+      flush32_read(tile, fl1, 2 * h + 1, lane, r1);
+      lds_signal32(lds.drained + b * kTileStride, lane);   // behind this wave's reads in LDS order
+      flush32_store(a, fl0, pend_out, pend_left, 2 * h, lane, r0);
+      flush32_store(a, fl1, pend_out, pend_left, 2 * h + 1, lane, r1);
+      tw.xclip = xnext;
+      tw.oclip = onext;
+      tw.ft = ftnext;
+    }
+    __builtin_amdgcn_s_setprio(0);
+  }
+
+  // Border frames: as stft2048_power32_kernel (the flush waves take part in the barriers and in the scatter)
+  if (a.border_left + a.border_right > 0) {
+    const int per = a.border_left + a.border_right;
+    const int64_t lead = a.total_tiles / a.tiles_per_clip;
+    const int64_t total = lead * per;
+    auto locate = [&](int64_t beta, int64_t &clip, int64_t &p) {
+      clip = beta / per;
+      const int r = (int)(beta % per);
+      p = r < a.border_left ? a.border_p0 + r : a.border_i1 + (r - a.border_left);
+    };
+    float *bt_tile = lds.tiles;
+    for (int64_t bt = (int64_t)gridDim.x - 1 - tw.uid; bt * kFT < total; bt += gridDim.x) {   // from the last workgroup down: idle ones first
+      __syncthreads();   // the buffer is free: every tile has been read out / the previous border tile scattered
+      if (wave < 8 && bt * kFT + 2 * wave < total) {   // wave-uniform
+        int64_t beta = bt * kFT + 2 * wave + L.h;
+        if (beta >= total) beta = bt * kFT + 2 * wave;   // a half without a pair repeats the first one (never stored)
+        int64_t clip, p;
+        locate(beta, clip, p);
+        const float *xs = a.x + clip * a.x_stride;
+        const int s0 = (int)(p * a.hop - a.left);
+        float2 braw[32];
+#pragma unroll
+        for (int j = 0; j < 32; ++j) {
+          const int s = s0 + 2 * (L.l + 32 * j);
+          braw[j] = make_float2(fetch_padded(xs, (int)a.n, s, a.pad, a.pad_value),
+                                fetch_padded(xs, (int)a.n, s + 1, a.pad, a.pad_value));
+        }
+        frame32_to_tile<PMODE>(a, L, braw, bt_tile, NoMid32{});
+      }
+      __syncthreads();
+      for (int e = tid; e < kBins * kFT; e += 768) {
         const int k = e / kFT, f = e % kFT;
         const int64_t bf = bt * kFT + f;
         if (bf < total) {

@@ -33,6 +33,16 @@ for p, lib, h in libs:
     for _ in range(3): run(lib, h)
     clearenv(p)
 torch.cuda.synchronize()
+# do the builds agree?  (bit for bit, and the largest difference relative to the output's peak)
+ref = None
+for p, lib, h in libs:
+    setenv(p); out.zero_(); run(lib, h); torch.cuda.synchronize(); clearenv(p)
+    print("%-52s checksum %016x" % (p[-52:], int(out.view(torch.int32).to(torch.int64).sum().item()) & (2**64 - 1)))
+    if ref is None:
+        ref = out.clone()
+    else:
+        print("%-52s vs first: bit-identical %s, max |diff| / peak %.3g" % (p[-52:], bool(torch.equal(ref, out)), float((ref - out).abs().max() / ref.abs().max())))
+del ref
 ts = {p: [] for p in paths}
 for rnd in range(int(os.environ.get("AB_ROUNDS", "40"))):
     for p, lib, h in libs:

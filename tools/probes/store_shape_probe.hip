@@ -4,7 +4,7 @@
 // (mode 0: neighbours on different XCDs), XCD-contiguous (mode 2: 32 neighbouring tiles per XCD at a time) or as
 // one contiguous range per workgroup (mode 1).
 // Mode 3: ranges of R consecutive tiles, the ranges dealt like mode 2 (what a frame-ring pipeline would write).
-// align = 1: every row run is moved down to its 64-byte boundary (the "skewed" block stores such a pipeline
+// align = 1 (or 64) / 128: every row run is moved down to its 64- / 128-byte boundary (the "skewed" block stores such a pipeline
 // could issue: one whole 64-byte block per row and tile instead of a run straddling two).
 //   ./store_shape_probe <run frames: 16|32|64|128> <pitch floats> <mode 0|1|2|3> [shift floats] [align 0|1] [R]
 // Build: hipcc -O3 --offload-arch=gfx950 -o store_shape_probe store_shape_probe.hip
@@ -37,7 +37,7 @@ __global__ void __launch_bounds__(1024) k(float *out, long pitch_f, long total_t
     for (int i = 0; i < 64 / RPI; ++i) {   // 64 rows per wave
       const int row = 64 * wave + RPI * i + lane / LPR;
       float *p = base + row * pitch_f;
-      if (align) p = (float *)((unsigned long)p & ~63ul);
+      if (align) p = (float *)((unsigned long)p & ~(unsigned long)((align == 1 ? 64 : align) - 1));
       p += 4 * (lane % LPR);
       const float v = (float)(g + row);
       using f4 = __attribute__((ext_vector_type(4))) float;
