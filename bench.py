@@ -10,16 +10,19 @@ WORLD_SIZE / MASTER_* set, rendezvous on 127.0.0.1) BEFORE importing torch or th
 library -- the parent makes no GPU call -- forwards rank 0's JSON line and exits
 with the worst child status.  Under `torch.distributed.run` (RANK set) it is a rank.
 
-Workloads (BASELINE.json `configs`):
-  N = 1   C2: 256 clips x 10 s x 48 kHz resident on the GPU; a step = one
-          Stft.power_spectrum pass over the batch through the C ABI = ONE launch of
-          stft2048_power32_kernel (asserted through the library's launch counter).
-          `extra` carries C3 (fused mel, 128 mels), C4 (FIR 8192 taps, 8 x 60 s) and
-          the one-GPU point of C5, each timed with HIP events the same way.
-  N > 1   C5: 4096 clips x 30 s, contiguous clip ranges per rank
-          (soundml_amd.shard.clip_range; 512 clips per GPU at 8), no collective on the
-          data path: `scaling` = "strong".  `extra.c2_weak` is the weak-scaled C2 figure
-          (256 clips per GPU) of the same ranks.
+Workloads (BASELINE.json `configs`).  `value` is the SAME workload at every N, so that a scaling
+efficiency computed from the per-N lines compares like with like:
+  every N C2 per GPU: 256 clips x 10 s x 48 kHz resident on each GPU (`scaling` = "weak": rank r
+          owns clips [256 r, 256 r + 256) of a 256 N clip job; no collective on the data path);
+          a step = one Stft.power_spectrum pass over the rank's batch through the C ABI = ONE
+          launch of stft2048_power32_kernel (asserted through the library's launch counter).
+  N = 1   `extra` carries C3 (fused mel, 128 mels), C4 (FIR 8192 taps, 8 x 60 s), C1's geometry,
+          Stft.transform and the one-GPU point of C5, each timed with HIP events the same way.
+  N > 1   `extra.c5_strong` is BASELINE configs[4]: 4096 clips x 30 s sharded by contiguous clip
+          ranges (soundml_amd.shard.clip_range; 512 clips per GPU at 8), strong scaling; its
+          one-GPU point is `extra.c5_one_gpu` of the N = 1 line.  (--workload c5 makes it `value`.)
+The line also says what the ranks saw: `world_size_seen`, the backend, and the per-rank kernel
+time (min / max over ranks).
 The only communication is the timing barrier and the MAX-over-ranks reduction of
 the clock (RCCL when every rank has its own GPU; gloo when ranks share a device,
 which RCCL refuses -- the 2-rank test on a 1-GPU box).
@@ -56,7 +59,7 @@ def parse_args():
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--workload", choices=("auto", "c2", "c5"), default="auto",
-                    help="auto: C2 at one GPU, C5 sharded above (BASELINE configs[1] / configs[4])")
+                    help="auto = c2: BASELINE configs[1] per GPU at every N (weak); c5: configs[4] sharded (strong)")
     ap.add_argument("--clips", type=int, default=0,
                     help="override the clip count (C2: per GPU, default 256; C5: whole job, default 4096)")
     ap.add_argument("--seconds", type=float, default=0.0, help="override the clip length (C2: 10 s, C5: 30 s)")
@@ -159,6 +162,16 @@ def cpu_baseline(x_host, gpu_out_host):
             "gate": 1e-5}
 
 
+def workload_name(workload, clips_arg, seconds_arg, world):
+    """The name in config.workload.  For the default workload it does not depend on N: every line of a 1 / 2 / 4 / 8 GPU
+    series names the same per-GPU batch (tests/test_sharding_gloo.py asserts that)."""
+    if workload == "c2":
+        return "C2 per GPU: %d clips x %.0f s mono 48 kHz fp32" % (clips_arg or 256, seconds_arg or 10.0)
+    total = clips_arg or 4096
+    return "C5: %d clips x %.0f s mono 48 kHz fp32 sharded by contiguous clip ranges (%d per GPU)" % (
+        total, seconds_arg or 30.0, (total + world - 1) // world)
+
+
 def main():
     args = parse_args()
     if args.gpus > 1 and "RANK" not in os.environ:
@@ -177,9 +190,12 @@ def main():
         shard.barrier()
         t = shard.timed_region_max(1.0 + rank)
         lo, hi = shard.clip_range(args.clips or 4096, world, rank)
+        wl = args.workload if args.workload != "auto" else "c2"
         if rank == 0:
             print(json.dumps({"dry_run": True, "n_gpus": world, "max_clock": t, "rank0_clips": [lo, hi],
-                              "local_rank": local_rank, "master": os.environ.get("MASTER_ADDR")}), flush=True)
+                              "local_rank": local_rank, "master": os.environ.get("MASTER_ADDR"),
+                              "workload": workload_name(wl, args.clips, args.seconds, world), "scaling": "weak" if wl == "c2" else "strong",
+                              "world_size_seen": dist.get_world_size() if world > 1 else 1}), flush=True)
         if world > 1:
             dist.destroy_process_group()
         return
@@ -246,7 +262,7 @@ def main():
         return lambda: check(lib.smx_stft_power_range_f32_dev(cfg._h, vp(x.data_ptr()), clips, n, n, 0, frames, 2.0,
                                                               vp(out.data_ptr()), sptr))
 
-    workload = args.workload if args.workload != "auto" else ("c2" if world == 1 else "c5")
+    workload = args.workload if args.workload != "auto" else "c2"   # the same workload at every N (see the module docstring)
     line = {"metric": "STFT Mframes/sec (n_fft=2048 hop=512)", "unit": "Mframes/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "higher_is_better": True, "vs_baseline": None,
             "dtype": "f32", "data": "synthetic"}
@@ -259,15 +275,14 @@ def main():
         lo, hi = rank * clips, (rank + 1) * clips
         total_clips = clips * world
         scaling = "weak"
-        wname = "C2 per GPU: %d clips x %.0f s mono 48 kHz fp32" % (clips, n / SR)
+        wname = workload_name("c2", args.clips, args.seconds, world)
     else:
         total_clips = args.clips or 4096
         n = int(round((args.seconds or 30.0) * SR))
         lo, hi = S.shard.clip_range(total_clips, world, rank)
         clips = hi - lo
         scaling = "strong"
-        wname = "C5: %d clips x %.0f s mono 48 kHz fp32 sharded by contiguous clip ranges (%d per GPU)" % (
-            total_clips, n / SR, (total_clips + world - 1) // world)
+        wname = workload_name("c5", args.clips, args.seconds, world)
     frames = Stft.frames(cfg, n)
     x = make_clip_batch(lo, hi, n)
     out = torch.empty(clips, BINS, frames, device=dev, dtype=torch.float32)
@@ -279,6 +294,17 @@ def main():
         raise SystemExit("bench.py: a step of the hot path issued %.2f kernel launches, expected 1 -- the step events "
                          "are no longer one kernel's duration" % launches)
     avg_ms = sum(step_ms) / len(step_ms)
+
+    def over_ranks(v):
+        """(min, max) of a per-rank scalar"""
+        if world == 1:
+            return v, v
+        t = torch.tensor([v, -v], dtype=torch.float64, device=red_dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MIN)
+        return float(t[0].item()), -float(t[1].item())
+    rank_ms = over_ranks(avg_ms)
+    ranks_seen = {"world_size_seen": dist.get_world_size() if world > 1 else 1, "backend": backend,
+                  "rank_kernel_ms_avg_min": round(rank_ms[0], 4), "rank_kernel_ms_avg_max": round(rank_ms[1], 4)}
 
     shard_check = None
     if args.verify_shards:   # the reference's per-slice law (stft_grid.ml:180-205) across ranks, on the HIP path
@@ -322,6 +348,7 @@ def main():
                          "kernel_ms_min": round(step_ms[0], 4),
                          "algorithmic_bytes_per_frame": ALGO_BYTES_PER_FRAME},
         })
+        line.update(ranks_seen)
         if shard_check:
             line["shard_check"] = shard_check
 
@@ -426,19 +453,23 @@ def main():
                                                     "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                                     "frac": round(c5_clips * f5 * ALGO_BYTES_PER_FRAME / a / 1e6 / HBM_PEAK_GBS, 4)}}
                 del x5, o5
-        elif world > 1 and workload == "c5" and not args.clips:
-            # the weak-scaled C2 figure of the same ranks: 256 clips x 10 s per GPU
+        elif world > 1 and workload == "c2" and not args.clips:
+            # BASELINE configs[4], strong scaling: 4096 clips x 30 s sharded by contiguous clip ranges over the same ranks
             del x, out
-            n2 = 10 * SR
-            f2 = Stft.frames(cfg, n2)
-            x2 = make_clip_batch(100000 + 256 * rank, 100000 + 256 * (rank + 1), n2)
-            o2 = torch.empty(256, BINS, f2, device=dev, dtype=torch.float32)
-            el, ms, nl = timed(power_step(x2, o2, 256, n2, f2), k, w)
+            c5_clips, n5 = 4096, 30 * SR
+            f5 = Stft.frames(cfg, n5)
+            lo5, hi5 = S.shard.clip_range(c5_clips, world, rank)
+            x5 = make_clip_batch(lo5, hi5, n5)
+            o5 = torch.empty(hi5 - lo5, BINS, f5, device=dev, dtype=torch.float32)
+            el, ms, nl = timed(power_step(x5, o5, hi5 - lo5, n5, f5), k, w)
             a = sum(ms) / len(ms)
-            extra["c2_weak"] = {"workload": "C2 per GPU (256 clips x 10 s), weak scaling over the same ranks",
-                                "value": round(256 * f2 * world * k / el / 1e6, 1), "unit": "Mframes/s",
-                                "ms_per_step": round(el / k * 1e3, 4), "rank0_kernel_ms_avg": round(a, 4), "scaling": "weak"}
-            del x2, o2
+            r5 = over_ranks(a)
+            extra["c5_strong"] = {"workload": workload_name("c5", 0, 0.0, world),
+                                  "value": round(c5_clips * f5 * k / el / 1e6, 1), "unit": "Mframes/s", "scaling": "strong",
+                                  "ms_per_step": round(el / k * 1e3, 4), "launches_per_step": nl,
+                                  "rank_kernel_ms_avg_min": round(r5[0], 4), "rank_kernel_ms_avg_max": round(r5[1], 4),
+                                  "n1_point": "extra.c5_one_gpu of the N = 1 line"}
+            del x5, o5
 
     if rank == 0:
         if extra:

@@ -530,13 +530,17 @@ CAMLprim value soundml_amd_synthesis_numbers(value v_cfg, value v_s) {   /* (Con
  * out [channels; capacity]; returns how many per channel (0 = the reference's None).  The prepared channel count is the
  * extent both buffers are checked against (the library reads and writes exactly that many rows). */
 CAMLprim value soundml_amd_synthesis_step(value v_s, value v_z, value v_out, value v_channels, value v_bins, value v_k,
-                                          value v_capacity, value v_is_flush) {
+                                          value v_capacity, value v_is_flush, value v_wide) {
   CAMLparam5(v_s, v_z, v_out, v_channels, v_bins);
-  CAMLxparam3(v_k, v_capacity, v_is_flush);
+  CAMLxparam4(v_k, v_capacity, v_is_flush, v_wide);
   smx_stft_synthesis *s = Synthesis_val(v_s);
   const int64_t channels = Long_val(v_channels), bins = Long_val(v_bins), k = Long_val(v_k), capacity = Long_val(v_capacity);
-  const int is_flush = Bool_val(v_is_flush);
+  const int is_flush = Bool_val(v_is_flush), wide = Bool_val(v_wide);
   if (channels < 1 || bins < 0 || k < 0 || capacity < 0) caml_failwith("soundml_amd: invalid geometry");
+  /* the element sizes the kernel was prepared for (as soundml_amd_stft_invert checks them): a complex64 chunk given to a
+     float64 kernel would be read past its end, a complex128 one given to a float32 kernel reinterpreted */
+  if (!is_flush && ba_kind(v_z) != (wide ? CAML_BA_COMPLEX64 : CAML_BA_COMPLEX32)) caml_failwith("soundml_amd: unsupported or mixed dtypes");
+  if (ba_kind(v_out) != (wide ? CAML_BA_FLOAT64 : CAML_BA_FLOAT32)) caml_failwith("soundml_amd: unsupported or mixed dtypes");
   if (!is_flush && ba_dim(v_z) < channels * bins * k) caml_failwith("soundml_amd: buffer extents disagree with geometry");
   if (ba_dim(v_out) < channels * capacity) caml_failwith("soundml_amd: output extents disagree with geometry");
   void *z = is_flush ? NULL : Caml_ba_data_val(v_z);
@@ -552,7 +556,7 @@ CAMLprim value soundml_amd_synthesis_step(value v_s, value v_z, value v_out, val
 }
 CAMLprim value soundml_amd_synthesis_step_bc(value *argv, int argn) {
   (void)argn;
-  return soundml_amd_synthesis_step(argv[0], argv[1], argv[2], argv[3], argv[4], argv[5], argv[6], argv[7]);
+  return soundml_amd_synthesis_step(argv[0], argv[1], argv[2], argv[3], argv[4], argv[5], argv[6], argv[7], argv[8]);
 }
 
 CAMLprim value soundml_amd_synthesis_reset(value v_s) {

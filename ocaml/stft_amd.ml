@@ -321,7 +321,7 @@ external synthesis_prepare_c : stft_handle -> bool -> int -> int -> synthesis_ha
 external synthesis_numbers_c : stft_handle -> synthesis_handle -> int * int = "soundml_amd_synthesis_numbers"
 
 external synthesis_step_c :
-  synthesis_handle -> ('a, 'b) flat -> ('c, 'd) flat -> int -> int -> int -> int -> bool -> int
+  synthesis_handle -> ('a, 'b) flat -> ('c, 'd) flat -> int -> int -> int -> int -> bool -> bool -> int
   = "soundml_amd_synthesis_step_bc" "soundml_amd_synthesis_step"
 
 external synthesis_reset_c : synthesis_handle -> unit = "soundml_amd_synthesis_reset"
@@ -330,32 +330,46 @@ module Synthesis = struct
   type ('a, 'c) t =
     { s: synthesis_handle
     ; sdtype: (float, 'a) Nx.dtype
+    ; cdtype: (Complex.t, 'c) Nx.dtype
+    ; wide: bool  (* the kernel computes in float64 / complex128 (float64 audio) or float32 / complex64 *)
     ; channels: int
     ; bins: int
     ; hop: int
     ; capacity: int  (* what one step of [max_block] frames or the drain can release, plus a hop *) }
 
-  let prepare dtype cfg (_cdtype : (Complex.t, 'c) Nx.dtype) ~channels ~max_block =
+  let prepare dtype cfg (cdtype : (Complex.t, 'c) Nx.dtype) ~channels ~max_block =
     (* the reference's checks and messages (channels, max_block, check_invertible "prepare") are smx_stft_synthesis_prepare's *)
     let wide = Nx.dtype_equal dtype Nx.float64 in
     let s = synthesis_prepare_c (handle_of_config cfg) wide channels max_block in
     let _, bound = synthesis_numbers_c (handle_of_config cfg) s in
-    {s; sdtype= dtype; channels; bins= Stft.Config.bins cfg; hop= Stft.Config.hop cfg; capacity= bound + Stft.Config.hop cfg}
+    {s; sdtype= dtype; cdtype; wide; channels; bins= Stft.Config.bins cfg; hop= Stft.Config.hop cfg; capacity= bound + Stft.Config.hop cfg}
 
   let emit t ~emitted out =
     if emitted = 0 then None else Some (Nx.shrink [|(0, t.channels); (0, emitted)|] out)
 
+  (* The reference types the audio ('a) and the frames ('c) independently and converts z itself (to_complex128,
+     stft.ml:1180-1200): here z is cast to the complex type the kernel was prepared for -- complex64 beside float32 audio,
+     complex128 beside float64 -- so that the library never reads a buffer of another element size, and the chunk's leading
+     axes must hold exactly the prepared channels (the library reads channels x bins rows of k frames). *)
   let step t z =
-    let k = (Nx.shape z).(Nx.ndim z - 1) and bins = (Nx.shape z).(Nx.ndim z - 2) in
+    let nd = Nx.ndim z in
+    if nd < 2 then invalid_arg "step: cannot invert a tensor without bin and frame axes" ;
+    let k = (Nx.shape z).(nd - 1) and bins = (Nx.shape z).(nd - 2) in
+    let lead = Array.fold_left ( * ) 1 (Array.sub (Nx.shape z) 0 (nd - 2)) in
+    if lead <> t.channels then
+      invalid_arg "step: cannot feed a chunk whose leading axes disagree with the kernel's channels" ;
     let capacity = Stdlib.max t.capacity ((k * t.hop) + t.hop) in
     let out = Nx.empty t.sdtype [|t.channels; capacity|] in
-    let emitted = synthesis_step_c t.s (flat z) (flat_out out) t.channels bins k capacity false in
+    let emitted =
+      if t.wide then synthesis_step_c t.s (flat (Nx.cast Nx.complex128 z)) (flat_out out) t.channels bins k capacity false true
+      else synthesis_step_c t.s (flat (Nx.cast Nx.complex64 z)) (flat_out out) t.channels bins k capacity false false
+    in
     emit t ~emitted out
 
   let flush t =
     let out = Nx.empty t.sdtype [|t.channels; t.capacity|] in
     let none = Bigarray.Array1.sub (flat_out out) 0 0 in
-    let emitted = synthesis_step_c t.s none (flat_out out) t.channels t.bins 0 t.capacity true in
+    let emitted = synthesis_step_c t.s none (flat_out out) t.channels t.bins 0 t.capacity true t.wide in
     emit t ~emitted out
 
   let reset t = synthesis_reset_c t.s

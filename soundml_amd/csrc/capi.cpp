@@ -489,6 +489,7 @@ struct smx_stft_synthesis {
   void *d_carry = nullptr;             // [channels; hold] real (valid when carry_len == hold)
   void *d_stage = nullptr;             // host-pointer steps: the chunk and the released samples
   int64_t cap = 0, carry_len = 0, stage_bytes = 0;
+  hipStream_t last_stream = nullptr;   // the stream of the latest step / flush: reset orders its memset behind it
   int64_t elem() const { return z_bytes / 2; }
   ~smx_stft_synthesis() {
     (void)hipFree(d_hist); (void)hipFree(d_local); (void)hipFree(d_quot); (void)hipFree(d_carry); (void)hipFree(d_stage);
@@ -542,7 +543,9 @@ int64_t frame_bound(const smx_stft_config &c, int64_t max_block) {  // stft.ml:1
   return (max_block + lat + c.hop - 1) / c.hop + 1;
 }
 
-void ensure_stream(smx_stft_kernel &k, int64_t need) {
+// (the copy into the grown buffer runs on the caller's stream, behind the previous step's asynchronous move of the pending
+// suffix; the old buffer is released only once that copy has run)
+void ensure_stream(smx_stft_kernel &k, int64_t need, hipStream_t stream) {
   if (need <= k.cap) return;
   int64_t cap = k.cap ? k.cap : 1024;
   while (cap < need) cap *= 2;
@@ -550,8 +553,9 @@ void ensure_stream(smx_stft_kernel &k, int64_t need) {
   const size_t es = (size_t)k.dtype_bytes;
   SMX_HIP_CHECK(hipMalloc(&fresh, (size_t)k.channels * (size_t)cap * es));
   if (k.d_stream && k.pending_len > 0)
-    SMX_HIP_CHECK(hipMemcpy2D(fresh, (size_t)cap * es, k.d_stream, (size_t)k.cap * es,
-                              (size_t)k.pending_len * es, (size_t)k.channels, hipMemcpyDeviceToDevice));
+    SMX_HIP_CHECK(hipMemcpy2DAsync(fresh, (size_t)cap * es, k.d_stream, (size_t)k.cap * es,
+                                   (size_t)k.pending_len * es, (size_t)k.channels, hipMemcpyDeviceToDevice, stream));
+  SMX_HIP_CHECK(hipStreamSynchronize(stream));
   (void)hipFree(k.d_stream);
   k.d_stream = fresh;
   k.cap = cap;
@@ -629,7 +633,7 @@ int64_t process(smx_stft_kernel &k, const void *extra, int64_t extra_stride, int
   const int64_t fft = c.fft_size, hop = c.hop;
   const size_t es = (size_t)k.dtype_bytes;
   const int64_t total = k.pending_len + extra_len;
-  ensure_stream(k, total);
+  ensure_stream(k, total, stream);
   rows_copy(k.d_stream, k.cap, k.pending_len, extra, extra_stride, extra_off, extra_len, k.channels, es, stream);
   const int64_t count = total < fft ? 0 : 1 + (total - fft) / hop;
   if (count == 0) {
@@ -1017,12 +1021,13 @@ int64_t synth_emit(smx_stft_synthesis &s, int64_t frames_local, int64_t nq, int6
   job.env_q0 = (s.fed - (s.blocks - 1)) * c.hop;
   job.env_count = env_count;
   job.env_open = open_end;
-  launch_istft(job);
   const int64_t total = s.carry_len + nq, release = total - keep;
   const int64_t dropped = std::min<int64_t>(s.drop, release);
-  s.drop -= dropped;
   const int64_t emit = release - dropped;
+  // checked before anything is launched or the head trim is consumed: a retry with a larger buffer starts from the same state
   if (emit > capacity) throw Failure("synthesis: output capacity below the samples this call releases");
+  launch_istft(job);
+  s.drop -= dropped;
   void *carry_next = nullptr;
   if (keep > 0) SMX_HIP_CHECK(smx::pool_malloc_async(&carry_next, (size_t)s.channels * (size_t)s.hold * (size_t)s.elem(), stream));
   launch_synthesis_release(s.d_carry, s.carry_len, s.d_quot, nq, s.channels, dropped, release, s.hold > 0 ? s.hold : 1, d_out, capacity,
@@ -1129,7 +1134,10 @@ int smx_stft_synthesis_sample_bound(const smx_stft_synthesis *s, int64_t *out) {
 int smx_stft_synthesis_reset(smx_stft_synthesis *s) {
   return guarded([&] {
     if (!s) throw Failure("reset: null kernel");
-    synth_clear(*s, nullptr);
+    // on the stream the kernel last ran on (a non-blocking side stream is not ordered with the null stream), then drained:
+    // the next step may come on any stream
+    synth_clear(*s, s->last_stream);
+    SMX_HIP_CHECK(hipStreamSynchronize(s->last_stream));
   });
 }
 
@@ -1138,6 +1146,7 @@ int smx_stft_synthesis_step_dev(smx_stft_synthesis *s, const void *d_z, int64_t 
   return guarded([&] {
     if (!s || !emitted) throw Failure("step: null argument");
     *emitted = 0;
+    s->last_stream = (hipStream_t)stream;
     *emitted = synth_step_dev(*s, d_z, bins, k, d_out, capacity, (hipStream_t)stream);
   });
 }
@@ -1146,6 +1155,7 @@ int smx_stft_synthesis_flush_dev(smx_stft_synthesis *s, void *d_out, int64_t cap
   return guarded([&] {
     if (!s || !emitted) throw Failure("flush: null argument");
     *emitted = 0;
+    s->last_stream = (hipStream_t)stream;
     *emitted = synth_flush_dev(*s, d_out, capacity, (hipStream_t)stream);
   });
 }

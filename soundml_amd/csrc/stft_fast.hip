@@ -163,7 +163,7 @@ struct FastArgs {
 // pw = m 2^e with m in [0.5, 1): h e is split into its rounded value and the exact residual (one fma), the integer part goes
 // to v_ldexp and only a fraction of a few units reaches v_exp_f32, so the result is good to 2-3 ulp over the whole range
 // (the library powf: 190 instructions and 13 selects per value, 2.6x the kernel's time).  pw = 0, inf and p = 0 come out as
-// powf gives them (0 or inf by the sign of p; 1): the logarithm is clamped to +-FLT_MAX, so that 0 x it is 0, not NaN.
+// powf gives them (0 or inf by the sign of p; 1): the logarithm is clamped to +-FLT_MAX, so that 0 x it is 0, not NaN; a NaN stays one.
 // -1 (the 64-lane power kernels kept for A/B timing): the run-time choice of rounds 1-2, both forms evaluated and selected.
 template <int PMODE>
 __device__ __forceinline__ float power_from_square(float pw, const FastArgs &a) {
@@ -178,7 +178,10 @@ __device__ __forceinline__ float power_from_square(float pw, const FastArgs &a) 
     const float tlo = __builtin_fmaf(h, ef, -thi);
     const float n = __builtin_rintf(thi);
     const float fr = (thi - n) + __builtin_fmaf(h, lm, tlo);
-    return __builtin_ldexpf(__builtin_amdgcn_exp2f(fr), (int)n);
+    const float r = __builtin_ldexpf(__builtin_amdgcn_exp2f(fr), (int)n);
+    // v_med3_f32 returns min3 when an operand is NaN and min3 drops the NaN: the clamp above turns log(NaN) into -FLT_MAX.
+    // A NaN power stays a NaN (as powf and the reference give it): an unordered compare, one select on an SGPR-pair mask.
+    return pw != pw ? pw : r;
   } else return a.pmode == 1 ? sqrtf(pw) : __powf(pw, a.half_power);
 }
 
@@ -1817,22 +1820,6 @@ void launch_interior(const StftJob &job, const FastTarget &tg, const float *x, i
       };
       return aligned ? by_power(std::true_type{}) : by_power(std::false_type{});
     };
-    // (the form with the output path on four waves of its own: SMX_POWER_P32H=1, A/B timing only)
-    if (env_flag("SMX_POWER_P32H") == 1) {
-      auto pick32h = [&](auto strip_tag) {
-        constexpr bool S = decltype(strip_tag)::value;
-        auto by_power = [&](auto al) {
-          constexpr bool A = decltype(al)::value;
-          return a.pmode == 2 ? stft2048_power32h_kernel<A, 2, S> : a.pmode == 1 ? stft2048_power32h_kernel<A, 1, S> : stft2048_power32h_kernel<A, 0, S>;
-        };
-        return aligned ? by_power(std::true_type{}) : by_power(std::false_type{});
-      };
-      auto k32h = strip ? pick32h(std::true_type{}) : pick32h(std::false_type{});
-      SMX_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k32h), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kFast32Lds));
-      SMX_LAUNCH(k32h, dim3((unsigned)a.blocks), dim3(768), kFast32Lds, job.stream, a);
-      SMX_HIP_CHECK(hipGetLastError());
-      return;
-    }
     // The flush in whole aligned 64-byte blocks (stft_fast_p32.hpp, SKEW): needs even block offsets in every row -- an even row
     // pitch and an origin on an 8-byte boundary -- and consecutive tiles of a clip on one workgroup (contiguous ranges).
     const bool skew = !strip && a.out_stride % 2 == 0 && ((reinterpret_cast<uintptr_t>(a.out) >> 2) + (uintptr_t)a.out_offset) % 2 == 0 &&

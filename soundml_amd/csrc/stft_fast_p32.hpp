@@ -37,7 +37,7 @@ constexpr int kRowPitch32 = 32 * kTileStride;      // floats between rows r and 
 struct Lds32 {
   float *tiles;
   // tables, read two complex values (16 bytes) per lane and instruction:
-  //   win4[m][l] = window pairs of points l + 32 (2m), l + 32 (2m + 1)                     m < 16
+  //   win4[m][l] = window pairs of points l + 32 j, l + 32 (j + 2); j = 4 m (rows 0..7, the even points), j = 4 (m - 8) + 1 (rows 8..15)
   //   twA4[m][l] = W_M^(l k1) for k1 = 2m + 1, 2m + 2 (m < 15), then one row of k1 = 31    (15 x 32 float4 + 32 float2)
   //   twP4[m][l] = exp(-2 pi i k / N) for k = l + 32 (2m), l + 32 (2m + 1)                 m < 8
   float4 *win4, *twA4, *twP4;
@@ -56,31 +56,41 @@ __device__ __forceinline__ Lds32 carve_lds32(unsigned char *smem) {
   return l;
 }
 
-// per-lane constants: offsets (floats) into a tile buffer
+// Per-lane constants.  Only the lane's indices are kept in registers; the offsets into a tile buffer and the table addresses
+// are re-derived where they are used (a few integer instructions per tile): ten loop-invariant address registers beside the
+// frame's 64, the samples' 64 and the carried output pairs spill, and every scratch reload waits for ALL of the wave's
+// outstanding memory operations.
 struct Lane32 {
-  int l, h;
-  int own;        // cell l of the frame's column: transposition / exchange writes (cell l + 33 j), results of bins l + 32 s
-  int rd;         // cell 33 l: transposition reads (cell i + 33 l)
-  int xr;         // exchange reads: cell p + 33 (15 - s) of slot s, p = 32 - l (l = 0: 33, i.e. its own register 32 - s)
-  int rm;         // results of bins M - k: row (32 - l) + 32 (31 - s)  (l = 0: 32 (32 - s); s = 0 is row 1024 = Nyquist)
-  int self;       // lane 0: row 512 (bin M/2); other lanes: a cell they overwrite afterwards
-  const float4 *win_l, *twA_l, *twP_l;
-  const float2 *twA31_l;
+  int l, h, col;
+  const float4 *win0, *twA0, *twP0;   // the tables (wave-uniform)
+  const float2 *twA310;
+  // offsets (floats) into a tile buffer:
+  __device__ __forceinline__ int li() const { int v = l; asm volatile("" : "+v"(v)); return v; }
+  __device__ __forceinline__ int own() const { return li() * kTileStride + col; }                 // cell l of the frame's column: transposition / exchange writes (cell l + 33 j), results of bins l + 32 s
+  __device__ __forceinline__ int rd() const { return 33 * kTileStride * li() + col; }             // cell 33 l: transposition reads (cell i + 33 l)
+  __device__ __forceinline__ int xr() const {                                                     // exchange reads: cell p + 33 (15 - s) of slot s, p = 32 - l (l = 0: 33, i.e. its own register 32 - s)
+    const int v = li();
+    return (33 - v - (v < 1 ? v : 1)) * kTileStride + col;
+  }
+  __device__ __forceinline__ int rm() const { return (32 + 32 * 16 - li()) * kTileStride + col; }   // results of bins M - k: row (32 - l) + 32 (31 - s)  (l = 0: 32 (32 - s); s = 0 is row 1024 = Nyquist)
+  __device__ __forceinline__ int self() const {                                                   // lane 0: row 512 (bin M/2); other lanes: a cell they overwrite afterwards
+    const int v = li();
+    return (v + 512 * (1 - (v < 1 ? v : 1))) * kTileStride + col;
+  }
+  __device__ __forceinline__ const float4 *win_l() const { return win0 + li(); }
+  __device__ __forceinline__ const float4 *twA_l() const { return twA0 + li(); }
+  __device__ __forceinline__ const float4 *twP_l() const { return twP0 + li(); }
+  __device__ __forceinline__ const float2 *twA31_l() const { return twA310 + li(); }
 };
 __device__ __forceinline__ Lane32 setup_lane32(const Lds32 &lds, int lane, int wave) {
   Lane32 L;
   L.l = lane & 31;
   L.h = lane >> 5;
-  const int col = 2 * wave + L.h;
-  L.own = L.l * kTileStride + col;
-  L.rd = 33 * L.l * kTileStride + col;
-  L.xr = (L.l == 0 ? 33 : 32 - L.l) * kTileStride + col;
-  L.rm = ((L.l == 0 ? 32 : 32 - L.l) + 32 * 16) * kTileStride + col;
-  L.self = (L.l == 0 ? 512 : L.l) * kTileStride + col;
-  L.win_l = lds.win4 + L.l;
-  L.twA_l = lds.twA4 + L.l;
-  L.twA31_l = lds.twA31 + L.l;
-  L.twP_l = lds.twP4 + L.l;
+  L.col = 2 * wave + L.h;
+  L.win0 = lds.win4;
+  L.twA0 = lds.twA4;
+  L.twA310 = lds.twA31;
+  L.twP0 = lds.twP4;
   return L;
 }
 
@@ -114,9 +124,9 @@ __device__ __forceinline__ void lds_wait32(unsigned *c, unsigned target, unsigne
 // fills the workgroup's tables (any number of threads); the caller synchronises before they are read
 __device__ __forceinline__ void fill_tables32(const FastArgs &a, const Lds32 &lds, int tid, int nthreads) {
   const float2 *hw = reinterpret_cast<const float2 *>(a.hwin);
-  for (int e = tid; e < 16 * 32; e += nthreads) {
-    const int m = e >> 5, l = e & 31;
-    const float2 w0 = hw[l + 32 * (2 * m)], w1 = hw[l + 32 * (2 * m + 1)];
+  for (int e = tid; e < 16 * 32; e += nthreads) {   // rows 0..7: the even points j = 4 m, 4 m + 2; rows 8..15: the odd points j = 4 m + 1, 4 m + 3
+    const int row = e >> 5, l = e & 31, j0 = 4 * (row & 7) + (row >> 3);
+    const float2 w0 = hw[l + 32 * j0], w1 = hw[l + 32 * (j0 + 2)];
     lds.win4[e] = make_float4(w0.x, w0.y, w1.x, w1.y);
   }
   for (int e = tid; e < 15 * 32; e += nthreads) {
@@ -277,16 +287,12 @@ struct NoMid32 {
 #ifndef SMX_P32_LOADS_FIRST
 #define SMX_P32_LOADS_FIRST 0
 #endif
-#ifndef SMX_P32_TWI
-#define SMX_P32_TWI 1      // 1: the transposition's first plane is written while the twiddle products are formed (shorter LDS bursts)
-#endif
-#ifndef SMX_P32_PK
-#define SMX_P32_PK 1       // 1: the frame's arithmetic on packed pairs (the same operations, the same bits, half the issue slots)
-#endif
 #ifndef SMX_P32_WAIT0
-#define SMX_P32_WAIT0 0
+#define SMX_P32_WAIT0 1
 #endif
-#if SMX_P32_PK
+// The window rows of the odd points and the twiddles are requested before the first 16-point transform (which needs the even
+// points only) and arrive under it.  (Requesting the even rows a frame pair ahead as well -- 32 registers across the loop
+// edge -- changed nothing in the power kernel and cost the fused mel kernel 40 %: profiles/r06/ab_mel_winpre2.log.)
 template <int PMODE, class Mid, bool CPLX = false>
 __device__ __forceinline__ void frame32_to_tile(const FastArgs &a, const Lane32 &L, float2 (&raw)[32], float *tile,
                                                 const Mid &mid) {
@@ -296,34 +302,47 @@ __device__ __forceinline__ void frame32_to_tile(const FastArgs &a, const Lane32 
   // the samples were requested most of a tile ago: one wait for all of them instead of one per product (a wait is an issue slot)
   __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0)
 #endif
+  f2 e[16], o[16];
+  float4 winE[8];
 #pragma unroll
-  for (int m0 = 0; m0 < 16; m0 += 8) {   // two batches: the window rows are not all in registers at once
-    float4 win[8];
+  for (int m = 0; m < 8; ++m) winE[m] = L.win_l()[32 * m];
 #pragma unroll
-    for (int m = 0; m < 8; ++m) win[m] = L.win_l[32 * (m0 + m)];
-#pragma unroll
-    for (int m = 0; m < 8; ++m) {
-      v[2 * (m0 + m)] = f2{raw[2 * (m0 + m)].x, raw[2 * (m0 + m)].y} * f2{win[m].x, win[m].y};
-      v[2 * (m0 + m) + 1] = f2{raw[2 * (m0 + m) + 1].x, raw[2 * (m0 + m) + 1].y} * f2{win[m].z, win[m].w};
-    }
-    SMX_FENCE();
+  for (int m = 0; m < 8; ++m) {   // even points j = 4 m, 4 m + 2 -> e[2 m], e[2 m + 1]
+    e[2 * m] = f2{raw[4 * m].x, raw[4 * m].y} * f2{winE[m].x, winE[m].y};
+    e[2 * m + 1] = f2{raw[4 * m + 2].x, raw[4 * m + 2].y} * f2{winE[m].z, winE[m].w};
   }
+  SMX_FENCE();
+  float4 winO[8];
+#pragma unroll
+  for (int m = 0; m < 8; ++m) winO[m] = L.win_l()[32 * (8 + m)];
   mid.template stamp<1>();
   SMX_FENCE();
-  // A: radix-32 over j, then twiddle W_M^(l k1)
+  // A: radix-32 over j, then twiddle W_M^(l k1) (requested only after the first transform -- 650 cycles of a wave's own issue
+  // before they are used -- the second half of the rows cost the fused mel kernel 8 %)
   {
     float4 tw[15];
 #pragma unroll
-    for (int m = 0; m < 15; ++m) tw[m] = L.twA_l[32 * m];
-    const float2 tw31 = L.twA31_l[0];
-    pk_fft32(v, [&] { SMX_FENCE(); mid.early(); SMX_FENCE(); });
+    for (int m = 0; m < 15; ++m) tw[m] = L.twA_l()[32 * m];
+    const float2 tw31 = L.twA31_l()[0];
+    SMX_FENCE();
+    pk_fft16(e);
+    SMX_FENCE(); mid.early(); SMX_FENCE();
+#pragma unroll
+    for (int m = 0; m < 8; ++m) {   // odd points j = 4 m + 1, 4 m + 3 -> o[2 m], o[2 m + 1]
+      o[2 * m] = f2{raw[4 * m + 1].x, raw[4 * m + 1].y} * f2{winO[m].x, winO[m].y};
+      o[2 * m + 1] = f2{raw[4 * m + 3].x, raw[4 * m + 3].y} * f2{winO[m].z, winO[m].w};
+    }
+    SMX_FENCE();
+    pk_fft16(o);
+    pk_fft32_combine0(v, e, o);
+    pk_fft32_combine1(v, e, o);
     SMX_FENCE();
     // X: lane l register k1 -> lane k1 register l through the frame's column, real parts then imaginary parts.
     // One wave's LDS operations execute in order, so no wait separates the rounds.
     mid.template stamp<2>();
     mid.before_cells();
     mid.template stamp<3>();
-    float *const wr = tile + opaque32(L.own);
+    float *const wr = tile + L.own();
     float *const wr_hi = wr + 16 * kCellPitch32;
     // the first plane is written while the twiddle products are formed (shorter LDS bursts)
     auto put = [&](int j) { (j < 16 ? wr : wr_hi)[kCellPitch32 * (j & 15)] = v[j].x; };
@@ -347,9 +366,9 @@ __device__ __forceinline__ void frame32_to_tile(const FastArgs &a, const Lane32 
 #undef SMX_TWV
   }
   SMX_FENCE();
-  float *const wr = tile + opaque32(L.own);
+  float *const wr = tile + L.own();
   float *const wr_hi = wr + 16 * kCellPitch32;   // (ds offsets are 16 bits: 31 x 2244 bytes does not fit)
-  const float *const rd = tile + opaque32(L.rd);
+  const float *const rd = tile + L.rd();
 #pragma unroll
   for (int i = 0; i < 32; ++i) t[i].x = rd[kTileStride * i];
 #pragma unroll
@@ -367,7 +386,7 @@ __device__ __forceinline__ void frame32_to_tile(const FastArgs &a, const Lane32 
   // P: partners through the cells.  Every lane parks registers 16..31 (cell l + 33 (q - 16)) and reads, for slot s,
   // register 31 - s of lane 32 - l (lanes 0 and 16: their own; lane 0: register 32 - s, and itself for s = 0).
   f2 pp[16];
-  const float *const xr = tile + opaque32(L.xr);
+  const float *const xr = tile + L.xr();
   // (register 0 goes to cell l + 33 x 16 as well: that is where lane 0 looks for the partner of bin 0 -- itself; slot 0
   // of that lane yields X[0] and the Nyquist bin.  A select instead would be two v_cndmask_b32 on vcc, 19 cycles each.)
 #pragma unroll
@@ -382,7 +401,7 @@ __device__ __forceinline__ void frame32_to_tile(const FastArgs &a, const Lane32 
   for (int s = 0; s < 16; ++s) pp[s].y = xr[kCellPitch32 * (15 - s)];
   float4 tw[8];
 #pragma unroll
-  for (int m = 0; m < 8; ++m) tw[m] = L.twP_l[32 * m];
+  for (int m = 0; m < 8; ++m) tw[m] = L.twP_l()[32 * m];
   SMX_FENCE();
   mid.after_exchange_issue();
   mid.template stamp<6>();
@@ -391,14 +410,14 @@ __device__ __forceinline__ void frame32_to_tile(const FastArgs &a, const Lane32 
   {   // bin M/2 (lane 0, register 16): X = 2 conj(Z)
     const f2 z = t[16] + t[16];
     if constexpr (CPLX) {
-      tile[opaque32(L.self)] = z.x;
-      tile[kTile32Floats + opaque32(L.self)] = -z.y;
+      tile[L.self()] = z.x;
+      tile[kTile32Floats + L.self()] = -z.y;
     } else {
-      tile[opaque32(L.self)] = power_from_square<PMODE>(__builtin_fmaf(z.x, z.x, z.y * z.y), a);
+      tile[L.self()] = power_from_square<PMODE>(__builtin_fmaf(z.x, z.x, z.y * z.y), a);
     }
   }
   float *const rk = wr;                 // row l + 32 s
-  float *const rm = tile + opaque32(L.rm);        // row (32 - l) + 32 (31 - s) = rm base + 32 (15 - s)
+  float *const rm = tile + L.rm();        // row (32 - l) + 32 (31 - s) = rm base + 32 (15 - s)
   // slot s: E = Z[k] + conj Z[M-k], D = Z[k] - conj Z[M-k], T = -i w D, X[k] = E + T, X[M-k] = conj(E - T); the generated
   // blocks return them as planes (re_k, re_(M-k)), (im_k, im_(M-k)) or as (|X_k|^2, |X_(M-k)|^2) = fma(re, re, im im) per half
   auto wtw = [&](int s) { return (s & 1) ? f2{tw[s >> 1].z, tw[s >> 1].w} : f2{tw[s >> 1].x, tw[s >> 1].y}; };
@@ -437,145 +456,6 @@ __device__ __forceinline__ void frame32_to_tile(const FastArgs &a, const Lane32 
 #undef SMX_PA
   mid.template stamp<7>();
 }
-#else
-template <int PMODE, class Mid, bool CPLX = false>
-__device__ __forceinline__ void frame32_to_tile(const FastArgs &a, const Lane32 &L, float2 (&raw)[32], float *tile,
-                                                const Mid &mid) {
-#pragma clang fp contract(off)
-  c32 v[32], t[32];
-#pragma unroll
-  for (int m0 = 0; m0 < 16; m0 += 8) {   // two batches: the window rows are not all in registers at once
-    float4 win[8];
-#pragma unroll
-    for (int m = 0; m < 8; ++m) win[m] = L.win_l[32 * (m0 + m)];
-#pragma unroll
-    for (int m = 0; m < 8; ++m) {
-      v[2 * (m0 + m)] = {raw[2 * (m0 + m)].x * win[m].x, raw[2 * (m0 + m)].y * win[m].y};
-      v[2 * (m0 + m) + 1] = {raw[2 * (m0 + m) + 1].x * win[m].z, raw[2 * (m0 + m) + 1].y * win[m].w};
-    }
-    SMX_FENCE();
-  }
-  mid.template stamp<1>();
-  SMX_FENCE();
-  // A: radix-32 over j, then twiddle W_M^(l k1)
-  {
-    float4 tw[15];
-#pragma unroll
-    for (int m = 0; m < 15; ++m) tw[m] = L.twA_l[32 * m];
-    const float2 tw31 = L.twA31_l[0];
-    fft32(v, [&] { SMX_FENCE(); mid.early(); SMX_FENCE(); });
-    if constexpr (!SMX_P32_TWI) {
-#pragma unroll
-      for (int m = 0; m < 15; ++m) {
-        v[2 * m + 1] = p32_cmul(v[2 * m + 1], tw[m].x, tw[m].y);
-        v[2 * m + 2] = p32_cmul(v[2 * m + 2], tw[m].z, tw[m].w);
-      }
-      v[31] = p32_cmul(v[31], tw31.x, tw31.y);
-    }
-    SMX_FENCE();
-    // X: lane l register k1 -> lane k1 register l through the frame's column, real parts then imaginary parts.
-    // One wave's LDS operations execute in order, so no wait separates the rounds.
-    mid.template stamp<2>();
-    mid.before_cells();
-    mid.template stamp<3>();
-    if constexpr (SMX_P32_TWI) {
-      float *const wr = tile + opaque32(L.own);
-      float *const wr_hi = wr + 16 * kCellPitch32;
-      wr[0] = v[0].x;
-#pragma unroll
-      for (int m = 0; m < 15; ++m) {
-        v[2 * m + 1] = p32_cmul(v[2 * m + 1], tw[m].x, tw[m].y);
-        v[2 * m + 2] = p32_cmul(v[2 * m + 2], tw[m].z, tw[m].w);
-        (2 * m + 1 < 16 ? wr : wr_hi)[kCellPitch32 * ((2 * m + 1) & 15)] = v[2 * m + 1].x;
-        (2 * m + 2 < 16 ? wr : wr_hi)[kCellPitch32 * ((2 * m + 2) & 15)] = v[2 * m + 2].x;
-        if ((m & 1) == 1) SMX_FENCE();
-      }
-      v[31] = p32_cmul(v[31], tw31.x, tw31.y);
-      wr_hi[kCellPitch32 * 15] = v[31].x;
-    }
-  }
-  SMX_FENCE();
-  float *const wr = tile + opaque32(L.own);
-  float *const wr_hi = wr + 16 * kCellPitch32;   // (ds offsets are 16 bits: 31 x 2244 bytes does not fit)
-  const float *const rd = tile + opaque32(L.rd);
-  if constexpr (!SMX_P32_TWI) {
-#pragma unroll
-    for (int j = 0; j < 32; ++j) (j < 16 ? wr : wr_hi)[kCellPitch32 * (j & 15)] = v[j].x;
-  }
-#pragma unroll
-  for (int i = 0; i < 32; ++i) t[i].x = rd[kTileStride * i];
-#pragma unroll
-  for (int j = 0; j < 32; ++j) (j < 16 ? wr : wr_hi)[kCellPitch32 * (j & 15)] = v[j].y;
-#pragma unroll
-  for (int i = 0; i < 32; ++i) t[i].y = rd[kTileStride * i];
-  SMX_FENCE();
-  mid.after_transposition_issue();
-  mid.template stamp<4>();
-  SMX_FENCE();
-  // B: radix-32 over l
-  fft32(t);
-  SMX_FENCE();
-  mid.template stamp<5>();
-  // P: partners through the cells.  Every lane parks registers 16..31 (cell l + 33 (q - 16)) and reads, for slot s,
-  // register 31 - s of lane 32 - l (lanes 0 and 16: their own; lane 0: register 32 - s, and itself for s = 0).
-  float px[16], py[16];
-  const float *const xr = tile + opaque32(L.xr);
-  // (register 0 goes to cell l + 33 x 16 as well: that is where lane 0 looks for the partner of bin 0 -- itself; slot 0
-  // of that lane yields X[0] and the Nyquist bin.  A select instead would be two v_cndmask_b32 on vcc, 19 cycles each.)
-#pragma unroll
-  for (int q = 16; q < 32; ++q) wr[kCellPitch32 * (q - 16)] = t[q].x;
-  wr_hi[0] = t[0].x;
-#pragma unroll
-  for (int s = 0; s < 16; ++s) px[s] = xr[kCellPitch32 * (15 - s)];
-#pragma unroll
-  for (int q = 16; q < 32; ++q) wr[kCellPitch32 * (q - 16)] = t[q].y;
-  wr_hi[0] = t[0].y;
-#pragma unroll
-  for (int s = 0; s < 16; ++s) py[s] = xr[kCellPitch32 * (15 - s)];
-  float4 tw[8];
-#pragma unroll
-  for (int m = 0; m < 8; ++m) tw[m] = L.twP_l[32 * m];
-  SMX_FENCE();
-  mid.after_exchange_issue();
-  mid.template stamp<6>();
-  SMX_FENCE();
-  auto power_of = [&](float re, float im) {
-    return power_from_square<PMODE>(__builtin_fmaf(re, re, im * im), a);
-  };
-  // CPLX: the spectrum itself, real parts in `tile`, imaginary parts in the plane after it (the other tile buffer)
-  {   // bin M/2 (lane 0, register 16): X = 2 conj(Z)
-    const float zx = t[16].x + t[16].x, zy = t[16].y + t[16].y;
-    if constexpr (CPLX) {
-      tile[opaque32(L.self)] = zx;
-      tile[kTile32Floats + opaque32(L.self)] = -zy;
-    } else {
-      tile[opaque32(L.self)] = power_of(zx, zy);
-    }
-  }
-  float *const rk = wr;                 // row l + 32 s
-  float *const rm = tile + opaque32(L.rm);        // row (32 - l) + 32 (31 - s) = rm base + 32 (15 - s)
-#pragma unroll
-  for (int s = 0; s < 16; ++s) {
-    const float wx = (s & 1) ? tw[s >> 1].z : tw[s >> 1].x, wy = (s & 1) ? tw[s >> 1].w : tw[s >> 1].y;
-    const c32 e = {t[s].x + px[s], t[s].y - py[s]};
-    const c32 d = {t[s].x - px[s], t[s].y + py[s]};
-    // T = -i w D
-    const float tr = __builtin_fmaf(wx, d.y, wy * d.x);
-    const float ti = __builtin_fmaf(wy, d.y, -(wx * d.x));
-    if constexpr (CPLX) {   // X[k] = E + T, X[M - k] = conj(E - T)
-      rk[kRowPitch32 * s] = e.x + tr;
-      rk[kTile32Floats + kRowPitch32 * s] = e.y + ti;
-      rm[kRowPitch32 * (15 - s)] = e.x - tr;
-      rm[kTile32Floats + kRowPitch32 * (15 - s)] = ti - e.y;
-    } else {
-    rk[kRowPitch32 * s] = power_of(e.x + tr, e.y + ti);
-    rm[kRowPitch32 * (15 - s)] = power_of(e.x - tr, e.y - ti);
-    }
-    if (s == SMX_P32_STORE_AT || s == SMX_P32_LOAD_AT) { SMX_FENCE(); mid.postpass_at(s); SMX_FENCE(); }
-  }
-  mid.template stamp<7>();
-}
-#endif
 
 // raw samples of the lane's frame: z[n] = (x[2n], x[2n+1]), n = l + 32 j; `src` is the frame's first sample (per lane:
 // the two halves of a wave read different frames)
@@ -684,42 +564,38 @@ __device__ __forceinline__ void flush32_store(const FastArgs &a, const Flush32 &
 // The workgroup must walk consecutive tiles of a clip (TileWalk's contiguous ranges); where a range or a clip begins there
 // is nothing carried (those lanes store nothing), where it ends the carried pairs go out as the partial block they are.
 struct Skew32 {
-  int src0;                    // float offset in a tile of part 0's pair: row0 * 17 + 2 g2
-  int g2, row0;
-  unsigned goffL;              // byte offset of out[row0][2 g2] from a tile's origin
-  unsigned goffc[2];           // part class c, from 64 bytes BEFORE a tile's origin (the offset register of a store is unsigned): goffL + 4 c pitch, plus 64 for the lanes that store the current pair
+  unsigned goffc[2];           // part class c, from 64 bytes BEFORE a tile's origin (the offset register of a store is unsigned): byte offset of out[row0 + 4 c][2 g2] from a tile's origin, plus 64 for the lanes that store the current pair
   unsigned long long sel[2];   // part class c: the lanes whose pair of the current tile completes the block
 };
 struct SkewRegs {
   float2 cur[16];
   float nyq;
 };
-__device__ __forceinline__ Skew32 setup_skew32(const FastArgs &a, int lane, int wave) {
-  Skew32 sk;
+// (the lane's row and pair are re-derived from the lane index where they are used: see Lane32)
+__device__ __forceinline__ void skew32_lane(int lane, int wave, int &row0, int &g2) {
+  asm volatile("" : "+v"(lane));
   const int rsel = lane >> 3;
-  sk.g2 = lane & 7;
-  sk.row0 = 128 * wave + (rsel & 1) + 16 * ((rsel >> 1) & 1) + 2 * (rsel >> 2);
-  sk.src0 = sk.row0 * kTileStride + 2 * sk.g2;
-  sk.goffL = ((unsigned)sk.row0 * (unsigned)a.out_stride + 2u * sk.g2) * 4u;
-  sk.goffc[0] = sk.goffc[1] = 0;
-  sk.sel[0] = sk.sel[1] = 0;
-  return sk;
+  g2 = lane & 7;
+  row0 = 128 * wave + (rsel & 1) + 16 * ((rsel >> 1) & 1) + 2 * (rsel >> 2);
 }
 // the block offsets of the clip whose output begins at oclip (every tile origin of a clip is oclip + 16 t floats)
-__device__ __forceinline__ void skew32_clip(const FastArgs &a, Skew32 &sk, const float *oclip) {
-  const unsigned pitch = (unsigned)a.out_stride * 4u;
+__device__ __forceinline__ void skew32_clip(const FastArgs &a, Skew32 &sk, const float *oclip, int lane, int wave) {
+  int row0, g2;
+  skew32_lane(lane, wave, row0, g2);
 #pragma unroll
   for (int c = 0; c < 2; ++c) {
-    const unsigned at = (unsigned)((reinterpret_cast<uintptr_t>(oclip) >> 2) + (uintptr_t)(sk.row0 + 4 * c) * (uintptr_t)a.out_stride) & 15u;
+    const unsigned at = (unsigned)((reinterpret_cast<uintptr_t>(oclip) >> 2) + (uintptr_t)(row0 + 4 * c) * (uintptr_t)a.out_stride) & 15u;
     const unsigned e = at ? 16u - at : 16u;          // frames of a tile that end the row's open block
-    const bool now = 2u * sk.g2 < e;
+    const bool now = 2u * g2 < e;
     sk.sel[c] = __ballot(now);
-    sk.goffc[c] = sk.goffL + 4u * c * pitch + (now ? 64u : 0u);
+    sk.goffc[c] = ((unsigned)(row0 + 4 * c) * (unsigned)a.out_stride + 2u * g2) * 4u + (now ? 64u : 0u);
   }
 }
 __device__ __forceinline__ constexpr int skew32_part_rows(int p) { return 8 * ((p >> 1) & 1) + 32 * (p >> 2); }
-__device__ __forceinline__ void skew32_read(const float *tile, const Skew32 &sk, int lane, SkewRegs &r) {
-  const float *src0 = tile + opaque32(sk.src0);
+__device__ __forceinline__ void skew32_read(const float *tile, int lane, int wave, SkewRegs &r) {
+  int row0, g2;
+  skew32_lane(lane, wave, row0, g2);
+  const float *src0 = tile + row0 * kTileStride + 2 * g2;
 #pragma unroll
   for (int p = 0; p < 16; ++p) {
     const float *src = src0 + (4 * (p & 1) + skew32_part_rows(p)) * kTileStride;
@@ -730,7 +606,7 @@ __device__ __forceinline__ void skew32_read(const float *tile, const Skew32 &sk,
 __device__ __forceinline__ void store2_at(float *base /* wave-uniform */, unsigned byte_off, float x, float y) {
   using f32x2 = __attribute__((ext_vector_type(2))) float;
   const f32x2 v = {x, y};
-  asm volatile("global_store_dwordx2 %0, %1, %2" SMX_STORE_MOD "\n\ts_nop 1" : : "v"(byte_off), "v"(v), "s"(base) : "memory");
+  asm volatile("global_store_dwordx2 %0, %1, %2" SMX_STORE_MOD : : "v"(byte_off), "v"(v), "s"(base) : "memory");   // (the wait state behind a store is for 12 bytes and more)
 }
 __device__ __forceinline__ float select_lanes(float other, float chosen, unsigned long long lanes) {   // lanes ? chosen : other
   float d;
@@ -760,8 +636,10 @@ __device__ __forceinline__ void skew32_store(const FastArgs &a, const Skew32 &sk
       carry[p] = r.cur[p];
     }
   } else {
-    const unsigned gl = opaque32(sk.goffL);
-    const int f = 2 * sk.g2;
+    int row0, g2;
+    skew32_lane(lane, wave, row0, g2);
+    const unsigned gl = ((unsigned)row0 * (unsigned)a.out_stride + 2u * g2) * 4u;
+    const int f = 2 * g2;
 #pragma unroll
     for (int p = 0; p < 16; ++p) {
       const int c = p & 1;
@@ -831,7 +709,7 @@ struct PowerMid32 {
 #ifdef SMX_STAMPS
       stamp_sum[13] += __builtin_amdgcn_s_memtime() - w0;
 #endif
-      if constexpr (SKEW) skew32_read(lds.tiles + (b ^ 1) * kTile32Floats, sk, lane, sr);
+      if constexpr (SKEW) skew32_read(lds.tiles + (b ^ 1) * kTile32Floats, lane, wave, sr);
       else flush32_read(lds.tiles + (b ^ 1) * kTile32Floats, fl, wave, lane, fr);
       // "read out" may be signalled as soon as the reads are ISSUED: the counter's add executes behind them in this wave's
       // LDS order, and nobody writes the buffer before seeing it.  Every frame fraction the signal comes earlier is slack
@@ -898,7 +776,7 @@ __global__ void __launch_bounds__(512) stft2048_power32_kernel(FastArgs a) {
     fl.goff0 = ((unsigned)row0 * (unsigned)a.out_stride + 4u * fl.g) * 4u;
   }
   FlushRegs fr;
-  Skew32 sk = setup_skew32(a, lane, wave);
+  Skew32 sk{};
   SkewRegs sr;
   float2 carry[16];
 #pragma unroll
@@ -924,7 +802,7 @@ __global__ void __launch_bounds__(512) stft2048_power32_kernel(FastArgs a) {
 #endif
     const bool have = (int64_t)tw.ft * kFT + 2 * wave < a.count;   // wave-uniform: at least the first half has a frame
     if constexpr (SKEW) {
-      if (it > 0 && pend_fresh) skew32_clip(a, sk, pend_oclip);   // (wave-uniform) the pending tile begins a clip or this workgroup's range
+      if (it > 0 && pend_fresh) skew32_clip(a, sk, pend_oclip, lane, wave);   // (wave-uniform) the pending tile begins a clip or this workgroup's range
     }
 #ifdef SMX_STAMPS
     const PowerMid32<ALIGNED, SKEW> mid{a, lds, fl, fr, sk, sr, carry, pend_fresh, pend_closing, raw, src, pend_out, pend_left, lane, wave, b, it, stamp_sum, &stamp_prev, pk_drained, pk_filled};
@@ -968,8 +846,8 @@ __global__ void __launch_bounds__(512) stft2048_power32_kernel(FastArgs a) {
     const int b = (ntiles - 1) & 1;
     lds_wait(lds.filled + b * kTileStride, 8u * (((unsigned)(ntiles - 1) >> 1) + 1));
     if constexpr (SKEW) {
-      if (pend_fresh) skew32_clip(a, sk, pend_oclip);
-      skew32_read(lds.tiles + b * kTile32Floats, sk, lane, sr);
+      if (pend_fresh) skew32_clip(a, sk, pend_oclip, lane, wave);
+      skew32_read(lds.tiles + b * kTile32Floats, lane, wave, sr);
       skew32_store(a, sk, pend_out, pend_left, pend_fresh, true, wave, lane, sr, carry);
     } else {
       flush32_read(lds.tiles + b * kTile32Floats, fl, wave, lane, fr);
@@ -1015,172 +893,6 @@ __global__ void __launch_bounds__(512) stft2048_power32_kernel(FastArgs a) {
       }
       __syncthreads();
       for (int e = tid; e < kBins * kFT; e += 512) {
-        const int k = e / kFT, f = e % kFT;
-        const int64_t bf = bt * kFT + f;
-        if (bf < total) {
-          int64_t clip, p;
-          locate(bf, clip, p);
-          a.out[(clip * kBins + k) * a.out_stride + a.border_out_offset + (p - a.border_p0)] = bt_tile[k * kTileStride + f];
-        }
-      }
-    }
-  }
-}
-
-// ---- stft2048_power32h_kernel: the same tiles with the output path on waves of its own (round 4) -----------------------
-// 12 waves per workgroup: waves 0-7 run the frame code as above but issue no store and read no finished tile; waves 8-11
-// ("flush waves", one per SIMD) do nothing but read finished tiles out of LDS and store them.  Why: the ablations of round
-// 3 (profiles/r05/NOTES.md 3b) put 0.14 of the kernel's 0.51 ms on the stores although they are 9 instructions per wave
-// and tile -- a store issues only when the memory pipeline takes it, the wave that issues it is one of the eight that all
-// others wait for at the counters, and its 33 tile registers are live from the exchange to the store.  On waves of their
-// own the stores wait for nobody: a flush wave has a whole tile's time to get 2 x 9 instructions out.  Three waves per
-// SIMD need <= 168 registers, which the packed arithmetic (200 with the tile registers, 168 without) makes possible.
-// Counters per buffer: filled += 1 per compute wave and tile (8), drained += 1 per flush wave and tile (4).
-#ifndef SMX_P32H_PRIO
-#define SMX_P32H_PRIO 2
-#endif
-template <bool ALIGNED>
-struct PowerMid32H {
-  const Lds32 &lds;
-  float2 (&raw)[32];
-  const float *src;      // the next frames' samples (per lane)
-  int lane, b, it;
-  unsigned &pk_drained;
-  template <int I> __device__ __forceinline__ void stamp() const {}
-  __device__ __forceinline__ void early() const { pk_drained = peek32(lds.drained + b * kTileStride); }
-  __device__ __forceinline__ void before_cells() const {
-    // buffer b last held tile it - 2, the (it >> 1)-th tile written there: the four flush waves have read it out
-    lds_wait32(lds.drained + b * kTileStride, 4u * ((unsigned)it >> 1), pk_drained);
-  }
-  __device__ __forceinline__ void after_transposition_issue() const {}
-  __device__ __forceinline__ void after_exchange_issue() const {}
-  __device__ __forceinline__ void postpass_at(int s) const {
-    if (s == SMX_P32_LOAD_AT) load_frame32<ALIGNED>(src, lane & 31, raw);
-  }
-};
-
-template <bool ALIGNED, int PMODE, bool STRIP>
-__global__ void __launch_bounds__(768) stft2048_power32h_kernel(FastArgs a) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const Lds32 lds = carve_lds32(smem);
-  fill_tables32(a, lds, tid, 768);
-  TileWalk tw;
-  tw.init(a, a.out + a.out_offset, kBins * a.out_stride);
-  const int ntiles = tw.ntiles > 0 ? tw.ntiles : 0;
-  const Lane32 L = setup_lane32(lds, lane, wave & 7);
-
-  if (wave < 8) {
-    // first sample of this lane's frame in tile t of the clip at xc (a lane-half without a frame re-reads the tile's
-    // first frame and its results are never stored)
-    auto frame_ptr = [&](const float *xc, int t) {
-      const int64_t f0 = (int64_t)t * kFT;
-      const int avail = (int)(a.count - f0 < kFT ? a.count - f0 : kFT) - 1;   // last frame of the tile that exists (wave-uniform)
-      const int fi = 2 * wave + L.h;
-      const int64_t p = a.p0 + f0 + (fi <= avail ? fi : 0);
-      if (a.fold_frames && (p < a.border_i0 || p >= a.border_i1)) {
-        const int64_t clip = (xc - a.x) / a.x_stride;
-        return p < a.border_i0 ? a.strip_l + clip * a.strip_l_stride + (p - a.p0) * a.hop
-                               : a.strip_r + clip * a.strip_r_stride + (p - a.border_i1) * a.hop;
-      }
-      return xc + (p * a.hop - a.left);
-    };
-    float2 raw[32];
-#pragma unroll
-    for (int j = 0; j < 32; ++j) raw[j] = make_float2(0.f, 0.f);
-    if (ntiles > 0) load_frame32<ALIGNED>(frame_ptr(tw.xclip, tw.ft), L.l, raw);
-    __syncthreads();   // tables and zeroed counters visible
-    unsigned pk_drained = 0;
-    for (int it = 0; it < ntiles; ++it) {   // tile `it` of this workgroup lives in buffer it & 1
-      const int b = it & 1;
-      int ftnext;
-      const float *xnext;
-      float *onext;
-      tw.peek(a, ftnext, xnext, onext);
-      const bool more = it + 1 < ntiles;
-      const float *src = frame_ptr(more ? xnext : tw.xclip, more ? ftnext : tw.ft);
-#ifdef SMX_DIAG
-      if (a.abl_p32 & 1) src = frame_ptr(a.x, 1);   // timing only: every tile reads the same resident samples
-#endif
-      const PowerMid32H<ALIGNED> mid{lds, raw, src, lane, b, it, pk_drained};
-      frame32_to_tile<PMODE>(a, L, raw, lds.tiles + b * kTile32Floats, mid);
-      lds_signal32(lds.filled + b * kTileStride, lane);
-      tw.xclip = xnext;
-      tw.oclip = onext;
-      tw.ft = ftnext;
-    }
-  } else {
-    // flush wave h: the shares of (former) waves 2 h and 2 h + 1 of every finished tile -- 2 x 8 parts of 16 rows x 4 frames
-    __builtin_amdgcn_s_setprio(SMX_P32H_PRIO);
-    const int h = wave - 8;
-    Flush32 fl0, fl1;
-    {
-      const int hsel = lane >> 5, jj = (lane & 31) >> 2;
-      fl0.g = fl1.g = lane & 3;
-      const int row0 = 128 * (2 * h) + (jj & 3) + 16 * (jj >> 2) + 4 * hsel;
-      fl0.src0 = row0 * kTileStride + 4 * fl0.g;
-      fl0.goff0 = ((unsigned)row0 * (unsigned)a.out_stride + 4u * fl0.g) * 4u;
-      fl1.src0 = fl0.src0 + 128 * kTileStride;
-      fl1.goff0 = fl0.goff0 + 128u * (unsigned)a.out_stride * 4u;
-    }
-    __syncthreads();
-    for (int it = 0; it < ntiles; ++it) {
-      const int b = it & 1;
-      int ftnext;
-      const float *xnext;
-      float *onext;
-      tw.peek(a, ftnext, xnext, onext);
-      float *const pend_out = tw.oclip + tw.ft * kFT;   // wave-uniform
-      const int64_t left = a.count - (int64_t)tw.ft * kFT;
-      const int pend_left = left < kFT ? (int)left : kFT;
-      FlushRegs r0, r1;
-      lds_wait(lds.filled + b * kTileStride, 8u * (((unsigned)it >> 1) + 1));   // every column of the tile is in
-      const float *tile = lds.tiles + b * kTile32Floats;
-      flush32_read(tile, fl0, 2 * h, lane, r0);
-      flush32_read(tile, fl1, 2 * h + 1, lane, r1);
-      lds_signal32(lds.drained + b * kTileStride, lane);   // behind this wave's reads in LDS order
-      flush32_store(a, fl0, pend_out, pend_left, 2 * h, lane, r0);
-      flush32_store(a, fl1, pend_out, pend_left, 2 * h + 1, lane, r1);
-      tw.xclip = xnext;
-      tw.oclip = onext;
-      tw.ft = ftnext;
-    }
-    __builtin_amdgcn_s_setprio(0);
-  }
-
-  // Border frames: as stft2048_power32_kernel (the flush waves take part in the barriers and in the scatter)
-  if (a.border_left + a.border_right > 0) {
-    const int per = a.border_left + a.border_right;
-    const int64_t lead = a.total_tiles / a.tiles_per_clip;
-    const int64_t total = lead * per;
-    auto locate = [&](int64_t beta, int64_t &clip, int64_t &p) {
-      clip = beta / per;
-      const int r = (int)(beta % per);
-      p = r < a.border_left ? a.border_p0 + r : a.border_i1 + (r - a.border_left);
-    };
-    float *bt_tile = lds.tiles;
-    for (int64_t bt = (int64_t)gridDim.x - 1 - tw.uid; bt * kFT < total; bt += gridDim.x) {   // from the last workgroup down: idle ones first
-      __syncthreads();   // the buffer is free: every tile has been read out / the previous border tile scattered
-      if (wave < 8 && bt * kFT + 2 * wave < total) {   // wave-uniform
-        int64_t beta = bt * kFT + 2 * wave + L.h;
-        if (beta >= total) beta = bt * kFT + 2 * wave;   // a half without a pair repeats the first one (never stored)
-        int64_t clip, p;
-        locate(beta, clip, p);
-        const float *xs = a.x + clip * a.x_stride;
-        const int s0 = (int)(p * a.hop - a.left);
-        float2 braw[32];
-#pragma unroll
-        for (int j = 0; j < 32; ++j) {
-          const int s = s0 + 2 * (L.l + 32 * j);
-          braw[j] = make_float2(fetch_padded(xs, (int)a.n, s, a.pad, a.pad_value),
-                                fetch_padded(xs, (int)a.n, s + 1, a.pad, a.pad_value));
-        }
-        frame32_to_tile<PMODE>(a, L, braw, bt_tile, NoMid32{});
-      }
-      __syncthreads();
-      for (int e = tid; e < kBins * kFT; e += 768) {
         const int k = e / kFT, f = e % kFT;
         const int64_t bf = bt * kFT + f;
         if (bf < total) {

@@ -458,13 +458,22 @@ class Synthesis:
         if 0 in shape[:-2]:  # stft.ml:1189-1193
             raise _lib.InvalidArgument("step: cannot synthesise frames with a zero-size leading axis (channels must be at least 1)")
         bins, k = int(shape[-2]), int(shape[-1])
+        lead = 1
+        for d in shape[:-2]:
+            lead *= int(d)
+        # the library reads channels x bins rows of k frames: a chunk whose leading axes hold another number of channels than the
+        # kernel was prepared for would be read past its end (or silently truncated)
+        if lead != self._channels:
+            raise _lib.InvalidArgument("step: the chunk holds %d channel(s) (leading axes %s), the kernel was prepared for %d"
+                                       % (lead, list(shape[:-2]), self._channels))
         cdt = np.complex128 if self._dtype == np.float64 else np.complex64
         cap = self._capacity(k)
         emitted = C.c_int64()
         if is_device(z):
             import torch
-            tz = z.to(torch.complex128 if self._dtype == np.float64 else torch.complex64).contiguous()
+            tz = z.to(torch.complex128 if self._dtype == np.float64 else torch.complex64).reshape(self._channels, bins, k).contiguous()
             zr = torch.view_as_real(tz)
+            self._device = z.device
             out = torch.empty((self._channels, cap), device=z.device, dtype=torch.float64 if self._dtype == np.float64 else torch.float32)
             with torch.cuda.device(z.device):
                 stream = C.c_void_p(torch.cuda.current_stream(z.device).cuda_stream)
@@ -479,13 +488,22 @@ class Synthesis:
 
     def flush(self):
         cap = self._capacity(0)
-        out = np.zeros((self._channels, cap), dtype=self._dtype)
         emitted = C.c_int64()
+        dev = getattr(self, "_device", None)
+        if dev is not None:   # the stream was fed from the device: the tail stays there (as Kernel.flush does)
+            import torch
+            out = torch.empty((self._channels, cap), device=dev, dtype=torch.float64 if self._dtype == np.float64 else torch.float32)
+            with torch.cuda.device(dev):
+                stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+                check(lib.smx_stft_synthesis_flush_dev(self._h, C.c_void_p(out.data_ptr()), cap, C.byref(emitted), stream))
+            return None if emitted.value == 0 else out[:, :emitted.value].contiguous()
+        out = np.zeros((self._channels, cap), dtype=self._dtype)
         check(lib.smx_stft_synthesis_flush(self._h, C.c_void_p(out.ctypes.data), cap, C.byref(emitted)))
         return None if emitted.value == 0 else np.ascontiguousarray(out[:, :emitted.value])
 
     def reset(self):
         check(lib.smx_stft_synthesis_reset(self._h))
+        self._device = None
 
 
 # ---- Pipeline-stage faces (stft.ml:1301-1409) ---------------------------------------------------------------

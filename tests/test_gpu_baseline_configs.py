@@ -168,11 +168,12 @@ def test_bench_two_ranks_one_box():
     computes its clip range of a C5-shaped job through the HIP path, and shard == slice of the whole batch bit
     for bit on every rank."""
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--clips", "8", "--seconds", "3", "--steps", "2",
-           "--warmup", "1", "--verify-shards", "--no-extras"]
+           "--warmup", "1", "--verify-shards", "--no-extras", "--workload", "c5"]
     out = subprocess.run(cmd, capture_output=True, text=True, timeout=800, cwd=ROOT)
     assert out.returncode == 0, out.stdout + out.stderr
     line = json.loads(out.stdout.strip().splitlines()[-1])
-    assert line["n_gpus"] == 2 and line["scaling"] == "strong"
+    assert line["n_gpus"] == 2 and line["scaling"] == "strong" and line["world_size_seen"] == 2
+    assert 0 < line["rank_kernel_ms_avg_min"] <= line["rank_kernel_ms_avg_max"]
     assert line["shard_check"] == {"ranks_bit_exact": 2, "ranks": 2, "world_size_seen": 2,
                                    "backend": line["shard_check"]["backend"]}
     assert line["roofline"]["launches_per_step"] == 1

@@ -187,6 +187,28 @@ def test_fused_general_power_vs_oracle(power):
         assert np.array_equal(Stft.power_range(c, x, a, b, power), got[..., a:b])
 
 
+@pytest.mark.parametrize("fft,hop", [(2048, 512), (1024, 256), (512, 128)])
+@pytest.mark.parametrize("power", [0.5, 1.0, 2.0, 3.0, -0.5])
+def test_nan_sample_propagates_through_every_power(fft, hop, power):
+    """One NaN sample makes every bin of every frame that covers it NaN, whatever the exponent (the reference's float64
+    arithmetic and `Float.pow` propagate it: stft.ml:670-674); the frames that do not cover it stay finite.  The general
+    power of the register pipelines clamps its logarithm with v_med3_f32, which drops a NaN operand -- it must be put back."""
+    rng = np.random.default_rng(fft + int(10 * power))
+    n = 40 * hop + 17
+    x = rng.uniform(-1, 1, size=(2, n)).astype(np.float32)
+    pos = 17 * hop + 5
+    x[1, pos] = np.nan
+    c = Stft.Config.create(fft_size=fft, hop=hop)
+    got = Stft.power_spectrum(c, x, power)
+    assert np.isfinite(got[0]).all()
+    frames = got.shape[-1]
+    starts = np.arange(frames) * hop - fft // 2       # centered frames (librosa convention of the default configuration)
+    covered = (starts <= pos) & (pos < starts + fft)
+    assert covered.any() and not covered.all()
+    assert np.isnan(got[1][:, covered]).all(), (fft, power)
+    assert np.isfinite(got[1][:, ~covered]).all(), (fft, power)
+
+
 @pytest.mark.parametrize("hop,n,lead", [(512, 480000, 2), (512, 5000, 3), (512, 16 * 512 * 3 + 17, 2), (500, 30000, 2),
                                         (511, 30000, 2)])
 def test_transform_float32_vs_oracle(hop, n, lead):

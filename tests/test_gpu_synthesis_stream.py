@@ -168,3 +168,26 @@ def test_totals_latency_and_contracts():
         k.step(z)
     k.reset()
     assert np.array_equal(np.concatenate([k.step(z)[0], k.flush()[0]]), Stft.invert(c8, z))
+
+
+def test_step_checks_the_channels_and_flush_stays_on_the_device():
+    """A chunk must hold exactly the prepared channels (the library reads channels x bins rows of k frames: fewer would be
+    read past their end, more silently dropped) on both the host and the device path; a stream fed from the device gets
+    its tail on the device, equal to the host path's."""
+    import torch
+    c = Stft.Config.create(fft_size=64, hop=16)
+    rng = np.random.default_rng(5)
+    z = (rng.standard_normal((2, c.bins, 9)) + 1j * rng.standard_normal((2, c.bins, 9))).astype(np.complex64)
+    k2 = Stft.Synthesis.prepare(c, np.complex64, channels=2, max_block=16)
+    for bad in (z[0], z[:1], np.concatenate([z, z[:1]])):
+        with pytest.raises(S.InvalidArgument, match="step: the chunk holds"):
+            k2.step(bad)
+        with pytest.raises(S.InvalidArgument, match="step: the chunk holds"):
+            k2.step(torch.from_numpy(np.ascontiguousarray(bad)).cuda())
+    host = [k2.step(z), k2.flush()]
+    k2.reset()
+    dev = [k2.step(torch.from_numpy(z).cuda()), k2.flush()]
+    assert all(isinstance(d, torch.Tensor) and d.is_cuda for d in dev if d is not None)
+    cat = lambda parts: np.concatenate([np.asarray(p.cpu() if hasattr(p, "cpu") else p) for p in parts if p is not None], axis=-1)
+    assert np.array_equal(cat(host), cat(dev))
+    assert np.array_equal(cat(host), Stft.invert(c, z))

@@ -82,6 +82,18 @@ def test_bench_launcher_starts_the_ranks(tmp_path):
     line = json.loads(out.stdout.strip().splitlines()[-1])
     assert line["n_gpus"] == 2 and line["max_clock"] == 2.0 and line["rank0_clips"] == [0, 2048]
     assert line["master"] == "127.0.0.1"
+    # `value` names the SAME workload at every N (a scaling efficiency divides like by like), and the line says what the
+    # ranks saw
+    assert line["world_size_seen"] == 2 and line["scaling"] == "weak"
+    names = {line["workload"]}
+    for n in (1, 8):
+        o = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", str(n), "--dry-run"], capture_output=True,
+                           text=True, timeout=600, env=env)
+        assert o.returncode == 0, o.stdout + o.stderr
+        ln = json.loads(o.stdout.strip().splitlines()[-1])
+        assert ln["n_gpus"] == n and ln["world_size_seen"] == n
+        names.add(ln["workload"])
+    assert len(names) == 1, names
     # a failing rank is a failing run (here: no HIP device in this container -> every rank exits non-zero)
     import torch
     if not torch.cuda.is_available():
