@@ -1720,6 +1720,17 @@ void launch_interior(const StftJob &job, const FastTarget &tg, const float *x, i
       constexpr bool A = decltype(al)::value;
       return a.pmode == 2 ? stft2048_mel32_kernel<A, 2> : a.pmode == 1 ? stft2048_mel32_kernel<A, 1> : stft2048_mel32_kernel<A, 0>;
     };
+    if (env_flag("SMX_MEL32_V1") != 1) {   // the product on waves of its own (stft2048_mel32h_kernel); SMX_MEL32_V1=1: the eight-wave kernel, A/B timing
+      auto by_power_h = [&](auto al) {
+        constexpr bool A = decltype(al)::value;
+        return a.pmode == 2 ? stft2048_mel32h_kernel<A, 2> : a.pmode == 1 ? stft2048_mel32h_kernel<A, 1> : stft2048_mel32h_kernel<A, 0>;
+      };
+      auto k32h = aligned ? by_power_h(std::true_type{}) : by_power_h(std::false_type{});
+      SMX_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k32h), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kFast32Lds));
+      SMX_LAUNCH(k32h, dim3((unsigned)a.blocks), dim3(768), kFast32Lds, job.stream, a, m);
+      SMX_HIP_CHECK(hipGetLastError());
+      return;
+    }
     auto k32 = aligned ? by_power(std::true_type{}) : by_power(std::false_type{});
     SMX_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k32), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kFast32Lds));
     SMX_LAUNCH(k32, dim3((unsigned)a.blocks), dim3(512), kFast32Lds, job.stream, a, m);
@@ -1822,15 +1833,19 @@ void launch_interior(const StftJob &job, const FastTarget &tg, const float *x, i
     };
     // The flush in whole aligned 64-byte blocks (stft_fast_p32.hpp, SKEW): needs even block offsets in every row -- an even row
     // pitch and an origin on an 8-byte boundary -- and consecutive tiles of a clip on one workgroup (contiguous ranges).
-    const bool skew = !strip && a.out_stride % 2 == 0 && ((reinterpret_cast<uintptr_t>(a.out) >> 2) + (uintptr_t)a.out_offset) % 2 == 0 &&
-                      reinterpret_cast<uintptr_t>(a.out) % 4 == 0 && env_flag("SMX_POWER_SKEW") != 0;
+    const bool even = a.out_stride % 2 == 0 && ((reinterpret_cast<uintptr_t>(a.out) >> 2) + (uintptr_t)a.out_offset) % 2 == 0;
+    const int skew_env = env_flag("SMX_POWER_SKEW");   // unset: a pair of frames per lane where the geometry is even, else a frame per lane; "0": the unskewed flush
+    const int skew_form = (int)diag_int("SMX_POWER_SKEW_FORM", 0);   // diagnostic builds: 1 / 2 force a form
+    const int skew = (strip || reinterpret_cast<uintptr_t>(a.out) % 4 != 0 || skew_env == 0) ? 0 : (skew_form == 2 || !even) ? 2 : 1;
     if (skew) {
       a.interleave = 0;
-      auto by_power = [&](auto al) {
+      auto by_power = [&](auto al, auto sk) {
         constexpr bool A = decltype(al)::value;
-        return a.pmode == 2 ? stft2048_power32_kernel<A, 2, false, true> : a.pmode == 1 ? stft2048_power32_kernel<A, 1, false, true> : stft2048_power32_kernel<A, 0, false, true>;
+        constexpr int K = decltype(sk)::value;
+        return a.pmode == 2 ? stft2048_power32_kernel<A, 2, false, K> : a.pmode == 1 ? stft2048_power32_kernel<A, 1, false, K> : stft2048_power32_kernel<A, 0, false, K>;
       };
-      auto k32s = aligned ? by_power(std::true_type{}) : by_power(std::false_type{});
+      auto by_al = [&](auto sk) { return aligned ? by_power(std::true_type{}, sk) : by_power(std::false_type{}, sk); };
+      auto k32s = skew == 1 ? by_al(std::integral_constant<int, 1>{}) : by_al(std::integral_constant<int, 2>{});
       SMX_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k32s), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kFast32Lds));
       SMX_LAUNCH(k32s, dim3((unsigned)a.blocks), dim3(512), kFast32Lds, job.stream, a);
       SMX_HIP_CHECK(hipGetLastError());

@@ -293,7 +293,10 @@ struct NoMid32 {
 // The window rows of the odd points and the twiddles are requested before the first 16-point transform (which needs the even
 // points only) and arrive under it.  (Requesting the even rows a frame pair ahead as well -- 32 registers across the loop
 // edge -- changed nothing in the power kernel and cost the fused mel kernel 40 %: profiles/r06/ab_mel_winpre2.log.)
-template <int PMODE, class Mid, bool CPLX = false>
+// TWFIRST: twiddle rows requested before the first 16-point transform (the rest behind it): 15 where the registers allow
+// (their late arrival sits on the critical path of a kernel whose LDS queue is long), fewer in the 12-wave kernels whose
+// frame waves must fit 168 registers.
+template <int PMODE, class Mid, bool CPLX = false, int TWFIRST = 15>
 __device__ __forceinline__ void frame32_to_tile(const FastArgs &a, const Lane32 &L, float2 (&raw)[32], float *tile,
                                                 const Mid &mid) {
 #pragma clang fp contract(off)
@@ -322,11 +325,18 @@ __device__ __forceinline__ void frame32_to_tile(const FastArgs &a, const Lane32 
   {
     float4 tw[15];
 #pragma unroll
-    for (int m = 0; m < 15; ++m) tw[m] = L.twA_l()[32 * m];
-    const float2 tw31 = L.twA31_l()[0];
+    for (int m = 0; m < TWFIRST; ++m) tw[m] = L.twA_l()[32 * m];
+    float2 tw31;
+    if constexpr (TWFIRST == 15) tw31 = L.twA31_l()[0];
     SMX_FENCE();
     pk_fft16(e);
     SMX_FENCE(); mid.early(); SMX_FENCE();
+    if constexpr (TWFIRST < 15) {
+#pragma unroll
+      for (int m = TWFIRST; m < 15; ++m) tw[m] = L.twA_l()[32 * m];
+      tw31 = L.twA31_l()[0];
+      SMX_FENCE();
+    }
 #pragma unroll
     for (int m = 0; m < 8; ++m) {   // odd points j = 4 m + 1, 4 m + 3 -> o[2 m], o[2 m + 1]
       o[2 * m] = f2{raw[4 * m + 1].x, raw[4 * m + 1].y} * f2{winO[m].x, winO[m].y};
@@ -657,16 +667,94 @@ __device__ __forceinline__ void skew32_store(const FastArgs &a, const Skew32 &sk
   if (wave == 0 && lane < 16 && lane < frames_left) obase[(int64_t)kM * a.out_stride + lane] = r.nyq;
 }
 
+// ---- the same for ANY row pitch and origin (SKEW = 2): one frame per lane ------------------------------------------------
+// With an odd row pitch (2813 frames: BASELINE C5's thirty-second clips) a row's open block ends an odd number of frames into
+// a tile and the alignment differs from row to row with period 16, so a lane holds ONE frame of a row (16 lanes a row, 4 rows
+// an instruction: rows {r, r + 16} per half-wave keep the LDS reads conflict free) and a wave takes the rows of two residues
+// mod 16 -- rows 2 w + 16 k and 2 w + 1 + 16 k, k < 64 -- instead of 128 consecutive ones: all 32 parts of a lane (rows
+// row_l + 32 p) then share one block offset, i.e. one lane mask and one offset adjustment per lane and clip.
+struct SkewG32 {
+  unsigned goff;             // from 64 bytes BEFORE a tile's origin: byte offset of out[row_l][col], plus 64 for the lanes that store the current frame
+  unsigned long long sel;    // the lanes whose frame of the current tile completes the block
+};
+struct SkewGRegs {
+  float cur[32];
+  float nyq;
+};
+__device__ __forceinline__ void skewg32_lane(int lane, int wave, int &row_l, int &col) {
+  asm volatile("" : "+v"(lane));
+  const int rsel = lane >> 4;
+  col = lane & 15;
+  row_l = 2 * wave + (rsel >> 1) + 16 * (rsel & 1);
+}
+__device__ __forceinline__ void skewg32_clip(const FastArgs &a, SkewG32 &sk, const float *oclip, int lane, int wave) {
+  int row_l, col;
+  skewg32_lane(lane, wave, row_l, col);
+  const unsigned at = (unsigned)((reinterpret_cast<uintptr_t>(oclip) >> 2) + (uintptr_t)row_l * (uintptr_t)a.out_stride) & 15u;
+  const unsigned e = at ? 16u - at : 16u;          // frames of a tile that end the row's open block
+  const bool now = (unsigned)col < e;
+  sk.sel = __ballot(now);
+  sk.goff = ((unsigned)row_l * (unsigned)a.out_stride + (unsigned)col) * 4u + (now ? 64u : 0u);
+}
+__device__ __forceinline__ void skewg32_read(const float *tile, int lane, int wave, SkewGRegs &r) {
+  int row_l, col;
+  skewg32_lane(lane, wave, row_l, col);
+  const float *src0 = tile + row_l * kTileStride + col;
+  const float *src1 = src0 + 16 * 32 * kTileStride;   // (ds offsets are 16 bits)
+#pragma unroll
+  for (int p = 0; p < 32; ++p) r.cur[p] = (p < 16 ? src0 : src1)[32 * kTileStride * (p & 15)];
+  r.nyq = tile[kM * kTileStride + (lane & 15)];   // row 1024 = Nyquist bin (every wave reads it, wave 0 stores it)
+}
+__device__ __forceinline__ void store1_at(float *base /* wave-uniform */, unsigned byte_off, float x) {
+  asm volatile("global_store_dword %0, %1, %2" SMX_STORE_MOD : : "v"(byte_off), "v"(x), "s"(base) : "memory");
+}
+__device__ __forceinline__ void skewg32_store(const FastArgs &a, const SkewG32 &sk, float *obase, int frames_left, bool fresh, bool closing,
+                                              int wave, int lane, const SkewGRegs &r, float (&carry)[32]) {
+  const unsigned pitch = (unsigned)a.out_stride * 4u;
+#ifdef SMX_DIAG
+  if (a.abl_nostore == 1) {   // timing-only ablation: keep the LDS reads alive, drop the HBM stores
+#pragma unroll
+    for (int p = 0; p < 32; ++p) { asm volatile("" ::"v"(r.cur[p])); carry[p] = r.cur[p]; }
+    asm volatile("" ::"v"(r.nyq));
+    return;
+  }
+#endif
+  if (frames_left >= kFT && !fresh && !closing) {   // wave-uniform: one whole block per row and part
+    const unsigned g = opaque32(sk.goff);
+#pragma unroll
+    for (int p = 0; p < 32; ++p) {
+      store1_at(obase - kFT, g + 32u * (unsigned)p * pitch, select_lanes(carry[p], r.cur[p], sk.sel));
+      carry[p] = r.cur[p];
+    }
+  } else {
+    int row_l, col;
+    skewg32_lane(lane, wave, row_l, col);
+    const bool now = (sk.sel >> lane) & 1;
+    const unsigned gl = ((unsigned)row_l * (unsigned)a.out_stride + (unsigned)col) * 4u;
+#pragma unroll
+    for (int p = 0; p < 32; ++p) {
+      float *dst = reinterpret_cast<float *>(reinterpret_cast<char *>(obase) + gl + 32u * (unsigned)p * pitch);
+      if ((now || closing) && col < frames_left) dst[0] = r.cur[p];
+      if (!now && !fresh) dst[-16] = carry[p];
+      carry[p] = r.cur[p];
+    }
+  }
+  if (wave == 0 && lane < 16 && lane < frames_left) obase[(int64_t)kM * a.out_stride + lane] = r.nyq;
+}
+
 // what the power kernel does between the stages of a frame pair (see frame32_to_tile)
-template <bool ALIGNED, bool SKEW = false>
+template <bool ALIGNED, int SKEW = 0>
 struct PowerMid32 {
   const FastArgs &a;
   const Lds32 &lds;
   const Flush32 &fl;
   FlushRegs &fr;
-  const Skew32 &sk;      // SKEW: the flush in aligned blocks
+  const Skew32 &sk;      // SKEW = 1: the flush in aligned blocks, a pair of frames per lane (even row pitch and origin)
   SkewRegs &sr;
   float2 (&carry)[16];
+  const SkewG32 &skg;    // SKEW = 2: a frame per lane (any pitch and origin)
+  SkewGRegs &srg;
+  float (&carryg)[32];
   bool pend_fresh, pend_closing;
   float2 (&raw)[32];
   const float *src;      // the next frames' samples (per lane)
@@ -709,7 +797,8 @@ struct PowerMid32 {
 #ifdef SMX_STAMPS
       stamp_sum[13] += __builtin_amdgcn_s_memtime() - w0;
 #endif
-      if constexpr (SKEW) skew32_read(lds.tiles + (b ^ 1) * kTile32Floats, lane, wave, sr);
+      if constexpr (SKEW == 1) skew32_read(lds.tiles + (b ^ 1) * kTile32Floats, lane, wave, sr);
+      else if constexpr (SKEW == 2) skewg32_read(lds.tiles + (b ^ 1) * kTile32Floats, lane, wave, srg);
       else flush32_read(lds.tiles + (b ^ 1) * kTile32Floats, fl, wave, lane, fr);
       // "read out" may be signalled as soon as the reads are ISSUED: the counter's add executes behind them in this wave's
       // LDS order, and nobody writes the buffer before seeing it.  Every frame fraction the signal comes earlier is slack
@@ -724,7 +813,8 @@ struct PowerMid32 {
     const bool same = SMX_P32_STORE_AT == SMX_P32_LOAD_AT;
     if (s == SMX_P32_LOAD_AT && same && SMX_P32_LOADS_FIRST) { load_frame32<ALIGNED>(src, lane & 31, raw); SMX_FENCE(); }
     if (s == SMX_P32_STORE_AT && it > 0) {
-      if constexpr (SKEW) skew32_store(a, sk, pend_out, pend_left, pend_fresh, pend_closing, wave, lane, sr, carry);
+      if constexpr (SKEW == 1) skew32_store(a, sk, pend_out, pend_left, pend_fresh, pend_closing, wave, lane, sr, carry);
+      else if constexpr (SKEW == 2) skewg32_store(a, skg, pend_out, pend_left, pend_fresh, pend_closing, wave, lane, srg, carryg);
       else flush32_store(a, fl, pend_out, pend_left, wave, lane, fr);
     }
     SMX_FENCE();
@@ -732,7 +822,7 @@ struct PowerMid32 {
   }
 };
 
-template <bool ALIGNED, int PMODE, bool STRIP, bool SKEW = false>
+template <bool ALIGNED, int PMODE, bool STRIP, int SKEW = 0>
 __global__ void __launch_bounds__(512) stft2048_power32_kernel(FastArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x;
@@ -781,6 +871,11 @@ __global__ void __launch_bounds__(512) stft2048_power32_kernel(FastArgs a) {
   float2 carry[16];
 #pragma unroll
   for (int p = 0; p < 16; ++p) carry[p] = make_float2(0.f, 0.f);
+  SkewG32 skg{};
+  SkewGRegs srg;
+  float carryg[32];
+#pragma unroll
+  for (int p = 0; p < 32; ++p) carryg[p] = 0.f;
   bool pend_fresh = true, pend_closing = false;
   const float *pend_oclip = nullptr;
   unsigned pk_drained = 0, pk_filled = 0;
@@ -801,13 +896,15 @@ __global__ void __launch_bounds__(512) stft2048_power32_kernel(FastArgs a) {
     if (a.abl_p32 & 1) src = frame_ptr(a.x, 1);   // timing only: every tile reads the same resident samples
 #endif
     const bool have = (int64_t)tw.ft * kFT + 2 * wave < a.count;   // wave-uniform: at least the first half has a frame
-    if constexpr (SKEW) {
+    if constexpr (SKEW == 1) {
       if (it > 0 && pend_fresh) skew32_clip(a, sk, pend_oclip, lane, wave);   // (wave-uniform) the pending tile begins a clip or this workgroup's range
+    } else if constexpr (SKEW == 2) {
+      if (it > 0 && pend_fresh) skewg32_clip(a, skg, pend_oclip, lane, wave);
     }
 #ifdef SMX_STAMPS
-    const PowerMid32<ALIGNED, SKEW> mid{a, lds, fl, fr, sk, sr, carry, pend_fresh, pend_closing, raw, src, pend_out, pend_left, lane, wave, b, it, stamp_sum, &stamp_prev, pk_drained, pk_filled};
+    const PowerMid32<ALIGNED, SKEW> mid{a, lds, fl, fr, sk, sr, carry, skg, srg, carryg, pend_fresh, pend_closing, raw, src, pend_out, pend_left, lane, wave, b, it, stamp_sum, &stamp_prev, pk_drained, pk_filled};
 #else
-    const PowerMid32<ALIGNED, SKEW> mid{a, lds, fl, fr, sk, sr, carry, pend_fresh, pend_closing, raw, src, pend_out, pend_left, lane, wave, b, it, pk_drained, pk_filled};
+    const PowerMid32<ALIGNED, SKEW> mid{a, lds, fl, fr, sk, sr, carry, skg, srg, carryg, pend_fresh, pend_closing, raw, src, pend_out, pend_left, lane, wave, b, it, pk_drained, pk_filled};
 #endif
     mid.template stamp<0>();
 #ifdef SMX_STAMPS
@@ -845,10 +942,14 @@ __global__ void __launch_bounds__(512) stft2048_power32_kernel(FastArgs a) {
   if (ntiles > 0) {   // the last tile of this workgroup
     const int b = (ntiles - 1) & 1;
     lds_wait(lds.filled + b * kTileStride, 8u * (((unsigned)(ntiles - 1) >> 1) + 1));
-    if constexpr (SKEW) {
+    if constexpr (SKEW == 1) {
       if (pend_fresh) skew32_clip(a, sk, pend_oclip, lane, wave);
       skew32_read(lds.tiles + b * kTile32Floats, lane, wave, sr);
       skew32_store(a, sk, pend_out, pend_left, pend_fresh, true, wave, lane, sr, carry);
+    } else if constexpr (SKEW == 2) {
+      if (pend_fresh) skewg32_clip(a, skg, pend_oclip, lane, wave);
+      skewg32_read(lds.tiles + b * kTile32Floats, lane, wave, srg);
+      skewg32_store(a, skg, pend_out, pend_left, pend_fresh, true, wave, lane, srg, carryg);
     } else {
       flush32_read(lds.tiles + b * kTile32Floats, fl, wave, lane, fr);
       flush32_store(a, fl, pend_out, pend_left, wave, lane, fr);

@@ -72,9 +72,10 @@ def drive(c, z, sizes, device=False):
         pos += s
         if out is not None:
             outs.append(out.cpu().numpy() if device else out)
-    out = k.flush()
+    out = k.flush()   # (on the device when the stream was fed from the device, as Kernel.flush)
     if out is not None:
-        outs.append(out)
+        assert hasattr(out, "is_cuda") == device
+        outs.append(out.cpu().numpy() if device else out)
     real = np.float64 if z.dtype == np.complex128 else np.float32
     got = np.concatenate(outs, axis=-1) if outs else np.zeros((lead, 0), dtype=real)
     return got.reshape(z.shape[:-2] + (got.shape[-1],))
