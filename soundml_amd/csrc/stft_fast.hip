@@ -1720,17 +1720,6 @@ void launch_interior(const StftJob &job, const FastTarget &tg, const float *x, i
       constexpr bool A = decltype(al)::value;
       return a.pmode == 2 ? stft2048_mel32_kernel<A, 2> : a.pmode == 1 ? stft2048_mel32_kernel<A, 1> : stft2048_mel32_kernel<A, 0>;
     };
-    if (env_flag("SMX_MEL32_V1") != 1) {   // the product on waves of its own (stft2048_mel32h_kernel); SMX_MEL32_V1=1: the eight-wave kernel, A/B timing
-      auto by_power_h = [&](auto al) {
-        constexpr bool A = decltype(al)::value;
-        return a.pmode == 2 ? stft2048_mel32h_kernel<A, 2> : a.pmode == 1 ? stft2048_mel32h_kernel<A, 1> : stft2048_mel32h_kernel<A, 0>;
-      };
-      auto k32h = aligned ? by_power_h(std::true_type{}) : by_power_h(std::false_type{});
-      SMX_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k32h), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kFast32Lds));
-      SMX_LAUNCH(k32h, dim3((unsigned)a.blocks), dim3(768), kFast32Lds, job.stream, a, m);
-      SMX_HIP_CHECK(hipGetLastError());
-      return;
-    }
     auto k32 = aligned ? by_power(std::true_type{}) : by_power(std::false_type{});
     SMX_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k32), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kFast32Lds));
     SMX_LAUNCH(k32, dim3((unsigned)a.blocks), dim3(512), kFast32Lds, job.stream, a, m);

@@ -266,112 +266,3 @@ __global__ void __launch_bounds__(512) stft2048_mel32_kernel(FastArgs a, Mel32Ar
     mel32_items(m, iv, lds.tiles + b * kTile32Floats, pend_out, pend_left, lane);
   }
 }
-
-// ---- stft2048_mel32h_kernel: the filterbank product on waves of its own (round 4) ------------------------------------
-// 12 waves per workgroup: waves 0-7 run the frame code and nothing else (they never read a finished tile); waves 8-11, one
-// per SIMD, do nothing but multiply finished tiles by the filterbank -- product wave h takes the items the plan deals to
-// waves 2 h and 2 h + 1.  Why: in the eight-wave kernel above the product sits on every wave's critical path (five
-// dependent LDS round trips per tile at 40 steps; the MFMA pipe is 11 % busy, the vector pipe 30 %), so C3 took 0.52 ms
-// where the frame pipeline alone takes 0.36.  On waves of their own the steps wait for nobody but their operands, and the
-// frame waves -- which hold no tile registers -- fit the 168 registers that three waves per SIMD allow.  An item is still
-// summed over its band by ONE wave in ascending bin order: the values are those of the eight-wave kernel, bit for bit, and
-// the plan needs no balance over the frame waves any more (long items, dense filterbanks).
-// Counters per buffer: filled += 1 per frame wave and tile (8), drained += 1 per product wave and tile (4).
-#ifndef SMX_MEL32H_TWFIRST
-#define SMX_MEL32H_TWFIRST 7
-#endif
-template <bool ALIGNED, class SrcOf>
-struct MelMid32H {
-  const Lds32 &lds;
-  float2 (&raw)[32];
-  const SrcOf &src_of;   // the next frames' samples (per lane): computed where the loads are issued (a 64-bit address per lane
-                         // held from the loop's top to the post-pass does not fit the 168 registers)
-  int lane, b, it;
-  unsigned &pk_drained;
-  template <int I> __device__ __forceinline__ void stamp() const {}
-  __device__ __forceinline__ void early() const { pk_drained = peek32(lds.drained + b * kTileStride); }
-  __device__ __forceinline__ void before_cells() const {
-    // buffer b last held tile it - 2, the (it >> 1)-th tile written there: the four product waves are done with it
-    lds_wait32(lds.drained + b * kTileStride, 4u * ((unsigned)it >> 1), pk_drained);
-  }
-  __device__ __forceinline__ void after_transposition_issue() const {}
-  __device__ __forceinline__ void after_exchange_issue() const {}
-  __device__ __forceinline__ void postpass_at(int s) const {
-    if (s == SMX_P32_LOAD_AT) load_frame32<ALIGNED>(src_of(), lane & 31, raw);
-  }
-};
-
-template <bool ALIGNED, int PMODE>
-__global__ void __launch_bounds__(768) stft2048_mel32h_kernel(FastArgs a, Mel32Args m) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const Lds32 lds = carve_lds32(smem);
-  fill_tables32(a, lds, tid, 768);
-  TileWalk tw;
-  tw.init(a, m.out + m.out_offset, (int64_t)m.n_mels * m.out_stride);
-  const int ntiles = tw.ntiles > 0 ? tw.ntiles : 0;
-  if (wave < 8) {
-    const Lane32 L = setup_lane32(lds, lane, wave);
-    auto frame_ptr = [&](const float *xc, int t) {   // as stft2048_power32_kernel
-      const int64_t f0 = (int64_t)t * kFT;
-      const int avail = (int)(a.count - f0 < kFT ? a.count - f0 : kFT) - 1;
-      const int fi = 2 * wave + L.h;
-      const int64_t p = a.p0 + f0 + (fi <= avail ? fi : 0);
-      if (a.fold_frames && (p < a.border_i0 || p >= a.border_i1)) {
-        const int64_t clip = (xc - a.x) / a.x_stride;
-        return p < a.border_i0 ? a.strip_l + clip * a.strip_l_stride + (p - a.p0) * a.hop
-                               : a.strip_r + clip * a.strip_r_stride + (p - a.border_i1) * a.hop;
-      }
-      return xc + (p * a.hop - a.left);
-    };
-    float2 raw[32];
-#pragma unroll
-    for (int j = 0; j < 32; ++j) raw[j] = make_float2(0.f, 0.f);
-    if (ntiles > 0) load_frame32<ALIGNED>(frame_ptr(tw.xclip, tw.ft), L.l, raw);
-    __syncthreads();   // tables and zeroed counters visible: the only workgroup barrier
-    unsigned pk_drained = 0;
-    for (int it = 0; it < ntiles; ++it) {   // tile `it` of this workgroup lives in buffer it & 1
-      const int b = it & 1;
-      int ftnext;
-      const float *xnext;
-      float *onext;
-      tw.peek(a, ftnext, xnext, onext);
-      const bool more = it + 1 < ntiles;
-      const float *const xsrc = more ? xnext : tw.xclip;
-      const int tsrc = more ? ftnext : tw.ft;
-      auto src_of = [&] { return frame_ptr(xsrc, tsrc); };
-      using Mid = MelMid32H<ALIGNED, decltype(src_of)>;
-      const Mid mid{lds, raw, src_of, lane, b, it, pk_drained};
-      frame32_to_tile<PMODE, Mid, false, SMX_MEL32H_TWFIRST>(a, L, raw, lds.tiles + b * kTile32Floats, mid);
-      lds_signal32(lds.filled + b * kTileStride, lane);
-      tw.xclip = xnext;
-      tw.oclip = onext;
-      tw.ft = ftnext;
-    }
-  } else {
-    const int h = wave - 8;
-    const int iv0 = reinterpret_cast<const int *>(m.items + (2 * h) * kMel32MaxItems)[lane];       // the items of (former) waves 2 h, 2 h + 1
-    const int iv1 = reinterpret_cast<const int *>(m.items + (2 * h + 1) * kMel32MaxItems)[lane];
-    __syncthreads();
-    for (int it = 0; it < ntiles; ++it) {
-      const int b = it & 1;
-      int ftnext;
-      const float *xnext;
-      float *onext;
-      tw.peek(a, ftnext, xnext, onext);
-      float *const pend_out = tw.oclip + tw.ft * kFT;   // wave-uniform
-      const int64_t left = a.count - (int64_t)tw.ft * kFT;
-      const int pend_left = left < kFT ? (int)left : kFT;
-      lds_wait(lds.filled + b * kTileStride, 8u * (((unsigned)it >> 1) + 1));   // every column of the tile is in
-      const float *tile = lds.tiles + b * kTile32Floats;
-      mel32_items(m, iv0, tile, pend_out, pend_left, lane);
-      mel32_items(m, iv1, tile, pend_out, pend_left, lane);
-      lds_signal32(lds.drained + b * kTileStride, lane);   // behind the items' last LDS reads in this wave's order
-      tw.xclip = xnext;
-      tw.oclip = onext;
-      tw.ft = ftnext;
-    }
-  }
-}
