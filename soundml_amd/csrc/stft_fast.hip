@@ -1745,7 +1745,11 @@ void launch_interior(const StftJob &job, const FastTarget &tg, const float *x, i
     return;
   }
   if (tg.complex_out && env_flag("SMX_COMPLEX_V1") != 1) {   // the 32-lane frame pipeline; SMX_COMPLEX_V1=1: the 64-lane kernel (A/B timing)
-    auto k32 = aligned ? stft2048_complex32_kernel<true> : stft2048_complex32_kernel<false>;
+    // the flush in whole aligned 128-byte lines (stft_fast_p32.hpp, cplx_skew32_*): consecutive tiles of a clip on one workgroup
+    const bool cskew = reinterpret_cast<uintptr_t>(a.out) % 8 == 0 && env_flag("SMX_COMPLEX_SKEW") != 0;
+    if (cskew) a.interleave = 0;
+    auto k32 = cskew ? (aligned ? stft2048_complex32_kernel<true, true> : stft2048_complex32_kernel<false, true>)
+                     : (aligned ? stft2048_complex32_kernel<true, false> : stft2048_complex32_kernel<false, false>);
     SMX_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k32), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kFast32Lds));
     SMX_LAUNCH(k32, dim3((unsigned)a.blocks), dim3(512), kFast32Lds, job.stream, a);
     SMX_HIP_CHECK(hipGetLastError());

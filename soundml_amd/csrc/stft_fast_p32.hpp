@@ -464,6 +464,7 @@ __device__ __forceinline__ void frame32_to_tile(const FastArgs &a, const Lane32 
 #pragma unroll
   for (int i = 0; i < 5; ++i) put(11 + i, r[i], q[i]);
 #undef SMX_PA
+  SMX_FENCE(); mid.postpass_at(15); SMX_FENCE();   // (the complex kernel with carried lines requests its samples here: no registers before)
   mid.template stamp<7>();
 }
 
@@ -1048,11 +1049,67 @@ __device__ __forceinline__ void cplx_flush32(const FastArgs &a, const float *re,
     dst[1] = 0.0f;
   }
 }
-template <bool ALIGNED>
+// The flush in whole aligned 128-byte lines (SKEW, as skewg32_* of the power kernel with a complex value per lane: 16 lanes a
+// row = 16 frames x 8 bytes, rows by residue mod 16 so that a lane has one block offset).  The tile's 128-byte runs as they
+// stand -- rows 7504 bytes apart, so that 15 runs of 16 straddle a line -- take 0.4-0.56 ms per GB with nothing else running
+// (profiles/r06/store_shape_probe.log), whole lines 0.185: the complex spectrogram of C2 is 1.97 GB.
+struct CplxSkew32 {
+  unsigned goff;             // from 128 bytes BEFORE a tile's origin: byte offset of out[row_l][col], plus 128 for the lanes that store the current frame
+  unsigned long long sel;    // the lanes whose frame of the current tile completes the line
+};
+__device__ __forceinline__ void cplx_skew32_clip(const FastArgs &a, CplxSkew32 &sk, const float *oclip, int lane, int wave) {
+  int row_l, col;
+  skewg32_lane(lane, wave, row_l, col);
+  const unsigned at = (unsigned)((reinterpret_cast<uintptr_t>(oclip) >> 3) + (uintptr_t)row_l * (uintptr_t)a.out_stride) & 15u;
+  const unsigned e = at ? 16u - at : 16u;          // frames of a tile that end the row's open line
+  const bool now = (unsigned)col < e;
+  sk.sel = __ballot(now);
+  sk.goff = ((unsigned)row_l * (unsigned)a.out_stride + (unsigned)col) * 8u + (now ? 128u : 0u);
+}
+// reads the tile (re, im planes) and stores it; carry: the frames of the previous tile that opened a line
+__device__ __forceinline__ void cplx_skew32_flush(const FastArgs &a, const float *re, const CplxSkew32 &sk, float *obase, int frames_left,
+                                                  bool fresh, bool closing, int wave, int lane, float2 (&carry)[32]) {
+  const unsigned pitch = (unsigned)a.out_stride * 8u;
+  int row_l, col;
+  skewg32_lane(lane, wave, row_l, col);
+  const float *src0 = re + row_l * kTileStride + col;
+  const float *src1 = src0 + 16 * 32 * kTileStride;   // (ds offsets are 16 bits)
+  if (frames_left >= kFT && !fresh && !closing) {   // wave-uniform: one whole line per row and part
+    const unsigned g = opaque32(sk.goff);
+#pragma unroll
+    for (int p = 0; p < 32; ++p) {
+      const float *pr = (p < 16 ? src0 : src1) + 32 * kTileStride * (p & 15);
+      const float2 cur = make_float2(pr[0], pr[kTile32Floats]);
+      store2_at(obase - 2 * kFT, g + 32u * (unsigned)p * pitch, select_lanes(carry[p].x, cur.x, sk.sel), select_lanes(carry[p].y, cur.y, sk.sel));
+      carry[p] = cur;
+    }
+  } else {
+    const bool now = (sk.sel >> lane) & 1;
+    const unsigned gl = ((unsigned)row_l * (unsigned)a.out_stride + (unsigned)col) * 8u;
+#pragma unroll
+    for (int p = 0; p < 32; ++p) {
+      const float *pr = (p < 16 ? src0 : src1) + 32 * kTileStride * (p & 15);
+      const float2 cur = make_float2(pr[0], pr[kTile32Floats]);
+      float *dst = reinterpret_cast<float *>(reinterpret_cast<char *>(obase) + gl + 32u * (unsigned)p * pitch);
+      if ((now || closing) && col < frames_left) { dst[0] = cur.x; dst[1] = cur.y; }
+      if (!now && !fresh) { dst[-2 * kFT] = carry[p].x; dst[-2 * kFT + 1] = carry[p].y; }
+      carry[p] = cur;
+    }
+  }
+  if (wave == 0 && lane < 16 && lane < frames_left) {   // bin 1024: real
+    float *dst = obase + ((int64_t)kM * a.out_stride + lane) * 2;
+    dst[0] = re[kM * kTileStride + lane];
+    dst[1] = 0.0f;
+  }
+}
+template <bool ALIGNED, bool SKEW = false>
 struct CplxMid32 {
   const FastArgs &a;
   const Lds32 &lds;
   const CplxFlush32 &fl;
+  const CplxSkew32 &sk;
+  float2 (&carry)[32];
+  bool pend_fresh, pend_closing;
   float2 (&raw)[32];
   const float *src;
   float *pend_out;
@@ -1062,7 +1119,8 @@ struct CplxMid32 {
   __device__ __forceinline__ void early() const {   // between the two 16-point transforms of the first radix-32
     if (it > 0) {
       lds_wait(lds.filled, 8u * (unsigned)it);       // every wave's columns of the previous tile are in
-      cplx_flush32(a, lds.tiles, fl, pend_out, pend_left, wave, lane);
+      if constexpr (SKEW) cplx_skew32_flush(a, lds.tiles, sk, pend_out, pend_left, pend_fresh, pend_closing, wave, lane, carry);
+      else cplx_flush32(a, lds.tiles, fl, pend_out, pend_left, wave, lane);
       lds_signal32(lds.drained, lane);               // behind this wave's reads in LDS order
     }
   }
@@ -1072,11 +1130,11 @@ struct CplxMid32 {
   __device__ __forceinline__ void after_transposition_issue() const {}
   __device__ __forceinline__ void after_exchange_issue() const {}
   __device__ __forceinline__ void postpass_at(int s) const {
-    if (s == SMX_P32_LOAD_AT) load_frame32<ALIGNED>(src, lane & 31, raw);
+    if (s == (SKEW ? 15 : SMX_P32_LOAD_AT)) load_frame32<ALIGNED>(src, lane & 31, raw);
   }
 };
 
-template <bool ALIGNED>
+template <bool ALIGNED, bool SKEW = false>
 __global__ void __launch_bounds__(512) stft2048_complex32_kernel(FastArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x;
@@ -1106,6 +1164,12 @@ __global__ void __launch_bounds__(512) stft2048_complex32_kernel(FastArgs a) {
   if (ntiles > 0) load_frame32<ALIGNED>(frame_ptr(tw.xclip, tw.ft), L.l, raw);
   __syncthreads();
   const CplxFlush32 fl = setup_cplx_flush32(a, lane, wave);
+  CplxSkew32 sk{};
+  float2 carry[32];
+#pragma unroll
+  for (int p = 0; p < 32; ++p) carry[p] = make_float2(0.f, 0.f);
+  bool pend_fresh = true, pend_closing = false;
+  const float *pend_oclip = nullptr;
   float *pend_out = nullptr;
   int pend_left = 0;
   for (int it = 0; it < ntiles; ++it) {
@@ -1115,18 +1179,30 @@ __global__ void __launch_bounds__(512) stft2048_complex32_kernel(FastArgs a) {
     tw.peek(a, ftnext, xnext, onext);
     const bool more = it + 1 < ntiles;
     const float *src = frame_ptr(more ? xnext : tw.xclip, more ? ftnext : tw.ft);
-    const CplxMid32<ALIGNED> mid{a, lds, fl, raw, src, pend_out, pend_left, lane, wave, it};
-    frame32_to_tile<2, CplxMid32<ALIGNED>, true>(a, L, raw, lds.tiles, mid);
+    if constexpr (SKEW) {
+      if (it > 0 && pend_fresh) cplx_skew32_clip(a, sk, pend_oclip, lane, wave);   // (wave-uniform) the pending tile begins a clip or this workgroup's range
+    }
+    const CplxMid32<ALIGNED, SKEW> mid{a, lds, fl, sk, carry, pend_fresh, pend_closing, raw, src, pend_out, pend_left, lane, wave, it};
+    // (SKEW: the twiddle rows are requested behind the flush -- their 62 registers beside the 64 carried ones do not fit)
+    frame32_to_tile<2, CplxMid32<ALIGNED, SKEW>, true, SKEW ? 0 : 15>(a, L, raw, lds.tiles, mid);
     lds_signal32(lds.filled, lane);
     pend_out = tw.oclip + 2 * tw.ft * kFT;
     const int64_t left = a.count - (int64_t)tw.ft * kFT;
     pend_left = left < kFT ? (int)left : kFT;
+    pend_oclip = tw.oclip;
+    pend_fresh = it == 0 || tw.ft == 0;
+    pend_closing = tw.ft == a.tiles_per_clip - 1;
     tw.xclip = xnext;
     tw.oclip = onext;
     tw.ft = ftnext;
   }
   if (ntiles > 0) {
     lds_wait(lds.filled, 8u * (unsigned)ntiles);
-    cplx_flush32(a, lds.tiles, fl, pend_out, pend_left, wave, lane);
+    if constexpr (SKEW) {
+      if (pend_fresh) cplx_skew32_clip(a, sk, pend_oclip, lane, wave);
+      cplx_skew32_flush(a, lds.tiles, sk, pend_out, pend_left, pend_fresh, true, wave, lane, carry);
+    } else {
+      cplx_flush32(a, lds.tiles, fl, pend_out, pend_left, wave, lane);
+    }
   }
 }
