@@ -99,6 +99,31 @@ def mel_apply(mc: O.MelConfig, s: np.ndarray, threads: int = 1) -> np.ndarray:
     return out
 
 
+_REF_SO = os.path.join(_HERE, "_ref", "libresample_shape_ref.so")
+
+
+def have_ref() -> bool:
+    """oracle/_ref/libresample_shape_ref.so: the reference's own `soundml_resample_shape_run`, compiled from
+    /root/reference/soundml/lib/resample_stubs.c where it lies (oracle/Makefile; prebuilt when the reference is absent)"""
+    if not os.path.exists(_REF_SO) and os.path.exists("/root/reference/soundml/lib/resample_stubs.c"):
+        build()
+    return os.path.exists(_REF_SO)
+
+
+def ref_resample_shape(xs: np.ndarray, h: np.ndarray, n: int, sl: int, sm: int) -> np.ndarray:
+    """THE REFERENCE's shaping identity (resample_stubs.c:329-372, its own compiled code) on complex128 [lines; n/2+1]"""
+    lib = C.CDLL(_REF_SO)
+    lib.ref_resample_shape.restype = C.c_int
+    lib.ref_resample_shape.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_int64]
+    xs = np.ascontiguousarray(xs, dtype=np.complex128)
+    h = np.ascontiguousarray(h, dtype=np.complex128)
+    w = n * sl if sl > 1 else (n // sm if sm > 1 else n)
+    out = np.zeros((xs.shape[0], w // 2 + 1), dtype=np.complex128)
+    if lib.ref_resample_shape(xs.ctypes.data, h.ctypes.data, out.ctypes.data, xs.shape[0], n, sl, sm) != 0:
+        raise ValueError("resample_shape: invalid geometry")
+    return out
+
+
 def resample_shape(xs: np.ndarray, h: np.ndarray, n: int, sl: int, sm: int) -> np.ndarray:
     """the C restatement of resample_stubs.c:329-372 on complex128 [lines; n/2+1]"""
     lib = load()

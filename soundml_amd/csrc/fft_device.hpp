@@ -19,8 +19,13 @@ template <> struct vec2_of<double> { using type = double2; };
 
 template <typename S> __device__ __forceinline__ cpx<S> operator+(cpx<S> a, cpx<S> b) { return {a.x + b.x, a.y + b.y}; }
 template <typename S> __device__ __forceinline__ cpx<S> operator-(cpx<S> a, cpx<S> b) { return {a.x - b.x, a.y - b.y}; }
+// (two products and two fused multiply-adds, written out: the translation units that include this header are built with
+// -ffp-contract=off, so the compiler fuses nothing on its own and every instantiation rounds the same way)
 template <typename S> __device__ __forceinline__ cpx<S> cmul(cpx<S> a, cpx<S> w) {
-  return {a.x * w.x - a.y * w.y, a.x * w.y + a.y * w.x};
+  return {__builtin_fma(a.x, w.x, -(a.y * w.y)), __builtin_fma(a.x, w.y, a.y * w.x)};
+}
+template <> __device__ __forceinline__ cpx<float> cmul<float>(cpx<float> a, cpx<float> w) {
+  return {__builtin_fmaf(a.x, w.x, -(a.y * w.y)), __builtin_fmaf(a.x, w.y, a.y * w.x)};
 }
 template <typename S> __device__ __forceinline__ cpx<S> mul_neg_i(cpx<S> a) { return {a.y, -a.x}; }
 

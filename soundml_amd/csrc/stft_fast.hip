@@ -1,6 +1,6 @@
 // Fused framing + window + real FFT(2048) + output stage for gfx950 (MI355X): the three fft-2048 kernels
-//   stft2048_power_kernel     |X|^p               Stft.power_spectrum          stft.ml:670-691
-//   stft2048_complex_kernel   X                   Stft.transform / _range      stft.ml:632-666
+//   stft2048_power32_kernel   |X|^p               Stft.power_spectrum          stft.ml:670-691   (stft_fast_p32.hpp, 32-lane frame pipeline)
+//   stft2048_complex32_kernel X                   Stft.transform / _range      stft.ml:632-666   (the same)
 //   stft2048_mel_kernel       W |X|^p (MFMA)      Soundml.mel_spectrogram      soundml.ml:12-24
 // They replace, for float32 audio, the reference's hot call
 //   Nx.stft cdtype ~window:fft ~step:hop ~win (to_double samples)   stft.ml:356-364
@@ -738,543 +738,10 @@ struct SyncHook {
   }
 };
 
-// SQUARE = power 2 (no per-bin branch); otherwise |X|^p through pmode / half_power.
-// STRIP only names the instantiation used for the small gathered border strips, so that kernel-trace
-// statistics separate them from the interior launch (the code is identical).
-template <bool ALIGNED, bool SQUARE, bool STRIP SMX_ABL_PARAM>
-__global__ void __launch_bounds__(1024) stft2048_power_kernel(FastArgs a) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // provably wave-uniform (scalar)
-  const Lds lds = carve_lds(smem);
-  const LaneConst L = setup_lane(a, lds, tid, lane, wave);
-  const Counters cnt{reinterpret_cast<unsigned *>(lds.tabB), reinterpret_cast<unsigned *>(lds.tabB) + 2};
-  TileWalk tw;
-  tw.init(a, a.out + a.out_offset, kBins * a.out_stride);
-  if (tw.ntiles <= 0) return;   // uniform for the workgroup
-  const int ntiles = tw.ntiles;
-  // first sample of this wave's frame in tile t of the clip at xc (a wave without a frame re-reads the
-  // tile's first frame and ignores it)
-  auto frame_ptr = [&](const float *xc, int t, bool &hv) {
-    const int64_t f0 = (int64_t)t * kFT;
-    hv = f0 + wave < a.count;
-    const int64_t p = a.p0 + f0 + (hv ? wave : 0);
-    // batches of many short clips (launch_ranges): the launch covers every frame and border frames come from gathered strips
-    if (a.fold_frames && (p < a.border_i0 || p >= a.border_i1)) {   // wave-uniform
-      const int64_t clip = (xc - a.x) / a.x_stride;
-      return p < a.border_i0 ? a.strip_l + clip * a.strip_l_stride + (p - a.p0) * a.hop
-                             : a.strip_r + clip * a.strip_r_stride + (p - a.border_i1) * a.hop;
-    }
-    return xc + (p * a.hop - a.left);
-  };
-
-  float2 raw[16];
-#pragma unroll
-  for (int j = 0; j < 16; ++j) raw[j] = make_float2(0.f, 0.f);
-  bool have;
-  prefetch_frame<ALIGNED SMX_ABL_ARG>(a, frame_ptr(tw.xclip, tw.ft, have), lane, raw);
-  __syncthreads();   // tables and zeroed counters visible: the only workgroup barrier of the kernel
-  float *pend_out = nullptr; // output origin (clip, first frame) of the previous tile and frames left in that clip
-  int pend_left = 0, pend_ft = 0;
-  FlushLane fl;
-  {
-    const int hsel = lane >> 5, jj = (lane & 31) >> 2;
-    fl.g = lane & 3;
-    fl.row0 = 32 * wave + (jj & 3) + 16 * (jj >> 2) + 4 * hsel;
-    const int bin0 = (fl.row0 & 3) * 256 + (fl.row0 >> 2);
-    fl.goff0 = ((unsigned)bin0 * (unsigned)a.out_stride + 4u * fl.g) * 4u;
-  }
-  constexpr int kTileFloats = kTileBytes / sizeof(float);
-  // this wave's share of the tile in buffer b (the `fills`-th tile written there), once every column is in
-  auto flush_tile = [&](int b, unsigned fills) {
-    lds_wait(cnt.filled + b, 16u * fills);
-    const float *ptile = lds.tiles + b * kTileFloats;
-#pragma unroll
-    for (int part = 0; part < 4; ++part) flush_part(a, ptile, part, fl, pend_out, pend_left, wave, lane, pend_ft);
-    lds_signal(cnt.drained + b, lane);
-  };
-
-#ifdef SMX_STAMPS
-  unsigned long long stamp_sum[kStampSlots] = {0}, stamp_prev;
-  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(stamp_prev)::"memory");
-  const unsigned long long clk_t0 = stamp_prev, clk_r0 = __builtin_amdgcn_s_memrealtime();
-#endif
-  for (int it = 0; it < ntiles; ++it) {   // tile `it` of this workgroup lives in buffer it & 1
-    const int b = it & 1;
-    SMX_STAMP(0);
-    // next tile of this workgroup (possibly of another clip).  Past the end the current tile's first
-    // frame is re-read and ignored, so raw never carries old values around the loop.
-    int ftnext;
-    const float *xnext;
-    float *onext;
-    tw.peek(a, ftnext, xnext, onext);
-    bool have_next;
-    const float *src = frame_ptr(it + 1 < ntiles ? xnext : tw.xclip, it + 1 < ntiles ? ftnext : tw.ft, have_next);
-    have_next = have_next && it + 1 < ntiles;
-    if (have) {   // wave-uniform
-      // buffer b last held tile it - 2, the (it >> 1)-th tile written there
-#ifdef SMX_STAMPS
-      const SyncHook hook{cnt.drained + b, 16u * ((unsigned)it >> 1), stamp_sum, &stamp_prev};
-#else
-      const SyncHook hook{cnt.drained + b, 16u * ((unsigned)it >> 1)};
-#endif
-      if constexpr (SMX_ABL(12) || SMX_ABL(13) || SMX_ABL(14)) frame_to_tile<(SQUARE ? 2 : -1), kPre, false, false SMX_ABL_ARG>(a, L, raw, cells_of_column(L, lds.tiles + b * kTileFloats, wave), lane, NoHook{});
-      else frame_to_tile<(SQUARE ? 2 : -1), kPre, false, false SMX_ABL_ARG>(a, L, raw, cells_of_column(L, lds.tiles + b * kTileFloats, wave), lane, hook);
-    }
-    if constexpr (!(SMX_ABL(12) || SMX_ABL(13) || SMX_ABL(14))) lds_signal(cnt.filled + b, lane);
-    SMX_STAMP(17);
-    prefetch_frame<ALIGNED SMX_ABL_ARG>(a, src, lane, raw);
-    SMX_STAMP(18);
-    if constexpr (!(SMX_ABL(12) || SMX_ABL(13) || SMX_ABL(14)))
-      if (it > 0) flush_tile(b ^ 1, ((unsigned)(it - 1) >> 1) + 1);   // tile it - 1
-    SMX_STAMP(19);
-    pend_out = tw.oclip + tw.ft * kFT;   // wave-uniform
-    pend_ft = tw.ft;
-    const int64_t left = a.count - (int64_t)tw.ft * kFT;
-    pend_left = left < kFT ? (int)left : kFT;
-    have = have_next;
-    tw.xclip = xnext;
-    tw.oclip = onext;
-    tw.ft = ftnext;
-  }
-  if constexpr (!(SMX_ABL(12) || SMX_ABL(13) || SMX_ABL(14))) flush_tile((ntiles - 1) & 1, ((unsigned)(ntiles - 1) >> 1) + 1);   // the last tile of this workgroup
-#ifdef SMX_STAMPS
-  stamp_sum[20] = __builtin_amdgcn_s_memtime() - clk_t0;
-  stamp_sum[21] = __builtin_amdgcn_s_memrealtime() - clk_r0;
-#endif
-  // Border frames (the few per clip whose window reaches past either end of the signal): same frame code on
-  // samples fetched through the padding rule, 16 (clip, frame) pairs per tile, results scattered to their
-  // places.  A few dozen tiles in all, so plain barriers and element-wise stores do.
-  if (a.border_left + a.border_right > 0) {
-    const int per = a.border_left + a.border_right;
-    const int64_t lead = a.total_tiles / a.tiles_per_clip;
-    const int64_t total = lead * per;
-    auto locate = [&](int64_t beta, int64_t &clip, int64_t &p) {
-      clip = beta / per;
-      const int r = (int)(beta % per);
-      p = r < a.border_left ? a.border_p0 + r : a.border_i1 + (r - a.border_left);
-    };
-    float *bt_tile = lds.tiles;
-    for (int64_t bt = blockIdx.x; bt * kFT < total; bt += gridDim.x) {
-      __syncthreads();   // the buffer is free: every wave is past its last flush / the previous border tile
-      const int64_t beta = bt * kFT + wave;
-      if (beta < total) {   // wave-uniform
-        int64_t clip, p;
-        locate(beta, clip, p);
-        const float *xs = a.x + clip * a.x_stride;
-        const int s0 = (int)(p * a.hop - a.left);
-        float2 braw[16];
-#pragma unroll
-        for (int j = 0; j < 16; ++j) {
-          const int s = s0 + 2 * (lane + 64 * j);
-          braw[j] = make_float2(fetch_padded(xs, (int)a.n, s, a.pad, a.pad_value),
-                                fetch_padded(xs, (int)a.n, s + 1, a.pad, a.pad_value));
-        }
-        // the same PRE variant as the interior loop: with another instantiation the compiler contracts a few
-        // multiply-adds differently and a border frame would differ in the last bit from the same frame computed as
-        // an interior one (the streaming faces compute every frame as interior: partition law, stft_law.ml:79-164)
-        frame_to_tile<(SQUARE ? 2 : -1), SMX_EPILOGUE_PRE, false, false SMX_ABL_ZERO>(a, L, braw, cells_of_column(L, bt_tile, wave), lane, NoHook{});
-      }
-      __syncthreads();
-      for (int e = tid; e < kBins * kFT; e += 1024) {
-        const int k = e / kFT, f = e % kFT;
-        const int64_t bf = bt * kFT + f;
-        if (bf < total) {
-          int64_t clip, p;
-          locate(bf, clip, p);
-          const float v = k < kM ? bt_tile[(4 * (k & 255) + (k >> 8)) * kTileStride + f]
-                                 : bt_tile[nyquist_row(f) * kTileStride + kFT];
-          a.out[(clip * kBins + k) * a.out_stride + a.border_out_offset + (p - a.border_p0)] = v;
-        }
-      }
-    }
-  }
-#ifdef SMX_STAMPS
-  if (lane == 0 && blockIdx.x < 4096)
-    for (int i = 0; i < kStampSlots; ++i) g_stamp_sums[(blockIdx.x * 16 + wave) * kStampSlots + i] = stamp_sum[i];
-#endif
-}
-
 #include "stft_fast_p32.hpp"   // the 32-lane frame pipeline: stft2048_power32_kernel
 #include "stft_fast_mel32.hpp" // the fused audio -> mel kernel on the 32-lane pipeline: stft2048_mel32_kernel
 #include "stft_fast_p16.hpp"   // the same pipeline with a frame in 16 / 8 lanes: stft_power_lanes_kernel (power spectrogram at fft 1024 / 512)
 
-// ---- power spectrogram kernel, ring form ----------------------------------------------------------------------
-// The same frame pipeline; what changes is where the results wait in LDS and how they leave.
-//   * A workgroup walks a CONTIGUOUS range of the flat (clip, tile) sequence, i.e. consecutive tiles of one clip.
-//   * The two tile buffers form a ring of 32 frame positions per bin row.  Frame o of the segment goes to ring
-//     position (o + A_k) mod 32 of row k, where A_k = (address of out[clip][k][first frame] / 4) mod 16 is the row's
-//     own misalignment.  A block of 16 ring positions is therefore exactly one 64-byte-ALIGNED run of the output
-//     row: every full store is one whole 64-byte block, whatever the row pitch (3752 bytes at C2: only one row in
-//     eight starts on a 64-byte boundary, and an unaligned run costs two partial blocks -- 1.33x write traffic
-//     and the read-modify-writes behind it, profiles/r03/pmc.json).
-//     16 q pitch = 0 (mod 16 floats), so A_k is ONE value per lane for its 16 rows: the skew costs nothing per bin.
-//   * Block j (ring positions 16 j .. 16 j + 15) is complete once tile j is in, holds the last A_k frames of tile
-//     j - 1 and the first 16 - A_k of tile j, lives in buffer j & 1, and is stored while tile j + 1 is computed
-//     (at hook point kRingFlushAt of that frame).  The first block of a segment is masked below A_k, the last
-//     ones above the segment's end; those few partial runs use element stores.
-// Synchronisation: the monotonic LDS counters of the kernel above; a segment (the tiles of one clip in the range)
-// ends with its last two blocks flushed and a workgroup barrier.
-#ifndef SMX_RING_FLUSH_AT
-#define SMX_RING_FLUSH_AT 2
-#endif
-
-struct RingSeg {            // wave-uniform
-  const float *x0;          // first sample of the segment's first frame
-  char *S;                  // 64-byte-aligned address at or below out[clip][0][first frame of the segment]
-  unsigned d;               // bytes from S to that element (0 .. 60)
-  int nfr, tiles;           // frames and tiles (of 16) in the segment
-};
-
-// A lane's value that the optimiser must re-derive where it is used instead of carrying it in a register across the
-// FFT (the frame pipeline needs 120+ of the 128 registers a 16-wave workgroup allows): the asm pins the computation
-// behind it to this point of the program.
-__device__ __forceinline__ int opaque(int v) {
-  asm volatile("" : "+v"(v));
-  return v;
-}
-
-template <int FLUSH_AT, class Flush, class Ready>
-struct RingHook {
-  const Flush &flush;
-  const Ready &ready_fn;
-  template <int P>
-  __device__ __forceinline__ void at() const {
-    if constexpr (P == FLUSH_AT) flush();
-  }
-  __device__ __forceinline__ void ready(Cells &c) const { ready_fn(c); }
-};
-
-template <bool ALIGNED, bool SQUARE, bool STRIP, int FLUSH_AT SMX_ABL_PARAM>
-__global__ void __launch_bounds__(1024) stft2048_power_ring_kernel(FastArgs a) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const Lds lds = carve_lds(smem);
-  const LaneConst L = setup_lane(a, lds, tid, lane, wave);
-  unsigned *const c_filled = reinterpret_cast<unsigned *>(lds.tabB), *const c_drained = c_filled + 2;
-  constexpr int kTileFloats = kTileBytes / sizeof(float);
-  int64_t tau, tau_end;
-  block_to_range(a, tau, tau_end);
-  const unsigned pitch4 = (unsigned)a.out_stride * 4u;
-
-  auto seg_at = [&](int64_t t0) {   // the clip-contiguous run of this workgroup's tiles that starts at flat tile t0
-    RingSeg sg;
-    const int64_t clip = t0 / a.tiles_per_clip;
-    const int ft0 = (int)(t0 - clip * a.tiles_per_clip);
-    int64_t tiles = a.tiles_per_clip - ft0;
-    if (tiles > tau_end - t0) tiles = tau_end - t0;
-    const int64_t left = a.count - (int64_t)ft0 * kFT;
-    sg.tiles = (int)tiles;
-    sg.nfr = (int)(left < tiles * kFT ? left : tiles * kFT);
-    sg.x0 = a.x + clip * a.x_stride + ((a.p0 + (int64_t)ft0 * kFT) * a.hop - a.left);
-    const uintptr_t o = reinterpret_cast<uintptr_t>(a.out + a.out_offset + clip * (int64_t)kBins * a.out_stride + (int64_t)ft0 * kFT);
-    sg.S = reinterpret_cast<char *>(o & ~uintptr_t(63));
-    sg.d = (unsigned)(o & 63);
-    return sg;
-  };
-  // ring skew of bin row `bin` in segment sg: (byte address of out[clip][bin][first frame] mod 64) / 4
-  auto skew = [&](const RingSeg &sg, int bin) {
-#ifdef SMX_DIAG
-    if (a.abl_noskew) return 0;
-#endif
-    return (int)(((sg.d + (unsigned)bin * (pitch4 & 63u)) & 63u) >> 2);
-  };
-  // this wave's frame of tile `it` of a segment (a wave without a frame re-reads the tile's first frame and ignores it)
-  auto frame_src = [&](const RingSeg &sg, int it) {
-    const int f = it * kFT + wave;
-    return sg.x0 + (int64_t)(f < sg.nfr ? f : it * kFT) * a.hop;
-  };
-  // block j of a segment -> HBM: this wave's 64 rows (4 parts of 16 rows x 64 bytes).  Tile rows {0-3, 16-19} + 4 h
-  // per half-wave keep the LDS reads conflict free; a 4-lane group owns one row's 16 positions.
-  auto flush_block = [&](const RingSeg &sg, int j) {
-    const int l = opaque(lane);
-    const int fg = l & 3, hsel = l >> 5, jj = (l & 31) >> 2;
-    const int frow0 = 32 * wave + (jj & 3) + 16 * (jj >> 2) + 4 * hsel;
-    const int fbin0 = (frow0 & 3) * 256 + (frow0 >> 2);         // bin(row + 8) = bin + 2, bin(row + 512) = bin + 128
-    const unsigned t0 = sg.d + (unsigned)fbin0 * pitch4;
-    const float *buf = lds.tiles + (j & 1) * kTileFloats;
-    float *Sj = reinterpret_cast<float *>(sg.S + (int64_t)64 * j);
-    const int c0 = 4 * fg;
-    const int first = j == 0, left = sg.nfr - kFT * j;           // valid ring positions of a row: [first ? A : 0, A + left)
-#pragma unroll
-    for (int p = 0; p < 4; ++p) {
-      const int row = frow0 + 512 * (p >> 1) + 8 * (p & 1);
-      const float *src = buf + row * kTileStride + c0;
-      const float v0 = src[0], v1 = src[1], v2 = src[2], v3 = src[3];
-      const unsigned t = t0 + (unsigned)(2 * (p & 1) + 128 * (p >> 1)) * pitch4;
-#ifdef SMX_DIAG
-      const unsigned goff = (a.abl_noskew ? t : (t & ~63u)) + 16u * (unsigned)fg;
-      const int A = a.abl_noskew ? 0 : (int)((t & 63u) >> 2);
-#else
-      const unsigned goff = (t & ~63u) + 16u * (unsigned)fg;
-      const int A = (int)((t & 63u) >> 2);
-#endif
-      const int lo = first ? A : 0, hi = A + left;
-#ifdef SMX_DIAG
-      if (a.abl_nostore == 1) { asm volatile("" ::"v"(v0), "v"(v1), "v"(v2), "v"(v3)); continue; }
-#endif
-      if (c0 >= lo && c0 + 4 <= hi) {
-        store4_unaligned(Sj, goff, v0, v1, v2, v3);
-      } else {
-        float *dst = reinterpret_cast<float *>(reinterpret_cast<char *>(Sj) + goff);
-        if (c0 >= lo && c0 < hi) dst[0] = v0;
-        if (c0 + 1 >= lo && c0 + 1 < hi) dst[1] = v1;
-        if (c0 + 2 >= lo && c0 + 2 < hi) dst[2] = v2;
-        if (c0 + 3 >= lo && c0 + 3 < hi) dst[3] = v3;
-      }
-    }
-    if (wave == 0 && l < 16) {   // bin 1024: its 16 positions sit in the pad slots of rows 0..15
-      const unsigned t = sg.d + (unsigned)kM * pitch4;
-      const int A = (int)((t & 63u) >> 2);
-      const int lo = first ? A : 0, hi = A + left;
-      if (l >= lo && l < hi)
-        *reinterpret_cast<float *>(reinterpret_cast<char *>(Sj) + (t & ~63u) + 4u * (unsigned)l) = buf[l * kTileStride + kFT];
-    }
-  };
-  auto nth = [](int j) { return 16u * (((unsigned)j >> 1) + 1u); };   // counter value once tile / block j is through
-
-  float2 raw[16];
-#pragma unroll
-  for (int j = 0; j < 16; ++j) raw[j] = make_float2(0.f, 0.f);
-  RingSeg sg = seg_at(tau < tau_end ? tau : 0);
-  if (tau < tau_end) prefetch_frame<ALIGNED SMX_ABL_ARG>(a, frame_src(sg, 0), lane, raw);
-  __syncthreads();   // tables and zeroed counters visible
-
-  while (tau < tau_end) {   // one segment per trip (uniform for the workgroup)
-    const int64_t tau_next = tau + sg.tiles;
-    RingSeg sg_next = sg;
-    if (tau_next < tau_end) sg_next = seg_at(tau_next);
-    for (int it = 0; it < sg.tiles; ++it) {
-      const bool have = it * kFT + wave < sg.nfr;   // wave-uniform
-      auto flush_prev = [&]() {   // block it - 1: complete once every wave has written tile it - 1
-        if (it < 1) return;
-        lds_wait(c_filled + ((it - 1) & 1), nth(it - 1));
-        flush_block(sg, it - 1);
-        lds_signal(c_drained + ((it - 1) & 1), lane);
-      };
-      auto ready = [&]() {        // the cells of tile `it` lie in blocks it (buffer of block it - 2) and it + 1 (of block it - 1)
-        if (it >= 2) lds_wait(c_drained + (it & 1), nth(it - 2));
-        if (it >= 1) lds_wait(c_drained + ((it + 1) & 1), nth(it - 1));
-      };
-      if (have) {
-        // The frame's cells, derived where the post-pass needs them (nothing of this lives across the FFT): ring
-        // position of the frame in a row = 16 it + wave + the row's skew.
-        auto cell = [&](int row, int bin) {
-          const unsigned pos = 16u * (unsigned)it + (unsigned)wave + (unsigned)skew(sg, bin);
-          return lds.tiles + ((pos >> 4) & 1u) * kTileFloats + row * kTileStride + (pos & 15u);
-        };
-        auto ready_cells = [&](Cells &c) {
-          if constexpr (SMX_RING_PRIO != 0) __builtin_amdgcn_s_setprio(SMX_RING_PRIO);   // the end of a frame goes first: the others wait for it
-          ready();
-          const int l = opaque(lane);
-          const int k1 = l >> 2, qa = l & 3, r = ((qa & 1) << 1) | (qa >> 1);
-          c.own = cell(4 * k1 + r, k1 + 256 * r);
-          if (l >= 4) {   // partner lane 67 - l: k1' = 16 - k1, r' = 3 - r
-            c.pg = cell(4 * (16 - k1) + (3 - r), (16 - k1) + 256 * (3 - r));
-            c.p0 = c.pg + kCellStep * 15;
-          } else {        // the k1 = 0 column pairs inside itself (setup_lane)
-            c.pg = cell((3 - r) + 64, 256 * (3 - r));
-            c.p0 = cell((4 - r) & 3, 256 * ((4 - r) & 3));
-          }
-          const unsigned pos = 16u * (unsigned)it + (unsigned)wave + (unsigned)skew(sg, kM);
-          c.nyq = lds.tiles + ((pos >> 4) & 1u) * kTileFloats + (pos & 15u) * kTileStride + kFT;
-        };
-        const RingHook<FLUSH_AT, decltype(flush_prev), decltype(ready_cells)> hook{flush_prev, ready_cells};
-        frame_to_tile<(SQUARE ? 2 : -1), kPre, false, false SMX_ABL_ARG>(a, L, raw, Cells{}, lane, hook);
-      } else {
-        flush_prev();
-      }
-      lds_signal(c_filled + (it & 1), lane);
-      if constexpr (SMX_RING_PRIO != 0) __builtin_amdgcn_s_setprio(0);
-      // next frame: the segment's next tile, else the first tile of the next segment, else (the end) a dummy re-read
-      const float *src = it + 1 < sg.tiles ? frame_src(sg, it + 1) : (tau_next < tau_end ? frame_src(sg_next, 0) : frame_src(sg, it));
-      prefetch_frame<ALIGNED SMX_ABL_ARG>(a, src, lane, raw);
-    }
-    // drain: the last full block and the partial one behind it
-    lds_wait(c_filled + ((sg.tiles - 1) & 1), nth(sg.tiles - 1));
-    flush_block(sg, sg.tiles - 1);
-    flush_block(sg, sg.tiles);
-    __syncthreads();             // every wave has read both buffers: counters and ring restart with the next segment
-    if (tid < 4) c_filled[tid] = 0u;
-    __syncthreads();
-    tau = tau_next;
-    sg = sg_next;
-  }
-
-  // Border frames: as in stft2048_power_kernel (same frame code, unskewed tile, element stores)
-  if (a.border_left + a.border_right > 0) {
-    const int per = a.border_left + a.border_right;
-    const int64_t lead = a.total_tiles / a.tiles_per_clip;
-    const int64_t total = lead * per;
-    auto locate = [&](int64_t beta, int64_t &clip, int64_t &p) {
-      clip = beta / per;
-      const int r = (int)(beta % per);
-      p = r < a.border_left ? a.border_p0 + r : a.border_i1 + (r - a.border_left);
-    };
-    float *bt_tile = lds.tiles;
-    for (int64_t bt = blockIdx.x; bt * kFT < total; bt += gridDim.x) {
-      __syncthreads();
-      const int64_t beta = bt * kFT + wave;
-      if (beta < total) {   // wave-uniform
-        int64_t clip, p;
-        locate(beta, clip, p);
-        const float *xs = a.x + clip * a.x_stride;
-        const int s0 = (int)(p * a.hop - a.left);
-        float2 braw[16];
-#pragma unroll
-        for (int j = 0; j < 16; ++j) {
-          const int s = s0 + 2 * (lane + 64 * j);
-          braw[j] = make_float2(fetch_padded(xs, (int)a.n, s, a.pad, a.pad_value),
-                                fetch_padded(xs, (int)a.n, s + 1, a.pad, a.pad_value));
-        }
-        frame_to_tile<(SQUARE ? 2 : -1), SMX_EPILOGUE_PRE, false, false SMX_ABL_ZERO>(a, L, braw, cells_of_column(L, bt_tile, wave), lane, NoHook{});
-      }
-      __syncthreads();
-      for (int e = tid; e < kBins * kFT; e += 1024) {
-        const int k = e / kFT, f = e % kFT;
-        const int64_t bf = bt * kFT + f;
-        if (bf < total) {
-          int64_t clip, p;
-          locate(bf, clip, p);
-          const float v = k < kM ? bt_tile[(4 * (k & 255) + (k >> 8)) * kTileStride + f]
-                                 : bt_tile[nyquist_row(f) * kTileStride + kFT];
-          a.out[(clip * kBins + k) * a.out_stride + a.border_out_offset + (p - a.border_p0)] = v;
-        }
-      }
-    }
-  }
-}
-
-// ---- complex spectrum kernel (Stft.transform / transform_range, stft.ml:632-666) ------------------
-// Same frame pipeline; the tile holds the spectrum of 16 frames as two planes (re, im) in the space
-// of the power kernel's two buffers, so there is ONE tile: a wave stores its share of the previous
-// tile in the middle of its next FFT (after the transposes) and writes its new column at the end, which
-// leaves about half a frame of slack on either side of both counters.  A tile row leaves as 16 frames x
-// 8 bytes = one 128-byte run of out[clip][bin][frame] (interleaved re, im).
-struct CplxFlushLane {
-  int row0;          // tile row of instruction 0
-  unsigned goff0;    // byte offset of out[bin(row0)][2 g] from the tile origin
-  int g;             // frames 2 g, 2 g + 1
-};
-__device__ __forceinline__ void cplx_flush(const FastArgs &a, const float *re, int wave, int lane,
-                                           const CplxFlushLane &fl, float *obase, int frames_left) {
-  const float *im = re + kTileBytes / sizeof(float);
-  const int fleft = frames_left - 2 * fl.g;
-#pragma unroll
-  for (int i = 0; i < 8; ++i) {
-    // rows advance by 4 per instruction inside a 32-row block: bin(row + 4) = bin + 1, bin(row + 32) = bin + 8
-    const int row = fl.row0 + 32 * (i >> 2) + 4 * (i & 3);
-    const float *pr = re + row * kTileStride + 2 * fl.g, *pi = im + row * kTileStride + 2 * fl.g;
-    const float r0 = pr[0], r1 = pr[1], i0 = pi[0], i1 = pi[1];
-    const unsigned goff = fl.goff0 + (unsigned)((i & 3) + 8 * (i >> 2)) * (unsigned)a.out_stride * 8u;
-    if (fleft >= 2) {
-      store4_unaligned(obase, goff, r0, i0, r1, i1);
-    } else if (fleft == 1) {
-      float *dst = reinterpret_cast<float *>(reinterpret_cast<char *>(obase) + goff);
-      dst[0] = r0;
-      dst[1] = i0;
-    }
-  }
-  if (wave == 0 && lane < 16 && lane < frames_left) {   // bin 1024: real
-    float *dst = obase + ((int64_t)kM * a.out_stride + lane) * 2;
-    dst[0] = re[nyquist_row(lane) * kTileStride + kFT];
-    dst[1] = 0.0f;
-  }
-}
-
-template <bool ALIGNED>
-struct CplxHook {
-  const FastArgs &a;
-  unsigned *filled, *drained;
-  unsigned tiles_before;     // tiles this workgroup has completed before the current one
-  const float *tile;
-  const CplxFlushLane &fl;
-  float *pout;
-  int pleft, wave, lane;
-  __device__ __forceinline__ void flush_previous() const {
-    if (tiles_before == 0) return;
-    lds_wait(filled, 16u * tiles_before);
-    cplx_flush(a, tile, wave, lane, fl, pout, pleft);
-    lds_signal(drained, lane);
-  }
-  template <int P>
-  __device__ __forceinline__ void at() const {
-    if constexpr (P == 5) flush_previous();
-  }
-  __device__ __forceinline__ void ready(Cells &) const { lds_wait(drained, 16u * tiles_before); }
-};
-
-template <bool ALIGNED, bool STRIP>
-__global__ void __launch_bounds__(1024) stft2048_complex_kernel(FastArgs a) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const Lds lds = carve_lds(smem);
-  const LaneConst L = setup_lane(a, lds, tid, lane, wave);
-  unsigned *const c_filled = reinterpret_cast<unsigned *>(lds.tabB), *const c_drained = c_filled + 1;
-  TileWalk tw;
-  tw.init(a, a.out + 2 * a.out_offset, 2 * kBins * a.out_stride);
-  if (tw.ntiles <= 0) return;   // uniform for the workgroup
-  const int ntiles = tw.ntiles;
-  auto frame_ptr = [&](const float *xc, int t, bool &hv) {
-    const int64_t f0 = (int64_t)t * kFT;
-    hv = f0 + wave < a.count;
-    const int64_t p = a.p0 + f0 + (hv ? wave : 0);
-    if (a.fold_frames && (p < a.border_i0 || p >= a.border_i1)) {   // wave-uniform; four frames per clip at C3
-      const int64_t clip = (xc - a.x) / a.x_stride;
-      return p < a.border_i0 ? a.strip_l + clip * a.strip_l_stride + (p - a.p0) * a.hop
-                             : a.strip_r + clip * a.strip_r_stride + (p - a.border_i1) * a.hop;
-    }
-    return xc + (p * a.hop - a.left);
-  };
-  float2 raw[16];
-  bool have;
-  load_frame<ALIGNED>(frame_ptr(tw.xclip, tw.ft, have), lane, raw);
-  __syncthreads();   // tables and zeroed counters visible
-  CplxFlushLane fl;
-  {
-    // one store = 8 rows x 128 bytes; rows {0, 1, 16, 17} (+2 for the upper half-wave) keep the four
-    // LDS reads of a lane conflict free at row stride 17
-    const int half = lane >> 5, ridx = (lane & 31) >> 3;
-    fl.g = lane & 7;
-    fl.row0 = 64 * wave + (ridx & 1) + 16 * (ridx >> 1) + 2 * half;
-    const int bin0 = (fl.row0 & 3) * 256 + (fl.row0 >> 2);
-    fl.goff0 = ((unsigned)bin0 * (unsigned)a.out_stride + 2u * fl.g) * 8u;
-  }
-  float *pend_out = nullptr;
-  int pend_left = 0;
-  for (int it = 0; it < ntiles; ++it) {
-    const CplxHook<ALIGNED> hook{a, c_filled, c_drained, (unsigned)it, lds.tiles, fl, pend_out, pend_left, wave, lane};
-    if (have) {
-      frame_to_tile<2, false, true, false SMX_ABL_ZERO>(a, L, raw, cells_of_column(L, lds.tiles, wave), lane, hook);
-    } else {
-      hook.flush_previous();
-    }
-    lds_signal(c_filled, lane);
-    int ftnext;
-    const float *xnext;
-    float *onext;
-    tw.peek(a, ftnext, xnext, onext);
-    bool have_next;
-    const float *xsrc = it + 1 < ntiles ? xnext : tw.xclip;
-    const float *src = frame_ptr(xsrc, it + 1 < ntiles ? ftnext : tw.ft, have_next);
-    have_next = have_next && it + 1 < ntiles;
-    load_frame<ALIGNED>(src, lane, raw);
-    pend_out = tw.oclip + 2 * tw.ft * kFT;   // wave-uniform
-    const int64_t left = a.count - (int64_t)tw.ft * kFT;
-    pend_left = left < kFT ? (int)left : kFT;
-    have = have_next;
-    tw.xclip = xnext;
-    tw.oclip = onext;
-    tw.ft = ftnext;
-  }
-  lds_wait(c_filled, 16u * (unsigned)ntiles);
-  cplx_flush(a, lds.tiles, wave, lane, fl, pend_out, pend_left);
-}
 
 // ---- fused audio -> mel kernel -------------------------------------------------------------------
 // Soundml.mel_spectrogram (soundml.ml:12-24) = Mel.apply (Stft.power_spectrum x) with the power
@@ -1744,7 +1211,7 @@ void launch_interior(const StftJob &job, const FastTarget &tg, const float *x, i
     SMX_HIP_CHECK(hipGetLastError());
     return;
   }
-  if (tg.complex_out && env_flag("SMX_COMPLEX_V1") != 1) {   // the 32-lane frame pipeline; SMX_COMPLEX_V1=1: the 64-lane kernel (A/B timing)
+  if (tg.complex_out) {   // Stft.transform on the 32-lane frame pipeline
     // the flush in whole aligned 128-byte lines (stft_fast_p32.hpp, cplx_skew32_*): consecutive tiles of a clip on one workgroup
     const bool cskew = reinterpret_cast<uintptr_t>(a.out) % 8 == 0 && env_flag("SMX_COMPLEX_SKEW") != 0;
     if (cskew) a.interleave = 0;
@@ -1755,67 +1222,13 @@ void launch_interior(const StftJob &job, const FastTarget &tg, const float *x, i
     SMX_HIP_CHECK(hipGetLastError());
     return;
   }
-  if (tg.complex_out) {
-    auto kernel = strip ? (aligned ? stft2048_complex_kernel<true, true> : stft2048_complex_kernel<false, true>)
-                        : (aligned ? stft2048_complex_kernel<true, false> : stft2048_complex_kernel<false, false>);
-    SMX_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kernel),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)kFastLds));
-    SMX_LAUNCH(kernel, dim3((unsigned)a.blocks), dim3(1024), kFastLds, job.stream, a);
-    SMX_HIP_CHECK(hipGetLastError());
-    return;
-  }
 #ifdef SMX_DIAG
-  const int abl = (int)diag_int("SMX_ABLATE", 0);
-  a.abl_nostore = (abl == 1 || abl == 3 || abl == 7) ? 1 : abl == 8 ? 2 : 0;
-  if (diag_flag("SMX_NOSTORE") == 1) a.abl_nostore = 1;
-  if (diag_flag("SMX_ABL_RUN") >= 0) a.abl_nostore = (int)diag_int("SMX_ABL_RUN", 0);   // 2: 128 B, 3: 256 B, 4: 512 B runs
-  const bool ring = env_flag("SMX_POWER_RING") == 1 && !tg.fold_frames;
-  const int fl_at = (int)diag_int("SMX_RING_FLUSH", 2);
-  a.abl_noskew = diag_flag("SMX_RING_NOSKEW") == 1 ? 1 : 0;
+  if (diag_flag("SMX_NOSTORE") == 1) a.abl_nostore = 1;   // timing-only ablations of the 32-lane kernel (results wrong by construction)
   a.abl_p32 = (int)diag_int("SMX_P32_ABL", 0);
-  auto kernel = ring ? (abl == 4 ? stft2048_power_ring_kernel<true, true, false, 2, 4>
-                        : abl == 5 ? stft2048_power_ring_kernel<true, true, false, 2, 5>
-                        : (abl == 6 || abl == 7) ? stft2048_power_ring_kernel<true, true, false, 2, 6>
-                        : abl == 9 ? stft2048_power_ring_kernel<true, true, false, 2, 9>
-                        : abl == 10 ? stft2048_power_ring_kernel<true, true, false, 2, 10>
-                        : abl == 11 ? stft2048_power_ring_kernel<true, true, false, 2, 11>
-                        : fl_at == 5 ? stft2048_power_ring_kernel<true, true, false, 5, 0>
-                        : fl_at == 1 ? stft2048_power_ring_kernel<true, true, false, 1, 0>
-                        : fl_at == 3 ? stft2048_power_ring_kernel<true, true, false, 3, 0>
-                                     : stft2048_power_ring_kernel<true, true, false, 2, 0>)
-              : abl == 2 ? stft2048_power_kernel<true, true, false, 2>
-              : abl == 3 ? stft2048_power_kernel<true, true, false, 3>
-              : abl == 4 ? stft2048_power_kernel<true, true, false, 4>
-              : abl == 5 ? stft2048_power_kernel<true, true, false, 5>
-              : (abl == 6 || abl == 7 || abl == 8) ? stft2048_power_kernel<true, true, false, 6>
-              : abl == 9 ? stft2048_power_kernel<true, true, false, 9>
-              : abl == 10 ? stft2048_power_kernel<true, true, false, 10>
-              : abl == 11 ? stft2048_power_kernel<true, true, false, 11>
-              : abl == 12 ? stft2048_power_kernel<true, true, false, 12>
-              : abl == 13 ? stft2048_power_kernel<true, true, false, 13>
-              : abl == 14 ? stft2048_power_kernel<true, true, false, 14>
-                         : stft2048_power_kernel<true, true, false, 0>;
-  (void)aligned; (void)square; (void)strip;
-#else
-  // The ring-form kernel (whole 64-byte-aligned blocks: write traffic 1.07x instead of 1.3-1.4x the algorithmic bytes; same
-  // values bit for bit).  Measured 3 % behind the column kernel at C2 (1.5 GB), level with it at 8.9 GB (512 thirty-second
-  // clips) and steady at 430-450 Mframes/s from there to the 71 GB C5 batch, where the column kernel falls to 330-430 depending
-  // on the box (profiles/r04/c5_ring_sizes.log): it takes the launches whose input + output pass 8 GB.  SMX_POWER_RING=1 / 0 forces it.
-  const bool ring = !tg.fold_frames && !strip && env_flag("SMX_POWER_RING") == 1;   // the ring kernel (64-lane pipeline) only on request: its frames round differently from the 32-lane pipeline's
-  auto pick = [&](auto strip_tag) {
-    constexpr bool S = decltype(strip_tag)::value;
-    constexpr int F = SMX_RING_FLUSH_AT;
-    if (ring)
-      return aligned ? (square ? stft2048_power_ring_kernel<true, true, S, F> : stft2048_power_ring_kernel<true, false, S, F>)
-                     : (square ? stft2048_power_ring_kernel<false, true, S, F> : stft2048_power_ring_kernel<false, false, S, F>);
-    return aligned ? (square ? stft2048_power_kernel<true, true, S> : stft2048_power_kernel<true, false, S>)
-                   : (square ? stft2048_power_kernel<false, true, S> : stft2048_power_kernel<false, false, S>);
-  };
-  auto kernel = strip ? pick(std::true_type{}) : pick(std::false_type{});
 #endif
-  // The 32-lane pipeline (stft_fast_p32.hpp) is the power kernel; SMX_POWER_V1=1 keeps the 64-lane kernels above for A/B timing.
-  const bool v1 = env_flag("SMX_POWER_V1") == 1;
-  if (!v1 && !ring) {
+  (void)square;
+  // The power spectrogram at fft 2048: the 32-lane frame pipeline (stft_fast_p32.hpp).
+  {
     auto pick32 = [&](auto strip_tag) {
       constexpr bool S = decltype(strip_tag)::value;
       auto by_power = [&](auto al) {
@@ -1850,14 +1263,6 @@ void launch_interior(const StftJob &job, const FastTarget &tg, const float *x, i
     SMX_HIP_CHECK(hipGetLastError());
     return;
   }
-  SMX_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kernel),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)kFastLds));
-  unsigned threads = 1024;
-#ifdef SMX_DIAG
-  threads = (unsigned)diag_int("SMX_ABL_THREADS", 1024);   // ABLATE=12 only: fewer waves per SIMD, same work per wave
-#endif
-  SMX_LAUNCH(kernel, dim3((unsigned)a.blocks), dim3(threads), kFastLds, job.stream, a);
-  SMX_HIP_CHECK(hipGetLastError());
 }
 
 // frames [pa, pb) that touch a border: gather their padded span, then run the fused kernel on it
@@ -1882,7 +1287,7 @@ bool fast_eligible(const StftJob &job, bool power_face = false) {
   const smx_stft_config &c = *job.cfg;
   if (fast_path_disabled()) return false;
   const bool size_ok = c.fft_size == kN || (power_face && (c.fft_size == kN16 || c.fft_size == kN8) && diag_flag("SMX_POWER16_OFF") != 1 &&
-                                              (job.mode == OUT_POWER || env_flag("SMX_COMPLEX_V1") != 1));
+                                              true);
   if (!size_ok || job.in_bytes != 4 || job.interior != SMX_INTERIOR_F32) return false;
   if (diag_flag("SMX_GENERIC_2048") == 1) return false;   // diagnostic: time the stage-free generic kernels at fft 2048
   if (job.lead > 65535) return false;

@@ -195,41 +195,39 @@ def test_regression_gate_fast_kernels(fft, hop):
     check_clips(z, np.stack([w.real, w.imag], axis=-1), "transform %d" % fft)
 
 
-@pytest.mark.timeout(600)
-def test_ring_kernel_is_bit_identical_to_the_column_kernel():
-    """The two forms of the 64-lane pipeline (SMX_POWER_V1=1; kept for A/B timing beside the 32-lane power kernel):
-    SMX_POWER_RING=1 (whole 64-byte-aligned stores from a ring of the last 32 frames of every bin row) must produce the
-    column kernel's values bit for bit: same frame code, only the way the tile leaves LDS differs.  Geometries: ranges that
-    start mid-clip, partial last tiles, segments that cross clips, odd row pitches, every alignment, general powers."""
+def test_aligned_block_flush_is_bit_identical_to_the_plain_flush():
+    """The power and complex spectrograms at fft 2048 leave LDS in whole aligned 64- / 128-byte blocks (a row's values are
+    carried in registers until they complete a block: stft_fast_p32.hpp, SKEW).  SMX_POWER_SKEW=0 / SMX_COMPLEX_SKEW=0 select
+    the plain per-tile flush: same frame code, so the values must agree bit for bit -- over ranges that start mid-clip,
+    partial last tiles, ranges whose workgroups change clip, odd and even row pitches, every origin alignment, general powers."""
     code = """
 import json, sys, numpy as np
 sys.path.insert(0, %r)
 import torch
 from soundml_amd import Stft
-out = {}
-rng = np.random.default_rng(3)
-cases = [(3, 70000, 512, "centered", 2.0), (17, 33333, 512, "left", 2.0), (5, 9000, 300, "right", 1.0), (300, 5000, 512, "centered", 2.0),
-         (2, 480000, 512, "centered", 2.0), (1, 2048, 512, "left", 2.0), (7, 20001, 77, "centered", 0.7), (64, 48000, 1024, "centered", 2.0)]
-for i, (lead, n, hop, al, power) in enumerate(cases):
-    x = torch.from_numpy(rng.uniform(-1, 1, size=(lead, n)).astype(np.float32)).cuda()
-    c = Stft.Config.create(fft_size=2048, hop=hop, alignment=al)
-    out["p%%d" %% i] = Stft.power_spectrum(c, x, power).cpu().numpy()
-    total = Stft.frames(c, n)
-    if total > 40:
-        out["r%%d" %% i] = Stft.power_range(c, x, 3, total - 5, power).cpu().numpy()
-np.savez(sys.argv[1], **out)
+torch.manual_seed(3)
+c = Stft.Config.create(fft_size=2048, hop=512)
+out = []
+for clips, n in ((3, 16 * 512 * 3 + 100), (5, 40000), (2, 16 * 512 * 9), (7, 30001), (300, 16 * 512 * 2 + 7)):
+    x = (torch.rand(clips, n, device="cuda") * 2 - 1).float()
+    frames = Stft.frames(c, n)
+    for a, b in ((0, frames), (3, frames - 2), (5, 6), (1, min(frames, 40))):
+        for p in (2.0, 1.0, 0.7):
+            pw = Stft.power_range(c, x, a, b, p).contiguous()
+            out.append(int(pw.view(torch.int32).to(torch.int64).sum()))
+        z = torch.view_as_real(Stft.transform_range(c, x, a, b)).contiguous()
+        out.append(int(z.view(torch.int32).to(torch.int64).sum()))
+print(json.dumps(out))
 """ % ROOT
-    import tempfile
     res = []
-    for ring in ("0", "1"):
-        env = dict(os.environ, SMX_POWER_RING=ring, SMX_POWER_V1="1")
-        path = tempfile.mktemp(suffix=".npz")
-        subprocess.run([sys.executable, "-c", code, path], check=True, env=env, timeout=500)
-        res.append(dict(np.load(path)))
-        os.remove(path)
-    assert res[0].keys() == res[1].keys() and len(res[0]) >= 12
-    for k in res[0]:
-        assert np.array_equal(res[0][k], res[1][k]), k
+    for skew in ("1", "0"):
+        env = dict(os.environ)
+        if skew == "0":
+            env.update(SMX_POWER_SKEW="0", SMX_COMPLEX_SKEW="0")
+        out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=500, env=env, cwd=ROOT)
+        assert out.returncode == 0, out.stdout + out.stderr
+        res.append(json.loads(out.stdout.strip().splitlines()[-1]))
+    assert res[0] == res[1]
 
 
 @pytest.mark.timeout(600)

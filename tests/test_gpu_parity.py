@@ -744,6 +744,35 @@ def test_griffin_lim_fast_path_and_messages():
     assert str(e.value).startswith("griffin_lim: cannot start from a [1; 1025; 40] phase for a [2; 1025; 40] spectrogram")
 
 
+def test_griffin_lim_at_the_reference_defaults_float32_interior():
+    """The reference's defaults (stft.ml:961-964: 32 iterations, momentum 0.99) under the float32 interior, with a bound that is
+    derived, not tuned.  The accelerated update forms c_k - 0.99 c_(k-1), which cancels to ~1 % of |c|, so whatever
+    perturbs the spectra is amplified iteration after iteration; the float64 ORACLE itself moves by `sens` when the
+    magnitudes move by ONE float32 ulp.  The float32 interior rounds 64 transforms (32 analysis + 32 synthesis) to float32,
+    i.e. injects a perturbation of that size 64 times: the gate is 64 x sens (and never tighter than the 1e-3 l2 of the
+    short runs above).  `set_interior("float64")` is the reference's arithmetic and must sit at 1e-5."""
+    rng = np.random.default_rng(99)
+    x = rng.uniform(-1, 1, size=(2, 24000)).astype(np.float32)
+    c = Stft.Config.create(fft_size=2048, hop=512)
+    o = O.stft_config(2048, hop=512)
+    z = Stft.transform(c, x)
+    mag = np.abs(z).astype(np.float32)
+    phase = rng.uniform(-np.pi, np.pi, size=z.shape).astype(np.float32)   # (the default is a random phase: stft.ml:976-984)
+    want = O.griffin_lim(o, mag, 32, 0.99, phase, None)
+    moved = O.griffin_lim(o, np.nextafter(mag, np.float32(np.inf)), 32, 0.99, phase, None)
+    sens = np.linalg.norm(moved - want) / np.linalg.norm(want)
+    got = Stft.griffin_lim(c, mag, n_iter=32, momentum=0.99, init=phase)
+    rel = np.linalg.norm(got - want) / np.linalg.norm(want)
+    assert np.isfinite(got).all()
+    assert rel <= max(1e-3, 64 * sens), (rel, sens)
+    S.set_interior("float64")
+    try:
+        strict = Stft.griffin_lim(c, mag, n_iter=32, momentum=0.99, init=phase)
+    finally:
+        S.set_interior("float32")
+    assert np.linalg.norm(strict - want) <= 1e-5 * np.linalg.norm(want)
+
+
 @pytest.mark.parametrize("fft,hop", [(1024, 256), (512, 100), (4096, 1024)])
 def test_griffin_lim_other_sizes(fft, hop):
     """The folded loop on the Stockham frames kernel (fft 512 .. 4096, any hop): against the oracle after 6 round
@@ -1343,6 +1372,10 @@ def test_resample_shape_is_the_reference_stub_bit_for_bit(l, m):
     got = Resample.shape(spec, oh, n, l, m)
     assert np.array_equal(got, c_oracle.resample_shape(spec, oh, n, l, m))
     assert np.array_equal(got, O.ols_shape(spec, oh, n, l, m))
+    # the reference's own compiled `soundml_resample_shape_run` (oracle/_ref: built from the reference's source where it lies,
+    # the .so travels to the GPU box) is the checker proper
+    assert c_oracle.have_ref()
+    assert np.array_equal(got, c_oracle.ref_resample_shape(spec, oh, n, l, m))
     assert np.array_equal(Resample.shape(spec[3:4], oh, n, l, m), got[3:4])
 
 

@@ -1,5 +1,5 @@
 """Interleaved timing of ONE build under several environments (options the library reads per launch):
-  python tools/ab_env.py <lib.so> "" "SMX_POWER_V1=1" "SMX_NOSTORE=1" "SMX_POWER_V1=1,SMX_NOSTORE=1"
+  python tools/ab_env.py <lib.so> "" "SMX_POWER_SKEW=0" "SMX_NOSTORE=1"
 C2 power spectrogram (256 x 480000), HIP events, median / min over interleaved rounds.  AB_POWER=<p> in a variant sets the
 exponent of |X|^p for that variant (default 2)."""
 import ctypes, os, sys

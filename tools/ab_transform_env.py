@@ -1,5 +1,5 @@
 """Interleaved timing of Stft.transform (C2: 256 x 480000, fft 2048 / hop 512, complex64 out) under several environments:
-  python tools/ab_transform_env.py "" "SMX_COMPLEX_V1=1"     (AB_N: other clip lengths, AB_FFT: 1024 / 512)"""
+  python tools/ab_transform_env.py "" "SMX_COMPLEX_SKEW=0"   (AB_N: other clip lengths, AB_FFT: 1024 / 512)"""
 import os, sys, ctypes
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch

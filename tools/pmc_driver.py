@@ -1,6 +1,6 @@
 """Driver for tools/profile_round.sh: a few launches of every hot kernel of the BASELINE configurations, nothing else on
-the device (C2 power spectrogram on the 32-lane and the 64-lane kernel, C3 fused mel, Mel.apply, the power spectrogram at fft 1024 and
-512 on 256 clips of C1's length, C4 FIR)."""
+the device (C2 power spectrogram, C3 fused mel, Mel.apply, Stft.transform and Stft.invert of the C2 batch, the power spectrogram
+at fft 1024 and 512 on 256 clips of C1's length, C4 FIR)."""
 import ctypes, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -14,6 +14,7 @@ mc = Mel.Config.create(n_mels=128, sample_rate=48000, fft_size=2048)
 frames = Stft.frames(sc, 480000)
 out = torch.empty(256, 1025, frames, device="cuda")
 mout = torch.empty(256, 128, frames, device="cuda")
+zc = torch.empty(256, 1025, frames, 2, device="cuda")
 h = Fir.design_lowpass(8192, 0.25, 100.0)
 plan = Fir.Plan.create(h)
 c1k = Stft.Config.create(fft_size=1024, hop=256)      # the lanes kernels at the sizes of tools/bench_extra.py
@@ -26,11 +27,9 @@ xs = torch.rand(8, 2880000, device="cuda") * 2 - 1
 ys = torch.empty_like(xs)
 reps = int(os.environ.get("REPS", "4"))
 for _ in range(reps):
-    os.environ.pop("SMX_POWER_RING", None)
     check(lib.smx_stft_power_range_f32_dev(sc._h, vp(x.data_ptr()), 256, 480000, 480000, 0, frames, 2.0, vp(out.data_ptr()), None))
-    os.environ["SMX_POWER_V1"] = "1"      # the 64-lane kernel, for the record beside the 32-lane one
-    check(lib.smx_stft_power_range_f32_dev(sc._h, vp(x.data_ptr()), 256, 480000, 480000, 0, frames, 2.0, vp(out.data_ptr()), None))
-    os.environ.pop("SMX_POWER_V1", None)
+    check(lib.smx_stft_transform_range_f32_dev(sc._h, vp(x.data_ptr()), 256, 480000, 480000, 0, frames, vp(zc.data_ptr()), None))
+    xr = Stft.invert(sc, torch.view_as_complex(zc))   # (allocates its output: the synthesis kernel is what is profiled)
     check(lib.smx_mel_spectrogram_f32_dev(sc._h, mc._h, vp(x.data_ptr()), 256, 480000, 480000, 2.0, vp(mout.data_ptr()), None))
     check(lib.smx_mel_apply_f32_dev(mc._h, vp(out.data_ptr()), 256, 1025, frames, vp(mout.data_ptr()), None))
     check(lib.smx_stft_power_range_f32_dev(c1k._h, vp(x1.data_ptr()), 256, 441000, 441000, 0, f1k, 2.0, vp(o1k.data_ptr()), None))

@@ -2,7 +2,7 @@
 # Runs ON THE GPU BOX (via gpurun): the round's profile set.
 #   tools/profile_round.sh <tag>     ->  gpurun_out/<tag>/{kernel_stats.csv, bench_n1.json, pmc.json, hot_kernel_stats.csv}
 # 1. rocprofv3 --kernel-trace --stats of the bench command (the roofline's kernel duration must agree with it)
-# 2. PMC passes (one counter group per pass, --pmc alone) over tools/pmc_driver.py: every hot kernel of C2 / C3 / C4
+# 2. PMC passes (one counter group per pass, --pmc alone) over tools/pmc_driver.py: every hot kernel of C2 (power, complex, inverse) / C3 / C4
 set -u
 TAG=${1:-prof}
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
@@ -35,7 +35,7 @@ rows = collections.defaultdict(lambda: collections.defaultdict(list))
 for f in glob.glob(out_dir + '/pmc_g*/**/*counter_collection.csv', recursive=True):
     for r in csv.DictReader(open(f)):
         k = r['Kernel_Name']
-        if not re.search(r'stft2048|stft_power_lanes|mel_apply|fir_ols', k):
+        if not re.search(r'stft2048|stft_power_lanes|mel_apply|fir_ols|istft2048', k):
             continue
         k = re.sub(r'\(smx::.*', '', k.replace('void smx::(anonymous namespace)::', ''))
         rows[k][r['Counter_Name']].append(float(r['Counter_Value']))
