@@ -44,13 +44,11 @@ void set_last_error(const std::string &message);
   } while (0)
 
 // ---- environment switches ------------------------------------------------------------------------------------------
-// The shipped library reads nine variables, each once per use and parsed ONE way (env_flag: unset -> -1, "0" / "" /
+// The shipped library reads seven variables, each once per use and parsed ONE way (env_flag: unset -> -1, "0" / "" /
 // "false" / "off" -> 0, anything else -> 1); none alters results except by selecting another kernel of the same contract:
 //   SMX_DISABLE_FAST   the generic kernels instead of the hand-laid ones (tests: two implementations of one contract)
-//   SMX_POWER_V1       the 64-lane fft-2048 power kernel instead of the 32-lane one (A/B timing, tests)
-//   SMX_POWER_RING     with SMX_POWER_V1: its ring form (whole 64-byte-aligned stores)
-//   SMX_MEL_V1         the 64-lane fused mel kernel instead of the 32-lane one (A/B timing, tests)
-//   SMX_COMPLEX_V1     the 64-lane complex kernel instead of the 32-lane one (A/B timing)
+//   SMX_POWER_SKEW=0   fft-2048 power spectrogram: the plain per-tile flush instead of whole aligned 64-byte blocks (tests, A/B timing)
+//   SMX_COMPLEX_SKEW=0 fft-2048 Stft.transform: the plain per-tile flush instead of whole aligned 128-byte lines (tests, A/B timing)
 //   SMX_MIXED_OFF      chirp-z instead of the mixed-radix kernels (tests: the two agree)
 //   SMX_HOST_TRACE     print where a host-pointer call's time goes
 //   SMX_COPY_THREADS / SMX_COPY_PLAIN   host <-> device staging of the host-pointer entry points
@@ -164,7 +162,7 @@ struct smx_stft_config {
 
 namespace smx {
 struct MelFusedPlan {      // per device; built lazily by stft_fast.hip
-  void *items = nullptr;   // MelItem[16]
+  void *items = nullptr;   // Mel32Item[8][8]
   float *w_mfma = nullptr; // MFMA A operands in lane order
   int state = 0;           // 0 not built, 1 usable, -1 this configuration is not eligible
 };
@@ -190,14 +188,13 @@ struct smx_mel_config {
     int *block_lo = nullptr, *block_hi = nullptr;   // band per 32-row block
   };
   const Tables &tables() const;
-  const smx::MelFusedPlan &fused_plan() const;   // stft_fast.hip
   const smx::MelFusedPlan &fused32_plan() const; // stft_fast.hip: items of the 32-lane mel kernel (items = Mel32Item[8][8])
   ~smx_mel_config();
 
  private:
   mutable std::mutex mutex_;
   mutable std::map<int, Tables> tables_;
-  mutable std::map<int, smx::MelFusedPlan> fused_, fused32_;
+  mutable std::map<int, smx::MelFusedPlan> fused32_;
 };
 
 // Chroma.Config.t (chroma.ml:95-107): the [n_chroma; bins] projection matrix, float64, built once on the host

@@ -507,10 +507,6 @@ smx_mel_config::~smx_mel_config() {
     (void)hipFree(kv.second.block_hi);
     (void)hipFree(kv.second.tile_hi);
   }
-  for (auto &kv : fused_) {
-    (void)hipFree(kv.second.items);
-    (void)hipFree(kv.second.w_mfma);
-  }
   for (auto &kv : fused32_) {
     (void)hipFree(kv.second.items);
     (void)hipFree(kv.second.w_mfma);

@@ -1,5 +1,5 @@
 """Interleaved timing of the fused mel spectrogram (C3: 256 x 480000, 128 mels) under several environments:
-  python tools/ab_mel_env.py "" "SMX_MEL_V1=1"      (AB_MELS, AB_SR: other filterbanks; AB_FFT, AB_N: other sizes; switches as the build reads them)"""
+  python tools/ab_mel_env.py ""                  (AB_MELS, AB_SR: other filterbanks; AB_FFT, AB_N: other sizes; switches as the build reads them)"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import ctypes, torch
