@@ -123,33 +123,14 @@ __device__ __forceinline__ void fill_tablesL(const FastArgs &a, const LdsL<LL> &
   if (tid < 2) { lds.filled[tid * P::TS] = 0u; lds.drained[tid * P::TS] = 0u; }
 }
 
-// 8-point forward DFT, natural order in and out (operation by operation, as p32_fft16)
-__device__ __forceinline__ void p32_fft8(c32 (&v)[8]) {
-#pragma clang fp contract(off)
-  constexpr float hh = (float)0.70710678118654752;
-  p32_fft4(v[0], v[2], v[4], v[6]);
-  p32_fft4(v[1], v[3], v[5], v[7]);
-  const c32 o1 = p32_cmul(v[3], hh, -hh);     // W8^1
-  const c32 o2 = {v[5].y, -v[5].x};           // W8^2 = -i
-  const c32 o3 = p32_cmul(v[7], -hh, -hh);    // W8^3
-  const c32 e0 = v[0], e1 = v[2], e2 = v[4], e3 = v[6], o0 = v[1];
-  v[0] = {e0.x + o0.x, e0.y + o0.y};
-  v[4] = {e0.x - o0.x, e0.y - o0.y};
-  v[1] = {e1.x + o1.x, e1.y + o1.y};
-  v[5] = {e1.x - o1.x, e1.y - o1.y};
-  v[2] = {e2.x + o2.x, e2.y + o2.y};
-  v[6] = {e2.x - o2.x, e2.y - o2.y};
-  v[3] = {e3.x + o3.x, e3.y + o3.y};
-  v[7] = {e3.x - o3.x, e3.y - o3.y};
-}
-
 // 64 / LL frames (one per LL lanes): raw samples -> window -> FFT(M complex) -> post-pass -> |X|^p in the frames' columns of
 // `tile`; the hooks of `mid` are those of frame32_to_tile.
 template <int LL, int PMODE, class Mid, bool CPLX = false>
 __device__ __forceinline__ void frameL_to_tile(const FastArgs &a, const LaneL &L, float2 (&raw)[32], float *tile, const Mid &mid) {
 #pragma clang fp contract(off)
+  // (the arithmetic on packed pairs, one generated inline-assembly statement per stage: stft_pk_fft.inc, as frame32_to_tile)
   using P = PL<LL>;
-  c32 v[32], t[32];
+  f2 v[32], t[32];
 #pragma unroll
   for (int m0 = 0; m0 < 16; m0 += 8) {
     float4 win[8];
@@ -157,8 +138,8 @@ __device__ __forceinline__ void frameL_to_tile(const FastArgs &a, const LaneL &L
     for (int m = 0; m < 8; ++m) win[m] = L.win_l[LL * (m0 + m)];
 #pragma unroll
     for (int m = 0; m < 8; ++m) {
-      v[2 * (m0 + m)] = {raw[2 * (m0 + m)].x * win[m].x, raw[2 * (m0 + m)].y * win[m].y};
-      v[2 * (m0 + m) + 1] = {raw[2 * (m0 + m) + 1].x * win[m].z, raw[2 * (m0 + m) + 1].y * win[m].w};
+      v[2 * (m0 + m)] = f2{raw[2 * (m0 + m)].x, raw[2 * (m0 + m)].y} * f2{win[m].x, win[m].y};
+      v[2 * (m0 + m) + 1] = f2{raw[2 * (m0 + m) + 1].x, raw[2 * (m0 + m) + 1].y} * f2{win[m].z, win[m].w};
     }
     SMX_FENCE();
   }
@@ -168,22 +149,30 @@ __device__ __forceinline__ void frameL_to_tile(const FastArgs &a, const LaneL &L
 #pragma unroll
     for (int m = 0; m < 15; ++m) tw[m] = L.twA_l[LL * m];
     const float2 tw31 = L.twA31_l[0];
-    fft32(v, [&] { SMX_FENCE(); mid.early(); SMX_FENCE(); });
+    pk_fft32(v, [&] { SMX_FENCE(); mid.early(); SMX_FENCE(); });
     SMX_FENCE();
     mid.before_cells();
     float *const wr = tile + opaque32(L.own);
     float *const wr_hi = wr + 16 * P::CellPitch;
-    wr[0] = v[0].x;
+    auto put = [&](int j) { (j < 16 ? wr : wr_hi)[P::CellPitch * (j & 15)] = v[j].x; };
+#define SMX_TWV(m) f2{tw[m].x, tw[m].y}, f2{tw[m].z, tw[m].w}
+    put(0);
+    pk_twiddle8(v[1], v[2], v[3], v[4], v[5], v[6], v[7], v[8], SMX_TWV(0), SMX_TWV(1), SMX_TWV(2), SMX_TWV(3));
 #pragma unroll
-    for (int m = 0; m < 15; ++m) {
-      v[2 * m + 1] = p32_cmul(v[2 * m + 1], tw[m].x, tw[m].y);
-      v[2 * m + 2] = p32_cmul(v[2 * m + 2], tw[m].z, tw[m].w);
-      (2 * m + 1 < 16 ? wr : wr_hi)[P::CellPitch * ((2 * m + 1) & 15)] = v[2 * m + 1].x;
-      (2 * m + 2 < 16 ? wr : wr_hi)[P::CellPitch * ((2 * m + 2) & 15)] = v[2 * m + 2].x;
-      if ((m & 1) == 1) SMX_FENCE();
-    }
-    v[31] = p32_cmul(v[31], tw31.x, tw31.y);
-    wr_hi[P::CellPitch * 15] = v[31].x;
+    for (int j = 1; j <= 8; ++j) put(j);
+    SMX_FENCE();
+    pk_twiddle8(v[9], v[10], v[11], v[12], v[13], v[14], v[15], v[16], SMX_TWV(4), SMX_TWV(5), SMX_TWV(6), SMX_TWV(7));
+#pragma unroll
+    for (int j = 9; j <= 16; ++j) put(j);
+    SMX_FENCE();
+    pk_twiddle8(v[17], v[18], v[19], v[20], v[21], v[22], v[23], v[24], SMX_TWV(8), SMX_TWV(9), SMX_TWV(10), SMX_TWV(11));
+#pragma unroll
+    for (int j = 17; j <= 24; ++j) put(j);
+    SMX_FENCE();
+    pk_twiddle7(v[25], v[26], v[27], v[28], v[29], v[30], v[31], SMX_TWV(12), SMX_TWV(13), SMX_TWV(14), f2{tw31.x, tw31.y});
+#pragma unroll
+    for (int j = 25; j <= 31; ++j) put(j);
+#undef SMX_TWV
   }
   SMX_FENCE();
   float *const wr = tile + opaque32(L.own);
@@ -201,20 +190,20 @@ __device__ __forceinline__ void frameL_to_tile(const FastArgs &a, const LaneL &L
   SMX_FENCE();
   // B: 32 / LL radix-LL transforms over l; register u = a + (32 / LL) q holds Z[lam + LL u]
   if constexpr (LL == 16) {
-    c32 e[16], o[16];
+    f2 e[16], o[16];
 #pragma unroll
     for (int i = 0; i < 16; ++i) { e[i] = t[i]; o[i] = t[16 + i]; }
-    p32_fft16(e);
-    p32_fft16(o);
+    pk_fft16(e);
+    pk_fft16(o);
 #pragma unroll
     for (int q = 0; q < 16; ++q) { t[2 * q] = e[q]; t[2 * q + 1] = o[q]; }
   } else {
-    c32 g[4][8];
+    f2 g[4][8];
 #pragma unroll
     for (int aa = 0; aa < 4; ++aa) {
 #pragma unroll
       for (int i = 0; i < 8; ++i) g[aa][i] = t[8 * aa + i];
-      p32_fft8(g[aa]);
+      pk_fft8(g[aa]);
     }
 #pragma unroll
     for (int q = 0; q < 8; ++q)
@@ -223,55 +212,70 @@ __device__ __forceinline__ void frameL_to_tile(const FastArgs &a, const LaneL &L
   }
   SMX_FENCE();
   // P: partners through the cells (as frame32_to_tile, LL lanes)
-  float px[16], py[16];
+  f2 pp[16];
   const float *const xr = tile + opaque32(L.xr);
 #pragma unroll
   for (int q = 16; q < 32; ++q) wr[P::CellPitch * (q - 16)] = t[q].x;
   wr_hi[0] = t[0].x;
 #pragma unroll
-  for (int s = 0; s < 16; ++s) px[s] = xr[P::CellPitch * (15 - s)];
+  for (int s = 0; s < 16; ++s) pp[s].x = xr[P::CellPitch * (15 - s)];
 #pragma unroll
   for (int q = 16; q < 32; ++q) wr[P::CellPitch * (q - 16)] = t[q].y;
   wr_hi[0] = t[0].y;
 #pragma unroll
-  for (int s = 0; s < 16; ++s) py[s] = xr[P::CellPitch * (15 - s)];
+  for (int s = 0; s < 16; ++s) pp[s].y = xr[P::CellPitch * (15 - s)];
   float4 tw[8];
 #pragma unroll
   for (int m = 0; m < 8; ++m) tw[m] = L.twP_l[LL * m];
   SMX_FENCE();
   mid.after_exchange_issue();
   SMX_FENCE();
-  auto power_of = [&](float re, float im) { return power_from_square<PMODE>(__builtin_fmaf(re, re, im * im), a); };
   // CPLX: the spectrum itself, real parts in `tile`, imaginary parts in the plane after it (the other tile buffer)
   {   // bin M/2 (lane 0, register 16): X = 2 conj(Z)
-    const float zx = t[16].x + t[16].x, zy = t[16].y + t[16].y;
+    const f2 z = t[16] + t[16];
     if constexpr (CPLX) {
-      tile[opaque32(L.self)] = zx;
-      tile[P::TileFloats + opaque32(L.self)] = -zy;
+      tile[opaque32(L.self)] = z.x;
+      tile[P::TileFloats + opaque32(L.self)] = -z.y;
     } else {
-      tile[opaque32(L.self)] = power_of(zx, zy);
+      tile[opaque32(L.self)] = power_from_square<PMODE>(__builtin_fmaf(z.x, z.x, z.y * z.y), a);
     }
   }
   float *const rk = wr;                        // row l + LL s
   float *const rm = tile + opaque32(L.rm);     // row (LL - l) + LL (31 - s) = rm base + LL (15 - s)
-#pragma unroll
-  for (int s = 0; s < 16; ++s) {
-    const float wx = (s & 1) ? tw[s >> 1].z : tw[s >> 1].x, wy = (s & 1) ? tw[s >> 1].w : tw[s >> 1].y;
-    const c32 e = {t[s].x + px[s], t[s].y - py[s]};
-    const c32 d = {t[s].x - px[s], t[s].y + py[s]};
-    const float tr = __builtin_fmaf(wx, d.y, wy * d.x);
-    const float ti = __builtin_fmaf(wy, d.y, -(wx * d.x));
-    if constexpr (CPLX) {   // X[k] = E + T, X[M - k] = conj(E - T)
-      rk[P::RowPitch * s] = e.x + tr;
-      rk[P::TileFloats + P::RowPitch * s] = e.y + ti;
-      rm[P::RowPitch * (15 - s)] = e.x - tr;
-      rm[P::TileFloats + P::RowPitch * (15 - s)] = ti - e.y;
+  auto wtw = [&](int s) { return (s & 1) ? f2{tw[s >> 1].z, tw[s >> 1].w} : f2{tw[s >> 1].x, tw[s >> 1].y}; };
+  auto put = [&](int s, f2 re, f2 im) {
+    if constexpr (CPLX) {
+      rk[P::RowPitch * s] = re.x;
+      rk[P::TileFloats + P::RowPitch * s] = im.x;
+      rm[P::RowPitch * (15 - s)] = re.y;
+      rm[P::TileFloats + P::RowPitch * (15 - s)] = im.y;
     } else {
-    rk[P::RowPitch * s] = power_of(e.x + tr, e.y + ti);
-    rm[P::RowPitch * (15 - s)] = power_of(e.x - tr, e.y - ti);
+      rk[P::RowPitch * s] = power_from_square<PMODE>(re.x, a);
+      rm[P::RowPitch * (15 - s)] = power_from_square<PMODE>(re.y, a);
     }
-    if (s == SMX_P32_STORE_AT || s == SMX_P32_LOAD_AT) { SMX_FENCE(); mid.postpass_at(s); SMX_FENCE(); }
-  }
+  };
+#define SMX_PA(s) t[s], pp[s], wtw(s)
+  f2 r[6], q[6];
+  if constexpr (CPLX) pk_post_cplx2(SMX_PA(0), SMX_PA(1), r[0], q[0], r[1], q[1]);
+  else pk_post_power2(SMX_PA(0), SMX_PA(1), r[0], r[1]);
+#pragma unroll
+  for (int i = 0; i < 2; ++i) put(i, r[i], q[i]);
+  SMX_FENCE(); mid.postpass_at(1); SMX_FENCE();
+  if constexpr (CPLX) pk_post_cplx4(SMX_PA(2), SMX_PA(3), SMX_PA(4), SMX_PA(5), r[0], q[0], r[1], q[1], r[2], q[2], r[3], q[3]);
+  else pk_post_power4(SMX_PA(2), SMX_PA(3), SMX_PA(4), SMX_PA(5), r[0], r[1], r[2], r[3]);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) put(2 + i, r[i], q[i]);
+  SMX_FENCE(); mid.postpass_at(5); SMX_FENCE();
+  if constexpr (CPLX) pk_post_cplx5(SMX_PA(6), SMX_PA(7), SMX_PA(8), SMX_PA(9), SMX_PA(10), r[0], q[0], r[1], q[1], r[2], q[2], r[3], q[3], r[4], q[4]);
+  else pk_post_power5(SMX_PA(6), SMX_PA(7), SMX_PA(8), SMX_PA(9), SMX_PA(10), r[0], r[1], r[2], r[3], r[4]);
+#pragma unroll
+  for (int i = 0; i < 5; ++i) put(6 + i, r[i], q[i]);
+  if constexpr (CPLX) pk_post_cplx5(SMX_PA(11), SMX_PA(12), SMX_PA(13), SMX_PA(14), SMX_PA(15), r[0], q[0], r[1], q[1], r[2], q[2], r[3], q[3], r[4], q[4]);
+  else pk_post_power5(SMX_PA(11), SMX_PA(12), SMX_PA(13), SMX_PA(14), SMX_PA(15), r[0], r[1], r[2], r[3], r[4]);
+#pragma unroll
+  for (int i = 0; i < 5; ++i) put(11 + i, r[i], q[i]);
+#undef SMX_PA
+  SMX_FENCE(); mid.postpass_at(15); SMX_FENCE();
 }
 
 // raw samples of the lane's frame: z[n] = (x[2n], x[2n+1]), n = l + LL j; `src` is the frame's first sample (per lane)

@@ -196,8 +196,8 @@ def test_regression_gate_fast_kernels(fft, hop):
 
 
 def test_aligned_block_flush_is_bit_identical_to_the_plain_flush():
-    """The power and complex spectrograms at fft 2048 leave LDS in whole aligned 64- / 128-byte blocks (a row's values are
-    carried in registers until they complete a block: stft_fast_p32.hpp, SKEW).  SMX_POWER_SKEW=0 / SMX_COMPLEX_SKEW=0 select
+    """The power spectrograms at fft 2048 / 1024 / 512 and the complex one at fft 2048 leave LDS in whole aligned 64- / 128-byte
+    blocks (a row's values are carried in registers until they complete a block: stft_fast_p32.hpp, stft_fast_p16.hpp, SKEW).  SMX_POWER_SKEW=0 / SMX_COMPLEX_SKEW=0 select
     the plain per-tile flush: same frame code, so the values must agree bit for bit -- over ranges that start mid-clip,
     partial last tiles, ranges whose workgroups change clip, odd and even row pitches, every origin alignment, general powers."""
     code = """
@@ -206,17 +206,19 @@ sys.path.insert(0, %r)
 import torch
 from soundml_amd import Stft
 torch.manual_seed(3)
-c = Stft.Config.create(fft_size=2048, hop=512)
 out = []
-for clips, n in ((3, 16 * 512 * 3 + 100), (5, 40000), (2, 16 * 512 * 9), (7, 30001), (300, 16 * 512 * 2 + 7)):
-    x = (torch.rand(clips, n, device="cuda") * 2 - 1).float()
-    frames = Stft.frames(c, n)
-    for a, b in ((0, frames), (3, frames - 2), (5, 6), (1, min(frames, 40))):
-        for p in (2.0, 1.0, 0.7):
-            pw = Stft.power_range(c, x, a, b, p).contiguous()
-            out.append(int(pw.view(torch.int32).to(torch.int64).sum()))
-        z = torch.view_as_real(Stft.transform_range(c, x, a, b)).contiguous()
-        out.append(int(z.view(torch.int32).to(torch.int64).sum()))
+for fft in (2048, 1024, 512):
+    hop = fft // 4
+    c = Stft.Config.create(fft_size=fft, hop=hop)
+    for clips, n in ((3, 16 * hop * 3 + 100), (5, 40000), (2, 64 * hop * 9), (7, 30001), (300, 64 * hop * 2 + 7)):
+        x = (torch.rand(clips, n, device="cuda") * 2 - 1).float()
+        frames = Stft.frames(c, n)
+        for a, b in ((0, frames), (3, frames - 2), (5, 6), (1, min(frames, 70))):
+            for p in (2.0, 1.0, 0.7):
+                pw = Stft.power_range(c, x, a, b, p).contiguous()
+                out.append(int(pw.view(torch.int32).to(torch.int64).sum()))
+            z = torch.view_as_real(Stft.transform_range(c, x, a, b)).contiguous()
+            out.append(int(z.view(torch.int32).to(torch.int64).sum()))
 print(json.dumps(out))
 """ % ROOT
     res = []

@@ -159,6 +159,37 @@ def gen_fft16():
     return "\n".join(lines)
 
 
+def gen_fft8():
+    """p32_fft8 (stft_fast_p16.hpp): two 4-point transforms over the even / odd inputs, W8 twiddles, combining pass"""
+    b = Block("pk_fft8")
+    L = {i: b.slot("io", "s%d" % i) for i in range(8)}
+    free = [b.slot("tmp", "s%d" % (8 + i)) for i in range(4)]
+    table = {"kH": (HH, HH)}
+    fft4_pair(b, L, free, [(0, 2, 4, 6, False), (1, 3, 5, 7, False)])
+    cmul_group(b, L, free, [(3, HH, -HH), (7, -HH, -HH)], table)       # o1 = W8^1 v3, o3 = W8^3 v7; o2 = -i v5 is folded below
+    # v[k] = e_k + o_k, v[k + 4] = e_k - o_k with e = (v0, v2, v4, v6), o = (v1, o1, -i v5, o3)
+    out = {}
+    for g in ((0, 1), (2, 3)):
+        st = [(k, free.pop()) for k in g]
+        for k, t in st:
+            (b.add_mi if k == 2 else b.add)(t, L[2 * k], L[2 * k + 1])
+        for k, t in st:
+            (b.sub_mi if k == 2 else b.sub)(L[2 * k + 1], L[2 * k], L[2 * k + 1])
+        for k, t in st:
+            out[k] = t
+            out[k + 4] = L[2 * k + 1]
+            free.append(L[2 * k])
+    lines = ["// 8-point forward DFT, natural order in and out: p32_fft8's operations on packed pairs, one statement",
+             "__device__ __forceinline__ void pk_fft8(f2 (&v)[8]) {",
+             "  const f2 kH = {(float)%r, (float)%r};" % (HH, HH),
+             "  f2 " + ", ".join("s%d = v[%d]" % (i, i) for i in range(8)) + ", s8, s9, s10, s11;"]
+    lines.append(b.text().rstrip("\n"))
+    for i in range(8):
+        lines.append("  v[%d] = s%d;" % (i, out[i]))
+    lines.append("}")
+    return "\n".join(lines)
+
+
 def gen_combine(half):
     """v[k] = e[k] + W32^k o[k], v[k + 16] = e[k] - W32^k o[k] for k = 8 half .. 8 half + 7"""
     import math
@@ -280,6 +311,7 @@ if __name__ == "__main__":
     print("// GENERATED by tools/gen/gen_pk_fft.py -- do not edit; see that file for the why and the register plans.")
     print("// Included by stft_fast_p32.hpp (inside namespace smx::<anon>); f2 = float ext_vector_type(2), an aligned register pair.")
     print(gen_fft16())
+    print(gen_fft8())
     print(gen_combine(0))
     print(gen_combine(1))
     for n in (8, 7):
