@@ -6,10 +6,11 @@
 Usage: python tools/derive_profile_json.py r04"""
 import json, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-rnd = sys.argv[1] if len(sys.argv) > 1 else "r05"
+rnd = sys.argv[1] if len(sys.argv) > 1 else "r06"
 src = os.path.join(ROOT, "profiles", rnd, "pmc_hot_kernels.json")
 k = json.load(open(src))["kernels"]
-hkey = next((n for n in ("stft2048_power32_kernel<true, 2, false>", "stft2048_power32_kernel<true, true, false>") if n in k), "stft2048_power_kernel<true, true, false>")
+hkey = next(n for n in ("stft2048_power32_kernel<true, 2, false, 1>", "stft2048_power32_kernel<true, 2, false, 2>", "stft2048_power32_kernel<true, 2, false, 0>",
+                        "stft2048_power32_kernel<true, 2, false>") if n in k)
 head = k[hkey]
 c = head["counters"]
 read_b, write_b = int(c["FETCH_SIZE"] * 1024 * 2), int(c["WRITE_SIZE"] * 1024)
@@ -24,10 +25,30 @@ json.dump({"bytes_per_launch": read_b + write_b, "read_bytes": read_b, "write_by
            "source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes (tools/profile_round.sh) -> profiles/%s/pmc_hot_kernels.json" % rnd,
            "kernel": hkey, "kernel_us_in_profile": round(head["duration"]["avg_us"], 1) if head.get("duration") else None,
            "commit": os.popen("git -C %s rev-parse --short HEAD 2>/dev/null" % ROOT).read().strip() or None,
-           "box": "one MI355X gpurun box (fresh lease; boxes differ by +-10 % in kernel time)"}, open(os.path.join(ROOT, "profiles", "hbm_traffic.json"), "w"), indent=1)
+           "box": "one MI355X gpurun box (fresh lease; boxes differ by +-10 % in kernel time)",
+           "per_kernel": None}, open(os.path.join(ROOT, "profiles", "hbm_traffic.json"), "w"), indent=1)
+# every hot kernel: counter traffic against its algorithmic bytes (the launches of tools/pmc_driver.py)
+FR2048, FR1K, FR512 = 938, 1723, 3446
+ALGO = {"stft2048_power32": 256 * FR2048 * 6148, "stft2048_complex32": 256 * FR2048 * (2048 + 8200), "stft2048_mel32": 256 * FR2048 * (2048 + 512),
+        "istft2048": 256 * (FR2048 * 8200 + 480000 * 4), "mel_apply_mfma": 256 * FR2048 * (4100 + 512), "fir_ols_split": 8 * 2880000 * 8,
+        "stft_power_lanes_kernel<16": 256 * FR1K * (1024 + 2052), "stft_power_lanes_kernel<8": 256 * FR512 * (512 + 1028)}
+table = {}
+for name, v in k.items():
+    cc = v["counters"]
+    if "FETCH_SIZE" not in cc or "WRITE_SIZE" not in cc:
+        continue
+    algo_b = next((b for key, b in ALGO.items() if name.startswith(key)), None)
+    rb, wb = int(cc["FETCH_SIZE"] * 1024 * 2), int(cc["WRITE_SIZE"] * 1024)
+    table[name] = {"read_bytes_fetch_x2": rb, "write_bytes": wb, "algorithmic_bytes": algo_b,
+                   "traffic_over_algorithmic": round((rb + wb) / algo_b, 3) if algo_b else None,
+                   "avg_us": round(v["duration"]["avg_us"], 1) if v.get("duration") else None,
+                   "lds_bank_conflict_over_active": round(cc["SQ_LDS_BANK_CONFLICT"] / cc["SQ_LDS_IDX_ACTIVE"], 4) if cc.get("SQ_LDS_IDX_ACTIVE") else None}
+tj = json.load(open(os.path.join(ROOT, "profiles", "hbm_traffic.json")))
+tj["per_kernel"] = table
+json.dump(tj, open(os.path.join(ROOT, "profiles", "hbm_traffic.json"), "w"), indent=1)
 out = {"profile": "profiles/%s/pmc_hot_kernels.json" % rnd,
        "definition": "SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 XCDs x 1024 SIMDs); fp32 MFMA peak 157.3 TFLOP/s (MI355X_MICROARCH.md)"}
-for name, key, flop_per_mfma in (("fused_audio_to_mel", next((n for n in ("stft2048_mel32_kernel<true, 2>", "stft2048_mel_kernel<true, 2, false>") if n in k), "stft2048_mel_kernel<true, true, false>"), 2048), ("mel_apply", "mel_apply_mfma_kernel<true>", 4096)):
+for name, key, flop_per_mfma in (("fused_audio_to_mel", "stft2048_mel32_kernel<true, 2>", 2048), ("mel_apply", "mel_apply_mfma_kernel<true>", 4096)):
     cc, dur = k[key]["counters"], k[key]["duration"]
     util = cc["SQ_VALU_MFMA_BUSY_CYCLES"] / (cc["GRBM_GUI_ACTIVE"] / 8.0 * 1024.0)
     flops = cc["SQ_INSTS_VALU_MFMA_F32"] * flop_per_mfma

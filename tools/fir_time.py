@@ -1,4 +1,4 @@
-"""C4 FIR timing (8192 taps, 8 x 2 880 000 samples, device resident) plus a parity check on one channel against the oracle.
+"""C4 FIR timing (8192 taps, 8 x 2 880 000 samples, device resident; FIR_CH / FIR_NS: other batches) plus a parity check on one channel against the oracle.
 A/B of the two N = 32768 kernels: run once plain and once with SMX_FIR_SPLIT=0 (the switch is read once per process).
     python tools/fir_time.py [taps ...]
 """
@@ -15,7 +15,7 @@ from soundml_amd._lib import check, lib
 from oracle import soundml_oracle as O
 
 vp = ctypes.c_void_p
-ch, ns = 8, 2880000
+ch, ns = int(os.environ.get("FIR_CH", "8")), int(os.environ.get("FIR_NS", "2880000"))   # FIR_CH=64: the per-block cost without C4's tail (938 blocks on 256 CUs = 3.7 rounds)
 x = torch.empty(ch, ns, device="cuda").uniform_(-1, 1)
 y = torch.empty_like(x)
 for taps in ([int(a) for a in sys.argv[1:]] or [8192]):
