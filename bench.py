@@ -341,8 +341,9 @@ def main():
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_source,
                          "frac_of_measured": round(achieved / HBM_MEASURED_GBS, 4), "measured_peak": HBM_MEASURED_GBS,
-                         "kernel": "stft2048_power32_kernel<true, 2, false> (one launch per step: all %d frames of %d clips)"
-                                   % (frames, clips),
+                         "kernel": "stft2048_power32_kernel<true, 2, false, %d> (one launch per step: all %d frames of %d clips; "
+                                   "the flush in whole aligned 64-byte blocks, %s)"
+                                   % (1 if frames % 2 == 0 else 2, frames, clips, "a pair of frames per lane" if frames % 2 == 0 else "a frame per lane"),
                          "launches_per_step": launches,
                          "kernel_ms_avg": round(avg_ms, 4), "kernel_ms_median": round(step_ms[len(step_ms) // 2], 4),
                          "kernel_ms_min": round(step_ms[0], 4),
@@ -380,15 +381,16 @@ def main():
                                             "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                             "frac": round(clips * frames * MEL_BYTES_PER_FRAME / a / 1e6 / HBM_PEAK_GBS, 4),
                                             "algorithmic_bytes_per_frame": MEL_BYTES_PER_FRAME},
-                               # the mel product is 2 x 128 x 1025 flop per frame, priced against the fp32 MFMA peak
-                               # (bound 599 Mframes/s).  The kernel walks only the filters' nonzero band (1/3.7 of the dense
-                               # product), so the flops it EXECUTES are in "mfma" below; this object is the algorithmic rate.
-                               "roofline_mfma": {"bound": "mfma", "achieved": round(2.0 * 128 * BINS * clips * frames / a / 1e9, 1),
-                                                 "peak": 157.3, "unit": "TFLOP/s",
-                                                 "frac": round(2.0 * 128 * BINS * clips * frames / a / 1e9 / 157.3, 4),
-                                                 "algorithmic_flop_per_frame": 2 * 128 * BINS,
-                                                 "note": "dense-equivalent; executed flops and MFMA pipe occupancy under mfma"},
-                               "mfma": mfma}
+                               # What the MFMA pipe really does (committed PMC profile, profiles/mfma_util.json): pipe occupancy and
+                               # the flops EXECUTED -- the kernel walks only the filters' nonzero band, 1/3.7 of the dense product.
+                               "mfma": mfma,
+                               # SURVEY 8(d)'s bound for reference only: the DENSE product (2 x 128 x 1025 flop per frame) priced
+                               # against the fp32 MFMA peak.  Not a utilisation: 73 % of those flops are never executed.
+                               "mfma_dense_equivalent": {"bound": "mfma", "achieved": round(2.0 * 128 * BINS * clips * frames / a / 1e9, 1),
+                                                         "peak": 157.3, "unit": "TFLOP/s",
+                                                         "frac": round(2.0 * 128 * BINS * clips * frames / a / 1e9 / 157.3, 4),
+                                                         "algorithmic_flop_per_frame": 2 * 128 * BINS,
+                                                         "note": "dense-equivalent rate, NOT utilisation (see mfma)"}}
             del mout
             # C4: FIR 8192 taps on 8 channels x 60 s
             h = Fir.design_lowpass(8192, 0.25, 100.0)

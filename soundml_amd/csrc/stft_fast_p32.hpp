@@ -9,7 +9,11 @@
 //   A. n = l + 32 j  : radix-32 over j in registers (two radix-16 + one combining pass)      -> y_l[k1], twiddle W_M^(l k1)
 //   X. 32 x 32 transposition through the frame's own column of the output tile in LDS (the cells are free until the
 //      frame's results are written): one plane at a time, cell l + 33 j, i.e. base(lane) + immediate on both sides and
-//      every access bank-conflict free (a pitch of 33 cells needs 1056 rows per column instead of 1024)
+//      these accesses bank-conflict free (bank = 17 l + const mod 32 within a half-wave; a pitch of 33 cells needs 1056 rows
+//      per column instead of 1024).  The one conflict of the pipeline is in P's exchange reads: lane 0 looks for its own
+//      register one cell column further than the rule of the other lanes (cell 33, bank of lane 31's cell 1), a 2-way
+//      conflict on those 32 reads per frame = the 8 % of LDS cycles SQ_LDS_BANK_CONFLICT shows; removing it needs a select
+//      per parked register (32 per frame), which costs more vector time than the 64 LDS cycles it frees.
 //   B. radix-32 over l in registers                                                         -> lane k1, register q: Z[k1 + 32 q]
 //   P. real-FFT post-pass, one slot per PAIR (k, M - k): E = Z[k] + conj Z[M-k], D = Z[k] - conj Z[M-k], T = -i w_k D,
 //      X[k] = E + T, X[M-k] = conj(E - T) -- 16 instructions for two bins where the per-bin form takes 20.  Lane k1
