@@ -991,8 +991,13 @@ bool launch_stockham_power16_wide(const StftJob &job, GenericArgs a, const StftT
   return true;
 }
 
+#include "stft_wide_p64.hpp"   // fft 2048, float32 audio: the persistent-workgroup form of the same arithmetic
+
 template <typename Tio>
 bool launch_stockham_power16_wide_any(const StftJob &job, const GenericArgs &a, const StftTables &t, int64_t fft) {
+  if constexpr (sizeof(Tio) == 4) {
+    if (fft == 2048 && wide64::launch(job, a, t)) return true;
+  }
   switch (fft) {
     case 512: return launch_stockham_power16_wide<9, 16, Tio>(job, a, t);
     case 1024: return launch_stockham_power16_wide<10, 16, Tio>(job, a, t);
@@ -1839,3 +1844,9 @@ void launch_stft_generic(const StftJob &job) {
 }
 
 }  // namespace smx
+
+#ifdef SMX_STAMPS
+extern "C" int smx_debug_read_stamps64(unsigned long long *out, int count) {
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(smx::fftdev::g_stamp_sums), sizeof(unsigned long long) * (size_t)count);
+}
+#endif

@@ -1,6 +1,7 @@
 """In-process A/B timing of two builds of libsoundml_amd.so (interleaved rounds, same device, same data):
   python tools/ab.py soundml_amd/lib_a/libsoundml_amd.so soundml_amd/lib/libsoundml_amd.so
-(methodology: per-variant median and min over interleaved rounds; never compare separate runs/boxes)."""
+(methodology: per-variant median and min over interleaved rounds; never compare separate runs/boxes).
+AB_INTERIOR=float64 times the float64 interior instead; AB_CLIPS / AB_N / AB_ROUNDS size the run."""
 import ctypes, os, sys
 import torch
 i64, vp = ctypes.c_int64, ctypes.c_void_p
@@ -18,6 +19,8 @@ for p in paths:
     lib.smx_stft_config_create.argtypes = [i64, i64, i64, ctypes.c_int, ctypes.c_int, ctypes.c_double, ctypes.c_int, ctypes.c_int, vp, ctypes.POINTER(vp)]
     assert lib.smx_stft_config_create(2048, -(2**63), 512, 0, 0, 0.0, 0, 0, None, ctypes.byref(h)) == 0
     lib.smx_stft_power_range_f32_dev.argtypes = [vp, vp, i64, i64, i64, i64, i64, ctypes.c_double, vp, vp]
+    if os.environ.get("AB_INTERIOR") == "float64":   # the reference's interior (window, transform and |.|^p in float64)
+        assert lib.smx_set_interior(1) == 0
     libs.append((p, lib, h))
 def setenv(p):
     for kv in p.split("@")[1:]:
