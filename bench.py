@@ -437,6 +437,23 @@ def main():
                                                 "unit": "GB/s", "frac": round(clips * frames * bc / a / 1e6 / HBM_PEAK_GBS, 4),
                                                 "algorithmic_bytes_per_frame": bc}}
             del zc
+            # C2 on the reference's own numerics (window, transform and |.|^2 in float64; float32 in and out): the same entry
+            # point under set_interior("float64").  HBM bytes are C2's; what bounds this kernel is float64 vector issue
+            # (~5 900 cycles per frame and wave at 4 cycles per instruction: DESIGN 4.3b), stated beside the HBM figure.
+            S.set_interior("float64")
+            try:
+                _, ms, nl = timed(power_step(x, out, clips, n, frames), k, w)
+            finally:
+                S.set_interior("float32")
+            a = sum(ms) / len(ms)
+            extra["c2_float64_interior"] = {"workload": "C2 with the reference's float64 interior (set_interior float64): stft2048_power_wide_kernel",
+                                            "value": round(clips * frames / a / 1e3, 1), "unit": "Mframes/s", "ms": round(a, 4), "ms_min": round(ms[0], 4),
+                                            "launches_per_step": nl, "dtype": "f64",
+                                            "roofline": {"bound": "hbm", "achieved": round(clips * frames * ALGO_BYTES_PER_FRAME / a / 1e6, 1),
+                                                         "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                                         "frac": round(clips * frames * ALGO_BYTES_PER_FRAME / a / 1e6 / HBM_PEAK_GBS, 4),
+                                                         "algorithmic_bytes_per_frame": ALGO_BYTES_PER_FRAME,
+                                                         "note": "issue-bound, not HBM-bound: 16 frames x 5900 cycles of float64 vector instructions per SIMD quartet and tile"}}
             # C5 on ONE GPU: the N = 1 point of BASELINE configs[4] (71 GB resident)
             free_b, _ = torch.cuda.mem_get_info(dev)
             del x, out

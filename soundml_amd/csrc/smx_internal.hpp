@@ -44,12 +44,13 @@ void set_last_error(const std::string &message);
   } while (0)
 
 // ---- environment switches ------------------------------------------------------------------------------------------
-// The shipped library reads eight variables, each once per use and parsed ONE way (env_flag: unset -> -1, "0" / "" /
+// The shipped library reads nine variables, each once per use and parsed ONE way (env_flag: unset -> -1, "0" / "" /
 // "false" / "off" -> 0, anything else -> 1); none alters results except by selecting another kernel of the same contract:
 //   SMX_DISABLE_FAST   the generic kernels instead of the hand-laid ones (tests: two implementations of one contract)
 //   SMX_POWER_SKEW=0   fft-2048 power spectrogram: the plain per-tile flush instead of whole aligned 64-byte blocks (tests, A/B timing)
 //   SMX_COMPLEX_SKEW=0 fft-2048 Stft.transform: the plain per-tile flush instead of whole aligned 128-byte lines (tests, A/B timing)
 //   SMX_WIDE_PIPELINE=0 float64 interior at fft 2048: the one-tile-per-workgroup kernel instead of the persistent one (tests: bit-identical)
+//   SMX_MEL_DENSE=1    fused mel at fft 2048: the dense 16 x 16 x 4 product instead of the banded 4 x 4 x 1 one (tests, A/B timing)
 //   SMX_MIXED_OFF      chirp-z instead of the mixed-radix kernels (tests: the two agree)
 //   SMX_HOST_TRACE     print where a host-pointer call's time goes
 //   SMX_COPY_THREADS / SMX_COPY_PLAIN   host <-> device staging of the host-pointer entry points
@@ -166,6 +167,7 @@ struct MelFusedPlan {      // per device; built lazily by stft_fast.hip
   void *items = nullptr;   // Mel32Item[8][8]
   float *w_mfma = nullptr; // MFMA A operands in lane order
   int state = 0;           // 0 not built, 1 usable, -1 this configuration is not eligible
+  int resident = 0;        // fused4 plans: w_mfma is [wave][64 steps][64 lanes], a wave's items in order (the kernel keeps them in registers)
 };
 }  // namespace smx
 
@@ -190,12 +192,13 @@ struct smx_mel_config {
   };
   const Tables &tables() const;
   const smx::MelFusedPlan &fused32_plan() const; // stft_fast.hip: items of the 32-lane mel kernel (items = Mel32Item[8][8])
+  const smx::MelFusedPlan &fused4_plan() const;  // stft_fast.hip: the same product on 4 x 4 x 1 blocks (items = Mel4Item[8][8]; fft 2048)
   ~smx_mel_config();
 
  private:
   mutable std::mutex mutex_;
   mutable std::map<int, Tables> tables_;
-  mutable std::map<int, smx::MelFusedPlan> fused32_;
+  mutable std::map<int, smx::MelFusedPlan> fused32_, fused4_;
 };
 
 // Chroma.Config.t (chroma.ml:95-107): the [n_chroma; bins] projection matrix, float64, built once on the host

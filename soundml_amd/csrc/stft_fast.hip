@@ -402,11 +402,13 @@ void launch_interior(const StftJob &job, const FastTarget &tg, const float *x, i
   if (tg.mel && tg.mel32) {
     Mel32Args m = *tg.mel32;
     m.out_offset = out_offset;
-    auto by_power = [&](auto al) {
+    auto by_power = [&](auto al, auto fr) {
       constexpr bool A = decltype(al)::value;
-      return a.pmode == 2 ? stft2048_mel32_kernel<A, 2> : a.pmode == 1 ? stft2048_mel32_kernel<A, 1> : stft2048_mel32_kernel<A, 0>;
+      constexpr int F = decltype(fr)::value;
+      return a.pmode == 2 ? stft2048_mel32_kernel<A, 2, F> : a.pmode == 1 ? stft2048_mel32_kernel<A, 1, F> : stft2048_mel32_kernel<A, 0, F>;
     };
-    auto k32 = aligned ? by_power(std::true_type{}) : by_power(std::false_type{});
+    auto by_al = [&](auto fr) { return aligned ? by_power(std::true_type{}, fr) : by_power(std::false_type{}, fr); };
+    auto k32 = m.four == 2 ? by_al(std::integral_constant<int, 2>{}) : m.four == 1 ? by_al(std::integral_constant<int, 1>{}) : by_al(std::integral_constant<int, 0>{});
     SMX_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k32), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kFast32Lds));
     SMX_LAUNCH(k32, dim3((unsigned)a.blocks), dim3(512), kFast32Lds, job.stream, a, m);
     SMX_HIP_CHECK(hipGetLastError());
@@ -600,7 +602,10 @@ bool launch_mel_spectrogram_fused(const MelSpecJob &job) {
   if (sj0.in_bytes != 4 || sj0.interior != SMX_INTERIOR_F32 || sj0.mode == OUT_COMPLEX || fast_path_disabled())
     return launch_mel_spectrogram_16(job);
   if (!lanes && !fast_eligible(sj0)) return launch_mel_spectrogram_16(job);
-  const MelFusedPlan &pl = job.mel->fused32_plan();
+  // fft 2048: the banded 4 x 4 x 1 product where its plan exists (SMX_MEL_DENSE=1: the dense 16 x 16 x 4 one, A/B and tests)
+  const MelFusedPlan *p4 = (!lanes && env_flag("SMX_MEL_DENSE") != 1) ? &job.mel->fused4_plan() : nullptr;
+  const bool four = p4 && p4->state == 1;
+  const MelFusedPlan &pl = four ? *p4 : job.mel->fused32_plan();
   if (pl.state != 1) return launch_mel_spectrogram_16(job);
   if (sj0.count <= 0 || sj0.lead <= 0) return true;
   const int64_t n_mels = job.mel->n_mels;
@@ -618,6 +623,8 @@ bool launch_mel_spectrogram_fused(const MelSpecJob &job) {
     m32.out_stride = sj0.count;
     m32.out_offset = 0;
     m32.n_mels = (int)n_mels;
+    m32.last_bin = (int)(fft / 2);
+    m32.four = four ? (pl.resident ? 2 : 1) : 0;
     FastTarget tg;
     tg.out = m32.out;
     tg.out_stride = sj0.count;
@@ -708,6 +715,151 @@ const smx::MelFusedPlan &smx_mel_config::fused32_plan() const {
   // 22.05 kHz -- to the 64-lane kernel, which was 5 % ahead there; that kernel family is gone.)
   SMX_HIP_CHECK(hipMalloc(&plan.items, items.size() * sizeof(Mel32Item)));
   SMX_HIP_CHECK(hipMemcpy(plan.items, items.data(), items.size() * sizeof(Mel32Item), hipMemcpyHostToDevice));
+  SMX_HIP_CHECK(hipMalloc((void **)&plan.w_mfma, wm.size() * sizeof(float)));
+  SMX_HIP_CHECK(hipMemcpy(plan.w_mfma, wm.data(), wm.size() * sizeof(float), hipMemcpyHostToDevice));
+  plan.state = 1;
+  return plan;
+}
+
+// ---- work plan of the banded product (stft_fast_mel32.hpp, Mel4Item): mel groups of 4 rows, each over its own band; a band much
+// longer than a wave's share is cut in 2 or 4 K-parts inside one item; items dealt to the 8 waves longest first
+const smx::MelFusedPlan &smx_mel_config::fused4_plan() const {
+  using namespace smx;
+  int device = 0;
+  SMX_HIP_CHECK(hipGetDevice(&device));
+  std::lock_guard<std::mutex> lock(mutex_);
+  MelFusedPlan &plan = fused4_[device];
+  if (plan.state != 0) return plan;
+  plan.state = -1;
+  const int64_t nb = bins();
+  if (fft_size != kN || n_mels < 1 || n_mels > 252) return plan;
+  struct Group { int row0, nr, lo, len; };
+  std::vector<Group> groups;
+  int64_t total = 0;
+  for (int r0 = 0; r0 < n_mels; r0 += 4) {
+    Group g{r0, (int)std::min<int64_t>(4, n_mels - r0), 0, 0};
+    int lo = (int)nb, hi = 0;
+    for (int r = r0; r < r0 + g.nr; ++r)
+      for (int64_t k = 0; k < nb; ++k)
+        if ((float)weights[(size_t)(r * nb + k)] != 0.0f) {
+          lo = std::min(lo, (int)k);
+          hi = std::max(hi, (int)k + 1);
+        }
+    if (hi > lo) {
+      g.lo = lo;
+      g.len = hi - lo;
+    } else {
+      g.len = 1;   // rows without a weight: a step over zeros writes their zeros
+    }
+    total += g.len;
+    groups.push_back(g);
+  }
+  const int target = (int)std::max<int64_t>(8, (total + 31) / 32);   // steps of a wave when every lane group of every item is busy
+  struct Piece { int row0, nr, kb, kn; };
+  struct Item { Piece p[4]; int mode, steps; };
+  std::vector<Item> items;
+  std::vector<const Group *> ones, twos;
+  auto part = [](const Group &g, int parts, int q) {
+    const int per = (g.len + parts - 1) / parts, kb = g.lo + q * per;
+    const int kn = std::max(0, std::min(per, g.lo + g.len - kb));
+    return Piece{g.row0, g.nr, kn > 0 ? kb : g.lo, kn};
+  };
+  auto finish = [&](Item it) {
+    int longest = 1;
+    for (const Piece &q : it.p) longest = std::max(longest, q.kn);
+    it.steps = (longest + 3) / 4 * 4;
+    items.push_back(it);
+  };
+  for (const Group &g : groups) {
+    if (g.len > target * 5 / 2) finish(Item{{part(g, 4, 0), part(g, 4, 1), part(g, 4, 2), part(g, 4, 3)}, 4, 0});
+    else if (g.len > target * 5 / 4) twos.push_back(&g);
+    else ones.push_back(&g);
+  }
+  const Piece idle{0, 0, 0, 0};
+  for (size_t i = 0; i < twos.size(); i += 2) {
+    Item it{{part(*twos[i], 2, 0), part(*twos[i], 2, 1), idle, idle}, 2, 0};
+    if (i + 1 < twos.size()) {
+      it.p[2] = part(*twos[i + 1], 2, 0);
+      it.p[3] = part(*twos[i + 1], 2, 1);
+    }
+    finish(it);
+  }
+  for (size_t i = 0; i < ones.size(); i += 4) {
+    Item it{{idle, idle, idle, idle}, 1, 0};
+    for (size_t q = 0; q < 4 && i + q < ones.size(); ++q) it.p[q] = part(*ones[i + q], 1, 0);
+    finish(it);
+  }
+  if (items.size() > 8 * (size_t)kMel32MaxItems) return plan;
+  auto weight_row = [&](const Item &it, int st, std::vector<float> &dst) {   // the 64 A operands of step st
+    for (int lane = 0; lane < 64; ++lane) {
+      const Piece &q = it.p[lane >> 4];
+      const int r = lane & 3;
+      const int64_t k = (int64_t)q.kb + st;
+      dst.push_back((r < q.nr && st < q.kn && k < nb) ? (float)weights[(size_t)((q.row0 + r) * nb + k)] : 0.0f);
+    }
+  };
+  auto pack = [](const Item &it, int steps, int a_offset) {
+    Mel4Item d{};
+    for (int q = 0; q < 4; ++q) {
+      d.rows |= it.p[q].row0 << (8 * q);
+      d.nrows |= it.p[q].nr << (8 * q);
+      d.kb[q] = it.p[q].kb;
+    }
+    d.steps_mode = steps | (it.mode << 16);
+    d.a_offset = a_offset;
+    return d;
+  };
+  std::sort(items.begin(), items.end(), [](const Item &x, const Item &y) { return x.steps > y.steps; });
+  {   // resident form: items in whole chunks of 8 steps, at most 8 chunks (64 operand registers) and 8 items per wave
+    std::vector<std::vector<const Item *>> per_wave(8);
+    int chunks[8] = {0};
+    bool fits = true;
+    for (const Item &it : items) {
+      const int need = (it.steps + 7) / 8;
+      int w = -1;
+      for (int i = 0; i < 8; ++i)
+        if ((int)per_wave[(size_t)i].size() < kMel32MaxItems && chunks[i] + need <= kMel4rChunks && (w < 0 || chunks[i] < chunks[w])) w = i;
+      if (w < 0) { fits = false; break; }
+      per_wave[(size_t)w].push_back(&it);
+      chunks[w] += need;
+    }
+    if (fits) {
+      std::vector<Mel4Item> table(8 * kMel32MaxItems, Mel4Item{});
+      std::vector<float> wm;
+      wm.reserve((size_t)8 * 64 * 64);
+      for (int w = 0; w < 8; ++w) {
+        int n = 0, used = 0;
+        for (const Item *it : per_wave[(size_t)w]) {
+          const int steps = (it->steps + 7) / 8 * 8;
+          table[(size_t)(w * kMel32MaxItems + n++)] = pack(*it, steps, 0);
+          for (int st = 0; st < steps; ++st) weight_row(*it, st, wm);
+          used += steps;
+        }
+        wm.resize(wm.size() + (size_t)(64 - used) * 64, 0.0f);
+      }
+      SMX_HIP_CHECK(hipMalloc(&plan.items, table.size() * sizeof(Mel4Item)));
+      SMX_HIP_CHECK(hipMemcpy(plan.items, table.data(), table.size() * sizeof(Mel4Item), hipMemcpyHostToDevice));
+      SMX_HIP_CHECK(hipMalloc((void **)&plan.w_mfma, wm.size() * sizeof(float)));
+      SMX_HIP_CHECK(hipMemcpy(plan.w_mfma, wm.data(), wm.size() * sizeof(float), hipMemcpyHostToDevice));
+      plan.resident = 1;
+      plan.state = 1;
+      return plan;
+    }
+  }
+  std::vector<Mel4Item> table(8 * kMel32MaxItems, Mel4Item{});
+  int load[8] = {0}, count[8] = {0};
+  std::vector<float> wm;
+  for (const Item &it : items) {
+    int w = -1;
+    for (int i = 0; i < 8; ++i)
+      if (count[i] < kMel32MaxItems && (w < 0 || load[i] < load[w])) w = i;
+    if (w < 0) return plan;
+    table[(size_t)(w * kMel32MaxItems + count[w]++)] = pack(it, it.steps, (int)(wm.size() / 64));
+    load[w] += it.steps;
+    for (int st = 0; st < it.steps; ++st) weight_row(it, st, wm);
+  }
+  SMX_HIP_CHECK(hipMalloc(&plan.items, table.size() * sizeof(Mel4Item)));
+  SMX_HIP_CHECK(hipMemcpy(plan.items, table.data(), table.size() * sizeof(Mel4Item), hipMemcpyHostToDevice));
   SMX_HIP_CHECK(hipMalloc((void **)&plan.w_mfma, wm.size() * sizeof(float)));
   SMX_HIP_CHECK(hipMemcpy(plan.w_mfma, wm.data(), wm.size() * sizeof(float), hipMemcpyHostToDevice));
   plan.state = 1;

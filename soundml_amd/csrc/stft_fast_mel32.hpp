@@ -33,6 +33,8 @@ struct Mel32Args {
   float *out;             // [lead; n_mels; out_stride]
   int64_t out_stride, out_offset;
   int n_mels;
+  int last_bin;           // Mel4Item plans: the last spectrum row (rows beyond hold transposition cells)
+  int four;               // host side: 1 items are Mel4Item (the 4 x 4 x 1 product), 2 and the A operands are laid out per wave for residence
 };
 
 // the wave's items over the finished tile `tile` (rows = bins, 17 floats apart): out[mel][f0 + f] for its mels.
@@ -176,11 +178,206 @@ __device__ __forceinline__ void mel32_items_multi(const Mel32Args &m, int iv, co
   }
 }
 
+// ---- the product on v_mfma_f32_4x4x1_16B_f32 (fft 2048) ------------------------------------------------------------------
+// A mel filterbank is banded: of the 16 mels of a dense 16 x 16 x 4 step two have a weight at any bin, the other 14 multiply
+// zeros (C3: 284 steps of 32 cycles per tile).  The 4 x 4 x 1 form is 16 independent blocks D_b[4][4] += A_b[4] B_b[4]: block
+// b = 4 mg + fg is mel GROUP mg (4 consecutive mels) over frames 4 fg .. 4 fg + 3, and every mel group walks its OWN band --
+// lane (mg, fg, j) reads B = P[kb_mg + step][4 fg + j] from the tile (a per-lane row base, the same step offsets) and
+// A = W[row_mg + (lane & 3)][kb_mg + step] from the plan's table in lane order.  A step is 8 cycles instead of 32 and a
+// group's band is 5 half-widths instead of the 17 of a 16-mel union: C3 takes 341 steps of 8 cycles.  A long band is cut in
+// 2 or 4 K-parts that sit in the lane groups of ONE item (mode 2: groups a a b b, mode 4: a a a a) and are added at the end
+// in a fixed order, (p0 + p1) + (p2 + p3), across the lane groups: one wave still owns a (mel, frame) value, the plan depends
+// on the configuration alone, so a clip's values do not depend on its batch (mel_props.ml:136-155).
+struct Mel4Item {
+  int rows;        // first mel row of lane group mg in byte mg
+  int nrows;       // rows of lane group mg in byte mg (0: the group is idle)
+  int kb[4];       // first bin of lane group mg
+  int steps_mode;  // steps (a multiple of 4; 0: no item) | mode << 16 (1: four groups, 2: two groups x 2 K-parts, 4: one group x 4)
+  int a_offset;    // offset (in 64-float rows) of the item's A operands in w
+};
+static_assert(sizeof(Mel4Item) == sizeof(Mel32Item), "both plans are read as 8 ints per item");
+
+template <int TS = kTileStride>
+__device__ __forceinline__ void mel4_items(const Mel32Args &m, int iv, const float *tile, float *obase, int frames_left, int lane) {
+  using f32x4m = __attribute__((ext_vector_type(4))) float;
+  const int mg = lane >> 4, f = lane & 15;
+#pragma unroll 1
+  for (int i = 0; i < kMel32MaxItems; ++i) {
+    const int sm = __builtin_amdgcn_readlane(iv, 8 * i + 6);
+    const int nsteps = sm & 0xffff, mode = sm >> 16;
+    if (nsteps == 0) break;
+    const int rows = __builtin_amdgcn_readlane(iv, 8 * i), nrw = __builtin_amdgcn_readlane(iv, 8 * i + 1);
+    const int k0 = __builtin_amdgcn_readlane(iv, 8 * i + 2), k1 = __builtin_amdgcn_readlane(iv, 8 * i + 3);
+    const int k2 = __builtin_amdgcn_readlane(iv, 8 * i + 4), k3 = __builtin_amdgcn_readlane(iv, 8 * i + 5);
+    const int kbl = mg == 0 ? k0 : mg == 1 ? k1 : mg == 2 ? k2 : k3;
+    const float *ap = m.w + (int64_t)__builtin_amdgcn_readlane(iv, 8 * i + 7) * 64 + lane;
+    const float *bp = tile + kbl * TS + f;
+    const int room = m.last_bin - kbl;   // steps past it would leave the spectrum: they multiply zero weights, but must read spectrum
+    f32x4m acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+    constexpr int CH = kMel32Chunk;
+    float av[2][CH], bv[2][CH];
+    auto request = [&](int slot, int jj, auto n) {
+      constexpr int N = decltype(n)::value;
+#pragma unroll
+      for (int u = 0; u < N; ++u) {
+        av[slot][u] = ap[64 * (jj + u)];
+        const int st = jj + u;
+        bv[slot][u] = bp[(st < room ? st : room) * TS];
+      }
+    };
+    auto multiply = [&](int slot, auto n) {
+      constexpr int N = decltype(n)::value;
+#pragma unroll
+      for (int u = 0; u < N; u += 2) {
+        acc0 = __builtin_amdgcn_mfma_f32_4x4x1f32(av[slot][u], bv[slot][u], acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_4x4x1f32(av[slot][u + 1], bv[slot][u + 1], acc1, 0, 0, 0);
+      }
+    };
+    const std::integral_constant<int, CH> whole{};
+    const std::integral_constant<int, 4> tail{};
+    const int nch = nsteps / CH;
+    int j = 0;
+    if (nch > 0) {   // two chunks in flight, as mel32_items
+      request(0, 0, whole);
+#pragma unroll 1
+      for (int c = 0; c + 2 <= nch; c += 2) {
+        request(1, CH * (c + 1), whole);
+        multiply(0, whole);
+        if (c + 2 < nch) request(0, CH * (c + 2), whole);
+        multiply(1, whole);
+      }
+      if (nch & 1) multiply(0, whole);
+      j = nch * CH;
+    }
+#pragma unroll 1
+    for (; j < nsteps; j += 4) {
+      request(0, j, tail);
+      multiply(0, tail);
+    }
+    f32x4m acc = acc0 + acc1;
+    if (mode >= 2) {   // wave-uniform: add the K-parts across the lane groups, (p0 + p1) + (p2 + p3)
+      const int from16 = ((lane + 16) & 63) << 2, from32 = ((lane + 32) & 63) << 2;
+      // (element by element through scalars: __builtin_bit_cast of acc[r] itself made hipcc permute element 0 four times)
+      auto from = [&](int addr, float v) { return __int_as_float(__builtin_amdgcn_ds_bpermute(addr, __float_as_int(v))); };
+      const float a0 = acc[0], a1 = acc[1], a2 = acc[2], a3 = acc[3];
+      float s0 = a0 + from(from16, a0), s1 = a1 + from(from16, a1), s2 = a2 + from(from16, a2), s3 = a3 + from(from16, a3);
+      if (mode == 4) {
+        s0 = s0 + from(from32, s0);
+        s1 = s1 + from(from32, s1);
+        s2 = s2 + from(from32, s2);
+        s3 = s3 + from(from32, s3);
+      }
+      acc = f32x4m{s0, s1, s2, s3};
+    }
+    const bool owner = mode == 1 || (mode == 2 ? (mg & 1) == 0 : mg == 0);
+    const int row0 = (rows >> (8 * mg)) & 255, nr = (nrw >> (8 * mg)) & 255;
+    if (owner && f < frames_left) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        if (r < nr) obase[(int64_t)(row0 + r) * m.out_stride + f] = acc[r];
+    }
+  }
+}
+
+// The same product with the A operands RESIDENT: a wave's items take at most 8 chunks of 8 steps (C3: 7), i.e. 64 values per
+// lane, and the kernel has that many registers to spare -- they are loaded once per kernel and the tile loop reads nothing
+// but the tile.  (With the operands streamed from L2, two chunks in flight, a wave's ~46 steps took ~4 000 cycles per tile, all
+// of it L2 latency; the MFMA work itself is 46 x 8 cycles.)  Register indices must be static: the chunk loop is written out,
+// an item is a whole number of chunks (zero weights pad it), and the item that a chunk belongs to is scalar state.
+constexpr int kMel4rChunks = 8;
+template <int TS = kTileStride>
+__device__ __forceinline__ void mel4r_items(const Mel32Args &m, int iv, const float (&areg)[8 * kMel4rChunks], const float *tile, float *obase,
+                                            int frames_left, int lane) {
+  using f32x4m = __attribute__((ext_vector_type(4))) float;
+  const int mg = lane >> 4, f = lane & 15;
+  // scalar state of the chunk being REQUESTED (one ahead of the chunk being multiplied)
+  int item = 0, st = 0, steps = 0, mode = 0, rows = 0, nrw = 0;
+  const float *bp = tile;
+  int room = 0;
+  auto open_item = [&]() {
+    const int sm = __builtin_amdgcn_readlane(iv, 8 * item + 6);
+    steps = sm & 0xffff;
+    mode = sm >> 16;
+    rows = __builtin_amdgcn_readlane(iv, 8 * item);
+    nrw = __builtin_amdgcn_readlane(iv, 8 * item + 1);
+    const int k0 = __builtin_amdgcn_readlane(iv, 8 * item + 2), k1 = __builtin_amdgcn_readlane(iv, 8 * item + 3);
+    const int k2 = __builtin_amdgcn_readlane(iv, 8 * item + 4), k3 = __builtin_amdgcn_readlane(iv, 8 * item + 5);
+    const int kbl = mg == 0 ? k0 : mg == 1 ? k1 : mg == 2 ? k2 : k3;
+    bp = tile + kbl * TS + f;
+    room = m.last_bin - kbl;
+    st = 0;
+  };
+  open_item();
+  if (steps == 0) return;
+  float bv[2][8];
+  auto request = [&](int slot) {
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int q = st + u;
+      bv[slot][u] = bp[(q < room ? q : room) * TS];
+    }
+  };
+  f32x4m acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+  request(0);
+#pragma unroll
+  for (int c = 0; c < kMel4rChunks; ++c) {
+    // the chunk being multiplied: c.  Its item's output description, before the state moves on
+    const int c_mode = mode, c_rows = rows, c_nrw = nrw;
+    const bool c_last = st + 8 >= steps;
+    bool more = false;
+    if (c + 1 < kMel4rChunks) {   // advance the request state to chunk c + 1 and request it
+      if (c_last) {
+        ++item;
+        if (item < kMel32MaxItems) {
+          open_item();
+          more = steps != 0;
+        }
+      } else {
+        st += 8;
+        more = true;
+      }
+      if (more) request((c + 1) & 1);
+    }
+#pragma unroll
+    for (int u = 0; u < 8; u += 2) {
+      acc0 = __builtin_amdgcn_mfma_f32_4x4x1f32(areg[8 * c + u], bv[c & 1][u], acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f32_4x4x1f32(areg[8 * c + u + 1], bv[c & 1][u + 1], acc1, 0, 0, 0);
+    }
+    if (c_last) {
+      f32x4m acc = acc0 + acc1;
+      if (c_mode >= 2) {   // wave-uniform: add the K-parts across the lane groups, (p0 + p1) + (p2 + p3)
+        const int from16 = ((lane + 16) & 63) << 2, from32 = ((lane + 32) & 63) << 2;
+        auto from = [&](int addr, float v) { return __int_as_float(__builtin_amdgcn_ds_bpermute(addr, __float_as_int(v))); };
+        const float a0 = acc[0], a1 = acc[1], a2 = acc[2], a3 = acc[3];
+        float s0 = a0 + from(from16, a0), s1 = a1 + from(from16, a1), s2 = a2 + from(from16, a2), s3 = a3 + from(from16, a3);
+        if (c_mode == 4) {
+          s0 = s0 + from(from32, s0);
+          s1 = s1 + from(from32, s1);
+          s2 = s2 + from(from32, s2);
+          s3 = s3 + from(from32, s3);
+        }
+        acc = f32x4m{s0, s1, s2, s3};
+      }
+      const bool owner = c_mode == 1 || (c_mode == 2 ? (mg & 1) == 0 : mg == 0);
+      const int row0 = (c_rows >> (8 * mg)) & 255, nr = (c_nrw >> (8 * mg)) & 255;
+      if (owner && f < frames_left) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          if (r < nr) obase[(int64_t)(row0 + r) * m.out_stride + f] = acc[r];
+      }
+      acc0 = f32x4m{0.f, 0.f, 0.f, 0.f};
+      acc1 = f32x4m{0.f, 0.f, 0.f, 0.f};
+    }
+    if (!more) break;
+  }
+}
+
 // what the mel kernel does between the stages of a frame pair (see frame32_to_tile / PowerMid32)
-template <bool ALIGNED>
+template <bool ALIGNED, int FOUR>
 struct MelMid32 {
   const FastArgs &a;
   const Mel32Args &m;
+  const float (&areg)[8 * kMel4rChunks];
   int iv;
   const Lds32 &lds;
   float2 (&raw)[32];
@@ -200,7 +397,9 @@ struct MelMid32 {
   __device__ __forceinline__ void after_exchange_issue() const {
     if (it > 0) {
       lds_wait32(lds.filled + (b ^ 1) * kTileStride, 8u * (((unsigned)(it - 1) >> 1) + 1), pk_filled);
-      mel32_items(m, iv, lds.tiles + (b ^ 1) * kTile32Floats, pend_out, pend_left, lane);
+      if constexpr (FOUR == 2) mel4r_items(m, iv, areg, lds.tiles + (b ^ 1) * kTile32Floats, pend_out, pend_left, lane);
+      else if constexpr (FOUR == 1) mel4_items(m, iv, lds.tiles + (b ^ 1) * kTile32Floats, pend_out, pend_left, lane);
+      else mel32_items(m, iv, lds.tiles + (b ^ 1) * kTile32Floats, pend_out, pend_left, lane);
       lds_signal32(lds.drained + (b ^ 1) * kTileStride, lane);   // behind the item's last LDS read in this wave's order
     }
   }
@@ -209,7 +408,8 @@ struct MelMid32 {
   }
 };
 
-template <bool ALIGNED, int PMODE>
+// FOUR: 0 the dense 16 x 16 x 4 product (Mel32Item plan), 1 the banded 4 x 4 x 1 one with streamed operands, 2 with resident ones
+template <bool ALIGNED, int PMODE, int FOUR = 0>
 __global__ void __launch_bounds__(512) stft2048_mel32_kernel(FastArgs a, Mel32Args m) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x;
@@ -242,6 +442,11 @@ __global__ void __launch_bounds__(512) stft2048_mel32_kernel(FastArgs a, Mel32Ar
   int pend_left = 0;
   unsigned pk_drained = 0, pk_filled = 0;
   const int iv = reinterpret_cast<const int *>(m.items + wave * kMel32MaxItems)[lane];   // this wave's items (8 x 8 ints)
+  float areg[8 * kMel4rChunks];
+  if constexpr (FOUR == 2) {   // the wave's A operands: [wave][step][lane], loaded once
+#pragma unroll
+    for (int q = 0; q < 8 * kMel4rChunks; ++q) areg[q] = m.w[(wave * 8 * kMel4rChunks + q) * 64 + lane];
+  }
   for (int it = 0; it < ntiles; ++it) {   // tile `it` of this workgroup lives in buffer it & 1
     const int b = it & 1;
     int ftnext;
@@ -250,7 +455,7 @@ __global__ void __launch_bounds__(512) stft2048_mel32_kernel(FastArgs a, Mel32Ar
     tw.peek(a, ftnext, xnext, onext);
     const bool more = it + 1 < ntiles;
     const float *src = frame_ptr(more ? xnext : tw.xclip, more ? ftnext : tw.ft);
-    const MelMid32<ALIGNED> mid{a, m, iv, lds, raw, src, pend_out, pend_left, lane, wave, b, it, pk_drained, pk_filled};
+    const MelMid32<ALIGNED, FOUR> mid{a, m, areg, iv, lds, raw, src, pend_out, pend_left, lane, wave, b, it, pk_drained, pk_filled};
     frame32_to_tile<PMODE>(a, L, raw, lds.tiles + b * kTile32Floats, mid);
     lds_signal32(lds.filled + b * kTileStride, lane);
     pend_out = tw.oclip + tw.ft * kFT;   // wave-uniform
@@ -263,6 +468,8 @@ __global__ void __launch_bounds__(512) stft2048_mel32_kernel(FastArgs a, Mel32Ar
   if (ntiles > 0) {   // the last tile of this workgroup
     const int b = (ntiles - 1) & 1;
     lds_wait(lds.filled + b * kTileStride, 8u * (((unsigned)(ntiles - 1) >> 1) + 1));
-    mel32_items(m, iv, lds.tiles + b * kTile32Floats, pend_out, pend_left, lane);
+    if constexpr (FOUR == 2) mel4r_items(m, iv, areg, lds.tiles + b * kTile32Floats, pend_out, pend_left, lane);
+    else if constexpr (FOUR == 1) mel4_items(m, iv, lds.tiles + b * kTile32Floats, pend_out, pend_left, lane);
+    else mel32_items(m, iv, lds.tiles + b * kTile32Floats, pend_out, pend_left, lane);
   }
 }

@@ -511,6 +511,10 @@ smx_mel_config::~smx_mel_config() {
     (void)hipFree(kv.second.items);
     (void)hipFree(kv.second.w_mfma);
   }
+  for (auto &kv : fused4_) {
+    (void)hipFree(kv.second.items);
+    (void)hipFree(kv.second.w_mfma);
+  }
 }
 
 const double *smx_chroma_config::device_weights() const {
