@@ -1,6 +1,6 @@
 """Driver for tools/profile_round.sh: a few launches of every hot kernel of the BASELINE configurations, nothing else on
 the device (C2 power spectrogram, C3 fused mel, Mel.apply, Stft.transform and Stft.invert of the C2 batch, the power spectrogram
-at fft 1024 and 512 on 256 clips of C1's length, C4 FIR)."""
+at fft 1024 and 512 on 256 clips of C1's length, C4 FIR, the C2 power spectrogram under the float64 interior)."""
 import ctypes, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -35,4 +35,7 @@ for _ in range(reps):
     check(lib.smx_stft_power_range_f32_dev(c1k._h, vp(x1.data_ptr()), 256, 441000, 441000, 0, f1k, 2.0, vp(o1k.data_ptr()), None))
     check(lib.smx_stft_power_range_f32_dev(c512._h, vp(x1.data_ptr()), 256, 441000, 441000, 0, f512, 2.0, vp(o512.data_ptr()), None))
     check(lib.smx_fir_apply_f32_dev(plan._h, vp(xs.data_ptr()), 8, 2880000, 2880000, vp(ys.data_ptr()), 2880000, None))
+    S.set_interior("float64")   # the reference's own numerics at C2: stft2048_power_wide_kernel
+    check(lib.smx_stft_power_range_f32_dev(sc._h, vp(x.data_ptr()), 256, 480000, 480000, 0, frames, 2.0, vp(out.data_ptr()), None))
+    S.set_interior("float32")
 torch.cuda.synchronize()
