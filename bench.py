@@ -382,10 +382,11 @@ def main():
                                             "frac": round(clips * frames * MEL_BYTES_PER_FRAME / a / 1e6 / HBM_PEAK_GBS, 4),
                                             "algorithmic_bytes_per_frame": MEL_BYTES_PER_FRAME},
                                # What the MFMA pipe really does (committed PMC profile, profiles/mfma_util.json): pipe occupancy and
-                               # the flops EXECUTED -- the kernel walks only the filters' nonzero band, 1/3.7 of the dense product.
+                               # the flops EXECUTED -- v_mfma_f32_4x4x1_16B_f32 blocks, every 4-mel group over its own band: 1/20 of
+                               # the dense product's flops (round 3's 16 x 16 x 4 tiles executed 1/7 of it, at 2.5 times the pipe time).
                                "mfma": mfma,
                                # SURVEY 8(d)'s bound for reference only: the DENSE product (2 x 128 x 1025 flop per frame) priced
-                               # against the fp32 MFMA peak.  Not a utilisation: 73 % of those flops are never executed.
+                               # against the fp32 MFMA peak.  Not a utilisation: 95 % of those flops are never executed.
                                "mfma_dense_equivalent": {"bound": "mfma", "achieved": round(2.0 * 128 * BINS * clips * frames / a / 1e9, 1),
                                                          "peak": 157.3, "unit": "TFLOP/s",
                                                          "frac": round(2.0 * 128 * BINS * clips * frames / a / 1e9 / 157.3, 4),

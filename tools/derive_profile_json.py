@@ -6,7 +6,7 @@
 Usage: python tools/derive_profile_json.py r04"""
 import json, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-rnd = sys.argv[1] if len(sys.argv) > 1 else "r06"
+rnd = sys.argv[1] if len(sys.argv) > 1 else "r06b"
 src = os.path.join(ROOT, "profiles", rnd, "pmc_hot_kernels.json")
 k = json.load(open(src))["kernels"]
 hkey = next(n for n in ("stft2048_power32_kernel<true, 2, false, 1>", "stft2048_power32_kernel<true, 2, false, 2>", "stft2048_power32_kernel<true, 2, false, 0>",
@@ -31,7 +31,8 @@ json.dump({"bytes_per_launch": read_b + write_b, "read_bytes": read_b, "write_by
 FR2048, FR1K, FR512 = 938, 1723, 3446
 ALGO = {"stft2048_power32": 256 * FR2048 * 6148, "stft2048_complex32": 256 * FR2048 * (2048 + 8200), "stft2048_mel32": 256 * FR2048 * (2048 + 512),
         "istft2048": 256 * (FR2048 * 8200 + 480000 * 4), "mel_apply_mfma": 256 * FR2048 * (4100 + 512), "fir_ols_split": 8 * 2880000 * 8,
-        "stft_power_lanes_kernel<16": 256 * FR1K * (1024 + 2052), "stft_power_lanes_kernel<8": 256 * FR512 * (512 + 1028)}
+        "stft_power_lanes_kernel<16": 256 * FR1K * (1024 + 2052), "stft_power_lanes_kernel<8": 256 * FR512 * (512 + 1028),
+        "wide64::stft2048_power_wide": 256 * FR2048 * 6148}
 table = {}
 for name, v in k.items():
     cc = v["counters"]
@@ -48,7 +49,10 @@ tj["per_kernel"] = table
 json.dump(tj, open(os.path.join(ROOT, "profiles", "hbm_traffic.json"), "w"), indent=1)
 out = {"profile": "profiles/%s/pmc_hot_kernels.json" % rnd,
        "definition": "SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 XCDs x 1024 SIMDs); fp32 MFMA peak 157.3 TFLOP/s (MI355X_MICROARCH.md)"}
-for name, key, flop_per_mfma in (("fused_audio_to_mel", "stft2048_mel32_kernel<true, 2>", 2048), ("mel_apply", "mel_apply_mfma_kernel<true>", 4096)):
+# the fused kernel's product: v_mfma_f32_4x4x1_16B_f32 (16 blocks x 4 x 4 x 1 x 2 = 512 flop) where the banded plan is taken
+# (kernel<.., 2, 2> / <.., 2, 1>), v_mfma_f32_16x16x4_f32 (2048 flop) for the dense one; Mel.apply: v_mfma_f32_32x32x2_f32 (4096)
+mel_key = next(n for n in ("stft2048_mel32_kernel<true, 2, 2>", "stft2048_mel32_kernel<true, 2, 1>", "stft2048_mel32_kernel<true, 2, 0>", "stft2048_mel32_kernel<true, 2>") if n in k)
+for name, key, flop_per_mfma in (("fused_audio_to_mel", mel_key, 2048 if mel_key.endswith(("2, 0>", "true, 2>")) else 512), ("mel_apply", "mel_apply_mfma_kernel<true>", 4096)):
     cc, dur = k[key]["counters"], k[key]["duration"]
     util = cc["SQ_VALU_MFMA_BUSY_CYCLES"] / (cc["GRBM_GUI_ACTIVE"] / 8.0 * 1024.0)
     flops = cc["SQ_INSTS_VALU_MFMA_F32"] * flop_per_mfma
