@@ -366,11 +366,12 @@ void launch_interior(const StftJob &job, const FastTarget &tg, const float *x, i
     m.out_offset = out_offset;
     auto launch_mel_lanes = [&](auto ll) {
       constexpr int LL = decltype(ll)::value;
-      auto by_power = [&](auto al) {
-        constexpr bool A = decltype(al)::value;
-        return a.pmode == 2 ? stft_mel_lanes_kernel<LL, A, 2> : a.pmode == 1 ? stft_mel_lanes_kernel<LL, A, 1> : stft_mel_lanes_kernel<LL, A, 0>;
+      auto by_power = [&](auto al, auto fr) {
+        constexpr bool A = decltype(al)::value, F = decltype(fr)::value;
+        return a.pmode == 2 ? stft_mel_lanes_kernel<LL, A, 2, F> : a.pmode == 1 ? stft_mel_lanes_kernel<LL, A, 1, F> : stft_mel_lanes_kernel<LL, A, 0, F>;
       };
-      auto kl = aligned ? by_power(std::true_type{}) : by_power(std::false_type{});
+      auto by_al = [&](auto fr) { return aligned ? by_power(std::true_type{}, fr) : by_power(std::false_type{}, fr); };
+      auto kl = m.four == 2 ? by_al(std::true_type{}) : by_al(std::false_type{});
       SMX_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kl), hipFuncAttributeMaxDynamicSharedMemorySize, (int)PL<LL>::Lds));
       SMX_LAUNCH(kl, dim3((unsigned)a.blocks), dim3(512), PL<LL>::Lds, job.stream, a, m);
     };
@@ -603,8 +604,8 @@ bool launch_mel_spectrogram_fused(const MelSpecJob &job) {
     return launch_mel_spectrogram_16(job);
   if (!lanes && !fast_eligible(sj0)) return launch_mel_spectrogram_16(job);
   // fft 2048: the banded 4 x 4 x 1 product where its plan exists (SMX_MEL_DENSE=1: the dense 16 x 16 x 4 one, A/B and tests)
-  const MelFusedPlan *p4 = (!lanes && env_flag("SMX_MEL_DENSE") != 1) ? &job.mel->fused4_plan() : nullptr;
-  const bool four = p4 && p4->state == 1;
+  const MelFusedPlan *p4 = env_flag("SMX_MEL_DENSE") != 1 ? &job.mel->fused4_plan() : nullptr;
+  const bool four = p4 && p4->state == 1 && (!lanes || p4->resident);   // (the lanes kernels have the resident form only)
   const MelFusedPlan &pl = four ? *p4 : job.mel->fused32_plan();
   if (pl.state != 1) return launch_mel_spectrogram_16(job);
   if (sj0.count <= 0 || sj0.lead <= 0) return true;
@@ -732,7 +733,8 @@ const smx::MelFusedPlan &smx_mel_config::fused4_plan() const {
   if (plan.state != 0) return plan;
   plan.state = -1;
   const int64_t nb = bins();
-  if (fft_size != kN || n_mels < 1 || n_mels > 252) return plan;
+  if ((fft_size != kN && fft_size != kN16 && fft_size != kN8) || n_mels < 1 || n_mels > 252) return plan;
+  const int max_chunks = fft_size == kN ? kMel4rChunks : kMel4rChunksL;   // operand registers / 8 of the kernel that takes the plan
   struct Group { int row0, nr, lo, len; };
   std::vector<Group> groups;
   int64_t total = 0;
@@ -818,7 +820,7 @@ const smx::MelFusedPlan &smx_mel_config::fused4_plan() const {
       const int need = (it.steps + 7) / 8;
       int w = -1;
       for (int i = 0; i < 8; ++i)
-        if ((int)per_wave[(size_t)i].size() < kMel32MaxItems && chunks[i] + need <= kMel4rChunks && (w < 0 || chunks[i] < chunks[w])) w = i;
+        if ((int)per_wave[(size_t)i].size() < kMel32MaxItems && chunks[i] + need <= max_chunks && (w < 0 || chunks[i] < chunks[w])) w = i;
       if (w < 0) { fits = false; break; }
       per_wave[(size_t)w].push_back(&it);
       chunks[w] += need;
@@ -826,7 +828,7 @@ const smx::MelFusedPlan &smx_mel_config::fused4_plan() const {
     if (fits) {
       std::vector<Mel4Item> table(8 * kMel32MaxItems, Mel4Item{});
       std::vector<float> wm;
-      wm.reserve((size_t)8 * 64 * 64);
+      wm.reserve((size_t)8 * 8 * max_chunks * 64);
       for (int w = 0; w < 8; ++w) {
         int n = 0, used = 0;
         for (const Item *it : per_wave[(size_t)w]) {
@@ -835,7 +837,7 @@ const smx::MelFusedPlan &smx_mel_config::fused4_plan() const {
           for (int st = 0; st < steps; ++st) weight_row(*it, st, wm);
           used += steps;
         }
-        wm.resize(wm.size() + (size_t)(64 - used) * 64, 0.0f);
+        wm.resize(wm.size() + (size_t)(8 * max_chunks - used) * 64, 0.0f);
       }
       SMX_HIP_CHECK(hipMalloc(&plan.items, table.size() * sizeof(Mel4Item)));
       SMX_HIP_CHECK(hipMemcpy(plan.items, table.data(), table.size() * sizeof(Mel4Item), hipMemcpyHostToDevice));
@@ -846,6 +848,7 @@ const smx::MelFusedPlan &smx_mel_config::fused4_plan() const {
       return plan;
     }
   }
+  if (fft_size != kN) return plan;   // the streamed form exists for the fft-2048 kernel only
   std::vector<Mel4Item> table(8 * kMel32MaxItems, Mel4Item{});
   int load[8] = {0}, count[8] = {0};
   std::vector<float> wm;

@@ -285,12 +285,17 @@ __device__ __forceinline__ void mel4_items(const Mel32Args &m, int iv, const flo
 // of it L2 latency; the MFMA work itself is 46 x 8 cycles.)  Register indices must be static: the chunk loop is written out,
 // an item is a whole number of chunks (zero weights pad it), and the item that a chunk belongs to is scalar state.
 constexpr int kMel4rChunks = 8;
-template <int TS = kTileStride>
-__device__ __forceinline__ void mel4r_items(const Mel32Args &m, int iv, const float (&areg)[8 * kMel4rChunks], const float *tile, float *obase,
+// TS: floats per tile row; NCG: groups of 16 frame columns multiplied at once (the tiles of the 16- / 8-lane kernels hold 32 / 64
+// frames: an operand register serves every group); CHUNKS: operand registers / 8; SUB: steps per request (B values in flight:
+// 2 x SUB x NCG registers)
+template <int TS = kTileStride, int NCG = 1, int CHUNKS = kMel4rChunks, int SUB = 8>
+__device__ __forceinline__ void mel4r_items(const Mel32Args &m, int iv, const float (&areg)[8 * CHUNKS], const float *tile, float *obase,
                                             int frames_left, int lane) {
   using f32x4m = __attribute__((ext_vector_type(4))) float;
+  constexpr int SLOTS = 8 * CHUNKS / SUB;
+  constexpr int NA = NCG == 1 ? 2 : NCG;   // accumulators: two alternating ones for a single column group, one per group otherwise
   const int mg = lane >> 4, f = lane & 15;
-  // scalar state of the chunk being REQUESTED (one ahead of the chunk being multiplied)
+  // scalar state of the sub-chunk being REQUESTED (one ahead of the one being multiplied)
   int item = 0, st = 0, steps = 0, mode = 0, rows = 0, nrw = 0;
   const float *bp = tile;
   int room = 0;
@@ -309,23 +314,27 @@ __device__ __forceinline__ void mel4r_items(const Mel32Args &m, int iv, const fl
   };
   open_item();
   if (steps == 0) return;
-  float bv[2][8];
+  float bv[2][SUB][NCG];
   auto request = [&](int slot) {
 #pragma unroll
-    for (int u = 0; u < 8; ++u) {
+    for (int u = 0; u < SUB; ++u) {
       const int q = st + u;
-      bv[slot][u] = bp[(q < room ? q : room) * TS];
+      const float *row = bp + (q < room ? q : room) * TS;
+#pragma unroll
+      for (int g = 0; g < NCG; ++g) bv[slot][u][g] = row[16 * g];
     }
   };
-  f32x4m acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+  f32x4m acc[NA];
+#pragma unroll
+  for (int g = 0; g < NA; ++g) acc[g] = f32x4m{0.f, 0.f, 0.f, 0.f};
   request(0);
 #pragma unroll
-  for (int c = 0; c < kMel4rChunks; ++c) {
-    // the chunk being multiplied: c.  Its item's output description, before the state moves on
+  for (int c = 0; c < SLOTS; ++c) {
+    // the sub-chunk being multiplied: c.  Its item's output description, before the state moves on
     const int c_mode = mode, c_rows = rows, c_nrw = nrw;
-    const bool c_last = st + 8 >= steps;
+    const bool c_last = st + SUB >= steps;
     bool more = false;
-    if (c + 1 < kMel4rChunks) {   // advance the request state to chunk c + 1 and request it
+    if (c + 1 < SLOTS) {   // advance the request state to sub-chunk c + 1 and request it
       if (c_last) {
         ++item;
         if (item < kMel32MaxItems) {
@@ -333,40 +342,45 @@ __device__ __forceinline__ void mel4r_items(const Mel32Args &m, int iv, const fl
           more = steps != 0;
         }
       } else {
-        st += 8;
+        st += SUB;
         more = true;
       }
       if (more) request((c + 1) & 1);
     }
 #pragma unroll
-    for (int u = 0; u < 8; u += 2) {
-      acc0 = __builtin_amdgcn_mfma_f32_4x4x1f32(areg[8 * c + u], bv[c & 1][u], acc0, 0, 0, 0);
-      acc1 = __builtin_amdgcn_mfma_f32_4x4x1f32(areg[8 * c + u + 1], bv[c & 1][u + 1], acc1, 0, 0, 0);
-    }
-    if (c_last) {
-      f32x4m acc = acc0 + acc1;
-      if (c_mode >= 2) {   // wave-uniform: add the K-parts across the lane groups, (p0 + p1) + (p2 + p3)
-        const int from16 = ((lane + 16) & 63) << 2, from32 = ((lane + 32) & 63) << 2;
-        auto from = [&](int addr, float v) { return __int_as_float(__builtin_amdgcn_ds_bpermute(addr, __float_as_int(v))); };
-        const float a0 = acc[0], a1 = acc[1], a2 = acc[2], a3 = acc[3];
-        float s0 = a0 + from(from16, a0), s1 = a1 + from(from16, a1), s2 = a2 + from(from16, a2), s3 = a3 + from(from16, a3);
-        if (c_mode == 4) {
-          s0 = s0 + from(from32, s0);
-          s1 = s1 + from(from32, s1);
-          s2 = s2 + from(from32, s2);
-          s3 = s3 + from(from32, s3);
-        }
-        acc = f32x4m{s0, s1, s2, s3};
+    for (int u = 0; u < SUB; ++u)
+#pragma unroll
+      for (int g = 0; g < NCG; ++g) {
+        const int t = NCG == 1 ? (u & 1) : g;
+        acc[t] = __builtin_amdgcn_mfma_f32_4x4x1f32(areg[SUB * c + u], bv[c & 1][u][g], acc[t], 0, 0, 0);
       }
+    if (c_last) {
       const bool owner = c_mode == 1 || (c_mode == 2 ? (mg & 1) == 0 : mg == 0);
       const int row0 = (c_rows >> (8 * mg)) & 255, nr = (c_nrw >> (8 * mg)) & 255;
-      if (owner && f < frames_left) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r)
-          if (r < nr) obase[(int64_t)(row0 + r) * m.out_stride + f] = acc[r];
+      for (int g = 0; g < NCG; ++g) {
+        f32x4m sum = NCG == 1 ? acc[0] + acc[1] : acc[g];
+        if (c_mode >= 2) {   // wave-uniform: add the K-parts across the lane groups, (p0 + p1) + (p2 + p3)
+          const int from16 = ((lane + 16) & 63) << 2, from32 = ((lane + 32) & 63) << 2;
+          auto from = [&](int addr, float v) { return __int_as_float(__builtin_amdgcn_ds_bpermute(addr, __float_as_int(v))); };
+          const float a0 = sum[0], a1 = sum[1], a2 = sum[2], a3 = sum[3];
+          float s0 = a0 + from(from16, a0), s1 = a1 + from(from16, a1), s2 = a2 + from(from16, a2), s3 = a3 + from(from16, a3);
+          if (c_mode == 4) {
+            s0 = s0 + from(from32, s0);
+            s1 = s1 + from(from32, s1);
+            s2 = s2 + from(from32, s2);
+            s3 = s3 + from(from32, s3);
+          }
+          sum = f32x4m{s0, s1, s2, s3};
+        }
+        if (owner && 16 * g + f < frames_left) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            if (r < nr) obase[(int64_t)(row0 + r) * m.out_stride + 16 * g + f] = sum[r];
+        }
       }
-      acc0 = f32x4m{0.f, 0.f, 0.f, 0.f};
-      acc1 = f32x4m{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int g = 0; g < NA; ++g) acc[g] = f32x4m{0.f, 0.f, 0.f, 0.f};
     }
     if (!more) break;
   }

@@ -508,11 +508,13 @@ __global__ void __launch_bounds__(512) stft_power_lanes_kernel(FastArgs a) {
 #ifndef SMX_MEL_LANES_MULTI
 #define SMX_MEL_LANES_MULTI 1   // A operands once per chunk for all column groups (fft 1024: 0.572 -> 0.523 ms, fft 512: 0.671 -> 0.560)
 #endif
-template <int LL, bool ALIGNED>
+constexpr int kMel4rChunksL = 4;   // resident A operands of the lanes kernels: 32 registers (their bands are 2 - 4 times shorter)
+template <int LL, bool ALIGNED, bool FOUR>
 struct MelMidL {
   using P = PL<LL>;
   const FastArgs &a;
   const Mel32Args &m;
+  const float (&areg)[8 * kMel4rChunksL];
   int iv;
   const LdsL<LL> &lds;
   float2 (&raw)[32];
@@ -531,6 +533,11 @@ struct MelMidL {
   __device__ __forceinline__ void after_exchange_issue() const {
     if (it > 0) {
       lds_wait32(lds.filled + (b ^ 1) * P::TS, 8u * (((unsigned)(it - 1) >> 1) + 1), pk_filled);
+      if constexpr (FOUR) {
+        mel4r_items<P::TS, P::FT / 16, kMel4rChunksL, (LL == 16 ? 8 : 4)>(m, iv, areg, lds.tiles + (b ^ 1) * P::TileFloats, pend_out, pend_left, lane);
+        lds_signal32(lds.drained + (b ^ 1) * P::TS, lane);
+        return;
+      }
 #if SMX_MEL_LANES_MULTI
       mel32_items_multi<P::TS, P::FT / 16, (LL == 16 ? 4 : 2)>(m, iv, lds.tiles + (b ^ 1) * P::TileFloats, pend_out, pend_left, lane);
 #else
@@ -546,7 +553,7 @@ struct MelMidL {
   }
 };
 
-template <int LL, bool ALIGNED, int PMODE>
+template <int LL, bool ALIGNED, int PMODE, bool FOUR = false>
 __global__ void __launch_bounds__(512) stft_mel_lanes_kernel(FastArgs a, Mel32Args m) {
   using P = PL<LL>;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -580,6 +587,11 @@ __global__ void __launch_bounds__(512) stft_mel_lanes_kernel(FastArgs a, Mel32Ar
   int pend_left = 0;
   unsigned pk_drained = 0, pk_filled = 0;
   const int iv = reinterpret_cast<const int *>(m.items + wave * kMel32MaxItems)[lane];   // this wave's items (8 x 8 ints)
+  float areg[8 * kMel4rChunksL];
+  if constexpr (FOUR) {   // the wave's A operands of the banded product: [wave][step][lane], loaded once
+#pragma unroll
+    for (int q = 0; q < 8 * kMel4rChunksL; ++q) areg[q] = m.w[(wave * 8 * kMel4rChunksL + q) * 64 + lane];
+  }
   for (int it = 0; it < ntiles; ++it) {
     const int b = it & 1;
     int ftnext;
@@ -588,7 +600,7 @@ __global__ void __launch_bounds__(512) stft_mel_lanes_kernel(FastArgs a, Mel32Ar
     tw.peek(a, ftnext, xnext, onext);
     const bool more = it + 1 < ntiles;
     const float *src = frame_ptr(more ? xnext : tw.xclip, more ? ftnext : tw.ft);
-    const MelMidL<LL, ALIGNED> mid{a, m, iv, lds, raw, src, pend_out, pend_left, lane, wave, b, it, pk_drained, pk_filled};
+    const MelMidL<LL, ALIGNED, FOUR> mid{a, m, areg, iv, lds, raw, src, pend_out, pend_left, lane, wave, b, it, pk_drained, pk_filled};
     frameL_to_tile<LL, PMODE>(a, L, raw, lds.tiles + b * P::TileFloats, mid);
     lds_signal32(lds.filled + b * P::TS, lane);
     pend_out = tw.oclip + tw.ft * P::FT;
@@ -601,6 +613,10 @@ __global__ void __launch_bounds__(512) stft_mel_lanes_kernel(FastArgs a, Mel32Ar
   if (ntiles > 0) {
     const int b = (ntiles - 1) & 1;
     lds_wait(lds.filled + b * P::TS, 8u * (((unsigned)(ntiles - 1) >> 1) + 1));
+    if constexpr (FOUR) {
+      mel4r_items<P::TS, P::FT / 16, kMel4rChunksL, (LL == 16 ? 8 : 4)>(m, iv, areg, lds.tiles + b * P::TileFloats, pend_out, pend_left, lane);
+      return;
+    }
 #if SMX_MEL_LANES_MULTI
     mel32_items_multi<P::TS, P::FT / 16, (LL == 16 ? 4 : 2)>(m, iv, lds.tiles + b * P::TileFloats, pend_out, pend_left, lane);
 #else
