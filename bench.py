@@ -58,6 +58,10 @@ def parse_args():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--preroll-ms", type=float, default=60.0,
+                    help="device preconditioning before the W warm-up steps: the same step repeated for this long (not timed, not counted; "
+                         "0 = none).  A burst from idle runs up to 25 %% slower between its 5th and 25th launch while the power "
+                         "management settles (profiles/r06/step_time_transient.log); the metric is the sustained rate")
     ap.add_argument("--workload", choices=("auto", "c2", "c5"), default="auto",
                     help="auto = c2: BASELINE configs[1] per GPU at every N (weak); c5: configs[4] sharded (strong)")
     ap.add_argument("--clips", type=int, default=0,
@@ -242,6 +246,17 @@ def main():
     def timed(step, steps, warmup):
         """W warm-up steps, then K steps between barriers; HIP events on the launch stream around every step.
         Returns (elapsed seconds, MAX over ranks; sorted per-step ms of this rank; launches per step)."""
+        preroll_steps = 0
+        if args.preroll_ms > 0:   # bring the chip to its sustained state (see --preroll-ms)
+            t_pre = time.perf_counter()
+            while True:
+                for _ in range(4):
+                    step()
+                preroll_steps += 4
+                torch.cuda.synchronize()
+                if (time.perf_counter() - t_pre) * 1e3 >= args.preroll_ms:
+                    break
+        timed.preroll_steps = preroll_steps
         for _ in range(warmup):
             step()
         barrier()
@@ -287,6 +302,7 @@ def main():
     x = make_clip_batch(lo, hi, n)
     out = torch.empty(clips, BINS, frames, device=dev, dtype=torch.float32)
     elapsed, step_ms, launches = timed(power_step(x, out, clips, n, frames), args.steps, args.warmup)
+    main_preroll_steps = timed.preroll_steps
     # One step is ONE launch of the fused kernel (interior tiles, then the few border frames of every clip through
     # the same frame code), so the HIP events around a step are that kernel's launch durations: their average is
     # what `rocprofv3 --kernel-trace --stats` of this command reports for it (profiles/).
@@ -337,7 +353,10 @@ def main():
             "config": {"workload": "%s (uniform[-1,1), clip g seeded 42+g), STFT n_fft=2048 hop=512 Hann centered/reflect "
                                    "power=2 -> [clips;1025;%d], device-resident in and out" % (wname, frames),
                        "frames_per_gpu": clips * frames, "sharding": "clips over ranks, no collective",
-                       "timing_backend": backend},
+                       "timing_backend": backend,
+                       # untimed, uncounted: the same step repeated before the W warm-up steps until the chip's power management has
+                       # settled (--preroll-ms; `extra.c2_burst_from_idle` is the same measurement without it)
+                       "preconditioning": {"ms": args.preroll_ms, "steps": main_preroll_steps}},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_source,
                          "frac_of_measured": round(achieved / HBM_MEASURED_GBS, 4), "measured_peak": HBM_MEASURED_GBS,
@@ -361,6 +380,17 @@ def main():
     if not args.no_extras:
         k, w = max(5, min(args.steps, 20)), max(2, min(args.warmup, 5))
         if world == 1 and workload == "c2" and clips == 256:
+            # The headline measurement WITHOUT its preconditioning: W warm-up steps and K timed ones right out of an idle device
+            # (the CPU baseline above left it idle for seconds).  Reported so that the effect of --preroll-ms is on the record.
+            pre = args.preroll_ms
+            args.preroll_ms = 0.0
+            try:
+                el, ms, _ = timed(power_step(x, out, clips, n, frames), args.steps, args.warmup)
+            finally:
+                args.preroll_ms = pre
+            extra["c2_burst_from_idle"] = {"workload": "the headline step, %d timed after %d warm-up steps, from an idle device (no preconditioning)" % (args.steps, args.warmup),
+                                           "value": round(clips * frames * args.steps / el / 1e6, 1), "unit": "Mframes/s",
+                                           "kernel_ms_avg": round(sum(ms) / len(ms), 4), "kernel_ms_min": round(ms[0], 4), "kernel_ms_max": round(ms[-1], 4)}
             # C3: fused mel spectrogram (128 mels) of the same batch
             mc = Mel.Config.create(n_mels=128, sample_rate=SR, fft_size=FFT)
             mout = torch.empty(clips, 128, frames, device=dev, dtype=torch.float32)
