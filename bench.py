@@ -27,6 +27,12 @@ The only communication is the timing barrier and the MAX-over-ranks reduction of
 the clock (RCCL when every rank has its own GPU; gloo when ranks share a device,
 which RCCL refuses -- the 2-rank test on a 1-GPU box).
 
+Timing: W untimed warm-up steps, then exactly K steps between barrier + synchronize.  Before the warm-up steps the same step
+runs for --preroll-ms (default 60 ms, untimed, uncounted, reported as `config.preconditioning`): out of an idle device the
+kernel's time is not stationary (0.51 ms for three launches, 0.61-0.64 for the next ten, the sustained 0.50 after ~40 --
+profiles/r06/step_time_transient.log), and `--steps 20 --warmup 5` would sample that hump.  `value` is the sustained rate;
+`extra.c2_burst_from_idle` is the same K / W measurement out of an idle device, in every run.
+
 Rank 0 prints ONE JSON line: whole-job Mframes/s, the HBM roofline of the dominant
 kernel (HIP events on the launch stream) and, at N = 1, the CPU baseline: the
 oracle's C restatement (float64 interior, all host cores) on the SAME C2 batch, whose

@@ -6,7 +6,7 @@
 Usage: python tools/derive_profile_json.py r04"""
 import json, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-rnd = sys.argv[1] if len(sys.argv) > 1 else "r06b"
+rnd = sys.argv[1] if len(sys.argv) > 1 else "r06c"
 src = os.path.join(ROOT, "profiles", rnd, "pmc_hot_kernels.json")
 k = json.load(open(src))["kernels"]
 hkey = next(n for n in ("stft2048_power32_kernel<true, 2, false, 1>", "stft2048_power32_kernel<true, 2, false, 2>", "stft2048_power32_kernel<true, 2, false, 0>",
