@@ -23,8 +23,8 @@
 //    END: two LDS counters (tiles filled / tiles drained), no workgroup barrier in the loop.  The two waves of a SIMD settle
 //    half a frame apart: a wave of the late half finds the tile complete behind its first pass and flushes there.
 // What bounds it (profiles/r06/NOTES.md section 4): float64 vector instructions take 4 cycles per wave (v_fma / v_add / v_mul_f64;
-// the IEEE sqrt of magnitude_pow 69), ~5 900 cycles per frame, and the chip runs this kernel at 1.85-2.0 GHz: 0.70 ms of
-// pure issue at C2; measured 1.11 ms, 58 % of that rate.
+// the IEEE sqrt of magnitude_pow 69), ~5 900 cycles per frame, and the chip holds 2.20 GHz under the kernel (tools/clock_check.py):
+// 0.61 ms of pure issue at C2; measured 1.11 ms, 59 % of that rate.
 // LDS: 8 x 8,192 (scratch) + 65,664 (tile) + 16,384 (window) + 4,096 (pass twiddles) + 64 = 151,744 B.
 #ifndef SMX_W64_EARLY
 #define SMX_W64_EARLY 1
