@@ -4,14 +4,15 @@
 //
 // The frame code is frame32_to_tile unchanged: every tile of 16 frames x 1025 powers lands in LDS exactly as the power
 // kernel leaves it.  Where that kernel reads its share of the previous tile out to HBM, this one multiplies the tile by the
-// filterbank: v_mfma_f32_16x16x4_f32 with A = W[16 mels][4 bins] (global memory, pre-arranged in lane order, L2 resident),
-// B = P[4 bins][16 frames] (one LDS read per lane: tile rows ARE bins in this pipeline), K running over the union band of
-// the item's mels only.  The work is cut into ITEMS of up to 16 mel rows, each summed over its whole band by ONE wave in
-// ascending bin order -- no partial sums to combine, one value per (mel, frame) whatever the batch -- and the items are
-// dealt to the 8 waves by length (the planner splits the rows of the longest items until no wave holds much more than an
-// eighth of the steps: mel_config::fused32_plan).  The operands of kMel32Chunk steps (8: measured best of 4 / 8 / 12 / 16 / 24 / 32) are requested together and multiplied
-// together: an LDS round trip takes ~2000 cycles under this kernel's load, a dependent read -> multiply loop pays it per step.
-// The spectrogram never reaches HBM: 2048 + 4 n_mels bytes per frame.
+// filterbank; the spectrogram never reaches HBM: 2048 + 4 n_mels bytes per frame.  Two forms of the product (chosen by the
+// host: Mel32Args::four):
+//  * DENSE (Mel32Item; the form of rounds 1-3, SMX_MEL_DENSE=1, and of plans the banded form does not take):
+//    v_mfma_f32_16x16x4_f32 with A = W[16 mels][4 bins] (global memory, pre-arranged in lane order, L2 resident), B = P[4 bins]
+//    [16 frames] (one LDS read per lane: tile rows ARE bins in this pipeline), K running over the union band of the item's mels.
+//    The work is cut into ITEMS of up to 16 mel rows, each summed over its whole band by ONE wave in ascending bin order, dealt to
+//    the 8 waves by length (mel_config::fused32_plan); the operands of two chunks of 8 steps are in flight at a time.
+//  * BANDED (Mel4Item, further down; the default): v_mfma_f32_4x4x1_16B_f32, every 4-mel group over its own band, the A
+//    operands resident in registers (mel4r_items) or streamed (mel4_items).
 constexpr int kMel32MaxItems = 8;      // per wave
 #ifndef SMX_MEL32_CHUNK
 #define SMX_MEL32_CHUNK 8

@@ -30,6 +30,9 @@ BANKS = [
     (512, 80, 16000, "slaney", "slaney", 0.0, None),        # the 8-lane kernel: four groups of columns
     (512, 40, 16000, "htk", "slaney", 50.0, 7000.0),
     (512, 20, 8000, "slaney", "none", 0.0, None),
+    (2048, 1, 16000, "slaney", "slaney", 0.0, None),        # one, two, three rows: a single lane group, partly idle
+    (2048, 2, 16000, "htk", "none", 1000.0, 3000.0),
+    (1024, 3, 22050, "slaney", "slaney", 0.0, None),
 ]
 
 
@@ -50,7 +53,7 @@ def test_banded_and_dense_products_meet_the_oracle(fft, n_mels, sr, scale, norm,
     except S.InvalidArgument:
         pytest.skip("the reference rejects this filterbank (an empty filter)")
     om = O.mel_config(n_mels, sr, fft, f_min=f_min, f_max=f_max, scale=scale, norm=norm)
-    for power in (2.0, 1.0):
+    for power in (2.0, 1.0, 3.0):
         want = O.mel_spectrogram(so, om, x, power)
         peak = float(np.max(np.abs(want)))
         banded = S.mel_spectrogram(sc, mc, x, power)

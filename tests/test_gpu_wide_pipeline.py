@@ -107,3 +107,20 @@ def test_streaming_chunks_total_the_offline_result():
             parts.append(out)
     got = st.concat(parts + st.flush())
     assert got.shape == want.shape and np.array_equal(got, want)
+
+
+def test_single_frames_odd_origins_and_many_clips():
+    """one frame, a clip that starts on an odd float of its allocation (4-byte aligned samples only), a batch with more tiles than
+    workgroups several times over: both kernels, same bits"""
+    import torch
+    torch.manual_seed(2)
+    c = Stft.Config.create(fft_size=2048, hop=512, alignment="left", pad=("constant", 0.25))
+    big = (torch.rand(3 * 2048 + 7, device="cuda") * 2 - 1).float()
+    for off, n in ((1, 2048), (3, 2049), (0, 100), (5, 2048 * 3)):
+        x = big[off:off + n]
+        new, old = both(lambda: Stft.power_spectrum(c, x, 2.0))
+        assert new.shape == old.shape and torch.equal(new, old), (off, n)
+    c2 = Stft.Config.create(fft_size=2048, hop=512)
+    x = (torch.rand(1200, 9000, device="cuda") * 2 - 1).float()      # 18 frames per clip: a full and a ragged tile, 2400 tiles
+    new, old = both(lambda: Stft.power_spectrum(c2, x, 1.0))
+    assert torch.equal(new, old)
