@@ -13,6 +13,8 @@ from oracle import soundml_oracle as O
 cases = int(sys.argv[1]) if len(sys.argv) > 1 else 200
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
 FFTS = [16, 31, 64, 100, 256, 400, 441, 512, 1000, 1024, 1200, 2048, 4096]
+if os.environ.get("FUZZ_FFTS"):   # e.g. FUZZ_FFTS=2048,1024,512: the sizes of the register pipelines only
+    FFTS = [int(v) for v in os.environ["FUZZ_FFTS"].split(",")]
 
 
 def close(a, e, rtol, atol_rel, what, floor=0.0):
