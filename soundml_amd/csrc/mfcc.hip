@@ -61,6 +61,7 @@ struct MfccArgs {
   void *out;                // [lead; n_mfcc; frames]
   const double *dct;        // [n_mfcc; n_mels] raw type-II rows 2 cos(pi k (2m+1) / (2 n_mels))
   const double *post;       // [n_mfcc; 2]: orthonormal scale, lifter weight (1 when absent)
+  const double *dct_t;      // [n_mels; 32]: the rows transposed, zeros beyond n_mfcc (n_mfcc <= 32)
   const unsigned long long *max_bits;
   int64_t lead, frames;
   int n_mels, n_mfcc;
@@ -99,6 +100,90 @@ __global__ void __launch_bounds__(256) mfcc_kernel(MfccArgs a) {
         out[(int64_t)(k0 + i) * a.frames] = (T)c;
       }
   }
+}
+
+// The same for float32 data, where the double-precision logarithm was the cost (mfcc_kernel<float>: 0.25 ms at C3, three quarters
+// of it the library log, ~80 instructions per value).  A float64 logarithm good to 1.5e-14 absolute in 12 instructions: v = m 2^e,
+// the top 7 mantissa bits pick a centre c (table of 1 / c and ln c, 128 entries, built on the host with the host's log),
+// r = m / c - 1 (|r| < 2^-8), ln v = e ln 2 + ln c + (r - r^2/2 + r^3/3 - r^4/4 + r^5/5).  The decibels it feeds are float64 as
+// the reference's are (soundml.ml:50-95), rounded ONCE to float32 at the end: the result differs from the library log's by a
+// float32 rounding flip in ~1e-7 of the values.  The DCT rows sit in LDS (a value read by all lanes of a wave is one broadcast
+// access); four mel rows are requested per trip.
+constexpr int kFastMfccMaxCoeffs = 32;
+// (kept out of line so that it stays a branch: inlined, the compiler evaluates it beside the table form and selects)
+__device__ __noinline__ double library_log(double v) { return log(v); }
+__device__ __forceinline__ double table_log(double v, const double2 *tab) {
+  const long long b = __double_as_longlong(v);
+  const int e = (int)((b >> 52) & 0x7ff) - 1023;
+  const double2 t = tab[(int)((b >> 45) & 127)];
+  const double m = __longlong_as_double((b & 0x000fffffffffffffLL) | 0x3ff0000000000000LL);
+  const double r = fma(m, t.x, -1.0);
+  const double p = r * fma(r, fma(r, fma(r, fma(r, 0.2, -0.25), 1.0 / 3.0), -0.5), 1.0);
+  return fma((double)e, 0.69314718055994530942, t.y + p);
+}
+// NC: the coefficient count rounded up to a multiple of 8: the accumulation is NC fused multiply-adds per mel row with no branch
+// between them; a row's coefficients come as wave-uniform (scalar) loads from the transposed table [mel][32] (zeros beyond n_mfcc).
+// A workgroup is 64 frames x the mel axis in FOUR quarters, one per wave (lane = frame: a wave reads 256 contiguous bytes of a mel
+// row): four times the waves, a quarter of the dependent requests per thread; the quarters' sums meet in LDS and are added in
+// the fixed order ((q0 + q1) + q2) + q3 before the one rounding to float32.
+template <int NC>
+__global__ void __launch_bounds__(256) mfcc_fast_kernel(MfccArgs a, const double2 *log_table) {
+  __shared__ double2 ltab[128];                 // {1 / c, ln c}
+  __shared__ double part[3][NC][64];
+  for (int e = threadIdx.x; e < 128; e += 256) ltab[e] = log_table[e];
+  __syncthreads();
+  const int lane = threadIdx.x & 63, quarter = threadIdx.x >> 6;
+  const int64_t t = (int64_t)blockIdx.x * 64 + lane;
+  const int64_t clip = blockIdx.y;
+  const int64_t tc = t < a.frames ? t : a.frames - 1;               // (the last block's idle lanes read a valid column)
+  const float *mel = reinterpret_cast<const float *>(a.mel) + clip * a.n_mels * a.frames + tc;
+  constexpr double amin = 1e-10;                      // convert.ml:46, soundml.ml:80
+  const double decade = 10.0 / log(10.0);             // convert.ml:23
+  const double top = __longlong_as_double((long long)*a.max_bits);
+  const double floor_db = decade * log(top > amin ? top : amin) - 80.0;   // offset is 0 for reference 1
+  double acc[NC];
+#pragma unroll
+  for (int i = 0; i < NC; ++i) acc[i] = 0.0;
+  auto one = [&](int m, float x) {
+    const double v = (double)x;
+    const double u = v > amin ? v : amin;
+    // (inf and NaN take the library's log: the table form reads their bits as a number)
+    double lg;
+    if (u < 1.0e300) lg = table_log(u, ltab);
+    else lg = library_log(u);
+    double db = decade * lg;
+    db = db > floor_db ? db : floor_db;
+    const double *row = a.dct_t + m * 32;     // wave-uniform address: scalar loads
+#pragma unroll
+    for (int i = 0; i < NC; ++i) acc[i] = fma(db, row[i], acc[i]);
+  };
+  const int per = (a.n_mels + 3) / 4;
+  int m = __builtin_amdgcn_readfirstlane(quarter * per);
+  const int m_end = __builtin_amdgcn_readfirstlane(m + per < a.n_mels ? m + per : a.n_mels);
+  for (; m + 4 <= m_end; m += 4) {   // four mel rows requested per trip (sixteen: slower -- 16 x NC scalar operands do not fit)
+    const float x0 = mel[(int64_t)m * a.frames], x1 = mel[(int64_t)(m + 1) * a.frames];
+    const float x2 = mel[(int64_t)(m + 2) * a.frames], x3 = mel[(int64_t)(m + 3) * a.frames];
+    one(m, x0);
+    one(m + 1, x1);
+    one(m + 2, x2);
+    one(m + 3, x3);
+  }
+  for (; m < m_end; ++m) one(m, mel[(int64_t)m * a.frames]);
+  if (quarter > 0) {
+#pragma unroll
+    for (int i = 0; i < NC; ++i) part[quarter - 1][i][lane] = acc[i];
+  }
+  __syncthreads();
+  if (quarter > 0 || t >= a.frames) return;
+  float *out = reinterpret_cast<float *>(a.out) + clip * a.n_mfcc * a.frames + t;
+#pragma unroll
+  for (int i = 0; i < NC; ++i)
+    if (i < a.n_mfcc) {
+      double c = ((acc[i] + part[0][i][lane]) + part[1][i][lane]) + part[2][i][lane];
+      c = c * a.post[2 * i];
+      c = c * a.post[2 * i + 1];
+      out[(int64_t)i * a.frames] = (float)c;
+    }
 }
 
 // Convert.power_to_db / amplitude_to_db (convert.ml:30-62) in the data's own dtype: |s| first for amplitudes, floor at
@@ -261,7 +346,7 @@ const double *mfcc_tables(int n_mels, int n_mfcc, double lifter) {
   std::lock_guard<std::mutex> lock(g_mfcc_mutex);
   auto it = g_mfcc_tables.find(key);
   if (it != g_mfcc_tables.end()) return it->second;
-  std::vector<double> host((size_t)n_mfcc * n_mels + 2 * (size_t)n_mfcc);
+  std::vector<double> host((size_t)n_mfcc * n_mels + 2 * (size_t)n_mfcc + (n_mfcc <= 32 ? (size_t)n_mels * 32 : 0));
   const double pi = 3.14159265358979323846;
   for (int k = 0; k < n_mfcc; ++k)
     for (int m = 0; m < n_mels; ++m)
@@ -271,10 +356,38 @@ const double *mfcc_tables(int n_mels, int n_mfcc, double lifter) {
     post[2 * k] = k == 0 ? 1.0 / std::sqrt(4.0 * n_mels) : 1.0 / std::sqrt(2.0 * n_mels);
     post[2 * k + 1] = lifter > 0.0 ? 1.0 + lifter / 2.0 * std::sin(pi * (double)(k + 1) / lifter) : 1.0;
   }
+  if (n_mfcc <= 32) {   // the same rows transposed, [n_mels][32] with zeros beyond n_mfcc: what mfcc_fast_kernel reads with scalar loads
+    double *tr = post + 2 * (size_t)n_mfcc;
+    for (int m = 0; m < n_mels; ++m)
+      for (int k = 0; k < 32; ++k) tr[(size_t)m * 32 + k] = k < n_mfcc ? host[(size_t)k * n_mels + m] : 0.0;
+  }
   double *dev = nullptr;
   SMX_HIP_CHECK(hipMalloc((void **)&dev, host.size() * sizeof(double)));
   SMX_HIP_CHECK(hipMemcpy(dev, host.data(), host.size() * sizeof(double), hipMemcpyHostToDevice));
   g_mfcc_tables.emplace(key, dev);
+  return dev;
+}
+}  // namespace
+
+namespace {
+// {1 / c, ln c} for c = 1 + (i + 0.5) / 128, i < 128 (table_log), per device, built once
+const double2 *log_table_device() {
+  static std::mutex mutex;
+  static std::map<int, double2 *> tables;
+  int device = 0;
+  SMX_HIP_CHECK(hipGetDevice(&device));
+  std::lock_guard<std::mutex> lock(mutex);
+  auto it = tables.find(device);
+  if (it != tables.end()) return it->second;
+  std::vector<double2> host(128);
+  for (int i = 0; i < 128; ++i) {
+    const double c = 1.0 + ((double)i + 0.5) / 128.0;
+    host[(size_t)i] = make_double2(1.0 / c, std::log(c));
+  }
+  double2 *dev = nullptr;
+  SMX_HIP_CHECK(hipMalloc((void **)&dev, host.size() * sizeof(double2)));
+  SMX_HIP_CHECK(hipMemcpy(dev, host.data(), host.size() * sizeof(double2), hipMemcpyHostToDevice));
+  tables.emplace(device, dev);
   return dev;
 }
 }  // namespace
@@ -301,14 +414,26 @@ void launch_mfcc(const MfccJob &job) {
   a.out = job.out;
   a.dct = d_tab;
   a.post = d_tab + (size_t)n_mfcc * n_mels;
+  a.dct_t = a.post + 2 * (size_t)n_mfcc;
   a.max_bits = d_max;
   a.lead = job.lead;
   a.frames = job.frames;
   a.n_mels = n_mels;
   a.n_mfcc = n_mfcc;
   dim3 grid((unsigned)((job.frames + 255) / 256), (unsigned)job.lead);
-  if (job.elem_bytes == 8) SMX_LAUNCH(mfcc_kernel<double>, grid, dim3(256), 0, job.stream, a);
-  else SMX_LAUNCH(mfcc_kernel<float>, grid, dim3(256), 0, job.stream, a);
+  const int nc = (n_mfcc + 7) / 8 * 8;
+  if (job.elem_bytes == 8) {
+    SMX_LAUNCH(mfcc_kernel<double>, grid, dim3(256), 0, job.stream, a);
+  } else if (n_mfcc <= kFastMfccMaxCoeffs && diag_flag("SMX_MFCC_PLAIN") != 1) {
+    const dim3 grid4((unsigned)((job.frames + 63) / 64), (unsigned)job.lead);
+    auto go = [&](auto kernel) { SMX_LAUNCH(kernel, grid4, dim3(256), 0, job.stream, a, log_table_device()); };
+    if (nc == 8) go(mfcc_fast_kernel<8>);
+    else if (nc == 16) go(mfcc_fast_kernel<16>);
+    else if (nc == 24) go(mfcc_fast_kernel<24>);
+    else go(mfcc_fast_kernel<32>);
+  } else {
+    SMX_LAUNCH(mfcc_kernel<float>, grid, dim3(256), 0, job.stream, a);
+  }
   SMX_HIP_CHECK(hipGetLastError());
   SMX_HIP_CHECK(hipFreeAsync(d_max, job.stream));
 }
