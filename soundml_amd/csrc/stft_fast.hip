@@ -802,11 +802,14 @@ const smx::MelFusedPlan &smx_mel_config::fused4_plan() const {
   };
   auto pack = [](const Item &it, int steps, int a_offset) {
     Mel4Item d{};
+    unsigned rows = 0, nrows = 0;
     for (int q = 0; q < 4; ++q) {
-      d.rows |= it.p[q].row0 << (8 * q);
-      d.nrows |= it.p[q].nr << (8 * q);
+      rows |= (unsigned)it.p[q].row0 << (8 * q);
+      nrows |= (unsigned)it.p[q].nr << (8 * q);
       d.kb[q] = it.p[q].kb;
     }
+    d.rows = (int)rows;
+    d.nrows = (int)nrows;
     d.steps_mode = steps | (it.mode << 16);
     d.a_offset = a_offset;
     return d;

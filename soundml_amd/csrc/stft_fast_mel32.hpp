@@ -271,7 +271,7 @@ __device__ __forceinline__ void mel4_items(const Mel32Args &m, int iv, const flo
       acc = f32x4m{s0, s1, s2, s3};
     }
     const bool owner = mode == 1 || (mode == 2 ? (mg & 1) == 0 : mg == 0);
-    const int row0 = (rows >> (8 * mg)) & 255, nr = (nrw >> (8 * mg)) & 255;
+    const int row0 = (int)(((unsigned)rows >> (8 * mg)) & 255u), nr = (int)(((unsigned)nrw >> (8 * mg)) & 255u);
     if (owner && f < frames_left) {
 #pragma unroll
       for (int r = 0; r < 4; ++r)
@@ -357,7 +357,7 @@ __device__ __forceinline__ void mel4r_items(const Mel32Args &m, int iv, const fl
       }
     if (c_last) {
       const bool owner = c_mode == 1 || (c_mode == 2 ? (mg & 1) == 0 : mg == 0);
-      const int row0 = (c_rows >> (8 * mg)) & 255, nr = (c_nrw >> (8 * mg)) & 255;
+      const int row0 = (int)(((unsigned)c_rows >> (8 * mg)) & 255u), nr = (int)(((unsigned)c_nrw >> (8 * mg)) & 255u);
 #pragma unroll
       for (int g = 0; g < NCG; ++g) {
         f32x4m sum = NCG == 1 ? acc[0] + acc[1] : acc[g];
