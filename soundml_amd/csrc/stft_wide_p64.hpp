@@ -43,12 +43,19 @@ constexpr int kLds = kOffCnt + 64;
 static_assert(kLds <= 160 * 1024, "LDS budget");
 
 __device__ __forceinline__ void fence() { asm volatile("" ::: "memory"); }
+// The counters: a wave's DS operations execute in order, so the add lands behind the LDS accesses the wave issued before it and a
+// wave that has seen the count reads what those wrote; the compiler is held to the same order by the fences (a relaxed atomic
+// alone orders nothing for it).
 __device__ __forceinline__ void signal(unsigned *c, int lane) {
+  fence();
   if (lane == 0) __hip_atomic_fetch_add(c, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+  fence();
 }
 __device__ __forceinline__ void wait_for(unsigned *c, unsigned target) {
+  fence();
   while ((unsigned)__builtin_amdgcn_readfirstlane((int)__hip_atomic_load(c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) < target)
     __builtin_amdgcn_s_sleep(2);
+  fence();
 }
 
 struct Args {
@@ -374,8 +381,10 @@ __global__ void __launch_bounds__(512) stft2048_power_wide_kernel(Args A) {
     // The two waves of a SIMD settle half a frame apart.  A wave of the LATE half finds the tile complete already here, behind
     // its first pass, and flushes at once -- half a frame before the early waves want to write the tile again; a wave of the
     // early half finds it incomplete and comes back behind its third pass, when the late ones have finished.
-    if (flush_due && (unsigned)__builtin_amdgcn_readfirstlane((int)__hip_atomic_load(l.filled, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) >= 8u * (unsigned)it)
+    if (flush_due && (unsigned)__builtin_amdgcn_readfirstlane((int)__hip_atomic_load(l.filled, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) >= 8u * (unsigned)it) {
+      fence();
       flush_now();
+    }
 #endif
     auto mid = [&] {
       if (flush_due) {
