@@ -44,10 +44,11 @@ void set_last_error(const std::string &message);
   } while (0)
 
 // ---- environment switches ------------------------------------------------------------------------------------------
-// The shipped library reads nine variables, each once per use and parsed ONE way (env_flag: unset -> -1, "0" / "" /
+// The shipped library reads ten variables, each once per use and parsed ONE way (env_flag: unset -> -1, "0" / "" /
 // "false" / "off" -> 0, anything else -> 1); none alters results except by selecting another kernel of the same contract:
 //   SMX_DISABLE_FAST   the generic kernels instead of the hand-laid ones (tests: two implementations of one contract)
 //   SMX_POWER_SKEW=0   fft-2048 power spectrogram: the plain per-tile flush instead of whole aligned 64-byte blocks (tests, A/B timing)
+//   SMX_BORDER_INLINE=0 fft-2048 power spectrogram: the border frames in an epilogue / gathered strips instead of the tile sequence (tests: same values)
 //   SMX_COMPLEX_SKEW=0 fft-2048 Stft.transform: the plain per-tile flush instead of whole aligned 128-byte lines (tests, A/B timing)
 //   SMX_WIDE_PIPELINE=0 float64 interior at fft 2048: the one-tile-per-workgroup kernel instead of the persistent one (tests: bit-identical)
 //   SMX_MEL_DENSE=1    fused mel at fft 2048: the dense 16 x 16 x 4 product instead of the banded 4 x 4 x 1 one (tests, A/B timing)

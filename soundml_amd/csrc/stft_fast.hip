@@ -76,7 +76,7 @@ struct FastArgs {
   // complex / mel kernels: the launch covers ALL frames of the request; a frame that touches a border of the signal reads its
   // samples from a gathered, already padded strip (left: frames [p0, border_i0), right: frames [border_i1, ..)) -- only the
   // frame's base pointer differs (a scalar select), so the border frames cost no launches and no registers
-  int fold_frames;
+  int fold_frames;                     // 1: strips; 2 (stft2048_power32_kernel): no strips, a tile with such a frame loads through load_frame32_padded
   int64_t border_i0;                   // first interior frame (border_i1: first frame after the interior range)
   const float *strip_l, *strip_r;
   int64_t strip_l_stride, strip_r_stride;
@@ -221,6 +221,11 @@ __device__ __forceinline__ void lds_wait(unsigned *c, unsigned target) {
 }
 
 #include "stft_fast_p32.hpp"   // the 32-lane frame pipeline: stft2048_power32_kernel
+#ifdef SMX_ISA_ONE   // tools/isa_one.py: ONE instantiation of the headline kernel (registers / scratch / instruction mix in seconds, no GPU)
+template __global__ void stft2048_power32_kernel<true, 2, false, SMX_ISA_ONE>(FastArgs);
+}  // namespace
+}  // namespace smx
+#else
 #include "stft_fast_mel32.hpp" // the fused audio -> mel kernel on the 32-lane pipeline: stft2048_mel32_kernel
 #include "stft_fast_p16.hpp"   // the same pipeline with a frame in 16 / 8 lanes: stft_power_lanes_kernel (power spectrogram at fft 1024 / 512)
 }  // namespace
@@ -277,6 +282,7 @@ struct FastTarget {
   int border_left = 0, border_right = 0;
   int64_t border_p0 = 0, border_i1 = 0;
   bool fold_frames = false;     // complex / mel kernels: one launch over every frame of the request (FastArgs::fold_frames)
+  bool inline_border = false;   // power kernel at fft 2048 (round 5): one launch over every frame, the border tiles load through the padding rule (FastArgs::fold_frames == 2)
   const float *strip_l = nullptr, *strip_r = nullptr;
   int64_t strip_l_stride = 0, strip_r_stride = 0;
 };
@@ -340,7 +346,7 @@ void launch_interior(const StftJob &job, const FastTarget &tg, const float *x, i
   a.border_p0 = tg.border_p0;
   a.border_i1 = tg.border_i1;
   a.border_out_offset = tg.out_offset;
-  a.fold_frames = (!strip && tg.fold_frames) ? 1 : 0;
+  a.fold_frames = strip ? 0 : tg.inline_border ? 2 : tg.fold_frames ? 1 : 0;
   a.border_i0 = tg.border_p0;   // folded complex / mel launches: border_p0 carries the first interior frame
   a.strip_l = tg.strip_l;
   a.strip_r = tg.strip_r;
@@ -519,6 +525,19 @@ void launch_ranges(const StftJob &job, const FastTarget &tg) {
   // element-wise stores cost them more than the whole interior (2.76 ms against 1.1).
   const int64_t border_total = job.lead * ((i0 - p0) + (p1 - i1));
   static const int64_t epilogue_max = (int64_t)diag_int("SMX_BORDER_EPILOGUE_MAX", 20000);
+  // Round 5, fft 2048: the border frames ride in the tile sequence itself -- ONE launch over every frame of the request, a tile
+  // that holds such a frame takes its samples through the padding rule (load_frame32_padded: one reflection, hence n >= fft).
+  // The epilogue below ran 4 tile times deep on a quarter of the workgroups at C2: 30 of the launch's 495 us
+  // (profiles/r07/timeline_before.log).  SMX_BORDER_INLINE=0: the epilogue / strips as before (same values: tested).
+  if (!tg.mel && !tg.complex_out && c.fft_size == kN && (i0 - p0) + (p1 - i1) > 0 && job.n >= c.fft_size && job.n < (int64_t(1) << 30) &&
+      env_flag("SMX_BORDER_INLINE") != 0) {
+    FastTarget folded = tg;
+    folded.inline_border = true;
+    folded.border_p0 = i0;
+    folded.border_i1 = i1;
+    launch_interior(job, folded, reinterpret_cast<const float *>(job.x), job.n, job.x_stride, job.left, p0, p1 - p0, tg.out_offset);
+    return;
+  }
   if (!tg.mel && !tg.complex_out && !fold_off && job.n < (int64_t(1) << 30) && (i0 - p0) + (p1 - i1) > 0 &&
       (i0 - p0) + (p1 - i1) < 4096 && border_total <= epilogue_max) {
     FastTarget folded = tg;
@@ -871,3 +890,4 @@ const smx::MelFusedPlan &smx_mel_config::fused4_plan() const {
   plan.state = 1;
   return plan;
 }
+#endif   // SMX_ISA_ONE

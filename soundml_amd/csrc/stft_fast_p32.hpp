@@ -497,6 +497,36 @@ __device__ __forceinline__ void load_frame32(const float *src, int l, float2 (&r
   }
 }
 
+// The same for a tile with frames that reach past either end of the signal (round 5: the border frames ride in the tile
+// sequence instead of an epilogue of their own -- 30 us at the end of a 0.49 ms C2 launch on a quarter of the workgroups,
+// profiles/r07/timeline_before.log).  Sample s of the clip at xc extended by the configuration's rule (stft.ml:300-338), for
+// positions within ONE reflection of the signal (the launcher admits n >= fft_size only): reflect min(|s|, 2 (n - 1) - |s|),
+// edge clamp(s), constant pad_value where s is outside; four-byte loads at clamped indices, so any tile may take this path.
+// The values are those of fetch_padded: a frame has one value whichever path loads it.
+__device__ __forceinline__ void load_frame32_padded(const FastArgs &a, const float *xc /* wave-uniform */, int s0, int l, float2 (&raw)[32]) {
+  asm volatile("" : "+v"(s0));   // the index arithmetic below starts HERE (hoisted to the loop top it would hold registers through the frame)
+  const int n = (int)a.n, top = 2 * (n - 1);
+  const bool refl = a.pad == SMX_PAD_REFLECT;
+  auto at = [&](int s) {   // (an unsigned index: the load takes the clip's scalar base and a 32-bit offset, no 64-bit address pair per sample)
+    const int m = s < 0 ? -s : s;
+    const int ir = m < top - m ? m : top - m;
+    const int ie = s < 0 ? 0 : (s < n ? s : n - 1);
+    return *reinterpret_cast<const float *>(reinterpret_cast<const char *>(xc) + 4u * (unsigned)(refl ? ir : ie));
+  };
+  const int s00 = s0 + 2 * l;
+#pragma unroll
+  for (int j = 0; j < 32; ++j) raw[j] = make_float2(at(s00 + 64 * j), at(s00 + 64 * j + 1));
+  if (a.pad != SMX_PAD_REFLECT && a.pad != SMX_PAD_EDGE) {   // constant padding (wave-uniform): the one mode that waits for the loads here
+    const float pv = a.pad_value;
+#pragma unroll
+    for (int j = 0; j < 32; ++j) {
+      const int s = s00 + 64 * j;
+      if ((unsigned)s >= (unsigned)n) raw[j].x = pv;
+      if ((unsigned)(s + 1) >= (unsigned)n) raw[j].y = pv;
+    }
+  }
+}
+
 // A wave's share of a finished tile: 8 parts of 16 rows (bins) x 4 frames per lane -> out[clip][bin][f0 + 4 g ..].
 // Rows {0-3, 16-19} + 4 h per half-wave keep the LDS reads conflict free; a 4-lane group stores one 64-byte run.
 // The tile is read into registers at one point of the frame and stored at a later one (see frame32_to_tile).
@@ -763,9 +793,21 @@ struct PowerMid32 {
   bool pend_fresh, pend_closing;
   float2 (&raw)[32];
   const float *src;      // the next frames' samples (per lane)
+  const float *src_clip; // ... their clip (wave-uniform) and whether their tile holds a frame that reaches past the signal
+  bool src_border;
   float *pend_out;       // output origin and frames of the previous tile
   int pend_left;
   int lane, wave, b, it;
+  // A border tile's samples are requested at the END of the frame, by the padding rule, over an unconditional request behind
+  // slot 5 that reads the clip's first frame for such a tile (in bounds, never used).  A request behind slot 5 that is skipped
+  // for border tiles, or the padding rule there, made the loop spill (9 to 37 registers; the compiler's allocation, not a
+  // count of live values): this form costs one register.  The two border tiles of a clip begin a memory round trip late.
+  __device__ __forceinline__ void load_next() const {
+    load_frame32<ALIGNED>(src_border ? src_clip : src, lane & 31, raw);
+  }
+  __device__ __forceinline__ void load_next_border() const {
+    if (src_border) load_frame32_padded(a, src_clip, (int)(src - src_clip), lane & 31, raw);
+  }
 #ifdef SMX_STAMPS
   unsigned long long *stamp_sum, *stamp_prev_p;
   template <int I> __device__ __forceinline__ void stamp() const {
@@ -816,14 +858,15 @@ struct PowerMid32 {
   // frames' loads are issued; the same slot: SMX_P32_LOADS_FIRST says which goes first)
   __device__ __forceinline__ void postpass_at(int s) const {
     const bool same = SMX_P32_STORE_AT == SMX_P32_LOAD_AT;
-    if (s == SMX_P32_LOAD_AT && same && SMX_P32_LOADS_FIRST) { load_frame32<ALIGNED>(src, lane & 31, raw); SMX_FENCE(); }
+    if (s == SMX_P32_LOAD_AT && same && SMX_P32_LOADS_FIRST) { load_next(); SMX_FENCE(); }
     if (s == SMX_P32_STORE_AT && it > 0) {
       if constexpr (SKEW == 1) skew32_store(a, sk, pend_out, pend_left, pend_fresh, pend_closing, wave, lane, sr, carry);
       else if constexpr (SKEW == 2) skewg32_store(a, skg, pend_out, pend_left, pend_fresh, pend_closing, wave, lane, srg, carryg);
       else flush32_store(a, fl, pend_out, pend_left, wave, lane, fr);
     }
     SMX_FENCE();
-    if (s == SMX_P32_LOAD_AT && !(same && SMX_P32_LOADS_FIRST)) load_frame32<ALIGNED>(src, lane & 31, raw);   // (half of the frame's registers are free by now)
+    if (s == SMX_P32_LOAD_AT && !(same && SMX_P32_LOADS_FIRST)) load_next();   // (half of the frame's registers are free by now)
+    if (s == 15) load_next_border();
   }
 };
 
@@ -833,9 +876,11 @@ __global__ void __launch_bounds__(512) stft2048_power32_kernel(FastArgs a) {
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+#ifdef SMX_STAMPS
+  const unsigned long long tl_entry = __builtin_amdgcn_s_memrealtime();   // launch timeline (tools/launch_timeline.py): 100 MHz ticks, one clock for the chip
+#endif
   const Lds32 lds = carve_lds32(smem);
   const Lane32 L = setup_lane32(lds, lane, wave);
-  fill_tables32(a, lds, tid, 512);
   TileWalk tw;
   tw.init(a, a.out + a.out_offset, kBins * a.out_stride);
   const int ntiles = tw.ntiles > 0 ? tw.ntiles : 0;
@@ -847,18 +892,30 @@ __global__ void __launch_bounds__(512) stft2048_power32_kernel(FastArgs a) {
     const int avail = (int)(a.count - f0 < kFT ? a.count - f0 : kFT) - 1;   // last frame of the tile that exists (wave-uniform)
     const int fi = 2 * wave + L.h;
     const int64_t p = a.p0 + f0 + (fi <= avail ? fi : 0);
-    if (a.fold_frames && (p < a.border_i0 || p >= a.border_i1)) {
+    if (a.fold_frames == 1 && (p < a.border_i0 || p >= a.border_i1)) {
       const int64_t clip = (xc - a.x) / a.x_stride;
       return p < a.border_i0 ? a.strip_l + clip * a.strip_l_stride + (p - a.p0) * a.hop
                              : a.strip_r + clip * a.strip_r_stride + (p - a.border_i1) * a.hop;
     }
-    return xc + (p * a.hop - a.left);
+    return xc + (p * a.hop - a.left);   // (fold_frames == 2: possibly outside the clip -- then only its position is used)
+  };
+  // fold_frames == 2: tile t holds a frame that reaches past the signal and takes load_frame32_padded (wave-uniform)
+  auto tile_border = [&](int t) {
+    const int64_t q0 = a.p0 + (int64_t)t * kFT;
+    return a.fold_frames == 2 && (q0 < a.border_i0 || q0 + kFT > a.border_i1);
   };
 
   float2 raw[32];
 #pragma unroll
   for (int j = 0; j < 32; ++j) raw[j] = make_float2(0.f, 0.f);
-  if (ntiles > 0) load_frame32<ALIGNED>(frame_ptr(tw.xclip, tw.ft), L.l, raw);
+  // the first frames' samples are requested BEFORE the tables are filled: both round trips overlap (round 5: the prologue was
+  // 5.8 us of a 0.49 ms C2 launch, profiles/r07/timeline_before.log)
+  if (ntiles > 0) {
+    const float *src0 = frame_ptr(tw.xclip, tw.ft);
+    if (tile_border(tw.ft)) load_frame32_padded(a, tw.xclip, (int)(src0 - tw.xclip), L.l, raw);
+    else load_frame32<ALIGNED>(src0, L.l, raw);
+  }
+  fill_tables32(a, lds, tid, 512);
   __syncthreads();   // tables and zeroed counters visible: the only workgroup barrier of the main loop
   float *pend_out = nullptr;
   int pend_left = 0;
@@ -888,6 +945,9 @@ __global__ void __launch_bounds__(512) stft2048_power32_kernel(FastArgs a) {
   unsigned long long stamp_sum[kStampSlots] = {0}, stamp_prev;
   asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(stamp_prev)::"memory");
   const unsigned long long clk_t0 = stamp_prev, clk_r0 = __builtin_amdgcn_s_memrealtime();
+  stamp_sum[15] = tl_entry;
+  stamp_sum[16] = clk_r0;          // tables in, first samples requested
+  stamp_sum[22] = (unsigned long long)ntiles;
 #endif
   for (int it = 0; it < ntiles; ++it) {   // tile `it` of this workgroup lives in buffer it & 1
     const int b = it & 1;
@@ -896,7 +956,9 @@ __global__ void __launch_bounds__(512) stft2048_power32_kernel(FastArgs a) {
     float *onext;
     tw.peek(a, ftnext, xnext, onext);
     const bool more = it + 1 < ntiles;
-    const float *src = frame_ptr(more ? xnext : tw.xclip, more ? ftnext : tw.ft);
+    const float *src_clip = more ? xnext : tw.xclip;
+    const float *src = frame_ptr(src_clip, more ? ftnext : tw.ft);
+    const bool src_border = tile_border(more ? ftnext : tw.ft);
 #ifdef SMX_DIAG
     if (a.abl_p32 & 1) src = frame_ptr(a.x, 1);   // timing only: every tile reads the same resident samples
 #endif
@@ -907,13 +969,16 @@ __global__ void __launch_bounds__(512) stft2048_power32_kernel(FastArgs a) {
       if (it > 0 && pend_fresh) skewg32_clip(a, skg, pend_oclip, lane, wave);
     }
 #ifdef SMX_STAMPS
-    const PowerMid32<ALIGNED, SKEW> mid{a, lds, fl, fr, sk, sr, carry, skg, srg, carryg, pend_fresh, pend_closing, raw, src, pend_out, pend_left, lane, wave, b, it, stamp_sum, &stamp_prev, pk_drained, pk_filled};
+    const PowerMid32<ALIGNED, SKEW> mid{a, lds, fl, fr, sk, sr, carry, skg, srg, carryg, pend_fresh, pend_closing, raw, src, src_clip, src_border, pend_out, pend_left, lane, wave, b, it, stamp_sum, &stamp_prev, pk_drained, pk_filled};
 #else
-    const PowerMid32<ALIGNED, SKEW> mid{a, lds, fl, fr, sk, sr, carry, skg, srg, carryg, pend_fresh, pend_closing, raw, src, pend_out, pend_left, lane, wave, b, it, pk_drained, pk_filled};
+    const PowerMid32<ALIGNED, SKEW> mid{a, lds, fl, fr, sk, sr, carry, skg, srg, carryg, pend_fresh, pend_closing, raw, src, src_clip, src_border, pend_out, pend_left, lane, wave, b, it, pk_drained, pk_filled};
 #endif
     mid.template stamp<0>();
 #ifdef SMX_STAMPS
     if (it == 32) stamp_sum[14] = __builtin_amdgcn_s_memtime();   // when this wave starts its 33rd tile (wave offsets inside a workgroup)
+    if (it == 1) stamp_sum[9] = __builtin_amdgcn_s_memrealtime();
+    if (it == 2) stamp_sum[10] = __builtin_amdgcn_s_memrealtime();
+    if (it == ntiles - 1) stamp_sum[11] = __builtin_amdgcn_s_memrealtime();
 #endif
 #if SMX_P32_HAVE_BRANCH
     if (have) {
@@ -944,6 +1009,9 @@ __global__ void __launch_bounds__(512) stft2048_power32_kernel(FastArgs a) {
     tw.oclip = onext;
     tw.ft = ftnext;
   }
+#ifdef SMX_STAMPS
+  stamp_sum[17] = __builtin_amdgcn_s_memrealtime();   // tile loop left
+#endif
   if (ntiles > 0) {   // the last tile of this workgroup
     const int b = (ntiles - 1) & 1;
     lds_wait(lds.filled + b * kTileStride, 8u * (((unsigned)(ntiles - 1) >> 1) + 1));
@@ -963,8 +1031,8 @@ __global__ void __launch_bounds__(512) stft2048_power32_kernel(FastArgs a) {
 #ifdef SMX_STAMPS
   stamp_sum[20] = __builtin_amdgcn_s_memtime() - clk_t0;
   stamp_sum[21] = __builtin_amdgcn_s_memrealtime() - clk_r0;
-  if (lane == 0 && blockIdx.x < 4096)
-    for (int i = 0; i < kStampSlots; ++i) g_stamp_sums[(blockIdx.x * 16 + wave) * kStampSlots + i] = stamp_sum[i];
+  stamp_sum[18] = __builtin_amdgcn_s_memrealtime();   // last flush issued
+  stamp_sum[23] = 0;
 #endif
 
   // Border frames (the few per clip whose window reaches past either end of the signal): same frame code on samples
@@ -980,6 +1048,9 @@ __global__ void __launch_bounds__(512) stft2048_power32_kernel(FastArgs a) {
     };
     float *bt_tile = lds.tiles;
     for (int64_t bt = (int64_t)gridDim.x - 1 - tw.uid; bt * kFT < total; bt += gridDim.x) {   // from the last workgroup down: idle ones first
+#ifdef SMX_STAMPS
+      ++stamp_sum[23];
+#endif
       __syncthreads();   // the buffer is free: every wave is past its last flush / the previous border tile
       if (bt * kFT + 2 * wave < total) {   // wave-uniform
         int64_t beta = bt * kFT + 2 * wave + L.h;
@@ -1009,6 +1080,12 @@ __global__ void __launch_bounds__(512) stft2048_power32_kernel(FastArgs a) {
       }
     }
   }
+#ifdef SMX_STAMPS
+  __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): the wave's stores are out
+  stamp_sum[19] = __builtin_amdgcn_s_memrealtime();
+  if (lane == 0 && blockIdx.x < 4096)
+    for (int i = 0; i < kStampSlots; ++i) g_stamp_sums[(blockIdx.x * 16 + wave) * kStampSlots + i] = stamp_sum[i];
+#endif
 }
 
 // ---- Stft.transform at fft 2048 on the same frame code (stft.ml:632-666): the spectrum's two planes fill both tile buffers, so

@@ -232,6 +232,46 @@ print(json.dumps(out))
     assert res[0] == res[1]
 
 
+def test_border_tiles_in_the_tile_sequence_equal_the_epilogue():
+    """Round 5: at fft 2048 the frames that reach past the signal ride in the power kernel's tile sequence (a tile with such a frame
+    loads through the padding rule, stft_fast_p32.hpp load_frame32_padded) instead of an epilogue after the interior tiles.
+    SMX_BORDER_INLINE=0 selects the epilogue / strips: same frame code on the same samples, so every value agrees bit for bit --
+    every pad mode and alignment, odd hops (unaligned loads), ranges that begin or end inside the border, clips barely longer
+    than a frame, many short clips, general powers."""
+    code = """
+import json, sys, numpy as np
+sys.path.insert(0, %r)
+import torch
+from soundml_amd import Stft
+torch.manual_seed(5)
+out = []
+for alignment in ("centered", "left", "right"):
+    for pad in ("reflect", "edge", ("constant", 0.37)):
+        for hop in (512, 300, 77):
+            c = Stft.Config.create(fft_size=2048, hop=hop, alignment=alignment, pad=pad)
+            for clips, n in ((3, 2048), (2, 2049), (5, 40000), (260, 9001), (1, 4096 + 511)):
+                x = (torch.rand(clips, n, device="cuda") * 2 - 1).float()
+                frames = Stft.frames(c, n)
+                for a, b in ((0, frames), (1, frames - 1), (0, min(frames, 3)), (max(frames - 2, 0), frames)):
+                    if b <= a:
+                        continue
+                    for p in (2.0, 0.7):
+                        pw = Stft.power_range(c, x, a, b, p).contiguous()
+                        out.append(int(pw.view(torch.int32).to(torch.int64).sum()))
+print(json.dumps(out))
+""" % ROOT
+    res = []
+    for inline in ("1", "0"):
+        env = dict(os.environ)
+        env.pop("SMX_BORDER_INLINE", None)
+        if inline == "0":
+            env.update(SMX_BORDER_INLINE="0")
+        out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
+        assert out.returncode == 0, out.stdout + out.stderr
+        res.append(json.loads(out.stdout.strip().splitlines()[-1]))
+    assert len(res[0]) > 500 and res[0] == res[1]
+
+
 @pytest.mark.timeout(600)
 def test_many_short_clips_take_the_strip_path_and_agree():
     """6000 clips of 4000 samples: 8 frames each, 4 of them touching a border -- 24 000 border frames, above the launcher's

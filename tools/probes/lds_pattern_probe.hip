@@ -65,6 +65,37 @@ __global__ void __launch_bounds__(1024) k(unsigned long long *cyc, int reps, flo
 #pragma unroll
       for (int i = 0; i < 32; ++i) acc[i] = tile[rd + kStride * i];
     }
+    if constexpr (T == 8) {   // round 5: the transposition with the strides swapped -- lane l writes register j to cell 33 l + j (a PAIR
+      // of registers per ds_write2_b32: cells 68 bytes apart), lane k1 reads register l' from cell 33 l' + k1.  Both sides conflict free.
+      const unsigned wb = (unsigned)((33 * l * kStride + col + g * kRows * kStride) * 4);
+#pragma unroll
+      for (int j = 0; j < 32; j += 2)
+        asm volatile("ds_write2_b32 %0, %1, %2 offset0:%3 offset1:%4" ::"v"(wb + (unsigned)(j >= 14 ? 14 * kStride * 4 : 0) + (unsigned)(j >= 28 ? 14 * kStride * 4 : 0)), "v"(acc[j]), "v"(acc[j + 1]),
+                     "n"((j % 14) * kStride), "n"((j % 14 + 1) * kStride) : "memory");
+#pragma unroll
+      for (int i = 0; i < 32; ++i) acc[i] = tile[own + 33 * kStride * i];
+    }
+    if constexpr (T == 9) {   // the write half of T8 alone
+      const unsigned wb = (unsigned)((33 * l * kStride + col + g * kRows * kStride) * 4);
+#pragma unroll
+      for (int j = 0; j < 32; j += 2)
+        asm volatile("ds_write2_b32 %0, %1, %2 offset0:%3 offset1:%4" ::"v"(wb + (unsigned)(j >= 14 ? 14 * kStride * 4 : 0) + (unsigned)(j >= 28 ? 14 * kStride * 4 : 0)), "v"(acc[j]), "v"(acc[j + 1]),
+                     "n"((j % 14) * kStride), "n"((j % 14 + 1) * kStride) : "memory");
+    }
+    if constexpr (T == 10) {   // T7 with the reads as ds_read2_b32 (half the instructions, same LDS-array cycles)
+#pragma unroll
+      for (int j = 0; j < 32; ++j) tile[own + 33 * kStride * j] = acc[j];
+      const unsigned rb = (unsigned)((rd + g * kRows * kStride) * 4);
+      float2 t[16];
+#pragma unroll
+      for (int i = 0; i < 32; i += 2)
+        asm volatile("ds_read2_b32 %0, %1 offset0:%2 offset1:%3" : "=v"(t[i / 2]) : "v"(rb + (unsigned)(i >= 14 ? 14 * kStride * 4 : 0) + (unsigned)(i >= 28 ? 14 * kStride * 4 : 0)),
+                     "n"((i % 14) * kStride), "n"((i % 14 + 1) * kStride) : "memory");
+      asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(t[0]), "+v"(t[1]), "+v"(t[2]), "+v"(t[3]), "+v"(t[4]), "+v"(t[5]), "+v"(t[6]), "+v"(t[7]), "+v"(t[8]), "+v"(t[9]),
+                   "+v"(t[10]), "+v"(t[11]), "+v"(t[12]), "+v"(t[13]), "+v"(t[14]), "+v"(t[15])::"memory");
+#pragma unroll
+      for (int i = 0; i < 16; ++i) { acc[2 * i] = t[i].x; acc[2 * i + 1] = t[i].y; }
+    }
     asm volatile("" ::: "memory");
   }
   __syncthreads();
@@ -108,5 +139,8 @@ int main() {
   run<5>("plain read b32", 32);
   run<6>("plain write b32", 32);
   run<7>("transposition write + read", 64);
+  run<8>("  strides swapped, ds_write2_b32", 64);
+  run<9>("  its write half alone (write2)", 32);
+  run<10>("  T7 with ds_read2_b32 reads", 64);
   return 0;
 }
