@@ -68,6 +68,7 @@ struct FastArgs {
   int tiles_per_clip;
   int64_t total_tiles;     // lead * tiles_per_clip: a flat (clip, tile) sequence
   int64_t blocks;          // persistent workgroups; each owns a contiguous range of the sequence
+  int64_t range_base, range_extra;   // total_tiles / blocks and the remainder (block_to_range divides nothing)
   // power kernel: the frames that touch a border of the signal (reflect / edge / constant padding) are
   // computed by the same launch, after the interior tiles (0 = none: they come as gathered strips)
   int border_left, border_right;       // border frames per clip before / after the interior range
@@ -127,13 +128,15 @@ constexpr size_t kWinBytes = (size_t)kM * sizeof(float2); // 0.5 * window as (ev
 // Persistent workgroups: block b owns a contiguous range of the flat (clip, tile) sequence.
 // XCD-aware: blocks that share an XCD (b % 8) get neighbouring ranges, i.e. whole runs of clips,
 // so halo re-reads and the partial output lines of neighbouring tiles meet in one L2.
+// (No 64-bit division here or in TileWalk::init when the launch has fewer than 2^31 tiles: as scalar code one costs a few
+// hundred dependent instructions, and the ten of them were 5 us of every workgroup's start -- a C2 launch is 59 tiles of 7 us:
+// profiles/r07/timeline_inline_border.log.  The launcher supplies total_tiles / blocks and its remainder.)
 __device__ __forceinline__ void block_to_range(const FastArgs &a, int64_t &tau_begin, int64_t &tau_end) {
-  int64_t vb = blockIdx.x;
-  const int64_t nb = a.blocks, q = nb / 8, r = nb % 8, xcd = vb % 8, idx = vb / 8;
-  vb = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
-  const int64_t base = a.total_tiles / nb, extra = a.total_tiles % nb;
-  tau_begin = vb * base + (vb < extra ? vb : extra);
-  tau_end = tau_begin + base + (vb < extra ? 1 : 0);
+  const unsigned nb = (unsigned)a.blocks, q = nb / 8u, r = nb % 8u, xcd = blockIdx.x % 8u, idx = blockIdx.x / 8u;
+  const unsigned vb = (xcd < r ? xcd * (q + 1u) : r * (q + 1u) + (xcd - r) * q) + idx;
+  const int64_t base = a.range_base, extra = a.range_extra;
+  tau_begin = (int64_t)vb * base + ((int64_t)vb < extra ? (int64_t)vb : extra);
+  tau_end = tau_begin + base + ((int64_t)vb < extra ? 1 : 0);
 }
 
 // sample s of a signal of n samples extended by the configuration's padding (stft.ml:300-338); 32-bit positions
@@ -160,43 +163,55 @@ struct TileWalk {
   float *oclip;                             // output origin of the current clip
   int64_t x_step, o_step;                   // per-clip strides of input and output
 
-  __device__ __forceinline__ void init(const FastArgs &a, float *out, int64_t out_clip_floats) {
-    int64_t tau0;
+  // I: the integer type of the tile arithmetic -- unsigned when the launch has fewer than 2^31 tiles, else int64_t
+  template <class I>
+  __device__ __forceinline__ void init_as(const FastArgs &a, float *out, int64_t out_clip_floats) {
+    I tau0;
     int step;
     uid = (int)blockIdx.x;
+    const I total = (I)a.total_tiles, tpc = (I)a.tiles_per_clip;
     if (a.interleave) {
       // The workgroups of one XCD walk a contiguous chunk of the sequence side by side: at any time the
       // XCD is writing ~32 neighbouring tiles of the same clip, i.e. for every bin one contiguous run of
       // ~2 KB, which its L2 can assemble into whole lines before they go to HBM.
-      const int64_t nb = a.blocks, xcd = blockIdx.x % 8, idx = blockIdx.x / 8;
+      const I nb = (I)a.blocks, xcd = blockIdx.x % 8u, idx = blockIdx.x / 8u;
       if (a.interleave == 2) {   // all workgroups side by side; an XCD holds 32 neighbouring tiles of every 256
-        const int64_t q = nb / 8, r = nb % 8;
+        const I q = nb / 8, r = nb % 8;
         tau0 = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
         uid = (int)tau0;
         step = (int)nb;
-        ntiles = tau0 < a.total_tiles ? (int)((a.total_tiles - tau0 + nb - 1) / nb) : 0;
+        ntiles = tau0 < total ? (int)((total - tau0 + nb - 1) / nb) : 0;
       } else {
-        const int64_t nx = (nb - xcd + 7) / 8;                            // workgroups on this XCD
-        const int64_t nxcd = nb < 8 ? nb : 8;                             // XCDs that received a workgroup
-        const int64_t x0 = a.total_tiles * xcd / nxcd, x1 = a.total_tiles * (xcd + 1) / nxcd;
+        const I nx = (nb - xcd + 7) / 8;                            // workgroups on this XCD
+        const I nxcd = nb < 8 ? nb : 8;                             // XCDs that received a workgroup
+        // total * xcd / nxcd without the wide product: floor((Q n + R) x / n) = Q x + floor(R x / n)
+        const I tq = total / nxcd, tr = total % nxcd;
+        const I x0 = tq * xcd + tr * xcd / nxcd, x1 = tq * (xcd + 1) + tr * (xcd + 1) / nxcd;
         tau0 = x0 + idx;
         step = (int)nx;
         ntiles = tau0 < x1 ? (int)((x1 - tau0 + nx - 1) / nx) : 0;
       }
     } else {
-      int64_t tau_end;
-      block_to_range(a, tau0, tau_end);
+      int64_t tb, te;
+      block_to_range(a, tb, te);
+      tau0 = (I)tb;
       step = 1;
-      ntiles = (int)(tau_end - tau0);
+      ntiles = (int)(te - tb);
     }
     if (ntiles <= 0) return;
-    ft = (int)(tau0 % a.tiles_per_clip);
+    const I clip0 = tau0 / tpc;
+    ft = (int)(tau0 - clip0 * tpc);
     x_step = a.x_stride;
     o_step = out_clip_floats;
-    xclip = a.x + (tau0 / a.tiles_per_clip) * x_step;
-    oclip = out + (tau0 / a.tiles_per_clip) * o_step;
-    step_clips = step / a.tiles_per_clip;
-    step_tiles = step % a.tiles_per_clip;
+    xclip = a.x + (int64_t)clip0 * x_step;
+    oclip = out + (int64_t)clip0 * o_step;
+    step_clips = step == 1 ? 0 : (int)((unsigned)step / (unsigned)a.tiles_per_clip);
+    step_tiles = step == 1 ? 1 : (int)((unsigned)step % (unsigned)a.tiles_per_clip);
+    if (step == 1 && a.tiles_per_clip == 1) { step_clips = 1; step_tiles = 0; }
+  }
+  __device__ __forceinline__ void init(const FastArgs &a, float *out, int64_t out_clip_floats) {
+    if (a.total_tiles < (int64_t(1) << 31)) init_as<unsigned>(a, out, out_clip_floats);   // (wave-uniform)
+    else init_as<int64_t>(a, out, out_clip_floats);
   }
   // the tile after the current one
   __device__ __forceinline__ void peek(const FastArgs &a, int &ftn, const float *&xn, float *&on) const {
@@ -326,11 +341,14 @@ void launch_interior(const StftJob &job, const FastTarget &tg, const float *x, i
     cu_count = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
   }
   a.blocks = a.total_tiles < cu_count ? a.total_tiles : cu_count;
+  auto set_ranges = [&] { a.range_base = a.total_tiles / a.blocks; a.range_extra = a.total_tiles % a.blocks; };
+  set_ranges();
   if (!strip && !tg.mel && !tg.complex_out && tg.border_left + tg.border_right > 0 && a.blocks < cu_count) {
     // a small launch: the border tiles of the 32- / 16- / 8-lane kernels' epilogue go to workgroups of their own (they are
     // handed out from the last workgroup down), so that a short clip does not pay two tile latencies in a row
     const int64_t border_tiles = (job.lead * (tg.border_left + tg.border_right) + ft - 1) / ft;
     a.blocks = a.blocks + border_tiles < cu_count ? a.blocks + border_tiles : cu_count;
+    set_ranges();
   }
   {
     // Tile order (TileWalk::init).  Measured on whole batches: while input + output stay within ~2 GB the

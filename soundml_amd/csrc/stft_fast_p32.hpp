@@ -76,6 +76,10 @@ struct Lane32 {
     const int v = li();
     return (33 - v - (v < 1 ? v : 1)) * kTileStride + col;
   }
+  __device__ __forceinline__ int xr2() const {                                                    // exchange reads, cells 33 p + (15 - s) of slot s, p = 32 - l (l = 0: its own register 32 - s in cell 16 - s, i.e. base cell 1)
+    const int v = li();
+    return (v < 1 ? 1 : 33 * (32 - v)) * kTileStride + col;
+  }
   __device__ __forceinline__ int rm() const { return (32 + 32 * 16 - li()) * kTileStride + col; }   // results of bins M - k: row (32 - l) + 32 (31 - s)  (l = 0: 32 (32 - s); s = 0 is row 1024 = Nyquist)
   __device__ __forceinline__ int self() const {                                                   // lane 0: row 512 (bin M/2); other lanes: a cell they overwrite afterwards
     const int v = li();
@@ -125,26 +129,52 @@ __device__ __forceinline__ void lds_wait32(unsigned *c, unsigned target, unsigne
   lds_wait(c, target);
 }
 
-// fills the workgroup's tables (any number of threads); the caller synchronises before they are read
-__device__ __forceinline__ void fill_tables32(const FastArgs &a, const Lds32 &lds, int tid, int nthreads) {
+// two values into cells OFF0 and OFF1 dwords beyond the LDS byte address `at`: 6 cycles of the LDS store path where two
+// ds_write_b32 take 8 (MI355X_MICROARCH.md, LDS: 2 cycles per source dword).  Invisible to hipcc's lgkmcnt bookkeeping, which
+// only makes its counted waits stricter (the LDS executes a wave's operations in order).
+template <int OFF0, int OFF1>
+__device__ __forceinline__ void lds_write2_b32(unsigned at, float x, float y) {
+  static_assert(OFF0 >= 0 && OFF0 < 256 && OFF1 >= 0 && OFF1 < 256, "ds_write2_b32 offsets are 8 bits of dwords");
+  asm volatile("ds_write2_b32 %0, %1, %2 offset0:%3 offset1:%4" : : "v"(at), "v"(x), "v"(y), "n"(OFF0), "n"(OFF1) : "memory");
+}
+
+// The workgroup's tables, 512 threads: tables32_request() asks for a thread's share (registers), tables32_commit() puts it into
+// LDS; the caller synchronises before the tables are read.  In two steps so that the requests are ONE round trip that the tile
+// walk's divisions and the first frames' sample requests overlap (round 5: as four loops of load -> LDS store the fill was four
+// dependent round trips, 5.8 us of a C2 launch -- profiles/r07/timeline_before.log).
+struct Tables32Regs {
+  float2 w0, w1, a0, a1, a31, p0, p1;
+};
+__device__ __forceinline__ void tables32_request(const FastArgs &a, int tid, Tables32Regs &r) {
   const float2 *hw = reinterpret_cast<const float2 *>(a.hwin);
-  for (int e = tid; e < 16 * 32; e += nthreads) {   // rows 0..7: the even points j = 4 m, 4 m + 2; rows 8..15: the odd points j = 4 m + 1, 4 m + 3
-    const int row = e >> 5, l = e & 31, j0 = 4 * (row & 7) + (row >> 3);
-    const float2 w0 = hw[l + 32 * j0], w1 = hw[l + 32 * (j0 + 2)];
-    lds.win4[e] = make_float4(w0.x, w0.y, w1.x, w1.y);
+  {   // win4: rows 0..7: the even points j = 4 m, 4 m + 2; rows 8..15: the odd points j = 4 m + 1, 4 m + 3
+    const int row = tid >> 5, l = tid & 31, j0 = 4 * (row & 7) + (row >> 3);
+    r.w0 = hw[l + 32 * j0];
+    r.w1 = hw[l + 32 * (j0 + 2)];
   }
-  for (int e = tid; e < 15 * 32; e += nthreads) {
-    const int m = e >> 5, l = e & 31;
-    const float2 w0 = a.w_m[l * (2 * m + 1)], w1 = a.w_m[l * (2 * m + 2)];
-    lds.twA4[e] = make_float4(w0.x, w0.y, w1.x, w1.y);
+  {   // twA4 (the threads past its 15 rows re-read row 0; not stored)
+    const int m = tid < 15 * 32 ? tid >> 5 : 0, l = tid & 31;
+    r.a0 = a.w_m[l * (2 * m + 1)];
+    r.a1 = a.w_m[l * (2 * m + 2)];
   }
-  for (int e = tid; e < 32; e += nthreads) lds.twA31[e] = a.w_m[e * 31];
-  for (int e = tid; e < 8 * 32; e += nthreads) {
-    const int m = e >> 5, l = e & 31;
-    const float2 w0 = a.w_n[l + 32 * (2 * m)], w1 = a.w_n[l + 32 * (2 * m + 1)];
-    lds.twP4[e] = make_float4(w0.x, w0.y, w1.x, w1.y);
+  r.a31 = a.w_m[(tid & 31) * 31];
+  {   // twP4 (8 rows)
+    const int m = (tid >> 5) & 7, l = tid & 31;
+    r.p0 = a.w_n[l + 32 * (2 * m)];
+    r.p1 = a.w_n[l + 32 * (2 * m + 1)];
   }
+}
+__device__ __forceinline__ void tables32_commit(const Lds32 &lds, int tid, const Tables32Regs &r) {
+  lds.win4[tid] = make_float4(r.w0.x, r.w0.y, r.w1.x, r.w1.y);
+  if (tid < 15 * 32) lds.twA4[tid] = make_float4(r.a0.x, r.a0.y, r.a1.x, r.a1.y);
+  if (tid < 32) lds.twA31[tid] = r.a31;
+  if (tid < 8 * 32) lds.twP4[tid] = make_float4(r.p0.x, r.p0.y, r.p1.x, r.p1.y);
   if (tid < 2) { lds.filled[tid * kTileStride] = 0u; lds.drained[tid * kTileStride] = 0u; }
+}
+__device__ __forceinline__ void fill_tables32(const FastArgs &a, const Lds32 &lds, int tid, int /* 512 */) {
+  Tables32Regs r;
+  tables32_request(a, tid, r);
+  tables32_commit(lds, tid, r);
 }
 
 // The arithmetic of this pipeline is written out operation by operation (explicit fused multiply-adds, contraction off
@@ -294,6 +324,9 @@ struct NoMid32 {
 #ifndef SMX_P32_WAIT0
 #define SMX_P32_WAIT0 1
 #endif
+#ifndef SMX_P32_CELLS
+#define SMX_P32_CELLS 1   // 1: cell rule 33 l + j (ds_write2_b32 on the store side, round 5); 0: rounds 3-4's rule l + 33 j (A/B builds)
+#endif
 // The window rows of the odd points and the twiddles are requested before the first 16-point transform (which needs the even
 // points only) and arrive under it.  (Requesting the even rows a frame pair ahead as well -- 32 registers across the loop
 // edge -- changed nothing in the power kernel and cost the fused mel kernel 40 %: profiles/r06/ab_mel_winpre2.log.)
@@ -356,6 +389,31 @@ __device__ __forceinline__ void frame32_to_tile(const FastArgs &a, const Lane32 
     mid.template stamp<2>();
     mid.before_cells();
     mid.template stamp<3>();
+#if SMX_P32_CELLS
+    // (round 5: lane l writes register j to cell 33 l + j and lane k1 reads register l' from cell 33 l' + k1 -- the transpose of
+    // rounds 3-4's cell rule, conflict free on both sides as that one.  Consecutive registers now sit 68 bytes apart, within the
+    // reach of ds_write2_b32: 6 cycles of the LDS store path for two values where two ds_write_b32 take 8
+    // (profiles/r07/lds_pattern_probe.log: the transposition's 64 writes + 64 reads 3.0 -> 2.6 cycles per value and CU).)
+    float *const wc = tile + L.rd();
+    // the first plane is written while the twiddle products are formed (shorter LDS bursts)
+    auto put2 = [&](int j) { wc[kTileStride * j] = v[j].x; wc[kTileStride * (j + 1)] = v[j + 1].x; };
+#define SMX_TWV(m) f2{tw[m].x, tw[m].y}, f2{tw[m].z, tw[m].w}
+    pk_twiddle8(v[1], v[2], v[3], v[4], v[5], v[6], v[7], v[8], SMX_TWV(0), SMX_TWV(1), SMX_TWV(2), SMX_TWV(3));
+#pragma unroll
+    for (int j = 0; j < 8; j += 2) put2(j);
+    SMX_FENCE();
+    pk_twiddle8(v[9], v[10], v[11], v[12], v[13], v[14], v[15], v[16], SMX_TWV(4), SMX_TWV(5), SMX_TWV(6), SMX_TWV(7));
+#pragma unroll
+    for (int j = 8; j < 16; j += 2) put2(j);
+    SMX_FENCE();
+    pk_twiddle8(v[17], v[18], v[19], v[20], v[21], v[22], v[23], v[24], SMX_TWV(8), SMX_TWV(9), SMX_TWV(10), SMX_TWV(11));
+#pragma unroll
+    for (int j = 16; j < 24; j += 2) put2(j);
+    SMX_FENCE();
+    pk_twiddle7(v[25], v[26], v[27], v[28], v[29], v[30], v[31], SMX_TWV(12), SMX_TWV(13), SMX_TWV(14), f2{tw31.x, tw31.y});
+#pragma unroll
+    for (int j = 24; j < 32; j += 2) put2(j);
+#else
     float *const wr = tile + L.own();
     float *const wr_hi = wr + 16 * kCellPitch32;
     // the first plane is written while the twiddle products are formed (shorter LDS bursts)
@@ -377,9 +435,21 @@ __device__ __forceinline__ void frame32_to_tile(const FastArgs &a, const Lane32 
     pk_twiddle7(v[25], v[26], v[27], v[28], v[29], v[30], v[31], SMX_TWV(12), SMX_TWV(13), SMX_TWV(14), f2{tw31.x, tw31.y});
 #pragma unroll
     for (int j = 25; j <= 31; ++j) put(j);
+#endif
 #undef SMX_TWV
   }
   SMX_FENCE();
+#if SMX_P32_CELLS
+  float *const wr = tile + L.own();
+  float *const wr_hi = wr + 16 * kCellPitch32;   // (ds offsets are 16 bits: 31 x 2244 bytes does not fit)
+  float *const wc = tile + L.rd();
+#pragma unroll
+  for (int i = 0; i < 32; ++i) t[i].x = (i < 16 ? wr : wr_hi)[kCellPitch32 * (i & 15)];
+#pragma unroll
+  for (int j = 0; j < 32; ++j) wc[kTileStride * j] = v[j].y;
+#pragma unroll
+  for (int i = 0; i < 32; ++i) t[i].y = (i < 16 ? wr : wr_hi)[kCellPitch32 * (i & 15)];
+#else
   float *const wr = tile + L.own();
   float *const wr_hi = wr + 16 * kCellPitch32;   // (ds offsets are 16 bits: 31 x 2244 bytes does not fit)
   const float *const rd = tile + L.rd();
@@ -389,6 +459,7 @@ __device__ __forceinline__ void frame32_to_tile(const FastArgs &a, const Lane32 
   for (int j = 0; j < 32; ++j) (j < 16 ? wr : wr_hi)[kCellPitch32 * (j & 15)] = v[j].y;
 #pragma unroll
   for (int i = 0; i < 32; ++i) t[i].y = rd[kTileStride * i];
+#endif
   SMX_FENCE();
   mid.after_transposition_issue();
   mid.template stamp<4>();
@@ -399,6 +470,25 @@ __device__ __forceinline__ void frame32_to_tile(const FastArgs &a, const Lane32 
   mid.template stamp<5>();
   // P: partners through the cells.  Every lane parks registers 16..31 (cell l + 33 (q - 16)) and reads, for slot s,
   // register 31 - s of lane 32 - l (lanes 0 and 16: their own; lane 0: register 32 - s, and itself for s = 0).
+#if SMX_P32_CELLS
+  f2 pp[16];
+  const float *const xr = tile + L.xr2();
+  // (register 0 goes to cell 33 l + 16 as well: that is where lane 0 looks for the partner of bin 0 -- itself; slot 0
+  // of that lane yields X[0] and the Nyquist bin.  A select instead would be two v_cndmask_b32 on vcc, 19 cycles each.)
+  // Cells 33 l + (q - 16): consecutive registers 68 bytes apart (ds_write2_b32, as the transposition).
+  // (written as ds_write2_b32 by hand: hipcc pairs the transposition's stores by itself and leaves these seventeen single)
+  const unsigned wc_lds = (unsigned)reinterpret_cast<uintptr_t>(wc);
+#define SMX_PARK2(k, m) lds_write2_b32<2 * kTileStride * (k), 2 * kTileStride * (k) + kTileStride>(wc_lds, t[16 + 2 * (k)].m, t[17 + 2 * (k)].m)
+  SMX_PARK2(0, x); SMX_PARK2(1, x); SMX_PARK2(2, x); SMX_PARK2(3, x); SMX_PARK2(4, x); SMX_PARK2(5, x); SMX_PARK2(6, x); SMX_PARK2(7, x);
+  wc[kTileStride * 16] = t[0].x;
+#pragma unroll
+  for (int s = 0; s < 16; ++s) pp[s].x = xr[kTileStride * (15 - s)];
+  SMX_PARK2(0, y); SMX_PARK2(1, y); SMX_PARK2(2, y); SMX_PARK2(3, y); SMX_PARK2(4, y); SMX_PARK2(5, y); SMX_PARK2(6, y); SMX_PARK2(7, y);
+#undef SMX_PARK2
+  wc[kTileStride * 16] = t[0].y;
+#pragma unroll
+  for (int s = 0; s < 16; ++s) pp[s].y = xr[kTileStride * (15 - s)];
+#else
   f2 pp[16];
   const float *const xr = tile + L.xr();
   // (register 0 goes to cell l + 33 x 16 as well: that is where lane 0 looks for the partner of bin 0 -- itself; slot 0
@@ -413,6 +503,7 @@ __device__ __forceinline__ void frame32_to_tile(const FastArgs &a, const Lane32 
   wr_hi[0] = t[0].y;
 #pragma unroll
   for (int s = 0; s < 16; ++s) pp[s].y = xr[kCellPitch32 * (15 - s)];
+#endif
   float4 tw[8];
 #pragma unroll
   for (int m = 0; m < 8; ++m) tw[m] = L.twP_l()[32 * m];
@@ -881,6 +972,8 @@ __global__ void __launch_bounds__(512) stft2048_power32_kernel(FastArgs a) {
 #endif
   const Lds32 lds = carve_lds32(smem);
   const Lane32 L = setup_lane32(lds, lane, wave);
+  Tables32Regs tabs;
+  tables32_request(a, tid, tabs);   // in flight under the tile walk's divisions
   TileWalk tw;
   tw.init(a, a.out + a.out_offset, kBins * a.out_stride);
   const int ntiles = tw.ntiles > 0 ? tw.ntiles : 0;
@@ -915,7 +1008,7 @@ __global__ void __launch_bounds__(512) stft2048_power32_kernel(FastArgs a) {
     if (tile_border(tw.ft)) load_frame32_padded(a, tw.xclip, (int)(src0 - tw.xclip), L.l, raw);
     else load_frame32<ALIGNED>(src0, L.l, raw);
   }
-  fill_tables32(a, lds, tid, 512);
+  tables32_commit(lds, tid, tabs);
   __syncthreads();   // tables and zeroed counters visible: the only workgroup barrier of the main loop
   float *pend_out = nullptr;
   int pend_left = 0;
