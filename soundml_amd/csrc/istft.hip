@@ -692,6 +692,8 @@ __global__ void __launch_bounds__(1024) istft2048_kernel(SynArgs a) {
   }
 }
 
+#include "istft_pipe32.hpp"   // istft2048_pipe_kernel: the same synthesis on the 32-lane frame pipeline, persistent workgroups (round 5)
+
 // ---- even sizes whose half length L = N / 2 is 2^a 3^b 5^c, float32 (fft 400, 480, 960, 1000, 1200 ...) ------------------------
 // The direct real inverse DFT of istft_frames_kernel is O(N^2) per frame (fft 400 / hop 160 on 256 x 30 s: 103 ms).  Here one wave
 // owns a frame: it reads its column of the spectrum (the 16 waves of a workgroup read the 16 neighbouring frames of the same
@@ -951,6 +953,33 @@ void launch_istft(const IstftJob &job) {
     sa.env_tail = d_env + env.head + env.period;
     sa.head = head_n;
     sa.stop = stop;
+    // Round 5: the persistent pipeline kernel (istft_pipe32.hpp) takes every plain synthesis of this geometry, whatever its
+    // size, so that a position has one value however the frames reach the kernel (offline, streaming chunks).
+    // SMX_INVERT_PIPELINE=0: the one-tile-per-workgroup kernel of rounds 1-4 (tests, A/B timing).
+    if (!job.mag && !job.unit && env_flag("SMX_INVERT_PIPELINE") != 0 && job.frames < (int64_t(1) << 23)) {
+      PipeArgs pa{};
+      pa.s = sa;
+      const int64_t tiles16 = (need + 512 * kIpFT - 1) / (512 * kIpFT);
+      pa.s.tiles_per_clip = (int)tiles16;
+      pa.total_tiles = job.lead * tiles16;
+      static int cu_count = 0;
+      if (cu_count == 0) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        SMX_HIP_CHECK(hipGetDevice(&dev));
+        SMX_HIP_CHECK(hipGetDeviceProperties(&prop, dev));
+        cu_count = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+      }
+      pa.blocks = (int)std::min<int64_t>(pa.total_tiles, cu_count);
+      pa.range_base = pa.total_tiles / pa.blocks;
+      pa.range_extra = pa.total_tiles % pa.blocks;
+      pa.aligned_out = (reinterpret_cast<uintptr_t>(job.out) % 8 == 0 && job.out_len % 2 == 0 && sa.left % 2 == 0) ? 1 : 0;
+      SMX_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(istft2048_pipe_kernel),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)kIpLds));
+      SMX_LAUNCH(istft2048_pipe_kernel, dim3((unsigned)pa.blocks), dim3(512), kIpLds, job.stream, pa);
+      SMX_HIP_CHECK(hipGetLastError());
+      return;
+    }
     const int64_t blocks = job.lead * tiles;
     if (blocks <= 0x7ffffff0) {
       const bool linear = diag_flag("SMX_ISTFT_LINEAR") == 1;
