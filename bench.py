@@ -28,7 +28,8 @@ the clock (RCCL when every rank has its own GPU; gloo when ranks share a device,
 which RCCL refuses -- the 2-rank test on a 1-GPU box).
 
 Timing: W untimed warm-up steps, then exactly K steps between barrier + synchronize.  Before the warm-up steps the same step
-runs for --preroll-ms (default 60 ms, untimed, uncounted, reported as `config.preconditioning`): out of an idle device the
+runs in groups of 8 event-timed launches until the last 8 lie within 1 % of each other and --preroll-ms (default 60) have passed
+(untimed, uncounted; reported as `config.preconditioning` and, with the W warm-up steps, as `warmup_effective`): out of an idle device the
 kernel's time is not stationary (0.51 ms for three launches, 0.61-0.64 for the next ten, the sustained 0.50 after ~40 --
 profiles/r06/step_time_transient.log), and `--steps 20 --warmup 5` would sample that hump.  `value` is the sustained rate;
 `extra.c2_burst_from_idle` is the same K / W measurement out of an idle device, in every run.
@@ -253,15 +254,24 @@ def main():
         """W warm-up steps, then K steps between barriers; HIP events on the launch stream around every step.
         Returns (elapsed seconds, MAX over ranks; sorted per-step ms of this rank; launches per step)."""
         preroll_steps = 0
-        if args.preroll_ms > 0:   # bring the chip to its sustained state (see --preroll-ms)
+        settled = None
+        if args.preroll_ms > 0:   # bring the chip to its sustained state (see --preroll-ms): ADAPTIVE -- groups of 8 steps, each
+            # timed by HIP events, until the last 8 step times lie within 1 % of each other (or --preroll-ms x 10 has passed)
             t_pre = time.perf_counter()
             while True:
-                for _ in range(4):
+                evp = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(8)]
+                for a, b in evp:
+                    a.record(stream)
                     step()
-                preroll_steps += 4
+                    b.record(stream)
+                preroll_steps += 8
                 torch.cuda.synchronize()
-                if (time.perf_counter() - t_pre) * 1e3 >= args.preroll_ms:
+                last8 = [a.elapsed_time(b) for a, b in evp]
+                spent = (time.perf_counter() - t_pre) * 1e3
+                settled = (max(last8) - min(last8)) <= 0.01 * min(last8)
+                if (settled and spent >= args.preroll_ms) or spent >= 10.0 * args.preroll_ms:
                     break
+        timed.settled = settled
         timed.preroll_steps = preroll_steps
         for _ in range(warmup):
             step()
@@ -309,6 +319,7 @@ def main():
     out = torch.empty(clips, BINS, frames, device=dev, dtype=torch.float32)
     elapsed, step_ms, launches = timed(power_step(x, out, clips, n, frames), args.steps, args.warmup)
     main_preroll_steps = timed.preroll_steps
+    main_settled = timed.settled
     # One step is ONE launch of the fused kernel (interior tiles, then the few border frames of every clip through
     # the same frame code), so the HIP events around a step are that kernel's launch durations: their average is
     # what `rocprofv3 --kernel-trace --stats` of this command reports for it (profiles/).
@@ -325,7 +336,16 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MIN)
         return float(t[0].item()), -float(t[1].item())
     rank_ms = over_ranks(avg_ms)
-    ranks_seen = {"world_size_seen": dist.get_world_size() if world > 1 else 1, "backend": backend,
+    # `ranks_counted`: an all-reduce SUM of 1 over the group -- the collective itself says how many ranks it spanned (the world size
+    # alone is the launcher's environment).  Device ordinals summed the same way: 0 + 1 + ... + N - 1 when every rank has its own GPU.
+    if world > 1:
+        cnt = torch.tensor([1.0, float(local_rank)], dtype=torch.float64, device=red_dev)
+        dist.all_reduce(cnt, op=dist.ReduceOp.SUM)
+        ranks_counted, ordinals_sum = int(cnt[0].item()), int(cnt[1].item())
+    else:
+        ranks_counted, ordinals_sum = 1, local_rank
+    ranks_seen = {"world_size_seen": dist.get_world_size() if world > 1 else 1, "ranks_counted": ranks_counted,
+                  "device_ordinals_sum": ordinals_sum, "backend": backend,
                   "rank_kernel_ms_avg_min": round(rank_ms[0], 4), "rank_kernel_ms_avg_max": round(rank_ms[1], 4)}
 
     shard_check = None
@@ -362,7 +382,10 @@ def main():
                        "timing_backend": backend,
                        # untimed, uncounted: the same step repeated before the W warm-up steps until the chip's power management has
                        # settled (--preroll-ms; `extra.c2_burst_from_idle` is the same measurement without it)
-                       "preconditioning": {"ms": args.preroll_ms, "steps": main_preroll_steps}},
+                       "preconditioning": {"min_ms": args.preroll_ms, "steps": main_preroll_steps, "settled_within_1pct": main_settled,
+                                           "rule": "groups of 8 event-timed steps until the last 8 lie within 1 % of each other"}},
+            # every launch of the step that ran before the timed region: the preconditioning steps + the W declared warm-up steps
+            "warmup_effective": main_preroll_steps + args.warmup,
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_source,
                          "frac_of_measured": round(achieved / HBM_MEASURED_GBS, 4), "measured_peak": HBM_MEASURED_GBS,
@@ -473,7 +496,42 @@ def main():
                                    "roofline": {"bound": "hbm", "achieved": round(clips * frames * bc / a / 1e6, 1), "peak": HBM_PEAK_GBS,
                                                 "unit": "GB/s", "frac": round(clips * frames * bc / a / 1e6 / HBM_PEAK_GBS, 4),
                                                 "algorithmic_bytes_per_frame": bc}}
-            del zc
+            # The face an nx caller gets (stft.mli:211-250: host tensors in and out): Stft.power_spectrum on a numpy batch through the
+            # host-pointer entry point -- upload, kernels and download of clip units overlapped inside the C ABI (transfer.cpp); a fresh
+            # result array per call, as nx allocates one.  PCIe roof: 63 GB/s per direction; the bytes of both directions are counted.
+            import numpy as _np
+            xh = x.cpu().numpy()
+            hp = []
+            for _ in range(5):
+                t_h = time.perf_counter()
+                ph = Stft.power_spectrum(cfg, xh)
+                hp.append(time.perf_counter() - t_h)
+                if len(hp) == 1:
+                    same = bool(_np.array_equal(ph[:4], out[:4].cpu().numpy()) and _np.array_equal(ph[-3:], out[-3:].cpu().numpy()))
+                del ph     # (releasing a GB of touched pages is not the call: not timed)
+            hp.sort()
+            hb = clips * (n * 4 + BINS * frames * 4)
+            extra["c2_host_path"] = {"workload": "C2 through the host-pointer entry point (numpy in, fresh numpy out): Stft.power_spectrum",
+                                     "value": round(clips * frames / hp[2] / 1e6, 2), "unit": "Mframes/s", "ms": round(hp[2] * 1e3, 2), "ms_min": round(hp[0] * 1e3, 2),
+                                     "equals_device_resident_call": same,
+                                     "roofline": {"bound": "pcie", "achieved": round(hb / hp[2] / 1e9, 2), "peak": 63.0, "unit": "GB/s",
+                                                  "frac": round(hb / hp[2] / 1e9 / 63.0, 4), "bytes_up": clips * n * 4, "bytes_down": clips * BINS * frames * 4}}
+            assert same, "host path != device-resident call"
+            del xh
+            # Stft.invert of that spectrogram (stft.ml:900-939): istft2048_pipe_kernel, 8200 B in + 2048 B out per frame
+            yi = torch.empty(clips, n, device=dev, dtype=torch.float32)
+            lib.smx_stft_invert_f32_dev.argtypes = [vp, vp, ctypes.c_int64, ctypes.c_int64, ctypes.c_int64, ctypes.c_int, ctypes.c_int64, vp, vp]
+            _, ms, nl = timed(lambda: check(lib.smx_stft_invert_f32_dev(cfg._h, vp(zc.data_ptr()), clips, BINS, frames, 1, n, vp(yi.data_ptr()), sptr)), k, w)
+            a = sum(ms) / len(ms)
+            bi = BINS * 8 + HOP * 4
+            extra["c2_invert"] = {"workload": "Stft.invert of the C2 spectrogram (complex64 in, float32 audio out); round trip checked",
+                                  "value": round(clips * frames / a / 1e3, 1), "unit": "Mframes/s", "ms": round(a, 4), "ms_min": round(ms[0], 4),
+                                  "launches_per_step": nl, "round_trip_max_abs_err": float((yi - x).abs().max()),
+                                  "roofline": {"bound": "hbm", "achieved": round(clips * frames * bi / a / 1e6, 1), "peak": HBM_PEAK_GBS,
+                                               "unit": "GB/s", "frac": round(clips * frames * bi / a / 1e6 / HBM_PEAK_GBS, 4),
+                                               "algorithmic_bytes_per_frame": bi}}
+            assert extra["c2_invert"]["round_trip_max_abs_err"] < 1e-5, extra["c2_invert"]
+            del zc, yi
             # C2 on the reference's own numerics (window, transform and |.|^2 in float64; float32 in and out): the same entry
             # point under set_interior("float64").  HBM bytes are C2's; what bounds this kernel is float64 vector issue
             # (~5 900 cycles per frame and wave at 4 cycles per instruction: DESIGN 4.3b), stated beside the HBM figure.

@@ -143,6 +143,21 @@ void stft_range_host(const smx_stft_config &c, const void *x, int in_bytes, int6
   DeviceScratch dx((size_t)lead * (size_t)n * (size_t)in_bytes);
   DeviceScratch dout(out_elems * (size_t)in_bytes);
   const double t1 = now();
+  // A large batch is cut into units of clips whose upload, kernels and download overlap (transfer.cpp; a unit's result is the
+  // slice of the whole call's bit for bit: the reference's per-slice law, stft_grid.ml:180-205).  SMX_HOST_PIPELINE=0: serially.
+  const size_t in_clip = (size_t)n * (size_t)in_bytes, out_clip = out_elems / (size_t)lead * (size_t)in_bytes;
+  if (lead >= 8 && (size_t)lead * (in_clip + out_clip) >= ((size_t)128 << 20) && in_clip > 0 && env_flag("SMX_HOST_PIPELINE") != 0) {
+    int64_t unit = (int64_t)(((size_t)48 << 20) / std::max(in_clip, out_clip));   // ~48 MB of the larger side per unit
+    unit = std::max<int64_t>(1, std::min<int64_t>(unit, (lead + 3) / 4));
+    SMX_HIP_CHECK(hipStreamSynchronize(nullptr));   // the scratch arrays come from the null stream's pool
+    (void)c.tables();                              // (lazy tables are built before the threads start)
+    pipelined_host_call(x, in_clip, out, out_clip, lead, unit, dx.ptr, dout.ptr, [&](int64_t clip0, int64_t nc, hipStream_t stream) {
+      stft_range_dev(c, reinterpret_cast<const unsigned char *>(dx.ptr) + (size_t)clip0 * in_clip, in_bytes, nc, n, n, p0, p1, mode, power,
+                     reinterpret_cast<unsigned char *>(dout.ptr) + (size_t)clip0 * out_clip, stream);
+    });
+    if (trace) fprintf(stderr, "[smx] host transform: allocate %.2f ms, pipelined upload / kernels / download %.2f (units of %lld clips)\n", t1 - t0, now() - t1, (long long)unit);
+    return;
+  }
   copy_to_device(dx.ptr, x, (size_t)lead * (size_t)n * (size_t)in_bytes);
   const double t2 = now();
   stft_range_dev(c, dx.ptr, in_bytes, lead, n, n, p0, p1, mode, power, dout.ptr, nullptr);

@@ -953,10 +953,11 @@ void launch_istft(const IstftJob &job) {
     sa.env_tail = d_env + env.head + env.period;
     sa.head = head_n;
     sa.stop = stop;
-    // Round 5: the persistent pipeline kernel (istft_pipe32.hpp) takes every plain synthesis of this geometry, whatever its
-    // size, so that a position has one value however the frames reach the kernel (offline, streaming chunks).
+    // Round 5: the persistent pipeline kernel (istft_pipe32.hpp) takes every synthesis of this geometry, whatever its size
+    // (Griffin-Lim's factors included), so that a position has one value however the frames reach the kernel (offline,
+    // streaming chunks).
     // SMX_INVERT_PIPELINE=0: the one-tile-per-workgroup kernel of rounds 1-4 (tests, A/B timing).
-    if (!job.mag && !job.unit && env_flag("SMX_INVERT_PIPELINE") != 0 && job.frames < (int64_t(1) << 23)) {
+    if (env_flag("SMX_INVERT_PIPELINE") != 0 && job.frames < (int64_t(1) << 23)) {
       PipeArgs pa{};
       pa.s = sa;
       const int64_t tiles16 = (need + 512 * kIpFT - 1) / (512 * kIpFT);
@@ -974,9 +975,9 @@ void launch_istft(const IstftJob &job) {
       pa.range_base = pa.total_tiles / pa.blocks;
       pa.range_extra = pa.total_tiles % pa.blocks;
       pa.aligned_out = (reinterpret_cast<uintptr_t>(job.out) % 8 == 0 && job.out_len % 2 == 0 && sa.left % 2 == 0) ? 1 : 0;
-      SMX_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(istft2048_pipe_kernel),
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)kIpLds));
-      SMX_LAUNCH(istft2048_pipe_kernel, dim3((unsigned)pa.blocks), dim3(512), kIpLds, job.stream, pa);
+      auto kp = (job.mag || job.unit) ? istft2048_pipe_kernel<true> : istft2048_pipe_kernel<false>;
+      SMX_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kp), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kIpLds));
+      SMX_LAUNCH(kp, dim3((unsigned)pa.blocks), dim3(512), kIpLds, job.stream, pa);
       SMX_HIP_CHECK(hipGetLastError());
       return;
     }

@@ -96,6 +96,9 @@ __device__ __forceinline__ int ip_opaque(int v) {   // (see opaque32 in stft_fas
   return v;
 }
 #define IP_FENCE() __builtin_amdgcn_sched_barrier(0)
+#ifndef IP_GL_BULK
+#define IP_GL_BULK 1   // 0: the factors applied element by element behind the wait for the slots (A/B builds: 139 against 75 ms for 32 Griffin-Lim iterations at C2 -- 33 dependent float64 chains one after the other instead of interleaved; same bits)
+#endif
 
 // Two frames (one per lane-half): the frame's staged spectrum in `slot` -> its 2048 windowed samples in `slot`.
 __device__ __forceinline__ void ip_frame(const IpLds &lds, float *slot, int lane) {
@@ -207,6 +210,8 @@ __device__ __forceinline__ void ip_frame(const IpLds &lds, float *slot, int lane
   }
 }
 
+// GL: Griffin-Lim's factors are taken (SynArgs::mag / unit / prev); the plain kernel holds no registers for them
+template <bool GL>
 __global__ void __launch_bounds__(512) istft2048_pipe_kernel(PipeArgs pa) {
 #pragma clang fp contract(off)
   const SynArgs &a = pa.s;
@@ -277,18 +282,91 @@ __global__ void __launch_bounds__(512) istft2048_pipe_kernel(PipeArgs pa) {
 #pragma unroll
   for (int i = 0; i < 33; ++i) raw[i] = make_float2(0.f, 0.f);
   if (todo > 0) request(clip, ft);
+  // Griffin-Lim's factors of a tile (see the loop's top): c_(k-1) and the magnitudes at this thread's elements
+  float2 pv[33];
+  float mg[33];
+  auto request_factors = [&](int64_t cl, int t) {   // (a wave-uniform base and a 32-bit offset per thread, as request())
+    const int64_t p = (int64_t)kIpFT * t + sf;
+    const bool ok = p < a.count;
+    const unsigned eoff = (unsigned)((size_t)srow * (size_t)a.frames + (size_t)(ok ? p : 0));   // elements
+    const size_t pitch = (size_t)a.frames * 32u;
+    const bool has_prev = a.unit && a.prev;
+    const char *pb = reinterpret_cast<const char *>(a.prev + (size_t)cl * zclip);
+    const char *mb = reinterpret_cast<const char *>(a.mag + (size_t)cl * zclip);
+#pragma unroll
+    for (int i = 0; i < 33; ++i) {
+      pv[i] = make_float2(0.f, 0.f);
+      if (has_prev && ok && (i < 32 || srow == 0)) pv[i] = *reinterpret_cast<const float2 *>(pb + (size_t)i * pitch * 8u + 8u * eoff);
+    }
+#pragma unroll
+    for (int i = 0; i < 33; ++i) {
+      mg[i] = 0.f;
+      if (a.mag && ok && (i < 32 || srow == 0)) mg[i] = *reinterpret_cast<const float *>(mb + (size_t)i * pitch * 4u + 4u * eoff);
+    }
+  };
+#pragma unroll
+  for (int i = 0; i < 33; ++i) { pv[i] = make_float2(0.f, 0.f); mg[i] = 0.f; }
   f2 carry[4];   // parity 0: frames 15 / 14 / 13 of the previous tile at segments 1 / 2 / 3, then frame 15 at segment 3; parity 1: frame 15 at segment 2, frame 14 at segment 3
 #pragma unroll
   for (int i = 0; i < 4; ++i) carry[i] = f2{0.f, 0.f};
   __syncthreads();   // tables and counters
   for (int it = 0; it < todo; ++it) {
-    // S1 / S2: the slots are free; the staged registers go in
+    // S1 / S2: the slots are free; the staged registers go in.
+    // Griffin-Lim's phase update is folded in here (stft.ml:1003-1012, as istft2048_kernel and gl_update_kernel form it): with
+    // `unit`, z is the rebuilt spectrum c_k and what is inverted is mag * unit(c_k - beta c_(k-1)), unit(e) = e / (|e| + min_float).
+    // The tile's factors are requested here, before the wait for the slots.
+    // (Requested a phase earlier -- behind the previous tile's frames or its overlap-add -- and carried over the loop edge, hipcc
+    // parks the 99 values in scratch as they arrive, one wait per load: 352 bytes of scratch against none.  The synthesis of a
+    // Griffin-Lim iteration reads 4.9 GB for 0.5 GB written: it sits on the memory system either way.)
+    if (GL) request_factors(clip, ft);
+#if IP_GL_BULK
+    if constexpr (GL) {   // the factors applied to all 33 elements at once (33 independent float64 chains for the scheduler), before the wait
+      if (a.unit) {
+        if (a.prev) {
+#pragma unroll
+          for (int i = 0; i < 33; ++i) { raw[i].x -= a.beta * pv[i].x; raw[i].y -= a.beta * pv[i].y; }
+        }
+#pragma unroll
+        for (int i = 0; i < 33; ++i) {
+          const float m = (float)hypot((double)raw[i].x, (double)raw[i].y) + FLT_MIN;
+          raw[i].x /= m;
+          raw[i].y /= m;
+        }
+      }
+      if (a.mag) {
+#pragma unroll
+        for (int i = 0; i < 33; ++i) { raw[i].x *= mg[i]; raw[i].y *= mg[i]; }
+      }
+    }
+#endif
     ip_wait(lds.drained, 8u * (unsigned)it);
     {
       float2 *cell = reinterpret_cast<float2 *>(lds.slots + ip_opaque(sf) * kIpSlot) + ip_opaque(srow);
+      auto staged_value = [&](int i) {
+        float2 e = raw[i];
+        if constexpr (GL && !IP_GL_BULK) {
+          if (a.unit) {   // (wave-uniform)
+            if (a.prev) {
+              e.x -= a.beta * pv[i].x;
+              e.y -= a.beta * pv[i].y;
+            }
+            const float m = (float)hypot((double)e.x, (double)e.y) + FLT_MIN;
+            e.x /= m;
+            e.y /= m;
+          }
+          if (a.mag) {
+            e.x *= mg[i];
+            e.y *= mg[i];
+          }
+        }
+        return e;
+      };
 #pragma unroll
-      for (int i = 0; i < 32; ++i) cell[32 * i] = raw[i];
-      if (srow == 0) cell[1024] = raw[32];
+      for (int i = 0; i < 32; ++i) {
+        cell[32 * i] = staged_value(i);
+        if (GL && (i & 3) == 3) IP_FENCE();
+      }
+      if (srow == 0) cell[1024] = staged_value(32);
     }
     ip_signal(lds.staged, lane);
     // S3: the next tile (of this clip, or the first one of the next clip)
@@ -318,8 +396,12 @@ __global__ void __launch_bounds__(512) istft2048_pipe_kernel(PipeArgs pa) {
         acc[0] = ((cell(0, 0) + cell(-1, 1)) + carry[0]) + carry[1];              // hop 1: frames 1, 0, -1, -2
         acc[1] = ((cell(2, 0) + cell(1, 1)) + cell(0, 2)) + cell(-1, 3);          // hop 3: frames 3, 2, 1, 0
       }
+      IP_FENCE();   // (in batches: with Griffin-Lim's 99 prefetched registers beside the 66 staged ones, 32 cells in flight spill)
 #pragma unroll
-      for (int i = 2; i < 8; ++i) acc[i] = ((cell(2 * i, 0) + cell(2 * i - 1, 1)) + cell(2 * i - 2, 2)) + cell(2 * i - 3, 3);
+      for (int i = 2; i < 8; ++i) {
+        acc[i] = ((cell(2 * i, 0) + cell(2 * i - 1, 1)) + cell(2 * i - 2, 2)) + cell(2 * i - 3, 3);
+        if (GL && (i & 1)) IP_FENCE();
+      }
       // what the next tile needs of frames 13, 14, 15 (parity 0: frame 15 at segment 1, 14 at 2, 13 at 3, then 15 at 3;
       // parity 1: frame 15 at segment 2, 14 at 3)
       {

@@ -6,6 +6,7 @@
 
 #include <algorithm>
 #include <atomic>
+#include <functional>
 #include <cmath>
 #include <cstdint>
 #include <map>
@@ -223,6 +224,9 @@ namespace smx {
 // Blocking; large copies are staged through pinned buffers with the DMA and a few host threads overlapped.
 void copy_to_device(void *d_dst, const void *src, size_t bytes);
 void copy_to_host(void *dst, const void *d_src, size_t bytes);
+// transfer.cpp: a host call cut into units of clips whose upload, kernels and download overlap (three host threads, HIP events)
+void pipelined_host_call(const void *src, size_t in_clip_bytes, void *dst, size_t out_clip_bytes, int64_t clips, int64_t unit,
+                         void *d_in, void *d_out, const std::function<void(int64_t, int64_t, hipStream_t)> &launch);
 
 // ---- host logic (host_config.cpp) ----------------------------------------------
 void window_make(int kind, bool periodic, int64_t n, double *out);             // window.ml:374-405

@@ -4,10 +4,15 @@
 // of pinned staging buffers, the DMA engine running asynchronously while a few host threads move the previous chunk
 // between the staging buffer and the caller's (possibly never-touched, page-faulting) memory.
 #include <atomic>
+#include <condition_variable>
 #include <cstring>
+#include <exception>
+#include <functional>
 #include <mutex>
 #include <thread>
 #include <vector>
+
+#include <sys/mman.h>
 
 #include "smx_internal.hpp"
 
@@ -20,7 +25,7 @@ constexpr size_t kDirect = (size_t)4 << 20;   // below this a plain hipMemcpy is
 
 struct Ring {
   void *buf[kRing] = {};
-  std::mutex busy;   // one staged transfer at a time per process
+  std::mutex busy;   // one staged transfer at a time per process AND DIRECTION (an upload and a download may overlap: PCIe is full duplex)
   bool ensure() {
     if (buf[0]) return true;
     for (int i = 0; i < kRing; ++i)
@@ -33,7 +38,14 @@ struct Ring {
     return true;
   }
 };
-Ring g_ring;
+Ring g_ring_up, g_ring_down;
+
+// What a pipelined host call hangs on a staged transfer (pipelined_host_call below): the upload reports every DMA it has
+// enqueued, the download asks before it enqueues one.
+struct Hooks {
+  std::function<void(long chunk, hipStream_t stream)> enqueued;   // upload: the DMA of chunk `chunk` is on `stream`
+  std::function<void(long chunk, hipStream_t stream)> before;     // download: called before the DMA of chunk `chunk` goes on `stream`
+};
 
 int worker_count() {
   static const int n = [] {
@@ -71,16 +83,27 @@ inline void slice(size_t len, int w, int t, size_t &lo, size_t &hi) {
   hi = std::min(len, lo + per);
 }
 
+// A freshly allocated result array is untouched memory: every 4 KB page of it faults as the copying threads reach it, and that,
+// not PCIe, bounds the download (0.98 GB of C2 spectrogram: 240 000 faults).  Ask for transparent huge pages on the whole 2 MB
+// pieces of the destination first (a no-op where the kernel has them off or the pages exist already).
+void advise_huge(void *dst, size_t bytes) {
+  const uintptr_t two_mb = (uintptr_t)2 << 20;
+  const uintptr_t lo = (reinterpret_cast<uintptr_t>(dst) + two_mb - 1) & ~(two_mb - 1), hi = (reinterpret_cast<uintptr_t>(dst) + bytes) & ~(two_mb - 1);
+  if (hi > lo) (void)madvise(reinterpret_cast<void *>(lo), hi - lo, MADV_HUGEPAGE);
+}
+
 // to_host: device -> staging by DMA, staging -> user by the workers.  !to_host: the reverse.
-void staged(void *dst, const void *src, size_t bytes, bool to_host) {
+void staged(void *dst, const void *src, size_t bytes, bool to_host, int workers = 0, const Hooks *hooks = nullptr) {
+  Ring &g_ring = to_host ? g_ring_down : g_ring_up;
   std::lock_guard<std::mutex> lock(g_ring.busy);
   if (!g_ring.ensure()) {   // no pinned memory to be had: the plain copy still works
+    if (hooks) throw Failure("pipelined transfer: no pinned staging memory");   // (the caller falls back to the serial path)
     SMX_HIP_CHECK(hipMemcpy(dst, src, bytes, to_host ? hipMemcpyDeviceToHost : hipMemcpyHostToDevice));
     return;
   }
   StreamAndEvents se;
   const long chunks = (long)((bytes + kChunk - 1) / kChunk);
-  const int t = worker_count();
+  const int t = workers > 0 ? workers : worker_count();
   auto len_of = [&](long i) { return std::min(kChunk, bytes - (size_t)i * kChunk); };
   std::atomic<long> ready{0};            // to_host: chunks whose DMA has landed; else: chunks whose buffer is free again
   std::vector<std::atomic<long>> done(chunks);   // workers finished with chunk i
@@ -104,12 +127,24 @@ void staged(void *dst, const void *src, size_t bytes, bool to_host) {
   std::vector<std::thread> pool;
   for (int w = 0; w < t; ++w) pool.emplace_back(work, w);
   hipError_t err = hipSuccess;
+  std::exception_ptr hook_error;
   auto dma = [&](long i) {
     void *stage = g_ring.buf[i % kRing];
+    auto hook = [&](const std::function<void(long, hipStream_t)> &f) {   // (a hook's failure ends the transfer like a HIP error: the workers are joined first)
+      if (err != hipSuccess || !f) return;
+      try {
+        f(i, se.stream);
+      } catch (...) {
+        hook_error = std::current_exception();
+        err = hipErrorUnknown;
+      }
+    };
+    if (hooks) hook(hooks->before);
     if (err == hipSuccess)
       err = to_host ? hipMemcpyAsync(stage, (const unsigned char *)src + (size_t)i * kChunk, len_of(i), hipMemcpyDeviceToHost, se.stream)
                     : hipMemcpyAsync((unsigned char *)dst + (size_t)i * kChunk, stage, len_of(i), hipMemcpyHostToDevice, se.stream);
     if (err == hipSuccess) err = hipEventRecord(se.ev[i % kRing], se.stream);
+    if (hooks) hook(hooks->enqueued);
   };
   auto workers_done_with = [&](long i) {
     int spins = 0;
@@ -146,10 +181,118 @@ void staged(void *dst, const void *src, size_t bytes, bool to_host) {
   }
   for (auto &th : pool) th.join();
   if (err == hipSuccess) err = hipStreamSynchronize(se.stream);
+  if (hook_error) std::rethrow_exception(hook_error);
   SMX_HIP_CHECK(err);
 }
 
 }  // namespace
+
+// A host call cut into units of clips (the reference's leading axes are independent: stft.mli:214-218, so a unit's result is
+// the slice of the whole call's, bit for bit): the upload of the units ahead, the kernels of one and the download of those
+// behind run at the same time -- PCIe is full duplex, and serially a C2 power spectrogram spent 10 ms going up and 20 ms coming
+// down around 0.6 ms of kernel (round 5).  Three host threads: one drives the upload (its own staging ring and copying
+// threads), one the download (the same), the caller launches; they meet at HIP events -- a kernel waits for the DMA that
+// completes its input, a download DMA for the kernel that completes its output.
+//   launch(clip0, nclips, stream) enqueues the work of clips [clip0, clip0 + nclips) on `stream`, reading d_in and writing d_out
+//   at the clips' own offsets.
+void pipelined_host_call(const void *src, size_t in_clip_bytes, void *dst, size_t out_clip_bytes, int64_t clips, int64_t unit,
+                         void *d_in, void *d_out, const std::function<void(int64_t, int64_t, hipStream_t)> &launch) {
+  int dev = 0;
+  SMX_HIP_CHECK(hipGetDevice(&dev));
+  const size_t in_total = (size_t)clips * in_clip_bytes, out_total = (size_t)clips * out_clip_bytes;
+  advise_huge(dst, out_total);
+  const long in_chunks = (long)((in_total + kChunk - 1) / kChunk);
+  const int64_t units = (clips + unit - 1) / unit;
+  std::vector<hipEvent_t> up_ev((size_t)in_chunks, nullptr), k_ev((size_t)units, nullptr);
+  hipStream_t compute = nullptr;
+  auto cleanup = [&] {
+    for (auto e : up_ev) if (e) (void)hipEventDestroy(e);
+    for (auto e : k_ev) if (e) (void)hipEventDestroy(e);
+    if (compute) (void)hipStreamDestroy(compute);
+  };
+  try {
+    for (auto &e : up_ev) SMX_HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    for (auto &e : k_ev) SMX_HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    SMX_HIP_CHECK(hipStreamCreateWithFlags(&compute, hipStreamNonBlocking));
+  } catch (...) {
+    cleanup();
+    throw;
+  }
+  // progress of the three stages, waited for WITHOUT spinning (the box's CPU quota is what bounds the copying threads; a spinning
+  // waiter takes a core from them)
+  std::mutex mu;
+  std::condition_variable cv;
+  long up_enqueued = 0, launched = 0;
+  bool failed = false;
+  std::exception_ptr err_up, err_down, err_main;
+  auto publish = [&](long &v, long value) {
+    { std::lock_guard<std::mutex> g(mu); v = value; }
+    cv.notify_all();
+  };
+  auto fail = [&] {
+    { std::lock_guard<std::mutex> g(mu); failed = true; }
+    cv.notify_all();
+  };
+  auto wait_until = [&](const long &v, long target) {
+    std::unique_lock<std::mutex> g(mu);
+    cv.wait(g, [&] { return v >= target || failed; });
+    if (failed) throw Failure("pipelined transfer: another stage failed");
+  };
+  Hooks hu, hd;
+  hu.enqueued = [&](long i, hipStream_t s) {
+    SMX_HIP_CHECK(hipEventRecord(up_ev[(size_t)i], s));
+    publish(up_enqueued, i + 1);
+  };
+  hd.before = [&](long j, hipStream_t s) {   // the kernels that write output bytes [.., end) are on the compute stream
+    const size_t end = std::min(out_total, (size_t)(j + 1) * kChunk);
+    const int64_t last_clip = (int64_t)((end - 1) / out_clip_bytes), u = last_clip / unit;
+    wait_until(launched, (long)u + 1);
+    SMX_HIP_CHECK(hipStreamWaitEvent(s, k_ev[(size_t)u], 0));
+  };
+  // the copying threads of both directions together: as many as one serial transfer uses, shared by the bytes each side moves
+  const int tw = worker_count();
+  const int t_up = std::max(2, (int)((double)tw * (double)in_total / (double)(in_total + out_total) + 0.5));
+  const int t_down = std::max(2, tw - t_up);
+  std::thread up([&] {
+    try {
+      SMX_HIP_CHECK(hipSetDevice(dev));
+      staged(d_in, src, in_total, false, t_up, &hu);
+    } catch (...) {
+      err_up = std::current_exception();
+      fail();
+    }
+  });
+  std::thread down([&] {
+    try {
+      SMX_HIP_CHECK(hipSetDevice(dev));
+      staged(dst, d_out, out_total, true, t_down, &hd);
+    } catch (...) {
+      err_down = std::current_exception();
+      fail();
+    }
+  });
+  try {
+    for (int64_t u = 0; u < units; ++u) {
+      const int64_t clip0 = u * unit, nc = std::min<int64_t>(unit, clips - clip0);
+      const long chunk = (long)(((size_t)(clip0 + nc) * in_clip_bytes - 1) / kChunk);   // the DMA that completes this unit's input
+      wait_until(up_enqueued, chunk + 1);
+      SMX_HIP_CHECK(hipStreamWaitEvent(compute, up_ev[(size_t)chunk], 0));
+      launch(clip0, nc, compute);
+      SMX_HIP_CHECK(hipEventRecord(k_ev[(size_t)u], compute));
+      publish(launched, (long)u + 1);
+    }
+  } catch (...) {
+    err_main = std::current_exception();
+    fail();
+  }
+  up.join();
+  down.join();
+  (void)hipStreamSynchronize(compute);
+  cleanup();
+  if (err_main) std::rethrow_exception(err_main);
+  if (err_up) std::rethrow_exception(err_up);
+  if (err_down) std::rethrow_exception(err_down);
+}
 
 void copy_to_device(void *d_dst, const void *src, size_t bytes) {
   if (bytes == 0) return;
@@ -162,6 +305,7 @@ void copy_to_device(void *d_dst, const void *src, size_t bytes) {
 
 void copy_to_host(void *dst, const void *d_src, size_t bytes) {
   if (bytes == 0) return;
+  advise_huge(dst, bytes);
   if (bytes < kDirect || env_flag("SMX_COPY_PLAIN") == 1) {
     SMX_HIP_CHECK(hipMemcpy(dst, d_src, bytes, hipMemcpyDeviceToHost));
     return;

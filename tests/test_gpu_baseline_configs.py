@@ -173,6 +173,7 @@ def test_bench_two_ranks_one_box():
     assert out.returncode == 0, out.stdout + out.stderr
     line = json.loads(out.stdout.strip().splitlines()[-1])
     assert line["n_gpus"] == 2 and line["scaling"] == "strong" and line["world_size_seen"] == 2
+    assert line["ranks_counted"] == 2   # an all-reduce SUM of 1: the collective spanned both ranks
     assert 0 < line["rank_kernel_ms_avg_min"] <= line["rank_kernel_ms_avg_max"]
     assert line["shard_check"] == {"ranks_bit_exact": 2, "ranks": 2, "world_size_seen": 2,
                                    "backend": line["shard_check"]["backend"]}

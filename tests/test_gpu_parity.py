@@ -745,12 +745,18 @@ def test_griffin_lim_fast_path_and_messages():
 
 
 def test_griffin_lim_at_the_reference_defaults_float32_interior():
-    """The reference's defaults (stft.ml:961-964: 32 iterations, momentum 0.99) under the float32 interior, with a bound that is
-    derived, not tuned.  The accelerated update forms c_k - 0.99 c_(k-1), which cancels to ~1 % of |c|, so whatever
-    perturbs the spectra is amplified iteration after iteration; the float64 ORACLE itself moves by `sens` when the
-    magnitudes move by ONE float32 ulp.  The float32 interior rounds 64 transforms (32 analysis + 32 synthesis) to float32,
-    i.e. injects a perturbation of that size 64 times: the gate is 64 x sens (and never tighter than the 1e-3 l2 of the
-    short runs above).  `set_interior("float64")` is the reference's arithmetic and must sit at 1e-5."""
+    """The reference's defaults (stft.ml:961-964: 32 iterations, momentum 0.99) under the float32 interior.
+    The accelerated update forms c_k - 0.99 c_(k-1), which cancels to ~1 % of |c|, and unit() of a bin whose difference nearly
+    vanishes turns by O(1) under a perturbation of its size: the distance between two float32 trajectories is heavy-tailed, not
+    a rounding error.  Measured (tools/gl_growth.py, profiles/r07/gl_growth_*.log; rel l2 to the float64 oracle after 32
+    iterations): this kernel 3.3e-3 / 2.5e-4 on two seeds, the kernel of rounds 1-4 1.5e-4 / 1.1e-3 on the same two, the
+    ORACLE ITSELF with nothing but its stored intermediates rounded to float32 1.2e-5 / 1.2e-4 -- no float32 implementation
+    is consistently nearer, and rounds 3-4's gate (64 x the oracle's movement under one ulp of the magnitudes) held for the seed
+    it was written on by luck.  What is gated instead:
+      * the trajectory while it is still a rounding error: 2 iterations at momentum 0.99 within 1e-5 l2 of the oracle;
+      * what Griffin-Lim is FOR at 32 iterations: the spectral convergence || |STFT(y)| - S || / ||S|| of the device's result is
+        the oracle's to within 5 % (both evaluated by the float64 oracle), and the waveform stays in the oracle's basin (2 % l2);
+      * `set_interior("float64")` is the reference's arithmetic and must sit at 1e-5 of the oracle's waveform."""
     rng = np.random.default_rng(99)
     x = rng.uniform(-1, 1, size=(2, 24000)).astype(np.float32)
     c = Stft.Config.create(fft_size=2048, hop=512)
@@ -758,13 +764,17 @@ def test_griffin_lim_at_the_reference_defaults_float32_interior():
     z = Stft.transform(c, x)
     mag = np.abs(z).astype(np.float32)
     phase = rng.uniform(-np.pi, np.pi, size=z.shape).astype(np.float32)   # (the default is a random phase: stft.ml:976-984)
+    rel = lambda a, b: float(np.linalg.norm(a.astype(np.float64) - b) / np.linalg.norm(b))
+    short = O.griffin_lim(o, mag, 2, 0.99, phase, None).astype(np.float64)
+    assert rel(Stft.griffin_lim(c, mag, n_iter=2, momentum=0.99, init=phase), short) <= 1e-5
     want = O.griffin_lim(o, mag, 32, 0.99, phase, None)
-    moved = O.griffin_lim(o, np.nextafter(mag, np.float32(np.inf)), 32, 0.99, phase, None)
-    sens = np.linalg.norm(moved - want) / np.linalg.norm(want)
     got = Stft.griffin_lim(c, mag, n_iter=32, momentum=0.99, init=phase)
-    rel = np.linalg.norm(got - want) / np.linalg.norm(want)
     assert np.isfinite(got).all()
-    assert rel <= max(1e-3, 64 * sens), (rel, sens)
+    def convergence(y):
+        return float(np.linalg.norm(np.abs(O.transform(o, y.astype(np.float64))) - mag) / np.linalg.norm(mag))
+    cg, cw = convergence(got), convergence(want)
+    assert cg <= 1.05 * cw + 1e-6, (cg, cw)
+    assert rel(got, want.astype(np.float64)) <= 2e-2
     S.set_interior("float64")
     try:
         strict = Stft.griffin_lim(c, mag, n_iter=32, momentum=0.99, init=phase)
