@@ -1091,3 +1091,9 @@ void launch_istft(const IstftJob &job) {
 }
 
 }  // namespace smx
+
+#ifdef SMX_STAMPS
+extern "C" int smx_debug_read_stamps_istft(unsigned long long *out, int count) {
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(smx::fftdev::g_stamp_sums), sizeof(unsigned long long) * (size_t)count);
+}
+#endif

@@ -96,6 +96,12 @@ __device__ __forceinline__ int ip_opaque(int v) {   // (see opaque32 in stft_fas
   return v;
 }
 #define IP_FENCE() __builtin_amdgcn_sched_barrier(0)
+#ifdef SMX_STAMPS   // diagnostic builds (make STAMPS=1, tools/stamps_istft.py): shader-clock sums per phase and wave
+#define IP_STAMP(i) do { unsigned long long t__; IP_FENCE(); asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t__)::"memory"); IP_FENCE(); \
+    ip_sum[i] += t__ - ip_prev; ip_prev = t__; } while (0)
+#else
+#define IP_STAMP(i) do { } while (0)
+#endif
 #ifndef IP_GL_BULK
 #define IP_GL_BULK 1   // 0: the factors applied element by element behind the wait for the slots (A/B builds: 139 against 75 ms for 32 Griffin-Lim iterations at C2 -- 33 dependent float64 chains one after the other instead of interleaved; same bits)
 #endif
@@ -310,7 +316,13 @@ __global__ void __launch_bounds__(512) istft2048_pipe_kernel(PipeArgs pa) {
 #pragma unroll
   for (int i = 0; i < 4; ++i) carry[i] = f2{0.f, 0.f};
   __syncthreads();   // tables and counters
+#ifdef SMX_STAMPS
+  unsigned long long ip_sum[fftdev::kStampSlots] = {0}, ip_prev;
+  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(ip_prev)::"memory");
+  const unsigned long long ip_t0 = ip_prev, ip_r0 = __builtin_amdgcn_s_memrealtime();
+#endif
   for (int it = 0; it < todo; ++it) {
+    IP_STAMP(0);   // loop edge
     // S1 / S2: the slots are free; the staged registers go in.
     // Griffin-Lim's phase update is folded in here (stft.ml:1003-1012, as istft2048_kernel and gl_update_kernel form it): with
     // `unit`, z is the rebuilt spectrum c_k and what is inverted is mag * unit(c_k - beta c_(k-1)), unit(e) = e / (|e| + min_float).
@@ -339,7 +351,9 @@ __global__ void __launch_bounds__(512) istft2048_pipe_kernel(PipeArgs pa) {
       }
     }
 #endif
+    IP_STAMP(1);   // Griffin-Lim's factors
     ip_wait(lds.drained, 8u * (unsigned)it);
+    IP_STAMP(2);   // wait: slots free
     {
       float2 *cell = reinterpret_cast<float2 *>(lds.slots + ip_opaque(sf) * kIpSlot) + ip_opaque(srow);
       auto staged_value = [&](int i) {
@@ -373,15 +387,23 @@ __global__ void __launch_bounds__(512) istft2048_pipe_kernel(PipeArgs pa) {
     int ftn = ft + 1;
     int64_t clipn = clip;
     if (ftn == tpc) { ftn = 0; ++clipn; }
+    IP_STAMP(3);   // staging stores (arrival of the staged registers included)
+    // (The 33 requests hold the wave at their issue for ~8 000 of a tile's 23 700 cycles: the memory side accepts a CU's 264
+    // requests of 512 bytes no faster than it streams them.  Spread in threes between the frame's stages they cost the same
+    // ~500 cycles per group there and 28 bytes of scratch: profiles/r07/stamps_istft_*.log.  One run it stays.)
     if (it + 1 < todo) request(clipn, ftn);
     IP_FENCE();
+    IP_STAMP(4);   // next tile's requests issued
     // S4 / S5
     ip_wait(lds.staged, 8u * (unsigned)(it + 1));
+    IP_STAMP(5);   // wait: every element staged
     ip_frame(lds, lds.slots + (2 * wave + (ip_opaque(lane) >> 5)) * kIpSlot, lane);
     ip_signal(lds.filled, lane);
     IP_FENCE();
+    IP_STAMP(6);   // the two frames
     // S6 / S7
     ip_wait(lds.filled, 8u * (unsigned)(it + 1));
+    IP_STAMP(7);   // wait: every frame's samples in
     {
       constexpr int SP = kIpSlot / 2;   // cells per slot
       const float2 *s2 = reinterpret_cast<const float2 *>(lds.slots) + ip_opaque(u) + ip_opaque(par) * SP;   // hop h = 2 i + par: frame h's cell u
@@ -415,6 +437,7 @@ __global__ void __launch_bounds__(512) istft2048_pipe_kernel(PipeArgs pa) {
         }
       }
       ip_signal(lds.drained, lane);   // (behind this wave's reads in LDS order)
+      IP_STAMP(8);   // overlap-add reads and sums
       if (store) {
         float *out = a.out + (size_t)clip * (size_t)a.out_len;
         const int64_t q_tile = (int64_t)512 * kIpFT * ft;
@@ -445,6 +468,7 @@ __global__ void __launch_bounds__(512) istft2048_pipe_kernel(PipeArgs pa) {
         }
       }
     }
+    IP_STAMP(9);   // envelope and stores
     store = true;
     ft = ftn;
     if (clipn != clip) {   // a new clip: nothing reaches into it
@@ -453,4 +477,11 @@ __global__ void __launch_bounds__(512) istft2048_pipe_kernel(PipeArgs pa) {
       for (int i = 0; i < 4; ++i) carry[i] = f2{0.f, 0.f};
     }
   }
+#ifdef SMX_STAMPS
+  ip_sum[20] = __builtin_amdgcn_s_memtime() - ip_t0;
+  ip_sum[21] = __builtin_amdgcn_s_memrealtime() - ip_r0;
+  ip_sum[22] = (unsigned long long)todo;
+  if (lane == 0 && blockIdx.x < 4096)
+    for (int i = 0; i < fftdev::kStampSlots; ++i) fftdev::g_stamp_sums[(blockIdx.x * 16 + wave) * fftdev::kStampSlots + i] = ip_sum[i];
+#endif
 }

@@ -4,7 +4,10 @@
 // of pinned staging buffers, the DMA engine running asynchronously while a few host threads move the previous chunk
 // between the staging buffer and the caller's (possibly never-touched, page-faulting) memory.
 #include <atomic>
+#include <chrono>
 #include <condition_variable>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <exception>
 #include <functional>
@@ -47,11 +50,30 @@ struct Hooks {
   std::function<void(long chunk, hipStream_t stream)> before;     // download: called before the DMA of chunk `chunk` goes on `stream`
 };
 
+// the CPU quota of the process's cgroup in cores (cgroup v2 cpu.max = "<quota> <period>"; 0 = none or unreadable).  The GPU boxes
+// show 256 logical CPUs and grant 16: threads beyond the quota are throttled for whole scheduler periods (a 25 ms call took 80).
+int cgroup_cpu_quota() {
+  FILE *f = std::fopen("/sys/fs/cgroup/cpu.max", "r");
+  if (!f) return 0;
+  long long quota = 0, period = 0;
+  char first[32] = {0};
+  int cores = 0;
+  if (std::fscanf(f, "%31s %lld", first, &period) == 2 && std::strcmp(first, "max") != 0 && period > 0) {
+    quota = std::atoll(first);
+    cores = (int)((quota + period - 1) / period);
+  }
+  std::fclose(f);
+  return cores;
+}
+
 int worker_count() {
   static const int n = [] {
     if (env_flag("SMX_COPY_THREADS") >= 0) return std::max(1, std::min(64, (int)env_int("SMX_COPY_THREADS", 16)));
     const unsigned hw = std::thread::hardware_concurrency();
-    return (int)std::max(1u, std::min(16u, hw / 2));
+    int t = (int)std::max(1u, std::min(16u, hw / 2));
+    const int quota = cgroup_cpu_quota();
+    if (quota > 0) t = std::max(1, std::min(t, quota - 4));   // the DMA drivers, the launching thread and the HIP runtime's own keep a share
+    return t;
   }();
   return n;
 }
@@ -61,7 +83,8 @@ struct StreamAndEvents {
   hipEvent_t ev[kRing] = {};
   StreamAndEvents() {
     SMX_HIP_CHECK(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
-    for (auto &e : ev) SMX_HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    // (blocking waits: a thread that spins in hipEventSynchronize through a DMA spends CPU quota the copying threads need)
+    for (auto &e : ev) SMX_HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming | hipEventBlockingSync));
   }
   ~StreamAndEvents() {
     for (auto &e : ev)
@@ -70,10 +93,14 @@ struct StreamAndEvents {
   }
 };
 
+// (a short spin, then sleeps: the GPU boxes give a process a CPU quota -- 16 cores of 256 -- and a thread that spins through a DMA's
+// milliseconds spends the quota its copying neighbours need; with two transfers in flight that throttled the whole call)
 inline void wait_for(const std::atomic<long> &v, long target) {
   int spins = 0;
-  while (v.load(std::memory_order_acquire) < target)
-    if (++spins > 64) std::this_thread::yield();
+  while (v.load(std::memory_order_acquire) < target) {
+    if (++spins > 256) std::this_thread::sleep_for(std::chrono::microseconds(30));
+    else if (spins > 64) std::this_thread::yield();
+  }
 }
 
 // The slice of chunk `i` that worker `w` of `t` moves (64-byte aligned cuts).
@@ -148,8 +175,10 @@ void staged(void *dst, const void *src, size_t bytes, bool to_host, int workers 
   };
   auto workers_done_with = [&](long i) {
     int spins = 0;
-    while (done[i].load(std::memory_order_acquire) < t)
-      if (++spins > 64) std::this_thread::yield();
+    while (done[i].load(std::memory_order_acquire) < t) {
+      if (++spins > 256) std::this_thread::sleep_for(std::chrono::microseconds(30));
+      else if (spins > 64) std::this_thread::yield();
+    }
   };
   if (to_host) {
     // `ready` = chunks whose DMA has landed in their staging buffer

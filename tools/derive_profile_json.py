@@ -6,7 +6,7 @@
 Usage: python tools/derive_profile_json.py r04"""
 import json, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-rnd = sys.argv[1] if len(sys.argv) > 1 else "r06c"
+rnd = sys.argv[1] if len(sys.argv) > 1 else "r07"
 src = os.path.join(ROOT, "profiles", rnd, "pmc_hot_kernels.json")
 k = json.load(open(src))["kernels"]
 hkey = next(n for n in ("stft2048_power32_kernel<true, 2, false, 1>", "stft2048_power32_kernel<true, 2, false, 2>", "stft2048_power32_kernel<true, 2, false, 0>",
@@ -30,7 +30,7 @@ json.dump({"bytes_per_launch": read_b + write_b, "read_bytes": read_b, "write_by
 # every hot kernel: counter traffic against its algorithmic bytes (the launches of tools/pmc_driver.py)
 FR2048, FR1K, FR512 = 938, 1723, 3446
 ALGO = {"stft2048_power32": 256 * FR2048 * 6148, "stft2048_complex32": 256 * FR2048 * (2048 + 8200), "stft2048_mel32": 256 * FR2048 * (2048 + 512),
-        "istft2048": 256 * (FR2048 * 8200 + 480000 * 4), "mel_apply_mfma": 256 * FR2048 * (4100 + 512), "fir_ols_split": 8 * 2880000 * 8,
+        "istft2048": 256 * FR2048 * (8200 + 2048), "mel_apply_mfma": 256 * FR2048 * (4100 + 512), "fir_ols_split": 8 * 2880000 * 8,
         "stft_power_lanes_kernel<16": 256 * FR1K * (1024 + 2052), "stft_power_lanes_kernel<8": 256 * FR512 * (512 + 1028),
         "wide64::stft2048_power_wide": 256 * FR2048 * 6148}
 table = {}
@@ -44,6 +44,20 @@ for name, v in k.items():
                    "traffic_over_algorithmic": round((rb + wb) / algo_b, 3) if algo_b else None,
                    "avg_us": round(v["duration"]["avg_us"], 1) if v.get("duration") else None,
                    "lds_bank_conflict_over_active": round(cc["SQ_LDS_BANK_CONFLICT"] / cc["SQ_LDS_IDX_ACTIVE"], 4) if cc.get("SQ_LDS_IDX_ACTIVE") else None}
+# the bench line of the same box and call (profiles/<round>/bench_n1_full.json: a plain `python bench.py`): every kernel's
+# sustained duration here beside the `ms` the line reports for it -- tests/test_host_logic.py holds them within 5 %
+bench_path = os.path.join(ROOT, "profiles", rnd, "bench_n1_full.json")
+if os.path.exists(bench_path):
+    line = json.loads(open(bench_path).read().strip().splitlines()[-1])
+    ex = line.get("extra", {})
+    pairs = {"stft2048_power32": line["roofline"].get("kernel_ms_avg"), "stft2048_complex32": ex.get("c2_complex", {}).get("ms"),
+             "istft2048": ex.get("c2_invert", {}).get("ms"), "stft2048_mel32": ex.get("c3_mel", {}).get("ms"),
+             "stft_power_lanes_kernel<16": ex.get("c1_batch", {}).get("ms"), "fir_ols_split": ex.get("c4_fir", {}).get("ms"),
+             "wide64::stft2048_power_wide": ex.get("c2_float64_interior", {}).get("ms")}
+    for name, row in table.items():
+        ms = next((v for key, v in pairs.items() if name.startswith(key)), None)
+        row["bench_ms"] = ms
+        row["bench_source"] = "profiles/%s/bench_n1_full.json" % rnd if ms is not None else None
 tj = json.load(open(os.path.join(ROOT, "profiles", "hbm_traffic.json")))
 tj["per_kernel"] = table
 json.dump(tj, open(os.path.join(ROOT, "profiles", "hbm_traffic.json"), "w"), indent=1)

@@ -12,8 +12,11 @@ cd /tmp && export TMPDIR=/tmp
 # --no-extras: C5's one-GPU point launches the same kernel name on a 48x larger batch and would pollute the average
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -- python3 $ROOT/bench.py --no-cpu-baseline --no-extras --steps 20 --warmup 3 > "$OUT/bench_n1.json" 2> "$OUT/trace.err"
 find "$OUT/trace" -name '*kernel_stats.csv' | head -1 | xargs -r -I{} cp {} "$OUT/kernel_stats.csv"
+# the plain bench line of the same box (every `extra`): what profiles/hbm_traffic.json's per-kernel durations are held against
+(cd "$ROOT" && timeout 600 python3 bench.py > "$OUT/bench_n1_full.json" 2> "$OUT/bench_full.err")
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace_hot" -- python3 $ROOT/tools/pmc_driver.py > "$OUT/trace_hot.log" 2>&1
 find "$OUT/trace_hot" -name '*kernel_stats.csv' | head -1 | xargs -r -I{} cp {} "$OUT/hot_kernel_stats.csv"
+find "$OUT/trace_hot" -name '*kernel_trace.csv' | head -1 | xargs -r -I{} cp {} "$OUT/hot_kernel_trace.csv"
 i=0
 while read -r group; do
   i=$((i+1))
@@ -39,17 +42,25 @@ for f in glob.glob(out_dir + '/pmc_g*/**/*counter_collection.csv', recursive=Tru
             continue
         k = re.sub(r'\(smx::.*', '', k.replace('void smx::(anonymous namespace)::', ''))
         rows[k][r['Counter_Name']].append(float(r['Counter_Value']))
+# durations: the LAST 10 dispatches of every kernel in the per-dispatch trace (each kernel runs REPS times back to back in the
+# driver: the sustained state), with the whole-run statistics beside them
 dur = {}
-for f in glob.glob(out_dir + '/hot_kernel_stats.csv'):
+per = collections.defaultdict(list)
+for f in glob.glob(out_dir + '/hot_kernel_trace.csv'):
     for r in csv.DictReader(open(f)):
-        k = re.sub(r'\(smx::.*', '', r['Name'].replace('void smx::(anonymous namespace)::', ''))
-        dur[k] = {"calls": int(r['Calls']), "avg_us": float(r['AverageNs']) / 1e3, "min_us": float(r['MinNs']) / 1e3}
+        k = re.sub(r'\(smx::.*', '', r['Kernel_Name'].replace('void smx::(anonymous namespace)::', ''))
+        per[k].append((int(r['Start_Timestamp']), int(r['End_Timestamp']) - int(r['Start_Timestamp'])))
+for k, v in per.items():
+    v.sort()
+    last = [d for _, d in v[-10:]]
+    dur[k] = {"calls": len(v), "avg_us": sum(last) / len(last) / 1e3, "min_us": min(last) / 1e3, "of": "the last %d of %d back-to-back launches" % (len(last), len(v)),
+              "all_launches_avg_us": sum(d for _, d in v) / len(v) / 1e3}
 res = {"source": "tools/profile_round.sh: rocprofv3 --pmc, one counter group per pass over tools/pmc_driver.py (C2 256 x 480000 fft 2048 / hop 512; "
-                 "C3 128 mels; C4 8192 taps on 8 x 2880000); per launch, average over the launches after the first; durations from a "
-                 "--kernel-trace --stats pass of the same driver; FETCH_SIZE / WRITE_SIZE in KB as reported (FETCH_SIZE counts half the bytes "
+                 "C3 128 mels; C4 8192 taps on 8 x 2880000); per launch, average over each kernel's last 10 of REPS back-to-back launches; durations the same way from a "
+                 "--kernel-trace pass of the same driver; FETCH_SIZE / WRITE_SIZE in KB as reported (FETCH_SIZE counts half the bytes "
                  "of wide coalesced reads on gfx950: MI355X_MICROARCH.md)", "kernels": {}}
 for k, cs in rows.items():
-    res["kernels"][k] = {"duration": dur.get(k), "counters": {c: (sum(v[1:]) / max(1, len(v) - 1) if len(v) > 1 else v[0]) for c, v in sorted(cs.items())}}
+    res["kernels"][k] = {"duration": dur.get(k), "counters": {c: sum(v[-10:]) / len(v[-10:]) for c, v in sorted(cs.items())}}
 json.dump(res, open(out_dir + '/pmc.json', 'w'), indent=1)
 for k, v in res["kernels"].items():
     c = v["counters"]
