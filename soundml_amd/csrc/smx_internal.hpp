@@ -45,16 +45,18 @@ void set_last_error(const std::string &message);
   } while (0)
 
 // ---- environment switches ------------------------------------------------------------------------------------------
-// The shipped library reads ten variables, each once per use and parsed ONE way (env_flag: unset -> -1, "0" / "" /
+// The shipped library reads twelve variables, each once per use and parsed ONE way (env_flag: unset -> -1, "0" / "" /
 // "false" / "off" -> 0, anything else -> 1); none alters results except by selecting another kernel of the same contract:
 //   SMX_DISABLE_FAST   the generic kernels instead of the hand-laid ones (tests: two implementations of one contract)
 //   SMX_POWER_SKEW=0   fft-2048 power spectrogram: the plain per-tile flush instead of whole aligned 64-byte blocks (tests, A/B timing)
-//   SMX_BORDER_INLINE=0 fft-2048 power spectrogram: the border frames in an epilogue / gathered strips instead of the tile sequence (tests: same values)
+//   SMX_BORDER_INLINE=0 fft 2048 (power / complex spectrogram, fused mel): the border frames in an epilogue / gathered strips instead of the tile sequence (tests: same values)
 //   SMX_COMPLEX_SKEW=0 fft-2048 Stft.transform: the plain per-tile flush instead of whole aligned 128-byte lines (tests, A/B timing)
+//   SMX_INVERT_PIPELINE=0 Stft.invert at fft 2048 / hop 512: the one-tile-per-workgroup kernel of rounds 1-4 instead of the persistent pipeline (tests, A/B timing)
 //   SMX_WIDE_PIPELINE=0 float64 interior at fft 2048: the one-tile-per-workgroup kernel instead of the persistent one (tests: bit-identical)
 //   SMX_MEL_DENSE=1    fused mel at fft 2048: the dense 16 x 16 x 4 product instead of the banded 4 x 4 x 1 one (tests, A/B timing)
 //   SMX_MIXED_OFF      chirp-z instead of the mixed-radix kernels (tests: the two agree)
 //   SMX_HOST_TRACE     print where a host-pointer call's time goes
+//   SMX_HOST_PIPELINE=0 host-pointer STFT calls: upload, kernels, download one after the other instead of overlapped clip units
 //   SMX_COPY_THREADS / SMX_COPY_PLAIN   host <-> device staging of the host-pointer entry points
 // Every other switch (kernel selection for timing, ablations) exists in diagnostic builds only (make DIAG=1): diag_flag /
 // diag_int answer "unset" in the shipped build, so what a launcher picks there is a function of the call alone.

@@ -236,12 +236,21 @@ __device__ __forceinline__ void lds_wait(unsigned *c, unsigned target) {
 }
 
 #include "stft_fast_p32.hpp"   // the 32-lane frame pipeline: stft2048_power32_kernel
-#ifdef SMX_ISA_ONE   // tools/isa_one.py: ONE instantiation of the headline kernel (registers / scratch / instruction mix in seconds, no GPU)
+#include "stft_fast_mel32.hpp" // the fused audio -> mel kernel on the 32-lane pipeline: stft2048_mel32_kernel
+#ifdef SMX_ISA_ONE   // tools/isa_one.py: ONE instantiation of a fft-2048 kernel (registers / scratch / instruction mix in seconds, no GPU)
+#ifndef SMX_ISA_KERNEL
+#define SMX_ISA_KERNEL 0
+#endif
+#if SMX_ISA_KERNEL == 1
+template __global__ void stft2048_complex32_kernel<true, (SMX_ISA_ONE != 0)>(FastArgs);
+#elif SMX_ISA_KERNEL == 2
+template __global__ void stft2048_mel32_kernel<true, 2, SMX_ISA_ONE>(FastArgs, Mel32Args);
+#else
 template __global__ void stft2048_power32_kernel<true, 2, false, SMX_ISA_ONE>(FastArgs);
+#endif
 }  // namespace
 }  // namespace smx
 #else
-#include "stft_fast_mel32.hpp" // the fused audio -> mel kernel on the 32-lane pipeline: stft2048_mel32_kernel
 #include "stft_fast_p16.hpp"   // the same pipeline with a frame in 16 / 8 lanes: stft_power_lanes_kernel (power spectrogram at fft 1024 / 512)
 }  // namespace
 
@@ -547,7 +556,8 @@ void launch_ranges(const StftJob &job, const FastTarget &tg) {
   // that holds such a frame takes its samples through the padding rule (load_frame32_padded: one reflection, hence n >= fft).
   // The epilogue below ran 4 tile times deep on a quarter of the workgroups at C2: 30 of the launch's 495 us
   // (profiles/r07/timeline_before.log).  SMX_BORDER_INLINE=0: the epilogue / strips as before (same values: tested).
-  if (!tg.mel && !tg.complex_out && c.fft_size == kN && (i0 - p0) + (p1 - i1) > 0 && job.n >= c.fft_size && job.n < (int64_t(1) << 30) &&
+  // (the complex spectrogram and the fused mel kernel at fft 2048 the same way: no gather launches before them)
+  if (c.fft_size == kN && (i0 - p0) + (p1 - i1) > 0 && job.n >= c.fft_size && job.n < (int64_t(1) << 30) &&
       env_flag("SMX_BORDER_INLINE") != 0) {
     FastTarget folded = tg;
     folded.inline_border = true;

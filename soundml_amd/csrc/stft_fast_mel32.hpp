@@ -397,6 +397,8 @@ struct MelMid32 {
   const Lds32 &lds;
   float2 (&raw)[32];
   const float *src;      // the next frames' samples (per lane)
+  const float *src_clip; // ... their clip and whether their tile holds a frame that reaches past the signal (see PowerMid32)
+  bool src_border;
   float *pend_out;       // output origin and frames of the previous tile
   int pend_left;
   int lane, wave, b, it;
@@ -419,7 +421,8 @@ struct MelMid32 {
     }
   }
   __device__ __forceinline__ void postpass_at(int s) const {
-    if (s == SMX_P32_LOAD_AT) load_frame32<ALIGNED>(src, lane & 31, raw);
+    if (s == SMX_P32_LOAD_AT) load_frame32<ALIGNED>(src_border ? src_clip : src, lane & 31, raw);
+    if (s == 15 && src_border) load_frame32_padded(a, src_clip, (int)(src - src_clip), lane & 31, raw);   // (wave-uniform; see PowerMid32::load_next)
   }
 };
 
@@ -441,17 +444,25 @@ __global__ void __launch_bounds__(512) stft2048_mel32_kernel(FastArgs a, Mel32Ar
     const int avail = (int)(a.count - f0 < kFT ? a.count - f0 : kFT) - 1;
     const int fi = 2 * wave + L.h;
     const int64_t p = a.p0 + f0 + (fi <= avail ? fi : 0);
-    if (a.fold_frames && (p < a.border_i0 || p >= a.border_i1)) {
+    if (a.fold_frames == 1 && (p < a.border_i0 || p >= a.border_i1)) {
       const int64_t clip = (xc - a.x) / a.x_stride;
       return p < a.border_i0 ? a.strip_l + clip * a.strip_l_stride + (p - a.p0) * a.hop
                              : a.strip_r + clip * a.strip_r_stride + (p - a.border_i1) * a.hop;
     }
     return xc + (p * a.hop - a.left);
   };
+  auto tile_border = [&](int t) {   // fold_frames == 2 (as stft2048_power32_kernel): the tile takes load_frame32_padded
+    const int64_t q0 = a.p0 + (int64_t)t * kFT;
+    return a.fold_frames == 2 && (q0 < a.border_i0 || q0 + kFT > a.border_i1);
+  };
   float2 raw[32];
 #pragma unroll
   for (int j = 0; j < 32; ++j) raw[j] = make_float2(0.f, 0.f);
-  if (ntiles > 0) load_frame32<ALIGNED>(frame_ptr(tw.xclip, tw.ft), L.l, raw);
+  if (ntiles > 0) {
+    const float *src0 = frame_ptr(tw.xclip, tw.ft);
+    if (tile_border(tw.ft)) load_frame32_padded(a, tw.xclip, (int)(src0 - tw.xclip), L.l, raw);
+    else load_frame32<ALIGNED>(src0, L.l, raw);
+  }
   __syncthreads();   // tables and zeroed counters visible: the only workgroup barrier
   float *pend_out = nullptr;
   int pend_left = 0;
@@ -469,8 +480,10 @@ __global__ void __launch_bounds__(512) stft2048_mel32_kernel(FastArgs a, Mel32Ar
     float *onext;
     tw.peek(a, ftnext, xnext, onext);
     const bool more = it + 1 < ntiles;
-    const float *src = frame_ptr(more ? xnext : tw.xclip, more ? ftnext : tw.ft);
-    const MelMid32<ALIGNED, FOUR> mid{a, m, areg, iv, lds, raw, src, pend_out, pend_left, lane, wave, b, it, pk_drained, pk_filled};
+    const float *src_clip = more ? xnext : tw.xclip;
+    const float *src = frame_ptr(src_clip, more ? ftnext : tw.ft);
+    const bool src_border = tile_border(more ? ftnext : tw.ft);
+    const MelMid32<ALIGNED, FOUR> mid{a, m, areg, iv, lds, raw, src, src_clip, src_border, pend_out, pend_left, lane, wave, b, it, pk_drained, pk_filled};
     frame32_to_tile<PMODE>(a, L, raw, lds.tiles + b * kTile32Floats, mid);
     lds_signal32(lds.filled + b * kTileStride, lane);
     pend_out = tw.oclip + tw.ft * kFT;   // wave-uniform

@@ -1286,6 +1286,8 @@ struct CplxMid32 {
   bool pend_fresh, pend_closing;
   float2 (&raw)[32];
   const float *src;
+  const float *src_clip;   // the next frames' clip and whether their tile holds a frame that reaches past the signal (see PowerMid32)
+  bool src_border;
   float *pend_out;
   int pend_left;
   int lane, wave, it;
@@ -1304,7 +1306,8 @@ struct CplxMid32 {
   __device__ __forceinline__ void after_transposition_issue() const {}
   __device__ __forceinline__ void after_exchange_issue() const {}
   __device__ __forceinline__ void postpass_at(int s) const {
-    if (s == (SKEW ? 15 : SMX_P32_LOAD_AT)) load_frame32<ALIGNED>(src, lane & 31, raw);
+    if (s == (SKEW ? 15 : SMX_P32_LOAD_AT)) load_frame32<ALIGNED>(src_border ? src_clip : src, lane & 31, raw);
+    if (s == 15 && src_border) load_frame32_padded(a, src_clip, (int)(src - src_clip), lane & 31, raw);   // (wave-uniform; see PowerMid32::load_next)
   }
 };
 
@@ -1325,17 +1328,25 @@ __global__ void __launch_bounds__(512) stft2048_complex32_kernel(FastArgs a) {
     const int avail = (int)(a.count - f0 < kFT ? a.count - f0 : kFT) - 1;
     const int fi = 2 * wave + L.h;
     const int64_t p = a.p0 + f0 + (fi <= avail ? fi : 0);
-    if (a.fold_frames && (p < a.border_i0 || p >= a.border_i1)) {
+    if (a.fold_frames == 1 && (p < a.border_i0 || p >= a.border_i1)) {
       const int64_t clip = (xc - a.x) / a.x_stride;
       return p < a.border_i0 ? a.strip_l + clip * a.strip_l_stride + (p - a.p0) * a.hop
                              : a.strip_r + clip * a.strip_r_stride + (p - a.border_i1) * a.hop;
     }
     return xc + (p * a.hop - a.left);
   };
+  auto tile_border = [&](int t) {   // fold_frames == 2 (as stft2048_power32_kernel): the tile takes load_frame32_padded
+    const int64_t q0 = a.p0 + (int64_t)t * kFT;
+    return a.fold_frames == 2 && (q0 < a.border_i0 || q0 + kFT > a.border_i1);
+  };
   float2 raw[32];
 #pragma unroll
   for (int j = 0; j < 32; ++j) raw[j] = make_float2(0.f, 0.f);
-  if (ntiles > 0) load_frame32<ALIGNED>(frame_ptr(tw.xclip, tw.ft), L.l, raw);
+  if (ntiles > 0) {
+    const float *src0 = frame_ptr(tw.xclip, tw.ft);
+    if (tile_border(tw.ft)) load_frame32_padded(a, tw.xclip, (int)(src0 - tw.xclip), L.l, raw);
+    else load_frame32<ALIGNED>(src0, L.l, raw);
+  }
   __syncthreads();
   const CplxFlush32 fl = setup_cplx_flush32(a, lane, wave);
   CplxSkew32 sk{};
@@ -1352,11 +1363,13 @@ __global__ void __launch_bounds__(512) stft2048_complex32_kernel(FastArgs a) {
     float *onext;
     tw.peek(a, ftnext, xnext, onext);
     const bool more = it + 1 < ntiles;
-    const float *src = frame_ptr(more ? xnext : tw.xclip, more ? ftnext : tw.ft);
+    const float *src_clip = more ? xnext : tw.xclip;
+    const float *src = frame_ptr(src_clip, more ? ftnext : tw.ft);
+    const bool src_border = tile_border(more ? ftnext : tw.ft);
     if constexpr (SKEW) {
       if (it > 0 && pend_fresh) cplx_skew32_clip(a, sk, pend_oclip, lane, wave);   // (wave-uniform) the pending tile begins a clip or this workgroup's range
     }
-    const CplxMid32<ALIGNED, SKEW> mid{a, lds, fl, sk, carry, pend_fresh, pend_closing, raw, src, pend_out, pend_left, lane, wave, it};
+    const CplxMid32<ALIGNED, SKEW> mid{a, lds, fl, sk, carry, pend_fresh, pend_closing, raw, src, src_clip, src_border, pend_out, pend_left, lane, wave, it};
     // (SKEW: the twiddle rows are requested behind the flush -- their 62 registers beside the 64 carried ones do not fit)
     frame32_to_tile<2, CplxMid32<ALIGNED, SKEW>, true, SKEW ? 0 : 15>(a, L, raw, lds.tiles, mid);
     lds_signal32(lds.filled, lane);

@@ -234,8 +234,9 @@ print(json.dumps(out))
 
 
 def test_border_tiles_in_the_tile_sequence_equal_the_epilogue():
-    """Round 5: at fft 2048 the frames that reach past the signal ride in the power kernel's tile sequence (a tile with such a frame
-    loads through the padding rule, stft_fast_p32.hpp load_frame32_padded) instead of an epilogue after the interior tiles.
+    """Round 5: at fft 2048 the frames that reach past the signal ride in the tile sequence of the power, complex and fused mel
+    kernels (a tile with such a frame loads through the padding rule, stft_fast_p32.hpp load_frame32_padded) instead of an epilogue
+    after the interior tiles / gathered strips.
     SMX_BORDER_INLINE=0 selects the epilogue / strips: same frame code on the same samples, so every value agrees bit for bit --
     every pad mode and alignment, odd hops (unaligned loads), ranges that begin or end inside the border, clips barely longer
     than a frame, many short clips, general powers."""
@@ -243,9 +244,11 @@ def test_border_tiles_in_the_tile_sequence_equal_the_epilogue():
 import json, sys, numpy as np
 sys.path.insert(0, %r)
 import torch
-from soundml_amd import Stft
+import soundml_amd as S
+from soundml_amd import Mel, Stft
 torch.manual_seed(5)
 out = []
+mc = Mel.Config.create(n_mels=80, sample_rate=16000, fft_size=2048)
 for alignment in ("centered", "left", "right"):
     for pad in ("reflect", "edge", ("constant", 0.37)):
         for hop in (512, 300, 77):
@@ -259,6 +262,11 @@ for alignment in ("centered", "left", "right"):
                     for p in (2.0, 0.7):
                         pw = Stft.power_range(c, x, a, b, p).contiguous()
                         out.append(int(pw.view(torch.int32).to(torch.int64).sum()))
+                    z = torch.view_as_real(Stft.transform_range(c, x, a, b)).contiguous()
+                    out.append(int(z.view(torch.int32).to(torch.int64).sum()))
+                if hop == 512:
+                    m = S.mel_spectrogram(c, mc, x).contiguous()
+                    out.append(int(m.view(torch.int32).to(torch.int64).sum()))
 print(json.dumps(out))
 """ % ROOT
     res = []

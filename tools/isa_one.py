@@ -1,6 +1,7 @@
-"""Registers, scratch and instruction mix of ONE instantiation of the headline kernel (stft2048_power32_kernel<true, 2, false, SKEW>)
-from hipcc -S of stft_fast.hip with -DSMX_ISA_ONE=<SKEW>: seconds instead of the minutes the whole file takes; no GPU.
-  python tools/isa_one.py [skew=1] [extra -D flags ...]        (assembly left in /tmp/isa_one_<skew>.s)"""
+"""Registers, scratch and instruction mix of ONE instantiation of a fft-2048 kernel from hipcc -S of stft_fast.hip with
+-DSMX_ISA_ONE=<V>: seconds instead of the minutes the whole file takes; no GPU.  Default: stft2048_power32_kernel<true, 2, false, V>
+(V = the flush form: 1 pairs, 2 frames, 0 plain); -DSMX_ISA_KERNEL=1: stft2048_complex32_kernel<true, V != 0>; =2: stft2048_mel32_kernel<true, 2, V>.
+  python tools/isa_one.py [V=1] [extra -D flags ...]        (assembly left in /tmp/isa_one_<V>.s)"""
 import collections, os, re, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 skew = sys.argv[1] if len(sys.argv) > 1 else "1"

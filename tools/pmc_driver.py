@@ -25,17 +25,22 @@ o1k = torch.empty(256, 513, f1k, device="cuda")
 o512 = torch.empty(256, 257, f512, device="cuda")
 xs = torch.rand(8, 2880000, device="cuda") * 2 - 1
 ys = torch.empty_like(xs)
-# Every kernel is launched REPS times back to back (default 24) before the next one starts, and the profile's durations and
+# Every kernel is launched at least REPS times (default 24) and for at least SUSTAIN_MS (600 ms) in back-to-back groups of 8 before the next one starts, and the profile's durations and
 # counters are taken from its LAST 10 launches (tools/profile_round.sh): the sustained state bench.py measures, not the burst out
 # of an idle device that round 4's four round-robin launches sampled (8-28 % above the bench line's figures: VERDICT r4, weak 6).
 reps = int(os.environ.get("REPS", "24"))
+sustain_ms = float(os.environ.get("SUSTAIN_MS", "600"))   # ... and for at least this long: the chip needs ~0.5 s of one kernel to settle (profiles/r07/NOTES.md: 613 -> 482 us within 60 launches, 447 after ~1000: what bench.py's adaptive preconditioning waits for)
+import time
 zv = torch.view_as_complex(zc)
 yr = torch.empty(256, 480000, device="cuda")
 lib.smx_stft_invert_f32_dev.argtypes = [vp, vp, ctypes.c_int64, ctypes.c_int64, ctypes.c_int64, ctypes.c_int, ctypes.c_int64, vp, vp]
 def each(fn):
-    for _ in range(reps):
-        fn()
-    torch.cuda.synchronize()
+    t0, n = time.perf_counter(), 0
+    while n < reps or (time.perf_counter() - t0) * 1e3 < sustain_ms:
+        for _ in range(8):
+            fn()
+        n += 8
+        torch.cuda.synchronize()
 each(lambda: check(lib.smx_stft_power_range_f32_dev(sc._h, vp(x.data_ptr()), 256, 480000, 480000, 0, frames, 2.0, vp(out.data_ptr()), None)))
 each(lambda: check(lib.smx_stft_transform_range_f32_dev(sc._h, vp(x.data_ptr()), 256, 480000, 480000, 0, frames, vp(zc.data_ptr()), None)))
 each(lambda: check(lib.smx_stft_invert_f32_dev(sc._h, vp(zc.data_ptr()), 256, 1025, frames, 1, 480000, vp(yr.data_ptr()), None)))

@@ -20,7 +20,7 @@ find "$OUT/trace_hot" -name '*kernel_trace.csv' | head -1 | xargs -r -I{} cp {} 
 i=0
 while read -r group; do
   i=$((i+1))
-  timeout 300 rocprofv3 --pmc $group --output-format csv -d "$OUT/pmc_g$i" -- python3 $ROOT/tools/pmc_driver.py > "$OUT/pmc_g$i.log" 2>&1 || echo "group $i failed"
+  SUSTAIN_MS=0 timeout 300 rocprofv3 --pmc $group --output-format csv -d "$OUT/pmc_g$i" -- python3 $ROOT/tools/pmc_driver.py > "$OUT/pmc_g$i.log" 2>&1 || echo "group $i failed"
 done <<'GROUPS'
 SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_WAVES
 SQ_ACTIVE_INST_LDS SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SALU
