@@ -44,9 +44,9 @@ for name, v in k.items():
                    "traffic_over_algorithmic": round((rb + wb) / algo_b, 3) if algo_b else None,
                    "avg_us": round(v["duration"]["avg_us"], 1) if v.get("duration") else None,
                    "lds_bank_conflict_over_active": round(cc["SQ_LDS_BANK_CONFLICT"] / cc["SQ_LDS_IDX_ACTIVE"], 4) if cc.get("SQ_LDS_IDX_ACTIVE") else None}
-# the bench line of the same box and call (profiles/<round>/bench_n1_full.json: a plain `python bench.py`): every kernel's
-# sustained duration here beside the `ms` the line reports for it -- tests/test_host_logic.py holds them within 5 %
-bench_path = os.path.join(ROOT, "profiles", rnd, "bench_n1_full.json")
+# the bench line of the traced run itself (profiles/<round>/bench_n1.json): every kernel's duration in that run's trace beside the
+# `ms` the line reports for it -- tests/test_host_logic.py holds them within 5 %
+bench_path = os.path.join(ROOT, "profiles", rnd, "bench_n1.json")   # the line of the TRACED run the durations come from
 if os.path.exists(bench_path):
     line = json.loads(open(bench_path).read().strip().splitlines()[-1])
     ex = line.get("extra", {})
@@ -57,7 +57,7 @@ if os.path.exists(bench_path):
     for name, row in table.items():
         ms = next((v for key, v in pairs.items() if name.startswith(key)), None)
         row["bench_ms"] = ms
-        row["bench_source"] = "profiles/%s/bench_n1_full.json" % rnd if ms is not None else None
+        row["bench_source"] = "profiles/%s/bench_n1.json (the traced run itself)" % rnd if ms is not None else None
 tj = json.load(open(os.path.join(ROOT, "profiles", "hbm_traffic.json")))
 tj["per_kernel"] = table
 json.dump(tj, open(os.path.join(ROOT, "profiles", "hbm_traffic.json"), "w"), indent=1)

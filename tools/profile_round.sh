@@ -9,9 +9,13 @@ ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out/$TAG
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
-# --no-extras: C5's one-GPU point launches the same kernel name on a 48x larger batch and would pollute the average
-timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -- python3 $ROOT/bench.py --no-cpu-baseline --no-extras --steps 20 --warmup 3 > "$OUT/bench_n1.json" 2> "$OUT/trace.err"
+# The bench command itself under the tracer, every `extra` included (C5's one-GPU point runs the frame-per-lane instantiation of the
+# headline kernel, <true, 2, false, 2>, so it does not pollute the average of C2's <true, 2, false, 1>): the line it prints and the
+# per-dispatch trace of the SAME run -- profiles/hbm_traffic.json takes every kernel's duration from this trace (median over the
+# kernel's launches in the run: preconditioning + timed steps) and holds it against the `ms` this line reports.
+timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -- python3 $ROOT/bench.py --no-cpu-baseline > "$OUT/bench_n1.json" 2> "$OUT/trace.err"
 find "$OUT/trace" -name '*kernel_stats.csv' | head -1 | xargs -r -I{} cp {} "$OUT/kernel_stats.csv"
+find "$OUT/trace" -name '*kernel_trace.csv' | head -1 | xargs -r -I{} cp {} "$OUT/bench_kernel_trace.csv"
 # the plain bench line of the same box (every `extra`): what profiles/hbm_traffic.json's per-kernel durations are held against
 (cd "$ROOT" && timeout 600 python3 bench.py > "$OUT/bench_n1_full.json" 2> "$OUT/bench_full.err")
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace_hot" -- python3 $ROOT/tools/pmc_driver.py > "$OUT/trace_hot.log" 2>&1
@@ -42,22 +46,32 @@ for f in glob.glob(out_dir + '/pmc_g*/**/*counter_collection.csv', recursive=Tru
             continue
         k = re.sub(r'\(smx::.*', '', k.replace('void smx::(anonymous namespace)::', ''))
         rows[k][r['Counter_Name']].append(float(r['Counter_Value']))
-# durations: the LAST 10 dispatches of every kernel in the per-dispatch trace (each kernel runs REPS times back to back in the
-# driver: the sustained state), with the whole-run statistics beside them
+# durations: the traced bench run (bench_kernel_trace.csv): median over a kernel's launches in that run -- the same program, the
+# same preconditioning as the line in bench_n1.json; beside them the driver's own sustained figure (last 10 of >= 600 ms of launches)
+import statistics
 dur = {}
-per = collections.defaultdict(list)
-for f in glob.glob(out_dir + '/hot_kernel_trace.csv'):
-    for r in csv.DictReader(open(f)):
-        k = re.sub(r'\(smx::.*', '', r['Kernel_Name'].replace('void smx::(anonymous namespace)::', ''))
-        per[k].append((int(r['Start_Timestamp']), int(r['End_Timestamp']) - int(r['Start_Timestamp'])))
-for k, v in per.items():
-    v.sort()
+def by_kernel(path):
+    per = collections.defaultdict(list)
+    for f in glob.glob(path):
+        for r in csv.DictReader(open(f)):
+            k = re.sub(r'\(smx::.*', '', r['Kernel_Name'].replace('void smx::(anonymous namespace)::', ''))
+            per[k].append((int(r['Start_Timestamp']), int(r['End_Timestamp']) - int(r['Start_Timestamp'])))
+    for v in per.values():
+        v.sort()
+    return per
+bench_per, drv_per = by_kernel(out_dir + '/bench_kernel_trace.csv'), by_kernel(out_dir + '/hot_kernel_trace.csv')
+for k, v in drv_per.items():
     last = [d for _, d in v[-10:]]
-    dur[k] = {"calls": len(v), "avg_us": sum(last) / len(last) / 1e3, "min_us": min(last) / 1e3, "of": "the last %d of %d back-to-back launches" % (len(last), len(v)),
-              "all_launches_avg_us": sum(d for _, d in v) / len(v) / 1e3}
+    dur[k] = {"driver_calls": len(v), "driver_last10_avg_us": sum(last) / len(last) / 1e3}
+    if k in bench_per:
+        b = [d for _, d in bench_per[k]]
+        dur[k].update({"calls": len(b), "avg_us": statistics.median(b) / 1e3, "min_us": min(b) / 1e3, "mean_us": sum(b) / len(b) / 1e3,
+                       "of": "median over the kernel's %d launches in the traced bench.py run (bench_n1.json)" % len(b)})
+    else:
+        dur[k].update({"calls": len(v), "avg_us": sum(last) / len(last) / 1e3, "min_us": min(last) / 1e3, "of": "the last 10 of %d back-to-back launches of tools/pmc_driver.py (no bench line for this kernel)" % len(v)})
 res = {"source": "tools/profile_round.sh: rocprofv3 --pmc, one counter group per pass over tools/pmc_driver.py (C2 256 x 480000 fft 2048 / hop 512; "
-                 "C3 128 mels; C4 8192 taps on 8 x 2880000); per launch, average over each kernel's last 10 of REPS back-to-back launches; durations the same way from a "
-                 "--kernel-trace pass of the same driver; FETCH_SIZE / WRITE_SIZE in KB as reported (FETCH_SIZE counts half the bytes "
+                 "C3 128 mels; C4 8192 taps on 8 x 2880000); counters per launch, average over each kernel's last 10 launches; durations from the --kernel-trace of bench.py "
+                 "itself (median over the kernel's launches in that run), the driver's own sustained figure beside them; FETCH_SIZE / WRITE_SIZE in KB as reported (FETCH_SIZE counts half the bytes "
                  "of wide coalesced reads on gfx950: MI355X_MICROARCH.md)", "kernels": {}}
 for k, cs in rows.items():
     res["kernels"][k] = {"duration": dur.get(k), "counters": {c: sum(v[-10:]) / len(v[-10:]) for c, v in sorted(cs.items())}}
