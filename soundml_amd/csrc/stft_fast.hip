@@ -1,29 +1,24 @@
-// Fused framing + window + real FFT(2048) + output stage for gfx950 (MI355X): the three fft-2048 kernels
-//   stft2048_power32_kernel   |X|^p               Stft.power_spectrum          stft.ml:670-691   (stft_fast_p32.hpp, 32-lane frame pipeline)
-//   stft2048_complex32_kernel X                   Stft.transform / _range      stft.ml:632-666   (the same)
-//   stft2048_mel_kernel       W |X|^p (MFMA)      Soundml.mel_spectrogram      soundml.ml:12-24
+// Fused framing + window + real FFT + output stage for gfx950 (MI355X): the launchers, the tile walk and the border handling of
+//   stft2048_power32_kernel    |X|^p               Stft.power_spectrum          stft.ml:670-691   (stft_fast_p32.hpp: the 32-lane frame pipeline)
+//   stft2048_complex32_kernel  X                   Stft.transform / _range      stft.ml:632-666   (the same)
+//   stft2048_mel32_kernel      W |X|^p (MFMA)      Soundml.mel_spectrogram      soundml.ml:12-24  (stft_fast_mel32.hpp: the filterbank product over the pipeline's tiles)
+//   stft_power_lanes_kernel / stft_complex_lanes_kernel / stft_mel_lanes_kernel<16 | 8>    the same at fft 1024 / 512 (stft_fast_p16.hpp)
 // They replace, for float32 audio, the reference's hot call
 //   Nx.stft cdtype ~window:fft ~step:hop ~win (to_double samples)   stft.ml:356-364
-// Each audio sample is read from HBM once (hop-strided overlapping frames are re-read through L1 / L2) and
-// the [bins; frames] result is written once, in 64-byte (power) or 128-byte (complex) runs along the frame axis.
+// Each audio sample is read from HBM once (hop-strided overlapping frames are re-read through L1 / L2) and the [bins; frames]
+// result is written once, in whole aligned 64-byte blocks (power) or 128-byte lines (complex) along the frame axis.
 //
-// Frame pipeline (M = N/2 = 1024 complex points, z[n] = x[2n] + i x[2n+1]); one 64-lane wavefront owns one
-// frame, lane l holds 16 complex points:
-//   A. n = l + 64 j      : radix-16 over j in registers        -> y_l[k1],  twiddle W_M^(l k1)
-//   X. in-wave 16x16 transpose (permlane32/16_swap + DPP row ops, no LDS):
-//      lane l' = 4 k1 + a receives y_(4i+a)[k1], i = 0..15
-//   B. radix-16 over i in registers, twiddle W_64^(a q)
-//   C. radix-4 over a across the 4 lanes of a quad (v_fmac_f32_dpp)
-//      -> lane (k1, rr), register q holds Z[k1 + 16 q + 256 r], r = bitrev2(rr)
-//   P. real-FFT post-pass: partner Z[M-k] fetched with ds_bpermute (lane 67-l', register 15-q; lanes 0..3 are
-//      the k1 = 0 column and pair inside themselves), X[k] = E - i w_k D with the 1/2 folded into the window.
-//   T. the result goes into a workgroup tile [1024 bins (+ Nyquist in the pad column)][16 frames] in LDS with a
-//      bank-conflict-free row permutation.
-// A workgroup is 16 waves = 16 consecutive frames of one clip, one persistent workgroup per CU (LDS is full:
-// two 69.6 KB tiles + 24.5 KB of tables incl. the window).  There is no workgroup barrier in the loops: waves
-// synchronise through monotonic LDS counters and wait only for what they consume (see the kernels).
+// The frame pipeline itself (a frame in 32 / 16 / 8 lanes with 32 points per lane, radix-32 stages in registers, one transposition
+// through the frame's own column of the output tile in LDS, the real-FFT post-pass on pairs of bins) is described at the head of
+// stft_fast_p32.hpp; a workgroup is 8 waves = one tile of 16 (32, 64) consecutive frames of one clip, two tile buffers, one
+// persistent workgroup per CU walking a contiguous range of the flat (clip, tile) sequence (TileWalk below), waves meeting at
+// monotonic LDS counters instead of barriers.  (The 64-lane kernels of rounds 1-2 -- in-wave transposes by permlane / DPP -- are gone.)
 //
-// Algorithmic HBM bytes per frame at hop 512: power 2048 + 4100 = 6148 B, complex 2048 + 8200 = 10248 B,
+// Frames that reach past either end of the signal: at fft 2048 their tile takes its samples through the padding rule
+// (FastArgs::fold_frames == 2, load_frame32_padded: round 5); at fft 1024 / 512, and for clips shorter than a frame, from gathered,
+// already padded strips (fold_frames == 1) or the power kernel's border epilogue.
+//
+// Algorithmic HBM bytes per frame at fft 2048 / hop 512: power 2048 + 4100 = 6148 B, complex 2048 + 8200 = 10248 B,
 // mel 2048 + 4 n_mels.
 #include <cstdlib>
 #include <type_traits>
