@@ -14,9 +14,9 @@
 // persistent workgroup per CU walking a contiguous range of the flat (clip, tile) sequence (TileWalk below), waves meeting at
 // monotonic LDS counters instead of barriers.  (The 64-lane kernels of rounds 1-2 -- in-wave transposes by permlane / DPP -- are gone.)
 //
-// Frames that reach past either end of the signal: at fft 2048 their tile takes its samples through the padding rule
-// (FastArgs::fold_frames == 2, load_frame32_padded: round 5); at fft 1024 / 512, and for clips shorter than a frame, from gathered,
-// already padded strips (fold_frames == 1) or the power kernel's border epilogue.
+// Frames that reach past either end of the signal: their tile takes its samples through the padding rule (FastArgs::fold_frames
+// == 2, load_frame32_padded / load_frameL_padded: round 5); for clips shorter than a frame, from gathered, already padded strips
+// (fold_frames == 1) or the power kernels' border epilogue.
 //
 // Algorithmic HBM bytes per frame at fft 2048 / hop 512: power 2048 + 4100 = 6148 B, complex 2048 + 8200 = 10248 B,
 // mel 2048 + 4 n_mels.
@@ -232,7 +232,8 @@ __device__ __forceinline__ void lds_wait(unsigned *c, unsigned target) {
 
 #include "stft_fast_p32.hpp"   // the 32-lane frame pipeline: stft2048_power32_kernel
 #include "stft_fast_mel32.hpp" // the fused audio -> mel kernel on the 32-lane pipeline: stft2048_mel32_kernel
-#ifdef SMX_ISA_ONE   // tools/isa_one.py: ONE instantiation of a fft-2048 kernel (registers / scratch / instruction mix in seconds, no GPU)
+#include "stft_fast_p16.hpp"   // the same pipeline with a frame in 16 / 8 lanes: stft_power_lanes_kernel (power spectrogram at fft 1024 / 512)
+#ifdef SMX_ISA_ONE   // tools/isa_one.py: ONE instantiation of a register-pipeline kernel (registers / scratch / instruction mix in seconds, no GPU)
 #ifndef SMX_ISA_KERNEL
 #define SMX_ISA_KERNEL 0
 #endif
@@ -240,13 +241,18 @@ __device__ __forceinline__ void lds_wait(unsigned *c, unsigned target) {
 template __global__ void stft2048_complex32_kernel<true, (SMX_ISA_ONE != 0)>(FastArgs);
 #elif SMX_ISA_KERNEL == 2
 template __global__ void stft2048_mel32_kernel<true, 2, SMX_ISA_ONE>(FastArgs, Mel32Args);
+#elif SMX_ISA_KERNEL == 3
+template __global__ void stft_power_lanes_kernel<SMX_ISA_ONE, true, 2, false>(FastArgs);
+#elif SMX_ISA_KERNEL == 4
+template __global__ void stft_mel_lanes_kernel<SMX_ISA_ONE, true, 2, true>(FastArgs, Mel32Args);
+#elif SMX_ISA_KERNEL == 5
+template __global__ void stft_complex_lanes_kernel<SMX_ISA_ONE, true>(FastArgs);
 #else
 template __global__ void stft2048_power32_kernel<true, 2, false, SMX_ISA_ONE>(FastArgs);
 #endif
 }  // namespace
 }  // namespace smx
 #else
-#include "stft_fast_p16.hpp"   // the same pipeline with a frame in 16 / 8 lanes: stft_power_lanes_kernel (power spectrogram at fft 1024 / 512)
 }  // namespace
 
 namespace {
@@ -552,8 +558,9 @@ void launch_ranges(const StftJob &job, const FastTarget &tg) {
   // The epilogue below ran 4 tile times deep on a quarter of the workgroups at C2: 30 of the launch's 495 us
   // (profiles/r07/timeline_before.log).  SMX_BORDER_INLINE=0: the epilogue / strips as before (same values: tested).
   // (the complex spectrogram and the fused mel kernel at fft 2048 the same way: no gather launches before them)
-  if (c.fft_size == kN && (i0 - p0) + (p1 - i1) > 0 && job.n >= c.fft_size && job.n < (int64_t(1) << 30) &&
-      env_flag("SMX_BORDER_INLINE") != 0) {
+  // (and the fft 1024 / 512 kernels of stft_fast_p16.hpp: load_frameL_padded)
+  if ((c.fft_size == kN || c.fft_size == kN16 || c.fft_size == kN8) && (i0 - p0) + (p1 - i1) > 0 && job.n >= c.fft_size &&
+      job.n < (int64_t(1) << 30) && env_flag("SMX_BORDER_INLINE") != 0) {
     FastTarget folded = tg;
     folded.inline_border = true;
     folded.border_p0 = i0;

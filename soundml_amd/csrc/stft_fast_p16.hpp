@@ -292,6 +292,32 @@ __device__ __forceinline__ void load_frameL(const float *src, int l, float2 (&ra
   }
 }
 
+// the same for a tile with frames that reach past either end of the signal (see load_frame32_padded in stft_fast_p32.hpp: round 5)
+template <int LL>
+__device__ __forceinline__ void load_frameL_padded(const FastArgs &a, const float *xc /* wave-uniform */, int s0, int l, float2 (&raw)[32]) {
+  asm volatile("" : "+v"(s0));
+  const int n = (int)a.n, top = 2 * (n - 1);
+  const bool refl = a.pad == SMX_PAD_REFLECT;
+  auto at = [&](int s) {
+    const int m = s < 0 ? -s : s;
+    const int ir = m < top - m ? m : top - m;
+    const int ie = s < 0 ? 0 : (s < n ? s : n - 1);
+    return *reinterpret_cast<const float *>(reinterpret_cast<const char *>(xc) + 4u * (unsigned)(refl ? ir : ie));
+  };
+  const int s00 = s0 + 2 * l;
+#pragma unroll
+  for (int j = 0; j < 32; ++j) raw[j] = make_float2(at(s00 + 2 * LL * j), at(s00 + 2 * LL * j + 1));
+  if (a.pad != SMX_PAD_REFLECT && a.pad != SMX_PAD_EDGE) {   // constant padding (wave-uniform)
+    const float pv = a.pad_value;
+#pragma unroll
+    for (int j = 0; j < 32; ++j) {
+      const int s = s00 + 2 * LL * j;
+      if ((unsigned)s >= (unsigned)n) raw[j].x = pv;
+      if ((unsigned)(s + 1) >= (unsigned)n) raw[j].y = pv;
+    }
+  }
+}
+
 // A wave's share of a finished tile: 8 parts of (LL = 16: 8 rows; LL = 8: 4 rows of one 32-frame half of the tile per lane
 // half) x 4 frames per lane -> out[clip][bin][f0 + cb + 4 g ..]; 8 lanes store one 128-byte run.  Rows r' (r' < 4) and
 // frame groups g < 8 per 32-lane half keep the LDS reads conflict free.
@@ -368,6 +394,8 @@ struct PowerMidL {
   FlushRegsL &fr;
   float2 (&raw)[32];
   const float *src;      // the next frames' samples (per lane)
+  const float *src_clip; // ... their clip and whether their tile holds a frame that reaches past the signal (see PowerMid32)
+  bool src_border;
   float *pend_out;       // output origin and frames of the previous tile
   int pend_left;
   int lane, wave, b, it;
@@ -388,10 +416,11 @@ struct PowerMidL {
   }
   __device__ __forceinline__ void postpass_at(int s) const {
     const bool same = SMX_P32_STORE_AT == SMX_P32_LOAD_AT;
-    if (s == SMX_P32_LOAD_AT && same && SMX_P32_LOADS_FIRST) { load_frameL<LL, ALIGNED>(src, lane & (LL - 1), raw); SMX_FENCE(); }
+    if (s == SMX_P32_LOAD_AT && same && SMX_P32_LOADS_FIRST) { load_frameL<LL, ALIGNED>(src_border ? src_clip : src, lane & (LL - 1), raw); SMX_FENCE(); }
     if (s == SMX_P32_STORE_AT && it > 0) flushL_store<LL>(a, fl, pend_out, pend_left, fr);
     SMX_FENCE();
-    if (s == SMX_P32_LOAD_AT && !(same && SMX_P32_LOADS_FIRST)) load_frameL<LL, ALIGNED>(src, lane & (LL - 1), raw);
+    if (s == SMX_P32_LOAD_AT && !(same && SMX_P32_LOADS_FIRST)) load_frameL<LL, ALIGNED>(src_border ? src_clip : src, lane & (LL - 1), raw);
+    if (s == 15 && src_border) load_frameL_padded<LL>(a, src_clip, (int)(src - src_clip), lane & (LL - 1), raw);   // (wave-uniform; see PowerMid32::load_next)
   }
 };
 
@@ -416,7 +445,7 @@ __global__ void __launch_bounds__(512) stft_power_lanes_kernel(FastArgs a) {
     const int avail = (int)(a.count - f0 < P::FT ? a.count - f0 : P::FT) - 1;   // last frame of the tile that exists (wave-uniform)
     const int fi = L.col;
     const int64_t p = a.p0 + f0 + (fi <= avail ? fi : 0);
-    if (a.fold_frames && (p < a.border_i0 || p >= a.border_i1)) {
+    if (a.fold_frames == 1 && (p < a.border_i0 || p >= a.border_i1)) {
       const int64_t clip = (xc - a.x) / a.x_stride;
       return p < a.border_i0 ? a.strip_l + clip * a.strip_l_stride + (p - a.p0) * a.hop
                              : a.strip_r + clip * a.strip_r_stride + (p - a.border_i1) * a.hop;
@@ -427,7 +456,15 @@ __global__ void __launch_bounds__(512) stft_power_lanes_kernel(FastArgs a) {
   float2 raw[32];
 #pragma unroll
   for (int j = 0; j < 32; ++j) raw[j] = make_float2(0.f, 0.f);
-  if (ntiles > 0) load_frameL<LL, ALIGNED>(frame_ptr(tw.xclip, tw.ft), L.l, raw);
+  auto tile_border = [&](int t) {   // fold_frames == 2 (as stft2048_power32_kernel): the tile takes load_frameL_padded
+    const int64_t q0 = a.p0 + (int64_t)t * P::FT;
+    return a.fold_frames == 2 && (q0 < a.border_i0 || q0 + P::FT > a.border_i1);
+  };
+  if (ntiles > 0) {
+    const float *src0 = frame_ptr(tw.xclip, tw.ft);
+    if (tile_border(tw.ft)) load_frameL_padded<LL>(a, tw.xclip, (int)(src0 - tw.xclip), L.l, raw);
+    else load_frameL<LL, ALIGNED>(src0, L.l, raw);
+  }
   __syncthreads();   // tables and zeroed counters visible: the only workgroup barrier of the main loop
   float *pend_out = nullptr;
   int pend_left = 0;
@@ -441,8 +478,10 @@ __global__ void __launch_bounds__(512) stft_power_lanes_kernel(FastArgs a) {
     float *onext;
     tw.peek(a, ftnext, xnext, onext);
     const bool more = it + 1 < ntiles;
-    const float *src = frame_ptr(more ? xnext : tw.xclip, more ? ftnext : tw.ft);
-    const PowerMidL<LL, ALIGNED> mid{a, lds, fl, fr, raw, src, pend_out, pend_left, lane, wave, b, it, pk_drained, pk_filled};
+    const float *src_clip = more ? xnext : tw.xclip;
+    const float *src = frame_ptr(src_clip, more ? ftnext : tw.ft);
+    const bool src_border = tile_border(more ? ftnext : tw.ft);
+    const PowerMidL<LL, ALIGNED> mid{a, lds, fl, fr, raw, src, src_clip, src_border, pend_out, pend_left, lane, wave, b, it, pk_drained, pk_filled};
     frameL_to_tile<LL, PMODE>(a, L, raw, lds.tiles + b * P::TileFloats, mid);
     lds_signal32(lds.filled + b * P::TS, lane);
     pend_out = tw.oclip + tw.ft * P::FT;   // wave-uniform
@@ -519,6 +558,8 @@ struct MelMidL {
   const LdsL<LL> &lds;
   float2 (&raw)[32];
   const float *src;
+  const float *src_clip;
+  bool src_border;
   float *pend_out;
   int pend_left;
   int lane, wave, b, it;
@@ -549,7 +590,8 @@ struct MelMidL {
     }
   }
   __device__ __forceinline__ void postpass_at(int s) const {
-    if (s == SMX_P32_LOAD_AT) load_frameL<LL, ALIGNED>(src, lane & (LL - 1), raw);
+    if (s == SMX_P32_LOAD_AT) load_frameL<LL, ALIGNED>(src_border ? src_clip : src, lane & (LL - 1), raw);
+    if (s == 15 && src_border) load_frameL_padded<LL>(a, src_clip, (int)(src - src_clip), lane & (LL - 1), raw);
   }
 };
 
@@ -571,7 +613,7 @@ __global__ void __launch_bounds__(512) stft_mel_lanes_kernel(FastArgs a, Mel32Ar
     const int avail = (int)(a.count - f0 < P::FT ? a.count - f0 : P::FT) - 1;
     const int fi = L.col;
     const int64_t p = a.p0 + f0 + (fi <= avail ? fi : 0);
-    if (a.fold_frames && (p < a.border_i0 || p >= a.border_i1)) {
+    if (a.fold_frames == 1 && (p < a.border_i0 || p >= a.border_i1)) {
       const int64_t clip = (xc - a.x) / a.x_stride;
       return p < a.border_i0 ? a.strip_l + clip * a.strip_l_stride + (p - a.p0) * a.hop
                              : a.strip_r + clip * a.strip_r_stride + (p - a.border_i1) * a.hop;
@@ -581,7 +623,15 @@ __global__ void __launch_bounds__(512) stft_mel_lanes_kernel(FastArgs a, Mel32Ar
   float2 raw[32];
 #pragma unroll
   for (int j = 0; j < 32; ++j) raw[j] = make_float2(0.f, 0.f);
-  if (ntiles > 0) load_frameL<LL, ALIGNED>(frame_ptr(tw.xclip, tw.ft), L.l, raw);
+  auto tile_border = [&](int t) {   // fold_frames == 2 (as stft2048_power32_kernel): the tile takes load_frameL_padded
+    const int64_t q0 = a.p0 + (int64_t)t * P::FT;
+    return a.fold_frames == 2 && (q0 < a.border_i0 || q0 + P::FT > a.border_i1);
+  };
+  if (ntiles > 0) {
+    const float *src0 = frame_ptr(tw.xclip, tw.ft);
+    if (tile_border(tw.ft)) load_frameL_padded<LL>(a, tw.xclip, (int)(src0 - tw.xclip), L.l, raw);
+    else load_frameL<LL, ALIGNED>(src0, L.l, raw);
+  }
   __syncthreads();
   float *pend_out = nullptr;
   int pend_left = 0;
@@ -599,8 +649,10 @@ __global__ void __launch_bounds__(512) stft_mel_lanes_kernel(FastArgs a, Mel32Ar
     float *onext;
     tw.peek(a, ftnext, xnext, onext);
     const bool more = it + 1 < ntiles;
-    const float *src = frame_ptr(more ? xnext : tw.xclip, more ? ftnext : tw.ft);
-    const MelMidL<LL, ALIGNED, FOUR> mid{a, m, areg, iv, lds, raw, src, pend_out, pend_left, lane, wave, b, it, pk_drained, pk_filled};
+    const float *src_clip = more ? xnext : tw.xclip;
+    const float *src = frame_ptr(src_clip, more ? ftnext : tw.ft);
+    const bool src_border = tile_border(more ? ftnext : tw.ft);
+    const MelMidL<LL, ALIGNED, FOUR> mid{a, m, areg, iv, lds, raw, src, src_clip, src_border, pend_out, pend_left, lane, wave, b, it, pk_drained, pk_filled};
     frameL_to_tile<LL, PMODE>(a, L, raw, lds.tiles + b * P::TileFloats, mid);
     lds_signal32(lds.filled + b * P::TS, lane);
     pend_out = tw.oclip + tw.ft * P::FT;
@@ -685,6 +737,8 @@ struct CplxMidL {
   const CplxFlushL &fl;
   float2 (&raw)[32];
   const float *src;
+  const float *src_clip;
+  bool src_border;
   float *pend_out;
   int pend_left;
   int lane, wave, it;
@@ -701,7 +755,8 @@ struct CplxMidL {
   __device__ __forceinline__ void after_transposition_issue() const {}
   __device__ __forceinline__ void after_exchange_issue() const {}
   __device__ __forceinline__ void postpass_at(int s) const {
-    if (s == SMX_P32_LOAD_AT) load_frameL<LL, ALIGNED>(src, lane & (LL - 1), raw);
+    if (s == SMX_P32_LOAD_AT) load_frameL<LL, ALIGNED>(src_border ? src_clip : src, lane & (LL - 1), raw);
+    if (s == 15 && src_border) load_frameL_padded<LL>(a, src_clip, (int)(src - src_clip), lane & (LL - 1), raw);
   }
 };
 
@@ -723,7 +778,7 @@ __global__ void __launch_bounds__(512) stft_complex_lanes_kernel(FastArgs a) {
     const int avail = (int)(a.count - f0 < P::FT ? a.count - f0 : P::FT) - 1;
     const int fi = L.col;
     const int64_t p = a.p0 + f0 + (fi <= avail ? fi : 0);
-    if (a.fold_frames && (p < a.border_i0 || p >= a.border_i1)) {
+    if (a.fold_frames == 1 && (p < a.border_i0 || p >= a.border_i1)) {
       const int64_t clip = (xc - a.x) / a.x_stride;
       return p < a.border_i0 ? a.strip_l + clip * a.strip_l_stride + (p - a.p0) * a.hop
                              : a.strip_r + clip * a.strip_r_stride + (p - a.border_i1) * a.hop;
@@ -733,7 +788,15 @@ __global__ void __launch_bounds__(512) stft_complex_lanes_kernel(FastArgs a) {
   float2 raw[32];
 #pragma unroll
   for (int j = 0; j < 32; ++j) raw[j] = make_float2(0.f, 0.f);
-  if (ntiles > 0) load_frameL<LL, ALIGNED>(frame_ptr(tw.xclip, tw.ft), L.l, raw);
+  auto tile_border = [&](int t) {   // fold_frames == 2 (as stft2048_power32_kernel): the tile takes load_frameL_padded
+    const int64_t q0 = a.p0 + (int64_t)t * P::FT;
+    return a.fold_frames == 2 && (q0 < a.border_i0 || q0 + P::FT > a.border_i1);
+  };
+  if (ntiles > 0) {
+    const float *src0 = frame_ptr(tw.xclip, tw.ft);
+    if (tile_border(tw.ft)) load_frameL_padded<LL>(a, tw.xclip, (int)(src0 - tw.xclip), L.l, raw);
+    else load_frameL<LL, ALIGNED>(src0, L.l, raw);
+  }
   __syncthreads();
   const CplxFlushL fl = setup_cplx_flushL<LL>(a, lane, wave);
   float *pend_out = nullptr;
@@ -744,8 +807,10 @@ __global__ void __launch_bounds__(512) stft_complex_lanes_kernel(FastArgs a) {
     float *onext;
     tw.peek(a, ftnext, xnext, onext);
     const bool more = it + 1 < ntiles;
-    const float *src = frame_ptr(more ? xnext : tw.xclip, more ? ftnext : tw.ft);
-    const CplxMidL<LL, ALIGNED> mid{a, lds, fl, raw, src, pend_out, pend_left, lane, wave, it};
+    const float *src_clip = more ? xnext : tw.xclip;
+    const float *src = frame_ptr(src_clip, more ? ftnext : tw.ft);
+    const bool src_border = tile_border(more ? ftnext : tw.ft);
+    const CplxMidL<LL, ALIGNED> mid{a, lds, fl, raw, src, src_clip, src_border, pend_out, pend_left, lane, wave, it};
     frameL_to_tile<LL, 2, CplxMidL<LL, ALIGNED>, true>(a, L, raw, lds.tiles, mid);
     lds_signal32(lds.filled, lane);
     pend_out = tw.oclip + 2 * tw.ft * P::FT;
