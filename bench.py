@@ -269,7 +269,9 @@ def main():
                 last8 = [a.elapsed_time(b) for a, b in evp]
                 spent = (time.perf_counter() - t_pre) * 1e3
                 settled = (max(last8) - min(last8)) <= 0.01 * min(last8)
-                if (settled and spent >= args.preroll_ms) or spent >= 10.0 * args.preroll_ms:
+                # N > 1: every rank runs the full 10 x --preroll-ms (no early exit), so that the ranks reach the barrier together --
+                # a rank that settled early would idle there while the others go on, and leave its sustained state again
+                if (world == 1 and settled and spent >= args.preroll_ms) or spent >= 10.0 * args.preroll_ms:
                     break
         timed.settled = settled
         timed.preroll_steps = preroll_steps
@@ -383,7 +385,7 @@ def main():
                        # untimed, uncounted: the same step repeated before the W warm-up steps until the chip's power management has
                        # settled (--preroll-ms; `extra.c2_burst_from_idle` is the same measurement without it)
                        "preconditioning": {"min_ms": args.preroll_ms, "steps": main_preroll_steps, "settled_within_1pct": main_settled,
-                                           "rule": "groups of 8 event-timed steps until the last 8 lie within 1 % of each other"}},
+                                           "rule": "groups of 8 event-timed steps until the last 8 lie within 1 % of each other (at most 10 x min_ms; N > 1: always 10 x min_ms, so that the ranks meet the barrier together)"}},
             # every launch of the step that ran before the timed region: the preconditioning steps + the W declared warm-up steps
             "warmup_effective": main_preroll_steps + args.warmup,
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
