@@ -114,7 +114,6 @@ inline void slice(size_t len, int w, int t, size_t &lo, size_t &hi) {
 // not PCIe, bounds the download (0.98 GB of C2 spectrogram: 240 000 faults).  Ask for transparent huge pages on the whole 2 MB
 // pieces of the destination first (a no-op where the kernel has them off or the pages exist already).
 void advise_huge(void *dst, size_t bytes) {
-  if (env_flag("SMX_COPY_HUGEPAGE") == 0) return;
   const uintptr_t two_mb = (uintptr_t)2 << 20;
   const uintptr_t lo = (reinterpret_cast<uintptr_t>(dst) + two_mb - 1) & ~(two_mb - 1), hi = (reinterpret_cast<uintptr_t>(dst) + bytes) & ~(two_mb - 1);
   if (hi > lo) (void)madvise(reinterpret_cast<void *>(lo), hi - lo, MADV_HUGEPAGE);

@@ -10,7 +10,7 @@ x = (torch.rand(256, 480000, device="cuda") * 2 - 1).float()
 out = Stft.power_spectrum(c, x)
 xh = x.cpu().numpy()
 print("torch threads", torch.get_num_threads(), "interop", torch.get_num_interop_threads())
-envs = [{}, {"SMX_HOST_PIPELINE": "0"}, {"SMX_COPY_HUGEPAGE": "0"}, {"SMX_COPY_HUGEPAGE": "0", "SMX_HOST_PIPELINE": "0"}]
+envs = [{}, {"SMX_HOST_PIPELINE": "0"}]
 res = {i: [] for i in range(len(envs))}
 for rnd in range(8):
     for i, e in enumerate(envs):
