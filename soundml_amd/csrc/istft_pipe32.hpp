@@ -321,6 +321,81 @@ __global__ void __launch_bounds__(512) istft2048_pipe_kernel(PipeArgs pa) {
   asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(ip_prev)::"memory");
   const unsigned long long ip_t0 = ip_prev, ip_r0 = __builtin_amdgcn_s_memrealtime();
 #endif
+  // S6 / S7 of a tile (clip g_clip, tile g_ft of it; g_store: its output is this workgroup's): wait for every frame's samples, the
+  // overlap-add, "drained", envelope and stores.  Called at the TOP of the next tile's iteration (and once behind the loop), so that
+  // Griffin-Lim's factors of that next tile, requested just before, are in flight under it -- requested anywhere earlier and carried
+  // over the loop edge hipcc parks them in scratch load by load.
+  auto overlap_add = [&](int64_t g_clip, int g_ft, bool g_store, unsigned filled_target) {
+    ip_wait(lds.filled, filled_target);
+    IP_STAMP(7);   // wait: every frame's samples in
+    {
+      constexpr int SP = kIpSlot / 2;   // cells per slot
+      const float2 *s2 = reinterpret_cast<const float2 *>(lds.slots) + ip_opaque(u) + ip_opaque(par) * SP;   // hop h = 2 i + par: frame h's cell u
+      // hop h of parity par: frames h, h - 1, h - 2, h - 3 at segments 0, 1, 2, 3, summed in that order (frame index descending,
+      // stft.ml:806-831); the frames before this tile from the carried pairs
+      f2 acc[8];
+      auto cell = [&](int rel, int d) { const float2 x = s2[rel * SP + 256 * d]; return f2{x.x, x.y}; };   // frame 2 i + par + rel
+      if (par == 0) {
+        acc[0] = ((cell(0, 0) + carry[0]) + carry[1]) + carry[2];                 // hop 0: frames 0, -1, -2, -3
+        acc[1] = ((cell(2, 0) + cell(1, 1)) + cell(0, 2)) + carry[3];             // hop 2: frames 2, 1, 0, -1
+      } else {
+        acc[0] = ((cell(0, 0) + cell(-1, 1)) + carry[0]) + carry[1];              // hop 1: frames 1, 0, -1, -2
+        acc[1] = ((cell(2, 0) + cell(1, 1)) + cell(0, 2)) + cell(-1, 3);          // hop 3: frames 3, 2, 1, 0
+      }
+      IP_FENCE();   // (in batches: with Griffin-Lim's 99 prefetched registers beside the 66 staged ones, 32 cells in flight spill)
+#pragma unroll
+      for (int i = 2; i < 8; ++i) {
+        acc[i] = ((cell(2 * i, 0) + cell(2 * i - 1, 1)) + cell(2 * i - 2, 2)) + cell(2 * i - 3, 3);
+        if (GL && (i & 1)) IP_FENCE();
+      }
+      // what the next tile needs of frames 13, 14, 15 (parity 0: frame 15 at segment 1, 14 at 2, 13 at 3, then 15 at 3;
+      // parity 1: frame 15 at segment 2, 14 at 3)
+      {
+        const float2 *t2 = reinterpret_cast<const float2 *>(lds.slots) + ip_opaque(u);
+        if (par == 0) {
+          const float2 c0 = t2[15 * SP + 256], c1 = t2[14 * SP + 512], c2 = t2[13 * SP + 768], c3 = t2[15 * SP + 768];
+          carry[0] = f2{c0.x, c0.y}; carry[1] = f2{c1.x, c1.y}; carry[2] = f2{c2.x, c2.y}; carry[3] = f2{c3.x, c3.y};
+        } else {
+          const float2 c0 = t2[15 * SP + 512], c1 = t2[14 * SP + 768];
+          carry[0] = f2{c0.x, c0.y}; carry[1] = f2{c1.x, c1.y};
+        }
+      }
+      ip_signal(lds.drained, lane);   // (behind this wave's reads in LDS order)
+      IP_STAMP(8);   // overlap-add reads and sums
+      if (g_store) {
+        float *out = a.out + (size_t)g_clip * (size_t)a.out_len;
+        const int64_t q_tile = (int64_t)512 * kIpFT * g_ft;
+        const int64_t e_tile = q_tile + a.env_q0, m_tile = q_tile - a.left;
+        // (wave-uniform) every position of the tile is an interior one: inside the synthesis' span, the envelope's periodic part
+        // and the output
+        const bool inner = pa.aligned_out && e_tile >= a.head && e_tile + 512 * kIpFT <= a.stop && q_tile + 512 * kIpFT <= a.span &&
+                           m_tile >= 0 && m_tile + 512 * kIpFT <= a.out_len;
+        if (inner) {
+          float2 *o2 = reinterpret_cast<float2 *>(out + m_tile) + 256 * par + u;
+#pragma unroll
+          for (int i = 0; i < 8; ++i) o2[512 * i] = make_float2((float)((double)acc[i].x * renv0), (float)((double)acc[i].y * renv1));
+        } else {
+          // a sample that the output holds: 0 past the synthesis' span, else the sum over the envelope (its periodic part as a
+          // product with the reciprocal, the clip's first and last hops as a division: as istft2048_kernel)
+          auto value = [&](float sum, int64_t q, double renv) {
+            if (q >= a.span) return 0.f;
+            const int64_t E = q + a.env_q0;
+            if (E >= a.head && E < a.stop) return (float)((double)sum * renv);
+            return (float)((double)sum / (E < a.head ? a.env_head[E] : a.env_tail[E - a.stop]));
+          };
+#pragma unroll
+          for (int i = 0; i < 8; ++i) {
+            const int64_t Q = q_tile + 512 * (2 * i + par) + 2 * u, mo = Q - a.left;
+            if (mo >= 0 && mo < a.out_len) out[mo] = value(acc[i].x, Q, renv0);
+            if (mo + 1 >= 0 && mo + 1 < a.out_len) out[mo + 1] = value(acc[i].y, Q + 1, renv1);
+          }
+        }
+      }
+    }
+  };
+  int64_t p_clip = clip;
+  int p_ft = ft;
+  bool p_store = false;
   for (int it = 0; it < todo; ++it) {
     IP_STAMP(0);   // loop edge
     // S1 / S2: the slots are free; the staged registers go in.
@@ -331,6 +406,13 @@ __global__ void __launch_bounds__(512) istft2048_pipe_kernel(PipeArgs pa) {
     // parks the 99 values in scratch as they arrive, one wait per load: 352 bytes of scratch against none.  The synthesis of a
     // Griffin-Lim iteration reads 4.9 GB for 0.5 GB written: it sits on the memory system either way.)
     if (GL) request_factors(clip, ft);
+    if (it > 0) {   // the previous tile's overlap-add
+      overlap_add(p_clip, p_ft, p_store, 8u * (unsigned)it);
+      if (clip != p_clip) {   // a new clip: nothing reaches into it
+#pragma unroll
+        for (int i = 0; i < 4; ++i) carry[i] = f2{0.f, 0.f};
+      }
+    }
 #if IP_GL_BULK
     if constexpr (GL) {   // the factors applied to all 33 elements at once (33 independent float64 chains for the scheduler), before the wait
       if (a.unit) {
@@ -401,82 +483,14 @@ __global__ void __launch_bounds__(512) istft2048_pipe_kernel(PipeArgs pa) {
     ip_signal(lds.filled, lane);
     IP_FENCE();
     IP_STAMP(6);   // the two frames
-    // S6 / S7
-    ip_wait(lds.filled, 8u * (unsigned)(it + 1));
-    IP_STAMP(7);   // wait: every frame's samples in
-    {
-      constexpr int SP = kIpSlot / 2;   // cells per slot
-      const float2 *s2 = reinterpret_cast<const float2 *>(lds.slots) + ip_opaque(u) + ip_opaque(par) * SP;   // hop h = 2 i + par: frame h's cell u
-      // hop h of parity par: frames h, h - 1, h - 2, h - 3 at segments 0, 1, 2, 3, summed in that order (frame index descending,
-      // stft.ml:806-831); the frames before this tile from the carried pairs
-      f2 acc[8];
-      auto cell = [&](int rel, int d) { const float2 x = s2[rel * SP + 256 * d]; return f2{x.x, x.y}; };   // frame 2 i + par + rel
-      if (par == 0) {
-        acc[0] = ((cell(0, 0) + carry[0]) + carry[1]) + carry[2];                 // hop 0: frames 0, -1, -2, -3
-        acc[1] = ((cell(2, 0) + cell(1, 1)) + cell(0, 2)) + carry[3];             // hop 2: frames 2, 1, 0, -1
-      } else {
-        acc[0] = ((cell(0, 0) + cell(-1, 1)) + carry[0]) + carry[1];              // hop 1: frames 1, 0, -1, -2
-        acc[1] = ((cell(2, 0) + cell(1, 1)) + cell(0, 2)) + cell(-1, 3);          // hop 3: frames 3, 2, 1, 0
-      }
-      IP_FENCE();   // (in batches: with Griffin-Lim's 99 prefetched registers beside the 66 staged ones, 32 cells in flight spill)
-#pragma unroll
-      for (int i = 2; i < 8; ++i) {
-        acc[i] = ((cell(2 * i, 0) + cell(2 * i - 1, 1)) + cell(2 * i - 2, 2)) + cell(2 * i - 3, 3);
-        if (GL && (i & 1)) IP_FENCE();
-      }
-      // what the next tile needs of frames 13, 14, 15 (parity 0: frame 15 at segment 1, 14 at 2, 13 at 3, then 15 at 3;
-      // parity 1: frame 15 at segment 2, 14 at 3)
-      {
-        const float2 *t2 = reinterpret_cast<const float2 *>(lds.slots) + ip_opaque(u);
-        if (par == 0) {
-          const float2 c0 = t2[15 * SP + 256], c1 = t2[14 * SP + 512], c2 = t2[13 * SP + 768], c3 = t2[15 * SP + 768];
-          carry[0] = f2{c0.x, c0.y}; carry[1] = f2{c1.x, c1.y}; carry[2] = f2{c2.x, c2.y}; carry[3] = f2{c3.x, c3.y};
-        } else {
-          const float2 c0 = t2[15 * SP + 512], c1 = t2[14 * SP + 768];
-          carry[0] = f2{c0.x, c0.y}; carry[1] = f2{c1.x, c1.y};
-        }
-      }
-      ip_signal(lds.drained, lane);   // (behind this wave's reads in LDS order)
-      IP_STAMP(8);   // overlap-add reads and sums
-      if (store) {
-        float *out = a.out + (size_t)clip * (size_t)a.out_len;
-        const int64_t q_tile = (int64_t)512 * kIpFT * ft;
-        const int64_t e_tile = q_tile + a.env_q0, m_tile = q_tile - a.left;
-        // (wave-uniform) every position of the tile is an interior one: inside the synthesis' span, the envelope's periodic part
-        // and the output
-        const bool inner = pa.aligned_out && e_tile >= a.head && e_tile + 512 * kIpFT <= a.stop && q_tile + 512 * kIpFT <= a.span &&
-                           m_tile >= 0 && m_tile + 512 * kIpFT <= a.out_len;
-        if (inner) {
-          float2 *o2 = reinterpret_cast<float2 *>(out + m_tile) + 256 * par + u;
-#pragma unroll
-          for (int i = 0; i < 8; ++i) o2[512 * i] = make_float2((float)((double)acc[i].x * renv0), (float)((double)acc[i].y * renv1));
-        } else {
-          // a sample that the output holds: 0 past the synthesis' span, else the sum over the envelope (its periodic part as a
-          // product with the reciprocal, the clip's first and last hops as a division: as istft2048_kernel)
-          auto value = [&](float sum, int64_t q, double renv) {
-            if (q >= a.span) return 0.f;
-            const int64_t E = q + a.env_q0;
-            if (E >= a.head && E < a.stop) return (float)((double)sum * renv);
-            return (float)((double)sum / (E < a.head ? a.env_head[E] : a.env_tail[E - a.stop]));
-          };
-#pragma unroll
-          for (int i = 0; i < 8; ++i) {
-            const int64_t Q = q_tile + 512 * (2 * i + par) + 2 * u, mo = Q - a.left;
-            if (mo >= 0 && mo < a.out_len) out[mo] = value(acc[i].x, Q, renv0);
-            if (mo + 1 >= 0 && mo + 1 < a.out_len) out[mo + 1] = value(acc[i].y, Q + 1, renv1);
-          }
-        }
-      }
-    }
-    IP_STAMP(9);   // envelope and stores
+    p_clip = clip;
+    p_ft = ft;
+    p_store = store;
     store = true;
     ft = ftn;
-    if (clipn != clip) {   // a new clip: nothing reaches into it
-      clip = clipn;
-#pragma unroll
-      for (int i = 0; i < 4; ++i) carry[i] = f2{0.f, 0.f};
-    }
+    clip = clipn;
   }
+  if (todo > 0) overlap_add(p_clip, p_ft, p_store, 8u * (unsigned)todo);
 #ifdef SMX_STAMPS
   ip_sum[20] = __builtin_amdgcn_s_memtime() - ip_t0;
   ip_sum[21] = __builtin_amdgcn_s_memrealtime() - ip_r0;
