@@ -222,6 +222,20 @@ void invert_host(const smx_stft_config &c, const void *z, int z_bytes, int64_t l
   const size_t zb = (size_t)lead * (size_t)bins * (size_t)frames * (size_t)z_bytes;
   const size_t ob = (size_t)lead * (size_t)out_len * (size_t)(z_bytes / 2);
   DeviceScratch dz(zb), dout(ob);
+  // a large batch in units of clips whose upload, synthesis and download overlap (as stft_range_host; every clip is synthesised
+  // on its own: stft.mli:214-218)
+  const size_t z_clip = (size_t)bins * (size_t)frames * (size_t)z_bytes, o_clip = (size_t)out_len * (size_t)(z_bytes / 2);
+  if (lead >= 8 && zb + ob >= ((size_t)128 << 20) && z_clip > 0 && o_clip > 0 && env_flag("SMX_HOST_PIPELINE") != 0) {
+    int64_t unit = (int64_t)(((size_t)48 << 20) / std::max(z_clip, o_clip));
+    unit = std::max<int64_t>(1, std::min<int64_t>(unit, (lead + 3) / 4));
+    SMX_HIP_CHECK(hipStreamSynchronize(nullptr));
+    (void)c.tables();
+    pipelined_host_call(z, z_clip, out, o_clip, lead, unit, dz.ptr, dout.ptr, [&](int64_t clip0, int64_t nc, hipStream_t stream) {
+      invert_dev(c, reinterpret_cast<const unsigned char *>(dz.ptr) + (size_t)clip0 * z_clip, z_bytes, nc, bins, frames, has_length, length,
+                 reinterpret_cast<unsigned char *>(dout.ptr) + (size_t)clip0 * o_clip, stream);
+    });
+    return;
+  }
   if (zb) copy_to_device(dz.ptr, z, zb);
   invert_dev(c, dz.ptr, z_bytes, lead, bins, frames, has_length, length, dout.ptr, nullptr);
   SMX_HIP_CHECK(hipStreamSynchronize(nullptr));

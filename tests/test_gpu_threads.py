@@ -73,3 +73,22 @@ def test_two_threads_on_the_host_pointer_path():
     for i in range(2):
         want = Stft.power_spectrum(c, torch.from_numpy(xs[i]).cuda()).cpu().numpy()
         assert np.array_equal(got[i], want), i
+
+
+def test_pipelined_host_calls_equal_the_device_resident_ones():
+    """The host-pointer transform / power spectrogram / invert of a batch above the pipelining threshold (units of clips whose
+    upload, kernels and download overlap) against the device-resident entry points on the same data: bit for bit, including a
+    batch whose last unit is ragged (clips not a multiple of the unit)."""
+    import torch
+    rng = np.random.default_rng(8)
+    c = Stft.Config.create(fft_size=2048, hop=512)
+    x = rng.uniform(-1, 1, size=(37, 300000)).astype(np.float32)      # 44 MB in, 89 MB / 178 MB out
+    xd = torch.from_numpy(x).cuda()
+    p = Stft.power_spectrum(c, x)
+    assert np.array_equal(p, Stft.power_spectrum(c, xd).cpu().numpy())
+    z = Stft.transform(c, x)
+    zd = Stft.transform(c, xd)
+    assert np.array_equal(z, zd.cpu().numpy())
+    y = Stft.invert(c, z, length=x.shape[-1])
+    assert np.array_equal(y, Stft.invert(c, zd, length=x.shape[-1]).cpu().numpy())
+    assert np.max(np.abs(y - x)) < 2e-6
