@@ -451,9 +451,18 @@ __global__ void __launch_bounds__(512) stft2048_mel32_kernel(FastArgs a, Mel32Ar
     }
     return xc + (p * a.hop - a.left);
   };
-  auto tile_border = [&](int t) {   // fold_frames == 2 (as stft2048_power32_kernel): the tile takes load_frame32_padded
-    const int64_t q0 = a.p0 + (int64_t)t * kFT;
-    return a.fold_frames == 2 && (q0 < a.border_i0 || q0 + kFT > a.border_i1);
+  auto tile_border = [&](int t) {   // fold_frames == 2 (as stft2048_power32_kernel): one of this wave's two frames of tile t reaches past the signal
+    if (a.fold_frames != 2) return false;
+    const int64_t f0 = (int64_t)t * kFT;
+    const int avail = (int)(a.count - f0 < kFT ? a.count - f0 : kFT) - 1;
+    bool any = false;
+#pragma unroll
+    for (int hh = 0; hh < 2; ++hh) {
+      const int fi = 2 * wave + hh;
+      const int64_t p = a.p0 + f0 + (fi <= avail ? fi : 0);
+      any = any || p < a.border_i0 || p >= a.border_i1;
+    }
+    return any;
   };
   float2 raw[32];
 #pragma unroll

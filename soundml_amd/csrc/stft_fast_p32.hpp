@@ -974,9 +974,15 @@ __global__ void __launch_bounds__(512) stft2048_power32_kernel(FastArgs a) {
   const Lane32 L = setup_lane32(lds, lane, wave);
   Tables32Regs tabs;
   tables32_request(a, tid, tabs);   // in flight under the tile walk's divisions
+#ifdef SMX_STAMPS
+  const unsigned long long tl_p1 = __builtin_amdgcn_s_memrealtime();
+#endif
   TileWalk tw;
   tw.init(a, a.out + a.out_offset, kBins * a.out_stride);
   const int ntiles = tw.ntiles > 0 ? tw.ntiles : 0;
+#ifdef SMX_STAMPS
+  const unsigned long long tl_p2 = __builtin_amdgcn_s_memrealtime();
+#endif
 
   // first sample of this lane's frame in tile t of the clip at xc (a lane-half without a frame re-reads the tile's
   // first frame and its results are never stored)
@@ -992,10 +998,22 @@ __global__ void __launch_bounds__(512) stft2048_power32_kernel(FastArgs a) {
     }
     return xc + (p * a.hop - a.left);   // (fold_frames == 2: possibly outside the clip -- then only its position is used)
   };
-  // fold_frames == 2: tile t holds a frame that reaches past the signal and takes load_frame32_padded (wave-uniform)
+  // fold_frames == 2: one of THIS WAVE's two frames of tile t reaches past the signal: the wave takes load_frame32_padded for
+  // the tile (wave-uniform; the other waves of such a tile keep the plain requests -- a C2 clip's first tile has its border
+  // frames on wave 0, its last one on wave 4: with the whole tile on the padding rule the prologue's requests alone took
+  // 4.7 us, profiles/r07/timeline_prologue_pieces.log)
   auto tile_border = [&](int t) {
-    const int64_t q0 = a.p0 + (int64_t)t * kFT;
-    return a.fold_frames == 2 && (q0 < a.border_i0 || q0 + kFT > a.border_i1);
+    if (a.fold_frames != 2) return false;
+    const int64_t f0 = (int64_t)t * kFT;
+    const int avail = (int)(a.count - f0 < kFT ? a.count - f0 : kFT) - 1;
+    bool any = false;
+#pragma unroll
+    for (int hh = 0; hh < 2; ++hh) {
+      const int fi = 2 * wave + hh;
+      const int64_t p = a.p0 + f0 + (fi <= avail ? fi : 0);
+      any = any || p < a.border_i0 || p >= a.border_i1;
+    }
+    return any;
   };
 
   float2 raw[32];
@@ -1008,7 +1026,13 @@ __global__ void __launch_bounds__(512) stft2048_power32_kernel(FastArgs a) {
     if (tile_border(tw.ft)) load_frame32_padded(a, tw.xclip, (int)(src0 - tw.xclip), L.l, raw);
     else load_frame32<ALIGNED>(src0, L.l, raw);
   }
+#ifdef SMX_STAMPS
+  const unsigned long long tl_p3 = __builtin_amdgcn_s_memrealtime();
+#endif
   tables32_commit(lds, tid, tabs);
+#ifdef SMX_STAMPS
+  const unsigned long long tl_p4 = __builtin_amdgcn_s_memrealtime();
+#endif
   __syncthreads();   // tables and zeroed counters visible: the only workgroup barrier of the main loop
   float *pend_out = nullptr;
   int pend_left = 0;
@@ -1039,6 +1063,11 @@ __global__ void __launch_bounds__(512) stft2048_power32_kernel(FastArgs a) {
   asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(stamp_prev)::"memory");
   const unsigned long long clk_t0 = stamp_prev, clk_r0 = __builtin_amdgcn_s_memrealtime();
   stamp_sum[15] = tl_entry;
+  stamp_sum[0] = tl_p1 - tl_entry;   // (slots 0-3 before the loop adds to them: the prologue's pieces, 100 MHz ticks; launch_timeline.py reads them from a launch of ZERO tiles ... or subtracts)
+  stamp_sum[1] = tl_p2 - tl_p1;
+  stamp_sum[2] = tl_p3 - tl_p2;
+  stamp_sum[3] = tl_p4 - tl_p3;
+  stamp_sum[4] = clk_r0 - tl_p4;
   stamp_sum[16] = clk_r0;          // tables in, first samples requested
   stamp_sum[22] = (unsigned long long)ntiles;
 #endif
@@ -1335,9 +1364,18 @@ __global__ void __launch_bounds__(512) stft2048_complex32_kernel(FastArgs a) {
     }
     return xc + (p * a.hop - a.left);
   };
-  auto tile_border = [&](int t) {   // fold_frames == 2 (as stft2048_power32_kernel): the tile takes load_frame32_padded
-    const int64_t q0 = a.p0 + (int64_t)t * kFT;
-    return a.fold_frames == 2 && (q0 < a.border_i0 || q0 + kFT > a.border_i1);
+  auto tile_border = [&](int t) {   // fold_frames == 2 (as stft2048_power32_kernel): one of this wave's two frames of tile t reaches past the signal
+    if (a.fold_frames != 2) return false;
+    const int64_t f0 = (int64_t)t * kFT;
+    const int avail = (int)(a.count - f0 < kFT ? a.count - f0 : kFT) - 1;
+    bool any = false;
+#pragma unroll
+    for (int hh = 0; hh < 2; ++hh) {
+      const int fi = 2 * wave + hh;
+      const int64_t p = a.p0 + f0 + (fi <= avail ? fi : 0);
+      any = any || p < a.border_i0 || p >= a.border_i1;
+    }
+    return any;
   };
   float2 raw[32];
 #pragma unroll

@@ -63,6 +63,9 @@ for clips, n in shapes:
     q = lambda v: "mean %.1f  median %.1f  p90 %.1f  max %.1f" % (np.mean(v), np.median(v), np.percentile(v, 90), np.max(v))
     print("   entry after the first workgroup's entry, us: " + q(wg_entry))
     print("   prologue (entry -> tables in, first samples requested), us: " + q(wg_ready))
+    pieces = [us(st[:, :, k]).mean() for k in range(5)]   # (COARSE builds leave slots 0-4 to the prologue)
+    print("      of it, mean over waves: table requests issued %.2f, tile walk %.2f, first samples requested %.2f, tables into LDS (their arrival) %.2f, barrier + loop set-up %.2f"
+          % tuple(pieces))
     print("   tile 0 (until every wave starts tile 1), us: " + q(wg_first))
     print("   tile 1, us: " + q(wg_second))
     print("   steady tile, us: " + q(per_tile) + "   x tiles = %.1f us mean" % np.mean(per_tile * ntiles))
