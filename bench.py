@@ -29,7 +29,7 @@ which RCCL refuses -- the 2-rank test on a 1-GPU box).
 
 Timing: W untimed warm-up steps, then exactly K steps between barrier + synchronize.  Before the warm-up steps the same step
 runs in groups of 8 event-timed launches until the last 8 lie within 1 % of each other, their mean lies within 0.3 % of the mean 128 launches
-earlier, and --preroll-ms (default 60) have passed (at most 10 x --preroll-ms)
+earlier, and --preroll-ms (default 500) have passed (at most 2 x --preroll-ms)
 (untimed, uncounted; reported as `config.preconditioning` and, with the W warm-up steps, as `warmup_effective`): out of an idle device the
 kernel's time is not stationary (0.51 ms for three launches, 0.61-0.64 for the next ten, the sustained 0.50 after ~40 --
 profiles/r06/step_time_transient.log), and `--steps 20 --warmup 5` would sample that hump.  `value` is the sustained rate;
@@ -66,7 +66,7 @@ def parse_args():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--preroll-ms", type=float, default=60.0,
+    ap.add_argument("--preroll-ms", type=float, default=500.0,
                     help="device preconditioning before the W warm-up steps: the same step repeated for this long (not timed, not counted; "
                          "0 = none).  A burst from idle runs up to 25 %% slower between its 5th and 25th launch while the power "
                          "management settles (profiles/r06/step_time_transient.log); the metric is the sustained rate")
@@ -258,7 +258,7 @@ def main():
         settled = None
         means = []
         if args.preroll_ms > 0:   # bring the chip to its sustained state (see --preroll-ms): ADAPTIVE -- groups of 8 steps, each
-            # timed by HIP events, until the last 8 step times lie within 1 % of each other (or --preroll-ms x 10 has passed)
+            # timed by HIP events, until --preroll-ms have passed AND the last 8 step times lie within 1 % of each other (at most 2 x --preroll-ms)
             t_pre = time.perf_counter()
             while True:
                 evp = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(8)]
@@ -275,9 +275,9 @@ def main():
                 # first condition alone is met on the slow part of the decay too (one box: 184 steps, 0.481 ms; the same box run to
                 # the cap: 0.457 ms -- profiles/r07/bench_n1_full.json against bench_n1.json)
                 settled = (max(last8) - min(last8)) <= 0.01 * min(last8) and len(means) > 16 and abs(means[-1] - means[-17]) <= 0.003 * means[-1]
-                # N > 1: every rank runs the full 10 x --preroll-ms (no early exit), so that the ranks reach the barrier together --
+                # N > 1: every rank runs the full 2 x --preroll-ms (no early exit), so that the ranks reach the barrier together --
                 # a rank that settled early would idle there while the others go on, and leave its sustained state again
-                if (world == 1 and settled and spent >= args.preroll_ms) or spent >= 10.0 * args.preroll_ms:
+                if (world == 1 and settled and spent >= args.preroll_ms) or spent >= 2.0 * args.preroll_ms:
                     break
         timed.settled = settled
         timed.preroll_steps = preroll_steps
@@ -391,7 +391,7 @@ def main():
                        # untimed, uncounted: the same step repeated before the W warm-up steps until the chip's power management has
                        # settled (--preroll-ms; `extra.c2_burst_from_idle` is the same measurement without it)
                        "preconditioning": {"min_ms": args.preroll_ms, "steps": main_preroll_steps, "settled_within_1pct": main_settled,
-                                           "rule": "groups of 8 event-timed steps until the last 8 lie within 1 % of each other and their mean within 0.3 % of the mean 128 steps earlier (at most 10 x min_ms; N > 1: always 10 x min_ms, so that the ranks meet the barrier together)"}},
+                                           "rule": "groups of 8 event-timed steps until the last 8 lie within 1 % of each other and their mean within 0.3 % of the mean 128 steps earlier (at least min_ms, at most 2 x min_ms; N > 1: always 2 x min_ms, so that the ranks meet the barrier together)"}},
             # every launch of the step that ran before the timed region: the preconditioning steps + the W declared warm-up steps
             "warmup_effective": main_preroll_steps + args.warmup,
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
