@@ -334,8 +334,8 @@ void launch_interior(const StftJob &job, const FastTarget &tg, const float *x, i
   a.hwin = t.fast_window;
   a.w_m = t.fast_w_m;
   a.w_n = t.fast_w_n;
-  const int lanes = c.fft_size == kN16 ? 16 : c.fft_size == kN8 ? 8 : 0;   // the power spectrogram at fft 1024 / 512 (launch_stft_fast admits nothing else of these sizes)
-  const int64_t ft = lanes == 16 ? PL<16>::FT : lanes == 8 ? PL<8>::FT : kFT, bins = c.fft_size / 2 + 1;
+  const int lanes = c.fft_size == kN16 ? 16 : c.fft_size == kN8 ? 8 : c.fft_size == kN4 ? 4 : 0;   // fft 1024 / 512 / 256 (launch_stft_fast admits nothing else of these sizes)
+  const int64_t ft = lanes == 16 ? PL<16>::FT : lanes == 8 ? PL<8>::FT : lanes == 4 ? PL<4>::FT : kFT, bins = c.fft_size / 2 + 1;
   const int64_t tiles = (count + ft - 1) / ft;
   if (tiles > 0x7fffffff) throw Failure("stft: too many frame tiles for one launch");
   a.tiles_per_clip = (int)tiles;
@@ -391,11 +391,12 @@ void launch_interior(const StftJob &job, const FastTarget &tg, const float *x, i
       SMX_LAUNCH(kl, dim3((unsigned)a.blocks), dim3(512), PL<LL>::Lds, job.stream, a);
     };
     if (lanes == 16) launch_cplx_lanes(std::integral_constant<int, 16>{});
-    else launch_cplx_lanes(std::integral_constant<int, 8>{});
+    else if (lanes == 8) launch_cplx_lanes(std::integral_constant<int, 8>{});
+    else launch_cplx_lanes(std::integral_constant<int, 4>{});
     SMX_HIP_CHECK(hipGetLastError());
     return;
   }
-  if (lanes && tg.mel32) {   // fused mel at fft 1024 / 512
+  if (lanes >= 8 && tg.mel32) {   // fused mel at fft 1024 / 512
     Mel32Args m = *tg.mel32;
     m.out_offset = out_offset;
     auto launch_mel_lanes = [&](auto ll) {
@@ -430,7 +431,8 @@ void launch_interior(const StftJob &job, const FastTarget &tg, const float *x, i
       SMX_LAUNCH(kl, dim3((unsigned)a.blocks), dim3(512), PL<LL>::Lds, job.stream, a);
     };
     if (lanes == 16) launch_lanes(std::integral_constant<int, 16>{});
-    else launch_lanes(std::integral_constant<int, 8>{});
+    else if (lanes == 8) launch_lanes(std::integral_constant<int, 8>{});
+    else launch_lanes(std::integral_constant<int, 4>{});
     SMX_HIP_CHECK(hipGetLastError());
     return;
   }
@@ -524,8 +526,8 @@ void launch_border(const StftJob &job, const FastTarget &tg, int64_t pa, int64_t
 bool fast_eligible(const StftJob &job, bool power_face = false) {
   const smx_stft_config &c = *job.cfg;
   if (fast_path_disabled()) return false;
-  const bool size_ok = c.fft_size == kN || (power_face && (c.fft_size == kN16 || c.fft_size == kN8) && diag_flag("SMX_POWER16_OFF") != 1 &&
-                                              true);
+  const bool size_ok = c.fft_size == kN || (power_face && (c.fft_size == kN16 || c.fft_size == kN8 || (c.fft_size == kN4 && diag_flag("SMX_FFT256_OFF") != 1)) &&
+                                              diag_flag("SMX_POWER16_OFF") != 1);
   if (!size_ok || job.in_bytes != 4 || job.interior != SMX_INTERIOR_F32) return false;
   if (diag_flag("SMX_GENERIC_2048") == 1) return false;   // diagnostic: time the stage-free generic kernels at fft 2048
   if (job.lead > 65535) return false;
@@ -559,7 +561,7 @@ void launch_ranges(const StftJob &job, const FastTarget &tg) {
   // (profiles/r07/timeline_before.log).  SMX_BORDER_INLINE=0: the epilogue / strips as before (same values: tested).
   // (the complex spectrogram and the fused mel kernel at fft 2048 the same way: no gather launches before them)
   // (and the fft 1024 / 512 kernels of stft_fast_p16.hpp: load_frameL_padded)
-  if ((c.fft_size == kN || c.fft_size == kN16 || c.fft_size == kN8) && (i0 - p0) + (p1 - i1) > 0 && job.n >= c.fft_size &&
+  if ((c.fft_size == kN || c.fft_size == kN16 || c.fft_size == kN8 || c.fft_size == kN4) && (i0 - p0) + (p1 - i1) > 0 && job.n >= c.fft_size &&
       job.n < (int64_t(1) << 30) && env_flag("SMX_BORDER_INLINE") != 0) {
     FastTarget folded = tg;
     folded.inline_border = true;

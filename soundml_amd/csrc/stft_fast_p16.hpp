@@ -19,14 +19,18 @@
 // LDS (LL = 16): 2 x 71,808 (tiles of 544 rows x 33) + 4,096 (window) + 3,968 (W_M^(l k1)) + 2,048 (post-pass twiddles);
 // (LL = 8): 2 x 74,880 (288 rows x 65) + half the tables.  The counters sit in the pad column.
 
-constexpr int kN16 = 1024, kN8 = 512;
+constexpr int kN16 = 1024, kN8 = 512, kN4 = 256;
 template <int LL>
 struct PL {
   static constexpr int N = 64 * LL, M = 32 * LL, Bins = M + 1;
   static constexpr int FT = 8 * (64 / LL);               // frames per tile
   static constexpr int TS = FT + 1;                      // floats per tile row
   static constexpr int CP = LL + 1;                      // rows between cells c and c + 1 of a lane
-  static constexpr int Rows = ((LL - 1 + CP * 31 + 1 + 15) / 16) * 16;
+  // LL = 4 (fft 256, round 5): the transposition runs in two passes of 16 cells (registers 0..15, then 16..31 through the same
+  // cells: a wave's LDS accesses complete in order), so that the cells stay inside the tile's 129 rows -- with 32 cells of pitch
+  // 5 a buffer would be 160 rows x 129 floats and two of them more than the CU's LDS.
+  static constexpr int CellsPerPass = LL == 4 ? 16 : 32;
+  static constexpr int Rows = LL == 4 ? 132 : ((LL - 1 + CP * 31 + 1 + 15) / 16) * 16;
   static constexpr int TileFloats = Rows * TS;
   static constexpr size_t TileBytes = (size_t)TileFloats * sizeof(float);
   static constexpr size_t WinBytes = 16 * LL * sizeof(float4);
@@ -35,9 +39,9 @@ struct PL {
   static constexpr size_t Lds = 2 * TileBytes + WinBytes + TwABytes + TwPBytes;
   static constexpr int CellPitch = CP * TS;              // floats between cells c and c + CP
   static constexpr int RowPitch = LL * TS;               // floats between rows r and r + LL
-  static constexpr int CounterRow = M + 16;
+  static constexpr int CounterRow = LL == 4 ? 0 : M + 16;   // (the pad column of four rows)
   static_assert(Lds <= 160 * 1024, "LDS budget");
-  static_assert(Rows > M + 19, "counter rows");
+  static_assert(Rows > CounterRow + 3 && Rows >= Bins && Rows > LL - 1 + CP * (CellsPerPass == 32 ? 31 : 16), "counter rows, cells");
 };
 template <int LL>
 struct LdsL {
@@ -69,6 +73,7 @@ __device__ __forceinline__ LdsL<LL> carve_ldsL(unsigned char *smem) {
 template <int LL>
 __device__ __forceinline__ int columnL(int wave, int lane) {
   const int h = lane >> 5, r = (lane & 31) / LL;
+  if constexpr (LL == 4) return 4 * r + (wave & 3) + 32 * (2 * h + (wave >> 2));   // (8 frames a half, 4 columns apart)
   return wave + 8 * (LL == 16 ? h + 2 * r : r + 4 * h);
 }
 
@@ -154,7 +159,7 @@ __device__ __forceinline__ void frameL_to_tile(const FastArgs &a, const LaneL &L
     mid.before_cells();
     float *const wr = tile + opaque32(L.own);
     float *const wr_hi = wr + 16 * P::CellPitch;
-    auto put = [&](int j) { (j < 16 ? wr : wr_hi)[P::CellPitch * (j & 15)] = v[j].x; };
+    auto put = [&](int j) { if (LL != 4 || j < 16) (j < 16 ? wr : wr_hi)[P::CellPitch * (j & 15)] = v[j].x; };   // (LL = 4: registers 16..31 in the second pass)
 #define SMX_TWV(m) f2{tw[m].x, tw[m].y}, f2{tw[m].z, tw[m].w}
     put(0);
     pk_twiddle8(v[1], v[2], v[3], v[4], v[5], v[6], v[7], v[8], SMX_TWV(0), SMX_TWV(1), SMX_TWV(2), SMX_TWV(3));
@@ -179,12 +184,29 @@ __device__ __forceinline__ void frameL_to_tile(const FastArgs &a, const LaneL &L
   float *const wr_hi = wr + 16 * P::CellPitch;   // (ds offsets are 16 bits)
   const float *const rd = tile + opaque32(L.rd);
   // X: lane lam takes V[i][lam + LL a], i < LL, a < 32 / LL: cell i + CP (lam + LL a); t[LL a + i]
+  if constexpr (LL == 4) {   // two passes of 16 cells: k1 = lam + 4 a < 16 (a < 4) is register j = k1 of lane i, k1 >= 16 its register 16 + ...
 #pragma unroll
-  for (int i = 0; i < 32; ++i) t[i].x = rd[P::TS * (i % LL) + LL * P::CellPitch * (i / LL)];
+    for (int i = 0; i < 16; ++i) t[i].x = rd[P::TS * (i % 4) + 4 * P::CellPitch * (i / 4)];
 #pragma unroll
-  for (int j = 0; j < 32; ++j) (j < 16 ? wr : wr_hi)[P::CellPitch * (j & 15)] = v[j].y;
+    for (int j = 16; j < 32; ++j) wr[P::CellPitch * (j - 16)] = v[j].x;
 #pragma unroll
-  for (int i = 0; i < 32; ++i) t[i].y = rd[P::TS * (i % LL) + LL * P::CellPitch * (i / LL)];
+    for (int i = 16; i < 32; ++i) t[i].x = rd[P::TS * (i % 4) + 4 * P::CellPitch * (i / 4 - 4)];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) wr[P::CellPitch * j] = v[j].y;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) t[i].y = rd[P::TS * (i % 4) + 4 * P::CellPitch * (i / 4)];
+#pragma unroll
+    for (int j = 16; j < 32; ++j) wr[P::CellPitch * (j - 16)] = v[j].y;
+#pragma unroll
+    for (int i = 16; i < 32; ++i) t[i].y = rd[P::TS * (i % 4) + 4 * P::CellPitch * (i / 4 - 4)];
+  } else {
+#pragma unroll
+    for (int i = 0; i < 32; ++i) t[i].x = rd[P::TS * (i % LL) + LL * P::CellPitch * (i / LL)];
+#pragma unroll
+    for (int j = 0; j < 32; ++j) (j < 16 ? wr : wr_hi)[P::CellPitch * (j & 15)] = v[j].y;
+#pragma unroll
+    for (int i = 0; i < 32; ++i) t[i].y = rd[P::TS * (i % LL) + LL * P::CellPitch * (i / LL)];
+  }
   SMX_FENCE();
   mid.after_transposition_issue();
   SMX_FENCE();
@@ -197,6 +219,18 @@ __device__ __forceinline__ void frameL_to_tile(const FastArgs &a, const LaneL &L
     pk_fft16(o);
 #pragma unroll
     for (int q = 0; q < 16; ++q) { t[2 * q] = e[q]; t[2 * q + 1] = o[q]; }
+  } else if constexpr (LL == 4) {   // eight 4-point transforms: t[4 a + i] -> register a + 8 q
+    f2 g[8][4];
+#pragma unroll
+    for (int aa = 0; aa < 8; ++aa)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) g[aa][i] = t[4 * aa + i];
+#pragma unroll
+    for (int aa = 0; aa < 8; aa += 2) pk_fft4x2(g[aa], g[aa + 1]);
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+      for (int aa = 0; aa < 8; ++aa) t[aa + 8 * q] = g[aa][q];
   } else {
     f2 g[4][8];
 #pragma unroll
@@ -321,12 +355,17 @@ __device__ __forceinline__ void load_frameL_padded(const FastArgs &a, const floa
 // A wave's share of a finished tile: 8 parts of (LL = 16: 8 rows; LL = 8: 4 rows of one 32-frame half of the tile per lane
 // half) x 4 frames per lane -> out[clip][bin][f0 + cb + 4 g ..]; 8 lanes store one 128-byte run.  Rows r' (r' < 4) and
 // frame groups g < 8 per 32-lane half keep the LDS reads conflict free.
+// (LL = 4: FT = 128, a part is 4 rows x 64 frames, parts 2 i / 2 i + 1 are the two 64-frame halves of rows 32 i + 4 wave ...)
 struct FlushL {
   int src0;         // float offset in the tile of part 0: row0 * TS + cb + 4 g
   unsigned goff0;   // byte offset of out[row0][cb + 4 g] from the tile's origin
-  int f0;           // cb + 4 g: the lane's first frame
+  int f0;           // cb + 4 g: the lane's first frame (LL = 4: of the even parts; the odd ones 64 further)
+  int nyq_f0;       // the lane's first frame of the Nyquist row
   bool nyq;         // this lane stores 4 frames of the Nyquist row
 };
+template <int LL> __device__ __forceinline__ constexpr int flush_rw() { return LL == 16 ? 8 : 4; }                  // rows per wave and part
+template <int LL> __device__ __forceinline__ constexpr int flush_part_row(int it) { return LL == 4 ? 32 * (it >> 1) : 8 * flush_rw<LL>() * it; }
+template <int LL> __device__ __forceinline__ constexpr int flush_part_col(int it) { return LL == 4 ? 64 * (it & 1) : 0; }
 struct FlushRegsL {
   float v[8][4];
   float nyq[4];
@@ -334,37 +373,35 @@ struct FlushRegsL {
 template <int LL>
 __device__ __forceinline__ FlushL setup_flushL(const FastArgs &a, int lane, int wave) {
   using P = PL<LL>;
-  constexpr int RW = LL == 16 ? 8 : 4;                       // rows per wave and part
+  constexpr int RW = flush_rw<LL>();
   FlushL fl;
   const int g = lane & 7, cb = LL == 16 ? 0 : 32 * (lane >> 5);
   const int row0 = RW * wave + ((lane >> 3) & (RW - 1));
   fl.f0 = cb + 4 * g;
   fl.src0 = row0 * P::TS + fl.f0;
   fl.goff0 = ((unsigned)row0 * (unsigned)a.out_stride + (unsigned)fl.f0) * 4u;
-  fl.nyq = wave == 0 && (lane & 31) < 8 && (LL == 8 || lane < 32);
+  fl.nyq = (LL == 4 ? wave < 2 : wave == 0) && (lane & 31) < 8 && (LL != 16 || lane < 32);
+  fl.nyq_f0 = fl.f0 + (LL == 4 ? 64 * (wave & 1) : 0);
   return fl;
 }
 template <int LL>
 __device__ __forceinline__ void flushL_read(const float *tile, const FlushL &fl, FlushRegsL &r) {
   using P = PL<LL>;
-  constexpr int RW = LL == 16 ? 8 : 4;
   const float *src0 = tile + opaque32(fl.src0);
 #pragma unroll
   for (int it = 0; it < 8; ++it) {
-    const float *src = src0 + 8 * RW * it * P::TS;
+    const float *src = src0 + flush_part_row<LL>(it) * P::TS + flush_part_col<LL>(it);
     r.v[it][0] = src[0]; r.v[it][1] = src[1]; r.v[it][2] = src[2]; r.v[it][3] = src[3];
   }
-  const float *ny = tile + P::M * P::TS + opaque32(fl.f0);   // the Nyquist row (every lane reads, FT / 4 lanes of wave 0 store)
+  const float *ny = tile + P::M * P::TS + opaque32(fl.nyq_f0);   // the Nyquist row (every lane reads, FT / 4 lanes of wave 0 (LL = 4: waves 0, 1) store)
   r.nyq[0] = ny[0]; r.nyq[1] = ny[1]; r.nyq[2] = ny[2]; r.nyq[3] = ny[3];
 }
 template <int LL>
 __device__ __forceinline__ void flushL_store(const FastArgs &a, const FlushL &fl, float *obase, int frames_left, const FlushRegsL &r) {
   using P = PL<LL>;
-  constexpr int RW = LL == 16 ? 8 : 4;
   const unsigned pitch = (unsigned)a.out_stride * 4u;
   const unsigned goff0 = opaque32(fl.goff0);
-  const int fleft = frames_left - fl.f0;
-  auto put = [&](unsigned goff, const float (&v)[4]) {
+  auto put = [&](unsigned goff, const float (&v)[4], int fleft) {
     if (fleft >= 4) {
       store4_unaligned(obase, goff, v[0], v[1], v[2], v[3]);
     } else {
@@ -377,12 +414,13 @@ __device__ __forceinline__ void flushL_store(const FastArgs &a, const FlushL &fl
   if (frames_left >= P::FT) {   // wave-uniform: a whole tile, no masks
 #pragma unroll
     for (int it = 0; it < 8; ++it)
-      store4_unaligned(obase, goff0 + (unsigned)(8 * RW * it) * pitch, r.v[it][0], r.v[it][1], r.v[it][2], r.v[it][3]);
+      store4_unaligned(obase, goff0 + (unsigned)flush_part_row<LL>(it) * pitch + 4u * (unsigned)flush_part_col<LL>(it), r.v[it][0], r.v[it][1], r.v[it][2], r.v[it][3]);
   } else {
 #pragma unroll
-    for (int it = 0; it < 8; ++it) put(goff0 + (unsigned)(8 * RW * it) * pitch, r.v[it]);
+    for (int it = 0; it < 8; ++it)
+      put(goff0 + (unsigned)flush_part_row<LL>(it) * pitch + 4u * (unsigned)flush_part_col<LL>(it), r.v[it], frames_left - fl.f0 - flush_part_col<LL>(it));
   }
-  if (fl.nyq) put((unsigned)P::M * pitch + 4u * (unsigned)fl.f0, r.nyq);
+  if (fl.nyq) put((unsigned)P::M * pitch + 4u * (unsigned)fl.nyq_f0, r.nyq, frames_left - fl.nyq_f0);
 }
 
 template <int LL, bool ALIGNED>

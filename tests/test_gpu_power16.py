@@ -1,4 +1,4 @@
-"""The power spectrogram at fft 1024 and fft 512 on the register pipeline with a frame in 16 / 8 lanes
+"""The power spectrogram at fft 1024, fft 512 and fft 256 on the register pipeline with a frame in 16 / 8 / 4 lanes
 (stft_power_lanes_kernel, stft_fast_p16.hpp): BASELINE C1's geometry (fft 1024 / hop 256), fft 512 / hop 128 and their
 neighbours against the float64 oracle, and the reference's structural
 laws bit for bit -- frame-range tiling across tile boundaries (stft_grid.ml:32-73), batch == stack of slices (:180-205),
@@ -39,15 +39,17 @@ def _check(got, want, power, msg):
     (dict(hop=256), 1, 2),
 ])
 @pytest.mark.parametrize("power", [2.0, 1.0])
-@pytest.mark.parametrize("fft", [1024, 512])
+@pytest.mark.parametrize("fft", [1024, 512, 256])
 def test_against_the_oracle(fft, kw, n, lead, power):
     rng = np.random.default_rng(n + int(power))
     kw = dict(kw)
-    if fft == 512:                                          # the same shapes at half the size
+    for _ in range({1024: 0, 512: 1, 256: 2}[fft]):         # the same shapes at half / a quarter of the size
         kw["hop"] = max(1, kw["hop"] // 2) if kw["hop"] % 2 == 0 else kw["hop"] // 2 | 1
         if "win_length" in kw:
             kw["win_length"] //= 2
         n = n if n < 1000 else n // 2
+    if fft == 256 and n >= 1000:
+        n *= 2                                              # (128 frames a tile: keep several tiles per clip)
     x = rng.uniform(-1, 1, size=(lead, n)).astype(np.float32)
     c = Stft.Config.create(fft_size=fft, **kw)
     okw = dict(kw)
@@ -75,14 +77,14 @@ def test_regression_gate_on_a_c1_batch():
         assert np.max(np.abs(got[i] - want)) <= 2 * REGRESSION * float(np.max(want)), i
 
 
-@pytest.mark.parametrize("fft", [1024, 512])
+@pytest.mark.parametrize("fft", [1024, 512, 256])
 def test_ranges_tile_exactly_across_tile_boundaries(fft):
     import torch
     x = torch.rand(3, 70000, device="cuda") * 2 - 1
     c = Stft.Config.create(fft_size=fft, hop=fft // 4)
     full = Stft.power_spectrum(c, x)
     total = Stft.frames(c, x.shape[-1])
-    cuts = [0, 1, 2, 31, 32, 33, 63, 64, 65, 100, total - 65, total - 33, total - 2, total]
+    cuts = sorted({v for v in (0, 1, 2, 31, 32, 33, 63, 64, 65, 100, 127, 128, 129, 255, 256, 257, total - 129, total - 65, total - 33, total - 2, total) if 0 <= v <= total})
     parts = [Stft.power_range(c, x, a, b) for a, b in zip(cuts[:-1], cuts[1:])]
     assert torch.equal(torch.cat(parts, dim=-1), full)
     assert np.array_equal(full.cpu().numpy(), Stft.power_spectrum(c, x.cpu().numpy()))      # device path == host path
@@ -91,7 +93,7 @@ def test_ranges_tile_exactly_across_tile_boundaries(fft):
         assert torch.equal(torch.cat([Stft.power_range(c, x, a, b, power) for a, b in zip(cuts[:-1], cuts[1:])], dim=-1), f)
 
 
-@pytest.mark.parametrize("fft", [1024, 512])
+@pytest.mark.parametrize("fft", [1024, 512, 256])
 def test_batch_is_the_stack_of_its_slices(fft):
     rng = np.random.default_rng(3)
     x = rng.uniform(-1, 1, size=(2, 3, 4 * 1024 + 5)).astype(np.float32)
@@ -103,7 +105,7 @@ def test_batch_is_the_stack_of_its_slices(fft):
                 assert np.array_equal(full[i, j], Stft.power_spectrum(c, x[i, j]))
 
 
-@pytest.mark.parametrize("fft", [1024, 512])
+@pytest.mark.parametrize("fft", [1024, 512, 256])
 def test_many_short_clips_take_the_strip_path_and_agree(fft):
     """8000 clips of 8 frames each, 4 touching a border -- above the launcher's epilogue threshold, so the kernel reads the
     border frames from gathered strips; the same clips in a batch of 50 take the epilogue: identical frame code."""
@@ -122,7 +124,7 @@ def test_many_short_clips_take_the_strip_path_and_agree(fft):
 
 
 @pytest.mark.parametrize("alignment,pad", [("centered", "reflect"), ("left", "edge"), ("right", ("constant", 0.5))])
-@pytest.mark.parametrize("fft", [1024, 512])
+@pytest.mark.parametrize("fft", [1024, 512, 256])
 def test_power_stage_streams_the_offline_result(fft, alignment, pad):
     rng = np.random.default_rng(5)
     n = 40 * 1024 + 333
@@ -142,7 +144,7 @@ def test_power_stage_streams_the_offline_result(fft, alignment, pad):
 
 
 @pytest.mark.parametrize("power", [0.5, 3.0, 0.0])
-@pytest.mark.parametrize("fft", [1024, 512])
+@pytest.mark.parametrize("fft", [1024, 512, 256])
 def test_general_powers(fft, power):
     rng = np.random.default_rng(int(power * 10) + 3)
     x = rng.uniform(-1, 1, size=(2, 20000)).astype(np.float32)
@@ -207,7 +209,7 @@ def _check_c(got, want, msg):
     assert np.all(np.abs(got - want) <= 1e-5 * peak + 1e-5 * np.abs(want)), (msg, float(np.max(np.abs(got - want))), peak)
 
 
-@pytest.mark.parametrize("fft", [2048, 1024, 512])
+@pytest.mark.parametrize("fft", [2048, 1024, 512, 256])
 @pytest.mark.parametrize("kw,n,lead", [
     (dict(), 60000, 2),
     (dict(hop_odd=True), 30000, 2),                          # odd hop: the unaligned load variant
@@ -233,16 +235,16 @@ def test_transform_against_the_oracle(fft, kw, n, lead):
     assert np.all(got[..., 0, :].imag == 0) and np.all(got[..., -1, :].imag == 0)            # DC and Nyquist bins are real
 
 
-@pytest.mark.parametrize("fft", [2048, 1024, 512])
+@pytest.mark.parametrize("fft", [2048, 1024, 512, 256])
 def test_transform_ranges_streaming_and_device(fft):
     import torch
     rng = np.random.default_rng(fft)
-    n = 30 * fft + 77
+    n = (30 if fft > 256 else 80) * fft + 77
     x = rng.standard_normal((2, n)).astype(np.float32)
     c = Stft.Config.create(fft_size=fft, hop=fft // 4)
     full = Stft.transform(c, x)
     total = Stft.frames(c, n)
-    cuts = [0, 1, 15, 16, 17, 31, 32, 33, 64, 65, total - 3, total]
+    cuts = [0, 1, 15, 16, 17, 31, 32, 33, 64, 65, total - 3, total] if fft > 256 else [0, 1, 64, 127, 128, 129, 200, 256, 257, total - 3, total]
     parts = [Stft.transform_range(c, x, a, b) for a, b in zip(cuts[:-1], cuts[1:])]
     assert np.array_equal(np.concatenate(parts, axis=-1), full)                              # stft_grid.ml:32-73
     assert np.array_equal(Stft.transform(c, torch.from_numpy(x).cuda()).cpu().numpy(), full)  # device path == host path
@@ -259,10 +261,32 @@ def test_transform_ranges_streaming_and_device(fft):
 def test_transform_many_short_clips():
     import torch
     rng = np.random.default_rng(13)
-    for fft in (2048, 1024, 512):
+    for fft in (2048, 1024, 512, 256):
         x = torch.from_numpy(rng.uniform(-1, 1, size=(3000, 2 * fft - 48)).astype(np.float32)).cuda()
         c = Stft.Config.create(fft_size=fft, hop=fft // 4)
         z = Stft.transform(c, x)
         for lo in (0, 1475, 2950):
             assert torch.equal(z[lo:lo + 50], Stft.transform(c, x[lo:lo + 50])), (fft, lo)
         _check_c(z[777].cpu().numpy(), O.transform(O.stft_config(fft, hop=fft // 4), x[777].cpu().numpy()), (fft, 777))
+
+
+def test_fft_256_is_one_launch_of_the_four_lane_pipeline():
+    """fft 256 / hop 64 on a device-resident batch: one kernel launch for interior and border frames alike (the border frames ride
+    in the tile sequence), every value within the regression gate of the float64 oracle."""
+    import torch
+    from soundml_amd._lib import lib
+    rng = np.random.default_rng(256)
+    x = rng.uniform(-1, 1, size=(6, 100000)).astype(np.float32)
+    xd = torch.from_numpy(x).cuda()
+    c = Stft.Config.create(fft_size=256, hop=64)
+    Stft.power_spectrum(c, xd)
+    torch.cuda.synchronize()
+    l0 = lib.smx_debug_kernel_launches()
+    got = Stft.power_spectrum(c, xd)
+    torch.cuda.synchronize()
+    assert lib.smx_debug_kernel_launches() - l0 == 1
+    assert tuple(got.shape) == (6, 129, 1563)
+    o = O.stft_config(256, hop=64)
+    for i in (0, 5):
+        want = O.power_spectrum(o, x[i])
+        assert np.max(np.abs(got[i].cpu().numpy() - want)) <= 2 * REGRESSION * float(np.max(want)), i

@@ -85,6 +85,8 @@ class Block:
         def fix(line):
             return re.sub(r"%(\d+)", lambda m: "%%%d" % (remap[int(m.group(1))] if int(m.group(1)) < len(self.slots) else int(m.group(1))), line)
         body = "\n".join('%s    "%s\\n\\t"' % (indent, fix(l)) for l in self.ins)
+        if not ins:
+            return "%sasm(\n%s\n%s    : %s);\n" % (indent, body, indent, ", ".join(outs))
         return "%sasm(\n%s\n%s    : %s\n%s    : %s);\n" % (indent, body, indent, ", ".join(outs), indent, ", ".join(ins))
 
 
@@ -186,6 +188,22 @@ def gen_fft8():
     lines.append(b.text().rstrip("\n"))
     for i in range(8):
         lines.append("  v[%d] = s%d;" % (i, out[i]))
+    lines.append("}")
+    return "\n".join(lines)
+
+
+def gen_fft4x2():
+    """Two 4-point transforms in one statement (the radix-4 stage of the 4-lane pipeline at fft 256, stft_fast_p16.hpp): p32_fft4's operations"""
+    b = Block("pk_fft4x2")
+    L = {i: b.slot("io", "s%d" % i) for i in range(8)}
+    free = [b.slot("tmp", "s%d" % (8 + i)) for i in range(4)]
+    fft4_pair(b, L, free, [(0, 1, 2, 3, False), (4, 5, 6, 7, False)])
+    lines = ["// two 4-point forward DFTs (u and v), natural order in and out: p32_fft4's operations on packed pairs, one statement",
+             "__device__ __forceinline__ void pk_fft4x2(f2 (&u)[4], f2 (&v)[4]) {",
+             "  f2 " + ", ".join("s%d = %s[%d]" % (i, "uv"[i // 4], i % 4) for i in range(8)) + ", s8, s9, s10, s11;"]
+    lines.append(b.text().rstrip("\n"))
+    for i in range(8):
+        lines.append("  %s[%d] = s%d;" % ("uv"[i // 4], i % 4, L[i]))
     lines.append("}")
     return "\n".join(lines)
 
@@ -312,6 +330,7 @@ if __name__ == "__main__":
     print("// Included by stft_fast_p32.hpp (inside namespace smx::<anon>); f2 = float ext_vector_type(2), an aligned register pair.")
     print(gen_fft16())
     print(gen_fft8())
+    print(gen_fft4x2())
     print(gen_combine(0))
     print(gen_combine(1))
     for n in (8, 7):
