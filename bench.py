@@ -492,7 +492,20 @@ def main():
                                  "launches_per_step": nl,
                                  "roofline": {"bound": "hbm", "achieved": round(256 * f1 * b1 / a / 1e6, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                               "frac": round(256 * f1 * b1 / a / 1e6 / HBM_PEAK_GBS, 4), "algorithmic_bytes_per_frame": b1}}
-            del x1, o1
+            # the same batch at fft 256 / hop 64: the 4-lane form (round 5; the Stockham kernel before it took 0.93 ms)
+            c256 = Stft.Config.create(fft_size=256, hop=64)
+            f256 = Stft.frames(c256, n1)
+            o256 = torch.empty(256, 129, f256, device=dev, dtype=torch.float32)
+            _, ms, nl = timed(lambda: check(lib.smx_stft_power_range_f32_dev(c256._h, vp(x1.data_ptr()), 256, n1, n1, 0, f256, 2.0,
+                                                                             vp(o256.data_ptr()), sptr)), k, w)
+            a = sum(ms) / len(ms)
+            b256 = 64 * 4 + 129 * 4
+            extra["fft256_batch"] = {"workload": "256 clips x 441000 samples, fft 256 / hop 64 (%d frames)" % (256 * f256),
+                                     "value": round(256 * f256 / a / 1e3, 1), "unit": "Mframes/s", "ms": round(a, 4), "ms_min": round(ms[0], 4),
+                                     "launches_per_step": nl,
+                                     "roofline": {"bound": "hbm", "achieved": round(256 * f256 * b256 / a / 1e6, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                                  "frac": round(256 * f256 * b256 / a / 1e6 / HBM_PEAK_GBS, 4), "algorithmic_bytes_per_frame": b256}}
+            del x1, o1, o256
             # Stft.transform of the C2 batch (complex64 out: 10 248 algorithmic bytes per frame)
             zc = torch.empty(clips, BINS, frames, 2, device=dev, dtype=torch.float32)
             _, ms, nl = timed(lambda: check(lib.smx_stft_transform_range_f32_dev(cfg._h, vp(x.data_ptr()), clips, n, n, 0, frames,

@@ -3,6 +3,7 @@
 //   stft2048_complex32_kernel  X                   Stft.transform / _range      stft.ml:632-666   (the same)
 //   stft2048_mel32_kernel      W |X|^p (MFMA)      Soundml.mel_spectrogram      soundml.ml:12-24  (stft_fast_mel32.hpp: the filterbank product over the pipeline's tiles)
 //   stft_power_lanes_kernel / stft_complex_lanes_kernel / stft_mel_lanes_kernel<16 | 8>    the same at fft 1024 / 512 (stft_fast_p16.hpp)
+//   stft_power_lanes_kernel / stft_complex_lanes_kernel<4>                                  ... and at fft 256 (a frame in 4 lanes, 128-frame tiles)
 // They replace, for float32 audio, the reference's hot call
 //   Nx.stft cdtype ~window:fft ~step:hop ~win (to_double samples)   stft.ml:356-364
 // Each audio sample is read from HBM once (hop-strided overlapping frames are re-read through L1 / L2) and the [bins; frames]
@@ -232,7 +233,7 @@ __device__ __forceinline__ void lds_wait(unsigned *c, unsigned target) {
 
 #include "stft_fast_p32.hpp"   // the 32-lane frame pipeline: stft2048_power32_kernel
 #include "stft_fast_mel32.hpp" // the fused audio -> mel kernel on the 32-lane pipeline: stft2048_mel32_kernel
-#include "stft_fast_p16.hpp"   // the same pipeline with a frame in 16 / 8 lanes: stft_power_lanes_kernel (power spectrogram at fft 1024 / 512)
+#include "stft_fast_p16.hpp"   // the same pipeline with a frame in 16 / 8 / 4 lanes: stft_power_lanes_kernel (power spectrogram at fft 1024 / 512 / 256)
 #ifdef SMX_ISA_ONE   // tools/isa_one.py: ONE instantiation of a register-pipeline kernel (registers / scratch / instruction mix in seconds, no GPU)
 #ifndef SMX_ISA_KERNEL
 #define SMX_ISA_KERNEL 0
@@ -383,7 +384,7 @@ void launch_interior(const StftJob &job, const FastTarget &tg, const float *x, i
   const bool aligned = (c.hop % 2 == 0) && (left % 2 == 0) && (x_stride % 2 == 0) &&
                        (reinterpret_cast<uintptr_t>(x) % 8 == 0);
   const bool square = a.pmode == 2;
-  if (lanes && tg.complex_out) {   // Stft.transform at fft 1024 / 512
+  if (lanes && tg.complex_out) {   // Stft.transform at fft 1024 / 512 / 256
     auto launch_cplx_lanes = [&](auto ll) {
       constexpr int LL = decltype(ll)::value;
       auto kl = aligned ? stft_complex_lanes_kernel<LL, true> : stft_complex_lanes_kernel<LL, false>;
@@ -560,7 +561,7 @@ void launch_ranges(const StftJob &job, const FastTarget &tg) {
   // The epilogue below ran 4 tile times deep on a quarter of the workgroups at C2: 30 of the launch's 495 us
   // (profiles/r07/timeline_before.log).  SMX_BORDER_INLINE=0: the epilogue / strips as before (same values: tested).
   // (the complex spectrogram and the fused mel kernel at fft 2048 the same way: no gather launches before them)
-  // (and the fft 1024 / 512 kernels of stft_fast_p16.hpp: load_frameL_padded)
+  // (and the fft 1024 / 512 / 256 kernels of stft_fast_p16.hpp: load_frameL_padded)
   if ((c.fft_size == kN || c.fft_size == kN16 || c.fft_size == kN8 || c.fft_size == kN4) && (i0 - p0) + (p1 - i1) > 0 && job.n >= c.fft_size &&
       job.n < (int64_t(1) << 30) && env_flag("SMX_BORDER_INLINE") != 0) {
     FastTarget folded = tg;

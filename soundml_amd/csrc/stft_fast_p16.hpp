@@ -1,4 +1,4 @@
-// stft_power_lanes_kernel<LL> -- the power spectrogram at fft 1024 (LL = 16) and fft 512 (LL = 8) on the register frame pipeline
+// stft_power_lanes_kernel<LL> -- the power spectrogram at fft 1024 (LL = 16), fft 512 (LL = 8) and fft 256 (LL = 4) on the register frame pipeline
 // of stft_fast_p32.hpp with a frame in LL lanes (included by stft_fast.hip after stft_fast_p32.hpp, inside its anonymous
 // namespace).  Replaces the reference's hot call for Stft.power_spectrum at BASELINE C1's geometry (fft 1024 / hop 256) and
 // at fft 512, stft.ml:356-364 + 670-691.
@@ -17,7 +17,8 @@
 // 32-lane kernel's with the second radix-32 replaced by radix-LL transforms; every function rounds operation by operation
 // (contraction off), so a frame gets the same bits wherever it sits.
 // LDS (LL = 16): 2 x 71,808 (tiles of 544 rows x 33) + 4,096 (window) + 3,968 (W_M^(l k1)) + 2,048 (post-pass twiddles);
-// (LL = 8): 2 x 74,880 (288 rows x 65) + half the tables.  The counters sit in the pad column.
+// (LL = 8): 2 x 74,880 (288 rows x 65) + half the tables; (LL = 4): 2 x 68,112 (132 rows x 129: the transposition in two passes of 16
+// cells, see PL) + a quarter of the tables.  The counters sit in the pad column.
 
 constexpr int kN16 = 1024, kN8 = 512, kN4 = 256;
 template <int LL>

@@ -28,10 +28,11 @@ json.dump({"bytes_per_launch": read_b + write_b, "read_bytes": read_b, "write_by
            "box": "one MI355X gpurun box (fresh lease; boxes differ by +-10 % in kernel time)",
            "per_kernel": None}, open(os.path.join(ROOT, "profiles", "hbm_traffic.json"), "w"), indent=1)
 # every hot kernel: counter traffic against its algorithmic bytes (the launches of tools/pmc_driver.py)
-FR2048, FR1K, FR512 = 938, 1723, 3446
+FR2048, FR1K, FR512, FR256 = 938, 1723, 3446, 6891
 ALGO = {"stft2048_power32": 256 * FR2048 * 6148, "stft2048_complex32": 256 * FR2048 * (2048 + 8200), "stft2048_mel32": 256 * FR2048 * (2048 + 512),
         "istft2048": 256 * FR2048 * (8200 + 2048), "mel_apply_mfma": 256 * FR2048 * (4100 + 512), "fir_ols_split": 8 * 2880000 * 8,
         "stft_power_lanes_kernel<16": 256 * FR1K * (1024 + 2052), "stft_power_lanes_kernel<8": 256 * FR512 * (512 + 1028),
+        "stft_power_lanes_kernel<4": 256 * FR256 * (256 + 516),
         "wide64::stft2048_power_wide": 256 * FR2048 * 6148}
 table = {}
 for name, v in k.items():
@@ -55,7 +56,7 @@ if os.path.exists(bench_path):
     ex = line.get("extra", {})
     pairs = {"stft2048_power32": line["roofline"].get("kernel_ms_avg"), "stft2048_complex32": ex.get("c2_complex", {}).get("ms"),
              "istft2048": ex.get("c2_invert", {}).get("ms"), "stft2048_mel32": ex.get("c3_mel", {}).get("ms"),
-             "stft_power_lanes_kernel<16": ex.get("c1_batch", {}).get("ms"), "fir_ols_split": ex.get("c4_fir", {}).get("ms"),
+             "stft_power_lanes_kernel<16": ex.get("c1_batch", {}).get("ms"), "stft_power_lanes_kernel<4": ex.get("fft256_batch", {}).get("ms"), "fir_ols_split": ex.get("c4_fir", {}).get("ms"),
              "wide64::stft2048_power_wide": ex.get("c2_float64_interior", {}).get("ms")}
     for name, row in table.items():
         ms = next((v for key, v in pairs.items() if name.startswith(key)), None)

@@ -1,6 +1,6 @@
 """Driver for tools/profile_round.sh: REPS back-to-back launches of every hot kernel of the BASELINE configurations, one kernel
 after the other, nothing else on the device (C2 power spectrogram, C3 fused mel, Mel.apply, Stft.transform and Stft.invert of the C2 batch, the power spectrogram
-at fft 1024 and 512 on 256 clips of C1's length, C4 FIR, the C2 power spectrogram under the float64 interior)."""
+at fft 1024, 512 and 256 on 256 clips of C1's length, C4 FIR, the C2 power spectrogram under the float64 interior)."""
 import ctypes, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -19,10 +19,12 @@ h = Fir.design_lowpass(8192, 0.25, 100.0)
 plan = Fir.Plan.create(h)
 c1k = Stft.Config.create(fft_size=1024, hop=256)      # the lanes kernels at the sizes of tools/bench_extra.py
 c512 = Stft.Config.create(fft_size=512, hop=128)
-f1k, f512 = Stft.frames(c1k, 441000), Stft.frames(c512, 441000)
+c256 = Stft.Config.create(fft_size=256, hop=64)
+f1k, f512, f256 = Stft.frames(c1k, 441000), Stft.frames(c512, 441000), Stft.frames(c256, 441000)
 x1 = torch.rand(256, 441000, device="cuda") * 2 - 1
 o1k = torch.empty(256, 513, f1k, device="cuda")
 o512 = torch.empty(256, 257, f512, device="cuda")
+o256 = torch.empty(256, 129, f256, device="cuda")
 xs = torch.rand(8, 2880000, device="cuda") * 2 - 1
 ys = torch.empty_like(xs)
 # Every kernel is launched at least REPS times (default 24) and for at least SUSTAIN_MS (600 ms) in back-to-back groups of 8 before the next one starts, and the profile's durations and
@@ -48,6 +50,7 @@ each(lambda: check(lib.smx_mel_spectrogram_f32_dev(sc._h, mc._h, vp(x.data_ptr()
 each(lambda: check(lib.smx_mel_apply_f32_dev(mc._h, vp(out.data_ptr()), 256, 1025, frames, vp(mout.data_ptr()), None)))
 each(lambda: check(lib.smx_stft_power_range_f32_dev(c1k._h, vp(x1.data_ptr()), 256, 441000, 441000, 0, f1k, 2.0, vp(o1k.data_ptr()), None)))
 each(lambda: check(lib.smx_stft_power_range_f32_dev(c512._h, vp(x1.data_ptr()), 256, 441000, 441000, 0, f512, 2.0, vp(o512.data_ptr()), None)))
+each(lambda: check(lib.smx_stft_power_range_f32_dev(c256._h, vp(x1.data_ptr()), 256, 441000, 441000, 0, f256, 2.0, vp(o256.data_ptr()), None)))
 each(lambda: check(lib.smx_fir_apply_f32_dev(plan._h, vp(xs.data_ptr()), 8, 2880000, 2880000, vp(ys.data_ptr()), 2880000, None)))
 S.set_interior("float64")   # the reference's own numerics at C2: stft2048_power_wide_kernel
 each(lambda: check(lib.smx_stft_power_range_f32_dev(sc._h, vp(x.data_ptr()), 256, 480000, 480000, 0, frames, 2.0, vp(out.data_ptr()), None)))
