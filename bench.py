@@ -519,7 +519,8 @@ def main():
                                                 "algorithmic_bytes_per_frame": bc}}
             # The face an nx caller gets (stft.mli:211-250: host tensors in and out): Stft.power_spectrum on a numpy batch through the
             # host-pointer entry point -- upload, kernels and download of clip units overlapped inside the C ABI (transfer.cpp); a fresh
-            # result array per call, as nx allocates one.  PCIe roof: 63 GB/s per direction; the bytes of both directions are counted.
+            # result array per call, as nx allocates one -- since late round 5 from the library's page-locked pool (smx_host_alloc: what
+            # the OCaml binding's result tensors use too; the block goes back to the pool when the array is dropped).  PCIe roof: 63 GB/s per direction; the bytes of both directions are counted.
             import numpy as _np
             # (an ordinary numpy array, as a host caller holds: a copy made by this thread.  The array that torch's x.cpu() returns reads
             # 1.7x slower from the library's copying threads -- 44 against 26 ms for the same call, tools/host_path_in_bench.py)
@@ -529,12 +530,14 @@ def main():
                 t_h = time.perf_counter()
                 ph = Stft.power_spectrum(cfg, xh)
                 hp.append(time.perf_counter() - t_h)
+                ph_owndata = bool(ph.flags["OWNDATA"])
                 if len(hp) == 1:
                     same = bool(_np.array_equal(ph[:4], out[:4].cpu().numpy()) and _np.array_equal(ph[-3:], out[-3:].cpu().numpy()))
                 del ph     # (releasing a GB of touched pages is not the call: not timed)
             hp.sort()
             hb = clips * (n * 4 + BINS * frames * 4)
-            extra["c2_host_path"] = {"workload": "C2 through the host-pointer entry point (numpy in, fresh numpy out): Stft.power_spectrum",
+            extra["c2_host_path"] = {"workload": "C2 through the host-pointer entry point (numpy in, fresh numpy out in a block of the page-locked result pool): Stft.power_spectrum",
+                                     "result_page_locked": bool(not ph_owndata),
                                      "value": round(clips * frames / hp[2] / 1e6, 2), "unit": "Mframes/s", "ms": round(hp[2] * 1e3, 2), "ms_min": round(hp[0] * 1e3, 2),
                                      "ms_all_sorted": [round(v * 1e3, 1) for v in hp],
                                      "equals_device_resident_call": same,

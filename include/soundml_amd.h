@@ -29,6 +29,7 @@
 #ifndef SOUNDML_AMD_H
 #define SOUNDML_AMD_H
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -106,6 +107,16 @@ int smx_set_interior(int interior);    /* SMX_INTERIOR_*, process-wide default f
 int smx_set_scratch_retention(int64_t bytes);
 int smx_get_interior(void);
 int smx_synchronize(void *stream);
+/* Result arrays for the host-pointer entry points.  The reference's faces return a fresh host tensor per call (`analyse`
+ * allocates its result inside Nx.stft: stft.ml:356-364; Stft.power_spectrum: stft.ml:670-691).  Fresh pageable memory is the slow
+ * half of such a call -- every page of a 0.98 GB spectrogram faults as the copying threads reach it, and the bytes cross host
+ * memory twice (DMA into a staging ring, then memcpy).  A block from smx_host_alloc is page-locked: when the `out` (or `x`)
+ * pointer of a host-pointer entry point lies inside one, the DMA engine writes (reads) it directly.  smx_host_free returns the
+ * block to the library, which keeps up to 3 GiB of released blocks for the next result of about the same size.  A binding
+ * allocates its result tensors here (the OCaml stub wraps the block in a Bigarray whose finaliser calls smx_host_free:
+ * INTEGRATION.md section 2); a pointer from any other allocator takes the staged path, as before.  Thread-safe. */
+int smx_host_alloc(size_t bytes, void **ptr);
+int smx_host_free(void *ptr);
 
 /* ---- Window.make (window.ml:374-405), float64, Hann & friends ------------ */
 int smx_window_make(int kind, int periodic, int64_t n, double *out);

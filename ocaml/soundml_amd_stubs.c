@@ -49,6 +49,28 @@ static void smx_raise(int status) {
 static int64_t ba_dim(value v) { return (int64_t)Caml_ba_array_val(v)->dim[0]; }
 static int ba_kind(value v) { return Caml_ba_array_val(v)->flags & CAML_BA_KIND_MASK; }
 
+/* Result tensors in page-locked memory (include/soundml_amd.h, smx_host_alloc): a one-dimensional Bigarray over a block of the
+ * library's pool.  CAML_BA_EXTERNAL: the runtime does not own the data; stft_amd.ml hangs soundml_amd_host_release on the
+ * Bigarray with Gc.finalise, so the block goes back to the pool when the tensor is collected.  The host-pointer entry points
+ * recognise such a block and let the device write it directly (no staging copy, no page faults of a fresh array). */
+CAMLprim value soundml_amd_host_array(value v_kind, value v_n) {
+  CAMLparam2(v_kind, v_n);
+  const int kind = Int_val(v_kind);
+  const intnat n = Long_val(v_n);
+  const size_t elem = kind == CAML_BA_FLOAT32 ? 4 : kind == CAML_BA_FLOAT64 ? 8 : kind == CAML_BA_COMPLEX32 ? 8 : kind == CAML_BA_COMPLEX64 ? 16 : 0;
+  if (elem == 0 || n < 0) caml_invalid_argument("soundml_amd_host_array: float32 / float64 / complex32 / complex64 and a non-negative length");
+  void *block = NULL;
+  smx_raise(smx_host_alloc((size_t)n * elem, &block));
+  CAMLreturn(caml_ba_alloc_dims(kind | CAML_BA_C_LAYOUT | CAML_BA_EXTERNAL, 1, block, n));
+}
+CAMLprim value soundml_amd_host_release(value v_ba) {
+  CAMLparam1(v_ba);
+  void *block = Caml_ba_data_val(v_ba);
+  Caml_ba_array_val(v_ba)->data = NULL;   /* (a finaliser runs once; a stray second call frees nothing) */
+  if (block) (void)smx_host_free(block);
+  CAMLreturn(Val_unit);
+}
+
 /* Stft.Config.create: window table (float64, win_length points) comes from Window.make on the
  * OCaml side, so every window family of the reference is supported unchanged. */
 CAMLprim value soundml_amd_stft_config(value v_fft, value v_win_length, value v_hop, value v_alignment,

@@ -113,6 +113,34 @@ external resample_kernel_reset_c : rkernel_handle -> unit = "soundml_amd_resampl
 
 (* ---- helpers ---------------------------------------------------------------------------------------------------- *)
 
+(* Result tensors of the offline faces.  [Nx.empty] gives fresh pageable memory: every page of a large result faults while the
+   library copies into it, and the bytes cross host memory twice.  A block of the library's page-locked pool is written by the
+   device directly; it returns to the pool when the tensor is collected.  Small results stay [Nx.empty].
+   ([Nx_buffer.of_bigarray1] is the inverse of the [to_bigarray1] used below; [Nx.of_buffer] is the zero-copy view
+   soundml-io builds its decode results with, soundml_io.ml:848-849.) *)
+external host_array_c : int -> int -> ('a, 'b, Bigarray.c_layout) Bigarray.Array1.t = "soundml_amd_host_array"
+external host_release_c : ('a, 'b, Bigarray.c_layout) Bigarray.Array1.t -> unit = "soundml_amd_host_release"
+
+let pinned_result_min_bytes = 32 * 1024 * 1024
+
+(* (the stub takes the Bigarray kind as its C enumerator: CAML_BA_FLOAT32 = 0, FLOAT64 = 1, COMPLEX32 = 10, COMPLEX64 = 11) *)
+let kind_code_and_size : type a b. (a, b) Bigarray.kind -> int * int = function
+  | Bigarray.Float32 -> (0, 4)
+  | Bigarray.Float64 -> (1, 8)
+  | Bigarray.Complex32 -> (10, 8)
+  | Bigarray.Complex64 -> (11, 16)
+  | _ -> (-1, 0)
+
+let result_tensor dtype shape =
+  let n = Array.fold_left ( * ) 1 shape in
+  let kind_code, elem = kind_code_and_size (Nx_buffer.kind_of_dtype dtype) in
+  if kind_code < 0 || n * elem < pinned_result_min_bytes then Nx.empty dtype shape
+  else begin
+    let ba = host_array_c kind_code n in
+    Gc.finalise host_release_c ba ;
+    Nx.of_buffer (Nx_buffer.of_bigarray1 ba) ~shape
+  end
+
 let flat t = Nx_buffer.to_bigarray1 (Nx.to_buffer (Nx.contiguous t))
 let flat_out t = Nx_buffer.to_bigarray1 (Nx.to_buffer t) (* freshly allocated, contiguous by construction *)
 let product = Array.fold_left ( * ) 1
@@ -199,7 +227,7 @@ let handle_of_chroma (c : Chroma.Config.t) =
 let transform_range cdtype (c : Stft.Config.t) ~p0 ~p1 x =
   let batch, n = split_last x in
   let lead = product batch in
-  let out = Nx.empty cdtype (Array.append batch [|Stft.Config.bins c; p1 - p0|]) in
+  let out = result_tensor cdtype (Array.append batch [|Stft.Config.bins c; p1 - p0|]) in
   if lead > 0 && p1 > p0 then stft_range_c (handle_of_config c) (flat x) (flat_out out) lead n p0 p1 0 0. ;
   out
 
@@ -211,7 +239,7 @@ let transform cdtype (c : Stft.Config.t) x =
 let power_range ?(power = 2.) (c : Stft.Config.t) ~p0 ~p1 x =
   let batch, n = split_last x in
   let lead = product batch in
-  let out = Nx.empty (Nx.dtype x) (Array.append batch [|Stft.Config.bins c; p1 - p0|]) in
+  let out = result_tensor (Nx.dtype x) (Array.append batch [|Stft.Config.bins c; p1 - p0|]) in
   if lead > 0 && p1 > p0 then stft_range_c (handle_of_config c) (flat x) (flat_out out) lead n p0 p1 1 power ;
   out
 

@@ -66,6 +66,8 @@ SIGNATURES = {
     "smx_set_interior": (cint, [cint]),
     "smx_get_interior": (cint, []),
     "smx_synchronize": (cint, [vp]),
+    "smx_host_alloc": (cint, [C.c_size_t, C.POINTER(vp)]),
+    "smx_host_free": (cint, [vp]),
     "smx_window_make": (cint, [cint, cint, i64, vp]),
     "smx_stft_config_create": (cint, [i64, i64, i64, cint, cint, f64, cint, cint, vp, C.POINTER(vp)]),
     "smx_stft_config_destroy": (None, [vp]),
@@ -220,3 +222,49 @@ def check(status: int) -> None:
     if status == SMX_INVALID_ARGUMENT:
         raise InvalidArgument(message)
     raise Failure(message)
+
+
+# ---- result arrays of the host faces --------------------------------------------------------------------------------------
+# The reference's faces return a fresh host tensor per call (stft.ml:356-364).  Large results come from the library's pool of
+# page-locked blocks (smx_host_alloc): the DMA engine writes them directly, and a released block serves the next result --
+# fresh pageable memory costs a page fault per 4 KB and a second pass over the bytes (include/soundml_amd.h).
+PINNED_RESULT_MIN_BYTES = 32 << 20
+_pinned_results = True
+
+
+def set_pinned_results(flag: bool) -> None:
+    """False: every host result is an ordinary numpy array again (np.zeros), e.g. where page-locked memory is scarce."""
+    global _pinned_results
+    _pinned_results = bool(flag)
+
+
+class _PinnedBlock:
+    """A block of smx_host_alloc as a buffer numpy can view; released to the library's pool when the last view dies."""
+
+    def __init__(self, nbytes: int):
+        p = vp()
+        check(lib.smx_host_alloc(nbytes, C.byref(p)))
+        self._ptr = p.value
+        self.__array_interface__ = {"shape": (nbytes,), "typestr": "|u1", "data": (self._ptr, False), "version": 3}
+
+    def __del__(self):
+        ptr, self._ptr = getattr(self, "_ptr", None), None
+        if ptr:
+            try:
+                lib.smx_host_free(ptr)
+            except Exception:   # interpreter shutdown
+                pass
+
+
+def host_result(shape, dtype):
+    """A fresh host array for a result the library overwrites completely: page-locked when it is large."""
+    import numpy as np
+    dt = np.dtype(dtype)
+    nbytes = int(np.prod(shape, dtype=np.int64)) * dt.itemsize
+    if not _pinned_results or nbytes < PINNED_RESULT_MIN_BYTES:
+        return np.zeros(shape, dtype=dt)
+    try:
+        block = _PinnedBlock(nbytes)
+    except Failure:
+        return np.zeros(shape, dtype=dt)
+    return np.asarray(block).view(dt).reshape(shape)

@@ -56,9 +56,10 @@ class Batch:
             return C.c_void_p(self.data.data_ptr())
         return C.c_void_p(self.data.ctypes.data)
 
-    def empty(self, shape, complex_=False):
+    def empty(self, shape, complex_=False, overwritten=False):
         """Fresh output tensor of the caller's kind; complex outputs get the
-        matching complex dtype (stft.ml:681-685 spectrum_witness)."""
+        matching complex dtype (stft.ml:681-685 spectrum_witness).  overwritten: the library
+        writes every element (a large host result may then come from its page-locked pool)."""
         if self.device:
             if complex_:
                 dt = torch.complex64 if self.bytes == 4 else torch.complex128
@@ -69,6 +70,8 @@ class Batch:
             dt = np.complex64 if self.bytes == 4 else np.complex128
         else:
             dt = self.data.dtype
+        if overwritten:
+            return _lib.host_result(shape, dt)
         return np.zeros(shape, dtype=dt)
 
     def wrap(self, out):

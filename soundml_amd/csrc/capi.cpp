@@ -286,6 +286,18 @@ int smx_synchronize(void *stream) {
   return guarded([&] { SMX_HIP_CHECK(hipStreamSynchronize((hipStream_t)stream)); });
 }
 
+int smx_host_alloc(size_t bytes, void **ptr) {
+  return guarded([&] {
+    if (!ptr) throw Failure("smx_host_alloc: null result pointer");
+    *ptr = nullptr;
+    require_device();
+    *ptr = host_alloc(bytes);
+  });
+}
+int smx_host_free(void *ptr) {
+  return guarded([&] { host_free(ptr); });
+}
+
 // =============================== Window ======================================
 int smx_window_make(int kind, int periodic, int64_t n, double *out) {
   return guarded([&] {

@@ -226,6 +226,10 @@ namespace smx {
 // Blocking; large copies are staged through pinned buffers with the DMA and a few host threads overlapped.
 void copy_to_device(void *d_dst, const void *src, size_t bytes);
 void copy_to_host(void *dst, const void *d_src, size_t bytes);
+// page-locked result arrays (smx_host_alloc / smx_host_free): the DMA engine reads / writes them directly, no staging
+void *host_alloc(size_t bytes);
+void host_free(void *p);
+bool host_is_pinned(const void *p, size_t bytes);   // [p, p + bytes) lies inside a live block of host_alloc
 // transfer.cpp: a host call cut into units of clips whose upload, kernels and download overlap (three host threads, HIP events)
 void pipelined_host_call(const void *src, size_t in_clip_bytes, void *dst, size_t out_clip_bytes, int64_t clips, int64_t unit,
                          void *d_in, void *d_out, const std::function<void(int64_t, int64_t, hipStream_t)> &launch);

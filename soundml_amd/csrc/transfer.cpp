@@ -11,6 +11,7 @@
 #include <cstring>
 #include <exception>
 #include <functional>
+#include <map>
 #include <mutex>
 #include <thread>
 #include <vector>
@@ -119,8 +120,62 @@ void advise_huge(void *dst, size_t bytes) {
   if (hi > lo) (void)madvise(reinterpret_cast<void *>(lo), hi - lo, MADV_HUGEPAGE);
 }
 
+// ---- pinned result arrays (smx_host_alloc / smx_host_free) -------------------------------------------------------------------
+// The reference's faces return a FRESH host tensor per call (stft.ml:356-364: `analyse` allocates its result).  Fresh pageable memory
+// is the slow half of a host call: every page of a 0.98 GB spectrogram faults and is zeroed by the kernel as the copying threads reach
+// it, and the bytes cross memory twice (DMA into the staging ring, then memcpy).  A caller that takes its result array from this
+// pool instead gets page-locked memory the DMA engine writes directly -- no staging, no faults -- and a released block is kept for
+// the next result (at most kPinnedCacheMax bytes are held while unused).
+constexpr size_t kPinnedCacheMax = (size_t)3 << 30;
+struct PinnedPool {
+  std::mutex mu;
+  std::map<uintptr_t, size_t> live;                      // blocks handed out: base -> capacity
+  std::vector<std::pair<void *, size_t>> cached;         // released blocks, oldest first
+  size_t cached_bytes = 0;
+};
+PinnedPool &pinned_pool() {
+  static PinnedPool *p = new PinnedPool;   // (never destroyed: a block may outlive the HIP runtime's own teardown order)
+  return *p;
+}
+
+// Device -> page-locked host memory by the shader engines (the block is mapped into the device's address space).  Why not the DMA
+// engine: an upload and a download that both go through hipMemcpyAsync overlap in a bare two-stream test (0.49 GB up + 0.98 GB
+// down: 9.4 / 19.4 ms) but ran one after the other inside a pipelined call (12 / 25.5 ms = the sum of the two alone); with the
+// download on a copy kernel only the upload needs a DMA engine and the two directions share the link: 12.6 / 18.9 ms
+// (tools/probes/pcie_duplex_probe.hip, profiles/r07/pcie_duplex_probe.log).
+__global__ void __launch_bounds__(256) copy_to_host_kernel(uint4 *dst, const uint4 *src, size_t n16, unsigned char *dst_tail, const unsigned char *src_tail, int tail) {
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n16; i += (size_t)gridDim.x * 256) dst[i] = src[i];
+  if (blockIdx.x == 0 && (int)threadIdx.x < tail) dst_tail[threadIdx.x] = src_tail[threadIdx.x];
+}
+hipError_t copy_to_host_by_kernel(void *dst, const void *src, size_t len, hipStream_t stream) {
+  if ((reinterpret_cast<uintptr_t>(dst) | reinterpret_cast<uintptr_t>(src)) & 15) return hipMemcpyAsync(dst, src, len, hipMemcpyDeviceToHost, stream);
+  const size_t n16 = len / 16;
+  hipLaunchKernelGGL(copy_to_host_kernel, dim3(64), dim3(256), 0, stream, reinterpret_cast<uint4 *>(dst), reinterpret_cast<const uint4 *>(src), n16,
+                     reinterpret_cast<unsigned char *>(dst) + n16 * 16, reinterpret_cast<const unsigned char *>(src) + n16 * 16, (int)(len - n16 * 16));
+  return hipGetLastError();
+}
+
+// to_host: device -> host, !to_host: the reverse, with the host side page-locked: no staging, chunk by chunk so that a pipelined
+// call's hooks see the same chunk indices as the staged form
+void direct(void *dst, const void *src, size_t bytes, bool to_host, const Hooks *hooks) {
+  StreamAndEvents se;
+  const long chunks = (long)((bytes + kChunk - 1) / kChunk);
+  for (long i = 0; i < chunks; ++i) {
+    const size_t off = (size_t)i * kChunk, len = std::min(kChunk, bytes - off);
+    if (hooks && hooks->before) hooks->before(i, se.stream);
+    if (to_host) SMX_HIP_CHECK(copy_to_host_by_kernel((unsigned char *)dst + off, (const unsigned char *)src + off, len, se.stream));
+    else SMX_HIP_CHECK(hipMemcpyAsync((unsigned char *)dst + off, (const unsigned char *)src + off, len, hipMemcpyHostToDevice, se.stream));
+    if (hooks && hooks->enqueued) hooks->enqueued(i, se.stream);
+  }
+  SMX_HIP_CHECK(hipStreamSynchronize(se.stream));
+}
+
 // to_host: device -> staging by DMA, staging -> user by the workers.  !to_host: the reverse.
 void staged(void *dst, const void *src, size_t bytes, bool to_host, int workers = 0, const Hooks *hooks = nullptr) {
+  if (host_is_pinned(to_host ? dst : src, bytes)) {
+    direct(dst, src, bytes, to_host, hooks);
+    return;
+  }
   Ring &g_ring = to_host ? g_ring_down : g_ring_up;
   std::lock_guard<std::mutex> lock(g_ring.busy);
   if (!g_ring.ensure()) {   // no pinned memory to be had: the plain copy still works
@@ -216,6 +271,70 @@ void staged(void *dst, const void *src, size_t bytes, bool to_host, int workers 
 
 }  // namespace
 
+void *host_alloc(size_t bytes) {
+  if (bytes == 0) bytes = 1;
+  const size_t want = (bytes + (((size_t)2 << 20) - 1)) & ~(((size_t)2 << 20) - 1);
+  PinnedPool &pp = pinned_pool();
+  {
+    std::lock_guard<std::mutex> g(pp.mu);
+    for (size_t i = 0; i < pp.cached.size(); ++i)
+      if (pp.cached[i].second >= want && pp.cached[i].second <= want + want / 4) {   // a released block of about this size
+        void *p = pp.cached[i].first;
+        pp.live[reinterpret_cast<uintptr_t>(p)] = pp.cached[i].second;
+        pp.cached_bytes -= pp.cached[i].second;
+        pp.cached.erase(pp.cached.begin() + (long)i);
+        return p;
+      }
+  }
+  void *p = nullptr;
+  if (hipHostMalloc(&p, want, hipHostMallocPortable) != hipSuccess) {
+    (void)hipGetLastError();
+    std::vector<void *> drop;
+    {   // make room: the cache goes first
+      std::lock_guard<std::mutex> g(pp.mu);
+      for (auto &c : pp.cached) drop.push_back(c.first);
+      pp.cached.clear();
+      pp.cached_bytes = 0;
+    }
+    for (void *d : drop) (void)hipHostFree(d);
+    SMX_HIP_CHECK(hipHostMalloc(&p, want, hipHostMallocPortable));
+  }
+  std::lock_guard<std::mutex> g(pp.mu);
+  pp.live[reinterpret_cast<uintptr_t>(p)] = want;
+  return p;
+}
+
+void host_free(void *p) {
+  if (!p) return;
+  PinnedPool &pp = pinned_pool();
+  std::vector<void *> drop;
+  {
+    std::lock_guard<std::mutex> g(pp.mu);
+    auto it = pp.live.find(reinterpret_cast<uintptr_t>(p));
+    if (it == pp.live.end()) throw Failure("smx_host_free: not a block of smx_host_alloc");
+    pp.cached.emplace_back(p, it->second);
+    pp.cached_bytes += it->second;
+    pp.live.erase(it);
+    while (pp.cached_bytes > kPinnedCacheMax && !pp.cached.empty()) {
+      drop.push_back(pp.cached.front().first);
+      pp.cached_bytes -= pp.cached.front().second;
+      pp.cached.erase(pp.cached.begin());
+    }
+  }
+  for (void *d : drop) (void)hipHostFree(d);
+}
+
+bool host_is_pinned(const void *p, size_t bytes) {
+  PinnedPool &pp = pinned_pool();
+  std::lock_guard<std::mutex> g(pp.mu);
+  if (pp.live.empty()) return false;
+  const uintptr_t a = reinterpret_cast<uintptr_t>(p);
+  auto it = pp.live.upper_bound(a);
+  if (it == pp.live.begin()) return false;
+  --it;
+  return a >= it->first && a + bytes <= it->first + it->second;
+}
+
 // A host call cut into units of clips (the reference's leading axes are independent: stft.mli:214-218, so a unit's result is
 // the slice of the whole call's, bit for bit): the upload of the units ahead, the kernels of one and the download of those
 // behind run at the same time -- PCIe is full duplex, and serially a C2 power spectrogram spent 10 ms going up and 20 ms coming
@@ -229,7 +348,8 @@ void pipelined_host_call(const void *src, size_t in_clip_bytes, void *dst, size_
   int dev = 0;
   SMX_HIP_CHECK(hipGetDevice(&dev));
   const size_t in_total = (size_t)clips * in_clip_bytes, out_total = (size_t)clips * out_clip_bytes;
-  advise_huge(dst, out_total);
+  const bool dst_pinned = host_is_pinned(dst, out_total), src_pinned = host_is_pinned(src, in_total);
+  if (!dst_pinned) advise_huge(dst, out_total);
   const long in_chunks = (long)((in_total + kChunk - 1) / kChunk);
   const int64_t units = (clips + unit - 1) / unit;
   std::vector<hipEvent_t> up_ev((size_t)in_chunks, nullptr), k_ev((size_t)units, nullptr);
@@ -279,13 +399,20 @@ void pipelined_host_call(const void *src, size_t in_clip_bytes, void *dst, size_
     SMX_HIP_CHECK(hipStreamWaitEvent(s, k_ev[(size_t)u], 0));
   };
   // the copying threads of both directions together: as many as one serial transfer uses, shared by the bytes each side moves
+  // (a page-locked side needs none: the DMA engine moves it)
   const int tw = worker_count();
-  const int t_up = std::max(2, (int)((double)tw * (double)in_total / (double)(in_total + out_total) + 0.5));
-  const int t_down = std::max(2, tw - t_up);
+  // (... and the upload alone is served by six: 4, 8 and 16 threads finish it at the same 13 ms, profiles/r07/host_path_pinned_threads.log)
+  const int t_up = dst_pinned ? std::min(tw, 6) : std::max(2, (int)((double)tw * (double)in_total / (double)(in_total + out_total) + 0.5));
+  const int t_down = src_pinned ? tw : std::max(2, tw - t_up);
+  static const bool trace = env_flag("SMX_HOST_TRACE") == 1;
+  auto now = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+  const double t_start = now();
+  double t_up_done = 0, t_down_done = 0, t_launch_done = 0;
   std::thread up([&] {
     try {
       SMX_HIP_CHECK(hipSetDevice(dev));
       staged(d_in, src, in_total, false, t_up, &hu);
+      t_up_done = now() - t_start;
     } catch (...) {
       err_up = std::current_exception();
       fail();
@@ -295,6 +422,7 @@ void pipelined_host_call(const void *src, size_t in_clip_bytes, void *dst, size_
     try {
       SMX_HIP_CHECK(hipSetDevice(dev));
       staged(dst, d_out, out_total, true, t_down, &hd);
+      t_down_done = now() - t_start;
     } catch (...) {
       err_down = std::current_exception();
       fail();
@@ -310,12 +438,16 @@ void pipelined_host_call(const void *src, size_t in_clip_bytes, void *dst, size_
       SMX_HIP_CHECK(hipEventRecord(k_ev[(size_t)u], compute));
       publish(launched, (long)u + 1);
     }
+    t_launch_done = now() - t_start;
   } catch (...) {
     err_main = std::current_exception();
     fail();
   }
   up.join();
   down.join();
+  if (trace)
+    fprintf(stderr, "[smx] pipelined host call: upload done at %.2f ms (%d copying threads%s), last launch at %.2f, download done at %.2f (%d%s)\n", t_up_done, t_up,
+            src_pinned ? ", page-locked source" : "", t_launch_done, t_down_done, t_down, dst_pinned ? ", page-locked destination" : "");
   (void)hipStreamSynchronize(compute);
   cleanup();
   if (err_main) std::rethrow_exception(err_main);
@@ -334,6 +466,10 @@ void copy_to_device(void *d_dst, const void *src, size_t bytes) {
 
 void copy_to_host(void *dst, const void *d_src, size_t bytes) {
   if (bytes == 0) return;
+  if (host_is_pinned(dst, bytes)) {
+    SMX_HIP_CHECK(hipMemcpy(dst, d_src, bytes, hipMemcpyDeviceToHost));
+    return;
+  }
   advise_huge(dst, bytes);
   if (bytes < kDirect || env_flag("SMX_COPY_PLAIN") == 1) {
     SMX_HIP_CHECK(hipMemcpy(dst, d_src, bytes, hipMemcpyDeviceToHost));

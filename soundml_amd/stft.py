@@ -148,7 +148,7 @@ def _range(c: Config, x, p0, p1, power, op):
         p0, p1 = 0, total
     complex_ = power is None
     count = max(0, p1 - p0)
-    out = b.empty(lead_shape + (c.bins, count), complex_=complex_)
+    out = b.empty(lead_shape + (c.bins, count), complex_=complex_, overwritten=True)
     sfx = "f32" if b.bytes == 4 else "f64"
     if b.device:
         with b.device_guard():

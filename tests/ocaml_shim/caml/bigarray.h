@@ -7,6 +7,7 @@ enum caml_ba_kind {
   CAML_BA_FLOAT16, CAML_BA_KIND_MASK = 0xFF
 };
 enum caml_ba_layout { CAML_BA_C_LAYOUT = 0, CAML_BA_FORTRAN_LAYOUT = 0x100, CAML_BA_LAYOUT_MASK = 0x100 };
+enum caml_ba_managed { CAML_BA_EXTERNAL = 0, CAML_BA_MANAGED = 0x200, CAML_BA_MAPPED_FILE = 0x400, CAML_BA_MANAGED_MASK = 0x600 };
 struct caml_ba_array {
   void *data;
   intnat num_dims;

@@ -61,11 +61,14 @@ def test_one_fresh_config_from_four_threads(fft, hop):
             assert torch.equal(g, w), (name, i)
 
 
-def test_two_threads_on_the_host_pointer_path():
+@pytest.mark.parametrize("pinned", [False, True])
+def test_two_threads_on_the_host_pointer_path(pinned):
     """Two host threads call the host-pointer power spectrogram at once on batches large enough for the pipelined transfer
     (clip units whose upload, kernels and download overlap: transfer.cpp): the staging rings serialise the two calls per
-    direction, and each result equals the device-resident call's."""
+    direction, and each result equals the device-resident call's.  pinned: the results come from the page-locked pool (the
+    download then needs no ring), else they are ordinary arrays (both directions staged)."""
     import torch
+    S.set_pinned_results(pinned)
     rng = np.random.default_rng(5)
     c = Stft.Config.create(fft_size=2048, hop=512)
     xs = [rng.uniform(-1, 1, size=(64, 200000 + 4096 * i)).astype(np.float32) for i in range(2)]   # ~51 MB in, ~103 MB out each: above the 128 MB threshold of the pipelined path
@@ -73,6 +76,7 @@ def test_two_threads_on_the_host_pointer_path():
     for i in range(2):
         want = Stft.power_spectrum(c, torch.from_numpy(xs[i]).cuda()).cpu().numpy()
         assert np.array_equal(got[i], want), i
+    S.set_pinned_results(True)
 
 
 def test_pipelined_host_calls_equal_the_device_resident_ones():
@@ -84,6 +88,7 @@ def test_pipelined_host_calls_equal_the_device_resident_ones():
     c = Stft.Config.create(fft_size=2048, hop=512)
     x = rng.uniform(-1, 1, size=(37, 300000)).astype(np.float32)      # 44 MB in, 89 MB / 178 MB out
     xd = torch.from_numpy(x).cuda()
+    S.set_pinned_results(False)   # (ordinary result arrays: both directions through the staging rings; tests/test_gpu_pinned_results.py holds the other form)
     p = Stft.power_spectrum(c, x)
     assert np.array_equal(p, Stft.power_spectrum(c, xd).cpu().numpy())
     z = Stft.transform(c, x)
@@ -92,3 +97,4 @@ def test_pipelined_host_calls_equal_the_device_resident_ones():
     y = Stft.invert(c, z, length=x.shape[-1])
     assert np.array_equal(y, Stft.invert(c, zd, length=x.shape[-1]).cpu().numpy())
     assert np.max(np.abs(y - x)) < 2e-6
+    S.set_pinned_results(True)
