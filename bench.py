@@ -543,7 +543,10 @@ def main():
                                      "ms_all_sorted": [round(v * 1e3, 1) for v in hp],
                                      "equals_device_resident_call": same,
                                      "roofline": {"bound": "pcie", "achieved": round(hb / hp[2] / 1e9, 2), "peak": 63.0, "unit": "GB/s",
-                                                  "frac": round(hb / hp[2] / 1e9 / 63.0, 4), "bytes_up": clips * n * 4, "bytes_down": clips * BINS * frames * 4}}
+                                                  "frac": round(hb / hp[2] / 1e9 / 63.0, 4), "bytes_up": clips * n * 4, "bytes_down": clips * BINS * frames * 4,
+                                                  "note": "both directions' bytes over ONE direction's peak (the round-4 verdict's definition); the link is full duplex, so this "
+                                                          "fraction can pass 1: measured bare, these bytes take 18.9 ms with the two directions overlapped "
+                                                          "(profiles/r07/pcie_duplex_probe.log) -- that is this call's floor"}}
             assert same, "host path != device-resident call"
             del xh
             # Stft.invert of that spectrogram (stft.ml:900-939): istft2048_pipe_kernel, 8200 B in + 2048 B out per frame
