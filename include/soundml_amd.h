@@ -96,6 +96,11 @@ int smx_version(void);
 /* diagnostics: kernel launches issued by this process through the library so far (bench.py asserts that one step
  * of the hot path is one launch, so that HIP events around a step time that kernel) */
 unsigned long long smx_debug_kernel_launches(void);
+/* diagnostics (tests of Griffin-Lim's internal layout): Stft.transform of device-resident float32 audio at fft 2048 with the
+ * spectrum FRAME-MAJOR -- out[clip][frame][bin] complex64 in rows of pitch_floats floats, rows_per_clip (the frames rounded up to
+ * a multiple of 16) rows per clip; fails where the frame-major kernel does not apply */
+int smx_debug_stft_transform_frame_major_f32_dev(const smx_stft_config *c, const float *d_x, int64_t lead, int64_t n, float *d_out,
+                                                 int64_t pitch_floats, int64_t rows_per_clip, void *stream);
 int smx_device_count(int *count);
 int smx_set_device(int device);        /* device used by this thread's subsequent calls */
 int smx_set_interior(int interior);    /* SMX_INTERIOR_*, process-wide default for f32 audio */

@@ -61,6 +61,7 @@ SIGNATURES = {
     "smx_last_error": (C.c_char_p, []),
     "smx_version": (cint, []),
     "smx_debug_kernel_launches": (C.c_ulonglong, []),
+    "smx_debug_stft_transform_frame_major_f32_dev": (cint, [vp, vp, i64, i64, vp, i64, i64, vp]),
     "smx_device_count": (cint, [C.POINTER(cint)]),
     "smx_set_device": (cint, [cint]),
     "smx_set_interior": (cint, [cint]),

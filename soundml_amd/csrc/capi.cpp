@@ -286,6 +286,34 @@ int smx_synchronize(void *stream) {
   return guarded([&] { SMX_HIP_CHECK(hipStreamSynchronize((hipStream_t)stream)); });
 }
 
+// diagnostics (tests): Stft.transform of device-resident float32 audio into Griffin-Lim's internal frame-major layout
+int smx_debug_stft_transform_frame_major_f32_dev(const smx_stft_config *c, const float *d_x, int64_t lead, int64_t n, float *d_out,
+                                                 int64_t pitch_floats, int64_t rows_per_clip, void *stream) {
+  return guarded([&] {
+    check_config(c, "transform");
+    StftJob job;
+    job.cfg = c;
+    job.x = d_x;
+    job.in_bytes = 4;
+    job.interior = g_interior.load();
+    job.lead = lead;
+    job.n = n;
+    job.x_stride = n;
+    job.left = c->left_width();
+    job.pad = c->pad;
+    job.pad_value = c->pad_value;
+    job.p0 = 0;
+    job.count = c->frames(n);
+    job.mode = OUT_COMPLEX;
+    job.power = 0.0;
+    job.out = d_out;
+    job.out_stride = job.count;
+    job.out_offset = 0;
+    job.stream = (hipStream_t)stream;
+    if (!launch_stft_complex_fm(job, d_out, pitch_floats, rows_per_clip)) throw Failure("transform (frame-major): not eligible");
+  });
+}
+
 int smx_host_alloc(size_t bytes, void **ptr) {
   return guarded([&] {
     if (!ptr) throw Failure("smx_host_alloc: null result pointer");
@@ -1427,12 +1455,82 @@ void griffin_lim_dev(const smx_stft_config &c, const void *d_s, int elem_bytes, 
     launch_istft(job);
   };
   void *angles = nullptr, *rebuilt = nullptr, *previous = nullptr, *signal = nullptr;
-  SMX_HIP_CHECK(smx::pool_malloc_async(&angles, cbytes, stream));
-  launch_gl_init(d_phase, angles, total, elem_bytes, stream);
   const bool iterate = natural > 0 && frames > 0;   // stft.ml:993-996
   const double beta = momentum / (1.0 + momentum);
-  const bool folded = iterate && istft_takes_factors(make_job(angles, 0, 0, nullptr, natural));
-  if (folded) {
+  const bool folded = iterate && istft_takes_factors(make_job(nullptr, 0, 0, nullptr, natural));
+  // Round 5 (late): the loop's spectra FRAME-MAJOR where both fft-2048 pipelines take them so -- c_k never leaves the library, so its
+  // layout is free: the analysis stores a frame's bins straight from its registers (no output tile, no flush, waves that never
+  // wait for each other: stft2048_complex_fm_kernel) and the synthesis stages whole rows (istft2048_pipe_kernel<.., true>).  The
+  // arithmetic of every value is that of the reference-layout kernels: same bits.  SMX_GL_FRAME_MAJOR=0: the reference layout.
+  bool frame_major = false;
+  const int64_t fm_rows = (frames + 15) / 16 * 16, fm_pitch = 1032;   // (rows of 8256 bytes: whole 64-byte blocks)
+  auto fm_analysis_job = [&](const void *x, void *out) {
+    StftJob job;
+    job.cfg = &c;
+    job.x = x;
+    job.in_bytes = 4;
+    job.interior = g_interior.load();
+    job.lead = lead;
+    job.n = natural;
+    job.x_stride = natural;
+    job.left = c.left_width();
+    job.pad = c.pad;
+    job.pad_value = c.pad_value;
+    job.p0 = 0;
+    job.count = frames;
+    job.mode = OUT_COMPLEX;
+    job.power = 0.0;
+    job.out = out;
+    job.out_stride = frames;
+    job.out_offset = 0;
+    job.stream = stream;
+    return job;
+  };
+  if (folded && elem_bytes == 4 && env_flag("SMX_GL_FRAME_MAJOR") != 0 && c.frames(natural) == frames) {
+    IstftJob probe = make_job(nullptr, 0, 0, nullptr, natural);
+    probe.fm_pitch = fm_pitch;
+    probe.fm_rows = fm_rows;
+    frame_major = istft_frame_major_ok(probe) && launch_stft_complex_fm(fm_analysis_job(nullptr, nullptr), nullptr, 2 * fm_pitch, fm_rows, /*only_ask=*/true);
+  }
+  if (!frame_major || d_phase) {   // the initial angles in the reference layout (the frame-major loop without a phase fills its own)
+    SMX_HIP_CHECK(smx::pool_malloc_async(&angles, cbytes, stream));
+    launch_gl_init(d_phase, angles, total, elem_bytes, stream);
+  }
+  if (frame_major) {
+    const size_t fm_elems = (size_t)lead * (size_t)fm_rows * (size_t)fm_pitch;
+    void *mag_fm = nullptr, *a_fm = nullptr, *b_fm = nullptr, *c_fm = nullptr;
+    SMX_HIP_CHECK(smx::pool_malloc_async(&mag_fm, fm_elems * 4, stream));
+    SMX_HIP_CHECK(smx::pool_malloc_async(&a_fm, fm_elems * 8, stream));
+    SMX_HIP_CHECK(smx::pool_malloc_async(&b_fm, fm_elems * 8, stream));
+    SMX_HIP_CHECK(smx::pool_malloc_async(&c_fm, fm_elems * 8, stream));
+    SMX_HIP_CHECK(smx::pool_malloc_async(&signal, (size_t)lead * (size_t)natural * 4, stream));
+    launch_gl_to_frame_major(d_s, mag_fm, lead, bins, frames, fm_rows, fm_pitch, 4, stream);
+    if (d_phase) launch_gl_to_frame_major(angles, a_fm, lead, bins, frames, fm_rows, fm_pitch, 8, stream);
+    else launch_gl_init(nullptr, a_fm, (int64_t)fm_elems, 4, stream);   // (1, 0) everywhere
+    auto synth_fm = [&](const void *z, const void *prev, bool unit, int has_len, int64_t len, void *out, int64_t olen) {
+      IstftJob job = make_job(z, has_len, len, out, olen);
+      job.mag = mag_fm;
+      job.unit = unit;
+      job.prev = prev;
+      job.beta = beta;
+      job.fm_pitch = fm_pitch;
+      job.fm_rows = fm_rows;
+      launch_istft(job);
+    };
+    void *cur = nullptr, *old = nullptr;          // c_k, c_(k-1)
+    void *spare[2] = {b_fm, c_fm};
+    for (int64_t k = 0; k < n_iter; ++k) {
+      if (!cur) synth_fm(a_fm, nullptr, false, 0, 0, signal, natural);
+      else synth_fm(cur, old, true, 0, 0, signal, natural);
+      void *target = !cur ? spare[0] : (old ? old : spare[1]);
+      if (!launch_stft_complex_fm(fm_analysis_job(signal, target), target, 2 * fm_pitch, fm_rows)) throw Failure("griffin_lim: the frame-major analysis refused a job it had accepted");
+      old = cur;
+      cur = target;
+    }
+    synth_fm(cur, old, true, has_length, length, d_out, out_len);
+    for (void *ptr : {mag_fm, a_fm, b_fm, c_fm})
+      SMX_HIP_CHECK(hipFreeAsync(ptr, stream));
+  } else if (folded) {
     // fused fft-2048 kernels: neither S * angles nor the angles themselves are materialised after the first pass --
     // the synthesis kernel forms S * unit(c_k - beta c_(k-1)) from the two latest rebuilt spectra as it stages them
     // (stft.ml:1003-1012), and the analysis of iteration k + 1 overwrites c_(k-1), which nothing reads any more

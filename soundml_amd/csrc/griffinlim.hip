@@ -65,6 +65,23 @@ __global__ void __launch_bounds__(256) gl_convert_kernel(const Ta *src, Tb *dst,
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) dst[i] = (Tb)src[i];
 }
 
+// [lead][bins][frames] -> [lead][rows][pitch] (frame-major, rows >= frames, pitch >= bins): Griffin-Lim's own layout for the
+// fft-2048 pipelines (capi.cpp); 32 x 32 tiles through LDS, both sides coalesced
+template <typename T>
+__global__ void __launch_bounds__(256) gl_to_frame_major_kernel(const T *src, T *dst, int64_t bins, int64_t frames, int64_t rows, int64_t pitch) {
+  __shared__ T tile[32][33];
+  const int64_t clip = blockIdx.z;
+  const int64_t f0 = (int64_t)blockIdx.x * 32, b0 = (int64_t)blockIdx.y * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;   // 32 x 8
+  const T *s = src + clip * bins * frames;
+  T *d = dst + clip * rows * pitch;
+  for (int r = ty; r < 32; r += 8)
+    if (b0 + r < bins && f0 + tx < frames) tile[r][tx] = s[(b0 + r) * frames + f0 + tx];
+  __syncthreads();
+  for (int r = ty; r < 32; r += 8)
+    if (f0 + r < frames && b0 + tx < bins) d[(f0 + r) * pitch + b0 + tx] = tile[tx][r];
+}
+
 unsigned grid_for(int64_t total) { return (unsigned)std::min<int64_t>((total + 255) / 256, 16384); }
 
 }  // namespace
@@ -77,6 +94,18 @@ void launch_gl_widen(const float *src, double *dst, int64_t total, hipStream_t s
 void launch_gl_narrow(const double *src, float *dst, int64_t total, hipStream_t stream) {
   if (total <= 0) return;
   SMX_LAUNCH((gl_convert_kernel<double, float>), dim3(grid_for(total)), dim3(256), 0, stream, src, dst, total);
+  SMX_HIP_CHECK(hipGetLastError());
+}
+
+void launch_gl_to_frame_major(const void *src, void *dst, int64_t lead, int64_t bins, int64_t frames, int64_t rows, int64_t pitch, int elem_bytes,
+                              hipStream_t stream) {
+  if (lead <= 0 || bins <= 0 || frames <= 0) return;
+  if (lead > 65535) throw Failure("griffin_lim: too many clips for the frame-major transposition");
+  const dim3 grid((unsigned)((frames + 31) / 32), (unsigned)((bins + 31) / 32), (unsigned)lead);
+  if (elem_bytes == 8)
+    SMX_LAUNCH(gl_to_frame_major_kernel<float2>, grid, dim3(256), 0, stream, (const float2 *)src, (float2 *)dst, bins, frames, rows, pitch);
+  else
+    SMX_LAUNCH(gl_to_frame_major_kernel<float>, grid, dim3(256), 0, stream, (const float *)src, (float *)dst, bins, frames, rows, pitch);
   SMX_HIP_CHECK(hipGetLastError());
 }
 

@@ -879,6 +879,12 @@ bool istft_takes_factors(const IstftJob &job) {
   return istft_fused_2048(job) || (!fast_off && !f64 && (n == 512 || n == 1024 || n == 2048 || n == 4096));
 }
 
+// the frame-major form of a synthesis (Griffin-Lim's own spectra) exists on the persistent pipeline only
+bool istft_frame_major_ok(const IstftJob &job) {
+  return istft_fused_2048(job) && diag_flag("SMX_ISTFT_NEW2048") != 1 && env_flag("SMX_INVERT_PIPELINE") != 0 && job.frames < (int64_t(1) << 23) &&
+         job.fm_pitch >= job.cfg->fft_size / 2 + 1 && job.fm_rows >= job.frames && job.fm_rows * job.fm_pitch * 8 < (int64_t(1) << 32);
+}
+
 template <typename T>
 __global__ void __launch_bounds__(256) synthesis_release_kernel(const T *carry, int64_t carry_len, const T *quot, int64_t nq, int64_t drop,
                                                                 int64_t release, int64_t hold, T *out, int64_t out_stride, T *carry_out) {
@@ -909,6 +915,7 @@ void launch_synthesis_release(const void *carry, int64_t carry_len, const void *
 }
 
 void launch_istft(const IstftJob &job) {
+  if (job.fm_pitch > 0 && !istft_frame_major_ok(job)) throw Failure("invert: no kernel takes this synthesis frame-major");
   const smx_stft_config &c = *job.cfg;
   if (job.mag && !istft_takes_factors(job)) throw Failure("istft: factors are only taken by the fused kernel");
   if (job.lead <= 0 || job.out_len <= 0) return;
@@ -975,7 +982,10 @@ void launch_istft(const IstftJob &job) {
       pa.range_base = pa.total_tiles / pa.blocks;
       pa.range_extra = pa.total_tiles % pa.blocks;
       pa.aligned_out = (reinterpret_cast<uintptr_t>(job.out) % 8 == 0 && job.out_len % 2 == 0 && sa.left % 2 == 0) ? 1 : 0;
-      auto kp = (job.mag || job.unit) ? istft2048_pipe_kernel<true> : istft2048_pipe_kernel<false>;
+      pa.fm_pitch = (int)job.fm_pitch;
+      pa.fm_clip = job.fm_pitch * job.fm_rows;
+      auto kp = job.fm_pitch > 0 ? ((job.mag || job.unit) ? istft2048_pipe_kernel<true, true> : istft2048_pipe_kernel<false, true>)
+                                 : ((job.mag || job.unit) ? istft2048_pipe_kernel<true> : istft2048_pipe_kernel<false>);
       SMX_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kp), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kIpLds));
       SMX_LAUNCH(kp, dim3((unsigned)pa.blocks), dim3(512), kIpLds, job.stream, pa);
       SMX_HIP_CHECK(hipGetLastError());

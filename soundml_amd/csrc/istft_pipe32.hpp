@@ -54,6 +54,10 @@ struct PipeArgs {
   int64_t range_base, range_extra; // total_tiles / blocks and the remainder
   int blocks;
   int aligned_out;                 // every clip's output pairs are 8-byte aligned (out, out_len and left even)
+  // FM (Griffin-Lim's own spectra, capi.cpp): z, prev and mag FRAME-MAJOR -- [clip][frame][bin] in rows of fm_pitch elements,
+  // fm_clip elements per clip (stft2048_complex_fm_kernel writes z / prev that way)
+  int fm_pitch;
+  int64_t fm_clip;
 };
 
 struct IpLds {
@@ -217,7 +221,9 @@ __device__ __forceinline__ void ip_frame(const IpLds &lds, float *slot, int lane
 }
 
 // GL: Griffin-Lim's factors are taken (SynArgs::mag / unit / prev); the plain kernel holds no registers for them
-template <bool GL>
+// FM: the spectra (and factors) are frame-major: a thread stages 33 bins of ONE frame (32 lanes a contiguous 256-byte piece of the
+// frame's row) -- and a wave stages exactly the two frames it inverts, so it does not wait for the other waves' staging
+template <bool GL, bool FM = false>
 __global__ void __launch_bounds__(512) istft2048_pipe_kernel(PipeArgs pa) {
 #pragma clang fp contract(off)
   const SynArgs &a = pa.s;
@@ -270,11 +276,23 @@ __global__ void __launch_bounds__(512) istft2048_pipe_kernel(PipeArgs pa) {
   }
   const size_t zclip = (size_t)(kIpM + 1) * (size_t)a.frames;   // complex values per clip
   // this thread's elements of a tile: (row, frame) = ((tid >> 4) + 32 i, tid & 15), i < 33 (i = 32: row 1024, threads 0..15)
-  const int sf = tid & 15, srow = tid >> 4;
+  // (FM: (row, frame) = ((tid & 31) + 32 i, tid >> 5))
+  const int sf = FM ? tid >> 5 : tid & 15, srow = FM ? tid & 31 : tid >> 4;
   float2 raw[33];
   auto request = [&](int64_t cl, int t) {
     const int64_t p = (int64_t)kIpFT * t + sf;
     const bool ok = p < a.count;
+    if constexpr (FM) {
+      const char *src = reinterpret_cast<const char *>(a.z + (size_t)cl * (size_t)pa.fm_clip);   // (wave-uniform)
+      const unsigned off = (unsigned)(((size_t)(ok ? p : 0) * (size_t)pa.fm_pitch + (size_t)srow) * 8u);
+#pragma unroll
+      for (int i = 0; i < 33; ++i) {
+        float2 vv = make_float2(0.f, 0.f);
+        if (ok && (i < 32 || srow == 0)) vv = *reinterpret_cast<const float2 *>(src + off + 256u * (unsigned)i);
+        raw[i] = vv;
+      }
+      return;
+    }
     const float2 *src = a.z + (size_t)cl * zclip;   // (wave-uniform)
     const unsigned off = (unsigned)(((size_t)srow * (size_t)a.frames + (size_t)(ok ? p : 0)) * 8u);   // < 2^32: the launcher checks
     const size_t pitch = (size_t)a.frames * 32u * 8u;
@@ -294,6 +312,23 @@ __global__ void __launch_bounds__(512) istft2048_pipe_kernel(PipeArgs pa) {
   auto request_factors = [&](int64_t cl, int t) {   // (a wave-uniform base and a 32-bit offset per thread, as request())
     const int64_t p = (int64_t)kIpFT * t + sf;
     const bool ok = p < a.count;
+    if constexpr (FM) {
+      const unsigned eoff = (unsigned)((size_t)(ok ? p : 0) * (size_t)pa.fm_pitch + (size_t)srow);
+      const bool has_prev = a.unit && a.prev;
+      const char *pb = reinterpret_cast<const char *>(a.prev + (size_t)cl * (size_t)pa.fm_clip);
+      const char *mb = reinterpret_cast<const char *>(a.mag + (size_t)cl * (size_t)pa.fm_clip);
+#pragma unroll
+      for (int i = 0; i < 33; ++i) {
+        pv[i] = make_float2(0.f, 0.f);
+        if (has_prev && ok && (i < 32 || srow == 0)) pv[i] = *reinterpret_cast<const float2 *>(pb + 8u * eoff + 256u * (unsigned)i);
+      }
+#pragma unroll
+      for (int i = 0; i < 33; ++i) {
+        mg[i] = 0.f;
+        if (a.mag && ok && (i < 32 || srow == 0)) mg[i] = *reinterpret_cast<const float *>(mb + 4u * eoff + 128u * (unsigned)i);
+      }
+      return;
+    }
     const unsigned eoff = (unsigned)((size_t)srow * (size_t)a.frames + (size_t)(ok ? p : 0));   // elements
     const size_t pitch = (size_t)a.frames * 32u;
     const bool has_prev = a.unit && a.prev;
@@ -477,7 +512,7 @@ __global__ void __launch_bounds__(512) istft2048_pipe_kernel(PipeArgs pa) {
     IP_FENCE();
     IP_STAMP(4);   // next tile's requests issued
     // S4 / S5
-    ip_wait(lds.staged, 8u * (unsigned)(it + 1));
+    if constexpr (!FM) ip_wait(lds.staged, 8u * (unsigned)(it + 1));   // (FM: the wave staged its own two frames; its LDS accesses complete in order)
     IP_STAMP(5);   // wait: every element staged
     ip_frame(lds, lds.slots + (2 * wave + (ip_opaque(lane) >> 5)) * kIpSlot, lane);
     ip_signal(lds.filled, lane);

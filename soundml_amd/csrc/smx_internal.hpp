@@ -45,13 +45,14 @@ void set_last_error(const std::string &message);
   } while (0)
 
 // ---- environment switches ------------------------------------------------------------------------------------------
-// The shipped library reads twelve variables, each once per use and parsed ONE way (env_flag: unset -> -1, "0" / "" /
+// The shipped library reads thirteen variables, each once per use and parsed ONE way (env_flag: unset -> -1, "0" / "" /
 // "false" / "off" -> 0, anything else -> 1); none alters results except by selecting another kernel of the same contract:
 //   SMX_DISABLE_FAST   the generic kernels instead of the hand-laid ones (tests: two implementations of one contract)
 //   SMX_POWER_SKEW=0   fft-2048 power spectrogram: the plain per-tile flush instead of whole aligned 64-byte blocks (tests, A/B timing)
 //   SMX_BORDER_INLINE=0 fft 2048 / 1024 / 512 (power / complex spectrogram, fused mel): the border frames in an epilogue / gathered strips instead of the tile sequence (tests: same values)
 //   SMX_COMPLEX_SKEW=0 fft-2048 Stft.transform: the plain per-tile flush instead of whole aligned 128-byte lines (tests, A/B timing)
 //   SMX_INVERT_PIPELINE=0 Stft.invert at fft 2048 / hop 512: the one-tile-per-workgroup kernel of rounds 1-4 instead of the persistent pipeline (tests, A/B timing)
+//   SMX_GL_FRAME_MAJOR=0 Griffin-Lim at fft 2048 / hop 512: its rebuilt spectra in the reference layout [bin][frame] instead of frame-major (tests: bit-identical; A/B timing)
 //   SMX_WIDE_PIPELINE=0 float64 interior at fft 2048: the one-tile-per-workgroup kernel instead of the persistent one (tests: bit-identical)
 //   SMX_MEL_DENSE=1    fused mel at fft 2048: the dense 16 x 16 x 4 product instead of the banded 4 x 4 x 1 one (tests, A/B timing)
 //   SMX_MIXED_OFF      chirp-z instead of the mixed-radix kernels (tests: the two agree)
@@ -285,6 +286,9 @@ struct StftJob {
 void launch_stft(const StftJob &job);             // dispatch: fast path or generic
 void launch_stft_generic(const StftJob &job);     // stft_generic.hip
 bool launch_stft_fast(const StftJob &job);        // stft_fast.hip; false = not eligible
+// stft_fast.hip: the complex spectrum frame-major (Griffin-Lim's own layout: out[clip][frame][bin], rows of pitch_floats floats,
+// rows_per_clip = the frames rounded up to 16); false = not eligible
+bool launch_stft_complex_fm(const StftJob &job, void *out, int64_t pitch_floats, int64_t rows_per_clip, bool only_ask = false);
 bool fast_path_disabled();                        // env SMX_DISABLE_FAST=1 (tests)
 void init_device_pool();                          // tables.cpp: the library's own stream-ordered pool of the current device
 hipError_t pool_malloc_async(void **ptr, size_t bytes, hipStream_t stream);   // tables.cpp: scratch from that pool
@@ -316,8 +320,12 @@ struct IstftJob {
   // frames (no tail region: every position read is settled, stft.ml:1137-1142)
   int64_t left = -1, env_q0 = 0, env_count = 0;
   bool env_open = false;
+  // Griffin-Lim's own spectra (capi.cpp): z, prev and mag FRAME-MAJOR, [lead; fm_rows; fm_pitch] elements (fm_pitch > 0; fft 2048 /
+  // hop 512 / complex64 / float32 interior on the persistent pipeline only: istft_frame_major_ok(job))
+  int64_t fm_pitch = 0, fm_rows = 0;
 };
 void launch_istft(const IstftJob &job);           // istft.hip
+bool istft_frame_major_ok(const IstftJob &job);   // the frame-major form of the job (fm_pitch / fm_rows set) has a kernel
 // Stft.Synthesis' release (stft.ml:1172-1179, 1229-1241): stream = carry ++ quot per channel; out gets stream[drop, release),
 // carry_out gets stream[release, carry_len + nq).  Rows: carry / carry_out `hold` apart, quot `nq` apart, out `out_stride` apart.
 void launch_synthesis_release(const void *carry, int64_t carry_len, const void *quot, int64_t nq, int64_t channels, int64_t drop,
@@ -329,6 +337,9 @@ bool istft_takes_factors(const IstftJob &job);    // istft.hip: the fused fft-20
 void launch_gl_widen(const float *src, double *dst, int64_t total, hipStream_t stream);    // float32 -> float64
 void launch_gl_narrow(const double *src, float *dst, int64_t total, hipStream_t stream);   // float64 -> float32
 void launch_gl_init(const void *phase, void *angles, int64_t total, int elem_bytes, hipStream_t stream);
+// [lead][bins][frames] -> [lead][rows][pitch] of elem_bytes-wide elements (4: magnitudes, 8: complex64 angles)
+void launch_gl_to_frame_major(const void *src, void *dst, int64_t lead, int64_t bins, int64_t frames, int64_t rows, int64_t pitch, int elem_bytes,
+                              hipStream_t stream);
 void launch_gl_apply(const void *mag, const void *angles, void *z, int64_t total, int elem_bytes, hipStream_t stream);
 void launch_gl_update(const void *rebuilt, const void *previous, double beta, void *angles, int64_t total,
                       int elem_bytes, hipStream_t stream);

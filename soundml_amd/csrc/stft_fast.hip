@@ -246,6 +246,8 @@ template __global__ void stft2048_mel32_kernel<true, 2, SMX_ISA_ONE>(FastArgs, M
 template __global__ void stft_power_lanes_kernel<SMX_ISA_ONE, true, 2, false>(FastArgs);
 #elif SMX_ISA_KERNEL == 4
 template __global__ void stft_mel_lanes_kernel<SMX_ISA_ONE, true, 2, true>(FastArgs, Mel32Args);
+#elif SMX_ISA_KERNEL == 6
+template __global__ void stft2048_complex_fm_kernel<(SMX_ISA_ONE != 0)>(FastArgs);
 #elif SMX_ISA_KERNEL == 5
 template __global__ void stft_complex_lanes_kernel<SMX_ISA_ONE, true>(FastArgs);
 #else
@@ -304,6 +306,7 @@ struct FastTarget {
   bool mel = false;              // a fused mel launch (the plan and the output: mel32)
   const Mel32Args *mel32 = nullptr;   // with mel: the 32-lane kernel's plan (nullptr: the 64-lane kernel)
   bool complex_out = false;     // Stft.transform: interleaved (re, im)
+  bool frame_major = false;     // ... as out[clip][frame][bin] in rows of out_stride floats, tiles_per_clip x 16 rows a clip (Griffin-Lim's own spectra)
   // power kernel only: border frames folded into the interior launch (see stft2048_power_kernel's epilogue)
   int border_left = 0, border_right = 0;
   int64_t border_p0 = 0, border_i1 = 0;
@@ -449,6 +452,13 @@ void launch_interior(const StftJob &job, const FastTarget &tg, const float *x, i
     auto k32 = m.four == 2 ? by_al(std::integral_constant<int, 2>{}) : m.four == 1 ? by_al(std::integral_constant<int, 1>{}) : by_al(std::integral_constant<int, 0>{});
     SMX_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k32), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kFast32Lds));
     SMX_LAUNCH(k32, dim3((unsigned)a.blocks), dim3(512), kFast32Lds, job.stream, a, m);
+    SMX_HIP_CHECK(hipGetLastError());
+    return;
+  }
+  if (tg.complex_out && tg.frame_major) {   // the spectrum frame-major, straight from the registers (stft_fast_p32.hpp: stft2048_complex_fm_kernel)
+    auto kf = aligned ? stft2048_complex_fm_kernel<true> : stft2048_complex_fm_kernel<false>;
+    SMX_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kf), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kFast32Lds));
+    SMX_LAUNCH(kf, dim3((unsigned)a.blocks), dim3(512), kFast32Lds, job.stream, a);
     SMX_HIP_CHECK(hipGetLastError());
     return;
   }
@@ -639,6 +649,38 @@ bool launch_stft_fast(const StftJob &job) {
   tg.out_stride = job.out_stride;
   tg.out_offset = job.out_offset;
   launch_ranges(job, tg);
+  return true;
+}
+
+// Griffin-Lim's analysis step (capi.cpp): the complex spectrum of every frame of the request frame-major -- out[clip][frame][bin] in
+// rows of pitch_floats floats, rows_per_clip (= a multiple of 16, at least the frames) rows a clip.  false = not taken (the caller
+// keeps the reference layout): fft 2048 / float32 interior only, and a request whose border frames can ride in the tile sequence.
+bool launch_stft_complex_fm(const StftJob &job, void *out, int64_t pitch_floats, int64_t rows_per_clip, bool only_ask) {
+  const smx_stft_config &c = *job.cfg;
+  if (!fast_eligible(job, /*power_face=*/false) || c.fft_size != kN || job.mode != OUT_COMPLEX) return false;
+  if (job.count <= 0 || job.lead <= 0) return true;
+  if (rows_per_clip != (job.count + kFT - 1) / kFT * kFT || pitch_floats < 2 * (kN / 2 + 1) || pitch_floats % 2 != 0) return false;
+  const int64_t p0 = job.p0, p1 = job.p0 + job.count;
+  int64_t i0 = job.left > 0 ? (job.left + c.hop - 1) / c.hop : 0;
+  int64_t i1 = job.n + job.left - c.fft_size >= 0 ? (job.n + job.left - c.fft_size) / c.hop + 1 : 0;
+  if (i0 < p0) i0 = p0;
+  if (i1 > p1) i1 = p1;
+  if (i1 <= i0) return false;
+  const bool border = (i0 - p0) + (p1 - i1) > 0;
+  if (border && !(job.n >= c.fft_size && job.n < (int64_t(1) << 30) && env_flag("SMX_BORDER_INLINE") != 0)) return false;
+  if (only_ask) return true;
+  FastTarget tg;
+  tg.complex_out = true;
+  tg.frame_major = true;
+  tg.out = out;
+  tg.out_stride = pitch_floats;
+  tg.out_offset = 0;
+  if (border) {
+    tg.inline_border = true;
+    tg.border_p0 = i0;
+    tg.border_i1 = i1;
+  }
+  launch_interior(job, tg, reinterpret_cast<const float *>(job.x), job.n, job.x_stride, job.left, p0, p1 - p0, 0);
   return true;
 }
 

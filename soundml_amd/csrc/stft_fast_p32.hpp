@@ -333,7 +333,9 @@ struct NoMid32 {
 // TWFIRST: twiddle rows requested before the first 16-point transform (the rest behind it): 15 where the registers allow
 // (their late arrival sits on the critical path of a kernel whose LDS queue is long), fewer in the 12-wave kernels whose
 // frame waves must fit 168 registers.
-template <int PMODE, class Mid, bool CPLX = false, int TWFIRST = 15>
+// CPLX: 0 |X|^p into the tile; 1 the spectrum into the tile's two planes; 2 the spectrum handed to mid.emit() / mid.emit_self() slot
+// by slot (Griffin-Lim's frame-major spectra: nothing of a frame stays in LDS, so waves never meet)
+template <int PMODE, class Mid, int CPLX = 0, int TWFIRST = 15>
 __device__ __forceinline__ void frame32_to_tile(const FastArgs &a, const Lane32 &L, float2 (&raw)[32], float *tile,
                                                 const Mid &mid) {
 #pragma clang fp contract(off)
@@ -514,7 +516,9 @@ __device__ __forceinline__ void frame32_to_tile(const FastArgs &a, const Lane32 
   // CPLX: the spectrum itself, real parts in `tile`, imaginary parts in the plane after it (the other tile buffer)
   {   // bin M/2 (lane 0, register 16): X = 2 conj(Z)
     const f2 z = t[16] + t[16];
-    if constexpr (CPLX) {
+    if constexpr (CPLX == 2) {
+      mid.emit_self(z.x, -z.y);
+    } else if constexpr (CPLX == 1) {
       tile[L.self()] = z.x;
       tile[kTile32Floats + L.self()] = -z.y;
     } else {
@@ -527,7 +531,9 @@ __device__ __forceinline__ void frame32_to_tile(const FastArgs &a, const Lane32 
   // blocks return them as planes (re_k, re_(M-k)), (im_k, im_(M-k)) or as (|X_k|^2, |X_(M-k)|^2) = fma(re, re, im im) per half
   auto wtw = [&](int s) { return (s & 1) ? f2{tw[s >> 1].z, tw[s >> 1].w} : f2{tw[s >> 1].x, tw[s >> 1].y}; };
   auto put = [&](int s, f2 re, f2 im) {
-    if constexpr (CPLX) {
+    if constexpr (CPLX == 2) {
+      mid.emit(s, re, im);
+    } else if constexpr (CPLX == 1) {
       rk[kRowPitch32 * s] = re.x;
       rk[kTile32Floats + kRowPitch32 * s] = im.x;
       rm[kRowPitch32 * (15 - s)] = re.y;
@@ -1447,5 +1453,97 @@ __global__ void __launch_bounds__(512) stft2048_complex32_kernel(FastArgs a) {
     } else {
       cplx_flush32(a, lds.tiles, fl, pend_out, pend_left, wave, lane);
     }
+  }
+}
+
+// ---- the spectrum FRAME-MAJOR: out[clip][frame][k], k < 1025, rows of `a.out_stride` floats (Griffin-Lim's rebuilt spectra, which
+// only this library's own synthesis reads: capi.cpp).  A lane holds bins l + 32 s and 1024 - l - 32 s of its frame, so 32 lanes
+// store 256 contiguous bytes of the frame's row per slot straight from their registers: no tile, no flush, no counters -- the
+// frame's column of LDS carries its transposition and exchange only, and the waves of a workgroup never wait for each other.
+// Every clip owns tiles_per_clip x 16 rows: the frames a clip's last tile does not have land in rows nobody reads.
+template <bool ALIGNED>
+struct FmMid32 {
+  const FastArgs &a;
+  float2 (&raw)[32];
+  const float *src;
+  const float *src_clip;
+  bool src_border;
+  int lane;
+  char *pk;   // the frame's row, bin l                        (slot s: + 256 s)
+  char *pm;   // the frame's row, bin 1024 - l - 32 x 15       (slot s: + 256 (15 - s))
+  template <int I> __device__ __forceinline__ void stamp() const {}
+  __device__ __forceinline__ void early() const {}
+  __device__ __forceinline__ void before_cells() const {}
+  __device__ __forceinline__ void after_transposition_issue() const {}
+  __device__ __forceinline__ void after_exchange_issue() const {}
+  __device__ __forceinline__ void emit(int s, f2 re, f2 im) const {
+    *reinterpret_cast<float2 *>(pk + 256 * s) = make_float2(re.x, im.x);
+    *reinterpret_cast<float2 *>(pm + 256 * (15 - s)) = make_float2(re.y, im.y);
+  }
+  __device__ __forceinline__ void emit_self(float x, float y) const {   // bin 512: lane 0's
+    if ((lane & 31) == 0) *reinterpret_cast<float2 *>(pk + 8 * 512) = make_float2(x, y);
+  }
+  __device__ __forceinline__ void postpass_at(int s) const {
+    if (s == SMX_P32_LOAD_AT) load_frame32<ALIGNED>(src_border ? src_clip : src, lane & 31, raw);
+    if (s == 15 && src_border) load_frame32_padded(a, src_clip, (int)(src - src_clip), lane & 31, raw);
+  }
+};
+
+template <bool ALIGNED>
+__global__ void __launch_bounds__(512) stft2048_complex_fm_kernel(FastArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const Lds32 lds = carve_lds32(smem);
+  const Lane32 L = setup_lane32(lds, lane, wave);
+  fill_tables32(a, lds, tid, 512);
+  TileWalk tw;
+  tw.init(a, a.out, (int64_t)a.tiles_per_clip * kFT * a.out_stride);
+  const int ntiles = tw.ntiles > 0 ? tw.ntiles : 0;
+  auto frame_ptr = [&](const float *xc, int t) {   // as stft2048_power32_kernel (the border frames ride in the tile sequence or there are none)
+    const int64_t f0 = (int64_t)t * kFT;
+    const int avail = (int)(a.count - f0 < kFT ? a.count - f0 : kFT) - 1;
+    const int fi = 2 * wave + L.h;
+    const int64_t p = a.p0 + f0 + (fi <= avail ? fi : 0);
+    return xc + (p * a.hop - a.left);
+  };
+  auto tile_border = [&](int t) {
+    if (a.fold_frames != 2) return false;
+    const int64_t f0 = (int64_t)t * kFT;
+    const int avail = (int)(a.count - f0 < kFT ? a.count - f0 : kFT) - 1;
+    bool any = false;
+#pragma unroll
+    for (int hh = 0; hh < 2; ++hh) {
+      const int fi = 2 * wave + hh;
+      const int64_t p = a.p0 + f0 + (fi <= avail ? fi : 0);
+      any = any || p < a.border_i0 || p >= a.border_i1;
+    }
+    return any;
+  };
+  float2 raw[32];
+#pragma unroll
+  for (int j = 0; j < 32; ++j) raw[j] = make_float2(0.f, 0.f);
+  if (ntiles > 0) {
+    const float *src0 = frame_ptr(tw.xclip, tw.ft);
+    if (tile_border(tw.ft)) load_frame32_padded(a, tw.xclip, (int)(src0 - tw.xclip), L.l, raw);
+    else load_frame32<ALIGNED>(src0, L.l, raw);
+  }
+  __syncthreads();   // the tables
+  for (int it = 0; it < ntiles; ++it) {
+    int ftnext;
+    const float *xnext;
+    float *onext;
+    tw.peek(a, ftnext, xnext, onext);
+    const bool more = it + 1 < ntiles;
+    const float *src_clip = more ? xnext : tw.xclip;
+    const float *src = frame_ptr(src_clip, more ? ftnext : tw.ft);
+    const bool src_border = tile_border(more ? ftnext : tw.ft);
+    char *row = reinterpret_cast<char *>(tw.oclip + ((int64_t)tw.ft * kFT + L.col) * a.out_stride);   // this lane's frame
+    const FmMid32<ALIGNED> mid{a, raw, src, src_clip, src_border, lane, row + 8 * L.li(), row + 8 * (1024 - 32 * 15) - 8 * L.li()};
+    frame32_to_tile<2, FmMid32<ALIGNED>, 2>(a, L, raw, lds.tiles, mid);
+    tw.xclip = xnext;
+    tw.oclip = onext;
+    tw.ft = ftnext;
   }
 }
