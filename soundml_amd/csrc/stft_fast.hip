@@ -3,6 +3,7 @@
 //   stft2048_complex32_kernel  X                   Stft.transform / _range      stft.ml:632-666   (the same)
 //   stft2048_mel32_kernel      W |X|^p (MFMA)      Soundml.mel_spectrogram      soundml.ml:12-24  (stft_fast_mel32.hpp: the filterbank product over the pipeline's tiles)
 //   stft_power_lanes_kernel / stft_complex_lanes_kernel / stft_mel_lanes_kernel<16 | 8>    the same at fft 1024 / 512 (stft_fast_p16.hpp)
+//   stft2048_complex_fm_kernel                                                             the complex spectrum frame-major, bins stored straight from the registers (Griffin-Lim's own layout)
 //   stft_power_lanes_kernel / stft_complex_lanes_kernel<4>                                  ... and at fft 256 (a frame in 4 lanes, 128-frame tiles)
 // They replace, for float32 audio, the reference's hot call
 //   Nx.stft cdtype ~window:fft ~step:hop ~win (to_double samples)   stft.ml:356-364

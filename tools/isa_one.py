@@ -1,6 +1,6 @@
 """Registers, scratch and instruction mix of ONE instantiation of a fft-2048 kernel from hipcc -S of stft_fast.hip with
 -DSMX_ISA_ONE=<V>: seconds instead of the minutes the whole file takes; no GPU.  Default: stft2048_power32_kernel<true, 2, false, V>
-(V = the flush form: 1 pairs, 2 frames, 0 plain); -DSMX_ISA_KERNEL=1: stft2048_complex32_kernel<true, V != 0>; =2: stft2048_mel32_kernel<true, 2, V>.
+(V = the flush form: 1 pairs, 2 frames, 0 plain); -DSMX_ISA_KERNEL=1: stft2048_complex32_kernel<true, V != 0>; =2: stft2048_mel32_kernel<true, 2, V>; =3 / 4 / 5: the lanes kernels (V = 16 / 8 / 4 lanes) power / mel / complex; =6: stft2048_complex_fm_kernel<V != 0>.
   python tools/isa_one.py [V=1] [extra -D flags ...]        (assembly left in /tmp/isa_one_<V>.s)"""
 import collections, os, re, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
