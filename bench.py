@@ -580,6 +580,31 @@ def main():
                                                          "frac": round(clips * frames * ALGO_BYTES_PER_FRAME / a / 1e6 / HBM_PEAK_GBS, 4),
                                                          "algorithmic_bytes_per_frame": ALGO_BYTES_PER_FRAME,
                                                          "note": "issue-bound, not HBM-bound: 16 frames x 5900 cycles of float64 vector instructions per SIMD quartet and tile"}}
+            # Stft.griffin_lim (stft.ml:961-1017), 32 iterations at the reference's defaults on the C2 magnitudes: 33 syntheses + 32 analyses, the
+            # rebuilt spectra frame-major inside the library (round 5).  Per frame and iteration: c_k, c_(k-1) and the magnitudes read, the signal
+            # written and read, c_(k+1) written = 8200 x 3 + 4100 + 2048 x 2 bytes.
+            out.copy_(torch.rand_like(out))          # magnitudes in [0, 1)
+            yg = torch.empty(clips, n, device=dev, dtype=torch.float32)
+            lib.smx_stft_griffin_lim_f32_dev.argtypes = [vp, vp, ctypes.c_int64, ctypes.c_int64, ctypes.c_int64, ctypes.c_int64, ctypes.c_double, vp, ctypes.c_int,
+                                                         ctypes.c_int64, vp, vp]
+            gl_ms = []
+            for it_g in range(4):                    # one untimed call (its scratch comes out of the pool), then three timed
+                ea, eb = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                ea.record(torch.cuda.current_stream())
+                check(lib.smx_stft_griffin_lim_f32_dev(cfg._h, vp(out.data_ptr()), clips, BINS, frames, 32, 0.99, None, 1, n, vp(yg.data_ptr()), sptr))
+                eb.record(torch.cuda.current_stream())
+                torch.cuda.synchronize()
+                if it_g:
+                    gl_ms.append(ea.elapsed_time(eb))
+            gl_ms.sort()
+            bg = 8200 * 3 + 4100 + 2048 * 2
+            extra["c2_griffin_lim"] = {"workload": "Stft.griffin_lim, 32 iterations, momentum 0.99, on 256 x 1025 x 938 magnitudes -> 256 x 480000 samples",
+                                       "value": round(clips * frames * 32 / gl_ms[1] / 1e3, 1), "unit": "Mframes/s (frame-iterations)", "ms": round(gl_ms[1], 2),
+                                       "ms_per_iteration": round(gl_ms[1] / 32, 4), "finite": bool(torch.isfinite(yg).all()),
+                                       "roofline": {"bound": "hbm", "achieved": round(clips * frames * 32 * bg / gl_ms[1] / 1e6, 1), "peak": HBM_PEAK_GBS,
+                                                    "unit": "GB/s", "frac": round(clips * frames * 32 * bg / gl_ms[1] / 1e6 / HBM_PEAK_GBS, 4),
+                                                    "algorithmic_bytes_per_frame_and_iteration": bg}}
+            del yg
             # C5 on ONE GPU: the N = 1 point of BASELINE configs[4] (71 GB resident)
             free_b, _ = torch.cuda.mem_get_info(dev)
             del x, out

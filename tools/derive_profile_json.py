@@ -29,7 +29,8 @@ json.dump({"bytes_per_launch": read_b + write_b, "read_bytes": read_b, "write_by
            "per_kernel": None}, open(os.path.join(ROOT, "profiles", "hbm_traffic.json"), "w"), indent=1)
 # every hot kernel: counter traffic against its algorithmic bytes (the launches of tools/pmc_driver.py)
 FR2048, FR1K, FR512, FR256 = 938, 1723, 3446, 6891
-ALGO = {"stft2048_power32": 256 * FR2048 * 6148, "stft2048_complex32": 256 * FR2048 * (2048 + 8200), "stft2048_mel32": 256 * FR2048 * (2048 + 512),
+ALGO = {"stft2048_power32": 256 * FR2048 * 6148, "stft2048_complex32": 256 * FR2048 * (2048 + 8200), "stft2048_complex_fm": 256 * FR2048 * (2048 + 8200),
+        "istft2048_pipe_kernel<true, true>": 256 * FR2048 * (8200 * 2 + 4100 + 2048), "stft2048_mel32": 256 * FR2048 * (2048 + 512),
         "istft2048": 256 * FR2048 * (8200 + 2048), "mel_apply_mfma": 256 * FR2048 * (4100 + 512), "fir_ols_split": 8 * 2880000 * 8,
         "stft_power_lanes_kernel<16": 256 * FR1K * (1024 + 2052), "stft_power_lanes_kernel<8": 256 * FR512 * (512 + 1028),
         "stft_power_lanes_kernel<4": 256 * FR256 * (256 + 516),

@@ -52,6 +52,10 @@ each(lambda: check(lib.smx_stft_power_range_f32_dev(c1k._h, vp(x1.data_ptr()), 2
 each(lambda: check(lib.smx_stft_power_range_f32_dev(c512._h, vp(x1.data_ptr()), 256, 441000, 441000, 0, f512, 2.0, vp(o512.data_ptr()), None)))
 each(lambda: check(lib.smx_stft_power_range_f32_dev(c256._h, vp(x1.data_ptr()), 256, 441000, 441000, 0, f256, 2.0, vp(o256.data_ptr()), None)))
 each(lambda: check(lib.smx_fir_apply_f32_dev(plan._h, vp(xs.data_ptr()), 8, 2880000, 2880000, vp(ys.data_ptr()), 2880000, None)))
+# Griffin-Lim's loop (6 iterations a call): its frame-major kernels, stft2048_complex_fm_kernel and istft2048_pipe_kernel<true, true>
+lib.smx_stft_griffin_lim_f32_dev.argtypes = [vp, vp, ctypes.c_int64, ctypes.c_int64, ctypes.c_int64, ctypes.c_int64, ctypes.c_double, vp, ctypes.c_int, ctypes.c_int64, vp, vp]
+out.copy_(torch.rand_like(out))
+each(lambda: check(lib.smx_stft_griffin_lim_f32_dev(sc._h, vp(out.data_ptr()), 256, 1025, frames, 6, 0.99, None, 1, 480000, vp(yr.data_ptr()), None)))
 S.set_interior("float64")   # the reference's own numerics at C2: stft2048_power_wide_kernel
 each(lambda: check(lib.smx_stft_power_range_f32_dev(sc._h, vp(x.data_ptr()), 256, 480000, 480000, 0, frames, 2.0, vp(out.data_ptr()), None)))
 S.set_interior("float32")
