@@ -1486,7 +1486,7 @@ void griffin_lim_dev(const smx_stft_config &c, const void *d_s, int elem_bytes, 
     job.stream = stream;
     return job;
   };
-  if (folded && elem_bytes == 4 && env_flag("SMX_GL_FRAME_MAJOR") != 0 && c.frames(natural) == frames) {
+  if (folded && elem_bytes == 4 && env_flag("SMX_GL_FRAME_MAJOR") != 0 && c.frames(natural) == frames && lead <= 65535) {   // (the transposition's grid: a clip per blockIdx.z)
     IstftJob probe = make_job(nullptr, 0, 0, nullptr, natural);
     probe.fm_pitch = fm_pitch;
     probe.fm_rows = fm_rows;
