@@ -277,7 +277,7 @@ void *host_alloc(size_t bytes) {
   PinnedPool &pp = pinned_pool();
   {
     std::lock_guard<std::mutex> g(pp.mu);
-    for (size_t i = 0; i < pp.cached.size(); ++i)
+    for (size_t i = pp.cached.size(); i-- > 0;)   // the most recently released first
       if (pp.cached[i].second >= want && pp.cached[i].second <= want + want / 4) {   // a released block of about this size
         void *p = pp.cached[i].first;
         pp.live[reinterpret_cast<uintptr_t>(p)] = pp.cached[i].second;
