@@ -409,6 +409,45 @@ def main():
         if shard_check:
             line["shard_check"] = shard_check
 
+    # ---- what the board does under the headline kernel (rank 0, one GPU; outside every timed region) --------------------------------
+    # rocm-smi sampled twice while the step runs back to back for ~0.7 s: package power and shader clock.  The kernel sits at the
+    # board's power cap (profiles/r07/power_clock_sample.log: 1381-1394 W of 1400, sclk ~2240 of 2400 MHz), and how far the cap pulls
+    # the clock down differs by box -- this puts the box's own figures beside its line.  None where rocm-smi does not answer.
+    if world == 1 and workload == "c2" and rank == 0:
+        def power_sample():
+            import subprocess, threading
+            got = []
+            def smp():
+                time.sleep(0.3)
+                for _ in range(2):
+                    try:
+                        r = subprocess.run(["rocm-smi", "--showpower", "--showclocks", "--csv"], capture_output=True, text=True, timeout=5)
+                        rows = [ln.split(",") for ln in r.stdout.strip().splitlines() if "," in ln]
+                        if len(rows) >= 2:
+                            hdr, val = rows[0], rows[1 + min(local_rank, len(rows) - 2)]
+                            col = lambda key: next((val[i] for i, hname in enumerate(hdr) if key in hname.lower()), None)
+                            pw, sc = col("power (w)"), col("sclk clock speed")
+                            got.append({"package_w": float(pw) if pw not in (None, "", "N/A") else None,
+                                        "sclk_mhz": int("".join(ch for ch in sc if ch.isdigit())) if sc else None})
+                    except Exception:
+                        pass
+            th = threading.Thread(target=smp)
+            th.start()
+            step = power_step(x, out, clips, n, frames)
+            while th.is_alive():
+                for _ in range(20):
+                    step()
+                torch.cuda.synchronize(dev)
+            th.join()
+            return got[-1] if got else None
+        try:
+            ps = power_sample()
+        except Exception:
+            ps = None
+        if ps:
+            ps["note"] = "rocm-smi while the step runs back to back (outside the timed region); the board's cap is 1400 W and the clock's ceiling 2400 MHz"
+        line["roofline"]["board_under_the_kernel"] = ps
+
     # ---- CPU baseline on the same batch (rank 0, one GPU) ------------------------------------------------------
     if world == 1 and workload == "c2" and not args.no_cpu_baseline:
         line["cpu_baseline"] = cpu_baseline(x.cpu().numpy(), out.cpu().numpy())
