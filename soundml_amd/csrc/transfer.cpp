@@ -402,7 +402,8 @@ void pipelined_host_call(const void *src, size_t in_clip_bytes, void *dst, size_
   // (a page-locked side needs none: the DMA engine moves it)
   const int tw = worker_count();
   // (... and the upload alone is served by six: 4, 8 and 16 threads finish it at the same 13 ms, profiles/r07/host_path_pinned_threads.log)
-  const int t_up = dst_pinned ? std::min(tw, 6) : std::max(2, (int)((double)tw * (double)in_total / (double)(in_total + out_total) + 0.5));
+  // (a synthesis uploads four times what it downloads: there the upload takes them all)
+  const int t_up = dst_pinned ? (in_total > out_total ? tw : std::min(tw, 6)) : std::max(2, (int)((double)tw * (double)in_total / (double)(in_total + out_total) + 0.5));
   const int t_down = src_pinned ? tw : std::max(2, tw - t_up);
   static const bool trace = env_flag("SMX_HOST_TRACE") == 1;
   auto now = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };

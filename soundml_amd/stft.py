@@ -254,7 +254,7 @@ def invert(c: Config, z, length=None):
         # run the checks (and nothing else: lead 0) so that the reference's errors come first
         check(fn(c._h, None, 0, bins, frames, 1 if has_length else 0, int(length) if has_length else 0, None))
     out_len = int(length) if has_length else output_length(c, frames)
-    out = np.zeros(lead_shape + (out_len,), dtype=np.float64 if wide else np.float32)
+    out = _lib.host_result(lead_shape + (out_len,), np.float64 if wide else np.float32)   # (the ABI copies the whole device result out: every element is written)
     check(fn(c._h, C.c_void_p(a.ctypes.data), lead, bins, frames, 1 if has_length else 0,
              out_len if has_length else 0, C.c_void_p(out.ctypes.data)))
     return torch.from_numpy(out) if was_torch else out
@@ -306,7 +306,7 @@ def griffin_lim(c: Config, s, n_iter: int = 32, momentum: float = 0.99, init=Non
     fn = lib.smx_stft_griffin_lim_f64 if wide else lib.smx_stft_griffin_lim_f32
     check(fn(c._h, None, 0, bins, frames, *args_tail, None, 1 if has_length else 0, int(length) if has_length else 0, None))
     out_len = int(length) if has_length else output_length(c, frames)
-    out = np.zeros(lead_shape + (out_len,), dtype=a.dtype)
+    out = _lib.host_result(lead_shape + (out_len,), a.dtype)
     check(fn(c._h, C.c_void_p(a.ctypes.data), lead, bins, frames, *args_tail,
              None if p is None else C.c_void_p(p.ctypes.data), 1 if has_length else 0,
              out_len if has_length else 0, C.c_void_p(out.ctypes.data)))

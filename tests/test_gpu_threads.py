@@ -79,7 +79,8 @@ def test_two_threads_on_the_host_pointer_path(pinned):
     S.set_pinned_results(True)
 
 
-def test_pipelined_host_calls_equal_the_device_resident_ones():
+@pytest.mark.parametrize("pinned", [False, True])
+def test_pipelined_host_calls_equal_the_device_resident_ones(pinned):
     """The host-pointer transform / power spectrogram / invert of a batch above the pipelining threshold (units of clips whose
     upload, kernels and download overlap) against the device-resident entry points on the same data: bit for bit, including a
     batch whose last unit is ragged (clips not a multiple of the unit)."""
@@ -88,7 +89,7 @@ def test_pipelined_host_calls_equal_the_device_resident_ones():
     c = Stft.Config.create(fft_size=2048, hop=512)
     x = rng.uniform(-1, 1, size=(37, 300000)).astype(np.float32)      # 44 MB in, 89 MB / 178 MB out
     xd = torch.from_numpy(x).cuda()
-    S.set_pinned_results(False)   # (ordinary result arrays: both directions through the staging rings; tests/test_gpu_pinned_results.py holds the other form)
+    S.set_pinned_results(pinned)   # ordinary result arrays (both directions through the staging rings) / blocks of the page-locked pool (transform, power and invert alike)
     p = Stft.power_spectrum(c, x)
     assert np.array_equal(p, Stft.power_spectrum(c, xd).cpu().numpy())
     z = Stft.transform(c, x)
