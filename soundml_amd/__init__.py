@@ -10,7 +10,7 @@ Everything computes in hand-written HIP kernels (gfx950) behind the C ABI of
 if the HIP library is missing (no CPU fallback).
 """
 from . import _lib
-from ._lib import Failure, InvalidArgument, LIB_PATH, set_pinned_results
+from ._lib import Failure, InvalidArgument, LIB_PATH, set_pinned_results, pinned_empty
 from . import stft as Stft
 from . import mel as Mel
 from . import window as Window
@@ -42,5 +42,5 @@ def device_count() -> int:
 
 
 __all__ = ["Stft", "Mel", "Chroma", "Convert", "Window", "Fir", "Resample", "mel_spectrogram", "mfcc", "chroma_stft", "power_to_db", "amplitude_to_db", "spectral_centroid",
-           "spectral_bandwidth", "spectral_rolloff", "spectral_flatness", "shard", "set_interior", "set_pinned_results", "set_scratch_retention", "device_count",
+           "spectral_bandwidth", "spectral_rolloff", "spectral_flatness", "shard", "set_interior", "set_pinned_results", "pinned_empty", "set_scratch_retention", "device_count",
            "InvalidArgument", "Failure", "LIB_PATH"]

@@ -269,3 +269,13 @@ def host_result(shape, dtype):
     except Failure:
         return np.zeros(shape, dtype=dt)
     return np.asarray(block).view(dt).reshape(shape)
+
+
+def pinned_empty(shape, dtype):
+    """An uninitialised numpy array over a block of the library's page-locked pool, whatever its size (smx_host_alloc): an INPUT
+    batch kept in one is uploaded by the DMA engine directly, as a result in one is downloaded -- no staging copy on either side
+    (tests/test_gpu_pinned_results.py: both directions).  Released to the pool when the array and its views are gone."""
+    import numpy as np
+    dt = np.dtype(dtype)
+    nbytes = max(1, int(np.prod(shape, dtype=np.int64)) * dt.itemsize)
+    return np.asarray(_PinnedBlock(nbytes))[:int(np.prod(shape, dtype=np.int64)) * dt.itemsize].view(dt).reshape(shape)

@@ -92,11 +92,12 @@ def test_host_alloc_and_free_at_the_c_abi():
 def test_a_caller_supplied_block_takes_the_direct_path_in_both_directions():
     """x AND out inside blocks of smx_host_alloc (what a binding that allocates its tensors there hands over): upload and download
     by the DMA engine alone; same bits as ordinary arrays."""
-    from soundml_amd._lib import host_result
     rng = np.random.default_rng(3)
     x = rng.uniform(-1, 1, size=(40, 300000)).astype(np.float32)
-    xp = host_result(x.shape, np.float32)
+    xp = S.pinned_empty(x.shape, np.float32)
     assert _is_pinned_result(xp)
+    small = S.pinned_empty((3, 5), np.complex64)          # any size
+    assert small.shape == (3, 5) and small.dtype == np.complex64 and not small.flags["OWNDATA"]
     xp[...] = x
     c = Stft.Config.create(fft_size=2048, hop=512)
     S.set_pinned_results(False)
