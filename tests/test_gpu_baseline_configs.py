@@ -197,8 +197,9 @@ def test_regression_gate_fast_kernels(fft, hop):
 
 
 def test_aligned_block_flush_is_bit_identical_to_the_plain_flush():
-    """The power spectrograms at fft 2048 / 1024 / 512 and the complex one at fft 2048 leave LDS in whole aligned 64- / 128-byte
-    blocks (a row's values are carried in registers until they complete a block: stft_fast_p32.hpp, stft_fast_p16.hpp, SKEW).  SMX_POWER_SKEW=0 / SMX_COMPLEX_SKEW=0 select
+    """The power and the complex spectrogram at fft 2048 leave LDS in whole aligned 64- / 128-byte blocks (a row's values are carried in
+    registers until they complete a block: stft_fast_p32.hpp, SKEW; the fft 1024 / 512 kernels of stft_fast_p16.hpp have no such form and
+    ride along as a control: the switches must not touch them).  SMX_POWER_SKEW=0 / SMX_COMPLEX_SKEW=0 select
     the plain per-tile flush: same frame code, so the values must agree bit for bit -- over ranges that start mid-clip,
     partial last tiles, ranges whose workgroups change clip, odd and even row pitches, every origin alignment, general powers."""
     code = """
