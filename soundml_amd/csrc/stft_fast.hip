@@ -245,6 +245,8 @@ template __global__ void stft2048_complex32_kernel<true, (SMX_ISA_ONE != 0)>(Fas
 template __global__ void stft2048_mel32_kernel<true, 2, SMX_ISA_ONE>(FastArgs, Mel32Args);
 #elif SMX_ISA_KERNEL == 3
 template __global__ void stft_power_lanes_kernel<SMX_ISA_ONE, true, 2, false>(FastArgs);
+#elif SMX_ISA_KERNEL == 7
+template __global__ void stft_power_lanes_kernel<SMX_ISA_ONE, true, 2, false, true>(FastArgs);
 #elif SMX_ISA_KERNEL == 4
 template __global__ void stft_mel_lanes_kernel<SMX_ISA_ONE, true, 2, true>(FastArgs, Mel32Args);
 #elif SMX_ISA_KERNEL == 6
@@ -432,6 +434,20 @@ void launch_interior(const StftJob &job, const FastTarget &tg, const float *x, i
         return aligned ? by_power(std::true_type{}) : by_power(std::false_type{});
       };
       auto kl = strip ? pick(std::true_type{}) : pick(std::false_type{});
+      // The flush in whole aligned 128-byte lines (stft_fast_p16.hpp, SkL: a frame per lane, the row's trailing frames carried in
+      // registers): fft 1024, consecutive tiles of a clip on one workgroup.  SMX_POWER_SKEW=0: the plain per-tile flush.
+      // (Sustained, interleaved, 256 clips of C1's length: fft 1024 0.435 -> 0.400 ms, 0.458 -> 0.404 at 1729 frames a clip; fft 512,
+      // whose plain runs are 256 bytes, 0.368 -> 0.379: it keeps the plain flush.  profiles/r07/ab_lanes_skew.log)
+      if constexpr (LL == 16) {
+        if (!strip && env_flag("SMX_POWER_SKEW") != 0 && reinterpret_cast<uintptr_t>(a.out) % 4 == 0) {
+          a.interleave = 0;
+          auto by_power = [&](auto al) {
+            constexpr bool A = decltype(al)::value;
+            return a.pmode == 2 ? stft_power_lanes_kernel<LL, A, 2, false, true> : a.pmode == 1 ? stft_power_lanes_kernel<LL, A, 1, false, true> : stft_power_lanes_kernel<LL, A, 0, false, true>;
+          };
+          kl = aligned ? by_power(std::true_type{}) : by_power(std::false_type{});
+        }
+      }
       SMX_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kl), hipFuncAttributeMaxDynamicSharedMemorySize, (int)PL<LL>::Lds));
       SMX_LAUNCH(kl, dim3((unsigned)a.blocks), dim3(512), PL<LL>::Lds, job.stream, a);
     };

@@ -424,13 +424,111 @@ __device__ __forceinline__ void flushL_store(const FastArgs &a, const FlushL &fl
   if (fl.nyq) put((unsigned)P::M * pitch + 4u * (unsigned)fl.nyq_f0, r.nyq, frames_left - fl.nyq_f0);
 }
 
-template <int LL, bool ALIGNED>
+// ---- the flush in whole aligned 128-byte lines (round 5, late; LL = 16 / 8: as skewg32_* of stft_fast_p32.hpp, a frame per lane) ----
+// A tile's FT frames of a row straddle the row's 128-byte lines wherever the row does not start on one (C1: rows of 1723 floats), and
+// runs that straddle lines stream at 1.7-2.4 TB/s against 5.3 for whole lines (profiles/r06/store_shape_probe.log; the counters put the
+// plain flush of fft 1024 at 1.23x its bytes).  Here a lane holds ONE frame of a row: the FT - phi frames that complete lines are stored at
+// once, the trailing phi frames (phi = the row's offset into its line, the same for every tile of the row: FT is a multiple of 32) wait in
+// registers for the next tile -- every store instruction writes whole lines: lane c stores either its frame of this tile or the carried
+// frame of the previous one, each at its own natural address.  Rows a lane serves are 32 apart, so that they share phi; the 32 residues
+// are NP passes of 8 x RPI (RPI = rows per instruction = 64 / FT): NP x PARTS = 32 carried registers.  Needs consecutive tiles of a
+// clip on one workgroup (contiguous ranges).  Same values as the plain flush (tests: SMX_POWER_SKEW=0).
+template <int LL>
+struct SkL {
+  static constexpr int FT = PL<LL>::FT, RPI = 64 / FT, NP = 4 / RPI, PARTS = PL<LL>::M / 32;
+  static_assert(LL == 16 || LL == 8, "a frame per lane, 64 lanes = 1 or 2 rows");
+  static_assert(NP * PARTS == 32, "carried registers");
+};
+template <int LL>
+struct SkewL {
+  unsigned goff[SkL<LL>::NP];             // from FT floats BEFORE a tile's origin: byte offset of out[row][col], plus 4 FT for the lanes that store this tile's frame
+  unsigned long long sel[SkL<LL>::NP];    // the lanes whose frame of the current tile completes a line
+};
+struct SkewLRegs {
+  float cur[32];
+  float nyq;
+};
+template <int LL>
+__device__ __forceinline__ void skewL_lane(int lane, int wave, int &row0, int &col) {   // pass q: rows row0 + 8 RPI q + 32 p
+  asm volatile("" : "+v"(lane));
+  col = lane & (SkL<LL>::FT - 1);
+  row0 = SkL<LL>::RPI * wave + lane / SkL<LL>::FT;
+}
+template <int LL>
+__device__ __forceinline__ void skewL_clip(const FastArgs &a, SkewL<LL> &sk, const float *oclip, int lane, int wave) {
+  using K = SkL<LL>;
+  int row0, col;
+  skewL_lane<LL>(lane, wave, row0, col);
+#pragma unroll
+  for (int q = 0; q < K::NP; ++q) {
+    const int row = row0 + 8 * K::RPI * q;
+    const unsigned phi = (unsigned)((reinterpret_cast<uintptr_t>(oclip) >> 2) + (uintptr_t)row * (uintptr_t)a.out_stride) & 31u;
+    const bool now = (unsigned)col < (unsigned)K::FT - phi;
+    sk.sel[q] = __ballot(now);
+    sk.goff[q] = ((unsigned)row * (unsigned)a.out_stride + (unsigned)col) * 4u + (now ? 4u * K::FT : 0u);
+  }
+}
+template <int LL>
+__device__ __forceinline__ void skewL_read(const float *tile, int lane, int wave, SkewLRegs &r) {
+  using K = SkL<LL>;
+  using P = PL<LL>;
+  int row0, col;
+  skewL_lane<LL>(lane, wave, row0, col);
+  const float *src = tile + row0 * P::TS + col;
+#pragma unroll
+  for (int q = 0; q < K::NP; ++q)
+#pragma unroll
+    for (int pp = 0; pp < K::PARTS; ++pp) r.cur[q * K::PARTS + pp] = src[(8 * K::RPI * q + 32 * pp) * P::TS];
+  r.nyq = tile[P::M * P::TS + col];   // the Nyquist row (every wave reads it, wave 0 stores it)
+}
+template <int LL>
+__device__ __forceinline__ void skewL_store(const FastArgs &a, const SkewL<LL> &sk, float *obase, int frames_left, bool fresh, bool closing, int wave,
+                                            int lane, const SkewLRegs &r, float (&carry)[32]) {
+  using K = SkL<LL>;
+  using P = PL<LL>;
+  const unsigned pitch = (unsigned)a.out_stride * 4u;
+  int row0, col;
+  skewL_lane<LL>(lane, wave, row0, col);
+  if (frames_left >= K::FT && !fresh && !closing) {   // wave-uniform: whole lines for every row and part
+#pragma unroll
+    for (int q = 0; q < K::NP; ++q) {
+      const unsigned g = opaque32(sk.goff[q]);
+#pragma unroll
+      for (int pp = 0; pp < K::PARTS; ++pp) {
+        const int i = q * K::PARTS + pp;
+        store1_at(obase - K::FT, g + 32u * (unsigned)pp * pitch, select_lanes(carry[i], r.cur[i], sk.sel[q]));
+        carry[i] = r.cur[i];
+      }
+    }
+  } else {
+#pragma unroll
+    for (int q = 0; q < K::NP; ++q) {
+      const bool now = (sk.sel[q] >> lane) & 1;
+      const unsigned gl = ((unsigned)(row0 + 8 * K::RPI * q) * (unsigned)a.out_stride + (unsigned)col) * 4u;
+#pragma unroll
+      for (int pp = 0; pp < K::PARTS; ++pp) {
+        const int i = q * K::PARTS + pp;
+        float *dst = reinterpret_cast<float *>(reinterpret_cast<char *>(obase) + gl + 32u * (unsigned)pp * pitch);
+        if ((now || closing) && col < frames_left) dst[0] = r.cur[i];
+        if (!now && !fresh) dst[-K::FT] = carry[i];
+        carry[i] = r.cur[i];
+      }
+    }
+  }
+  if (wave == 0 && lane < K::FT && lane < frames_left) obase[(int64_t)P::M * a.out_stride + lane] = r.nyq;
+}
+
+template <int LL, bool ALIGNED, bool SKEW = false>
 struct PowerMidL {
   using P = PL<LL>;
   const FastArgs &a;
   const LdsL<LL> &lds;
   const FlushL &fl;
   FlushRegsL &fr;
+  const SkewL<(LL >= 8 ? LL : 8)> &sk;   // SKEW: the flush in whole aligned lines
+  SkewLRegs &sr;
+  float (&carry)[32];
+  bool pend_fresh, pend_closing;
   float2 (&raw)[32];
   const float *src;      // the next frames' samples (per lane)
   const float *src_clip; // ... their clip and whether their tile holds a frame that reaches past the signal (see PowerMid32)
@@ -449,21 +547,25 @@ struct PowerMidL {
   __device__ __forceinline__ void after_exchange_issue() const {
     if (it > 0) {
       lds_wait32(lds.filled + (b ^ 1) * P::TS, 8u * (((unsigned)(it - 1) >> 1) + 1), pk_filled);
-      flushL_read<LL>(lds.tiles + (b ^ 1) * P::TileFloats, fl, fr);
+      if constexpr (SKEW) skewL_read<LL>(lds.tiles + (b ^ 1) * P::TileFloats, lane, wave, sr);
+      else flushL_read<LL>(lds.tiles + (b ^ 1) * P::TileFloats, fl, fr);
       lds_signal32(lds.drained + (b ^ 1) * P::TS, lane);   // "read out" as soon as the reads are issued (in-order LDS)
     }
   }
   __device__ __forceinline__ void postpass_at(int s) const {
     const bool same = SMX_P32_STORE_AT == SMX_P32_LOAD_AT;
     if (s == SMX_P32_LOAD_AT && same && SMX_P32_LOADS_FIRST) { load_frameL<LL, ALIGNED>(src_border ? src_clip : src, lane & (LL - 1), raw); SMX_FENCE(); }
-    if (s == SMX_P32_STORE_AT && it > 0) flushL_store<LL>(a, fl, pend_out, pend_left, fr);
+    if (s == SMX_P32_STORE_AT && it > 0) {
+      if constexpr (SKEW) skewL_store<LL>(a, sk, pend_out, pend_left, pend_fresh, pend_closing, wave, lane, sr, carry);
+      else flushL_store<LL>(a, fl, pend_out, pend_left, fr);
+    }
     SMX_FENCE();
     if (s == SMX_P32_LOAD_AT && !(same && SMX_P32_LOADS_FIRST)) load_frameL<LL, ALIGNED>(src_border ? src_clip : src, lane & (LL - 1), raw);
     if (s == 15 && src_border) load_frameL_padded<LL>(a, src_clip, (int)(src - src_clip), lane & (LL - 1), raw);   // (wave-uniform; see PowerMid32::load_next)
   }
 };
 
-template <int LL, bool ALIGNED, int PMODE, bool STRIP>
+template <int LL, bool ALIGNED, int PMODE, bool STRIP, bool SKEW = false>
 __global__ void __launch_bounds__(512) stft_power_lanes_kernel(FastArgs a) {
   using P = PL<LL>;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -509,6 +611,13 @@ __global__ void __launch_bounds__(512) stft_power_lanes_kernel(FastArgs a) {
   int pend_left = 0;
   const FlushL fl = setup_flushL<LL>(a, lane, wave);
   FlushRegsL fr;
+  SkewL<(LL >= 8 ? LL : 8)> sk{};
+  SkewLRegs sr;
+  float carry[32];
+#pragma unroll
+  for (int i = 0; i < 32; ++i) carry[i] = 0.f;
+  bool pend_fresh = true, pend_closing = false;
+  const float *pend_oclip = nullptr;
   unsigned pk_drained = 0, pk_filled = 0;
   for (int it = 0; it < ntiles; ++it) {   // tile `it` of this workgroup lives in buffer it & 1
     const int b = it & 1;
@@ -520,12 +629,18 @@ __global__ void __launch_bounds__(512) stft_power_lanes_kernel(FastArgs a) {
     const float *src_clip = more ? xnext : tw.xclip;
     const float *src = frame_ptr(src_clip, more ? ftnext : tw.ft);
     const bool src_border = tile_border(more ? ftnext : tw.ft);
-    const PowerMidL<LL, ALIGNED> mid{a, lds, fl, fr, raw, src, src_clip, src_border, pend_out, pend_left, lane, wave, b, it, pk_drained, pk_filled};
+    if constexpr (SKEW) {
+      if (it > 0 && pend_fresh) skewL_clip<LL>(a, sk, pend_oclip, lane, wave);   // (wave-uniform) the pending tile begins a clip or this workgroup's range
+    }
+    const PowerMidL<LL, ALIGNED, SKEW> mid{a, lds, fl, fr, sk, sr, carry, pend_fresh, pend_closing, raw, src, src_clip, src_border, pend_out, pend_left, lane, wave, b, it, pk_drained, pk_filled};
     frameL_to_tile<LL, PMODE>(a, L, raw, lds.tiles + b * P::TileFloats, mid);
     lds_signal32(lds.filled + b * P::TS, lane);
     pend_out = tw.oclip + tw.ft * P::FT;   // wave-uniform
     const int64_t left = a.count - (int64_t)tw.ft * P::FT;
     pend_left = left < P::FT ? (int)left : P::FT;
+    pend_oclip = tw.oclip;
+    pend_fresh = it == 0 || tw.ft == 0;
+    pend_closing = tw.ft == a.tiles_per_clip - 1;
     tw.xclip = xnext;
     tw.oclip = onext;
     tw.ft = ftnext;
@@ -533,8 +648,14 @@ __global__ void __launch_bounds__(512) stft_power_lanes_kernel(FastArgs a) {
   if (ntiles > 0) {   // the last tile of this workgroup
     const int b = (ntiles - 1) & 1;
     lds_wait(lds.filled + b * P::TS, 8u * (((unsigned)(ntiles - 1) >> 1) + 1));
-    flushL_read<LL>(lds.tiles + b * P::TileFloats, fl, fr);
-    flushL_store<LL>(a, fl, pend_out, pend_left, fr);
+    if constexpr (SKEW) {
+      if (pend_fresh) skewL_clip<LL>(a, sk, pend_oclip, lane, wave);
+      skewL_read<LL>(lds.tiles + b * P::TileFloats, lane, wave, sr);
+      skewL_store<LL>(a, sk, pend_out, pend_left, pend_fresh, true, wave, lane, sr, carry);
+    } else {
+      flushL_read<LL>(lds.tiles + b * P::TileFloats, fl, fr);
+      flushL_store<LL>(a, fl, pend_out, pend_left, fr);
+    }
   }
 
   // Border frames (the few per clip whose window reaches past either end of the signal): same frame code on samples fetched
