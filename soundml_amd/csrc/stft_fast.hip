@@ -439,7 +439,8 @@ void launch_interior(const StftJob &job, const FastTarget &tg, const float *x, i
       // (Sustained, interleaved, 256 clips of C1's length: fft 1024 0.435 -> 0.400 ms, 0.458 -> 0.404 at 1729 frames a clip; fft 512,
       // whose plain runs are 256 bytes, 0.368 -> 0.379: it keeps the plain flush.  profiles/r07/ab_lanes_skew.log)
       if constexpr (LL == 16) {
-        if (!strip && env_flag("SMX_POWER_SKEW") != 0 && reinterpret_cast<uintptr_t>(a.out) % 4 == 0) {
+        // (a launch whose workgroups hold a single tile each -- C1 itself: one clip, 54 tiles -- has nothing to carry: the plain flush, 18.4 against 19.4 us a call)
+        if (!strip && env_flag("SMX_POWER_SKEW") != 0 && reinterpret_cast<uintptr_t>(a.out) % 4 == 0 && a.total_tiles >= 2 * (int64_t)a.blocks) {
           a.interleave = 0;
           auto by_power = [&](auto al) {
             constexpr bool A = decltype(al)::value;
