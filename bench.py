@@ -409,45 +409,6 @@ def main():
         if shard_check:
             line["shard_check"] = shard_check
 
-    # ---- what the board does under the headline kernel (rank 0, one GPU; outside every timed region) --------------------------------
-    # rocm-smi sampled twice while the step runs back to back for ~0.7 s: package power and shader clock.  The kernel sits at the
-    # board's power cap (profiles/r07/power_clock_sample.log: 1381-1394 W of 1400, sclk ~2240 of 2400 MHz), and how far the cap pulls
-    # the clock down differs by box -- this puts the box's own figures beside its line.  None where rocm-smi does not answer.
-    if world == 1 and workload == "c2" and rank == 0:
-        def power_sample():
-            import subprocess, threading
-            got = []
-            def smp():
-                time.sleep(0.3)
-                for _ in range(2):
-                    try:
-                        r = subprocess.run(["rocm-smi", "--showpower", "--showclocks", "--csv"], capture_output=True, text=True, timeout=5)
-                        rows = [ln.split(",") for ln in r.stdout.strip().splitlines() if "," in ln]
-                        if len(rows) >= 2:
-                            hdr, val = rows[0], rows[1 + min(local_rank, len(rows) - 2)]
-                            col = lambda key: next((val[i] for i, hname in enumerate(hdr) if key in hname.lower()), None)
-                            pw, sc = col("power (w)"), col("sclk clock speed")
-                            got.append({"package_w": float(pw) if pw not in (None, "", "N/A") else None,
-                                        "sclk_mhz": int("".join(ch for ch in sc if ch.isdigit())) if sc else None})
-                    except Exception:
-                        pass
-            th = threading.Thread(target=smp)
-            th.start()
-            step = power_step(x, out, clips, n, frames)
-            while th.is_alive():
-                for _ in range(20):
-                    step()
-                torch.cuda.synchronize(dev)
-            th.join()
-            return got[-1] if got else None
-        try:
-            ps = power_sample()
-        except Exception:
-            ps = None
-        if ps:
-            ps["note"] = "rocm-smi while the step runs back to back (outside the timed region); the board's cap is 1400 W and the clock's ceiling 2400 MHz"
-        line["roofline"]["board_under_the_kernel"] = ps
-
     # ---- CPU baseline on the same batch (rank 0, one GPU) ------------------------------------------------------
     if world == 1 and workload == "c2" and not args.no_cpu_baseline:
         line["cpu_baseline"] = cpu_baseline(x.cpu().numpy(), out.cpu().numpy())
@@ -679,6 +640,49 @@ def main():
                                   "rank_kernel_ms_avg_min": round(r5[0], 4), "rank_kernel_ms_avg_max": round(r5[1], 4),
                                   "n1_point": "extra.c5_one_gpu of the N = 1 line"}
             del x5, o5
+
+    # ---- what the board does under the headline kernel (rank 0, one GPU; outside every timed region) --------------------------------
+    # LAST of all (a first version ran it before the CPU baseline, and the measurement out of an idle device that follows the baseline then
+    # took 65 ms of wall clock for its 50 steps instead of 26: whatever rocm-smi's query leaves behind, nothing is measured after it now).
+    # rocm-smi sampled twice while the step runs back to back for ~1.5 s: package power and shader clock.  The kernel sits at the
+    # board's power cap (profiles/r07/power_clock_sample.log: 1381-1394 W of 1400, sclk ~2240 of 2400 MHz), and how far the cap pulls
+    # the clock down differs by box -- this puts the box's own figures beside its line.  None where rocm-smi does not answer.
+    if world == 1 and workload == "c2" and rank == 0:
+        def power_sample():
+            import subprocess, threading
+            got = []
+            def smp():
+                time.sleep(1.0)   # (the package power rocm-smi reports lags the load by a few hundred ms: 1154 W at 0.3 s, 1380-1390 from ~0.6 s on)
+                for _ in range(2):
+                    try:
+                        r = subprocess.run(["rocm-smi", "--showpower", "--showclocks", "--csv"], capture_output=True, text=True, timeout=5)
+                        rows = [ln.split(",") for ln in r.stdout.strip().splitlines() if "," in ln]
+                        if len(rows) >= 2:
+                            hdr, val = rows[0], rows[1 + min(local_rank, len(rows) - 2)]
+                            col = lambda key: next((val[i] for i, hname in enumerate(hdr) if key in hname.lower()), None)
+                            pw, sc = col("power (w)"), col("sclk clock speed")
+                            got.append({"package_w": float(pw) if pw not in (None, "", "N/A") else None,
+                                        "sclk_mhz": int("".join(ch for ch in sc if ch.isdigit())) if sc else None})
+                    except Exception:
+                        pass
+            xb = make_clip_batch(lo, hi, n)
+            ob = torch.empty(clips, BINS, frames, device=dev, dtype=torch.float32)
+            step = power_step(xb, ob, clips, n, frames)
+            th = threading.Thread(target=smp)
+            th.start()
+            while th.is_alive():
+                for _ in range(20):
+                    step()
+                torch.cuda.synchronize(dev)
+            th.join()
+            return got[-1] if got else None
+        try:
+            ps = power_sample()
+        except Exception:
+            ps = None
+        if ps:
+            ps["note"] = "rocm-smi while the step runs back to back (outside the timed region); the board's cap is 1400 W and the clock's ceiling 2400 MHz"
+        line["roofline"]["board_under_the_kernel"] = ps
 
     if rank == 0:
         if extra:
