@@ -644,7 +644,7 @@ def main():
     # ---- what the board does under the headline kernel (rank 0, one GPU; outside every timed region) --------------------------------
     # LAST of all (a first version ran it before the CPU baseline, and the measurement out of an idle device that follows the baseline then
     # took 65 ms of wall clock for its 50 steps instead of 26: whatever rocm-smi's query leaves behind, nothing is measured after it now).
-    # rocm-smi sampled twice while the step runs back to back for ~1.5 s: package power and shader clock.  The kernel sits at the
+    # rocm-smi sampled four times while the step runs back to back for ~2.5 s: package power and shader clock.  The kernel sits at the
     # board's power cap (profiles/r07/power_clock_sample.log: 1381-1394 W of 1400, sclk ~2240 of 2400 MHz), and how far the cap pulls
     # the clock down differs by box -- this puts the box's own figures beside its line.  None where rocm-smi does not answer.
     if world == 1 and workload == "c2" and rank == 0:
@@ -653,8 +653,9 @@ def main():
             got = []
             def smp():
                 time.sleep(1.0)   # (the package power rocm-smi reports lags the load by a few hundred ms: 1154 W at 0.3 s, 1380-1390 from ~0.6 s on)
-                for _ in range(2):
+                for _ in range(4):
                     try:
+                        time.sleep(0.25)
                         r = subprocess.run(["rocm-smi", "--showpower", "--showclocks", "--csv"], capture_output=True, text=True, timeout=5)
                         rows = [ln.split(",") for ln in r.stdout.strip().splitlines() if "," in ln]
                         if len(rows) >= 2:
@@ -675,7 +676,8 @@ def main():
                     step()
                 torch.cuda.synchronize(dev)
             th.join()
-            return got[-1] if got else None
+            got = [g for g in got if g.get("package_w") is not None]
+            return max(got, key=lambda g: g["package_w"]) if got else None   # (the reported power is a moving average: the sample furthest into the load)
         try:
             ps = power_sample()
         except Exception:
