@@ -290,3 +290,41 @@ def test_fft_256_is_one_launch_of_the_four_lane_pipeline():
     for i in (0, 5):
         want = O.power_spectrum(o, x[i])
         assert np.max(np.abs(got[i].cpu().numpy() - want)) <= 2 * REGRESSION * float(np.max(want)), i
+
+
+@pytest.mark.parametrize("n,kw", [
+    (256 * 32 * 3 + 5, dict(hop=256)),                          # 97 frames a clip: odd rows, a ragged last tile
+    (256 * 32 * 4, dict(hop=256)),                              # 129 frames
+    (256 * 32 * 3 + 200, dict(hop=255)),                        # odd hop
+    (30000, dict(hop=256, alignment="left", pad="edge")),
+    (30000, dict(hop=256, alignment="right", pad=("constant", 0.5))),
+    (256 * 32 * 2 + 3 * 256, dict(hop=256)),                    # 76 frames: even rows
+])
+def test_fft_1024_aligned_lines_equal_the_plain_flush(n, kw):
+    """fft 1024: the flush in whole aligned 128-byte lines (stft_fast_p16.hpp SkL: a frame per lane, a row's trailing frames carried to
+    the next tile) is taken when a launch's workgroups hold several tiles each -- 520 clips here.  Bit for bit the plain flush's values
+    (SMX_POWER_SKEW=0), whole batches and ranges that begin and end inside clips and tiles, every exponent form; three clips against the oracle."""
+    import os
+    import torch
+    torch.manual_seed(n)
+    x = (torch.rand(520, n, device="cuda") * 2 - 1).float()
+    c = Stft.Config.create(fft_size=1024, **kw)
+    frames = Stft.frames(c, n)
+    calls = [(0, frames, 2.0), (0, frames, 1.0), (0, frames, 0.7), (3, frames - 2, 2.0), (31, 66, 2.0), (33, frames, 1.0)]
+    got = {}
+    for mode in ("1", "0"):
+        os.environ["SMX_POWER_SKEW"] = mode
+        try:
+            got[mode] = [Stft.power_range(c, x, a, b, p) for a, b, p in calls]
+        finally:
+            os.environ.pop("SMX_POWER_SKEW", None)
+    for g1, g0, call in zip(got["1"], got["0"], calls):
+        assert torch.equal(g1, g0), call
+    okw = dict(kw)
+    if isinstance(okw.get("pad"), tuple):
+        okw["pad"], okw["pad_value"] = okw["pad"]
+    o = O.stft_config(1024, **okw)
+    full = got["1"][0].cpu().numpy()
+    for clip in (0, 259, 519):
+        want = O.power_spectrum(o, x[clip].cpu().numpy())
+        assert np.max(np.abs(full[clip] - want)) <= 2 * REGRESSION * float(np.max(want)), clip
