@@ -103,6 +103,21 @@ int smx_debug_stft_transform_frame_major_f32_dev(const smx_stft_config *c, const
                                                  int64_t pitch_floats, int64_t rows_per_clip, void *stream);
 int smx_device_count(int *count);
 int smx_set_device(int device);        /* device used by this thread's subsequent calls */
+/* Clip sharding for the HOST-POINTER batch calls (round 6).  The reference's caller is one process that hands over host
+ * tensors, "a batch of clips is one call" (stft.mli:211-250, soundml.mli:3-24), and its leading axes are independent by contract
+ * (stft.mli:214-218; per-slice law tested in stft_grid.ml:180-205, mel_props.ml:136-155).  With a device list set, every
+ * host-pointer entry point of Stft.transform / transform_range / power_spectrum / power_range / invert and
+ * Soundml.mel_spectrogram splits `lead` into contiguous clip ranges -- shard s of S owns clips [s*q + min(s, r), ...) with
+ * q = lead / S, r = lead % S, the first r shards one clip more (soundml_amd/shard.py clip_range) -- and runs each range on its
+ * device from a host thread of its own, with that device's own staging rings and PCIe link; every shard writes its slice of the
+ * caller's `out`, so the result is the single-device call's bit for bit and no collective is involved.  A device may be listed
+ * more than once (virtual shards).  n = 0 clears the list: calls run on the calling thread's current device (smx_set_device).
+ * Process-wide; the `*_dev` entry points and the streaming states are not affected (they live on one device by construction).
+ * smx_get_devices writes min(*n, capacity) ordinals. */
+int smx_set_devices(const int *devices, int n);
+int smx_get_devices(int *devices, int capacity, int *n);
+/* diagnostics (tests of the per-device staging): the most staged uploads / downloads that were ever in flight at once */
+int smx_debug_staging_peak(int *uploads, int *downloads, int reset);
 int smx_set_interior(int interior);    /* SMX_INTERIOR_*, process-wide default for f32 audio */
 /* Scratch arrays (Griffin-Lim's spectra, scratch spectrograms, small tables) come from a stream-ordered memory pool
  * that the library creates for itself on each device (the process-wide default pool is never touched); it keeps up to

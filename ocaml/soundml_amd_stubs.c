@@ -49,26 +49,68 @@ static void smx_raise(int status) {
 static int64_t ba_dim(value v) { return (int64_t)Caml_ba_array_val(v)->dim[0]; }
 static int ba_kind(value v) { return Caml_ba_array_val(v)->flags & CAML_BA_KIND_MASK; }
 
-/* Result tensors in page-locked memory (include/soundml_amd.h, smx_host_alloc): a one-dimensional Bigarray over a block of the
- * library's pool.  CAML_BA_EXTERNAL: the runtime does not own the data; stft_amd.ml hangs soundml_amd_host_release on the
- * Bigarray with Gc.finalise, so the block goes back to the pool when the tensor is collected.  The host-pointer entry points
- * recognise such a block and let the device write it directly (no staging copy, no page faults of a fresh array). */
-CAMLprim value soundml_amd_host_array(value v_kind, value v_n) {
-  CAMLparam2(v_kind, v_n);
+/* Result tensors in page-locked memory (include/soundml_amd.h, smx_host_alloc), OPT-IN (Stft_amd.set_pinned_results true).
+ * The block is owned by a custom value that (a) reports its out-of-heap bytes to the GC (caml_alloc_custom_mem: a loop producing
+ * 1 GB results then triggers major collections at the rate of the page-locked memory it holds, not of the few words on the
+ * heap) and (b) returns the block to the library's pool exactly once, from its finaliser or from an explicit release.  The
+ * Bigarray over it is CAML_BA_EXTERNAL -- the runtime neither owns nor reference-counts the data -- so stft_amd.ml keeps the
+ * owner reachable from a finaliser closure on THE Bigarray it hands to Nx (result_tensor); headers derived from that Bigarray
+ * outside Nx (Array1.sub, reshape, genarray_of_array1) do not keep the owner alive: that is the documented condition of the
+ * opt-in, and why the default is an ordinary Nx.empty. */
+#define Block_val(v) (*((void **)Data_custom_val(v)))
+static void block_finalize(value v) {
+  void *p = Block_val(v);
+  Block_val(v) = NULL;
+  if (p) (void)smx_host_free(p);
+}
+static struct custom_operations block_ops = {"soundml.amd.host_block", block_finalize, custom_compare_default,
+                                             custom_hash_default, custom_serialize_default,
+                                             custom_deserialize_default, custom_compare_ext_default,
+                                             custom_fixed_length_default};
+/* bytes -> owner; Failure when the library has no page-locked memory to give (the caller falls back to Nx.empty) */
+CAMLprim value soundml_amd_host_block(value v_bytes) {
+  CAMLparam1(v_bytes);
+  CAMLlocal1(v_block);
+  const intnat bytes = Long_val(v_bytes);
+  if (bytes < 0) caml_invalid_argument("soundml_amd_host_block: a non-negative size");
+  void *block = NULL;
+  smx_raise(smx_host_alloc((size_t)bytes, &block));
+  v_block = caml_alloc_custom_mem(&block_ops, sizeof(void *), (mlsize_t)bytes);
+  Block_val(v_block) = block;
+  CAMLreturn(v_block);
+}
+/* a one-dimensional Bigarray of `n` elements of kind `kind` over the owner's block (the owner was sized for it) */
+CAMLprim value soundml_amd_host_block_array(value v_block, value v_kind, value v_n) {
+  CAMLparam3(v_block, v_kind, v_n);
   const int kind = Int_val(v_kind);
   const intnat n = Long_val(v_n);
   const size_t elem = kind == CAML_BA_FLOAT32 ? 4 : kind == CAML_BA_FLOAT64 ? 8 : kind == CAML_BA_COMPLEX32 ? 8 : kind == CAML_BA_COMPLEX64 ? 16 : 0;
-  if (elem == 0 || n < 0) caml_invalid_argument("soundml_amd_host_array: float32 / float64 / complex32 / complex64 and a non-negative length");
-  void *block = NULL;
-  smx_raise(smx_host_alloc((size_t)n * elem, &block));
-  CAMLreturn(caml_ba_alloc_dims(kind | CAML_BA_C_LAYOUT | CAML_BA_EXTERNAL, 1, block, n));
+  if (elem == 0 || n < 0 || !Block_val(v_block))
+    caml_invalid_argument("soundml_amd_host_block_array: float32 / float64 / complex32 / complex64, a non-negative length and a live block");
+  CAMLreturn(caml_ba_alloc_dims(kind | CAML_BA_C_LAYOUT | CAML_BA_EXTERNAL, 1, Block_val(v_block), n));
 }
-CAMLprim value soundml_amd_host_release(value v_ba) {
-  CAMLparam1(v_ba);
-  void *block = Caml_ba_data_val(v_ba);
-  Caml_ba_array_val(v_ba)->data = NULL;   /* (a finaliser runs once; a stray second call frees nothing) */
-  if (block) (void)smx_host_free(block);
+CAMLprim value soundml_amd_host_block_release(value v_block) {
+  CAMLparam1(v_block);
+  block_finalize(v_block);   /* (idempotent: the owner's own finaliser then finds nothing) */
   CAMLreturn(Val_unit);
+}
+
+/* smx_set_devices: the device list of the host-pointer batch calls (one process, several GPUs: clip ranges side by side, one
+ * host thread + staging ring pair per device).  An int array of device ordinals; [||] restores the single-device behaviour. */
+CAMLprim value soundml_amd_set_devices(value v_ids) {
+  CAMLparam1(v_ids);
+  const mlsize_t n = Wosize_val(v_ids);
+  int ids[64];
+  if (n > 64) caml_invalid_argument("soundml_amd_set_devices: at most 64 devices");
+  for (mlsize_t i = 0; i < n; ++i) ids[i] = Int_val(Field(v_ids, i));
+  smx_raise(smx_set_devices(ids, (int)n));
+  CAMLreturn(Val_unit);
+}
+CAMLprim value soundml_amd_device_count(value v_unit) {
+  CAMLparam1(v_unit);
+  int n = 0;
+  smx_raise(smx_device_count(&n));
+  CAMLreturn(Val_int(n));
 }
 
 /* Stft.Config.create: window table (float64, win_length points) comes from Window.make on the

@@ -114,14 +114,36 @@ external resample_kernel_reset_c : rkernel_handle -> unit = "soundml_amd_resampl
 (* ---- helpers ---------------------------------------------------------------------------------------------------- *)
 
 (* Result tensors of the offline faces.  [Nx.empty] gives fresh pageable memory: every page of a large result faults while the
-   library copies into it, and the bytes cross host memory twice.  A block of the library's page-locked pool is written by the
-   device directly; it returns to the pool when the tensor is collected.  Small results stay [Nx.empty].
+   library copies into it, and the bytes cross host memory twice (C2 power_spectrum: 25-36 ms per call).  A block of the
+   library's page-locked pool is written by the device directly (23.4-24.5 ms).  OPT-IN, [set_pinned_results true], because the
+   block is out-of-heap memory with one owner:
+     - the owner is a custom value that reports the block's bytes to the GC ([caml_alloc_custom_mem]) and returns the block to
+       the pool exactly once;
+     - the Bigarray over it is [CAML_BA_EXTERNAL] (no proxy, no reference count).  The owner is kept reachable by a finaliser
+       closure on the one Bigarray handed to [Nx.of_buffer], i.e. for as long as the tensor is.  A Bigarray header derived from
+       that one OUTSIDE Nx ([Array1.sub], [reshape], [genarray_of_array1], a view taken with [Nx.to_bigarray]) does not keep
+       the owner alive: with pinned results on, copy such a view ([Nx.copy]) before the tensor goes out of scope;
+     - when the pool has no page-locked memory to give, the result is an ordinary [Nx.empty].
    ([Nx_buffer.of_bigarray1] is the inverse of the [to_bigarray1] used below; [Nx.of_buffer] is the zero-copy view
    soundml-io builds its decode results with, soundml_io.ml:848-849.) *)
-external host_array_c : int -> int -> ('a, 'b, Bigarray.c_layout) Bigarray.Array1.t = "soundml_amd_host_array"
-external host_release_c : ('a, 'b, Bigarray.c_layout) Bigarray.Array1.t -> unit = "soundml_amd_host_release"
+type host_block
+
+external host_block_c : int -> host_block = "soundml_amd_host_block"
+external host_block_array_c : host_block -> int -> int -> ('a, 'b, Bigarray.c_layout) Bigarray.Array1.t = "soundml_amd_host_block_array"
+external host_block_release_c : host_block -> unit = "soundml_amd_host_block_release"
 
 let pinned_result_min_bytes = 32 * 1024 * 1024
+let pinned_results = ref false
+let set_pinned_results on = pinned_results := on
+
+(* Several GPUs from this one process: [set_devices [|0; 1; 2; 3; 4; 5; 6; 7|]] makes every offline face below that takes a host
+   tensor ([transform], [transform_range], [power_spectrum], [power_range], [invert], [mel_spectrogram]) split its leading axes
+   into contiguous clip ranges, one range per listed device, each on a host thread of its own with that device's staging rings
+   and PCIe link; every range writes its slice of the one result tensor (the per-slice law, stft_grid.ml:180-205: bit-equal to
+   the single-device call).  [set_devices [||]]: the single device again.  The runtime lock is released around the call as for
+   every other stub, so other domains run meanwhile. *)
+external set_devices : int array -> unit = "soundml_amd_set_devices"
+external device_count : unit -> int = "soundml_amd_device_count"
 
 (* (the stub takes the Bigarray kind as its C enumerator: CAML_BA_FLOAT32 = 0, FLOAT64 = 1, COMPLEX32 = 10, COMPLEX64 = 11) *)
 let kind_code_and_size : type a b. (a, b) Bigarray.kind -> int * int = function
@@ -134,12 +156,16 @@ let kind_code_and_size : type a b. (a, b) Bigarray.kind -> int * int = function
 let result_tensor dtype shape =
   let n = Array.fold_left ( * ) 1 shape in
   let kind_code, elem = kind_code_and_size (Nx_buffer.kind_of_dtype dtype) in
-  if kind_code < 0 || n * elem < pinned_result_min_bytes then Nx.empty dtype shape
-  else begin
-    let ba = host_array_c kind_code n in
-    Gc.finalise host_release_c ba ;
-    Nx.of_buffer (Nx_buffer.of_bigarray1 ba) ~shape
-  end
+  if (not !pinned_results) || kind_code < 0 || n * elem < pinned_result_min_bytes then Nx.empty dtype shape
+  else
+    match host_block_c (n * elem) with
+    | exception Failure _ -> Nx.empty dtype shape (* no page-locked memory: the staged path into an ordinary tensor *)
+    | block ->
+        let ba = host_block_array_c block kind_code n in
+        (* the closure keeps [block] reachable while [ba] is; releasing early returns the memory at the tensor's death
+           instead of at the owner's own (later) finalisation *)
+        Gc.finalise (fun _ -> host_block_release_c block) ba ;
+        Nx.of_buffer (Nx_buffer.of_bigarray1 ba) ~shape
 
 let flat t = Nx_buffer.to_bigarray1 (Nx.to_buffer (Nx.contiguous t))
 let flat_out t = Nx_buffer.to_bigarray1 (Nx.to_buffer t) (* freshly allocated, contiguous by construction *)

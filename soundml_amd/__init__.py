@@ -41,6 +41,28 @@ def device_count() -> int:
     return n.value
 
 
+def set_devices(devices) -> None:
+    """Clip sharding of the host-array batch calls over several GPUs from ONE process (the reference's caller is one process:
+    stft.mli:211-250).  ``devices`` is a list of device ordinals (a device may appear more than once); ``Stft.transform`` /
+    ``transform_range`` / ``power_spectrum`` / ``invert`` and ``mel_spectrogram`` on host arrays then split their leading
+    axes into contiguous clip ranges (``shard.clip_range``), one host thread, staging ring pair and PCIe link per listed
+    device, each writing its slice of the one result: bit-equal to the single-device call (stft_grid.ml:180-205).
+    ``[]`` or ``None`` restores the single-device behaviour."""
+    import ctypes
+    ids = [int(d) for d in (devices or [])]
+    arr = (ctypes.c_int * max(1, len(ids)))(*ids)
+    _lib.check(_lib.lib.smx_set_devices(arr, len(ids)))
+
+
+def get_devices():
+    import ctypes
+    n = ctypes.c_int()
+    _lib.check(_lib.lib.smx_get_devices(None, 0, ctypes.byref(n)))
+    arr = (ctypes.c_int * max(1, n.value))()
+    _lib.check(_lib.lib.smx_get_devices(arr, n.value, ctypes.byref(n)))
+    return [int(arr[i]) for i in range(n.value)]
+
+
 __all__ = ["Stft", "Mel", "Chroma", "Convert", "Window", "Fir", "Resample", "mel_spectrogram", "mfcc", "chroma_stft", "power_to_db", "amplitude_to_db", "spectral_centroid",
-           "spectral_bandwidth", "spectral_rolloff", "spectral_flatness", "shard", "set_interior", "set_pinned_results", "pinned_empty", "set_scratch_retention", "device_count",
+           "spectral_bandwidth", "spectral_rolloff", "spectral_flatness", "shard", "set_interior", "set_pinned_results", "pinned_empty", "set_scratch_retention", "device_count", "set_devices", "get_devices",
            "InvalidArgument", "Failure", "LIB_PATH"]

@@ -64,6 +64,9 @@ SIGNATURES = {
     "smx_debug_stft_transform_frame_major_f32_dev": (cint, [vp, vp, i64, i64, vp, i64, i64, vp]),
     "smx_device_count": (cint, [C.POINTER(cint)]),
     "smx_set_device": (cint, [cint]),
+    "smx_set_devices": (cint, [C.POINTER(cint), cint]),
+    "smx_get_devices": (cint, [C.POINTER(cint), cint, C.POINTER(cint)]),
+    "smx_debug_staging_peak": (cint, [C.POINTER(cint), C.POINTER(cint), cint]),
     "smx_set_interior": (cint, [cint]),
     "smx_get_interior": (cint, []),
     "smx_synchronize": (cint, [vp]),

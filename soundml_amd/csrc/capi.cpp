@@ -10,6 +10,7 @@
 #include <cstring>
 #include <atomic>
 #include <memory>
+#include <thread>
 
 #include <algorithm>
 
@@ -78,6 +79,68 @@ struct DeviceScratch {  // RAII device allocation for the host-pointer entry poi
   DeviceScratch &operator=(const DeviceScratch &) = delete;
 };
 
+// ---- the device list of the host-pointer batch calls (smx_set_devices; round 6) ----------------------------------------------
+// The reference's caller is ONE process handing over host tensors, "a batch of clips is one call" (stft.mli:211-250); its leading
+// axes are independent by contract (stft.mli:214-218, tested per slice: stft_grid.ml:180-205).  With a device list set, a
+// host-pointer batch call splits `lead` into contiguous clip ranges by the rule of soundml_amd/shard.py clip_range (the first
+// lead % S shards own one clip more) and runs each range on its device from a host thread of its own: its own HIP streams, its own
+// staging rings (transfer.cpp: per device), its own PCIe link; tables are built lazily per device as before.  No collective: every
+// shard writes its slice of the caller's result.  A device may be listed more than once (virtual shards: two uploads of one device
+// in flight at a time).
+std::mutex g_devices_mutex;
+std::vector<int> g_devices;   // empty: the calling thread's current device (smx_set_device), as rounds 1-5
+
+std::vector<int> device_list() {
+  std::lock_guard<std::mutex> g(g_devices_mutex);
+  return g_devices;
+}
+
+// clips [lo, hi) of shard `rank` of `world` (soundml_amd/shard.py: clip_range)
+void clip_range(int64_t total, int64_t world, int64_t rank, int64_t &lo, int64_t &hi) {
+  const int64_t base = total / world, extra = total % world;
+  lo = rank * base + std::min(rank, extra);
+  hi = lo + base + (rank < extra ? 1 : 0);
+}
+
+// body(clip0, nclips) for every shard, on the shard's device; the first failure is rethrown as it was thrown (InvalidArgument
+// stays InvalidArgument).  Without a device list: body(0, lead) on the caller's thread and device.
+template <class F>
+void for_each_shard(int64_t lead, F &&body) {
+  const std::vector<int> devices = device_list();
+  if (devices.empty() || lead <= 0) {
+    body((int64_t)0, lead);
+    return;
+  }
+  const int64_t shards = std::min<int64_t>((int64_t)devices.size(), lead);
+  int caller_device = 0;
+  SMX_HIP_CHECK(hipGetDevice(&caller_device));
+  std::vector<std::exception_ptr> errors((size_t)shards);
+  auto run = [&](int64_t s) {
+    try {
+      SMX_HIP_CHECK(hipSetDevice(devices[(size_t)s]));
+      set_transfer_share((int)shards);
+      int64_t lo, hi;
+      clip_range(lead, shards, s, lo, hi);
+      if (hi > lo) body(lo, hi - lo);
+    } catch (...) {
+      errors[(size_t)s] = std::current_exception();
+    }
+    set_transfer_share(1);
+  };
+  if (shards == 1) {
+    run(0);
+    (void)hipSetDevice(caller_device);
+  } else {
+    std::vector<std::thread> threads;
+    for (int64_t s = 1; s < shards; ++s) threads.emplace_back(run, s);
+    run(0);   // the caller's thread takes the first shard
+    for (auto &t : threads) t.join();
+    (void)hipSetDevice(caller_device);
+  }
+  for (auto &e : errors)
+    if (e) std::rethrow_exception(e);
+}
+
 void check_config(const void *c, const char *fn) {
   if (!c) throw Failure(format("%s: configuration handle is null", fn));
 }
@@ -127,9 +190,9 @@ void stft_range_dev(const smx_stft_config &c, const void *d_x, int in_bytes, int
   launch_stft(job);
 }
 
-// host-pointer analysis: upload, run, download
-void stft_range_host(const smx_stft_config &c, const void *x, int in_bytes, int64_t lead, int64_t n,
-                     int64_t p0, int64_t p1, OutMode mode, double power, void *out) {
+// host-pointer analysis on the current device: upload, run, download
+void stft_range_host_one(const smx_stft_config &c, const void *x, int in_bytes, int64_t lead, int64_t n,
+                         int64_t p0, int64_t p1, OutMode mode, double power, void *out) {
   check_rank_extents("transform", lead, n);
   check_range(c, n, p0, p1);
   const int64_t count = p1 - p0;
@@ -146,7 +209,9 @@ void stft_range_host(const smx_stft_config &c, const void *x, int in_bytes, int6
   // A large batch is cut into units of clips whose upload, kernels and download overlap (transfer.cpp; a unit's result is the
   // slice of the whole call's bit for bit: the reference's per-slice law, stft_grid.ml:180-205).  SMX_HOST_PIPELINE=0: serially.
   const size_t in_clip = (size_t)n * (size_t)in_bytes, out_clip = out_elems / (size_t)lead * (size_t)in_bytes;
-  if (lead >= 8 && (size_t)lead * (in_clip + out_clip) >= ((size_t)128 << 20) && in_clip > 0 && env_flag("SMX_HOST_PIPELINE") != 0) {
+  // (without page-locked staging memory the pipelined form cannot run: the serial path's plain hipMemcpy still completes the call)
+  if (lead >= 8 && (size_t)lead * (in_clip + out_clip) >= ((size_t)128 << 20) && in_clip > 0 && env_flag("SMX_HOST_PIPELINE") != 0 &&
+      staging_available()) {
     int64_t unit = (int64_t)(((size_t)48 << 20) / std::max(in_clip, out_clip));   // ~48 MB of the larger side per unit
     unit = std::max<int64_t>(1, std::min<int64_t>(unit, (lead + 3) / 4));
     SMX_HIP_CHECK(hipStreamSynchronize(nullptr));   // the scratch arrays come from the null stream's pool
@@ -169,6 +234,22 @@ void stft_range_host(const smx_stft_config &c, const void *x, int in_bytes, int6
             t3 - t2, now() - t3);
 }
 
+// host-pointer analysis: the whole batch on the current device, or -- with a device list (smx_set_devices) -- contiguous clip
+// ranges on the listed devices side by side (a range's result is the slice of the whole call's bit for bit: stft_grid.ml:180-205)
+void stft_range_host(const smx_stft_config &c, const void *x, int in_bytes, int64_t lead, int64_t n,
+                     int64_t p0, int64_t p1, OutMode mode, double power, void *out) {
+  check_rank_extents("transform", lead, n);
+  check_range(c, n, p0, p1);
+  if (p1 == p0 || lead == 0) return;
+  if (!x || !out) throw Failure("transform: null pointer");
+  require_device();
+  const size_t in_clip = (size_t)n * (size_t)in_bytes;
+  const size_t out_clip = (size_t)c.bins() * (size_t)(p1 - p0) * (mode == OUT_COMPLEX ? 2 : 1) * (size_t)in_bytes;
+  for_each_shard(lead, [&](int64_t clip0, int64_t nc) {
+    stft_range_host_one(c, reinterpret_cast<const unsigned char *>(x) + (size_t)clip0 * in_clip, in_bytes, nc, n, p0, p1, mode, power,
+                        reinterpret_cast<unsigned char *>(out) + (size_t)clip0 * out_clip);
+  });
+}
 
 // Stft.invert's checks (stft.ml:745-786), in the reference's order and wording
 void check_synthesis(const smx_stft_config &c, int64_t bins, int64_t length, bool has_length) {
@@ -211,8 +292,8 @@ void invert_dev(const smx_stft_config &c, const void *d_z, int z_bytes, int64_t 
   launch_istft(job);
 }
 
-void invert_host(const smx_stft_config &c, const void *z, int z_bytes, int64_t lead, int64_t bins, int64_t frames,
-                 int has_length, int64_t length, void *out) {
+void invert_host_one(const smx_stft_config &c, const void *z, int z_bytes, int64_t lead, int64_t bins, int64_t frames,
+                     int has_length, int64_t length, void *out) {
   if (lead < 0 || frames < 0) throw Failure("invert: negative extent");
   check_synthesis(c, bins, length, has_length != 0);
   const int64_t out_len = has_length ? length : stft_output_length(c, frames);
@@ -225,7 +306,7 @@ void invert_host(const smx_stft_config &c, const void *z, int z_bytes, int64_t l
   // a large batch in units of clips whose upload, synthesis and download overlap (as stft_range_host; every clip is synthesised
   // on its own: stft.mli:214-218)
   const size_t z_clip = (size_t)bins * (size_t)frames * (size_t)z_bytes, o_clip = (size_t)out_len * (size_t)(z_bytes / 2);
-  if (lead >= 8 && zb + ob >= ((size_t)128 << 20) && z_clip > 0 && o_clip > 0 && env_flag("SMX_HOST_PIPELINE") != 0) {
+  if (lead >= 8 && zb + ob >= ((size_t)128 << 20) && z_clip > 0 && o_clip > 0 && env_flag("SMX_HOST_PIPELINE") != 0 && staging_available()) {
     int64_t unit = (int64_t)(((size_t)48 << 20) / std::max(z_clip, o_clip));
     unit = std::max<int64_t>(1, std::min<int64_t>(unit, (lead + 3) / 4));
     SMX_HIP_CHECK(hipStreamSynchronize(nullptr));
@@ -240,6 +321,23 @@ void invert_host(const smx_stft_config &c, const void *z, int z_bytes, int64_t l
   invert_dev(c, dz.ptr, z_bytes, lead, bins, frames, has_length, length, dout.ptr, nullptr);
   SMX_HIP_CHECK(hipStreamSynchronize(nullptr));
   copy_to_host(out, dout.ptr, ob);
+}
+
+// host-pointer synthesis: the current device, or the device list's clip ranges side by side (every clip is synthesised on its
+// own: stft.mli:214-218)
+void invert_host(const smx_stft_config &c, const void *z, int z_bytes, int64_t lead, int64_t bins, int64_t frames,
+                 int has_length, int64_t length, void *out) {
+  if (lead < 0 || frames < 0) throw Failure("invert: negative extent");
+  check_synthesis(c, bins, length, has_length != 0);
+  const int64_t out_len = has_length ? length : stft_output_length(c, frames);
+  if (lead == 0 || out_len == 0) return;
+  if (!out || (frames > 0 && !z)) throw Failure("invert: null pointer");
+  require_device();
+  const size_t z_clip = (size_t)bins * (size_t)frames * (size_t)z_bytes, o_clip = (size_t)out_len * (size_t)(z_bytes / 2);
+  for_each_shard(lead, [&](int64_t clip0, int64_t nc) {
+    invert_host_one(c, z ? reinterpret_cast<const unsigned char *>(z) + (size_t)clip0 * z_clip : nullptr, z_bytes, nc, bins, frames, has_length,
+                    length, reinterpret_cast<unsigned char *>(out) + (size_t)clip0 * o_clip);
+  });
 }
 
 }  // namespace
@@ -264,6 +362,32 @@ int smx_device_count(int *count) {
 
 int smx_set_device(int device) {
   return guarded([&] { SMX_HIP_CHECK(hipSetDevice(device)); });
+}
+int smx_set_devices(const int *devices, int n) {
+  return guarded([&] {
+    if (n < 0 || n > 1024) throw Failure(format("smx_set_devices: cannot list %d devices", n));
+    if (n > 0 && !devices) throw Failure("smx_set_devices: null device list");
+    int count = 0;
+    if (n > 0 && (hipGetDeviceCount(&count) != hipSuccess || count < 1))
+      throw Failure("soundml_amd: no HIP device is available (this library has no CPU fallback)");
+    for (int i = 0; i < n; ++i)
+      if (devices[i] < 0 || devices[i] >= count)
+        throw Failure(format("smx_set_devices: device %d is not one of the %d visible devices", devices[i], count));
+    std::lock_guard<std::mutex> g(g_devices_mutex);
+    g_devices.assign(devices, devices + n);
+  });
+}
+int smx_get_devices(int *devices, int capacity, int *n) {
+  return guarded([&] {
+    if (!n) throw Failure("smx_get_devices: null count pointer");
+    const std::vector<int> d = device_list();
+    *n = (int)d.size();
+    if (devices)
+      for (int i = 0; i < (int)d.size() && i < capacity; ++i) devices[i] = d[(size_t)i];
+  });
+}
+int smx_debug_staging_peak(int *uploads, int *downloads, int reset) {
+  return guarded([&] { staging_peak(uploads, downloads, reset != 0); });
 }
 
 int smx_set_scratch_retention(int64_t bytes) {
@@ -1361,8 +1485,8 @@ void mel_spectrogram_dev(const smx_stft_config &sc, const smx_mel_config &mc, co
   SMX_HIP_CHECK(hipFreeAsync(scratch, stream));
 }
 
-void mel_spectrogram_host(const smx_stft_config &sc, const smx_mel_config &mc, const void *x, int in_bytes,
-                          int64_t lead, int64_t n, double power, void *out) {
+void mel_spectrogram_host_one(const smx_stft_config &sc, const smx_mel_config &mc, const void *x, int in_bytes,
+                              int64_t lead, int64_t n, double power, void *out) {
   check_fft_sizes(sc, mc);
   check_rank_extents("mel_spectrogram", lead, n);
   const int64_t count = sc.frames(n);
@@ -1376,6 +1500,23 @@ void mel_spectrogram_host(const smx_stft_config &sc, const smx_mel_config &mc, c
   mel_spectrogram_dev(sc, mc, dx.ptr, in_bytes, lead, n, n, power, dout.ptr, nullptr);
   SMX_HIP_CHECK(hipStreamSynchronize(nullptr));
   copy_to_host(out, dout.ptr, out_total);
+}
+
+// Soundml.mel_spectrogram from host memory: the current device, or the device list's clip ranges side by side (soundml.mli:85-101:
+// leading axes broadcast; mel_props.ml:136-155 tests the slices)
+void mel_spectrogram_host(const smx_stft_config &sc, const smx_mel_config &mc, const void *x, int in_bytes,
+                          int64_t lead, int64_t n, double power, void *out) {
+  check_fft_sizes(sc, mc);
+  check_rank_extents("mel_spectrogram", lead, n);
+  const int64_t count = sc.frames(n);
+  if (lead == 0 || count == 0) return;
+  if (!x || !out) throw Failure("mel_spectrogram: null pointer");
+  require_device();
+  const size_t in_clip = (size_t)n * (size_t)in_bytes, out_clip = (size_t)mc.n_mels * (size_t)count * (size_t)in_bytes;
+  for_each_shard(lead, [&](int64_t clip0, int64_t nc) {
+    mel_spectrogram_host_one(sc, mc, reinterpret_cast<const unsigned char *>(x) + (size_t)clip0 * in_clip, in_bytes, nc, n, power,
+                             reinterpret_cast<unsigned char *>(out) + (size_t)clip0 * out_clip);
+  });
 }
 
 

@@ -767,18 +767,6 @@ int guarded_fir(F &&body) {
 }  // namespace
 
 namespace smx {
-static int64_t device_cu_count() {
-  static int64_t cached[64] = {};
-  int device = 0;
-  SMX_HIP_CHECK(hipGetDevice(&device));
-  if (device < 0 || device >= 64) return 256;
-  if (cached[device] == 0) {
-    hipDeviceProp_t prop;
-    SMX_HIP_CHECK(hipGetDeviceProperties(&prop, device));
-    cached[device] = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-  }
-  return cached[device];
-}
 // y[c][i] = (h * x[c])[out_shift + i], i in [0, n_out): the convolution of n input samples (zeros outside), any window of it
 void fir_apply_window_dev(const smx_fir_plan &p, const float *d_x, int64_t channels, int64_t n, int64_t x_stride,
                           float *d_y, int64_t y_stride, int64_t n_out, int64_t out_shift, hipStream_t stream) {

@@ -970,14 +970,7 @@ void launch_istft(const IstftJob &job) {
       const int64_t tiles16 = (need + 512 * kIpFT - 1) / (512 * kIpFT);
       pa.s.tiles_per_clip = (int)tiles16;
       pa.total_tiles = job.lead * tiles16;
-      static int cu_count = 0;
-      if (cu_count == 0) {
-        int dev = 0;
-        hipDeviceProp_t prop;
-        SMX_HIP_CHECK(hipGetDevice(&dev));
-        SMX_HIP_CHECK(hipGetDeviceProperties(&prop, dev));
-        cu_count = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-      }
+      const int cu_count = device_cu_count();   // (per device, thread-safe: tables.cpp)
       pa.blocks = (int)std::min<int64_t>(pa.total_tiles, cu_count);
       pa.range_base = pa.total_tiles / pa.blocks;
       pa.range_extra = pa.total_tiles % pa.blocks;

@@ -231,6 +231,10 @@ void copy_to_host(void *dst, const void *d_src, size_t bytes);
 void *host_alloc(size_t bytes);
 void host_free(void *p);
 bool host_is_pinned(const void *p, size_t bytes);   // [p, p + bytes) lies inside a live block of host_alloc
+bool staging_available();                            // a pipelined call can stage both directions on the current device
+void set_transfer_share(int parts);                  // this thread's transfers take 1 / parts of the copying threads (shards of a device-list call)
+void staging_peak(int *up, int *down, bool reset);   // most staged transfers ever in flight at once, per direction (tests)
+int device_cu_count();                               // compute units of the CURRENT device (cached per device, thread-safe; tables.cpp)
 // transfer.cpp: a host call cut into units of clips whose upload, kernels and download overlap (three host threads, HIP events)
 void pipelined_host_call(const void *src, size_t in_clip_bytes, void *dst, size_t out_clip_bytes, int64_t clips, int64_t unit,
                          void *d_in, void *d_out, const std::function<void(int64_t, int64_t, hipStream_t)> &launch);

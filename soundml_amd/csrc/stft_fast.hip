@@ -349,14 +349,7 @@ void launch_interior(const StftJob &job, const FastTarget &tg, const float *x, i
   // persistent workgroups: one per CU (160 KB of LDS each), every one walks a contiguous range of the
   // flat (clip, tile) sequence, so the table fill / first-load latency / final flush are paid once
   a.total_tiles = job.lead * tiles;
-  static int cu_count = 0;
-  if (cu_count == 0) {
-    int dev = 0;
-    hipDeviceProp_t prop;
-    SMX_HIP_CHECK(hipGetDevice(&dev));
-    SMX_HIP_CHECK(hipGetDeviceProperties(&prop, dev));
-    cu_count = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-  }
+  const int cu_count = device_cu_count();   // (per device, thread-safe: tables.cpp)
   a.blocks = a.total_tiles < cu_count ? a.total_tiles : cu_count;
   auto set_ranges = [&] { a.range_base = a.total_tiles / a.blocks; a.range_extra = a.total_tiles % a.blocks; };
   set_ranges();

@@ -478,14 +478,7 @@ inline bool launch(const StftJob &job, const GenericArgs &g, const StftTables &t
   if (tiles > 0x7fffffff) return false;
   A.tiles_per_clip = (int)tiles;
   A.total_tiles = g.lead * tiles;
-  static int cu_count = 0;
-  if (cu_count == 0) {
-    int dev = 0;
-    hipDeviceProp_t prop;
-    SMX_HIP_CHECK(hipGetDevice(&dev));
-    SMX_HIP_CHECK(hipGetDeviceProperties(&prop, dev));
-    cu_count = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-  }
+  const int cu_count = device_cu_count();   // (per device, thread-safe: tables.cpp)
   A.blocks = A.total_tiles < cu_count ? A.total_tiles : cu_count;
   auto kernel = g.power == 2.0 ? stft2048_power_wide_kernel<2> : g.power == 1.0 ? stft2048_power_wide_kernel<1> : stft2048_power_wide_kernel<0>;
   SMX_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, kLds));

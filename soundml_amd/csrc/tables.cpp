@@ -89,6 +89,25 @@ hipError_t pool_malloc_async(void **ptr, size_t bytes, hipStream_t stream) {
   return pool ? hipMallocFromPoolAsync(ptr, bytes, pool, stream) : hipMallocAsync(ptr, bytes, stream);
 }
 
+// Compute units of the current device: the size of every persistent grid.  Cached per device ordinal in atomics (rounds 1-5 kept
+// one unsynchronised `static int` per launcher, filled by whichever device called first: a data race under concurrent host
+// threads and the wrong grid after smx_set_device to a different part).
+int device_cu_count() {
+  static std::atomic<int> cached[64];
+  int dev = 0;
+  SMX_HIP_CHECK(hipGetDevice(&dev));
+  const bool slot = dev >= 0 && dev < 64;
+  if (slot) {
+    const int c = cached[dev].load(std::memory_order_relaxed);
+    if (c > 0) return c;
+  }
+  hipDeviceProp_t prop;
+  SMX_HIP_CHECK(hipGetDeviceProperties(&prop, dev));
+  const int cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+  if (slot) cached[dev].store(cus, std::memory_order_relaxed);
+  return cus;
+}
+
 }  // namespace smx
 
 const smx::StftTables &smx_stft_config::tables() const {

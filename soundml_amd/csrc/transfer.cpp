@@ -12,6 +12,7 @@
 #include <exception>
 #include <functional>
 #include <map>
+#include <memory>
 #include <mutex>
 #include <thread>
 #include <vector>
@@ -27,11 +28,15 @@ constexpr size_t kChunk = (size_t)16 << 20;   // bytes per staging buffer
 constexpr int kRing = 4;                      // staging buffers in flight
 constexpr size_t kDirect = (size_t)4 << 20;   // below this a plain hipMemcpy is as fast
 
+// Staging rings: a pool PER DEVICE AND DIRECTION (round 6; rounds 2-5 kept one ring pair per process behind one mutex, so eight host
+// threads on eight GPUs -- smx_set_devices -- would have taken turns on every upload).  A staged transfer leases a ring of its
+// device for its duration; a second concurrent transfer on the same device (two host threads, or one device listed twice in
+// smx_set_devices) gets a ring of its own, up to kMaxRings per device and direction, after which callers wait for a free one.
+// Every MI355X has its own PCIe Gen5 link: transfers of different devices never meet here.
 struct Ring {
   void *buf[kRing] = {};
-  std::mutex busy;   // one staged transfer at a time per process AND DIRECTION (an upload and a download may overlap: PCIe is full duplex)
-  bool ensure() {
-    if (buf[0]) return true;
+  bool busy = false;
+  bool allocate() {
     for (int i = 0; i < kRing; ++i)
       if (hipHostMalloc(&buf[i], kChunk, hipHostMallocPortable) != hipSuccess) {
         for (int j = 0; j < i; ++j) (void)hipHostFree(buf[j]);
@@ -42,13 +47,71 @@ struct Ring {
     return true;
   }
 };
-Ring g_ring_up, g_ring_down;
+constexpr int kMaxRings = 4;       // per device and direction (64 MB of page-locked memory each, allocated on first use)
+constexpr int kMaxDevices = 64;
+struct RingPool {
+  std::mutex mu;
+  std::condition_variable freed;
+  std::vector<std::unique_ptr<Ring>> rings;
+};
+RingPool &ring_pool(int device, bool to_host) {
+  static RingPool *pools = new RingPool[2 * kMaxDevices];   // (never destroyed: see pinned_pool)
+  return pools[2 * (device >= 0 && device < kMaxDevices ? device : 0) + (to_host ? 1 : 0)];
+}
+// how many staged transfers hold a ring right now, and the most that ever did at once (smx_debug_staging_peak: the tests of the
+// per-device staging look at it)
+std::atomic<int> g_staged_now[2] = {{0}, {0}}, g_staged_peak[2] = {{0}, {0}};
+struct RingLease {
+  RingPool *pool = nullptr;
+  Ring *ring = nullptr;
+  int dir = 0;
+  // a free ring of the current device, a new one while the pool is below kMaxRings, else the next one released; nullptr when no
+  // page-locked memory is to be had at all
+  RingLease(bool to_host) : dir(to_host ? 1 : 0) {
+    int device = 0;
+    if (hipGetDevice(&device) != hipSuccess) { (void)hipGetLastError(); device = 0; }
+    pool = &ring_pool(device, to_host);
+    std::unique_lock<std::mutex> g(pool->mu);
+    for (;;) {
+      for (auto &r : pool->rings)
+        if (!r->busy) { ring = r.get(); break; }
+      if (ring) break;
+      if ((int)pool->rings.size() < kMaxRings) {
+        auto r = std::make_unique<Ring>();
+        if (r->allocate()) {
+          ring = r.get();
+          pool->rings.push_back(std::move(r));
+          break;
+        }
+        if (pool->rings.empty()) return;   // nothing allocated, nothing to wait for
+      }
+      pool->freed.wait(g);
+    }
+    ring->busy = true;
+    const int now = g_staged_now[dir].fetch_add(1) + 1;
+    int peak = g_staged_peak[dir].load();
+    while (now > peak && !g_staged_peak[dir].compare_exchange_weak(peak, now)) {}
+  }
+  ~RingLease() {
+    if (!ring) return;
+    g_staged_now[dir].fetch_sub(1);
+    { std::lock_guard<std::mutex> g(pool->mu); ring->busy = false; }
+    pool->freed.notify_one();
+  }
+  RingLease(const RingLease &) = delete;
+  RingLease &operator=(const RingLease &) = delete;
+};
 
 // What a pipelined host call hangs on a staged transfer (pipelined_host_call below): the upload reports every DMA it has
 // enqueued, the download asks before it enqueues one.
 struct Hooks {
   std::function<void(long chunk, hipStream_t stream)> enqueued;   // upload: the DMA of chunk `chunk` is on `stream`
   std::function<void(long chunk, hipStream_t stream)> before;     // download: called before the DMA of chunk `chunk` goes on `stream`
+};
+
+// what a stage of a pipelined call throws when it stops because ANOTHER stage failed (never the root cause)
+struct StageAborted : Failure {
+  using Failure::Failure;
 };
 
 // the CPU quota of the process's cgroup in cores (cgroup v2 cpu.max = "<quota> <period>"; 0 = none or unreadable).  The GPU boxes
@@ -67,7 +130,7 @@ int cgroup_cpu_quota() {
   return cores;
 }
 
-int worker_count() {
+int worker_count_whole() {
   static const int n = [] {
     if (env_flag("SMX_COPY_THREADS") >= 0) return std::max(1, std::min(64, (int)env_int("SMX_COPY_THREADS", 16)));
     const unsigned hw = std::thread::hardware_concurrency();
@@ -78,6 +141,10 @@ int worker_count() {
   }();
   return n;
 }
+// the shards of a device-list call (capi.cpp: for_each_shard) run side by side on the same host cores: each takes its share of
+// the copying threads
+thread_local int t_transfer_share = 1;
+int worker_count() { return std::max(1, worker_count_whole() / std::max(1, t_transfer_share)); }
 
 struct StreamAndEvents {
   hipStream_t stream = nullptr;
@@ -160,12 +227,17 @@ hipError_t copy_to_host_by_kernel(void *dst, const void *src, size_t len, hipStr
 void direct(void *dst, const void *src, size_t bytes, bool to_host, const Hooks *hooks) {
   StreamAndEvents se;
   const long chunks = (long)((bytes + kChunk - 1) / kChunk);
-  for (long i = 0; i < chunks; ++i) {
-    const size_t off = (size_t)i * kChunk, len = std::min(kChunk, bytes - off);
-    if (hooks && hooks->before) hooks->before(i, se.stream);
-    if (to_host) SMX_HIP_CHECK(copy_to_host_by_kernel((unsigned char *)dst + off, (const unsigned char *)src + off, len, se.stream));
-    else SMX_HIP_CHECK(hipMemcpyAsync((unsigned char *)dst + off, (const unsigned char *)src + off, len, hipMemcpyHostToDevice, se.stream));
-    if (hooks && hooks->enqueued) hooks->enqueued(i, se.stream);
+  try {
+    for (long i = 0; i < chunks; ++i) {
+      const size_t off = (size_t)i * kChunk, len = std::min(kChunk, bytes - off);
+      if (hooks && hooks->before) hooks->before(i, se.stream);
+      if (to_host) SMX_HIP_CHECK(copy_to_host_by_kernel((unsigned char *)dst + off, (const unsigned char *)src + off, len, se.stream));
+      else SMX_HIP_CHECK(hipMemcpyAsync((unsigned char *)dst + off, (const unsigned char *)src + off, len, hipMemcpyHostToDevice, se.stream));
+      if (hooks && hooks->enqueued) hooks->enqueued(i, se.stream);
+    }
+  } catch (...) {
+    (void)hipStreamSynchronize(se.stream);   // nothing of this transfer is in flight once the caller unwinds (and frees what it touches)
+    throw;
   }
   SMX_HIP_CHECK(hipStreamSynchronize(se.stream));
 }
@@ -176,13 +248,14 @@ void staged(void *dst, const void *src, size_t bytes, bool to_host, int workers 
     direct(dst, src, bytes, to_host, hooks);
     return;
   }
-  Ring &g_ring = to_host ? g_ring_down : g_ring_up;
-  std::lock_guard<std::mutex> lock(g_ring.busy);
-  if (!g_ring.ensure()) {   // no pinned memory to be had: the plain copy still works
-    if (hooks) throw Failure("pipelined transfer: no pinned staging memory");   // (the caller falls back to the serial path)
+  RingLease lease(to_host);
+  if (!lease.ring) {   // no pinned memory to be had: the plain copy still works
+    // (a pipelined call checks staging_available() before it starts its threads; this is the race where the memory went in between)
+    if (hooks) throw Failure("pipelined transfer: no pinned staging memory");
     SMX_HIP_CHECK(hipMemcpy(dst, src, bytes, to_host ? hipMemcpyDeviceToHost : hipMemcpyHostToDevice));
     return;
   }
+  Ring &g_ring = *lease.ring;
   StreamAndEvents se;
   const long chunks = (long)((bytes + kChunk - 1) / kChunk);
   const int t = workers > 0 ? workers : worker_count();
@@ -264,7 +337,10 @@ void staged(void *dst, const void *src, size_t bytes, bool to_host, int workers 
     ready.store(chunks + kRing, std::memory_order_release);
   }
   for (auto &th : pool) th.join();
-  if (err == hipSuccess) err = hipStreamSynchronize(se.stream);
+  // on every path, also the failing ones: no DMA of this transfer is in flight when the ring goes back to the pool and the
+  // caller unwinds (it frees the device arrays this transfer reads / writes)
+  const hipError_t sync_err = hipStreamSynchronize(se.stream);
+  if (err == hipSuccess) err = sync_err;
   if (hook_error) std::rethrow_exception(hook_error);
   SMX_HIP_CHECK(err);
 }
@@ -385,7 +461,7 @@ void pipelined_host_call(const void *src, size_t in_clip_bytes, void *dst, size_
   auto wait_until = [&](const long &v, long target) {
     std::unique_lock<std::mutex> g(mu);
     cv.wait(g, [&] { return v >= target || failed; });
-    if (failed) throw Failure("pipelined transfer: another stage failed");
+    if (failed) throw StageAborted("pipelined transfer: another stage failed");
   };
   Hooks hu, hd;
   hu.enqueued = [&](long i, hipStream_t s) {
@@ -449,11 +525,35 @@ void pipelined_host_call(const void *src, size_t in_clip_bytes, void *dst, size_
   if (trace)
     fprintf(stderr, "[smx] pipelined host call: upload done at %.2f ms (%d copying threads%s), last launch at %.2f, download done at %.2f (%d%s)\n", t_up_done, t_up,
             src_pinned ? ", page-locked source" : "", t_launch_done, t_down_done, t_down, dst_pinned ? ", page-locked destination" : "");
-  (void)hipStreamSynchronize(compute);
+  (void)hipStreamSynchronize(compute);   // (the two transfer threads synchronise their own streams on every path: staged / direct)
   cleanup();
-  if (err_main) std::rethrow_exception(err_main);
-  if (err_up) std::rethrow_exception(err_up);
-  if (err_down) std::rethrow_exception(err_down);
+  // the root cause first: a stage that only noticed another one failing reports StageAborted
+  auto aborted = [](const std::exception_ptr &e) {
+    if (!e) return false;
+    try { std::rethrow_exception(e); } catch (const StageAborted &) { return true; } catch (...) { return false; }
+  };
+  for (const std::exception_ptr *e : {&err_main, &err_up, &err_down})
+    if (*e && !aborted(*e)) std::rethrow_exception(*e);
+  for (const std::exception_ptr *e : {&err_main, &err_up, &err_down})
+    if (*e) std::rethrow_exception(*e);
+}
+
+// Can a pipelined call stage its transfers on the current device?  (One ring per direction exists or can be allocated now.  Asked
+// BEFORE the threads start: without page-locked memory the serial path's plain hipMemcpy still completes the call.)
+bool staging_available() {
+  for (int dir = 0; dir < 2; ++dir) {
+    RingLease lease(dir == 1);
+    if (!lease.ring) return false;
+  }
+  return true;
+}
+
+void set_transfer_share(int parts) { t_transfer_share = parts < 1 ? 1 : parts; }
+
+void staging_peak(int *up, int *down, bool reset) {
+  if (up) *up = g_staged_peak[0].load();
+  if (down) *down = g_staged_peak[1].load();
+  if (reset) { g_staged_peak[0].store(0); g_staged_peak[1].store(0); }
 }
 
 void copy_to_device(void *d_dst, const void *src, size_t bytes) {
