@@ -706,6 +706,35 @@ def griffin_lim(c: StftConfig, s: np.ndarray, n_iter: int = 32, momentum: float 
     return synthesise(c, magnitudes * angles, length).astype(dtype)
 
 
+def griffin_lim_float32_storage(c: StftConfig, s: np.ndarray, n_iter: int = 32, momentum: float = 0.99, init=None,
+                                length: Optional[int] = None) -> np.ndarray:
+    """NOT a restatement of the reference: a YARDSTICK for float32 implementations of ``griffin_lim`` above.  The same loop
+    (stft.ml:961-1017) in float64 arithmetic, with nothing but the values it STORES between its transforms rounded to float32
+    (the synthesised signal to float32, the rebuilt spectrum to complex64) -- the least any float32 interior can do.  The
+    accelerated update forms c_k - a c_(k-1), which cancels to ~1 % of |c|, and unit() of a nearly silent bin turns by O(1) under
+    a perturbation of its size, so the distance between this trajectory and the float64 one is heavy-tailed; a float32
+    implementation is judged by the DISTRIBUTION of its distance against the distribution of this one's
+    (tests/test_gpu_parity.py::test_griffin_lim_defaults_statistical_gate, tools/gl_stat.py)."""
+    s = np.asarray(s)
+    magnitudes = s.astype(np.float64).astype(np.complex128)
+    if init is None:
+        angles = np.ones(s.shape, dtype=np.complex128)
+    else:
+        p = np.asarray(init).astype(np.float64)
+        angles = np.cos(p) + 1j * np.sin(p)
+    frames_ = s.shape[-1]
+    beta = momentum / (1.0 + momentum)
+    previous = None
+    tiny = float(np.finfo(np.float64).tiny)
+    for _ in range(n_iter):
+        y = synthesise(c, magnitudes * angles).astype(np.float32).astype(np.float64)
+        rebuilt = transform_range(c, y, 0, frames_, np.complex128).astype(np.complex64).astype(np.complex128)
+        extrapolated = rebuilt if previous is None else rebuilt - previous * beta
+        angles = extrapolated / (np.abs(extrapolated) + tiny)
+        previous = rebuilt
+    return synthesise(c, magnitudes * angles, length).astype(np.float32)
+
+
 # ----------------------------------------------------------------------------
 # Mel (mel.ml, convert.ml:70-102)
 # ----------------------------------------------------------------------------

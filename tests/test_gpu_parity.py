@@ -744,43 +744,55 @@ def test_griffin_lim_fast_path_and_messages():
     assert str(e.value).startswith("griffin_lim: cannot start from a [1; 1025; 40] phase for a [2; 1025; 40] spectrogram")
 
 
-def test_griffin_lim_at_the_reference_defaults_float32_interior():
-    """The reference's defaults (stft.ml:961-964: 32 iterations, momentum 0.99) under the float32 interior.
+GL_GATE_K = 16.0   # see test_griffin_lim_defaults_statistical_gate
+
+
+def test_griffin_lim_defaults_statistical_gate():
+    """The reference's defaults (stft.ml:961-964: 32 iterations, momentum 0.99, random initial phase) under the float32 interior,
+    gated STATISTICALLY over 48 seeds (round 5's gate was two seeds and a convergence fallback).
     The accelerated update forms c_k - 0.99 c_(k-1), which cancels to ~1 % of |c|, and unit() of a bin whose difference nearly
-    vanishes turns by O(1) under a perturbation of its size: the distance between two float32 trajectories is heavy-tailed, not
-    a rounding error.  Measured (tools/gl_growth.py, profiles/r07/gl_growth_*.log; rel l2 to the float64 oracle after 32
-    iterations): this kernel 3.3e-3 / 2.5e-4 on two seeds, the kernel of rounds 1-4 1.5e-4 / 1.1e-3 on the same two, the
-    ORACLE ITSELF with nothing but its stored intermediates rounded to float32 1.2e-5 / 1.2e-4 -- no float32 implementation
-    is consistently nearer, and rounds 3-4's gate (64 x the oracle's movement under one ulp of the magnitudes) held for the seed
-    it was written on by luck.  What is gated instead:
-      * the trajectory while it is still a rounding error: 2 iterations at momentum 0.99 within 1e-5 l2 of the oracle;
-      * what Griffin-Lim is FOR at 32 iterations: the spectral convergence || |STFT(y)| - S || / ||S|| of the device's result is
-        the oracle's to within 5 % (both evaluated by the float64 oracle), and the waveform stays in the oracle's basin (2 % l2);
-      * `set_interior("float64")` is the reference's arithmetic and must sit at 1e-5 of the oracle's waveform."""
-    rng = np.random.default_rng(99)
-    x = rng.uniform(-1, 1, size=(2, 24000)).astype(np.float32)
+    vanishes turns by O(1) under a perturbation of its size: the distance between two trajectories that differ by rounding is
+    heavy-tailed (chaotic dynamics), so a single draw says little and a distribution says what there is to say.
+    Yardstick: O.griffin_lim_float32_storage -- the float64 ORACLE with nothing but its stored intermediates rounded to float32,
+    the least any float32 interior can do.  It injects 2^-24 = 6.0e-8 relative per stored value and iteration; this library's
+    float32 transforms inject their own rounding on top, measured 4.5e-7 of the peak per transform over all of C2
+    (bench.py, gpu_vs_oracle_max_err_over_peak) = 7.5 x the yardstick's.  The same dynamics amplify both, so the device's
+    distance distribution must be the yardstick's scaled by about that factor: GATE K = 16 (2 x 7.5) on the MEDIAN and on the
+    MAXIMUM of the relative l2 distance to the float64 oracle.  Measured on 48 seeds (profiles/r08/gl_stat_f32.log): device
+    median 1.18e-4 / max 1.97e-2, yardstick median 1.51e-5 / max 1.50e-2: ratios 7.8 and 1.3.
+    Beside it, for every seed: the result is finite and does what Griffin-Lim is for -- its spectral convergence
+    || |STFT(y)| - S || / ||S|| is the oracle's within 1 % (measured: within 0.006 %); and on the first seed the trajectory
+    while it is still a rounding error (2 iterations within 1e-5) and the reference's own arithmetic (set_interior float64
+    within 1e-5 of the oracle after all 32)."""
     c = Stft.Config.create(fft_size=2048, hop=512)
     o = O.stft_config(2048, hop=512)
-    z = Stft.transform(c, x)
-    mag = np.abs(z).astype(np.float32)
-    phase = rng.uniform(-np.pi, np.pi, size=z.shape).astype(np.float32)   # (the default is a random phase: stft.ml:976-984)
     rel = lambda a, b: float(np.linalg.norm(a.astype(np.float64) - b) / np.linalg.norm(b))
-    short = O.griffin_lim(o, mag, 2, 0.99, phase, None).astype(np.float64)
-    assert rel(Stft.griffin_lim(c, mag, n_iter=2, momentum=0.99, init=phase), short) <= 1e-5
-    want = O.griffin_lim(o, mag, 32, 0.99, phase, None)
-    got = Stft.griffin_lim(c, mag, n_iter=32, momentum=0.99, init=phase)
-    assert np.isfinite(got).all()
-    def convergence(y):
-        return float(np.linalg.norm(np.abs(O.transform(o, y.astype(np.float64))) - mag) / np.linalg.norm(mag))
-    cg, cw = convergence(got), convergence(want)
-    assert cg <= 1.05 * cw + 1e-6, (cg, cw)
-    assert rel(got, want.astype(np.float64)) <= 2e-2
-    S.set_interior("float64")
-    try:
-        strict = Stft.griffin_lim(c, mag, n_iter=32, momentum=0.99, init=phase)
-    finally:
-        S.set_interior("float32")
-    assert np.linalg.norm(strict - want) <= 1e-5 * np.linalg.norm(want)
+    dev, yard = [], []
+    for seed in range(1000, 1048):
+        rng = np.random.default_rng(seed)
+        x = rng.uniform(-1, 1, size=(1, 24000)).astype(np.float32)
+        mag = np.abs(Stft.transform(c, x)).astype(np.float32)
+        phase = rng.uniform(-np.pi, np.pi, size=mag.shape).astype(np.float32)   # (the default is a random phase: stft.ml:976-984)
+        want = O.griffin_lim(o, mag, 32, 0.99, phase, None).astype(np.float64)
+        got = Stft.griffin_lim(c, mag, n_iter=32, momentum=0.99, init=phase)
+        assert got.shape == want.shape and np.isfinite(got).all(), seed
+        dev.append(rel(got, want))
+        yard.append(rel(O.griffin_lim_float32_storage(o, mag, 32, 0.99, phase, None), want))
+        conv = lambda y: float(np.linalg.norm(np.abs(O.transform(o, y.astype(np.float64))) - mag) / np.linalg.norm(mag))
+        cg, cw = conv(got), conv(want)
+        assert cg <= 1.01 * cw + 1e-6, (seed, cg, cw)
+        if seed == 1000:
+            short = O.griffin_lim(o, mag, 2, 0.99, phase, None).astype(np.float64)
+            assert rel(Stft.griffin_lim(c, mag, n_iter=2, momentum=0.99, init=phase), short) <= 1e-5
+            S.set_interior("float64")
+            try:
+                strict = Stft.griffin_lim(c, mag, n_iter=32, momentum=0.99, init=phase)
+            finally:
+                S.set_interior("float32")
+            assert np.linalg.norm(strict - want) <= 1e-5 * np.linalg.norm(want)
+    dev, yard = np.asarray(dev), np.asarray(yard)
+    assert np.median(dev) <= GL_GATE_K * np.median(yard), (np.median(dev), np.median(yard))
+    assert dev.max() <= GL_GATE_K * yard.max(), (dev.max(), yard.max())
 
 
 @pytest.mark.parametrize("fft,hop", [(1024, 256), (512, 100), (4096, 1024)])

@@ -28,6 +28,9 @@ def close(a, e, rtol, atol_rel, what, floor=0.0):
         what, int(bad.sum()), e.size, float(np.max(np.abs(a.astype(np.complex128) - e))), peak)
 
 
+GL_PAIRS = []   # (device's rel l2 to the float64 oracle, the float32-storage yardstick's) of every Griffin-Lim draw
+
+
 def feature_case(rng):
     """One draw of the callers around the STFT; returns the parameters it used (for the failure line)."""
     which = str(rng.choice(["mel_apply", "mfcc", "db", "spectral", "chroma", "fir", "griffin_lim"]))
@@ -118,16 +121,16 @@ def feature_case(rng):
             want = O.griffin_lim(o, mag, n_iter=n_iter, momentum=mom, init=init)
             if os.environ.get("FUZZ_DUMP_GL") and not (np.linalg.norm(got - want) < 1e-3 * np.linalg.norm(want)):   # keep the draw for a replay
                 np.savez(os.path.join(os.environ["FUZZ_DUMP_GL"], "gl_case_%d_%d_%g.npz" % (fft, n_iter, mom)), mag=mag, init=init, fft=fft, hop=hop, n_iter=n_iter, mom=mom)
-            # the unit-modulus step is ill-conditioned where a bin is nearly silent: the float32 interior is held to
-            # the norm bound of tests/test_gpu_parity.py, the float64 one to the pointwise one
-            # (round 5: ... or, where a nearly silent bin has turned the trajectory -- one draw in ~1500, whichever synthesis kernel: the
-            # fused loop equals plain invert / transform / unit() by hand bit for bit on such draws, tools/gl_manual_check.py --, to the
-            # oracle's spectral convergence within 5 % and its basin within 5 %)
+            # The unit-modulus step is ill-conditioned where a bin is nearly silent, and with momentum the loop is chaotic: one draw's
+            # distance to the float64 oracle says little (round 5 gated it at 1e-3 and fell back to a convergence check on the draws
+            # that turned).  Round 6: every draw is paired with the YARDSTICK's distance on the same draw (the float64 oracle with its
+            # stored intermediates rounded to float32, O.griffin_lim_float32_storage) and the sweep is judged at its end by the gate
+            # of tests/test_gpu_parity.py::test_griffin_lim_defaults_statistical_gate: median and maximum of the device's distances
+            # within 16 x the yardstick's.  Per draw only what holds for every trajectory: finite, and inside the oracle's basin.
             rel_gl = float(np.linalg.norm(got - want) / np.linalg.norm(want))
-            if not rel_gl < 1e-3:
-                conv = lambda y: float(np.linalg.norm(np.abs(O.transform(o, y.astype(np.float64))) - mag) / np.linalg.norm(mag))
-                assert got.shape == want.shape and rel_gl < 5e-2 and conv(got) <= 1.05 * conv(want) + 1e-6, \
-                    "griffin_lim: relative l2 error %.3g, convergence %.4g against the oracle's %.4g" % (rel_gl, conv(got), conv(want))
+            rel_yard = float(np.linalg.norm(O.griffin_lim_float32_storage(o, mag, n_iter, mom, init) - want) / np.linalg.norm(want))
+            GL_PAIRS.append((rel_gl, rel_yard))
+            assert got.shape == want.shape and np.isfinite(got).all() and rel_gl < 5e-2, "griffin_lim: relative l2 error %.3g (the yardstick's %.3g)" % (rel_gl, rel_yard)
             S.set_interior("float64")
             try:
                 close(Stft.griffin_lim(c, mag, n_iter=n_iter, momentum=mom, init=init), want, 1e-5, 1e-5, "griffin_lim (float64 interior)")
@@ -146,6 +149,12 @@ if len(sys.argv) > 3 and sys.argv[3] == "features":
         r = feature_case(rng)
         fails += r is False
         skipped += r is None
+    if GL_PAIRS:   # the statistical gate of tests/test_gpu_parity.py::test_griffin_lim_defaults_statistical_gate over the sweep's draws
+        d, y = np.asarray(GL_PAIRS).T
+        ok = bool(np.median(d) <= 16.0 * np.median(y) and d.max() <= 16.0 * y.max())
+        print("griffin_lim: %d draws, device median %.3g / max %.3g, float32-storage oracle median %.3g / max %.3g: %s"
+              % (len(d), np.median(d), d.max(), np.median(y), y.max(), "inside 16 x the yardstick" if ok else "OUTSIDE 16 x the yardstick"))
+        fails += not ok
     print("%d feature cases (%d drew a filterbank the reference rejects), %d failures" % (cases, skipped, fails))
     sys.exit(min(fails, 100))
 for case in range(cases):

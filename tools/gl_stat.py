@@ -11,22 +11,7 @@ import soundml_amd as S
 from soundml_amd import Stft
 
 
-def rounded_gl(c, s, n_iter, momentum, init):
-    """O.griffin_lim with the stored intermediates rounded to float32 (arithmetic still float64)."""
-    magnitudes = s.astype(np.float64).astype(np.complex128)
-    p = init.astype(np.float64)
-    angles = np.cos(p) + 1j * np.sin(p)
-    frames_ = s.shape[-1]
-    beta = momentum / (1.0 + momentum)
-    previous = None
-    tiny = float(np.finfo(np.float64).tiny)
-    for _ in range(n_iter):
-        y = O.synthesise(c, magnitudes * angles).astype(np.float32).astype(np.float64)
-        rebuilt = O.transform_range(c, y, 0, frames_, np.complex128).astype(np.complex64).astype(np.complex128)
-        extrapolated = rebuilt if previous is None else rebuilt - previous * beta
-        angles = extrapolated / (np.abs(extrapolated) + tiny)
-        previous = rebuilt
-    return O.synthesise(c, magnitudes * angles, None).astype(np.float32)
+rounded_gl = O.griffin_lim_float32_storage   # the yardstick (oracle/soundml_oracle.py)
 
 
 def main():
