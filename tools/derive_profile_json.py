@@ -16,6 +16,7 @@ c = head["counters"]
 read_b, write_b = int(c["FETCH_SIZE"] * 1024 * 2), int(c["WRITE_SIZE"] * 1024)
 algo = 256 * 938 * 6148
 json.dump({"bytes_per_launch": read_b + write_b, "read_bytes": read_b, "write_bytes": write_b, "algorithmic_bytes": algo,
+           "fetch_factor": 2, "fetch_factor_why": "TCC_EA0_RDREQ %.2f M requests for 491.5 MB of audio = %.0f B per request: 128-byte requests, which FETCH_SIZE tallies at 64" % (c.get("TCC_EA0_RDREQ_sum", 0) / 1e6, 256 * 480000 * 4 / max(1.0, c.get("TCC_EA0_RDREQ_sum", 1.0))),
            "write_amplification": round(write_b / (256 * 938 * 4100), 3),
            "note": "one launch of the C2 workload (938 frames per clip); FETCH_SIZE doubled per the gfx950 correction (calibrated for "
                    "16 B/lane streams; these loads are 8 B/lane, so the read side is an upper estimate between 1x and 2x FETCH_SIZE); "
@@ -29,24 +30,50 @@ json.dump({"bytes_per_launch": read_b + write_b, "read_bytes": read_b, "write_by
            "per_kernel": None}, open(os.path.join(ROOT, "profiles", "hbm_traffic.json"), "w"), indent=1)
 # every hot kernel: counter traffic against its algorithmic bytes (the launches of tools/pmc_driver.py)
 FR2048, FR1K, FR512, FR256 = 938, 1723, 3446, 6891
-ALGO = {"stft2048_power32": 256 * FR2048 * 6148, "stft2048_complex32": 256 * FR2048 * (2048 + 8200), "stft2048_complex_fm": 256 * FR2048 * (2048 + 8200),
-        "istft2048_pipe_kernel<true, true>": 256 * FR2048 * (8200 * 2 + 4100 + 2048), "stft2048_mel32": 256 * FR2048 * (2048 + 512),
-        "istft2048": 256 * FR2048 * (8200 + 2048), "mel_apply_mfma": 256 * FR2048 * (4100 + 512), "fir_ols_split": 8 * 2880000 * 8,
-        "stft_power_lanes_kernel<16": 256 * FR1K * (1024 + 2052), "stft_power_lanes_kernel<8": 256 * FR512 * (512 + 1028),
-        "stft_power_lanes_kernel<4": 256 * FR256 * (256 + 516),
-        "wide64::stft2048_power_wide": 256 * FR2048 * 6148}
+# (bytes read, bytes written) that the kernel must move per launch of tools/pmc_driver.py
+ALGO = {"stft2048_power32": (256 * FR2048 * 2048, 256 * FR2048 * 4100), "stft2048_complex32": (256 * FR2048 * 2048, 256 * FR2048 * 8200),
+        "stft2048_complex_fm": (256 * FR2048 * 2048, 256 * FR2048 * 8200),
+        "istft2048_pipe_kernel<true, true>": (256 * FR2048 * (8200 * 2 + 4100), 256 * FR2048 * 2048), "stft2048_mel32": (256 * FR2048 * 2048, 256 * FR2048 * 512),
+        "istft2048": (256 * FR2048 * 8200, 256 * FR2048 * 2048), "mel_apply_mfma": (256 * FR2048 * 4100, 256 * FR2048 * 512), "fir_ols": (8 * 2880000 * 4, 8 * 2880000 * 4),
+        "stft_power_lanes_kernel<16": (256 * FR1K * 1024, 256 * FR1K * 2052), "stft_power_lanes_kernel<8": (256 * FR512 * 512, 256 * FR512 * 1028),
+        "stft_power_lanes_kernel<4": (256 * FR256 * 256, 256 * FR256 * 516),
+        "wide64::stft2048_power_wide": (256 * FR2048 * 2048, 256 * FR2048 * 4100)}
+
+
+def fetch_factor(cc, algo_read):
+    """FETCH_SIZE = TCC_EA0_RDREQ x 64 B on gfx950 whatever the request's size (MI355X_MICROARCH.md: a 128-byte request is tallied
+    at 64).  Which size a kernel's requests have is read off the request counter against the bytes the kernel must read: the
+    power spectrogram's 4.00 M requests fetch 491.5 MB = 123 B each (128-byte requests: x 2), the inverse pipeline's 28.9 M fetch
+    1.969 GB = 68 B each (64-byte requests: x 1; x 2 would claim 1.7x the spectra it reads).  x 1 where the requests come out
+    below 96 bytes each AND FETCH_SIZE x 1 already covers (>= 0.9 of) the algorithmic reads; x 2 otherwise (an upper bound where the sizes mix)."""
+    req = cc.get("TCC_EA0_RDREQ_sum")
+    if not req or not algo_read:
+        return 2, None, "no request counter: the guide's x 2"
+    per = algo_read / req
+    x1 = cc["FETCH_SIZE"] * 1024
+    if per < 96 and x1 >= 0.90 * algo_read:
+        return 1, per, "%.0f B of algorithmic reads per TCC_EA0_RDREQ request: 64-byte requests, FETCH_SIZE as reported" % per
+    return 2, per, ("%.0f B of algorithmic reads per TCC_EA0_RDREQ request: 128-byte requests, FETCH_SIZE x 2" % per) if per >= 96 else \
+        ("%.0f B of algorithmic reads per request but FETCH_SIZE x 1 is below the algorithmic reads: mixed request sizes, x 2 is an upper bound" % per)
+
+
 table = {}
 for name, v in k.items():
     cc = v["counters"]
     if "FETCH_SIZE" not in cc or "WRITE_SIZE" not in cc:
         continue
-    algo_b = next((b for key, b in ALGO.items() if name.startswith(key)), None)
-    rb, wb = int(cc["FETCH_SIZE"] * 1024 * 2), int(cc["WRITE_SIZE"] * 1024)
-    table[name] = {"read_bytes_fetch_x2": rb, "write_bytes": wb, "algorithmic_bytes": algo_b,
+    algo_rw = next((b for key, b in ALGO.items() if name.startswith(key)), None)
+    algo_b = sum(algo_rw) if algo_rw else None
+    factor, per_req, why = fetch_factor(cc, algo_rw[0] if algo_rw else None)
+    rb, wb = int(cc["FETCH_SIZE"] * 1024 * factor), int(cc["WRITE_SIZE"] * 1024)
+    table[name] = {"read_bytes": rb, "fetch_factor": factor, "fetch_factor_why": why, "write_bytes": wb, "algorithmic_bytes": algo_b,
+                   "algorithmic_read_bytes": algo_rw[0] if algo_rw else None, "algorithmic_write_bytes": algo_rw[1] if algo_rw else None,
                    "traffic_over_algorithmic": round((rb + wb) / algo_b, 3) if algo_b else None,
-                   # FETCH_SIZE as reported (the x2 correction is calibrated on 16 B/lane streams; every kernel here requests 8 B per lane, so the
-                   # truth lies between the two figures: the inverse kernel reads 1.97 GB of spectra and FETCH_SIZE x 1 says 1.85)
-                   "traffic_over_algorithmic_fetch_x1": round((rb // 2 + wb) / algo_b, 3) if algo_b else None,
+                   "read_over_algorithmic": round(rb / algo_rw[0], 3) if algo_rw else None, "write_over_algorithmic": round(wb / algo_rw[1], 3) if algo_rw else None,
+                   # the other choice of the factor, for the record
+                   "traffic_over_algorithmic_other_factor": round((int(cc["FETCH_SIZE"] * 1024 * (3 - factor)) + wb) / algo_b, 3) if algo_b else None,
+                   # what the CU's memory pipe carried: vector-memory read instructions x 512 B (64 lanes x 8 B) against the algorithmic reads
+                   "vmem_read_request_bytes_over_algorithmic_reads": round(cc["SQ_INSTS_VMEM_RD"] * 512 / algo_rw[0], 3) if (algo_rw and cc.get("SQ_INSTS_VMEM_RD")) else None,
                    "avg_us": round(v["duration"]["avg_us"], 1) if v.get("duration") else None,
                    "lds_bank_conflict_over_active": round(cc["SQ_LDS_BANK_CONFLICT"] / cc["SQ_LDS_IDX_ACTIVE"], 4) if cc.get("SQ_LDS_IDX_ACTIVE") else None}
 # the bench line of the traced run itself (profiles/<round>/bench_n1.json): every kernel's duration in that run's trace beside the

@@ -1,6 +1,6 @@
 """Griffin-Lim at the reference's defaults (32 iterations, momentum 0.99: stft.ml:961-1017) over MANY seeds: the distribution of
 the device's distance to the float64 oracle beside the yardstick -- the ORACLE ITSELF with nothing but its stored intermediates
-rounded to float32 (tools/gl_growth.py: rounded_gl).  The statistical gate of tests/test_gpu_parity.py
+rounded to float32 (O.griffin_lim_float32_storage).  The statistical gate of tests/test_gpu_parity.py
 (test_griffin_lim_defaults_statistical_gate) takes its bound from this table.
   python tools/gl_stat.py [seeds=48] [first_seed=1000]      GL_ITERS / GL_MOMENTUM / GL_N / GL_INTERIOR=float64 vary the case"""
 import json, os, sys
