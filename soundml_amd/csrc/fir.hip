@@ -47,6 +47,9 @@ struct smx_fir_plan {
     float2 *h_split = nullptr;  // h_half[16 k' + r] at [1024 r + k'], h_half[M] at [M]
     float2 *w_split = nullptr;  // exp(-2 pi i (16 k' + r) / N) at [1024 r + k']
     float2 *tw_1k = nullptr;    // exp(-2 pi i j / 1024), j < 512
+    // register-pipeline kernel (fir_ols_pk32_kernel): W_1024^(l k1) in the order its lanes read it -- rows m < 15 hold the pair
+    // k1 = 2 m + 1, 2 m + 2 per lane l (a float4), then one row of k1 = 31 (as stft_fast_p32.hpp's twA4 / twA31)
+    float2 *tw_a32 = nullptr;
   };
   const Tables &tables() const;
   ~smx_fir_plan();
@@ -79,6 +82,7 @@ struct FirArgs {
   const float2 *h_half; // H[k] / (4 M), k <= M
   const float2 *tw_m;   // exp(-2 pi i j / M), j < M/2
   const float2 *h_split, *w_split, *tw_1k;   // wave-split kernel
+  const float2 *tw_a32;                      // register-pipeline kernel
   int64_t lead;         // samples of every circular result that are discarded (even, >= taps - 1)
   int64_t step;         // block advance = N - lead (even)
   int64_t blocks_per_channel;
@@ -383,6 +387,299 @@ __global__ void __launch_bounds__(1024, 4) fir_ols_split_kernel(FirArgs a) {
       }
     }
   }
+}
+
+// ---- N = 32768 on the frame pipeline's register form (round 6): fir_ols_pk32_kernel ---------------------------------------------
+// What bounded fir_ols_split_kernel (profiles/r06/fir_channels.log, profiles/r07 PMC): 22-27 us per block and CU whatever the channel
+// count -- ~3000 vector instructions per thread x 16 waves (a third of them address arithmetic of the XOR-swizzled Stockham passes)
+// and nine to ten trips of the 128 KB block through LDS, one after the other because five workgroup barriers keep all sixteen waves
+// in the same phase.  Here the same decomposition M = 16384 = 16 x 1024 runs on the STFT pipeline's register form (stft_fast_p32.hpp):
+//   * a 1024-point sub-transform lives in a HALF-WAVE, 32 lanes x 32 points, 1024 = 32 x 32: radix-32 in registers, the twiddle
+//     W_1024^(l k1) from an LDS table, ONE 32 x 32 transposition through the sub-transform's own LDS region (pitch-33 cells, conflict
+//     free), radix-32 in registers -- one LDS exchange per sub-transform where the Stockham form has two, no swizzle arithmetic;
+//   * every butterfly is packed float32 (the generated v_pk_* stages of stft_pk_fft.inc, one issue slot per complex add / half a
+//     complex product), the twiddle powers of the cross-block passes and the pointwise stage too (pk_powers16, pk_ols_pairs1);
+//   * 512 threads (8 waves, 32 points a thread, up to 256 registers) instead of 1024 x 16 points.
+// Per block: radix-16 across the block (thread n' takes columns n' and n' + 512) -> [barrier] -> sub-transforms -> [barrier] -> pointwise
+// pairs (k, M - k) -> [barrier] -> sub-transforms -> [barrier] -> radix-16 across the block, stores.  Same arithmetic as the split kernel up
+// to the order of roundings inside a complex product (p32_cmul's form); parity is the FIR contract's (1e-5 sum|h|, tests).
+using f2 = float __attribute__((ext_vector_type(2)));
+#include "stft_pk_fft.inc"
+__device__ __forceinline__ void pk_fft32_nat(f2 (&v)[32]) {   // 32-point forward DFT, natural order in and out (stft_fast_p32.hpp: pk_fft32)
+  f2 e[16], o[16];
+#pragma unroll
+  for (int m = 0; m < 16; ++m) { e[m] = v[2 * m]; o[m] = v[2 * m + 1]; }
+  pk_fft16(e);
+  pk_fft16(o);
+  pk_fft32_combine0(v, e, o);
+  pk_fft32_combine1(v, e, o);
+}
+constexpr int kPkM = 16384;
+constexpr size_t kPkTwBytes = 31 * 32 * sizeof(float2);
+constexpr size_t kPkLds = (size_t)kPkM * sizeof(float2) + kPkTwBytes;   // 139,008 B: one workgroup per CU
+static_assert(kPkLds <= 160 * 1024, "LDS budget");
+
+// the 1024-point forward transform of a half-wave, registers to registers: lane l holds points l + 32 j in v on entry and bins
+// l + 32 q in t on return; `cells` = 1056 four-byte cells of LDS that belong to the half-wave for the duration
+struct PkNoMid {
+  __device__ __forceinline__ void operator()() const {}
+};
+// `mid()` runs once the transposition's reads are issued: v is dead there, so requests placed in it have their registers and the
+// second radix-32 pass to arrive under
+template <class Mid = PkNoMid>
+__device__ __forceinline__ void pk_sub1024(f2 (&v)[32], f2 (&t)[32], float *cells, int l, const float4 *twA4, const float2 *twA31, const Mid &mid = Mid{}) {
+  float4 tw[15];
+#pragma unroll
+  for (int m = 0; m < 15; ++m) tw[m] = twA4[32 * m + l];
+  const float2 tw31 = twA31[l];
+  __builtin_amdgcn_sched_barrier(0);
+  pk_fft32_nat(v);   // y_l[k1] = sum_j a[l + 32 j] W_32^(j k1)
+  __builtin_amdgcn_sched_barrier(0);
+#define SMX_TWV(m) f2{tw[m].x, tw[m].y}, f2{tw[m].z, tw[m].w}
+  pk_twiddle8(v[1], v[2], v[3], v[4], v[5], v[6], v[7], v[8], SMX_TWV(0), SMX_TWV(1), SMX_TWV(2), SMX_TWV(3));
+  pk_twiddle8(v[9], v[10], v[11], v[12], v[13], v[14], v[15], v[16], SMX_TWV(4), SMX_TWV(5), SMX_TWV(6), SMX_TWV(7));
+  pk_twiddle8(v[17], v[18], v[19], v[20], v[21], v[22], v[23], v[24], SMX_TWV(8), SMX_TWV(9), SMX_TWV(10), SMX_TWV(11));
+  pk_twiddle7(v[25], v[26], v[27], v[28], v[29], v[30], v[31], SMX_TWV(12), SMX_TWV(13), SMX_TWV(14), f2{tw31.x, tw31.y});
+#undef SMX_TWV
+  __builtin_amdgcn_sched_barrier(0);
+  // lane l register k1 -> lane k1 register l: lane l writes register j to cell 33 l + j, lane k1 reads register l' from cell
+  // 33 l' + k1 (bank = lane + register mod 32 on both sides: conflict free); the real parts, then the imaginary parts.  A wave's
+  // LDS operations execute in order, so no wait separates the rounds.
+  float *wc = cells + 33 * l, *rc = cells + l;
+#pragma unroll
+  for (int j = 0; j < 32; ++j) wc[j] = v[j].x;
+#pragma unroll
+  for (int i = 0; i < 32; ++i) t[i].x = rc[33 * i];
+#pragma unroll
+  for (int j = 0; j < 32; ++j) wc[j] = v[j].y;
+#pragma unroll
+  for (int i = 0; i < 32; ++i) t[i].y = rc[33 * i];
+  __builtin_amdgcn_sched_barrier(0);
+  mid();
+  __builtin_amdgcn_sched_barrier(0);
+  pk_fft32_nat(t);   // lane k1, register q: bin k1 + 32 q
+  __builtin_amdgcn_sched_barrier(0);
+}
+
+// A WAVE holds a sub-transform and its partner in the pointwise stage: half 0 sub-transform r, half 1 sub-transform 16 - r (waves
+// 1 .. 7; wave 0: sub-transforms 0 and 8, which pair inside themselves).  Bin k = 16 k' + r pairs with M - k = 16 (1023 - k') + (16 - r):
+// lane l, register q of one half against lane 31 - l, register 31 - q of the other -- so forward sub-transform, pointwise stage and
+// inverse sub-transform are ONE chain inside the wave, through the wave's own LDS cells and with no workgroup barrier: the eight
+// waves drift apart and one wave's LDS round trips run under the others' butterflies (fir_ols_split_kernel held all sixteen waves
+// in one phase with a barrier either side of the pointwise stage and sent the block through LDS twice more).
+// Every pair is formed ONCE, by the member with q < 16: exchange 1 hands it the partner's registers 16 .. 31, exchange 2 returns
+// the partner's results.  Sub-transform 0 pairs (0, k') with (0, 1024 - k'): lane (32 - l) mod 32, and lane 0 pairs inside itself one
+// register further (k' = 32 q with 32 (32 - q)); k' = 0 (whose partner in the product is bin M) and k' = 512 pair with themselves.
+template <bool ALIGNED>
+__global__ void __launch_bounds__(512) fir_ols_pk32_kernel(FirArgs a) {
+  constexpr int M = kPkM;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  f2 *z = reinterpret_cast<f2 *>(smem);   // [16][1024]: sub-transform r at z + 1024 r
+  const float4 *twA4 = reinterpret_cast<const float4 *>(smem + (size_t)M * sizeof(float2));
+  const float2 *twA31 = reinterpret_cast<const float2 *>(smem + (size_t)M * sizeof(float2) + 15 * 32 * sizeof(float4));
+  const int tid = threadIdx.x;
+  for (int i = tid; i < 31 * 32; i += 512) reinterpret_cast<float2 *>(smem + (size_t)M * sizeof(float2))[i] = a.tw_a32[i];
+  // columns tid and tid + 512 of the block: element n = column + 1024 q, q < 16
+  auto load_block = [&](int64_t b, f2 (&va)[16], f2 (&vb)[16]) {
+    const int64_t channel = b / a.blocks_per_channel, blk = b % a.blocks_per_channel;
+    const float *x = a.x + channel * a.x_stride;
+    const int64_t base = blk * a.step - a.lead;      // first sample of the window (even)
+    int tl = threadIdx.x;
+    asm volatile("" : "+v"(tl));
+    if (ALIGNED && base >= 0 && base + 2 * M <= a.n) {     // the whole window lies inside the stream (block-uniform)
+      // (a wave-uniform base and ONE 32-bit lane offset: the sixteen row offsets are immediates)
+      const char *src = reinterpret_cast<const char *>(x + base);
+      const unsigned off = 8u * (unsigned)tl;
+#pragma unroll
+      for (int q = 0; q < 16; ++q) {
+        const float2 p0 = *reinterpret_cast<const float2 *>(src + (size_t)(off + 8192u * (unsigned)q));
+        const float2 p1 = *reinterpret_cast<const float2 *>(src + (size_t)(off + 8192u * (unsigned)q + 4096u));
+        va[q] = f2{p0.x, p0.y};
+        vb[q] = f2{p1.x, p1.y};
+      }
+    } else {
+#pragma unroll
+      for (int q = 0; q < 16; ++q) {
+        const int64_t g0 = base + 2 * (int64_t)(tl + 1024 * q), g1 = g0 + 1024;
+        va[q] = f2{(g0 >= 0 && g0 < a.n) ? x[g0] : 0.0f, (g0 + 1 >= 0 && g0 + 1 < a.n) ? x[g0 + 1] : 0.0f};
+        vb[q] = f2{(g1 >= 0 && g1 < a.n) ? x[g1] : 0.0f, (g1 + 1 >= 0 && g1 + 1 < a.n) ? x[g1 + 1] : 0.0f};
+      }
+    }
+  };
+  const int64_t total = a.channels * a.blocks_per_channel;
+#ifdef SMX_STAMPS
+  unsigned long long stamp_sum[kStampSlots] = {0}, stamp_prev;
+  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(stamp_prev)::"memory");
+  const unsigned long long clk_t0 = stamp_prev, clk_r0 = __builtin_amdgcn_s_memrealtime();
+#endif
+  const float2 w1a_ = a.tw_m[tid], w1b_ = a.tw_m[tid + 512];   // W_M^(column): the same for every block of this thread
+  const f2 w1a = {w1a_.x, w1a_.y}, w1b = {w1b_.x, w1b_.y};
+  f2 na[16], nb[16];
+  load_block(blockIdx.x, na, nb);
+  __syncthreads();   // the twiddle table
+  for (int64_t b = blockIdx.x; b < total; b += gridDim.x) {
+    {   // radix-16 across the block, then W_M^(n' r): u_r[n'] for sub-transform r
+      f2 w[16];
+      pk_fft16(na);
+      w[1] = w1a;
+      pk_powers16(w);
+      pk_twiddle8(na[1], na[2], na[3], na[4], na[5], na[6], na[7], na[8], w[1], w[2], w[3], w[4], w[5], w[6], w[7], w[8]);
+      pk_twiddle7(na[9], na[10], na[11], na[12], na[13], na[14], na[15], w[9], w[10], w[11], w[12], w[13], w[14], w[15]);
+      pk_fft16(nb);
+      w[1] = w1b;
+      pk_powers16(w);
+      pk_twiddle8(nb[1], nb[2], nb[3], nb[4], nb[5], nb[6], nb[7], nb[8], w[1], w[2], w[3], w[4], w[5], w[6], w[7], w[8]);
+      pk_twiddle7(nb[9], nb[10], nb[11], nb[12], nb[13], nb[14], nb[15], w[9], w[10], w[11], w[12], w[13], w[14], w[15]);
+      int tw_ = tid;
+      asm volatile("" : "+v"(tw_));
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { z[1024 * r + tw_] = na[r]; z[1024 * r + tw_ + 512] = nb[r]; }
+    }
+    SMX_STAMP(0);
+    __syncthreads();
+    SMX_STAMP(1);
+#ifdef SMX_STAMPS
+    ++stamp_sum[22];
+#endif
+    {
+      int ls = tid;
+      asm volatile("" : "+v"(ls));
+      const int l = ls & 31, h = (ls >> 5) & 1, wave = ls >> 6;
+      const int rs = wave ? (h ? 16 - wave : wave) : 8 * h;   // this half-wave's sub-transform
+      f2 *zr = z + 1024 * rs;
+      f2 v[32], t[32];
+#pragma unroll
+      for (int j = 0; j < 32; ++j) v[j] = zr[l + 32 * j];
+      // the pointwise stage's tables for this lane's pairs q < 16, bin (rs, kq = l + 32 q): w_k, H_k and H_(M-k) (the same for every
+      // block of this thread, but 48 values do not stay in registers across the sub-transforms): requested inside the forward
+      // sub-transform, behind its transposition, where the first pass's registers are free
+      // (a wave-uniform base and a 32-bit unsigned lane offset per request: no 64-bit address pair per value)
+      auto tab = [](const float2 *base, unsigned idx) { return *reinterpret_cast<const float2 *>(reinterpret_cast<const char *>(base) + (size_t)(idx * 8u)); };
+      const unsigned rp = (16u - (unsigned)rs) & 15u, ul = (unsigned)l, urs = (unsigned)rs;
+      float2 pw[16], phk[16], php[16], w5, h5;
+      auto request_tables = [&]() {
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+          const unsigned kq = ul + 32u * (unsigned)q;
+          pw[q] = tab(a.w_split, 1024u * urs + kq);
+          phk[q] = tab(a.h_split, 1024u * urs + kq);
+        }
+      };
+      auto request_partner_tables = [&]() {   // behind exchange 1's writes: registers 16 .. 31 of the sub-transform are parked by then
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+          const unsigned kq = ul + 32u * (unsigned)q;
+          php[q] = tab(a.h_split, (urs == 0u && kq == 0u) ? (unsigned)M : 1024u * rp + (urs ? 1023u - kq : 1024u - kq));
+        }
+        w5 = tab(a.w_split, 512u);   // bin M/2 = (0, 512): lane 0 of sub-transform 0, with itself
+        h5 = tab(a.h_split, 512u);
+      };
+      pk_sub1024(v, t, reinterpret_cast<float *>(zr), l, twA4, twA31, request_tables);
+      SMX_STAMP(2);
+      // exchange 1: rows of 17 eight-byte cells per lane (rows two banks apart: a half-wave's 32 accesses spread evenly over the banks);
+      // a lane parks registers 16 .. 31 in cells 0 .. 15 of its row and register 0 in cell 16 (where lane 0 of sub-transform 0 finds
+      // the partner of bin 0: itself); it reads, for q < 16, register 31 - q of its partner lane: cell 15 - q of that row -- lane 0 of
+      // sub-transform 0: its OWN register 32 - q, cell 16 - q of its own row
+      // the rows live in the half-wave's own region (32 x 17 x 8 = 4352 of its 8192 bytes; the transposition's cells before and after
+      // use the same bytes -- a wave's LDS operations execute in order).  Partner: waves 1 .. 7 the other half's lane 31 - l; wave 0
+      // the same half's lane 31 - l (sub-transform 8) or (32 - l) mod 32 (sub-transform 0)
+      const int partner_lane = wave ? 31 - l : (h ? 31 - l : (32 - l) & 31);
+      f2 *own_row = zr + 17 * l;
+      f2 *partner_row = (wave ? z + 1024 * (16 - rs) : zr) + 17 * partner_lane + ((wave == 0 && h == 0 && l == 0) ? 1 : 0);
+#pragma unroll
+      for (int q = 16; q < 32; ++q) own_row[q - 16] = t[q];
+      own_row[16] = t[0];
+      request_partner_tables();
+      f2 pb[16];
+#pragma unroll
+      for (int q = 0; q < 16; ++q) pb[q] = partner_row[15 - q];
+      // the pairs
+      f2 bq[16];
+#pragma unroll
+      for (int q = 0; q < 16; ++q) {
+        bq[q] = pb[q];
+        pk_ols_pairs1(t[q], bq[q], f2{pw[q].x, pw[q].y}, f2{phk[q].x, phk[q].y}, f2{php[q].x, php[q].y});
+      }
+      f2 mid = t[16], mid_b = t[16];
+      pk_ols_pairs1(mid, mid_b, f2{w5.x, w5.y}, f2{h5.x, h5.y}, f2{h5.x, h5.y});
+      // exchange 2: the partner members' results go back: cell q of the own row holds the result for the partner's register 31 - q
+#pragma unroll
+      for (int q = 0; q < 16; ++q) own_row[q] = bq[q];
+#pragma unroll
+      for (int Q = 16; Q < 32; ++Q) t[Q] = partner_row[31 - Q];
+      if (wave == 0 && h == 0 && l == 0) t[16] = mid;   // bin M/2 pairs with itself (the read above fetched cell 16 of the own row: stale)
+      SMX_STAMP(3);
+      // inverse sub-transform (as conj(FFT(conj .)): the pairs stored conjugates), its points back into the region for the last pass
+      pk_sub1024(t, v, reinterpret_cast<float *>(zr), l, twA4, twA31);
+#pragma unroll
+      for (int q = 0; q < 32; ++q) zr[l + 32 * q] = v[q];
+    }
+    // the next block's samples are requested HERE, before the barrier: the sub-transforms' registers are free, and the requests have
+    // the barrier, the last pass's LDS reads, its barrier and its arithmetic to arrive under (behind the second barrier, as the split
+    // kernel has them, a block opened with ~1 us of exposed HBM latency: eight waves do not cover it)
+    if (b + gridDim.x < total) load_block(b + gridDim.x, na, nb);
+    SMX_STAMP(4);
+    __syncthreads();
+    SMX_STAMP(5);
+    int to = tid;
+    asm volatile("" : "+v"(to));
+    f2 va[16], vb[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { va[r] = z[1024 * r + to]; vb[r] = z[1024 * r + to + 512]; }
+    __syncthreads();   // every thread holds its columns: the next block's first pass may overwrite the buffer
+    SMX_STAMP(6);
+    {
+      f2 w[16];
+      w[1] = w1a;
+      pk_powers16(w);
+      pk_twiddle8(va[1], va[2], va[3], va[4], va[5], va[6], va[7], va[8], w[1], w[2], w[3], w[4], w[5], w[6], w[7], w[8]);
+      pk_twiddle7(va[9], va[10], va[11], va[12], va[13], va[14], va[15], w[9], w[10], w[11], w[12], w[13], w[14], w[15]);
+      pk_fft16(va);
+      w[1] = w1b;
+      pk_powers16(w);
+      pk_twiddle8(vb[1], vb[2], vb[3], vb[4], vb[5], vb[6], vb[7], vb[8], w[1], w[2], w[3], w[4], w[5], w[6], w[7], w[8]);
+      pk_twiddle7(vb[9], vb[10], vb[11], vb[12], vb[13], vb[14], vb[15], w[9], w[10], w[11], w[12], w[13], w[14], w[15]);
+      pk_fft16(vb);
+    }
+    SMX_STAMP(7);
+    const int64_t channel = b / a.blocks_per_channel, blk = b % a.blocks_per_channel;
+    float *y = a.y + channel * a.y_stride;
+    const int64_t out0 = blk * a.step - a.out_shift;   // y index of the block's first kept sample
+    const bool whole = out0 >= 0 && out0 + a.step <= a.n_out;
+    if (ALIGNED && whole) {   // (block-uniform) every kept sample of the block is wanted: 32-bit positions, one unsigned compare per value
+      char *dst = reinterpret_cast<char *>(y + out0);
+      const int s0 = 2 * to - (int)a.lead;
+      const unsigned span = (unsigned)a.step;
+#pragma unroll
+      for (int q = 0; q < 16; ++q)
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+          const int sp = s0 + 1024 * c + 2048 * q;   // position inside the kept span (even)
+          const f2 v = c ? vb[q] : va[q];
+          if ((unsigned)sp < span) *reinterpret_cast<float2 *>(dst + (size_t)(4u * (unsigned)sp)) = make_float2(v.x, -v.y);   // conj(FFT(conj .))
+        }
+    } else {
+#pragma unroll
+      for (int q = 0; q < 16; ++q)
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+          const int64_t sp = 2 * (int64_t)(to + 512 * c + 1024 * q) - a.lead;
+          if (sp >= 0 && sp < a.step) {
+            const int64_t o = out0 + sp;
+            const f2 v = c ? vb[q] : va[q];
+            if (o >= 0 && o < a.n_out) y[o] = v.x;
+            if (o + 1 >= 0 && o + 1 < a.n_out) y[o + 1] = -v.y;
+          }
+        }
+    }
+    SMX_STAMP(8);
+  }
+#ifdef SMX_STAMPS
+  stamp_sum[20] = __builtin_amdgcn_s_memtime() - clk_t0;
+  stamp_sum[21] = __builtin_amdgcn_s_memrealtime() - clk_r0;
+  if ((tid & 63) == 0 && blockIdx.x < 4096)
+    for (int i = 0; i < kStampSlots; ++i) g_stamp_sums[(blockIdx.x * 16 + (tid >> 6)) * kStampSlots + i] = stamp_sum[i];
+#endif
 }
 
 // ---- short filters (taps <= 128: pre-emphasis, DC blockers, smoothers, short anti-alias filters): the sum itself ----------------
@@ -726,6 +1023,19 @@ const smx_fir_plan::Tables &smx_fir_plan::tables() const {
       SMX_HIP_CHECK(hipMemcpy(t.w_split, ws.data(), ws.size() * sizeof(float2), hipMemcpyHostToDevice));
       SMX_HIP_CHECK(hipMalloc((void **)&t.tw_1k, t1k.size() * sizeof(float2)));
       SMX_HIP_CHECK(hipMemcpy(t.tw_1k, t1k.data(), t1k.size() * sizeof(float2), hipMemcpyHostToDevice));
+      std::vector<float2> ta(31 * 32);
+      auto w1k = [](int e) {
+        const double ang = -2.0 * M_PI * (double)(e % 1024) / 1024.0;
+        return make_float2((float)std::cos(ang), (float)std::sin(ang));
+      };
+      for (int m = 0; m < 15; ++m)
+        for (int l = 0; l < 32; ++l) {
+          ta[(size_t)(2 * (32 * m + l))] = w1k(l * (2 * m + 1));
+          ta[(size_t)(2 * (32 * m + l) + 1)] = w1k(l * (2 * m + 2));
+        }
+      for (int l = 0; l < 32; ++l) ta[(size_t)(2 * 15 * 32 + l)] = w1k(l * 31);
+      SMX_HIP_CHECK(hipMalloc((void **)&t.tw_a32, ta.size() * sizeof(float2)));
+      SMX_HIP_CHECK(hipMemcpy(t.tw_a32, ta.data(), ta.size() * sizeof(float2), hipMemcpyHostToDevice));
     }
   }
   SMX_HIP_CHECK(hipMalloc((void **)&t.h_nat, hb.size() * sizeof(float2)));
@@ -744,6 +1054,7 @@ smx_fir_plan::~smx_fir_plan() {
     (void)hipFree(kv.second.h_split);
     (void)hipFree(kv.second.w_split);
     (void)hipFree(kv.second.tw_1k);
+    (void)hipFree(kv.second.tw_a32);
   }
 }
 
@@ -794,6 +1105,7 @@ void fir_apply_window_dev(const smx_fir_plan &p, const float *d_x, int64_t chann
   a.h_split = t.h_split;
   a.w_split = t.w_split;
   a.tw_1k = t.tw_1k;
+  a.tw_a32 = t.tw_a32;
   static const bool direct_off = diag_flag("SMX_FIR_DIRECT") == 0;   // A/B timing: FFT blocks for short filters too
   static const int64_t direct_max = (int64_t)diag_int("SMX_FIR_DIRECT_MAX", 80);
   if (p.taps <= direct_max && p.taps <= 128 && !direct_off && channels <= 65535) {   // measured crossover with the FFT blocks: see DESIGN 4.5
@@ -837,17 +1149,19 @@ void fir_apply_window_dev(const smx_fir_plan &p, const float *d_x, int64_t chann
       case 14: aligned ? launch(fir_ols_real_kernel<13, true>, 512) : launch(fir_ols_real_kernel<13, false>, 512); break;
       case 15: {
         static const bool pass_by_pass = diag_flag("SMX_FIR_SPLIT") == 0;   // A/B timing
+        const bool split16 = diag_flag("SMX_FIR_PK") == 0;                 // A/B timing (read per launch): round 2-5's wave-split kernel
         if (pass_by_pass) aligned ? launch(fir_ols_real_kernel<14, true>, 1024) : launch(fir_ols_real_kernel<14, false>, 1024);
         else {
           a.channels = channels;
           const int64_t cus = device_cu_count();
           const unsigned g = (unsigned)(grid < cus ? grid : cus);   // persistent: one workgroup per CU walks the blocks
-          auto launch_p = [&](auto kernel) {
+          auto launch_p = [&](auto kernel, int threads, size_t bytes) {
             SMX_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kernel),
-                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            SMX_LAUNCH(kernel, dim3(g), dim3(1024), lds, stream, a);
+                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+            SMX_LAUNCH(kernel, dim3(g), dim3(threads), bytes, stream, a);
           };
-          aligned ? launch_p(fir_ols_split_kernel<true>) : launch_p(fir_ols_split_kernel<false>);
+          if (split16) aligned ? launch_p(fir_ols_split_kernel<true>, 1024, lds) : launch_p(fir_ols_split_kernel<false>, 1024, lds);
+          else aligned ? launch_p(fir_ols_pk32_kernel<true>, 512, kPkLds) : launch_p(fir_ols_pk32_kernel<false>, 512, kPkLds);   // the register pipeline (round 6)
         }
         break;
       }
@@ -887,6 +1201,12 @@ void fir_apply_dev(const smx_fir_plan &p, const float *d_x, int64_t channels, in
   fir_apply_window_dev(p, d_x, channels, n, x_stride, d_y, y_stride, n, 0, stream);
 }
 }  // namespace
+
+#ifdef SMX_STAMPS
+extern "C" int smx_debug_read_stamps_fir(unsigned long long *out, int count) {
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(smx::fftdev::g_stamp_sums), sizeof(unsigned long long) * (size_t)count);
+}
+#endif
 
 extern "C" {
 

@@ -325,6 +325,74 @@ def gen_post(n, cplx):
     return "\n".join(lines)
 
 
+def gen_powers16():
+    """w^2 .. w^15 of a unit twiddle w by binary multiplication (depth 4), the powers of fftdev::twiddle_powers<16> on packed pairs:
+    the cross-block radix-16 passes of the FIR kernel (fir.hip: fir_ols_pk32_kernel) multiply column n' by W_M^(n' r), r = 1 .. 15."""
+    b = Block("pk_powers16")
+    W = {1: b.slot("in", "w1")}
+    for j in range(2, 16):
+        W[j] = b.slot("tmp", "w%d" % j)
+    def group(items):   # [(dst, a, b)]: W[dst] = W[a] * W[b]; products first, then the fused multiply-adds
+        fin = [b.cmul_reg(W[d], W[x], W[y]) for d, x, y in items]
+        for f in fin:
+            f()
+    group([(2, 1, 1)])
+    group([(3, 2, 1), (4, 2, 2)])
+    group([(5, 4, 1), (6, 4, 2), (7, 4, 3), (8, 4, 4)])
+    group([(8 + j, 8, j) for j in range(1, 8)])
+    lines = ["// w[2] .. w[15] = powers of the unit twiddle w[1] (14 complex products, depth 4), one statement",
+             "__device__ __forceinline__ void pk_powers16(f2 (&w)[16]) {",
+             "  const f2 w1 = w[1];",
+             "  f2 " + ", ".join("w%d" % j for j in range(2, 16)) + ";"]
+    lines.append(b.text().rstrip("\n"))
+    for j in range(2, 16):
+        lines.append("  w[%d] = w%d;" % (j, j))
+    lines.append("}")
+    return "\n".join(lines)
+
+
+def gen_ols_pairs(n):
+    """n pairs (k, M - k) of the overlap-save pointwise stage (fir.hip): real-FFT post-pass, product with H, inverse pre-pass, in place:
+       E = A + conj B, D = A - conj B, t = w D, X_k = E - i t, X_(M-k) = conj(E + i t), Y = X H,
+       P = Y_k + conj Y_(M-k), Q = Y_k - conj Y_(M-k), u = conj(w) Q,
+       A' = conj(P + i u) = (P.x - u.y, -(P.y + u.x)),  B' = P - i u = (P.x + u.y, P.y - u.x)
+    (the inverse transform runs as conj(FFT(conj .)), so the conjugates of Z'[k] are stored: fir_ols_split_kernel's `pair`)."""
+    b = Block("pk_ols_pairs")
+    A = {i: b.slot("io", "a%d" % i) for i in range(n)}
+    B = {i: b.slot("io", "b%d" % i) for i in range(n)}
+    T = {i: [b.slot("tmp", "x%d_%d" % (i, k)) for k in range(3)] for i in range(n)}
+    W = {i: b.slot("in", "w%d" % i) for i in range(n)}
+    HK = {i: b.slot("in", "hk%d" % i) for i in range(n)}
+    HP = {i: b.slot("in", "hp%d" % i) for i in range(n)}
+    R = range(n)
+    E, D, t = {i: T[i][0] for i in R}, {i: T[i][1] for i in R}, {i: T[i][2] for i in R}
+    for i in R: b.emit("v_pk_add_f32", E[i], [A[i], B[i]], "neg_hi:[0,1]")
+    for i in R: b.emit("v_pk_add_f32", D[i], [A[i], B[i]], "neg_lo:[0,1]")
+    fin = [b.cmul_reg(t[i], D[i], W[i]) for i in R]                        # t = w D
+    for f in fin: f()
+    for i in R: b.add_mi(A[i], E[i], t[i])                                  # X_k = E + (-i) t            -> slot a
+    for i in R: b.sub_mi(B[i], E[i], t[i])                                  # conj X_(M-k) = E - (-i) t   -> slot b
+    fin = [b.cmul_reg(E[i], A[i], HK[i]) for i in R]                        # Y_k -> slot E
+    for f in fin: f()
+    for i in R: b.emit("v_pk_mul_f32", D[i], [B[i], HP[i]], "op_sel_hi:[0,1]")                                  # Y_(M-k) = conj(slot b) * hp -> slot D
+    for i in R: b.emit("v_pk_fma_f32", D[i], [B[i], HP[i], D[i]], "op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_hi:[0,1,0]")
+    for i in R: b.emit("v_pk_add_f32", A[i], [E[i], D[i]], "neg_hi:[0,1]")  # P -> slot a
+    for i in R: b.emit("v_pk_add_f32", B[i], [E[i], D[i]], "neg_lo:[0,1]")  # Q -> slot b
+    for i in R: b.emit("v_pk_mul_f32", t[i], [B[i], W[i]], "op_sel_hi:[0,1] neg_hi:[0,1]")                      # u = Q conj(w) -> slot t
+    for i in R: b.emit("v_pk_fma_f32", t[i], [B[i], W[i], t[i]], "op_sel:[1,1,0] op_sel_hi:[1,0,1]")
+    for i in R: b.add_mi(B[i], A[i], t[i])                                  # B' = P + (-i) u = (P.x + u.y, P.y - u.x)
+    for i in R: b.emit("v_pk_add_f32", A[i], [A[i], t[i]], "op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,1] neg_hi:[1,1]")   # A' = (P.x - u.y, -(P.y + u.x))
+    args = ", ".join("f2 &A%d, f2 &B%d, f2 w%d, f2 hk%d, f2 hp%d" % (i, i, i, i, i) for i in R)
+    lines = ["// %d pair(s) (k, M - k) of the overlap-save pointwise stage, in place (18 packed instructions per pair), one statement" % n,
+             "__device__ __forceinline__ void pk_ols_pairs%d(%s) {" % (n, args),
+             "  f2 " + ", ".join("a%d = A%d, b%d = B%d, x%d_0, x%d_1, x%d_2" % (i, i, i, i, i, i, i) for i in R) + ";"]
+    lines.append(b.text().rstrip("\n"))
+    for i in R:
+        lines.append("  A%d = a%d; B%d = b%d;" % (i, i, i, i))
+    lines.append("}")
+    return "\n".join(lines)
+
+
 if __name__ == "__main__":
     print("// GENERATED by tools/gen/gen_pk_fft.py -- do not edit; see that file for the why and the register plans.")
     print("// Included by stft_fast_p32.hpp (inside namespace smx::<anon>); f2 = float ext_vector_type(2), an aligned register pair.")
@@ -338,3 +406,6 @@ if __name__ == "__main__":
     for n in (2, 4, 5):
         print(gen_post(n, False))
         print(gen_post(n, True))
+    print(gen_powers16())
+    for n in (1, 2):
+        print(gen_ols_pairs(n))
