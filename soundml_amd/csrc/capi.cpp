@@ -9,7 +9,9 @@
 #include <cstdlib>
 #include <cstring>
 #include <atomic>
+#include <condition_variable>
 #include <memory>
+#include <mutex>
 #include <thread>
 
 #include <algorithm>
@@ -115,15 +117,31 @@ void for_each_shard(int64_t lead, F &&body) {
   int caller_device = 0;
   SMX_HIP_CHECK(hipGetDevice(&caller_device));
   std::vector<std::exception_ptr> errors((size_t)shards);
+  // the shards start their transfers together (a thread's first HIP call can take milliseconds: without the rendezvous the first
+  // shard's upload was over before the last one's began, and the link sat idle in between)
+  std::mutex gate_mutex;
+  std::condition_variable gate_cv;
+  int64_t arrived = 0;
+  auto rendezvous = [&] {
+    std::unique_lock<std::mutex> g(gate_mutex);
+    if (++arrived == shards) gate_cv.notify_all();
+    else gate_cv.wait(g, [&] { return arrived == shards; });
+  };
   auto run = [&](int64_t s) {
+    bool met = false;
     try {
-      SMX_HIP_CHECK(hipSetDevice(devices[(size_t)s]));
+      const hipError_t set = hipSetDevice(devices[(size_t)s]);
+      if (set == hipSuccess) (void)hipFree(nullptr);   // (the thread's HIP state for the device exists before the rendezvous)
+      met = true;
+      rendezvous();
+      SMX_HIP_CHECK(set);
       set_transfer_share((int)shards);
       int64_t lo, hi;
       clip_range(lead, shards, s, lo, hi);
       if (hi > lo) body(lo, hi - lo);
     } catch (...) {
       errors[(size_t)s] = std::current_exception();
+      if (!met) rendezvous();   // (nobody waits for a shard that failed early)
     }
     set_transfer_share(1);
   };

@@ -563,14 +563,10 @@ __global__ void __launch_bounds__(512) fir_ols_pk32_kernel(FirArgs a) {
           const unsigned kq = ul + 32u * (unsigned)q;
           pw[q] = tab(a.w_split, 1024u * urs + kq);
           phk[q] = tab(a.h_split, 1024u * urs + kq);
-        }
-      };
-      auto request_partner_tables = [&]() {   // behind exchange 1's writes: registers 16 .. 31 of the sub-transform are parked by then
-#pragma unroll
-        for (int q = 0; q < 16; ++q) {
-          const unsigned kq = ul + 32u * (unsigned)q;
           php[q] = tab(a.h_split, (urs == 0u && kq == 0u) ? (unsigned)M : 1024u * rp + (urs ? 1023u - kq : 1024u - kq));
         }
+      };
+      auto request_partner_tables = [&]() {   // (H_(M-k) requested here instead, behind exchange 1's writes, measured the same: profiles/r08/ab_fir_php.log)
         w5 = tab(a.w_split, 512u);   // bin M/2 = (0, 512): lane 0 of sub-transform 0, with itself
         h5 = tab(a.h_split, 512u);
       };

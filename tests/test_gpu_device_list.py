@@ -91,9 +91,13 @@ def test_pipelined_shards_equal_the_single_device_call_and_their_uploads_overlap
     want_y = Stft.invert(c, want_z, length=x.shape[-1])
     for devices in device_lists():
         S.set_devices(devices)
-        staging_peak(reset=True)
-        got_p = Stft.power_spectrum(c, x)
-        up, down = staging_peak()
+        Stft.power_spectrum(c, x)   # (first call with this list: every shard's device arrays come out of the driver, milliseconds apart)
+        up = down = 0
+        for _ in range(3):          # the shards start together (a rendezvous inside the call); their transfers take milliseconds
+            staging_peak(reset=True)
+            got_p = Stft.power_spectrum(c, x)
+            u, d = staging_peak()
+            up, down = max(up, u), max(down, d)
         got_z = Stft.transform(c, x)
         got_y = Stft.invert(c, got_z, length=x.shape[-1])
         S.set_devices([])
@@ -114,18 +118,21 @@ def test_two_threads_on_one_device_no_longer_take_turns():
     xs = [rng.uniform(-1, 1, size=(64, 200000)).astype(np.float32) for _ in range(2)]
     S.set_pinned_results(False)
     Stft.power_spectrum(c, xs[0][:8])   # tables built
-    staging_peak(reset=True)
-    gate = threading.Barrier(2)
     out = [None, None]
+    up = down = 0
+    for attempt in range(4):   # (the first round also warms the device-side pool for two callers; the transfers take milliseconds and the threads start microseconds apart)
+        staging_peak(reset=True)
+        gate = threading.Barrier(2)
 
-    def work(i):
-        gate.wait()
-        out[i] = Stft.power_spectrum(c, xs[i])
+        def work(i):
+            gate.wait()
+            out[i] = Stft.power_spectrum(c, xs[i])
 
-    ts = [threading.Thread(target=work, args=(i,)) for i in range(2)]
-    for t in ts: t.start()
-    for t in ts: t.join()
-    up, down = staging_peak()
+        ts = [threading.Thread(target=work, args=(i,)) for i in range(2)]
+        for t in ts: t.start()
+        for t in ts: t.join()
+        u, d = staging_peak()
+        up, down = max(up, u), max(down, d)
     assert up >= 2 and down >= 2, (up, down)
     import torch
     for i in range(2):
