@@ -44,8 +44,8 @@ struct smx_fir_plan {
                               // pre-pass and the inverse transform's 1/M folded in)
     float2 *tw_m = nullptr;   // exp(-2 pi i j / M), j < M/2
     // wave-split kernel (N = 32768: sixteen 1024-point sub-transforms, one per wave): tables in the order its lanes read
-    float2 *h_split = nullptr;  // h_half[16 k' + r] at [1024 r + k'], h_half[M] at [M]
-    float2 *w_split = nullptr;  // exp(-2 pi i (16 k' + r) / N) at [1024 r + k']
+    float2 *h_split = nullptr;  // h_half[NS k' + r] at [1024 r + k'] (NS = M / 1024 sub-transforms: 16 or 8), h_half[M] at [M]
+    float2 *w_split = nullptr;  // exp(-2 pi i (NS k' + r) / N) at [1024 r + k']
     float2 *tw_1k = nullptr;    // exp(-2 pi i j / 1024), j < 512
     // register-pipeline kernel (fir_ols_pk32_kernel): W_1024^(l k1) in the order its lanes read it -- rows m < 15 hold the pair
     // k1 = 2 m + 1, 2 m + 2 per lane l (a float4), then one row of k1 = 31 (as stft_fast_p32.hpp's twA4 / twA31)
@@ -414,10 +414,7 @@ __device__ __forceinline__ void pk_fft32_nat(f2 (&v)[32]) {   // 32-point forwar
   pk_fft32_combine0(v, e, o);
   pk_fft32_combine1(v, e, o);
 }
-constexpr int kPkM = 16384;
 constexpr size_t kPkTwBytes = 31 * 32 * sizeof(float2);
-constexpr size_t kPkLds = (size_t)kPkM * sizeof(float2) + kPkTwBytes;   // 139,008 B: one workgroup per CU
-static_assert(kPkLds <= 160 * 1024, "LDS budget");
 
 // the 1024-point forward transform of a half-wave, registers to registers: lane l holds points l + 32 j in v on entry and bins
 // l + 32 q in t on return; `cells` = 1056 four-byte cells of LDS that belong to the half-wave for the duration
@@ -470,17 +467,42 @@ __device__ __forceinline__ void pk_sub1024(f2 (&v)[32], f2 (&t)[32], float *cell
 // Every pair is formed ONCE, by the member with q < 16: exchange 1 hands it the partner's registers 16 .. 31, exchange 2 returns
 // the partner's results.  Sub-transform 0 pairs (0, k') with (0, 1024 - k'): lane (32 - l) mod 32, and lane 0 pairs inside itself one
 // register further (k' = 32 q with 32 (32 - q)); k' = 0 (whose partner in the product is bin M) and k' = 512 pair with themselves.
-template <bool ALIGNED>
-__global__ void __launch_bounds__(512) fir_ols_pk32_kernel(FirArgs a) {
-  constexpr int M = kPkM;
+// NS = 16: N = 32768 (M = 16 x 1024), 512 threads, 139 KB of LDS, one workgroup per CU.  NS = 8: N = 16384 (M = 8 x 1024: filters of
+// up to 4096 taps at 75 % kept, up to 8192 at 50 %), 256 threads with FOUR columns each, 73.5 KB of LDS: TWO workgroups per CU, whose
+// barrier-separated phases interleave -- what one block of 128 KB cannot have.
+template <int NS> struct PkRadix;
+template <> struct PkRadix<16> {
+  static __device__ __forceinline__ void dft(f2 (&v)[16]) { pk_fft16(v); }
+  static __device__ __forceinline__ void twiddle(f2 (&v)[16], f2 w1) {
+    f2 w[16];
+    w[1] = w1;
+    pk_powers16(w);
+    pk_twiddle8(v[1], v[2], v[3], v[4], v[5], v[6], v[7], v[8], w[1], w[2], w[3], w[4], w[5], w[6], w[7], w[8]);
+    pk_twiddle7(v[9], v[10], v[11], v[12], v[13], v[14], v[15], w[9], w[10], w[11], w[12], w[13], w[14], w[15]);
+  }
+};
+template <> struct PkRadix<8> {
+  static __device__ __forceinline__ void dft(f2 (&v)[8]) { pk_fft8(v); }
+  static __device__ __forceinline__ void twiddle(f2 (&v)[8], f2 w1) {
+    f2 w[16];
+    w[1] = w1;
+    pk_powers8(w);
+    pk_twiddle7(v[1], v[2], v[3], v[4], v[5], v[6], v[7], w[1], w[2], w[3], w[4], w[5], w[6], w[7]);
+  }
+};
+template <int NS> constexpr size_t pk_lds_bytes() { return (size_t)NS * 1024 * sizeof(float2) + kPkTwBytes; }
+
+template <bool ALIGNED, int NS>
+__global__ void __launch_bounds__(32 * NS) fir_ols_pk32_kernel(FirArgs a) {
+  constexpr int M = 1024 * NS, T = 32 * NS, CPT = 1024 / T;   // threads, columns per thread (2 / 4): CPT x NS = 32 points a thread
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   f2 *z = reinterpret_cast<f2 *>(smem);   // [16][1024]: sub-transform r at z + 1024 r
   const float4 *twA4 = reinterpret_cast<const float4 *>(smem + (size_t)M * sizeof(float2));
   const float2 *twA31 = reinterpret_cast<const float2 *>(smem + (size_t)M * sizeof(float2) + 15 * 32 * sizeof(float4));
   const int tid = threadIdx.x;
-  for (int i = tid; i < 31 * 32; i += 512) reinterpret_cast<float2 *>(smem + (size_t)M * sizeof(float2))[i] = a.tw_a32[i];
-  // columns tid and tid + 512 of the block: element n = column + 1024 q, q < 16
-  auto load_block = [&](int64_t b, f2 (&va)[16], f2 (&vb)[16]) {
+  for (int i = tid; i < 31 * 32; i += T) reinterpret_cast<float2 *>(smem + (size_t)M * sizeof(float2))[i] = a.tw_a32[i];
+  // columns tid + T c (c < CPT) of the block: element n = column + 1024 q, q < NS
+  auto load_block = [&](int64_t b, f2 (&va)[CPT][NS]) {
     const int64_t channel = b / a.blocks_per_channel, blk = b % a.blocks_per_channel;
     const float *x = a.x + channel * a.x_stride;
     const int64_t base = blk * a.step - a.lead;      // first sample of the window (even)
@@ -491,19 +513,20 @@ __global__ void __launch_bounds__(512) fir_ols_pk32_kernel(FirArgs a) {
       const char *src = reinterpret_cast<const char *>(x + base);
       const unsigned off = 8u * (unsigned)tl;
 #pragma unroll
-      for (int q = 0; q < 16; ++q) {
-        const float2 p0 = *reinterpret_cast<const float2 *>(src + (size_t)(off + 8192u * (unsigned)q));
-        const float2 p1 = *reinterpret_cast<const float2 *>(src + (size_t)(off + 8192u * (unsigned)q + 4096u));
-        va[q] = f2{p0.x, p0.y};
-        vb[q] = f2{p1.x, p1.y};
-      }
+      for (int q = 0; q < NS; ++q)
+#pragma unroll
+        for (int c = 0; c < CPT; ++c) {
+          const float2 p = *reinterpret_cast<const float2 *>(src + (size_t)(off + 8192u * (unsigned)q + 8u * (unsigned)(T * c)));
+          va[c][q] = f2{p.x, p.y};
+        }
     } else {
 #pragma unroll
-      for (int q = 0; q < 16; ++q) {
-        const int64_t g0 = base + 2 * (int64_t)(tl + 1024 * q), g1 = g0 + 1024;
-        va[q] = f2{(g0 >= 0 && g0 < a.n) ? x[g0] : 0.0f, (g0 + 1 >= 0 && g0 + 1 < a.n) ? x[g0 + 1] : 0.0f};
-        vb[q] = f2{(g1 >= 0 && g1 < a.n) ? x[g1] : 0.0f, (g1 + 1 >= 0 && g1 + 1 < a.n) ? x[g1 + 1] : 0.0f};
-      }
+      for (int q = 0; q < NS; ++q)
+#pragma unroll
+        for (int c = 0; c < CPT; ++c) {
+          const int64_t g = base + 2 * (int64_t)(tl + T * c + 1024 * q);
+          va[c][q] = f2{(g >= 0 && g < a.n) ? x[g] : 0.0f, (g + 1 >= 0 && g + 1 < a.n) ? x[g + 1] : 0.0f};
+        }
     }
   };
   const int64_t total = a.channels * a.blocks_per_channel;
@@ -512,28 +535,26 @@ __global__ void __launch_bounds__(512) fir_ols_pk32_kernel(FirArgs a) {
   asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(stamp_prev)::"memory");
   const unsigned long long clk_t0 = stamp_prev, clk_r0 = __builtin_amdgcn_s_memrealtime();
 #endif
-  const float2 w1a_ = a.tw_m[tid], w1b_ = a.tw_m[tid + 512];   // W_M^(column): the same for every block of this thread
-  const f2 w1a = {w1a_.x, w1a_.y}, w1b = {w1b_.x, w1b_.y};
-  f2 na[16], nb[16];
-  load_block(blockIdx.x, na, nb);
+  f2 w1[CPT];   // W_M^(column): the same for every block of this thread
+#pragma unroll
+  for (int c = 0; c < CPT; ++c) {
+    const float2 w = a.tw_m[tid + T * c];
+    w1[c] = f2{w.x, w.y};
+  }
+  f2 na[CPT][NS];
+  load_block(blockIdx.x, na);
   __syncthreads();   // the twiddle table
   for (int64_t b = blockIdx.x; b < total; b += gridDim.x) {
-    {   // radix-16 across the block, then W_M^(n' r): u_r[n'] for sub-transform r
-      f2 w[16];
-      pk_fft16(na);
-      w[1] = w1a;
-      pk_powers16(w);
-      pk_twiddle8(na[1], na[2], na[3], na[4], na[5], na[6], na[7], na[8], w[1], w[2], w[3], w[4], w[5], w[6], w[7], w[8]);
-      pk_twiddle7(na[9], na[10], na[11], na[12], na[13], na[14], na[15], w[9], w[10], w[11], w[12], w[13], w[14], w[15]);
-      pk_fft16(nb);
-      w[1] = w1b;
-      pk_powers16(w);
-      pk_twiddle8(nb[1], nb[2], nb[3], nb[4], nb[5], nb[6], nb[7], nb[8], w[1], w[2], w[3], w[4], w[5], w[6], w[7], w[8]);
-      pk_twiddle7(nb[9], nb[10], nb[11], nb[12], nb[13], nb[14], nb[15], w[9], w[10], w[11], w[12], w[13], w[14], w[15]);
+    {   // radix-NS across the block, then W_M^(n' r): u_r[n'] for sub-transform r
       int tw_ = tid;
       asm volatile("" : "+v"(tw_));
 #pragma unroll
-      for (int r = 0; r < 16; ++r) { z[1024 * r + tw_] = na[r]; z[1024 * r + tw_ + 512] = nb[r]; }
+      for (int c = 0; c < CPT; ++c) {
+        PkRadix<NS>::dft(na[c]);
+        PkRadix<NS>::twiddle(na[c], w1[c]);
+#pragma unroll
+        for (int r = 0; r < NS; ++r) z[1024 * r + tw_ + T * c] = na[c][r];
+      }
     }
     SMX_STAMP(0);
     __syncthreads();
@@ -545,7 +566,7 @@ __global__ void __launch_bounds__(512) fir_ols_pk32_kernel(FirArgs a) {
       int ls = tid;
       asm volatile("" : "+v"(ls));
       const int l = ls & 31, h = (ls >> 5) & 1, wave = ls >> 6;
-      const int rs = wave ? (h ? 16 - wave : wave) : 8 * h;   // this half-wave's sub-transform
+      const int rs = wave ? (h ? NS - wave : wave) : (NS / 2) * h;   // this half-wave's sub-transform
       f2 *zr = z + 1024 * rs;
       f2 v[32], t[32];
 #pragma unroll
@@ -555,7 +576,7 @@ __global__ void __launch_bounds__(512) fir_ols_pk32_kernel(FirArgs a) {
       // sub-transform, behind its transposition, where the first pass's registers are free
       // (a wave-uniform base and a 32-bit unsigned lane offset per request: no 64-bit address pair per value)
       auto tab = [](const float2 *base, unsigned idx) { return *reinterpret_cast<const float2 *>(reinterpret_cast<const char *>(base) + (size_t)(idx * 8u)); };
-      const unsigned rp = (16u - (unsigned)rs) & 15u, ul = (unsigned)l, urs = (unsigned)rs;
+      const unsigned rp = ((unsigned)NS - (unsigned)rs) & (unsigned)(NS - 1), ul = (unsigned)l, urs = (unsigned)rs;
       float2 pw[16], phk[16], php[16], w5, h5;
       auto request_tables = [&]() {
 #pragma unroll
@@ -581,7 +602,7 @@ __global__ void __launch_bounds__(512) fir_ols_pk32_kernel(FirArgs a) {
       // the same half's lane 31 - l (sub-transform 8) or (32 - l) mod 32 (sub-transform 0)
       const int partner_lane = wave ? 31 - l : (h ? 31 - l : (32 - l) & 31);
       f2 *own_row = zr + 17 * l;
-      f2 *partner_row = (wave ? z + 1024 * (16 - rs) : zr) + 17 * partner_lane + ((wave == 0 && h == 0 && l == 0) ? 1 : 0);
+      f2 *partner_row = (wave ? z + 1024 * (NS - rs) : zr) + 17 * partner_lane + ((wave == 0 && h == 0 && l == 0) ? 1 : 0);
 #pragma unroll
       for (int q = 16; q < 32; ++q) own_row[q - 16] = t[q];
       own_row[16] = t[0];
@@ -613,29 +634,23 @@ __global__ void __launch_bounds__(512) fir_ols_pk32_kernel(FirArgs a) {
     // the next block's samples are requested HERE, before the barrier: the sub-transforms' registers are free, and the requests have
     // the barrier, the last pass's LDS reads, its barrier and its arithmetic to arrive under (behind the second barrier, as the split
     // kernel has them, a block opened with ~1 us of exposed HBM latency: eight waves do not cover it)
-    if (b + gridDim.x < total) load_block(b + gridDim.x, na, nb);
+    if (b + gridDim.x < total) load_block(b + gridDim.x, na);
     SMX_STAMP(4);
     __syncthreads();
     SMX_STAMP(5);
     int to = tid;
     asm volatile("" : "+v"(to));
-    f2 va[16], vb[16];
+    f2 va[CPT][NS];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) { va[r] = z[1024 * r + to]; vb[r] = z[1024 * r + to + 512]; }
+    for (int c = 0; c < CPT; ++c)
+#pragma unroll
+      for (int r = 0; r < NS; ++r) va[c][r] = z[1024 * r + to + T * c];
     __syncthreads();   // every thread holds its columns: the next block's first pass may overwrite the buffer
     SMX_STAMP(6);
-    {
-      f2 w[16];
-      w[1] = w1a;
-      pk_powers16(w);
-      pk_twiddle8(va[1], va[2], va[3], va[4], va[5], va[6], va[7], va[8], w[1], w[2], w[3], w[4], w[5], w[6], w[7], w[8]);
-      pk_twiddle7(va[9], va[10], va[11], va[12], va[13], va[14], va[15], w[9], w[10], w[11], w[12], w[13], w[14], w[15]);
-      pk_fft16(va);
-      w[1] = w1b;
-      pk_powers16(w);
-      pk_twiddle8(vb[1], vb[2], vb[3], vb[4], vb[5], vb[6], vb[7], vb[8], w[1], w[2], w[3], w[4], w[5], w[6], w[7], w[8]);
-      pk_twiddle7(vb[9], vb[10], vb[11], vb[12], vb[13], vb[14], vb[15], w[9], w[10], w[11], w[12], w[13], w[14], w[15]);
-      pk_fft16(vb);
+#pragma unroll
+    for (int c = 0; c < CPT; ++c) {
+      PkRadix<NS>::twiddle(va[c], w1[c]);
+      PkRadix<NS>::dft(va[c]);
     }
     SMX_STAMP(7);
     const int64_t channel = b / a.blocks_per_channel, blk = b % a.blocks_per_channel;
@@ -647,22 +662,22 @@ __global__ void __launch_bounds__(512) fir_ols_pk32_kernel(FirArgs a) {
       const int s0 = 2 * to - (int)a.lead;
       const unsigned span = (unsigned)a.step;
 #pragma unroll
-      for (int q = 0; q < 16; ++q)
+      for (int q = 0; q < NS; ++q)
 #pragma unroll
-        for (int c = 0; c < 2; ++c) {
-          const int sp = s0 + 1024 * c + 2048 * q;   // position inside the kept span (even)
-          const f2 v = c ? vb[q] : va[q];
+        for (int c = 0; c < CPT; ++c) {
+          const int sp = s0 + 2 * T * c + 2048 * q;   // position inside the kept span (even)
+          const f2 v = va[c][q];
           if ((unsigned)sp < span) *reinterpret_cast<float2 *>(dst + (size_t)(4u * (unsigned)sp)) = make_float2(v.x, -v.y);   // conj(FFT(conj .))
         }
     } else {
 #pragma unroll
-      for (int q = 0; q < 16; ++q)
+      for (int q = 0; q < NS; ++q)
 #pragma unroll
-        for (int c = 0; c < 2; ++c) {
-          const int64_t sp = 2 * (int64_t)(to + 512 * c + 1024 * q) - a.lead;
+        for (int c = 0; c < CPT; ++c) {
+          const int64_t sp = 2 * (int64_t)(to + T * c + 1024 * q) - a.lead;
           if (sp >= 0 && sp < a.step) {
             const int64_t o = out0 + sp;
-            const f2 v = c ? vb[q] : va[q];
+            const f2 v = va[c][q];
             if (o >= 0 && o < a.n_out) y[o] = v.x;
             if (o + 1 >= 0 && o + 1 < a.n_out) y[o + 1] = -v.y;
           }
@@ -1000,10 +1015,11 @@ const smx_fir_plan::Tables &smx_fir_plan::tables() const {
     SMX_HIP_CHECK(hipMemcpy(t.h_half, hh.data(), hh.size() * sizeof(float2), hipMemcpyHostToDevice));
     SMX_HIP_CHECK(hipMalloc((void **)&t.tw_m, twm.size() * sizeof(float2)));
     SMX_HIP_CHECK(hipMemcpy(t.tw_m, twm.data(), twm.size() * sizeof(float2), hipMemcpyHostToDevice));
-    if (log2n == 15) {   // the wave-split kernel's tables, in the order its lanes read them
+    if (log2n == 15 || log2n == 14) {   // the split kernels' tables (M = NS x 1024 points, NS = 16 / 8 sub-transforms), in the order their lanes read them
+      const int64_t ns = M / 1024;
       std::vector<float2> hs((size_t)M + 1), ws((size_t)M), t1k(512);
       for (int64_t k = 0; k < M; ++k) {
-        const size_t at = (size_t)((k % 16) * 1024 + k / 16);
+        const size_t at = (size_t)((k % ns) * 1024 + k / ns);
         hs[at] = hh[(size_t)k];
         const double ang = -2.0 * M_PI * (double)k / (double)N;
         ws[at] = make_float2((float)std::cos(ang), (float)std::sin(ang));
@@ -1142,7 +1158,25 @@ void fir_apply_window_dev(const smx_fir_plan &p, const float *d_x, int64_t chann
       case 11: aligned ? launch(fir_ols_real_kernel<10, true>, 64) : launch(fir_ols_real_kernel<10, false>, 64); break;
       case 12: aligned ? launch(fir_ols_real_kernel<11, true>, 128) : launch(fir_ols_real_kernel<11, false>, 128); break;
       case 13: aligned ? launch(fir_ols_real_kernel<12, true>, 256) : launch(fir_ols_real_kernel<12, false>, 256); break;
-      case 14: aligned ? launch(fir_ols_real_kernel<13, true>, 512) : launch(fir_ols_real_kernel<13, false>, 512); break;
+      case 14: {
+        // N = 16384 stays on the Stockham kernel: the register pipeline with eight sub-transforms and TWO workgroups per CU (73.5 KB of LDS
+        // each) measured 4 % behind it (8192 taps 0.1316 against 0.1286 ms, 4096 taps 0.1008 / 0.0969, 3000 taps 0.0922 / 0.0882:
+        // profiles/r08/fir_time_n16384.log) -- two independent workgroups did not cover what bounds a wave there, its own chain of LDS round
+        // trips at two waves per SIMD.  SMX_FIR_PK=1 in diagnostic builds selects it (same results to rounding; A/B timing).
+        const bool stockham = diag_flag("SMX_FIR_PK") != 1;
+        if (stockham) aligned ? launch(fir_ols_real_kernel<13, true>, 512) : launch(fir_ols_real_kernel<13, false>, 512);
+        else {   // persistent, two workgroups per CU
+          a.channels = channels;
+          const int64_t slots = 2 * (int64_t)device_cu_count();
+          const unsigned g = (unsigned)(grid < slots ? grid : slots);
+          auto launch_p = [&](auto kernel) {
+            SMX_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)pk_lds_bytes<8>()));
+            SMX_LAUNCH(kernel, dim3(g), dim3(256), pk_lds_bytes<8>(), stream, a);
+          };
+          aligned ? launch_p(fir_ols_pk32_kernel<true, 8>) : launch_p(fir_ols_pk32_kernel<false, 8>);
+        }
+        break;
+      }
       case 15: {
         static const bool pass_by_pass = diag_flag("SMX_FIR_SPLIT") == 0;   // A/B timing
         const bool split16 = diag_flag("SMX_FIR_PK") == 0;                 // A/B timing (read per launch): round 2-5's wave-split kernel
@@ -1157,7 +1191,7 @@ void fir_apply_window_dev(const smx_fir_plan &p, const float *d_x, int64_t chann
             SMX_LAUNCH(kernel, dim3(g), dim3(threads), bytes, stream, a);
           };
           if (split16) aligned ? launch_p(fir_ols_split_kernel<true>, 1024, lds) : launch_p(fir_ols_split_kernel<false>, 1024, lds);
-          else aligned ? launch_p(fir_ols_pk32_kernel<true>, 512, kPkLds) : launch_p(fir_ols_pk32_kernel<false>, 512, kPkLds);   // the register pipeline (round 6)
+          else aligned ? launch_p(fir_ols_pk32_kernel<true, 16>, 512, pk_lds_bytes<16>()) : launch_p(fir_ols_pk32_kernel<false, 16>, 512, pk_lds_bytes<16>());   // the register pipeline (round 6)
         }
         break;
       }

@@ -325,6 +325,30 @@ def gen_post(n, cplx):
     return "\n".join(lines)
 
 
+def gen_powers8():
+    """w^2 .. w^7 of a unit twiddle (6 complex products, depth 3): the radix-8 form of gen_powers16 (N = 16384 blocks of the FIR kernel)"""
+    b = Block("pk_powers8")
+    W = {1: b.slot("in", "w1")}
+    for j in range(2, 8):
+        W[j] = b.slot("tmp", "w%d" % j)
+    def group(items):
+        fin = [b.cmul_reg(W[d], W[x], W[y]) for d, x, y in items]
+        for f in fin:
+            f()
+    group([(2, 1, 1)])
+    group([(3, 2, 1), (4, 2, 2)])
+    group([(5, 4, 1), (6, 4, 2), (7, 4, 3)])
+    lines = ["// w[2] .. w[7] = powers of the unit twiddle w[1] (6 complex products, depth 3), one statement",
+             "__device__ __forceinline__ void pk_powers8(f2 (&w)[16]) {",
+             "  const f2 w1 = w[1];",
+             "  f2 " + ", ".join("w%d" % j for j in range(2, 8)) + ";"]
+    lines.append(b.text().rstrip("\n"))
+    for j in range(2, 8):
+        lines.append("  w[%d] = w%d;" % (j, j))
+    lines.append("}")
+    return "\n".join(lines)
+
+
 def gen_powers16():
     """w^2 .. w^15 of a unit twiddle w by binary multiplication (depth 4), the powers of fftdev::twiddle_powers<16> on packed pairs:
     the cross-block radix-16 passes of the FIR kernel (fir.hip: fir_ols_pk32_kernel) multiply column n' by W_M^(n' r), r = 1 .. 15."""
@@ -407,5 +431,6 @@ if __name__ == "__main__":
         print(gen_post(n, False))
         print(gen_post(n, True))
     print(gen_powers16())
+    print(gen_powers8())
     for n in (1, 2):
         print(gen_ols_pairs(n))
