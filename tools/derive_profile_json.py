@@ -85,7 +85,7 @@ if os.path.exists(bench_path):
     pairs = {"istft2048_pipe_kernel<true, true>": None, "stft2048_complex_fm": None,   # Griffin-Lim's kernels: the line has the whole loop only (extra.c2_griffin_lim)
              "stft2048_power32": line["roofline"].get("kernel_ms_avg"), "stft2048_complex32": ex.get("c2_complex", {}).get("ms"),
              "istft2048": ex.get("c2_invert", {}).get("ms"), "stft2048_mel32": ex.get("c3_mel", {}).get("ms"),
-             "stft_power_lanes_kernel<16": ex.get("c1_batch", {}).get("ms"), "stft_power_lanes_kernel<4": ex.get("fft256_batch", {}).get("ms"), "fir_ols_split": ex.get("c4_fir", {}).get("ms"),
+             "stft_power_lanes_kernel<16": ex.get("c1_batch", {}).get("ms"), "stft_power_lanes_kernel<4": ex.get("fft256_batch", {}).get("ms"), "fir_ols": ex.get("c4_fir", {}).get("ms"),
              "wide64::stft2048_power_wide": ex.get("c2_float64_interior", {}).get("ms")}
     for name, row in table.items():
         ms = next((v for key, v in pairs.items() if name.startswith(key)), None)
