@@ -116,6 +116,9 @@ int smx_set_device(int device);        /* device used by this thread's subsequen
  * smx_get_devices writes min(*n, capacity) ordinals. */
 int smx_set_devices(const int *devices, int n);
 int smx_get_devices(int *devices, int capacity, int *n);
+/* the rule itself (no device needed): clips [*lo, *hi) of shard `shard` of `shards` -- what a caller that gathers per-device results
+ * itself, or a test, checks the split against (soundml_amd/shard.py clip_range is the same function) */
+int smx_shard_clip_range(int64_t total_clips, int64_t shards, int64_t shard, int64_t *lo, int64_t *hi);
 /* diagnostics (tests of the per-device staging): the most staged uploads / downloads that were ever in flight at once */
 int smx_debug_staging_peak(int *uploads, int *downloads, int reset);
 int smx_set_interior(int interior);    /* SMX_INTERIOR_*, process-wide default for f32 audio */

@@ -66,6 +66,7 @@ SIGNATURES = {
     "smx_set_device": (cint, [cint]),
     "smx_set_devices": (cint, [C.POINTER(cint), cint]),
     "smx_get_devices": (cint, [C.POINTER(cint), cint, C.POINTER(cint)]),
+    "smx_shard_clip_range": (cint, [i64, i64, i64, pi64, pi64]),
     "smx_debug_staging_peak": (cint, [C.POINTER(cint), C.POINTER(cint), cint]),
     "smx_set_interior": (cint, [cint]),
     "smx_get_interior": (cint, []),

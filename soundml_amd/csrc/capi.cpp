@@ -404,6 +404,15 @@ int smx_get_devices(int *devices, int capacity, int *n) {
       for (int i = 0; i < (int)d.size() && i < capacity; ++i) devices[i] = d[(size_t)i];
   });
 }
+int smx_shard_clip_range(int64_t total_clips, int64_t shards, int64_t shard, int64_t *lo, int64_t *hi) {
+  return guarded([&] {
+    if (!lo || !hi) throw Failure("smx_shard_clip_range: null result pointer");
+    if (total_clips < 0) throw Failure("smx_shard_clip_range: negative clip count");
+    if (shards < 1 || shard < 0 || shard >= shards)
+      throw Failure(format("smx_shard_clip_range: shard %lld outside a list of %lld", (long long)shard, (long long)shards));
+    clip_range(total_clips, shards, shard, *lo, *hi);
+  });
+}
 int smx_debug_staging_peak(int *uploads, int *downloads, int reset) {
   return guarded([&] { staging_peak(uploads, downloads, reset != 0); });
 }

@@ -100,3 +100,24 @@ def test_bench_launcher_starts_the_ranks(tmp_path):
         bad = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1"], capture_output=True,
                              text=True, timeout=600, env=env)
         assert bad.returncode != 0
+
+
+def test_the_c_abi_splits_clips_by_the_same_rule():
+    """smx_set_devices shards the host-pointer batch calls inside the C ABI (capi.cpp for_each_shard); its split is
+    smx_shard_clip_range, which must be shard.clip_range -- the rule bench.py's ranks use -- for every (clips, shards, shard):
+    contiguous, balanced, the first clips % shards shards one clip more, every clip owned exactly once.  No device needed."""
+    import ctypes
+    from soundml_amd import _lib, shard
+    lo, hi = ctypes.c_int64(), ctypes.c_int64()
+    for total in (0, 1, 2, 7, 8, 255, 256, 257, 4096, 4099):
+        for world in (1, 2, 3, 4, 8, 16):
+            covered = 0
+            for r in range(world):
+                _lib.check(_lib.lib.smx_shard_clip_range(total, world, r, ctypes.byref(lo), ctypes.byref(hi)))
+                assert (lo.value, hi.value) == shard.clip_range(total, world, r), (total, world, r)
+                assert lo.value == covered
+                covered = hi.value
+            assert covered == total
+    assert _lib.lib.smx_shard_clip_range(10, 4, 4, ctypes.byref(lo), ctypes.byref(hi)) == 2
+    assert b"outside a list of 4" in _lib.lib.smx_last_error()
+    assert _lib.lib.smx_shard_clip_range(10, 0, 0, ctypes.byref(lo), ctypes.byref(hi)) == 2
