@@ -235,6 +235,7 @@ __device__ __forceinline__ void lds_wait(unsigned *c, unsigned target) {
 #include "stft_fast_p32.hpp"   // the 32-lane frame pipeline: stft2048_power32_kernel
 #include "stft_fast_mel32.hpp" // the fused audio -> mel kernel on the 32-lane pipeline: stft2048_mel32_kernel
 #include "stft_fast_p16.hpp"   // the same pipeline with a frame in 16 / 8 / 4 lanes: stft_power_lanes_kernel (power spectrogram at fft 1024 / 512 / 256)
+#include "stft_fast_p64.hpp"   // ... and with a frame in a whole wave: stft4096_power64_kernel (power spectrogram at fft 4096; round 6)
 #ifdef SMX_ISA_ONE   // tools/isa_one.py: ONE instantiation of a register-pipeline kernel (registers / scratch / instruction mix in seconds, no GPU)
 #ifndef SMX_ISA_KERNEL
 #define SMX_ISA_KERNEL 0
@@ -253,6 +254,8 @@ template __global__ void stft_mel_lanes_kernel<SMX_ISA_ONE, true, 2, true>(FastA
 template __global__ void stft2048_complex_fm_kernel<(SMX_ISA_ONE != 0)>(FastArgs);
 #elif SMX_ISA_KERNEL == 5
 template __global__ void stft_complex_lanes_kernel<SMX_ISA_ONE, true>(FastArgs);
+#elif SMX_ISA_KERNEL == 8
+template __global__ void stft4096_power64_kernel<true, 2, (SMX_ISA_ONE != 0)>(FastArgs);
 #else
 template __global__ void stft2048_power32_kernel<true, 2, false, SMX_ISA_ONE>(FastArgs);
 #endif
@@ -342,7 +345,8 @@ void launch_interior(const StftJob &job, const FastTarget &tg, const float *x, i
   a.w_m = t.fast_w_m;
   a.w_n = t.fast_w_n;
   const int lanes = c.fft_size == kN16 ? 16 : c.fft_size == kN8 ? 8 : c.fft_size == kN4 ? 4 : 0;   // fft 1024 / 512 / 256 (launch_stft_fast admits nothing else of these sizes)
-  const int64_t ft = lanes == 16 ? PL<16>::FT : lanes == 8 ? PL<8>::FT : lanes == 4 ? PL<4>::FT : kFT, bins = c.fft_size / 2 + 1;
+  const bool p64 = c.fft_size == k64N;   // fft 4096: a frame in a whole wave, 8-frame tiles (stft_fast_p64.hpp; power output only)
+  const int64_t ft = p64 ? k64FT : lanes == 16 ? PL<16>::FT : lanes == 8 ? PL<8>::FT : lanes == 4 ? PL<4>::FT : kFT, bins = c.fft_size / 2 + 1;
   const int64_t tiles = (count + ft - 1) / ft;
   if (tiles > 0x7fffffff) throw Failure("stft: too many frame tiles for one launch");
   a.tiles_per_clip = (int)tiles;
@@ -383,6 +387,23 @@ void launch_interior(const StftJob &job, const FastTarget &tg, const float *x, i
   const bool aligned = (c.hop % 2 == 0) && (left % 2 == 0) && (x_stride % 2 == 0) &&
                        (reinterpret_cast<uintptr_t>(x) % 8 == 0);
   const bool square = a.pmode == 2;
+  if (p64) {
+    if (tg.complex_out || tg.mel) throw Failure("stft: the fft-4096 pipeline has the power face only");
+    a.interleave = 0;   // contiguous tile ranges
+    a.pmode = job.power == 2.0 ? 2 : (job.power == 1.0 ? 1 : 0);
+    const bool even = a.out_stride % 2 == 0 && ((reinterpret_cast<uintptr_t>(a.out) >> 2) + (uintptr_t)a.out_offset) % 2 == 0 &&
+                      reinterpret_cast<uintptr_t>(a.out) % 4 == 0;
+    auto by_power = [&](auto al, auto ev) {
+      constexpr bool A = decltype(al)::value, E = decltype(ev)::value;
+      return a.pmode == 2 ? stft4096_power64_kernel<A, 2, E> : a.pmode == 1 ? stft4096_power64_kernel<A, 1, E> : stft4096_power64_kernel<A, 0, E>;
+    };
+    auto by_al = [&](auto ev) { return aligned ? by_power(std::true_type{}, ev) : by_power(std::false_type{}, ev); };
+    auto k64 = even ? by_al(std::true_type{}) : by_al(std::false_type{});
+    SMX_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k64), hipFuncAttributeMaxDynamicSharedMemorySize, (int)k64Lds));
+    SMX_LAUNCH(k64, dim3((unsigned)a.blocks), dim3(512), k64Lds, job.stream, a);
+    SMX_HIP_CHECK(hipGetLastError());
+    return;
+  }
   if (lanes && tg.complex_out) {   // Stft.transform at fft 1024 / 512 / 256
     auto launch_cplx_lanes = [&](auto ll) {
       constexpr int LL = decltype(ll)::value;
@@ -549,7 +570,8 @@ bool fast_eligible(const StftJob &job, bool power_face = false) {
   const smx_stft_config &c = *job.cfg;
   if (fast_path_disabled()) return false;
   const bool size_ok = c.fft_size == kN || (power_face && (c.fft_size == kN16 || c.fft_size == kN8 || (c.fft_size == kN4 && diag_flag("SMX_FFT256_OFF") != 1)) &&
-                                              diag_flag("SMX_POWER16_OFF") != 1);
+                                              diag_flag("SMX_POWER16_OFF") != 1) ||
+                       (power_face && c.fft_size == k64N && job.mode != OUT_COMPLEX && diag_flag("SMX_P64_OFF") != 1);   // fft 4096: the power face (round 6)
   if (!size_ok || job.in_bytes != 4 || job.interior != SMX_INTERIOR_F32) return false;
   if (diag_flag("SMX_GENERIC_2048") == 1) return false;   // diagnostic: time the stage-free generic kernels at fft 2048
   if (job.lead > 65535) return false;
@@ -593,7 +615,7 @@ void launch_ranges(const StftJob &job, const FastTarget &tg) {
     return;
   }
   if (!tg.mel && !tg.complex_out && !fold_off && job.n < (int64_t(1) << 30) && (i0 - p0) + (p1 - i1) > 0 &&
-      (i0 - p0) + (p1 - i1) < 4096 && border_total <= epilogue_max) {
+      (i0 - p0) + (p1 - i1) < 4096 && border_total <= epilogue_max && c.fft_size != k64N) {   // (fft 4096: gathered strips, below)
     FastTarget folded = tg;
     folded.border_left = (int)(i0 - p0);
     folded.border_right = (int)(p1 - i1);
