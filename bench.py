@@ -534,7 +534,21 @@ def main():
                                      "launches_per_step": nl,
                                      "roofline": {"bound": "hbm", "achieved": round(256 * f256 * b256 / a / 1e6, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                                   "frac": round(256 * f256 * b256 / a / 1e6 / HBM_PEAK_GBS, 4), "algorithmic_bytes_per_frame": b256}}
-            del x1, o1, o256
+            # ... and at fft 4096 / hop 1024 (the reference reaches this size from cqt.ml:648 and hpss.ml:490-492): a frame in a whole wave,
+            # 8-frame single-buffered tiles (round 6: stft4096_power64_kernel; the Stockham kernel before it took 1.07 ms)
+            c4k = Stft.Config.create(fft_size=4096, hop=1024)
+            f4k = Stft.frames(c4k, n1)
+            o4k = torch.empty(256, 2049, f4k, device=dev, dtype=torch.float32)
+            _, ms, nl = timed(lambda: check(lib.smx_stft_power_range_f32_dev(c4k._h, vp(x1.data_ptr()), 256, n1, n1, 0, f4k, 2.0,
+                                                                             vp(o4k.data_ptr()), sptr)), k, w)
+            a = sum(ms) / len(ms)
+            b4k = 1024 * 4 + 2049 * 4
+            extra["fft4096_batch"] = {"workload": "256 clips x 441000 samples, fft 4096 / hop 1024 (%d frames)" % (256 * f4k),
+                                      "value": round(256 * f4k / a / 1e3, 1), "unit": "Mframes/s", "ms": round(a, 4), "ms_min": round(ms[0], 4),
+                                      "launches_per_step": nl,
+                                      "roofline": {"bound": "hbm", "achieved": round(256 * f4k * b4k / a / 1e6, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                                   "frac": round(256 * f4k * b4k / a / 1e6 / HBM_PEAK_GBS, 4), "algorithmic_bytes_per_frame": b4k}}
+            del x1, o1, o256, o4k
             # Stft.transform of the C2 batch (complex64 out: 10 248 algorithmic bytes per frame)
             zc = torch.empty(clips, BINS, frames, 2, device=dev, dtype=torch.float32)
             _, ms, nl = timed(lambda: check(lib.smx_stft_transform_range_f32_dev(cfg._h, vp(x.data_ptr()), clips, n, n, 0, frames,

@@ -5,6 +5,7 @@
 //   stft_power_lanes_kernel / stft_complex_lanes_kernel / stft_mel_lanes_kernel<16 | 8>    the same at fft 1024 / 512 (stft_fast_p16.hpp)
 //   stft2048_complex_fm_kernel                                                             the complex spectrum frame-major, bins stored straight from the registers (Griffin-Lim's own layout)
 //   stft_power_lanes_kernel / stft_complex_lanes_kernel<4>                                  ... and at fft 256 (a frame in 4 lanes, 128-frame tiles)
+//   stft4096_power64_kernel    |X|^p at fft 4096                                            a frame in a WHOLE wave, 8-frame single-buffered tiles (stft_fast_p64.hpp; round 6)
 // They replace, for float32 audio, the reference's hot call
 //   Nx.stft cdtype ~window:fft ~step:hop ~win (to_double samples)   stft.ml:356-364
 // Each audio sample is read from HBM once (hop-strided overlapping frames are re-read through L1 / L2) and the [bins; frames]
@@ -255,7 +256,7 @@ template __global__ void stft2048_complex_fm_kernel<(SMX_ISA_ONE != 0)>(FastArgs
 #elif SMX_ISA_KERNEL == 5
 template __global__ void stft_complex_lanes_kernel<SMX_ISA_ONE, true>(FastArgs);
 #elif SMX_ISA_KERNEL == 8
-template __global__ void stft4096_power64_kernel<true, 2, (SMX_ISA_ONE != 0)>(FastArgs);
+template __global__ void stft4096_power64_kernel<true, 2, SMX_ISA_ONE>(FastArgs);
 #else
 template __global__ void stft2048_power32_kernel<true, 2, false, SMX_ISA_ONE>(FastArgs);
 #endif
@@ -391,14 +392,18 @@ void launch_interior(const StftJob &job, const FastTarget &tg, const float *x, i
     if (tg.complex_out || tg.mel) throw Failure("stft: the fft-4096 pipeline has the power face only");
     a.interleave = 0;   // contiguous tile ranges
     a.pmode = job.power == 2.0 ? 2 : (job.power == 1.0 ? 1 : 0);
-    const bool even = a.out_stride % 2 == 0 && ((reinterpret_cast<uintptr_t>(a.out) >> 2) + (uintptr_t)a.out_offset) % 2 == 0 &&
-                      reinterpret_cast<uintptr_t>(a.out) % 4 == 0;
-    auto by_power = [&](auto al, auto ev) {
-      constexpr bool A = decltype(al)::value, E = decltype(ev)::value;
-      return a.pmode == 2 ? stft4096_power64_kernel<A, 2, E> : a.pmode == 1 ? stft4096_power64_kernel<A, 1, E> : stft4096_power64_kernel<A, 0, E>;
+    // The flush in whole aligned 32-byte sectors (a row's open sector carried across the tiles of a clip): a pair of frames per lane
+    // where the row pitch and the origin are even, else a frame per lane; SMX_POWER_SKEW=0 (tests: same bits; A/B timing) or an output
+    // that is not 4-byte aligned: the plain per-tile flush
+    const bool even = a.out_stride % 2 == 0 && ((reinterpret_cast<uintptr_t>(a.out) >> 2) + (uintptr_t)a.out_offset) % 2 == 0;
+    const int skew = (reinterpret_cast<uintptr_t>(a.out) % 4 != 0 || env_flag("SMX_POWER_SKEW") == 0) ? 0 : even ? 1 : 2;
+    auto by_power = [&](auto al, auto sk) {
+      constexpr bool A = decltype(al)::value;
+      constexpr int K = decltype(sk)::value;
+      return a.pmode == 2 ? stft4096_power64_kernel<A, 2, K> : a.pmode == 1 ? stft4096_power64_kernel<A, 1, K> : stft4096_power64_kernel<A, 0, K>;
     };
-    auto by_al = [&](auto ev) { return aligned ? by_power(std::true_type{}, ev) : by_power(std::false_type{}, ev); };
-    auto k64 = even ? by_al(std::true_type{}) : by_al(std::false_type{});
+    auto by_al = [&](auto sk) { return aligned ? by_power(std::true_type{}, sk) : by_power(std::false_type{}, sk); };
+    auto k64 = skew == 1 ? by_al(std::integral_constant<int, 1>{}) : skew == 2 ? by_al(std::integral_constant<int, 2>{}) : by_al(std::integral_constant<int, 0>{});
     SMX_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k64), hipFuncAttributeMaxDynamicSharedMemorySize, (int)k64Lds));
     SMX_LAUNCH(k64, dim3((unsigned)a.blocks), dim3(512), k64Lds, job.stream, a);
     SMX_HIP_CHECK(hipGetLastError());
