@@ -48,7 +48,7 @@ void set_last_error(const std::string &message);
 // The shipped library reads thirteen variables, each once per use and parsed ONE way (env_flag: unset -> -1, "0" / "" /
 // "false" / "off" -> 0, anything else -> 1); none alters results except by selecting another kernel of the same contract:
 //   SMX_DISABLE_FAST   the generic kernels instead of the hand-laid ones (tests: two implementations of one contract)
-//   SMX_POWER_SKEW=0   fft-2048 / fft-1024 / fft-4096 power spectrogram: the plain per-tile flush instead of whole aligned 64-byte blocks / 128-byte lines / 32-byte sectors (tests, A/B timing)
+//   SMX_POWER_SKEW=0   fft-2048 / fft-1024 power spectrogram: the plain per-tile flush instead of whole aligned 64-byte blocks / 128-byte lines (tests, A/B timing)
 //   SMX_BORDER_INLINE=0 fft 2048 / 1024 / 512 (power / complex spectrogram, fused mel): the border frames in an epilogue / gathered strips instead of the tile sequence (tests: same values)
 //   SMX_COMPLEX_SKEW=0 fft-2048 Stft.transform: the plain per-tile flush instead of whole aligned 128-byte lines (tests, A/B timing)
 //   SMX_INVERT_PIPELINE=0 Stft.invert at fft 2048 / hop 512: the one-tile-per-workgroup kernel of rounds 1-4 instead of the persistent pipeline (tests, A/B timing)

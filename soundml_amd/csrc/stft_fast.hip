@@ -256,7 +256,7 @@ template __global__ void stft2048_complex_fm_kernel<(SMX_ISA_ONE != 0)>(FastArgs
 #elif SMX_ISA_KERNEL == 5
 template __global__ void stft_complex_lanes_kernel<SMX_ISA_ONE, true>(FastArgs);
 #elif SMX_ISA_KERNEL == 8
-template __global__ void stft4096_power64_kernel<true, 2, SMX_ISA_ONE>(FastArgs);
+template __global__ void stft4096_power64_kernel<true, 2, (SMX_ISA_ONE != 0)>(FastArgs);
 #else
 template __global__ void stft2048_power32_kernel<true, 2, false, SMX_ISA_ONE>(FastArgs);
 #endif
@@ -390,20 +390,18 @@ void launch_interior(const StftJob &job, const FastTarget &tg, const float *x, i
   const bool square = a.pmode == 2;
   if (p64) {
     if (tg.complex_out || tg.mel) throw Failure("stft: the fft-4096 pipeline has the power face only");
-    a.interleave = 0;   // contiguous tile ranges
+    // a.interleave as chosen above (2 chip-wide / 1 per XCD): this kernel's 32-byte row runs need the neighbouring tiles written at the
+    // same time (stft_fast_p64.hpp); SMX_P64_CONTIGUOUS=1 in diagnostic builds: contiguous ranges (A/B timing: 0.74 against 0.54 ms)
+    if (diag_flag("SMX_P64_CONTIGUOUS") == 1) a.interleave = 0;
     a.pmode = job.power == 2.0 ? 2 : (job.power == 1.0 ? 1 : 0);
-    // The flush in whole aligned 32-byte sectors (a row's open sector carried across the tiles of a clip): a pair of frames per lane
-    // where the row pitch and the origin are even, else a frame per lane; SMX_POWER_SKEW=0 (tests: same bits; A/B timing) or an output
-    // that is not 4-byte aligned: the plain per-tile flush
-    const bool even = a.out_stride % 2 == 0 && ((reinterpret_cast<uintptr_t>(a.out) >> 2) + (uintptr_t)a.out_offset) % 2 == 0;
-    const int skew = (reinterpret_cast<uintptr_t>(a.out) % 4 != 0 || env_flag("SMX_POWER_SKEW") == 0) ? 0 : even ? 1 : 2;
-    auto by_power = [&](auto al, auto sk) {
-      constexpr bool A = decltype(al)::value;
-      constexpr int K = decltype(sk)::value;
-      return a.pmode == 2 ? stft4096_power64_kernel<A, 2, K> : a.pmode == 1 ? stft4096_power64_kernel<A, 1, K> : stft4096_power64_kernel<A, 0, K>;
+    const bool even = a.out_stride % 2 == 0 && ((reinterpret_cast<uintptr_t>(a.out) >> 2) + (uintptr_t)a.out_offset) % 2 == 0 &&
+                      reinterpret_cast<uintptr_t>(a.out) % 8 == 0;
+    auto by_power = [&](auto al, auto ev) {
+      constexpr bool A = decltype(al)::value, E = decltype(ev)::value;
+      return a.pmode == 2 ? stft4096_power64_kernel<A, 2, E> : a.pmode == 1 ? stft4096_power64_kernel<A, 1, E> : stft4096_power64_kernel<A, 0, E>;
     };
-    auto by_al = [&](auto sk) { return aligned ? by_power(std::true_type{}, sk) : by_power(std::false_type{}, sk); };
-    auto k64 = skew == 1 ? by_al(std::integral_constant<int, 1>{}) : skew == 2 ? by_al(std::integral_constant<int, 2>{}) : by_al(std::integral_constant<int, 0>{});
+    auto by_al = [&](auto ev) { return aligned ? by_power(std::true_type{}, ev) : by_power(std::false_type{}, ev); };
+    auto k64 = even ? by_al(std::true_type{}) : by_al(std::false_type{});
     SMX_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k64), hipFuncAttributeMaxDynamicSharedMemorySize, (int)k64Lds));
     SMX_LAUNCH(k64, dim3((unsigned)a.blocks), dim3(512), k64Lds, job.stream, a);
     SMX_HIP_CHECK(hipGetLastError());

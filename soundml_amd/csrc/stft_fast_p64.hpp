@@ -19,7 +19,8 @@
 // halves' 1056 transposition cells each); with 2 x 76 KB of tile and 48 KB of tables the LDS holds ONE tile, so the tile is
 // single-buffered the way stft2048_complex32_kernel is: a wave reads its share of the previous tile out in the middle of the next
 // frame's first radix-32 (its stores run under the rest of the frame) and nobody writes a cell before every wave has done so.
-// Persistent workgroups over contiguous tile ranges (TileWalk), the next frame's samples requested at the end of the current one.
+// Persistent workgroups walking the tile sequence side by side (TileWalk's interleaved orders: see the kernel), the next frame's samples
+// requested at the end of the current one.
 // LDS: 76,032 (tile) + 16,384 (window) + 7,936 (W_1024^(l k1)) + 16,384 (F per half) + 8,192 (post-pass twiddles) = 124,928 B.
 // The arithmetic is written out operation by operation (packed stages, explicit fused multiply-adds): a frame has ONE value wherever
 // and however it is computed (range tiling, slices, streaming partitions: stft_grid.ml:32-73,180-205, stft_law.ml:79-164).
@@ -153,128 +154,6 @@ __device__ __forceinline__ void flush64_store(const FastArgs &a, const Flush64 &
       else { dst[0] = r.v[p].x; dst[1] = r.v[p].y; }
     } else if (fleft == 1) {
       dst[0] = r.v[p].x;
-    }
-  }
-  if (wave == 0 && lane < 8 && lane < frames_left) obase[(int64_t)2048 * a.out_stride + lane] = r.nyq;
-}
-
-// ---- the flush in whole, aligned 32-byte sectors (even row pitch and origin) -------------------------------------------------------
-// A tile's row run is 8 frames = 32 bytes at whatever alignment the row has: the memory side completes every partial 32-byte sector
-// by a read-modify-write (profiles/r06/store_shape_probe.log: what the fft-2048 kernel's aligned 64-byte blocks cured).  As there
-// (stft_fast_p32.hpp, Skew32), a row's run is held back until it completes a sector: row r's sectors begin e(r) frames into a tile
-// (e even when the pitch and the origin are), the lanes of the first e frames store the tile's pair at once, the lanes of frames
-// e .. 7 store the pair they carried from the previous tile 32 bytes further down -- one instruction, one whole sector per row -- and
-// carry theirs.  Rows 4 apart share an alignment when the pitch is even, and a lane's sixteen parts are rows row0 + 4 (p & 1) +
-// 32 (p >> 1): ONE sector offset per lane and clip.  The workgroup walks consecutive tiles of a clip (contiguous ranges); where a
-// range or a clip begins nothing is carried, where it ends the carried pairs go out as the partial sector they are.
-struct Skew64 {
-  unsigned goff;             // from 32 bytes BEFORE a tile's origin: byte offset of out[row0][2 g], plus 32 for the lanes that store the current pair
-  unsigned long long sel;    // the lanes whose pair of the current tile completes the sector
-};
-__device__ __forceinline__ void skew64_lane(int lane, int wave, int &row0, int &g) {
-  asm volatile("" : "+v"(lane));
-  const int half = lane >> 5, ridx = (lane & 31) >> 2;
-  g = lane & 3;
-  row0 = 256 * wave + (ridx & 1) + 8 * (ridx >> 1) + 2 * half;
-}
-__device__ __forceinline__ void skew64_clip(const FastArgs &a, Skew64 &sk, const float *oclip, int lane, int wave) {
-  int row0, g;
-  skew64_lane(lane, wave, row0, g);
-  const unsigned at = (unsigned)((reinterpret_cast<uintptr_t>(oclip) >> 2) + (uintptr_t)row0 * (uintptr_t)a.out_stride) & 7u;
-  const unsigned e = at ? 8u - at : 8u;          // frames of a tile that end the row's open sector
-  const bool now = 2u * (unsigned)g < e;
-  sk.sel = __ballot(now);
-  sk.goff = ((unsigned)row0 * (unsigned)a.out_stride + 2u * (unsigned)g) * 4u + (now ? 32u : 0u);
-}
-// obase: origin of the tile that `r` holds; fresh: nothing is carried into it; closing: nothing follows it in its clip (or in this
-// workgroup's range); frames_left: its frames that exist (8 unless it is a clip's last tile)
-__device__ __forceinline__ void skew64_store(const FastArgs &a, const Skew64 &sk, float *obase, int frames_left, bool fresh, bool closing,
-                                             int wave, int lane, const Flush64Regs &r, float2 (&carry)[16]) {
-  const unsigned pitch = (unsigned)a.out_stride * 4u;
-  if (frames_left >= k64FT && !fresh && !closing) {   // wave-uniform: one whole sector per row and part
-    const unsigned g0 = opaque32(sk.goff);
-#pragma unroll
-    for (int p = 0; p < 16; ++p) {
-      store2_at(obase - k64FT, g0 + (unsigned)flush64_rows(p) * pitch, select_lanes(carry[p].x, r.v[p].x, sk.sel), select_lanes(carry[p].y, r.v[p].y, sk.sel));
-      carry[p] = r.v[p];
-    }
-  } else {
-    int row0, g;
-    skew64_lane(lane, wave, row0, g);
-    const bool now = (sk.sel >> lane) & 1;
-    const unsigned gl = ((unsigned)row0 * (unsigned)a.out_stride + 2u * (unsigned)g) * 4u;
-    const int f = 2 * g;
-#pragma unroll
-    for (int p = 0; p < 16; ++p) {
-      float *dst = reinterpret_cast<float *>(reinterpret_cast<char *>(obase) + (gl + (unsigned)flush64_rows(p) * pitch));
-      if (now || closing) {
-        if (f + 1 < frames_left) *reinterpret_cast<float2 *>(dst) = r.v[p];          // (8-byte aligned: even pitch and origin)
-        else if (f < frames_left) dst[0] = r.v[p].x;
-      }
-      if (!now && !fresh) *reinterpret_cast<float2 *>(dst - k64FT) = carry[p];
-      carry[p] = r.v[p];
-    }
-  }
-  if (wave == 0 && lane < 8 && lane < frames_left) obase[(int64_t)2048 * a.out_stride + lane] = r.nyq;
-}
-
-// ---- the same for ANY row pitch and origin: one frame per lane -----------------------------------------------------------------------
-// With an odd row pitch (431 or 469 frames a clip: ten seconds at 44.1 / 48 kHz and hop 1024) a row's open sector ends an odd number of
-// frames into a tile and the alignment differs from row to row with period 8, so a lane holds ONE frame of a row (8 lanes a row, 8 rows
-// an instruction) and a wave takes the rows of one residue mod 8 -- rows wave + 8 k, k < 256 -- instead of 256 consecutive ones: all 32
-// parts of a lane (rows row_l + 64 p) then share one sector offset.  (LDS reads: bank = 8 (lane >> 3) + (lane & 7) within a half-wave.)
-struct SkewG64 {
-  unsigned goff;             // from 32 bytes BEFORE a tile's origin: byte offset of out[row_l][col], plus 32 for the lanes that store the current frame
-  unsigned long long sel;    // the lanes whose frame of the current tile completes the sector
-};
-struct FlushG64Regs {
-  float cur[32];
-  float nyq;
-};
-__device__ __forceinline__ void skewg64_lane(int lane, int wave, int &row_l, int &col) {
-  asm volatile("" : "+v"(lane));
-  col = lane & 7;
-  row_l = wave + 8 * (lane >> 3);
-}
-__device__ __forceinline__ void skewg64_clip(const FastArgs &a, SkewG64 &sk, const float *oclip, int lane, int wave) {
-  int row_l, col;
-  skewg64_lane(lane, wave, row_l, col);
-  const unsigned at = (unsigned)((reinterpret_cast<uintptr_t>(oclip) >> 2) + (uintptr_t)row_l * (uintptr_t)a.out_stride) & 7u;
-  const unsigned e = at ? 8u - at : 8u;
-  const bool now = (unsigned)col < e;
-  sk.sel = __ballot(now);
-  sk.goff = ((unsigned)row_l * (unsigned)a.out_stride + (unsigned)col) * 4u + (now ? 32u : 0u);
-}
-__device__ __forceinline__ void skewg64_read(const float *tile, int lane, int wave, FlushG64Regs &r) {
-  int row_l, col;
-  skewg64_lane(lane, wave, row_l, col);
-  const float *src0 = tile + row_l * k64TS + col;
-  const float *src1 = src0 + 16 * 64 * k64TS;   // (ds offsets are 16 bits)
-#pragma unroll
-  for (int p = 0; p < 32; ++p) r.cur[p] = (p < 16 ? src0 : src1)[64 * k64TS * (p & 15)];
-  r.nyq = tile[2048 * k64TS + (lane & 7)];
-}
-__device__ __forceinline__ void skewg64_store(const FastArgs &a, const SkewG64 &sk, float *obase, int frames_left, bool fresh, bool closing,
-                                              int wave, int lane, const FlushG64Regs &r, float (&carry)[32]) {
-  const unsigned pitch = (unsigned)a.out_stride * 4u;
-  if (frames_left >= k64FT && !fresh && !closing) {   // wave-uniform: one whole sector per row and part
-    const unsigned g = opaque32(sk.goff);
-#pragma unroll
-    for (int p = 0; p < 32; ++p) {
-      store1_at(obase - k64FT, g + 64u * (unsigned)p * pitch, select_lanes(carry[p], r.cur[p], sk.sel));
-      carry[p] = r.cur[p];
-    }
-  } else {
-    int row_l, col;
-    skewg64_lane(lane, wave, row_l, col);
-    const bool now = (sk.sel >> lane) & 1;
-    const unsigned gl = ((unsigned)row_l * (unsigned)a.out_stride + (unsigned)col) * 4u;
-#pragma unroll
-    for (int p = 0; p < 32; ++p) {
-      float *dst = reinterpret_cast<float *>(reinterpret_cast<char *>(obase) + (gl + 64u * (unsigned)p * pitch));
-      if ((now || closing) && col < frames_left) dst[0] = r.cur[p];
-      if (!now && !fresh) dst[-k64FT] = carry[p];
-      carry[p] = r.cur[p];
     }
   }
   if (wave == 0 && lane < 8 && lane < frames_left) obase[(int64_t)2048 * a.out_stride + lane] = r.nyq;
@@ -434,16 +313,11 @@ __device__ __forceinline__ void frame64_to_tile(const FastArgs &a, const Lds64 &
 #undef SMX_PA
 }
 
-template <bool ALIGNED, int SKEW>
+template <bool ALIGNED, bool EVEN>
 struct PowerMid64 {
   const FastArgs &a;
   const Lds64 &lds;
   const Flush64 &fl;
-  const Skew64 &sk;
-  float2 (&carry)[16];
-  const SkewG64 &skg;
-  float (&carryg)[32];
-  bool pend_fresh, pend_closing;
   float2 (&raw)[32];
   const float *src;
   float *pend_out;
@@ -452,18 +326,10 @@ struct PowerMid64 {
   __device__ __forceinline__ void early() const {   // between the two 16-point transforms of the first radix-32
     if (it > 0) {
       lds_wait(lds.filled, 8u * (unsigned)it);       // every wave's column of the previous tile is in
-      if constexpr (SKEW == 2) {
-        FlushG64Regs fg;
-        skewg64_read(lds.tile, lane, wave, fg);
-        lds_signal32(lds.drained, lane);             // behind this wave's reads in LDS order
-        skewg64_store(a, skg, pend_out, pend_left, pend_fresh, pend_closing, wave, lane, fg, carryg);
-      } else {
-        Flush64Regs fr;
-        flush64_read(lds.tile, fl, lane, fr);
-        lds_signal32(lds.drained, lane);
-        if constexpr (SKEW == 1) skew64_store(a, sk, pend_out, pend_left, pend_fresh, pend_closing, wave, lane, fr, carry);
-        else flush64_store<false>(a, fl, pend_out, pend_left, wave, lane, fr);
-      }
+      Flush64Regs fr;
+      flush64_read(lds.tile, fl, lane, fr);
+      lds_signal32(lds.drained, lane);               // behind this wave's reads in LDS order
+      flush64_store<EVEN>(a, fl, pend_out, pend_left, wave, lane, fr);
     }
   }
   __device__ __forceinline__ void before_cells() const {
@@ -472,8 +338,12 @@ struct PowerMid64 {
   __device__ __forceinline__ void load_next() const { load_frame64<ALIGNED>(src, 2 * (lane & 31) + (lane >> 5), raw); }
 };
 
-// SKEW: 0 the plain per-tile flush, 1 aligned sectors with a pair of frames per lane (even pitch and origin), 2 with a frame per lane
-template <bool ALIGNED, int PMODE, int SKEW>
+// EVEN: even row pitch and origin (8-byte stores of a frame pair).  Tile order: the workgroups walk the flat (clip, tile) sequence SIDE BY
+// SIDE (TileWalk's interleaved orders), not contiguous ranges: a tile's row run is only 32 bytes, and a 128-byte line of the result is
+// complete after FOUR consecutive tiles -- with contiguous ranges those are 60 us apart in one workgroup and 67 MB of lines stand open
+// chip-wide against 32 MB of L2 (0.74 ms; aligned-sector carries helped 5 %); side by side the 32 workgroups of an XCD write 32
+// neighbouring tiles at once, 1 KB per row, and its L2 assembles whole lines: 0.54 ms (profiles/r08/ab_p64_interleave.log).
+template <bool ALIGNED, int PMODE, bool EVEN>
 __global__ void __launch_bounds__(512) stft4096_power64_kernel(FastArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x;
@@ -503,16 +373,6 @@ __global__ void __launch_bounds__(512) stft4096_power64_kernel(FastArgs a) {
   if (ntiles > 0) load_frame64<ALIGNED>(frame_ptr(tw.xclip, tw.ft), 2 * (lane & 31) + (lane >> 5), raw);
   __syncthreads();   // tables and zeroed counters
   const Flush64 fl = setup_flush64(a, lane, wave);
-  Skew64 sk{};
-  float2 carry[16];
-#pragma unroll
-  for (int p = 0; p < 16; ++p) carry[p] = make_float2(0.f, 0.f);
-  SkewG64 skg{};
-  float carryg[32];
-#pragma unroll
-  for (int p = 0; p < 32; ++p) carryg[p] = 0.f;
-  bool pend_fresh = true, pend_closing = false;
-  const float *pend_oclip = nullptr;
   float *pend_out = nullptr;
   int pend_left = 0;
   for (int it = 0; it < ntiles; ++it) {
@@ -522,40 +382,20 @@ __global__ void __launch_bounds__(512) stft4096_power64_kernel(FastArgs a) {
     tw.peek(a, ftnext, xnext, onext);
     const bool more = it + 1 < ntiles;
     const float *src = frame_ptr(more ? xnext : tw.xclip, more ? ftnext : tw.ft);
-    if constexpr (SKEW == 1) {
-      if (it > 0 && pend_fresh) skew64_clip(a, sk, pend_oclip, lane, wave);   // (wave-uniform) the pending tile begins a clip or this workgroup's range
-    } else if constexpr (SKEW == 2) {
-      if (it > 0 && pend_fresh) skewg64_clip(a, skg, pend_oclip, lane, wave);
-    }
-    const PowerMid64<ALIGNED, SKEW> mid{a, lds, fl, sk, carry, skg, carryg, pend_fresh, pend_closing, raw, src, pend_out, pend_left, lane, wave, it};
+    const PowerMid64<ALIGNED, EVEN> mid{a, lds, fl, raw, src, pend_out, pend_left, lane, wave, it};
     frame64_to_tile<PMODE>(a, lds, lane, wave, raw, mid);
     lds_signal32(lds.filled, lane);
     pend_out = tw.oclip + tw.ft * k64FT;
     const int64_t left = a.count - (int64_t)tw.ft * k64FT;
     pend_left = left < k64FT ? (int)left : k64FT;
-    pend_oclip = tw.oclip;
-    pend_fresh = it == 0 || tw.ft == 0;
-    pend_closing = tw.ft == a.tiles_per_clip - 1;
     tw.xclip = xnext;
     tw.oclip = onext;
     tw.ft = ftnext;
   }
   if (ntiles > 0) {
     lds_wait(lds.filled, 8u * (unsigned)ntiles);
-    if constexpr (SKEW == 2) {
-      FlushG64Regs fg;
-      skewg64_read(lds.tile, lane, wave, fg);
-      if (pend_fresh) skewg64_clip(a, skg, pend_oclip, lane, wave);
-      skewg64_store(a, skg, pend_out, pend_left, pend_fresh, true, wave, lane, fg, carryg);
-    } else {
-      Flush64Regs fr;
-      flush64_read(lds.tile, fl, lane, fr);
-      if constexpr (SKEW == 1) {
-        if (pend_fresh) skew64_clip(a, sk, pend_oclip, lane, wave);
-        skew64_store(a, sk, pend_out, pend_left, pend_fresh, true, wave, lane, fr, carry);
-      } else {
-        flush64_store<false>(a, fl, pend_out, pend_left, wave, lane, fr);
-      }
-    }
+    Flush64Regs fr;
+    flush64_read(lds.tile, fl, lane, fr);
+    flush64_store<EVEN>(a, fl, pend_out, pend_left, wave, lane, fr);
   }
 }

@@ -64,6 +64,7 @@ struct Args {
   const V2 *tw_m, *tw_n;    // exp(-2 pi i j / 1024) (j < 256 read), exp(-2 pi i k / 2048) (k < 1024 read)
   int tiles_per_clip;
   int64_t total_tiles, blocks;
+  int contiguous;   // 1: contiguous tile ranges per workgroup (rounds 4-5); 0: the workgroups side by side through the sequence
 };
 
 // the samples of frame p of the clip at x (lane tid: pairs 2 (tid + 64 m)), zero for a frame beyond the request
@@ -306,11 +307,19 @@ __global__ void __launch_bounds__(512) stft2048_power_wide_kernel(Args A) {
       *l.drained = 0u;
     }
   }
-  // this workgroup's contiguous range of the flat (clip, tile) sequence
+  // This workgroup's tiles of the flat (clip, tile) sequence.  Round 6: the workgroups walk the sequence SIDE BY SIDE -- tile
+  // tau0 + it * blocks, the workgroups of an XCD (blockIdx.x % 8) on neighbouring tiles -- instead of contiguous ranges: the plain flush
+  // writes a 64-byte run per row and tile, a 128-byte line of the result is complete after two consecutive tiles, and with contiguous
+  // ranges those are ~70 us apart in one workgroup (34 MB of open lines against 32 MB of L2: WRITE_SIZE 1.35-1.38 x the output);
+  // side by side an XCD writes 32 neighbouring tiles at once and its L2 assembles whole lines (what profiles/r08/NOTES.md section 9
+  // found for the fft-4096 kernel).  A.contiguous (SMX_WIDE_CONTIGUOUS=1 in diagnostic builds): the ranges of rounds 4-5, A/B timing.
   const int64_t nb = A.blocks, vb = blockIdx.x;
   const int64_t per = A.total_tiles / nb, extra = A.total_tiles % nb;
-  const int64_t tau0 = vb * per + (vb < extra ? vb : extra);
-  const int ntiles = (int)(per + (vb < extra ? 1 : 0));
+  const int64_t xq = nb / 8, xr = nb % 8, xcd = vb % 8, xidx = vb / 8;
+  const int64_t side0 = (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + xidx;
+  const int64_t tau0 = A.contiguous ? vb * per + (vb < extra ? vb : extra) : side0;
+  const int64_t tau_step = A.contiguous ? 1 : nb;
+  const int ntiles = A.contiguous ? (int)(per + (vb < extra ? 1 : 0)) : (side0 < A.total_tiles ? (int)((A.total_tiles - side0 + nb - 1) / nb) : 0);
   const float *x0 = reinterpret_cast<const float *>(a.x);
   float *out0 = reinterpret_cast<float *>(a.out);
   auto tile_of = [&](int64_t tau, const float *&xc, float *&oc, int64_t &f0, int &nf) {
@@ -409,7 +418,7 @@ __global__ void __launch_bounds__(512) stft2048_power_wide_kernel(Args A) {
     if (rd == 1) {
       hq = false;
       if (it + 1 < ntiles) {
-        tile_of(tau0 + it + 1, xn, on, f0n, nfn);
+        tile_of(tau0 + (int64_t)(it + 1) * tau_step, xn, on, f0n, nfn);
         xq = xn;
         pq = a.p0 + f0n + wave;
         hq = wave < nfn;
@@ -480,6 +489,7 @@ inline bool launch(const StftJob &job, const GenericArgs &g, const StftTables &t
   A.total_tiles = g.lead * tiles;
   const int cu_count = device_cu_count();   // (per device, thread-safe: tables.cpp)
   A.blocks = A.total_tiles < cu_count ? A.total_tiles : cu_count;
+  A.contiguous = diag_flag("SMX_WIDE_CONTIGUOUS") == 1 ? 1 : 0;
   auto kernel = g.power == 2.0 ? stft2048_power_wide_kernel<2> : g.power == 1.0 ? stft2048_power_wide_kernel<1> : stft2048_power_wide_kernel<0>;
   SMX_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, kLds));
   SMX_LAUNCH(kernel, dim3((unsigned)A.blocks), dim3(512), kLds, job.stream, A);
