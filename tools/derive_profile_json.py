@@ -37,7 +37,8 @@ ALGO = {"stft2048_power32": (256 * FR2048 * 2048, 256 * FR2048 * 4100), "stft204
         "istft2048": (256 * FR2048 * 8200, 256 * FR2048 * 2048), "mel_apply_mfma": (256 * FR2048 * 4100, 256 * FR2048 * 512), "fir_ols": (8 * 2880000 * 4, 8 * 2880000 * 4),
         "stft_power_lanes_kernel<16": (256 * FR1K * 1024, 256 * FR1K * 2052), "stft_power_lanes_kernel<8": (256 * FR512 * 512, 256 * FR512 * 1028),
         "stft_power_lanes_kernel<4": (256 * FR256 * 256, 256 * FR256 * 516),
-        "wide64::stft2048_power_wide": (256 * FR2048 * 2048, 256 * FR2048 * 4100)}
+        "wide64::stft2048_power_wide": (256 * FR2048 * 2048, 256 * FR2048 * 4100),
+        "stft4096_power64": (256 * 431 * 4096, 256 * 431 * 8196)}
 
 
 def fetch_factor(cc, algo_read):
@@ -86,7 +87,7 @@ if os.path.exists(bench_path):
              "stft2048_power32": line["roofline"].get("kernel_ms_avg"), "stft2048_complex32": ex.get("c2_complex", {}).get("ms"),
              "istft2048": ex.get("c2_invert", {}).get("ms"), "stft2048_mel32": ex.get("c3_mel", {}).get("ms"),
              "stft_power_lanes_kernel<16": ex.get("c1_batch", {}).get("ms"), "stft_power_lanes_kernel<4": ex.get("fft256_batch", {}).get("ms"), "fir_ols": ex.get("c4_fir", {}).get("ms"),
-             "wide64::stft2048_power_wide": ex.get("c2_float64_interior", {}).get("ms")}
+             "wide64::stft2048_power_wide": ex.get("c2_float64_interior", {}).get("ms"), "stft4096_power64": ex.get("fft4096_batch", {}).get("ms")}
     for name, row in table.items():
         ms = next((v for key, v in pairs.items() if name.startswith(key)), None)
         row["bench_ms"] = ms

@@ -52,6 +52,12 @@ each(lambda: check(lib.smx_stft_power_range_f32_dev(c1k._h, vp(x1.data_ptr()), 2
 each(lambda: check(lib.smx_stft_power_range_f32_dev(c512._h, vp(x1.data_ptr()), 256, 441000, 441000, 0, f512, 2.0, vp(o512.data_ptr()), None)))
 each(lambda: check(lib.smx_stft_power_range_f32_dev(c256._h, vp(x1.data_ptr()), 256, 441000, 441000, 0, f256, 2.0, vp(o256.data_ptr()), None)))
 each(lambda: check(lib.smx_fir_apply_f32_dev(plan._h, vp(xs.data_ptr()), 8, 2880000, 2880000, vp(ys.data_ptr()), 2880000, None)))
+# fft 4096 / hop 1024 on the same 256 x 441000 batch: stft4096_power64_kernel (round 6)
+c4k = Stft.Config.create(fft_size=4096, hop=1024)
+f4k = Stft.frames(c4k, 441000)
+o4k = torch.empty(256, 2049, f4k, device="cuda")
+each(lambda: check(lib.smx_stft_power_range_f32_dev(c4k._h, vp(x1.data_ptr()), 256, 441000, 441000, 0, f4k, 2.0, vp(o4k.data_ptr()), None)))
+del o4k
 # Griffin-Lim's loop (6 iterations a call): its frame-major kernels, stft2048_complex_fm_kernel and istft2048_pipe_kernel<true, true>
 lib.smx_stft_griffin_lim_f32_dev.argtypes = [vp, vp, ctypes.c_int64, ctypes.c_int64, ctypes.c_int64, ctypes.c_int64, ctypes.c_double, vp, ctypes.c_int, ctypes.c_int64, vp, vp]
 out.copy_(torch.rand_like(out))

@@ -42,7 +42,7 @@ rows = collections.defaultdict(lambda: collections.defaultdict(list))
 for f in glob.glob(out_dir + '/pmc_g*/**/*counter_collection.csv', recursive=True):
     for r in csv.DictReader(open(f)):
         k = r['Kernel_Name']
-        if not re.search(r'stft2048|stft_power_lanes|mel_apply|fir_ols|istft2048', k):
+        if not re.search(r'stft2048|stft4096|stft_power_lanes|mel_apply|fir_ols|istft2048', k):
             continue
         k = re.sub(r'\(smx::.*', '', k.replace('void smx::(anonymous namespace)::', ''))
         rows[k][r['Counter_Name']].append(float(r['Counter_Value']))
