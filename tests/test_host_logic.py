@@ -553,6 +553,9 @@ def test_committed_profile_reproduces_the_committed_bench_line():
     assert len(rows) >= 6, sorted(tj["per_kernel"])
     for name, row in rows.items():
         # (5 %, or the ~10 us a HIP-event pair around a step holds beyond the kernel itself: the launch gap -- it matters for C4's 0.09 ms step only)
-        assert row["avg_us"] is not None and abs(row["avg_us"] / 1e3 - row["bench_ms"]) <= max(0.05 * row["bench_ms"], 0.010), (name, row["avg_us"], row["bench_ms"])
+        # (`companion_us`: a second kernel inside the same timed step -- the fft-4096 step gathers its border strips first)
+        assert row["avg_us"] is not None, name
+        in_trace_ms = (row["avg_us"] + row.get("companion_us", 0.0)) / 1e3
+        assert abs(in_trace_ms - row["bench_ms"]) <= max(0.05 * row["bench_ms"], 0.010), (name, in_trace_ms, row["bench_ms"])
     inv = next(v for k, v in tj["per_kernel"].items() if k.startswith("istft2048"))
     assert inv["algorithmic_bytes"] == 256 * 938 * (8200 + 2048)

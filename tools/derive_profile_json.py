@@ -88,9 +88,21 @@ if os.path.exists(bench_path):
              "istft2048": ex.get("c2_invert", {}).get("ms"), "stft2048_mel32": ex.get("c3_mel", {}).get("ms"),
              "stft_power_lanes_kernel<16": ex.get("c1_batch", {}).get("ms"), "stft_power_lanes_kernel<4": ex.get("fft256_batch", {}).get("ms"), "fir_ols": ex.get("c4_fir", {}).get("ms"),
              "wide64::stft2048_power_wide": ex.get("c2_float64_interior", {}).get("ms"), "stft4096_power64": ex.get("fft4096_batch", {}).get("ms")}
+    # the fft-4096 step is TWO launches (launches_per_step in the line): the gather of the clips' border strips, then the pipeline; the
+    # event pair around the step holds both, so the gather's average in the same trace (kernel_stats.csv) stands beside the pipeline's
+    gather_us = None
+    stats_path = os.path.join(ROOT, "profiles", rnd, "kernel_stats.csv")
+    if os.path.exists(stats_path):
+        import csv
+        for r in csv.DictReader(open(stats_path)):
+            if "gather_padded_kernel" in r["Name"]:
+                gather_us = round(float(r["AverageNs"]) / 1e3, 1)
     for name, row in table.items():
         ms = next((v for key, v in pairs.items() if name.startswith(key)), None)
         row["bench_ms"] = ms
+        if name.startswith("stft4096_power64") and ms is not None and gather_us is not None:
+            row["companion_us"] = gather_us
+            row["companion"] = "gather_padded_kernel (the border strips), launched before the pipeline inside the same timed step"
         row["bench_source"] = "profiles/%s/bench_n1.json (the traced run itself)" % rnd if ms is not None else None
 tj = json.load(open(os.path.join(ROOT, "profiles", "hbm_traffic.json")))
 tj["per_kernel"] = table
