@@ -298,8 +298,16 @@ __device__ __forceinline__ void mel4r_items(const Mel32Args &m, int iv, const fl
   const int mg = lane >> 4, f = lane & 15;
   // scalar state of the sub-chunk being REQUESTED (one ahead of the one being multiplied)
   int item = 0, st = 0, steps = 0, mode = 0, rows = 0, nrw = 0;
-  const float *bp = tile;
-  int room = 0;
+  // (the tile through an LDS-address-space pointer: 32-bit address arithmetic and the rows of a request as IMMEDIATE offsets of one
+  // base register; through the generic pointer every read cost a v_min and a 64-bit v_mad beside the ds_read itself)
+  using lds_f = const __attribute__((address_space(3))) float;
+  lds_f *const tile3 = (lds_f *)tile;
+  // (the row pitch of the result as a scalar of its own: read out of the argument block at every use, the compiler reloaded the
+  // block's eight spilled registers around each of an item's four stores)
+  int64_t out_pitch = m.out_stride;
+  asm volatile("" : "+s"(out_pitch));
+  lds_f *bp = tile3;
+  int room = 0, room_min = 0;
   auto open_item = [&]() {
     const int sm = __builtin_amdgcn_readlane(iv, 8 * item + 6);
     steps = sm & 0xffff;
@@ -308,19 +316,32 @@ __device__ __forceinline__ void mel4r_items(const Mel32Args &m, int iv, const fl
     nrw = __builtin_amdgcn_readlane(iv, 8 * item + 1);
     const int k0 = __builtin_amdgcn_readlane(iv, 8 * item + 2), k1 = __builtin_amdgcn_readlane(iv, 8 * item + 3);
     const int k2 = __builtin_amdgcn_readlane(iv, 8 * item + 4), k3 = __builtin_amdgcn_readlane(iv, 8 * item + 5);
-    const int kbl = mg == 0 ? k0 : mg == 1 ? k1 : mg == 2 ? k2 : k3;
-    bp = tile + kbl * TS + f;
+    int kbl = k0;   // (three selects: the nested form compiled to branches on the execution mask)
+    kbl = mg == 1 ? k1 : kbl;
+    kbl = mg == 2 ? k2 : kbl;
+    kbl = mg == 3 ? k3 : kbl;
+    bp = tile3 + kbl * TS + f;
     room = m.last_bin - kbl;
+    const int k01 = k0 > k1 ? k0 : k1, k23 = k2 > k3 ? k2 : k3;
+    room_min = m.last_bin - (k01 > k23 ? k01 : k23);   // (scalar: the group that comes closest to the last spectrum row)
     st = 0;
   };
   open_item();
   if (steps == 0) return;
   float bv[2][SUB][NCG];
   auto request = [&](int slot) {
+    if (st + SUB - 1 <= room_min) {   // wave-uniform: no group's rows of this request pass the last spectrum row (all but a filterbank's top items)
+      lds_f *row0 = bp + st * TS;
+#pragma unroll
+      for (int u = 0; u < SUB; ++u)
+#pragma unroll
+        for (int g = 0; g < NCG; ++g) bv[slot][u][g] = row0[u * TS + 16 * g];
+      return;
+    }
 #pragma unroll
     for (int u = 0; u < SUB; ++u) {
       const int q = st + u;
-      const float *row = bp + (q < room ? q : room) * TS;
+      lds_f *row = bp + (q < room ? q : room) * TS;
 #pragma unroll
       for (int g = 0; g < NCG; ++g) bv[slot][u][g] = row[16 * g];
     }
@@ -356,7 +377,7 @@ __device__ __forceinline__ void mel4r_items(const Mel32Args &m, int iv, const fl
         acc[t] = __builtin_amdgcn_mfma_f32_4x4x1f32(areg[SUB * c + u], bv[c & 1][u][g], acc[t], 0, 0, 0);
       }
     if (c_last) {
-      const bool owner = c_mode == 1 || (c_mode == 2 ? (mg & 1) == 0 : mg == 0);
+      const bool owner = (mg & (c_mode - 1)) == 0;   // mode 1: every lane group its own rows; 2: groups 0 and 2; 4: group 0
       const int row0 = (int)(((unsigned)c_rows >> (8 * mg)) & 255u), nr = (int)(((unsigned)c_nrw >> (8 * mg)) & 255u);
 #pragma unroll
       for (int g = 0; g < NCG; ++g) {
@@ -374,10 +395,13 @@ __device__ __forceinline__ void mel4r_items(const Mel32Args &m, int iv, const fl
           }
           sum = f32x4m{s0, s1, s2, s3};
         }
-        if (owner && 16 * g + f < frames_left) {
+        if (owner && 16 * g + f < frames_left) {   // (one 64-bit row address, the other rows a pitch further each)
+          float *po = obase + (int64_t)row0 * out_pitch + (16 * g + f);
 #pragma unroll
-          for (int r = 0; r < 4; ++r)
-            if (r < nr) obase[(int64_t)(row0 + r) * m.out_stride + 16 * g + f] = sum[r];
+          for (int r = 0; r < 4; ++r) {
+            if (r < nr) po[0] = sum[r];   // (an idle lane group of an item has no rows)
+            po += out_pitch;
+          }
         }
       }
 #pragma unroll
