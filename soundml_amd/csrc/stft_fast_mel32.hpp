@@ -289,9 +289,54 @@ constexpr int kMel4rChunks = 8;
 // TS: floats per tile row; NCG: groups of 16 frame columns multiplied at once (the tiles of the 16- / 8-lane kernels hold 32 / 64
 // frames: an operand register serves every group); CHUNKS: operand registers / 8; SUB: steps per request (B values in flight:
 // 2 x SUB x NCG registers)
-template <int TS = kTileStride, int NCG = 1, int CHUNKS = kMel4rChunks, int SUB = 8>
+// Where a wave's requests begin, worked out ONCE per kernel (the plan is the same for every tile): per lane the tile offset (in floats)
+// of the first B row of each of the 8 sub-chunks, two to a register, and a scalar mask of the sub-chunks whose rows pass the last
+// spectrum row for some lane group (those take the clamped path).  With it a request is one address register and 4 ds_read2 with
+// immediate offsets; without it (the lanes kernels) the band of the lane's group is re-derived from the plan at every item.
+struct Mel4rSlots {
+  unsigned boff[4];
+  unsigned slow_mask;
+};
+template <int TS = kTileStride, int CHUNKS = kMel4rChunks, int SUB = 8>
+__device__ __forceinline__ Mel4rSlots mel4r_slots(const Mel32Args &m, int iv, int lane) {
+  constexpr int SLOTS = 8 * CHUNKS / SUB;
+  static_assert(SLOTS == 8, "two 16-bit offsets to each of four registers");
+  Mel4rSlots p{{0u, 0u, 0u, 0u}, 0u};
+  const int mg = lane >> 4, f = lane & 15;
+  int item = 0, st = 0, steps = 0, kbl = 0, room_min = 0;
+  auto open = [&]() {
+    steps = __builtin_amdgcn_readlane(iv, 8 * item + 6) & 0xffff;
+    const int k0 = __builtin_amdgcn_readlane(iv, 8 * item + 2), k1 = __builtin_amdgcn_readlane(iv, 8 * item + 3);
+    const int k2 = __builtin_amdgcn_readlane(iv, 8 * item + 4), k3 = __builtin_amdgcn_readlane(iv, 8 * item + 5);
+    kbl = k0;
+    kbl = mg == 1 ? k1 : kbl;
+    kbl = mg == 2 ? k2 : kbl;
+    kbl = mg == 3 ? k3 : kbl;
+    const int k01 = k0 > k1 ? k0 : k1, k23 = k2 > k3 ? k2 : k3;
+    room_min = m.last_bin - (k01 > k23 ? k01 : k23);
+    st = 0;
+  };
+  open();
+#pragma unroll
+  for (int c = 0; c < SLOTS; ++c) {
+    if (steps != 0) {
+      const unsigned off = (unsigned)((kbl + st) * TS + f);
+      p.boff[c >> 1] |= (c & 1) ? off << 16 : off;
+      if (st + SUB - 1 > room_min) p.slow_mask |= 1u << c;
+      if (st + SUB >= steps) {
+        ++item;
+        if (item < kMel32MaxItems) open();
+        else steps = 0;
+      } else {
+        st += SUB;
+      }
+    }
+  }
+  return p;
+}
+template <int TS = kTileStride, int NCG = 1, int CHUNKS = kMel4rChunks, int SUB = 8, bool PRE = false>
 __device__ __forceinline__ void mel4r_items(const Mel32Args &m, int iv, const float (&areg)[8 * CHUNKS], const float *tile, float *obase,
-                                            int frames_left, int lane) {
+                                            int frames_left, int lane, const Mel4rSlots &pre = Mel4rSlots{}) {
   using f32x4m = __attribute__((ext_vector_type(4))) float;
   constexpr int SLOTS = 8 * CHUNKS / SUB;
   constexpr int NA = NCG == 1 ? 2 : NCG;   // accumulators: two alternating ones for a single column group, one per group otherwise
@@ -314,6 +359,8 @@ __device__ __forceinline__ void mel4r_items(const Mel32Args &m, int iv, const fl
     mode = sm >> 16;
     rows = __builtin_amdgcn_readlane(iv, 8 * item);
     nrw = __builtin_amdgcn_readlane(iv, 8 * item + 1);
+    st = 0;
+    if constexpr (PRE) return;   // (the band of the lane's group is in pre.boff; the clamped path derives it itself)
     const int k0 = __builtin_amdgcn_readlane(iv, 8 * item + 2), k1 = __builtin_amdgcn_readlane(iv, 8 * item + 3);
     const int k2 = __builtin_amdgcn_readlane(iv, 8 * item + 4), k3 = __builtin_amdgcn_readlane(iv, 8 * item + 5);
     int kbl = k0;   // (three selects: the nested form compiled to branches on the execution mask)
@@ -329,8 +376,29 @@ __device__ __forceinline__ void mel4r_items(const Mel32Args &m, int iv, const fl
   open_item();
   if (steps == 0) return;
   float bv[2][SUB][NCG];
-  auto request = [&](int slot) {
-    if (st + SUB - 1 <= room_min) {   // wave-uniform: no group's rows of this request pass the last spectrum row (all but a filterbank's top items)
+  auto band_of_item = [&]() {   // (PRE, clamped path only)
+    const int k0 = __builtin_amdgcn_readlane(iv, 8 * item + 2), k1 = __builtin_amdgcn_readlane(iv, 8 * item + 3);
+    const int k2 = __builtin_amdgcn_readlane(iv, 8 * item + 4), k3 = __builtin_amdgcn_readlane(iv, 8 * item + 5);
+    int kbl = k0;
+    kbl = mg == 1 ? k1 : kbl;
+    kbl = mg == 2 ? k2 : kbl;
+    kbl = mg == 3 ? k3 : kbl;
+    bp = tile3 + kbl * TS + f;
+    room = m.last_bin - kbl;
+  };
+  auto request = [&](int slot, int c) {   // c: the sub-chunk requested (a constant once the loop is unrolled)
+    if constexpr (PRE) {
+      if (((pre.slow_mask >> c) & 1u) == 0u) {
+        lds_f *row0 = tile3 + ((c & 1) ? pre.boff[c >> 1] >> 16 : pre.boff[c >> 1] & 0xffffu);
+#pragma unroll
+        for (int u = 0; u < SUB; ++u)
+#pragma unroll
+          for (int g = 0; g < NCG; ++g) bv[slot][u][g] = row0[u * TS + 16 * g];
+        return;
+      }
+      band_of_item();
+    }
+    if (!PRE && st + SUB - 1 <= room_min) {   // wave-uniform: no group's rows of this request pass the last spectrum row (all but a filterbank's top items)
       lds_f *row0 = bp + st * TS;
 #pragma unroll
       for (int u = 0; u < SUB; ++u)
@@ -349,7 +417,7 @@ __device__ __forceinline__ void mel4r_items(const Mel32Args &m, int iv, const fl
   f32x4m acc[NA];
 #pragma unroll
   for (int g = 0; g < NA; ++g) acc[g] = f32x4m{0.f, 0.f, 0.f, 0.f};
-  request(0);
+  request(0, 0);
 #pragma unroll
   for (int c = 0; c < SLOTS; ++c) {
     // the sub-chunk being multiplied: c.  Its item's output description, before the state moves on
@@ -367,7 +435,7 @@ __device__ __forceinline__ void mel4r_items(const Mel32Args &m, int iv, const fl
         st += SUB;
         more = true;
       }
-      if (more) request((c + 1) & 1);
+      if (more) request((c + 1) & 1, c + 1);
     }
 #pragma unroll
     for (int u = 0; u < SUB; ++u)
@@ -386,12 +454,18 @@ __device__ __forceinline__ void mel4r_items(const Mel32Args &m, int iv, const fl
           const int from16 = ((lane + 16) & 63) << 2, from32 = ((lane + 32) & 63) << 2;
           auto from = [&](int addr, float v) { return __int_as_float(__builtin_amdgcn_ds_bpermute(addr, __float_as_int(v))); };
           const float a0 = sum[0], a1 = sum[1], a2 = sum[2], a3 = sum[3];
-          float s0 = a0 + from(from16, a0), s1 = a1 + from(from16, a1), s2 = a2 + from(from16, a2), s3 = a3 + from(from16, a3);
+          // (the four permutes of a level issued together, then the four additions: written value by value the compiler waited for
+          // every permute before it issued the next one -- eight LDS round trips in a row at an item's end instead of two)
+          const float t0 = from(from16, a0), t1 = from(from16, a1), t2 = from(from16, a2), t3 = from(from16, a3);
+          SMX_FENCE();
+          float s0 = a0 + t0, s1 = a1 + t1, s2 = a2 + t2, s3 = a3 + t3;
           if (c_mode == 4) {
-            s0 = s0 + from(from32, s0);
-            s1 = s1 + from(from32, s1);
-            s2 = s2 + from(from32, s2);
-            s3 = s3 + from(from32, s3);
+            const float u0 = from(from32, s0), u1 = from(from32, s1), u2 = from(from32, s2), u3 = from(from32, s3);
+            SMX_FENCE();
+            s0 = s0 + u0;
+            s1 = s1 + u1;
+            s2 = s2 + u2;
+            s3 = s3 + u3;
           }
           sum = f32x4m{s0, s1, s2, s3};
         }
@@ -417,6 +491,7 @@ struct MelMid32 {
   const FastArgs &a;
   const Mel32Args &m;
   const float (&areg)[8 * kMel4rChunks];
+  const Mel4rSlots &slots;
   int iv;
   const Lds32 &lds;
   float2 (&raw)[32];
@@ -438,7 +513,7 @@ struct MelMid32 {
   __device__ __forceinline__ void after_exchange_issue() const {
     if (it > 0) {
       lds_wait32(lds.filled + (b ^ 1) * kTileStride, 8u * (((unsigned)(it - 1) >> 1) + 1), pk_filled);
-      if constexpr (FOUR == 2) mel4r_items(m, iv, areg, lds.tiles + (b ^ 1) * kTile32Floats, pend_out, pend_left, lane);
+      if constexpr (FOUR == 2) mel4r_items<kTileStride, 1, kMel4rChunks, 8, true>(m, iv, areg, lds.tiles + (b ^ 1) * kTile32Floats, pend_out, pend_left, lane, slots);
       else if constexpr (FOUR == 1) mel4_items(m, iv, lds.tiles + (b ^ 1) * kTile32Floats, pend_out, pend_left, lane);
       else mel32_items(m, iv, lds.tiles + (b ^ 1) * kTile32Floats, pend_out, pend_left, lane);
       lds_signal32(lds.drained + (b ^ 1) * kTileStride, lane);   // behind the item's last LDS read in this wave's order
@@ -506,6 +581,8 @@ __global__ void __launch_bounds__(512) stft2048_mel32_kernel(FastArgs a, Mel32Ar
 #pragma unroll
     for (int q = 0; q < 8 * kMel4rChunks; ++q) areg[q] = m.w[(wave * 8 * kMel4rChunks + q) * 64 + lane];
   }
+  Mel4rSlots slots{};
+  if constexpr (FOUR == 2) slots = mel4r_slots(m, iv, lane);
   for (int it = 0; it < ntiles; ++it) {   // tile `it` of this workgroup lives in buffer it & 1
     const int b = it & 1;
     int ftnext;
@@ -516,7 +593,7 @@ __global__ void __launch_bounds__(512) stft2048_mel32_kernel(FastArgs a, Mel32Ar
     const float *src_clip = more ? xnext : tw.xclip;
     const float *src = frame_ptr(src_clip, more ? ftnext : tw.ft);
     const bool src_border = tile_border(more ? ftnext : tw.ft);
-    const MelMid32<ALIGNED, FOUR> mid{a, m, areg, iv, lds, raw, src, src_clip, src_border, pend_out, pend_left, lane, wave, b, it, pk_drained, pk_filled};
+    const MelMid32<ALIGNED, FOUR> mid{a, m, areg, slots, iv, lds, raw, src, src_clip, src_border, pend_out, pend_left, lane, wave, b, it, pk_drained, pk_filled};
     frame32_to_tile<PMODE>(a, L, raw, lds.tiles + b * kTile32Floats, mid);
     lds_signal32(lds.filled + b * kTileStride, lane);
     pend_out = tw.oclip + tw.ft * kFT;   // wave-uniform
@@ -529,7 +606,7 @@ __global__ void __launch_bounds__(512) stft2048_mel32_kernel(FastArgs a, Mel32Ar
   if (ntiles > 0) {   // the last tile of this workgroup
     const int b = (ntiles - 1) & 1;
     lds_wait(lds.filled + b * kTileStride, 8u * (((unsigned)(ntiles - 1) >> 1) + 1));
-    if constexpr (FOUR == 2) mel4r_items(m, iv, areg, lds.tiles + b * kTile32Floats, pend_out, pend_left, lane);
+    if constexpr (FOUR == 2) mel4r_items<kTileStride, 1, kMel4rChunks, 8, true>(m, iv, areg, lds.tiles + b * kTile32Floats, pend_out, pend_left, lane, slots);
     else if constexpr (FOUR == 1) mel4_items(m, iv, lds.tiles + b * kTile32Floats, pend_out, pend_left, lane);
     else mel32_items(m, iv, lds.tiles + b * kTile32Floats, pend_out, pend_left, lane);
   }
