@@ -300,7 +300,7 @@ struct Mel4rSlots {
 template <int TS = kTileStride, int CHUNKS = kMel4rChunks, int SUB = 8>
 __device__ __forceinline__ Mel4rSlots mel4r_slots(const Mel32Args &m, int iv, int lane) {
   constexpr int SLOTS = 8 * CHUNKS / SUB;
-  static_assert(SLOTS == 8, "two 16-bit offsets to each of four registers");
+  static_assert(SLOTS <= 8, "two 16-bit offsets to each of four registers");
   Mel4rSlots p{{0u, 0u, 0u, 0u}, 0u};
   const int mg = lane >> 4, f = lane & 15;
   int item = 0, st = 0, steps = 0, kbl = 0, room_min = 0;

@@ -714,6 +714,7 @@ struct MelMidL {
   const FastArgs &a;
   const Mel32Args &m;
   const float (&areg)[8 * kMel4rChunksL];
+  const Mel4rSlots &slots;
   int iv;
   const LdsL<LL> &lds;
   float2 (&raw)[32];
@@ -735,7 +736,7 @@ struct MelMidL {
     if (it > 0) {
       lds_wait32(lds.filled + (b ^ 1) * P::TS, 8u * (((unsigned)(it - 1) >> 1) + 1), pk_filled);
       if constexpr (FOUR) {
-        mel4r_items<P::TS, P::FT / 16, kMel4rChunksL, (LL == 16 ? 8 : 4)>(m, iv, areg, lds.tiles + (b ^ 1) * P::TileFloats, pend_out, pend_left, lane);
+        mel4r_items<P::TS, P::FT / 16, kMel4rChunksL, (LL == 16 ? 8 : 4), true>(m, iv, areg, lds.tiles + (b ^ 1) * P::TileFloats, pend_out, pend_left, lane, slots);
         lds_signal32(lds.drained + (b ^ 1) * P::TS, lane);
         return;
       }
@@ -802,6 +803,8 @@ __global__ void __launch_bounds__(512) stft_mel_lanes_kernel(FastArgs a, Mel32Ar
 #pragma unroll
     for (int q = 0; q < 8 * kMel4rChunksL; ++q) areg[q] = m.w[(wave * 8 * kMel4rChunksL + q) * 64 + lane];
   }
+  Mel4rSlots slots{};
+  if constexpr (FOUR) slots = mel4r_slots<P::TS, kMel4rChunksL, (LL == 16 ? 8 : 4)>(m, iv, lane);
   for (int it = 0; it < ntiles; ++it) {
     const int b = it & 1;
     int ftnext;
@@ -812,7 +815,7 @@ __global__ void __launch_bounds__(512) stft_mel_lanes_kernel(FastArgs a, Mel32Ar
     const float *src_clip = more ? xnext : tw.xclip;
     const float *src = frame_ptr(src_clip, more ? ftnext : tw.ft);
     const bool src_border = tile_border(more ? ftnext : tw.ft);
-    const MelMidL<LL, ALIGNED, FOUR> mid{a, m, areg, iv, lds, raw, src, src_clip, src_border, pend_out, pend_left, lane, wave, b, it, pk_drained, pk_filled};
+    const MelMidL<LL, ALIGNED, FOUR> mid{a, m, areg, slots, iv, lds, raw, src, src_clip, src_border, pend_out, pend_left, lane, wave, b, it, pk_drained, pk_filled};
     frameL_to_tile<LL, PMODE>(a, L, raw, lds.tiles + b * P::TileFloats, mid);
     lds_signal32(lds.filled + b * P::TS, lane);
     pend_out = tw.oclip + tw.ft * P::FT;
@@ -826,7 +829,7 @@ __global__ void __launch_bounds__(512) stft_mel_lanes_kernel(FastArgs a, Mel32Ar
     const int b = (ntiles - 1) & 1;
     lds_wait(lds.filled + b * P::TS, 8u * (((unsigned)(ntiles - 1) >> 1) + 1));
     if constexpr (FOUR) {
-      mel4r_items<P::TS, P::FT / 16, kMel4rChunksL, (LL == 16 ? 8 : 4)>(m, iv, areg, lds.tiles + b * P::TileFloats, pend_out, pend_left, lane);
+      mel4r_items<P::TS, P::FT / 16, kMel4rChunksL, (LL == 16 ? 8 : 4), true>(m, iv, areg, lds.tiles + b * P::TileFloats, pend_out, pend_left, lane, slots);
       return;
     }
 #if SMX_MEL_LANES_MULTI
