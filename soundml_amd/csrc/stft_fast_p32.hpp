@@ -1295,14 +1295,19 @@ __device__ __forceinline__ void cplx_skew32_clip(const FastArgs &a, CplxSkew32 &
 }
 // reads the tile (re, im planes) and stores it; carry: the frames of the previous tile that opened a line
 __device__ __forceinline__ void cplx_skew32_flush(const FastArgs &a, const float *re, const CplxSkew32 &sk, float *obase, int frames_left,
-                                                  bool fresh, bool closing, int wave, int lane, float2 (&carry)[32]) {
+                                                  bool fresh, bool closing, int wave, int lane_, float2 (&carry)[32]) {
+  // (the lane index made opaque: everything derived from it below is loop-invariant, and hoisted out of the tile loop a dozen such
+  // values did not fit beside the 64 carried registers -- they were spilled, and every scratch reload in the loop waits for ALL of
+  // the wave's outstanding loads and stores (s_waitcnt vmcnt(0)); re-derived per tile they cost a handful of instructions)
+  int lane = lane_;
+  asm volatile("" : "+v"(lane));
   const unsigned pitch = (unsigned)a.out_stride * 8u;
   int row_l, col;
   skewg32_lane(lane, wave, row_l, col);
   const float *src0 = re + row_l * kTileStride + col;
   const float *src1 = src0 + 16 * 32 * kTileStride;   // (ds offsets are 16 bits)
   if (frames_left >= kFT && !fresh && !closing) {   // wave-uniform: one whole line per row and part
-    const unsigned g = opaque32(sk.goff);
+    const unsigned g = sk.goff;
 #pragma unroll
     for (int p = 0; p < 32; ++p) {
       const float *pr = (p < 16 ? src0 : src1) + 32 * kTileStride * (p & 15);
